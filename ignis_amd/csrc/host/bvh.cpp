@@ -1,0 +1,447 @@
+#include "bvh.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <optional>
+#include <queue>
+#include <stack>
+#include <stdexcept>
+
+namespace igh {
+
+// ---------------------------------------------------------------- BVH2 (sweep SAH)
+
+namespace {
+
+struct SweepBuilder {
+    const std::vector<BBox>& bboxes;
+    const std::vector<V3>& centers;
+    size_t min_leaf_size = 1;
+    size_t max_leaf_size = 8;
+
+    std::vector<size_t> prim_ids[3];
+    std::vector<bool> marks;
+    std::vector<float> accum;
+
+    struct Split {
+        size_t pos;
+        float cost;
+        size_t axis;
+    };
+
+    SweepBuilder(const std::vector<BBox>& b, const std::vector<V3>& c, size_t max_leaf)
+        : bboxes(b)
+        , centers(c)
+        , max_leaf_size(max_leaf)
+    {
+        const size_t n = bboxes.size();
+        marks.resize(n);
+        accum.resize(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            prim_ids[axis].resize(n);
+            for (size_t i = 0; i < n; ++i)
+                prim_ids[axis][i] = i;
+            std::stable_sort(prim_ids[axis].begin(), prim_ids[axis].end(),
+                             [&](size_t i, size_t j) { return centers[i][axis] < centers[j][axis]; });
+        }
+    }
+
+    // SplitHeuristic with log_cluster_size 0, cost_ratio 1
+    static float leafCost(size_t begin, size_t end, const BBox& bbox) { return bbox.halfArea() * (float)(end - begin); }
+    static float nonSplitCost(size_t begin, size_t end, const BBox& bbox) { return bbox.halfArea() * ((float)(end - begin) - 1.0f); }
+
+    BBox computeBBox(size_t begin, size_t end) const
+    {
+        BBox b;
+        for (size_t i = begin; i < end; ++i)
+            b.extend(bboxes[prim_ids[0][i]]);
+        return b;
+    }
+
+    void findBestSplit(size_t axis, size_t begin, size_t end, Split& best)
+    {
+        size_t first_right = begin;
+
+        // Sweep from the right to the left, computing the partial SAH cost
+        BBox right_bbox;
+        for (size_t i = end - 1; i > begin;) {
+            constexpr size_t chunk_size = 32;
+            const size_t next           = i - std::min(i - begin, chunk_size);
+            float right_cost            = 0;
+            for (; i > next; --i) {
+                right_bbox.extend(bboxes[prim_ids[axis][i]]);
+                accum[i] = right_cost = leafCost(i, end, right_bbox);
+            }
+            // Every chunk, check that we are not above the maximum cost
+            if (right_cost > best.cost) {
+                first_right = i;
+                break;
+            }
+        }
+
+        // Sweep from the left to the right, computing the full cost
+        BBox left_bbox;
+        for (size_t i = begin; i < first_right; ++i)
+            left_bbox.extend(bboxes[prim_ids[axis][i]]);
+        for (size_t i = first_right; i < end - 1; ++i) {
+            left_bbox.extend(bboxes[prim_ids[axis][i]]);
+            const float left_cost = leafCost(begin, i + 1, left_bbox);
+            const float cost      = left_cost + accum[i + 1];
+            if (cost < best.cost)
+                best = Split{ i + 1, cost, axis };
+            else if (left_cost > best.cost)
+                break;
+        }
+    }
+
+    std::optional<size_t> trySplit(const BBox& bbox, size_t begin, size_t end)
+    {
+        const float leaf_cost = nonSplitCost(begin, end, bbox);
+        Split best{ (begin + end + 1) / 2, leaf_cost, 0 };
+        for (size_t axis = 0; axis < 3; ++axis)
+            findBestSplit(axis, begin, end, best);
+
+        if (best.cost >= leaf_cost) {
+            if (end - begin <= max_leaf_size)
+                return std::nullopt;
+            // Too many primitives for a leaf: median split on the largest axis
+            best.pos   = (begin + end + 1) / 2;
+            const V3 d = bbox.diameter();
+            best.axis  = (d.x > d.y) ? (d.x > d.z ? 0 : 2) : (d.y > d.z ? 1 : 2);
+        }
+
+        // Partition, keeping the per-axis orders intact
+        for (size_t i = begin; i < best.pos; ++i)
+            marks[prim_ids[best.axis][i]] = true;
+        for (size_t i = best.pos; i < end; ++i)
+            marks[prim_ids[best.axis][i]] = false;
+        for (size_t axis = 0; axis < 3; ++axis) {
+            if (axis == best.axis)
+                continue;
+            std::stable_partition(prim_ids[axis].begin() + begin, prim_ids[axis].begin() + end,
+                                  [&](size_t i) { return (bool)marks[i]; });
+        }
+        return best.pos;
+    }
+};
+
+inline void setBounds(Bvh2Node& n, const BBox& b)
+{
+    n.bounds[0] = b.min.x;
+    n.bounds[1] = b.max.x;
+    n.bounds[2] = b.min.y;
+    n.bounds[3] = b.max.y;
+    n.bounds[4] = b.min.z;
+    n.bounds[5] = b.max.z;
+}
+
+inline BBox getBounds(const Bvh2Node& n)
+{
+    BBox b;
+    b.min = V3(n.bounds[0], n.bounds[2], n.bounds[4]);
+    b.max = V3(n.bounds[1], n.bounds[3], n.bounds[5]);
+    return b;
+}
+
+} // namespace
+
+Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers, size_t max_leaf_size)
+{
+    const size_t prim_count = bboxes.size();
+    if (prim_count == 0)
+        throw std::runtime_error("build_bvh2: no primitives");
+
+    SweepBuilder builder(bboxes, centers, max_leaf_size);
+
+    struct WorkItem {
+        size_t node_id, begin, end;
+        size_t size() const { return end - begin; }
+    };
+
+    Bvh2 bvh;
+    bvh.nodes.reserve(2 * prim_count);
+    bvh.nodes.emplace_back();
+    setBounds(bvh.nodes.back(), builder.computeBBox(0, prim_count));
+
+    std::stack<WorkItem> stack;
+    stack.push(WorkItem{ 0, 0, prim_count });
+    while (!stack.empty()) {
+        const WorkItem item = stack.top();
+        stack.pop();
+
+        if (item.size() > builder.min_leaf_size) {
+            const BBox node_bbox = getBounds(bvh.nodes[item.node_id]);
+            if (auto split_pos = builder.trySplit(node_bbox, item.begin, item.end)) {
+                const size_t first_child        = bvh.nodes.size();
+                bvh.nodes[item.node_id].first      = (uint32_t)first_child;
+                bvh.nodes[item.node_id].prim_count = 0;
+                bvh.nodes.resize(first_child + 2);
+
+                BBox first_bbox   = builder.computeBBox(item.begin, *split_pos);
+                BBox second_bbox  = builder.computeBBox(*split_pos, item.end);
+                auto first_range  = std::make_pair(item.begin, *split_pos);
+                auto second_range = std::make_pair(*split_pos, item.end);
+
+                // Largest-area child first (surface-area traversal order for any-hit queries)
+                if (first_bbox.halfArea() < second_bbox.halfArea()) {
+                    std::swap(first_bbox, second_bbox);
+                    std::swap(first_range, second_range);
+                }
+
+                WorkItem first_item{ first_child + 0, first_range.first, first_range.second };
+                WorkItem second_item{ first_child + 1, second_range.first, second_range.second };
+                setBounds(bvh.nodes[first_child + 0], first_bbox);
+                setBounds(bvh.nodes[first_child + 1], second_bbox);
+
+                if (first_item.size() < second_item.size())
+                    std::swap(first_item, second_item);
+                stack.push(first_item);
+                stack.push(second_item);
+                continue;
+            }
+        }
+
+        bvh.nodes[item.node_id].first      = (uint32_t)item.begin;
+        bvh.nodes[item.node_id].prim_count = (uint32_t)item.size();
+    }
+
+    bvh.prim_ids = builder.prim_ids[0];
+    return bvh;
+}
+
+// ---------------------------------------------------------------- N-ary collapse
+
+namespace {
+
+constexpr size_t N = 8;
+
+struct NNode {
+    float bounds[6];
+    int32_t primitive_or_child_count; // < 0: leaf with -count primitives
+    uint32_t first_child_or_primitive;
+    bool isLeaf() const { return primitive_or_child_count < 0; }
+    uint32_t primitiveCount() const { return (uint32_t)-primitive_or_child_count; }
+};
+
+struct NBvh {
+    std::vector<NNode> nodes;
+    std::vector<size_t> primitive_indices;
+};
+
+inline NNode cloneNode(const Bvh2Node& o)
+{
+    NNode n;
+    std::memcpy(n.bounds, o.bounds, sizeof(n.bounds));
+    n.primitive_or_child_count = o.isLeaf() ? -(int32_t)o.prim_count : (int32_t)N;
+    n.first_child_or_primitive = o.first;
+    return n;
+}
+
+void convertNode(const Bvh2& original, const Bvh2Node& node, NBvh& bvh, uint32_t cur_id)
+{
+    constexpr size_t MaxIter = (size_t)1 << (3 /*log2(8)*/ - 1);
+    if (node.isLeaf())
+        return;
+
+    std::queue<Bvh2Node> queue;
+    queue.push(original.nodes[node.first + 0]);
+    queue.push(original.nodes[node.first + 1]);
+
+    std::vector<Bvh2Node> children;
+    for (size_t k = 0; k < MaxIter && !queue.empty(); ++k) {
+        const Bvh2Node cur = queue.front();
+        queue.pop();
+        if (cur.isLeaf()) {
+            children.push_back(cur);
+        } else {
+            queue.push(original.nodes[cur.first + 0]);
+            queue.push(original.nodes[cur.first + 1]);
+        }
+    }
+    while (!queue.empty()) {
+        children.push_back(queue.front());
+        queue.pop();
+    }
+
+    bvh.nodes[cur_id].primitive_or_child_count = (int32_t)children.size();
+    bvh.nodes[cur_id].first_child_or_primitive = (uint32_t)bvh.nodes.size();
+    for (const auto& child : children)
+        bvh.nodes.push_back(cloneNode(child));
+
+    const uint32_t first = bvh.nodes[cur_id].first_child_or_primitive;
+    for (size_t i = 0; i < children.size(); ++i)
+        convertNode(original, children[i], bvh, first + (uint32_t)i);
+}
+
+NBvh convertToNArity(const Bvh2& original)
+{
+    NBvh bvh;
+    bvh.nodes.reserve((original.nodes.size() - 1) / (N / 2) + 1);
+    bvh.nodes.push_back(cloneNode(original.nodes[0]));
+    convertNode(original, original.nodes[0], bvh, 0);
+    bvh.primitive_indices = original.prim_ids;
+    return bvh;
+}
+
+// write_node with a leaf callback (BvhNAdapter.h:37-93)
+using LeafWriter = std::function<void(const NBvh&, const NNode&, size_t parent, size_t child)>;
+
+void writeNode(std::vector<ig_node8>& nodes, const NBvh& bvh, const NNode& node, int parent, size_t child, const LeafWriter& writeLeaf)
+{
+    const size_t node_id = nodes.size();
+    if (parent >= 0)
+        nodes[(size_t)parent].child[child] = (int32_t)node_id + 1;
+    nodes.emplace_back();
+    std::memset(&nodes.back(), 0, sizeof(ig_node8));
+
+    const size_t count = (size_t)node.primitive_or_child_count;
+    if (count == 0 || count > N)
+        throw std::runtime_error("BVH collapse produced an invalid node");
+
+    for (size_t i = 0; i < count; ++i) {
+        const NNode src = bvh.nodes.at(node.first_child_or_primitive + i);
+        for (int k = 0; k < 6; ++k)
+            nodes[node_id].bounds[k][i] = src.bounds[k];
+        if (src.isLeaf())
+            writeLeaf(bvh, src, node_id, i);
+        else
+            writeNode(nodes, bvh, src, (int)node_id, i, writeLeaf);
+    }
+
+    const float inf = std::numeric_limits<float>::infinity();
+    for (size_t i = count; i < N; ++i) {
+        ig_node8& dst    = nodes[node_id];
+        dst.bounds[0][i] = inf;
+        dst.bounds[2][i] = inf;
+        dst.bounds[4][i] = inf;
+        dst.bounds[1][i] = -inf;
+        dst.bounds[3][i] = -inf;
+        dst.bounds[5][i] = -inf;
+        dst.child[i]     = 0;
+    }
+}
+
+void adapt(std::vector<ig_node8>& nodes, const Bvh2& bvh2, const LeafWriter& writeLeaf)
+{
+    const NBvh nbvh = convertToNArity(bvh2);
+    if (nbvh.nodes[0].isLeaf()) {
+        // Root is already a leaf: a node with one child (BvhNAdapter.h:26-31)
+        NNode root                    = nbvh.nodes[0];
+        root.primitive_or_child_count = 1;
+        root.first_child_or_primitive = 0;
+        writeNode(nodes, nbvh, root, -1, 0, writeLeaf);
+    } else {
+        writeNode(nodes, nbvh, nbvh.nodes[0], -1, 0, writeLeaf);
+    }
+}
+
+struct TriangleProxy {
+    V3 p0, e1, e2, n;
+    TriangleProxy(V3 a, V3 b, V3 c)
+        : p0(a)
+        , e1(c - a)
+        , e2(a - b)
+    {
+        // compute_stable_triangle_normal(e1, e2, p1 - p2), TriBVHAdapter.h:41-50
+        const V3 A = e1, B = e2, C = b - c;
+        const float ab_x = A[2] * B[1], ab_y = A[0] * B[2], ab_z = A[1] * B[0];
+        const float bc_x = B[2] * C[1], bc_y = B[0] * C[2], bc_z = B[1] * C[0];
+        const V3 cross_ab(A[1] * B[2] - ab_x, A[2] * B[0] - ab_y, A[0] * B[1] - ab_z);
+        const V3 cross_bc(B[1] * C[2] - bc_x, B[2] * C[0] - bc_y, B[0] * C[1] - bc_z);
+        n = V3(std::abs(ab_x) < std::abs(bc_x) ? cross_ab[0] : cross_bc[0],
+               std::abs(ab_y) < std::abs(bc_y) ? cross_ab[1] : cross_bc[1],
+               std::abs(ab_z) < std::abs(bc_z) ? cross_ab[2] : cross_bc[2]);
+    }
+    V3 p1() const { return p0 - e2; }
+    V3 p2() const { return p0 + e1; }
+    BBox bbox() const
+    {
+        BBox b;
+        b.extend(p0);
+        b.extend(p1());
+        b.extend(p2());
+        return b;
+    }
+    V3 center() const { return (p0 + p1() + p2()) * (1.0f / 3); }
+};
+
+} // namespace
+
+void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vector<ig_tri4>& tris)
+{
+    constexpr size_t M = 4;
+    std::vector<TriangleProxy> triangles;
+    triangles.reserve(mesh.faceCount());
+    for (size_t f = 0; f < mesh.faceCount(); ++f)
+        triangles.emplace_back(mesh.vertices.at(mesh.indices[f * 4 + 0]), mesh.vertices.at(mesh.indices[f * 4 + 1]), mesh.vertices.at(mesh.indices[f * 4 + 2]));
+
+    std::vector<BBox> bboxes;
+    std::vector<V3> centers;
+    for (const auto& t : triangles) {
+        bboxes.push_back(t.bbox());
+        centers.push_back(t.center());
+    }
+
+    const Bvh2 bvh2 = build_bvh2(bboxes, centers);
+
+    adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
+        nodes[parent].child[child] = ~(int32_t)tris.size();
+        const size_t ref_count     = node.primitiveCount();
+        for (size_t i = 0; i < ref_count; i += M) {
+            const size_t c = i + M <= ref_count ? M : ref_count - i;
+            ig_tri4 tri;
+            std::memset(&tri, 0, sizeof(tri));
+            for (size_t j = 0; j < c; ++j) {
+                const int id            = (int)bvh.primitive_indices.at(node.first_child_or_primitive + i + j);
+                const TriangleProxy& in = triangles[(size_t)id];
+                for (int k = 0; k < 3; ++k) {
+                    tri.v0[k][j] = in.p0[k];
+                    tri.e1[k][j] = in.e1[k];
+                    tri.e2[k][j] = in.e2[k];
+                    tri.n[k][j]  = in.n[k];
+                }
+                tri.prim_id[j] = id;
+            }
+            for (size_t j = c; j < M; ++j)
+                tri.prim_id[j] = (int32_t)0xFFFFFFFF;
+            tris.push_back(tri);
+        }
+        tris.back().prim_id[M - 1] |= (int32_t)0x80000000;
+    });
+}
+
+void build_scene_bvh8(const std::vector<EntityObject>& objs, std::vector<ig_node8>& nodes, std::vector<ig_entity_leaf1>& leaves)
+{
+    std::vector<BBox> bboxes;
+    std::vector<V3> centers;
+    for (const auto& o : objs) {
+        bboxes.push_back(o.bbox);
+        centers.push_back(o.bbox.center());
+    }
+
+    const Bvh2 bvh2 = build_bvh2(bboxes, centers);
+
+    adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
+        nodes[parent].child[child] = ~(int32_t)leaves.size();
+        for (size_t i = 0; i < node.primitiveCount(); ++i) {
+            const int id           = (int)bvh.primitive_indices.at(node.first_child_or_primitive + i);
+            const EntityObject& in = objs[(size_t)id];
+            ig_entity_leaf1 l;
+            l.min[0] = in.bbox.min.x, l.min[1] = in.bbox.min.y, l.min[2] = in.bbox.min.z;
+            l.max[0] = in.bbox.max.x, l.max[1] = in.bbox.max.y, l.max[2] = in.bbox.max.z;
+            l.entity_id = in.entity_id;
+            l.shape_id  = in.shape_id;
+            std::memcpy(l.local, in.local, sizeof(l.local));
+            l.flags   = in.flags;
+            l.mat_id  = in.material_id;
+            l.user[0] = in.user1;
+            l.user[1] = in.user2;
+            leaves.push_back(l);
+        }
+        leaves.back().entity_id |= (int32_t)0x80000000;
+    });
+}
+
+} // namespace igh

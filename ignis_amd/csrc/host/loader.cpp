@@ -1,0 +1,873 @@
+// Scene loader: Ignis JSON scene -> SceneDatabase-compatible tables + POD
+// lowering of materials / lights / camera / technique (include/ig_tables.h).
+//
+// Follows (restated, not shared) the reference's loader path:
+//   Parser (properties, transforms)      src/runtime/loader/Parser.cpp:110-300
+//   shapes -> "shapes" / "trimesh_primbvh" src/runtime/shape/TriMeshProvider.cpp:478-615
+//   entities -> "entities" + scene BVH    src/runtime/loader/LoaderEntity.cpp:32-205
+//   lights                                src/runtime/light/{AreaLight,PointLight}.cpp, loader/LoaderLight.cpp
+//   camera                                src/runtime/camera/PerspectiveCamera.cpp:7-76
+//   technique                             src/runtime/technique/PathTechnique.cpp:8-33
+//   film                                  src/runtime/Runtime.cpp:38-54
+//
+// Documented deviation: the reference iterates std::unordered_map's and loads
+// shapes in parallel, so its entity / shape / material ids are not a function
+// of the scene file. Here ids follow declaration
+// order, entities grouped by first-seen material as the reference groups them.
+#include "bvh.h"
+#include "igh_host.h"
+#include "json.h"
+#include "mesh.h"
+
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+
+namespace igh {
+
+static constexpr float Pi      = 3.14159265358979323846f;
+static constexpr float Deg2Rad = Pi / 180.0f;
+
+[[noreturn]] static void fail(const std::string& msg) { throw std::runtime_error(msg); }
+
+// ---------------------------------------------------------------- property helpers
+
+static V3 getVector3(const JsonValue& v, const char* what)
+{
+    if (!v.isArray() || v.arr.size() != 3)
+        fail(std::string("Expected vector of length 3 for ") + what);
+    for (const auto& e : v.arr)
+        if (!e.isNumber())
+            fail(std::string("Given vector is not only numbers: ") + what);
+    return V3((float)v.arr[0].num, (float)v.arr[1].num, (float)v.arr[2].num);
+}
+
+static Affine fromMatrixArray(const JsonValue& v)
+{
+    const size_t len = v.arr.size();
+    for (const auto& e : v.arr)
+        if (!e.isNumber())
+            fail("Given matrix is not only numbers");
+    Affine t;
+    if (len == 9) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                t.L.m[i][j] = (float)v.arr[(size_t)(i * 3 + j)].num;
+    } else if (len == 12 || len == 16) {
+        // Row major input (Parser.cpp:127-140)
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j)
+                t.L.m[i][j] = (float)v.arr[(size_t)(i * 4 + j)].num;
+            t.t[i] = (float)v.arr[(size_t)(i * 4 + 3)].num;
+        }
+    } else {
+        fail("Expected transform property to be an array of size 9, 12 or 16");
+    }
+    return t;
+}
+
+static M3 angleAxis(float angle, V3 axis)
+{
+    // Eigen::AngleAxis::toRotationMatrix
+    const float s = std::sin(angle), c = std::cos(angle);
+    const V3 sin_axis = axis * s;
+    const V3 cos1_axis = axis * (1 - c);
+    M3 r;
+    float tmp;
+    tmp       = cos1_axis.x * axis.y;
+    r.m[0][1] = tmp - sin_axis.z;
+    r.m[1][0] = tmp + sin_axis.z;
+    tmp       = cos1_axis.x * axis.z;
+    r.m[0][2] = tmp + sin_axis.y;
+    r.m[2][0] = tmp - sin_axis.y;
+    tmp       = cos1_axis.y * axis.z;
+    r.m[1][2] = tmp - sin_axis.x;
+    r.m[2][1] = tmp + sin_axis.x;
+    r.m[0][0] = cos1_axis.x * axis.x + c;
+    r.m[1][1] = cos1_axis.y * axis.y + c;
+    r.m[2][2] = cos1_axis.z * axis.z + c;
+    return r;
+}
+
+static Affine lookAt(V3 eye, V3 center, V3 up)
+{
+    // Parser.cpp:142-170
+    V3 f = normalized(center - eye);
+    if (dot(f, f) <= 1.1920928955e-07f)
+        f = V3(0, 0, 1);
+    V3 u = normalized(up);
+    V3 s = normalized(cross(f, u));
+    u    = cross(s, f);
+    Affine m;
+    for (int i = 0; i < 3; ++i) {
+        m.L.m[i][0] = s[i];
+        m.L.m[i][1] = u[i];
+        m.L.m[i][2] = f[i];
+        m.t[i]      = eye[i];
+    }
+    return m;
+}
+
+static void applyTransformOps(Affine& transform, const JsonValue& obj)
+{
+    for (const auto& kv : obj.obj) {
+        const std::string& name = kv.first;
+        const JsonValue& val    = kv.second;
+        if (name == "translate") {
+            Affine t;
+            t.t       = getVector3(val, "translate");
+            transform = transform * t;
+        } else if (name == "scale") {
+            Affine s;
+            if (val.isNumber()) {
+                s.L.m[0][0] = s.L.m[1][1] = s.L.m[2][2] = (float)val.num;
+            } else {
+                const V3 v  = getVector3(val, "scale");
+                s.L.m[0][0] = v.x;
+                s.L.m[1][1] = v.y;
+                s.L.m[2][2] = v.z;
+            }
+            transform = transform * s;
+        } else if (name == "rotate") {
+            const V3 a = getVector3(val, "rotate");
+            Affine r;
+            r.L       = angleAxis(Deg2Rad * a.x, V3(1, 0, 0)) * angleAxis(Deg2Rad * a.y, V3(0, 1, 0)) * angleAxis(Deg2Rad * a.z, V3(0, 0, 1));
+            transform = transform * r;
+        } else if (name == "lookat") {
+            if (!val.isObject())
+                fail("Expected transform lookat property to be an object");
+            V3 origin(0, 0, 0), target(0, 1, 0), up(0, 0, 1);
+            bool has_dir = false;
+            V3 direction;
+            for (const auto& kv2 : val.obj) {
+                if (kv2.first == "origin")
+                    origin = getVector3(kv2.second, "origin");
+                else if (kv2.first == "target")
+                    target = getVector3(kv2.second, "target");
+                else if (kv2.first == "up")
+                    up = getVector3(kv2.second, "up");
+                else if (kv2.first == "direction") {
+                    direction = getVector3(kv2.second, "direction");
+                    has_dir   = true;
+                }
+            }
+            transform = transform * lookAt(origin, has_dir ? direction + origin : target, up);
+        } else if (name == "matrix") {
+            if (!val.isArray())
+                fail("Expected transform matrix to be an array");
+            transform = transform * fromMatrixArray(val);
+        } else {
+            fail("Transform property got unknown entry type '" + name + "' (qrotate is not supported by this loader)");
+        }
+    }
+}
+
+static Affine getTransform(const JsonValue& parent, const char* key = "transform")
+{
+    const JsonValue* v = parent.find(key);
+    if (!v)
+        return Affine();
+    if (v->isObject()) {
+        Affine t;
+        applyTransformOps(t, *v);
+        return t;
+    }
+    if (!v->isArray())
+        fail("Transform property is neither an array nor an object");
+    if (!v->arr.empty() && v->arr[0].isObject()) {
+        Affine t;
+        for (const auto& e : v->arr) {
+            if (!e.isObject())
+                fail("Given transform property does not consist of transform operations only");
+            applyTransformOps(t, e);
+        }
+        return t;
+    }
+    return fromMatrixArray(*v);
+}
+
+// The reference evaluates colour properties through PExpr (ShadingTree). Only
+// constants are lowered here: a number, [r,g,b], or the literal "color(r,g,b)"
+// form the in-tree scenes use; anything else is refused.
+static bool parseConstColor(const JsonValue& v, V3& out)
+{
+    if (v.isNumber()) {
+        out = V3((float)v.num, (float)v.num, (float)v.num);
+        return true;
+    }
+    if (v.isArray() && v.arr.size() == 3 && v.arr[0].isNumber() && v.arr[1].isNumber() && v.arr[2].isNumber()) {
+        out = V3((float)v.arr[0].num, (float)v.arr[1].num, (float)v.arr[2].num);
+        return true;
+    }
+    if (v.isString()) {
+        std::string s;
+        for (char c : v.str)
+            if (!std::isspace((unsigned char)c))
+                s += c;
+        if (s.rfind("color(", 0) == 0 && s.back() == ')') {
+            std::stringstream ss(s.substr(6, s.size() - 7));
+            std::string tok;
+            float vals[3];
+            int n = 0;
+            while (std::getline(ss, tok, ',') && n < 3) {
+                char* end = nullptr;
+                vals[n]   = std::strtof(tok.c_str(), &end);
+                if (end == tok.c_str() || *end != '\0')
+                    return false;
+                ++n;
+            }
+            if (n == 3 && !std::getline(ss, tok, ',')) {
+                out = V3(vals[0], vals[1], vals[2]);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+static V3 getColor(const JsonValue& obj, const std::string& key, V3 def, const std::string& owner)
+{
+    const JsonValue* v = obj.find(key);
+    if (!v)
+        return def;
+    V3 c;
+    if (!parseConstColor(*v, c))
+        fail("'" + owner + "': property '" + key + "' is not a constant colour; expressions and textures here are not supported by the HIP backend");
+    return c;
+}
+
+static float getConstNumber(const JsonValue& obj, const std::string& key, float def, const std::string& owner)
+{
+    const JsonValue* v = obj.find(key);
+    if (!v)
+        return def;
+    if (!v->isNumber())
+        fail("'" + owner + "': property '" + key + "' is not a constant number; expressions and textures here are not supported by the HIP backend");
+    return (float)v->num;
+}
+
+// ---------------------------------------------------------------- scene container
+
+struct ShapeRec {
+    std::string name;
+    BBox bbox;
+    int32_t user1 = 0, user2 = 0; // prim-BVH offset in floats, split (TriMeshProvider.cpp:598)
+    std::optional<PlaneShape> plane;
+    float area = 0;
+};
+
+struct Scene {
+    std::vector<float> entities;
+    std::vector<ig_lookup_entry> shape_lookups;
+    std::vector<uint8_t> shape_data;
+    std::vector<uint8_t> primbvh;
+    std::vector<ig_node8> scene_nodes;
+    std::vector<ig_entity_leaf1> scene_leaves;
+    std::vector<ig_material> materials;
+    std::vector<int32_t> entity_per_material;
+    std::vector<ig_light> lights;
+    std::vector<float> light_hierarchy;
+    std::vector<std::string> entity_names;
+    std::vector<std::string> material_names;
+    igd_scene tables{};
+};
+
+template <typename T>
+static void appendBytes(std::vector<uint8_t>& dst, const T* src, size_t count)
+{
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(src);
+    dst.insert(dst.end(), p, p + sizeof(T) * count);
+}
+
+static void padTo(std::vector<uint8_t>& dst, size_t alignment)
+{
+    // FixTable/DynTable::addEntry semantics (src/runtime/table/FixTable.h:14-23)
+    if (alignment != 0 && !dst.empty()) {
+        const size_t defect = alignment - dst.size() % alignment;
+        dst.resize(dst.size() + defect);
+    }
+}
+
+static constexpr size_t Pack4Alignment = 16;
+
+static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, const std::string& base_dir)
+{
+    const std::string type = elem.getString("type");
+    if (type == "triangle") {
+        const V3 p0 = elem.has("p0") ? getVector3(*elem.find("p0"), "p0") : V3(0, 0, 0);
+        const V3 p1 = elem.has("p1") ? getVector3(*elem.find("p1"), "p1") : V3(1, 0, 0);
+        const V3 p2 = elem.has("p2") ? getVector3(*elem.find("p2"), "p2") : V3(0, 1, 0);
+        return TriMesh::MakeTriangle(p0, p1, p2);
+    } else if (type == "rectangle") {
+        if (!elem.has("p0")) {
+            const float width  = elem.getNumber("width", 2.0f);
+            const float height = elem.getNumber("height", 2.0f);
+            const V3 origin    = elem.has("origin") ? getVector3(*elem.find("origin"), "origin") : V3(-width / 2, -height / 2, 0);
+            return TriMesh::MakePlane(origin, V3(1, 0, 0) * width, V3(0, 1, 0) * height);
+        }
+        const V3 p0 = getVector3(*elem.find("p0"), "p0");
+        const V3 p1 = elem.has("p1") ? getVector3(*elem.find("p1"), "p1") : V3(1, -1, 0);
+        const V3 p2 = elem.has("p2") ? getVector3(*elem.find("p2"), "p2") : V3(1, 1, 0);
+        const V3 p3 = elem.has("p3") ? getVector3(*elem.find("p3"), "p3") : V3(-1, 1, 0);
+        return TriMesh::MakeRectangle(p0, p1, p2, p3);
+    } else if (type == "cube" || type == "box") {
+        const float width  = elem.getNumber("width", 2.0f);
+        const float height = elem.getNumber("height", 2.0f);
+        const float depth  = elem.getNumber("depth", 2.0f);
+        const V3 origin    = elem.has("origin") ? getVector3(*elem.find("origin"), "origin") : V3(-width / 2, -height / 2, -depth / 2);
+        return TriMesh::MakeBox(origin, V3(1, 0, 0) * width, V3(0, 1, 0) * height, V3(0, 0, 1) * depth);
+    } else if (type == "ply" || type == "external") {
+        const std::string filename = elem.getString("filename");
+        if (filename.empty())
+            fail("Shape '" + name + "': No filename given");
+        const std::string path = (filename[0] == '/' || base_dir.empty()) ? filename : base_dir + "/" + filename;
+        const size_t dot       = path.rfind('.');
+        std::string ext        = dot == std::string::npos ? "" : path.substr(dot);
+        for (auto& c : ext)
+            c = (char)std::tolower((unsigned char)c);
+        if (ext != ".ply")
+            fail("Shape '" + name + "': only .ply external meshes are supported by this loader (got '" + filename + "')");
+        return load_ply(path);
+    }
+    fail("Shape '" + name + "': Can not load shape type '" + type + "'");
+}
+
+static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::string& name, const JsonValue& elem, const std::string& base_dir)
+{
+    TriMesh mesh = loadShapeMesh(name, elem, base_dir);
+    if (mesh.vertices.empty())
+        fail("Shape '" + name + "': no vertices were generated");
+    if (mesh.faceCount() == 0)
+        fail("Shape '" + name + "': no indices were generated");
+
+    // User options, TriMeshProvider.cpp:526-545
+    if (elem.getBool("flip_normals", false))
+        mesh.flipNormals();
+    if (elem.getBool("face_normals", false))
+        mesh.setupFaceNormalsAsVertexNormals();
+    else if (elem.getBool("smooth_normals", false))
+        mesh.computeVertexNormals();
+    if (elem.getBool("generic_uv", false))
+        mesh.makeTexCoordsNormalized();
+    const Affine shapeT = getTransform(elem);
+    if (!shapeT.isIdentity())
+        mesh.transform(shapeT);
+    for (const char* unsupported : { "displacement", "subdivision", "refinement" })
+        if (elem.has(unsupported))
+            fail("Shape '" + name + "': option '" + unsupported + "' is not supported by this loader");
+
+    BBox bbox = mesh.computeBBox();
+    bbox.inflate(1e-5f);
+
+    // Prim BVH -> fix table "trimesh_primbvh" (TriMeshProvider.cpp:305-362)
+    std::vector<ig_node8> nodes;
+    std::vector<ig_tri4> tris;
+    build_tri_bvh8(mesh, nodes, tris);
+
+    padTo(sc.primbvh, Pack4Alignment);
+    const uint64_t bvh_offset = sc.primbvh.size() / sizeof(float);
+    const uint32_t header[4]  = { (uint32_t)nodes.size(), (uint32_t)tris.size(), 0, 0 };
+    appendBytes(sc.primbvh, header, 4);
+    appendBytes(sc.primbvh, nodes.data(), nodes.size());
+    appendBytes(sc.primbvh, tris.data(), tris.size());
+
+    // Mesh -> dyn table "shapes" (TriMeshProvider.cpp:575-596)
+    padTo(sc.shape_data, Pack4Alignment);
+    sc.shape_lookups.push_back(ig_lookup_entry{ 0 /* trimesh provider */, 0, (uint64_t)sc.shape_data.size() });
+    const uint32_t mheader[4] = { (uint32_t)mesh.faceCount(), (uint32_t)mesh.vertices.size(), (uint32_t)mesh.normals.size(), (uint32_t)mesh.texcoords.size() };
+    appendBytes(sc.shape_data, mheader, 4);
+    const float bb[8] = { bbox.min.x, bbox.min.y, bbox.min.z, 0, bbox.max.x, bbox.max.y, bbox.max.z, 0 };
+    appendBytes(sc.shape_data, bb, 8);
+    for (const auto& v : mesh.vertices) {
+        const float f[4] = { v.x, v.y, v.z, 0 };
+        appendBytes(sc.shape_data, f, 4);
+    }
+    for (const auto& n : mesh.normals) {
+        const float f[4] = { n.x, n.y, n.z, 0 };
+        appendBytes(sc.shape_data, f, 4);
+    }
+    appendBytes(sc.shape_data, mesh.indices.data(), mesh.indices.size());
+    for (const auto& t : mesh.texcoords) {
+        const float f[2] = { t.x, t.y };
+        appendBytes(sc.shape_data, f, 2);
+    }
+
+    ShapeRec rec;
+    rec.name  = name;
+    rec.bbox  = bbox;
+    rec.user1 = (int32_t)(uint32_t)(bvh_offset & 0xFFFFFFFFu);
+    rec.user2 = (int32_t)(uint32_t)((bvh_offset >> 32) & 0xFFFFFFFFu);
+    rec.plane = mesh.getAsPlane();
+    rec.area  = mesh.computeArea();
+    shapes.push_back(rec);
+}
+
+static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, int depth = 0)
+{
+    const JsonValue* bsdf = nullptr;
+    for (const auto& b : scene_bsdfs.arr)
+        if (b.getString("name") == name)
+            bsdf = &b;
+    if (!bsdf)
+        fail("Unknown bsdf '" + name + "'");
+    if (depth > 4)
+        fail("BSDF '" + name + "': nesting too deep");
+
+    ig_material m;
+    std::memset(&m, 0, sizeof(m));
+    m.light_id = -1;
+    m.tex_id   = -1;
+
+    const std::string type = bsdf->getString("type");
+    if (type == "diffuse" || type == "roughdiffuse") {
+        m.bsdf_type = IG_BSDF_DIFFUSE;
+        const V3 kd = getColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), name);
+        m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
+        m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
+        if (m.p[3] > 1.1920928955e-07f)
+            fail("BSDF '" + name + "': rough (Oren-Nayar) diffuse is not supported by the HIP backend");
+    } else if (type == "dielectric" || type == "glass") {
+        // DielectricBSDF.cpp:13-41; IOR table BSDF.cpp:7-30 (vacuum 1.0, bk7 1.5046)
+        if (bsdf->has("roughness") || bsdf->has("alpha") || bsdf->has("roughness_u") || bsdf->has("alpha_u"))
+            fail("BSDF '" + name + "': rough dielectrics are not supported by the HIP backend");
+        if (bsdf->has("ext_ior_material") || bsdf->has("int_ior_material"))
+            fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
+        m.bsdf_type = IG_BSDF_DIELECTRIC;
+        m.p[0]      = getConstNumber(*bsdf, "ext_ior", 1.0f, name);
+        m.p[1]      = getConstNumber(*bsdf, "int_ior", 1.5046f, name);
+        const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
+        const V3 kt = getColor(*bsdf, "specular_transmittance", V3(1, 1, 1), name);
+        m.p[2] = ks.x, m.p[3] = ks.y, m.p[4] = ks.z;
+        m.p[5] = kt.x, m.p[6] = kt.y, m.p[7] = kt.z;
+        if (bsdf->getBool("thin", false))
+            m.flags |= IG_MAT_THIN;
+    } else {
+        fail("BSDF '" + name + "': type '" + type + "' is not supported by the HIP backend");
+    }
+    return m;
+}
+
+static void writeEntity(std::vector<float>& tbl, const Affine& toLocal, const Affine& toGlobal, const M3& normalMat, uint32_t shapeID, uint32_t materialID)
+{
+    // Column-major 3x4, 3x4, 3x3, then ids (LoaderEntity.cpp:150-162)
+    auto write34 = [&](const Affine& a) {
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r)
+                tbl.push_back(a.L.m[r][c]);
+        tbl.push_back(a.t.x);
+        tbl.push_back(a.t.y);
+        tbl.push_back(a.t.z);
+    };
+    write34(toLocal);
+    write34(toGlobal);
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+            tbl.push_back(normalMat.m[r][c]);
+    float f;
+    std::memcpy(&f, &shapeID, 4);
+    tbl.push_back(f);
+    std::memcpy(&f, &materialID, 4);
+    tbl.push_back(f);
+    tbl.push_back(0.0f);
+}
+
+static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string& base_dir, const igh_options* opts)
+{
+    if (!doc.isObject())
+        fail("Expected scene root to be an object");
+
+    auto sc = std::make_unique<Scene>();
+
+    // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
+    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM };
+    std::string selector;
+    if (const JsonValue* t = doc.find("technique")) {
+        const std::string type = t->getString("type", "path");
+        if (type != "path")
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path')");
+        tech.max_depth = t->getInt("max_depth", 64);
+        tech.min_depth = t->getInt("min_depth", 2);
+        tech.clamp     = t->getNumber("clamp", 0.0f);
+        tech.nee       = t->getBool("nee", true) ? 1 : 0;
+        selector       = t->getString("light_selector");
+        if (t->getBool("aov_mis", false))
+            fail("Technique option 'aov_mis' (advanced shadow handling) is not supported by the HIP backend");
+    }
+
+    // ---- film (Runtime.cpp:38-54)
+    float film_w = 800, film_h = 600;
+    if (const JsonValue* film = doc.find("film")) {
+        if (const JsonValue* size = film->find("size")) {
+            if (!size->isArray() || size->arr.size() != 2 || !size->arr[0].isNumber() || !size->arr[1].isNumber())
+                fail("Expected film size to be a vector of length 2");
+            film_w = (float)size->arr[0].num;
+            film_h = (float)size->arr[1].num;
+        }
+        const std::string sampler = film->getString("sampler", "independent");
+        if (sampler != "independent" && sampler != "uniform")
+            fail("Pixel sampler '" + sampler + "' is not supported by the HIP backend");
+    }
+    int width  = (opts && opts->film_width > 0) ? opts->film_width : (int)film_w;
+    int height = (opts && opts->film_height > 0) ? opts->film_height : (int)film_h;
+    width      = std::max(1, width);
+    height     = std::max(1, height);
+
+    // ---- camera (PerspectiveCamera.cpp:7-24,69-76; Camera.cpp:5-15)
+    ig_camera cam;
+    std::memset(&cam, 0, sizeof(cam));
+    cam.eye[2] = 0;
+    cam.dir[2] = 1;
+    cam.up[1]  = 1;
+    cam.fov    = 60 * Deg2Rad;
+    cam.near_clip    = 0;
+    cam.far_clip     = std::numeric_limits<float>::max();
+    cam.aspect_ratio = -1;
+    if (const JsonValue* c = doc.find("camera")) {
+        const std::string type = c->getString("type", "perspective");
+        if (type != "perspective")
+            fail("Camera '" + type + "' is not supported by the HIP backend (only 'perspective')");
+        if (c->getNumber("aperture_radius", 0.0f) > 1.1920928955e-07f)
+            fail("Depth of field cameras are not supported by the HIP backend");
+        if (c->has("transform")) {
+            const Affine T = getTransform(*c);
+            const V3 eye   = T.point(V3(0, 0, 0));
+            for (int i = 0; i < 3; ++i) {
+                cam.eye[i] = eye[i];
+                cam.dir[i] = T.L.m[i][2];
+                cam.up[i]  = T.L.m[i][1];
+            }
+        }
+        if (c->has("vfov")) {
+            cam.fov             = c->getNumber("vfov", 60) * Deg2Rad;
+            cam.fov_is_vertical = 1;
+        } else if (c->has("hfov")) {
+            cam.fov = c->getNumber("hfov", 60) * Deg2Rad;
+        } else {
+            cam.fov = c->getNumber("fov", 60) * Deg2Rad;
+        }
+        cam.near_clip = c->getNumber("near_clip", 0.0f);
+        cam.far_clip  = c->getNumber("far_clip", std::numeric_limits<float>::max());
+        if (cam.far_clip < cam.near_clip)
+            std::swap(cam.near_clip, cam.far_clip);
+        if (c->has("aspect_ratio"))
+            cam.aspect_ratio = c->getNumber("aspect_ratio", 1);
+    }
+
+    // ---- shapes
+    std::vector<ShapeRec> shapes;
+    std::map<std::string, uint32_t> shape_ids;
+    if (const JsonValue* arr = doc.find("shapes")) {
+        if (!arr->isArray())
+            fail("Expected 'shapes' to be an array");
+        for (const auto& s : arr->arr) {
+            const std::string name = s.getString("name");
+            if (name.empty())
+                fail("Shape without a name");
+            if (shape_ids.count(name))
+                fail("Shape name '" + name + "' is used twice");
+            shape_ids[name] = (uint32_t)shapes.size();
+            handleShape(*sc, shapes, name, s, base_dir);
+        }
+    }
+
+    static const JsonValue emptyArray = [] { JsonValue v; v.type = JsonValue::Array; return v; }();
+    const JsonValue& bsdfs    = doc.find("bsdfs") ? *doc.find("bsdfs") : emptyArray;
+    const JsonValue& jlights  = doc.find("lights") ? *doc.find("lights") : emptyArray;
+    const JsonValue& entities = doc.find("entities") ? *doc.find("entities") : emptyArray;
+    if (!bsdfs.isArray() || !jlights.isArray() || !entities.isArray())
+        fail("Expected 'bsdfs', 'lights' and 'entities' to be arrays");
+    if (doc.has("media") && !doc.find("media")->arr.empty())
+        fail("Participating media are not supported by the HIP backend");
+
+    // ---- which entities are area lights (LoaderLight::setupAreaLights)
+    std::map<std::string, std::string> area_light_of_entity; // entity -> light name
+    for (const auto& l : jlights.arr)
+        if (l.getString("type") == "area")
+            area_light_of_entity[l.getString("entity")] = l.getString("name");
+
+    // ---- group entities by material (LoaderEntity.cpp:43-97)
+    struct MatKey {
+        std::string bsdf, light_entity;
+    };
+    std::vector<MatKey> mat_keys;
+    std::vector<std::vector<const JsonValue*>> groups;
+    for (const auto& e : entities.arr) {
+        const std::string ename = e.getString("name");
+        const std::string bname = e.getString("bsdf");
+        if (bname.empty())
+            fail("Entity " + ename + " has no bsdf");
+        if (e.has("inner_medium") || e.has("outer_medium"))
+            fail("Entity " + ename + ": participating media are not supported by the HIP backend");
+        if (area_light_of_entity.count(ename)) {
+            mat_keys.push_back(MatKey{ bname, ename });
+            groups.emplace_back().push_back(&e);
+        } else {
+            size_t id = 0;
+            for (; id < mat_keys.size(); ++id)
+                if (mat_keys[id].bsdf == bname && mat_keys[id].light_entity.empty())
+                    break;
+            if (id == mat_keys.size()) {
+                mat_keys.push_back(MatKey{ bname, "" });
+                groups.emplace_back();
+            }
+            groups[id].push_back(&e);
+        }
+    }
+
+    // ---- entities in material order (LoaderEntity.cpp:99-175)
+    struct EmissiveEntity {
+        uint32_t id, shape_id, mat_id;
+        Affine transform;
+    };
+    std::map<std::string, EmissiveEntity> emissive;
+    std::vector<EntityObject> objs;
+    BBox sceneBBox;
+    uint32_t entityCount = 0;
+    for (size_t materialID = 0; materialID < groups.size(); ++materialID) {
+        for (const JsonValue* e : groups[materialID]) {
+            const std::string ename = e->getString("name");
+            const std::string sname = e->getString("shape");
+            if (sname.empty())
+                fail("Entity " + ename + " has no shape");
+            auto sit = shape_ids.find(sname);
+            if (sit == shape_ids.end())
+                fail("Entity " + ename + " has unknown shape " + sname);
+            const uint32_t shapeID = sit->second;
+            const ShapeRec& shape  = shapes[shapeID];
+
+            uint32_t flags = 0;
+            if (e->getBool("camera_visible", true))
+                flags |= 0x1;
+            if (e->getBool("light_visible", true))
+                flags |= 0x2;
+            if (e->getBool("bounce_visible", true))
+                flags |= 0x4;
+            if (e->getBool("shadow_visible", true))
+                flags |= 0x8;
+
+            const Affine transform    = getTransform(*e);
+            const Affine invTransform = inverse(transform);
+            const BBox entityBox      = shape.bbox.transformed(transform);
+            sceneBBox.extend(entityBox);
+
+            if (area_light_of_entity.count(ename))
+                emissive[ename] = EmissiveEntity{ entityCount, shapeID, (uint32_t)materialID, transform };
+
+            const M3 toGlobalNormal = transpose(inverse(transform.L));
+            writeEntity(sc->entities, invTransform, transform, toGlobalNormal, shapeID, (uint32_t)materialID);
+
+            EntityObject obj;
+            obj.bbox        = entityBox;
+            obj.entity_id   = (int32_t)entityCount;
+            obj.shape_id    = (int32_t)shapeID;
+            obj.material_id = (int32_t)materialID;
+            obj.user1       = shape.user1;
+            obj.user2       = shape.user2;
+            obj.flags       = flags;
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r)
+                    obj.local[c * 3 + r] = invTransform.L.m[r][c];
+            obj.local[9]  = invTransform.t.x;
+            obj.local[10] = invTransform.t.y;
+            obj.local[11] = invTransform.t.z;
+            objs.push_back(obj);
+
+            sc->entity_names.push_back(ename);
+            ++entityCount;
+        }
+        sc->entity_per_material.push_back((int32_t)groups[materialID].size());
+    }
+
+    if (entityCount > 0)
+        build_scene_bvh8(objs, sc->scene_nodes, sc->scene_leaves);
+
+    // ---- lights: infinite first, then finite (light_selector.art:26-46 id convention)
+    std::vector<ig_light> infinite, finite;
+    std::map<std::string, int32_t> finite_index_of_entity;
+    for (const auto& l : jlights.arr) {
+        const std::string lname = l.getString("name");
+        const std::string type  = l.getString("type");
+        ig_light out;
+        std::memset(&out, 0, sizeof(out));
+        out.entity_id = -1;
+        if (type == "area") {
+            const std::string ent = l.getString("entity");
+            auto it               = emissive.find(ent);
+            if (it == emissive.end())
+                fail("No entity named '" + ent + "' exists for area light '" + lname + "'");
+            const ShapeRec& shape = shapes[it->second.shape_id];
+            if (!shape.plane.has_value() || !l.getBool("optimize", true))
+                fail("Area light '" + lname + "': only planar (rectangle) emitters are supported by the HIP backend");
+            if (l.has("power"))
+                fail("Area light '" + lname + "': 'power' is not supported by this loader, use 'radiance'");
+            // AreaLight.cpp:138-170 + "SimplePlaneLight" layout (light/area.art:416-440)
+            const Affine& T    = it->second.transform;
+            const V3 origin    = T.point(shape.plane->origin);
+            const V3 x_axis    = T.direction(shape.plane->x_axis);
+            const V3 y_axis    = T.direction(shape.plane->y_axis);
+            const V3 cr        = cross(x_axis, y_axis);
+            const V3 normal    = normalized(cr);
+            const float area   = norm(cr);
+            const V3 radiance  = getColor(l, "radiance", V3(1, 1, 1), lname);
+            const auto& tc     = shape.plane->texcoords;
+            const float d[24]  = { origin.x, origin.y, origin.z, normal.x,
+                                   x_axis.x, x_axis.y, x_axis.z, normal.y,
+                                   y_axis.x, y_axis.y, y_axis.z, normal.z,
+                                   tc[0].x, tc[0].y, tc[1].x, tc[1].y,
+                                   tc[2].x, tc[2].y, tc[3].x, tc[3].y,
+                                   radiance.x, radiance.y, radiance.z, area };
+            out.type      = IG_LIGHT_PLANE;
+            out.entity_id = (int32_t)it->second.id;
+            std::memcpy(out.d, d, sizeof(d));
+            finite_index_of_entity[ent] = (int32_t)finite.size();
+            finite.push_back(out);
+        } else if (type == "point") {
+            // PointLight.cpp:16-71 ("SimplePointLight": pos, 0, intensity, 0)
+            const V3 pos = l.has("position") ? getVector3(*l.find("position"), "position") : V3(0, 0, 0);
+            V3 intensity;
+            if (l.has("power")) {
+                const V3 power = getColor(l, "power", V3(4 * Pi, 4 * Pi, 4 * Pi), lname);
+                intensity      = V3(power.x / (4 * Pi), power.y / (4 * Pi), power.z / (4 * Pi));
+            } else {
+                const V3 cache = getColor(l, "intensity", V3(1, 1, 1), lname) * (4 * Pi);
+                intensity      = V3(cache.x / (4 * Pi), cache.y / (4 * Pi), cache.z / (4 * Pi));
+            }
+            out.type = IG_LIGHT_POINT;
+            out.d[0] = pos.x, out.d[1] = pos.y, out.d[2] = pos.z;
+            out.d[4] = intensity.x, out.d[5] = intensity.y, out.d[6] = intensity.z;
+            finite.push_back(out);
+        } else if (type == "env" || type == "constant") {
+            if (l.has("radiance") && l.find("radiance")->isString() && l.find("radiance")->str.rfind("color(", 0) != 0)
+                fail("Environment light '" + lname + "': textured environment maps are not supported by the HIP backend");
+            const V3 radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
+            out.type          = IG_LIGHT_ENV;
+            out.d[0] = radiance.x, out.d[1] = radiance.y, out.d[2] = radiance.z;
+            infinite.push_back(out);
+        } else {
+            fail("Light '" + lname + "': type '" + type + "' is not supported by the HIP backend");
+        }
+    }
+    sc->lights = infinite;
+    sc->lights.insert(sc->lights.end(), finite.begin(), finite.end());
+
+    // ---- materials
+    for (size_t m = 0; m < mat_keys.size(); ++m) {
+        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs);
+        if (!mat_keys[m].light_entity.empty())
+            mat.light_id = (int32_t)infinite.size() + finite_index_of_entity.at(mat_keys[m].light_entity);
+        sc->materials.push_back(mat);
+        sc->material_names.push_back(mat_keys[m].bsdf);
+    }
+
+    // ---- light selector (LoaderLight.cpp:423-460: <= 1 light -> uniform)
+    if (sc->lights.size() > 1 && !selector.empty() && selector != "uniform")
+        fail("Light selector '" + selector + "' is not supported by the HIP backend (only 'uniform')");
+    tech.light_selector = IG_SELECTOR_UNIFORM;
+
+    // ---- publish
+    igd_scene& t         = sc->tables;
+    t.entities           = sc->entities.data();
+    t.entity_count       = entityCount;
+    t.shape_lookups      = sc->shape_lookups.data();
+    t.shape_count        = (uint32_t)sc->shape_lookups.size();
+    t.shape_data         = sc->shape_data.data();
+    t.shape_data_size    = sc->shape_data.size();
+    t.primbvh            = sc->primbvh.data();
+    t.primbvh_size       = sc->primbvh.size();
+    t.scene_nodes        = sc->scene_nodes.data();
+    t.scene_node_count   = (uint32_t)sc->scene_nodes.size();
+    t.scene_leaves       = sc->scene_leaves.data();
+    t.scene_leaf_count   = (uint32_t)sc->scene_leaves.size();
+    t.materials          = sc->materials.data();
+    t.material_count     = (uint32_t)sc->materials.size();
+    t.entity_per_material = sc->entity_per_material.data();
+    t.lights             = sc->lights.data();
+    t.light_count        = (uint32_t)sc->lights.size();
+    t.infinite_light_count = (uint32_t)infinite.size();
+    t.light_hierarchy    = nullptr;
+    t.light_hierarchy_nodes = 0;
+    t.camera             = cam;
+    t.technique          = tech;
+    for (int i = 0; i < 3; ++i) {
+        t.bbox_min[i] = entityCount ? sceneBBox.min[i] : 0;
+        t.bbox_max[i] = entityCount ? sceneBBox.max[i] : 0;
+    }
+    t.film_width  = width;
+    t.film_height = height;
+    return sc;
+}
+
+} // namespace igh
+
+// ---------------------------------------------------------------- C ABI
+
+struct igh_scene {
+    std::unique_ptr<igh::Scene> scene;
+};
+
+static thread_local std::string g_last_error;
+
+extern "C" {
+
+igh_scene* igh_load_string(const char* json, const char* base_dir, const igh_options* opts)
+{
+    g_last_error.clear();
+    if (!json) {
+        g_last_error = "igh_load_string: json is NULL";
+        return nullptr;
+    }
+    try {
+        const std::string text(json);
+        igh::JsonParser parser(text);
+        const igh::JsonValue doc = parser.parse();
+        auto sc                  = igh::buildScene(doc, base_dir ? base_dir : "", opts);
+        return new igh_scene{ std::move(sc) };
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return nullptr;
+    }
+}
+
+igh_scene* igh_load_file(const char* path, const igh_options* opts)
+{
+    g_last_error.clear();
+    if (!path) {
+        g_last_error = "igh_load_file: path is NULL";
+        return nullptr;
+    }
+    std::ifstream f(path, std::ios::in | std::ios::binary);
+    if (!f) {
+        g_last_error = std::string("Could not open file '") + path + "'";
+        return nullptr;
+    }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string p(path);
+    const size_t slash     = p.find_last_of('/');
+    const std::string base = slash == std::string::npos ? "." : p.substr(0, slash);
+    return igh_load_string(ss.str().c_str(), base.c_str(), opts);
+}
+
+const igd_scene* igh_tables(const igh_scene* scene) { return scene ? &scene->scene->tables : nullptr; }
+
+const char* igh_entity_name(const igh_scene* scene, uint32_t id)
+{
+    if (!scene || id >= scene->scene->entity_names.size())
+        return nullptr;
+    return scene->scene->entity_names[id].c_str();
+}
+
+const char* igh_material_name(const igh_scene* scene, uint32_t id)
+{
+    if (!scene || id >= scene->scene->material_names.size())
+        return nullptr;
+    return scene->scene->material_names[id].c_str();
+}
+
+void igh_free(igh_scene* scene) { delete scene; }
+
+const char* igh_last_error(void) { return g_last_error.c_str(); }
+
+} // extern "C"

@@ -1,0 +1,451 @@
+#include "mesh.h"
+
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace igh {
+
+static constexpr float FltEps = 1.1920928955e-07f;
+
+static inline V3 computeTriangleNormal(V3 v0, V3 v1, V3 v2) { return cross(v1 - v0, v2 - v0); }
+
+static inline bool isApprox(V3 a, V3 b, float prec)
+{
+    // Eigen isApprox: |a-b|^2 <= prec^2 * min(|a|^2, |b|^2)
+    const V3 d = a - b;
+    return dot(d, d) <= prec * prec * std::min(dot(a, a), dot(b, b));
+}
+
+void TriMesh::flipNormals()
+{
+    for (size_t i = 0; i < indices.size(); i += 4)
+        std::swap(indices[i + 1], indices[i + 2]);
+    for (auto& n : normals)
+        n = -n;
+}
+
+void TriMesh::computeVertexNormals()
+{
+    normals.assign(vertices.size(), V3(0, 0, 0));
+    for (size_t i = 0; i < indices.size(); i += 4) {
+        const V3 N = normalized(computeTriangleNormal(vertices[indices[i + 0]], vertices[indices[i + 1]], vertices[indices[i + 2]]));
+        normals[indices[i + 0]] = normals[indices[i + 0]] + N;
+        normals[indices[i + 1]] = normals[indices[i + 1]] + N;
+        normals[indices[i + 2]] = normals[indices[i + 2]] + N;
+    }
+    for (auto& n : normals)
+        n = normalized(n);
+}
+
+void TriMesh::makeTexCoordsNormalized()
+{
+    texcoords.resize(vertices.size());
+    const BBox bbox = computeBBox();
+    for (size_t i = 0; i < vertices.size(); ++i) {
+        const V3 d = bbox.diameter();
+        const V3 t = vertices[i] - bbox.min;
+        V2 p;
+        if (d.x > FltEps)
+            p.x = t.x / d.x;
+        if (d.y > FltEps)
+            p.y = t.y / d.y;
+        texcoords[i] = p;
+    }
+}
+
+void TriMesh::setupFaceNormalsAsVertexNormals()
+{
+    const size_t fc = faceCount();
+    std::vector<V3> nv(fc * 3), nn(fc * 3);
+    for (size_t f = 0; f < fc; ++f)
+        for (int k = 0; k < 3; ++k)
+            nv[3 * f + k] = vertices[indices[4 * f + k]];
+    for (size_t f = 0; f < fc; ++f) {
+        const V3 N = normalized(computeTriangleNormal(nv[3 * f], nv[3 * f + 1], nv[3 * f + 2]));
+        nn[3 * f] = nn[3 * f + 1] = nn[3 * f + 2] = N;
+    }
+    if (!texcoords.empty()) {
+        std::vector<V2> nt(fc * 3);
+        for (size_t f = 0; f < fc; ++f)
+            for (int k = 0; k < 3; ++k)
+                nt[3 * f + k] = texcoords[indices[4 * f + k]];
+        texcoords = std::move(nt);
+    }
+    vertices = std::move(nv);
+    normals  = std::move(nn);
+    for (uint32_t f = 0; f < (uint32_t)fc; ++f)
+        for (uint32_t k = 0; k < 3; ++k)
+            indices[4 * f + k] = 3 * f + k;
+}
+
+void TriMesh::transform(const Affine& t)
+{
+    if (t.isIdentity())
+        return;
+    const M3 normalMat = inverse(transpose(t.L));
+    for (auto& v : vertices)
+        v = t.point(v);
+    for (auto& n : normals)
+        n = normalized(normalMat * n);
+}
+
+BBox TriMesh::computeBBox() const
+{
+    BBox b;
+    for (const auto& v : vertices)
+        b.extend(v);
+    return b;
+}
+
+float TriMesh::computeArea() const
+{
+    float area = 0;
+    for (size_t f = 0; f < faceCount(); ++f)
+        area += 0.5f * norm(computeTriangleNormal(vertices[indices[4 * f]], vertices[indices[4 * f + 1]], vertices[indices[4 * f + 2]]));
+    return area;
+}
+
+std::optional<PlaneShape> TriMesh::getAsPlane() const
+{
+    constexpr float PlaneEPS = 1e-5f;
+    if (faceCount() != 2)
+        return std::nullopt;
+
+    std::array<V3, 4> unique_verts;
+    std::array<uint32_t, 4> unique_ids{};
+    if (vertices.size() != 4) {
+        // The reference also accepts 5-6 vertices with duplicates; its dedup loop reads
+        // uninitialised slots (TriMesh.cpp:534-557), so only the exact 4-vertex case is kept.
+        return std::nullopt;
+    }
+    for (size_t i = 0; i < 4; ++i) {
+        unique_verts[i] = vertices[i];
+        unique_ids[i]   = (uint32_t)i;
+    }
+
+    const V3 fn0 = normalized(computeTriangleNormal(vertices[indices[0]], vertices[indices[1]], vertices[indices[2]]));
+    const V3 fn1 = normalized(computeTriangleNormal(vertices[indices[4]], vertices[indices[5]], vertices[indices[6]]));
+    if (!isApprox(fn0, fn1, PlaneEPS))
+        return std::nullopt;
+
+    auto sq = [&](uint32_t a, uint32_t b) {
+        const V3 d = vertices[indices[a]] - vertices[indices[b]];
+        return dot(d, d);
+    };
+    const float e1 = sq(0, 1), e2 = sq(1, 2), e3 = sq(2, 0);
+    const float e4 = sq(4, 5), e5 = sq(5, 6), e6 = sq(6, 4);
+    const auto safeCheck = [=](float a, float b) { return std::abs(a - b) <= PlaneEPS; };
+    if (!safeCheck(e1, e4) && !safeCheck(e2, e4) && !safeCheck(e3, e4))
+        return std::nullopt;
+    if (!safeCheck(e1, e5) && !safeCheck(e2, e5) && !safeCheck(e3, e5))
+        return std::nullopt;
+    if (!safeCheck(e1, e6) && !safeCheck(e2, e6) && !safeCheck(e3, e6))
+        return std::nullopt;
+
+    const V3 origin   = unique_verts[0];
+    auto computeAngle = [&](size_t start) {
+        const V3 x = normalized(unique_verts[(start + 0) % 3 + 1] - origin);
+        const V3 y = normalized(unique_verts[(start + 1) % 3 + 1] - origin);
+        return std::acos(dot(x, y));
+    };
+    const float a12 = std::abs(computeAngle(0));
+    const float a23 = std::abs(computeAngle(1));
+    const float a31 = std::abs(computeAngle(2));
+    int sel         = 2;
+    if (a12 >= a23 && a12 >= a31)
+        sel = 0;
+    else if (a23 >= a31 && a23 >= a12)
+        sel = 1;
+
+    PlaneShape shape;
+    shape.origin = origin;
+    shape.x_axis = unique_verts[(sel + 0) % 3 + 1] - origin;
+    shape.y_axis = unique_verts[(sel + 1) % 3 + 1] - origin;
+
+    const V3 normal = normalized(cross(shape.x_axis, shape.y_axis));
+    if (dot(fn0, normal) < 0) {
+        std::swap(shape.x_axis, shape.y_axis);
+        std::swap(unique_verts[1], unique_verts[2]);
+        std::swap(unique_ids[1], unique_ids[2]);
+    }
+
+    if (!texcoords.empty()) {
+        shape.texcoords[0]                 = texcoords[unique_ids[0]];
+        shape.texcoords[(0 + sel) % 3 + 1] = texcoords[unique_ids[1]];
+        shape.texcoords[(1 + sel) % 3 + 1] = texcoords[unique_ids[2]];
+        shape.texcoords[(2 + sel) % 3 + 1] = texcoords[unique_ids[3]];
+    } else {
+        shape.texcoords[0] = V2{ 0, 0 };
+        shape.texcoords[1] = V2{ 1, 0 };
+        shape.texcoords[2] = V2{ 0, 1 };
+        shape.texcoords[3] = V2{ 1, 1 };
+    }
+    return shape;
+}
+
+static void addTriangle(TriMesh& mesh, V3 origin, V3 xAxis, V3 yAxis)
+{
+    const V3 N         = normalized(cross(xAxis, yAxis));
+    const uint32_t off = (uint32_t)mesh.vertices.size();
+    mesh.vertices.insert(mesh.vertices.end(), { origin, origin + xAxis, origin + yAxis });
+    mesh.normals.insert(mesh.normals.end(), { N, N, N });
+    mesh.texcoords.insert(mesh.texcoords.end(), { V2{ 0, 0 }, V2{ 1, 0 }, V2{ 0, 1 } });
+    mesh.indices.insert(mesh.indices.end(), { 0 + off, 1 + off, 2 + off, 0 });
+}
+
+// addGrid with count 1x1 (TriMesh.cpp:783-817)
+static void addPlane(TriMesh& mesh, V3 origin, V3 xAxis, V3 yAxis)
+{
+    const V3 N         = normalized(cross(xAxis, yAxis));
+    const uint32_t off = (uint32_t)mesh.vertices.size();
+    for (uint32_t j = 0; j <= 1; ++j) {
+        for (uint32_t i = 0; i <= 1; ++i) {
+            const float u = (float)i, v = (float)j;
+            mesh.vertices.push_back(origin + xAxis * u + yAxis * v);
+            mesh.normals.push_back(N);
+            mesh.texcoords.push_back(V2{ u, v });
+        }
+    }
+    const uint32_t ind1 = off, ind2 = 2 + off;
+    mesh.indices.insert(mesh.indices.end(), { ind1, ind1 + 1, ind2 + 1, 0, ind1, ind2 + 1, ind2, 0 });
+}
+
+TriMesh TriMesh::MakePlane(V3 origin, V3 x_axis, V3 y_axis)
+{
+    TriMesh m;
+    addPlane(m, origin, x_axis, y_axis);
+    return m;
+}
+
+TriMesh TriMesh::MakeTriangle(V3 p0, V3 p1, V3 p2)
+{
+    TriMesh m;
+    addTriangle(m, p0, p1 - p0, p2 - p0);
+    return m;
+}
+
+TriMesh TriMesh::MakeRectangle(V3 p0, V3 p1, V3 p2, V3 p3)
+{
+    TriMesh m;
+    addTriangle(m, p0, p1 - p0, p3 - p0);
+    addTriangle(m, p1, p2 - p1, p3 - p1);
+    return m;
+}
+
+TriMesh TriMesh::MakeBox(V3 origin, V3 xAxis, V3 yAxis, V3 zAxis)
+{
+    const V3 lll = origin;
+    const V3 hhh = origin + xAxis + yAxis + zAxis;
+    TriMesh m;
+    addPlane(m, lll, yAxis, xAxis);
+    addPlane(m, lll, xAxis, zAxis);
+    addPlane(m, lll, zAxis, yAxis);
+    addPlane(m, hhh, -xAxis, -yAxis);
+    addPlane(m, hhh, -zAxis, -xAxis);
+    addPlane(m, hhh, -yAxis, -zAxis);
+    return m;
+}
+
+// ---------------------------------------------------------------- PLY
+
+namespace {
+struct PlyHeader {
+    int VertexCount = 0, FaceCount = 0;
+    int XElem = -1, YElem = -1, ZElem = -1, NXElem = -1, NYElem = -1, NZElem = -1, UElem = -1, VElem = -1;
+    int VertexPropCount = 0;
+    int IndElem         = -1;
+    bool SwitchEndianness = false;
+    bool idxIsByteCount   = true;
+    bool hasVertices() const { return XElem >= 0 && YElem >= 0 && ZElem >= 0; }
+    bool hasNormals() const { return NXElem >= 0 && NYElem >= 0 && NZElem >= 0; }
+    bool hasUVs() const { return UElem >= 0 && VElem >= 0; }
+};
+
+template <typename T>
+T swap_endian(T u)
+{
+    unsigned char b[sizeof(T)];
+    std::memcpy(b, &u, sizeof(T));
+    for (size_t k = 0; k < sizeof(T) / 2; ++k)
+        std::swap(b[k], b[sizeof(T) - k - 1]);
+    std::memcpy(&u, b, sizeof(T));
+    return u;
+}
+
+// Faces with 3 vertices are kept, 4 become a fan; larger polygons use the
+// reference's convex-fan fallback (PlyFile.cpp:30-66; its ear-clipping path is
+// only reached by meshes outside the hot-path configs).
+void triangulate(const std::vector<uint32_t>& g, std::vector<uint32_t>& out)
+{
+    if (g.size() < 3)
+        return;
+    for (uint32_t j = 2; j < (uint32_t)g.size(); ++j)
+        out.insert(out.end(), { g[0], g[j - 1], g[j], 0 });
+}
+} // namespace
+
+TriMesh load_ply(const std::string& path)
+{
+    std::ifstream stream(path, std::ios::in | std::ios::binary);
+    if (!stream)
+        throw std::runtime_error("PLY file '" + path + "' can not be opened");
+
+    std::string magic;
+    stream >> magic;
+    if (magic != "ply")
+        throw std::runtime_error("'" + path + "' is not a ply file");
+
+    std::string method;
+    PlyHeader header;
+    int facePropCounter = 0;
+    for (std::string line; std::getline(stream, line);) {
+        std::stringstream ss(line);
+        std::string action;
+        ss >> action;
+        if (action == "comment")
+            continue;
+        else if (action == "format")
+            ss >> method;
+        else if (action == "element") {
+            std::string type;
+            ss >> type;
+            if (type == "vertex")
+                ss >> header.VertexCount;
+            else if (type == "face")
+                ss >> header.FaceCount;
+        } else if (action == "property") {
+            std::string type;
+            ss >> type;
+            if (type == "float") {
+                std::string name;
+                ss >> name;
+                const int c = header.VertexPropCount;
+                if (name == "x") header.XElem = c;
+                else if (name == "y") header.YElem = c;
+                else if (name == "z") header.ZElem = c;
+                else if (name == "nx") header.NXElem = c;
+                else if (name == "ny") header.NYElem = c;
+                else if (name == "nz") header.NZElem = c;
+                else if (name == "u" || name == "s") header.UElem = c;
+                else if (name == "v" || name == "t") header.VElem = c;
+                ++header.VertexPropCount;
+            } else if (type == "list") {
+                ++facePropCounter;
+                std::string countType, indType, name;
+                ss >> countType >> indType >> name;
+                if (name == "vertex_indices" || name == "vertex_index")
+                    header.IndElem = facePropCounter - 1;
+            } else {
+                ++header.VertexPropCount;
+            }
+        } else if (action == "end_header")
+            break;
+    }
+
+    if (!header.hasVertices() || header.IndElem < 0 || header.VertexCount <= 0 || header.FaceCount <= 0)
+        throw std::runtime_error("PLY file '" + path + "' does not contain valid mesh data");
+
+    header.SwitchEndianness = (method == "binary_big_endian");
+    const bool ascii        = (method == "ascii");
+
+    auto readFloat = [&]() {
+        float v = 0;
+        stream.read(reinterpret_cast<char*>(&v), sizeof(v));
+        return header.SwitchEndianness ? swap_endian(v) : v;
+    };
+    auto readIdx = [&]() {
+        uint32_t v = 0;
+        stream.read(reinterpret_cast<char*>(&v), sizeof(v));
+        return header.SwitchEndianness ? swap_endian(v) : v;
+    };
+
+    TriMesh mesh;
+    mesh.vertices.reserve(header.VertexCount);
+    for (int i = 0; i < header.VertexCount; ++i) {
+        float vals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // x y z nx ny nz u v
+        auto assign   = [&](int elem, float val) {
+            if (header.XElem == elem) vals[0] = val;
+            else if (header.YElem == elem) vals[1] = val;
+            else if (header.ZElem == elem) vals[2] = val;
+            else if (header.NXElem == elem) vals[3] = val;
+            else if (header.NYElem == elem) vals[4] = val;
+            else if (header.NZElem == elem) vals[5] = val;
+            else if (header.UElem == elem) vals[6] = val;
+            else if (header.VElem == elem) vals[7] = val;
+        };
+        if (ascii) {
+            std::string line;
+            if (!std::getline(stream, line))
+                throw std::runtime_error("PLY file '" + path + "': not enough vertices");
+            std::stringstream ss(line);
+            int elem = 0;
+            float val;
+            while (ss >> val)
+                assign(elem++, val);
+        } else {
+            for (int elem = 0; elem < header.VertexPropCount; ++elem)
+                assign(elem, readFloat());
+        }
+        mesh.vertices.emplace_back(vals[0], vals[1], vals[2]);
+        if (header.hasNormals()) {
+            float n = std::sqrt(vals[3] * vals[3] + vals[4] * vals[4] + vals[5] * vals[5]);
+            if (n == 0.0f)
+                n = 1.0f;
+            mesh.normals.emplace_back(vals[3] / n, vals[4] / n, vals[5] / n);
+        }
+        if (header.hasUVs())
+            mesh.texcoords.push_back(V2{ vals[6], vals[7] });
+    }
+    if (!stream && !ascii)
+        throw std::runtime_error("PLY file '" + path + "': truncated vertex data");
+
+    mesh.indices.reserve((size_t)header.FaceCount * 4);
+    std::vector<uint32_t> tmp;
+    for (int i = 0; i < header.FaceCount; ++i) {
+        tmp.clear();
+        if (ascii) {
+            std::string line;
+            if (!std::getline(stream, line))
+                throw std::runtime_error("PLY file '" + path + "': not enough faces");
+            std::stringstream ss(line);
+            uint32_t elems = 0;
+            ss >> elems;
+            for (uint32_t e = 0; e < elems; ++e) {
+                uint32_t idx = 0;
+                ss >> idx;
+                tmp.push_back(idx);
+            }
+        } else {
+            uint8_t elems = 0;
+            stream.read(reinterpret_cast<char*>(&elems), sizeof(elems));
+            for (uint32_t e = 0; e < elems; ++e)
+                tmp.push_back(readIdx());
+            if (!stream)
+                throw std::runtime_error("PLY file '" + path + "': truncated face data");
+        }
+        for (uint32_t idx : tmp)
+            if (idx >= mesh.vertices.size())
+                throw std::runtime_error("PLY file '" + path + "': face index out of range");
+        triangulate(tmp, mesh.indices);
+    }
+
+    if (mesh.normals.empty()) {
+        mesh.computeVertexNormals();
+    } else {
+        // fixNormals, TriMesh.cpp:17-32
+        for (auto& n : mesh.normals) {
+            const float len2 = dot(n, n);
+            if (len2 <= FltEps || std::isnan(len2))
+                n = V3(0, 1, 0);
+            else
+                { const float l = std::sqrt(len2); n = V3(n.x / l, n.y / l, n.z / l); }
+        }
+    }
+    if (mesh.texcoords.empty())
+        mesh.makeTexCoordsNormalized();
+    return mesh;
+}
+
+} // namespace igh

@@ -1,0 +1,160 @@
+"""ctypes mirrors of include/ig_tables.h (POD scene tables) and the host loader ABI.
+
+The loader itself is native (libig_host.so, include/igh_host.h); this module only
+declares the structures so Python callers (tests, bench, the Runtime mirror) can pass
+`igd_scene` pointers between the native libraries and inspect tables with numpy.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+
+class Node8(C.Structure):
+    _fields_ = [("bounds", (C.c_float * 8) * 6), ("child", C.c_int32 * 8), ("pad", C.c_int32 * 8)]
+
+
+class Tri4(C.Structure):
+    _fields_ = [("v0", (C.c_float * 4) * 3), ("e1", (C.c_float * 4) * 3), ("e2", (C.c_float * 4) * 3),
+                ("n", (C.c_float * 4) * 3), ("prim_id", C.c_int32 * 4)]
+
+
+class EntityLeaf1(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("entity_id", C.c_int32), ("max", C.c_float * 3), ("shape_id", C.c_int32),
+                ("local", C.c_float * 12), ("flags", C.c_uint32), ("mat_id", C.c_int32), ("user", C.c_int32 * 2)]
+
+
+class LookupEntry(C.Structure):
+    _fields_ = [("type_id", C.c_uint32), ("flags", C.c_uint32), ("offset", C.c_uint64)]
+
+
+class Material(C.Structure):
+    _fields_ = [("bsdf_type", C.c_int32), ("light_id", C.c_int32), ("flags", C.c_uint32), ("tex_id", C.c_int32),
+                ("p", C.c_float * 12), ("q", C.c_float * 8)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("entity_id", C.c_int32), ("pad", C.c_int32 * 2), ("d", C.c_float * 24)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("fov", C.c_float),
+                ("fov_is_vertical", C.c_int32), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("aspect_ratio", C.c_float)]
+
+
+class Technique(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("min_depth", C.c_int32), ("clamp", C.c_float), ("nee", C.c_int32),
+                ("light_selector", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("entities", C.POINTER(C.c_float)), ("entity_count", C.c_uint32),
+        ("shape_lookups", C.POINTER(LookupEntry)), ("shape_count", C.c_uint32),
+        ("shape_data", C.POINTER(C.c_uint8)), ("shape_data_size", C.c_uint64),
+        ("primbvh", C.POINTER(C.c_uint8)), ("primbvh_size", C.c_uint64),
+        ("scene_nodes", C.POINTER(Node8)), ("scene_node_count", C.c_uint32),
+        ("scene_leaves", C.POINTER(EntityLeaf1)), ("scene_leaf_count", C.c_uint32),
+        ("materials", C.POINTER(Material)), ("material_count", C.c_uint32),
+        ("entity_per_material", C.POINTER(C.c_int32)),
+        ("lights", C.POINTER(Light)), ("light_count", C.c_uint32), ("infinite_light_count", C.c_uint32),
+        ("light_hierarchy", C.POINTER(C.c_float)), ("light_hierarchy_nodes", C.c_uint32),
+        ("camera", Camera), ("technique", Technique),
+        ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+        ("film_width", C.c_int32), ("film_height", C.c_int32),
+    ]
+
+
+assert C.sizeof(Node8) == 256 and C.sizeof(Tri4) == 208 and C.sizeof(EntityLeaf1) == 96
+assert C.sizeof(Material) == 96 and C.sizeof(Light) == 112
+
+
+class HostOptions(C.Structure):
+    _fields_ = [("film_width", C.c_int32), ("film_height", C.c_int32)]
+
+
+_host = None
+
+
+def host_lib():
+    """Loads libig_host.so (built by __graft_entry__.build()); fails loudly if missing."""
+    global _host
+    if _host is None:
+        path = os.path.join(_LIB_DIR, "libig_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+        lib = C.CDLL(path)
+        lib.igh_load_file.restype = C.c_void_p
+        lib.igh_load_file.argtypes = [C.c_char_p, C.POINTER(HostOptions)]
+        lib.igh_load_string.restype = C.c_void_p
+        lib.igh_load_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(HostOptions)]
+        lib.igh_tables.restype = C.POINTER(Scene)
+        lib.igh_tables.argtypes = [C.c_void_p]
+        lib.igh_entity_name.restype = C.c_char_p
+        lib.igh_entity_name.argtypes = [C.c_void_p, C.c_uint32]
+        lib.igh_material_name.restype = C.c_char_p
+        lib.igh_material_name.argtypes = [C.c_void_p, C.c_uint32]
+        lib.igh_free.restype = None
+        lib.igh_free.argtypes = [C.c_void_p]
+        lib.igh_last_error.restype = C.c_char_p
+        _host = lib
+    return _host
+
+
+class LoadedScene:
+    """Owns an igh_scene; `.tables` is the borrowed igd_scene pointer (valid while this object lives)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.tables = host_lib().igh_tables(handle)
+
+    @staticmethod
+    def from_file(path, width=0, height=0):
+        opts = HostOptions(int(width), int(height))
+        h = host_lib().igh_load_file(os.fsencode(path), C.byref(opts))
+        if not h:
+            raise RuntimeError(host_lib().igh_last_error().decode())
+        return LoadedScene(h)
+
+    @staticmethod
+    def from_string(text, base_dir="", width=0, height=0):
+        opts = HostOptions(int(width), int(height))
+        h = host_lib().igh_load_string(text.encode(), os.fsencode(base_dir), C.byref(opts))
+        if not h:
+            raise RuntimeError(host_lib().igh_last_error().decode())
+        return LoadedScene(h)
+
+    @property
+    def scene(self):
+        return self.tables.contents
+
+    def entity_name(self, i):
+        s = host_lib().igh_entity_name(self._h, i)
+        return s.decode() if s else None
+
+    def material_name(self, i):
+        s = host_lib().igh_material_name(self._h, i)
+        return s.decode() if s else None
+
+    def scene_nodes(self):
+        sc = self.scene
+        return np.ctypeslib.as_array(C.cast(sc.scene_nodes, C.POINTER(C.c_float)), shape=(sc.scene_node_count, 64)).copy()
+
+    def primbvh_bytes(self):
+        sc = self.scene
+        return bytes(C.string_at(sc.primbvh, sc.primbvh_size))
+
+    def close(self):
+        if self._h:
+            host_lib().igh_free(self._h)
+            self._h = None
+            self.tables = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,203 @@
+/* ig_tables.h — POD byte layouts shared by the host loader, the HIP device and
+ * the CPU oracle.
+ *
+ * The BVH / table structs below are byte-for-byte the reference's own upload
+ * formats for its <N=8, M=4> configuration (CPU target with vector width >= 8),
+ * so a SceneDatabase produced by the reference runtime can be handed to the HIP
+ * device unchanged:
+ *
+ *   ig_node8         src/artic/traversal/bvh.art:85-89      (Node8, 256 B)
+ *   ig_tri4          src/artic/shapes/trimesh.art:116-122   (Tri4, 208 B)
+ *   ig_entity_leaf1  src/artic/traversal/bvh.art:64-73      (EntityLeaf1, 96 B)
+ *   ig_lookup_entry  src/runtime/table/DynTable.h:6-10
+ *   entity record    src/runtime/loader/LoaderEntity.cpp:150-162 (36 floats)
+ *   shape record     src/runtime/shape/TriMeshProvider.cpp:575-596
+ *   prim-BVH record  src/runtime/shape/TriMeshProvider.cpp:305-323
+ *
+ * Materials, lights, camera and technique reach the reference device only as
+ * generated Artic source; the ig_material / ig_light /
+ * ig_camera / ig_technique PODs below are this backend's lowering of the same
+ * parameters (cited per field).
+ */
+#ifndef IG_TABLES_H
+#define IG_TABLES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BVH -------------------------------------------------------------- */
+
+/* child > 0: inner node id + 1; child < 0: ~first_leaf; child == 0: empty slot
+ * (bounds = +inf / -inf), src/runtime/bvh/BvhNAdapter.h:37-93. */
+typedef struct ig_node8 {
+    float bounds[6][8]; /* min_x, max_x, min_y, max_y, min_z, max_z  x 8 children */
+    int32_t child[8];
+    int32_t pad[8];
+} ig_node8;
+
+/* Four triangles in Moeller-Trumbore form: v0, e1 = v2 - v0, e2 = v0 - v1,
+ * n = stable(e1 x e2); prim_id == -1 marks an unused slot, bit 31 of
+ * prim_id[3] marks the last packet of a leaf
+ * (src/runtime/bvh/TriBVHAdapter.h:94-151). */
+typedef struct ig_tri4 {
+    float v0[3][4];
+    float e1[3][4];
+    float e2[3][4];
+    float n[3][4];
+    int32_t prim_id[4];
+} ig_tri4;
+
+/* Scene-BVH leaf; bit 31 of entity_id marks the last leaf of a run
+ * (src/runtime/bvh/SceneBVHAdapter.h:68-100). `local` is the 3x4 to-local
+ * matrix, column major. `user` is the prim-BVH offset (in floats) into the
+ * "trimesh_primbvh" fix table, split into two u32. */
+typedef struct ig_entity_leaf1 {
+    float min[3];
+    int32_t entity_id;
+    float max[3];
+    int32_t shape_id;
+    float local[12];
+    uint32_t flags;
+    int32_t mat_id;
+    int32_t user[2];
+} ig_entity_leaf1;
+
+typedef struct ig_lookup_entry {
+    uint32_t type_id;
+    uint32_t flags;
+    uint64_t offset; /* bytes into the dyn-table data blob */
+} ig_lookup_entry;
+
+#define IG_ENTITY_FLOATS 36 /* toLocal 3x4 | toGlobal 3x4 | normal 3x3 | shape | mat | pad */
+
+/* Ray visibility flags, src/artic/traversal/ray.art:21-25 */
+#define IG_RAY_FLAG_CAMERA 0x1u
+#define IG_RAY_FLAG_LIGHT 0x2u
+#define IG_RAY_FLAG_BOUNCE 0x4u
+#define IG_RAY_FLAG_SHADOW 0x8u
+#define IG_RAY_FLAG_TYPE_MASK 0xFu
+
+/* ---- Materials -------------------------------------------------------- */
+
+enum ig_bsdf_type {
+    IG_BSDF_DIFFUSE    = 0, /* src/artic/bsdf/diffuse.art:2-61,   runtime/bsdf/DiffuseBSDF.cpp:13-27 */
+    IG_BSDF_DIELECTRIC = 1, /* src/artic/bsdf/dielectric.art:15-37, runtime/bsdf/DielectricBSDF.cpp:13-41 */
+    IG_BSDF_CONDUCTOR  = 2, /* src/artic/bsdf/conductor.art:47-141, runtime/bsdf/ConductorBSDF.cpp:13-34 */
+};
+
+enum ig_material_flags {
+    IG_MAT_THIN       = 1u << 0, /* dielectric "thin" */
+    IG_MAT_BUMP       = 1u << 1, /* wrapped in a bumpmap, src/artic/bsdf/map.art:36-42 */
+    IG_MAT_CHECKER    = 1u << 2, /* reflectance is a checkerboard texture */
+};
+
+/* One record per material (= unique bsdf / area-light entity,
+ * src/runtime/loader/LoaderEntity.cpp:82-96). 96 bytes. */
+typedef struct ig_material {
+    int32_t bsdf_type;
+    int32_t light_id; /* >= 0: emissive, index into lights (area light on this entity) */
+    uint32_t flags;
+    int32_t tex_id;   /* bitmap texture index for the bump map, -1 = none */
+    /* diffuse:    p[0..2] reflectance, p[3] alpha (roughness)
+     * dielectric: p[0] ext_ior (n1), p[1] int_ior (n2), p[2..4] specular_reflectance,
+     *             p[5..7] specular_transmittance
+     * conductor:  p[0..2] eta, p[3..5] k, p[6..8] specular_reflectance,
+     *             p[9] alpha_u, p[10] alpha_v
+     * bump:       p[11] strength
+     * checker:    q[0..2] color0, q[3..5] color1, q[6] scale_x, q[7] scale_y */
+    float p[12];
+    float q[8];
+} ig_material;
+
+/* ---- Lights ----------------------------------------------------------- */
+
+enum ig_light_type {
+    IG_LIGHT_PLANE = 0, /* "SimplePlaneLight", src/artic/light/area.art:416-440, 24 floats */
+    IG_LIGHT_POINT = 1, /* "SimplePointLight", src/artic/light/point.art:20-35, 8 floats */
+    IG_LIGHT_ENV   = 2, /* constant environment radiance, src/artic/light/env.art */
+};
+
+/* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
+ *                t0.xy, t1.xy | t2.xy, t3.xy | radiance.rgb, area
+ * d[] for POINT: position.xyz, 0 | intensity.rgb, 0
+ * d[] for ENV:   radiance.rgb, 0 */
+typedef struct ig_light {
+    int32_t type;
+    int32_t entity_id; /* emissive entity for area lights, -1 otherwise */
+    int32_t pad[2];
+    float d[24];
+} ig_light;
+
+enum ig_light_selector {
+    IG_SELECTOR_UNIFORM   = 0, /* src/artic/light/light_selector.art:26-46 */
+    IG_SELECTOR_HIERARCHY = 1, /* src/artic/light/light_selector.art:80-110 */
+};
+
+/* ---- Camera / technique ----------------------------------------------- */
+
+typedef struct ig_camera {
+    float eye[3];  /* T * 0,             src/runtime/camera/PerspectiveCamera.cpp:69-76 */
+    float dir[3];  /* T.linear.col(2) */
+    float up[3];   /* T.linear.col(1) */
+    float fov;     /* radians */
+    int32_t fov_is_vertical;
+    float near_clip, far_clip;
+    float aspect_ratio; /* <= 0: use width / height */
+} ig_camera;
+
+typedef struct ig_technique {
+    int32_t max_depth;      /* src/runtime/technique/PathTechnique.cpp:11 (default 64) */
+    int32_t min_depth;      /* default 2 */
+    float clamp;            /* 0 = off */
+    int32_t nee;            /* default 1 */
+    int32_t light_selector; /* enum ig_light_selector */
+} ig_technique;
+
+/* ---- Scene ------------------------------------------------------------ */
+
+/* Everything IRenderDevice::assignScene receives through SceneSettings
+ * (src/runtime/device/IRenderDevice.h:20-28: database, entity_per_material)
+ * plus the POD lowering of what the reference passes as generated Artic.
+ * All pointers are borrowed and must outlive the renders, as in the reference. */
+typedef struct igd_scene {
+    /* FixTable "entities" */
+    const float* entities;
+    uint32_t entity_count;
+    /* DynTable "shapes" */
+    const ig_lookup_entry* shape_lookups;
+    uint32_t shape_count;
+    const uint8_t* shape_data;
+    uint64_t shape_data_size;
+    /* FixTable "trimesh_primbvh": per shape {u32 node_count, tri_count, pad, pad} ig_node8[] ig_tri4[] */
+    const uint8_t* primbvh;
+    uint64_t primbvh_size;
+    /* SceneBVHs["trimesh"] */
+    const ig_node8* scene_nodes;
+    uint32_t scene_node_count;
+    const ig_entity_leaf1* scene_leaves;
+    uint32_t scene_leaf_count;
+    /* materials (entities are stored material-ordered, LoaderEntity.cpp:99-103) */
+    const ig_material* materials;
+    uint32_t material_count;
+    const int32_t* entity_per_material; /* material_count entries */
+    /* lights: infinite lights first, then finite */
+    const ig_light* lights;
+    uint32_t light_count;
+    uint32_t infinite_light_count;
+    /* light hierarchy for IG_SELECTOR_HIERARCHY: 8 floats per node */
+    const float* light_hierarchy;
+    uint32_t light_hierarchy_nodes;
+    ig_camera camera;
+    ig_technique technique;
+    float bbox_min[3];
+    float bbox_max[3];
+    int32_t film_width, film_height;
+} igd_scene;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IG_TABLES_H */

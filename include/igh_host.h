@@ -1,0 +1,52 @@
+/* igh_host.h — C ABI of the host-side scene loader (libig_host.so).
+ *
+ * Replaces, for the hot-path configs, what the reference runtime does between
+ * `Runtime::loadFromFile` and `IRenderDevice::assignScene`
+ * (src/runtime/Runtime.cpp:175-195,253-332,532-594): JSON scene -> meshes ->
+ * BVHs -> SceneDatabase tables, plus the POD lowering of materials, lights,
+ * camera and technique that the reference ships as generated Artic source.
+ * No GPU dependency; the result is handed to igd_assign_scene() (igd_device.h)
+ * or to the CPU oracle.
+ */
+#ifndef IGH_HOST_H
+#define IGH_HOST_H
+
+#include "ig_tables.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct igh_scene igh_scene;
+
+/* Mirrors the RuntimeOptions fields the loader consumes
+ * (src/runtime/RuntimeSettings.h:12-59: OverrideFilmSize). 0 = keep the scene's. */
+typedef struct igh_options {
+    int32_t film_width;
+    int32_t film_height;
+} igh_options;
+
+/* Runtime::loadFromFile (src/runtime/Runtime.cpp:175-195). Returns NULL on error;
+ * igh_last_error() then holds the message (the reference logs and returns false). */
+igh_scene* igh_load_file(const char* path, const igh_options* opts);
+
+/* Runtime::loadFromString (src/runtime/Runtime.cpp:197-213); `base_dir` resolves
+ * relative mesh/texture paths. */
+igh_scene* igh_load_string(const char* json, const char* base_dir, const igh_options* opts);
+
+/* Tables in the layout of ig_tables.h; owned by the igh_scene. */
+const igd_scene* igh_tables(const igh_scene* scene);
+
+/* Names by id (ids follow declaration order). */
+const char* igh_entity_name(const igh_scene* scene, uint32_t entity_id);
+const char* igh_material_name(const igh_scene* scene, uint32_t material_id);
+
+void igh_free(igh_scene* scene);
+
+/* Thread-local message of the last failed igh_* call ("" if none). */
+const char* igh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGH_HOST_H */

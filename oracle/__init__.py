@@ -1,0 +1,174 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg import this package. The product package `ignis_amd` never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class Settings(C.Structure):
+    _fields_ = [("spi", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("iteration", C.c_int32),
+                ("frame", C.c_int32), ("seed", C.c_int32), ("threads", C.c_int32),
+                ("xmin", C.c_int32), ("ymin", C.c_int32), ("xmax", C.c_int32), ("ymax", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("nodes", C.c_uint64), ("tris", C.c_uint64), ("leaves", C.c_uint64), ("unoccluded", C.c_uint64),
+                ("max_stack", C.c_int32), ("threads_used", C.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C oracle` (or __graft_entry__.build())")
+        l = C.CDLL(path)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        up = C.POINTER(C.c_uint32)
+        l.oracle_render.restype = C.c_int
+        l.oracle_render.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats)]
+        l.oracle_generate_rays.restype = C.c_int
+        l.oracle_generate_rays.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int64, C.c_int64, fp, up]
+        l.oracle_trace.restype = C.c_int
+        l.oracle_trace.argtypes = [C.c_void_p, C.c_int64, fp, C.c_uint32, C.c_int, ip, ip, fp, fp, fp, C.POINTER(Stats)]
+        l.oracle_trace_bruteforce.restype = C.c_int
+        l.oracle_trace_bruteforce.argtypes = [C.c_void_p, C.c_int64, fp, fp, ip, ip]
+        l.oracle_intersect_tri.restype = C.c_int
+        l.oracle_intersect_tri.argtypes = [fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, fp]
+        l.oracle_intersect_box.restype = C.c_int
+        l.oracle_intersect_box.argtypes = [fp, fp, C.c_float, C.c_float, fp, fp, fp]
+        l.oracle_random_seed.restype = C.c_uint32
+        l.oracle_random_seed.argtypes = [C.c_int32] * 6
+        l.oracle_random_f32.restype = None
+        l.oracle_random_f32.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, fp, up]
+        l.oracle_detmath.restype = None
+        l.oracle_detmath.argtypes = [C.c_int, C.c_int64, fp, fp]
+        l.oracle_hardware_threads.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _scene_ptr(scene):
+    """Accepts an ignis_amd.tables.LoadedScene or a raw pointer."""
+    t = getattr(scene, "tables", scene)
+    return C.cast(t, C.c_void_p)
+
+
+def make_settings(spi, width, height, iteration=0, frame=0, seed=0, threads=0, window=None):
+    s = Settings(spi, width, height, iteration, frame, seed, threads, 0, 0, 0, 0)
+    if window is not None:
+        s.xmin, s.ymin, s.xmax, s.ymax = window
+    return s
+
+
+def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None):
+    """One iteration of the reference CPU pipeline; returns (fb[h,w,3] float32 accumulated, stats dict)."""
+    if fb is None:
+        fb = np.zeros((height, width, 3), dtype=np.float32)
+    assert fb.dtype == np.float32 and fb.flags.c_contiguous and fb.shape == (height, width, 3)
+    cfg = make_settings(spi, width, height, iteration, frame, seed, threads, window)
+    st = Stats()
+    rc = lib().oracle_render(_scene_ptr(scene), C.byref(cfg), _fp(fb), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle_render failed")
+    return fb, st.as_dict()
+
+
+def generate_rays(scene, spi, width, height, first_id, count, iteration=0, frame=0, seed=0):
+    rays = np.empty((count, 8), dtype=np.float32)
+    ctr = np.empty(count, dtype=np.uint32)
+    cfg = make_settings(spi, width, height, iteration, frame, seed)
+    rc = lib().oracle_generate_rays(_scene_ptr(scene), C.byref(cfg), first_id, count, _fp(rays), _up(ctr))
+    if rc != 0:
+        raise RuntimeError("oracle_generate_rays failed")
+    return rays, ctr
+
+
+def trace(scene, rays, flags=0, any_hit=False):
+    """rays: (n, 8) float32 [org, dir, tmin, tmax]. Returns dict of ent_id, prim_id, t, u, v + stats."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    n = rays.shape[0]
+    ent = np.empty(n, dtype=np.int32)
+    prim = np.empty(n, dtype=np.int32)
+    t = np.empty(n, dtype=np.float32)
+    u = np.empty(n, dtype=np.float32)
+    v = np.empty(n, dtype=np.float32)
+    st = Stats()
+    rc = lib().oracle_trace(_scene_ptr(scene), n, _fp(rays), flags, 1 if any_hit else 0, _ip(ent), _ip(prim), _fp(t), _fp(u), _fp(v), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle_trace failed")
+    return {"ent_id": ent, "prim_id": prim, "t": t, "u": u, "v": v, "stats": st.as_dict()}
+
+
+def trace_bruteforce(scene, rays):
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    n = rays.shape[0]
+    t = np.empty(n, dtype=np.float32)
+    ent = np.empty(n, dtype=np.int32)
+    prim = np.empty(n, dtype=np.int32)
+    rc = lib().oracle_trace_bruteforce(_scene_ptr(scene), n, _fp(rays), _fp(t), _ip(ent), _ip(prim))
+    if rc != 0:
+        raise RuntimeError("oracle_trace_bruteforce failed")
+    return {"t": t, "ent_id": ent, "prim_id": prim}
+
+
+def intersect_tri(org, dir, tmin, tmax, v0, e1, e2, n):
+    a = [np.asarray(x, dtype=np.float32) for x in (org, dir, v0, e1, e2, n)]
+    out = np.zeros(3, dtype=np.float32)
+    hit = lib().oracle_intersect_tri(_fp(a[0]), _fp(a[1]), tmin, tmax, _fp(a[2]), _fp(a[3]), _fp(a[4]), _fp(a[5]), _fp(out))
+    return bool(hit), out
+
+
+def intersect_box(org, dir, tmin, tmax, bmin, bmax):
+    a = [np.asarray(x, dtype=np.float32) for x in (org, dir, bmin, bmax)]
+    out = np.zeros(2, dtype=np.float32)
+    hit = lib().oracle_intersect_box(_fp(a[0]), _fp(a[1]), tmin, tmax, _fp(a[2]), _fp(a[3]), _fp(out))
+    return bool(hit), out
+
+
+def random_seed(sample, iteration, frame, x, y, user):
+    return int(lib().oracle_random_seed(sample, iteration, frame, x, y, user))
+
+
+def random_sequence(seed, first_counter, count):
+    f = np.empty(count, dtype=np.float32)
+    r = np.empty(count, dtype=np.uint32)
+    lib().oracle_random_f32(seed, first_counter, count, _fp(f), _up(r))
+    return f, r
+
+
+def detmath(which, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().oracle_detmath({"sin": 0, "cos": 1, "acos": 2, "asin": 3}[which], x.size, _fp(x), _fp(y))
+    return y
+
+
+def hardware_threads():
+    return int(lib().oracle_hardware_threads())

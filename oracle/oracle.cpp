@@ -1,0 +1,589 @@
+// oracle.cpp — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the reference CPU device's wavefront loop `cpu_trace`
+// (src/artic/driver/mapping_cpu.art:719-861): 16x16 image tiles, one worker
+// thread per core, per-thread SoA streams of spi*256 rays, in-place counting
+// sort by entity, per-entity hit shading, stable compaction, any-hit shadow
+// traversal and a serial per-tile splat. Exposed through a plain C ABI so the
+// tests, __graft_entry__.smoke() and bench.py's cpu_baseline leg can call it
+// with ctypes. The product (ignis_amd/) never links or loads this library.
+#include "oracle_shade.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <thread>
+#include <vector>
+
+using namespace oracle;
+
+extern "C" {
+
+typedef struct oracle_settings {
+    int32_t spi;
+    int32_t width, height;
+    int32_t iteration, frame, seed;
+    int32_t threads; // <= 0: hardware concurrency
+    // optional pixel window (tile sharding); xmax/ymax <= 0 means full film
+    int32_t xmin, ymin, xmax, ymax;
+} oracle_settings;
+
+typedef struct oracle_stats {
+    uint64_t camera_rays, bounce_rays, shadow_rays;
+    uint64_t nodes, tris, leaves;
+    uint64_t unoccluded;
+    int32_t max_stack;
+    int32_t threads_used;
+} oracle_stats;
+
+} // extern "C"
+
+namespace {
+
+struct PrimaryStream {
+    std::vector<int32_t> id;
+    std::vector<float> org_x, org_y, org_z, dir_x, dir_y, dir_z, tmin, tmax;
+    std::vector<uint32_t> flags;
+    std::vector<int32_t> ent_id, prim_id;
+    std::vector<float> t, u, v;
+    std::vector<uint32_t> rnd;
+    std::vector<float> payload; // SoA: payload[c * capacity + i] (ShaderUtils.cpp:38)
+    int capacity = 0;
+
+    void resize(int cap)
+    {
+        capacity = cap;
+        id.resize(cap);
+        for (auto* p : { &org_x, &org_y, &org_z, &dir_x, &dir_y, &dir_z, &tmin, &tmax, &t, &u, &v })
+            p->resize(cap);
+        flags.resize(cap);
+        ent_id.resize(cap);
+        prim_id.resize(cap);
+        rnd.resize(cap);
+        payload.resize((size_t)cap * 6);
+    }
+};
+
+struct SecondaryStream {
+    std::vector<int32_t> id;
+    std::vector<float> org_x, org_y, org_z, dir_x, dir_y, dir_z, tmin, tmax;
+    std::vector<uint32_t> flags;
+    std::vector<int32_t> mat_id;
+    std::vector<float> color_r, color_g, color_b;
+
+    void resize(int cap)
+    {
+        id.resize(cap);
+        for (auto* p : { &org_x, &org_y, &org_z, &dir_x, &dir_y, &dir_z, &tmin, &tmax, &color_r, &color_g, &color_b })
+            p->resize(cap);
+        flags.resize(cap);
+        mat_id.resize(cap);
+    }
+};
+
+inline Ray read_ray(const PrimaryStream& s, int i)
+{
+    return make_ray(Vec3{ s.org_x[i], s.org_y[i], s.org_z[i] }, Vec3{ s.dir_x[i], s.dir_y[i], s.dir_z[i] }, s.tmin[i], s.tmax[i], s.flags[i]);
+}
+
+inline void write_ray(PrimaryStream& s, int i, const Ray& r)
+{
+    s.org_x[i] = r.org.x, s.org_y[i] = r.org.y, s.org_z[i] = r.org.z;
+    s.dir_x[i] = r.dir.x, s.dir_y[i] = r.dir.y, s.dir_z[i] = r.dir.z;
+    s.tmin[i]  = r.tmin;
+    s.tmax[i]  = r.tmax;
+    s.flags[i] = r.flags;
+}
+
+inline PTRayPayload read_payload(const PrimaryStream& s, int i)
+{
+    const int c = s.capacity;
+    PTRayPayload p;
+    p.inv_pdf = s.payload[i];
+    p.contrib = Color{ s.payload[c + i], s.payload[2 * c + i], s.payload[3 * c + i] };
+    p.depth   = (int32_t)s.payload[4 * c + i];
+    p.eta     = s.payload[5 * c + i];
+    return p;
+}
+
+inline void write_payload(PrimaryStream& s, int i, const PTRayPayload& p)
+{
+    const int c          = s.capacity;
+    s.payload[i]         = p.inv_pdf;
+    s.payload[c + i]     = p.contrib.r;
+    s.payload[2 * c + i] = p.contrib.g;
+    s.payload[3 * c + i] = p.contrib.b;
+    s.payload[4 * c + i] = (float)p.depth;
+    s.payload[5 * c + i] = p.eta;
+}
+
+template <typename T>
+inline void swp(std::vector<T>& v, int a, int b) { std::swap(v[a], v[b]); }
+
+// cpu_swap_primary_entry (mapping_cpu.art:23-43)
+void swap_primary(PrimaryStream& s, int a, int b)
+{
+    swp(s.id, a, b);
+    swp(s.org_x, a, b), swp(s.org_y, a, b), swp(s.org_z, a, b);
+    swp(s.dir_x, a, b), swp(s.dir_y, a, b), swp(s.dir_z, a, b);
+    swp(s.tmin, a, b), swp(s.tmax, a, b), swp(s.flags, a, b);
+    swp(s.ent_id, a, b), swp(s.prim_id, a, b), swp(s.t, a, b), swp(s.u, a, b), swp(s.v, a, b), swp(s.rnd, a, b);
+    for (int c = 0; c < 6; ++c)
+        std::swap(s.payload[(size_t)c * s.capacity + a], s.payload[(size_t)c * s.capacity + b]);
+}
+
+// cpu_sort_primary (mapping_cpu.art:63-103)
+int sort_primary(PrimaryStream& s, int size, std::vector<int>& ray_begins, std::vector<int>& ray_ends, int num_geometries)
+{
+    for (int i = 0; i <= num_geometries; ++i)
+        ray_ends[i] = 0;
+    auto key = [&](int i) { return s.ent_id[i] == -1 ? num_geometries : s.ent_id[i]; };
+    for (int i = 0; i < size; ++i)
+        ray_ends[key(i)]++;
+    int n = 0;
+    for (int i = 0; i <= num_geometries; ++i) {
+        ray_begins[i] = n;
+        n += ray_ends[i];
+        ray_ends[i] = n;
+    }
+    for (int i = 0; i < num_geometries; ++i) {
+        const int end = ray_ends[i];
+        int j         = ray_begins[i];
+        while (j < end) {
+            const int ent = key(j);
+            if (ent != i) {
+                const int k = ray_begins[ent]++;
+                swap_primary(s, k, j);
+            } else {
+                ++j;
+            }
+        }
+    }
+    return ray_ends[num_geometries - 1];
+}
+
+// cpu_compact_primary (mapping_cpu.art:205-253), scalar branch
+int compact_primary(PrimaryStream& s, int size)
+{
+    int k = 0;
+    for (int i = 0; i < size; ++i) {
+        if (s.id[i] >= 0) {
+            s.id[k]    = s.id[i];
+            s.org_x[k] = s.org_x[i], s.org_y[k] = s.org_y[i], s.org_z[k] = s.org_z[i];
+            s.dir_x[k] = s.dir_x[i], s.dir_y[k] = s.dir_y[i], s.dir_z[k] = s.dir_z[i];
+            s.tmin[k] = s.tmin[i], s.tmax[k] = s.tmax[i], s.flags[k] = s.flags[i];
+            s.rnd[k] = s.rnd[i];
+            for (int c = 0; c < 6; ++c)
+                s.payload[(size_t)c * s.capacity + k] = s.payload[(size_t)c * s.capacity + i];
+            ++k;
+        }
+    }
+    return k;
+}
+
+// cpu_compact_secondary (mapping_cpu.art:255-310), scalar branch
+int compact_secondary(SecondaryStream& s, int size)
+{
+    int k = 0;
+    for (int i = 0; i < size; ++i) {
+        if (s.id[i] >= 0) {
+            s.id[k]    = s.id[i];
+            s.org_x[k] = s.org_x[i], s.org_y[k] = s.org_y[i], s.org_z[k] = s.org_z[i];
+            s.dir_x[k] = s.dir_x[i], s.dir_y[k] = s.dir_y[i], s.dir_z[k] = s.dir_z[i];
+            s.tmin[k] = s.tmin[i], s.tmax[k] = s.tmax[i], s.flags[k] = s.flags[i];
+            s.mat_id[k]  = s.mat_id[i];
+            s.color_r[k] = s.color_r[i], s.color_g[k] = s.color_g[i], s.color_b[k] = s.color_b[i];
+            ++k;
+        }
+    }
+    return k;
+}
+
+struct Counters {
+    uint64_t camera = 0, bounce = 0, shadow = 0, unoccluded = 0;
+    TraversalStats trav;
+};
+
+void camera_scale(const igd_scene& sc, int width, int height, float& sx, float& sy)
+{
+    // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13); aspect = width / height
+    // unless fixed by the scene (PerspectiveCamera.cpp:41-45)
+    const float aspect = sc.camera.aspect_ratio > 0 ? sc.camera.aspect_ratio : (float)width / (float)height;
+    if (sc.camera.fov_is_vertical) {
+        sy = std::tan(sc.camera.fov / 2);
+        sx = sy * aspect;
+    } else {
+        sx = std::tan(sc.camera.fov / 2);
+        sy = sx / aspect;
+    }
+}
+
+// One tile of cpu_trace (mapping_cpu.art:731-857)
+void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSetup& cam, const PathTracer& pt_tech,
+                int xmin, int ymin, int xmax, int ymax, float* fb,
+                PrimaryStream& primary, SecondaryStream& secondary, std::vector<int>& ray_begins, std::vector<int>& ray_ends, Counters& cnt)
+{
+    const int spi      = cfg.spi;
+    const int capacity = primary.capacity;
+    const int W = cfg.width, H = cfg.height;
+    const int tile_width = xmax - xmin, tile_height = ymax - ymin;
+    const int num_rays  = spi * tile_height * tile_width;
+    const int E         = (int)sc.entity_count;
+    const float inv_spi = 1 / (float)spi; // make_standard_accumulator (driver/accumulator.art:23-30)
+    (void)H;
+
+    auto splat = [&](int ray_id, Color c) {
+        const int pixel = ray_id / spi;
+        fb[pixel * 3 + 0] += c.r * inv_spi;
+        fb[pixel * 3 + 1] += c.g * inv_spi;
+        fb[pixel * 3 + 2] += c.b * inv_spi;
+    };
+
+    int id = 0, current_size = 0;
+    while (id < num_rays || current_size > 0) {
+        // (Re-)generate primary rays: cpu_generate_rays (mapping_cpu.art:313-360)
+        if (current_size < capacity && id < num_rays) {
+            const int n = std::min(num_rays - id, capacity - current_size);
+            for (int i = 0; i < n; ++i) {
+                const int in_tile_id    = id + i;
+                const int sample        = in_tile_id % spi;
+                const int in_tile_pixel = in_tile_id / spi;
+                const int in_tile_y     = in_tile_pixel / tile_width;
+                const int in_tile_x     = in_tile_pixel - in_tile_y * tile_width;
+                const int x = xmin + in_tile_x, y = ymin + in_tile_y;
+                const int cur = current_size + i;
+                Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, x, y, cfg.seed), 1 };
+                const Ray ray = generate_camera_ray(cam, rnd, x, y, W, cfg.height);
+                write_ray(primary, cur, ray);
+                primary.id[cur]  = (y * W + x) * spi + sample;
+                primary.rnd[cur] = rnd.counter;
+                write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1 }); // init_pt_raypayload (pathtracer.art:33-38)
+            }
+            current_size += n;
+            id += n;
+            cnt.camera += (uint64_t)n;
+        }
+
+        if (E == 0) {
+            // only miss shading
+            for (int i = 0; i < current_size; ++i) {
+                Color c;
+                if (pt_tech.on_miss(read_payload(primary, i), c))
+                    splat(primary.id[i], c);
+            }
+            current_size = 0;
+            continue;
+        }
+
+        // cpu_traverse_primary (mapping_cpu.art:373-403)
+        for (int i = 0; i < current_size; ++i) {
+            const Hit hit      = traverse_scene(sc, read_ray(primary, i), false, cnt.trav);
+            primary.ent_id[i]  = hit.ent_id;
+            primary.prim_id[i] = hit.prim_id;
+            primary.t[i]       = hit.distance;
+            primary.u[i]       = hit.u;
+            primary.v[i]       = hit.v;
+        }
+
+        const int total_size = current_size;
+        current_size         = sort_primary(primary, current_size, ray_begins, ray_ends, E);
+
+        // cpu_hit_shade per entity range (mapping_cpu.art:467-559,773-784)
+        for (int ent = 0, begin = 0; ent < E; ++ent) {
+            const int end = ray_ends[ent];
+            if (begin < end) {
+                const Entity entity    = load_entity(sc, ent);
+                const ig_material& mat = sc.materials[entity.mat_id];
+                for (int i = begin; i < end; ++i) {
+                    const Ray ray     = read_ray(primary, i);
+                    const Hit hit     = Hit{ primary.t[i], primary.u[i], primary.v[i], primary.prim_id[i], primary.ent_id[i] };
+                    const int ray_id  = primary.id[i];
+                    const int sample  = ray_id % spi;
+                    const int pixel_l = ray_id / spi;
+                    const int px = pixel_l % W, py = pixel_l / W;
+                    Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, px, py, cfg.seed), primary.rnd[i] };
+
+                    PTRayPayload payload      = read_payload(primary, i);
+                    const SurfaceElement surf = surface_element(sc, entity, ray, hit);
+                    const Bsdf bsdf{ &mat, &surf };
+
+                    Color hit_color;
+                    if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
+                        hit_color = Color{ 0, 0, 0 };
+                    splat(ray_id, hit_color);
+
+                    const ShadowRayOut sh = pt_tech.on_shadow(ray, surf, rnd, payload, bsdf);
+                    if (sh.valid) {
+                        secondary.org_x[i] = sh.ray.org.x, secondary.org_y[i] = sh.ray.org.y, secondary.org_z[i] = sh.ray.org.z;
+                        secondary.dir_x[i] = sh.ray.dir.x, secondary.dir_y[i] = sh.ray.dir.y, secondary.dir_z[i] = sh.ray.dir.z;
+                        secondary.tmin[i]  = sh.ray.tmin;
+                        secondary.tmax[i]  = sh.ray.tmax;
+                        secondary.flags[i] = sh.ray.flags;
+                        secondary.mat_id[i]  = entity.mat_id + 1;
+                        secondary.color_r[i] = sh.color.r, secondary.color_g[i] = sh.color.g, secondary.color_b[i] = sh.color.b;
+                        secondary.id[i] = ray_id;
+                    } else {
+                        secondary.id[i] = -1;
+                    }
+
+                    Ray new_ray;
+                    if (pt_tech.on_bounce(ray, surf, rnd, payload, bsdf, new_ray)) {
+                        write_ray(primary, i, new_ray);
+                        primary.rnd[i] = rnd.counter;
+                        write_payload(primary, i, payload);
+                    } else {
+                        primary.id[i] = -1;
+                    }
+                }
+            }
+            begin = end;
+        }
+
+        // cpu_miss_shade (mapping_cpu.art:582-617,787-790)
+        {
+            const int begin = ray_ends[E - 1], last = ray_ends[E];
+            (void)total_size;
+            for (int i = begin; i < last; ++i) {
+                Color c;
+                if (!pt_tech.on_miss(read_payload(primary, i), c))
+                    c = Color{ 0, 0, 0 };
+                splat(primary.id[i], c);
+                primary.id[i] = -1;
+            }
+        }
+
+        int secondary_size = current_size;
+        current_size       = compact_primary(primary, current_size);
+        cnt.bounce += (uint64_t)current_size;
+
+        secondary_size = compact_secondary(secondary, secondary_size);
+        if (secondary_size > 0) {
+            // cpu_traverse_secondary (mapping_cpu.art:406-435): any-hit
+            for (int i = 0; i < secondary_size; ++i) {
+                const Ray ray = make_ray(Vec3{ secondary.org_x[i], secondary.org_y[i], secondary.org_z[i] },
+                                         Vec3{ secondary.dir_x[i], secondary.dir_y[i], secondary.dir_z[i] },
+                                         secondary.tmin[i], secondary.tmax[i], secondary.flags[i]);
+                const Hit hit = traverse_scene(sc, ray, true, cnt.trav);
+                const int m   = secondary.mat_id[i];
+                secondary.mat_id[i] = hit.prim_id < 0 ? -std::abs(m) : std::abs(m); // streams.art:112-118
+            }
+            cnt.shadow += (uint64_t)secondary_size;
+
+            // serial splat of unoccluded shadow rays (mapping_cpu.art:840-853)
+            for (int i = 0; i < secondary_size; ++i) {
+                if (secondary.mat_id[i] < 0) {
+                    splat(secondary.id[i], Color{ secondary.color_r[i], secondary.color_g[i], secondary.color_b[i] });
+                    ++cnt.unoccluded;
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// Renders ONE iteration into `fb` (float[height][width][3], accumulated with +=,
+// exactly like the reference framebuffer: Runtime divides by the iteration count on save,
+// src/runtime/Runtime.cpp:808-826).
+int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats)
+{
+    if (!sc || !cfg || !fb || cfg->spi <= 0 || cfg->width <= 0 || cfg->height <= 0)
+        return -1;
+
+    float sx, sy;
+    camera_scale(*sc, cfg->width, cfg->height, sx, sy);
+    const CameraSetup cam = make_camera(sc->camera, sx, sy);
+    const PathTracer pt(*sc);
+
+    const int tile_size = 16; // ShaderUtils.cpp:37
+    const int x0 = cfg->xmax > 0 ? cfg->xmin : 0, y0 = cfg->ymax > 0 ? cfg->ymin : 0;
+    const int x1 = cfg->xmax > 0 ? cfg->xmax : cfg->width, y1 = cfg->ymax > 0 ? cfg->ymax : cfg->height;
+    const int tiles_x = (x1 - x0 + tile_size - 1) / tile_size;
+    const int tiles_y = (y1 - y0 + tile_size - 1) / tile_size;
+    const int num_tiles = tiles_x * tiles_y;
+
+    int threads = cfg->threads > 0 ? cfg->threads : (int)std::thread::hardware_concurrency();
+    threads     = std::max(1, std::min(threads, std::max(1, num_tiles)));
+
+    std::atomic<int> next_tile{ 0 };
+    std::vector<Counters> counters((size_t)threads);
+    auto worker = [&](int tid) {
+        PrimaryStream primary;
+        SecondaryStream secondary;
+        const int capacity = cfg->spi * tile_size * tile_size; // cpu_get_stream_capacity (mapping_cpu.art:717)
+        primary.resize(capacity);
+        secondary.resize(capacity);
+        std::vector<int> ray_begins(sc->entity_count + 2), ray_ends(sc->entity_count + 2);
+        for (;;) {
+            const int tile = next_tile.fetch_add(1);
+            if (tile >= num_tiles)
+                break;
+            const int tx = tile % tiles_x, ty = tile / tiles_x;
+            const int xmin = x0 + tx * tile_size, ymin = y0 + ty * tile_size;
+            const int xmax = std::min(xmin + tile_size, x1), ymax = std::min(ymin + tile_size, y1);
+            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
+        }
+    };
+
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t)
+        pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool)
+        th.join();
+
+    if (stats) {
+        for (const auto& c : counters) {
+            stats->camera_rays += c.camera;
+            stats->bounce_rays += c.bounce;
+            stats->shadow_rays += c.shadow;
+            stats->unoccluded += c.unoccluded;
+            stats->nodes += c.trav.nodes;
+            stats->tris += c.trav.tris;
+            stats->leaves += c.trav.leaves;
+            stats->max_stack = std::max(stats->max_stack, c.trav.max_stack);
+        }
+        stats->threads_used = threads;
+    }
+    return 0;
+}
+
+// Camera rays for ray ids [first_id, first_id + count) of one iteration, id = (y*W + x)*spi + sample
+// (gpu_generate_rays id convention, mapping_gpu.art:616-669). rays: 8 floats each (org, dir, tmin, tmax).
+int oracle_generate_rays(const igd_scene* sc, const oracle_settings* cfg, int64_t first_id, int64_t count, float* rays, uint32_t* rnd_counter)
+{
+    if (!sc || !cfg || !rays)
+        return -1;
+    float sx, sy;
+    camera_scale(*sc, cfg->width, cfg->height, sx, sy);
+    const CameraSetup cam = make_camera(sc->camera, sx, sy);
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t id  = first_id + i;
+        const int sample  = (int)(id % cfg->spi);
+        const int pixel   = (int)(id / cfg->spi);
+        const int x = pixel % cfg->width, y = pixel / cfg->width;
+        Rng rnd{ create_random_seed(sample, cfg->iteration, cfg->frame, x, y, cfg->seed), 1 };
+        const Ray r = generate_camera_ray(cam, rnd, x, y, cfg->width, cfg->height);
+        float* o    = rays + i * 8;
+        o[0] = r.org.x, o[1] = r.org.y, o[2] = r.org.z;
+        o[3] = r.dir.x, o[4] = r.dir.y, o[5] = r.dir.z;
+        o[6] = r.tmin, o[7] = r.tmax;
+        if (rnd_counter)
+            rnd_counter[i] = rnd.counter;
+    }
+    return 0;
+}
+
+// Closest-hit (any_hit = 0) or any-hit (any_hit = 1) traversal of a ray list.
+// rays: 8 floats each (org, dir, tmin, tmax). Outputs may be NULL.
+int oracle_trace(const igd_scene* sc, int64_t count, const float* rays, uint32_t flags, int any_hit,
+                 int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v, oracle_stats* stats)
+{
+    if (!sc || !rays)
+        return -1;
+    TraversalStats st;
+    for (int64_t i = 0; i < count; ++i) {
+        const float* r = rays + i * 8;
+        const Ray ray  = make_ray(Vec3{ r[0], r[1], r[2] }, Vec3{ r[3], r[4], r[5] }, r[6], r[7], flags);
+        const Hit hit  = traverse_scene(*sc, ray, any_hit != 0, st);
+        if (ent_id) ent_id[i] = hit.ent_id;
+        if (prim_id) prim_id[i] = hit.prim_id;
+        if (t) t[i] = hit.distance;
+        if (u) u[i] = hit.u;
+        if (v) v[i] = hit.v;
+    }
+    if (stats) {
+        stats->nodes += st.nodes;
+        stats->tris += st.tris;
+        stats->leaves += st.leaves;
+        stats->max_stack = std::max(stats->max_stack, st.max_stack);
+    }
+    return 0;
+}
+
+// Brute force over every instanced triangle (no BVH): checks the BVH build + traversal.
+int oracle_trace_bruteforce(const igd_scene* sc, int64_t count, const float* rays, float* t_out, int32_t* ent_out, int32_t* prim_out)
+{
+    if (!sc || !rays)
+        return -1;
+    for (int64_t i = 0; i < count; ++i) {
+        const float* r = rays + i * 8;
+        Ray ray        = make_ray(Vec3{ r[0], r[1], r[2] }, Vec3{ r[3], r[4], r[5] }, r[6], r[7], 0);
+        float best     = ray.tmax;
+        int32_t be = -1, bp = -1;
+        for (uint32_t e = 0; e < sc->entity_count; ++e) {
+            const Entity ent       = load_entity(*sc, (int32_t)e);
+            const TriMeshView mesh = load_trimesh(*sc, ent.shape_id);
+            Ray local              = transform_ray(ray, ent.local_mat);
+            local.tmax             = best;
+            for (int f = 0; f < mesh.num_tris; ++f) {
+                auto vtx = [&](int32_t k) { return Vec3{ mesh.vertices[k * 4], mesh.vertices[k * 4 + 1], mesh.vertices[k * 4 + 2] }; };
+                const Vec3 v0 = vtx(mesh.indices[f * 4]), v1 = vtx(mesh.indices[f * 4 + 1]), v2 = vtx(mesh.indices[f * 4 + 2]);
+                const Vec3 e1 = vec3_sub(v2, v0), e2 = vec3_sub(v0, v1);
+                const Vec3 n  = compute_stable_triangle_normal(e1, e2, vec3_sub(v1, v2));
+                float t, u, v;
+                if (intersect_ray_tri_mt(local, v0, e1, e2, n, t, u, v)) {
+                    best       = t;
+                    local.tmax = t;
+                    be         = (int32_t)e;
+                    bp         = f;
+                }
+            }
+        }
+        if (t_out) t_out[i] = best;
+        if (ent_out) ent_out[i] = be;
+        if (prim_out) prim_out[i] = bp;
+    }
+    return 0;
+}
+
+// ---- unit-level entry points for the golden-vector tests
+int oracle_intersect_tri(const float org[3], const float dir[3], float tmin, float tmax,
+                         const float v0[3], const float e1[3], const float e2[3], const float n[3], float out_tuv[3])
+{
+    const Ray ray = make_ray(Vec3{ org[0], org[1], org[2] }, Vec3{ dir[0], dir[1], dir[2] }, tmin, tmax, 0);
+    return intersect_ray_tri_mt(ray, Vec3{ v0[0], v0[1], v0[2] }, Vec3{ e1[0], e1[1], e1[2] }, Vec3{ e2[0], e2[1], e2[2] }, Vec3{ n[0], n[1], n[2] },
+                                out_tuv[0], out_tuv[1], out_tuv[2])
+               ? 1
+               : 0;
+}
+
+int oracle_intersect_box(const float org[3], const float dir[3], float tmin, float tmax, const float bmin[3], const float bmax[3], float out[2])
+{
+    const Ray ray = make_ray(Vec3{ org[0], org[1], org[2] }, Vec3{ dir[0], dir[1], dir[2] }, tmin, tmax, 0);
+    intersect_ray_box(ray, bmin, bmax, out[0], out[1]);
+    return out[0] <= out[1] ? 1 : 0;
+}
+
+uint32_t oracle_random_seed(int32_t sample, int32_t iter, int32_t frame, int32_t x, int32_t y, int32_t user)
+{
+    return create_random_seed(sample, iter, frame, x, y, user);
+}
+
+void oracle_random_f32(uint32_t seed, uint32_t first_counter, int32_t count, float* out_f, uint32_t* out_raw)
+{
+    Rng a{ seed, first_counter }, b{ seed, first_counter };
+    for (int i = 0; i < count; ++i) {
+        if (out_f) out_f[i] = a.next_f32();
+        if (out_raw) out_raw[i] = b.next_u32();
+    }
+}
+
+// which: 0 sin, 1 cos, 2 acos, 3 asin
+void oracle_detmath(int which, int64_t n, const float* x, float* y)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (which) {
+        case 0: y[i] = igm_sin(x[i]); break;
+        case 1: y[i] = igm_cos(x[i]); break;
+        case 2: y[i] = igm_acos(x[i]); break;
+        default: y[i] = igm_asin(x[i]); break;
+        }
+    }
+}
+
+int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+} // extern "C"

@@ -1,0 +1,669 @@
+// oracle_shade.h — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference's shading side of the hot path: RNG, camera
+// ray generation, surface reconstruction, BSDFs, lights, the path tracer
+// callbacks. Each function cites the reference file:line it follows.
+#pragma once
+
+#include "oracle_core.h"
+
+namespace oracle {
+
+// ---- core/random.art
+static inline uint32_t hash_init() { return 0x811C9DC5u; } // random.art:4
+// random.art:7-13 (FNV-1a, bytewise)
+static inline uint32_t hash_combine(uint32_t h, uint32_t d)
+{
+    h = (h * 16777619u) ^ (d & 0xFF);
+    h = (h * 16777619u) ^ ((d >> 8) & 0xFF);
+    h = (h * 16777619u) ^ ((d >> 16) & 0xFF);
+    h = (h * 16777619u) ^ ((d >> 24) & 0xFF);
+    return h;
+}
+// random.art:15-24
+static inline uint32_t sample_tea_u32(uint32_t v0, uint32_t v1)
+{
+    uint32_t sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v1;
+}
+// random.art:34-43
+static inline uint32_t create_random_seed(int32_t sample, int32_t iter, int32_t frame, int32_t x, int32_t y, int32_t user)
+{
+    uint32_t hash = hash_init();
+    hash          = hash_combine(hash, (uint32_t)sample);
+    hash          = hash_combine(hash, (uint32_t)iter);
+    hash          = hash_combine(hash, (uint32_t)frame);
+    hash          = hash_combine(hash, (uint32_t)x);
+    hash          = hash_combine(hash, (uint32_t)y);
+    hash          = hash_combine(hash, (uint32_t)user);
+    return hash;
+}
+
+// random.art:45-87
+struct Rng {
+    uint32_t seed;
+    uint32_t counter;
+    uint32_t next_u32() { return sample_tea_u32(seed, counter++); }
+    float next_f32()
+    {
+        const uint32_t x = next_u32();
+        return igm_float((x & 0x7FFFFFu) | 0x3F800000u) - 1;
+    }
+    // next_i32(s, e), inclusive range, rejection sampling (random.art:46-61)
+    int32_t next_i32(int32_t s, int32_t e)
+    {
+        const uint32_t range     = (uint32_t)(e - s);
+        const uint32_t rng_range = 0xFFFFFFFFu;
+        if (rng_range == range)
+            return (int32_t)next_u32() + s;
+        const uint32_t erange  = range + 1;
+        const uint32_t scaling = rng_range / erange;
+        const uint32_t past    = erange * scaling;
+        uint32_t ret           = next_u32();
+        while (ret >= past)
+            ret = next_u32();
+        return (int32_t)(ret / scaling) + s;
+    }
+};
+
+// ---- camera/perspective.art + driver/camera.art + driver/emitter.art
+struct CameraSetup {
+    Vec3 eye;
+    Mat3x3 view; // right, up, dir
+    float sx, sy;
+    float tmin, tmax;
+};
+
+// make_perspective_camera (perspective.art:29-42); the scale comes from the host:
+// compute_scale_from_hfov / _vfov (perspective.art:2-13) evaluated with libm tanf.
+static inline CameraSetup make_camera(const ig_camera& c, float sx, float sy)
+{
+    CameraSetup s;
+    s.eye          = Vec3{ c.eye[0], c.eye[1], c.eye[2] };
+    const Vec3 dir = Vec3{ c.dir[0], c.dir[1], c.dir[2] };
+    const Vec3 up  = Vec3{ c.up[0], c.up[1], c.up[2] };
+    s.view.col[0]  = vec3_normalize(vec3_cross(dir, up));
+    s.view.col[1]  = up;
+    s.view.col[2]  = dir;
+    s.sx           = sx;
+    s.sy           = sy;
+    s.tmin         = c.near_clip;
+    s.tmax         = c.far_clip;
+    return s;
+}
+
+// make_camera_emitter (emitter.art:6-16) + make_uniform_pixel_sampler (pixel_sampler.art:4-10)
+// + make_pixelcoord_from_xy (camera.art:21-29) + generate_ray (perspective.art:37-42)
+static inline Ray generate_camera_ray(const CameraSetup& cam, Rng& rnd, int x, int y, int w, int h)
+{
+    const float rx = rnd.next_f32();
+    const float ry = rnd.next_f32();
+    const float nx = 2 * ((float)x + rx) / ((float)w) - 1;
+    const float ny = 1 - 2 * ((float)y + ry) / ((float)h);
+    const Vec3 d   = vec3_normalize(mat3x3_mul(cam.view, make_vec3(cam.sx * nx, cam.sy * ny, 1)));
+    return make_ray(cam.eye, d, cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+}
+
+// ---- driver/entity.art:12-28
+struct Entity {
+    Mat3x4 local_mat, global_mat;
+    Mat3x3 normal_mat;
+    int32_t shape_id, mat_id;
+};
+
+static inline Entity load_entity(const igd_scene& sc, int32_t id)
+{
+    const float* d = sc.entities + (size_t)id * IG_ENTITY_FLOATS;
+    Entity e;
+    for (int c = 0; c < 4; ++c) {
+        e.local_mat.col[c]  = Vec3{ d[c * 3], d[c * 3 + 1], d[c * 3 + 2] };
+        e.global_mat.col[c] = Vec3{ d[12 + c * 3], d[12 + c * 3 + 1], d[12 + c * 3 + 2] };
+    }
+    for (int c = 0; c < 3; ++c)
+        e.normal_mat.col[c] = Vec3{ d[24 + c * 3], d[24 + c * 3 + 1], d[24 + c * 3 + 2] };
+    std::memcpy(&e.shape_id, d + 33, 4);
+    std::memcpy(&e.mat_id, d + 34, 4);
+    return e;
+}
+
+// ---- shapes/trimesh.art:76-103 (make_trimesh_from_buffer / load_trimesh)
+struct TriMeshView {
+    const float* vertices;  // 4 floats each
+    const float* normals;   // 4 floats each
+    const int32_t* indices; // 4 ints each
+    const float* texcoords; // 2 floats each
+    int32_t num_tris;
+};
+
+static inline TriMeshView load_trimesh(const igd_scene& sc, int32_t shape_id)
+{
+    const uint8_t* base = sc.shape_data + sc.shape_lookups[shape_id].offset;
+    int32_t hdr[4];
+    std::memcpy(hdr, base, 16);
+    const float* f = reinterpret_cast<const float*>(base);
+    TriMeshView m;
+    const int v_start   = 12;
+    const int n_start   = v_start + hdr[1] * 4;
+    const int ind_start = n_start + hdr[2] * 4;
+    const int tex_start = ind_start + hdr[0] * 4;
+    m.vertices  = f + v_start;
+    m.normals   = f + n_start;
+    m.indices   = reinterpret_cast<const int32_t*>(f + ind_start);
+    m.texcoords = f + tex_start;
+    m.num_tris  = hdr[0];
+    return m;
+}
+
+// ---- driver/surface_element.art
+struct SurfaceElement {
+    bool is_entering;
+    Vec3 point, face_normal;
+    float area, inv_area;
+    Vec2 prim_coords, tex_coords;
+    Mat3x3 local;
+};
+
+// core/triangle.art:31-44
+static inline Vec3 compute_stable_triangle_normal(Vec3 e1, Vec3 e2, Vec3 e3)
+{
+    const float x12 = e1.z * e2.y, y12 = e1.x * e2.z, z12 = e1.y * e2.x;
+    const float x23 = e2.z * e3.y, y23 = e2.x * e3.z, z23 = e2.y * e3.x;
+    const Vec3 c12  = make_vec3(e1.y * e2.z - x12, e1.z * e2.x - y12, e1.x * e2.y - z12);
+    const Vec3 c23  = make_vec3(e2.y * e3.z - x23, e2.z * e3.x - y23, e2.x * e3.y - z23);
+    return make_vec3(igm_abs(x12) < igm_abs(x23) ? c12.x : c23.x,
+                     igm_abs(y12) < igm_abs(y23) ? c12.y : c23.y,
+                     igm_abs(z12) < igm_abs(z23) ? c12.z : c23.z);
+}
+
+// make_trimesh_shape.surface_element (trimesh.art:14-40) with
+// make_standard_pointmapperset (pointmapper.art:28-36) and make_triangle (triangle.art:12-29)
+static inline SurfaceElement surface_element(const igd_scene& sc, const Entity& entity, const Ray& ray, const Hit& hit)
+{
+    const TriMeshView mesh = load_trimesh(sc, entity.shape_id);
+    const int32_t i0 = mesh.indices[hit.prim_id * 4 + 0], i1 = mesh.indices[hit.prim_id * 4 + 1], i2 = mesh.indices[hit.prim_id * 4 + 2];
+    auto vtx = [&](int32_t i) { return Vec3{ mesh.vertices[i * 4], mesh.vertices[i * 4 + 1], mesh.vertices[i * 4 + 2] }; };
+    auto nrm = [&](int32_t i) { return Vec3{ mesh.normals[i * 4], mesh.normals[i * 4 + 1], mesh.normals[i * 4 + 2] }; };
+    auto tex = [&](int32_t i) { return Vec2{ mesh.texcoords[i * 2], mesh.texcoords[i * 2 + 1] }; };
+
+    const Vec3 v0 = mat3x4_transform_point(entity.global_mat, vtx(i0));
+    const Vec3 v1 = mat3x4_transform_point(entity.global_mat, vtx(i1));
+    const Vec3 v2 = mat3x4_transform_point(entity.global_mat, vtx(i2));
+    const Vec3 e1 = vec3_sub(v2, v0);
+    const Vec3 e2 = vec3_sub(v0, v1);
+    const Vec3 e3 = vec3_sub(v1, v2);
+    const Vec3 n  = compute_stable_triangle_normal(e1, e2, e3);
+    const float nn          = vec3_len(n);
+    const Vec3 face_normal  = vec3_mulf(n, 1 / nn);
+    const float area        = nn / 2;
+    const Vec3 normal       = vec3_normalize(mat3x3_mul(entity.normal_mat, vec3_lerp2(nrm(i0), nrm(i1), nrm(i2), hit.u, hit.v)));
+    const bool is_entering  = vec3_dot(ray.dir, face_normal) <= 0;
+    const Vec2 tex_coords   = vec2_lerp2(tex(i0), tex(i1), tex(i2), hit.u, hit.v);
+
+    SurfaceElement s;
+    s.is_entering = is_entering;
+    s.point       = vec3_add(ray.org, vec3_mulf(ray.dir, hit.distance));
+    s.face_normal = is_entering ? face_normal : vec3_neg(face_normal);
+    s.area        = area;
+    s.inv_area    = safe_div(1, area);
+    s.prim_coords = Vec2{ hit.u, hit.v };
+    s.tex_coords  = tex_coords;
+    s.local       = make_orthonormal_mat3x3(is_entering ? normal : vec3_neg(normal));
+    return s;
+}
+
+// ---- colours (core/color.art:14-36)
+static inline Color color_mul(Color a, Color b) { return Color{ a.r * b.r, a.g * b.g, a.b * b.b }; }
+static inline Color color_mulf(Color c, float f) { return Color{ c.r * f, c.g * f, c.b * f }; }
+static inline float color_average(Color c) { return (c.r + c.g + c.b) / 3; }
+static inline float color_max_component(Color c) { return igm_max(c.r, igm_max(c.g, c.b)); } // vec3_max_value, vector.art:38,113
+static inline Color color_saturate(Color a, float f) { return Color{ igm_min(a.r, f), igm_min(a.g, f), igm_min(a.b, f) }; }
+
+// ---- core/sampling.art:12-20,62-70
+struct DirSample {
+    Vec3 dir;
+    float pdf;
+};
+static inline float cosine_hemisphere_pdf(float c) { return c / flt_pi; }
+static inline DirSample sample_cosine_hemisphere(float u, float v)
+{
+    const float c   = safe_sqrt(v);
+    const float s   = safe_sqrt(1 - v);
+    const float phi = 2 * flt_pi * u;
+    DirSample d;
+    d.dir = make_vec3(s * igm_cos(phi), s * igm_sin(phi), c);
+    d.pdf = cosine_hemisphere_pdf(c);
+    return d;
+}
+static inline float positive_cos(Vec3 a, Vec3 b)
+{
+    const float c = vec3_dot(a, b);
+    return c >= 0 ? c : 0.0f;
+} // common.art:292-295
+
+// ---- core/fresnel.art:7-27
+static inline float fresnel_factor(float eta, float cos_i, float cos_t)
+{
+    const float R_s = safe_div(eta * cos_i - cos_t, eta * cos_i + cos_t);
+    const float R_p = safe_div(cos_i - eta * cos_t, cos_i + eta * cos_t);
+    return clampf((R_s * R_s + R_p * R_p) * 0.5f, 0, 1);
+}
+static inline float snell(float eta, float cos_i) { return 1 - (1 - cos_i * cos_i) * eta * eta; }
+static inline bool fresnel(float eta, float cos_i, float& cos_t_out, float& factor)
+{
+    const float eta2   = cos_i < 0 ? 1 / eta : eta;
+    const float cos2_t = snell(eta2, cos_i);
+    if (cos2_t <= 0.0f)
+        return false;
+    const float cos_t = igm_sqrt(cos2_t);
+    cos_t_out         = cos_i < 0 ? -cos_t : cos_t;
+    factor            = fresnel_factor(eta2, igm_abs(cos_i), cos_t);
+    return true;
+}
+
+// ---- BSDFs (driver/bsdf.art)
+struct BsdfSample {
+    Vec3 in_dir;
+    float pdf;
+    Color color;
+    float eta;
+    bool is_delta;
+};
+
+struct Bsdf {
+    const ig_material* mat;
+    const SurfaceElement* surf;
+
+    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
+
+    // make_lambertian_bsdf (bsdf/diffuse.art:2-13); delta BSDFs evaluate to black (dielectric.art:16-17)
+    Color eval(Vec3 in_dir, Vec3 /*out_dir*/) const
+    {
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+            const Color kd = Color{ mat->p[0], mat->p[1], mat->p[2] };
+            return color_mulf(kd, positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
+        }
+        return Color{ 0, 0, 0 };
+    }
+    float pdf(Vec3 in_dir, Vec3 /*out_dir*/) const
+    {
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+            return cosine_hemisphere_pdf(positive_cos(in_dir, surf->local.col[2]));
+        return 0;
+    }
+    bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+            const float u      = rnd.next_f32();
+            const float v      = rnd.next_f32();
+            const DirSample ds = sample_cosine_hemisphere(u, v);
+            s.in_dir           = mat3x3_mul(surf->local, ds.dir);
+            s.pdf              = ds.pdf;
+            s.color            = Color{ mat->p[0], mat->p[1], mat->p[2] };
+            s.eta              = 1;
+            s.is_delta         = false;
+            return true;
+        }
+        // make_pure_dielectric_bsdf (bsdf/dielectric.art:15-37); n1 = ext_ior, n2 = int_ior
+        // (runtime/bsdf/DielectricBSDF.cpp:31-38)
+        const float n1 = mat->p[0], n2 = mat->p[1];
+        const Color ks = Color{ mat->p[2], mat->p[3], mat->p[4] };
+        const Color kt = Color{ mat->p[5], mat->p[6], mat->p[7] };
+        const float k  = surf->is_entering ? n1 / n2 : n2 / n1;
+        const Vec3 n   = surf->local.col[2];
+        const float cos_o = vec3_dot(out_dir, n);
+        float cos_t = 0, factor = 1;
+        if (!fresnel(k, cos_o, cos_t, factor)) {
+            cos_t  = 0;
+            factor = 1;
+        }
+        if (rnd.next_f32() > factor) {
+            s.in_dir = vec3_refract(out_dir, n, k, cos_o, cos_t);
+            s.pdf    = 1;
+            s.color  = color_mulf(kt, 1); // adjoint = false
+            s.eta    = k;
+        } else {
+            s.in_dir = vec3_reflect(out_dir, n);
+            s.pdf    = 1;
+            s.color  = ks;
+            s.eta    = 1;
+        }
+        s.is_delta = true;
+        return true;
+    }
+};
+
+// ---- lights
+struct DirectLightSample {
+    Vec3 pos, dir;
+    Color intensity;
+    float pdf_value;
+    bool pdf_is_area; // make_area_pdf vs make_solid_pdf (driver/pdf.art:24-38)
+    bool pdf_is_delta;
+    float cos, dist;
+};
+
+struct SQ {
+    Vec3 o, n;
+    float x0, y0, z0, x1, y1, b0, b1, k, s;
+};
+
+// make_plane_area_emitter (light/area.art:124-257), parameters from the
+// "SimplePlaneLight" record (area.art:416-440)
+struct PlaneEmitter {
+    Vec3 origin, x_axis, y_axis, normal;
+    float area, inv_area, width, height;
+    Vec3 ex, ey;
+    Vec2 t0, t1, t2, t3;
+    Color radiance;
+
+    explicit PlaneEmitter(const ig_light& l)
+    {
+        const float* d = l.d;
+        origin   = Vec3{ d[0], d[1], d[2] };
+        x_axis   = Vec3{ d[4], d[5], d[6] };
+        y_axis   = Vec3{ d[8], d[9], d[10] };
+        normal   = Vec3{ d[3], d[7], d[11] };
+        t0       = Vec2{ d[12], d[13] };
+        t1       = Vec2{ d[14], d[15] };
+        t2       = Vec2{ d[16], d[17] };
+        t3       = Vec2{ d[18], d[19] };
+        radiance = Color{ d[20], d[21], d[22] };
+        area     = d[23];
+        inv_area = safe_div(1, area);
+        width    = vec3_len(x_axis);
+        height   = vec3_len(y_axis);
+        ex       = vec3_mulf(x_axis, 1 / width);
+        ey       = vec3_mulf(y_axis, 1 / height);
+    }
+
+    static float safe_acos(float a) { return igm_acos(clampf(a, -1, 1)); }
+
+    // area.art:133-181
+    SQ compute_sq(Vec3 from_point) const
+    {
+        const Vec3 dir  = vec3_sub(origin, from_point);
+        const float x0  = vec3_dot(dir, ex);
+        const float y0  = vec3_dot(dir, ey);
+        const float z0_ = vec3_dot(dir, normal);
+        const float x1  = x0 + width;
+        const float y1  = y0 + height;
+
+        const bool pos = !igm_signbit(z0_);
+        const float z0 = pos ? -z0_ : z0_;
+        const Vec3 n   = pos ? vec3_neg(normal) : normal;
+
+        const float diff[4] = { x0 - x1, y1 - y0, x1 - x0, y0 - y1 };
+        const float nzi[4]  = { y0 * diff[0], x1 * diff[1], y1 * diff[2], x0 * diff[3] };
+        float nz[4];
+        for (int i = 0; i < 4; ++i)
+            nz[i] = nzi[i] / igm_sqrt((diff[i] * diff[i]) * (z0 * z0) + nzi[i] * nzi[i]);
+
+        const float g0 = safe_acos(-nz[0] * nz[1]);
+        const float g1 = safe_acos(-nz[1] * nz[2]);
+        const float g2 = safe_acos(-nz[2] * nz[3]);
+        const float g3 = safe_acos(-nz[3] * nz[0]);
+
+        SQ sq;
+        sq.o  = from_point;
+        sq.n  = n;
+        sq.x0 = x0;
+        sq.y0 = y0;
+        sq.z0 = z0;
+        sq.x1 = x1;
+        sq.y1 = y1;
+        sq.b0 = nz[0];
+        sq.b1 = nz[2];
+        sq.k  = 2 * flt_pi - g2 - g3;
+        sq.s  = g0 + g1 - sq.k;
+        return sq;
+    }
+
+    // area.art:183-222; returns the sampled point, solid-angle pdf and weight
+    void sample_direct(Vec2 uv, Vec3 from_point, Vec3& p, float& pdf_s, float& weight) const
+    {
+        const SQ sq = compute_sq(from_point);
+
+        const float au = igm_fma(uv.x, sq.s, sq.k);
+        const float fu = igm_fma(igm_cos(au), sq.b0, -sq.b1) / igm_sin(au);
+        const float cu = clampf(igm_copysign(1.0f, fu) / igm_sqrt(sum_of_prod(fu, fu, sq.b0, sq.b0)), -1, 1);
+
+        const float xu = clampf(-(cu * sq.z0) / igm_sqrt(igm_fma(-cu, cu, 1.0f)), sq.x0, sq.x1);
+
+        const float d   = igm_sqrt(sum_of_prod(xu, xu, sq.z0, sq.z0));
+        const float h0  = sq.y0 / igm_sqrt(sum_of_prod(d, d, sq.y0, sq.y0));
+        const float h1  = sq.y1 / igm_sqrt(sum_of_prod(d, d, sq.y1, sq.y1));
+        const float hv  = igm_fma(uv.y, h1 - h0, h0);
+        const float hv2 = hv * hv;
+        const float yv  = (hv2 < 1 - 1e-6f) ? (hv * d) / igm_sqrt(1 - hv2) : sq.y1;
+
+        p      = vec3_add(sq.o, vec3_add(vec3_mulf(ex, xu), vec3_add(vec3_mulf(ey, yv), vec3_mulf(sq.n, sq.z0))));
+        pdf_s  = safe_div(1, sq.s);
+        weight = sq.s;
+    }
+
+    float pdf_direct(Vec3 from_point) const { return safe_div(1, compute_sq(from_point).s); } // area.art:224-228
+};
+
+// make_area_light.sample_direct (light/area.art:10-26) over the plane emitter
+static inline DirectLightSample sample_direct_plane(const ig_light& l, Rng& rnd, const SurfaceElement& from_surf)
+{
+    const PlaneEmitter pe(l);
+    Vec2 uv;
+    uv.x = rnd.next_f32();
+    uv.y = rnd.next_f32();
+    Vec3 p;
+    float pdf_s, weight;
+    pe.sample_direct(uv, from_surf.point, p, pdf_s, weight);
+    const Vec3 dir_  = vec3_sub(p, from_surf.point);
+    const float dist = vec3_len(dir_);
+    const Vec3 dir   = vec3_mulf(dir_, safe_div(1, dist));
+    const float cos  = vec3_dot(dir, pe.normal) * (from_surf.is_entering ? -1.0f : 1.0f);
+    DirectLightSample s;
+    s.pos          = p;
+    s.dir          = dir;
+    s.intensity    = color_mulf(pe.radiance, weight);
+    s.pdf_value    = pdf_s;
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = false;
+    s.cos          = cos;
+    s.dist         = dist;
+    return s;
+}
+
+// make_point_light.sample_direct (light/point.art:3-8)
+static inline DirectLightSample sample_direct_point(const ig_light& l, const SurfaceElement& from_surf)
+{
+    const Vec3 pos   = Vec3{ l.d[0], l.d[1], l.d[2] };
+    const Vec3 dir_  = vec3_sub(pos, from_surf.point);
+    const float dist = vec3_len(dir_);
+    DirectLightSample s;
+    s.pos          = pos;
+    s.dir          = vec3_mulf(dir_, safe_div(1, dist));
+    s.intensity    = Color{ l.d[4], l.d[5], l.d[6] };
+    s.pdf_value    = 1;
+    s.pdf_is_area  = true;
+    s.pdf_is_delta = false;
+    s.cos          = 1;
+    s.dist         = dist;
+    return s;
+}
+
+// pdf.as_solid (driver/pdf.art:19-45)
+static inline float pdf_as_solid(float value, bool is_area, float cos, float dist2) { return is_area ? value * dist2 / cos : value; }
+
+// ---- technique/pathtracer.art
+struct PTRayPayload {
+    float inv_pdf;
+    Color contrib;
+    int32_t depth;
+    float eta;
+};
+
+static inline float russian_roulette_pbrt(Color c, float clamp) { return clampf(color_max_component(c), 0.05f, clamp); } // pathtracer.art:5
+
+struct ShadowRayOut {
+    bool valid;
+    Ray ray;
+    Color color;
+};
+
+struct PathTracer {
+    const igd_scene& sc;
+    int32_t max_path_len, min_path_len;
+    float clamp_value;
+    bool enable_nee;
+    static constexpr float offset = 0.001f;
+
+    explicit PathTracer(const igd_scene& s)
+        : sc(s)
+        , max_path_len(s.technique.max_depth)
+        , min_path_len(s.technique.min_depth)
+        , clamp_value(s.technique.clamp)
+        , enable_nee(s.technique.nee != 0)
+    {
+    }
+
+    Color handle_color(Color c) const { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; }
+
+    // make_uniform_light_selector (light/light_selector.art:26-46)
+    float light_select_pdf() const { return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count; }
+    int pick_light_id(Rng& rnd) const { return sc.light_count <= 1 ? 0 : rnd.next_i32(0, (int32_t)sc.light_count - 1); }
+
+    // on_shadow (pathtracer.art:52-117)
+    ShadowRayOut on_shadow(const Ray& ray, const SurfaceElement& surf, Rng& rnd, const PTRayPayload& pt, const Bsdf& bsdf) const
+    {
+        ShadowRayOut out;
+        out.valid = false;
+        if (!enable_nee)
+            return out;
+        if (bsdf.is_all_delta() || sc.light_count == 0)
+            return out;
+        if (pt.depth + 1 > max_path_len)
+            return out;
+
+        const int id                 = pick_light_id(rnd);
+        const float light_select_pdf = this->light_select_pdf();
+        const ig_light& light        = sc.lights[id];
+
+        DirectLightSample ls;
+        bool delta = false, infinite = false;
+        switch (light.type) {
+        case IG_LIGHT_PLANE:
+            ls = sample_direct_plane(light, rnd, surf);
+            break;
+        case IG_LIGHT_POINT:
+            ls    = sample_direct_point(light, surf);
+            delta = true;
+            break;
+        default:
+            return out; // constant env NEE is lowered in a later round
+        }
+
+        const float pdf_l_s = pdf_as_solid(ls.pdf_value, ls.pdf_is_area, ls.cos, ls.dist * ls.dist) * light_select_pdf;
+        if (pdf_l_s <= flt_eps)
+            return out;
+
+        const Vec3 in_dir  = ls.dir;
+        const Vec3 out_dir = vec3_neg(ray.dir);
+
+        if (ls.cos > flt_eps) {
+            float mis;
+            if (delta) {
+                mis = 1;
+            } else {
+                const float pdf_e_s = bsdf.pdf(in_dir, out_dir);
+                mis                 = 1 / (1 + pdf_e_s / pdf_l_s);
+            }
+            const float factor  = ls.pdf_value / pdf_l_s;
+            const Color contrib = handle_color(color_mulf(color_mul(ls.intensity, color_mul(pt.contrib, bsdf.eval(in_dir, out_dir))), mis * factor));
+            if (color_average(contrib) <= flt_eps)
+                return out;
+
+            out.valid = true;
+            out.color = contrib;
+            if (infinite)
+                out.ray = make_ray(surf.point, in_dir, offset, flt_max, IG_RAY_FLAG_SHADOW);
+            else
+                out.ray = make_ray(surf.point, vec3_sub(ls.pos, surf.point), offset, 1 - offset, IG_RAY_FLAG_SHADOW);
+        }
+        return out;
+    }
+
+    // on_hit (pathtracer.art:119-139) with make_emissive_material (driver/material.art:22-30)
+    bool on_hit(const Ray& ray, const Hit& hit, const SurfaceElement& surf, const PTRayPayload& pt, const ig_material& mat, Color& out) const
+    {
+        if (mat.light_id >= 0 && surf.is_entering) {
+            const float dot = -vec3_dot(ray.dir, surf.local.col[2]);
+            if (dot > flt_eps) {
+                const ig_light& light = sc.lights[mat.light_id];
+                const PlaneEmitter pe(light);
+                const Color emit  = pe.radiance;                 // light.emission(ctx)
+                const float pdf_s = pe.pdf_direct(ray.org);      // solid-angle pdf: as_solid is the identity
+                (void)hit;
+                const float mis     = enable_nee ? 1 / (1 + pt.inv_pdf * light_select_pdf() * pdf_s) : 1.0f;
+                out                 = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
+                return true;
+            }
+        }
+        return false;
+    }
+
+    // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
+    bool on_miss(const PTRayPayload& pt, Color& out) const
+    {
+        int inflights = 0;
+        Color color   = Color{ 0, 0, 0 };
+        for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
+            const ig_light& light = sc.lights[i];
+            if (light.type != IG_LIGHT_ENV)
+                continue;
+            ++inflights;
+            const Color emit  = Color{ light.d[0], light.d[1], light.d[2] };
+            const float pdf_s = 1 / (4 * flt_pi); // uniform sphere pdf of a constant environment
+            const float mis   = enable_nee ? 1 / (1 + pt.inv_pdf * light_select_pdf() * pdf_s) : 1.0f;
+            const Color c     = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
+            color             = Color{ color.r + c.r, color.g + c.g, color.b + c.b };
+        }
+        if (inflights > 0) {
+            out = color;
+            return true;
+        }
+        return false;
+    }
+
+    // on_bounce (pathtracer.art:170-210)
+    bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, Ray& new_ray) const
+    {
+        if (pt.depth + 1 > max_path_len)
+            return false;
+
+        const Vec3 out_dir = vec3_neg(ray.dir);
+        BsdfSample ms;
+        if (!bsdf.sample(rnd, out_dir, ms))
+            return false;
+        if (ms.pdf <= flt_eps)
+            return false;
+
+        const Color contrib = color_mul(pt.contrib, ms.color);
+        const float rr_prob = (pt.depth + 1 > min_path_len) ? russian_roulette_pbrt(color_mulf(contrib, pt.eta * pt.eta), 0.95f) : 1.0f;
+        if (rnd.next_f32() >= rr_prob)
+            return false;
+
+        const float inv_pdf     = ms.is_delta ? 0 : 1 / ms.pdf;
+        const Color new_contrib = color_mulf(contrib, 1 / rr_prob);
+
+        pt.inv_pdf = inv_pdf;
+        pt.contrib = new_contrib;
+        pt.depth   = pt.depth + 1;
+        pt.eta     = pt.eta * ms.eta;
+        new_ray    = make_ray(surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+        return true;
+    }
+};
+
+} // namespace oracle
