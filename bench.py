@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric for the Ignis hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one render iteration (Runtime::step, src/runtime/Runtime.cpp:334-387) of the workload
+BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path integrator,
+spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region.
+With N > 1 the film is tile-sharded (rank r renders rows r, r+N, ...) and the
+framebuffers are reduced to rank 0 over RCCL once, inside the timed region (strong scaling).
+
+Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts
+them (src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the
+roofline of the dominant kernel (closest-hit traversal) and the CPU baseline (oracle) on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPI, SEED = 1920, 1080, 8, 1
+SCENE = os.path.join(ROOT, "scenes", "diamond_scene.json")
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spi", type=int, default=SPI)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n_rays, nodes, tris, leaves):
+    """SURVEY.md 8(d) with this backend's layouts: 60 B per closest-hit ray (40 B read + 20 B hit
+    written) + 256 B per Node8 fetched + 52 B per triangle tested (a 208 B Tri4 packet holds 4)
+    + 96 B per EntityLeaf1 tested."""
+    return 60 * n_rays + 256 * nodes + 52 * tris + 96 * leaves
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime and RCCL are the ones every library in this process binds to
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from ignis_amd import Device, LoadedScene
+
+    W, H, spi = args.width, args.height, args.spi
+    scene = LoadedScene.from_file(SCENE, W, H)
+    dev = Device(local_rank, acquire_stats=1)
+    dev.assign_scene(scene)
+    dev.resize(W, H)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(it):
+        dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=world)
+
+    for it in range(args.warmup):
+        step(it)
+    dev.clear_framebuffer()
+    dev.reset_stats()
+
+    fb_tensor = None
+    if dist is not None:
+        class _Wrap:  # zero-copy view of the device framebuffer for RCCL
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+        fb_tensor = torch.as_tensor(_Wrap(dev.framebuffer_device_ptr(), (H, W, 3)), device=torch.device("cuda", local_rank))
+
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(it)  # igd_render is blocking: the stream is drained when it returns
+    if dist is not None:
+        # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
+        # a rank does not own are zero)
+        dist.reduce(fb_tensor, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = dev.stats()
+    rays_local = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    samples_local = st["camera_rays"]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rays_local, samples_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rays_total, samples_total = float(c[0].item()), float(c[1].item())
+    else:
+        rays_total, samples_total = float(rays_local), float(samples_local)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's launches
+        launches = max(1, st["traverse_primary_launches"])
+        avg_ms = st["ms_traverse_primary"] / launches
+        # units per launch: replay the same steps with the work counters on (deterministic workload)
+        cdev = Device(local_rank, acquire_stats=2)
+        cdev.assign_scene(scene)
+        cdev.resize(W, H)
+        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank, row_stride=world)
+        cs = cdev.stats()
+        cdev.close()
+        n_primary = cs["camera_rays"] + cs["bounce_rays"]
+        a_bytes = algorithmic_bytes(n_primary, cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"])
+        a_per_launch = a_bytes / max(1, cs["traverse_primary_launches"])
+        achieved = a_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                    "algorithmic_bytes_per_launch": int(a_per_launch)}
+
+        stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_resolve")}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            cw, ch = W, H
+            t1 = time.perf_counter()
+            _, os_ = oracle.render(scene, spi, cw, ch, iteration=0, seed=SEED)
+            dt = time.perf_counter() - t1
+            cpu_rays = os_["camera_rays"] + os_["bounce_rays"] + os_["shadow_rays"]
+            cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(os_["threads_used"]), "kind": "port",
+                   "sample": f"1 iteration of diamond_scene {cw}x{ch} spi {spi} (oracle/, CPU restatement, not the AnyDSL binary)",
+                   "msamples_per_s": round(os_["camera_rays"] / dt / 1e6, 3), "seconds": round(dt, 2)}
+
+        out = {
+            "metric": "Mrays/s (primary+shadow)",
+            "value": round(rays_total / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"scenes/diamond_scene.json {W}x{H}, path integrator, spi {spi} x {args.steps} iterations, seed {SEED}",
+                       "sharding": "whole film" if world == 1 else f"rows interleaved over {world} GPUs + one RCCL reduce"},
+            "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
+            "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},
+            "stage_ms_rank0": stage_ms,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,845 @@
+// device.hip — host side of the MI355X render device and its C ABI (include/igd_device.h).
+//
+// Counterpart of src/device/Device.cpp: owns HBM (scene tables, SoA ray streams, per-sample
+// accumulators, framebuffer), uploads the scene once, and drives the wavefront loop of
+// `gpu_trace` (src/artic/driver/mapping_gpu.art:727-867). Differences that are the point of the
+// MI355X design: queue sizes stay in HBM (no D2H/H2D per stage), each bounce round is
+// traverse -> shade -> shadow-traverse (3 persistent kernels + 2 one-thread bookkeeping kernels
+// instead of >= 8 + M launches with >= 5 host syncs), and the streams are sized for a whole
+// iteration in flight (288 GB HBM) instead of 1 M rays.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <memory>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "igd_device.h"
+#include "kernels.h"
+
+namespace igdev {
+void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream);
+void launch_generate(const GenerateArgs& args, hipStream_t stream);
+void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
+void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
+void launch_secondary_end(QueueState* qs, hipStream_t stream);
+void launch_resolve(const ResolveArgs& args, hipStream_t stream);
+} // namespace igdev
+
+using namespace igdev;
+
+static thread_local std::string g_error;
+
+namespace {
+
+struct HipError {
+    int code;
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess)                                                                                    \
+            throw HipError{ _e == hipErrorOutOfMemory ? IGD_ERR_OUT_OF_MEMORY : IGD_ERR_DEVICE,                  \
+                            std::string(#expr) + ": " + hipGetErrorString(_e) };                                 \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* ptr       = nullptr;
+    size_t count = 0;
+    void alloc(size_t n)
+    {
+        if (n <= count && ptr)
+            return;
+        release();
+        if (n == 0)
+            return;
+        HIP_CHECK(hipMalloc(&ptr, n * sizeof(T)));
+        count = n;
+    }
+    void upload(const T* src, size_t n)
+    {
+        alloc(n);
+        if (n)
+            HIP_CHECK(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr   = nullptr;
+        count = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+constexpr int kPrimaryCols   = 22;
+constexpr int kSecondaryCols = 12;
+
+} // namespace
+
+struct igd_device {
+    igd_setup setup{};
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+
+    // scene
+    bool has_scene = false;
+    DevBuf<uint8_t> geom, shape_data;
+    DevBuf<ig_entity_leaf1> leaves;
+    DevBuf<uint2> leaf_ext;
+    DevBuf<float> entities;
+    DevBuf<uint64_t> shape_offsets;
+    DevBuf<ig_material> materials;
+    DevBuf<int32_t> entity_material;
+    DevBuf<ig_light> lights;
+    DevScene dscene{};
+    ig_camera camera{};
+
+    // streams
+    size_t capacity = 0;
+    DevBuf<float> primary[2], secondary, accum;
+    DevBuf<QueueState> qs;
+    DevBuf<float> list_rays;
+
+    // framebuffer
+    int fb_w = 0, fb_h = 0;
+    DevBuf<float> fb;
+    std::vector<float> fb_host;
+    bool fb_host_dirty = true;
+
+    // statistics
+    igd_stats stats{};
+    std::vector<hipEvent_t> events;
+
+    ~igd_device()
+    {
+        for (auto e : events)
+            (void)hipEventDestroy(e);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+
+    PrimaryCols primaryCols(int slot) const
+    {
+        float* b       = primary[slot].ptr;
+        const size_t c = capacity;
+        PrimaryCols p;
+        p.id      = reinterpret_cast<int32_t*>(b + 0 * c);
+        p.ox      = b + 1 * c, p.oy = b + 2 * c, p.oz = b + 3 * c;
+        p.dx      = b + 4 * c, p.dy = b + 5 * c, p.dz = b + 6 * c;
+        p.tmin    = b + 7 * c, p.tmax = b + 8 * c;
+        p.flags   = reinterpret_cast<uint32_t*>(b + 9 * c);
+        p.ent_id  = reinterpret_cast<int32_t*>(b + 10 * c);
+        p.prim_id = reinterpret_cast<int32_t*>(b + 11 * c);
+        p.t       = b + 12 * c, p.u = b + 13 * c, p.v = b + 14 * c;
+        p.rnd     = reinterpret_cast<uint32_t*>(b + 15 * c);
+        for (int k = 0; k < 6; ++k)
+            p.payload[k] = b + (size_t)(16 + k) * c;
+        return p;
+    }
+
+    SecondaryCols secondaryCols() const
+    {
+        float* b       = secondary.ptr;
+        const size_t c = capacity;
+        SecondaryCols s;
+        s.id   = reinterpret_cast<int32_t*>(b);
+        s.ox   = b + 1 * c, s.oy = b + 2 * c, s.oz = b + 3 * c;
+        s.dx   = b + 4 * c, s.dy = b + 5 * c, s.dz = b + 6 * c;
+        s.tmin = b + 7 * c, s.tmax = b + 8 * c;
+        s.cr   = b + 9 * c, s.cg = b + 10 * c, s.cb = b + 11 * c;
+        return s;
+    }
+
+    void ensureStreams(size_t needed)
+    {
+        size_t cap = setup.stream_capacity ? (size_t)setup.stream_capacity : ((size_t)1 << 24);
+        cap        = std::min(cap, needed);
+        cap        = (cap + 255) & ~(size_t)255;
+        if (cap <= capacity && primary[0].ptr)
+            return;
+        capacity = cap;
+        for (int s = 0; s < 2; ++s) {
+            primary[s].release();
+            primary[s].alloc(capacity * kPrimaryCols);
+        }
+        secondary.release();
+        secondary.alloc(capacity * kSecondaryCols);
+        accum.release();
+        accum.alloc(capacity * 3);
+    }
+
+    int traverseGrid() const { return num_cus * 2; } // 64 KiB LDS per workgroup -> 2 per CU
+    int shadeGrid() const { return num_cus * 8; }
+
+    hipEvent_t event(size_t i)
+    {
+        while (events.size() <= i) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        return events[i];
+    }
+};
+
+namespace {
+
+int guarded(const char* what, const std::function<void()>& fn);
+
+void assignScene(igd_device* d, const igd_scene* s)
+{
+    if (s->entity_count > 0 && (!s->entities || !s->scene_nodes || !s->scene_leaves || !s->primbvh || !s->shape_data))
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
+    for (uint32_t m = 0; m < s->material_count; ++m) {
+        const ig_material& mat = s->materials[m];
+        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
+        if (mat.flags != 0)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses bump/texture/thin flags the HIP backend cannot shade yet" };
+        if (mat.light_id >= (int32_t)s->light_count)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material light id out of range" };
+        if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only planar area lights can be emissive entities" };
+    }
+    if (s->technique.light_selector != IG_SELECTOR_UNIFORM && s->light_count > 1)
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only the uniform light selector is implemented" };
+
+    // geometry blob: prim BVH fix table, then the scene BVH nodes
+    std::vector<uint8_t> blob(s->primbvh, s->primbvh + s->primbvh_size);
+    blob.resize((blob.size() + 255) & ~(size_t)255);
+    const uint32_t scene_nodes_off = (uint32_t)blob.size();
+    const uint8_t* sn              = reinterpret_cast<const uint8_t*>(s->scene_nodes);
+    blob.insert(blob.end(), sn, sn + (size_t)s->scene_node_count * sizeof(ig_node8));
+    if (blob.size() >= ((size_t)1 << 32))
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: BVH blob exceeds 4 GiB (32-bit node offsets)" };
+    blob.resize(blob.size() + 256); // tail padding: vector loads never run past the allocation
+    d->geom.upload(blob.data(), blob.size());
+
+    // per scene leaf: where its shape's Node8[] / Tri4[] start (EntityLeaf1.user = offset in floats,
+    // shapes/trimesh.art:201-219: header {node_count, tri_count, pad, pad}, nodes, tris)
+    std::vector<uint2> ext(s->scene_leaf_count);
+    for (uint32_t i = 0; i < s->scene_leaf_count; ++i) {
+        const ig_entity_leaf1& l = s->scene_leaves[i];
+        const uint64_t off       = (((uint64_t)(uint32_t)l.user[1] << 32) | (uint64_t)(uint32_t)l.user[0]) * 4;
+        if (off + 16 > s->primbvh_size)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: prim BVH offset out of range" };
+        uint32_t node_count;
+        std::memcpy(&node_count, s->primbvh + off, 4);
+        ext[i] = make_uint2((uint32_t)(off + 16), (uint32_t)(off + 16 + (uint64_t)node_count * sizeof(ig_node8)));
+    }
+    d->leaf_ext.upload(ext.data(), ext.size());
+    d->leaves.upload(s->scene_leaves, s->scene_leaf_count);
+
+    d->entities.upload(s->entities, (size_t)s->entity_count * IG_ENTITY_FLOATS);
+    std::vector<uint8_t> sd(s->shape_data, s->shape_data + s->shape_data_size);
+    sd.resize(sd.size() + 64);
+    d->shape_data.upload(sd.data(), sd.size());
+    std::vector<uint64_t> so(s->shape_count);
+    for (uint32_t i = 0; i < s->shape_count; ++i)
+        so[i] = s->shape_lookups[i].offset;
+    d->shape_offsets.upload(so.data(), so.size());
+    d->materials.upload(s->materials, s->material_count);
+    d->lights.upload(s->lights, s->light_count);
+
+    // material id per entity (entity table word 34, LoaderEntity.cpp:159)
+    std::vector<int32_t> em(s->entity_count);
+    for (uint32_t e = 0; e < s->entity_count; ++e) {
+        std::memcpy(&em[e], s->entities + (size_t)e * IG_ENTITY_FLOATS + 34, 4);
+        if (em[e] < 0 || em[e] >= (int32_t)s->material_count)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: entity material id out of range" };
+    }
+    d->entity_material.upload(em.data(), em.size());
+
+    DevScene& ds            = d->dscene;
+    ds.geom                 = d->geom.ptr;
+    ds.scene_nodes_off      = scene_nodes_off;
+    ds.scene_node_count     = s->scene_node_count;
+    ds.leaves               = d->leaves.ptr;
+    ds.leaf_ext             = d->leaf_ext.ptr;
+    ds.entities             = d->entities.ptr;
+    ds.shape_data           = d->shape_data.ptr;
+    ds.shape_offsets        = d->shape_offsets.ptr;
+    ds.materials            = d->materials.ptr;
+    ds.entity_material      = d->entity_material.ptr;
+    ds.lights               = d->lights.ptr;
+    ds.entity_count         = s->entity_count;
+    ds.material_count       = s->material_count;
+    ds.light_count          = s->light_count;
+    ds.infinite_light_count = s->infinite_light_count;
+    ds.tech                 = s->technique;
+    d->camera               = s->camera;
+    d->has_scene            = true;
+}
+
+void resizeFb(igd_device* d, int w, int h)
+{
+    if (w == d->fb_w && h == d->fb_h && d->fb.ptr)
+        return;
+    d->fb.release();
+    d->fb.alloc((size_t)w * h * 3);
+    HIP_CHECK(hipMemset(d->fb.ptr, 0, (size_t)w * h * 3 * sizeof(float)));
+    d->fb_w = w;
+    d->fb_h = h;
+    d->fb_host.assign((size_t)w * h * 3, 0.0f);
+    d->fb_host_dirty = true;
+}
+
+void readQueueState(igd_device* d, QueueState& out)
+{
+    HIP_CHECK(hipMemcpyAsync(&out, d->qs.ptr, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+}
+
+void render(igd_device* d, const igd_render_settings* rs)
+{
+    if (!d->has_scene)
+        throw HipError{ IGD_ERR_NO_SCENE, "igd_render: no scene assigned" };
+    if (rs->spi <= 0 || rs->width <= 0 || rs->height <= 0)
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: spi, width and height must be positive" };
+    const int row_stride = rs->row_stride > 0 ? rs->row_stride : 1;
+    const int row_offset = rs->row_offset;
+    if (row_offset < 0 || row_offset >= row_stride)
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: row_offset must be in [0, row_stride)" };
+    const bool list_mode = rs->rays != nullptr;
+    if (list_mode && rs->height != 1)
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: ray-list mode expects width = #rays, height = 1" };
+
+    const auto t_start = std::chrono::steady_clock::now();
+    resizeFb(d, rs->width, rs->height);
+
+    const int local_rows = (rs->height - row_offset + row_stride - 1) / row_stride;
+    const int64_t total  = (int64_t)local_rows * rs->width * rs->spi;
+    if (total >= ((int64_t)1 << 31))
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: width * height * spi must stay below 2^31" };
+    d->ensureStreams((size_t)std::max<int64_t>(total, 256));
+
+    if (list_mode)
+        d->list_rays.upload(rs->rays, (size_t)rs->width * 8);
+
+    // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13), aspect = width / height
+    // unless the scene fixes it (PerspectiveCamera.cpp:41-45)
+    float sx, sy;
+    {
+        const float aspect = d->camera.aspect_ratio > 0 ? d->camera.aspect_ratio : (float)rs->width / (float)rs->height;
+        if (d->camera.fov_is_vertical) {
+            sy = std::tan(d->camera.fov / 2);
+            sx = sy * aspect;
+        } else {
+            sx = std::tan(d->camera.fov / 2);
+            sy = sx / aspect;
+        }
+    }
+
+    const bool stats    = d->setup.acquire_stats != 0;
+    const bool counters = d->setup.acquire_stats >= 2;
+    hipStream_t st      = d->stream;
+    QueueState* qs    = d->qs.ptr;
+    const float inv   = 1 / (float)rs->spi;
+    size_t ev         = 0;
+    struct Span {
+        int kind;
+        size_t e0, e1;
+    };
+    std::vector<Span> spans;
+    auto timed = [&](int kind, const std::function<void()>& fn) {
+        if (!stats) {
+            fn();
+            return;
+        }
+        const size_t e0 = ev++, e1 = ev++;
+        HIP_CHECK(hipEventRecord(d->event(e0), st));
+        fn();
+        HIP_CHECK(hipEventRecord(d->event(e1), st));
+        spans.push_back(Span{ kind, e0, e1 });
+    };
+
+    // chunk the iteration's ray ids so that every pixel's samples stay together
+    const int64_t chunk_rays = ((int64_t)d->capacity / rs->spi) * rs->spi;
+    if (chunk_rays <= 0)
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
+
+    QueueState host_qs;
+    HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, camera_rays), st));
+
+    for (int64_t first = 0; first < total; first += chunk_rays) {
+        const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
+        HIP_CHECK(hipMemsetAsync(d->accum.ptr, 0, (size_t)n * 3 * sizeof(float), st));
+
+        int in_slot = 0;
+        GenerateArgs ga{};
+        ga.out            = d->primaryCols(in_slot);
+        ga.out_count      = &qs->primary_count[in_slot];
+        ga.qs             = qs;
+        ga.cam            = d->camera;
+        ga.sx             = sx;
+        ga.sy             = sy;
+        ga.width          = rs->width;
+        ga.height         = rs->height;
+        ga.spi            = rs->spi;
+        ga.iteration      = rs->iteration;
+        ga.frame          = rs->frame;
+        ga.seed           = rs->user_seed;
+        ga.row_offset     = row_offset;
+        ga.row_stride     = row_stride;
+        ga.first_local_id = first;
+        ga.n              = n;
+        ga.list_rays      = list_mode ? d->list_rays.ptr : nullptr;
+        timed(0, [&] { launch_generate(ga, st); });
+
+        uint32_t live          = n;
+        int rounds_since_check = 0;
+        for (int round = 0;; ++round) {
+            // ---- closest-hit traversal of the primary stream (K2)
+            const PrimaryCols in = d->primaryCols(in_slot);
+            TraverseArgs ta{};
+            ta.scene = d->dscene;
+            ta.ox = in.ox, ta.oy = in.oy, ta.oz = in.oz, ta.dx = in.dx, ta.dy = in.dy, ta.dz = in.dz;
+            ta.tmin = in.tmin, ta.tmax = in.tmax, ta.flags = in.flags;
+            ta.count        = &qs->primary_count[in_slot];
+            ta.work_counter = &qs->work_counter[0];
+            ta.qs           = qs;
+            ta.ent_id = in.ent_id, ta.prim_id = in.prim_id, ta.t = in.t, ta.u = in.u, ta.v = in.v;
+            timed(1, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
+
+            // ---- sort + shade + compact (K3, K4, K5, K9)
+            ShadeArgs sa{};
+            sa.scene     = d->dscene;
+            sa.in        = in;
+            sa.out       = d->primaryCols(in_slot ^ 1);
+            sa.sec       = d->secondaryCols();
+            sa.in_count  = &qs->primary_count[in_slot];
+            sa.out_count = &qs->primary_count[in_slot ^ 1];
+            sa.sec_count = &qs->secondary_count;
+            sa.qs        = qs;
+            sa.accum     = d->accum.ptr;
+            sa.id_base   = first;
+            sa.width = rs->width, sa.height = rs->height, sa.spi = rs->spi;
+            sa.iteration = rs->iteration, sa.frame = rs->frame, sa.seed = rs->user_seed;
+            sa.row_offset = row_offset, sa.row_stride = row_stride;
+            sa.inv_spi   = inv;
+            sa.list_mode = list_mode ? 1 : 0;
+            timed(2, [&] {
+                launch_shade(sa, d->shadeGrid(), st);
+                launch_round_end(qs, in_slot, st);
+            });
+
+            // ---- any-hit traversal of the shadow rays + splat (K6)
+            const SecondaryCols sec = d->secondaryCols();
+            TraverseArgs tb{};
+            tb.scene = d->dscene;
+            tb.ox = sec.ox, tb.oy = sec.oy, tb.oz = sec.oz, tb.dx = sec.dx, tb.dy = sec.dy, tb.dz = sec.dz;
+            tb.tmin = sec.tmin, tb.tmax = sec.tmax, tb.flags = nullptr;
+            tb.uniform_flags = IG_RAY_FLAG_SHADOW;
+            tb.count         = &qs->secondary_count;
+            tb.work_counter  = &qs->work_counter[2];
+            tb.qs            = qs;
+            tb.ray_id        = sec.id;
+            tb.cr = sec.cr, tb.cg = sec.cg, tb.cb = sec.cb;
+            tb.accum   = d->accum.ptr;
+            tb.id_base = first;
+            tb.inv_spi = inv;
+            timed(3, [&] {
+                launch_traverse(tb, true, counters, d->traverseGrid(), st);
+                launch_secondary_end(qs, st);
+            });
+
+            in_slot ^= 1;
+            d->stats.rounds++;
+            d->stats.traverse_primary_launches++;
+            d->stats.traverse_secondary_launches++;
+
+            // The host only needs to know when the stream ran dry; look at the counter after every
+            // round while rounds are long, every 4th once they are short.
+            ++rounds_since_check;
+            const int interval = live > 262144u ? 1 : 4;
+            if (rounds_since_check >= interval) {
+                readQueueState(d, host_qs);
+                rounds_since_check = 0;
+                if (host_qs.error_flags & 1u)
+                    throw HipError{ IGD_ERR_DEVICE, "igd_render: traversal stack overflow (BVH deeper than the LDS stack)" };
+                live = host_qs.primary_count[in_slot];
+                if (live == 0)
+                    break;
+            }
+            if (round > d->dscene.tech.max_depth + 8)
+                throw HipError{ IGD_ERR_DEVICE, "igd_render: wavefront loop did not terminate" };
+        }
+
+        ResolveArgs ra{};
+        ra.accum             = d->accum.ptr;
+        ra.fb                = d->fb.ptr;
+        ra.width             = rs->width;
+        ra.spi               = rs->spi;
+        ra.row_offset        = row_offset;
+        ra.row_stride        = row_stride;
+        ra.first_local_pixel = first / rs->spi;
+        ra.pixels            = n / (uint32_t)rs->spi;
+        timed(4, [&] { launch_resolve(ra, st); });
+    }
+
+    readQueueState(d, host_qs);
+    HIP_CHECK(hipGetLastError());
+    d->fb_host_dirty = true;
+
+    d->stats.camera_rays += host_qs.camera_rays;
+    d->stats.bounce_rays += host_qs.bounce_rays;
+    d->stats.shadow_rays += host_qs.shadow_rays;
+    d->stats.unoccluded += host_qs.unoccluded;
+    d->stats.nodes_primary += host_qs.nodes[0], d->stats.nodes_secondary += host_qs.nodes[1];
+    d->stats.tris_primary += host_qs.tris[0], d->stats.tris_secondary += host_qs.tris[1];
+    d->stats.leaves_primary += host_qs.leaves[0], d->stats.leaves_secondary += host_qs.leaves[1];
+    HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(qs) + offsetof(QueueState, camera_rays), 0, sizeof(QueueState) - offsetof(QueueState, camera_rays), st));
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    for (const Span& s : spans) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, d->event(s.e0), d->event(s.e1)));
+        switch (s.kind) {
+        case 0: d->stats.ms_generate += ms; break;
+        case 1: d->stats.ms_traverse_primary += ms; break;
+        case 2: d->stats.ms_shade += ms; break;
+        case 3: d->stats.ms_traverse_secondary += ms; break;
+        default: d->stats.ms_resolve += ms; break;
+        }
+    }
+    d->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+}
+
+void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_flags, int any_hit,
+                  int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v, int repeat, double* kernel_ms)
+{
+    if (!d->has_scene)
+        throw HipError{ IGD_ERR_NO_SCENE, "igd_traverse: no scene assigned" };
+    if (count < 0 || count >= ((int64_t)1 << 31) || (count > 0 && !rays))
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_traverse: bad ray list" };
+    if (kernel_ms)
+        *kernel_ms = 0;
+    if (count == 0)
+        return;
+    const size_t n = (size_t)count;
+
+    // AoS host list -> SoA columns in HBM
+    std::vector<float> soa(n * 8);
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 8; ++c)
+            soa[(size_t)c * n + i] = rays[i * 8 + c];
+    DevBuf<float> in, out;
+    in.upload(soa.data(), soa.size());
+    out.alloc(n * 5);
+    HIP_CHECK(hipMemset(out.ptr, 0xFF, n * 5 * sizeof(float)));
+
+    hipStream_t st = d->stream;
+    QueueState* qs = d->qs.ptr;
+    const uint32_t cnt = (uint32_t)n;
+    HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, camera_rays), st));
+    HIP_CHECK(hipMemcpyAsync(&qs->primary_count[0], &cnt, 4, hipMemcpyHostToDevice, st));
+
+    TraverseArgs ta{};
+    ta.scene = d->dscene;
+    float* b = in.ptr;
+    ta.ox = b, ta.oy = b + n, ta.oz = b + 2 * n, ta.dx = b + 3 * n, ta.dy = b + 4 * n, ta.dz = b + 5 * n;
+    ta.tmin = b + 6 * n, ta.tmax = b + 7 * n;
+    ta.flags         = nullptr;
+    ta.uniform_flags = ray_flags;
+    ta.count         = &qs->primary_count[0];
+    ta.work_counter  = &qs->work_counter[0];
+    ta.qs            = qs;
+    ta.ent_id        = reinterpret_cast<int32_t*>(out.ptr);
+    ta.prim_id       = reinterpret_cast<int32_t*>(out.ptr + n);
+    ta.t = out.ptr + 2 * n, ta.u = out.ptr + 3 * n, ta.v = out.ptr + 4 * n;
+
+    const bool stats = d->setup.acquire_stats >= 2;
+    if (repeat < 1)
+        repeat = 1;
+    float total_ms = 0;
+    for (int r = 0; r < repeat; ++r) {
+        HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, 4, st));
+        HIP_CHECK(hipEventRecord(d->event(0), st));
+        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), st);
+        HIP_CHECK(hipEventRecord(d->event(1), st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, d->event(0), d->event(1)));
+        total_ms += ms;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (kernel_ms)
+        *kernel_ms = total_ms / repeat;
+
+    QueueState host_qs;
+    readQueueState(d, host_qs);
+    if (host_qs.error_flags & 1u)
+        throw HipError{ IGD_ERR_DEVICE, "igd_traverse: traversal stack overflow (BVH deeper than the LDS stack)" };
+    d->stats.nodes_primary += host_qs.nodes[0], d->stats.nodes_secondary += host_qs.nodes[1];
+    d->stats.tris_primary += host_qs.tris[0], d->stats.tris_secondary += host_qs.tris[1];
+    d->stats.leaves_primary += host_qs.leaves[0], d->stats.leaves_secondary += host_qs.leaves[1];
+    d->stats.unoccluded += host_qs.unoccluded;
+    if (any_hit)
+        d->stats.traverse_secondary_launches += (uint64_t)repeat;
+    else
+        d->stats.traverse_primary_launches += (uint64_t)repeat;
+    HIP_CHECK(hipMemset(reinterpret_cast<uint8_t*>(qs) + offsetof(QueueState, camera_rays), 0, sizeof(QueueState) - offsetof(QueueState, camera_rays)));
+
+    std::vector<float> host(n * 5);
+    HIP_CHECK(hipMemcpy(host.data(), out.ptr, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (ent_id)
+        std::memcpy(ent_id, host.data(), n * 4);
+    if (prim_id)
+        std::memcpy(prim_id, host.data() + n, n * 4);
+    if (!any_hit) {
+        if (t)
+            std::memcpy(t, host.data() + 2 * n, n * 4);
+        if (u)
+            std::memcpy(u, host.data() + 3 * n, n * 4);
+        if (v)
+            std::memcpy(v, host.data() + 4 * n, n * 4);
+    }
+}
+
+int guarded(const char* what, const std::function<void()>& fn)
+{
+    g_error.clear();
+    try {
+        fn();
+        return IGD_OK;
+    } catch (const HipError& e) {
+        g_error = std::string(what) + ": " + e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_error = std::string(what) + ": " + e.what();
+        return IGD_ERR_DEVICE;
+    }
+}
+
+bool isColorName(const char* name) { return !name || !*name || std::strcmp(name, "Color") == 0 || std::strcmp(name, "Default") == 0; }
+
+} // namespace
+
+extern "C" {
+
+uint32_t igd_get_abi_version(void) { return IGD_ABI_VERSION; }
+
+int32_t igd_device_count(void)
+{
+    g_error.clear();
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return 0;
+    }
+    int usable = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0)
+            ++usable;
+    }
+    if (usable == 0)
+        g_error = "no gfx950 (MI355X) device visible";
+    return usable;
+}
+
+igd_device* igd_create(const igd_setup* setup)
+{
+    igd_device* dev = nullptr;
+    const int rc    = guarded("igd_create", [&] {
+        if (!setup)
+            throw HipError{ IGD_ERR_INVALID_ARG, "setup is NULL" };
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            throw HipError{ IGD_ERR_NO_DEVICE, "no HIP device visible; the HIP backend has no CPU fallback" };
+        if (setup->gpu_index < 0 || setup->gpu_index >= n)
+            throw HipError{ IGD_ERR_NO_DEVICE, "gpu_index out of range" };
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, setup->gpu_index));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            throw HipError{ IGD_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", kernels are built for gfx950 only" };
+        HIP_CHECK(hipSetDevice(setup->gpu_index));
+        auto d     = std::make_unique<igd_device>();
+        d->setup   = *setup;
+        d->num_cus = p.multiProcessorCount;
+        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        d->qs.alloc(1);
+        HIP_CHECK(hipMemset(d->qs.ptr, 0, sizeof(QueueState)));
+        dev = d.release();
+    });
+    if (rc != IGD_OK) {
+        delete dev;
+        return nullptr;
+    }
+    return dev;
+}
+
+void igd_destroy(igd_device* dev) { delete dev; }
+
+int32_t igd_assign_scene(igd_device* dev, const igd_scene* scene)
+{
+    return guarded("igd_assign_scene", [&] {
+        if (!dev || !scene)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        dev->has_scene = false;
+        assignScene(dev, scene);
+    });
+}
+
+int32_t igd_render(igd_device* dev, const igd_render_settings* settings)
+{
+    return guarded("igd_render", [&] {
+        if (!dev || !settings)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        render(dev, settings);
+    });
+}
+
+int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
+{
+    return guarded("igd_resize", [&] {
+        if (!dev || width <= 0 || height <= 0)
+            throw HipError{ IGD_ERR_INVALID_ARG, "bad size" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        if (width != dev->fb_w || height != dev->fb_h) {
+            dev->fb.release();
+            dev->fb_w = dev->fb_h = 0;
+        }
+        resizeFb(dev, width, height);
+        HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float)));
+        dev->fb_host_dirty = true;
+    });
+}
+
+int32_t igd_release_all(igd_device* dev)
+{
+    return guarded("igd_release_all", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        for (int s = 0; s < 2; ++s)
+            dev->primary[s].release();
+        dev->secondary.release();
+        dev->accum.release();
+        dev->list_rays.release();
+        dev->capacity = 0;
+        dev->geom.release();
+        dev->shape_data.release();
+        dev->leaves.release();
+        dev->leaf_ext.release();
+        dev->entities.release();
+        dev->shape_offsets.release();
+        dev->materials.release();
+        dev->entity_material.release();
+        dev->lights.release();
+        dev->has_scene = false;
+    });
+}
+
+int32_t igd_framebuffer_width(const igd_device* dev) { return dev ? dev->fb_w : 0; }
+int32_t igd_framebuffer_height(const igd_device* dev) { return dev ? dev->fb_h : 0; }
+
+const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t sync)
+{
+    const float* result = nullptr;
+    guarded("igd_framebuffer_host", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        if (!isColorName(name))
+            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" }; // Device.cpp:1391-1395
+        if (!dev->fb.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (render or resize first)" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        if (sync && dev->fb_host_dirty) {
+            HIP_CHECK(hipMemcpy(dev->fb_host.data(), dev->fb.ptr, dev->fb_host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            dev->fb_host_dirty = false;
+        }
+        result = dev->fb_host.data();
+    });
+    return result;
+}
+
+float* igd_framebuffer_device(igd_device* dev, const char* name)
+{
+    g_error.clear();
+    if (!dev || !isColorName(name)) {
+        g_error = "igd_framebuffer_device: unknown AOV or NULL device";
+        return nullptr;
+    }
+    return dev->fb.ptr;
+}
+
+int32_t igd_clear_framebuffer(igd_device* dev, const char* name)
+{
+    return guarded("igd_clear_framebuffer", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        if (!isColorName(name))
+            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        if (dev->fb.ptr)
+            HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float)));
+        std::fill(dev->fb_host.begin(), dev->fb_host.end(), 0.0f);
+        dev->fb_host_dirty = true;
+    });
+}
+
+int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const float* data)
+{
+    return guarded("igd_sync_framebuffer_to_device", [&] {
+        if (!dev || !data)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        if (!isColorName(name))
+            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
+        if (!dev->fb.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (resize first)" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        HIP_CHECK(hipMemcpy(dev->fb.ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
+        dev->fb_host_dirty = true;
+    });
+}
+
+int32_t igd_get_stats(igd_device* dev, igd_stats* out)
+{
+    g_error.clear();
+    if (!dev || !out) {
+        g_error = "igd_get_stats: NULL argument";
+        return IGD_ERR_INVALID_ARG;
+    }
+    *out = dev->stats;
+    return IGD_OK;
+}
+
+int32_t igd_reset_stats(igd_device* dev)
+{
+    g_error.clear();
+    if (!dev) {
+        g_error = "igd_reset_stats: NULL device";
+        return IGD_ERR_INVALID_ARG;
+    }
+    dev->stats = igd_stats{};
+    return IGD_OK;
+}
+
+int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t ray_flags, int32_t any_hit,
+                     int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v, int32_t repeat, double* kernel_ms)
+{
+    return guarded("igd_traverse", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        traverseList(dev, count, rays, ray_flags, any_hit, ent_id, prim_id, t, u, v, repeat, kernel_ms);
+    });
+}
+
+const char* igd_last_error(void) { return g_error.c_str(); }
+
+} // extern "C"

@@ -1,0 +1,122 @@
+// kernels.h — argument blocks shared by the HIP kernels and the host-side device code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ig_tables.h"
+
+namespace igdev {
+
+// Geometry resident in HBM. `geom` = ["trimesh_primbvh" fix table | scene Node8 array], so every
+// BVH node / Tri4 packet is addressed as geom + 32-bit byte offset (SGPR base + VGPR offset).
+struct DevScene {
+    const uint8_t* geom;
+    uint32_t scene_nodes_off;      // byte offset of SceneBVH nodes inside geom
+    uint32_t scene_node_count;     // 0: empty scene
+    const ig_entity_leaf1* leaves; // SceneBVH leaves
+    const uint2* leaf_ext;         // per leaf: {byte offset of its shape's Node8[], byte offset of its Tri4[]}
+    // shading tables
+    const float* entities;         // 36 floats each
+    const uint8_t* shape_data;     // dyn table "shapes" blob
+    const uint64_t* shape_offsets; // byte offset per shape
+    const ig_material* materials;
+    const int32_t* entity_material; // material id per entity
+    const ig_light* lights;
+    uint32_t entity_count, material_count, light_count, infinite_light_count;
+    ig_technique tech;
+};
+
+// SoA ray queue columns (src/artic/driver/streams.art:1-32 restated for HBM: one allocation per
+// stream, column c at base + c * capacity).
+struct PrimaryCols {
+    int32_t* id;
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
+    uint32_t* flags;
+    int32_t *ent_id, *prim_id;
+    float *t, *u, *v;
+    uint32_t* rnd;
+    float* payload[6]; // inv_pdf, contrib rgb, depth, eta (technique/pathtracer.art:7-12), SoA
+};
+
+struct SecondaryCols {
+    int32_t* id;
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
+    float *cr, *cg, *cb;
+};
+
+// Device-resident queue state: no host round trip per bounce (the reference reads counters back
+// 3x per bounce, mapping_gpu.art:457-465,686-711).
+struct QueueState {
+    uint32_t primary_count[2]; // sizes of the two primary streams
+    uint32_t secondary_count;
+    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] shade, [2] traverse secondary
+    uint32_t error_flags;      // bit 0: traversal stack overflow
+    uint32_t pad0;
+    // statistics (Statistics.h:57-64)
+    unsigned long long camera_rays, bounce_rays, shadow_rays, unoccluded;
+    unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches
+};
+
+struct TraverseArgs {
+    DevScene scene;
+    // input rays (SoA). flags == nullptr -> uniform_flags
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
+    const uint32_t* flags;
+    uint32_t uniform_flags;
+    const uint32_t* count;  // device pointer to the number of rays
+    uint32_t* work_counter; // zero before launch
+    QueueState* qs;
+    // closest-hit outputs
+    int32_t *ent_id, *prim_id;
+    float *t, *u, *v;
+    // any-hit epilogue (shadow rays): unoccluded rays add their colour into accum[(id - id_base) * 3]
+    const int32_t* ray_id;
+    const float *cr, *cg, *cb;
+    float* accum;
+    int64_t id_base;
+    float inv_spi;
+};
+
+struct GenerateArgs {
+    PrimaryCols out;
+    uint32_t* out_count;
+    QueueState* qs;
+    ig_camera cam;
+    float sx, sy; // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13), evaluated on the host
+    int32_t width, height, spi;
+    int32_t iteration, frame, seed;
+    int32_t row_offset, row_stride; // tile sharding: local row r -> film row row_offset + r * row_stride
+    int64_t first_local_id;         // first local ray id of this chunk
+    uint32_t n;                     // rays to generate
+    const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
+};
+
+struct ShadeArgs {
+    DevScene scene;
+    PrimaryCols in;
+    PrimaryCols out;
+    SecondaryCols sec;
+    const uint32_t* in_count;
+    uint32_t* out_count;
+    uint32_t* sec_count;
+    QueueState* qs;
+    float* accum;
+    int64_t id_base; // global ray id of accum[0]
+    int32_t width, height, spi;
+    int32_t iteration, frame, seed;
+    int32_t row_offset, row_stride; // tile sharding (same mapping as GenerateArgs)
+    float inv_spi;
+    int32_t list_mode; // rays came from the list emitter: pixel = ray id, flags 0
+};
+
+struct ResolveArgs {
+    const float* accum;
+    float* fb;
+    int32_t width, spi;
+    int32_t row_offset, row_stride;
+    int64_t first_local_pixel; // local pixel index of accum[0]
+    uint32_t pixels;
+};
+
+} // namespace igdev

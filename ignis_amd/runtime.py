@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's Python API for the hot path.
+
+Mirrors the names and semantics of the nanobind module `ignis`
+(src/frontend/python/runtime.cpp:223-312 over src/runtime/Runtime.cpp:334-446): `loadFromFile`,
+`loadFromString`, `RuntimeOptions`, `Ray`, and a `Runtime` with `step`, `trace`, `reset`,
+`getFramebufferForHost`, `clearFramebuffer`, `IterationCount`, `SampleCount`, ... so the
+reference's integrator tests (src/tests/integrator/*.py) read the same against this backend.
+The render work is done by the MI355X device behind include/igd_device.h; scene loading by the
+native host library behind include/igh_host.h. There is no CPU render path.
+"""
+import math
+
+import numpy as np
+
+from .device import Device
+from .tables import LoadedScene
+
+
+class RuntimeOptions:
+    """Subset of RuntimeOptions (src/runtime/RuntimeSettings.h:12-59) the hot path consumes."""
+
+    def __init__(self):
+        self.Device = 0               # Target.Device: HIP ordinal
+        self.AcquireStats = False
+        self.SPI = 0                  # 0 = recommendSPI (Runtime.cpp:71-79)
+        self.Seed = 0
+        self.OverrideFilmSize = (0, 0)
+        self.StreamCapacity = 0       # rays in flight, 0 = device default
+        self.IsTracer = False
+        # tile sharding across devices: this runtime renders rows offset, offset+stride, ...
+        self.RowOffset = 0
+        self.RowStride = 1
+
+    @staticmethod
+    def makeDefault(trace=False):
+        o = RuntimeOptions()
+        o.IsTracer = bool(trace)
+        return o
+
+
+class Ray:
+    """RuntimeStructs.h:39-43."""
+
+    def __init__(self, org, dir, tmin=0.0, tmax=3.4028234664e+38):
+        self.Origin = tuple(float(x) for x in org)
+        self.Direction = tuple(float(x) for x in dir)
+        self.Range = (float(tmin), float(tmax))
+
+
+def recommend_spi(width, height, interactive=False):
+    """recommendSPI for a GPU target (src/runtime/Runtime.cpp:71-79)."""
+    spi_f = 8 // 2 if interactive else 8
+    spi = int(math.ceil(spi_f / ((width / 1000.0) * (height / 1000.0))))
+    return max(1, min(64, spi))
+
+
+class Runtime:
+    def __init__(self, scene: LoadedScene, opts: RuntimeOptions):
+        self._scene = scene
+        self._opts = opts
+        sc = scene.scene
+        self._width, self._height = int(sc.film_width), int(sc.film_height)
+        self._spi = opts.SPI if opts.SPI > 0 else recommend_spi(self._width, self._height)
+        self._device = Device(opts.Device, opts.AcquireStats, opts.StreamCapacity)
+        self._device.assign_scene(scene)
+        self._iteration = 0
+        self._samples = 0
+        self._frame = 0
+        if not opts.IsTracer:
+            self._device.resize(self._width, self._height)
+
+    # -- context manager like RuntimeWrap (runtime.cpp:313-320)
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.shutdown()
+        return False
+
+    def shutdown(self):
+        if self._device is not None:
+            self._device.close()
+            self._device = None
+        if self._scene is not None:
+            self._scene.close()
+            self._scene = None
+
+    # -- Runtime::step (Runtime.cpp:334-387)
+    def step(self, ignoreDenoiser=False):
+        if self._opts.IsTracer:
+            raise RuntimeError("Trying to use step() in a trace driver!")
+        self._device.render(self._spi, self._width, self._height, iteration=self._iteration, frame=self._frame,
+                            seed=self._opts.Seed, row_offset=self._opts.RowOffset, row_stride=self._opts.RowStride)
+        self._samples += self._spi
+        self._iteration += 1
+
+    # -- Runtime::trace (Runtime.cpp:389-446): returns (n, 3) radiance, accumulated over calls
+    def trace(self, rays):
+        if not self._opts.IsTracer:
+            raise RuntimeError("Trying to use trace() in a camera driver!")
+        arr = np.empty((len(rays), 8), dtype=np.float32)
+        for i, r in enumerate(rays):
+            d = np.asarray(r.Direction, dtype=np.float32)
+            n = np.linalg.norm(d)
+            arr[i, 0:3] = r.Origin
+            arr[i, 3:6] = d / n if n > 0 else d  # rays are normalised on upload (Device.cpp:602-643)
+            arr[i, 6:8] = r.Range
+        self._device.render(self._spi, len(rays), 1, iteration=self._iteration, frame=self._frame,
+                            seed=self._opts.Seed, rays=arr)
+        self._samples += self._spi
+        self._iteration += 1
+        return self._device.framebuffer().reshape(-1, 3)[: len(rays)]
+
+    def reset(self):
+        self._device.clear_framebuffer()
+        self._iteration = 0
+        self._samples = 0
+
+    def getFramebufferForHost(self, aov=""):
+        return self._device.framebuffer(aov or None)
+
+    def clearFramebuffer(self, aov=""):
+        self._device.clear_framebuffer(aov or None)
+
+    def incFrameCount(self):
+        self._frame += 1
+
+    def getStatistics(self):
+        return self._device.stats()
+
+    IterationCount = property(lambda self: self._iteration)
+    SampleCount = property(lambda self: self._samples)
+    FrameCount = property(lambda self: self._frame)
+    FramebufferWidth = property(lambda self: self._width)
+    FramebufferHeight = property(lambda self: self._height)
+    Seed = property(lambda self: self._opts.Seed)
+    SPI = property(lambda self: self._spi)
+    Technique = property(lambda self: "path")
+    Camera = property(lambda self: "perspective")
+
+    @property
+    def SceneBoundingBox(self):
+        sc = self._scene.scene
+        return tuple(sc.bbox_min), tuple(sc.bbox_max)
+
+
+def _film_override(opts):
+    w, h = opts.OverrideFilmSize
+    return int(w), int(h)
+
+
+def loadFromFile(path, opts=None):
+    """ignis.loadFromFile (runtime.cpp:322-340)."""
+    opts = opts or RuntimeOptions.makeDefault()
+    w, h = _film_override(opts)
+    return Runtime(LoadedScene.from_file(str(path), w, h), opts)
+
+
+def loadFromString(text, opts=None, dir=""):
+    """ignis.loadFromString (runtime.cpp:342-360)."""
+    opts = opts or RuntimeOptions.makeDefault()
+    w, h = _film_override(opts)
+    return Runtime(LoadedScene.from_string(text, str(dir), w, h), opts)

@@ -1,0 +1,140 @@
+/* igd_device.h — C ABI of the MI355X render device (libig_device_hip.so).
+ *
+ * The reference's device boundary is the C++ plugin interface
+ *   IDeviceInterface  src/runtime/device/IDeviceInterface.h:9-17
+ *   IRenderDevice     src/runtime/device/IRenderDevice.h:14-81
+ * loaded by DeviceManager through `ig_get_interface` (src/device/Interface.cpp:70-76).
+ * Its signatures carry std::string / std::vector / Eigen types, so a plugin has
+ * to be built with the runtime's own toolchain; this library exports the same
+ * operations as a plain C ABI (pointers + sizes), and the ~200-line C++ adapter
+ * in ignis_amd/csrc/adapter/ maps IRenderDevice onto it.
+ * Each entry point names the reference method it replaces.
+ *
+ * Error convention: the reference logs and carries on (or std::abort()s on OOM,
+ * src/device/Device.cpp:303-306). Here every call returns IGD_OK or a negative
+ * code and igd_last_error() holds the message; nothing falls back to the CPU.
+ */
+#ifndef IGD_DEVICE_H
+#define IGD_DEVICE_H
+
+#include "ig_tables.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGD_ABI_VERSION 1u
+
+enum igd_status {
+    IGD_OK                = 0,
+    IGD_ERR_INVALID_ARG   = -1,
+    IGD_ERR_NO_DEVICE     = -2, /* no HIP device / wrong architecture */
+    IGD_ERR_OUT_OF_MEMORY = -3,
+    IGD_ERR_NO_SCENE      = -4,
+    IGD_ERR_UNSUPPORTED   = -5, /* scene feature the HIP backend cannot lower */
+    IGD_ERR_DEVICE        = -6, /* HIP runtime error, traversal stack overflow, ... */
+};
+
+typedef struct igd_device igd_device;
+
+/* IRenderDevice::SetupSettings (IRenderDevice.h:16-21) + GPU selection
+ * (Target::device(), src/runtime/device/Target.h). */
+typedef struct igd_setup {
+    int32_t gpu_index;      /* HIP device ordinal */
+    int32_t acquire_stats;  /* 0 off, 1 per-stage HIP-event timers, 2 timers + traversal work counters */
+    int32_t debug_trace;
+    int32_t is_interactive;
+    uint64_t stream_capacity; /* rays in flight; 0 = default (reference: 1 048 576, mapping_gpu.art:1119) */
+} igd_setup;
+
+/* IRenderDevice::RenderSettings (IRenderDevice.h:30-40). `rays` != NULL selects the
+ * list emitter of Runtime::trace (src/runtime/Runtime.cpp:389-446): width = #rays, height = 1.
+ * Tile sharding (new): this device renders film rows
+ * row_offset, row_offset + row_stride, ...; (0, 1) = the whole film. */
+typedef struct igd_render_settings {
+    const float* rays; /* host pointer, 8 floats per ray: org, dir, tmin, tmax; or NULL */
+    int32_t spi;
+    int32_t width, height;
+    int32_t iteration, frame, user_seed;
+    int32_t row_offset, row_stride;
+} igd_render_settings;
+
+/* Statistics (src/runtime/Statistics.h:57-64 quantities + ShaderType timers). */
+typedef struct igd_stats {
+    uint64_t camera_rays, bounce_rays, shadow_rays; /* shadow_rays counts real shadow rays */
+    uint64_t unoccluded;                             /* shadow rays that reached the light */
+    /* traversal work (inner nodes fetched, triangles tested, entity leaves tested), split by kernel;
+     * only counted with acquire_stats >= 2 */
+    uint64_t nodes_primary, tris_primary, leaves_primary;
+    uint64_t nodes_secondary, tris_secondary, leaves_secondary;
+    uint64_t traverse_primary_launches, traverse_secondary_launches;
+    double ms_generate, ms_traverse_primary, ms_shade, ms_traverse_secondary, ms_resolve; /* HIP-event time, acquire_stats */
+    double ms_total;   /* wall time inside igd_render, host clock */
+    uint32_t rounds;   /* bounce rounds executed */
+    uint32_t pad;
+} igd_stats;
+
+/* IDeviceInterface::getVersion (IDeviceInterface.h:11) */
+uint32_t igd_get_abi_version(void);
+
+/* Number of usable gfx950 devices; <= 0 means none (igd_last_error says why). */
+int32_t igd_device_count(void);
+
+/* IDeviceInterface::createRenderDevice (IDeviceInterface.h:14) / Device::Device (Device.cpp:1621-1640) */
+igd_device* igd_create(const igd_setup* setup);
+void igd_destroy(igd_device* dev);
+
+/* IRenderDevice::assignScene (IRenderDevice.h:43, Device.cpp:1642-1670): uploads all tables once.
+ * The scene is copied to HBM; the host pointers need not outlive this call. */
+int32_t igd_assign_scene(igd_device* dev, const igd_scene* scene);
+
+/* IRenderDevice::render (IRenderDevice.h:44, Device.cpp:1672-1682): one iteration, blocking. */
+int32_t igd_render(igd_device* dev, const igd_render_settings* settings);
+
+/* IRenderDevice::resize (IRenderDevice.h:45): reallocates and clears the framebuffer. */
+int32_t igd_resize(igd_device* dev, int32_t width, int32_t height);
+
+/* IRenderDevice::releaseAll (IRenderDevice.h:47) */
+int32_t igd_release_all(igd_device* dev);
+
+int32_t igd_framebuffer_width(const igd_device* dev);  /* IRenderDevice::framebufferWidth */
+int32_t igd_framebuffer_height(const igd_device* dev); /* IRenderDevice::framebufferHeight */
+
+/* IRenderDevice::getFramebufferForHost(name, sync) (IRenderDevice.h:53, Device.cpp:1385-1417):
+ * float[height][width][3], device -> host copy if dirty; pointer owned by the device, valid
+ * until resize/destroy. name NULL or "" = colour buffer. Returns NULL for unknown AOVs. */
+const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t sync);
+
+/* IRenderDevice::getFramebufferForDevice (IRenderDevice.h:54): device pointer (HBM). */
+float* igd_framebuffer_device(igd_device* dev, const char* name);
+
+/* IRenderDevice::clearFramebuffer / clearAllFramebuffer (IRenderDevice.h:55-56) */
+int32_t igd_clear_framebuffer(igd_device* dev, const char* name);
+
+/* IRenderDevice::syncFramebufferHostToDevice (IRenderDevice.h:58): uploads `data`
+ * (float[height][width][3]) into the device framebuffer (checkpoint resume). */
+int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const float* data);
+
+/* IRenderDevice::getStatistics (IRenderDevice.h:66): cumulative since igd_reset_stats. */
+int32_t igd_get_stats(igd_device* dev, igd_stats* out);
+int32_t igd_reset_stats(igd_device* dev);
+
+/* Stage dispatch of the traversal kernels on a ray list — what the reference reaches through
+ * ignis_handle_traverse_primary / _secondary (src/device/Device.cpp:1020-1061,2044-2054) with the
+ * list emitter (src/artic/driver/emitter.art:18-30). rays: host, 8 floats per ray (org, dir,
+ * tmin, tmax). any_hit = 0: closest hit, outputs (ent_id, prim_id, t, u, v) as the primary
+ * stream's hit columns (src/artic/driver/streams.art:16-20); any_hit = 1: prim_id >= 0 marks
+ * an occluded ray. Output pointers are host arrays of `count` entries and may be NULL.
+ * `repeat` >= 1 re-runs the kernel on the resident rays (timing); kernel_ms (may be NULL)
+ * receives the average HIP-event duration of one launch. */
+int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t ray_flags, int32_t any_hit,
+                     int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v,
+                     int32_t repeat, double* kernel_ms);
+
+/* Thread-local message of the last failed igd_* call ("" if none). */
+const char* igd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGD_DEVICE_H */

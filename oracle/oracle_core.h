@@ -344,7 +344,9 @@ static inline Hit traverse_prim(Ray ray, const PrimBvh& bvh, bool any_hit, Trave
             float leaf_t;
             stack.pop(leaf, leaf_t);
             int32_t prim_id = ~leaf;
-            for (;;) {
+            // An inactive leaf (entry behind the current hit) has no observable effect in the
+            // reference: its items are iterated with every test masked out.
+            while (active) {
                 const ig_tri4& tri = bvh.tris[prim_id++];
                 for (int i = 0; i < 4; ++i) {
                     if (tri.prim_id[i] == -1)
@@ -455,7 +457,8 @@ static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, Tra
             float leaf_t;
             stack.pop(leaf_ref, leaf_t);
             int32_t ref_id = ~leaf_ref;
-            for (;;) {
+            // Inactive run: the reference still calls handle_local but discards the result.
+            while (active) {
                 const ig_entity_leaf1& leaf = sc.scene_leaves[ref_id++];
                 ++st.leaves;
                 if (check_ray_visibility(ray, leaf.flags)) {

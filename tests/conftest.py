@@ -1,0 +1,54 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs():
+    """Build the native libraries once per session if they are missing (seconds; no GPU needed)."""
+    need = [os.path.join(ROOT, "ignis_amd", "lib", "libig_host.so"),
+            os.path.join(ROOT, "ignis_amd", "lib", "libig_device_hip.so"),
+            os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def diamond_scene():
+    from ignis_amd.tables import LoadedScene
+    return LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 128, 128)
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    from ignis_amd import Device
+    dev = Device(0, acquire_stats=True)
+    yield dev
+    dev.close()
+
+
+def flat_scene(lights=(), max_depth=2, size=(64, 64)):
+    """The reference's integrator test scene (src/tests/integrator/common/__init__.py:37-65)."""
+    return {
+        "technique": {"type": "path", "max_depth": max_depth},
+        "camera": {"type": "perspective", "fov": 90, "near_clip": 0.01, "far_clip": 100,
+                   "transform": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1]},
+        "film": {"size": list(size)},
+        "bsdfs": [{"type": "diffuse", "name": "ground", "reflectance": [1, 1, 1]}],
+        "shapes": [{"type": "rectangle", "name": "Bottom", "width": 2, "height": 2, "flip_normals": True}],
+        "entities": [{"name": "Bottom", "shape": "Bottom", "bsdf": "ground"}],
+        "lights": list(lights),
+    }

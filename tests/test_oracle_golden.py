@@ -1,0 +1,166 @@
+"""Pins the CPU oracle against the reference's own known answers:
+ * src/tests/artic/test_intersection.art:1-151 (ray-triangle / ray-box vectors, restated with tight tolerances)
+ * src/tests/integrator/test_lights.py:5-44, test_init.py:9-12 (analytic image means)
+ * src/tests/integrator/test_reproducibility.py:5-20
+ * RNG construction of src/artic/core/random.art (FNV-1a offset basis / prime, TEA rounds, [1,2)-1 float trick)
+"""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+from ignis_amd.tables import LoadedScene
+from conftest import flat_scene
+
+
+# ---- test_intersection.art: triangle v0=0, e1=(0,1,0), e2=(-1,0,0), n=(0,0,1)
+TRI = dict(v0=[0, 0, 0], e1=[0, 1, 0], e2=[-1, 0, 0], n=[0, 0, 1])
+
+
+def test_tri_hit_known_answer():
+    hit, tuv = oracle.intersect_tri([0.2, 0.4, 1], [0, 0, -1], 0, 100, **TRI)
+    assert hit
+    np.testing.assert_allclose(tuv, [1.0, 0.2, 0.4], rtol=0, atol=1e-6)
+
+
+def test_tri_miss_outside():
+    hit, _ = oracle.intersect_tri([0.2, 4.4, 1], [0, 0, -1], 0, 100, **TRI)
+    assert not hit
+
+
+def test_tri_backface_hits_without_culling():
+    hit, tuv = oracle.intersect_tri([0.2, 0.4, -1], [0, 0, 1], 0, 100, **TRI)
+    assert hit and tuv[0] == pytest.approx(1.0, abs=1e-6)
+
+
+def test_tri_range_limits():
+    assert not oracle.intersect_tri([0.2, 0.4, 1], [0, 0, -1], 0, 0.5, **TRI)[0]   # beyond tmax
+    assert not oracle.intersect_tri([0.2, 0.4, 1], [0, 0, -1], 1.5, 100, **TRI)[0]  # before tmin
+    assert oracle.intersect_tri([0.2, 0.4, 1], [0, 0, -1], 0, 1.0, **TRI)[0]        # t == tmax is accepted (<=)
+
+
+def test_box_known_answers():
+    hit, t = oracle.intersect_box([0.2, 0.4, 2], [0, 0, -1], 0, 100, [0, 0, 0], [1, 1, 1])
+    assert hit and t[0] == pytest.approx(1.0, abs=1e-6) and t[1] == pytest.approx(2.0, abs=1e-6)
+    assert not oracle.intersect_box([0.2, 3.4, 2], [0, 0, -1], 0, 100, [0, 0, 0], [1, 1, 1])[0]
+    hit, t = oracle.intersect_box([0.2, 0.4, 2], [0, 0, -1], 0, 100, [0, 0, 0], [1, 1, 0])  # flat box
+    assert hit and t[0] == pytest.approx(2.0, abs=1e-6)
+
+
+# ---- RNG (core/random.art)
+def test_fnv_seed_matches_reference_construction():
+    def fnv(vals):
+        h = 0x811C9DC5
+        for d in vals:
+            d &= 0xFFFFFFFF
+            for s in (0, 8, 16, 24):
+                h = ((h * 16777619) & 0xFFFFFFFF) ^ ((d >> s) & 0xFF)
+        return h
+    for args in [(0, 0, 0, 0, 0, 0), (3, 1, 0, 17, 255, 42), (7, 12, 5, 1919, 1079, -1)]:
+        assert oracle.random_seed(*args) == fnv(args)
+
+
+def test_tea_sequence_matches_reference_construction():
+    def tea(v0, v1):
+        s = 0
+        for _ in range(4):
+            s = (s + 0x9e3779b9) & 0xFFFFFFFF
+            v0 = (v0 + ((((v1 << 4) & 0xFFFFFFFF) + 0xa341316c) ^ (v1 + s) ^ ((v1 >> 5) + 0xc8013ea4))) & 0xFFFFFFFF
+            v1 = (v1 + ((((v0 << 4) & 0xFFFFFFFF) + 0xad90777d) ^ (v0 + s) ^ ((v0 >> 5) + 0x7e95761e))) & 0xFFFFFFFF
+        return v1
+    for seed in (0, 1, 0xDEADBEEF, 0x811C9DC5):
+        f, raw = oracle.random_sequence(seed, 1, 16)
+        expect = np.array([tea(seed, c) for c in range(1, 17)], dtype=np.uint32)
+        np.testing.assert_array_equal(raw, expect)
+        ef = ((expect & 0x7FFFFF) | 0x3F800000).view(np.float32) - np.float32(1)
+        np.testing.assert_array_equal(f, ef)
+        assert (f >= 0).all() and (f < 1).all()
+
+
+def test_rng_golden_fixture():
+    """First 16 outputs for 4 seeds, committed as a fixture (tests/golden/make_golden.py)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rng_tea.npz"))
+    for i, seed in enumerate(g["seeds"]):
+        _, raw = oracle.random_sequence(int(seed), 1, 16)
+        np.testing.assert_array_equal(raw, g["raw"][i])
+
+
+# ---- deterministic libm
+@pytest.mark.parametrize("name,ref,lo,hi,tol", [
+    ("sin", np.sin, -20.0, 20.0, 1.5e-7), ("cos", np.cos, -20.0, 20.0, 1.5e-7),
+    ("acos", np.arccos, -1.0, 1.0, 4e-7), ("asin", np.arcsin, -1.0, 1.0, 3e-7)])
+def test_detmath_accuracy(name, ref, lo, hi, tol):
+    x = np.linspace(lo, hi, 200001).astype(np.float32)
+    y = oracle.detmath(name, x)
+    assert np.abs(y - ref(x.astype(np.float64))).max() <= tol
+
+
+# ---- analytic integrator answers (test_lights.py, test_init.py)
+def _mean(scene_dict, spp=8, spi=4, size=(64, 64), seed=0):
+    sc = LoadedScene.from_string(json.dumps(scene_dict), "", *size)
+    fb = np.zeros((size[1], size[0], 3), np.float32)
+    for it in range(spp):
+        oracle.render(sc, spi, size[0], size[1], iteration=it, seed=seed, fb=fb)
+    return float((fb / spp).mean())
+
+
+def test_empty_scene_is_black():
+    assert _mean({}) == pytest.approx(0, abs=1e-8)
+
+
+def test_no_light_is_black():
+    assert _mean(flat_scene()) == pytest.approx(0, abs=1e-8)
+
+
+def test_point_light_known_answer():
+    scene = flat_scene([{"type": "point", "name": "_light", "position": [0, 0, -2], "power": 1}])
+    assert _mean(scene, spp=8, spi=4, size=(128, 128)) == pytest.approx(0.005100456, abs=1e-4)
+
+
+def test_reproducibility_same_seed_bit_identical():
+    scene = flat_scene([{"type": "point", "name": "_light", "position": [0, 0, -2], "intensity": [1, 1, 1]}])
+    sc = LoadedScene.from_string(json.dumps(scene), "", 64, 64)
+    a, _ = oracle.render(sc, 1, 64, 64, seed=42, threads=1)
+    b, _ = oracle.render(sc, 1, 64, 64, seed=42, threads=4)
+    np.testing.assert_array_equal(a, b)
+    c, _ = oracle.render(sc, 4, 64, 64, seed=42)
+    assert not np.allclose(a, c)
+
+
+# ---- BVH build + traversal vs brute force over every instanced triangle
+def test_bvh_traversal_equals_bruteforce(diamond_scene):
+    rays, _ = oracle.generate_rays(diamond_scene, 1, 128, 128, 0, 128 * 128, seed=5)
+    hit = oracle.trace(diamond_scene, rays, flags=1)
+    bf = oracle.trace_bruteforce(diamond_scene, rays)
+    assert (hit["ent_id"] >= 0).mean() > 0.5
+    np.testing.assert_array_equal(hit["ent_id"] >= 0, bf["ent_id"] >= 0)
+    np.testing.assert_array_equal(hit["t"].view(np.uint32), bf["t"].view(np.uint32))
+    same = (hit["ent_id"] == bf["ent_id"]) & (hit["prim_id"] == bf["prim_id"])
+    assert same.mean() > 0.999  # ids may differ only on exact-t ties (shared edges)
+
+
+def test_any_hit_consistent_with_closest(diamond_scene):
+    rng = np.random.default_rng(1)
+    org = rng.uniform(-0.9, 0.9, (4096, 3)).astype(np.float32)
+    dst = rng.uniform(-0.9, 0.9, (4096, 3)).astype(np.float32)
+    rays = np.concatenate([org, dst - org, np.full((4096, 1), 1e-3, np.float32), np.full((4096, 1), 1 - 1e-3, np.float32)], axis=1)
+    closest = oracle.trace(diamond_scene, rays, flags=8)
+    anyhit = oracle.trace(diamond_scene, rays, flags=8, any_hit=True)
+    np.testing.assert_array_equal(closest["prim_id"] >= 0, anyhit["prim_id"] >= 0)
+
+
+def test_diamond_golden_hits(diamond_scene):
+    """4096 fixed camera rays of diamond_scene with the oracle's hits, committed as a fixture."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "diamond_hits_4096.npz"))
+    rays, _ = oracle.generate_rays(diamond_scene, 1, 128, 128, 0, 4096, seed=1)
+    np.testing.assert_array_equal(rays.view(np.uint32), g["rays"].view(np.uint32))
+    hit = oracle.trace(diamond_scene, rays, flags=1)
+    for k in ("ent_id", "prim_id"):
+        np.testing.assert_array_equal(hit[k], g[k])
+    for k in ("t", "u", "v"):
+        np.testing.assert_array_equal(hit[k].view(np.uint32), g[k].view(np.uint32))
