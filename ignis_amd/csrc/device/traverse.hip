@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
     int top_node = 0;
     float top_tmin = kFltMax;
     int ptr = -1;
-    int level = 0, mode = 0, cursor = 0;
+    int level = 0, mode = 0;
+    int ent_cursor = 0, tri_cursor = 0; // next entity leaf of the run / next Tri4 packet of the leaf
     uint32_t node_off = 0, tri_off = 0;
     int cur_ent = -1;
     bool ent_last = true;
@@ -179,7 +180,10 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                     // ---- leaf on top (mapping_cpu.art:379-381): an entry that starts behind the
                     // current hit is dropped, its items have no effect in the reference either
                     const bool active = top_tmin <= tmax;
-                    cursor            = ~top_node;
+                    if (level)
+                        tri_cursor = ~top_node;
+                    else
+                        ent_cursor = ~top_node;
                     pop_top();
                     if (active)
                         mode = level ? 1 : 2;
@@ -190,9 +194,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
 
             if (mode == 2) {
                 // ---- one entity leaf (mapping_cpu.art:481-515)
-                const float4* lf = reinterpret_cast<const float4*>(a.scene.leaves + cursor);
-                const uint2 ext  = a.scene.leaf_ext[cursor];
-                ++cursor;
+                const float4* lf = reinterpret_cast<const float4*>(a.scene.leaves + ent_cursor);
+                const uint2 ext  = a.scene.leaf_ext[ent_cursor];
+                ++ent_cursor;
                 const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
                 const int entity_id   = (int)igm_bits(l0.w);
                 const uint32_t lflags = igm_bits(l5.x);
@@ -232,8 +236,8 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                 }
             } else if (mode == 1) {
                 // ---- one Tri4 packet of a leaf (mapping_cpu.art:379-410)
-                const uint8_t* tp = geom + tri_off + (uint32_t)cursor * 208u;
-                ++cursor;
+                const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
+                ++tri_cursor;
                 const float4* tf = reinterpret_cast<const float4*>(tp);
                 float q[12][4];
 #pragma unroll
