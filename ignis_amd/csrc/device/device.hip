@@ -108,6 +108,7 @@ struct igd_device {
     DevBuf<float> primary[2], secondary, accum;
     DevBuf<QueueState> qs;
     DevBuf<float> list_rays;
+    DevBuf<uint2> stack_overflow; // behind the 16-entry LDS stack: 48 more entries per traversal thread
 
     // framebuffer
     int fb_w = 0, fb_h = 0;
@@ -177,7 +178,12 @@ struct igd_device {
         accum.alloc(capacity * 3);
     }
 
-    int traverseGrid() const { return num_cus * 2; } // 64 KiB LDS per workgroup -> 2 per CU
+    int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
+    void bindStack(TraverseArgs& t)
+    {
+        t.stack_overflow   = nullptr;
+        t.overflow_entries = 0;
+    }
     int shadeGrid() const { return num_cus * 8; }
 
     hipEvent_t event(size_t i)
@@ -407,6 +413,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.count        = &qs->primary_count[in_slot];
             ta.work_counter = &qs->work_counter[0];
             ta.qs           = qs;
+            d->bindStack(ta);
             ta.ent_id = in.ent_id, ta.prim_id = in.prim_id, ta.t = in.t, ta.u = in.u, ta.v = in.v;
             timed(1, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
 
@@ -442,6 +449,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.count         = &qs->secondary_count;
             tb.work_counter  = &qs->work_counter[2];
             tb.qs            = qs;
+            d->bindStack(tb);
             tb.ray_id        = sec.id;
             tb.cr = sec.cr, tb.cg = sec.cg, tb.cb = sec.cb;
             tb.accum   = d->accum.ptr;
@@ -553,6 +561,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     ta.count         = &qs->primary_count[0];
     ta.work_counter  = &qs->work_counter[0];
     ta.qs            = qs;
+    d->bindStack(ta);
     ta.ent_id        = reinterpret_cast<int32_t*>(out.ptr);
     ta.prim_id       = reinterpret_cast<int32_t*>(out.ptr + n);
     ta.t = out.ptr + 2 * n, ta.u = out.ptr + 3 * n, ta.v = out.ptr + 4 * n;

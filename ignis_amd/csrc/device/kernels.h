@@ -67,6 +67,9 @@ struct TraverseArgs {
     const uint32_t* count;  // device pointer to the number of rays
     uint32_t* work_counter; // zero before launch
     QueueState* qs;
+    // traversal-stack overflow behind the LDS stack: [entry][grid thread], overflow_entries deep
+    uint2* stack_overflow;
+    int32_t overflow_entries;
     // closest-hit outputs
     int32_t *ent_id, *prim_id;
     float *t, *u, *v;

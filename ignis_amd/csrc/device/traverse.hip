@@ -3,18 +3,21 @@
 // Replaces the reference kernels K2/K6 (`gpu_traverse_primary` / `_secondary`,
 // src/artic/driver/mapping_gpu.art:52-121 over src/artic/traversal/mapping_gpu.art:67-219)
 // with a persistent-threads design:
-//   * one ray per lane; each wave pulls rays from a device-resident counter and re-fills
-//     idle lanes (__ballot + lane rank) instead of one thread per ray + one launch per batch;
+//   * one ray per lane; each wave reserves batches of ray indices from a device-resident counter
+//     (one atomic per 256 rays) and re-fills idle lanes from its batch (__ballot + lane rank)
+//     instead of one thread per ray and one launch per batch;
 //   * the traversal stack lives in LDS, [entry][thread] layout (conflict-free ds_read/write_b64),
 //     instead of the reference's 64-entry private array that spills to scratch;
-//   * scene level and shape level share ONE inner-node loop and ONE stack: entering an instance
-//     saves the scene top, pushes a sentinel and switches the node base offset, so lanes in
-//     different levels stay converged (the reference nests two complete traversals);
+//   * scene level and shape level share ONE inner-node section and ONE stack: entering an instance
+//     saves the scene top, pushes a sentinel and switches the node base offset. Every loop
+//     iteration runs the sections in pipeline order  entity leaf -> inner node -> triangle packet,
+//     with cheap state transitions in between, so a lane can walk a whole instance (leaf test,
+//     shape root, triangles) in one iteration and the lanes of a wave stay in phase;
 //   * nodes / Tri4 packets / entity leaves are fetched as 16-byte vectors from one HBM blob
 //     (SGPR base + 32-bit VGPR offset).
 //
-// Per-ray semantics (visit order, culling, acceptance `t <= tmax`, hence tie-breaking) are those
-// of the reference CPU device, `cpu_traverse_helper(_prim)` with vector width 1
+// Per-ray semantics (visit order, culling points, acceptance `t <= tmax`, hence tie-breaking) are
+// those of the reference CPU device, `cpu_traverse_helper(_prim)` with vector width 1
 // (src/artic/traversal/mapping_cpu.art:282-518), on the same Node8 / Tri4 / EntityLeaf1 bytes,
 // so hits AND the visited-node / tested-triangle counts equal the CPU oracle's
 // (DESIGN.md "Traversal order").
@@ -23,21 +26,21 @@
 
 namespace igdev {
 
-constexpr int kStackEntries  = 32; // LDS: 32 * 256 threads * 8 B = 64 KiB per workgroup
-constexpr int kBlockThreads  = 256;
-constexpr int kRefillMinIdle = 20; // refill when at least this many lanes of a wave are idle
+constexpr int kLdsStack     = 24;  // LDS: 24 entries * 256 threads * 8 B = 48 KiB per workgroup (3 workgroups per CU)
+constexpr int kBlockThreads = 256;
+constexpr int kRefillIdle   = 16;  // refill when at least this many lanes of a wave are idle
+constexpr int kRayBatch     = 256; // ray indices reserved per atomic
 
 template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a)
 {
-    __shared__ uint2 s_stack[kStackEntries][kBlockThreads];
+    __shared__ uint2 s_stack[kLdsStack][kBlockThreads];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
 
     const uint32_t count = *a.count;
     const uint8_t* geom  = a.scene.geom;
-
     // ---- per-lane ray state
     bool has_ray     = false;
     uint32_t ray_idx = 0;
@@ -49,45 +52,101 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
     int top_node = 0;
     float top_tmin = kFltMax;
     int ptr = -1;
-    int level = 0, mode = 0;
-    int ent_cursor = 0, tri_cursor = 0; // next entity leaf of the run / next Tri4 packet of the leaf
+    int level = 0; // 0 scene BVH, 1 shape BVH
+    int mode  = 0; // 0 stack driven, 1 inside a triangle leaf, 2 inside an entity leaf run
+    int ent_cursor = 0, tri_cursor = 0;
     uint32_t node_off = 0, tri_off = 0;
     int cur_ent = -1;
     bool ent_last = true;
     bool need_cull = true;
+    bool finished = false;
     bool overflow = false;
     uint32_t st_nodes = 0, st_tris = 0, st_leaves = 0, st_unoccluded = 0;
 
+    // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here the
+    // stack is 24 entries of LDS per lane; deeper pushes raise error bit 0 (igd_render fails loudly).
     auto push_entry = [&](int n, float t) {
         ++ptr;
-        if (ptr < kStackEntries)
+        if (ptr < kLdsStack)
             s_stack[ptr][tid] = make_uint2((uint32_t)n, igm_bits(t));
         else
             overflow = true;
     };
     auto pop_top = [&]() {
-        const int p    = ptr < kStackEntries ? ptr : kStackEntries - 1;
-        const uint2 e  = s_stack[p][tid];
-        top_node       = (int)e.x;
-        top_tmin       = igm_float(e.y);
+        const uint2 e = s_stack[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
+        top_node      = (int)e.x;
+        top_tmin      = igm_float(e.y);
         --ptr;
     };
 
+    // Cheap state transitions up to the next heavy action: an entity-leaf step (mode 2), an inner
+    // node on top (mode 0, top_node > 0), a triangle packet (mode 1), or the end of the ray.
+    // The cull points are exactly the reference's (mapping_cpu.art:326-347): at level entry, after
+    // a leaf and after an inner node that pushed nothing.
+    auto settle = [&]() {
+        while (mode == 0 && !finished) {
+            if (need_cull) {
+                while (top_node != 0 && !(top_tmin <= tmax))
+                    pop_top();
+                need_cull = false;
+            }
+            if (top_node == 0) {
+                if (level == 1) {
+                    // shape BVH exhausted: back to the scene leaf run (mapping_cpu.art:489-508)
+                    level = 0;
+                    pop_top(); // saved scene-level top
+                    cur      = gray;
+                    node_off = a.scene.scene_nodes_off;
+                    if (ent_last)
+                        need_cull = true;
+                    else
+                        mode = 2;
+                } else {
+                    finished = true;
+                }
+            } else if (top_node > 0) {
+                break; // inner node pending
+            } else {
+                // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
+                // hit is dropped, its items have no effect in the reference either
+                const bool active = top_tmin <= tmax;
+                if (level)
+                    tri_cursor = ~top_node;
+                else
+                    ent_cursor = ~top_node;
+                pop_top();
+                if (active)
+                    mode = level ? 1 : 2;
+                else
+                    need_cull = true;
+            }
+        }
+    };
+
+    // wave-local batch of reserved ray indices (uniform across the wave)
+    uint32_t batch_next = 0, batch_end = 0;
     bool exhausted = false;
+
     for (;;) {
-        // ---- refill idle lanes from the global queue
+        // ---- refill idle lanes
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle              = __popcll(idle);
-        if (!exhausted && (n_idle >= kRefillMinIdle)) {
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(a.work_counter, (uint32_t)n_idle);
-            base = __shfl(base, 0);
-            if (base + (uint32_t)n_idle >= count)
-                exhausted = true;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const uint32_t idx  = base + rank;
-            if (!has_ray && base < count && idx < count) {
+        if (n_idle >= kRefillIdle && !(exhausted && batch_next >= batch_end)) {
+            if (batch_next >= batch_end) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(a.work_counter, (uint32_t)kRayBatch);
+                base       = __shfl(base, 0);
+                batch_next = base < count ? base : count;
+                batch_end  = base + kRayBatch < count ? base + kRayBatch : count;
+                if (base + kRayBatch >= count)
+                    exhausted = true;
+            }
+            const uint32_t avail = batch_end - batch_next;
+            const uint32_t take  = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+            const uint32_t rank  = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has_ray && rank < take) {
+                const uint32_t idx = batch_next + rank;
                 ray_idx = idx;
                 has_ray = true;
                 const f3 org = f3{ a.ox[idx], a.oy[idx], a.oz[idx] };
@@ -101,7 +160,8 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                 hit_prim = hit_ent = -1;
                 level = 0, mode = 0;
                 need_cull = true;
-                node_off = a.scene.scene_nodes_off;
+                finished  = false;
+                node_off  = a.scene.scene_nodes_off;
                 // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
                 ptr      = -1;
                 top_node = 0, top_tmin = kFltMax;
@@ -109,91 +169,19 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                 top_node = a.scene.scene_node_count ? 1 : 0;
                 top_tmin = tmin;
             }
+            batch_next += take;
         }
         if (!__any(has_ray)) {
-            if (exhausted)
+            if (exhausted && batch_next >= batch_end)
                 break;
             continue;
         }
 
-        bool finished = false;
         if (has_ray) {
-            if (mode == 0) {
-                // cull loop (mapping_cpu.art:326-347): runs at level entry, after a leaf and after an
-                // inner node that pushed nothing -- exactly where the reference culls
-                if (need_cull) {
-                    while (top_node != 0 && !(top_tmin <= tmax))
-                        pop_top();
-                    need_cull = false;
-                }
+            settle();
 
-                if (top_node == 0) {
-                    if (level == 1) {
-                        // shape BVH exhausted: back to the scene leaf run (mapping_cpu.art:489-508)
-                        level = 0;
-                        pop_top(); // saved scene-level top
-                        cur      = gray;
-                        node_off = a.scene.scene_nodes_off;
-                        if (ent_last)
-                            need_cull = true;
-                        else
-                            mode = 2;
-                    } else {
-                        finished = true;
-                    }
-                } else if (top_node > 0) {
-                    // ---- inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
-                    const uint8_t* np = geom + node_off + (uint32_t)(top_node - 1) * 256u;
-                    pop_top();
-                    const float4* nf = reinterpret_cast<const float4*>(np);
-                    float bnd[6][8];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const float4 lo = nf[2 * k], hi = nf[2 * k + 1];
-                        bnd[k][0] = lo.x, bnd[k][1] = lo.y, bnd[k][2] = lo.z, bnd[k][3] = lo.w;
-                        bnd[k][4] = hi.x, bnd[k][5] = hi.y, bnd[k][6] = hi.z, bnd[k][7] = hi.w;
-                    }
-                    const int4 c0 = reinterpret_cast<const int4*>(np)[12], c1 = reinterpret_cast<const int4*>(np)[13];
-                    const int ch[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-                    if (STATS)
-                        ++st_nodes;
-                    bool pushed = false;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float entry, exit;
-                        slab_test(cur, tmin, tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
-                        const bool hit = (ch[i] != 0) & !(exit < entry);
-                        if (hit) {
-                            // push (becomes the top) if nearer than the current top, else push_after
-                            const bool front = ANY_HIT || (top_tmin > entry);
-                            push_entry(front ? top_node : ch[i], front ? top_tmin : entry);
-                            if (front) {
-                                top_node = ch[i];
-                                top_tmin = entry;
-                            }
-                            pushed = true;
-                        }
-                    }
-                    if (!pushed)
-                        need_cull = true;
-                } else {
-                    // ---- leaf on top (mapping_cpu.art:379-381): an entry that starts behind the
-                    // current hit is dropped, its items have no effect in the reference either
-                    const bool active = top_tmin <= tmax;
-                    if (level)
-                        tri_cursor = ~top_node;
-                    else
-                        ent_cursor = ~top_node;
-                    pop_top();
-                    if (active)
-                        mode = level ? 1 : 2;
-                    else
-                        need_cull = true;
-                }
-            }
-
+            // ---- one entity leaf of the current run (mapping_cpu.art:481-515)
             if (mode == 2) {
-                // ---- one entity leaf (mapping_cpu.art:481-515)
                 const float4* lf = reinterpret_cast<const float4*>(a.scene.leaves + ent_cursor);
                 const uint2 ext  = a.scene.leaf_ext[ent_cursor];
                 ++ent_cursor;
@@ -223,19 +211,64 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                     // save the scene-level top, then a fresh stack: sentinel + shape root
                     push_entry(top_node, top_tmin);
                     push_entry(0, kFltMax);
-                    top_node = 1;
-                    top_tmin = tmin;
+                    top_node  = 1;
+                    top_tmin  = tmin;
                     level     = 1;
                     mode      = 0;
                     need_cull = true;
                     node_off  = ext.x;
-                    tri_off  = ext.y;
+                    tri_off   = ext.y;
                 } else if (ent_last) {
                     mode      = 0;
                     need_cull = true;
                 }
-            } else if (mode == 1) {
-                // ---- one Tri4 packet of a leaf (mapping_cpu.art:379-410)
+                settle();
+            }
+
+            // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
+            if (mode == 0 && !finished) {
+                const uint8_t* np = geom + node_off + (uint32_t)(top_node - 1) * 256u;
+                pop_top();
+                const float4* nf = reinterpret_cast<const float4*>(np);
+                const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
+                if (STATS)
+                    ++st_nodes;
+                bool pushed = false;
+                // two halves of four children keep the live register set small (occupancy 4 waves/SIMD)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float bnd[6][4];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const float4 x = nf[2 * k + h];
+                        bnd[k][0] = x.x, bnd[k][1] = x.y, bnd[k][2] = x.z, bnd[k][3] = x.w;
+                    }
+                    const int4 c4   = nc[h];
+                    const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float entry, exit;
+                        slab_test(cur, tmin, tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
+                        const bool hit = (ch[i] != 0) & !(exit < entry);
+                        if (hit) {
+                            // push (becomes the top) if nearer than the current top, else push_after
+                            const bool front = ANY_HIT || (top_tmin > entry);
+                            push_entry(front ? top_node : ch[i], front ? top_tmin : entry);
+                            if (front) {
+                                top_node = ch[i];
+                                top_tmin = entry;
+                            }
+                            pushed = true;
+                        }
+                    }
+                }
+                if (!pushed)
+                    need_cull = true;
+                settle();
+            }
+
+            // ---- one Tri4 packet of a leaf (mapping_cpu.art:379-410)
+            if (mode == 1) {
                 const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
                 ++tri_cursor;
                 const float4* tf = reinterpret_cast<const float4*>(tp);
@@ -272,33 +305,33 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                     need_cull = true;
                 }
             }
-        }
 
-        if (finished) {
-            has_ray = false;
-            if (ANY_HIT) {
-                if (a.prim_id)
-                    a.prim_id[ray_idx] = hit_prim;
-                if (a.ent_id)
-                    a.ent_id[ray_idx] = hit_ent;
-                if (hit_prim < 0) {
-                    if (STATS)
-                        ++st_unoccluded;
-                    if (a.accum) {
-                        // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample
-                        // accumulator: plain read-modify-write, the slot is owned by this ray.
-                        float* dst = a.accum + ((int64_t)a.ray_id[ray_idx] - a.id_base) * 3;
-                        dst[0] += a.cr[ray_idx] * a.inv_spi;
-                        dst[1] += a.cg[ray_idx] * a.inv_spi;
-                        dst[2] += a.cb[ray_idx] * a.inv_spi;
+            if (finished) {
+                has_ray = false;
+                if (ANY_HIT) {
+                    if (a.prim_id)
+                        a.prim_id[ray_idx] = hit_prim;
+                    if (a.ent_id)
+                        a.ent_id[ray_idx] = hit_ent;
+                    if (hit_prim < 0) {
+                        if (STATS)
+                            ++st_unoccluded;
+                        if (a.accum) {
+                            // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample
+                            // accumulator: plain read-modify-write, the slot is owned by this ray.
+                            float* dst = a.accum + ((int64_t)a.ray_id[ray_idx] - a.id_base) * 3;
+                            dst[0] += a.cr[ray_idx] * a.inv_spi;
+                            dst[1] += a.cg[ray_idx] * a.inv_spi;
+                            dst[2] += a.cb[ray_idx] * a.inv_spi;
+                        }
                     }
+                } else {
+                    a.ent_id[ray_idx]  = hit_ent;
+                    a.prim_id[ray_idx] = hit_prim;
+                    a.t[ray_idx]       = tmax;
+                    a.u[ray_idx]       = hit_u;
+                    a.v[ray_idx]       = hit_v;
                 }
-            } else {
-                a.ent_id[ray_idx]  = hit_ent;
-                a.prim_id[ray_idx] = hit_prim;
-                a.t[ray_idx]       = tmax;
-                a.u[ray_idx]       = hit_u;
-                a.v[ray_idx]       = hit_v;
             }
         }
     }
