@@ -15,6 +15,7 @@
 #include <memory>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,6 +30,7 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
+void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 } // namespace igdev
 
 using namespace igdev;
@@ -108,13 +110,16 @@ struct igd_device {
     DevBuf<float> primary[2], secondary, accum;
     DevBuf<QueueState> qs;
     DevBuf<float> list_rays;
-    DevBuf<uint2> stack_overflow; // behind the 16-entry LDS stack: 48 more entries per traversal thread
 
     // framebuffer
     int fb_w = 0, fb_h = 0;
     DevBuf<float> fb;
     std::vector<float> fb_host;
     bool fb_host_dirty = true;
+
+    // Once at most this many paths are alive the remaining bounces run in one launch (tail.hip).
+    // IGD_TAIL_THRESHOLD overrides (0 disables).
+    uint32_t tail_threshold = 131072;
 
     // statistics
     igd_stats stats{};
@@ -374,11 +379,12 @@ void render(igd_device* d, const igd_render_settings* rs)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
 
     QueueState host_qs;
-    HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, camera_rays), st));
+    HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
 
     for (int64_t first = 0; first < total; first += chunk_rays) {
         const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
         HIP_CHECK(hipMemsetAsync(d->accum.ptr, 0, (size_t)n * 3 * sizeof(float), st));
+        HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, error_flags), st)); // queue sizes + work counters
 
         int in_slot = 0;
         GenerateArgs ga{};
@@ -468,7 +474,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             // The host only needs to know when the stream ran dry; look at the counter after every
             // round while rounds are long, every 4th once they are short.
             ++rounds_since_check;
-            const int interval = live > 262144u ? 1 : 4;
+            const int interval = (d->tail_threshold > 0 || live > 262144u) ? 1 : 4;
             if (rounds_since_check >= interval) {
                 readQueueState(d, host_qs);
                 rounds_since_check = 0;
@@ -477,6 +483,21 @@ void render(igd_device* d, const igd_render_settings* rs)
                 live = host_qs.primary_count[in_slot];
                 if (live == 0)
                     break;
+                if (live <= d->tail_threshold) {
+                    // few paths left: follow each to its end in one launch instead of ~50 more rounds
+                    TailArgs tl{};
+                    tl.scene    = d->dscene;
+                    tl.in       = d->primaryCols(in_slot);
+                    tl.in_count = &qs->primary_count[in_slot];
+                    tl.qs       = qs;
+                    tl.accum    = d->accum.ptr;
+                    tl.id_base  = first;
+                    tl.frame    = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
+                    tl.inv_spi  = inv;
+                    const int tail_grid = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
+                    timed(5, [&] { launch_tail(tl, counters, tail_grid, st); });
+                    break;
+                }
             }
             if (round > d->dscene.tech.max_depth + 8)
                 throw HipError{ IGD_ERR_DEVICE, "igd_render: wavefront loop did not terminate" };
@@ -502,10 +523,12 @@ void render(igd_device* d, const igd_render_settings* rs)
     d->stats.bounce_rays += host_qs.bounce_rays;
     d->stats.shadow_rays += host_qs.shadow_rays;
     d->stats.unoccluded += host_qs.unoccluded;
+    d->stats.tail_rays += host_qs.tail_rays;
+    if (host_qs.error_flags & 1u)
+        throw HipError{ IGD_ERR_DEVICE, "igd_render: traversal stack overflow (BVH deeper than the LDS stack)" };
     d->stats.nodes_primary += host_qs.nodes[0], d->stats.nodes_secondary += host_qs.nodes[1];
     d->stats.tris_primary += host_qs.tris[0], d->stats.tris_secondary += host_qs.tris[1];
     d->stats.leaves_primary += host_qs.leaves[0], d->stats.leaves_secondary += host_qs.leaves[1];
-    HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(qs) + offsetof(QueueState, camera_rays), 0, sizeof(QueueState) - offsetof(QueueState, camera_rays), st));
     HIP_CHECK(hipStreamSynchronize(st));
 
     for (const Span& s : spans) {
@@ -516,7 +539,8 @@ void render(igd_device* d, const igd_render_settings* rs)
         case 1: d->stats.ms_traverse_primary += ms; break;
         case 2: d->stats.ms_shade += ms; break;
         case 3: d->stats.ms_traverse_secondary += ms; break;
-        default: d->stats.ms_resolve += ms; break;
+        case 4: d->stats.ms_resolve += ms; break;
+        default: d->stats.ms_tail += ms; break;
         }
     }
     d->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -548,7 +572,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     hipStream_t st = d->stream;
     QueueState* qs = d->qs.ptr;
     const uint32_t cnt = (uint32_t)n;
-    HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, camera_rays), st));
+    HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
     HIP_CHECK(hipMemcpyAsync(&qs->primary_count[0], &cnt, 4, hipMemcpyHostToDevice, st));
 
     TraverseArgs ta{};
@@ -596,7 +620,6 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
         d->stats.traverse_secondary_launches += (uint64_t)repeat;
     else
         d->stats.traverse_primary_launches += (uint64_t)repeat;
-    HIP_CHECK(hipMemset(reinterpret_cast<uint8_t*>(qs) + offsetof(QueueState, camera_rays), 0, sizeof(QueueState) - offsetof(QueueState, camera_rays)));
 
     std::vector<float> host(n * 5);
     HIP_CHECK(hipMemcpy(host.data(), out.ptr, host.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -678,6 +701,8 @@ igd_device* igd_create(const igd_setup* setup)
         d->num_cus = p.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         d->qs.alloc(1);
+        if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))
+            d->tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         HIP_CHECK(hipMemset(d->qs.ptr, 0, sizeof(QueueState)));
         dev = d.release();
     });

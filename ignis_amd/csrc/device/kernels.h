@@ -51,8 +51,10 @@ struct QueueState {
     uint32_t primary_count[2]; // sizes of the two primary streams
     uint32_t secondary_count;
     uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] shade, [2] traverse secondary
-    uint32_t error_flags;      // bit 0: traversal stack overflow
     uint32_t pad0;
+    // ---- from here on: cleared once per igd_render, not per chunk
+    uint32_t error_flags;      // bit 0: traversal stack overflow
+    uint32_t tail_rays;        // paths handed to the tail kernel (tail.hip)
     // statistics (Statistics.h:57-64)
     unsigned long long camera_rays, bounce_rays, shadow_rays, unoccluded;
     unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches
@@ -111,6 +113,23 @@ struct ShadeArgs {
     int32_t row_offset, row_stride; // tile sharding (same mapping as GenerateArgs)
     float inv_spi;
     int32_t list_mode; // rays came from the list emitter: pixel = ray id, flags 0
+};
+
+struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-11)
+    int32_t width, spi;
+    int32_t iteration, frame, seed;
+    int32_t row_offset, row_stride;
+};
+
+struct TailArgs {
+    DevScene scene;
+    PrimaryCols in;
+    const uint32_t* in_count;
+    QueueState* qs;
+    float* accum;
+    int64_t id_base;
+    ShadeFrame frame;
+    float inv_spi;
 };
 
 struct ResolveArgs {

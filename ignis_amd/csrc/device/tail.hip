@@ -1,0 +1,142 @@
+// tail.hip — finishes the last few thousand paths of an iteration in ONE launch.
+//
+// The wavefront loop pays three kernel launches per bounce; with max_depth 64 (diamond_scene) a
+// handful of paths bouncing inside the dielectrics keeps it alive for ~50 more rounds of nearly
+// empty launches, each costing a cold-start latency chain (the reference has the same long tail,
+// src/artic/driver/mapping_gpu.art:756-866, plus its host round trips). Once the live stream is
+// small, every remaining path is instead followed to its end by one lane:
+//   closest-hit traversal -> shade_vertex -> (any-hit traversal of the NEE ray) -> next bounce ...
+// using the same device code as the wavefront kernels (traverse_core.h, shade_core.h), so every
+// path produces bit-identical contributions and counters; only the scheduling differs.
+#include "shade_core.h"
+#include "traverse_core.h"
+
+namespace igdev {
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
+{
+    __shared__ StackLds s_stack;
+
+    const int tid      = threadIdx.x;
+    const int lane     = tid & 63;
+    const DevScene& sc = a.scene;
+    const uint32_t n   = *a.in_count;
+
+    uint32_t c_bounce = 0, c_shadow = 0, c_unoccluded = 0;
+    uint32_t c_nodes[2] = { 0, 0 }, c_tris[2] = { 0, 0 }, c_leaves[2] = { 0, 0 };
+    bool overflow = false;
+
+    for (uint32_t i = blockIdx.x * kBlockThreads + tid; i < n; i += gridDim.x * kBlockThreads) {
+        PathVertexIn in;
+        in.ray_id  = a.in.id[i];
+        in.org     = f3{ a.in.ox[i], a.in.oy[i], a.in.oz[i] };
+        in.dir     = f3{ a.in.dx[i], a.in.dy[i], a.in.dz[i] };
+        in.rnd     = a.in.rnd[i];
+        in.inv_pdf = a.in.payload[0][i];
+        in.contrib = Col{ a.in.payload[1][i], a.in.payload[2][i], a.in.payload[3][i] };
+        in.depth   = (int)a.in.payload[4][i];
+        in.eta     = a.in.payload[5][i];
+        float tmin = a.in.tmin[i], tmax = a.in.tmax[i];
+        uint32_t flags = a.in.flags[i];
+        float* acc     = a.accum + ((int64_t)in.ray_id - a.id_base) * 3;
+
+        for (;;) {
+            {
+                Traverser<false, STATS> tr;
+                tr.init_counters();
+                tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
+                while (!tr.finished)
+                    tr.step(sc, s_stack, tid);
+                in.ent  = tr.hit_ent;
+                in.prim = tr.hit_prim;
+                in.t = tr.tmax, in.u = tr.hit_u, in.v = tr.hit_v;
+                overflow |= tr.overflow;
+                if (STATS) {
+                    c_nodes[0] += tr.st_nodes;
+                    c_tris[0] += tr.st_tris;
+                    c_leaves[0] += tr.st_leaves;
+                }
+            }
+
+            PathVertexOut out;
+            shade_vertex(sc, a.frame, in, out);
+            if (out.has_radiance) {
+                acc[0] += out.radiance.r * a.inv_spi;
+                acc[1] += out.radiance.g * a.inv_spi;
+                acc[2] += out.radiance.b * a.inv_spi;
+            }
+
+            if (out.shadow) {
+                ++c_shadow;
+                Traverser<true, STATS> ts;
+                ts.init_counters();
+                ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, IG_RAY_FLAG_SHADOW);
+                while (!ts.finished)
+                    ts.step(sc, s_stack, tid);
+                overflow |= ts.overflow;
+                if (STATS) {
+                    c_nodes[1] += ts.st_nodes;
+                    c_tris[1] += ts.st_tris;
+                    c_leaves[1] += ts.st_leaves;
+                }
+                if (ts.hit_prim < 0) {
+                    ++c_unoccluded;
+                    acc[0] += out.s_col.r * a.inv_spi;
+                    acc[1] += out.s_col.g * a.inv_spi;
+                    acc[2] += out.s_col.b * a.inv_spi;
+                }
+            }
+
+            if (!out.bounce)
+                break;
+            ++c_bounce;
+            in.org     = out.b_org;
+            in.dir     = out.b_dir;
+            in.rnd     = out.b_rnd;
+            in.inv_pdf = out.b_inv_pdf;
+            in.contrib = out.b_contrib;
+            in.depth   = out.b_depth;
+            in.eta     = out.b_eta;
+            tmin       = kRayOffset;
+            tmax       = kFltMax;
+            flags      = IG_RAY_FLAG_BOUNCE;
+        }
+    }
+
+    if (overflow)
+        atomicOr(&a.qs->error_flags, 1u);
+
+    const uint32_t b = wave_sum_u32(c_bounce), s = wave_sum_u32(c_shadow), u = wave_sum_u32(c_unoccluded);
+    if (lane == 0) {
+        if (b) atomicAdd(&a.qs->bounce_rays, (unsigned long long)b);
+        if (s) atomicAdd(&a.qs->shadow_rays, (unsigned long long)s);
+        if (u) atomicAdd(&a.qs->unoccluded, (unsigned long long)u);
+    }
+    if (STATS) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t nn = wave_sum_u32(c_nodes[k]), tt = wave_sum_u32(c_tris[k]), ll = wave_sum_u32(c_leaves[k]);
+            if (lane == 0) {
+                atomicAdd(&a.qs->nodes[k], (unsigned long long)nn);
+                atomicAdd(&a.qs->tris[k], (unsigned long long)tt);
+                atomicAdd(&a.qs->leaves[k], (unsigned long long)ll);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0)
+        a.qs->tail_rays += n;
+}
+
+template __global__ void k_tail<false>(const TailArgs);
+template __global__ void k_tail<true>(const TailArgs);
+
+void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream)
+{
+    if (stats)
+        hipLaunchKernelGGL((k_tail<true>), dim3((unsigned)grid_blocks), dim3(kBlockThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL((k_tail<false>), dim3((unsigned)grid_blocks), dim3(kBlockThreads), 0, stream, args);
+}
+
+} // namespace igdev

@@ -1,0 +1,286 @@
+// traverse_core.h — per-lane two-level BVH8 traversal state machine (gfx950).
+//
+// One ray per lane. The stack lives in LDS, [entry][thread] layout (conflict-free
+// ds_read/write_b64). Scene level and shape level share ONE inner-node section and ONE stack:
+// entering an instance saves the scene top, pushes a sentinel and switches the node base offset.
+// step() runs the sections in pipeline order  entity leaf -> inner node -> triangle packet, with
+// cheap state transitions (settle) in between, so a lane can walk a whole instance (leaf test,
+// shape root, triangles) in one step and the lanes of a wave stay in phase.
+//
+// Per-ray semantics (visit order, culling points, acceptance `t <= tmax`, hence tie-breaking) are
+// those of the reference CPU device, `cpu_traverse_helper(_prim)` with vector width 1
+// (src/artic/traversal/mapping_cpu.art:282-518), on the same Node8 / Tri4 / EntityLeaf1 bytes,
+// so hits AND the visited-node / tested-triangle counts equal the CPU oracle's
+// (DESIGN.md "Traversal order").
+#pragma once
+
+#include "dev_math.h"
+#include "kernels.h"
+
+namespace igdev {
+
+constexpr int kLdsStack     = 24;  // 24 entries * 256 threads * 8 B = 48 KiB per workgroup (3 workgroups per CU)
+constexpr int kBlockThreads = 256;
+
+using StackLds = uint2[kLdsStack][kBlockThreads];
+
+template <bool ANY_HIT, bool STATS>
+struct Traverser {
+    // ---- ray + hit
+    RayT gray, cur;
+    float tmin, tmax;
+    uint32_t rflags;
+    float hit_u, hit_v;
+    int hit_prim, hit_ent;
+    // ---- control
+    int top_node;
+    float top_tmin;
+    int ptr;
+    int level; // 0 scene BVH, 1 shape BVH
+    int mode;  // 0 stack driven, 1 inside a triangle leaf, 2 inside an entity leaf run
+    int ent_cursor, tri_cursor;
+    uint32_t node_off, tri_off;
+    int cur_ent;
+    bool ent_last, need_cull, finished, overflow;
+    uint32_t st_nodes, st_tris, st_leaves;
+
+    IG_DEV void init_counters()
+    {
+        overflow = false;
+        st_nodes = st_tris = st_leaves = 0;
+        finished = true;
+    }
+
+    // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here
+    // the stack is kLdsStack entries of LDS per lane; deeper pushes set `overflow` (the launch then
+    // raises error bit 0 and igd_render fails loudly).
+    IG_DEV void push_entry(StackLds& st, int tid, int n, float t)
+    {
+        ++ptr;
+        if (ptr < kLdsStack)
+            st[ptr][tid] = make_uint2((uint32_t)n, igm_bits(t));
+        else
+            overflow = true;
+    }
+    IG_DEV void pop_top(StackLds& st, int tid)
+    {
+        const uint2 e = st[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
+        top_node      = (int)e.x;
+        top_tmin      = igm_float(e.y);
+        --ptr;
+    }
+
+    IG_DEV void begin(const DevScene& sc, StackLds& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
+    {
+        gray   = make_ray_terms(org, dir);
+        cur    = gray;
+        tmin   = tmin_;
+        tmax   = tmax_;
+        rflags = flags;
+        hit_u = hit_v = 0;
+        hit_prim = hit_ent = -1;
+        level = 0, mode = 0;
+        ent_cursor = tri_cursor = 0;
+        tri_off    = 0;
+        cur_ent    = -1;
+        ent_last   = true;
+        need_cull  = true;
+        finished   = false;
+        node_off   = sc.scene_nodes_off;
+        // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
+        ptr      = -1;
+        top_node = 0, top_tmin = kFltMax;
+        push_entry(st, tid, top_node, top_tmin);
+        top_node = sc.scene_node_count ? 1 : 0;
+        top_tmin = tmin;
+    }
+
+    // Cheap state transitions up to the next heavy action: an entity-leaf step (mode 2), an inner
+    // node on top (mode 0, top_node > 0), a triangle packet (mode 1), or the end of the ray.
+    // The cull points are exactly the reference's (mapping_cpu.art:326-347): at level entry, after
+    // a leaf and after an inner node that pushed nothing.
+    IG_DEV void settle(const DevScene& sc, StackLds& st, int tid)
+    {
+        while (mode == 0 && !finished) {
+            if (need_cull) {
+                while (top_node != 0 && !(top_tmin <= tmax))
+                    pop_top(st, tid);
+                need_cull = false;
+            }
+            if (top_node == 0) {
+                if (level == 1) {
+                    // shape BVH exhausted: back to the scene leaf run (mapping_cpu.art:489-508)
+                    level = 0;
+                    pop_top(st, tid); // saved scene-level top
+                    cur      = gray;
+                    node_off = sc.scene_nodes_off;
+                    if (ent_last)
+                        need_cull = true;
+                    else
+                        mode = 2;
+                } else {
+                    finished = true;
+                }
+            } else if (top_node > 0) {
+                break; // inner node pending
+            } else {
+                // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
+                // hit is dropped, its items have no effect in the reference either
+                const bool active = top_tmin <= tmax;
+                if (level)
+                    tri_cursor = ~top_node;
+                else
+                    ent_cursor = ~top_node;
+                pop_top(st, tid);
+                if (active)
+                    mode = level ? 1 : 2;
+                else
+                    need_cull = true;
+            }
+        }
+    }
+
+    // One pipeline pass: entity leaf -> inner node -> triangle packet. Call while !finished.
+    IG_DEV void step(const DevScene& sc, StackLds& st, int tid)
+    {
+        const uint8_t* geom = sc.geom;
+        settle(sc, st, tid);
+
+        // ---- one entity leaf of the current run (mapping_cpu.art:481-515)
+        if (mode == 2) {
+            const float4* lf = reinterpret_cast<const float4*>(sc.leaves + ent_cursor);
+            const uint2 ext  = sc.leaf_ext[ent_cursor];
+            ++ent_cursor;
+            const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
+            const int entity_id   = (int)igm_bits(l0.w);
+            const uint32_t lflags = igm_bits(l5.x);
+            ent_last              = entity_id < 0;
+            if (STATS)
+                ++st_leaves;
+            bool enter = false;
+            // check_ray_visibility (traversal/ray.art:51)
+            if ((rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK)) {
+                float entry, exit;
+                slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
+                enter = (entry <= exit) & (exit >= 0) & (entry <= tmax);
+            }
+            if (enter) {
+                const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4];
+                m34 m;
+                m.c0 = f3{ l2.x, l2.y, l2.z };
+                m.c1 = f3{ l2.w, l3.x, l3.y };
+                m.c2 = f3{ l3.z, l3.w, l4.x };
+                m.c3 = f3{ l4.y, l4.z, l4.w };
+                // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
+                cur     = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                cur_ent = entity_id & 0x7FFFFFFF;
+                // save the scene-level top, then a fresh stack: sentinel + shape root
+                push_entry(st, tid, top_node, top_tmin);
+                push_entry(st, tid, 0, kFltMax);
+                top_node  = 1;
+                top_tmin  = tmin;
+                level     = 1;
+                mode      = 0;
+                need_cull = true;
+                node_off  = ext.x;
+                tri_off   = ext.y;
+            } else if (ent_last) {
+                mode      = 0;
+                need_cull = true;
+            }
+            settle(sc, st, tid);
+        }
+
+        // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
+        if (mode == 0 && !finished) {
+            const uint8_t* np = geom + node_off + (uint32_t)(top_node - 1) * 256u;
+            pop_top(st, tid);
+            const float4* nf = reinterpret_cast<const float4*>(np);
+            const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
+            if (STATS)
+                ++st_nodes;
+            bool pushed = false;
+            // two halves of four children keep the live register set small
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float bnd[6][4];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const float4 x = nf[2 * k + h];
+                    bnd[k][0] = x.x, bnd[k][1] = x.y, bnd[k][2] = x.z, bnd[k][3] = x.w;
+                }
+                const int4 c4   = nc[h];
+                const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float entry, exit;
+                    slab_test(cur, tmin, tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
+                    const bool hit = (ch[i] != 0) & !(exit < entry);
+                    if (hit) {
+                        // push (becomes the top) if nearer than the current top, else push_after
+                        const bool front = ANY_HIT || (top_tmin > entry);
+                        push_entry(st, tid, front ? top_node : ch[i], front ? top_tmin : entry);
+                        if (front) {
+                            top_node = ch[i];
+                            top_tmin = entry;
+                        }
+                        pushed = true;
+                    }
+                }
+            }
+            if (!pushed)
+                need_cull = true;
+            settle(sc, st, tid);
+        }
+
+        // ---- one Tri4 packet of a leaf (mapping_cpu.art:379-410)
+        if (mode == 1) {
+            const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
+            ++tri_cursor;
+            const float4* tf = reinterpret_cast<const float4*>(tp);
+            float q[12][4];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const float4 x = tf[k];
+                q[k][0] = x.x, q[k][1] = x.y, q[k][2] = x.z, q[k][3] = x.w;
+            }
+            const int4 pid4  = reinterpret_cast<const int4*>(tp)[12];
+            const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
+            bool valid       = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                valid = valid & (pid[i] != -1);
+                if (valid && !(ANY_HIT && finished)) {
+                    if (STATS)
+                        ++st_tris;
+                    float t, u, v;
+                    if (tri_test(cur, tmin, tmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
+                                 f3{ q[6][i], q[7][i], q[8][i] }, f3{ q[9][i], q[10][i], q[11][i] }, t, u, v)) {
+                        tmax     = t;
+                        hit_u    = u;
+                        hit_v    = v;
+                        hit_prim = pid[i] & 0x7FFFFFFF;
+                        hit_ent  = cur_ent;
+                        if (ANY_HIT)
+                            finished = true;
+                    }
+                }
+            }
+            if (pid[3] < 0) {
+                mode      = 0;
+                need_cull = true;
+            }
+        }
+    }
+};
+
+// wave-level sum of a per-lane counter
+IG_DEV uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    return v;
+}
+
+} // namespace igdev

@@ -70,8 +70,10 @@ typedef struct igd_stats {
     uint64_t traverse_primary_launches, traverse_secondary_launches;
     double ms_generate, ms_traverse_primary, ms_shade, ms_traverse_secondary, ms_resolve; /* HIP-event time, acquire_stats */
     double ms_total;   /* wall time inside igd_render, host clock */
-    uint32_t rounds;   /* bounce rounds executed */
+    uint32_t rounds;   /* wavefront bounce rounds executed */
     uint32_t pad;
+    uint64_t tail_rays; /* paths finished by the single-launch tail kernel instead of more rounds */
+    double ms_tail;
 } igd_stats;
 
 /* IDeviceInterface::getVersion (IDeviceInterface.h:11) */
