@@ -141,7 +141,7 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(a_per_launch)}
 
-        stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_resolve")}
+        stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -82,8 +82,8 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-constexpr int kPrimaryCols   = 22;
-constexpr int kSecondaryCols = 12;
+constexpr int kPrimaryCols   = 22; // 5 vector columns (20 floats) + eta + hit_v
+constexpr int kSecondaryCols = 12; // 3 vector columns
 
 } // namespace
 
@@ -133,22 +133,19 @@ struct igd_device {
             (void)hipStreamDestroy(stream);
     }
 
+    // column c of a stream starts at base + c * capacity floats; vector columns are 4 floats wide
     PrimaryCols primaryCols(int slot) const
     {
         float* b       = primary[slot].ptr;
         const size_t c = capacity;
         PrimaryCols p;
-        p.id      = reinterpret_cast<int32_t*>(b + 0 * c);
-        p.ox      = b + 1 * c, p.oy = b + 2 * c, p.oz = b + 3 * c;
-        p.dx      = b + 4 * c, p.dy = b + 5 * c, p.dz = b + 6 * c;
-        p.tmin    = b + 7 * c, p.tmax = b + 8 * c;
-        p.flags   = reinterpret_cast<uint32_t*>(b + 9 * c);
-        p.ent_id  = reinterpret_cast<int32_t*>(b + 10 * c);
-        p.prim_id = reinterpret_cast<int32_t*>(b + 11 * c);
-        p.t       = b + 12 * c, p.u = b + 13 * c, p.v = b + 14 * c;
-        p.rnd     = reinterpret_cast<uint32_t*>(b + 15 * c);
-        for (int k = 0; k < 6; ++k)
-            p.payload[k] = b + (size_t)(16 + k) * c;
+        p.rayA  = reinterpret_cast<float4*>(b + 0 * c);
+        p.rayB  = reinterpret_cast<float4*>(b + 4 * c);
+        p.meta  = reinterpret_cast<int4*>(b + 8 * c);
+        p.pay   = reinterpret_cast<float4*>(b + 12 * c);
+        p.hit   = reinterpret_cast<float4*>(b + 16 * c);
+        p.eta   = b + 20 * c;
+        p.hit_v = b + 21 * c;
         return p;
     }
 
@@ -156,13 +153,11 @@ struct igd_device {
     {
         float* b       = secondary.ptr;
         const size_t c = capacity;
-        SecondaryCols s;
-        s.id   = reinterpret_cast<int32_t*>(b);
-        s.ox   = b + 1 * c, s.oy = b + 2 * c, s.oz = b + 3 * c;
-        s.dx   = b + 4 * c, s.dy = b + 5 * c, s.dz = b + 6 * c;
-        s.tmin = b + 7 * c, s.tmax = b + 8 * c;
-        s.cr   = b + 9 * c, s.cg = b + 10 * c, s.cb = b + 11 * c;
-        return s;
+        SecondaryCols q;
+        q.rayA = reinterpret_cast<float4*>(b + 0 * c);
+        q.rayB = reinterpret_cast<float4*>(b + 4 * c);
+        q.col  = reinterpret_cast<float4*>(b + 8 * c);
+        return q;
     }
 
     void ensureStreams(size_t needed)
@@ -180,15 +175,10 @@ struct igd_device {
         secondary.release();
         secondary.alloc(capacity * kSecondaryCols);
         accum.release();
-        accum.alloc(capacity * 3);
+        accum.alloc(capacity * 4);
     }
 
     int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
-    void bindStack(TraverseArgs& t)
-    {
-        t.stack_overflow   = nullptr;
-        t.overflow_entries = 0;
-    }
     int shadeGrid() const { return num_cus * 8; }
 
     hipEvent_t event(size_t i)
@@ -383,7 +373,7 @@ void render(igd_device* d, const igd_render_settings* rs)
 
     for (int64_t first = 0; first < total; first += chunk_rays) {
         const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
-        HIP_CHECK(hipMemsetAsync(d->accum.ptr, 0, (size_t)n * 3 * sizeof(float), st));
+        HIP_CHECK(hipMemsetAsync(d->accum.ptr, 0, (size_t)n * 4 * sizeof(float), st));
         HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, error_flags), st)); // queue sizes + work counters
 
         int in_slot = 0;
@@ -414,13 +404,11 @@ void render(igd_device* d, const igd_render_settings* rs)
             const PrimaryCols in = d->primaryCols(in_slot);
             TraverseArgs ta{};
             ta.scene = d->dscene;
-            ta.ox = in.ox, ta.oy = in.oy, ta.oz = in.oz, ta.dx = in.dx, ta.dy = in.dy, ta.dz = in.dz;
-            ta.tmin = in.tmin, ta.tmax = in.tmax, ta.flags = in.flags;
+            ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
             ta.count        = &qs->primary_count[in_slot];
             ta.work_counter = &qs->work_counter[0];
             ta.qs           = qs;
-            d->bindStack(ta);
-            ta.ent_id = in.ent_id, ta.prim_id = in.prim_id, ta.t = in.t, ta.u = in.u, ta.v = in.v;
+            ta.hit = in.hit, ta.hit_v = in.hit_v;
             timed(1, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
 
             // ---- sort + shade + compact (K3, K4, K5, K9)
@@ -433,13 +421,10 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.out_count = &qs->primary_count[in_slot ^ 1];
             sa.sec_count = &qs->secondary_count;
             sa.qs        = qs;
-            sa.accum     = d->accum.ptr;
+            sa.accum     = reinterpret_cast<float4*>(d->accum.ptr);
             sa.id_base   = first;
-            sa.width = rs->width, sa.height = rs->height, sa.spi = rs->spi;
-            sa.iteration = rs->iteration, sa.frame = rs->frame, sa.seed = rs->user_seed;
-            sa.row_offset = row_offset, sa.row_stride = row_stride;
+            sa.frame     = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
             sa.inv_spi   = inv;
-            sa.list_mode = list_mode ? 1 : 0;
             timed(2, [&] {
                 launch_shade(sa, d->shadeGrid(), st);
                 launch_round_end(qs, in_slot, st);
@@ -449,16 +434,13 @@ void render(igd_device* d, const igd_render_settings* rs)
             const SecondaryCols sec = d->secondaryCols();
             TraverseArgs tb{};
             tb.scene = d->dscene;
-            tb.ox = sec.ox, tb.oy = sec.oy, tb.oz = sec.oz, tb.dx = sec.dx, tb.dy = sec.dy, tb.dz = sec.dz;
-            tb.tmin = sec.tmin, tb.tmax = sec.tmax, tb.flags = nullptr;
+            tb.rayA = sec.rayA, tb.rayB = sec.rayB, tb.meta = nullptr;
             tb.uniform_flags = IG_RAY_FLAG_SHADOW;
             tb.count         = &qs->secondary_count;
             tb.work_counter  = &qs->work_counter[2];
             tb.qs            = qs;
-            d->bindStack(tb);
-            tb.ray_id        = sec.id;
-            tb.cr = sec.cr, tb.cg = sec.cg, tb.cb = sec.cb;
-            tb.accum   = d->accum.ptr;
+            tb.col     = sec.col;
+            tb.accum   = reinterpret_cast<float4*>(d->accum.ptr);
             tb.id_base = first;
             tb.inv_spi = inv;
             timed(3, [&] {
@@ -490,7 +472,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     tl.in       = d->primaryCols(in_slot);
                     tl.in_count = &qs->primary_count[in_slot];
                     tl.qs       = qs;
-                    tl.accum    = d->accum.ptr;
+                    tl.accum    = reinterpret_cast<float4*>(d->accum.ptr);
                     tl.id_base  = first;
                     tl.frame    = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
                     tl.inv_spi  = inv;
@@ -504,7 +486,7 @@ void render(igd_device* d, const igd_render_settings* rs)
         }
 
         ResolveArgs ra{};
-        ra.accum             = d->accum.ptr;
+        ra.accum             = reinterpret_cast<const float4*>(d->accum.ptr);
         ra.fb                = d->fb.ptr;
         ra.width             = rs->width;
         ra.spi               = rs->spi;
@@ -559,13 +541,17 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
         return;
     const size_t n = (size_t)count;
 
-    // AoS host list -> SoA columns in HBM
-    std::vector<float> soa(n * 8);
-    for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 8; ++c)
-            soa[(size_t)c * n + i] = rays[i * 8 + c];
+    // host list (8 floats per ray) -> rayA = (org, tmin), rayB = (dir, tmax) columns in HBM
+    std::vector<float> cols(n * 8);
+    for (size_t i = 0; i < n; ++i) {
+        const float* r = rays + i * 8;
+        float* ra      = cols.data() + i * 4;
+        float* rb      = cols.data() + n * 4 + i * 4;
+        ra[0] = r[0], ra[1] = r[1], ra[2] = r[2], ra[3] = r[6];
+        rb[0] = r[3], rb[1] = r[4], rb[2] = r[5], rb[3] = r[7];
+    }
     DevBuf<float> in, out;
-    in.upload(soa.data(), soa.size());
+    in.upload(cols.data(), cols.size());
     out.alloc(n * 5);
     HIP_CHECK(hipMemset(out.ptr, 0xFF, n * 5 * sizeof(float)));
 
@@ -576,19 +562,16 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     HIP_CHECK(hipMemcpyAsync(&qs->primary_count[0], &cnt, 4, hipMemcpyHostToDevice, st));
 
     TraverseArgs ta{};
-    ta.scene = d->dscene;
-    float* b = in.ptr;
-    ta.ox = b, ta.oy = b + n, ta.oz = b + 2 * n, ta.dx = b + 3 * n, ta.dy = b + 4 * n, ta.dz = b + 5 * n;
-    ta.tmin = b + 6 * n, ta.tmax = b + 7 * n;
-    ta.flags         = nullptr;
+    ta.scene         = d->dscene;
+    ta.rayA          = reinterpret_cast<const float4*>(in.ptr);
+    ta.rayB          = reinterpret_cast<const float4*>(in.ptr + n * 4);
+    ta.meta          = nullptr;
     ta.uniform_flags = ray_flags;
     ta.count         = &qs->primary_count[0];
     ta.work_counter  = &qs->work_counter[0];
     ta.qs            = qs;
-    d->bindStack(ta);
-    ta.ent_id        = reinterpret_cast<int32_t*>(out.ptr);
-    ta.prim_id       = reinterpret_cast<int32_t*>(out.ptr + n);
-    ta.t = out.ptr + 2 * n, ta.u = out.ptr + 3 * n, ta.v = out.ptr + 4 * n;
+    ta.hit           = reinterpret_cast<float4*>(out.ptr);
+    ta.hit_v         = out.ptr + n * 4;
 
     const bool stats = d->setup.acquire_stats >= 2;
     if (repeat < 1)
@@ -623,17 +606,20 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
 
     std::vector<float> host(n * 5);
     HIP_CHECK(hipMemcpy(host.data(), out.ptr, host.size() * sizeof(float), hipMemcpyDeviceToHost));
-    if (ent_id)
-        std::memcpy(ent_id, host.data(), n * 4);
-    if (prim_id)
-        std::memcpy(prim_id, host.data() + n, n * 4);
-    if (!any_hit) {
-        if (t)
-            std::memcpy(t, host.data() + 2 * n, n * 4);
-        if (u)
-            std::memcpy(u, host.data() + 3 * n, n * 4);
-        if (v)
-            std::memcpy(v, host.data() + 4 * n, n * 4);
+    for (size_t i = 0; i < n; ++i) {
+        const float* h = host.data() + i * 4;
+        if (ent_id)
+            std::memcpy(&ent_id[i], &h[0], 4);
+        if (prim_id)
+            std::memcpy(&prim_id[i], &h[1], 4);
+        if (!any_hit) {
+            if (t)
+                t[i] = h[2];
+            if (u)
+                u[i] = h[3];
+            if (v)
+                v[i] = host[n * 4 + i];
+        }
     }
 }
 

@@ -27,22 +27,27 @@ struct DevScene {
     ig_technique tech;
 };
 
-// SoA ray queue columns (src/artic/driver/streams.art:1-32 restated for HBM: one allocation per
-// stream, column c at base + c * capacity).
+// Ray queues in HBM. The reference's streams are one float per column (src/artic/driver/streams.art:
+// 1-32); on CDNA a lane should move 16 bytes per memory instruction, so the same fields are kept as
+// structure-of-arrays of 16-byte groups (5 vector columns + 2 scalar columns = 88 B per ray, the
+// reference's live size):
+//   rayA = (org.xyz, tmin)   rayB = (dir.xyz, tmax)   meta = (id, flags, rnd counter, depth)
+//   pay  = (inv_pdf, contrib.rgb)   eta   |   hit = (ent_id, prim_id, t, u)   hit_v
 struct PrimaryCols {
-    int32_t* id;
-    float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
-    uint32_t* flags;
-    int32_t *ent_id, *prim_id;
-    float *t, *u, *v;
-    uint32_t* rnd;
-    float* payload[6]; // inv_pdf, contrib rgb, depth, eta (technique/pathtracer.art:7-12), SoA
+    float4* rayA;
+    float4* rayB;
+    int4* meta;
+    float4* pay;
+    float* eta;
+    float4* hit; // ent_id / prim_id stored as bit patterns
+    float* hit_v;
 };
 
+// Shadow-ray queue: rayA = (org.xyz, tmin), rayB = (dir.xyz, tmax), col = (rgb, ray id bits)
 struct SecondaryCols {
-    int32_t* id;
-    float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
-    float *cr, *cg, *cb;
+    float4* rayA;
+    float4* rayB;
+    float4* col;
 };
 
 // Device-resident queue state: no host round trip per bounce (the reference reads counters back
@@ -50,7 +55,7 @@ struct SecondaryCols {
 struct QueueState {
     uint32_t primary_count[2]; // sizes of the two primary streams
     uint32_t secondary_count;
-    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] shade, [2] traverse secondary
+    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [2] traverse secondary
     uint32_t pad0;
     // ---- from here on: cleared once per igd_render, not per chunk
     uint32_t error_flags;      // bit 0: traversal stack overflow
@@ -62,23 +67,20 @@ struct QueueState {
 
 struct TraverseArgs {
     DevScene scene;
-    // input rays (SoA). flags == nullptr -> uniform_flags
-    const float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
-    const uint32_t* flags;
+    // input rays: rayA = (org, tmin), rayB = (dir, tmax); meta == nullptr -> uniform_flags
+    const float4* rayA;
+    const float4* rayB;
+    const int4* meta;
     uint32_t uniform_flags;
     const uint32_t* count;  // device pointer to the number of rays
     uint32_t* work_counter; // zero before launch
     QueueState* qs;
-    // traversal-stack overflow behind the LDS stack: [entry][grid thread], overflow_entries deep
-    uint2* stack_overflow;
-    int32_t overflow_entries;
-    // closest-hit outputs
-    int32_t *ent_id, *prim_id;
-    float *t, *u, *v;
-    // any-hit epilogue (shadow rays): unoccluded rays add their colour into accum[(id - id_base) * 3]
-    const int32_t* ray_id;
-    const float *cr, *cg, *cb;
-    float* accum;
+    // outputs: hit = (ent_id, prim_id, t, u), hit_v = v. Any-hit launches may leave them null.
+    float4* hit;
+    float* hit_v;
+    // any-hit epilogue (shadow rays): unoccluded rays add col.rgb into accum[id - id_base], id = bits(col.w)
+    const float4* col;
+    float4* accum;
     int64_t id_base;
     float inv_spi;
 };
@@ -97,6 +99,12 @@ struct GenerateArgs {
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
 };
 
+struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-11)
+    int32_t width, spi;
+    int32_t iteration, frame, seed;
+    int32_t row_offset, row_stride;
+};
+
 struct ShadeArgs {
     DevScene scene;
     PrimaryCols in;
@@ -106,19 +114,10 @@ struct ShadeArgs {
     uint32_t* out_count;
     uint32_t* sec_count;
     QueueState* qs;
-    float* accum;
-    int64_t id_base; // global ray id of accum[0]
-    int32_t width, height, spi;
-    int32_t iteration, frame, seed;
-    int32_t row_offset, row_stride; // tile sharding (same mapping as GenerateArgs)
+    float4* accum;   // per-sample radiance accumulators, (r, g, b, unused)
+    int64_t id_base; // local ray id of accum[0]
+    ShadeFrame frame;
     float inv_spi;
-    int32_t list_mode; // rays came from the list emitter: pixel = ray id, flags 0
-};
-
-struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-11)
-    int32_t width, spi;
-    int32_t iteration, frame, seed;
-    int32_t row_offset, row_stride;
 };
 
 struct TailArgs {
@@ -126,14 +125,14 @@ struct TailArgs {
     PrimaryCols in;
     const uint32_t* in_count;
     QueueState* qs;
-    float* accum;
+    float4* accum;
     int64_t id_base;
     ShadeFrame frame;
     float inv_spi;
 };
 
 struct ResolveArgs {
-    const float* accum;
+    const float4* accum;
     float* fb;
     int32_t width, spi;
     int32_t row_offset, row_stride;

@@ -68,20 +68,12 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         flags   = IG_RAY_FLAG_CAMERA;
     }
 
-    a.out.id[i] = (int32_t)lid;
-    a.out.ox[i] = org.x, a.out.oy[i] = org.y, a.out.oz[i] = org.z;
-    a.out.dx[i] = dir.x, a.out.dy[i] = dir.y, a.out.dz[i] = dir.z;
-    a.out.tmin[i]  = tmin;
-    a.out.tmax[i]  = tmax;
-    a.out.flags[i] = flags;
-    a.out.rnd[i]   = rnd.counter;
-    // init_pt_raypayload (technique/pathtracer.art:33-38)
-    a.out.payload[0][i] = 0;
-    a.out.payload[1][i] = 1;
-    a.out.payload[2][i] = 1;
-    a.out.payload[3][i] = 1;
-    a.out.payload[4][i] = 1;
-    a.out.payload[5][i] = 1;
+    a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
+    a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
+    // init_pt_raypayload (technique/pathtracer.art:33-38): inv_pdf 0, contrib white, depth 1, eta 1
+    a.out.meta[i] = make_int4((int32_t)lid, (int32_t)flags, (int32_t)rnd.counter, 1);
+    a.out.pay[i]  = make_float4(0, 1, 1, 1);
+    a.out.eta[i]  = 1;
 }
 
 // ---------------------------------------------------------------- k_shade
@@ -94,6 +86,8 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
     __shared__ uint16_t s_perm[kShadeThreads];
+    __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
+    __shared__ uint32_t s_base[2];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -103,10 +97,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
     const int M        = (int)sc.material_count;
     const bool do_sort = (M + 2) <= kMaxSortBins;
 
-    ShadeFrame fr;
-    fr.width = a.width, fr.spi = a.spi;
-    fr.iteration = a.iteration, fr.frame = a.frame, fr.seed = a.seed;
-    fr.row_offset = a.row_offset, fr.row_stride = a.row_stride;
+    const ShadeFrame fr = a.frame;
 
     const uint32_t chunks = (n + kShadeThreads - 1) / kShadeThreads;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -118,25 +109,31 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
             const uint32_t i = base + tid;
             int key          = M + 1;
             if (i < n) {
-                const int ent = a.in.ent_id[i];
+                const int ent = (int)igm_bits(a.in.hit[i].x);
                 key           = ent < 0 ? M : sc.entity_material[ent];
             }
             s_hist[tid] = 0;
             __syncthreads();
             const uint32_t r = atomicAdd(&s_hist[key], 1u);
             __syncthreads();
-            // inclusive Hillis-Steele scan over the bins
-            uint32_t val = s_hist[tid];
-            s_scan[tid]  = val;
-            __syncthreads();
+            // inclusive scan over the 256 bins by the first wave: 4 bins per lane + wave shuffle scan
+            if (tid < 64) {
+                const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+                const uint32_t local = h0 + h1 + h2 + h3;
+                uint32_t incl        = local;
 #pragma unroll
-            for (int off = 1; off < kShadeThreads; off <<= 1) {
-                const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
-                __syncthreads();
-                val += add;
-                s_scan[tid] = val;
-                __syncthreads();
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off);
+                    if (lane >= off)
+                        incl += up;
+                }
+                const uint32_t excl = incl - local;
+                s_scan[4 * tid]     = excl + h0;
+                s_scan[4 * tid + 1] = excl + h0 + h1;
+                s_scan[4 * tid + 2] = excl + h0 + h1 + h2;
+                s_scan[4 * tid + 3] = incl;
             }
+            __syncthreads();
             const uint32_t start = key ? s_scan[key - 1] : 0u;
             s_perm[start + r]    = (uint16_t)tid;
             __syncthreads();
@@ -149,72 +146,67 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
         int ray_id = 0;
         if (j < n) {
             PathVertexIn in;
-            in.ray_id  = ray_id = a.in.id[j];
-            in.org     = f3{ a.in.ox[j], a.in.oy[j], a.in.oz[j] };
-            in.dir     = f3{ a.in.dx[j], a.in.dy[j], a.in.dz[j] };
-            in.rnd     = a.in.rnd[j];
-            in.inv_pdf = a.in.payload[0][j];
-            in.contrib = Col{ a.in.payload[1][j], a.in.payload[2][j], a.in.payload[3][j] };
-            in.depth   = (int)a.in.payload[4][j];
-            in.eta     = a.in.payload[5][j];
-            in.ent     = a.in.ent_id[j];
-            in.prim    = a.in.prim_id[j];
-            in.t = a.in.t[j], in.u = a.in.u[j], in.v = a.in.v[j];
+            const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], pay = a.in.pay[j], hit = a.in.hit[j];
+            const int4 meta = a.in.meta[j];
+            in.ray_id  = ray_id = meta.x;
+            in.org     = f3{ ra.x, ra.y, ra.z };
+            in.dir     = f3{ rb.x, rb.y, rb.z };
+            in.rnd     = (uint32_t)meta.z;
+            in.inv_pdf = pay.x;
+            in.contrib = Col{ pay.y, pay.z, pay.w };
+            in.depth   = meta.w;
+            in.eta     = a.in.eta[j];
+            in.ent     = (int)igm_bits(hit.x);
+            in.prim    = (int)igm_bits(hit.y);
+            in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
             shade_vertex(sc, fr, in, out);
             if (out.has_radiance) {
                 // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
-                float* acc = a.accum + ((int64_t)ray_id - a.id_base) * 3;
-                acc[0] += out.radiance.r * a.inv_spi;
-                acc[1] += out.radiance.g * a.inv_spi;
-                acc[2] += out.radiance.b * a.inv_spi;
+                float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
+                float4 v    = *acc;
+                v.x += out.radiance.r * a.inv_spi;
+                v.y += out.radiance.g * a.inv_spi;
+                v.z += out.radiance.b * a.inv_spi;
+                *acc = v;
             }
         }
 
-        // ---- append survivors / shadow rays: one atomic per wave and queue (replaces K9)
+        // ---- append survivors / shadow rays: ONE atomic per workgroup and queue (replaces K9). A single
+        // counter word sustains only ~88 atomics/us, so per-wave appends would serialise the kernel.
         {
-            const unsigned long long m = __ballot(out.bounce);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t pos0    = 0;
-                if (lane == leader)
-                    pos0 = atomicAdd(a.out_count, (uint32_t)__popcll(m));
-                pos0 = __shfl(pos0, leader);
-                if (out.bounce) {
-                    const uint32_t o = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    a.out.id[o] = ray_id;
-                    a.out.ox[o] = out.b_org.x, a.out.oy[o] = out.b_org.y, a.out.oz[o] = out.b_org.z;
-                    a.out.dx[o] = out.b_dir.x, a.out.dy[o] = out.b_dir.y, a.out.dz[o] = out.b_dir.z;
-                    a.out.tmin[o]  = kRayOffset;
-                    a.out.tmax[o]  = kFltMax;
-                    a.out.flags[o] = IG_RAY_FLAG_BOUNCE;
-                    a.out.rnd[o]   = out.b_rnd;
-                    a.out.payload[0][o] = out.b_inv_pdf;
-                    a.out.payload[1][o] = out.b_contrib.r;
-                    a.out.payload[2][o] = out.b_contrib.g;
-                    a.out.payload[3][o] = out.b_contrib.b;
-                    a.out.payload[4][o] = (float)out.b_depth;
-                    a.out.payload[5][o] = out.b_eta;
-                }
+            const unsigned long long mb = __ballot(out.bounce);
+            const unsigned long long ms = __ballot(out.shadow);
+            const int wave              = tid >> 6;
+            if (lane == 0) {
+                s_wave_cnt[0][wave] = (uint32_t)__popcll(mb);
+                s_wave_cnt[1][wave] = (uint32_t)__popcll(ms);
             }
-        }
-        {
-            const unsigned long long m = __ballot(out.shadow);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t pos0    = 0;
-                if (lane == leader)
-                    pos0 = atomicAdd(a.sec_count, (uint32_t)__popcll(m));
-                pos0 = __shfl(pos0, leader);
-                if (out.shadow) {
-                    const uint32_t o = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    a.sec.id[o] = ray_id;
-                    a.sec.ox[o] = out.s_org.x, a.sec.oy[o] = out.s_org.y, a.sec.oz[o] = out.s_org.z;
-                    a.sec.dx[o] = out.s_dir.x, a.sec.dy[o] = out.s_dir.y, a.sec.dz[o] = out.s_dir.z;
-                    a.sec.tmin[o] = kRayOffset;
-                    a.sec.tmax[o] = out.s_tmax;
-                    a.sec.cr[o] = out.s_col.r, a.sec.cg[o] = out.s_col.g, a.sec.cb[o] = out.s_col.b;
-                }
+            __syncthreads();
+            if (tid < 2) {
+                const uint32_t total = s_wave_cnt[tid][0] + s_wave_cnt[tid][1] + s_wave_cnt[tid][2] + s_wave_cnt[tid][3];
+                s_base[tid]          = total ? atomicAdd(tid == 0 ? a.out_count : a.sec_count, total) : 0u;
             }
+            __syncthreads();
+            uint32_t ob = s_base[0], os = s_base[1];
+            for (int w = 0; w < wave; ++w) {
+                ob += s_wave_cnt[0][w];
+                os += s_wave_cnt[1][w];
+            }
+            if (out.bounce) {
+                const uint32_t o = ob + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, kRayOffset);
+                a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
+                a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
+                a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
+                a.out.eta[o]  = out.b_eta;
+            }
+            if (out.shadow) {
+                const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+                a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
+                a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
+                a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)ray_id));
+            }
+            __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
         }
     }
 }
@@ -255,12 +247,13 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     const int64_t lp = a.first_local_pixel + i;
     const int x      = (int)(lp % a.width);
     const int y      = a.row_offset + (int)(lp / a.width) * a.row_stride;
-    const float* src = a.accum + (size_t)i * a.spi * 3;
+    const float4* src = a.accum + (size_t)i * a.spi;
     float r = 0, g = 0, b = 0;
     for (int s = 0; s < a.spi; ++s) {
-        r += src[s * 3 + 0];
-        g += src[s * 3 + 1];
-        b += src[s * 3 + 2];
+        const float4 v = src[s];
+        r += v.x;
+        g += v.y;
+        b += v.z;
     }
     float* dst = a.fb + ((size_t)y * a.width + x) * 3;
     dst[0] += r;

@@ -83,17 +83,24 @@ IG_DEV f3 stable_normal(f3 e1, f3 e2, f3 e3) // core/triangle.art:31-44
 IG_DEV float lerp2(float a, float b, float c, float k1, float k2) { return (1 - k1 - k2) * a + k1 * b + k2 * c; } // core/common.art:238
 
 IG_DEV f3 ld3(const float* p) { return f3{ p[0], p[1], p[2] }; }
+IG_DEV f3 ld3v(const float* p) // 16-byte aligned (x, y, z, pad) record
+{
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f3{ v.x, v.y, v.z };
+}
 
 // make_trimesh_shape.surface_element (shapes/trimesh.art:14-40), entity table (driver/entity.art:12-28),
 // point mappers (driver/pointmapper.art:28-36)
 IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org, f3 dir, float t, float u, float v)
 {
-    const float* e = sc.entities + (size_t)ent_id * IG_ENTITY_FLOATS;
+    // entity record = 9 x 16 bytes; words 12..35 hold toGlobal 3x4, the normal 3x3, shape id, material id
+    const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)ent_id * IG_ENTITY_FLOATS);
+    const float4 r3 = e[3], r4 = e[4], r5 = e[5], r6 = e[6], r7 = e[7], r8 = e[8];
     m34 global;
-    global.c0 = ld3(e + 12), global.c1 = ld3(e + 15), global.c2 = ld3(e + 18), global.c3 = ld3(e + 21);
+    global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
     m33 nmat;
-    nmat.c0 = ld3(e + 24), nmat.c1 = ld3(e + 27), nmat.c2 = ld3(e + 30);
-    const int shape_id = (int)igm_bits(e[33]);
+    nmat.c0 = f3{ r6.x, r6.y, r6.z }, nmat.c1 = f3{ r6.w, r7.x, r7.y }, nmat.c2 = f3{ r7.z, r7.w, r8.x };
+    const int shape_id = (int)igm_bits(r8.y);
 
     const uint8_t* base = sc.shape_data + sc.shape_offsets[shape_id];
     const int4 hdr      = *reinterpret_cast<const int4*>(base); // faces, vertices, normals, texcoords
@@ -102,15 +109,15 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     const float* norms  = verts + hdr.y * 4;
     const int4 tri      = *reinterpret_cast<const int4*>(norms + hdr.z * 4 + prim_id * 4);
 
-    const f3 v0 = xform_point(global, ld3(verts + tri.x * 4));
-    const f3 v1 = xform_point(global, ld3(verts + tri.y * 4));
-    const f3 v2 = xform_point(global, ld3(verts + tri.z * 4));
+    const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4));
+    const f3 v1 = xform_point(global, ld3v(verts + tri.y * 4));
+    const f3 v2 = xform_point(global, ld3v(verts + tri.z * 4));
     const f3 e1 = v2 - v0, e2 = v0 - v1, e3 = v1 - v2;
     const f3 n  = stable_normal(e1, e2, e3); // make_triangle, core/triangle.art:12-29
     const float nn = len3(n);
     const f3 fn    = n * (1 / nn);
 
-    const f3 n0 = ld3(norms + tri.x * 4), n1 = ld3(norms + tri.y * 4), n2 = ld3(norms + tri.z * 4);
+    const f3 n0 = ld3v(norms + tri.x * 4), n1 = ld3v(norms + tri.y * 4), n2 = ld3v(norms + tri.z * 4);
     const f3 ln = f3{ lerp2(n0.x, n1.x, n2.x, u, v), lerp2(n0.y, n1.y, n2.y, u, v), lerp2(n0.z, n1.z, n2.z, u, v) };
     const f3 sn = normalize3(mul33(nmat, ln));
 

@@ -29,17 +29,19 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
 
     for (uint32_t i = blockIdx.x * kBlockThreads + tid; i < n; i += gridDim.x * kBlockThreads) {
         PathVertexIn in;
-        in.ray_id  = a.in.id[i];
-        in.org     = f3{ a.in.ox[i], a.in.oy[i], a.in.oz[i] };
-        in.dir     = f3{ a.in.dx[i], a.in.dy[i], a.in.dz[i] };
-        in.rnd     = a.in.rnd[i];
-        in.inv_pdf = a.in.payload[0][i];
-        in.contrib = Col{ a.in.payload[1][i], a.in.payload[2][i], a.in.payload[3][i] };
-        in.depth   = (int)a.in.payload[4][i];
-        in.eta     = a.in.payload[5][i];
-        float tmin = a.in.tmin[i], tmax = a.in.tmax[i];
-        uint32_t flags = a.in.flags[i];
-        float* acc     = a.accum + ((int64_t)in.ray_id - a.id_base) * 3;
+        const float4 ra = a.in.rayA[i], rb = a.in.rayB[i], pay = a.in.pay[i];
+        const int4 meta = a.in.meta[i];
+        in.ray_id  = meta.x;
+        in.org     = f3{ ra.x, ra.y, ra.z };
+        in.dir     = f3{ rb.x, rb.y, rb.z };
+        in.rnd     = (uint32_t)meta.z;
+        in.inv_pdf = pay.x;
+        in.contrib = Col{ pay.y, pay.z, pay.w };
+        in.depth   = meta.w;
+        in.eta     = a.in.eta[i];
+        float tmin = ra.w, tmax = rb.w;
+        uint32_t flags = (uint32_t)meta.y;
+        float4 acc     = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
 
         for (;;) {
             {
@@ -62,9 +64,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
             PathVertexOut out;
             shade_vertex(sc, a.frame, in, out);
             if (out.has_radiance) {
-                acc[0] += out.radiance.r * a.inv_spi;
-                acc[1] += out.radiance.g * a.inv_spi;
-                acc[2] += out.radiance.b * a.inv_spi;
+                acc.x += out.radiance.r * a.inv_spi;
+                acc.y += out.radiance.g * a.inv_spi;
+                acc.z += out.radiance.b * a.inv_spi;
             }
 
             if (out.shadow) {
@@ -82,14 +84,16 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
                 }
                 if (ts.hit_prim < 0) {
                     ++c_unoccluded;
-                    acc[0] += out.s_col.r * a.inv_spi;
-                    acc[1] += out.s_col.g * a.inv_spi;
-                    acc[2] += out.s_col.b * a.inv_spi;
+                    acc.x += out.s_col.r * a.inv_spi;
+                    acc.y += out.s_col.g * a.inv_spi;
+                    acc.z += out.s_col.b * a.inv_spi;
                 }
             }
 
-            if (!out.bounce)
+            if (!out.bounce) {
+                a.accum[(int64_t)in.ray_id - a.id_base] = acc;
                 break;
+            }
             ++c_bounce;
             in.org     = out.b_org;
             in.dir     = out.b_dir;

@@ -10,7 +10,7 @@
 namespace igdev {
 
 constexpr int kRefillIdle = 16;  // refill when at least this many lanes of a wave are idle
-constexpr int kRayBatch   = 256; // ray indices reserved per atomic
+constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a)
@@ -21,6 +21,11 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
     const int lane = tid & 63;
 
     const uint32_t count = *a.count;
+    // batch size: large enough to keep the shared counter cold, small enough that every wave gets work
+    const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
+    uint32_t kRayBatch         = count / (total_waves * 4u);
+    kRayBatch                  = kRayBatch < 64u ? 64u : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
+    kRayBatch &= ~63u;
 
     Traverser<ANY_HIT, STATS> tr;
     tr.init_counters();
@@ -54,8 +59,9 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
                 const uint32_t idx = batch_next + rank;
                 ray_idx = idx;
                 has_ray = true;
-                tr.begin(a.scene, s_stack, tid, f3{ a.ox[idx], a.oy[idx], a.oz[idx] }, f3{ a.dx[idx], a.dy[idx], a.dz[idx] },
-                         a.tmin[idx], a.tmax[idx], a.flags ? a.flags[idx] : a.uniform_flags);
+                const float4 ra = a.rayA[idx], rb = a.rayB[idx];
+                tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
+                         a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
             }
             batch_next += take;
         }
@@ -71,28 +77,26 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
             if (tr.finished) {
                 has_ray = false;
                 if (ANY_HIT) {
-                    if (a.prim_id)
-                        a.prim_id[ray_idx] = tr.hit_prim;
-                    if (a.ent_id)
-                        a.ent_id[ray_idx] = tr.hit_ent;
+                    if (a.hit)
+                        a.hit[ray_idx] = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
                     if (tr.hit_prim < 0) {
                         if (STATS)
                             ++st_unoccluded;
                         if (a.accum) {
                             // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample
                             // accumulator: plain read-modify-write, the slot is owned by this ray.
-                            float* dst = a.accum + ((int64_t)a.ray_id[ray_idx] - a.id_base) * 3;
-                            dst[0] += a.cr[ray_idx] * a.inv_spi;
-                            dst[1] += a.cg[ray_idx] * a.inv_spi;
-                            dst[2] += a.cb[ray_idx] * a.inv_spi;
+                            const float4 c = a.col[ray_idx];
+                            float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
+                            float4 v       = *dst;
+                            v.x += c.x * a.inv_spi;
+                            v.y += c.y * a.inv_spi;
+                            v.z += c.z * a.inv_spi;
+                            *dst = v;
                         }
                     }
                 } else {
-                    a.ent_id[ray_idx]  = tr.hit_ent;
-                    a.prim_id[ray_idx] = tr.hit_prim;
-                    a.t[ray_idx]       = tr.tmax;
-                    a.u[ray_idx]       = tr.hit_u;
-                    a.v[ray_idx]       = tr.hit_v;
+                    a.hit[ray_idx]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
+                    a.hit_v[ray_idx] = tr.hit_v;
                 }
             }
         }
