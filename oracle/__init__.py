@@ -14,7 +14,8 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 class Settings(C.Structure):
     _fields_ = [("spi", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("iteration", C.c_int32),
                 ("frame", C.c_int32), ("seed", C.c_int32), ("threads", C.c_int32),
-                ("xmin", C.c_int32), ("ymin", C.c_int32), ("xmax", C.c_int32), ("ymax", C.c_int32)]
+                ("xmin", C.c_int32), ("ymin", C.c_int32), ("xmax", C.c_int32), ("ymax", C.c_int32),
+                ("row_offset", C.c_int32), ("row_stride", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -80,19 +81,21 @@ def _scene_ptr(scene):
     return C.cast(t, C.c_void_p)
 
 
-def make_settings(spi, width, height, iteration=0, frame=0, seed=0, threads=0, window=None):
-    s = Settings(spi, width, height, iteration, frame, seed, threads, 0, 0, 0, 0)
+def make_settings(spi, width, height, iteration=0, frame=0, seed=0, threads=0, window=None, rows=None):
+    s = Settings(spi, width, height, iteration, frame, seed, threads, 0, 0, 0, 0, 0, 1)
+    if rows is not None:
+        s.row_offset, s.row_stride = rows
     if window is not None:
         s.xmin, s.ymin, s.xmax, s.ymax = window
     return s
 
 
-def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None):
+def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None, rows=None):
     """One iteration of the reference CPU pipeline; returns (fb[h,w,3] float32 accumulated, stats dict)."""
     if fb is None:
         fb = np.zeros((height, width, 3), dtype=np.float32)
     assert fb.dtype == np.float32 and fb.flags.c_contiguous and fb.shape == (height, width, 3)
-    cfg = make_settings(spi, width, height, iteration, frame, seed, threads, window)
+    cfg = make_settings(spi, width, height, iteration, frame, seed, threads, window, rows)
     st = Stats()
     rc = lib().oracle_render(_scene_ptr(scene), C.byref(cfg), _fp(fb), C.byref(st))
     if rc != 0:

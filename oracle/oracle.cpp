@@ -26,6 +26,8 @@ typedef struct oracle_settings {
     int32_t threads; // <= 0: hardware concurrency
     // optional pixel window (tile sharding); xmax/ymax <= 0 means full film
     int32_t xmin, ymin, xmax, ymax;
+    // optional row sharding: only film rows row_offset, row_offset + row_stride, ... (stride <= 1: all)
+    int32_t row_offset, row_stride;
 } oracle_settings;
 
 typedef struct oracle_stats {
@@ -401,7 +403,14 @@ int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, or
     const int x0 = cfg->xmax > 0 ? cfg->xmin : 0, y0 = cfg->ymax > 0 ? cfg->ymin : 0;
     const int x1 = cfg->xmax > 0 ? cfg->xmax : cfg->width, y1 = cfg->ymax > 0 ? cfg->ymax : cfg->height;
     const int tiles_x = (x1 - x0 + tile_size - 1) / tile_size;
-    const int tiles_y = (y1 - y0 + tile_size - 1) / tile_size;
+    // with row sharding a "tile" is a 16-pixel run of one owned row
+    const bool sharded = cfg->row_stride > 1;
+    std::vector<int> rows;
+    if (sharded)
+        for (int y = y0; y < y1; ++y)
+            if (y % cfg->row_stride == cfg->row_offset)
+                rows.push_back(y);
+    const int tiles_y   = sharded ? (int)rows.size() : (y1 - y0 + tile_size - 1) / tile_size;
     const int num_tiles = tiles_x * tiles_y;
 
     int threads = cfg->threads > 0 ? cfg->threads : (int)std::thread::hardware_concurrency();
@@ -421,8 +430,8 @@ int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, or
             if (tile >= num_tiles)
                 break;
             const int tx = tile % tiles_x, ty = tile / tiles_x;
-            const int xmin = x0 + tx * tile_size, ymin = y0 + ty * tile_size;
-            const int xmax = std::min(xmin + tile_size, x1), ymax = std::min(ymin + tile_size, y1);
+            const int xmin = x0 + tx * tile_size, ymin = sharded ? rows[(size_t)ty] : y0 + ty * tile_size;
+            const int xmax = std::min(xmin + tile_size, x1), ymax = sharded ? ymin + 1 : std::min(ymin + tile_size, y1);
             trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
         }
     };
