@@ -102,6 +102,8 @@ struct igd_device {
     DevBuf<ig_material> materials;
     DevBuf<int32_t> entity_material;
     DevBuf<ig_light> lights;
+    DevBuf<float> light_hierarchy;
+    DevBuf<uint32_t> light_codes;
     DevScene dscene{};
     ig_camera camera{};
 
@@ -202,17 +204,26 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const ig_material& mat = s->materials[m];
-        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC)
+        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
-        if (mat.flags != 0)
-            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses bump/texture/thin flags the HIP backend cannot shade yet" };
+        if (mat.flags & ~(uint32_t)IG_MAT_CHECKER)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses bump/thin flags the HIP backend cannot shade yet" };
+        if ((mat.flags & IG_MAT_CHECKER) && mat.bsdf_type != IG_BSDF_DIFFUSE)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard reflectance is only lowered for diffuse BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material light id out of range" };
         if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only planar area lights can be emissive entities" };
     }
-    if (s->technique.light_selector != IG_SELECTOR_UNIFORM && s->light_count > 1)
-        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only the uniform light selector is implemented" };
+    const uint32_t n_finite = s->light_count - s->infinite_light_count;
+    const bool hierarchy    = s->technique.light_selector == IG_SELECTOR_HIERARCHY && n_finite > 0;
+    if (hierarchy && n_finite > 1 && (!s->light_hierarchy || !s->light_codes || s->light_hierarchy_nodes == 0))
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: hierarchy light selector without a hierarchy table" };
+    for (uint32_t l = 0; l < s->light_count; ++l) {
+        const bool inf = l < s->infinite_light_count;
+        if (inf != (s->lights[l].type == IG_LIGHT_ENV))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment lights" };
+    }
 
     // geometry blob: prim BVH fix table, then the scene BVH nodes
     std::vector<uint8_t> blob(s->primbvh, s->primbvh + s->primbvh_size);
@@ -250,6 +261,8 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->shape_offsets.upload(so.data(), so.size());
     d->materials.upload(s->materials, s->material_count);
     d->lights.upload(s->lights, s->light_count);
+    d->light_hierarchy.upload(s->light_hierarchy, (size_t)s->light_hierarchy_nodes * 8);
+    d->light_codes.upload(s->light_codes, s->light_codes ? n_finite : 0);
 
     // material id per entity (entity table word 34, LoaderEntity.cpp:159)
     std::vector<int32_t> em(s->entity_count);
@@ -277,6 +290,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_count          = s->light_count;
     ds.infinite_light_count = s->infinite_light_count;
     ds.tech                 = s->technique;
+    ds.light_hierarchy      = d->light_hierarchy.ptr;
+    ds.light_codes          = d->light_codes.ptr;
+    ds.use_hierarchy        = hierarchy ? 1u : 0u;
+    ds.scene_radius         = s->scene_radius;
     d->camera               = s->camera;
     d->has_scene            = true;
 }
@@ -760,6 +777,8 @@ int32_t igd_release_all(igd_device* dev)
         dev->materials.release();
         dev->entity_material.release();
         dev->lights.release();
+        dev->light_hierarchy.release();
+        dev->light_codes.release();
         dev->has_scene = false;
     });
 }

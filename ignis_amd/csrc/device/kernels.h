@@ -25,6 +25,11 @@ struct DevScene {
     const ig_light* lights;
     uint32_t entity_count, material_count, light_count, infinite_light_count;
     ig_technique tech;
+    // light selection (light/light_selector.art): hierarchy table + per-light codes, or uniform
+    const float* light_hierarchy;
+    const uint32_t* light_codes;
+    uint32_t use_hierarchy;
+    float scene_radius; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)
 };
 
 // Ray queues in HBM. The reference's streams are one float per column (src/artic/driver/streams.art:

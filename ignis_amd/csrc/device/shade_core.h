@@ -68,6 +68,7 @@ struct Tea {
 struct Surf { // driver/surface_element.art
     bool entering;
     f3 point, face_normal;
+    f2 tex;
     m33 local;
 };
 
@@ -107,7 +108,9 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     const float* f      = reinterpret_cast<const float*>(base);
     const float* verts  = f + 12;
     const float* norms  = verts + hdr.y * 4;
-    const int4 tri      = *reinterpret_cast<const int4*>(norms + hdr.z * 4 + prim_id * 4);
+    const float* inds   = norms + hdr.z * 4;
+    const int4 tri      = *reinterpret_cast<const int4*>(inds + prim_id * 4);
+    const float* texs   = inds + hdr.x * 4;
 
     const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4));
     const f3 v1 = xform_point(global, ld3v(verts + tri.y * 4));
@@ -121,7 +124,10 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     const f3 ln = f3{ lerp2(n0.x, n1.x, n2.x, u, v), lerp2(n0.y, n1.y, n2.y, u, v), lerp2(n0.z, n1.z, n2.z, u, v) };
     const f3 sn = normalize3(mul33(nmat, ln));
 
+    const f2 t0 = *reinterpret_cast<const f2*>(texs + tri.x * 2), t1 = *reinterpret_cast<const f2*>(texs + tri.y * 2), t2 = *reinterpret_cast<const f2*>(texs + tri.z * 2);
+
     Surf s;
+    s.tex         = f2{ lerp2(t0.x, t1.x, t2.x, u, v), lerp2(t0.y, t1.y, t2.y, u, v) };
     s.entering    = dot3(dir, fn) <= 0;
     s.point       = org + dir * t;
     s.face_normal = s.entering ? fn : -fn;
@@ -244,6 +250,309 @@ IG_DEV bool fresnel(float eta, float cos_i, float& cos_t, float& factor)
     return true;
 }
 
+// ---------------------------------------------------------------- BSDFs
+
+// core/fresnel.art:29-36
+IG_DEV float conductor_factor(float n, float k, float cos_i)
+{
+    const float f  = n * n + k * k;
+    const float d1 = f * cos_i * cos_i;
+    const float d2 = 2.0f * n * cos_i;
+    const float rs = safe_div(d1 - d2, d1 + d2);
+    const float rp = safe_div(f - d2 + cos_i * cos_i, f + d2 + cos_i * cos_i);
+    return clampf((rs * rs + rp * rp) * 0.5f, 0, 1);
+}
+
+IG_DEV float abs_cos(f3 a, f3 b) { return igm_abs(dot3(a, b)); } // core/common.art:302
+
+// GGX model (core/microfacet.art:158-199) + VNDF sampling with spherical caps (:372-404)
+struct Ggx {
+    m33 local;
+    float au, av;
+
+    IG_DEV float D(f3 m) const
+    {
+        const float cz = dot3(local.c2, m), cx = dot3(local.c0, m), cy = dot3(local.c1, m);
+        const float kx = cx / au, ky = cy / av;
+        const float k  = kx * kx + ky * ky + cz * cz;
+        return safe_div(1, kPi * au * av * k * k);
+    }
+    IG_DEV float G1(f3 w) const
+    {
+        const float cz = dot3(local.c2, w);
+        if (igm_abs(cz) <= kFltEps)
+            return 0;
+        const float cx = dot3(local.c0, w), cy = dot3(local.c1, w);
+        const float kx = au * cx, ky = av * cy;
+        const float a2 = kx * kx + ky * ky;
+        if (a2 <= kFltEps)
+            return 1;
+        const float k2 = a2 / (cz * cz);
+        return 2 / (1 + igm_sqrt(1 + k2));
+    }
+    IG_DEV float pdf(f3 w, f3 h) const { return safe_div(G1(w) * abs_cos(w, h) * D(h), abs_cos(local.c2, w)); }
+    IG_DEV f3 sample(Tea& rnd, f3 vN) const
+    {
+        const f3 vL    = f3{ dot3(local.c0, vN), dot3(local.c1, vN), dot3(local.c2, vN) };
+        const f3 sL    = normalize3(f3{ au * vL.x, av * vL.y, vL.z });
+        const float u0 = rnd.f32();
+        const float u1 = rnd.f32();
+        const float phi = 2 * kPi * u0;
+        const float z   = (1 - u1) * (1 + sL.z) - sL.z;
+        const float st  = igm_sqrt(clampf(1 - z * z, 0, 1));
+        const f3 h      = f3{ st * igm_cos(phi), st * igm_sin(phi), z } + vL;
+        const f3 Nh     = normalize3(f3{ h.x * au, h.y * av, h.z });
+        return (local.c0 * Nh.x + local.c1 * Nh.y) + local.c2 * Nh.z;
+    }
+};
+
+// make_checkerboard_texture, identity transform (texture/checkerboard.art; math::wrap core/math.art:88-91)
+IG_DEV float wrapf(float v, float mn, float mx)
+{
+    const float range = mx - mn;
+    return range <= kFltEps ? mn : v - (range * igm_floor((v - mn) / range));
+}
+
+struct BsdfCtx {
+    const ig_material* mat;
+    Surf surf;
+    Col kd; // diffuse reflectance (constant or checkerboard)
+
+    IG_DEV BsdfCtx(const ig_material& m, const Surf& s)
+        : mat(&m)
+        , surf(s)
+    {
+        if (m.flags & IG_MAT_CHECKER) {
+            const bool px = ((int)wrapf(s.tex.x * m.q[6], 0, 2) % 2) == 0;
+            const bool py = ((int)wrapf(s.tex.y * m.q[7], 0, 2) % 2) == 0;
+            kd            = (px ^ py) ? Col{ m.q[0], m.q[1], m.q[2] } : Col{ m.q[3], m.q[4], m.q[5] };
+        } else {
+            kd = Col{ m.p[0], m.p[1], m.p[2] };
+        }
+    }
+    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
+    IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
+
+    // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
+    IG_DEV Col eval(f3 in_dir, f3 out_dir) const
+    {
+        const f3 N = surf.local.c2;
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+            return kd * (pos_cos(in_dir, N) * kInvPi);
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            const float cos_o = abs_cos(out_dir, N);
+            const float cos_i = abs_cos(in_dir, N);
+            if (cos_o <= kFltEps || cos_i <= kFltEps)
+                return Col{ 0, 0, 0 };
+            const Ggx g   = ggx();
+            const f3 H    = normalize3(in_dir + out_dir);
+            const float D = g.D(H);
+            const float G = g.G1(in_dir) * g.G1(out_dir);
+            const float c = abs_cos(out_dir, H);
+            const Col F   = Col{ conductor_factor(mat->p[0], mat->p[3], c), conductor_factor(mat->p[1], mat->p[4], c), conductor_factor(mat->p[2], mat->p[5], c) };
+            const Col IF  = Col{ 1 - F.r, 1 - F.g, 1 - F.b };
+            const Col col = Col{ 0.0f * IF.r + mat->p[6] * F.r, 0.0f * IF.g + mat->p[7] * F.g, 0.0f * IF.b + mat->p[8] * F.b };
+            return col * (D * G / (4 * cos_o));
+        }
+        return Col{ 0, 0, 0 };
+    }
+    IG_DEV float pdf(f3 in_dir, f3 out_dir) const
+    {
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+            return pos_cos(in_dir, surf.local.c2) / kPi;
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            const f3 H      = normalize3(in_dir + out_dir);
+            const float cho = abs_cos(out_dir, H);
+            return ggx().pdf(out_dir, H) * safe_div(1, 4 * cho);
+        }
+        return 0;
+    }
+    // returns false when the sample is rejected
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
+    {
+        const f3 N = surf.local.c2;
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+            // make_lambertian_bsdf.sample (bsdf/diffuse.art:5-9), sample_cosine_hemisphere (core/sampling.art:62-70)
+            const float u   = rnd.f32();
+            const float v   = rnd.f32();
+            const float c   = safe_sqrt(v);
+            const float s   = safe_sqrt(1 - v);
+            const float phi = 2 * kPi * u;
+            in_dir          = mul33(surf.local, f3{ s * igm_cos(phi), s * igm_sin(phi), c });
+            pdf_out         = c / kPi;
+            color           = kd;
+            s_eta           = 1;
+            sdelta          = false;
+            return true;
+        }
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            // make_rough_base_conductor_bsdf.sample (bsdf/conductor.art:93-114)
+            const float cos_o = abs_cos(out_dir, N);
+            if (cos_o <= kFltEps)
+                return false;
+            const Ggx g      = ggx();
+            const f3 m       = g.sample(rnd, out_dir);
+            const float mpdf = g.pdf(out_dir, m);
+            if (dot3(m, m) <= kFltEps)
+                return false;
+            const f3 oH = normalize3(m);
+            const f3 H  = igm_signbit(dot3(oH, out_dir)) ? -oH : oH;
+            in_dir      = H * (2 * dot3(H, out_dir)) - out_dir; // vec3_reflect
+            if (abs_cos(in_dir, N) <= kFltEps)
+                return false;
+            const float cho = abs_cos(out_dir, H);
+            pdf_out         = mpdf * (1 / (4 * cho));
+            color           = eval(in_dir, out_dir) * safe_div(1, pdf_out);
+            s_eta           = 1;
+            sdelta          = false;
+            return true;
+        }
+        // make_pure_dielectric_bsdf.sample (bsdf/dielectric.art:18-34); n1 = ext_ior, n2 = int_ior
+        const float n1 = mat->p[0], n2 = mat->p[1];
+        const float k     = surf.entering ? n1 / n2 : n2 / n1;
+        const float cos_o = dot3(out_dir, N);
+        float cos_t = 0, F = 1;
+        if (!fresnel(k, cos_o, cos_t, F)) {
+            cos_t = 0;
+            F     = 1;
+        }
+        if (rnd.f32() > F) {
+            in_dir = N * (k * cos_o - cos_t) - out_dir * k; // vec3_refract (core/vector.art:126)
+            color  = Col{ mat->p[5], mat->p[6], mat->p[7] } * 1.0f;
+            s_eta  = k;
+        } else {
+            in_dir = N * (2 * dot3(N, out_dir)) - out_dir; // vec3_reflect (core/vector.art:123)
+            color  = Col{ mat->p[2], mat->p[3], mat->p[4] };
+            s_eta  = 1;
+        }
+        pdf_out = 1;
+        sdelta  = true;
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- light selection
+
+// equal_area_square_to_sphere (core/warp.art:63-91)
+IG_DEV f3 square_to_sphere(float px, float py)
+{
+    const float u  = 2 * px - 1;
+    const float v  = 2 * py - 1;
+    const float au = igm_abs(u), av = igm_abs(v);
+    const float sd = 1 - (au + av);
+    const float d  = igm_abs(sd);
+    const float r  = 1 - d;
+    const float phi = (r == 0 ? 1.0f : (av - au) / r + 1) * kPi / 4;
+    const float ct  = igm_copysign(1 - r * r, sd);
+    const float st  = safe_sqrt(2 - r * r) * r;
+    const float cp  = igm_copysign(igm_cos(phi), u);
+    const float sp  = igm_copysign(igm_sin(phi), v);
+    return f3{ cp * st, sp * st, ct };
+}
+
+// light/light_hierarchy.art:14-96
+struct HierEntry {
+    f3 pos, dir;
+    float flux;
+    int id;
+    bool has_dir, is_leaf;
+};
+IG_DEV HierEntry hier_load(const DevScene& sc, int id)
+{
+    const float4* e = reinterpret_cast<const float4*>(sc.light_hierarchy + (size_t)id * 8);
+    const float4 e1 = e[0], e2 = e[1];
+    const int index = (int)igm_bits(e2.w);
+    HierEntry h;
+    h.pos     = f3{ e1.x, e1.y, e1.z };
+    h.dir     = f3{ e2.x, e2.y, e2.z };
+    h.flux    = igm_abs(e1.w);
+    h.id      = index < 0 ? -index - 1 : index;
+    h.has_dir = !igm_signbit(e1.w);
+    h.is_leaf = index >= 0;
+    return h;
+}
+IG_DEV float hier_cost(const HierEntry& e, f3 pos)
+{
+    const f3 cdir     = e.pos - pos;
+    const float dist2 = dot3(cdir, cdir);
+    const float cos_d = e.has_dir ? igm_abs(dot3(e.dir, normalize3(cdir))) : 1.0f;
+    return safe_div(e.flux * cos_d, dist2);
+}
+IG_DEV float hier_left_prop(const HierEntry& l, const HierEntry& r, f3 pos) { return 1 / (1 + hier_cost(r, pos) / hier_cost(l, pos)); }
+IG_DEV int hier_sample(const DevScene& sc, Tea& rnd, f3 pos, float& pdf)
+{
+    pdf           = 1;
+    HierEntry ent = hier_load(sc, 0);
+    while (!ent.is_leaf) {
+        const HierEntry left = hier_load(sc, ent.id), right = hier_load(sc, ent.id + 1);
+        const float prop     = hier_left_prop(left, right, pos);
+        const bool is_left   = rnd.f32() < prop;
+        ent                  = is_left ? left : right;
+        pdf *= is_left ? prop : 1 - prop;
+    }
+    return ent.id;
+}
+IG_DEV float hier_pdf(const DevScene& sc, int finite_id, f3 pos)
+{
+    uint32_t code = sc.light_codes[finite_id];
+    float pdf     = 1;
+    HierEntry ent = hier_load(sc, 0);
+    while (!ent.is_leaf) {
+        const HierEntry left = hier_load(sc, ent.id), right = hier_load(sc, ent.id + 1);
+        const float prop     = hier_left_prop(left, right, pos);
+        const bool is_left   = (code & 0x1) == 0;
+        ent                  = is_left ? left : right;
+        pdf *= is_left ? prop : 1 - prop;
+        code >>= 1;
+    }
+    return pdf;
+}
+
+// LightSelector (light/light_selector.art): uniform (:26-46) or hierarchy (:80-110)
+IG_DEV int pick_light_id(Tea& rnd, int num) { return num <= 1 ? 0 : rnd.range(0, num - 1); }
+
+IG_DEV int select_light(const DevScene& sc, Tea& rnd, f3 from_pos, float& pdf)
+{
+    const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    if (!sc.use_hierarchy) {
+        const int num = (int)sc.light_count;
+        pdf           = num == 0 ? 1.0f : 1 / (float)num;
+        return pick_light_id(rnd, num);
+    }
+    if (n_inf == 0) {
+        if (n_fin == 1) {
+            pdf = 1;
+            return 0;
+        }
+        return hier_sample(sc, rnd, from_pos, pdf);
+    }
+    const float pdf_inf = 1 / (float)n_inf;
+    const float q       = rnd.f32();
+    if (q < 0.5f) {
+        const int id = pick_light_id(rnd, n_inf);
+        pdf          = pdf_inf * 0.5f;
+        return id;
+    }
+    float p = 1;
+    int fid = 0;
+    if (n_fin != 1)
+        fid = hier_sample(sc, rnd, from_pos, p);
+    pdf = p * (1 - 0.5f);
+    return n_inf + fid;
+}
+
+IG_DEV float select_pdf(const DevScene& sc, int li, f3 from_pos)
+{
+    const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    if (!sc.use_hierarchy)
+        return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
+    if (n_inf == 0)
+        return n_fin == 1 ? 1.0f : hier_pdf(sc, li, from_pos);
+    if (li < n_inf)
+        return (1 / (float)n_inf) * 0.5f;
+    return (n_fin == 1 ? 1.0f : hier_pdf(sc, li - n_inf, from_pos)) * (1 - 0.5f);
+}
+
 // ---------------------------------------------------------------- one path vertex
 
 struct PathVertexIn {
@@ -293,9 +602,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     out.radiance     = Col{ 0, 0, 0 };
 
     const ig_technique tech = sc.tech;
-    // make_uniform_light_selector (light/light_selector.art:26-46)
-    const float sel_pdf = sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
-    const bool nee      = tech.nee != 0;
+    const bool nee          = tech.nee != 0;
 
     if (in.ent < 0) {
         // ---- miss: on_miss (technique/pathtracer.art:141-168) over infinite, non-delta lights
@@ -304,8 +611,8 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             const ig_light& L = sc.lights[li];
             if (L.type != IG_LIGHT_ENV)
                 continue;
-            const float pdf_s = 1 / (4 * kPi);
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * sel_pdf * pdf_s) : 1.0f;
+            const float pdf_s = 1 / (4 * kPi); // equal_area_sphere_pdf (light/env.art:101)
+            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, (int)li, in.org) * pdf_s) : 1.0f;
             const Col c       = clamp_color(tech, (in.contrib * Col{ L.d[0], L.d[1], L.d[2] }) * mis);
             sum               = Col{ sum.r + c.r, sum.g + c.g, sum.b + c.b };
         }
@@ -314,10 +621,11 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         return;
     }
 
-    const Surf surf        = surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
-    const f3 N             = surf.local.c2;
-    const f3 out_dir       = -in.dir;
+    const BsdfCtx bsdf(mat, surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v));
+    const Surf& surf = bsdf.surf;
+    const f3 N       = surf.local.c2;
+    const f3 out_dir = -in.dir;
 
     // RNG resumes where the path left off (mapping_gpu.art:171)
     const int sample = in.ray_id % fr.spi;
@@ -332,23 +640,21 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         if (dcos > kFltEps) {
             const PlaneLight pl(sc.lights[mat.light_id]);
             const float pdf_s = pl.pdf(in.org);
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * sel_pdf * pdf_s) : 1.0f;
+            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
             out.has_radiance  = true;
             out.radiance      = clamp_color(tech, (in.contrib * pl.radiance) * mis);
         }
     }
 
-    const bool is_delta = mat.bsdf_type == IG_BSDF_DIELECTRIC;
-    const Col kd        = Col{ mat.p[0], mat.p[1], mat.p[2] };
-
     // ---- on_shadow (technique/pathtracer.art:52-117): next event estimation
-    if (nee && !is_delta && sc.light_count != 0 && in.depth + 1 <= tech.max_depth) {
-        const int lid     = sc.light_count <= 1 ? 0 : rnd.range(0, (int)sc.light_count - 1); // pick_light_id
+    if (nee && !bsdf.all_delta() && sc.light_count != 0 && in.depth + 1 <= tech.max_depth) {
+        float sel_pdf;
+        const int lid     = select_light(sc, rnd, surf.point, sel_pdf);
         const ig_light& L = sc.lights[lid];
         f3 lpos{}, ldir{};
         Col lint{ 0, 0, 0 };
         float pdf_value = 0, lcos = 0, ldist = 0;
-        bool pdf_area = false, delta = false, usable = true;
+        bool pdf_area = false, delta = false, infinite = false;
         if (L.type == IG_LIGHT_PLANE) {
             // make_area_light.sample_direct (light/area.art:10-26)
             const PlaneLight pl(L);
@@ -373,27 +679,31 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             lcos        = 1;
             delta       = true;
         } else {
-            usable = false;
+            // constant environment: make_environment_light_function_spherical.sample_direct (light/env.art:89-93)
+            const float ux = rnd.f32();
+            const float uy = rnd.f32();
+            ldir           = square_to_sphere(ux, uy);
+            pdf_value      = 1 / (4 * kPi);
+            lint           = Col{ L.d[0], L.d[1], L.d[2] } * (1 / pdf_value);
+            lpos           = surf.point + ldir * sc.scene_radius;
+            lcos           = 1.0f;
+            ldist          = sc.scene_radius;
+            infinite       = true;
         }
-        if (usable) {
-            const float dist2   = ldist * ldist;
-            const float pdf_l_s = (pdf_area ? pdf_value * dist2 / lcos : pdf_value) * sel_pdf; // driver/pdf.art:19-38
-            if (pdf_l_s > kFltEps && lcos > kFltEps) {
-                float mis = 1;
-                if (!delta) {
-                    const float pdf_e_s = pos_cos(ldir, N) / kPi; // lambertian pdf (bsdf/diffuse.art:4)
-                    mis                 = 1 / (1 + pdf_e_s / pdf_l_s);
-                }
-                const float factor = pdf_value / pdf_l_s;
-                const Col ev       = kd * (pos_cos(ldir, N) * kInvPi); // lambertian eval (bsdf/diffuse.art:3)
-                const Col c        = clamp_color(tech, (lint * (in.contrib * ev)) * (mis * factor));
-                if ((c.r + c.g + c.b) / 3 > kFltEps) {
-                    out.shadow = true;
-                    out.s_org  = surf.point;
-                    out.s_dir  = lpos - surf.point;
-                    out.s_tmax = 1 - kRayOffset;
-                    out.s_col  = c;
-                }
+        const float dist2   = ldist * ldist;
+        const float pdf_l_s = (pdf_area ? pdf_value * dist2 / lcos : pdf_value) * sel_pdf; // driver/pdf.art:19-38
+        if (pdf_l_s > kFltEps && lcos > kFltEps) {
+            float mis = 1;
+            if (!delta)
+                mis = 1 / (1 + bsdf.pdf(ldir, out_dir) / pdf_l_s);
+            const float factor = pdf_value / pdf_l_s;
+            const Col c        = clamp_color(tech, (lint * (in.contrib * bsdf.eval(ldir, out_dir))) * (mis * factor));
+            if ((c.r + c.g + c.b) / 3 > kFltEps) {
+                out.shadow = true;
+                out.s_org  = surf.point;
+                out.s_dir  = infinite ? ldir : lpos - surf.point;
+                out.s_tmax = infinite ? kFltMax : 1 - kRayOffset;
+                out.s_col  = c;
             }
         }
     }
@@ -404,41 +714,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         float pdf, s_eta;
         Col color;
         bool sdelta;
-        if (!is_delta) {
-            // make_lambertian_bsdf.sample (bsdf/diffuse.art:5-9), sample_cosine_hemisphere (core/sampling.art:62-70)
-            const float u   = rnd.f32();
-            const float v   = rnd.f32();
-            const float c   = safe_sqrt(v);
-            const float s   = safe_sqrt(1 - v);
-            const float phi = 2 * kPi * u;
-            in_dir          = mul33(surf.local, f3{ s * igm_cos(phi), s * igm_sin(phi), c });
-            pdf             = c / kPi;
-            color           = kd;
-            s_eta           = 1;
-            sdelta          = false;
-        } else {
-            // make_pure_dielectric_bsdf.sample (bsdf/dielectric.art:18-34); n1 = ext_ior, n2 = int_ior
-            const float n1 = mat.p[0], n2 = mat.p[1];
-            const float k     = surf.entering ? n1 / n2 : n2 / n1;
-            const float cos_o = dot3(out_dir, N);
-            float cos_t = 0, F = 1;
-            if (!fresnel(k, cos_o, cos_t, F)) {
-                cos_t = 0;
-                F     = 1;
-            }
-            if (rnd.f32() > F) {
-                in_dir = N * (k * cos_o - cos_t) - out_dir * k; // vec3_refract (core/vector.art:126)
-                color  = Col{ mat.p[5], mat.p[6], mat.p[7] } * 1.0f;
-                s_eta  = k;
-            } else {
-                in_dir = N * (2 * dot3(N, out_dir)) - out_dir; // vec3_reflect (core/vector.art:123)
-                color  = Col{ mat.p[2], mat.p[3], mat.p[4] };
-                s_eta  = 1;
-            }
-            pdf    = 1;
-            sdelta = true;
-        }
-        if (pdf > kFltEps) {
+        if (bsdf.sample(rnd, out_dir, in_dir, pdf, color, s_eta, sdelta) && pdf > kFltEps) {
             const Col nc        = in.contrib * color;
             const float e2      = in.eta * in.eta;
             const float rr_prob = (in.depth + 1 > tech.min_depth) ? clampf(igm_max(nc.r * e2, igm_max(nc.g * e2, nc.b * e2)), 0.05f, 0.95f) : 1.0f;

@@ -28,10 +28,15 @@ template <bool ANY_HIT, bool STATS>
 struct Traverser {
     // ---- ray + hit
     RayT gray, cur;
-    float tmin, tmax;
+    float tmin, tmax; // tmax == distance of the accepted hit (ray.tmax shrinks with it)
     uint32_t rflags;
     float hit_u, hit_v;
     int hit_prim, hit_ent;
+    // ---- hit of the shape-level traversal in flight (local_hit / local ray.tmax of handle_local)
+    float ltmax, l_u, l_v;
+    int l_prim;
+    int lbase;  // stack pointer of the saved scene-level top
+    bool lterm; // any-hit: the shape-level traversal found its hit
     // ---- control
     int top_node;
     float top_tmin;
@@ -86,6 +91,10 @@ struct Traverser {
         ent_last   = true;
         need_cull  = true;
         finished   = false;
+        ltmax = l_u = l_v = 0;
+        l_prim = -1;
+        lbase  = 0;
+        lterm  = false;
         node_off   = sc.scene_nodes_off;
         // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
         ptr      = -1;
@@ -102,18 +111,34 @@ struct Traverser {
     IG_DEV void settle(const DevScene& sc, StackLds& st, int tid)
     {
         while (mode == 0 && !finished) {
-            if (need_cull) {
-                while (top_node != 0 && !(top_tmin <= tmax))
+            if (level == 1 && lterm) {
+                // any-hit: the shape-level traversal returned early; unwind its stack entries
+                ptr      = lbase;
+                top_node = 0;
+            } else if (need_cull) {
+                const float cull_t = level ? ltmax : tmax;
+                while (top_node != 0 && !(top_tmin <= cull_t))
                     pop_top(st, tid);
                 need_cull = false;
             }
             if (top_node == 0) {
                 if (level == 1) {
-                    // shape BVH exhausted: back to the scene leaf run (mapping_cpu.art:489-508)
+                    // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
+                    // accepted only if its (rounded) distance does not exceed the current one.
                     level = 0;
+                    lterm = false;
                     pop_top(st, tid); // saved scene-level top
                     cur      = gray;
                     node_off = sc.scene_nodes_off;
+                    if (l_prim != -1 && ltmax <= tmax) {
+                        tmax     = ltmax;
+                        hit_u    = l_u;
+                        hit_v    = l_v;
+                        hit_prim = l_prim;
+                        hit_ent  = cur_ent;
+                        if (ANY_HIT)
+                            finished = true;
+                    }
                     if (ent_last)
                         need_cull = true;
                     else
@@ -126,7 +151,7 @@ struct Traverser {
             } else {
                 // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
                 // hit is dropped, its items have no effect in the reference either
-                const bool active = top_tmin <= tmax;
+                const bool active = top_tmin <= (level ? ltmax : tmax);
                 if (level)
                     tri_cursor = ~top_node;
                 else
@@ -176,6 +201,10 @@ struct Traverser {
                 cur_ent = entity_id & 0x7FFFFFFF;
                 // save the scene-level top, then a fresh stack: sentinel + shape root
                 push_entry(st, tid, top_node, top_tmin);
+                lbase  = ptr;
+                ltmax  = tmax; // invalid_hit(local_ray.tmax)
+                l_prim = -1;
+                lterm  = false;
                 push_entry(st, tid, 0, kFltMax);
                 top_node  = 1;
                 top_tmin  = tmin;
@@ -199,7 +228,8 @@ struct Traverser {
             const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
             if (STATS)
                 ++st_nodes;
-            bool pushed = false;
+            bool pushed           = false;
+            const float node_tmax = level ? ltmax : tmax;
             // two halves of four children keep the live register set small
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -214,7 +244,7 @@ struct Traverser {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float entry, exit;
-                    slab_test(cur, tmin, tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
+                    slab_test(cur, tmin, node_tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
                     const bool hit = (ch[i] != 0) & !(exit < entry);
                     if (hit) {
                         // push (becomes the top) if nearer than the current top, else push_after
@@ -250,26 +280,27 @@ struct Traverser {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 valid = valid & (pid[i] != -1);
-                if (valid && !(ANY_HIT && finished)) {
+                if (valid && !(ANY_HIT && lterm)) {
                     if (STATS)
                         ++st_tris;
                     float t, u, v;
-                    if (tri_test(cur, tmin, tmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
+                    if (tri_test(cur, tmin, ltmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
                                  f3{ q[6][i], q[7][i], q[8][i] }, f3{ q[9][i], q[10][i], q[11][i] }, t, u, v)) {
-                        tmax     = t;
-                        hit_u    = u;
-                        hit_v    = v;
-                        hit_prim = pid[i] & 0x7FFFFFFF;
-                        hit_ent  = cur_ent;
+                        ltmax  = t;
+                        l_u    = u;
+                        l_v    = v;
+                        l_prim = pid[i] & 0x7FFFFFFF;
                         if (ANY_HIT)
-                            finished = true;
+                            lterm = true;
                     }
                 }
             }
-            if (pid[3] < 0) {
+            if (pid[3] < 0 || (ANY_HIT && lterm)) {
                 mode      = 0;
                 need_cull = true;
             }
+            if (ANY_HIT && lterm)
+                settle(sc, st, tid); // return to the scene level now: the hit may end the ray
         }
     }
 };

@@ -21,6 +21,7 @@
 
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <string>
@@ -269,6 +270,7 @@ struct Scene {
     std::vector<int32_t> entity_per_material;
     std::vector<ig_light> lights;
     std::vector<float> light_hierarchy;
+    std::vector<uint32_t> light_codes;
     std::vector<std::string> entity_names;
     std::vector<std::string> material_names;
     igd_scene tables{};
@@ -404,7 +406,32 @@ static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::str
     shapes.push_back(rec);
 }
 
-static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, int depth = 0)
+// A colour property that names a checkerboard texture (src/runtime/pattern/CheckerBoardPattern.cpp:13-33,
+// src/artic/texture/checkerboard.art) is lowered into the material record; other textures are refused.
+static bool lowerCheckerboard(const JsonValue& prop, const JsonValue& textures, ig_material& m, const std::string& owner)
+{
+    if (!prop.isString())
+        return false;
+    for (const auto& t : textures.arr) {
+        if (t.getString("name") != prop.str)
+            continue;
+        if (t.getString("type") != "checkerboard")
+            fail("'" + owner + "': texture '" + prop.str + "' of type '" + t.getString("type") + "' is not supported by the HIP backend here");
+        if (t.has("transform"))
+            fail("'" + owner + "': checkerboard transforms are not supported by this loader");
+        const V3 c0 = getColor(t, "color0", V3(0, 0, 0), prop.str);
+        const V3 c1 = getColor(t, "color1", V3(1, 1, 1), prop.str);
+        m.flags |= IG_MAT_CHECKER;
+        m.q[0] = c0.x, m.q[1] = c0.y, m.q[2] = c0.z;
+        m.q[3] = c1.x, m.q[4] = c1.y, m.q[5] = c1.z;
+        m.q[6] = getConstNumber(t, "scale_x", 2.0f, prop.str);
+        m.q[7] = getConstNumber(t, "scale_y", 2.0f, prop.str);
+        return true;
+    }
+    return false;
+}
+
+static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, int depth = 0)
 {
     const JsonValue* bsdf = nullptr;
     for (const auto& b : scene_bsdfs.arr)
@@ -423,8 +450,11 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
     const std::string type = bsdf->getString("type");
     if (type == "diffuse" || type == "roughdiffuse") {
         m.bsdf_type = IG_BSDF_DIFFUSE;
-        const V3 kd = getColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), name);
-        m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
+        const JsonValue* refl = bsdf->find("reflectance");
+        if (!(refl && lowerCheckerboard(*refl, textures, m, name))) {
+            const V3 kd = getColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), name);
+            m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
+        }
         m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
         if (m.p[3] > 1.1920928955e-07f)
             fail("BSDF '" + name + "': rough (Oren-Nayar) diffuse is not supported by the HIP backend");
@@ -443,10 +473,145 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[5] = kt.x, m.p[6] = kt.y, m.p[7] = kt.z;
         if (bsdf->getBool("thin", false))
             m.flags |= IG_MAT_THIN;
+    } else if (type == "conductor" || type == "roughconductor") {
+        // ConductorBSDF.cpp:13-34 (defaults: material "none" = eta 0, k 1, BSDF.cpp:41), roughness via
+        // BSDF::setupRoughness (BSDF.cpp:53-99): VNDF-GGX, compute_explicit(roughness, anisotropic)
+        // (src/artic/core/microfacet.art:427-432)
+        if (bsdf->has("material"))
+            fail("BSDF '" + name + "': named conductor materials are not supported by this loader");
+        if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
+            fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
+        const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
+        if (!bsdf->has(rname))
+            fail("BSDF '" + name + "': perfectly smooth conductors (mirror) are not supported by the HIP backend");
+        m.bsdf_type    = IG_BSDF_CONDUCTOR;
+        const V3 eta   = getColor(*bsdf, "eta", V3(0, 0, 0), name);
+        const V3 k     = getColor(*bsdf, "k", V3(1, 1, 1), name);
+        const V3 ks    = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
+        const float r  = getConstNumber(*bsdf, rname, 0.1f, name);
+        const float an = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
+        const float aspect = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+        m.p[0] = eta.x, m.p[1] = eta.y, m.p[2] = eta.z;
+        m.p[3] = k.x, m.p[4] = k.y, m.p[5] = k.z;
+        m.p[6] = ks.x, m.p[7] = ks.y, m.p[8] = ks.z;
+        m.p[9]  = r / aspect;
+        m.p[10] = r * aspect;
+        if (m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
+            fail("BSDF '" + name + "': roughness <= 1e-4 makes a delta conductor, which is not supported by the HIP backend");
     } else {
         fail("BSDF '" + name + "': type '" + type + "' is not supported by the HIP backend");
     }
     return m;
+}
+
+// ---------------------------------------------------------------- light hierarchy
+// LightHierarchy::setup (src/runtime/light/LightHierarchy.cpp:47-125) over PointBvh
+// (src/runtime/container/PointBvh.inl:23-96), restated including its quirks (the stored split value
+// `mid` is half the node's largest extent, not a coordinate).
+struct LightEntry {
+    V3 position, direction;
+    float flux; // negative: no direction (delta light)
+    int32_t id;
+};
+
+struct PointBvhNode {
+    size_t index;
+    BBox bbox;
+    float mid;
+    int axis; // < 0: leaf
+};
+
+static void buildLightHierarchy(const std::vector<LightEntry>& lights, std::vector<float>& out_nodes, std::vector<uint32_t>& out_codes)
+{
+    std::vector<PointBvhNode> inner;
+    std::vector<LightEntry> leaves;
+    auto makeLeaf = [](const BBox& b) { return PointBvhNode{ 0, b, 0, -1 }; };
+
+    for (const LightEntry& elem : lights) {
+        const V3 p = elem.position;
+        leaves.push_back(elem);
+        if (inner.empty()) {
+            BBox b;
+            b.extend(p);
+            inner.push_back(makeLeaf(b));
+            continue;
+        }
+        // getForPointExtend: extend boxes along the path, descend by the box centre
+        size_t cur = 0;
+        for (;;) {
+            inner[cur].bbox.extend(p);
+            if (inner[cur].axis < 0)
+                break;
+            const float mid = inner[cur].bbox.center()[inner[cur].axis];
+            cur             = p[inner[cur].axis] < mid ? inner[cur].index : inner[cur].index + 1;
+        }
+        const size_t leafIdx    = leaves.size() - 1;
+        const size_t oldLeafIdx = inner[cur].index;
+        const BBox nodeBox      = inner[cur].bbox;
+        const V3 diam           = nodeBox.diameter();
+        int axis                = 0;
+        float maxc              = diam.x;
+        if (diam.y > maxc) { maxc = diam.y; axis = 1; }
+        if (diam.z > maxc) { maxc = diam.z; axis = 2; }
+        const float mid      = maxc / 2;
+        const size_t leftIdx = inner.size();
+        inner[cur].index = leftIdx;
+        inner[cur].axis  = axis;
+        inner[cur].mid   = mid;
+        // computeSplit(left, right, axis, 0.5) (math/BoundingBox.h:74-82)
+        BBox leftBox = nodeBox, rightBox = nodeBox;
+        const float off = (nodeBox.max[axis] - nodeBox.min[axis]) * 0.5f;
+        leftBox.max[axis] -= off;
+        rightBox.min[axis] += off;
+        inner.push_back(makeLeaf(leftBox));
+        inner.push_back(makeLeaf(rightBox));
+        if (p[axis] < mid) {
+            inner[leftIdx].index     = leafIdx;
+            inner[leftIdx + 1].index = oldLeafIdx;
+        } else {
+            inner[leftIdx].index     = oldLeafIdx;
+            inner[leftIdx + 1].index = leafIdx;
+        }
+    }
+
+    std::vector<LightEntry> entries(inner.size());
+    out_codes.assign(lights.size(), 0);
+    std::function<LightEntry(size_t, uint32_t, uint32_t)> populate = [&](size_t id, uint32_t code, uint32_t depth) -> LightEntry {
+        const PointBvhNode& node = inner.at(id);
+        LightEntry& entry        = entries[id];
+        if (node.axis < 0) {
+            entry                        = leaves.at(node.index);
+            out_codes[(size_t)entry.id] = code;
+        } else {
+            const LightEntry left  = populate(node.index, code, depth + 1);
+            const LightEntry right = populate(node.index + 1, code | (0x1u << depth), depth + 1);
+            entry.position         = node.bbox.center();
+            entry.id               = -(int32_t)(node.index + 1);
+            if (left.flux < 0 && right.flux < 0) {
+                entry.direction = V3(0, 0, 1);
+                entry.flux      = left.flux + right.flux;
+            } else if (left.flux < 0) {
+                entry.direction = V3(0, 0, 1);
+                entry.flux      = -(-left.flux + right.flux);
+            } else if (right.flux < 0) {
+                entry.direction = V3(0, 0, 1);
+                entry.flux      = -(left.flux - right.flux);
+            } else {
+                entry.direction = normalized(left.direction + right.direction);
+                entry.flux      = left.flux + right.flux;
+            }
+        }
+        return entry;
+    };
+    populate(0, 0, 0);
+
+    out_nodes.clear();
+    for (const LightEntry& e : entries) {
+        float idf;
+        std::memcpy(&idf, &e.id, 4);
+        const float rec[8] = { e.position.x, e.position.y, e.position.z, e.flux, e.direction.x, e.direction.y, e.direction.z, idf };
+        out_nodes.insert(out_nodes.end(), rec, rec + 8);
+    }
 }
 
 static void writeEntity(std::vector<float>& tbl, const Affine& toLocal, const Affine& toGlobal, const M3& normalMat, uint32_t shapeID, uint32_t materialID)
@@ -576,6 +741,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     const JsonValue& bsdfs    = doc.find("bsdfs") ? *doc.find("bsdfs") : emptyArray;
     const JsonValue& jlights  = doc.find("lights") ? *doc.find("lights") : emptyArray;
     const JsonValue& entities = doc.find("entities") ? *doc.find("entities") : emptyArray;
+    const JsonValue& textures = doc.find("textures") ? *doc.find("textures") : emptyArray;
+    if (!textures.isArray())
+        fail("Expected 'textures' to be an array");
     if (!bsdfs.isArray() || !jlights.isArray() || !entities.isArray())
         fail("Expected 'bsdfs', 'lights' and 'entities' to be arrays");
     if (doc.has("media") && !doc.find("media")->arr.empty())
@@ -685,6 +853,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
 
     // ---- lights: infinite first, then finite (light_selector.art:26-46 id convention)
     std::vector<ig_light> infinite, finite;
+    std::vector<LightEntry> hier_entries; // position / direction / flux per finite light (Light::position, direction, computeFlux)
     std::map<std::string, int32_t> finite_index_of_entity;
     for (const auto& l : jlights.arr) {
         const std::string lname = l.getString("name");
@@ -722,6 +891,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             out.entity_id = (int32_t)it->second.id;
             std::memcpy(out.d, d, sizeof(d));
             finite_index_of_entity[ent] = (int32_t)finite.size();
+            // AreaLight.cpp:68-70,96-107: centre of the plane, its normal, flux = mean(radiance * area * pi)
+            const V3 cache = radiance * (area * Pi);
+            hier_entries.push_back(LightEntry{ origin + x_axis * 0.5f + y_axis * 0.5f, normal, (cache.x + cache.y + cache.z) / 3, (int32_t)finite.size() });
             finite.push_back(out);
         } else if (type == "point") {
             // PointLight.cpp:16-71 ("SimplePointLight": pos, 0, intensity, 0)
@@ -737,13 +909,21 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             out.type = IG_LIGHT_POINT;
             out.d[0] = pos.x, out.d[1] = pos.y, out.d[2] = pos.z;
             out.d[4] = intensity.x, out.d[5] = intensity.y, out.d[6] = intensity.z;
+            // PointLight.cpp:17-31: no direction (stored as negative flux), flux = mean(intensity * 4 pi)
+            const V3 cache = intensity * (4 * Pi);
+            hier_entries.push_back(LightEntry{ pos, V3(0, 0, 1), -((cache.x + cache.y + cache.z) / 3), (int32_t)finite.size() });
             finite.push_back(out);
         } else if (type == "env" || type == "constant") {
+            // EnvironmentLight.cpp:40-98: a constant radiance bakes to a 1x1 texture, so the reference
+            // builds make_environment_light (uniform sphere sampling), not the CDF-sampled variant.
             if (l.has("radiance") && l.find("radiance")->isString() && l.find("radiance")->str.rfind("color(", 0) != 0)
                 fail("Environment light '" + lname + "': textured environment maps are not supported by the HIP backend");
+            if (l.has("transform"))
+                fail("Environment light '" + lname + "': a transform has no effect on a constant environment and is refused");
             const V3 radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
+            const V3 scale    = getColor(l, "scale", V3(1, 1, 1), lname);
             out.type          = IG_LIGHT_ENV;
-            out.d[0] = radiance.x, out.d[1] = radiance.y, out.d[2] = radiance.z;
+            out.d[0] = scale.x * radiance.x, out.d[1] = scale.y * radiance.y, out.d[2] = scale.z * radiance.z; // color_mul(scale, tex), env.art:163
             infinite.push_back(out);
         } else {
             fail("Light '" + lname + "': type '" + type + "' is not supported by the HIP backend");
@@ -754,7 +934,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
 
     // ---- materials
     for (size_t m = 0; m < mat_keys.size(); ++m) {
-        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs);
+        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures);
         if (!mat_keys[m].light_entity.empty())
             mat.light_id = (int32_t)infinite.size() + finite_index_of_entity.at(mat_keys[m].light_entity);
         sc->materials.push_back(mat);
@@ -762,9 +942,16 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     }
 
     // ---- light selector (LoaderLight.cpp:423-460: <= 1 light -> uniform)
-    if (sc->lights.size() > 1 && !selector.empty() && selector != "uniform")
-        fail("Light selector '" + selector + "' is not supported by the HIP backend (only 'uniform')");
     tech.light_selector = IG_SELECTOR_UNIFORM;
+    if (sc->lights.size() > 1 && !selector.empty() && selector != "uniform") {
+        if (selector != "hierarchy")
+            fail("Light selector '" + selector + "' is not supported by the HIP backend (only 'uniform' and 'hierarchy')");
+        // make_hierarchy_light_selector falls back to uniform without finite lights (light_selector.art:81-83)
+        if (!finite.empty()) {
+            tech.light_selector = IG_SELECTOR_HIERARCHY;
+            buildLightHierarchy(hier_entries, sc->light_hierarchy, sc->light_codes);
+        }
+    }
 
     // ---- publish
     igd_scene& t         = sc->tables;
@@ -786,8 +973,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.lights             = sc->lights.data();
     t.light_count        = (uint32_t)sc->lights.size();
     t.infinite_light_count = (uint32_t)infinite.size();
-    t.light_hierarchy    = nullptr;
-    t.light_hierarchy_nodes = 0;
+    t.light_hierarchy    = sc->light_hierarchy.empty() ? nullptr : sc->light_hierarchy.data();
+    t.light_hierarchy_nodes = (uint32_t)(sc->light_hierarchy.size() / 8);
+    t.light_codes        = sc->light_codes.empty() ? nullptr : sc->light_codes.data();
     t.camera             = cam;
     t.technique          = tech;
     for (int i = 0; i < 3; ++i) {
@@ -796,6 +984,11 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     }
     t.film_width  = width;
     t.film_height = height;
+    {
+        // bbox_radius(scene_bbox) * 1.01 (src/artic/core/bbox.art:24, light/env.art:88)
+        const V3 size  = entityCount ? sceneBBox.diameter() : V3(0, 0, 0);
+        t.scene_radius = std::sqrt(size.x * size.x + size.y * size.y + size.z * size.z) / 2 * 1.01f;
+    }
     return sc;
 }
 

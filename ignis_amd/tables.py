@@ -62,9 +62,10 @@ class Scene(C.Structure):
         ("entity_per_material", C.POINTER(C.c_int32)),
         ("lights", C.POINTER(Light)), ("light_count", C.c_uint32), ("infinite_light_count", C.c_uint32),
         ("light_hierarchy", C.POINTER(C.c_float)), ("light_hierarchy_nodes", C.c_uint32),
+        ("light_codes", C.POINTER(C.c_uint32)),
         ("camera", Camera), ("technique", Technique),
         ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-        ("film_width", C.c_int32), ("film_height", C.c_int32),
+        ("film_width", C.c_int32), ("film_height", C.c_int32), ("scene_radius", C.c_float),
     ]
 
 

@@ -123,7 +123,9 @@ enum ig_light_type {
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
  *                t0.xy, t1.xy | t2.xy, t3.xy | radiance.rgb, area
  * d[] for POINT: position.xyz, 0 | intensity.rgb, 0
- * d[] for ENV:   radiance.rgb, 0 */
+ * d[] for ENV:   radiance.rgb (= scale * radiance), 0   -- constant environment, sampled uniformly over
+ *                the sphere (make_environment_light -> make_environment_light_function_spherical,
+ *                src/artic/light/env.art:83-108,161-164) */
 typedef struct ig_light {
     int32_t type;
     int32_t entity_id; /* emissive entity for area lights, -1 otherwise */
@@ -187,14 +189,19 @@ typedef struct igd_scene {
     const ig_light* lights;
     uint32_t light_count;
     uint32_t infinite_light_count;
-    /* light hierarchy for IG_SELECTOR_HIERARCHY: 8 floats per node */
+    /* light hierarchy for IG_SELECTOR_HIERARCHY over the finite lights (src/runtime/light/LightHierarchy.cpp:
+     * 47-125, src/artic/light/light_hierarchy.art:14-96): 8 floats per node {pos.xyz, +-flux, dir.xyz, id};
+     * id >= 0: leaf = finite light id, id < 0: inner, children at -id-1 and -id. light_codes[finite id] =
+     * left(0)/right(1) decisions from the root, LSB first (used for the selection pdf). */
     const float* light_hierarchy;
     uint32_t light_hierarchy_nodes;
+    const uint32_t* light_codes;
     ig_camera camera;
     ig_technique technique;
     float bbox_min[3];
     float bbox_max[3];
     int32_t film_width, film_height;
+    float scene_radius; /* bbox_radius(scene_bbox) * 1.01, src/artic/light/env.art:88 */
 } igd_scene;
 
 #ifdef __cplusplus

@@ -270,7 +270,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
             // only miss shading
             for (int i = 0; i < current_size; ++i) {
                 Color c;
-                if (pt_tech.on_miss(read_payload(primary, i), c))
+                if (pt_tech.on_miss(read_ray(primary, i), read_payload(primary, i), c))
                     splat(primary.id[i], c);
             }
             current_size = 0;
@@ -347,7 +347,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
             (void)total_size;
             for (int i = begin; i < last; ++i) {
                 Color c;
-                if (!pt_tech.on_miss(read_payload(primary, i), c))
+                if (!pt_tech.on_miss(read_ray(primary, i), read_payload(primary, i), c))
                     c = Color{ 0, 0, 0 };
                 splat(primary.id[i], c);
                 primary.id[i] = -1;

@@ -265,6 +265,90 @@ static inline bool fresnel(float eta, float cos_i, float& cos_t_out, float& fact
     return true;
 }
 
+// ---- core/fresnel.art:29-36
+static inline float conductor_factor(float n, float k, float cos_i)
+{
+    const float f   = n * n + k * k;
+    const float d1  = f * cos_i * cos_i;
+    const float d2  = 2.0f * n * cos_i;
+    const float R_s = safe_div(d1 - d2, d1 + d2);
+    const float R_p = safe_div(f - d2 + cos_i * cos_i, f + d2 + cos_i * cos_i);
+    return clampf((R_s * R_s + R_p * R_p) * 0.5f, 0, 1);
+}
+
+static inline float absolute_cos(Vec3 a, Vec3 b) { return igm_abs(vec3_dot(a, b)); } // common.art:302
+static inline Vec3 vec3_halfway(Vec3 a, Vec3 b) { return vec3_normalize(vec3_add(a, b)); } // vector.art:142
+
+// ---- GGX microfacet model (core/microfacet.art:158-199) and the VNDF sampler of Dupuy & Benyoub
+// (microfacet.art:372-404), distribution make_vndf_ggx_distribution (:404-425)
+struct GGX {
+    Mat3x3 local;
+    float alpha_u, alpha_v;
+
+    float D(Vec3 m) const // ndf_ggx
+    {
+        const float cosZ = vec3_dot(local.col[2], m);
+        const float cosX = vec3_dot(local.col[0], m);
+        const float cosY = vec3_dot(local.col[1], m);
+        const float kx   = cosX / alpha_u;
+        const float ky   = cosY / alpha_v;
+        const float k    = kx * kx + ky * ky + cosZ * cosZ;
+        return safe_div(1, flt_pi * alpha_u * alpha_v * k * k);
+    }
+    float G1(Vec3 w) const // g_1_smith
+    {
+        const float cosZ = vec3_dot(local.col[2], w);
+        if (igm_abs(cosZ) <= flt_eps)
+            return 0;
+        const float cosX = vec3_dot(local.col[0], w);
+        const float cosY = vec3_dot(local.col[1], w);
+        const float kx   = alpha_u * cosX;
+        const float ky   = alpha_v * cosY;
+        const float a2   = kx * kx + ky * ky;
+        if (a2 <= flt_eps)
+            return 1;
+        const float k2    = a2 / (cosZ * cosZ);
+        const float denom = 1 + igm_sqrt(1 + k2);
+        return 2 / denom;
+    }
+    float pdf(Vec3 w, Vec3 h) const // pdf_vndf_ggx
+    {
+        const float cosZ = absolute_cos(local.col[2], w);
+        return safe_div(G1(w) * absolute_cos(w, h) * D(h), cosZ);
+    }
+    Vec3 sample(Rng& rnd, Vec3 vN) const // sample_vndf_ggx
+    {
+        const Vec3 vL = make_vec3(vec3_dot(local.col[0], vN), vec3_dot(local.col[1], vN), vec3_dot(local.col[2], vN)); // shading::to_local
+        const Vec3 sL = vec3_normalize(make_vec3(alpha_u * vL.x, alpha_v * vL.y, vL.z));
+        const float u0 = rnd.next_f32();
+        const float u1 = rnd.next_f32();
+        const float phi      = 2 * flt_pi * u0;
+        const float z        = (1 - u1) * (1 + sL.z) - sL.z;
+        const float sinTheta = igm_sqrt(clampf(1 - z * z, 0, 1));
+        const float x        = sinTheta * igm_cos(phi);
+        const float y        = sinTheta * igm_sin(phi);
+        const Vec3 h         = vec3_add(make_vec3(x, y, z), vL);
+        const Vec3 Nh        = vec3_normalize(make_vec3(h.x * alpha_u, h.y * alpha_v, h.z));
+        // shading::to_world
+        return vec3_add(vec3_add(vec3_mulf(local.col[0], Nh.x), vec3_mulf(local.col[1], Nh.y)), vec3_mulf(local.col[2], Nh.z));
+    }
+};
+
+// make_checkerboard_texture with the identity transform (texture/checkerboard.art, core/math.art:88-91)
+static inline float math_wrap(float v, float mn, float mx)
+{
+    const float range = mx - mn;
+    return range <= flt_eps ? mn : v - (range * igm_floor((v - mn) / range));
+}
+static inline Color checkerboard(const ig_material& mat, Vec2 uv)
+{
+    const float sx      = uv.x * mat.q[6];
+    const float sy      = uv.y * mat.q[7];
+    const bool parity_x = ((int32_t)math_wrap(sx, 0, 2) % 2) == 0;
+    const bool parity_y = ((int32_t)math_wrap(sy, 0, 2) % 2) == 0;
+    return (parity_x ^ parity_y) ? Color{ mat.q[0], mat.q[1], mat.q[2] } : Color{ mat.q[3], mat.q[4], mat.q[5] };
+}
+
 // ---- BSDFs (driver/bsdf.art)
 struct BsdfSample {
     Vec3 in_dir;
@@ -280,19 +364,55 @@ struct Bsdf {
 
     bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
 
-    // make_lambertian_bsdf (bsdf/diffuse.art:2-13); delta BSDFs evaluate to black (dielectric.art:16-17)
-    Color eval(Vec3 in_dir, Vec3 /*out_dir*/) const
+    Color kd() const
     {
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
-            const Color kd = Color{ mat->p[0], mat->p[1], mat->p[2] };
-            return color_mulf(kd, positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
+        if (mat->flags & IG_MAT_CHECKER)
+            return checkerboard(*mat, surf->tex_coords);
+        return Color{ mat->p[0], mat->p[1], mat->p[2] };
+    }
+    GGX ggx() const { return GGX{ surf->local, mat->p[9], mat->p[10] }; }
+
+    // fresnelTerm of make_rough_conductor_bsdf (bsdf/conductor.art:118-125)
+    Color conductor_fresnel(float cosTheta) const
+    {
+        return Color{ conductor_factor(mat->p[0], mat->p[3], cosTheta), conductor_factor(mat->p[1], mat->p[4], cosTheta), conductor_factor(mat->p[2], mat->p[5], cosTheta) };
+    }
+
+    // make_lambertian_bsdf (bsdf/diffuse.art:2-13); make_rough_base_conductor_bsdf (bsdf/conductor.art:70-84);
+    // delta BSDFs evaluate to black (dielectric.art:16-17)
+    Color eval(Vec3 in_dir, Vec3 out_dir) const
+    {
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+            return color_mulf(kd(), positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            const Vec3 N      = surf->local.col[2];
+            const float cos_o = absolute_cos(out_dir, N);
+            const float cos_i = absolute_cos(in_dir, N);
+            if (cos_o <= flt_eps || cos_i <= flt_eps)
+                return Color{ 0, 0, 0 };
+            const GGX g   = ggx();
+            const Vec3 H  = vec3_halfway(in_dir, out_dir);
+            const float D = g.D(H);
+            const float G = g.G1(in_dir) * g.G1(out_dir);
+            const Color F = conductor_fresnel(absolute_cos(out_dir, H));
+            const Color IF{ 1 - F.r, 1 - F.g, 1 - F.b };
+            const Color kdz{ 0, 0, 0 }; // kd = black for conductors
+            const Color ks{ mat->p[6], mat->p[7], mat->p[8] };
+            const Color c = Color{ kdz.r * IF.r + ks.r * F.r, kdz.g * IF.g + ks.g * F.g, kdz.b * IF.b + ks.b * F.b };
+            return color_mulf(c, D * G / (4 * cos_o));
         }
         return Color{ 0, 0, 0 };
     }
-    float pdf(Vec3 in_dir, Vec3 /*out_dir*/) const
+    float pdf(Vec3 in_dir, Vec3 out_dir) const
     {
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return cosine_hemisphere_pdf(positive_cos(in_dir, surf->local.col[2]));
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            const Vec3 H        = vec3_halfway(in_dir, out_dir);
+            const float cos_h_o = absolute_cos(out_dir, H);
+            const float jacob   = safe_div(1, 4 * cos_h_o);
+            return ggx().pdf(out_dir, H) * jacob;
+        }
         return 0;
     }
     bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
@@ -303,9 +423,35 @@ struct Bsdf {
             const DirSample ds = sample_cosine_hemisphere(u, v);
             s.in_dir           = mat3x3_mul(surf->local, ds.dir);
             s.pdf              = ds.pdf;
-            s.color            = Color{ mat->p[0], mat->p[1], mat->p[2] };
+            s.color            = kd();
             s.eta              = 1;
             s.is_delta         = false;
+            return true;
+        }
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+            // make_rough_base_conductor_bsdf.sample (bsdf/conductor.art:93-114)
+            const Vec3 N      = surf->local.col[2];
+            const float cos_o = absolute_cos(out_dir, N);
+            if (cos_o <= flt_eps)
+                return false;
+            const GGX g      = ggx();
+            const Vec3 m     = g.sample(rnd, out_dir);
+            const float mpdf = g.pdf(out_dir, m);
+            if (vec3_len2(m) <= flt_eps)
+                return false;
+            const Vec3 oH = vec3_normalize(m);
+            const Vec3 H  = igm_signbit(vec3_dot(oH, out_dir)) ? vec3_neg(oH) : oH;
+            const Vec3 in_dir = vec3_reflect(out_dir, H);
+            const float cos_i = absolute_cos(in_dir, N);
+            if (cos_i <= flt_eps)
+                return false;
+            const float cos_h_o = absolute_cos(out_dir, H);
+            const float jacob   = 1 / (4 * cos_h_o);
+            s.in_dir   = in_dir;
+            s.pdf      = mpdf * jacob;
+            s.color    = color_mulf(eval(in_dir, out_dir), safe_div(1, s.pdf));
+            s.eta      = 1;
+            s.is_delta = false;
             return true;
         }
         // make_pure_dielectric_bsdf (bsdf/dielectric.art:15-37); n1 = ext_ior, n2 = int_ior
@@ -496,6 +642,108 @@ static inline DirectLightSample sample_direct_point(const ig_light& l, const Sur
 // pdf.as_solid (driver/pdf.art:19-45)
 static inline float pdf_as_solid(float value, bool is_area, float cos, float dist2) { return is_area ? value * dist2 / cos : value; }
 
+// make_environment_light -> make_environment_light_function_spherical with a constant colour
+// (light/env.art:83-108,161-164); equal_area_square_to_sphere (core/warp.art:63-91)
+static inline Vec3 equal_area_square_to_sphere(float px, float py)
+{
+    const float u  = 2 * px - 1;
+    const float v  = 2 * py - 1;
+    const float au = igm_abs(u);
+    const float av = igm_abs(v);
+    const float signedDistance = 1 - (au + av);
+    const float d  = igm_abs(signedDistance);
+    const float r  = 1 - d;
+    const float phi      = (r == 0 ? 1.0f : (av - au) / r + 1) * flt_pi / 4;
+    const float cosTheta = igm_copysign(1 - r * r, signedDistance);
+    const float sinTheta = safe_sqrt(2 - r * r) * r;
+    const float cosPhi   = igm_copysign(igm_cos(phi), u);
+    const float sinPhi   = igm_copysign(igm_sin(phi), v);
+    return make_vec3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+}
+
+static inline DirectLightSample sample_direct_env(const ig_light& l, Rng& rnd, const SurfaceElement& from_surf, float scene_radius)
+{
+    const float u   = rnd.next_f32();
+    const float v   = rnd.next_f32();
+    const Vec3 dir  = equal_area_square_to_sphere(u, v);
+    const float pdf = 1 / (4 * flt_pi); // equal_area_sphere_pdf
+    DirectLightSample s;
+    s.pos          = vec3_add(from_surf.point, vec3_mulf(dir, scene_radius));
+    s.dir          = dir;
+    s.intensity    = color_mulf(Color{ l.d[0], l.d[1], l.d[2] }, 1 / pdf);
+    s.pdf_value    = pdf;
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = false;
+    s.cos          = 1.0f;
+    s.dist         = scene_radius;
+    return s;
+}
+
+// ---- light/light_hierarchy.art:14-96 over the table built by the host (LightHierarchy.cpp)
+struct HierEntry {
+    Vec3 pos, dir;
+    float flux;
+    int32_t id;
+    bool has_dir, is_leaf;
+};
+static inline HierEntry hier_load(const igd_scene& sc, int32_t id)
+{
+    const float* e = sc.light_hierarchy + (size_t)id * 8;
+    int32_t index;
+    std::memcpy(&index, e + 7, 4);
+    HierEntry h;
+    h.pos     = Vec3{ e[0], e[1], e[2] };
+    h.dir     = Vec3{ e[4], e[5], e[6] };
+    h.flux    = igm_abs(e[3]);
+    h.id      = index < 0 ? -index - 1 : index;
+    h.has_dir = !igm_signbit(e[3]);
+    h.is_leaf = index >= 0;
+    return h;
+}
+static inline float hier_cost(const HierEntry& e, Vec3 pos)
+{
+    const Vec3 cdir   = vec3_sub(e.pos, pos);
+    const float dist2 = vec3_len2(cdir);
+    const float cos_d = e.has_dir ? igm_abs(vec3_dot(e.dir, vec3_normalize(cdir))) : 1.0f;
+    return safe_div(e.flux * cos_d, dist2);
+}
+static inline float hier_left_prop(const HierEntry& l, const HierEntry& r, Vec3 pos)
+{
+    const float cl = hier_cost(l, pos);
+    const float cr = hier_cost(r, pos);
+    return 1 / (1 + cr / cl);
+}
+static inline int32_t hier_sample(const igd_scene& sc, Rng& rnd, Vec3 pos, float& pdf)
+{
+    pdf           = 1;
+    HierEntry ent = hier_load(sc, 0);
+    while (!ent.is_leaf) {
+        const HierEntry left  = hier_load(sc, ent.id);
+        const HierEntry right = hier_load(sc, ent.id + 1);
+        const float prop      = hier_left_prop(left, right, pos);
+        const bool is_left    = rnd.next_f32() < prop;
+        ent                   = is_left ? left : right;
+        pdf *= is_left ? prop : 1 - prop;
+    }
+    return ent.id;
+}
+static inline float hier_pdf(const igd_scene& sc, int32_t finite_id, Vec3 pos)
+{
+    uint32_t code = sc.light_codes[finite_id];
+    float pdf     = 1;
+    HierEntry ent = hier_load(sc, 0);
+    while (!ent.is_leaf) {
+        const HierEntry left  = hier_load(sc, ent.id);
+        const HierEntry right = hier_load(sc, ent.id + 1);
+        const float prop      = hier_left_prop(left, right, pos);
+        const bool is_left    = (code & 0x1) == 0;
+        ent                   = is_left ? left : right;
+        pdf *= is_left ? prop : 1 - prop;
+        code >>= 1;
+    }
+    return pdf;
+}
+
 // ---- technique/pathtracer.art
 struct PTRayPayload {
     float inv_pdf;
@@ -530,9 +778,62 @@ struct PathTracer {
 
     Color handle_color(Color c) const { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; }
 
-    // make_uniform_light_selector (light/light_selector.art:26-46)
-    float light_select_pdf() const { return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count; }
-    int pick_light_id(Rng& rnd) const { return sc.light_count <= 1 ? 0 : rnd.next_i32(0, (int32_t)sc.light_count - 1); }
+    int32_t n_inf() const { return (int32_t)sc.infinite_light_count; }
+    int32_t n_fin() const { return (int32_t)(sc.light_count - sc.infinite_light_count); }
+    bool use_hierarchy() const { return sc.technique.light_selector == IG_SELECTOR_HIERARCHY && n_fin() > 0 && sc.light_hierarchy != nullptr; }
+
+    // pick_light_id (light/light_selector.art:18-24)
+    static int32_t pick_light_id(Rng& rnd, int32_t num_lights) { return num_lights <= 1 ? 0 : rnd.next_i32(0, num_lights - 1); }
+
+    // LightSelector::sample: make_uniform_light_selector (light_selector.art:26-46) or
+    // make_hierarchy_light_selector (:80-110) + make_light_hierarchy (light_hierarchy.art:103-123).
+    // Returns the index into sc.lights.
+    int32_t select_light(Rng& rnd, Vec3 from_pos, float& pdf) const
+    {
+        if (!use_hierarchy()) {
+            const int32_t num = (int32_t)sc.light_count;
+            pdf               = num == 0 ? 1.0f : 1 / (float)num;
+            return pick_light_id(rnd, num);
+        }
+        auto hsample = [&](float& p) -> int32_t {
+            if (n_fin() == 1) {
+                p = 1;
+                return 0;
+            }
+            return hier_sample(sc, rnd, from_pos, p);
+        };
+        if (n_inf() == 0) {
+            const int32_t fid = hsample(pdf);
+            return fid;
+        }
+        const float pdf_infinite = 1 / (float)n_inf();
+        const float ratio        = 0.5f;
+        const float q            = rnd.next_f32();
+        if (q < ratio) {
+            const int32_t id = pick_light_id(rnd, n_inf());
+            pdf              = pdf_infinite * ratio;
+            return id;
+        }
+        float p;
+        const int32_t fid = hsample(p);
+        pdf               = p * (1 - ratio);
+        return n_inf() + fid;
+    }
+
+    // LightSelector::pdf for light index `li` seen from `from_pos`
+    float select_pdf(int32_t li, Vec3 from_pos) const
+    {
+        if (!use_hierarchy())
+            return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
+        const bool infinite = li < n_inf();
+        auto hpdf           = [&]() { return n_fin() == 1 ? 1.0f : hier_pdf(sc, li - n_inf(), from_pos); };
+        if (n_inf() == 0)
+            return hpdf();
+        const float ratio = 0.5f;
+        if (infinite)
+            return (1 / (float)n_inf()) * ratio;
+        return hpdf() * (1 - ratio);
+    }
 
     // on_shadow (pathtracer.art:52-117)
     ShadowRayOut on_shadow(const Ray& ray, const SurfaceElement& surf, Rng& rnd, const PTRayPayload& pt, const Bsdf& bsdf) const
@@ -546,9 +847,9 @@ struct PathTracer {
         if (pt.depth + 1 > max_path_len)
             return out;
 
-        const int id                 = pick_light_id(rnd);
-        const float light_select_pdf = this->light_select_pdf();
-        const ig_light& light        = sc.lights[id];
+        float light_select_pdf;
+        const int id          = select_light(rnd, surf.point, light_select_pdf);
+        const ig_light& light = sc.lights[id];
 
         DirectLightSample ls;
         bool delta = false, infinite = false;
@@ -561,7 +862,9 @@ struct PathTracer {
             delta = true;
             break;
         default:
-            return out; // constant env NEE is lowered in a later round
+            ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);
+            infinite = true;
+            break;
         }
 
         const float pdf_l_s = pdf_as_solid(ls.pdf_value, ls.pdf_is_area, ls.cos, ls.dist * ls.dist) * light_select_pdf;
@@ -602,11 +905,11 @@ struct PathTracer {
             if (dot > flt_eps) {
                 const ig_light& light = sc.lights[mat.light_id];
                 const PlaneEmitter pe(light);
-                const Color emit  = pe.radiance;                 // light.emission(ctx)
-                const float pdf_s = pe.pdf_direct(ray.org);      // solid-angle pdf: as_solid is the identity
+                const Color emit  = pe.radiance;            // light.emission(ctx)
+                const float pdf_s = pe.pdf_direct(ray.org); // solid-angle pdf: as_solid is the identity
                 (void)hit;
-                const float mis     = enable_nee ? 1 / (1 + pt.inv_pdf * light_select_pdf() * pdf_s) : 1.0f;
-                out                 = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
+                const float mis = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf(mat.light_id, ray.org) * pdf_s) : 1.0f;
+                out             = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
                 return true;
             }
         }
@@ -614,7 +917,7 @@ struct PathTracer {
     }
 
     // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
-    bool on_miss(const PTRayPayload& pt, Color& out) const
+    bool on_miss(const Ray& ray, const PTRayPayload& pt, Color& out) const
     {
         int inflights = 0;
         Color color   = Color{ 0, 0, 0 };
@@ -624,8 +927,8 @@ struct PathTracer {
                 continue;
             ++inflights;
             const Color emit  = Color{ light.d[0], light.d[1], light.d[2] };
-            const float pdf_s = 1 / (4 * flt_pi); // uniform sphere pdf of a constant environment
-            const float mis   = enable_nee ? 1 / (1 + pt.inv_pdf * light_select_pdf() * pdf_s) : 1.0f;
+            const float pdf_s = 1 / (4 * flt_pi); // equal_area_sphere_pdf (env.art:101)
+            const float mis   = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf((int32_t)i, ray.org) * pdf_s) : 1.0f;
             const Color c     = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
             color             = Color{ color.r + c.r, color.g + c.g, color.b + c.b };
         }

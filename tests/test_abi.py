@@ -92,6 +92,7 @@ def test_transform_parsing_matches_matrix_form():
     a["entities"][0]["transform"] = [{"translate": [0.5, 0, 0]}, {"scale": 2}]
     b = flat_scene()
     b["entities"][0]["transform"] = [2, 0, 0, 0.5, 0, 2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 1]
-    ea = np.ctypeslib.as_array(LoadedScene.from_string(json.dumps(a)).scene.entities, shape=(36,)).copy()
-    eb = np.ctypeslib.as_array(LoadedScene.from_string(json.dumps(b)).scene.entities, shape=(36,)).copy()
+    sa, sb = LoadedScene.from_string(json.dumps(a)), LoadedScene.from_string(json.dumps(b))  # keep the owners alive
+    ea = np.ctypeslib.as_array(sa.scene.entities, shape=(36,)).copy()
+    eb = np.ctypeslib.as_array(sb.scene.entities, shape=(36,)).copy()
     np.testing.assert_array_equal(ea, eb)

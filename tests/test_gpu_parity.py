@@ -205,3 +205,70 @@ def test_error_paths(gpu_device):
     with pytest.raises(DeviceError):
         Device(99)
     d.close()
+
+
+# ---- config 4 features: point lights + hierarchy selector, constant environment, rough conductor (VNDF-GGX),
+# checkerboard reflectance (a13, a14)
+def _many_lights_scene(w, h):
+    from ignis_amd.tables import LoadedScene
+    return LoadedScene.from_file(os.path.join(SCENES, "many_point_lights_hip.json"), w, h)
+
+
+def test_many_point_lights_radiance_vs_oracle(gpu_device):
+    import oracle
+    w, h, spi = 160, 120, 4
+    scene = _many_lights_scene(w, h)
+    assert scene.scene.technique.light_selector == 1 and scene.scene.light_hierarchy_nodes == 19
+    fb, st = _render_gpu(gpu_device, scene, spi, w, h, iters=2, seed=4)
+    ref = np.zeros((h, w, 3), np.float32)
+    tot = {}
+    for it in range(2):
+        _, s = oracle.render(scene, spi, w, h, iteration=it, seed=4, fb=ref)
+        for k, v in s.items():
+            tot[k] = tot.get(k, 0) + v
+    assert _rel_l2(fb, ref) <= RADIANCE_TOL
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+        assert st[k] == tot[k], k
+
+
+@pytest.mark.parametrize("selector", ["uniform", "hierarchy"])
+def test_selectors_and_env_vs_oracle(gpu_device, selector):
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    pts = [{"type": "point", "name": f"L{i}", "position": [0.3 * i - 0.6, 0.2 * i - 0.4, -2 + 0.1 * i], "power": 1} for i in range(5)]
+    sc = flat_scene(pts + [{"type": "env", "name": "e", "radiance": [0.1, 0.2, 0.3]}], max_depth=4)
+    sc["technique"]["light_selector"] = selector
+    sc["textures"] = [{"type": "checkerboard", "name": "check", "scale_x": 6, "scale_y": 4, "color0": [0.2, 0.3, 0.4], "color1": [1, 0.9, 0.8]}]
+    sc["bsdfs"][0]["reflectance"] = "check"
+    scene = LoadedScene.from_string(json.dumps(sc), "", 96, 96)
+    fb, st = _render_gpu(gpu_device, scene, 4, 96, 96, seed=6)
+    ref, s = oracle.render(scene, 4, 96, 96, seed=6)
+    assert _rel_l2(fb, ref) <= RADIANCE_TOL
+    for k in ("bounce_rays", "shadow_rays", "unoccluded"):
+        assert st[k] == s[k], k
+
+
+def test_rough_conductor_vs_oracle(gpu_device):
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    sc = flat_scene([{"type": "env", "name": "e", "radiance": [1, 1, 1]},
+                     {"type": "point", "name": "p", "position": [0.2, 0.1, -1.5], "intensity": [2, 1, 0.5]}], max_depth=5)
+    sc["bsdfs"][0] = {"type": "conductor", "name": "ground", "roughness": 0.16, "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.2]}
+    scene = LoadedScene.from_string(json.dumps(sc), "", 96, 96)
+    fb, st = _render_gpu(gpu_device, scene, 4, 96, 96, seed=8)
+    ref, s = oracle.render(scene, 4, 96, 96, seed=8)
+    assert _rel_l2(fb, ref) <= RADIANCE_TOL
+    assert st["bounce_rays"] == s["bounce_rays"] and st["shadow_rays"] == s["shadow_rays"]
+
+
+def test_env_light_known_answer(gpu_device):
+    """src/tests/integrator/test_lights.py:40-44: constant environment over the white plane -> 1."""
+    import ignis_amd
+    opts = ignis_amd.RuntimeOptions.makeDefault()
+    opts.SPI = 8
+    opts.OverrideFilmSize = (256, 256)
+    with ignis_amd.loadFromString(json.dumps(flat_scene([{"type": "env", "name": "_light", "radiance": [1, 1, 1]}])), opts) as rt:
+        for _ in range(8):
+            rt.step()
+        value = float(np.mean(rt.getFramebufferForHost() / rt.IterationCount))
+    assert value == pytest.approx(1, abs=1.5e-3)  # 4.2 M samples; the reference uses 8 M and 1e-4

@@ -120,6 +120,39 @@ def test_point_light_known_answer():
     assert _mean(scene, spp=8, spi=4, size=(128, 128)) == pytest.approx(0.005100456, abs=1e-4)
 
 
+def test_env_light_known_answer():
+    scene = flat_scene([{"type": "env", "name": "_light", "radiance": [1, 1, 1]}])
+    assert _mean(scene, spp=8, spi=8, size=(192, 192)) == pytest.approx(1, abs=2e-3)
+
+
+def test_hierarchy_selector_is_unbiased():
+    pts = [{"type": "point", "name": f"L{i}", "position": [0.3 * i - 0.6, 0.2 * i - 0.4, -2 + 0.1 * i], "power": 1} for i in range(5)]
+    uniform = flat_scene(pts)
+    hier = flat_scene(pts)
+    hier["technique"]["light_selector"] = "hierarchy"
+    a, b = _mean(uniform, spp=8, spi=8, size=(96, 96)), _mean(hier, spp=8, spi=8, size=(96, 96))
+    assert a == pytest.approx(b, rel=5e-3) and a == pytest.approx(5 * 0.0057, rel=0.2)
+
+
+def test_light_hierarchy_table_layout():
+    """LightHierarchy.cpp: 2n-1 nodes for n lights, leaves carry light ids, codes retrace the path."""
+    import numpy as np
+    sc = LoadedScene.from_file(__import__("os").path.join(__import__("conftest").SCENES, "many_point_lights_hip.json"))
+    s = sc.scene
+    n = s.light_count - s.infinite_light_count
+    assert n == 10 and s.light_hierarchy_nodes == 2 * n - 1
+    nodes = np.ctypeslib.as_array(s.light_hierarchy, shape=(s.light_hierarchy_nodes, 8)).copy()
+    ids = nodes[:, 7].view(np.int32)
+    assert sorted(ids[ids >= 0].tolist()) == list(range(n))
+    for lid in range(n):
+        code, cur = int(s.light_codes[lid]), 0
+        while ids[cur] < 0:
+            cur = (-ids[cur] - 1) + (code & 1)
+            code >>= 1
+        assert ids[cur] == lid
+    assert (nodes[:, 3] < 0).all()  # point lights only: every flux is stored negative (no direction)
+
+
 def test_reproducibility_same_seed_bit_identical():
     scene = flat_scene([{"type": "point", "name": "_light", "position": [0, 0, -2], "intensity": [1, 1, 1]}])
     sc = LoadedScene.from_string(json.dumps(scene), "", 64, 64)
