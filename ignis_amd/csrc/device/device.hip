@@ -488,12 +488,14 @@ void render(igd_device* d, const igd_render_settings* rs)
                     tl.scene    = d->dscene;
                     tl.in       = d->primaryCols(in_slot);
                     tl.in_count = &qs->primary_count[in_slot];
+                    tl.work_counter = &qs->work_counter[1];
                     tl.qs       = qs;
                     tl.accum    = reinterpret_cast<float4*>(d->accum.ptr);
                     tl.id_base  = first;
                     tl.frame    = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
                     tl.inv_spi  = inv;
-                    const int tail_grid = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
+                    // 2 waves/SIMD (VGPR bound): 2 workgroups per CU; fewer when the stream is tiny
+                    const int tail_grid = std::max(1, std::min(d->num_cus * 2, (int)((live + 255) / 256)));
                     timed(5, [&] { launch_tail(tl, counters, tail_grid, st); });
                     break;
                 }

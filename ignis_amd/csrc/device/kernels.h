@@ -129,6 +129,7 @@ struct TailArgs {
     DevScene scene;
     PrimaryCols in;
     const uint32_t* in_count;
+    uint32_t* work_counter; // zero before launch
     QueueState* qs;
     float4* accum;
     int64_t id_base;

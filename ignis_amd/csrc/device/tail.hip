@@ -27,23 +27,48 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
     uint32_t c_nodes[2] = { 0, 0 }, c_tris[2] = { 0, 0 }, c_leaves[2] = { 0, 0 };
     bool overflow = false;
 
-    for (uint32_t i = blockIdx.x * kBlockThreads + tid; i < n; i += gridDim.x * kBlockThreads) {
-        PathVertexIn in;
-        const float4 ra = a.in.rayA[i], rb = a.in.rayB[i], pay = a.in.pay[i];
-        const int4 meta = a.in.meta[i];
-        in.ray_id  = meta.x;
-        in.org     = f3{ ra.x, ra.y, ra.z };
-        in.dir     = f3{ rb.x, rb.y, rb.z };
-        in.rnd     = (uint32_t)meta.z;
-        in.inv_pdf = pay.x;
-        in.contrib = Col{ pay.y, pay.z, pay.w };
-        in.depth   = meta.w;
-        in.eta     = a.in.eta[i];
-        float tmin = ra.w, tmax = rb.w;
-        uint32_t flags = (uint32_t)meta.y;
-        float4 acc     = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
+    // Persistent lanes: a lane whose path ended takes the next unprocessed path (wave-aggregated fetch from
+    // the device counter), so a wave stays full until the stream is empty instead of idling behind its
+    // longest path.
+    bool have = false;
+    PathVertexIn in{};
+    float tmin = 0, tmax = 0;
+    uint32_t flags = 0;
+    float4 acc     = make_float4(0, 0, 0, 0);
+    bool exhausted = false;
 
-        for (;;) {
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        if (idle && !exhausted) {
+            const int n_idle = __popcll(idle);
+            uint32_t base    = 0;
+            if (lane == 0)
+                base = atomicAdd(a.work_counter, (uint32_t)n_idle);
+            base = __shfl(base, 0);
+            if (base + (uint32_t)n_idle >= n)
+                exhausted = true;
+            const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!have && i < n) {
+                have            = true;
+                const float4 ra = a.in.rayA[i], rb = a.in.rayB[i], pay = a.in.pay[i];
+                const int4 meta = a.in.meta[i];
+                in.ray_id  = meta.x;
+                in.org     = f3{ ra.x, ra.y, ra.z };
+                in.dir     = f3{ rb.x, rb.y, rb.z };
+                in.rnd     = (uint32_t)meta.z;
+                in.inv_pdf = pay.x;
+                in.contrib = Col{ pay.y, pay.z, pay.w };
+                in.depth   = meta.w;
+                in.eta     = a.in.eta[i];
+                tmin = ra.w, tmax = rb.w;
+                flags = (uint32_t)meta.y;
+                acc   = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
+            }
+        }
+        if (!__any(have))
+            break;
+
+        if (have) {
             {
                 Traverser<false, STATS> tr;
                 tr.init_counters();
@@ -92,19 +117,20 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
 
             if (!out.bounce) {
                 a.accum[(int64_t)in.ray_id - a.id_base] = acc;
-                break;
+                have                                    = false;
+            } else {
+                ++c_bounce;
+                in.org     = out.b_org;
+                in.dir     = out.b_dir;
+                in.rnd     = out.b_rnd;
+                in.inv_pdf = out.b_inv_pdf;
+                in.contrib = out.b_contrib;
+                in.depth   = out.b_depth;
+                in.eta     = out.b_eta;
+                tmin       = kRayOffset;
+                tmax       = kFltMax;
+                flags      = IG_RAY_FLAG_BOUNCE;
             }
-            ++c_bounce;
-            in.org     = out.b_org;
-            in.dir     = out.b_dir;
-            in.rnd     = out.b_rnd;
-            in.inv_pdf = out.b_inv_pdf;
-            in.contrib = out.b_contrib;
-            in.depth   = out.b_depth;
-            in.eta     = out.b_eta;
-            tmin       = kRayOffset;
-            tmax       = kFltMax;
-            flags      = IG_RAY_FLAG_BOUNCE;
         }
     }
 
