@@ -171,24 +171,31 @@ struct Traverser {
         const uint8_t* geom = sc.geom;
         settle(sc, st, tid);
 
-        // ---- one entity leaf of the current run (mapping_cpu.art:481-515)
+        // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
         if (mode == 2) {
-            const float4* lf = reinterpret_cast<const float4*>(sc.leaves + ent_cursor);
-            const uint2 ext  = sc.leaf_ext[ent_cursor];
-            ++ent_cursor;
-            const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
-            const int entity_id   = (int)igm_bits(l0.w);
-            const uint32_t lflags = igm_bits(l5.x);
-            ent_last              = entity_id < 0;
-            if (STATS)
-                ++st_leaves;
-            bool enter = false;
-            // check_ray_visibility (traversal/ray.art:51)
-            if ((rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK)) {
-                float entry, exit;
-                slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
-                enter = (entry <= exit) & (exit >= 0) & (entry <= tmax);
-            }
+            // leaves whose box (or visibility mask) rejects the ray cost only this short loop
+            const float4* lf;
+            uint2 ext;
+            int entity_id;
+            bool enter;
+            do {
+                lf  = reinterpret_cast<const float4*>(sc.leaves + ent_cursor);
+                ext = sc.leaf_ext[ent_cursor];
+                ++ent_cursor;
+                const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
+                entity_id             = (int)igm_bits(l0.w);
+                const uint32_t lflags = igm_bits(l5.x);
+                ent_last              = entity_id < 0;
+                if (STATS)
+                    ++st_leaves;
+                enter = false;
+                // check_ray_visibility (traversal/ray.art:51)
+                if ((rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK)) {
+                    float entry, exit;
+                    slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
+                    enter = (entry <= exit) & (exit >= 0) & (entry <= tmax);
+                }
+            } while (!enter && !ent_last);
             if (enter) {
                 const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4];
                 m34 m;
@@ -213,7 +220,7 @@ struct Traverser {
                 need_cull = true;
                 node_off  = ext.x;
                 tri_off   = ext.y;
-            } else if (ent_last) {
+            } else {
                 mode      = 0;
                 need_cull = true;
             }
@@ -263,8 +270,8 @@ struct Traverser {
             settle(sc, st, tid);
         }
 
-        // ---- one Tri4 packet of a leaf (mapping_cpu.art:379-410)
-        if (mode == 1) {
+        // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
+        while (mode == 1) {
             const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
             ++tri_cursor;
             const float4* tf = reinterpret_cast<const float4*>(tp);
@@ -299,9 +306,9 @@ struct Traverser {
                 mode      = 0;
                 need_cull = true;
             }
-            if (ANY_HIT && lterm)
-                settle(sc, st, tid); // return to the scene level now: the hit may end the ray
         }
+        if (ANY_HIT && lterm)
+            settle(sc, st, tid); // return to the scene level now: the hit may end the ray
     }
 };
 
