@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
@@ -98,7 +98,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        step(it)  # igd_render is blocking: the stream is drained when it returns
+        step(it)  # returns once the wavefront rounds are done; the tail paths + resolve of step i overlap step i + 1
+    dev.synchronize()  # everything submitted above is finished before the clock stops (and before the reduce)
     if dist is not None:
         # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
         # a rank does not own are zero)

@@ -31,6 +31,7 @@ void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
+void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
 } // namespace igdev
 
 using namespace igdev;
@@ -84,13 +85,15 @@ struct DevBuf {
 
 constexpr int kPrimaryCols   = 22; // 5 vector columns (20 floats) + eta + hit_v
 constexpr int kSecondaryCols = 12; // 3 vector columns
+constexpr int kMaxTailPasses = 24;
 
 } // namespace
 
 struct igd_device {
     igd_setup setup{};
     int num_cus = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // wavefront rounds
+    hipStream_t side   = nullptr; // tail + resolve of a chunk, overlapping the next chunk's rounds
 
     // scene
     bool has_scene = false;
@@ -109,9 +112,28 @@ struct igd_device {
 
     // streams
     size_t capacity = 0;
-    DevBuf<float> primary[2], secondary, accum;
-    DevBuf<QueueState> qs;
+    DevBuf<float> primary[2], secondary;
     DevBuf<float> list_rays;
+
+    // Two chunks can be in flight: while the side stream finishes chunk k (tail kernel, resolve, counter
+    // read-back) the main stream already runs the rounds of chunk k + 1. Everything a chunk's second half
+    // touches is therefore double-buffered by chunk parity.
+    struct Flight {
+        DevBuf<float> accum;     // per-sample radiance accumulators of the chunk
+        DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
+        DevBuf<float> tail_long; // those still alive after a pass (the two buffers alternate)
+        DevBuf<uint32_t> tail_ctr; // per pass: [2 * j] output count, [2 * j + 1] fetch counter
+        size_t tail_capacity = 0;
+        QueueState* qs       = nullptr; // device
+        QueueState* host     = nullptr; // pinned read-back of qs once the chunk is complete
+        hipEvent_t rounds_done = nullptr, done = nullptr;
+        bool pending = false;
+        std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans; // timers recorded on either stream
+    } flight[2];
+    DevBuf<QueueState> qs_store;
+    QueueState* host_store = nullptr; // pinned: [0],[1] per flight, [2] per-round polling
+    uint64_t chunk_seq     = 0;
+    bool async_tail        = true; // IGD_ASYNC_TAIL=0: drain the side stream at the end of every igd_render
 
     // framebuffer
     int fb_w = 0, fb_h = 0;
@@ -119,27 +141,45 @@ struct igd_device {
     std::vector<float> fb_host;
     bool fb_host_dirty = true;
 
-    // Once at most this many paths are alive the remaining bounces run in one launch (tail.hip).
-    // IGD_TAIL_THRESHOLD overrides (0 disables).
-    uint32_t tail_threshold = 131072;
+    // Once at most this many paths are alive the remaining bounces are followed per lane (tail.hip) on the
+    // side stream. IGD_TAIL_THRESHOLD overrides (0 disables).
+    uint32_t tail_threshold = 524288;
+    int tail_waves_per_cu   = 8; // IGD_TAIL_WAVES
+    // The tail runs as a sequence of launches: each follows its paths for at most this many bounces and hands
+    // the survivors, compacted, to the next one. Path lengths are geometric (a path inside a dielectric survives
+    // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
+    // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
+    int tail_split = 6;
 
     // statistics
     igd_stats stats{};
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events; // pool for the stage timers
+    size_t events_used = 0;
 
     ~igd_device()
     {
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        if (side)
+            (void)hipStreamSynchronize(side);
         for (auto e : events)
             (void)hipEventDestroy(e);
+        for (auto& f : flight) {
+            if (f.rounds_done)
+                (void)hipEventDestroy(f.rounds_done);
+            if (f.done)
+                (void)hipEventDestroy(f.done);
+        }
+        if (host_store)
+            (void)hipHostFree(host_store);
         if (stream)
             (void)hipStreamDestroy(stream);
+        if (side)
+            (void)hipStreamDestroy(side);
     }
 
-    // column c of a stream starts at base + c * capacity floats; vector columns are 4 floats wide
-    PrimaryCols primaryCols(int slot) const
+    static PrimaryCols colsAt(float* b, size_t c)
     {
-        float* b       = primary[slot].ptr;
-        const size_t c = capacity;
         PrimaryCols p;
         p.rayA  = reinterpret_cast<float4*>(b + 0 * c);
         p.rayB  = reinterpret_cast<float4*>(b + 4 * c);
@@ -150,6 +190,9 @@ struct igd_device {
         p.hit_v = b + 21 * c;
         return p;
     }
+
+    // column c of a stream starts at base + c * capacity floats; vector columns are 4 floats wide
+    PrimaryCols primaryCols(int slot) const { return colsAt(primary[slot].ptr, capacity); }
 
     SecondaryCols secondaryCols() const
     {
@@ -162,11 +205,17 @@ struct igd_device {
         return q;
     }
 
-    void ensureStreams(size_t needed)
+    size_t wantedCapacity(size_t needed) const
     {
         size_t cap = setup.stream_capacity ? (size_t)setup.stream_capacity : ((size_t)1 << 24);
         cap        = std::min(cap, needed);
-        cap        = (cap + 255) & ~(size_t)255;
+        return (cap + 255) & ~(size_t)255;
+    }
+    bool streamsTooSmall(size_t needed) const { return !(wantedCapacity(needed) <= capacity && primary[0].ptr); }
+
+    void ensureStreams(size_t needed)
+    {
+        const size_t cap = wantedCapacity(needed);
         if (cap <= capacity && primary[0].ptr)
             return;
         capacity = cap;
@@ -176,8 +225,22 @@ struct igd_device {
         }
         secondary.release();
         secondary.alloc(capacity * kSecondaryCols);
-        accum.release();
-        accum.alloc(capacity * 4);
+        for (auto& f : flight) {
+            f.accum.release();
+            f.accum.alloc(capacity * 4);
+        }
+    }
+
+    void ensureTailInput(Flight& f, size_t paths)
+    {
+        paths = (paths + 255) & ~(size_t)255;
+        if (paths <= f.tail_capacity && f.tail_in.ptr)
+            return;
+        f.tail_in.release();
+        f.tail_in.alloc(paths * kPrimaryCols);
+        f.tail_long.release();
+        f.tail_long.alloc(paths * kPrimaryCols);
+        f.tail_capacity = paths;
     }
 
     int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
@@ -192,6 +255,7 @@ struct igd_device {
         }
         return events[i];
     }
+    hipEvent_t nextEvent() { return event(events_used++); }
 };
 
 namespace {
@@ -311,10 +375,74 @@ void resizeFb(igd_device* d, int w, int h)
     d->fb_host_dirty = true;
 }
 
-void readQueueState(igd_device* d, QueueState& out)
+// Polls the queue sizes of the chunk in flight on the main stream (64 bytes, pinned).
+void readQueueState(igd_device* d, const QueueState* dev_qs, QueueState& out)
 {
-    HIP_CHECK(hipMemcpyAsync(&out, d->qs.ptr, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
+    QueueState* slot = d->host_store + 2;
+    HIP_CHECK(hipMemcpyAsync(slot, dev_qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
+    out = *slot;
+}
+
+void addSpan(igd_device* d, int kind, float ms)
+{
+    switch (kind) {
+    case 0: d->stats.ms_generate += ms; break;
+    case 1: d->stats.ms_traverse_primary += ms; break;
+    case 2: d->stats.ms_shade += ms; break;
+    case 3: d->stats.ms_traverse_secondary += ms; break;
+    case 4: d->stats.ms_resolve += ms; break;
+    default: d->stats.ms_tail += ms; break;
+    }
+}
+
+// Waits for the chunk that last used this flight slot (its tail + resolve run on the side stream), folds its
+// counters and timers into the statistics and reports its errors. Errors of an overlapped chunk therefore
+// surface at the next call that touches the device, not inside the igd_render that submitted it.
+void collect(igd_device* d, igd_device::Flight& f)
+{
+    if (!f.pending)
+        return;
+    f.pending = false;
+    HIP_CHECK(hipEventSynchronize(f.done));
+    const QueueState& q = *f.host;
+    d->stats.camera_rays += q.camera_rays;
+    d->stats.bounce_rays += q.bounce_rays;
+    d->stats.shadow_rays += q.shadow_rays;
+    d->stats.unoccluded += q.unoccluded;
+    d->stats.tail_rays += q.tail_rays;
+    d->stats.nodes_primary += q.nodes[0], d->stats.nodes_secondary += q.nodes[1];
+    d->stats.tris_primary += q.tris[0], d->stats.tris_secondary += q.tris[1];
+    d->stats.leaves_primary += q.leaves[0], d->stats.leaves_secondary += q.leaves[1];
+    for (const auto& sp : f.spans) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, sp.second.first, sp.second.second));
+        addSpan(d, sp.first, ms);
+    }
+    f.spans.clear();
+    if (q.error_flags & 1u)
+        throw HipError{ IGD_ERR_DEVICE, "traversal stack overflow (BVH deeper than the LDS stack)" };
+}
+
+// Drains both streams; afterwards framebuffer, statistics and every buffer are quiescent.
+void finish(igd_device* d)
+{
+    HipError first{ IGD_OK, "" };
+    for (int k = 0; k < 2; ++k) {
+        // oldest chunk first
+        igd_device::Flight& f = d->flight[(d->chunk_seq + (uint64_t)k) & 1];
+        try {
+            collect(d, f);
+        } catch (const HipError& e) {
+            if (first.code == IGD_OK)
+                first = e;
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->side));
+    d->events_used = 0;
+    if (first.code != IGD_OK)
+        throw first;
 }
 
 void render(igd_device* d, const igd_render_settings* rs)
@@ -332,12 +460,16 @@ void render(igd_device* d, const igd_render_settings* rs)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: ray-list mode expects width = #rays, height = 1" };
 
     const auto t_start = std::chrono::steady_clock::now();
+    if (rs->width != d->fb_w || rs->height != d->fb_h || !d->fb.ptr)
+        finish(d); // the side stream may still be resolving into the old framebuffer
     resizeFb(d, rs->width, rs->height);
 
     const int local_rows = (rs->height - row_offset + row_stride - 1) / row_stride;
     const int64_t total  = (int64_t)local_rows * rs->width * rs->spi;
     if (total >= ((int64_t)1 << 31))
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: width * height * spi must stay below 2^31" };
+    if (d->streamsTooSmall((size_t)std::max<int64_t>(total, 256)))
+        finish(d);
     d->ensureStreams((size_t)std::max<int64_t>(total, 256));
 
     if (list_mode)
@@ -360,38 +492,44 @@ void render(igd_device* d, const igd_render_settings* rs)
     const bool stats    = d->setup.acquire_stats != 0;
     const bool counters = d->setup.acquire_stats >= 2;
     hipStream_t st      = d->stream;
-    QueueState* qs    = d->qs.ptr;
-    const float inv   = 1 / (float)rs->spi;
-    size_t ev         = 0;
-    struct Span {
-        int kind;
-        size_t e0, e1;
-    };
-    std::vector<Span> spans;
-    auto timed = [&](int kind, const std::function<void()>& fn) {
-        if (!stats) {
-            fn();
-            return;
-        }
-        const size_t e0 = ev++, e1 = ev++;
-        HIP_CHECK(hipEventRecord(d->event(e0), st));
-        fn();
-        HIP_CHECK(hipEventRecord(d->event(e1), st));
-        spans.push_back(Span{ kind, e0, e1 });
-    };
+    const float inv     = 1 / (float)rs->spi;
+    if (d->events_used > 8192)
+        finish(d); // keeps the timer event pool bounded when nobody asks for the statistics
 
     // chunk the iteration's ray ids so that every pixel's samples stay together
     const int64_t chunk_rays = ((int64_t)d->capacity / rs->spi) * rs->spi;
     if (chunk_rays <= 0)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
 
+    d->fb_host_dirty = true;
     QueueState host_qs;
-    HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
 
     for (int64_t first = 0; first < total; first += chunk_rays) {
         const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
-        HIP_CHECK(hipMemsetAsync(d->accum.ptr, 0, (size_t)n * 4 * sizeof(float), st));
-        HIP_CHECK(hipMemsetAsync(qs, 0, offsetof(QueueState, error_flags), st)); // queue sizes + work counters
+
+        // this chunk's flight slot: wait (host side) until the chunk two back has left it
+        igd_device::Flight& fl = d->flight[d->chunk_seq & 1];
+        collect(d, fl);
+        ++d->chunk_seq;
+        QueueState* qs = fl.qs;
+        float4* accum  = reinterpret_cast<float4*>(fl.accum.ptr);
+
+        auto timed = [&](int kind, hipStream_t on, const std::function<void()>& fn) {
+            if (!stats) {
+                fn();
+                return;
+            }
+            const hipEvent_t e0 = d->nextEvent(), e1 = d->nextEvent();
+            HIP_CHECK(hipEventRecord(e0, on));
+            fn();
+            HIP_CHECK(hipEventRecord(e1, on));
+            fl.spans.push_back({ kind, { e0, e1 } });
+        };
+
+        fl.pending = true; // from here on the slot owns work that collect() has to wait for
+        HIP_CHECK(hipEventRecord(fl.done, st)); // placeholder so that an early throw leaves a valid event
+        HIP_CHECK(hipMemsetAsync(fl.accum.ptr, 0, (size_t)n * 4 * sizeof(float), st));
+        HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
 
         int in_slot = 0;
         GenerateArgs ga{};
@@ -412,10 +550,12 @@ void render(igd_device* d, const igd_render_settings* rs)
         ga.first_local_id = first;
         ga.n              = n;
         ga.list_rays      = list_mode ? d->list_rays.ptr : nullptr;
-        timed(0, [&] { launch_generate(ga, st); });
+        timed(0, st, [&] { launch_generate(ga, st); });
 
+        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
         uint32_t live          = n;
         int rounds_since_check = 0;
+        bool run_tail          = false;
         for (int round = 0;; ++round) {
             // ---- closest-hit traversal of the primary stream (K2)
             const PrimaryCols in = d->primaryCols(in_slot);
@@ -426,7 +566,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.work_counter = &qs->work_counter[0];
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
-            timed(1, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
+            timed(1, st, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
 
             // ---- sort + shade + compact (K3, K4, K5, K9)
             ShadeArgs sa{};
@@ -438,11 +578,11 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.out_count = &qs->primary_count[in_slot ^ 1];
             sa.sec_count = &qs->secondary_count;
             sa.qs        = qs;
-            sa.accum     = reinterpret_cast<float4*>(d->accum.ptr);
+            sa.accum     = accum;
             sa.id_base   = first;
-            sa.frame     = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
+            sa.frame     = frame;
             sa.inv_spi   = inv;
-            timed(2, [&] {
+            timed(2, st, [&] {
                 launch_shade(sa, d->shadeGrid(), st);
                 launch_round_end(qs, in_slot, st);
             });
@@ -457,10 +597,10 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.work_counter  = &qs->work_counter[2];
             tb.qs            = qs;
             tb.col     = sec.col;
-            tb.accum   = reinterpret_cast<float4*>(d->accum.ptr);
+            tb.accum   = accum;
             tb.id_base = first;
             tb.inv_spi = inv;
-            timed(3, [&] {
+            timed(3, st, [&] {
                 launch_traverse(tb, true, counters, d->traverseGrid(), st);
                 launch_secondary_end(qs, st);
             });
@@ -475,28 +615,15 @@ void render(igd_device* d, const igd_render_settings* rs)
             ++rounds_since_check;
             const int interval = (d->tail_threshold > 0 || live > 262144u) ? 1 : 4;
             if (rounds_since_check >= interval) {
-                readQueueState(d, host_qs);
+                readQueueState(d, qs, host_qs);
                 rounds_since_check = 0;
                 if (host_qs.error_flags & 1u)
-                    throw HipError{ IGD_ERR_DEVICE, "igd_render: traversal stack overflow (BVH deeper than the LDS stack)" };
+                    break; // reported by collect()
                 live = host_qs.primary_count[in_slot];
                 if (live == 0)
                     break;
                 if (live <= d->tail_threshold) {
-                    // few paths left: follow each to its end in one launch instead of ~50 more rounds
-                    TailArgs tl{};
-                    tl.scene    = d->dscene;
-                    tl.in       = d->primaryCols(in_slot);
-                    tl.in_count = &qs->primary_count[in_slot];
-                    tl.work_counter = &qs->work_counter[1];
-                    tl.qs       = qs;
-                    tl.accum    = reinterpret_cast<float4*>(d->accum.ptr);
-                    tl.id_base  = first;
-                    tl.frame    = ShadeFrame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
-                    tl.inv_spi  = inv;
-                    // 2 waves/SIMD (VGPR bound): 2 workgroups per CU; fewer when the stream is tiny
-                    const int tail_grid = std::max(1, std::min(d->num_cus * 2, (int)((live + 255) / 256)));
-                    timed(5, [&] { launch_tail(tl, counters, tail_grid, st); });
+                    run_tail = true;
                     break;
                 }
             }
@@ -504,8 +631,53 @@ void render(igd_device* d, const igd_render_settings* rs)
                 throw HipError{ IGD_ERR_DEVICE, "igd_render: wavefront loop did not terminate" };
         }
 
+        // ---- second half of the chunk, on the side stream: the next chunk's rounds start meanwhile
+        TailArgs tl{};
+        int tail_grid = 0;
+        if (run_tail) {
+            // few paths left: follow each to its end in one launch instead of ~50 more rounds. Its input is
+            // moved out of the primary stream, which the next chunk overwrites.
+            d->ensureTailInput(fl, live);
+            const PrimaryCols keep = igd_device::colsAt(fl.tail_in.ptr, fl.tail_capacity);
+            launch_copy_paths(d->primaryCols(in_slot), keep, &qs->primary_count[in_slot], live, st);
+            tl.scene        = d->dscene;
+            tl.in           = keep;
+            tl.in_count     = &qs->primary_count[in_slot];
+            tl.work_counter = &qs->work_counter[1];
+            tl.qs           = qs;
+            tl.accum        = accum;
+            tl.id_base      = first;
+            tl.frame        = frame;
+            tl.inv_spi      = inv;
+            tl.count_paths  = 1;
+            fl.tail_ctr.alloc(2 * kMaxTailPasses);
+            HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
+            // one-wave workgroups, 2 waves/SIMD (VGPR bound) = 8 per CU; fewer when the stream is tiny
+            tail_grid = std::max(1, std::min(d->num_cus * d->tail_waves_per_cu, (int)((live + 63) / 64)));
+        }
+        HIP_CHECK(hipEventRecord(fl.rounds_done, st));
+        HIP_CHECK(hipStreamWaitEvent(d->side, fl.rounds_done, 0));
+        if (run_tail)
+            timed(5, d->side, [&] {
+                // pass j reads buffer j & 1 and appends its survivors to the other one; the last pass is unbounded
+                const int depth_left = std::max(1, d->dscene.tech.max_depth);
+                const int passes     = d->tail_split > 0 ? std::min(kMaxTailPasses, (depth_left + d->tail_split - 1) / d->tail_split) : 1;
+                const PrimaryCols buf[2] = { tl.in, igd_device::colsAt(fl.tail_long.ptr, fl.tail_capacity) };
+                for (int j = 0; j < passes; ++j) {
+                    TailArgs p     = tl;
+                    p.in           = buf[j & 1];
+                    p.out          = buf[(j & 1) ^ 1];
+                    p.in_count     = j == 0 ? tl.in_count : fl.tail_ctr.ptr + 2 * (j - 1);
+                    p.out_count    = fl.tail_ctr.ptr + 2 * j;
+                    p.work_counter = fl.tail_ctr.ptr + 2 * j + 1;
+                    p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
+                    p.count_paths  = j == 0;
+                    launch_tail(p, counters, tail_grid, d->side);
+                }
+            });
+
         ResolveArgs ra{};
-        ra.accum             = reinterpret_cast<const float4*>(d->accum.ptr);
+        ra.accum             = accum;
         ra.fb                = d->fb.ptr;
         ra.width             = rs->width;
         ra.spi               = rs->spi;
@@ -513,37 +685,14 @@ void render(igd_device* d, const igd_render_settings* rs)
         ra.row_stride        = row_stride;
         ra.first_local_pixel = first / rs->spi;
         ra.pixels            = n / (uint32_t)rs->spi;
-        timed(4, [&] { launch_resolve(ra, st); });
+        timed(4, d->side, [&] { launch_resolve(ra, d->side); });
+        HIP_CHECK(hipMemcpyAsync(fl.host, qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->side));
+        HIP_CHECK(hipEventRecord(fl.done, d->side));
     }
-
-    readQueueState(d, host_qs);
     HIP_CHECK(hipGetLastError());
-    d->fb_host_dirty = true;
 
-    d->stats.camera_rays += host_qs.camera_rays;
-    d->stats.bounce_rays += host_qs.bounce_rays;
-    d->stats.shadow_rays += host_qs.shadow_rays;
-    d->stats.unoccluded += host_qs.unoccluded;
-    d->stats.tail_rays += host_qs.tail_rays;
-    if (host_qs.error_flags & 1u)
-        throw HipError{ IGD_ERR_DEVICE, "igd_render: traversal stack overflow (BVH deeper than the LDS stack)" };
-    d->stats.nodes_primary += host_qs.nodes[0], d->stats.nodes_secondary += host_qs.nodes[1];
-    d->stats.tris_primary += host_qs.tris[0], d->stats.tris_secondary += host_qs.tris[1];
-    d->stats.leaves_primary += host_qs.leaves[0], d->stats.leaves_secondary += host_qs.leaves[1];
-    HIP_CHECK(hipStreamSynchronize(st));
-
-    for (const Span& s : spans) {
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, d->event(s.e0), d->event(s.e1)));
-        switch (s.kind) {
-        case 0: d->stats.ms_generate += ms; break;
-        case 1: d->stats.ms_traverse_primary += ms; break;
-        case 2: d->stats.ms_shade += ms; break;
-        case 3: d->stats.ms_traverse_secondary += ms; break;
-        case 4: d->stats.ms_resolve += ms; break;
-        default: d->stats.ms_tail += ms; break;
-        }
-    }
+    if (!d->async_tail || list_mode)
+        finish(d);
     d->stats.ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 }
 
@@ -574,8 +723,9 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     out.alloc(n * 5);
     HIP_CHECK(hipMemset(out.ptr, 0xFF, n * 5 * sizeof(float)));
 
+    finish(d);
     hipStream_t st = d->stream;
-    QueueState* qs = d->qs.ptr;
+    QueueState* qs = d->flight[0].qs;
     const uint32_t cnt = (uint32_t)n;
     HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
     HIP_CHECK(hipMemcpyAsync(&qs->primary_count[0], &cnt, 4, hipMemcpyHostToDevice, st));
@@ -611,7 +761,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
         *kernel_ms = total_ms / repeat;
 
     QueueState host_qs;
-    readQueueState(d, host_qs);
+    readQueueState(d, qs, host_qs);
     if (host_qs.error_flags & 1u)
         throw HipError{ IGD_ERR_DEVICE, "igd_traverse: traversal stack overflow (BVH deeper than the LDS stack)" };
     d->stats.nodes_primary += host_qs.nodes[0], d->stats.nodes_secondary += host_qs.nodes[1];
@@ -705,10 +855,30 @@ igd_device* igd_create(const igd_setup* setup)
         d->setup   = *setup;
         d->num_cus = p.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-        d->qs.alloc(1);
+        {
+            // the side stream only has to finish before the next chunk does: lowest priority
+            int lo = 0, hi = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_CHECK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
+        }
+        d->qs_store.alloc(2);
+        HIP_CHECK(hipMemset(d->qs_store.ptr, 0, 2 * sizeof(QueueState)));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), 3 * sizeof(QueueState), hipHostMallocDefault));
+        std::memset(d->host_store, 0, 3 * sizeof(QueueState));
+        for (int k = 0; k < 2; ++k) {
+            d->flight[k].qs   = d->qs_store.ptr + k;
+            d->flight[k].host = d->host_store + k;
+            HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].rounds_done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].done, hipEventDisableTiming));
+        }
         if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))
             d->tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
-        HIP_CHECK(hipMemset(d->qs.ptr, 0, sizeof(QueueState)));
+        if (const char* e = std::getenv("IGD_TAIL_WAVES"))
+            d->tail_waves_per_cu = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
+            d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_ASYNC_TAIL"))
+            d->async_tail = std::atoi(e) != 0;
         dev = d.release();
     });
     if (rc != IGD_OK) {
@@ -726,6 +896,7 @@ int32_t igd_assign_scene(igd_device* dev, const igd_scene* scene)
         if (!dev || !scene)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
         dev->has_scene = false;
         assignScene(dev, scene);
     });
@@ -747,6 +918,7 @@ int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
         if (!dev || width <= 0 || height <= 0)
             throw HipError{ IGD_ERR_INVALID_ARG, "bad size" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
         if (width != dev->fb_w || height != dev->fb_h) {
             dev->fb.release();
             dev->fb_w = dev->fb_h = 0;
@@ -763,11 +935,16 @@ int32_t igd_release_all(igd_device* dev)
         if (!dev)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
-        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        finish(dev);
         for (int s = 0; s < 2; ++s)
             dev->primary[s].release();
         dev->secondary.release();
-        dev->accum.release();
+        for (auto& f : dev->flight) {
+            f.accum.release();
+            f.tail_in.release();
+            f.tail_long.release();
+            f.tail_capacity = 0;
+        }
         dev->list_rays.release();
         dev->capacity = 0;
         dev->geom.release();
@@ -799,6 +976,7 @@ const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t syn
         if (!dev->fb.ptr)
             throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (render or resize first)" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
         if (sync && dev->fb_host_dirty) {
             HIP_CHECK(hipMemcpy(dev->fb_host.data(), dev->fb.ptr, dev->fb_host.size() * sizeof(float), hipMemcpyDeviceToHost));
             dev->fb_host_dirty = false;
@@ -815,6 +993,12 @@ float* igd_framebuffer_device(igd_device* dev, const char* name)
         g_error = "igd_framebuffer_device: unknown AOV or NULL device";
         return nullptr;
     }
+    // the pointer is about to be read by other device work: make the framebuffer final first
+    if (guarded("igd_framebuffer_device", [&] {
+            HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+            finish(dev);
+        }) != IGD_OK)
+        return nullptr;
     return dev->fb.ptr;
 }
 
@@ -826,6 +1010,7 @@ int32_t igd_clear_framebuffer(igd_device* dev, const char* name)
         if (!isColorName(name))
             throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
         if (dev->fb.ptr)
             HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float)));
         std::fill(dev->fb_host.begin(), dev->fb_host.end(), 0.0f);
@@ -843,6 +1028,7 @@ int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const 
         if (!dev->fb.ptr)
             throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (resize first)" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
         HIP_CHECK(hipMemcpy(dev->fb.ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
         dev->fb_host_dirty = true;
     });
@@ -855,8 +1041,13 @@ int32_t igd_get_stats(igd_device* dev, igd_stats* out)
         g_error = "igd_get_stats: NULL argument";
         return IGD_ERR_INVALID_ARG;
     }
+    // counters and timers of chunks still in flight are folded in first
+    const int rc = guarded("igd_get_stats", [&] {
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
+    });
     *out = dev->stats;
-    return IGD_OK;
+    return rc;
 }
 
 int32_t igd_reset_stats(igd_device* dev)
@@ -866,8 +1057,12 @@ int32_t igd_reset_stats(igd_device* dev)
         g_error = "igd_reset_stats: NULL device";
         return IGD_ERR_INVALID_ARG;
     }
+    const int rc = guarded("igd_reset_stats", [&] {
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
+    });
     dev->stats = igd_stats{};
-    return IGD_OK;
+    return rc;
 }
 
 int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t ray_flags, int32_t any_hit,
@@ -878,6 +1073,16 @@ int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         traverseList(dev, count, rays, ray_flags, any_hit, ent_id, prim_id, t, u, v, repeat, kernel_ms);
+    });
+}
+
+int32_t igd_synchronize(igd_device* dev)
+{
+    return guarded("igd_synchronize", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
     });
 }
 

@@ -135,6 +135,12 @@ struct TailArgs {
     int64_t id_base;
     ShadeFrame frame;
     float inv_spi;
+    // max_bounces > 0: a path still alive after that many bounces inside this launch is appended to `out`
+    // (same columns as `in`) instead of being followed further; a second launch over `out` finishes it.
+    int32_t max_bounces;
+    PrimaryCols out;
+    uint32_t* out_count;
+    int32_t count_paths; // add the input size to qs->tail_rays
 };
 
 struct ResolveArgs {

@@ -13,6 +13,8 @@
 //                seed reproduces the image bit for bit (the reference GPU path uses float atomics).
 // Shading arithmetic follows src/artic/{core,bsdf,light,technique,camera} expression by expression
 // (citations inline); transcendental functions come from include/ig_detmath.h.
+#include <algorithm>
+
 #include "shade_core.h"
 
 namespace igdev {
@@ -274,6 +276,25 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream)
 
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream) { hipLaunchKernelGGL(k_round_end, dim3(1), dim3(64), 0, stream, qs, in_slot); }
 void launch_secondary_end(QueueState* qs, hipStream_t stream) { hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs); }
+
+// Moves the surviving paths (the columns the tail kernel reads) out of a primary stream.
+__global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols dst, const uint32_t* __restrict__ count)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        dst.rayA[i] = src.rayA[i];
+        dst.rayB[i] = src.rayB[i];
+        dst.meta[i] = src.meta[i];
+        dst.pay[i]  = src.pay[i];
+        dst.eta[i]  = src.eta[i];
+    }
+}
+
+void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream)
+{
+    const unsigned blocks = std::min(4096u, (max_count + 255u) / 256u);
+    hipLaunchKernelGGL(k_copy_paths, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, src, dst, count);
+}
 
 void launch_resolve(const ResolveArgs& args, hipStream_t stream)
 {

@@ -1,22 +1,31 @@
-// tail.hip — finishes the last few thousand paths of an iteration in ONE launch.
+// tail.hip — follows the paths that are left once the wavefront stream has become small, one lane per path.
 //
-// The wavefront loop pays three kernel launches per bounce; with max_depth 64 (diamond_scene) a
-// handful of paths bouncing inside the dielectrics keeps it alive for ~50 more rounds of nearly
-// empty launches, each costing a cold-start latency chain (the reference has the same long tail,
-// src/artic/driver/mapping_gpu.art:756-866, plus its host round trips). Once the live stream is
-// small, every remaining path is instead followed to its end by one lane:
+// The wavefront loop pays three kernel launches per bounce; with max_depth 64 (diamond_scene) the paths
+// bouncing inside the dielectrics keep it alive for ~50 more rounds of ever emptier launches, each costing
+// a cold-start latency chain (the reference has the same long tail, src/artic/driver/mapping_gpu.art:756-866,
+// plus its host round trips). Once the live stream is small, every remaining path is instead followed by
+// one lane:
 //   closest-hit traversal -> shade_vertex -> (any-hit traversal of the NEE ray) -> next bounce ...
-// using the same device code as the wavefront kernels (traverse_core.h, shade_core.h), so every
-// path produces bit-identical contributions and counters; only the scheduling differs.
+// using the same device code as the wavefront kernels (traverse_core.h, shade_core.h), so every path
+// produces bit-identical contributions and counters; only the scheduling differs.
+//
+// The host (device.hip) runs it on a second stream, overlapping the next chunk's rounds, as a sequence of
+// passes: a pass follows each path for at most `max_bounces` bounces and appends the survivors, compacted,
+// to the input of the next pass, so that the long paths (geometric length distribution) end up in a few
+// full waves instead of pinning every wave of the grid behind its longest lane.
 #include "shade_core.h"
 #include "traverse_core.h"
 
 namespace igdev {
 
+// One wave per workgroup: a straggling path then pins 12 KiB of LDS and one wave slot, not a 256-lane
+// workgroup's 48 KiB, which matters because the tail overlaps the next chunk's traversal launches.
+constexpr int kTailThreads = 64;
+
 template <bool STATS>
-__global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
+__global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
 {
-    __shared__ StackLds s_stack;
+    __shared__ StackOf<kTailThreads> s_stack;
 
     const int tid      = threadIdx.x;
     const int lane     = tid & 63;
@@ -36,6 +45,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
     uint32_t flags = 0;
     float4 acc     = make_float4(0, 0, 0, 0);
     bool exhausted = false;
+    int hops       = 0; // bounces this lane has followed its current path for
 
     for (;;) {
         const unsigned long long idle = __ballot(!have);
@@ -63,6 +73,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
                 tmin = ra.w, tmax = rb.w;
                 flags = (uint32_t)meta.y;
                 acc   = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
+                hops  = 0;
             }
         }
         if (!__any(have))
@@ -70,7 +81,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
 
         if (have) {
             {
-                Traverser<false, STATS> tr;
+                Traverser<false, STATS, kTailThreads> tr;
                 tr.init_counters();
                 tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
                 while (!tr.finished)
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
 
             if (out.shadow) {
                 ++c_shadow;
-                Traverser<true, STATS> ts;
+                Traverser<true, STATS, kTailThreads> ts;
                 ts.init_counters();
                 ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, IG_RAY_FLAG_SHADOW);
                 while (!ts.finished)
@@ -130,6 +141,27 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
                 tmin       = kRayOffset;
                 tmax       = kFltMax;
                 flags      = IG_RAY_FLAG_BOUNCE;
+                ++hops;
+            }
+        }
+
+        // long paths leave this launch: they would pin the wave (and its registers / LDS) for milliseconds
+        const bool spill               = have && a.max_bounces > 0 && hops >= a.max_bounces;
+        const unsigned long long mspill = __ballot(spill);
+        if (mspill) {
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(a.out_count, (uint32_t)__popcll(mspill));
+            base = __shfl(base, 0);
+            if (spill) {
+                const uint32_t o = base + (uint32_t)__popcll(mspill & ((1ull << lane) - 1ull));
+                a.out.rayA[o] = make_float4(in.org.x, in.org.y, in.org.z, tmin);
+                a.out.rayB[o] = make_float4(in.dir.x, in.dir.y, in.dir.z, tmax);
+                a.out.meta[o] = make_int4(in.ray_id, (int32_t)flags, (int32_t)in.rnd, in.depth);
+                a.out.pay[o]  = make_float4(in.inv_pdf, in.contrib.r, in.contrib.g, in.contrib.b);
+                a.out.eta[o]  = in.eta;
+                a.accum[(int64_t)in.ray_id - a.id_base] = acc;
+                have                                    = false;
             }
         }
     }
@@ -154,7 +186,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_tail(const TailArgs a)
             }
         }
     }
-    if (blockIdx.x == 0 && tid == 0)
+    if (a.count_paths && blockIdx.x == 0 && tid == 0)
         a.qs->tail_rays += n;
 }
 
@@ -164,9 +196,9 @@ template __global__ void k_tail<true>(const TailArgs);
 void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream)
 {
     if (stats)
-        hipLaunchKernelGGL((k_tail<true>), dim3((unsigned)grid_blocks), dim3(kBlockThreads), 0, stream, args);
+        hipLaunchKernelGGL((k_tail<true>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
     else
-        hipLaunchKernelGGL((k_tail<false>), dim3((unsigned)grid_blocks), dim3(kBlockThreads), 0, stream, args);
+        hipLaunchKernelGGL((k_tail<false>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
 }
 
 } // namespace igdev

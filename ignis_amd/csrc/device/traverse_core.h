@@ -22,10 +22,14 @@ namespace igdev {
 constexpr int kLdsStack     = 24;  // 24 entries * 256 threads * 8 B = 48 KiB per workgroup (3 workgroups per CU)
 constexpr int kBlockThreads = 256;
 
-using StackLds = uint2[kLdsStack][kBlockThreads];
+// per-lane traversal stacks of one workgroup of BLOCK lanes, entry-major so that a wave's accesses are conflict free
+template <int BLOCK>
+using StackOf = uint2[kLdsStack][BLOCK];
+using StackLds = StackOf<kBlockThreads>;
 
-template <bool ANY_HIT, bool STATS>
+template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads>
 struct Traverser {
+    using Stack = StackOf<BLOCK>;
     // ---- ray + hit
     RayT gray, cur;
     float tmin, tmax; // tmax == distance of the accepted hit (ray.tmax shrinks with it)
@@ -59,7 +63,7 @@ struct Traverser {
     // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here
     // the stack is kLdsStack entries of LDS per lane; deeper pushes set `overflow` (the launch then
     // raises error bit 0 and igd_render fails loudly).
-    IG_DEV void push_entry(StackLds& st, int tid, int n, float t)
+    IG_DEV void push_entry(Stack& st, int tid, int n, float t)
     {
         ++ptr;
         if (ptr < kLdsStack)
@@ -67,7 +71,7 @@ struct Traverser {
         else
             overflow = true;
     }
-    IG_DEV void pop_top(StackLds& st, int tid)
+    IG_DEV void pop_top(Stack& st, int tid)
     {
         const uint2 e = st[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
         top_node      = (int)e.x;
@@ -75,7 +79,7 @@ struct Traverser {
         --ptr;
     }
 
-    IG_DEV void begin(const DevScene& sc, StackLds& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
+    IG_DEV void begin(const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
     {
         gray   = make_ray_terms(org, dir);
         cur    = gray;
@@ -108,7 +112,7 @@ struct Traverser {
     // node on top (mode 0, top_node > 0), a triangle packet (mode 1), or the end of the ray.
     // The cull points are exactly the reference's (mapping_cpu.art:326-347): at level entry, after
     // a leaf and after an inner node that pushed nothing.
-    IG_DEV void settle(const DevScene& sc, StackLds& st, int tid)
+    IG_DEV void settle(const DevScene& sc, Stack& st, int tid)
     {
         while (mode == 0 && !finished) {
             if (level == 1 && lterm) {
@@ -166,7 +170,7 @@ struct Traverser {
     }
 
     // One pipeline pass: entity leaf -> inner node -> triangle packet. Call while !finished.
-    IG_DEV void step(const DevScene& sc, StackLds& st, int tid)
+    IG_DEV void step(const DevScene& sc, Stack& st, int tid)
     {
         const uint8_t* geom = sc.geom;
         settle(sc, st, tid);

@@ -44,7 +44,7 @@ EXPORTS = [
     "igd_get_abi_version", "igd_device_count", "igd_create", "igd_destroy", "igd_assign_scene", "igd_render",
     "igd_resize", "igd_release_all", "igd_framebuffer_width", "igd_framebuffer_height", "igd_framebuffer_host",
     "igd_framebuffer_device", "igd_clear_framebuffer", "igd_sync_framebuffer_to_device", "igd_get_stats",
-    "igd_reset_stats", "igd_traverse", "igd_last_error",
+    "igd_reset_stats", "igd_traverse", "igd_synchronize", "igd_last_error",
 ]
 
 _lib = None
@@ -93,6 +93,8 @@ def lib():
         l.igd_traverse.restype = C.c_int32
         l.igd_traverse.argtypes = [C.c_void_p, C.c_int64, fp, C.c_uint32, C.c_int32, ip, ip, fp, fp, fp, C.c_int32,
                                    C.POINTER(C.c_double)]
+        l.igd_synchronize.restype = C.c_int32
+        l.igd_synchronize.argtypes = [C.c_void_p]
         l.igd_last_error.restype = C.c_char_p
         _lib = l
     return _lib
@@ -149,6 +151,11 @@ class Device:
             rs.rays = keep.ctypes.data_as(C.POINTER(C.c_float))
             rs.width, rs.height = keep.shape[0], 1
         _check(lib().igd_render(self._h, C.byref(rs)))
+
+    def synchronize(self):
+        """Waits for the part of the last render that overlaps the next one (tail paths + resolve) and reports
+        its errors; the framebuffer / stats accessors do this implicitly."""
+        _check(lib().igd_synchronize(self._h))
 
     def resize(self, width, height):
         _check(lib().igd_resize(self._h, width, height))

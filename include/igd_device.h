@@ -133,6 +133,15 @@ int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t
                      int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v,
                      int32_t repeat, double* kernel_ms);
 
+/* igd_render returns once the wavefront rounds of its last chunk are done; that chunk's long-path tail
+ * and its framebuffer resolve may still be running on a second HIP stream, overlapping the next
+ * igd_render (the reference's render() is followed by getFramebufferForHost(), which is where it syncs,
+ * Device.cpp:1385-1425). Every accessor below/above that reads results (framebuffer_host/_device, get_stats,
+ * clear, resize, assign_scene, traverse) drains that work first; igd_synchronize does only that, and is
+ * where an error of the overlapped part (e.g. a stack overflow inside the tail kernel) is reported if no
+ * other call has surfaced it yet. IGD_ASYNC_TAIL=0 in the environment makes igd_render fully blocking. */
+int32_t igd_synchronize(igd_device* dev);
+
 /* Thread-local message of the last failed igd_* call ("" if none). */
 const char* igd_last_error(void);
 

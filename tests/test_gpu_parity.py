@@ -143,6 +143,33 @@ def test_small_stream_capacity_chunks_match(diamond_scene):
     b.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"IGD_TAIL_THRESHOLD": "0"},                                                   # wavefront rounds only
+    {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "0"},                          # one tail launch
+    {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_TAIL_WAVES": "1"},   # many compacting passes
+    {"IGD_TAIL_THRESHOLD": "100000000", "IGD_TAIL_SPLIT": "5"},                     # everything after round 0
+])
+def test_overlapped_tail_schedules_match_blocking(diamond_scene, monkeypatch, env):
+    """The long-path tail of iteration i runs on a second stream while iteration i + 1 starts, in one or many
+    passes. None of that may change a bit of the image or a single counter (only the schedule differs)."""
+    from ignis_amd import Device
+    monkeypatch.setenv("IGD_ASYNC_TAIL", "0")
+    monkeypatch.setenv("IGD_TAIL_THRESHOLD", "0")
+    ref_dev = Device(0, acquire_stats=True)
+    ref, ref_st = _render_gpu(ref_dev, diamond_scene, 4, 96, 96, iters=3, seed=9)
+    ref_dev.close()
+    monkeypatch.setenv("IGD_ASYNC_TAIL", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for cap in (0, 8192):  # whole iteration in flight / several chunks per iteration
+        dev = Device(0, acquire_stats=True, stream_capacity=cap)
+        fb, st = _render_gpu(dev, diamond_scene, 4, 96, 96, iters=3, seed=9)
+        dev.close()
+        np.testing.assert_array_equal(fb, ref)
+        for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+            assert st[k] == ref_st[k], (k, cap)
+
+
 def test_reproducible_and_seed_sensitive(gpu_device, diamond_scene):
     """src/tests/integrator/test_reproducibility.py: same seed -> bit-identical image."""
     f1, _ = _render_gpu(gpu_device, diamond_scene, 4, 128, 128, seed=42)
