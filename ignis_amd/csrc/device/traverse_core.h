@@ -31,7 +31,10 @@ template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     // ---- ray + hit
-    RayT gray, cur;
+    // `gray` (the ray in scene space) is never written after begin(); `loc` (the ray in the current shape's
+    // space) only when an entity leaf is entered. Nothing in settle() touches either, which keeps the twelve
+    // registers of each out of every control-flow merge of the state machine.
+    RayT gray, loc;
     float tmin, tmax; // tmax == distance of the accepted hit (ray.tmax shrinks with it)
     uint32_t rflags;
     float hit_u, hit_v;
@@ -40,7 +43,7 @@ struct Traverser {
     float ltmax, l_u, l_v;
     int l_prim;
     int lbase;  // stack pointer of the saved scene-level top
-    bool lterm; // any-hit: the shape-level traversal found its hit
+    bool lterm;  // any-hit: the shape-level traversal found its hit
     // ---- control
     int top_node;
     float top_tmin;
@@ -82,7 +85,7 @@ struct Traverser {
     IG_DEV void begin(const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
     {
         gray   = make_ray_terms(org, dir);
-        cur    = gray;
+        loc    = gray;
         tmin   = tmin_;
         tmax   = tmax_;
         rflags = flags;
@@ -99,7 +102,7 @@ struct Traverser {
         l_prim = -1;
         lbase  = 0;
         lterm  = false;
-        node_off   = sc.scene_nodes_off;
+        node_off   = 0; // Node8[] of the entered shape; the scene level uses sc.scene_nodes_off
         // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
         ptr      = -1;
         top_node = 0, top_tmin = kFltMax;
@@ -132,8 +135,6 @@ struct Traverser {
                     level = 0;
                     lterm = false;
                     pop_top(st, tid); // saved scene-level top
-                    cur      = gray;
-                    node_off = sc.scene_nodes_off;
                     if (l_prim != -1 && ltmax <= tmax) {
                         tmax     = ltmax;
                         hit_u    = l_u;
@@ -208,7 +209,7 @@ struct Traverser {
                 m.c2 = f3{ l3.z, l3.w, l4.x };
                 m.c3 = f3{ l4.y, l4.z, l4.w };
                 // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                cur     = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                loc     = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
                 cur_ent = entity_id & 0x7FFFFFFF;
                 // save the scene-level top, then a fresh stack: sentinel + shape root
                 push_entry(st, tid, top_node, top_tmin);
@@ -233,7 +234,7 @@ struct Traverser {
 
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
         if (mode == 0 && !finished) {
-            const uint8_t* np = geom + node_off + (uint32_t)(top_node - 1) * 256u;
+            const uint8_t* np = geom + (level ? node_off : sc.scene_nodes_off) + (uint32_t)(top_node - 1) * 256u;
             pop_top(st, tid);
             const float4* nf = reinterpret_cast<const float4*>(np);
             const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
@@ -241,6 +242,9 @@ struct Traverser {
                 ++st_nodes;
             bool pushed           = false;
             const float node_tmax = level ? ltmax : tmax;
+            RayT r; // only the slab terms are used below
+            r.inv_dir = level ? loc.inv_dir : gray.inv_dir;
+            r.inv_org = level ? loc.inv_org : gray.inv_org;
             // two halves of four children keep the live register set small
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -255,7 +259,7 @@ struct Traverser {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float entry, exit;
-                    slab_test(cur, tmin, node_tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
+                    slab_test(r, tmin, node_tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
                     const bool hit = (ch[i] != 0) & !(exit < entry);
                     if (hit) {
                         // push (becomes the top) if nearer than the current top, else push_after
@@ -295,7 +299,7 @@ struct Traverser {
                     if (STATS)
                         ++st_tris;
                     float t, u, v;
-                    if (tri_test(cur, tmin, ltmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
+                    if (tri_test(loc, tmin, ltmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
                                  f3{ q[6][i], q[7][i], q[8][i] }, f3{ q[9][i], q[10][i], q[11][i] }, t, u, v)) {
                         ltmax  = t;
                         l_u    = u;
