@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPI, SEED = 1920, 1080, 8, 1
 SCENE = os.path.join(ROOT, "scenes", "diamond_scene.json")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_FILE = "r01_traffic.json"  # PMC summary of this command, see tools/collect_profiles.sh
 
 
 def parse():
@@ -137,8 +138,16 @@ def main():
         a_bytes = algorithmic_bytes(n_primary, cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"])
         a_per_launch = a_bytes / max(1, cs["traverse_primary_launches"])
         achieved = a_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # measured HBM-side bytes per launch of the same kernel: PMC passes of this command, summarised into
+        # profiles/ by tools/prof_summary.py (counters cannot be read from inside the process)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1:
+            tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false>")
+            if tk:
+                traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, x2 read correction)"
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(a_per_launch)}
 
@@ -147,14 +156,21 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle
+            # bounded sample of the same workload: whole iterations until ~12 s of wall clock (at most 8)
             cw, ch = W, H
+            cpu_rays = cpu_samples = 0
+            n_it, threads = 0, 1
             t1 = time.perf_counter()
-            _, os_ = oracle.render(scene, spi, cw, ch, iteration=0, seed=SEED)
+            while n_it < 8 and (n_it == 0 or time.perf_counter() - t1 < 12.0):
+                _, os_ = oracle.render(scene, spi, cw, ch, iteration=n_it, seed=SEED)
+                cpu_rays += os_["camera_rays"] + os_["bounce_rays"] + os_["shadow_rays"]
+                cpu_samples += os_["camera_rays"]
+                threads = int(os_["threads_used"])
+                n_it += 1
             dt = time.perf_counter() - t1
-            cpu_rays = os_["camera_rays"] + os_["bounce_rays"] + os_["shadow_rays"]
-            cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(os_["threads_used"]), "kind": "port",
-                   "sample": f"1 iteration of diamond_scene {cw}x{ch} spi {spi} (oracle/, CPU restatement, not the AnyDSL binary)",
-                   "msamples_per_s": round(os_["camera_rays"] / dt / 1e6, 3), "seconds": round(dt, 2)}
+            cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"{n_it} iteration(s) of diamond_scene {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",
+                   "msamples_per_s": round(cpu_samples / dt / 1e6, 3), "seconds": round(dt, 2)}
 
         out = {
             "metric": "Mrays/s (primary+shadow)",

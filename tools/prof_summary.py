@@ -1,9 +1,16 @@
-"""Summarise rocprofv3 (rocpd sqlite) outputs into a small text file for profiles/.
+"""Summarise rocprofv3 (rocpd sqlite) outputs into small text / JSON files for profiles/.
 
-usage: python tools/prof_summary.py <stats.db> [<pmc.db> ...] > profiles/rNN_xxx.txt
-Kernel table = `rocprofv3 --kernel-trace --stats` (top_kernels view); PMC tables = per-kernel sum and
-per-launch mean of each collected counter (`--pmc X --kernel-trace`, one counter per pass).
+usage:
+  python tools/prof_summary.py stats <stats.db>                      kernel table of `--kernel-trace --stats`
+  python tools/prof_summary.py pmc <pmc.db> [<pmc.db> ...]           per-kernel sum / per-launch mean of each counter
+  python tools/prof_summary.py traffic <fetch.db> <write.db>         JSON: HBM-side bytes per launch per kernel
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. Calibration inside the same run (known byte counts):
+k_generate writes exactly 68 B per camera ray (WRITE_SIZE matches to 6 digits -> no correction); k_copy_paths reads
+what it writes (68 B per path, 16 B/lane coalesced loads) and FETCH_SIZE shows exactly half of its WRITE_SIZE, i.e.
+the x2 correction MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 applies to our stream reads.
 """
+import json
 import sqlite3
 import sys
 
@@ -17,17 +24,58 @@ def kernel_stats(path):
     print()
 
 
-def pmc(path):
+def counters(path):
     cur = sqlite3.connect(path).cursor()
+    out = {}
+    q = "select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"
+    for k, c, n, s, a, d in cur.execute(q):
+        out.setdefault(k, {})[c] = {"launches": n, "sum": s, "mean": a, "avg_ns": d}
+    return out
+
+
+def pmc(path):
     print(f"# counters: {path}")
-    rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name order by sum(value) desc")
-    print(f"{'kernel':60s} {'counter':12s} {'launches':>8s} {'sum':>16s} {'mean/launch':>14s} {'avg_ns':>10s}")
-    for k, c, n, s, a, d in rows:
-        print(f"{k[:60]:60s} {c:12s} {n:8d} {s:16.1f} {a:14.2f} {d:10.0f}")
+    print(f"{'kernel':60s} {'counter':30s} {'launches':>8s} {'sum':>16s} {'mean/launch':>14s} {'avg_ns':>10s}")
+    for k, cs in sorted(counters(path).items()):
+        for c, v in sorted(cs.items()):
+            print(f"{k[:60]:60s} {c:30s} {v['launches']:8d} {v['sum']:16.1f} {v['mean']:14.2f} {v['avg_ns']:10.0f}")
     print()
 
 
+def short(name):
+    n = name.replace("void ", "").replace("igdev::", "")
+    return n.split("(")[0]
+
+
+def traffic(fetch_db, write_db):
+    f, w = counters(fetch_db), counters(write_db)
+    res = {"unit": "bytes per launch", "fetch_correction": 2.0,
+           "note": "FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; reads doubled (gfx950 coalesced-read "
+                   "correction, confirmed in-run by k_copy_paths: FETCH == WRITE / 2 for a pure copy), writes as reported "
+                   "(k_generate: 68 B/ray exactly)",
+           "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        fr = f.get(k, {}).get("FETCH_SIZE")
+        wr = w.get(k, {}).get("WRITE_SIZE")
+        if not fr or not wr:
+            continue
+        res["kernels"][short(k)] = {
+            "launches": fr["launches"],
+            "fetch_kib_raw": round(fr["mean"], 2),
+            "write_kib_raw": round(wr["mean"], 2),
+            "hbm_bytes": int((2.0 * fr["mean"] + wr["mean"]) * 1024),
+        }
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
-    kernel_stats(sys.argv[1])
-    for p in sys.argv[2:]:
-        pmc(p)
+    mode = sys.argv[1]
+    if mode == "stats":
+        kernel_stats(sys.argv[2])
+    elif mode == "pmc":
+        for p in sys.argv[2:]:
+            pmc(p)
+    elif mode == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
+    else:
+        sys.exit(__doc__)
