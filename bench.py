@@ -143,7 +143,7 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1:
-            tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false>")
+            tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false, false>")
             if tk:
                 traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, x2 read correction)"
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -24,7 +24,7 @@
 #include "kernels.h"
 
 namespace igdev {
-void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream);
+void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream);
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
@@ -106,6 +106,7 @@ struct igd_device {
     DevBuf<int32_t> entity_material;
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy;
+    DevBuf<uint2> deep_stack; // kDeepStack entries for every lane that can be resident (traversal grid + tail grid)
     DevBuf<uint32_t> light_codes;
     DevScene dscene{};
     ig_camera camera{};
@@ -113,6 +114,7 @@ struct igd_device {
     // streams
     size_t capacity = 0;
     DevBuf<float> primary[2], secondary;
+    DevBuf<uint32_t> deep_rays; // indices of the rays a traversal launch hands to its DEEP launch
     DevBuf<float> list_rays;
 
     // Two chunks can be in flight: while the side stream finishes chunk k (tail kernel, resolve, counter
@@ -225,6 +227,8 @@ struct igd_device {
         }
         secondary.release();
         secondary.alloc(capacity * kSecondaryCols);
+        deep_rays.release();
+        deep_rays.alloc(capacity);
         for (auto& f : flight) {
             f.accum.release();
             f.accum.alloc(capacity * 4);
@@ -358,6 +362,14 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_codes          = d->light_codes.ptr;
     ds.use_hierarchy        = hierarchy ? 1u : 0u;
     ds.scene_radius         = s->scene_radius;
+    {
+        const uint32_t trav_lanes = (uint32_t)d->traverseGrid() * 256u;
+        const uint32_t tail_lanes = (uint32_t)d->num_cus * (uint32_t)d->tail_waves_per_cu * 64u;
+        d->deep_stack.alloc((size_t)(trav_lanes + tail_lanes) * (size_t)kDeepStack);
+        ds.deep_stack     = d->deep_stack.ptr;
+        ds.deep_stride    = trav_lanes + tail_lanes;
+        ds.deep_tail_base = trav_lanes;
+    }
     d->camera               = s->camera;
     d->has_scene            = true;
 }
@@ -564,9 +576,11 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
             ta.count        = &qs->primary_count[in_slot];
             ta.work_counter = &qs->work_counter[0];
+            ta.index_list   = d->deep_rays.ptr;
+            ta.index_count  = &qs->deep_count;
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
-            timed(1, st, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), st); });
+            timed(1, st, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), &qs->work_counter[1], st); });
 
             // ---- sort + shade + compact (K3, K4, K5, K9)
             ShadeArgs sa{};
@@ -595,13 +609,15 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.uniform_flags = IG_RAY_FLAG_SHADOW;
             tb.count         = &qs->secondary_count;
             tb.work_counter  = &qs->work_counter[2];
+            tb.index_list    = d->deep_rays.ptr;
+            tb.index_count   = &qs->deep_count;
             tb.qs            = qs;
             tb.col     = sec.col;
             tb.accum   = accum;
             tb.id_base = first;
             tb.inv_spi = inv;
             timed(3, st, [&] {
-                launch_traverse(tb, true, counters, d->traverseGrid(), st);
+                launch_traverse(tb, true, counters, d->traverseGrid(), &qs->work_counter[3], st);
                 launch_secondary_end(qs, st);
             });
 
@@ -643,7 +659,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.scene        = d->dscene;
             tl.in           = keep;
             tl.in_count     = &qs->primary_count[in_slot];
-            tl.work_counter = &qs->work_counter[1];
+            tl.work_counter = nullptr; // set per pass
             tl.qs           = qs;
             tl.accum        = accum;
             tl.id_base      = first;
@@ -719,6 +735,8 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
         rb[0] = r[3], rb[1] = r[4], rb[2] = r[5], rb[3] = r[7];
     }
     DevBuf<float> in, out;
+    DevBuf<uint32_t> deep_rays;
+    deep_rays.alloc(n);
     in.upload(cols.data(), cols.size());
     out.alloc(n * 5);
     HIP_CHECK(hipMemset(out.ptr, 0xFF, n * 5 * sizeof(float)));
@@ -738,6 +756,8 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     ta.uniform_flags = ray_flags;
     ta.count         = &qs->primary_count[0];
     ta.work_counter  = &qs->work_counter[0];
+    ta.index_list    = deep_rays.ptr;
+    ta.index_count   = &qs->deep_count;
     ta.qs            = qs;
     ta.hit           = reinterpret_cast<float4*>(out.ptr);
     ta.hit_v         = out.ptr + n * 4;
@@ -747,9 +767,9 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
         repeat = 1;
     float total_ms = 0;
     for (int r = 0; r < repeat; ++r) {
-        HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, 4, st));
+        HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, sizeof(qs->work_counter) + sizeof(qs->deep_count), st));
         HIP_CHECK(hipEventRecord(d->event(0), st));
-        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), st);
+        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st);
         HIP_CHECK(hipEventRecord(d->event(1), st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms = 0;
@@ -939,6 +959,7 @@ int32_t igd_release_all(igd_device* dev)
         for (int s = 0; s < 2; ++s)
             dev->primary[s].release();
         dev->secondary.release();
+        dev->deep_rays.release();
         for (auto& f : dev->flight) {
             f.accum.release();
             f.tail_in.release();

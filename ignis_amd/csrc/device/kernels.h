@@ -10,6 +10,8 @@ namespace igdev {
 
 // Geometry resident in HBM. `geom` = ["trimesh_primbvh" fix table | scene Node8 array], so every
 // BVH node / Tri4 packet is addressed as geom + 32-bit byte offset (SGPR base + VGPR offset).
+constexpr int kDeepStack = 104; // traversal stack entries per lane beyond the LDS part, in DevScene::deep_stack
+
 struct DevScene {
     const uint8_t* geom;
     uint32_t scene_nodes_off;      // byte offset of SceneBVH nodes inside geom
@@ -29,7 +31,12 @@ struct DevScene {
     const float* light_hierarchy;
     const uint32_t* light_codes;
     uint32_t use_hierarchy;
-    float scene_radius; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)
+    float scene_radius;
+    // deep traversal stacks: entry e of resident lane l at deep_stack[e * deep_stride + l]; the persistent traversal
+    // grid uses lanes [0, deep_tail_base), the tail kernel's grid the lanes from deep_tail_base on (they overlap in time)
+    uint2* deep_stack;
+    uint32_t deep_stride;
+    uint32_t deep_tail_base; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)
 };
 
 // Ray queues in HBM. The reference's streams are one float per column (src/artic/driver/streams.art:
@@ -60,8 +67,8 @@ struct SecondaryCols {
 struct QueueState {
     uint32_t primary_count[2]; // sizes of the two primary streams
     uint32_t secondary_count;
-    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [2] traverse secondary
-    uint32_t pad0;
+    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch
+    uint32_t deep_count;       // rays of the traversal launch in flight whose stack outgrew LDS (re-traversed by the DEEP launch)
     // ---- from here on: cleared once per igd_render, not per chunk
     uint32_t error_flags;      // bit 0: traversal stack overflow
     uint32_t tail_rays;        // paths handed to the tail kernel (tail.hip)
@@ -78,6 +85,10 @@ struct TraverseArgs {
     const int4* meta;
     uint32_t uniform_flags;
     const uint32_t* count;  // device pointer to the number of rays
+    // first launch: rays whose stack outgrows LDS are appended here (indices) instead of being finished;
+    // DEEP launch: the rays to traverse are index_list[0 .. *count)
+    uint32_t* index_list;
+    uint32_t* index_count;
     uint32_t* work_counter; // zero before launch
     QueueState* qs;
     // outputs: hit = (ent_id, prim_id, t, u), hit_v = v. Any-hit launches may leave them null.

@@ -225,6 +225,8 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
         qs->work_counter[0]        = 0;
         qs->work_counter[1]        = 0;
         qs->work_counter[2]        = 0;
+        qs->work_counter[3]        = 0;
+        qs->deep_count             = 0;
     }
 }
 
@@ -234,6 +236,8 @@ __global__ void k_secondary_end(QueueState* qs)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         qs->secondary_count = 0;
         qs->work_counter[2] = 0;
+        qs->work_counter[3] = 0;
+        qs->deep_count      = 0;
     }
 }
 

@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
     const int lane     = tid & 63;
     const DevScene& sc = a.scene;
     const uint32_t n   = *a.in_count;
+    uint2* deep_col    = sc.deep_stack + (sc.deep_tail_base + blockIdx.x * kTailThreads + tid);
 
     uint32_t c_bounce = 0, c_shadow = 0, c_unoccluded = 0;
     uint32_t c_nodes[2] = { 0, 0 }, c_tris[2] = { 0, 0 }, c_leaves[2] = { 0, 0 };
@@ -81,8 +82,9 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
 
         if (have) {
             {
-                Traverser<false, STATS, kTailThreads> tr;
+                Traverser<false, STATS, kTailThreads, true> tr;
                 tr.init_counters();
+                tr.attach_deep(deep_col, sc.deep_stride);
                 tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
                 while (!tr.finished)
                     tr.step(sc, s_stack, tid);
@@ -107,8 +109,9 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
 
             if (out.shadow) {
                 ++c_shadow;
-                Traverser<true, STATS, kTailThreads> ts;
+                Traverser<true, STATS, kTailThreads, true> ts;
                 ts.init_counters();
+                ts.attach_deep(deep_col, sc.deep_stride);
                 ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, IG_RAY_FLAG_SHADOW);
                 while (!ts.finished)
                     ts.step(sc, s_stack, tid);

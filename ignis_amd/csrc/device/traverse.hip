@@ -12,7 +12,7 @@ namespace igdev {
 constexpr int kRefillIdle = 16;  // refill when at least this many lanes of a wave are idle
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
-template <bool ANY_HIT, bool STATS>
+template <bool ANY_HIT, bool STATS, bool DEEP>
 __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
@@ -21,17 +21,22 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
     const int lane = tid & 63;
 
     const uint32_t count = *a.count;
+    if (DEEP && count == 0)
+        return; // the usual case: no ray of the first launch needed the deep stack
     // batch size: large enough to keep the shared counter cold, small enough that every wave gets work
     const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
     uint32_t kRayBatch         = count / (total_waves * 4u);
     kRayBatch                  = kRayBatch < 64u ? 64u : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
     kRayBatch &= ~63u;
 
-    Traverser<ANY_HIT, STATS> tr;
+    Traverser<ANY_HIT, STATS, kBlockThreads, DEEP> tr;
+    tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
     bool has_ray          = false;
     uint32_t ray_idx      = 0;
     uint32_t st_unoccluded = 0;
+    uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
+    bool fatal = false;
 
     // wave-local batch of reserved ray indices (uniform across the wave)
     uint32_t batch_next = 0, batch_end = 0;
@@ -56,12 +61,14 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
             const uint32_t take  = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
             const uint32_t rank  = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!has_ray && rank < take) {
-                const uint32_t idx = batch_next + rank;
+                const uint32_t idx = DEEP ? a.index_list[batch_next + rank] : batch_next + rank;
                 ray_idx = idx;
                 has_ray = true;
                 const float4 ra = a.rayA[idx], rb = a.rayB[idx];
                 tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
                          a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
+                if (STATS && !DEEP)
+                    snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
             batch_next += take;
         }
@@ -74,7 +81,17 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
         if (has_ray) {
             tr.step(a.scene, s_stack, tid);
 
-            if (tr.finished) {
+            if (tr.finished && tr.overflow) {
+                has_ray = false;
+                if (DEEP) {
+                    fatal = true; // deeper than LDS + global part together
+                } else {
+                    // hand the ray to the DEEP launch; what this lane counted for it does not count
+                    a.index_list[atomicAdd(a.index_count, 1u)] = ray_idx;
+                    if (STATS)
+                        tr.st_nodes = snap_nodes, tr.st_tris = snap_tris, tr.st_leaves = snap_leaves;
+                }
+            } else if (tr.finished) {
                 has_ray = false;
                 if (ANY_HIT) {
                     if (a.hit)
@@ -102,7 +119,7 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
         }
     }
 
-    if (tr.overflow)
+    if (fatal)
         atomicOr(&a.qs->error_flags, 1u);
 
     if (STATS) {
@@ -117,25 +134,32 @@ __global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a
     }
 }
 
-template __global__ void k_traverse<false, false>(const TraverseArgs);
-template __global__ void k_traverse<false, true>(const TraverseArgs);
-template __global__ void k_traverse<true, false>(const TraverseArgs);
-template __global__ void k_traverse<true, true>(const TraverseArgs);
-
-void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)
+template <bool DEEP>
+static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)
 {
     const dim3 grid((unsigned)grid_blocks), block(kBlockThreads);
     if (any_hit) {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<true, true>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, true, DEEP>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<true, false>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, false, DEEP>), grid, block, 0, stream, args);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<false, true>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, true, DEEP>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<false, false>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, false, DEEP>), grid, block, 0, stream, args);
     }
+}
+
+// Two launches: the LDS-stack kernel over the whole stream, then the DEEP kernel over the rays the first one
+// could not finish (almost always none: it reads one counter and exits). `deep_work_counter` must be zero.
+void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream)
+{
+    launch_one<false>(args, any_hit, stats, grid_blocks, stream);
+    TraverseArgs deep = args;
+    deep.count        = args.index_count;
+    deep.work_counter = deep_work_counter;
+    launch_one<true>(deep, any_hit, stats, grid_blocks < 64 ? grid_blocks : 64, stream);
 }
 
 } // namespace igdev

@@ -27,7 +27,10 @@ template <int BLOCK>
 using StackOf = uint2[kLdsStack][BLOCK];
 using StackLds = StackOf<kBlockThreads>;
 
-template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads>
+// DEEP: entries above the LDS part spill to global memory (push_entry); the persistent kernels run without it
+// and re-traverse the rare rays that need it in a second, DEEP launch (traverse.hip), because the extra branch in
+// every push / pop costs 5 % on scenes that never need it.
+template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     // ---- ray + hit
@@ -54,6 +57,8 @@ struct Traverser {
     uint32_t node_off, tri_off;
     int cur_ent;
     bool ent_last, need_cull, finished, overflow;
+    uint2* deep; // this lane's column of the deep-stack buffer
+    uint32_t deep_stride;
     uint32_t st_nodes, st_tris, st_leaves;
 
     IG_DEV void init_counters()
@@ -63,22 +68,41 @@ struct Traverser {
         finished = true;
     }
 
-    // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here
-    // the stack is kLdsStack entries of LDS per lane; deeper pushes set `overflow` (the launch then
-    // raises error bit 0 and igd_render fails loudly).
+    // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here the first
+    // kLdsStack entries of a lane live in LDS; entries above that (deep BVHs only) go to the lane's column of a
+    // global buffer (kDeepStack more entries, [entry][lane] so that a wave's accesses coalesce). Beyond both,
+    // `overflow` is set: the launch raises error bit 0 and igd_render fails loudly.
+    IG_DEV void attach_deep(uint2* lane_column, uint32_t stride)
+    {
+        deep        = lane_column;
+        deep_stride = stride;
+    }
     IG_DEV void push_entry(Stack& st, int tid, int n, float t)
     {
         ++ptr;
+        const uint2 e = make_uint2((uint32_t)n, igm_bits(t));
         if (ptr < kLdsStack)
-            st[ptr][tid] = make_uint2((uint32_t)n, igm_bits(t));
-        else
+            st[ptr][tid] = e;
+        else if (DEEP && ptr < kLdsStack + kDeepStack)
+            deep[(size_t)(ptr - kLdsStack) * deep_stride] = e;
+        else {
+            // out of stack: the ray ends here (popping a clamped slot again and again would never terminate);
+            // the caller sees finished && overflow and re-traverses it with the DEEP variant or reports the error
             overflow = true;
+            finished = true;
+        }
     }
     IG_DEV void pop_top(Stack& st, int tid)
     {
-        const uint2 e = st[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
-        top_node      = (int)e.x;
-        top_tmin      = igm_float(e.y);
+        uint2 e;
+        if (!DEEP)
+            e = st[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
+        else if (ptr < kLdsStack)
+            e = st[ptr][tid];
+        else
+            e = deep[(size_t)((ptr < kLdsStack + kDeepStack ? ptr : kLdsStack + kDeepStack - 1) - kLdsStack) * deep_stride];
+        top_node = (int)e.x;
+        top_tmin = igm_float(e.y);
         --ptr;
     }
 
@@ -89,6 +113,7 @@ struct Traverser {
         tmin   = tmin_;
         tmax   = tmax_;
         rflags = flags;
+        overflow = false;
         hit_u = hit_v = 0;
         hit_prim = hit_ent = -1;
         level = 0, mode = 0;
