@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spi", type=int, default=SPI)
+    ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
     return ap.parse_args()
 
 
@@ -71,7 +72,7 @@ def main():
     from ignis_amd import Device, LoadedScene
 
     W, H, spi = args.width, args.height, args.spi
-    scene = LoadedScene.from_file(SCENE, W, H)
+    scene = LoadedScene.from_file(args.scene, W, H)
     dev = Device(local_rank, acquire_stats=1)
     dev.assign_scene(scene)
     dev.resize(W, H)
@@ -142,7 +143,7 @@ def main():
         # profiles/ by tools/prof_summary.py (counters cannot be read from inside the process)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-        if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1:
+        if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1 and args.scene == SCENE:
             tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false, false>")
             if tk:
                 traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, x2 read correction)"
@@ -169,7 +170,7 @@ def main():
                 n_it += 1
             dt = time.perf_counter() - t1
             cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": f"{n_it} iteration(s) of diamond_scene {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",
+                   "sample": f"{n_it} iteration(s) of {os.path.basename(args.scene)} {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",
                    "msamples_per_s": round(cpu_samples / dt / 1e6, 3), "seconds": round(dt, 2)}
 
         out = {
@@ -185,7 +186,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"scenes/diamond_scene.json {W}x{H}, path integrator, spi {spi} x {args.steps} iterations, seed {SEED}",
+            "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps} iterations, seed {SEED}",
                        "sharding": "whole film" if world == 1 else f"rows interleaved over {world} GPUs + one RCCL reduce"},
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},

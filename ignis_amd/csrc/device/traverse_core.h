@@ -19,6 +19,8 @@
 
 namespace igdev {
 
+constexpr int kPostponeNum   = 1;   // a section needs kPostponeNum / 2^kPostponeShift of the wave's active lanes
+constexpr int kPostponeShift = 1;   // (0 disables postponing)
 constexpr int kLdsStack     = 24;  // 24 entries * 256 threads * 8 B = 48 KiB per workgroup (3 workgroups per CU)
 constexpr int kBlockThreads = 256;
 
@@ -201,8 +203,23 @@ struct Traverser {
         const uint8_t* geom = sc.geom;
         settle(sc, st, tid);
 
+        // Postponing: a section runs only when enough lanes of the wave want it (they wait in their mode until
+        // then), so the wave does not pay a whole section for a handful of lanes. If no section reaches the
+        // quorum the threshold drops to one lane for this pass, which guarantees progress.
+        int quorum = 1;
+        if (kPostponeShift > 0) {
+            const int active = __popcll(__ballot(true));
+            const int n_ent  = __popcll(__ballot(mode == 2));
+            const int n_node = __popcll(__ballot(mode == 0 && !finished));
+            const int n_tri  = __popcll(__ballot(mode == 1));
+            const int most   = n_ent > n_node ? (n_ent > n_tri ? n_ent : n_tri) : (n_node > n_tri ? n_node : n_tri);
+            quorum           = (active * kPostponeNum) >> kPostponeShift;
+            if (quorum < 1 || most < quorum)
+                quorum = 1;
+        }
+
         // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
-        if (mode == 2) {
+        if (mode == 2 && (quorum <= 1 || __popcll(__ballot(mode == 2)) >= quorum)) {
             // leaves whose box (or visibility mask) rejects the ray cost only this short loop
             const float4* lf;
             uint2 ext;
@@ -258,7 +275,7 @@ struct Traverser {
         }
 
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
-        if (mode == 0 && !finished) {
+        if (mode == 0 && !finished && (quorum <= 1 || __popcll(__ballot(mode == 0 && !finished)) >= quorum)) {
             const uint8_t* np = geom + (level ? node_off : sc.scene_nodes_off) + (uint32_t)(top_node - 1) * 256u;
             pop_top(st, tid);
             const float4* nf = reinterpret_cast<const float4*>(np);
@@ -304,7 +321,8 @@ struct Traverser {
         }
 
         // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
-        while (mode == 1) {
+        const bool run_tri = quorum <= 1 || __popcll(__ballot(mode == 1)) >= quorum;
+        while (run_tri && mode == 1) {
             const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
             ++tri_cursor;
             const float4* tf = reinterpret_cast<const float4*>(tp);
