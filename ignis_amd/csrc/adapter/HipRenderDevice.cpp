@@ -64,8 +64,18 @@ public:
             IG_LOG(L_ERROR) << "ig_device_hip: " << igd_last_error() << std::endl;
     }
 
-    void render(const TechniqueVariantShaderSet&, const RenderSettings& rs, ParameterSet*) override
+    void render(const TechniqueVariantShaderSet&, const RenderSettings& rs, ParameterSet* params) override
     {
+        if (params) { // the global registry of this iteration (Runtime.cpp:366-387)
+            for (const auto& p : params->IntParameters)
+                igd_set_parameter_i32(mDev, p.first.c_str(), p.second);
+            for (const auto& p : params->FloatParameters)
+                igd_set_parameter_f32(mDev, p.first.c_str(), p.second);
+            for (const auto& p : params->VectorParameters) {
+                const float v[3] = { p.second.x(), p.second.y(), p.second.z() };
+                igd_set_parameter_vec3(mDev, p.first.c_str(), v);
+            }
+        }
         igd_render_settings s{};
         std::vector<float> rays;
         if (rs.rays) { // Runtime::trace: width = #rays, height = 1 (Runtime.cpp:389-446)

@@ -1097,6 +1097,46 @@ int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t
     });
 }
 
+int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value)
+{
+    return guarded("igd_set_parameter_i32", [&] {
+        if (!dev || !name)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        // kernel arguments are captured by value at launch, so work already submitted keeps its parameters
+        if (std::strcmp(name, "__tech_max_depth") == 0)
+            dev->dscene.tech.max_depth = value;
+        else if (std::strcmp(name, "__tech_min_depth") == 0)
+            dev->dscene.tech.min_depth = value;
+    });
+}
+
+int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value)
+{
+    return guarded("igd_set_parameter_f32", [&] {
+        if (!dev || !name)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        if (std::strcmp(name, "__tech_clamp") == 0)
+            dev->dscene.tech.clamp = value;
+    });
+}
+
+int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float value[3])
+{
+    return guarded("igd_set_parameter_vec3", [&] {
+        if (!dev || !name || !value)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        float* dst = nullptr;
+        if (std::strcmp(name, "__camera_eye") == 0)
+            dst = dev->camera.eye;
+        else if (std::strcmp(name, "__camera_dir") == 0)
+            dst = dev->camera.dir;
+        else if (std::strcmp(name, "__camera_up") == 0)
+            dst = dev->camera.up;
+        if (dst)
+            std::memcpy(dst, value, 3 * sizeof(float));
+    });
+}
+
 int32_t igd_synchronize(igd_device* dev)
 {
     return guarded("igd_synchronize", [&] {

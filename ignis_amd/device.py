@@ -44,7 +44,8 @@ EXPORTS = [
     "igd_get_abi_version", "igd_device_count", "igd_create", "igd_destroy", "igd_assign_scene", "igd_render",
     "igd_resize", "igd_release_all", "igd_framebuffer_width", "igd_framebuffer_height", "igd_framebuffer_host",
     "igd_framebuffer_device", "igd_clear_framebuffer", "igd_sync_framebuffer_to_device", "igd_get_stats",
-    "igd_reset_stats", "igd_traverse", "igd_synchronize", "igd_last_error",
+    "igd_reset_stats", "igd_traverse", "igd_set_parameter_i32", "igd_set_parameter_f32", "igd_set_parameter_vec3",
+    "igd_synchronize", "igd_last_error",
 ]
 
 _lib = None
@@ -93,6 +94,12 @@ def lib():
         l.igd_traverse.restype = C.c_int32
         l.igd_traverse.argtypes = [C.c_void_p, C.c_int64, fp, C.c_uint32, C.c_int32, ip, ip, fp, fp, fp, C.c_int32,
                                    C.POINTER(C.c_double)]
+        l.igd_set_parameter_i32.restype = C.c_int32
+        l.igd_set_parameter_i32.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        l.igd_set_parameter_f32.restype = C.c_int32
+        l.igd_set_parameter_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
+        l.igd_set_parameter_vec3.restype = C.c_int32
+        l.igd_set_parameter_vec3.argtypes = [C.c_void_p, C.c_char_p, fp]
         l.igd_synchronize.restype = C.c_int32
         l.igd_synchronize.argtypes = [C.c_void_p]
         l.igd_last_error.restype = C.c_char_p
@@ -151,6 +158,19 @@ class Device:
             rs.rays = keep.ctypes.data_as(C.POINTER(C.c_float))
             rs.width, rs.height = keep.shape[0], 1
         _check(lib().igd_render(self._h, C.byref(rs)))
+
+    def set_parameter(self, name, value):
+        """Registry parameter of the next render: int, float or a 3-vector (see include/igd_device.h)."""
+        n = name.encode()
+        if isinstance(value, (bool, int, np.integer)):
+            _check(lib().igd_set_parameter_i32(self._h, n, int(value)))
+        elif isinstance(value, (float, np.floating)):
+            _check(lib().igd_set_parameter_f32(self._h, n, float(value)))
+        else:
+            v = np.ascontiguousarray(value, dtype=np.float32).reshape(-1)
+            if v.size != 3:
+                raise ValueError("vector parameters have 3 components here")
+            _check(lib().igd_set_parameter_vec3(self._h, n, v.ctypes.data_as(C.POINTER(C.c_float))))
 
     def synchronize(self):
         """Waits for the part of the last render that overlaps the next one (tail paths + resolve) and reports

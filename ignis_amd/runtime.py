@@ -47,6 +47,15 @@ class Ray:
         self.Range = (float(tmin), float(tmax))
 
 
+class CameraOrientation:
+    """src/runtime/camera/CameraOrientation.h: Eye, Dir, Up."""
+
+    def __init__(self, eye=(0, 0, 0), dir=(0, 0, 1), up=(0, 1, 0)):
+        self.Eye = tuple(float(x) for x in eye)
+        self.Dir = tuple(float(x) for x in dir)
+        self.Up = tuple(float(x) for x in up)
+
+
 def recommend_spi(width, height, interactive=False):
     """recommendSPI for a GPU target (src/runtime/Runtime.cpp:71-79)."""
     spi_f = 8 // 2 if interactive else 8
@@ -66,6 +75,11 @@ class Runtime:
         self._iteration = 0
         self._samples = 0
         self._frame = 0
+        cam = sc.camera
+        self._initial_orientation = CameraOrientation(tuple(cam.eye), tuple(cam.dir), tuple(cam.up))
+        # the global registry of Runtime (Runtime.cpp:696-719): what the device does not read is only stored
+        self.IntParameters, self.FloatParameters, self.VectorParameters = {}, {}, {}
+        self.ColorParameters, self.StringParameters = {}, {}
         if not opts.IsTracer:
             self._device.resize(self._width, self._height)
 
@@ -121,6 +135,36 @@ class Runtime:
 
     def clearFramebuffer(self, aov=""):
         self._device.clear_framebuffer(aov or None)
+
+    # -- Runtime::setParameter overloads (Runtime.cpp:696-719); the device reads the ones igd_device.h lists
+    def setParameter(self, name, value):
+        if isinstance(value, str):
+            self.StringParameters[name] = value
+            return
+        if isinstance(value, (bool, int, np.integer)):
+            self.IntParameters[name] = int(value)
+        elif isinstance(value, (float, np.floating)):
+            self.FloatParameters[name] = float(value)
+        else:
+            v = tuple(float(x) for x in value)
+            if len(v) == 4:
+                self.ColorParameters[name] = v
+                return
+            self.VectorParameters[name] = v
+            value = v
+        self._device.set_parameter(name, value)
+
+    # -- Runtime::setCameraOrientation (Runtime.cpp:736-741)
+    def setCameraOrientation(self, orientation):
+        self.setParameter("__camera_eye", orientation.Eye)
+        self.setParameter("__camera_dir", orientation.Dir)
+        self.setParameter("__camera_up", orientation.Up)
+
+    def getCameraOrientation(self):
+        g = self.VectorParameters
+        return CameraOrientation(g.get("__camera_eye", (0, 0, 0)), g.get("__camera_dir", (0, 0, 1)), g.get("__camera_up", (0, 1, 0)))
+
+    InitialCameraOrientation = property(lambda self: self._initial_orientation)
 
     def incFrameCount(self):
         self._frame += 1

@@ -133,6 +133,16 @@ int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t
                      int32_t* ent_id, int32_t* prim_id, float* t, float* u, float* v,
                      int32_t repeat, double* kernel_ms);
 
+/* The registry parameters IRenderDevice::render receives with every call (ParameterSet*, IRenderDevice.h:53;
+ * filled by Runtime::setParameter / setCameraOrientation, Runtime.cpp:696-741) that this path reads:
+ *   vec3 "__camera_eye" / "__camera_dir" / "__camera_up"   (PerspectiveCamera.cpp:69-76, camera/perspective.art)
+ *   i32  "__tech_max_depth" / "__tech_min_depth", f32 "__tech_clamp"   (PathTechnique.cpp:38-40)
+ * They take effect from the next igd_render. Other names are accepted and ignored, as the reference's registry
+ * stores parameters no shader reads. */
+int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value);
+int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value);
+int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float value[3]);
+
 /* igd_render returns once the wavefront rounds of its last chunk are done; that chunk's long-path tail
  * and its framebuffer resolve may still be running on a second HIP stream, overlapping the next
  * igd_render (the reference's render() is followed by getFramebufferForHost(), which is where it syncs,

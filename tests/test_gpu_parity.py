@@ -371,3 +371,31 @@ def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances):
     dev = Device(0, acquire_stats=True)
     _compare_with_oracle(dev, sc, 192, 108, 2, seed=7, iters=2)
     dev.close()
+
+
+def test_registry_parameters_camera_and_technique(gpu_device):
+    """IRenderDevice::render's ParameterSet: __camera_eye/dir/up and __tech_max_depth take effect on the next
+    iteration and give bit-identical images to a scene file that says the same thing."""
+    import ignis_amd
+    base = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    moved = json.loads(json.dumps(base))
+    moved["camera"]["transform"] = [{"lookat": {"origin": [0.4, 0.3, 3.2], "target": [0, -0.1, 0], "up": [0, 1, 0]}}]
+    moved["technique"]["max_depth"] = 5
+    opts = ignis_amd.RuntimeOptions.makeDefault()
+    opts.OverrideFilmSize = (96, 64)
+    opts.SPI = 2
+    opts.Seed = 3
+    with ignis_amd.loadFromString(json.dumps(moved), opts, dir=SCENES) as want:
+        want.step()
+        ref = want.getFramebufferForHost().copy()
+        o = want.InitialCameraOrientation
+    with ignis_amd.loadFromString(json.dumps(base), opts, dir=SCENES) as rt:
+        rt.step()
+        assert not np.array_equal(rt.getFramebufferForHost(), ref)
+        rt.setCameraOrientation(o)
+        rt.setParameter("__tech_max_depth", 5)
+        rt.setParameter("__some_unknown_parameter", 1.5)  # stored, not an error (Runtime.cpp:701-704)
+        rt.reset()
+        rt.step()
+        np.testing.assert_array_equal(rt.getFramebufferForHost(), ref)
+        assert rt.getCameraOrientation().Eye == o.Eye and rt.IntParameters["__tech_max_depth"] == 5
