@@ -106,6 +106,8 @@ struct igd_device {
     DevBuf<int32_t> entity_material;
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy;
+    DevBuf<ig_texture> textures;
+    DevBuf<uint8_t> texture_data;
     DevBuf<uint2> deep_stack; // kDeepStack entries for every lane that can be resident (traversal grid + tail grid)
     DevBuf<uint32_t> light_codes;
     DevScene dscene{};
@@ -274,8 +276,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         const ig_material& mat = s->materials[m];
         if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
-        if (mat.flags & ~(uint32_t)IG_MAT_CHECKER)
-            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses bump/thin flags the HIP backend cannot shade yet" };
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP))
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses the thin flag, which the HIP backend cannot shade yet" };
+        if ((mat.flags & IG_MAT_BUMP) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump-mapped material " + std::to_string(m) + " has no valid texture" };
         if ((mat.flags & IG_MAT_CHECKER) && mat.bsdf_type != IG_BSDF_DIFFUSE)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard reflectance is only lowered for diffuse BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
@@ -331,6 +335,18 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->lights.upload(s->lights, s->light_count);
     d->light_hierarchy.upload(s->light_hierarchy, (size_t)s->light_hierarchy_nodes * 8);
     d->light_codes.upload(s->light_codes, s->light_codes ? n_finite : 0);
+    for (uint32_t i = 0; i < s->texture_count; ++i) {
+        const ig_texture& t = s->textures[i];
+        const uint64_t bytes = (uint64_t)t.width * t.height * (t.channels == 1 ? 1 : 4);
+        if (t.width == 0 || t.height == 0 || (t.channels != 1 && t.channels != 4) || t.offset + bytes > s->texture_data_size)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: texture " + std::to_string(i) + " is malformed" };
+    }
+    d->textures.upload(s->textures, s->texture_count);
+    {
+        std::vector<uint8_t> td(s->texture_data, s->texture_data + (s->texture_count ? s->texture_data_size : 0));
+        td.resize(td.size() + 16);
+        d->texture_data.upload(td.data(), td.size());
+    }
 
     // material id per entity (entity table word 34, LoaderEntity.cpp:159)
     std::vector<int32_t> em(s->entity_count);
@@ -362,6 +378,8 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_codes          = d->light_codes.ptr;
     ds.use_hierarchy        = hierarchy ? 1u : 0u;
     ds.scene_radius         = s->scene_radius;
+    ds.textures             = d->textures.ptr;
+    ds.texture_data         = d->texture_data.ptr;
     {
         const uint32_t trav_lanes = (uint32_t)d->traverseGrid() * 256u;
         const uint32_t tail_lanes = (uint32_t)d->num_cus * (uint32_t)d->tail_waves_per_cu * 64u;
@@ -979,6 +997,8 @@ int32_t igd_release_all(igd_device* dev)
         dev->lights.release();
         dev->light_hierarchy.release();
         dev->light_codes.release();
+        dev->textures.release();
+        dev->texture_data.release();
         dev->has_scene = false;
     });
 }

@@ -32,6 +32,9 @@ struct DevScene {
     const uint32_t* light_codes;
     uint32_t use_hierarchy;
     float scene_radius;
+    // bitmap textures (ig_material.tex_id)
+    const ig_texture* textures;
+    const uint8_t* texture_data;
     // deep traversal stacks: entry e of resident lane l at deep_stack[e * deep_stride + l]; the persistent traversal
     // grid uses lanes [0, deep_tail_base), the tail kernel's grid the lanes from deep_tail_base on (they overlap in time)
     uint2* deep_stack;

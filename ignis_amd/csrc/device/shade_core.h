@@ -313,15 +313,157 @@ IG_DEV float wrapf(float v, float mn, float mx)
     return range <= kFltEps ? mn : v - (range * igm_floor((v - mn) / range));
 }
 
+// ---- bitmap textures (texture/image.art, driver/image.art:9-16): packed 8-bit texels, divided by 255 on fetch
+IG_DEV Col image_pixel(const DevScene& sc, const ig_texture& t, int x, int y)
+{
+    const uint8_t* base = sc.texture_data + t.offset;
+    if (t.channels == 1) {
+        const float g = (float)base[y * (int)t.width + x] / 255;
+        return Col{ g, g, g };
+    }
+    const uint32_t packed = reinterpret_cast<const uint32_t*>(base)[y * (int)t.width + x];
+    return Col{ (float)(packed & 0xFFu) / 255, (float)((packed >> 8) & 0xFFu) / 255, (float)((packed >> 16) & 0xFFu) / 255 };
+}
+IG_DEV int image_border(uint32_t mode, int x, int w) // image.art:9-40
+{
+    if (mode == IG_WRAP_CLAMP)
+        return x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    if (mode == IG_WRAP_MIRROR) {
+        const int t = x < 0 ? -1 - x : x;
+        const int i = t / w;
+        const int k = t - i * w;
+        return (i & 1) == 0 ? w - 1 - k : k;
+    }
+    const int t = x % w;
+    return t < 0 ? t + w : t;
+}
+IG_DEV Col lerp_col(Col a, Col b, float t) // core/color.art:17-21
+{
+    return Col{ (1 - t) * a.r + t * b.r, (1 - t) * a.g + t * b.g, (1 - t) * a.b + t * b.b };
+}
+IG_DEV float cubic_w0(float a) { return (a * (a * (-a + 3) - 3) + 1) / 6; } // image.art:107-118
+IG_DEV float cubic_w1(float a) { return (a * a * (3 * a - 6) + 4) / 6; }
+IG_DEV float cubic_w2(float a) { return (a * (a * (-3 * a + 3) + 3) + 1) / 6; }
+IG_DEV float cubic_w3(float a) { return (a * a * a) / 6; }
+IG_DEV float cubic_g0(float a) { return cubic_w0(a) + cubic_w1(a); }
+IG_DEV float cubic_g1(float a) { return cubic_w2(a) + cubic_w3(a); }
+IG_DEV float cubic_h0(float a) { return (cubic_w1(a) / cubic_g0(a)) - 1; }
+IG_DEV float cubic_h1(float a) { return (cubic_w3(a) / cubic_g1(a)) + 1; }
+
+// make_image_texture with an identity transform (image.art:158-163) over the three filters (image.art:85-156)
+IG_DEV Col image_lookup(const DevScene& sc, const ig_texture& t, f2 uv)
+{
+    const int W = (int)t.width, H = (int)t.height;
+    if (t.filter == IG_TEX_NEAREST) {
+        const float u = uv.x * (float)W, v = uv.y * (float)H;
+        return image_pixel(sc, t, image_border(t.wrap_u, (int)igm_floor(u), W), image_border(t.wrap_v, (int)igm_floor(v), H));
+    }
+    const float u = uv.x * (float)W - 0.5f;
+    const float v = uv.y * (float)H - 0.5f;
+    const int ix = (int)igm_floor(u), iy = (int)igm_floor(v);
+    const float fx = u - igm_floor(u), fy = v - igm_floor(v);
+    if (t.filter == IG_TEX_BILINEAR) {
+        const int x0 = image_border(t.wrap_u, ix, W), x1 = image_border(t.wrap_u, ix + 1, W);
+        const int y0 = image_border(t.wrap_v, iy, H), y1 = image_border(t.wrap_v, iy + 1, H);
+        return lerp_col(lerp_col(image_pixel(sc, t, x0, y0), image_pixel(sc, t, x1, y0), fx),
+                        lerp_col(image_pixel(sc, t, x0, y1), image_pixel(sc, t, x1, y1), fx), fy);
+    }
+    const float g0x = cubic_g0(fx), g0y = cubic_g0(fy), g1x = cubic_g1(fx), g1y = cubic_g1(fy);
+    const int x0 = image_border(t.wrap_u, (int)igm_floor((float)ix + cubic_h0(fx) + 0.5f), W);
+    const int y0 = image_border(t.wrap_v, (int)igm_floor((float)iy + cubic_h0(fy) + 0.5f), H);
+    const int x1 = image_border(t.wrap_u, (int)igm_floor((float)ix + cubic_h1(fx) + 0.5f), W);
+    const int y1 = image_border(t.wrap_v, (int)igm_floor((float)iy + cubic_h1(fy) + 0.5f), H);
+    const Col p00 = image_pixel(sc, t, x0, y0) * (g0x * g0y);
+    const Col p10 = image_pixel(sc, t, x1, y0) * (g1x * g0y);
+    const Col p01 = image_pixel(sc, t, x0, y1) * (g0x * g1y);
+    const Col p11 = image_pixel(sc, t, x1, y1) * (g1x * g1y);
+    const Col a{ p00.r + p10.r, p00.g + p10.g, p00.b + p10.b }, c{ p01.r + p11.r, p01.g + p11.g, p01.b + p11.b };
+    return Col{ a.r + c.r, a.g + c.g, a.b + c.b };
+}
+
+// ---- bump mapping (bsdf/map.art:36-42,64-67; MapBSDF.cpp:44-47)
+IG_DEV f3 ensure_valid_reflection(f3 Ng, f3 I, f3 N) // core/sampling.art:118-166
+{
+    const f3 R            = N * (2 * dot3(N, I)) - I; // vec3_reflect
+    const float threshold = igm_min(0.9f * dot3(Ng, I), 0.01f);
+    if (dot3(Ng, R) >= threshold)
+        return N;
+    const float NdotNg = dot3(N, Ng);
+    const f3 X         = normalize3(N - Ng * NdotNg);
+    const float Ix = dot3(I, X), Iz = dot3(I, Ng);
+    const float Ix2 = Ix * Ix, Iz2 = Iz * Iz;
+    const float a   = Ix2 + Iz2;
+    const float b   = safe_sqrt(Ix2 * (a - threshold * threshold));
+    const float c   = Iz * threshold + a;
+    const float fac = 0.5f / a;
+    const float N1_z2 = fac * (b + c), N2_z2 = fac * (-b + c);
+    const bool valid1 = (N1_z2 > 1e-5f) && (N1_z2 <= (1.0f + 1e-5f));
+    const bool valid2 = (N2_z2 > 1e-5f) && (N2_z2 <= (1.0f + 1e-5f));
+    f2 Nn;
+    if (valid1 && valid2) {
+        const f2 N1{ safe_sqrt(1 - N1_z2), safe_sqrt(N1_z2) };
+        const f2 N2{ safe_sqrt(1 - N2_z2), safe_sqrt(N2_z2) };
+        const float R1 = 2 * (N1.x * Ix + N1.y * Iz) * N1.y - Iz;
+        const float R2 = 2 * (N2.x * Ix + N2.y * Iz) * N2.y - Iz;
+        if (R1 >= 1e-5f && R2 >= 1e-5f)
+            Nn = R1 < R2 ? N1 : N2;
+        else
+            Nn = R1 > R2 ? N1 : N2;
+    } else if (valid1 || valid2) {
+        const float Nz2 = valid1 ? N1_z2 : N2_z2;
+        Nn              = f2{ safe_sqrt(1 - Nz2), safe_sqrt(Nz2) };
+    } else {
+        Nn = f2{ 0, 1 };
+    }
+    return X * Nn.x + Ng * Nn.y;
+}
+IG_DEV m33 align_vectors(f3 a, f3 b) // core/matrix.art:261-284
+{
+    const f3 axis    = cross3(b, a);
+    const float cosA = dot3(a, b);
+    m33 m;
+    if (cosA <= -1) {
+        m.c0 = f3{ -1, 0, 0 }, m.c1 = f3{ 0, -1, 0 }, m.c2 = f3{ 0, 0, -1 };
+        return m;
+    }
+    const float k = 1 / (1 + cosA);
+    m.c0 = f3{ (axis.x * axis.x * k) + cosA, (axis.y * axis.x * k) - axis.z, (axis.z * axis.x * k) + axis.y };
+    m.c1 = f3{ (axis.x * axis.y * k) + axis.z, (axis.y * axis.y * k) + cosA, (axis.z * axis.y * k) - axis.x };
+    m.c2 = f3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
+    return m;
+}
+// the local frame the inner BSDF of a bump-mapped material sees (make_bumpmap -> make_normal_set; camera paths
+// are not adjoint, so nothing else of transform_surf_bsdf applies)
+IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& s, f3 ray_dir)
+{
+    const ig_texture& t = sc.textures[mat.tex_id];
+    const float delta   = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
+    const Col c0        = image_lookup(sc, t, s.tex);
+    const Col cx        = image_lookup(sc, t, f2{ s.tex.x + delta, s.tex.y });
+    const Col cy        = image_lookup(sc, t, f2{ s.tex.x, s.tex.y + delta });
+    const float dx      = (cx.r - c0.r) * (1 / delta);
+    const float dy      = (cy.r - c0.r) * (1 / delta);
+    const f3 N          = normalize3(s.local.c2 - (s.local.c0 * dx + s.local.c1 * dy) * mat.p[11]);
+    const f3 n          = ensure_valid_reflection(s.face_normal, -ray_dir, normalize3(N));
+    const m33 trans     = align_vectors(s.local.c2, n);
+    m33 out;
+    out.c0 = mul33(trans, s.local.c0); // mat3x3_matmul(trans, local), core/matrix.art:124-127
+    out.c1 = mul33(trans, s.local.c1);
+    out.c2 = mul33(trans, s.local.c2);
+    return out;
+}
+
 struct BsdfCtx {
     const ig_material* mat;
-    Surf surf;
-    Col kd; // diffuse reflectance (constant or checkerboard)
+    Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
+    Col kd;    // diffuse reflectance (constant or checkerboard)
 
-    IG_DEV BsdfCtx(const ig_material& m, const Surf& s)
+    IG_DEV BsdfCtx(const DevScene& sc, const ig_material& m, const Surf& s, f3 ray_dir)
         : mat(&m)
         , surf(s)
     {
+        if (m.flags & IG_MAT_BUMP)
+            surf.local = bumped_frame(sc, m, s, ray_dir);
         if (m.flags & IG_MAT_CHECKER) {
             const bool px = ((int)wrapf(s.tex.x * m.q[6], 0, 2) % 2) == 0;
             const bool py = ((int)wrapf(s.tex.y * m.q[7], 0, 2) % 2) == 0;
@@ -622,8 +764,9 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     }
 
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
-    const BsdfCtx bsdf(mat, surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v));
-    const Surf& surf = bsdf.surf;
+    // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
+    const Surf surf = surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    const BsdfCtx bsdf(sc, mat, surf, in.dir);
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 

@@ -18,6 +18,7 @@
 #include "igh_host.h"
 #include "json.h"
 #include "mesh.h"
+#include "png.h"
 
 #include <cstring>
 #include <fstream>
@@ -273,6 +274,8 @@ struct Scene {
     std::vector<uint32_t> light_codes;
     std::vector<std::string> entity_names;
     std::vector<std::string> material_names;
+    std::vector<ig_texture> textures;
+    std::vector<uint8_t> texture_data;
     igd_scene tables{};
 };
 
@@ -431,7 +434,99 @@ static bool lowerCheckerboard(const JsonValue& prop, const JsonValue& textures, 
     return false;
 }
 
-static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, int depth = 0)
+// Bitmap textures ("image" / "bitmap", LoaderTexture.cpp:65-66) loaded on first use into the packed form the
+// reference uploads for 8-bit files (ImagePattern.cpp:17-75, Image::loadAsPacked Image.cpp:714-808).
+struct TextureBank {
+    const JsonValue& defs;
+    std::string base_dir;
+    std::vector<ig_texture>& recs;
+    std::vector<uint8_t>& data;
+    std::map<std::string, int> ids;
+
+    static uint8_t toLinear(uint8_t c)
+    {
+        // byte_color_to_linear (Image.cpp:40-51)
+        const float v = c / 255.0f;
+        const float l = v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+        return (uint8_t)std::min<uint16_t>(255, (uint16_t)std::floor(l * 255));
+    }
+    static uint32_t wrapMode(const std::string& s) { return s == "mirror" ? IG_WRAP_MIRROR : (s == "clamp" ? IG_WRAP_CLAMP : IG_WRAP_REPEAT); }
+
+    int get(const std::string& tex_name, const std::string& owner)
+    {
+        auto it = ids.find(tex_name);
+        if (it != ids.end())
+            return it->second;
+        const JsonValue* def = nullptr;
+        for (const auto& t : defs.arr)
+            if (t.getString("name") == tex_name)
+                def = &t;
+        if (!def)
+            fail("'" + owner + "': unknown texture '" + tex_name + "'");
+        const std::string type = def->getString("type");
+        if (type != "image" && type != "bitmap")
+            fail("'" + owner + "': texture '" + tex_name + "' of type '" + type + "' is not supported by the HIP backend here");
+        if (def->has("transform"))
+            fail("Texture '" + tex_name + "': image transforms are not supported by this loader");
+        if (def->getBool("force_unpacked", false))
+            fail("Texture '" + tex_name + "': force_unpacked is not supported by this loader");
+        const std::string filename = def->getString("filename");
+        if (filename.empty())
+            fail("Texture '" + tex_name + "': no filename");
+        const std::string path = (filename[0] == '/' || base_dir.empty()) ? filename : base_dir + "/" + filename;
+        if (path.size() < 4 || path.substr(path.size() - 4) != ".png")
+            fail("Texture '" + tex_name + "': only PNG files are supported by this loader");
+        const PngImage png = readPng(path);
+        const bool linear  = def->getBool("linear", false);
+
+        ig_texture rec{};
+        rec.width  = png.width;
+        rec.height = png.height;
+        // ImagePattern.cpp:25-29: anything but "bilinear" / "nearest" (e.g. the scenes' "trilinear") is bicubic
+        const std::string filter = def->getString("filter_type", "bicubic");
+        rec.filter               = filter == "bilinear" ? IG_TEX_BILINEAR : (filter == "nearest" ? IG_TEX_NEAREST : IG_TEX_BICUBIC);
+        if (def->has("wrap_mode_u")) {
+            rec.wrap_u = wrapMode(def->getString("wrap_mode_u", "repeat"));
+            rec.wrap_v = wrapMode(def->getString("wrap_mode_v", "repeat"));
+        } else {
+            rec.wrap_u = rec.wrap_v = wrapMode(def->getString("wrap_mode", "repeat"));
+        }
+        data.resize((data.size() + 15) & ~(size_t)15);
+        rec.offset = data.size();
+        // rows bottom to top (stbi_set_flip_vertically_on_load, Image.cpp:724)
+        const size_t n = (size_t)png.width * png.height;
+        if (png.channels == 1) {
+            rec.channels = 1;
+            data.resize(rec.offset + n);
+            for (uint32_t y = 0; y < png.height; ++y)
+                for (uint32_t x = 0; x < png.width; ++x) {
+                    const uint8_t v = png.data[(size_t)(png.height - 1 - y) * png.width + x];
+                    data[rec.offset + (size_t)y * png.width + x] = linear ? v : toLinear(v);
+                }
+        } else {
+            // 3 channels get alpha 255; 2 (gray + alpha) is re-requested as RGBA from stb (Image.cpp:731-736)
+            rec.channels = 4;
+            data.resize(rec.offset + n * 4);
+            for (uint32_t y = 0; y < png.height; ++y)
+                for (uint32_t x = 0; x < png.width; ++x) {
+                    const uint8_t* p = &png.data[((size_t)(png.height - 1 - y) * png.width + x) * png.channels];
+                    uint8_t r, g, b, a;
+                    if (png.channels == 2)
+                        r = g = b = p[0], a = p[1];
+                    else
+                        r = p[0], g = p[1], b = p[2], a = png.channels == 4 ? p[3] : 255;
+                    uint8_t* o = &data[rec.offset + ((size_t)y * png.width + x) * 4];
+                    o[0] = linear ? r : toLinear(r), o[1] = linear ? g : toLinear(g), o[2] = linear ? b : toLinear(b), o[3] = a;
+                }
+        }
+        const int id = (int)recs.size();
+        recs.push_back(rec);
+        ids[tex_name] = id;
+        return id;
+    }
+};
+
+static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, TextureBank& bank, int depth = 0)
 {
     const JsonValue* bsdf = nullptr;
     for (const auto& b : scene_bsdfs.arr)
@@ -498,6 +593,20 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[10] = r * aspect;
         if (m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
             fail("BSDF '" + name + "': roughness <= 1e-4 makes a delta conductor, which is not supported by the HIP backend");
+    } else if (type == "bumpmap") {
+        // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength)
+        const std::string inner = bsdf->getString("bsdf");
+        if (inner.empty())
+            fail("BSDF '" + name + "': has no inner bsdf given");
+        m = lowerBsdf(inner, scene_bsdfs, textures, bank, depth + 1);
+        if (m.flags & IG_MAT_BUMP)
+            fail("BSDF '" + name + "': nested bump maps are not supported by the HIP backend");
+        const JsonValue* map = bsdf->find("map");
+        if (!map || !map->isString())
+            fail("BSDF '" + name + "': 'map' must name a bitmap texture");
+        m.flags |= IG_MAT_BUMP;
+        m.tex_id = bank.get(map->str, name);
+        m.p[11]  = getConstNumber(*bsdf, "strength", 1.0f, name);
     } else {
         fail("BSDF '" + name + "': type '" + type + "' is not supported by the HIP backend");
     }
@@ -933,8 +1042,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     sc->lights.insert(sc->lights.end(), finite.begin(), finite.end());
 
     // ---- materials
+    TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {} };
     for (size_t m = 0; m < mat_keys.size(); ++m) {
-        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures);
+        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures, bank);
         if (!mat_keys[m].light_entity.empty())
             mat.light_id = (int32_t)infinite.size() + finite_index_of_entity.at(mat_keys[m].light_entity);
         sc->materials.push_back(mat);
@@ -976,6 +1086,11 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.light_hierarchy    = sc->light_hierarchy.empty() ? nullptr : sc->light_hierarchy.data();
     t.light_hierarchy_nodes = (uint32_t)(sc->light_hierarchy.size() / 8);
     t.light_codes        = sc->light_codes.empty() ? nullptr : sc->light_codes.data();
+    sc->texture_data.resize(sc->texture_data.size() + 16); // vector loads never run past the allocation
+    t.textures           = sc->textures.empty() ? nullptr : sc->textures.data();
+    t.texture_count      = (uint32_t)sc->textures.size();
+    t.texture_data       = sc->texture_data.data();
+    t.texture_data_size  = sc->texture_data.size();
     t.camera             = cam;
     t.technique          = tech;
     for (int i = 0; i < 3; ++i) {

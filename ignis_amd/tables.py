@@ -50,6 +50,11 @@ class Technique(C.Structure):
                 ("light_selector", C.c_int32)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("filter", C.c_uint32),
+                ("wrap_u", C.c_uint32), ("wrap_v", C.c_uint32), ("offset", C.c_uint64)]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("entities", C.POINTER(C.c_float)), ("entity_count", C.c_uint32),
@@ -66,6 +71,8 @@ class Scene(C.Structure):
         ("camera", Camera), ("technique", Technique),
         ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
         ("film_width", C.c_int32), ("film_height", C.c_int32), ("scene_radius", C.c_float),
+        ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
+        ("texture_data", C.POINTER(C.c_uint8)), ("texture_data_size", C.c_uint64),
     ]
 
 

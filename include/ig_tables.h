@@ -90,7 +90,7 @@ enum ig_bsdf_type {
 
 enum ig_material_flags {
     IG_MAT_THIN       = 1u << 0, /* dielectric "thin" */
-    IG_MAT_BUMP       = 1u << 1, /* wrapped in a bumpmap, src/artic/bsdf/map.art:36-42 */
+    IG_MAT_BUMP       = 1u << 1, /* wrapped in a bumpmap (src/artic/bsdf/map.art:36-42,64-67, MapBSDF.cpp:44-47): tex_id, p[11] */
     IG_MAT_CHECKER    = 1u << 2, /* reflectance is a checkerboard texture */
 };
 
@@ -111,6 +111,23 @@ typedef struct ig_material {
     float p[12];
     float q[8];
 } ig_material;
+
+/* ---- Bitmap textures --------------------------------------------------- */
+
+/* A "packed" image as the reference uploads it for 8-bit files (src/runtime/Image.cpp:714-808,
+ * src/artic/driver/image.art:9-16): texels are bytes, rows bottom-to-top (stb's vertical flip), sRGB files
+ * already mapped to linear and re-quantised by the loader; 4 channels = one little-endian u32 RGBA per texel,
+ * 1 channel = one byte. The device divides by 255. */
+enum ig_tex_filter { IG_TEX_NEAREST = 0, IG_TEX_BILINEAR = 1, IG_TEX_BICUBIC = 2 }; /* src/artic/texture/image.art:85-156 */
+enum ig_tex_wrap { IG_WRAP_REPEAT = 0, IG_WRAP_MIRROR = 1, IG_WRAP_CLAMP = 2 };      /* image.art:9-40 */
+
+typedef struct ig_texture {
+    uint32_t width, height;
+    uint32_t channels; /* 1 or 4 */
+    uint32_t filter;   /* enum ig_tex_filter */
+    uint32_t wrap_u, wrap_v;
+    uint64_t offset;   /* bytes into texture_data, 16-byte aligned */
+} ig_texture;
 
 /* ---- Lights ----------------------------------------------------------- */
 
@@ -202,6 +219,11 @@ typedef struct igd_scene {
     float bbox_max[3];
     int32_t film_width, film_height;
     float scene_radius; /* bbox_radius(scene_bbox) * 1.01, src/artic/light/env.art:88 */
+    /* bitmap textures referenced by ig_material.tex_id */
+    const ig_texture* textures;
+    uint32_t texture_count;
+    const uint8_t* texture_data;
+    uint64_t texture_data_size;
 } igd_scene;
 
 #ifdef __cplusplus

@@ -307,7 +307,9 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
 
                     PTRayPayload payload      = read_payload(primary, i);
                     const SurfaceElement surf = surface_element(sc, entity, ray, hit);
-                    const Bsdf bsdf{ &mat, &surf };
+                    // a bump-mapped material hands its inner BSDF a re-oriented surface (bsdf/map.art:64-67)
+                    const SurfaceElement bsurf = (mat.flags & IG_MAT_BUMP) ? bumped_surface(sc, mat, surf, ray) : surf;
+                    const Bsdf bsdf{ &mat, &bsurf };
 
                     Color hit_color;
                     if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))

@@ -349,6 +349,146 @@ static inline Color checkerboard(const ig_material& mat, Vec2 uv)
     return (parity_x ^ parity_y) ? Color{ mat.q[0], mat.q[1], mat.q[2] } : Color{ mat.q[3], mat.q[4], mat.q[5] };
 }
 
+// ---- bitmap textures (texture/image.art, driver/image.art:9-16, mapping_cpu.art:980-992)
+static inline Color image_pixel(const igd_scene& sc, const ig_texture& t, int32_t x, int32_t y)
+{
+    const uint8_t* base = sc.texture_data + t.offset;
+    if (t.channels == 1) {
+        const float g = (float)base[y * (int32_t)t.width + x] / 255; // image_mono_unpack
+        return Color{ g, g, g };
+    }
+    uint32_t packed;
+    std::memcpy(&packed, base + 4 * (size_t)(y * (int32_t)t.width + x), 4);
+    // image_rgba_unpack (alpha is not part of Color here)
+    return Color{ (float)(packed & 0x000000FFu) / 255, (float)((packed & 0x0000FF00u) >> 8) / 255, (float)((packed & 0x00FF0000u) >> 16) / 255 };
+}
+static inline int32_t image_border(uint32_t mode, int32_t x, int32_t w)
+{
+    if (mode == IG_WRAP_CLAMP) // image.art:9-15
+        return x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    if (mode == IG_WRAP_MIRROR) { // image.art:28-40
+        const int32_t t = x < 0 ? -1 - x : x;
+        const int32_t i = t / w;
+        const int32_t k = t - i * w;
+        return (i & 1) == 0 ? w - 1 - k : k;
+    }
+    const int32_t t = x % w; // image.art:17-26
+    return t < 0 ? t + w : t;
+}
+static inline Color color_lerp(Color a, Color b, float t) // color.art:17-21
+{
+    return Color{ (1 - t) * a.r + t * b.r, (1 - t) * a.g + t * b.g, (1 - t) * a.b + t * b.b };
+}
+// make_image_texture with an identity transform (image.art:158-163) over the three filters (image.art:85-156)
+static inline Color image_lookup(const igd_scene& sc, const ig_texture& t, Vec2 uv)
+{
+    const int32_t W = (int32_t)t.width, H = (int32_t)t.height;
+    auto px = [&](int32_t x, int32_t y) { return image_pixel(sc, t, image_border(t.wrap_u, x, W), image_border(t.wrap_v, y, H)); };
+    if (t.filter == IG_TEX_NEAREST) {
+        const float u = uv.x * (float)W, v = uv.y * (float)H; // map_uv_to_image_pixel_nearest
+        return px((int32_t)igm_floor(u), (int32_t)igm_floor(v));
+    }
+    const float u    = uv.x * (float)W - 0.5f; // map_uv_to_image_pixel
+    const float v    = uv.y * (float)H - 0.5f;
+    const int32_t ix = (int32_t)igm_floor(u), iy = (int32_t)igm_floor(v);
+    const float fx = u - igm_floor(u), fy = v - igm_floor(v); // math::fract
+    if (t.filter == IG_TEX_BILINEAR)
+        return color_lerp(color_lerp(px(ix, iy), px(ix + 1, iy), fx), color_lerp(px(ix, iy + 1), px(ix + 1, iy + 1), fx), fy);
+    // bicubic B-spline through two bilinear-like taps per axis (image.art:105-156)
+    auto w0 = [](float a) { return (a * (a * (-a + 3) - 3) + 1) / 6; };
+    auto w1 = [](float a) { return (a * a * (3 * a - 6) + 4) / 6; };
+    auto w2 = [](float a) { return (a * (a * (-3 * a + 3) + 3) + 1) / 6; };
+    auto w3 = [](float a) { return (a * a * a) / 6; };
+    auto g0 = [&](float a) { return w0(a) + w1(a); };
+    auto g1 = [&](float a) { return w2(a) + w3(a); };
+    auto h0 = [&](float a) { return (w1(a) / g0(a)) - 1; };
+    auto h1 = [&](float a) { return (w3(a) / g1(a)) + 1; };
+    const float g0x = g0(fx), g0y = g0(fy), g1x = g1(fx), g1y = g1(fy);
+    const int32_t ix0 = (int32_t)igm_floor((float)ix + h0(fx) + 0.5f);
+    const int32_t iy0 = (int32_t)igm_floor((float)iy + h0(fy) + 0.5f);
+    const int32_t ix1 = (int32_t)igm_floor((float)ix + h1(fx) + 0.5f);
+    const int32_t iy1 = (int32_t)igm_floor((float)iy + h1(fy) + 0.5f);
+    const Color p00 = color_mulf(px(ix0, iy0), g0x * g0y);
+    const Color p10 = color_mulf(px(ix1, iy0), g1x * g0y);
+    const Color p01 = color_mulf(px(ix0, iy1), g0x * g1y);
+    const Color p11 = color_mulf(px(ix1, iy1), g1x * g1y);
+    const Color a{ p00.r + p10.r, p00.g + p10.g, p00.b + p10.b }, c{ p01.r + p11.r, p01.g + p11.g, p01.b + p11.b };
+    return Color{ a.r + c.r, a.g + c.g, a.b + c.b };
+}
+
+// ---- bump mapping (bsdf/map.art:36-42,64-67; MapBSDF.cpp:44-47; core/sampling.art:118-166; core/matrix.art:261-284)
+static inline Vec3 ensure_valid_reflection(Vec3 Ng, Vec3 I, Vec3 N)
+{
+    const Vec3 R          = vec3_reflect(I, N);
+    const float threshold = igm_min(0.9f * vec3_dot(Ng, I), 0.01f);
+    if (vec3_dot(Ng, R) >= threshold)
+        return N;
+    const float NdotNg = vec3_dot(N, Ng);
+    const Vec3 X       = vec3_normalize(vec3_sub(N, vec3_mulf(Ng, NdotNg)));
+    const float Ix = vec3_dot(I, X), Iz = vec3_dot(I, Ng);
+    const float Ix2 = Ix * Ix, Iz2 = Iz * Iz;
+    const float a   = Ix2 + Iz2;
+    const float b   = safe_sqrt(Ix2 * (a - threshold * threshold));
+    const float c   = Iz * threshold + a;
+    const float fac = 0.5f / a;
+    const float N1_z2 = fac * (b + c), N2_z2 = fac * (-b + c);
+    const bool valid1 = (N1_z2 > 1e-5f) && (N1_z2 <= (1.0f + 1e-5f));
+    const bool valid2 = (N2_z2 > 1e-5f) && (N2_z2 <= (1.0f + 1e-5f));
+    Vec2 Nn;
+    if (valid1 && valid2) {
+        const Vec2 N1{ safe_sqrt(1 - N1_z2), safe_sqrt(N1_z2) };
+        const Vec2 N2{ safe_sqrt(1 - N2_z2), safe_sqrt(N2_z2) };
+        const float R1 = 2 * (N1.x * Ix + N1.y * Iz) * N1.y - Iz;
+        const float R2 = 2 * (N2.x * Ix + N2.y * Iz) * N2.y - Iz;
+        const bool valid3 = R1 >= 1e-5f, valid4 = R2 >= 1e-5f;
+        if (valid3 && valid4)
+            Nn = R1 < R2 ? N1 : N2;
+        else
+            Nn = R1 > R2 ? N1 : N2;
+    } else if (valid1 || valid2) {
+        const float Nz2 = valid1 ? N1_z2 : N2_z2;
+        Nn              = Vec2{ safe_sqrt(1 - Nz2), safe_sqrt(Nz2) };
+    } else {
+        Nn = Vec2{ 0, 1 };
+    }
+    return vec3_add(vec3_mulf(X, Nn.x), vec3_mulf(Ng, Nn.y));
+}
+static inline Mat3x3 mat3x3_align_vectors(Vec3 a, Vec3 b)
+{
+    const Vec3 axis  = vec3_cross(b, a);
+    const float cosA = vec3_dot(a, b);
+    Mat3x3 m;
+    if (cosA <= -1) {
+        m.col[0] = Vec3{ -1, 0, 0 }, m.col[1] = Vec3{ 0, -1, 0 }, m.col[2] = Vec3{ 0, 0, -1 };
+        return m;
+    }
+    const float k = 1 / (1 + cosA);
+    m.col[0] = Vec3{ (axis.x * axis.x * k) + cosA, (axis.y * axis.x * k) - axis.z, (axis.z * axis.x * k) + axis.y };
+    m.col[1] = Vec3{ (axis.x * axis.y * k) + axis.z, (axis.y * axis.y * k) + cosA, (axis.z * axis.y * k) - axis.x };
+    m.col[2] = Vec3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
+    return m;
+}
+// The surface the inner BSDF of a bump-mapped material sees: make_bumpmap -> make_normal_set (adjoint == false
+// on camera paths, so transform_surf_bsdf changes nothing else).
+static inline SurfaceElement bumped_surface(const igd_scene& sc, const ig_material& mat, const SurfaceElement& surf, const Ray& ray)
+{
+    const ig_texture& t = sc.textures[mat.tex_id];
+    const float delta   = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
+    const Color c0      = image_lookup(sc, t, surf.tex_coords);
+    const Color cx      = image_lookup(sc, t, Vec2{ surf.tex_coords.x + delta, surf.tex_coords.y });
+    const Color cy      = image_lookup(sc, t, Vec2{ surf.tex_coords.x, surf.tex_coords.y + delta });
+    const float dx      = (cx.r - c0.r) * (1 / delta);
+    const float dy      = (cy.r - c0.r) * (1 / delta);
+    const Vec3 N        = vec3_normalize(vec3_sub(surf.local.col[2], vec3_mulf(vec3_add(vec3_mulf(surf.local.col[0], dx), vec3_mulf(surf.local.col[1], dy)), mat.p[11])));
+    const Vec3 n        = ensure_valid_reflection(surf.face_normal, vec3_neg(ray.dir), vec3_normalize(N));
+    const Mat3x3 trans  = mat3x3_align_vectors(surf.local.col[2], n);
+    SurfaceElement out  = surf;
+    out.local.col[0]    = mat3x3_mul(trans, surf.local.col[0]); // mat3x3_matmul(trans, local), matrix.art:124-127
+    out.local.col[1]    = mat3x3_mul(trans, surf.local.col[1]);
+    out.local.col[2]    = mat3x3_mul(trans, surf.local.col[2]);
+    return out;
+}
+
 // ---- BSDFs (driver/bsdf.art)
 struct BsdfSample {
     Vec3 in_dir;

@@ -96,3 +96,59 @@ def test_transform_parsing_matches_matrix_form():
     ea = np.ctypeslib.as_array(sa.scene.entities, shape=(36,)).copy()
     eb = np.ctypeslib.as_array(sb.scene.entities, shape=(36,)).copy()
     np.testing.assert_array_equal(ea, eb)
+
+
+def test_loader_bitmap_texture_matches_an_independent_png_decode():
+    """Bump-map texture of many_point_lights: the loader's PNG reader + packing (bottom-up rows, sRGB -> linear
+    re-quantised to 8 bit, Image.cpp:40-51,714-808) against a decode written with Python's zlib."""
+    import struct
+    import zlib
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_file(os.path.join(ROOT, "scenes", "many_point_lights_hip.json"), 64, 64)
+    s = sc.scene
+    assert s.texture_count == 1
+    t = s.textures[0]
+    raw = open(os.path.join(ROOT, "scenes", "textures", "bumpmap.png"), "rb").read()
+    pos, idat, hdr = 8, b"", None
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ctype = hdr[:4]
+    assert (t.width, t.height, t.channels, t.filter) == (w, h, 4, 2) and depth == 8 and ctype == 6  # "trilinear" -> bicubic
+    data = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 4 * w)
+    img = np.zeros((h, w * 4), np.int32)
+    for y in range(h):
+        ft, line = int(data[y, 0]), data[y, 1:].astype(np.int32)
+        up = img[y - 1] if y else np.zeros(w * 4, np.int32)
+        out = img[y]
+        for x in range(w * 4):
+            a = out[x - 4] if x >= 4 else 0
+            b = up[x]
+            c = up[x - 4] if x >= 4 else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) // 2
+            else:
+                q = a + b - c
+                pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[x] = (line[x] + p) & 255
+    img = img.reshape(h, w, 4)[::-1]  # stb's vertical flip
+    v = img[..., :3].astype(np.float32) / np.float32(255)
+    lin = np.where(v <= np.float32(0.04045), v / np.float32(12.92), ((v + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4))
+    want = np.concatenate([np.minimum(255, np.floor(lin * np.float32(255))).astype(np.uint8), img[..., 3:].astype(np.uint8)], axis=-1)
+    got = np.ctypeslib.as_array(s.texture_data, shape=(s.texture_data_size,))[t.offset:t.offset + w * h * 4].reshape(h, w, 4)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff[..., 3].max() == 0
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # powf rounding may move a value across a floor() boundary
