@@ -7,8 +7,10 @@
 A "step" is one render iteration (Runtime::step, src/runtime/Runtime.cpp:334-387) of the workload
 BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path integrator,
 spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region.
-With N > 1 the film is tile-sharded (rank r renders rows r, r+N, ...) and the
-framebuffers are reduced to rank 0 over RCCL once, inside the timed region (strong scaling).
+With N > 1 the camera samples are sharded with no data-path exchange and the framebuffers are
+reduced to rank 0 over RCCL once, inside the timed region. Default partition: whole-film iterations (rank r
+renders iterations r, r+N, ...: per-GPU work stays one full iteration per step, "weak"); `--sharding rows`
+splits every iteration by interleaved film rows instead (rank r renders rows r, r+N, ...: "strong").
 
 Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts
 them (src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the
@@ -38,6 +40,7 @@ def parse():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spi", type=int, default=SPI)
+    ap.add_argument("--sharding", choices=("iterations", "rows"), default="iterations", help="N > 1: how camera samples are split")
     ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
     return ap.parse_args()
 
@@ -82,8 +85,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    by_rows = world > 1 and args.sharding == "rows"
+
     def step(it):
-        dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=world)
+        if by_rows:
+            dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=world)
+        else:
+            dev.render(spi, W, H, iteration=it * world + rank, seed=SEED)  # ignis_amd.sharding.shard_iterations
 
     for it in range(args.warmup):
         step(it)
@@ -132,7 +140,7 @@ def main():
         cdev = Device(local_rank, acquire_stats=2)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
-        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank, row_stride=world)
+        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank if by_rows else 0, row_stride=world if by_rows else 1)
         cs = cdev.stats()
         cdev.close()
         n_primary = cs["camera_rays"] + cs["bounce_rays"]
@@ -182,12 +190,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if by_rows else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps} iterations, seed {SEED}",
-                       "sharding": "whole film" if world == 1 else f"rows interleaved over {world} GPUs + one RCCL reduce"},
+            "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps * (1 if by_rows else world)} iterations, seed {SEED}",
+                       "sharding": "whole film" if world == 1 else (f"film rows interleaved over {world} GPUs + one RCCL reduce" if by_rows else
+                                                                    f"{args.steps} full-film iterations per GPU (iteration i*{world}+rank) + one RCCL reduce")},
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},
             "stage_ms_rank0": stage_ms,

@@ -93,7 +93,9 @@ struct igd_device {
     igd_setup setup{};
     int num_cus = 0;
     hipStream_t stream = nullptr; // wavefront rounds
-    hipStream_t side   = nullptr; // tail + resolve of a chunk, overlapping the next chunk's rounds
+    static constexpr int kMaxFlights = 8;
+    hipStream_t side[kMaxFlights] = {}; // tail + resolve of a chunk, overlapping the rounds of the next chunks
+    int n_flights = 4;                  // IGD_FLIGHTS (2 .. kMaxFlights)
 
     // scene
     bool has_scene = false;
@@ -108,6 +110,7 @@ struct igd_device {
     DevBuf<float> light_hierarchy;
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
+    uint32_t tail_lanes = 0; // lanes of one tail grid (its share of the deep-stack columns)
     DevBuf<uint2> deep_stack; // kDeepStack entries for every lane that can be resident (traversal grid + tail grid)
     DevBuf<uint32_t> light_codes;
     DevScene dscene{};
@@ -119,9 +122,9 @@ struct igd_device {
     DevBuf<uint32_t> deep_rays; // indices of the rays a traversal launch hands to its DEEP launch
     DevBuf<float> list_rays;
 
-    // Two chunks can be in flight: while the side stream finishes chunk k (tail kernel, resolve, counter
-    // read-back) the main stream already runs the rounds of chunk k + 1. Everything a chunk's second half
-    // touches is therefore double-buffered by chunk parity.
+    // Several chunks can be in flight: while side streams finish chunks k - 3 .. k (tail passes, resolve, counter
+    // read-back: a latency chain of ~max_depth dependent bounces, little work) the main stream already runs the
+    // rounds of chunk k + 1. Everything a chunk's second half touches therefore exists once per flight slot.
     struct Flight {
         DevBuf<float> accum;     // per-sample radiance accumulators of the chunk
         DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
@@ -130,12 +133,12 @@ struct igd_device {
         size_t tail_capacity = 0;
         QueueState* qs       = nullptr; // device
         QueueState* host     = nullptr; // pinned read-back of qs once the chunk is complete
-        hipEvent_t rounds_done = nullptr, done = nullptr;
-        bool pending = false;
+        hipEvent_t rounds_done = nullptr, resolved = nullptr, done = nullptr;
+        bool pending = false, used = false;
         std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans; // timers recorded on either stream
-    } flight[2];
+    } flight[kMaxFlights];
     DevBuf<QueueState> qs_store;
-    QueueState* host_store = nullptr; // pinned: [0],[1] per flight, [2] per-round polling
+    QueueState* host_store = nullptr; // pinned: one per flight, [kMaxFlights] per-round polling
     uint64_t chunk_seq     = 0;
     bool async_tail        = true; // IGD_ASYNC_TAIL=0: drain the side stream at the end of every igd_render
 
@@ -164,8 +167,9 @@ struct igd_device {
     {
         if (stream)
             (void)hipStreamSynchronize(stream);
-        if (side)
-            (void)hipStreamSynchronize(side);
+        for (auto sd : side)
+            if (sd)
+                (void)hipStreamSynchronize(sd);
         for (auto e : events)
             (void)hipEventDestroy(e);
         for (auto& f : flight) {
@@ -173,13 +177,16 @@ struct igd_device {
                 (void)hipEventDestroy(f.rounds_done);
             if (f.done)
                 (void)hipEventDestroy(f.done);
+            if (f.resolved)
+                (void)hipEventDestroy(f.resolved);
         }
         if (host_store)
             (void)hipHostFree(host_store);
         if (stream)
             (void)hipStreamDestroy(stream);
-        if (side)
-            (void)hipStreamDestroy(side);
+        for (auto sd : side)
+            if (sd)
+                (void)hipStreamDestroy(sd);
     }
 
     static PrimaryCols colsAt(float* b, size_t c)
@@ -231,9 +238,9 @@ struct igd_device {
         secondary.alloc(capacity * kSecondaryCols);
         deep_rays.release();
         deep_rays.alloc(capacity);
-        for (auto& f : flight) {
-            f.accum.release();
-            f.accum.alloc(capacity * 4);
+        for (int k = 0; k < n_flights; ++k) {
+            flight[k].accum.release();
+            flight[k].accum.alloc(capacity * 4);
         }
     }
 
@@ -383,9 +390,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     {
         const uint32_t trav_lanes = (uint32_t)d->traverseGrid() * 256u;
         const uint32_t tail_lanes = (uint32_t)d->num_cus * (uint32_t)d->tail_waves_per_cu * 64u;
-        d->deep_stack.alloc((size_t)(trav_lanes + tail_lanes) * (size_t)kDeepStack);
+        d->deep_stack.alloc((size_t)(trav_lanes + tail_lanes * (uint32_t)d->n_flights) * (size_t)kDeepStack);
         ds.deep_stack     = d->deep_stack.ptr;
-        ds.deep_stride    = trav_lanes + tail_lanes;
+        ds.deep_stride    = trav_lanes + tail_lanes * (uint32_t)d->n_flights;
+        d->tail_lanes     = tail_lanes;
         ds.deep_tail_base = trav_lanes;
     }
     d->camera               = s->camera;
@@ -408,7 +416,7 @@ void resizeFb(igd_device* d, int w, int h)
 // Polls the queue sizes of the chunk in flight on the main stream (64 bytes, pinned).
 void readQueueState(igd_device* d, const QueueState* dev_qs, QueueState& out)
 {
-    QueueState* slot = d->host_store + 2;
+    QueueState* slot = d->host_store + igd_device::kMaxFlights;
     HIP_CHECK(hipMemcpyAsync(slot, dev_qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
     out = *slot;
@@ -458,9 +466,9 @@ void collect(igd_device* d, igd_device::Flight& f)
 void finish(igd_device* d)
 {
     HipError first{ IGD_OK, "" };
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < d->n_flights; ++k) {
         // oldest chunk first
-        igd_device::Flight& f = d->flight[(d->chunk_seq + (uint64_t)k) & 1];
+        igd_device::Flight& f = d->flight[(d->chunk_seq + (uint64_t)k) % (uint64_t)d->n_flights];
         try {
             collect(d, f);
         } catch (const HipError& e) {
@@ -469,7 +477,8 @@ void finish(igd_device* d)
         }
     }
     HIP_CHECK(hipStreamSynchronize(d->stream));
-    HIP_CHECK(hipStreamSynchronize(d->side));
+    for (int k = 0; k < d->n_flights; ++k)
+        HIP_CHECK(hipStreamSynchronize(d->side[k]));
     d->events_used = 0;
     if (first.code != IGD_OK)
         throw first;
@@ -537,8 +546,11 @@ void render(igd_device* d, const igd_render_settings* rs)
     for (int64_t first = 0; first < total; first += chunk_rays) {
         const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
 
-        // this chunk's flight slot: wait (host side) until the chunk two back has left it
-        igd_device::Flight& fl = d->flight[d->chunk_seq & 1];
+        // this chunk's flight slot: wait (host side) until the chunk n_flights back has left it
+        const int slot         = (int)(d->chunk_seq % (uint64_t)d->n_flights);
+        igd_device::Flight& fl = d->flight[slot];
+        igd_device::Flight& prev = d->flight[(slot + d->n_flights - 1) % d->n_flights];
+        hipStream_t side       = d->side[slot];
         collect(d, fl);
         ++d->chunk_seq;
         QueueState* qs = fl.qs;
@@ -684,15 +696,16 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.frame        = frame;
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
+            tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
             HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
             // one-wave workgroups, 2 waves/SIMD (VGPR bound) = 8 per CU; fewer when the stream is tiny
             tail_grid = std::max(1, std::min(d->num_cus * d->tail_waves_per_cu, (int)((live + 63) / 64)));
         }
         HIP_CHECK(hipEventRecord(fl.rounds_done, st));
-        HIP_CHECK(hipStreamWaitEvent(d->side, fl.rounds_done, 0));
+        HIP_CHECK(hipStreamWaitEvent(side, fl.rounds_done, 0));
         if (run_tail)
-            timed(5, d->side, [&] {
+            timed(5, side, [&] {
                 // pass j reads buffer j & 1 and appends its survivors to the other one; the last pass is unbounded
                 const int depth_left = std::max(1, d->dscene.tech.max_depth);
                 const int passes     = d->tail_split > 0 ? std::min(kMaxTailPasses, (depth_left + d->tail_split - 1) / d->tail_split) : 1;
@@ -706,7 +719,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.work_counter = fl.tail_ctr.ptr + 2 * j + 1;
                     p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
                     p.count_paths  = j == 0;
-                    launch_tail(p, counters, tail_grid, d->side);
+                    launch_tail(p, counters, tail_grid, side);
                 }
             });
 
@@ -719,9 +732,15 @@ void render(igd_device* d, const igd_render_settings* rs)
         ra.row_stride        = row_stride;
         ra.first_local_pixel = first / rs->spi;
         ra.pixels            = n / (uint32_t)rs->spi;
-        timed(4, d->side, [&] { launch_resolve(ra, d->side); });
-        HIP_CHECK(hipMemcpyAsync(fl.host, qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->side));
-        HIP_CHECK(hipEventRecord(fl.done, d->side));
+        // framebuffer updates stay in chunk order (pixels of successive iterations coincide, and the float sum
+        // must not depend on which tail finished first)
+        if (prev.used && &prev != &fl)
+            HIP_CHECK(hipStreamWaitEvent(side, prev.resolved, 0));
+        timed(4, side, [&] { launch_resolve(ra, side); });
+        HIP_CHECK(hipEventRecord(fl.resolved, side));
+        fl.used = true;
+        HIP_CHECK(hipMemcpyAsync(fl.host, qs, sizeof(QueueState), hipMemcpyDeviceToHost, side));
+        HIP_CHECK(hipEventRecord(fl.done, side));
     }
     HIP_CHECK(hipGetLastError());
 
@@ -897,16 +916,21 @@ igd_device* igd_create(const igd_setup* setup)
             // the side stream only has to finish before the next chunk does: lowest priority
             int lo = 0, hi = 0;
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_CHECK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
+            if (const char* e = std::getenv("IGD_FLIGHTS"))
+                d->n_flights = std::min(igd_device::kMaxFlights, std::max(2, std::atoi(e)));
+            for (int k = 0; k < d->n_flights; ++k)
+                HIP_CHECK(hipStreamCreateWithPriority(&d->side[k], hipStreamNonBlocking, lo));
         }
-        d->qs_store.alloc(2);
-        HIP_CHECK(hipMemset(d->qs_store.ptr, 0, 2 * sizeof(QueueState)));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), 3 * sizeof(QueueState), hipHostMallocDefault));
-        std::memset(d->host_store, 0, 3 * sizeof(QueueState));
-        for (int k = 0; k < 2; ++k) {
+        constexpr int F = igd_device::kMaxFlights;
+        d->qs_store.alloc(F);
+        HIP_CHECK(hipMemset(d->qs_store.ptr, 0, F * sizeof(QueueState)));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 1) * sizeof(QueueState), hipHostMallocDefault));
+        std::memset(d->host_store, 0, (F + 1) * sizeof(QueueState));
+        for (int k = 0; k < d->n_flights; ++k) {
             d->flight[k].qs   = d->qs_store.ptr + k;
             d->flight[k].host = d->host_store + k;
             HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].rounds_done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].resolved, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].done, hipEventDisableTiming));
         }
         if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))

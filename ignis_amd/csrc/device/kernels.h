@@ -155,6 +155,7 @@ struct TailArgs {
     PrimaryCols out;
     uint32_t* out_count;
     int32_t count_paths; // add the input size to qs->tail_rays
+    uint32_t deep_lane_base; // first deep-stack column of this launch's lanes
 };
 
 struct ResolveArgs {

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
     const int lane     = tid & 63;
     const DevScene& sc = a.scene;
     const uint32_t n   = *a.in_count;
-    uint2* deep_col    = sc.deep_stack + (sc.deep_tail_base + blockIdx.x * kTailThreads + tid);
+    uint2* deep_col    = sc.deep_stack + (a.deep_lane_base + blockIdx.x * kTailThreads + tid);
 
     uint32_t c_bounce = 0, c_shadow = 0, c_unoccluded = 0;
     uint32_t c_nodes[2] = { 0, 0 }, c_tris[2] = { 0, 0 }, c_leaves[2] = { 0, 0 };

@@ -1,5 +1,10 @@
-"""Film sharding across GPUs: scene replicated, rank r of G renders film rows
-r, r+G, r+2G, ... into a full-size framebuffer; one reduce(SUM) to rank 0 assembles the image.
+"""Sharding across GPUs: scene replicated, no data-path exchange, one reduce(SUM) at the end.
+
+Two partitions of the same unit (camera samples), both exact up to float summation order:
+  * rows:       rank r of G renders film rows r, r+G, r+2G, ... of every iteration (strong scaling of one image)
+  * iterations: rank r renders whole-film iterations r, r+G, r+2G, ... (the per-sample RNG depends on the iteration
+                index, core/random.art:34-43, so the union is the single-device sample set; per-GPU work stays a
+                full iteration however many GPUs take part — the partition to use when the image is small)
 
 Rows are interleaved (not contiguous bands) because scene content concentrates work in a few rows
 (diamond_scene: the diamonds and their caustics). The sum is exact: rows a rank does not own are 0.
@@ -19,6 +24,13 @@ def shard_settings(rank, world):
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
     return rank, world
+
+
+def shard_iterations(rank, world, steps):
+    """Global iteration indices rendered by `rank` when every rank runs `steps` steps."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return [rank + world * i for i in range(steps)]
 
 
 def reduce_framebuffer(fb, dist, dst=0):

@@ -45,6 +45,54 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def _worker_iterations(rank, world, port, out_path, steps):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from ignis_amd import sharding
+    from ignis_amd.tables import LoadedScene
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), W, H)
+    fb = np.zeros((H, W, 3), np.float32)
+    rays = 0
+    for it in sharding.shard_iterations(rank, world, steps):
+        _, st = oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=fb)
+        rays += st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    t = torch.from_numpy(fb)
+    sharding.reduce_framebuffer(t, dist, dst=0)
+    r = torch.tensor([rays], dtype=torch.float64)
+    dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.savez(out_path, fb=t.numpy(), rays=r.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_iteration_sharding_sums_to_the_single_process_image(tmp_path):
+    """bench.py's default N > 1 partition: rank r renders iterations r, r + N, ...; reduce(SUM) = all iterations."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from ignis_amd.tables import LoadedScene
+
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker_iterations, args=(2, _free_port(), out, 2), nprocs=2, join=True)
+    got = np.load(out)
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), W, H)
+    ref = np.zeros((H, W, 3), np.float32)
+    rays = 0
+    for it in range(4):
+        _, st = oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=ref)
+        rays += st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    np.testing.assert_allclose(got["fb"], ref, rtol=2e-5, atol=1e-6)  # (i0 + i2) + (i1 + i3) vs ((i0 + i1) + i2) + i3
+    assert int(got["rays"][0]) == rays
+
+
 def test_two_rank_row_sharding_reassembles_the_image(tmp_path):
     import torch.multiprocessing as mp
 
