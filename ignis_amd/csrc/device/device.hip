@@ -28,7 +28,7 @@ void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int gri
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
-void launch_secondary_end(QueueState* qs, hipStream_t stream);
+void launch_secondary_end(QueueState* qs, int slot, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
@@ -576,7 +576,7 @@ void render(igd_device* d, const igd_render_settings* rs)
         int in_slot = 0;
         GenerateArgs ga{};
         ga.out            = d->primaryCols(in_slot);
-        ga.out_count      = &qs->primary_count[in_slot];
+        ga.out_count      = &qs->q[in_slot].primary;
         ga.qs             = qs;
         ga.cam            = d->camera;
         ga.sx             = sx;
@@ -604,7 +604,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             TraverseArgs ta{};
             ta.scene = d->dscene;
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
-            ta.count        = &qs->primary_count[in_slot];
+            ta.count        = &qs->q[in_slot].primary;
             ta.work_counter = &qs->work_counter[0];
             ta.index_list   = d->deep_rays.ptr;
             ta.index_count  = &qs->deep_count;
@@ -618,9 +618,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.in        = in;
             sa.out       = d->primaryCols(in_slot ^ 1);
             sa.sec       = d->secondaryCols();
-            sa.in_count  = &qs->primary_count[in_slot];
-            sa.out_count = &qs->primary_count[in_slot ^ 1];
-            sa.sec_count = &qs->secondary_count;
+            sa.in_count  = &qs->q[in_slot].primary;
+            sa.out_count = &qs->q[in_slot ^ 1].primary;
             sa.qs        = qs;
             sa.accum     = accum;
             sa.id_base   = first;
@@ -637,7 +636,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.scene = d->dscene;
             tb.rayA = sec.rayA, tb.rayB = sec.rayB, tb.meta = nullptr;
             tb.uniform_flags = IG_RAY_FLAG_SHADOW;
-            tb.count         = &qs->secondary_count;
+            tb.count         = &qs->q[in_slot ^ 1].secondary; // generated by this round's k_shade
             tb.work_counter  = &qs->work_counter[2];
             tb.index_list    = d->deep_rays.ptr;
             tb.index_count   = &qs->deep_count;
@@ -648,7 +647,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.inv_spi = inv;
             timed(3, st, [&] {
                 launch_traverse(tb, true, counters, d->traverseGrid(), &qs->work_counter[3], st);
-                launch_secondary_end(qs, st);
+                launch_secondary_end(qs, in_slot ^ 1, st);
             });
 
             in_slot ^= 1;
@@ -665,7 +664,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 rounds_since_check = 0;
                 if (host_qs.error_flags & 1u)
                     break; // reported by collect()
-                live = host_qs.primary_count[in_slot];
+                live = host_qs.q[in_slot].primary;
                 if (live == 0)
                     break;
                 if (live <= d->tail_threshold) {
@@ -685,10 +684,10 @@ void render(igd_device* d, const igd_render_settings* rs)
             // moved out of the primary stream, which the next chunk overwrites.
             d->ensureTailInput(fl, live);
             const PrimaryCols keep = igd_device::colsAt(fl.tail_in.ptr, fl.tail_capacity);
-            launch_copy_paths(d->primaryCols(in_slot), keep, &qs->primary_count[in_slot], live, st);
+            launch_copy_paths(d->primaryCols(in_slot), keep, &qs->q[in_slot].primary, live, st);
             tl.scene        = d->dscene;
             tl.in           = keep;
-            tl.in_count     = &qs->primary_count[in_slot];
+            tl.in_count     = &qs->q[in_slot].primary;
             tl.work_counter = nullptr; // set per pass
             tl.qs           = qs;
             tl.accum        = accum;
@@ -783,7 +782,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     QueueState* qs = d->flight[0].qs;
     const uint32_t cnt = (uint32_t)n;
     HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
-    HIP_CHECK(hipMemcpyAsync(&qs->primary_count[0], &cnt, 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(&qs->q[0].primary, &cnt, 4, hipMemcpyHostToDevice, st));
 
     TraverseArgs ta{};
     ta.scene         = d->dscene;
@@ -791,7 +790,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     ta.rayB          = reinterpret_cast<const float4*>(in.ptr + n * 4);
     ta.meta          = nullptr;
     ta.uniform_flags = ray_flags;
-    ta.count         = &qs->primary_count[0];
+    ta.count         = &qs->q[0].primary;
     ta.work_counter  = &qs->work_counter[0];
     ta.index_list    = deep_rays.ptr;
     ta.index_count   = &qs->deep_count;

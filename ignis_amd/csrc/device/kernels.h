@@ -68,8 +68,13 @@ struct SecondaryCols {
 // Device-resident queue state: no host round trip per bounce (the reference reads counters back
 // 3x per bounce, mapping_gpu.art:457-465,686-711).
 struct QueueState {
-    uint32_t primary_count[2]; // sizes of the two primary streams
-    uint32_t secondary_count;
+    // q[s].primary: size of primary stream s; q[s].secondary: shadow rays generated together with it. The pair is one
+    // aligned 64-bit word so that k_shade reserves space in both queues with ONE atomic (a counter word sustains only
+    // ~88 atomics/us, and there are 2^16 workgroup windows per 16 M hits).
+    struct Counts {
+        uint32_t primary, secondary;
+    };
+    alignas(8) Counts q[2];
     uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch
     uint32_t deep_count;       // rays of the traversal launch in flight whose stack outgrew LDS (re-traversed by the DEEP launch)
     // ---- from here on: cleared once per igd_render, not per chunk
@@ -131,7 +136,6 @@ struct ShadeArgs {
     SecondaryCols sec;
     const uint32_t* in_count;
     uint32_t* out_count;
-    uint32_t* sec_count;
     QueueState* qs;
     float4* accum;   // per-sample radiance accumulators, (r, g, b, unused)
     int64_t id_base; // local ray id of accum[0]

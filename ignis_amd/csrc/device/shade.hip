@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
 constexpr int kShadeThreads = 256;
 constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry per thread
 
-__global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
+__global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
@@ -184,9 +184,15 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(const ShadeArgs a)
                 s_wave_cnt[1][wave] = (uint32_t)__popcll(ms);
             }
             __syncthreads();
-            if (tid < 2) {
-                const uint32_t total = s_wave_cnt[tid][0] + s_wave_cnt[tid][1] + s_wave_cnt[tid][2] + s_wave_cnt[tid][3];
-                s_base[tid]          = total ? atomicAdd(tid == 0 ? a.out_count : a.sec_count, total) : 0u;
+            if (tid == 0) {
+                // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
+                const uint32_t tb = s_wave_cnt[0][0] + s_wave_cnt[0][1] + s_wave_cnt[0][2] + s_wave_cnt[0][3];
+                const uint32_t ts = s_wave_cnt[1][0] + s_wave_cnt[1][1] + s_wave_cnt[1][2] + s_wave_cnt[1][3];
+                unsigned long long old = 0;
+                if (tb | ts)
+                    old = atomicAdd(reinterpret_cast<unsigned long long*>(a.out_count), (unsigned long long)tb | ((unsigned long long)ts << 32));
+                s_base[0] = (uint32_t)old;
+                s_base[1] = (uint32_t)(old >> 32);
             }
             __syncthreads();
             uint32_t ob = s_base[0], os = s_base[1];
@@ -219,9 +225,9 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const int out_slot = in_slot ^ 1;
-        qs->bounce_rays += qs->primary_count[out_slot];
-        qs->shadow_rays += qs->secondary_count;
-        qs->primary_count[in_slot] = 0; // becomes the append target of the next round
+        qs->bounce_rays += qs->q[out_slot].primary;
+        qs->shadow_rays += qs->q[out_slot].secondary;
+        qs->q[in_slot].primary = 0; // becomes the append target of the next round (its .secondary is already 0)
         qs->work_counter[0]        = 0;
         qs->work_counter[1]        = 0;
         qs->work_counter[2]        = 0;
@@ -231,10 +237,10 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
 }
 
 // Runs after the shadow traversal of a round.
-__global__ void k_secondary_end(QueueState* qs)
+__global__ void k_secondary_end(QueueState* qs, int slot)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        qs->secondary_count = 0;
+        qs->q[slot].secondary = 0;
         qs->work_counter[2] = 0;
         qs->work_counter[3] = 0;
         qs->deep_count      = 0;
@@ -279,7 +285,7 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream)
 }
 
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream) { hipLaunchKernelGGL(k_round_end, dim3(1), dim3(64), 0, stream, qs, in_slot); }
-void launch_secondary_end(QueueState* qs, hipStream_t stream) { hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs); }
+void launch_secondary_end(QueueState* qs, int slot, hipStream_t stream) { hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs, slot); }
 
 // Moves the surviving paths (the columns the tail kernel reads) out of a primary stream.
 __global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols dst, const uint32_t* __restrict__ count)

@@ -13,7 +13,7 @@ constexpr int kRefillIdle = 16;  // refill when at least this many lanes of a wa
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS, bool DEEP>
-__global__ void __launch_bounds__(kBlockThreads) k_traverse(const TraverseArgs a)
+__global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
 

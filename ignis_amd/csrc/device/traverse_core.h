@@ -284,24 +284,28 @@ struct Traverser {
                 ++st_nodes;
             bool pushed           = false;
             const float node_tmax = level ? ltmax : tmax;
-            RayT r; // only the slab terms are used below
-            r.inv_dir = level ? loc.inv_dir : gray.inv_dir;
-            r.inv_org = level ? loc.inv_org : gray.inv_org;
+            const f3 inv = level ? loc.inv_dir : gray.inv_dir;
+            const f3 io  = level ? loc.inv_org : gray.inv_org;
+            // The slab test of the reference takes min / max of the two plane distances per axis
+            // (intersection.art:38-58); which plane is the near one is decided by the sign of inv_dir alone
+            // (fma is monotonic and lo <= hi), so the near / far rows are picked by address instead and six
+            // of the eighteen min / max per child disappear. Results are bit-identical for real children
+            // (empty slots are masked by child == 0).
+            const int ox = inv.x < 0 ? 1 : 0, oy = inv.y < 0 ? 1 : 0, oz = inv.z < 0 ? 1 : 0;
             // two halves of four children keep the live register set small
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float bnd[6][4];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const float4 x = nf[2 * k + h];
-                    bnd[k][0] = x.x, bnd[k][1] = x.y, bnd[k][2] = x.z, bnd[k][3] = x.w;
-                }
+                const float4 nx = nf[2 * ox + h], fx = nf[2 * (1 - ox) + h];
+                const float4 ny = nf[2 * (2 + oy) + h], fy = nf[2 * (3 - oy) + h];
+                const float4 nz = nf[2 * (4 + oz) + h], fz = nf[2 * (5 - oz) + h];
+                const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
+                const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
                 const int4 c4   = nc[h];
                 const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float entry, exit;
-                    slab_test(r, tmin, node_tmax, bnd[0][i], bnd[1][i], bnd[2][i], bnd[3][i], bnd[4][i], bnd[5][i], entry, exit);
+                    const float entry = igm_max(igm_max(igm_fma(inv.x, nb[0][i], io.x), igm_fma(inv.y, nb[1][i], io.y)), igm_max(igm_fma(inv.z, nb[2][i], io.z), tmin));
+                    const float exit  = igm_min(igm_min(igm_fma(inv.x, fb[0][i], io.x), igm_fma(inv.y, fb[1][i], io.y)), igm_min(igm_fma(inv.z, fb[2][i], io.z), node_tmax));
                     const bool hit = (ch[i] != 0) & !(exit < entry);
                     if (hit) {
                         // push (becomes the top) if nearer than the current top, else push_after
