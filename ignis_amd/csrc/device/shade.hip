@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
     __shared__ uint16_t s_perm[kShadeThreads];
     __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
     __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_bin[8], s_binoff[8]; // bounce rays of a window are written grouped by direction octant
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -143,6 +144,8 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             __syncthreads();
         }
 
+        if (tid < 8)
+            s_bin[tid] = 0; // (ordered against its use below by the barriers of the sort / of the previous append)
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
         int ray_id = 0;
@@ -176,17 +179,29 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
         // ---- append survivors / shadow rays: ONE atomic per workgroup and queue (replaces K9). A single
         // counter word sustains only ~88 atomics/us, so per-wave appends would serialise the kernel.
         {
-            const unsigned long long mb = __ballot(out.bounce);
+            // Continuation rays leave grouped by the octant of their direction: rays of one octant visit BVH children
+            // in the same order, so the next round's traversal waves diverge less. (Order inside the stream is free:
+            // nothing downstream depends on it.)
             const unsigned long long ms = __ballot(out.shadow);
             const int wave              = tid >> 6;
-            if (lane == 0) {
-                s_wave_cnt[0][wave] = (uint32_t)__popcll(mb);
+            if (lane == 0)
                 s_wave_cnt[1][wave] = (uint32_t)__popcll(ms);
+            int bkey       = 0;
+            uint32_t brank = 0;
+            if (!do_sort)
+                __syncthreads(); // s_bin was cleared above without a barrier in between
+            if (out.bounce) {
+                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0);
+                brank = atomicAdd(&s_bin[bkey], 1u);
             }
             __syncthreads();
             if (tid == 0) {
                 // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
-                const uint32_t tb = s_wave_cnt[0][0] + s_wave_cnt[0][1] + s_wave_cnt[0][2] + s_wave_cnt[0][3];
+                uint32_t tb = 0;
+                for (int k = 0; k < 8; ++k) {
+                    s_binoff[k] = tb;
+                    tb += s_bin[k];
+                }
                 const uint32_t ts = s_wave_cnt[1][0] + s_wave_cnt[1][1] + s_wave_cnt[1][2] + s_wave_cnt[1][3];
                 unsigned long long old = 0;
                 if (tb | ts)
@@ -195,13 +210,11 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
                 s_base[1] = (uint32_t)(old >> 32);
             }
             __syncthreads();
-            uint32_t ob = s_base[0], os = s_base[1];
-            for (int w = 0; w < wave; ++w) {
-                ob += s_wave_cnt[0][w];
+            uint32_t os = s_base[1];
+            for (int w = 0; w < wave; ++w)
                 os += s_wave_cnt[1][w];
-            }
             if (out.bounce) {
-                const uint32_t o = ob + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
                 a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, kRayOffset);
                 a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
                 a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
