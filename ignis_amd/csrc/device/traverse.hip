@@ -23,11 +23,12 @@ __global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArg
     const uint32_t count = *a.count;
     if (DEEP && count == 0)
         return; // the usual case: no ray of the first launch needed the deep stack
-    // batch size: large enough to keep the shared counter cold, small enough that every wave gets work
+    // Guided self-scheduling: a wave asks for (what it believes is left) / (4 x waves) rays, between 64 and
+    // kMaxRayBatch. Large batches keep the shared counter cold while the stream is long; towards its end the
+    // batches shrink to one wave's worth, so the launch does not end with a few waves chewing on 1024 rays
+    // each while the rest of the chip idles.
     const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
-    uint32_t kRayBatch         = count / (total_waves * 4u);
-    kRayBatch                  = kRayBatch < 64u ? 64u : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
-    kRayBatch &= ~63u;
+    uint32_t last_base         = 0; // where the previous reservation of this wave started
 
     Traverser<ANY_HIT, STATS, kBlockThreads, DEEP> tr;
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
@@ -48,10 +49,15 @@ __global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArg
         const int n_idle              = __popcll(idle);
         if (n_idle >= kRefillIdle && !(exhausted && batch_next >= batch_end)) {
             if (batch_next >= batch_end) {
+                const uint32_t left = count > last_base ? count - last_base : 0u;
+                uint32_t kRayBatch  = left / (total_waves * 4u);
+                kRayBatch           = kRayBatch < 64u ? 64u : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
+                kRayBatch &= ~63u;
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(a.work_counter, (uint32_t)kRayBatch);
                 base       = __shfl(base, 0);
+                last_base  = base;
                 batch_next = base < count ? base : count;
                 batch_end  = base + kRayBatch < count ? base + kRayBatch : count;
                 if (base + kRayBatch >= count)
