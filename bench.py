@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timers", action="store_true", help="experiments only: no HIP-event stage timers in the timed loop (roofline.achieved becomes 0)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spi", type=int, default=SPI)
@@ -76,7 +77,7 @@ def main():
 
     W, H, spi = args.width, args.height, args.spi
     scene = LoadedScene.from_file(args.scene, W, H)
-    dev = Device(local_rank, acquire_stats=1)
+    dev = Device(local_rank, acquire_stats=0 if args.no_stage_timers else 1)
     dev.assign_scene(scene)
     dev.resize(W, H)
 

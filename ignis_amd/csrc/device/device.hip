@@ -130,6 +130,8 @@ struct igd_device {
         DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
         DevBuf<float> tail_long; // those still alive after a pass (the two buffers alternate)
         DevBuf<uint32_t> tail_ctr; // per pass: [2 * j] output count, [2 * j + 1] fetch counter
+        DevBuf<float> side_secondary;     // shadow rays of the wavefront rounds that run on the side stream
+        DevBuf<uint32_t> side_deep_rays;
         size_t tail_capacity = 0;
         QueueState* qs       = nullptr; // device
         QueueState* host     = nullptr; // pinned read-back of qs once the chunk is complete
@@ -157,6 +159,11 @@ struct igd_device {
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     int tail_split = 6;
+    // Wavefront rounds that continue on the side stream before the per-lane tail takes over: -1 = as many as it
+    // takes to get from the hand-over size to ~8 K paths at the usual survival rate, 0 = none (default: measured
+    // 3 % to 10 % slower than handing over directly, the small launches disturb the main stream more than the
+    // per-lane passes do). IGD_SIDE_ROUNDS.
+    int side_rounds = 0;
 
     // statistics
     igd_stats stats{};
@@ -241,6 +248,24 @@ struct igd_device {
         for (int k = 0; k < n_flights; ++k) {
             flight[k].accum.release();
             flight[k].accum.alloc(capacity * 4);
+        }
+    }
+
+    static SecondaryCols secAt(float* b, size_t c)
+    {
+        SecondaryCols q;
+        q.rayA = reinterpret_cast<float4*>(b + 0 * c);
+        q.rayB = reinterpret_cast<float4*>(b + 4 * c);
+        q.col  = reinterpret_cast<float4*>(b + 8 * c);
+        return q;
+    }
+    void ensureSideStreams(Flight& f)
+    {
+        if (f.side_secondary.count < f.tail_capacity * kSecondaryCols) {
+            f.side_secondary.release();
+            f.side_secondary.alloc(f.tail_capacity * kSecondaryCols);
+            f.side_deep_rays.release();
+            f.side_deep_rays.alloc(f.tail_capacity);
         }
     }
 
@@ -598,26 +623,31 @@ void render(igd_device* d, const igd_render_settings* rs)
         uint32_t live          = n;
         int rounds_since_check = 0;
         bool run_tail          = false;
-        for (int round = 0;; ++round) {
-            // ---- closest-hit traversal of the primary stream (K2)
-            const PrimaryCols in = d->primaryCols(in_slot);
+        // One bounce round on stream `on` over the given stream buffers: closest-hit traversal (K2) -> sort +
+        // shade + compact (K3, K4, K5, K9) -> any-hit traversal of the shadow rays + splat (K6).
+        struct RoundBufs {
+            PrimaryCols prim[2];
+            SecondaryCols sec;
+            uint32_t* deep_rays;
+        };
+        auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid) {
+            const PrimaryCols in = b.prim[in_slot];
             TraverseArgs ta{};
             ta.scene = d->dscene;
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
             ta.count        = &qs->q[in_slot].primary;
             ta.work_counter = &qs->work_counter[0];
-            ta.index_list   = d->deep_rays.ptr;
+            ta.index_list   = b.deep_rays;
             ta.index_count  = &qs->deep_count;
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
-            timed(1, st, [&] { launch_traverse(ta, false, counters, d->traverseGrid(), &qs->work_counter[1], st); });
+            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on); });
 
-            // ---- sort + shade + compact (K3, K4, K5, K9)
             ShadeArgs sa{};
             sa.scene     = d->dscene;
             sa.in        = in;
-            sa.out       = d->primaryCols(in_slot ^ 1);
-            sa.sec       = d->secondaryCols();
+            sa.out       = b.prim[in_slot ^ 1];
+            sa.sec       = b.sec;
             sa.in_count  = &qs->q[in_slot].primary;
             sa.out_count = &qs->q[in_slot ^ 1].primary;
             sa.qs        = qs;
@@ -625,35 +655,37 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.id_base   = first;
             sa.frame     = frame;
             sa.inv_spi   = inv;
-            timed(2, st, [&] {
-                launch_shade(sa, d->shadeGrid(), st);
-                launch_round_end(qs, in_slot, st);
+            timed(2, on, [&] {
+                launch_shade(sa, shade_grid, on);
+                launch_round_end(qs, in_slot, on);
             });
 
-            // ---- any-hit traversal of the shadow rays + splat (K6)
-            const SecondaryCols sec = d->secondaryCols();
             TraverseArgs tb{};
             tb.scene = d->dscene;
-            tb.rayA = sec.rayA, tb.rayB = sec.rayB, tb.meta = nullptr;
+            tb.rayA = b.sec.rayA, tb.rayB = b.sec.rayB, tb.meta = nullptr;
             tb.uniform_flags = IG_RAY_FLAG_SHADOW;
             tb.count         = &qs->q[in_slot ^ 1].secondary; // generated by this round's k_shade
             tb.work_counter  = &qs->work_counter[2];
-            tb.index_list    = d->deep_rays.ptr;
+            tb.index_list    = b.deep_rays;
             tb.index_count   = &qs->deep_count;
             tb.qs            = qs;
-            tb.col     = sec.col;
+            tb.col     = b.sec.col;
             tb.accum   = accum;
             tb.id_base = first;
             tb.inv_spi = inv;
-            timed(3, st, [&] {
-                launch_traverse(tb, true, counters, d->traverseGrid(), &qs->work_counter[3], st);
-                launch_secondary_end(qs, in_slot ^ 1, st);
+            timed(3, on, [&] {
+                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on);
+                launch_secondary_end(qs, in_slot ^ 1, on);
             });
-
-            in_slot ^= 1;
             d->stats.rounds++;
             d->stats.traverse_primary_launches++;
             d->stats.traverse_secondary_launches++;
+        };
+
+        const RoundBufs main_bufs{ { d->primaryCols(0), d->primaryCols(1) }, d->secondaryCols(), d->deep_rays.ptr };
+        for (int round = 0;; ++round) {
+            launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid());
+            in_slot ^= 1;
 
             // The host only needs to know when the stream ran dry; look at the counter after every
             // round while rounds are long, every 4th once they are short.
@@ -678,15 +710,19 @@ void render(igd_device* d, const igd_render_settings* rs)
 
         // ---- second half of the chunk, on the side stream: the next chunk's rounds start meanwhile
         TailArgs tl{};
-        int tail_grid = 0;
+        int tail_grid = 0, tail_in_first = 0;
+        (void)tail_in_first;
         if (run_tail) {
             // few paths left: follow each to its end in one launch instead of ~50 more rounds. Its input is
             // moved out of the primary stream, which the next chunk overwrites.
             d->ensureTailInput(fl, live);
-            const PrimaryCols keep = igd_device::colsAt(fl.tail_in.ptr, fl.tail_capacity);
+            // the two tail buffers double as the primary streams of the side rounds: slot in_slot receives the paths
+            const PrimaryCols side_prim[2] = { igd_device::colsAt(in_slot == 0 ? fl.tail_in.ptr : fl.tail_long.ptr, fl.tail_capacity),
+                                               igd_device::colsAt(in_slot == 0 ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity) };
+            const PrimaryCols keep = side_prim[in_slot];
             launch_copy_paths(d->primaryCols(in_slot), keep, &qs->q[in_slot].primary, live, st);
             tl.scene        = d->dscene;
-            tl.in           = keep;
+            tl.in           = keep; // (replaced below when side rounds run first)
             tl.in_count     = &qs->q[in_slot].primary;
             tl.work_counter = nullptr; // set per pass
             tl.qs           = qs;
@@ -703,12 +739,39 @@ void render(igd_device* d, const igd_render_settings* rs)
         }
         HIP_CHECK(hipEventRecord(fl.rounds_done, st));
         HIP_CHECK(hipStreamWaitEvent(side, fl.rounds_done, 0));
+        if (run_tail && d->side_rounds != 0) {
+            // Wavefront rounds continue on the side stream (compacted, sorted: the efficient way to advance half a
+            // million paths) while the main stream starts the next chunk; only what is left after them goes to the
+            // per-lane tail. The stream decays geometrically, so the number of rounds is fixed up front.
+            int rounds = d->side_rounds;
+            if (rounds < 0) {
+                const double target = 8192.0, survive = 0.85;
+                rounds = live > target ? (int)std::ceil(std::log((double)live / target) / std::log(1.0 / survive)) : 0;
+            }
+            rounds = std::max(0, std::min(rounds, std::min(40, d->dscene.tech.max_depth + 2)));
+            d->ensureSideStreams(fl);
+            RoundBufs sb;
+            sb.prim[0]   = igd_device::colsAt(in_slot == 0 ? fl.tail_in.ptr : fl.tail_long.ptr, fl.tail_capacity);
+            sb.prim[1]   = igd_device::colsAt(in_slot == 0 ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity);
+            sb.sec       = igd_device::secAt(fl.side_secondary.ptr, fl.tail_capacity);
+            sb.deep_rays = fl.side_deep_rays.ptr;
+            const int tg = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
+            const int sg = std::max(1, std::min(d->shadeGrid(), (int)((live + 255) / 256)));
+            for (int r = 0; r < rounds; ++r) {
+                launchRound(side, sb, in_slot, tg, sg);
+                in_slot ^= 1;
+            }
+            tl.in       = sb.prim[in_slot];
+            tl.in_count = &qs->q[in_slot].primary;
+            tail_in_first = in_slot;
+        }
         if (run_tail)
             timed(5, side, [&] {
                 // pass j reads buffer j & 1 and appends its survivors to the other one; the last pass is unbounded
                 const int depth_left = std::max(1, d->dscene.tech.max_depth);
                 const int passes     = d->tail_split > 0 ? std::min(kMaxTailPasses, (depth_left + d->tail_split - 1) / d->tail_split) : 1;
-                const PrimaryCols buf[2] = { tl.in, igd_device::colsAt(fl.tail_long.ptr, fl.tail_capacity) };
+                const PrimaryCols other  = igd_device::colsAt(tl.in.rayA == reinterpret_cast<float4*>(fl.tail_in.ptr) ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity);
+                const PrimaryCols buf[2] = { tl.in, other };
                 for (int j = 0; j < passes; ++j) {
                     TailArgs p     = tl;
                     p.in           = buf[j & 1];
@@ -936,6 +999,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_WAVES"))
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("IGD_SIDE_ROUNDS"))
+            d->side_rounds = std::atoi(e);
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("IGD_ASYNC_TAIL"))
@@ -1005,6 +1070,8 @@ int32_t igd_release_all(igd_device* dev)
             f.accum.release();
             f.tail_in.release();
             f.tail_long.release();
+            f.side_secondary.release();
+            f.side_deep_rays.release();
             f.tail_capacity = 0;
         }
         dev->list_rays.release();
