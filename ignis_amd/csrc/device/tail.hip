@@ -23,7 +23,7 @@ namespace igdev {
 constexpr int kTailThreads = 64;
 
 template <bool STATS>
-__global__ void __launch_bounds__(kTailThreads) k_tail(const TailArgs a)
+__global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
 {
     __shared__ StackOf<kTailThreads> s_stack;
 
