@@ -106,6 +106,7 @@ struct igd_device {
     DevBuf<uint64_t> shape_offsets;
     DevBuf<ig_material> materials;
     DevBuf<int32_t> entity_material;
+    DevBuf<uint4> entity_ext;
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy;
     DevBuf<ig_texture> textures;
@@ -389,6 +390,25 @@ void assignScene(igd_device* d, const igd_scene* s)
     }
     d->entity_material.upload(em.data(), em.size());
 
+    // where each entity's shape keeps its arrays (see DevScene::entity_ext)
+    std::vector<uint4> ext4(s->entity_count);
+    for (uint32_t e = 0; e < s->entity_count; ++e) {
+        uint32_t shape_id;
+        std::memcpy(&shape_id, s->entities + (size_t)e * IG_ENTITY_FLOATS + 33, 4);
+        if (shape_id >= s->shape_count)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: entity shape id out of range" };
+        const uint64_t base = s->shape_lookups[shape_id].offset;
+        if (base + 48 > s->shape_data_size)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape offset out of range" };
+        int32_t hdr[4]; // faces, vertices, normals, texcoords
+        std::memcpy(hdr, s->shape_data + base, 16);
+        const uint64_t verts = base + 48, norms = verts + (uint64_t)hdr[1] * 16, inds = norms + (uint64_t)hdr[2] * 16, texs = inds + (uint64_t)hdr[0] * 16;
+        if (texs + (uint64_t)hdr[3] * 8 > s->shape_data_size || texs >= ((uint64_t)1 << 32))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape table is truncated or exceeds 4 GiB" };
+        ext4[e] = make_uint4((uint32_t)verts, (uint32_t)norms, (uint32_t)inds, (uint32_t)texs);
+    }
+    d->entity_ext.upload(ext4.data(), ext4.size());
+
     DevScene& ds            = d->dscene;
     ds.geom                 = d->geom.ptr;
     ds.scene_nodes_off      = scene_nodes_off;
@@ -400,6 +420,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.shape_offsets        = d->shape_offsets.ptr;
     ds.materials            = d->materials.ptr;
     ds.entity_material      = d->entity_material.ptr;
+    ds.entity_ext           = d->entity_ext.ptr;
     ds.lights               = d->lights.ptr;
     ds.entity_count         = s->entity_count;
     ds.material_count       = s->material_count;
@@ -1084,6 +1105,7 @@ int32_t igd_release_all(igd_device* dev)
         dev->shape_offsets.release();
         dev->materials.release();
         dev->entity_material.release();
+        dev->entity_ext.release();
         dev->lights.release();
         dev->light_hierarchy.release();
         dev->light_codes.release();

@@ -32,6 +32,9 @@ struct DevScene {
     const uint32_t* light_codes;
     uint32_t use_hierarchy;
     float scene_radius;
+    // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
+    // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)
+    const uint4* entity_ext;
     // bitmap textures (ig_material.tex_id)
     const ig_texture* textures;
     const uint8_t* texture_data;

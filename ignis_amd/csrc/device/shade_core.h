@@ -101,16 +101,14 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
     m33 nmat;
     nmat.c0 = f3{ r6.x, r6.y, r6.z }, nmat.c1 = f3{ r6.w, r7.x, r7.y }, nmat.c2 = f3{ r7.z, r7.w, r8.x };
-    const int shape_id = (int)igm_bits(r8.y);
-
-    const uint8_t* base = sc.shape_data + sc.shape_offsets[shape_id];
-    const int4 hdr      = *reinterpret_cast<const int4*>(base); // faces, vertices, normals, texcoords
-    const float* f      = reinterpret_cast<const float*>(base);
-    const float* verts  = f + 12;
-    const float* norms  = verts + hdr.y * 4;
-    const float* inds   = norms + hdr.z * 4;
-    const int4 tri      = *reinterpret_cast<const int4*>(inds + prim_id * 4);
-    const float* texs   = inds + hdr.x * 4;
+    // shape arrays (header {faces, vertices, normals, texcoords}, then vertices, normals, indices, texcoords:
+    // TriMeshProvider.cpp:575-596) through the offsets igd_assign_scene precomputed per entity
+    const uint4 ext    = sc.entity_ext[ent_id];
+    const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
+    const float* norms = reinterpret_cast<const float*>(sc.shape_data + ext.y);
+    const float* inds  = reinterpret_cast<const float*>(sc.shape_data + ext.z);
+    const float* texs  = reinterpret_cast<const float*>(sc.shape_data + ext.w);
+    const int4 tri     = *reinterpret_cast<const int4*>(inds + prim_id * 4);
 
     const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4));
     const f3 v1 = xform_point(global, ld3v(verts + tri.y * 4));
