@@ -19,6 +19,7 @@
 #include "json.h"
 #include "mesh.h"
 #include "png.h"
+#include "exr.h"
 
 #include <cstring>
 #include <fstream>
@@ -1175,6 +1176,23 @@ const char* igh_material_name(const igh_scene* scene, uint32_t id)
 }
 
 void igh_free(igh_scene* scene) { delete scene; }
+
+int32_t igh_save_exr(const char* path, const float* rgb, int32_t width, int32_t height, float scale, const char* const* meta)
+{
+    g_last_error.clear();
+    try {
+        if (!path)
+            throw std::runtime_error("igh_save_exr: path is NULL");
+        std::vector<std::pair<std::string, std::string>> attrs;
+        for (const char* const* m = meta; m && m[0] && m[1]; m += 2)
+            attrs.emplace_back(m[0], m[1]);
+        igh::writeExr(path, rgb, width, height, scale, attrs);
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
 
 const char* igh_last_error(void) { return g_last_error.c_str(); }
 

@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from .device import Device
-from .tables import LoadedScene
+from .tables import LoadedScene, save_exr
 
 
 class RuntimeOptions:
@@ -165,6 +165,21 @@ class Runtime:
         return CameraOrientation(g.get("__camera_eye", (0, 0, 0)), g.get("__camera_dir", (0, 0, 1)), g.get("__camera_up", (0, 1, 0)))
 
     InitialCameraOrientation = property(lambda self: self._initial_orientation)
+
+    # -- Runtime::saveFramebuffer (Runtime.cpp:794-876): mean over the iterations so far, channels B, G, R
+    def saveFramebuffer(self, path):
+        fb = self._device.framebuffer()
+        if self._opts.IsTracer:
+            fb = fb.reshape(1, -1, 3)
+        o = self.getCameraOrientation() if "__camera_eye" in self.VectorParameters else self._initial_orientation
+        meta = {"igTechniqueType": self.Technique, "igCameraType": self.Camera, "igSeed": self.Seed, "igSPP": self._samples,
+                "igSPI": self._spi, "igIteration": self._iteration, "igFrame": self._frame, "igTargetString": "MI355X (gfx950, HIP)",
+                "igCameraEye": o.Eye, "igCameraUp": o.Up, "igCameraDir": o.Dir}
+        try:
+            save_exr(path, fb, 1.0 / self._iteration if self._iteration > 0 else 1.0, meta)
+            return True
+        except RuntimeError:
+            return False
 
     def incFrameCount(self):
         self._frame += 1

@@ -107,9 +107,26 @@ def host_lib():
         lib.igh_material_name.argtypes = [C.c_void_p, C.c_uint32]
         lib.igh_free.restype = None
         lib.igh_free.argtypes = [C.c_void_p]
+        lib.igh_save_exr.restype = C.c_int32
+        lib.igh_save_exr.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_char_p)]
         lib.igh_last_error.restype = C.c_char_p
         _host = lib
     return _host
+
+
+def save_exr(path, rgb, scale=1.0, meta=None):
+    """Image::save for the framebuffer (igh_save_exr): float32 [H, W, 3] -> OpenEXR with channels B, G, R."""
+    import numpy as np
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected an [H, W, 3] image")
+    items = []
+    for k, v in (meta or {}).items():
+        items += [str(k).encode(), str(v).encode()]
+    arr = (C.c_char_p * (len(items) + 1))(*items, None)
+    rc = host_lib().igh_save_exr(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0], float(scale), arr)
+    if rc != 0:
+        raise RuntimeError(host_lib().igh_last_error().decode())
 
 
 class LoadedScene:

@@ -44,6 +44,12 @@ const char* igh_material_name(const igh_scene* scene, uint32_t material_id);
 void igh_free(igh_scene* scene);
 
 /* Thread-local message of the last failed igh_* call ("" if none). */
+/* Runtime::saveFramebuffer (src/runtime/Runtime.cpp:794-876): writes `rgb` (float[height][width][3], the device's
+ * accumulated framebuffer) times `scale` (1 / iterations) as an OpenEXR file with float channels B, G, R.
+ * `meta` is an optional NULL-terminated list of key, value string pairs stored as header attributes (the reference's
+ * ImageMetaData). Returns 0 on success. */
+int32_t igh_save_exr(const char* path, const float* rgb, int32_t width, int32_t height, float scale, const char* const* meta);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

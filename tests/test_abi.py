@@ -152,3 +152,60 @@ def test_loader_bitmap_texture_matches_an_independent_png_decode():
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff[..., 3].max() == 0
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # powf rounding may move a value across a floor() boundary
+
+
+def _read_exr(path):
+    """Independent reader for the subset igh_save_exr writes: single-part scanline, uncompressed, float channels."""
+    import struct
+    import numpy as np
+    d = open(path, "rb").read()
+    magic, version = struct.unpack_from("<ii", d, 0)
+    assert magic == 20000630 and version == 2
+    pos, attrs = 8, {}
+    while d[pos] != 0:
+        e = d.index(b"\0", pos)
+        name = d[pos:e].decode()
+        pos = e + 1
+        e = d.index(b"\0", pos)
+        typ = d[pos:e].decode()
+        pos = e + 1
+        size, = struct.unpack_from("<i", d, pos)
+        pos += 4
+        attrs[name] = (typ, d[pos:pos + size])
+        pos += size
+    pos += 1
+    chans, cp = [], 0
+    cl = attrs["channels"][1]
+    while cl[cp] != 0:
+        e = cl.index(b"\0", cp)
+        chans.append((cl[cp:e].decode(), struct.unpack_from("<i", cl, e + 1)[0]))
+        cp = e + 1 + 16
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    offsets = struct.unpack_from(f"<{h}Q", d, pos)
+    planes = {c: np.zeros((h, w), np.float32) for c, _ in chans}
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", d, off)
+        assert size == w * 4 * len(chans)
+        row = np.frombuffer(d, np.float32, w * len(chans), off + 8).reshape(len(chans), w)
+        for k, (c, t) in enumerate(chans):
+            assert t == 2  # FLOAT
+            planes[c][y - y0] = row[k]
+    return planes, attrs
+
+
+def test_exr_writer_round_trip(tmp_path):
+    """Runtime::saveFramebuffer's file (Runtime.cpp:794-876): channels B, G, R, float, scaled by 1 / iterations."""
+    import numpy as np
+    from ignis_amd.tables import save_exr
+    img = np.random.default_rng(1).random((5, 7, 3), dtype=np.float32)
+    p = str(tmp_path / "t.exr")
+    save_exr(p, img, 0.5, {"igSeed": 3, "igTechniqueType": "path"})
+    planes, attrs = _read_exr(p)
+    assert sorted(planes) == ["B", "G", "R"]
+    for k, c in enumerate("RGB"):
+        np.testing.assert_array_equal(planes[c], img[..., k] * np.float32(0.5))
+    assert attrs["igSeed"] == ("string", b"3") and attrs["igTechniqueType"][1] == b"path"
+    with pytest.raises(RuntimeError):
+        save_exr("/nonexistent_dir/x.exr", img)

@@ -401,3 +401,25 @@ def test_registry_parameters_camera_and_technique(gpu_device):
         rt.step()
         np.testing.assert_array_equal(rt.getFramebufferForHost(), ref)
         assert rt.getCameraOrientation().Eye == o.Eye and rt.IntParameters["__tech_max_depth"] == 5
+
+
+def test_cli_renders_and_saves_the_mean_image(tmp_path, capsys):
+    """igcli counterpart (src/frontend/cli/main.cpp:60-185): N iterations, EXR = framebuffer / iterations."""
+    import oracle
+    from ignis_amd import cli
+    from ignis_amd.tables import LoadedScene
+    from test_abi import _read_exr
+    out = str(tmp_path / "out.exr")
+    rc = cli.main([os.path.join(SCENES, "diamond_scene.json"), "--spp", "8", "--spi", "4", "--width", "64", "--height", "48",
+                   "--seed", "5", "-o", out, "--full-stats"])
+    assert rc == 0
+    text = capsys.readouterr().out
+    assert "min/med/max Msamples/s" in text and "SPP: 8" in text and "Iterations: 2" in text
+    planes, attrs = _read_exr(out)
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 64, 48)
+    ref = np.zeros((48, 64, 3), np.float32)
+    for it in range(2):
+        oracle.render(scene, 4, 64, 48, iteration=it, seed=5, fb=ref)
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    assert _rel_l2(got, ref * np.float32(0.5)) <= RADIANCE_TOL
+    assert attrs["igSPP"][1] == b"8"
