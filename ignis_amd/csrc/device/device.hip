@@ -141,7 +141,8 @@ struct igd_device {
         std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans; // timers recorded on either stream
     } flight[kMaxFlights];
     DevBuf<QueueState> qs_store;
-    QueueState* host_store = nullptr; // pinned: one per flight, [kMaxFlights] per-round polling
+    QueueState* host_store = nullptr; // pinned: one per flight, [kMaxFlights], [kMaxFlights + 1] per-round polling
+    hipEvent_t poll_event[2] = {};
     uint64_t chunk_seq     = 0;
     bool async_tail        = true; // IGD_ASYNC_TAIL=0: drain the side stream at the end of every igd_render
 
@@ -180,6 +181,9 @@ struct igd_device {
                 (void)hipStreamSynchronize(sd);
         for (auto e : events)
             (void)hipEventDestroy(e);
+        for (auto e : poll_event)
+            if (e)
+                (void)hipEventDestroy(e);
         for (auto& f : flight) {
             if (f.rounds_done)
                 (void)hipEventDestroy(f.rounds_done);
@@ -462,7 +466,7 @@ void resizeFb(igd_device* d, int w, int h)
 // Polls the queue sizes of the chunk in flight on the main stream (64 bytes, pinned).
 void readQueueState(igd_device* d, const QueueState* dev_qs, QueueState& out)
 {
-    QueueState* slot = d->host_store + igd_device::kMaxFlights;
+    QueueState* slot = d->host_store + igd_device::kMaxFlights + 2;
     HIP_CHECK(hipMemcpyAsync(slot, dev_qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
     out = *slot;
@@ -587,8 +591,6 @@ void render(igd_device* d, const igd_render_settings* rs)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
 
     d->fb_host_dirty = true;
-    QueueState host_qs;
-
     for (int64_t first = 0; first < total; first += chunk_rays) {
         const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
 
@@ -642,7 +644,6 @@ void render(igd_device* d, const igd_render_settings* rs)
 
         const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
         uint32_t live          = n;
-        int rounds_since_check = 0;
         bool run_tail          = false;
         // One bounce round on stream `on` over the given stream buffers: closest-hit traversal (K2) -> sort +
         // shade + compact (K3, K4, K5, K9) -> any-hit traversal of the shadow rays + splat (K6).
@@ -704,27 +705,35 @@ void render(igd_device* d, const igd_render_settings* rs)
         };
 
         const RoundBufs main_bufs{ { d->primaryCols(0), d->primaryCols(1) }, d->secondaryCols(), d->deep_rays.ptr };
+        // The host runs one round ahead of what it knows: the queue sizes after round r are copied back
+        // asynchronously and looked at only after round r + 1 has been submitted, so the stream never drains while
+        // the host waits. The hand-over decision therefore uses the size one round old — an upper bound of the
+        // current one (a stream never grows), which is all the tail's buffers and grid need. A round submitted
+        // on an already empty stream costs a few empty launches.
+        uint32_t known_live = n; // upper bound of the stream size after the last submitted round
         for (int round = 0;; ++round) {
+            if (known_live == 0)
+                break;
+            if (known_live <= d->tail_threshold) {
+                live     = known_live;
+                run_tail = true;
+                break;
+            }
             launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid());
             in_slot ^= 1;
-
-            // The host only needs to know when the stream ran dry; look at the counter after every
-            // round while rounds are long, every 4th once they are short.
-            ++rounds_since_check;
-            const int interval = (d->tail_threshold > 0 || live > 262144u) ? 1 : 4;
-            if (rounds_since_check >= interval) {
-                readQueueState(d, qs, host_qs);
-                rounds_since_check = 0;
-                if (host_qs.error_flags & 1u)
+            // size after this round -> pinned slot (round & 1)
+            QueueState* pin = d->host_store + igd_device::kMaxFlights + (round & 1);
+            HIP_CHECK(hipMemcpyAsync(pin, qs, sizeof(QueueState), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipEventRecord(d->poll_event[round & 1], st));
+            if (round >= 1) {
+                const int r = round - 1;
+                HIP_CHECK(hipEventSynchronize(d->poll_event[r & 1]));
+                const QueueState& hq = d->host_store[igd_device::kMaxFlights + (r & 1)];
+                if (hq.error_flags & 1u)
                     break; // reported by collect()
-                live = host_qs.q[in_slot].primary;
-                if (live == 0)
-                    break;
-                if (live <= d->tail_threshold) {
-                    run_tail = true;
-                    break;
-                }
+                known_live = hq.q[(r & 1) ^ 1].primary; // in_slot after round r (starts at 0, flips every round)
             }
+            live = known_live;
             if (round > d->dscene.tech.max_depth + 8)
                 throw HipError{ IGD_ERR_DEVICE, "igd_render: wavefront loop did not terminate" };
         }
@@ -1007,8 +1016,10 @@ igd_device* igd_create(const igd_setup* setup)
         constexpr int F = igd_device::kMaxFlights;
         d->qs_store.alloc(F);
         HIP_CHECK(hipMemset(d->qs_store.ptr, 0, F * sizeof(QueueState)));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 1) * sizeof(QueueState), hipHostMallocDefault));
-        std::memset(d->host_store, 0, (F + 1) * sizeof(QueueState));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 3) * sizeof(QueueState), hipHostMallocDefault));
+        std::memset(d->host_store, 0, (F + 3) * sizeof(QueueState));
+        for (auto& e : d->poll_event)
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (int k = 0; k < d->n_flights; ++k) {
             d->flight[k].qs   = d->qs_store.ptr + k;
             d->flight[k].host = d->host_store + k;
