@@ -324,7 +324,7 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
         const float depth  = elem.getNumber("depth", 2.0f);
         const V3 origin    = elem.has("origin") ? getVector3(*elem.find("origin"), "origin") : V3(-width / 2, -height / 2, -depth / 2);
         return TriMesh::MakeBox(origin, V3(1, 0, 0) * width, V3(0, 1, 0) * height, V3(0, 0, 1) * depth);
-    } else if (type == "ply" || type == "external") {
+    } else if (type == "ply" || type == "obj" || type == "external") {
         const std::string filename = elem.getString("filename");
         if (filename.empty())
             fail("Shape '" + name + "': No filename given");
@@ -333,8 +333,11 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
         std::string ext        = dot == std::string::npos ? "" : path.substr(dot);
         for (auto& c : ext)
             c = (char)std::tolower((unsigned char)c);
+        // ExternalShape dispatch by extension (TriMeshProvider.cpp:41-75)
+        if (ext == ".obj" || (type == "obj" && ext != ".ply"))
+            return load_obj(path);
         if (ext != ".ply")
-            fail("Shape '" + name + "': only .ply external meshes are supported by this loader (got '" + filename + "')");
+            fail("Shape '" + name + "': only .ply and .obj external meshes are supported by this loader (got '" + filename + "')");
         return load_ply(path);
     }
     fail("Shape '" + name + "': Can not load shape type '" + type + "'");

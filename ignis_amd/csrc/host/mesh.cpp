@@ -1,5 +1,9 @@
 #include "mesh.h"
 
+#include <map>
+#include <sstream>
+#include <tuple>
+
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -444,6 +448,115 @@ TriMesh load_ply(const std::string& path)
         }
     }
     if (mesh.texcoords.empty())
+        mesh.makeTexCoordsNormalized();
+    return mesh;
+}
+
+// Wavefront OBJ (src/runtime/mesh/ObjFile.cpp:25-213 over tinyobjloader): v / vt / vn / f records, 1-based and
+// negative (relative) indices, `v`, `v/vt`, `v//vn`, `v/vt/vn` corners. A mesh vertex is created per distinct
+// (v, vn, vt) triple in first-use order (ObjFile.cpp:125-139); polygons are split as a fan (tinyobjloader does the
+// same for quads and ear-clips larger polygons; the fan equals it for convex faces). Groups / objects / materials
+// are merged into one mesh like the reference's default (no shape_index).
+TriMesh load_obj(const std::string& path)
+{
+    std::ifstream stream(path);
+    if (!stream)
+        throw std::runtime_error("OBJ file '" + path + "' can not be opened");
+    std::vector<V3> pos, nrm;
+    std::vector<V2> tex;
+    struct Corner {
+        int v, n, t;
+    };
+    std::vector<std::vector<Corner>> faces;
+    std::string line;
+    while (std::getline(stream, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#')
+            continue;
+        if (tag == "v") {
+            float x = 0, y = 0, z = 0;
+            ls >> x >> y >> z;
+            pos.emplace_back(x, y, z);
+        } else if (tag == "vn") {
+            float x = 0, y = 0, z = 0;
+            ls >> x >> y >> z;
+            nrm.emplace_back(x, y, z);
+        } else if (tag == "vt") {
+            float u = 0, v = 0;
+            ls >> u >> v;
+            tex.push_back(V2{ u, v });
+        } else if (tag == "f") {
+            std::vector<Corner> f;
+            std::string c;
+            while (ls >> c) {
+                int idx[3] = { 0, 0, 0 }; // v, vt, vn as written (0 = absent)
+                int k = 0;
+                size_t start = 0;
+                while (k < 3 && start <= c.size()) {
+                    const size_t slash = c.find('/', start);
+                    const std::string part = c.substr(start, slash == std::string::npos ? std::string::npos : slash - start);
+                    if (!part.empty())
+                        idx[k] = std::atoi(part.c_str());
+                    ++k;
+                    if (slash == std::string::npos)
+                        break;
+                    start = slash + 1;
+                }
+                auto fix = [&](int i, size_t count) -> int { // 1-based or negative-relative -> 0-based, -1 = absent
+                    if (i > 0)
+                        return i - 1;
+                    if (i < 0)
+                        return (int)count + i;
+                    return -1;
+                };
+                Corner cr{ fix(idx[0], pos.size()), fix(idx[2], nrm.size()), fix(idx[1], tex.size()) };
+                if (cr.v < 0 || cr.v >= (int)pos.size())
+                    throw std::runtime_error("OBJ file '" + path + "': face references a missing vertex");
+                if (cr.n >= (int)nrm.size() || cr.t >= (int)tex.size())
+                    throw std::runtime_error("OBJ file '" + path + "': face references a missing normal / texcoord");
+                f.push_back(cr);
+            }
+            if (f.size() >= 3)
+                faces.push_back(std::move(f));
+        }
+    }
+    if (pos.empty())
+        throw std::runtime_error("OBJ file '" + path + "': No vertices given!");
+
+    bool has_norms = false, has_tex = false; // ObjFile.cpp:62-106: used by at least one corner
+    for (const auto& f : faces)
+        for (const auto& c : f) {
+            has_norms |= c.n >= 0;
+            has_tex |= c.t >= 0;
+        }
+
+    TriMesh mesh;
+    std::map<std::tuple<int, int, int>, uint32_t> index_map;
+    auto embed = [&](const Corner& c) -> uint32_t {
+        const auto key = std::make_tuple(c.v, c.n, c.t);
+        const auto it  = index_map.find(key);
+        if (it != index_map.end())
+            return it->second;
+        const uint32_t id = (uint32_t)index_map.size();
+        index_map[key]    = id;
+        mesh.vertices.push_back(pos[c.v]);
+        if (has_norms)
+            mesh.normals.push_back(c.n >= 0 ? nrm[c.n] : V3(0, 0, 1));
+        if (has_tex)
+            mesh.texcoords.push_back(c.t >= 0 ? tex[c.t] : V2{ 0.0f, 0.0f });
+        return id;
+    };
+    for (const auto& f : faces)
+        for (size_t k = 1; k + 1 < f.size(); ++k) {
+            mesh.indices.push_back(embed(f[0]));
+            mesh.indices.push_back(embed(f[k]));
+            mesh.indices.push_back(embed(f[k + 1]));
+            mesh.indices.push_back(0);
+        }
+    if (!has_norms)
+        mesh.computeVertexNormals();
+    if (!has_tex)
         mesh.makeTexCoordsNormalized();
     return mesh;
 }

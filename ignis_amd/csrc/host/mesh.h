@@ -42,5 +42,6 @@ struct TriMesh {
 
 // Throws std::runtime_error with a message on malformed input.
 TriMesh load_ply(const std::string& path);
+TriMesh load_obj(const std::string& path); // src/runtime/mesh/ObjFile.cpp
 
 } // namespace igh

@@ -209,3 +209,64 @@ def test_exr_writer_round_trip(tmp_path):
     assert attrs["igSeed"] == ("string", b"3") and attrs["igTechniqueType"][1] == b"path"
     with pytest.raises(RuntimeError):
         save_exr("/nonexistent_dir/x.exr", img)
+
+
+def test_obj_loader_matches_the_same_mesh_as_ply(tmp_path):
+    """OBJ meshes (src/runtime/mesh/ObjFile.cpp): a quad-faced OBJ with v/vt/vn corners, negative indices and a
+    shared-vertex fan loads into the same tables as the equivalent hand-written triangle soup in PLY."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    obj = """# unit quad in the xy plane, split by the loader, plus a triangle using relative indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+f 1/1/1 2/2/1 3/3/1 4/4/1
+v 2 0 0
+v 3 0 0
+v 2 1 0
+f -3/1/-1 -2/2/-1 -1/4/-1
+"""
+    (tmp_path / "m.obj").write_text(obj)
+    ply = """ply
+format ascii 1.0
+element vertex 7
+property float x
+property float y
+property float z
+property float nx
+property float ny
+property float nz
+property float s
+property float t
+element face 3
+property list uchar int vertex_indices
+end_header
+0 0 0 0 0 1 0 0
+1 0 0 0 0 1 1 0
+1 1 0 0 0 1 1 1
+0 1 0 0 0 1 0 1
+2 0 0 0 0 1 0 0
+3 0 0 0 0 1 1 0
+2 1 0 0 0 1 0 1
+3 0 1 2
+3 0 2 3
+3 4 5 6
+"""
+    (tmp_path / "m.ply").write_text(ply)
+    scenes = []
+    for fn in ("m.obj", "m.ply"):
+        s = flat_scene()
+        s["shapes"][0] = {"type": "external", "name": s["shapes"][0]["name"], "filename": fn}
+        scenes.append(LoadedScene.from_string(json.dumps(s), str(tmp_path)))
+    a, b = scenes
+    assert a.scene.shape_data_size == b.scene.shape_data_size
+    da = np.ctypeslib.as_array(a.scene.shape_data, shape=(a.scene.shape_data_size,))
+    db = np.ctypeslib.as_array(b.scene.shape_data, shape=(b.scene.shape_data_size,))
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(np.frombuffer(a.primbvh_bytes(), np.uint8), np.frombuffer(b.primbvh_bytes(), np.uint8))
