@@ -173,5 +173,28 @@ def detmath(which, x):
     return y
 
 
+def align_vectors(a, b, v):
+    """(M v, M) for M = mat3x3_align_vectors(a, b); M as a [3, 3] array of columns."""
+    x = [np.asarray(t, dtype=np.float32) for t in (a, b, v)]
+    out, m = np.zeros(3, np.float32), np.zeros(9, np.float32)
+    lib().oracle_align_vectors(_fp(x[0]), _fp(x[1]), _fp(x[2]), _fp(out), _fp(m))
+    return out, m.reshape(3, 3)
+
+
+def ensure_valid_reflection(ng, i, n):
+    x = [np.asarray(t, dtype=np.float32) for t in (ng, i, n)]
+    out = np.zeros(3, np.float32)
+    lib().oracle_ensure_valid_reflection(_fp(x[0]), _fp(x[1]), _fp(x[2]), _fp(out))
+    return out
+
+
+def vndf_ggx(alpha_u, alpha_v, seed, wo):
+    wo = np.asarray(wo, dtype=np.float32)
+    n = np.zeros(3, np.float32)
+    pdf, dcos = C.c_float(0), C.c_float(0)
+    lib().oracle_vndf_ggx(C.c_float(alpha_u), C.c_float(alpha_v), C.c_uint32(seed), _fp(wo), _fp(n), C.byref(pdf), C.byref(dcos))
+    return n, pdf.value, dcos.value
+
+
 def hardware_threads():
     return int(lib().oracle_hardware_threads())

@@ -595,6 +595,37 @@ void oracle_detmath(int which, int64_t n, const float* x, float* y)
     }
 }
 
+// mat3x3_align_vectors (core/matrix.art:261-284) applied to v: out = M * v, m9 = M column by column
+void oracle_align_vectors(const float a[3], const float b[3], const float v[3], float out[3], float m9[9])
+{
+    const Mat3x3 m = mat3x3_align_vectors(Vec3{ a[0], a[1], a[2] }, Vec3{ b[0], b[1], b[2] });
+    const Vec3 r   = mat3x3_mul(m, Vec3{ v[0], v[1], v[2] });
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+    for (int c = 0; c < 3; ++c)
+        m9[3 * c] = m.col[c].x, m9[3 * c + 1] = m.col[c].y, m9[3 * c + 2] = m.col[c].z;
+}
+
+// ensure_valid_reflection (core/sampling.art:118-166)
+void oracle_ensure_valid_reflection(const float ng[3], const float i[3], const float n[3], float out[3])
+{
+    const Vec3 r = ensure_valid_reflection(Vec3{ ng[0], ng[1], ng[2] }, Vec3{ i[0], i[1], i[2] }, Vec3{ n[0], n[1], n[2] });
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+
+// VNDF-GGX (core/microfacet.art:403-425): sampled normal, its pdf, and D(h) * h.z for the identity frame
+void oracle_vndf_ggx(float alpha_u, float alpha_v, uint32_t seed, const float wo[3], float normal[3], float* pdf, float* d_times_cos)
+{
+    Mat3x3 id;
+    id.col[0] = Vec3{ 1, 0, 0 }, id.col[1] = Vec3{ 0, 1, 0 }, id.col[2] = Vec3{ 0, 0, 1 };
+    const GGX g{ id, alpha_u, alpha_v };
+    Rng rnd{ seed, 0 };
+    const Vec3 w = Vec3{ wo[0], wo[1], wo[2] };
+    const Vec3 m = g.sample(rnd, w);
+    normal[0] = m.x, normal[1] = m.y, normal[2] = m.z;
+    *pdf         = g.pdf(w, m);
+    *d_times_cos = g.D(m) * m.z;
+}
+
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 } // extern "C"

@@ -197,3 +197,50 @@ def test_diamond_golden_hits(diamond_scene):
         np.testing.assert_array_equal(hit[k], g[k])
     for k in ("t", "u", "v"):
         np.testing.assert_array_equal(hit[k].view(np.uint32), g[k].view(np.uint32))
+
+
+# ---- src/tests/artic/test_matrix.art:114-167 (mat3x3_align_vectors, used by the bump map)
+def test_align_vectors_known_answers():
+    import oracle
+    z = (0, 0, 1)
+    _, m = oracle.align_vectors(z, z, z)
+    np.testing.assert_allclose(m, np.eye(3), atol=1e-6)               # test_matrix3_align_identity
+    _, m = oracle.align_vectors(z, (0, 0, -1), z)
+    np.testing.assert_allclose(m, -np.eye(3), atol=1e-6)              # test_matrix3_align_neg_identity
+    s = 1 / np.sqrt(2)
+    for a, b in (((0, 0, 1), (0, 1, 0)), ((1, 0, 0), (0, 1, 0)), ((0, 0, 1), (0, -1, 0)), ((0, s, s), (0, -1, 0))):
+        r, _ = oracle.align_vectors(a, b, a)                          # test_matrix3_align: M a == b
+        np.testing.assert_allclose(r, b, atol=1e-6)
+
+
+# ---- src/tests/artic/test_microfacet.art:118-136 (VNDF-GGX of the rough conductor) and test_bbox.art:12-16
+def test_vndf_ggx_sample_pdf_consistency():
+    import oracle
+    wo = np.array([-1, 1, 1], np.float32) / np.sqrt(3)                # make_setup()
+    for seed in (42, 7, 12345):
+        n, pdf, d_cos = oracle.vndf_ggx(0.05, 0.45, seed, wo)
+        assert abs(np.linalg.norm(n) - 1) < 1e-5 and n[2] > 0         # a unit micro-normal in the upper hemisphere
+        assert pdf > 0 and np.isfinite(pdf)
+        # pdf_vndf_ggx = G1(wo) |wo.m| D(m) / |wo.n|  (microfacet.art:403-419); G1 <= 1, so pdf <= |wo.m| D / |wo.n|
+        assert pdf <= abs(float(np.dot(wo, n))) * (d_cos / n[2]) / abs(wo[2]) * (1 + 1e-5)
+
+
+def test_ensure_valid_reflection_keeps_good_normals_and_repairs_bad_ones():
+    import oracle
+    ng = np.array([0, 0, 1], np.float32)
+    i = np.array([0.6, 0, 0.8], np.float32)
+    good = np.array([0.1, 0, 0.99498744], np.float32)
+    np.testing.assert_array_equal(oracle.ensure_valid_reflection(ng, i, good), good)      # reflection already above the surface
+    bad = np.array([-0.9, 0, 0.43588989], np.float32)                                     # would reflect below the surface
+    fixed = oracle.ensure_valid_reflection(ng, i, bad)
+    r = 2 * np.dot(fixed, i) * fixed - i
+    assert abs(np.linalg.norm(fixed) - 1) < 1e-5 and np.dot(ng, r) >= 0.01 - 1e-5         # threshold min(0.9 Ng.I, 0.01)
+
+
+def test_scene_radius_follows_bbox_radius():
+    """bbox_radius2((0,0,0)-(2,4,8)) == 21 (test_bbox.art:12-16); the loader stores 1.01 * bbox_radius for env sampling."""
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene()
+    s["shapes"][0] = {"type": "cube", "name": "Bottom", "width": 2, "height": 4, "depth": 8, "origin": [0, 0, 0]}
+    sc = LoadedScene.from_string(json.dumps(s))
+    np.testing.assert_allclose(sc.scene.scene_radius, np.sqrt(21.0) * 1.01, rtol=1e-5)
