@@ -270,3 +270,26 @@ end_header
     db = np.ctypeslib.as_array(b.scene.shape_data, shape=(b.scene.shape_data_size,))
     np.testing.assert_array_equal(da, db)
     np.testing.assert_array_equal(np.frombuffer(a.primbvh_bytes(), np.uint8), np.frombuffer(b.primbvh_bytes(), np.uint8))
+
+
+def test_generated_plane_is_detected_as_plane_and_triangle_is_not():
+    """src/tests/units/trimesh_plane.cpp: MakePlane(0, X, Y) -> origin 0, axes X / Y, area 1, normal +Z; a triangle is
+    not a plane (the loader then refuses it as an analytic area light instead of mis-sampling it)."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene()
+    s["shapes"].append({"type": "rectangle", "name": "L", "origin": [0, 0, 0], "width": 1, "height": 1})
+    s["entities"].append({"name": "L", "shape": "L", "bsdf": "ground"})
+    s["lights"] = [{"type": "area", "name": "A", "entity": "L", "radiance": [1, 1, 1]}]
+    sc = LoadedScene.from_string(json.dumps(s))
+    light = sc.scene.lights[0]
+    d = np.array(list(light.d), np.float32)
+    assert light.type == 0  # IG_LIGHT_PLANE
+    np.testing.assert_allclose(d[0:3], [0, 0, 0], atol=1e-7)          # origin
+    np.testing.assert_allclose(d[4:7], [1, 0, 0], rtol=1e-6)          # x axis
+    np.testing.assert_allclose(d[8:11], [0, 1, 0], rtol=1e-6)         # y axis
+    np.testing.assert_allclose([d[3], d[7], d[11]], [0, 0, 1], atol=1e-6)  # normal
+    np.testing.assert_allclose(d[23], 1.0, rtol=1e-6)                 # area
+    s["shapes"][-1] = {"type": "triangle", "name": "L", "p0": [0, 0, 0], "p1": [1, 0, 0], "p2": [0, 1, 0]}
+    with pytest.raises(RuntimeError):
+        LoadedScene.from_string(json.dumps(s))

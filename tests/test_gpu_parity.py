@@ -423,3 +423,26 @@ def test_cli_renders_and_saves_the_mean_image(tmp_path, capsys):
     got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
     assert _rel_l2(got, ref * np.float32(0.5)) <= RADIANCE_TOL
     assert attrs["igSPP"][1] == b"8"
+
+
+def test_multiple_runtimes_in_one_process():
+    """src/tests/multiple_runtimes/main.cpp: several runtimes, one after another (and two alive at once), 8 spp each."""
+    import ignis_amd
+    scenes = [os.path.join(SCENES, n) for n in ("diamond_scene.json", "many_point_lights_hip.json", "diamond_scene.json")]
+    opts = ignis_amd.RuntimeOptions.makeDefault()
+    opts.OverrideFilmSize = (64, 64)
+    opts.SPI = 4
+    means = []
+    keep = None
+    for path in scenes:
+        rt = ignis_amd.loadFromFile(path, opts)
+        while rt.SampleCount < 8:
+            rt.step()
+        means.append(float(rt.getFramebufferForHost().mean()))
+        if keep is None:
+            keep = rt  # stays alive while the others are created and destroyed
+        else:
+            rt.shutdown()
+    keep.step()
+    assert keep.SampleCount == 12 and np.isfinite(means).all() and means[0] == means[2]
+    keep.shutdown()
