@@ -10,6 +10,11 @@
 // restated; its post-build reinsertion optimiser is not. Tree topology is
 // therefore "parity unpinned" (the reference has no test that inspects it).
 //
+// Since the topology cannot be matched anyway, the default build is tuned for the <8,4> layout (bvh.cpp): triangle
+// leaves are at least one full Tri4 packet and the N-ary collapse opens children by surface area until a node has
+// eight. IGH_BVH_REFERENCE=1 selects the reference-like parameters (min_leaf_size 1, breadth-first collapse of at
+// most four openings) instead. Results (hits, radiance) do not depend on the topology; work counters do.
+//
 // The collapse and the node/leaf writers follow the reference's own code:
 //   convert_to_narity   src/runtime/bvh/NArityBvh.h:93-155
 //   write_node          src/runtime/bvh/BvhNAdapter.h:37-93
@@ -38,7 +43,7 @@ struct Bvh2 {
     std::vector<size_t> prim_ids;
 };
 
-Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers, size_t max_leaf_size = 8);
+Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers, size_t max_leaf_size = 8, size_t min_leaf_size = 1);
 
 // Triangle BVH of a mesh in the reference's <8,4> layout.
 void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vector<ig_tri4>& tris);
