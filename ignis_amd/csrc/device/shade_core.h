@@ -435,13 +435,23 @@ IG_DEV m33 align_vectors(f3 a, f3 b) // core/matrix.art:261-284
 IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& s, f3 ray_dir)
 {
     const ig_texture& t = sc.textures[mat.tex_id];
-    const float delta   = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
-    const Col c0        = image_lookup(sc, t, s.tex);
-    const Col cx        = image_lookup(sc, t, f2{ s.tex.x + delta, s.tex.y });
-    const Col cy        = image_lookup(sc, t, f2{ s.tex.x, s.tex.y + delta });
-    const float dx      = (cx.r - c0.r) * (1 / delta);
-    const float dy      = (cy.r - c0.r) * (1 / delta);
-    const f3 N          = normalize3(s.local.c2 - (s.local.c0 * dx + s.local.c1 * dy) * mat.p[11]);
+    f3 N;
+    if (mat.flags & IG_MAT_NORMALMAP) {
+        // make_normalmap (bsdf/map.art:55-61): normal given as [0, 1] RGB; mat3x3_left_mul = (col_i . v)
+        const Col c    = image_lookup(sc, t, s.tex);
+        const f3 nt    = normalize3(f3{ 2 * c.r - 1, 2 * c.g - 1, 2 * c.b - 1 });
+        const f3 oN    = f3{ dot3(s.local.c0, nt), dot3(s.local.c1, nt), dot3(s.local.c2, nt) };
+        const float st = mat.p[11];
+        N = st != 1 ? normalize3(s.local.c2 + (oN - s.local.c2) * st) : oN;
+    } else {
+        const float delta = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
+        const Col c0      = image_lookup(sc, t, s.tex);
+        const Col cx      = image_lookup(sc, t, f2{ s.tex.x + delta, s.tex.y });
+        const Col cy      = image_lookup(sc, t, f2{ s.tex.x, s.tex.y + delta });
+        const float dx    = (cx.r - c0.r) * (1 / delta);
+        const float dy    = (cy.r - c0.r) * (1 / delta);
+        N = normalize3(s.local.c2 - (s.local.c0 * dx + s.local.c1 * dy) * mat.p[11]);
+    }
     const f3 n          = ensure_valid_reflection(s.face_normal, -ray_dir, normalize3(N));
     const m33 trans     = align_vectors(s.local.c2, n);
     m33 out;
@@ -460,8 +470,12 @@ struct BsdfCtx {
         : mat(&m)
         , surf(s)
     {
-        if (m.flags & IG_MAT_BUMP)
+        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
             surf.local = bumped_frame(sc, m, s, ray_dir);
+        if (m.flags & IG_MAT_IMAGE) {
+            kd = image_lookup(sc, sc.textures[m.tex_refl], s.tex);
+            return;
+        }
         if (m.flags & IG_MAT_CHECKER) {
             const bool px = ((int)wrapf(s.tex.x * m.q[6], 0, 2) % 2) == 0;
             const bool py = ((int)wrapf(s.tex.y * m.q[7], 0, 2) % 2) == 0;

@@ -545,12 +545,21 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
     std::memset(&m, 0, sizeof(m));
     m.light_id = -1;
     m.tex_id   = -1;
+    m.tex_refl = -1;
 
     const std::string type = bsdf->getString("type");
     if (type == "diffuse" || type == "roughdiffuse") {
         m.bsdf_type = IG_BSDF_DIFFUSE;
         const JsonValue* refl = bsdf->find("reflectance");
-        if (!(refl && lowerCheckerboard(*refl, textures, m, name))) {
+        bool is_bitmap        = false;
+        if (refl && refl->isString())
+            for (const auto& t : textures.arr)
+                if (t.getString("name") == refl->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
+                    is_bitmap = true;
+        if (is_bitmap) {
+            m.flags |= IG_MAT_IMAGE;
+            m.tex_refl = bank.get(refl->str, name);
+        } else if (!(refl && lowerCheckerboard(*refl, textures, m, name))) {
             const V3 kd = getColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), name);
             m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
         }
@@ -597,18 +606,19 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[10] = r * aspect;
         if (m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
             fail("BSDF '" + name + "': roughness <= 1e-4 makes a delta conductor, which is not supported by the HIP backend");
-    } else if (type == "bumpmap") {
-        // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength)
+    } else if (type == "bumpmap" || type == "normalmap") {
+        // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
+        // make_normalmap(ctx, inner, map colour, strength)
         const std::string inner = bsdf->getString("bsdf");
         if (inner.empty())
             fail("BSDF '" + name + "': has no inner bsdf given");
         m = lowerBsdf(inner, scene_bsdfs, textures, bank, depth + 1);
-        if (m.flags & IG_MAT_BUMP)
-            fail("BSDF '" + name + "': nested bump maps are not supported by the HIP backend");
+        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
+            fail("BSDF '" + name + "': nested bump / normal maps are not supported by the HIP backend");
         const JsonValue* map = bsdf->find("map");
         if (!map || !map->isString())
             fail("BSDF '" + name + "': 'map' must name a bitmap texture");
-        m.flags |= IG_MAT_BUMP;
+        m.flags |= type == "bumpmap" ? IG_MAT_BUMP : IG_MAT_NORMALMAP;
         m.tex_id = bank.get(map->str, name);
         m.p[11]  = getConstNumber(*bsdf, "strength", 1.0f, name);
     } else {

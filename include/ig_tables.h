@@ -92,24 +92,29 @@ enum ig_material_flags {
     IG_MAT_THIN       = 1u << 0, /* dielectric "thin" */
     IG_MAT_BUMP       = 1u << 1, /* wrapped in a bumpmap (src/artic/bsdf/map.art:36-42,64-67, MapBSDF.cpp:44-47): tex_id, p[11] */
     IG_MAT_CHECKER    = 1u << 2, /* reflectance is a checkerboard texture */
+    IG_MAT_NORMALMAP  = 1u << 3, /* wrapped in a normalmap (src/artic/bsdf/map.art:36-42,55-61): tex_id, p[11] */
+    IG_MAT_IMAGE      = 1u << 4, /* diffuse reflectance is the bitmap texture tex_refl (DiffuseBSDF.cpp:18, texture/image.art) */
 };
 
 /* One record per material (= unique bsdf / area-light entity,
- * src/runtime/loader/LoaderEntity.cpp:82-96). 96 bytes. */
+ * src/runtime/loader/LoaderEntity.cpp:82-96). 112 bytes. */
 typedef struct ig_material {
     int32_t bsdf_type;
     int32_t light_id; /* >= 0: emissive, index into lights (area light on this entity) */
     uint32_t flags;
-    int32_t tex_id;   /* bitmap texture index for the bump map, -1 = none */
+    int32_t tex_id;   /* bitmap texture index of the bump / normal map, -1 = none */
     /* diffuse:    p[0..2] reflectance, p[3] alpha (roughness)
      * dielectric: p[0] ext_ior (n1), p[1] int_ior (n2), p[2..4] specular_reflectance,
      *             p[5..7] specular_transmittance
+     * bump / normal map: p[11] strength
      * conductor:  p[0..2] eta, p[3..5] k, p[6..8] specular_reflectance,
      *             p[9] alpha_u, p[10] alpha_v
      * bump:       p[11] strength
      * checker:    q[0..2] color0, q[3..5] color1, q[6] scale_x, q[7] scale_y */
     float p[12];
     float q[8];
+    int32_t tex_refl; /* bitmap texture index of the diffuse reflectance (IG_MAT_IMAGE), -1 = none */
+    int32_t pad[3];
 } ig_material;
 
 /* ---- Bitmap textures --------------------------------------------------- */

@@ -196,5 +196,13 @@ def vndf_ggx(alpha_u, alpha_v, seed, wo):
     return n, pdf.value, dcos.value
 
 
+def image_lookup(scene, tex_id, uv):
+    """Bitmap texture lookup at uv [n, 2] -> rgb [n, 3] (texture/image.art filters and borders)."""
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    out = np.zeros((uv.shape[0], 3), np.float32)
+    lib().oracle_image_lookup(scene.tables, C.c_int32(tex_id), C.c_int64(uv.shape[0]), _fp(uv), _fp(out))
+    return out
+
+
 def hardware_threads():
     return int(lib().oracle_hardware_threads())

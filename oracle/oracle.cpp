@@ -308,8 +308,8 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     PTRayPayload payload      = read_payload(primary, i);
                     const SurfaceElement surf = surface_element(sc, entity, ray, hit);
                     // a bump-mapped material hands its inner BSDF a re-oriented surface (bsdf/map.art:64-67)
-                    const SurfaceElement bsurf = (mat.flags & IG_MAT_BUMP) ? bumped_surface(sc, mat, surf, ray) : surf;
-                    const Bsdf bsdf{ &mat, &bsurf };
+                    const SurfaceElement bsurf = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) ? bumped_surface(sc, mat, surf, ray) : surf;
+                    const Bsdf bsdf{ &mat, &bsurf, &sc };
 
                     Color hit_color;
                     if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
@@ -624,6 +624,15 @@ void oracle_vndf_ggx(float alpha_u, float alpha_v, uint32_t seed, const float wo
     normal[0] = m.x, normal[1] = m.y, normal[2] = m.z;
     *pdf         = g.pdf(w, m);
     *d_times_cos = g.D(m) * m.z;
+}
+
+// make_image_texture lookup (texture/image.art) of bitmap texture `tex_id` of the scene at n (u, v) pairs
+void oracle_image_lookup(const igd_scene* scene, int32_t tex_id, int64_t n, const float* uv, float* rgb)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const Color c = image_lookup(*scene, scene->textures[tex_id], Vec2{ uv[2 * i], uv[2 * i + 1] });
+        rgb[3 * i] = c.r, rgb[3 * i + 1] = c.g, rgb[3 * i + 2] = c.b;
+    }
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

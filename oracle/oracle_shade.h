@@ -473,13 +473,23 @@ static inline Mat3x3 mat3x3_align_vectors(Vec3 a, Vec3 b)
 static inline SurfaceElement bumped_surface(const igd_scene& sc, const ig_material& mat, const SurfaceElement& surf, const Ray& ray)
 {
     const ig_texture& t = sc.textures[mat.tex_id];
-    const float delta   = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
-    const Color c0      = image_lookup(sc, t, surf.tex_coords);
-    const Color cx      = image_lookup(sc, t, Vec2{ surf.tex_coords.x + delta, surf.tex_coords.y });
-    const Color cy      = image_lookup(sc, t, Vec2{ surf.tex_coords.x, surf.tex_coords.y + delta });
-    const float dx      = (cx.r - c0.r) * (1 / delta);
-    const float dy      = (cy.r - c0.r) * (1 / delta);
-    const Vec3 N        = vec3_normalize(vec3_sub(surf.local.col[2], vec3_mulf(vec3_add(vec3_mulf(surf.local.col[0], dx), vec3_mulf(surf.local.col[1], dy)), mat.p[11])));
+    Vec3 N;
+    if (mat.flags & IG_MAT_NORMALMAP) {
+        // make_normalmap (bsdf/map.art:55-61): normal given as [0, 1] RGB; mat3x3_left_mul = (col_i . v)
+        const Color c  = image_lookup(sc, t, surf.tex_coords);
+        const Vec3 nt  = vec3_normalize(make_vec3(2 * c.r - 1, 2 * c.g - 1, 2 * c.b - 1));
+        const Vec3 oN  = make_vec3(vec3_dot(surf.local.col[0], nt), vec3_dot(surf.local.col[1], nt), vec3_dot(surf.local.col[2], nt));
+        const float st = mat.p[11];
+        N = st != 1 ? vec3_normalize(vec3_add(surf.local.col[2], vec3_mulf(vec3_sub(oN, surf.local.col[2]), st))) : oN;
+    } else {
+        const float delta = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
+        const Color c0    = image_lookup(sc, t, surf.tex_coords);
+        const Color cx    = image_lookup(sc, t, Vec2{ surf.tex_coords.x + delta, surf.tex_coords.y });
+        const Color cy    = image_lookup(sc, t, Vec2{ surf.tex_coords.x, surf.tex_coords.y + delta });
+        const float dx    = (cx.r - c0.r) * (1 / delta);
+        const float dy    = (cy.r - c0.r) * (1 / delta);
+        N = vec3_normalize(vec3_sub(surf.local.col[2], vec3_mulf(vec3_add(vec3_mulf(surf.local.col[0], dx), vec3_mulf(surf.local.col[1], dy)), mat.p[11])));
+    }
     const Vec3 n        = ensure_valid_reflection(surf.face_normal, vec3_neg(ray.dir), vec3_normalize(N));
     const Mat3x3 trans  = mat3x3_align_vectors(surf.local.col[2], n);
     SurfaceElement out  = surf;
@@ -501,11 +511,14 @@ struct BsdfSample {
 struct Bsdf {
     const ig_material* mat;
     const SurfaceElement* surf;
+    const igd_scene* scene = nullptr; // bitmap reflectance lookups
 
     bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
 
     Color kd() const
     {
+        if (mat->flags & IG_MAT_IMAGE)
+            return image_lookup(*scene, scene->textures[mat->tex_refl], surf->tex_coords);
         if (mat->flags & IG_MAT_CHECKER)
             return checkerboard(*mat, surf->tex_coords);
         return Color{ mat->p[0], mat->p[1], mat->p[2] };

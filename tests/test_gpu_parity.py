@@ -446,3 +446,20 @@ def test_multiple_runtimes_in_one_process():
     keep.step()
     assert keep.SampleCount == 12 and np.isfinite(means).all() and means[0] == means[2]
     keep.shutdown()
+
+
+def test_image_reflectance_and_normal_map_vs_oracle(gpu_device, tmp_path):
+    """Bitmap-textured diffuse reflectance (texture/image.art) and a normal-mapped conductor (bsdf/map.art:55-61)."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s["textures"].append({"type": "bitmap", "name": "ntex", "filename": "textures/bumpmap.png", "filter_type": "bilinear", "linear": True,
+                          "wrap_mode": "mirror"})
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-Ground":
+            b["reflectance"] = "tex"            # the sRGB bitmap, bicubic, as a colour
+        if b["name"] == "mat-Pillar":
+            b.update({"type": "normalmap", "map": "ntex", "strength": 0.5})
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 160, 120)
+    mats = [sc.scene.materials[i] for i in range(sc.scene.material_count)]
+    assert any(m.flags & 16 for m in mats) and any(m.flags & 8 for m in mats)  # IG_MAT_IMAGE, IG_MAT_NORMALMAP
+    _compare_with_oracle(gpu_device, sc, 160, 120, 4, seed=3, iters=2)

@@ -244,3 +244,90 @@ def test_scene_radius_follows_bbox_radius():
     s["shapes"][0] = {"type": "cube", "name": "Bottom", "width": 2, "height": 4, "depth": 8, "origin": [0, 0, 0]}
     sc = LoadedScene.from_string(json.dumps(s))
     np.testing.assert_allclose(sc.scene.scene_radius, np.sqrt(21.0) * 1.01, rtol=1e-5)
+
+
+# ---- bitmap textures (texture/image.art, driver/image.art, Image.cpp:714-808) against an independent numpy restatement
+def _write_png(path, rgba):
+    import struct
+    import zlib
+    h, w, c = rgba.shape
+    raw = b"".join(b"\x00" + rgba[y].tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                           + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _textured_scene(tmp_path, texture, bsdfs):
+    s = flat_scene(lights=[{"type": "point", "name": "p", "position": [0, 0, -0.5], "intensity": [1, 1, 1]}])
+    s["textures"] = [texture]
+    s["bsdfs"] = bsdfs
+    s["entities"][0]["bsdf"] = bsdfs[-1]["name"]
+    return LoadedScene.from_string(json.dumps(s), str(tmp_path))
+
+
+@pytest.mark.parametrize("filt,wrap", [("nearest", "repeat"), ("bilinear", "mirror"), ("bilinear", "clamp"), ("bicubic", "repeat")])
+def test_image_lookup_matches_numpy_restatement(tmp_path, filt, wrap):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    _write_png(str(tmp_path / "t.png"), img)
+    sc = _textured_scene(tmp_path, {"type": "bitmap", "name": "t", "filename": "t.png", "filter_type": filt, "wrap_mode": wrap, "linear": True},
+                         [{"type": "diffuse", "name": "m", "reflectance": "t"}])
+    H, W = 5, 7
+    tex = img[::-1].astype(np.float32) / np.float32(255)  # rows bottom-to-top
+
+    def border(x, w):
+        if wrap == "clamp":
+            return np.clip(x, 0, w - 1)
+        if wrap == "mirror":
+            t = np.where(x < 0, -1 - x, x)
+            i = t // w
+            k = t - i * w
+            return np.where((i & 1) == 0, w - 1 - k, k)
+        return np.mod(x, w)
+
+    def px(x, y):
+        return tex[border(y, H), border(x, W)]
+
+    uv = rng.uniform(-1.5, 2.5, (200, 2)).astype(np.float32)
+    f32 = np.float32
+    if filt == "nearest":
+        want = px(np.floor(uv[:, 0] * f32(W)).astype(int), np.floor(uv[:, 1] * f32(H)).astype(int))
+    else:
+        u = uv[:, 0] * f32(W) - f32(0.5)
+        v = uv[:, 1] * f32(H) - f32(0.5)
+        ix, iy = np.floor(u).astype(int), np.floor(v).astype(int)
+        fx, fy = (u - np.floor(u)).astype(f32)[:, None], (v - np.floor(v)).astype(f32)[:, None]
+        if filt == "bilinear":
+            top = (1 - fx) * px(ix, iy) + fx * px(ix + 1, iy)
+            bot = (1 - fx) * px(ix, iy + 1) + fx * px(ix + 1, iy + 1)
+            want = (1 - fy) * top + fy * bot
+        else:
+            w0 = lambda a: (a * (a * (-a + 3) - 3) + 1) / 6
+            w1 = lambda a: (a * a * (3 * a - 6) + 4) / 6
+            w2 = lambda a: (a * (a * (-3 * a + 3) + 3) + 1) / 6
+            w3 = lambda a: (a * a * a) / 6
+            g0, g1 = (lambda a: w0(a) + w1(a)), (lambda a: w2(a) + w3(a))
+            h0, h1 = (lambda a: w1(a) / g0(a) - 1), (lambda a: w3(a) / g1(a) + 1)
+            x0 = np.floor(ix + h0(fx[:, 0]) + f32(0.5)).astype(int)
+            x1 = np.floor(ix + h1(fx[:, 0]) + f32(0.5)).astype(int)
+            y0 = np.floor(iy + h0(fy[:, 0]) + f32(0.5)).astype(int)
+            y1 = np.floor(iy + h1(fy[:, 0]) + f32(0.5)).astype(int)
+            want = (px(x0, y0) * (g0(fx) * g0(fy)) + px(x1, y0) * (g1(fx) * g0(fy))) + (px(x0, y1) * (g0(fx) * g1(fy)) + px(x1, y1) * (g1(fx) * g1(fy)))
+    got = oracle.image_lookup(sc, 0, uv)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_constant_image_equals_constant_reflectance(tmp_path):
+    """A one-colour sRGB image behaves exactly like the constant colour its texels decode to (byte_color_to_linear)."""
+    _write_png(str(tmp_path / "c.png"), np.full((4, 4, 3), (200, 100, 50), np.uint8))
+    tex = {"type": "image", "name": "c", "filename": "c.png", "filter_type": "nearest"}
+    a = _textured_scene(tmp_path, tex, [{"type": "diffuse", "name": "m", "reflectance": "c"}])
+    lin = [float(np.float32(np.floor(((v / 255 + 0.055) / 1.055) ** 2.4 * 255)) / np.float32(255)) for v in (200, 100, 50)]
+    b = _textured_scene(tmp_path, tex, [{"type": "diffuse", "name": "m", "reflectance": lin}])
+    fa, _ = oracle.render(a, 4, 32, 32, seed=2)
+    fb, _ = oracle.render(b, 4, 32, 32, seed=2)
+    assert fa.mean() > 0
+    np.testing.assert_array_equal(fa, fb)
