@@ -150,15 +150,19 @@ def main():
         achieved = a_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # measured HBM-side bytes per launch of the same kernel: PMC passes of this command, summarised into
         # profiles/ by tools/prof_summary.py (counters cannot be read from inside the process)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, limiter = None, None, None
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1 and args.scene == SCENE:
             tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false, false>")
             if tk:
                 traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, x2 read correction)"
+                if "valu_lane_utilisation" in tk:
+                    # what actually limits the kernel on this 40 KB scene (SURVEY.md 8d asks for it next to the HBM fraction)
+                    limiter = {"kind": "VALU issue + latency (geometry is cache resident)", "valu_lane_utilisation": tk["valu_lane_utilisation"],
+                               "wave_wait_share": tk.get("wave_wait_share"), "wave_issue_share": tk.get("wave_issue_share"), "source": f"profiles/{TRAFFIC_FILE} (SQ counters)"}
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                    "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(a_per_launch)}
 
         stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")}

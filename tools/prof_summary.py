@@ -3,7 +3,7 @@
 usage:
   python tools/prof_summary.py stats <stats.db>                      kernel table of `--kernel-trace --stats`
   python tools/prof_summary.py pmc <pmc.db> [<pmc.db> ...]           per-kernel sum / per-launch mean of each counter
-  python tools/prof_summary.py traffic <fetch.db> <write.db>         JSON: HBM-side bytes per launch per kernel
+  python tools/prof_summary.py traffic <fetch.db> <write.db> [<sq.db>]   JSON: HBM-side bytes per launch per kernel (+ VALU lane utilisation)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. Calibration inside the same run (known byte counts):
 k_generate writes exactly 68 B per camera ray (WRITE_SIZE matches to 6 digits -> no correction); k_copy_paths reads
@@ -47,8 +47,9 @@ def short(name):
     return n.split("(")[0]
 
 
-def traffic(fetch_db, write_db):
+def traffic(fetch_db, write_db, sq_db=None):
     f, w = counters(fetch_db), counters(write_db)
+    sq = counters(sq_db) if sq_db else {}
     res = {"unit": "bytes per launch", "fetch_correction": 2.0,
            "note": "FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; reads doubled (gfx950 coalesced-read "
                    "correction, confirmed in-run by k_copy_paths: FETCH == WRITE / 2 for a pure copy), writes as reported "
@@ -65,6 +66,12 @@ def traffic(fetch_db, write_db):
             "write_kib_raw": round(wr["mean"], 2),
             "hbm_bytes": int((2.0 * fr["mean"] + wr["mean"]) * 1024),
         }
+        q = sq.get(k)
+        if q and all(c in q and q[c]["sum"] > 0 for c in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES")):
+            # lane utilisation = active lanes per issued VALU instruction / 64; wait share = waves parked on s_waitcnt
+            res["kernels"][short(k)]["valu_lane_utilisation"] = round(q["SQ_THREAD_CYCLES_VALU"]["sum"] / (64.0 * q["SQ_ACTIVE_INST_VALU"]["sum"]), 4)
+            res["kernels"][short(k)]["wave_wait_share"] = round(q["SQ_WAIT_ANY"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"], 4)
+            res["kernels"][short(k)]["wave_issue_share"] = round(q["SQ_ACTIVE_INST_ANY"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"], 4) if "SQ_ACTIVE_INST_ANY" in q else None
     print(json.dumps(res, indent=1))
 
 
@@ -76,6 +83,6 @@ if __name__ == "__main__":
         for p in sys.argv[2:]:
             pmc(p)
     elif mode == "traffic":
-        traffic(sys.argv[2], sys.argv[3])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         sys.exit(__doc__)
