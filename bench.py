@@ -64,12 +64,14 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank
         # torch first: its bundled HIP runtime and RCCL are the ones every library in this process binds to
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import numpy as np
@@ -208,12 +210,16 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
 
     dev.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C stdout buffer; push it out first so that the JSON line is the LAST line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
