@@ -212,14 +212,17 @@ def main():
         }
 
     dev.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    # RCCL writes a version banner to the C stdout buffer; push it out first so that the JSON line is the LAST line
+    # RCCL writes a version banner to the C stdout buffer of the ranks; every rank pushes its buffer out before rank 0
+    # prints, so that the JSON line is the LAST line of the job's stdout
     import ctypes
     ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
     if out is not None:
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
