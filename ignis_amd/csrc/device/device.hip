@@ -31,6 +31,7 @@ void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
+void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
 } // namespace igdev
 
@@ -131,7 +132,8 @@ struct igd_device {
         DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
         DevBuf<float> tail_long; // those still alive after a pass (the two buffers alternate)
         DevBuf<uint32_t> tail_ctr; // per pass: [2 * j] output count, [2 * j + 1] fetch counter
-        DevBuf<float> side_secondary;     // shadow rays of the wavefront rounds that run on the side stream
+        DevBuf<float> tail_work[2];       // k_tail_wave: per-wave private regions for the continuation rays
+        DevBuf<float> side_secondary;     // shadow rays of the side-stream rounds / of k_tail_wave
         DevBuf<uint32_t> side_deep_rays;
         size_t tail_capacity = 0;
         QueueState* qs       = nullptr; // device
@@ -166,6 +168,11 @@ struct igd_device {
     // 3 % to 10 % slower than handing over directly, the small launches disturb the main stream more than the
     // per-lane passes do). IGD_SIDE_ROUNDS.
     int side_rounds = 0;
+    // Tail kernel: 0 = one path per lane from start to end (k_tail, default), 1 = every wave runs a wavefront of its own
+    // over a slice of paths (k_tail_wave; better lane utilisation but a 2x longer dependent chain per wave: measured 9 %
+    // slower end to end). IGD_TAIL_WAVEFRONT. Slice = paths per wave (IGD_TAIL_SLICE, multiple of 64, <= 4096).
+    int tail_wavefront = 0;
+    int tail_slice     = 256;
 
     // statistics
     igd_stats stats{};
@@ -264,6 +271,14 @@ struct igd_device {
         q.col  = reinterpret_cast<float4*>(b + 8 * c);
         return q;
     }
+    void ensureTailWork(Flight& f)
+    {
+        for (auto& w : f.tail_work)
+            if (w.count < f.tail_capacity * kPrimaryCols) {
+                w.release();
+                w.alloc(f.tail_capacity * kPrimaryCols);
+            }
+    }
     void ensureSideStreams(Flight& f)
     {
         if (f.side_secondary.count < f.tail_capacity * kSecondaryCols) {
@@ -276,7 +291,7 @@ struct igd_device {
 
     void ensureTailInput(Flight& f, size_t paths)
     {
-        paths = (paths + 255) & ~(size_t)255;
+        paths = ((paths + 4095) & ~(size_t)4095) + 4096; // room for whole slices of k_tail_wave (slice <= 4096)
         if (paths <= f.tail_capacity && f.tail_in.ptr)
             return;
         f.tail_in.release();
@@ -764,6 +779,10 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
+            if (d->tail_wavefront) {
+                d->ensureTailWork(fl);
+                d->ensureSideStreams(fl);
+            }
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
             HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
             // one-wave workgroups, 2 waves/SIMD (VGPR bound) = 8 per CU; fewer when the stream is tiny
@@ -813,7 +832,23 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.work_counter = fl.tail_ctr.ptr + 2 * j + 1;
                     p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
                     p.count_paths  = j == 0;
-                    launch_tail(p, counters, tail_grid, side);
+                    if (d->tail_wavefront) {
+                        // every wave gets a slice of the pass's input; the grid covers the upper bound `live`
+                        p.work[0] = igd_device::colsAt(fl.tail_work[0].ptr, fl.tail_capacity);
+                        p.work[1] = igd_device::colsAt(fl.tail_work[1].ptr, fl.tail_capacity);
+                        p.sec     = igd_device::secAt(fl.side_secondary.ptr, fl.tail_capacity);
+                        // no more waves than the tail's share of the deep-stack columns (one column per lane)
+                        const uint32_t max_waves = std::max(1u, d->tail_lanes / 64u);
+                        uint32_t slice           = (uint32_t)d->tail_slice;
+                        while ((live + slice - 1) / slice > max_waves && slice < 4096u)
+                            slice *= 2;
+                        if ((live + slice - 1) / slice > max_waves)
+                            throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: IGD_TAIL_THRESHOLD is too large for the wave-local tail kernel" };
+                        p.slice = slice;
+                        launch_tail_wave(p, counters, (int)((live + slice - 1) / slice), side);
+                    } else {
+                        launch_tail(p, counters, tail_grid, side);
+                    }
                 }
             });
 
@@ -1033,6 +1068,10 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_WAVES"))
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("IGD_TAIL_WAVEFRONT"))
+            d->tail_wavefront = std::atoi(e);
+        if (const char* e = std::getenv("IGD_TAIL_SLICE"))
+            d->tail_slice = std::min(4096, std::max(64, (std::atoi(e) + 63) / 64 * 64));
         if (const char* e = std::getenv("IGD_SIDE_ROUNDS"))
             d->side_rounds = std::atoi(e);
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
@@ -1106,6 +1145,8 @@ int32_t igd_release_all(igd_device* dev)
             f.tail_long.release();
             f.side_secondary.release();
             f.side_deep_rays.release();
+            f.tail_work[0].release();
+            f.tail_work[1].release();
             f.tail_capacity = 0;
         }
         dev->list_rays.release();

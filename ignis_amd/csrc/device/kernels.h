@@ -163,6 +163,11 @@ struct TailArgs {
     uint32_t* out_count;
     int32_t count_paths; // add the input size to qs->tail_rays
     uint32_t deep_lane_base; // first deep-stack column of this launch's lanes
+    // k_tail_wave: every wave owns `slice` consecutive paths of `in` and runs bounce rounds over them in its private
+    // regions [wave * slice, (wave + 1) * slice) of work[0] / work[1] (continuation rays) and sec (shadow rays)
+    PrimaryCols work[2];
+    SecondaryCols sec;
+    uint32_t slice;
 };
 
 struct ResolveArgs {
