@@ -465,3 +465,21 @@ def test_image_reflectance_and_normal_map_vs_oracle(gpu_device, tmp_path):
     mats = [sc.scene.materials[i] for i in range(sc.scene.material_count)]
     assert any(m.flags & 16 for m in mats) and any(m.flags & 8 for m in mats)  # IG_MAT_IMAGE, IG_MAT_NORMALMAP
     _compare_with_oracle(gpu_device, sc, 160, 120, 4, seed=3, iters=2)
+
+
+def test_cpp_cli_matches_the_python_one(tmp_path):
+    """ignis_amd/lib/igcli_hip (C++, on the two C ABIs only) renders the same EXR as the Python CLI."""
+    import subprocess
+    from ignis_amd import cli
+    from test_abi import _read_exr
+    exe = os.path.join(os.path.dirname(SCENES), "ignis_amd", "lib", "igcli_hip")
+    assert os.path.exists(exe), "igcli_hip was not built (__graft_entry__.build())"
+    args = [os.path.join(SCENES, "diamond_scene.json"), "--spp", "8", "--spi", "4", "--width", "64", "--height", "48", "--seed", "5"]
+    r = subprocess.run([exe] + args + ["-o", str(tmp_path / "cpp.exr"), "--stats"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "min/med/max Msamples/s" in r.stdout and "SPP: 8" in r.stdout and "Ray Count" in r.stdout
+    assert cli.main(args + ["-o", str(tmp_path / "py.exr")]) == 0
+    a, _ = _read_exr(str(tmp_path / "cpp.exr"))
+    b, _ = _read_exr(str(tmp_path / "py.exr"))
+    for c in "RGB":
+        np.testing.assert_array_equal(a[c], b[c])
