@@ -347,7 +347,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: hierarchy light selector without a hierarchy table" };
     for (uint32_t l = 0; l < s->light_count; ++l) {
         const bool inf = l < s->infinite_light_count;
-        if (inf != (s->lights[l].type == IG_LIGHT_ENV))
+        const int lt = s->lights[l].type;
+        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_DIRECTIONAL)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
+        if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment lights" };
     }
 

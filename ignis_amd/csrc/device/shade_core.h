@@ -833,6 +833,38 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             pdf_area    = true;
             lcos        = 1;
             delta       = true;
+        } else if (L.type == IG_LIGHT_SPOT) {
+            // make_spot_light.sample_direct (light/spot.art:8-42); cosines of cutoff / falloff come from the table
+            lpos                = f3{ L.d[0], L.d[1], L.d[2] };
+            const f3 sdir       = f3{ L.d[4], L.d[5], L.d[6] };
+            const float cos_cut = L.d[3], blend = L.d[7] - L.d[3];
+            const f3 d_         = lpos - surf.point;
+            ldist               = len3(d_);
+            ldir                = d_ * safe_div(1, ldist);
+            const float cos_a   = dot3(-ldir, sdir);
+            float factor;
+            if (blend <= kFltEps) {
+                factor = cos_a <= cos_cut ? 0.0f : 1.0f;
+            } else {
+                const float x = clampf((cos_a - cos_cut) / blend, 0, 1);
+                factor        = x * x * (3 - 2 * x);
+            }
+            lint      = Col{ L.d[8] * factor, L.d[9] * factor, L.d[10] * factor };
+            pdf_value = dot3(-ldir, sdir) > cos_cut ? 1.0f : 0.0f;
+            pdf_area  = true;
+            lcos      = -dot3(ldir, sdir);
+            delta     = true;
+        } else if (L.type == IG_LIGHT_DIRECTIONAL) {
+            // make_directional_light.sample_direct (light/directional.art:6)
+            const f3 ddir = f3{ L.d[0], L.d[1], L.d[2] };
+            lpos          = surf.point + ddir * (-sc.scene_radius);
+            ldir          = -ddir;
+            lint          = Col{ L.d[4], L.d[5], L.d[6] };
+            pdf_value     = 1;
+            lcos          = 1;
+            ldist         = sc.scene_radius;
+            delta         = true;
+            infinite      = true;
         } else {
             // constant environment: make_environment_light_function_spherical.sample_direct (light/env.art:89-93)
             const float ux = rnd.f32();

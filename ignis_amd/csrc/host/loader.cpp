@@ -1036,6 +1036,41 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             const V3 cache = intensity * (4 * Pi);
             hier_entries.push_back(LightEntry{ pos, V3(0, 0, 1), -((cache.x + cache.y + cache.z) / 3), (int32_t)finite.size() });
             finite.push_back(out);
+        } else if (type == "spot") {
+            // SpotLight.cpp:13-97, light/spot.art: position, direction, cutoff / falloff (degrees), intensity or power
+            if (!l.has("direction") || l.has("elevation") || l.has("azimuth"))
+                fail("Light '" + lname + "': only an explicit 'direction' is supported by this loader");
+            const V3 pos     = l.has("position") ? getVector3(*l.find("position"), "position") : V3(0, 0, 0);
+            V3 dir           = getVector3(*l.find("direction"), "direction");
+            const float dl   = std::sqrt(dot(dir, dir));
+            dir              = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
+            const float cutoff  = getConstNumber(l, "cutoff", 30.0f, lname) * Deg2Rad;
+            const float falloff = getConstNumber(l, "falloff", 20.0f, lname) * Deg2Rad;
+            const float factor  = 2 * Pi * (1 - 0.5f * (std::cos(cutoff) + std::cos(falloff))); // power_factor
+            V3 cache; // mColor_Cache: power
+            if (l.has("power"))
+                cache = getColor(l, "power", V3(factor, factor, factor), lname);
+            else
+                cache = getColor(l, "intensity", V3(1, 1, 1), lname) * factor;
+            const V3 intensity = cache * (1 / factor);
+            out.type = IG_LIGHT_SPOT;
+            out.d[0] = pos.x, out.d[1] = pos.y, out.d[2] = pos.z, out.d[3] = std::cos(cutoff);
+            out.d[4] = dir.x, out.d[5] = dir.y, out.d[6] = dir.z, out.d[7] = std::cos(falloff);
+            out.d[8] = intensity.x, out.d[9] = intensity.y, out.d[10] = intensity.z;
+            hier_entries.push_back(LightEntry{ pos, dir, (cache.x + cache.y + cache.z) / 3, (int32_t)finite.size() });
+            finite.push_back(out);
+        } else if (type == "directional" || type == "direction" || type == "distant") {
+            // DirectionalLight.cpp, light/directional.art: an infinite delta light
+            if (!l.has("direction") || l.has("elevation") || l.has("azimuth"))
+                fail("Light '" + lname + "': only an explicit 'direction' is supported by this loader");
+            V3 dir         = getVector3(*l.find("direction"), "direction");
+            const float dl = std::sqrt(dot(dir, dir));
+            dir            = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
+            const V3 irr   = getColor(l, "irradiance", V3(1, 1, 1), lname);
+            out.type       = IG_LIGHT_DIRECTIONAL;
+            out.d[0] = dir.x, out.d[1] = dir.y, out.d[2] = dir.z;
+            out.d[4] = irr.x, out.d[5] = irr.y, out.d[6] = irr.z;
+            infinite.push_back(out);
         } else if (type == "env" || type == "constant") {
             // EnvironmentLight.cpp:40-98: a constant radiance bakes to a 1x1 texture, so the reference
             // builds make_environment_light (uniform sphere sampling), not the CDF-sampled variant.

@@ -140,6 +140,8 @@ enum ig_light_type {
     IG_LIGHT_PLANE = 0, /* "SimplePlaneLight", src/artic/light/area.art:416-440, 24 floats */
     IG_LIGHT_POINT = 1, /* "SimplePointLight", src/artic/light/point.art:20-35, 8 floats */
     IG_LIGHT_ENV   = 2, /* constant environment radiance, src/artic/light/env.art */
+    IG_LIGHT_SPOT  = 3, /* "SimpleSpotLight", src/artic/light/spot.art:8-53, SpotLight.cpp:83-97 (finite, delta) */
+    IG_LIGHT_DIRECTIONAL = 4, /* src/artic/light/directional.art:1-17, DirectionalLight.cpp (infinite, delta) */
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
@@ -147,7 +149,10 @@ enum ig_light_type {
  * d[] for POINT: position.xyz, 0 | intensity.rgb, 0
  * d[] for ENV:   radiance.rgb (= scale * radiance), 0   -- constant environment, sampled uniformly over
  *                the sphere (make_environment_light -> make_environment_light_function_spherical,
- *                src/artic/light/env.art:83-108,161-164) */
+ *                src/artic/light/env.art:83-108,161-164)
+ * d[] for SPOT:  position.xyz, cos(cutoff) | direction.xyz, cos(falloff) | intensity.rgb, 0   (the reference stores the
+ *                angles and takes the cosines on the device; the loader does it here)
+ * d[] for DIRECTIONAL: direction.xyz (the way the light travels, normalised), 0 | irradiance.rgb, 0 */
 typedef struct ig_light {
     int32_t type;
     int32_t entity_id; /* emissive entity for area lights, -1 otherwise */

@@ -775,6 +775,52 @@ static inline DirectLightSample sample_direct_plane(const ig_light& l, Rng& rnd,
 }
 
 // make_point_light.sample_direct (light/point.art:3-8)
+// make_spot_light.sample_direct (light/spot.art:8-42)
+static inline DirectLightSample sample_direct_spot(const ig_light& l, const SurfaceElement& from_surf)
+{
+    const Vec3 pos = Vec3{ l.d[0], l.d[1], l.d[2] }, dir = Vec3{ l.d[4], l.d[5], l.d[6] };
+    const float cosCutoffAngle = l.d[3], cosFalloffAngle = l.d[7];
+    const float blendRange = cosFalloffAngle - cosCutoffAngle;
+    const Vec3 out_dir_    = vec3_sub(pos, from_surf.point);
+    const float dist       = vec3_len(out_dir_);
+    const Vec3 out_dir     = vec3_mulf(out_dir_, safe_div(1, dist));
+    const Vec3 to_surf     = vec3_neg(out_dir);
+    const float cos_angle  = vec3_dot(to_surf, dir); // eval_dir(vec3_neg(out_dir))
+    float factor;
+    if (blendRange <= flt_eps) {
+        factor = cos_angle <= cosCutoffAngle ? 0.0f : 1.0f;
+    } else {
+        const float x = clampf((cos_angle - cosCutoffAngle) / blendRange, 0, 1);
+        factor        = x * x * (3 - 2 * x); // smoothstep (core/common.art:241)
+    }
+    DirectLightSample s;
+    s.pos          = pos;
+    s.dir          = out_dir;
+    s.intensity    = Color{ l.d[8] * factor, l.d[9] * factor, l.d[10] * factor };
+    s.pdf_value    = vec3_dot(to_surf, dir) > cosCutoffAngle ? 1.0f : 0.0f; // check_valid
+    s.pdf_is_area  = true;
+    s.pdf_is_delta = false;
+    s.cos          = -vec3_dot(out_dir, dir);
+    s.dist         = dist;
+    return s;
+}
+
+// make_directional_light.sample_direct (light/directional.art:6): make_delta_pdf -> value 1 in either measure
+static inline DirectLightSample sample_direct_directional(const ig_light& l, const SurfaceElement& from_surf, float scene_radius)
+{
+    const Vec3 dir = Vec3{ l.d[0], l.d[1], l.d[2] };
+    DirectLightSample s;
+    s.pos          = vec3_add(from_surf.point, vec3_mulf(dir, -scene_radius));
+    s.dir          = vec3_neg(dir);
+    s.intensity    = Color{ l.d[4], l.d[5], l.d[6] };
+    s.pdf_value    = 1;
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = true;
+    s.cos          = 1;
+    s.dist         = scene_radius;
+    return s;
+}
+
 static inline DirectLightSample sample_direct_point(const ig_light& l, const SurfaceElement& from_surf)
 {
     const Vec3 pos   = Vec3{ l.d[0], l.d[1], l.d[2] };
@@ -1013,6 +1059,15 @@ struct PathTracer {
         case IG_LIGHT_POINT:
             ls    = sample_direct_point(light, surf);
             delta = true;
+            break;
+        case IG_LIGHT_SPOT:
+            ls    = sample_direct_spot(light, surf);
+            delta = true;
+            break;
+        case IG_LIGHT_DIRECTIONAL:
+            ls       = sample_direct_directional(light, surf, sc.scene_radius);
+            delta    = true;
+            infinite = true;
             break;
         default:
             ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);

@@ -211,6 +211,25 @@ def test_analytic_integrator_answers(gpu_device):
     assert mean(flat_scene()) == pytest.approx(0, abs=1e-8)
     point = flat_scene([{"type": "point", "name": "_light", "position": [0, 0, -2], "power": 1}])
     assert mean(point) == pytest.approx(0.005100456, abs=1e-4)
+    spot = flat_scene([{"type": "spot", "name": "_light", "cutoff": 45, "falloff": 45, "position": [0, 0, -2], "direction": [0, 0, 1], "power": 1}])
+    assert mean(spot) == pytest.approx(0.0348280902, abs=2.5e-3)   # test_lights.py:25-36
+    sun = flat_scene([{"type": "directional", "name": "_light", "direction": [0.6, 0, 0.8], "irradiance": [2, 2, 2]}])
+    assert mean(sun) == pytest.approx(2 * 0.8 / np.pi, rel=1e-5)
+
+
+def test_spot_and_directional_lights_vs_oracle(gpu_device):
+    """Spot lights (in the light hierarchy, with a soft falloff band) and a directional light next to point lights."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s["lights"] = [l for l in s["lights"] if l["type"] != "env"][:4] + [
+        {"type": "spot", "name": "S1", "position": [0.8, 1.5, 0.8], "direction": [-0.4, -1, -0.4], "cutoff": 35, "falloff": 20, "intensity": [6, 5, 4]},
+        {"type": "spot", "name": "S2", "position": [-1.0, 0.5, 1.2], "direction": [1, -0.6, -1], "cutoff": 25, "falloff": 25, "power": [20, 20, 30]},
+        {"type": "directional", "name": "D", "direction": [0.3, -1, -0.2], "irradiance": [0.6, 0.6, 0.5]},
+    ]
+    for sel in ("uniform", "hierarchy"):
+        s["technique"]["light_selector"] = sel
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 128, 128)
+        _compare_with_oracle(gpu_device, sc, 128, 128, 4, seed=6)
 
 
 def test_trace_ray_list_mode(gpu_device, diamond_scene):

@@ -120,6 +120,21 @@ def test_point_light_known_answer():
     assert _mean(scene, spp=8, spi=4, size=(128, 128)) == pytest.approx(0.005100456, abs=1e-4)
 
 
+def test_spot_light_known_answer():
+    """test_lights.py:25-36: cutoff = falloff = 45 degrees, power 1 -> 0.005100456 * 4 pi / (2 pi (1 - cos 45)) = 0.0348280902
+    (the reference allows 2.5e-3 and notes a small residual error)."""
+    scene = flat_scene([{"type": "spot", "name": "_light", "cutoff": 45, "falloff": 45, "position": [0, 0, -2], "direction": [0, 0, 1], "power": 1}])
+    assert _mean(scene, spp=8, spi=4, size=(128, 128)) == pytest.approx(0.0348280902, abs=2.5e-3)
+
+
+def test_directional_light_analytic_answer():
+    """No reference test; analytic: irradiance 1 straight onto the white lambertian plane that fills the view -> 1 / pi."""
+    scene = flat_scene([{"type": "directional", "name": "_light", "direction": [0, 0, 1], "irradiance": [1, 1, 1]}])
+    assert _mean(scene, spp=4, spi=4, size=(64, 64)) == pytest.approx(1 / np.pi, rel=1e-5)
+    grazing = flat_scene([{"type": "directional", "name": "_light", "direction": [0.6, 0, 0.8], "irradiance": [2, 2, 2]}])
+    assert _mean(grazing, spp=4, spi=4, size=(64, 64)) == pytest.approx(2 * 0.8 / np.pi, rel=1e-5)
+
+
 def test_env_light_known_answer():
     scene = flat_scene([{"type": "env", "name": "_light", "radiance": [1, 1, 1]}])
     assert _mean(scene, spp=8, spi=8, size=(192, 192)) == pytest.approx(1, abs=2e-3)
