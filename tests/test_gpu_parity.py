@@ -502,3 +502,29 @@ def test_cpp_cli_matches_the_python_one(tmp_path):
     b, _ = _read_exr(str(tmp_path / "py.exr"))
     for c in "RGB":
         np.testing.assert_array_equal(a[c], b[c])
+
+
+def test_trace_cli_matches_camera_rays(tmp_path, diamond_scene):
+    """igtrace counterpart (src/frontend/trace/main.cpp): rays from a file, mean radiance per ray as text. Tracing the
+    camera's own rays with the tracer reproduces what the path tracer returns for explicit rays via Runtime.trace."""
+    import ignis_amd
+    import oracle
+    from ignis_amd import trace
+    W, H = diamond_scene.scene.film_width, diamond_scene.scene.film_height
+    cam, _ = oracle.generate_rays(diamond_scene, 1, W, H, 0, W * H, seed=1)
+    cam = cam[(H // 2) * W + W // 4:(H // 2) * W + W // 4 + 50]  # a stretch of the middle row (the border pixels look past the box)
+    with open(tmp_path / "rays.txt", "w") as f:
+        for r in cam[:50]:
+            f.write(" ".join(repr(float(x)) for x in r[:6]) + f" {float(r[6])!r}\n")   # tmax omitted -> unbounded
+    assert trace.main([os.path.join(SCENES, "diamond_scene.json"), "-i", str(tmp_path / "rays.txt"), "-o", str(tmp_path / "out.txt"),
+                       "--spp", "16", "--seed", "3"]) == 0
+    got = np.loadtxt(tmp_path / "out.txt")
+    assert got.shape == (50, 3) and np.isfinite(got).all() and got.max() > 0
+    opts = ignis_amd.RuntimeOptions.makeDefault(trace=True)
+    opts.SPI, opts.Seed = 1, 3
+    rays = [ignis_amd.Ray(r[0:3], r[3:6], float(r[6])) for r in cam[:50]]
+    with ignis_amd.loadFromFile(os.path.join(SCENES, "diamond_scene.json"), opts) as rt:
+        for _ in range(16):
+            ref = rt.trace(rays)
+        ref = ref / rt.SampleCount
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-9)
