@@ -528,3 +528,40 @@ def test_trace_cli_matches_camera_rays(tmp_path, diamond_scene):
             ref = rt.trace(rays)
         ref = ref / rt.SampleCount
     np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-9)
+
+
+def test_randomised_configurations_vs_oracle(monkeypatch):
+    """Seeded sweep over film sizes, spi, stream capacities and scheduling knobs (tail threshold / split / flights / row
+    sharding): every combination must give the oracle's image and counters."""
+    import oracle
+    from ignis_amd import Device
+    from ignis_amd.tables import LoadedScene
+    rng = np.random.default_rng(2024)
+    scene_files = ["diamond_scene.json", "many_point_lights_hip.json"]
+    for case in range(10):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        spi = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        cap = int(rng.choice([0, 0, spi * 64, spi * 257, 4096]))
+        stride = int(rng.choice([1, 1, 2, 3]))
+        offset = int(rng.integers(0, stride))
+        env = {"IGD_TAIL_THRESHOLD": str(int(rng.choice([0, 500, 5000, 1 << 20]))), "IGD_TAIL_SPLIT": str(int(rng.choice([0, 1, 4, 6]))),
+               "IGD_FLIGHTS": str(int(rng.choice([2, 4, 8]))), "IGD_ASYNC_TAIL": str(int(rng.choice([0, 1, 1])))}
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scene = LoadedScene.from_file(os.path.join(SCENES, scene_files[case % 2]), w, h)
+        seed = int(rng.integers(0, 1000))
+        dev = Device(0, acquire_stats=True, stream_capacity=cap)
+        fb, st = _render_gpu(dev, scene, spi, w, h, iters=2, seed=seed, row_offset=offset, row_stride=stride)
+        dev.close()
+        ref = np.zeros((h, w, 3), np.float32)
+        tot = {}
+        for it in range(2):
+            _, s = oracle.render(scene, spi, w, h, iteration=it, seed=seed, fb=ref, rows=(offset, stride))
+            for k, v in s.items():
+                tot[k] = tot.get(k, 0) + v
+        ctx = (case, w, h, spi, cap, offset, stride, env)
+        assert _rel_l2(fb, ref) <= RADIANCE_TOL or not ref.any(), ctx
+        if not ref.any():
+            assert not fb.any(), ctx
+        for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+            assert st[k] == tot[k], (k, ctx)
