@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
     __shared__ uint16_t s_perm[kShadeThreads];
     __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
     __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_bin[8], s_binoff[8]; // bounce rays of a window are written grouped by direction octant
+    __shared__ uint32_t s_bin[16], s_binoff[16]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             __syncthreads();
         }
 
-        if (tid < 8)
+        if (tid < 16)
             s_bin[tid] = 0; // (ordered against its use below by the barriers of the sort / of the previous append)
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
@@ -191,14 +191,16 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             if (!do_sort)
                 __syncthreads(); // s_bin was cleared above without a barrier in between
             if (out.bounce) {
-                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0);
+                // rays that continue through a specular (dielectric) vertex start inside or on a refractive object and
+                // walk its BVH first; the others cross the room: two populations with different traversal shapes
+                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0) | (out.b_inv_pdf == 0 ? 8 : 0);
                 brank = atomicAdd(&s_bin[bkey], 1u);
             }
             __syncthreads();
             if (tid == 0) {
                 // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
                 uint32_t tb = 0;
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 16; ++k) {
                     s_binoff[k] = tb;
                     tb += s_bin[k];
                 }
