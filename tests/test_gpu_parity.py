@@ -565,3 +565,23 @@ def test_randomised_configurations_vs_oracle(monkeypatch):
             assert not fb.any(), ctx
         for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
             assert st[k] == tot[k], (k, ctx)
+
+
+def test_device_reuse_across_sizes_and_scenes(diamond_scene):
+    """One device: film size, spi, stream capacity needs and the scene change between renders; each result equals a
+    fresh device's (nothing leaks from the chunks still in flight when the change arrives)."""
+    from ignis_amd import Device
+    from ignis_amd.tables import LoadedScene
+    other = LoadedScene.from_file(os.path.join(SCENES, "many_point_lights_hip.json"), 80, 60)
+    plan = [(diamond_scene, 64, 64, 4), (diamond_scene, 96, 32, 2), (other, 80, 60, 8), (diamond_scene, 33, 47, 1), (other, 64, 64, 4)]
+    dev = Device(0)
+    for scene, w, h, spi in plan:
+        got, _ = _render_gpu(dev, scene, spi, w, h, iters=2, seed=7)
+        fresh = Device(0)
+        want, _ = _render_gpu(fresh, scene, spi, w, h, iters=2, seed=7)
+        fresh.close()
+        np.testing.assert_array_equal(got, want)
+    dev.release_all()
+    got, _ = _render_gpu(dev, diamond_scene, 4, 64, 64, iters=1, seed=7)
+    assert got.any()
+    dev.close()
