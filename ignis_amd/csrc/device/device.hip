@@ -28,7 +28,7 @@ void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int gri
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
-void launch_secondary_end(QueueState* qs, int slot, hipStream_t stream);
+void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
@@ -145,6 +145,7 @@ struct igd_device {
     DevBuf<QueueState> qs_store;
     QueueState* host_store = nullptr; // pinned: one per flight, [kMaxFlights], [kMaxFlights + 1] per-round polling
     hipEvent_t poll_event[2] = {};
+    QueueState* host_store_dev = nullptr; // device-side address of host_store (mapped pinned memory)
     uint64_t chunk_seq     = 0;
     bool async_tail        = true; // IGD_ASYNC_TAIL=0: drain the side stream at the end of every igd_render
 
@@ -672,7 +673,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             SecondaryCols sec;
             uint32_t* deep_rays;
         };
-        auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid) {
+        auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror) {
             const PrimaryCols in = b.prim[in_slot];
             TraverseArgs ta{};
             ta.scene = d->dscene;
@@ -717,7 +718,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.inv_spi = inv;
             timed(3, on, [&] {
                 launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on);
-                launch_secondary_end(qs, in_slot ^ 1, on);
+                launch_secondary_end(qs, in_slot ^ 1, mirror, on);
             });
             d->stats.rounds++;
             d->stats.traverse_primary_launches++;
@@ -739,11 +740,9 @@ void render(igd_device* d, const igd_render_settings* rs)
                 run_tail = true;
                 break;
             }
-            launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid());
+            // size after this round -> pinned slot (round & 1), written by the round's last kernel itself
+            launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid(), d->host_store_dev + igd_device::kMaxFlights + (round & 1));
             in_slot ^= 1;
-            // size after this round -> pinned slot (round & 1)
-            QueueState* pin = d->host_store + igd_device::kMaxFlights + (round & 1);
-            HIP_CHECK(hipMemcpyAsync(pin, qs, sizeof(QueueState), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipEventRecord(d->poll_event[round & 1], st));
             if (round >= 1) {
                 const int r = round - 1;
@@ -812,7 +811,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             const int tg = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
             const int sg = std::max(1, std::min(d->shadeGrid(), (int)((live + 255) / 256)));
             for (int r = 0; r < rounds; ++r) {
-                launchRound(side, sb, in_slot, tg, sg);
+                launchRound(side, sb, in_slot, tg, sg, nullptr);
                 in_slot ^= 1;
             }
             tl.in       = sb.prim[in_slot];
@@ -1056,7 +1055,8 @@ igd_device* igd_create(const igd_setup* setup)
         constexpr int F = igd_device::kMaxFlights;
         d->qs_store.alloc(F);
         HIP_CHECK(hipMemset(d->qs_store.ptr, 0, F * sizeof(QueueState)));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 3) * sizeof(QueueState), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 3) * sizeof(QueueState), hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d->host_store_dev), d->host_store, 0));
         std::memset(d->host_store, 0, (F + 3) * sizeof(QueueState));
         for (auto& e : d->poll_event)
             HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

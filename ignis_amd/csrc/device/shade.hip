@@ -252,13 +252,20 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
 }
 
 // Runs after the shadow traversal of a round.
-__global__ void k_secondary_end(QueueState* qs, int slot)
+// `mirror` (optional) is host memory mapped into the device: the queue state of the finished round is written
+// there by this kernel, so the host never needs a copy-engine transfer between two rounds (a 64-byte
+// hipMemcpyAsync D2H put ~155 us of engine hand-over between the shadow traversal and the next round).
+__global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         qs->q[slot].secondary = 0;
         qs->work_counter[2] = 0;
         qs->work_counter[3] = 0;
         qs->deep_count      = 0;
+        if (mirror) {
+            *mirror = *qs;
+            __threadfence_system();
+        }
     }
 }
 
@@ -300,7 +307,10 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream)
 }
 
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream) { hipLaunchKernelGGL(k_round_end, dim3(1), dim3(64), 0, stream, qs, in_slot); }
-void launch_secondary_end(QueueState* qs, int slot, hipStream_t stream) { hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs, slot); }
+void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs, slot, mirror);
+}
 
 // Moves the surviving paths (the columns the tail kernel reads) out of a primary stream.
 __global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols dst, const uint32_t* __restrict__ count)
