@@ -8,9 +8,10 @@ A "step" is one render iteration (Runtime::step, src/runtime/Runtime.cpp:334-387
 BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path integrator,
 spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region.
 With N > 1 the camera samples are sharded with no data-path exchange and the framebuffers are
-reduced to rank 0 over RCCL once, inside the timed region. Default partition: whole-film iterations (rank r
-renders iterations r, r+N, ...: per-GPU work stays one full iteration per step, "weak"); `--sharding rows`
-splits every iteration by interleaved film rows instead (rank r renders rows r, r+N, ...: "strong").
+reduced to rank 0 over RCCL once, inside the timed region. Default partition: film rows (rank r renders rows
+r, r+N, ... of every iteration, N iterations per wavefront so that launches stay as large as on one GPU; the sum
+of the shards is the single-GPU image bit for bit; "strong": K steps = K iterations of the film whatever N is).
+`--sharding iterations` gives rank r the whole-film iterations r, r+N, ... instead ("weak": N x K iterations).
 
 Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts
 them (src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the
@@ -41,7 +42,8 @@ def parse():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spi", type=int, default=SPI)
-    ap.add_argument("--sharding", choices=("iterations", "rows"), default="iterations", help="N > 1: how camera samples are split")
+    ap.add_argument("--sharding", choices=("rows", "iterations"), default="rows", help="N > 1: how camera samples are split")
+    ap.add_argument("--as-rank-of", type=int, default=0, help="experiments only: one process renders what rank 0 of N row-sharding ranks would (estimate of per-GPU throughput at N GPUs)")
     ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
     return ap.parse_args()
 
@@ -88,16 +90,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    by_rows = world > 1 and args.sharding == "rows"
+    by_rows = (world > 1 and args.sharding == "rows") or args.as_rank_of > 1
+    shards = args.as_rank_of if args.as_rank_of > 1 else world
+    # Row sharding leaves every rank 1 / N of an iteration: N iterations are rendered as one wavefront per call
+    # (igd_render_settings.iterations, bit-identical to N single calls) so that a launch stays as large as on one GPU.
+    batch = shards if by_rows else 1
 
-    def step(it):
+    def step(it, count=1):
         if by_rows:
-            dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=world)
+            dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=shards, iterations=count)
         else:
             dev.render(spi, W, H, iteration=it * world + rank, seed=SEED)  # ignis_amd.sharding.shard_iterations
 
-    for it in range(args.warmup):
-        step(it)
+    def run(steps):
+        it = 0
+        while it < steps:
+            c = min(batch, steps - it)
+            step(it, c)
+            it += c
+
+    run(args.warmup)
     dev.clear_framebuffer()
     dev.reset_stats()
 
@@ -110,8 +122,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(it)  # returns once the wavefront rounds are done; the tail paths + resolve of step i overlap step i + 1
+    run(args.steps)  # a call returns once its wavefront rounds are done; its tail paths + resolve overlap the next call
     dev.synchronize()  # everything submitted above is finished before the clock stops (and before the reduce)
     if dist is not None:
         # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
@@ -143,7 +154,7 @@ def main():
         cdev = Device(local_rank, acquire_stats=2)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
-        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank if by_rows else 0, row_stride=world if by_rows else 1)
+        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank if by_rows else 0, row_stride=shards if by_rows else 1, iterations=batch)
         cs = cdev.stats()
         cdev.close()
         n_primary = cs["camera_rays"] + cs["bounce_rays"]
@@ -202,7 +213,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps * (1 if by_rows else world)} iterations, seed {SEED}",
-                       "sharding": "whole film" if world == 1 else (f"film rows interleaved over {world} GPUs + one RCCL reduce" if by_rows else
+                       "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs, {batch} iterations per wavefront, + one RCCL reduce" if by_rows else
                                                                     f"{args.steps} full-film iterations per GPU (iteration i*{world}+rank) + one RCCL reduce")},
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},

@@ -574,10 +574,12 @@ void render(igd_device* d, const igd_render_settings* rs)
         finish(d); // the side stream may still be resolving into the old framebuffer
     resizeFb(d, rs->width, rs->height);
 
-    const int local_rows = (rs->height - row_offset + row_stride - 1) / row_stride;
-    const int64_t total  = (int64_t)local_rows * rs->width * rs->spi;
+    const int local_rows  = (rs->height - row_offset + row_stride - 1) / row_stride;
+    const int iterations  = list_mode ? 1 : std::max(1, rs->iterations);
+    const int64_t per_it  = (int64_t)local_rows * rs->width * rs->spi; // rays of one iteration
+    const int64_t total   = per_it * iterations;
     if (total >= ((int64_t)1 << 31))
-        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: width * height * spi must stay below 2^31" };
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: width * height * spi * iterations must stay below 2^31" };
     if (d->streamsTooSmall((size_t)std::max<int64_t>(total, 256)))
         finish(d);
     d->ensureStreams((size_t)std::max<int64_t>(total, 256));
@@ -606,10 +608,13 @@ void render(igd_device* d, const igd_render_settings* rs)
     if (d->events_used > 8192)
         finish(d); // keeps the timer event pool bounded when nobody asks for the statistics
 
-    // chunk the iteration's ray ids so that every pixel's samples stay together
-    const int64_t chunk_rays = ((int64_t)d->capacity / rs->spi) * rs->spi;
+    // Chunk the call's ray ids so that every pixel's samples stay together and a chunk is either a number of whole
+    // iterations (resolved per pixel, iteration after iteration) or at most one iteration's worth of pixels (all distinct).
+    int64_t chunk_rays = ((int64_t)d->capacity / rs->spi) * rs->spi;
     if (chunk_rays <= 0)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
+    if (per_it > 0 && chunk_rays >= per_it)
+        chunk_rays = (chunk_rays / per_it) * per_it;
 
     d->fb_host_dirty = true;
     for (int64_t first = 0; first < total; first += chunk_rays) {
@@ -659,11 +664,12 @@ void render(igd_device* d, const igd_render_settings* rs)
         ga.row_offset     = row_offset;
         ga.row_stride     = row_stride;
         ga.first_local_id = first;
+        ga.rays_per_iteration = (int32_t)std::max<int64_t>(per_it, 1);
         ga.n              = n;
         ga.list_rays      = list_mode ? d->list_rays.ptr : nullptr;
         timed(0, st, [&] { launch_generate(ga, st); });
 
-        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride };
+        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1) };
         uint32_t live          = n;
         bool run_tail          = false;
         // One bounce round on stream `on` over the given stream buffers: closest-hit traversal (K2) -> sort +
@@ -863,6 +869,8 @@ void render(igd_device* d, const igd_render_settings* rs)
         ra.row_stride        = row_stride;
         ra.first_local_pixel = first / rs->spi;
         ra.pixels            = n / (uint32_t)rs->spi;
+        ra.local_pixels      = (uint32_t)std::max<int64_t>(per_it / rs->spi, 1);
+        ra.iterations        = (per_it > 0 && (int64_t)n > per_it) ? (uint32_t)((int64_t)n / per_it) : 1u; // whole iterations, see the chunking above
         // framebuffer updates stay in chunk order (pixels of successive iterations coincide, and the float sum
         // must not depend on which tail finished first)
         if (prev.used && &prev != &fl)

@@ -122,6 +122,7 @@ struct GenerateArgs {
     int32_t iteration, frame, seed;
     int32_t row_offset, row_stride; // tile sharding: local row r -> film row row_offset + r * row_stride
     int64_t first_local_id;         // first local ray id of this chunk
+    int32_t rays_per_iteration;     // local pixels * spi (multi-iteration calls: iteration += id / rays_per_iteration)
     uint32_t n;                     // rays to generate
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
 };
@@ -130,6 +131,7 @@ struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-
     int32_t width, spi;
     int32_t iteration, frame, seed;
     int32_t row_offset, row_stride;
+    int32_t rays_per_iteration; // local pixels * spi: ray ids of a multi-iteration call continue across iterations
 };
 
 struct ShadeArgs {
@@ -175,8 +177,10 @@ struct ResolveArgs {
     float* fb;
     int32_t width, spi;
     int32_t row_offset, row_stride;
-    int64_t first_local_pixel; // local pixel index of accum[0]
-    uint32_t pixels;
+    int64_t first_local_pixel; // local (virtual) pixel index of accum[0]
+    uint32_t pixels;           // virtual pixels in accum (a pixel of iteration k of the call is virtual pixel k * local_pixels + p)
+    uint32_t local_pixels;     // pixels of one iteration
+    uint32_t iterations;       // > 1: accum holds that many whole iterations, one thread sums a pixel's iterations in order
 };
 
 } // namespace igdev

@@ -33,12 +33,14 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
 
     // gpu_generate_rays id convention: ray id = pixel * spi + sample, linear over the film
     const int64_t lid     = a.first_local_id + i;
-    const int sample      = (int)(lid % a.spi);
-    const int64_t lpixel  = lid / a.spi;
+    const int it_local    = (int)(lid / a.rays_per_iteration); // multi-iteration call: which of its iterations
+    const int64_t within  = lid % a.rays_per_iteration;
+    const int sample      = (int)(within % a.spi);
+    const int64_t lpixel  = within / a.spi;
     const int x           = (int)(lpixel % a.width);
     const int y           = a.row_offset + (int)(lpixel / a.width) * a.row_stride;
 
-    Tea rnd{ make_seed(sample, a.iteration, a.frame, x, y, a.seed), 1 };
+    Tea rnd{ make_seed(sample, a.iteration + it_local, a.frame, x, y, a.seed), 1 };
     f3 org, dir;
     float tmin, tmax;
     uint32_t flags;
@@ -276,9 +278,32 @@ __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
 __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.iterations > 1) {
+        // the chunk holds whole iterations: one thread per pixel adds them one after the other, which is exactly what
+        // that many single-iteration resolves would have done to this pixel
+        if (i >= a.local_pixels)
+            return;
+        const int x = (int)(i % (uint32_t)a.width);
+        const int y = a.row_offset + (int)(i / (uint32_t)a.width) * a.row_stride;
+        float* dst  = a.fb + ((size_t)y * a.width + x) * 3;
+        float fr = dst[0], fg = dst[1], fbb = dst[2];
+        for (uint32_t it = 0; it < a.iterations; ++it) {
+            const float4* src = a.accum + ((size_t)it * a.local_pixels + i) * a.spi;
+            float r = 0, g = 0, b = 0;
+            for (int s = 0; s < a.spi; ++s) {
+                const float4 v = src[s];
+                r += v.x;
+                g += v.y;
+                b += v.z;
+            }
+            fr += r, fg += g, fbb += b;
+        }
+        dst[0] = fr, dst[1] = fg, dst[2] = fbb;
+        return;
+    }
     if (i >= a.pixels)
         return;
-    const int64_t lp = a.first_local_pixel + i;
+    const int64_t lp = (a.first_local_pixel + i) % a.local_pixels; // a chunk of at most one iteration's pixels: all distinct
     const int x      = (int)(lp % a.width);
     const int y      = a.row_offset + (int)(lp / a.width) * a.row_stride;
     const float4* src = a.accum + (size_t)i * a.spi;

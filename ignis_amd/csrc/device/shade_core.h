@@ -783,11 +783,13 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const f3 out_dir = -in.dir;
 
     // RNG resumes where the path left off (mapping_gpu.art:171)
-    const int sample = in.ray_id % fr.spi;
-    const int lpix   = in.ray_id / fr.spi;
+    const int it_l   = in.ray_id / fr.rays_per_iteration; // multi-iteration call: which of its iterations
+    const int within = in.ray_id % fr.rays_per_iteration;
+    const int sample = within % fr.spi;
+    const int lpix   = within / fr.spi;
     const int px     = lpix % fr.width;
     const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
-    Tea rnd{ make_seed(sample, fr.iteration, fr.frame, px, py, fr.seed), in.rnd };
+    Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
     // ---- on_hit (technique/pathtracer.art:119-139): emission with MIS
     if (mat.light_id >= 0 && surf.entering) {

@@ -19,7 +19,7 @@ class Setup(C.Structure):
 class RenderSettings(C.Structure):
     _fields_ = [("rays", C.POINTER(C.c_float)), ("spi", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("iteration", C.c_int32), ("frame", C.c_int32), ("user_seed", C.c_int32),
-                ("row_offset", C.c_int32), ("row_stride", C.c_int32)]
+                ("row_offset", C.c_int32), ("row_stride", C.c_int32), ("iterations", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -148,9 +148,9 @@ class Device:
         """scene: ignis_amd.tables.LoadedScene (or anything with a `.tables` igd_scene pointer)."""
         _check(lib().igd_assign_scene(self._h, scene.tables))
 
-    def render(self, spi, width, height, iteration=0, frame=0, seed=0, rays=None, row_offset=0, row_stride=1):
+    def render(self, spi, width, height, iteration=0, frame=0, seed=0, rays=None, row_offset=0, row_stride=1, iterations=1):
         rs = RenderSettings(None, int(spi), int(width), int(height), int(iteration), int(frame), int(seed),
-                            int(row_offset), int(row_stride))
+                            int(row_offset), int(row_stride), int(iterations))
         keep = None
         if rays is not None:
             keep = np.ascontiguousarray(rays, dtype=np.float32)

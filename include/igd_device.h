@@ -57,6 +57,10 @@ typedef struct igd_render_settings {
     int32_t width, height;
     int32_t iteration, frame, user_seed;
     int32_t row_offset, row_stride;
+    /* > 1: this call renders the iterations iteration, iteration + 1, ... as one wavefront (ray id = ((it * pixels + pixel)
+     * * spi + sample)). The result is bit-identical to that many single-iteration calls; the point is efficiency when one
+     * iteration is too small to fill the GPU (small films, row-sharded films). 0 or 1: one iteration, as the reference. */
+    int32_t iterations;
 } igd_render_settings;
 
 /* Statistics (src/runtime/Statistics.h:57-64 quantities + ShaderType timers). */

@@ -585,3 +585,24 @@ def test_device_reuse_across_sizes_and_scenes(diamond_scene):
     got, _ = _render_gpu(dev, diamond_scene, 4, 64, 64, iters=1, seed=7)
     assert got.any()
     dev.close()
+
+
+@pytest.mark.parametrize("cap", [0, 4096, 64 * 48 * 2 * 2, 5000])
+def test_multi_iteration_call_equals_single_iterations(diamond_scene, cap):
+    """igd_render_settings.iterations = 5: one wavefront over five iterations (what keeps small or row-sharded films
+    efficient) gives bit for bit the image and the counters of five single-iteration calls, whatever the chunking."""
+    from ignis_amd import Device
+    w, h, spi = 64, 48, 2
+    a = Device(0, acquire_stats=True, stream_capacity=cap)
+    ref, ref_st = _render_gpu(a, diamond_scene, spi, w, h, iters=5, seed=21, row_offset=1, row_stride=2)
+    a.close()
+    b = Device(0, acquire_stats=True, stream_capacity=cap)
+    b.assign_scene(diamond_scene)
+    b.resize(w, h)
+    b.render(spi, w, h, iteration=0, seed=21, row_offset=1, row_stride=2, iterations=2)
+    b.render(spi, w, h, iteration=2, seed=21, row_offset=1, row_stride=2, iterations=3)
+    got, st = b.framebuffer(), b.stats()
+    b.close()
+    np.testing.assert_array_equal(got, ref)
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+        assert st[k] == ref_st[k], k
