@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="iterations rendered as one wavefront per call (0 = as many as fill the GPU, 1 = like the reference)")
     ap.add_argument("--stats", action="store_true", help="acquire ray statistics and stage timers")
     ap.add_argument("--full-stats", action="store_true", help="also count traversal work (slower kernels)")
     args = ap.parse_args(argv)
@@ -50,14 +51,16 @@ def main(argv=None):
         print(f"Given spp {args.spp} is not a multiple of the spi {spi}. Using spp {desired_iter * spi} instead", file=sys.stderr)
     print("Started rendering...", file=sys.stderr)
     samples_sec, t_render = [], 0.0
+    batch = args.batch if args.batch > 0 else rt.recommendedBatch()
     while True:
+        count = batch if desired_iter <= 0 else min(batch, desired_iter - rt.IterationCount)
         t0 = time.perf_counter()
-        rt.step()
-        rt._device.synchronize()  # per-iteration timing like the reference's blocking step()
+        rt.stepMany(count)
+        rt._device.synchronize()  # per-call timing like the reference's blocking step()
         dt = time.perf_counter() - t0
         t_render += dt
-        samples_sec.append(spi * rt.FramebufferWidth * rt.FramebufferHeight / dt)
-        if desired_iter > 0 and len(samples_sec) == desired_iter:
+        samples_sec += [spi * rt.FramebufferWidth * rt.FramebufferHeight * count / dt] * count
+        if desired_iter > 0 and rt.IterationCount >= desired_iter:
             break
         if args.time is not None and t_render > args.time:
             break

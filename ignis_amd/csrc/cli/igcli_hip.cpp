@@ -98,16 +98,21 @@ int main(int argc, char** argv)
     std::fprintf(stderr, "Started rendering...\n");
     std::vector<double> samples_sec;
     double t_render = 0;
-    for (int it = 0; rc == IGD_OK && it < desired_iter; ++it) {
+    // several iterations per call when one does not fill the GPU (igd_render_settings.iterations, bit-identical results)
+    const int batch = std::max(1, std::min(64, (1 << 24) / std::max(1, width * height * spi)));
+    for (int it = 0; rc == IGD_OK && it < desired_iter;) {
+        const int count = std::min(batch, desired_iter - it);
         const double t0 = now_ms();
         igd_render_settings rs{};
-        rs.spi = spi, rs.width = width, rs.height = height, rs.iteration = it, rs.user_seed = seed, rs.row_stride = 1;
+        rs.spi = spi, rs.width = width, rs.height = height, rs.iteration = it, rs.user_seed = seed, rs.row_stride = 1, rs.iterations = count;
         rc = igd_render(dev, &rs);
         if (rc == IGD_OK)
-            rc = igd_synchronize(dev); // per-iteration timing like the reference's blocking step()
+            rc = igd_synchronize(dev); // per-call timing like the reference's blocking step()
         const double dt = now_ms() - t0;
         t_render += dt;
-        samples_sec.push_back(1000.0 * double(spi) * width * height / dt);
+        for (int k = 0; k < count; ++k)
+            samples_sec.push_back(1000.0 * double(spi) * width * height * count / dt);
+        it += count;
     }
     if (rc != IGD_OK) {
         std::fprintf(stderr, "%s\n", igd_last_error());

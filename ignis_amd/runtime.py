@@ -108,6 +108,22 @@ class Runtime:
         self._samples += self._spi
         self._iteration += 1
 
+    # -- several iterations as one wavefront (igd_render_settings.iterations): bit-identical to `count` step() calls, but
+    # the launches are `count` times larger — what a small film needs to fill the GPU
+    def stepMany(self, count):
+        if self._opts.IsTracer:
+            raise RuntimeError("Trying to use step() in a trace driver!")
+        count = max(1, int(count))
+        self._device.render(self._spi, self._width, self._height, iteration=self._iteration, frame=self._frame, seed=self._opts.Seed,
+                            row_offset=self._opts.RowOffset, row_stride=self._opts.RowStride, iterations=count)
+        self._samples += self._spi * count
+        self._iteration += count
+
+    def recommendedBatch(self):
+        """Iterations per call that make a call about as large as a full 1080p iteration at spi 8 (16.6 M camera rays)."""
+        rays = self._width * self._height * self._spi / max(1, self._opts.RowStride)
+        return int(max(1, min(64, (1 << 24) // max(1, int(rays)))))
+
     # -- Runtime::trace (Runtime.cpp:389-446): returns (n, 3) radiance, accumulated over calls
     def trace(self, rays):
         if not self._opts.IsTracer:
