@@ -92,24 +92,21 @@ def main():
 
     by_rows = (world > 1 and args.sharding == "rows") or args.as_rank_of > 1
     shards = args.as_rank_of if args.as_rank_of > 1 else world
-    # Row sharding leaves every rank 1 / N of an iteration: N iterations are rendered as one wavefront per call
-    # (igd_render_settings.iterations, bit-identical to N single calls) so that a launch stays as large as on one GPU.
-    batch = shards if by_rows else 1
+    # One igd_render per iteration, like Runtime::step. The device executes consecutive iterations as one wavefront
+    # (up to 2^27 camera rays, bit-identical to executing them one by one): that is what keeps a
+    # row-sharded rank, which owns 1 / N of every iteration, as efficient as a whole film on one GPU.
 
-    def step(it, count=1):
+    def step(on, it):
         if by_rows:
-            dev.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=shards, iterations=count)
+            on.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=shards)
         else:
-            dev.render(spi, W, H, iteration=it * world + rank, seed=SEED)  # ignis_amd.sharding.shard_iterations
+            on.render(spi, W, H, iteration=it * world + rank, seed=SEED)  # ignis_amd.sharding.shard_iterations
 
-    def run(steps):
-        it = 0
-        while it < steps:
-            c = min(batch, steps - it)
-            step(it, c)
-            it += c
+    def run(on, steps):
+        for it in range(steps):
+            step(on, it)
 
-    run(args.warmup)
+    run(dev, args.warmup)
     dev.clear_framebuffer()
     dev.reset_stats()
 
@@ -122,7 +119,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)  # a call returns once its wavefront rounds are done; its tail paths + resolve overlap the next call
+    run(dev, args.steps)  # calls return at once or when a wavefront's rounds are done; tails + resolves overlap the next one
     dev.synchronize()  # everything submitted above is finished before the clock stops (and before the reduce)
     if dist is not None:
         # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
@@ -154,7 +151,7 @@ def main():
         cdev = Device(local_rank, acquire_stats=2)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
-        cdev.render(spi, W, H, iteration=0, seed=SEED, row_offset=rank if by_rows else 0, row_stride=shards if by_rows else 1, iterations=batch)
+        run(cdev, args.steps)
         cs = cdev.stats()
         cdev.close()
         n_primary = cs["camera_rays"] + cs["bounce_rays"]
@@ -213,7 +210,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps * (1 if by_rows else world)} iterations, seed {SEED}",
-                       "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs, {batch} iterations per wavefront, + one RCCL reduce" if by_rows else
+                       "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs + one RCCL reduce" if by_rows else
                                                                     f"{args.steps} full-film iterations per GPU (iteration i*{world}+rank) + one RCCL reduce")},
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},
