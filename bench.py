@@ -81,7 +81,10 @@ def main():
 
     W, H, spi = args.width, args.height, args.spi
     scene = LoadedScene.from_file(args.scene, W, H)
-    dev = Device(local_rank, acquire_stats=0 if args.no_stage_timers else 1)
+    # streams sized once for a full batch of iterations (2^27 camera rays, ~39 GB): the warm-up then pays for the
+    # allocation (and for the driver's scrubbing of memory a previous process just released), not the timed region
+    CAPACITY = 1 << 27
+    dev = Device(local_rank, acquire_stats=0 if args.no_stage_timers else 1, stream_capacity=CAPACITY)
     dev.assign_scene(scene)
     dev.resize(W, H)
 
@@ -104,7 +107,10 @@ def main():
 
     def run(on, steps):
         for it in range(steps):
+            t = time.perf_counter()
             step(on, it)
+            if os.environ.get("BENCH_TRACE") and time.perf_counter() - t > 0.005:
+                print(f"[trace] call {it}: {(time.perf_counter() - t) * 1e3:.1f} ms", file=sys.stderr, flush=True)
 
     run(dev, args.warmup)
     warm = dev.stats()  # (profilers see the warm-up launches too: their average is reported next to the timed one)
@@ -121,7 +127,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(dev, args.steps)  # calls return at once or when a wavefront's rounds are done; tails + resolves overlap the next one
+    t_sync = time.perf_counter()
     dev.synchronize()  # everything submitted above is finished before the clock stops (and before the reduce)
+    if os.environ.get("BENCH_TRACE"):
+        print(f"[trace] loop {(t_sync - t0) * 1e3:.1f} ms, final synchronize {(time.perf_counter() - t_sync) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     if dist is not None:
         # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
         # a rank does not own are zero)
@@ -149,7 +158,7 @@ def main():
         launches = max(1, st["traverse_primary_launches"])
         avg_ms = st["ms_traverse_primary"] / launches
         # units per launch: replay the same steps with the work counters on (deterministic workload)
-        cdev = Device(local_rank, acquire_stats=2)
+        cdev = Device(local_rank, acquire_stats=2, stream_capacity=CAPACITY)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
         run(cdev, args.steps)

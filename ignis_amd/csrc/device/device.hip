@@ -249,8 +249,10 @@ struct igd_device {
 
     size_t wantedCapacity(size_t needed) const
     {
-        size_t cap = setup.stream_capacity ? (size_t)setup.stream_capacity : std::max<size_t>((size_t)1 << 24, (size_t)batch_rays);
-        cap        = std::min(cap, needed);
+        // an explicit igd_setup.stream_capacity is allocated as given, once (no reallocation when larger batches arrive);
+        // otherwise the streams grow with the largest request, up to what one batch can hold
+        size_t cap = setup.stream_capacity ? (size_t)setup.stream_capacity
+                                           : std::min(std::max<size_t>((size_t)1 << 24, (size_t)batch_rays), needed);
         return (cap + 255) & ~(size_t)255;
     }
     bool streamsTooSmall(size_t needed) const { return !(wantedCapacity(needed) <= capacity && primary[0].ptr); }

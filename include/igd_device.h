@@ -44,7 +44,9 @@ typedef struct igd_setup {
     int32_t acquire_stats;  /* 0 off, 1 per-stage HIP-event timers, 2 timers + traversal work counters */
     int32_t debug_trace;
     int32_t is_interactive;
-    uint64_t stream_capacity; /* rays in flight; 0 = default (reference: 1 048 576, mapping_gpu.art:1119) */
+    uint64_t stream_capacity; /* rays in flight, allocated as given at the first render; 0 = grow with the largest request up to
+                               * one batch of iterations (2^27 rays); larger requests run in chunks (reference: 1 048 576,
+                               * mapping_gpu.art:1119) */
 } igd_setup;
 
 /* IRenderDevice::RenderSettings (IRenderDevice.h:30-40). `rays` != NULL selects the
