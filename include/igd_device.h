@@ -149,13 +149,15 @@ int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value);
 int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value);
 int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float value[3]);
 
-/* igd_render returns once the wavefront rounds of its last chunk are done; that chunk's long-path tail
- * and its framebuffer resolve may still be running on a second HIP stream, overlapping the next
- * igd_render (the reference's render() is followed by getFramebufferForHost(), which is where it syncs,
- * Device.cpp:1385-1425). Every accessor below/above that reads results (framebuffer_host/_device, get_stats,
- * clear, resize, assign_scene, traverse) drains that work first; igd_synchronize does only that, and is
- * where an error of the overlapped part (e.g. a stack overflow inside the tail kernel) is reported if no
- * other call has surfaced it yet. IGD_ASYNC_TAIL=0 in the environment makes igd_render fully blocking. */
+/* igd_render validates its arguments and records the request; consecutive iterations of the same film, spi, seed and
+ * sharding are executed together as one wavefront of up to 2^27 camera rays (the result is bit-identical to executing each
+ * call on its own; IGD_BATCH_RAYS=0 in the environment or igd_setup.is_interactive make every call execute immediately).
+ * The long-path tail and the framebuffer resolve of a wavefront run on other HIP streams under the next one (the
+ * reference's render() is followed by getFramebufferForHost(), which is where it syncs, Device.cpp:1385-1425). Every
+ * accessor that reads results (framebuffer_host/_device, get_stats, clear, resize, assign_scene, traverse), a parameter
+ * change and igd_synchronize execute and drain what is pending; igd_synchronize does only that, and is where an error of
+ * deferred or overlapped work (e.g. a traversal stack overflow) is reported if no other call has surfaced it yet.
+ * IGD_ASYNC_TAIL=0 keeps the tail on the critical path. */
 int32_t igd_synchronize(igd_device* dev);
 
 /* Thread-local message of the last failed igd_* call ("" if none). */
