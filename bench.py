@@ -9,7 +9,7 @@ BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path 
 spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region.
 With N > 1 the camera samples are sharded with no data-path exchange and the framebuffers are
 reduced to rank 0 over RCCL once, inside the timed region. Default partition: whole-film iterations (rank r renders
-iterations r, r+N, ...: K steps per GPU, N x K iterations in total, "weak"). `--sharding rows` tile-shards the film
+iterations r*K .. r*K+K-1: K steps per GPU, N x K iterations in total, "weak"). `--sharding rows` tile-shards the film
 instead (rank r renders rows r, r+N, ... of every iteration; the device batches the small per-rank iterations into
 full-size wavefronts; the sum of the shards is the single-GPU image bit for bit; "strong": K iterations in total,
 which leaves each of 8 GPUs only K / 8 iterations' worth of work — 6.4x at K = 16, 7.9x from K = 64).
@@ -100,11 +100,13 @@ def main():
     # (up to 2^27 camera rays, bit-identical to executing them one by one): that is what keeps a
     # row-sharded rank, which owns 1 / N of every iteration, as efficient as a whole film on one GPU.
 
+    steps_per_rank = max(args.steps, args.warmup)  # a rank's iterations are consecutive, so the device can batch them
+
     def step(on, it):
         if by_rows:
             on.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=shards)
         else:
-            on.render(spi, W, H, iteration=it * world + rank, seed=SEED)  # ignis_amd.sharding.shard_iterations
+            on.render(spi, W, H, iteration=rank * steps_per_rank + it, seed=SEED)  # ignis_amd.sharding.shard_iterations
 
     def run(on, steps):
         for it in range(steps):
@@ -227,7 +229,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps * (1 if by_rows else world)} iterations, seed {SEED}",
                        "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs + one RCCL reduce" if by_rows else
-                                                                    f"{args.steps} full-film iterations per GPU (iteration i*{world}+rank) + one RCCL reduce")},
+                                                                    f"{args.steps} full-film iterations per GPU (rank r: iterations r*K .. r*K+K-1) + one RCCL reduce")},
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},
             "stage_ms_rank0": stage_ms,

@@ -2,7 +2,7 @@
 
 Two partitions of the same unit (camera samples), both exact up to float summation order:
   * rows:       rank r of G renders film rows r, r+G, r+2G, ... of every iteration (strong scaling of one image)
-  * iterations: rank r renders whole-film iterations r, r+G, r+2G, ... (the per-sample RNG depends on the iteration
+  * iterations: rank r renders the whole-film iterations r*K .. r*K + K - 1 of G*K (the per-sample RNG depends on the iteration
                 index, core/random.art:34-43, so the union is the single-device sample set; per-GPU work stays a
                 full iteration however many GPUs take part — the partition to use when the image is small)
 
@@ -27,10 +27,11 @@ def shard_settings(rank, world):
 
 
 def shard_iterations(rank, world, steps):
-    """Global iteration indices rendered by `rank` when every rank runs `steps` steps."""
+    """Global iteration indices rendered by `rank` when every rank runs `steps` steps: a contiguous block, so that the
+    device can execute a rank's consecutive iterations as one wavefront (igd_device.h, deferred batching)."""
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
-    return [rank + world * i for i in range(steps)]
+    return [rank * steps + i for i in range(steps)]
 
 
 def reduce_framebuffer(fb, dist, dst=0):

@@ -89,7 +89,7 @@ def test_two_rank_iteration_sharding_sums_to_the_single_process_image(tmp_path):
     for it in range(4):
         _, st = oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=ref)
         rays += st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
-    np.testing.assert_allclose(got["fb"], ref, rtol=2e-5, atol=1e-6)  # (i0 + i2) + (i1 + i3) vs ((i0 + i1) + i2) + i3
+    np.testing.assert_allclose(got["fb"], ref, rtol=2e-5, atol=1e-6)  # (i0 + i1) + (i2 + i3) vs ((i0 + i1) + i2) + i3
     assert int(got["rays"][0]) == rays
 
 
