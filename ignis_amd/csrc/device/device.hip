@@ -1252,8 +1252,9 @@ int32_t igd_release_all(igd_device* dev)
     });
 }
 
-int32_t igd_framebuffer_width(const igd_device* dev) { return dev ? dev->fb_w : 0; }
-int32_t igd_framebuffer_height(const igd_device* dev) { return dev ? dev->fb_h : 0; }
+// (a recorded but not yet executed request already determines the size of the framebuffer)
+int32_t igd_framebuffer_width(const igd_device* dev) { return dev ? (dev->pending.active ? dev->pending.rs.width : dev->fb_w) : 0; }
+int32_t igd_framebuffer_height(const igd_device* dev) { return dev ? (dev->pending.active ? dev->pending.rs.height : dev->fb_h) : 0; }
 
 const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t sync)
 {
@@ -1263,10 +1264,10 @@ const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t syn
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
         if (!isColorName(name))
             throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" }; // Device.cpp:1391-1395
-        if (!dev->fb.ptr)
-            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (render or resize first)" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
+        if (!dev->fb.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (render or resize first)" };
         if (sync && dev->fb_host_dirty) {
             HIP_CHECK(hipMemcpy(dev->fb_host.data(), dev->fb.ptr, dev->fb_host.size() * sizeof(float), hipMemcpyDeviceToHost));
             dev->fb_host_dirty = false;
@@ -1315,10 +1316,10 @@ int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const 
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
         if (!isColorName(name))
             throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
-        if (!dev->fb.ptr)
-            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (resize first)" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
+        if (!dev->fb.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (resize first)" };
         HIP_CHECK(hipMemcpy(dev->fb.ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
         dev->fb_host_dirty = true;
     });

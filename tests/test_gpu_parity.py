@@ -606,3 +606,15 @@ def test_multi_iteration_call_equals_single_iterations(diamond_scene, cap):
     np.testing.assert_array_equal(got, ref)
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
         assert st[k] == ref_st[k], k
+
+
+def test_render_without_resize_then_read(diamond_scene):
+    """A deferred igd_render already determines the framebuffer: size queries and the first read work without a resize."""
+    from ignis_amd import Device
+    dev = Device(0)
+    dev.assign_scene(diamond_scene)
+    dev.render(2, 40, 30, iteration=0, seed=1)
+    assert dev.framebuffer_size() == (40, 30)
+    fb = dev.framebuffer()
+    assert fb.shape == (30, 40, 3) and fb.any()
+    dev.close()
