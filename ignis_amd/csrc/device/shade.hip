@@ -275,49 +275,61 @@ __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
 
 // fb[pixel] += sum over samples of the per-sample accumulator, in sample order. The reference adds
 // `color / spi` per event (driver/accumulator.art:4-30); the accumulators already hold those products.
+// One workgroup handles tiles of kResolveFloat4 / spi pixels: the tile's accumulators are one contiguous run, loaded
+// coalesced into LDS (a thread reading its pixel's spi slots directly strides 16 * spi bytes between lanes and fetched
+// every line three times from HBM), then one thread per pixel adds its samples in order, iteration after iteration.
+constexpr int kResolveFloat4 = 2048; // 32 KiB of LDS
+
 __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a.iterations > 1) {
-        // the chunk holds whole iterations: one thread per pixel adds them one after the other, which is exactly what
-        // that many single-iteration resolves would have done to this pixel
-        if (i >= a.local_pixels)
-            return;
-        const int x = (int)(i % (uint32_t)a.width);
-        const int y = a.row_offset + (int)(i / (uint32_t)a.width) * a.row_stride;
-        float* dst  = a.fb + ((size_t)y * a.width + x) * 3;
-        float fr = dst[0], fg = dst[1], fbb = dst[2];
-        for (uint32_t it = 0; it < a.iterations; ++it) {
-            const float4* src = a.accum + ((size_t)it * a.local_pixels + i) * a.spi;
-            float r = 0, g = 0, b = 0;
-            for (int s = 0; s < a.spi; ++s) {
-                const float4 v = src[s];
-                r += v.x;
-                g += v.y;
-                b += v.z;
-            }
-            fr += r, fg += g, fbb += b;
+    __shared__ float4 s_acc[kResolveFloat4];
+    const int tid       = threadIdx.x;
+    const uint32_t spi  = (uint32_t)a.spi;
+    const uint32_t tile = kResolveFloat4 / spi < 256u ? (kResolveFloat4 / spi > 0u ? kResolveFloat4 / spi : 1u) : 256u; // pixels per pass
+    // pixels this launch covers: a whole iteration's (multi-iteration chunks) or the chunk's virtual pixels
+    const uint32_t n_pix  = a.iterations > 1 ? a.local_pixels : a.pixels;
+    const uint32_t n_iter = a.iterations > 1 ? a.iterations : 1u;
+    const uint32_t tiles  = (n_pix + tile - 1) / tile;
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint32_t p0 = t * tile;
+        const uint32_t np = n_pix - p0 < tile ? n_pix - p0 : tile;
+        // destination of this thread's pixel
+        float* dst = nullptr;
+        float fr = 0, fg = 0, fbb = 0;
+        if ((uint32_t)tid < np) {
+            const int64_t lp = a.iterations > 1 ? (int64_t)(p0 + tid) : (a.first_local_pixel + p0 + tid) % a.local_pixels;
+            const int x      = (int)(lp % a.width);
+            const int y      = a.row_offset + (int)(lp / a.width) * a.row_stride;
+            dst              = a.fb + ((size_t)y * a.width + x) * 3;
+            fr = dst[0], fg = dst[1], fbb = dst[2];
         }
-        dst[0] = fr, dst[1] = fg, dst[2] = fbb;
-        return;
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            const float4* src = a.accum + ((size_t)it * a.local_pixels * (a.iterations > 1 ? 1u : 0u) + p0) * spi;
+            if (spi <= (uint32_t)kResolveFloat4) {
+                for (uint32_t e = (uint32_t)tid; e < np * spi; e += 256u)
+                    s_acc[e] = src[e];
+                __syncthreads();
+                if ((uint32_t)tid < np) {
+                    float r = 0, g = 0, b = 0;
+                    for (uint32_t k = 0; k < spi; ++k) {
+                        const float4 v = s_acc[(uint32_t)tid * spi + k];
+                        r += v.x, g += v.y, b += v.z;
+                    }
+                    fr += r, fg += g, fbb += b;
+                }
+                __syncthreads();
+            } else if ((uint32_t)tid < np) { // more samples per pixel than the staging buffer holds: read them directly
+                float r = 0, g = 0, b = 0;
+                for (uint32_t k = 0; k < spi; ++k) {
+                    const float4 v = src[(size_t)tid * spi + k];
+                    r += v.x, g += v.y, b += v.z;
+                }
+                fr += r, fg += g, fbb += b;
+            }
+        }
+        if (dst)
+            dst[0] = fr, dst[1] = fg, dst[2] = fbb;
     }
-    if (i >= a.pixels)
-        return;
-    const int64_t lp = (a.first_local_pixel + i) % a.local_pixels; // a chunk of at most one iteration's pixels: all distinct
-    const int x      = (int)(lp % a.width);
-    const int y      = a.row_offset + (int)(lp / a.width) * a.row_stride;
-    const float4* src = a.accum + (size_t)i * a.spi;
-    float r = 0, g = 0, b = 0;
-    for (int s = 0; s < a.spi; ++s) {
-        const float4 v = src[s];
-        r += v.x;
-        g += v.y;
-        b += v.z;
-    }
-    float* dst = a.fb + ((size_t)y * a.width + x) * 3;
-    dst[0] += r;
-    dst[1] += g;
-    dst[2] += b;
 }
 
 void launch_generate(const GenerateArgs& args, hipStream_t stream)
@@ -358,8 +370,11 @@ void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uin
 
 void launch_resolve(const ResolveArgs& args, hipStream_t stream)
 {
-    const unsigned blocks = (args.pixels + 255u) / 256u;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, args);
+    const unsigned n_pix = args.iterations > 1 ? args.local_pixels : args.pixels;
+    const unsigned spi   = (unsigned)std::max(1, args.spi);
+    const unsigned tile  = std::min(256u, std::max(1u, (unsigned)kResolveFloat4 / spi));
+    const unsigned tiles = (n_pix + tile - 1) / tile;
+    hipLaunchKernelGGL(k_resolve, dim3(std::min(tiles ? tiles : 1u, 16384u)), dim3(256), 0, stream, args);
 }
 
 } // namespace igdev
