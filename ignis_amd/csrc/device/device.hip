@@ -342,7 +342,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         const ig_material& mat = s->materials[m];
         if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
-        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE))
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses the thin flag, which the HIP backend cannot shade yet" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };

@@ -484,7 +484,7 @@ struct BsdfCtx {
             kd = Col{ m.p[0], m.p[1], m.p[2] };
         }
     }
-    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
+    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->flags & IG_MAT_SMOOTH); }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
@@ -537,6 +537,18 @@ struct BsdfCtx {
             color           = kd;
             s_eta           = 1;
             sdelta          = false;
+            return true;
+        }
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)) {
+            // delta branch of make_rough_base_conductor_bsdf (bsdf/conductor.art:56-68): compute_albedo(out_dir), kd = black
+            const float cos_o = abs_cos(out_dir, N);
+            const Col F  = Col{ conductor_factor(mat->p[0], mat->p[3], cos_o), conductor_factor(mat->p[1], mat->p[4], cos_o), conductor_factor(mat->p[2], mat->p[5], cos_o) };
+            const Col IF = Col{ 1 - F.r, 1 - F.g, 1 - F.b };
+            in_dir  = N * (2 * dot3(N, out_dir)) - out_dir; // vec3_reflect
+            pdf_out = 1;
+            color   = Col{ 0.0f * IF.r + mat->p[6] * F.r, 0.0f * IF.g + mat->p[7] * F.g, 0.0f * IF.b + mat->p[8] * F.b };
+            s_eta   = 1;
+            sdelta  = true;
             return true;
         }
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {

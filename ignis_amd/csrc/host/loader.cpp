@@ -581,7 +581,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[5] = kt.x, m.p[6] = kt.y, m.p[7] = kt.z;
         if (bsdf->getBool("thin", false))
             m.flags |= IG_MAT_THIN;
-    } else if (type == "conductor" || type == "roughconductor") {
+    } else if (type == "conductor" || type == "roughconductor" || type == "mirror") {
         // ConductorBSDF.cpp:13-34 (defaults: material "none" = eta 0, k 1, BSDF.cpp:41), roughness via
         // BSDF::setupRoughness (BSDF.cpp:53-99): VNDF-GGX, compute_explicit(roughness, anisotropic)
         // (src/artic/core/microfacet.art:427-432)
@@ -590,8 +590,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
             fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
         const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
-        if (!bsdf->has(rname))
-            fail("BSDF '" + name + "': perfectly smooth conductors (mirror) are not supported by the HIP backend");
+        const bool smooth       = !bsdf->has(rname); // BSDF::setupRoughness (BSDF.cpp:58-63): no roughness -> delta distribution
         m.bsdf_type    = IG_BSDF_CONDUCTOR;
         const V3 eta   = getColor(*bsdf, "eta", V3(0, 0, 0), name);
         const V3 k     = getColor(*bsdf, "k", V3(1, 1, 1), name);
@@ -604,8 +603,8 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[6] = ks.x, m.p[7] = ks.y, m.p[8] = ks.z;
         m.p[9]  = r / aspect;
         m.p[10] = r * aspect;
-        if (m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
-            fail("BSDF '" + name + "': roughness <= 1e-4 makes a delta conductor, which is not supported by the HIP backend");
+        if (smooth || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
+            m.flags |= IG_MAT_SMOOTH;
     } else if (type == "bumpmap" || type == "normalmap") {
         // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
         // make_normalmap(ctx, inner, map colour, strength)

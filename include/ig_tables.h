@@ -93,6 +93,8 @@ enum ig_material_flags {
     IG_MAT_BUMP       = 1u << 1, /* wrapped in a bumpmap (src/artic/bsdf/map.art:36-42,64-67, MapBSDF.cpp:44-47): tex_id, p[11] */
     IG_MAT_CHECKER    = 1u << 2, /* reflectance is a checkerboard texture */
     IG_MAT_NORMALMAP  = 1u << 3, /* wrapped in a normalmap (src/artic/bsdf/map.art:36-42,55-61): tex_id, p[11] */
+    IG_MAT_SMOOTH     = 1u << 5, /* conductor without roughness ("mirror", or roughness <= 1e-4): the delta branch of
+                                  * make_rough_base_conductor_bsdf, src/artic/bsdf/conductor.art:56-68 */
     IG_MAT_IMAGE      = 1u << 4, /* diffuse reflectance is the bitmap texture tex_refl (DiffuseBSDF.cpp:18, texture/image.art) */
 };
 

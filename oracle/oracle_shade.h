@@ -513,7 +513,7 @@ struct Bsdf {
     const SurfaceElement* surf;
     const igd_scene* scene = nullptr; // bitmap reflectance lookups
 
-    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC; }
+    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->flags & IG_MAT_SMOOTH); }
 
     Color kd() const
     {
@@ -579,6 +579,19 @@ struct Bsdf {
             s.color            = kd();
             s.eta              = 1;
             s.is_delta         = false;
+            return true;
+        }
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)) {
+            // delta branch of make_rough_base_conductor_bsdf (bsdf/conductor.art:56-68): compute_albedo(out_dir), kd = black
+            const Vec3 N      = surf->local.col[2];
+            const float cos_o = absolute_cos(out_dir, N);
+            const Color F     = Color{ conductor_factor(mat->p[0], mat->p[3], cos_o), conductor_factor(mat->p[1], mat->p[4], cos_o), conductor_factor(mat->p[2], mat->p[5], cos_o) };
+            const Color IF    = Color{ 1 - F.r, 1 - F.g, 1 - F.b };
+            s.in_dir   = vec3_reflect(out_dir, N);
+            s.pdf      = 1;
+            s.color    = Color{ 0.0f * IF.r + mat->p[6] * F.r, 0.0f * IF.g + mat->p[7] * F.g, 0.0f * IF.b + mat->p[8] * F.b };
+            s.eta      = 1;
+            s.is_delta = true;
             return true;
         }
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {

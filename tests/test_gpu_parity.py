@@ -618,3 +618,20 @@ def test_render_without_resize_then_read(diamond_scene):
     fb = dev.framebuffer()
     assert fb.shape == (30, 40, 3) and fb.any()
     dev.close()
+
+
+def test_mirror_and_smooth_conductor_vs_oracle(gpu_device):
+    """Conductors without roughness ("mirror", or roughness <= 1e-4): the delta branch of the conductor BSDF
+    (bsdf/conductor.art:56-68) — no NEE at the vertex, Fresnel-weighted perfect reflection."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-Inner":
+            b.clear()
+            b.update({"type": "mirror", "name": "mat-Inner", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": [0.9, 0.9, 0.95]})
+    s["bsdfs"].append({"type": "conductor", "name": "mat-Floor", "roughness": 0.00005})
+    s["entities"][0]["bsdf"] = "mat-Floor"
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 128, 96)
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & 32) == 2  # IG_MAT_SMOOTH
+    tot = _compare_with_oracle(gpu_device, sc, 128, 96, 4, seed=8)
+    assert tot["bounce_rays"] > 0 and tot["shadow_rays"] == 0  # every surface is a delta reflector: no next event estimation
