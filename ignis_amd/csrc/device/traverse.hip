@@ -165,7 +165,8 @@ void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int gri
     TraverseArgs deep = args;
     deep.count        = args.index_count;
     deep.work_counter = deep_work_counter;
-    launch_one<true>(deep, any_hit, stats, grid_blocks < 64 ? grid_blocks : 64, stream);
+    // a small grid: every workgroup of it waits for a free 48 KiB LDS slot, even if it only reads the empty counter
+    launch_one<true>(deep, any_hit, stats, grid_blocks < 8 ? grid_blocks : 8, stream);
 }
 
 } // namespace igdev
