@@ -316,7 +316,8 @@ struct igd_device {
     }
 
     int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
-    int shadeGrid() const { return num_cus * 8; }
+    int shade_mult = 64; // workgroups per CU in the k_shade grid (each loops over windows); IGD_SHADE_GRID
+    int shadeGrid() const { return num_cus * shade_mult; }
 
     hipEvent_t event(size_t i)
     {
@@ -1145,6 +1146,8 @@ igd_device* igd_create(const igd_setup* setup)
             HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].resolved, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&d->flight[k].done, hipEventDisableTiming));
         }
+        if (const char* e = std::getenv("IGD_SHADE_GRID"))
+            d->shade_mult = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_BATCH_RAYS"))
             d->batch_rays = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))
