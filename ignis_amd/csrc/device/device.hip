@@ -658,16 +658,37 @@ void render(igd_device* d, const igd_render_settings* rs)
     if (list_mode)
         d->list_rays.upload(rs->rays, (size_t)rs->width * 8);
 
-    // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13), aspect = width / height
-    // unless the scene fixes it (PerspectiveCamera.cpp:41-45)
+    // the per-film constants of the camera, evaluated on the host
     float sx, sy;
     {
-        const float aspect = d->camera.aspect_ratio > 0 ? d->camera.aspect_ratio : (float)rs->width / (float)rs->height;
-        if (d->camera.fov_is_vertical) {
-            sy = std::tan(d->camera.fov / 2);
+        const ig_camera& c = d->camera;
+        const float asp    = (float)rs->width / (float)rs->height;
+        // aspect = width / height unless the scene fixes it (PerspectiveCamera.cpp:41-45, OrthogonalCamera.cpp:33-35)
+        const float aspect = c.aspect_ratio > 0 ? c.aspect_ratio : asp;
+        if (c.type == IG_CAMERA_FISHLENS) {
+            // (xasp, yasp) of make_fishlens_camera (camera/fishlens.art:12-37)
+            if (c.fisheye_mode == IG_FISHEYE_CROPPED) {
+                sx = asp < 1 ? 1 / asp : 1;
+                sy = asp > 1 ? 1 / asp : 1;
+            } else if (c.fisheye_mode == IG_FISHEYE_FULL) {
+                const float diameter = std::sqrt(asp * asp + 1) * (float)rs->height;
+                const float f        = diameter / (float)std::min(rs->width, rs->height);
+                sx                   = asp < 1 ? f : f / asp;
+                sy                   = asp > 1 ? f : f * asp;
+            } else {
+                sx = asp < 1 ? 1 : asp;
+                sy = asp > 1 ? 1 : asp;
+            }
+        } else if (c.type == IG_CAMERA_ORTHOGONAL) {
+            // make_vec2(camera_scale, camera_scale / aspect) (OrthogonalCamera.cpp:46)
+            sx = c.scale;
+            sy = c.scale / aspect;
+        } else if (c.fov_is_vertical) {
+            // compute_scale_from_vfov / _hfov (camera/perspective.art:2-13)
+            sy = std::tan(c.fov / 2);
             sx = sy * aspect;
         } else {
-            sx = std::tan(d->camera.fov / 2);
+            sx = std::tan(c.fov / 2);
             sy = sx / aspect;
         }
     }
@@ -1395,6 +1416,8 @@ int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value)
         flushPending(dev);
         if (std::strcmp(name, "__tech_clamp") == 0)
             dev->dscene.tech.clamp = value;
+        else if (std::strcmp(name, "__camera_scale") == 0) // OrthogonalCamera.cpp:28,39
+            dev->camera.scale = value;
     });
 }
 

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         flags = 0;
     } else {
         // make_camera_emitter (driver/emitter.art:6-16), uniform pixel sampler (sampler/pixel_sampler.art:4-10),
-        // make_pixelcoord_from_xy (driver/camera.art:21-29), make_perspective_camera (camera/perspective.art:29-42)
+        // make_pixelcoord_from_xy (driver/camera.art:21-29), then Camera::generate_ray of the scene's camera
         const float rx = rnd.f32();
         const float ry = rnd.f32();
         const float nx = 2 * ((float)x + rx) / ((float)a.width) - 1;
@@ -66,10 +66,60 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         view.c1 = cup;
         view.c2 = cdir;
         org     = f3{ a.cam.eye[0], a.cam.eye[1], a.cam.eye[2] };
-        dir     = normalize3(mul33(view, f3{ a.sx * nx, a.sy * ny, 1 }));
         tmin    = a.cam.near_clip;
         tmax    = a.cam.far_clip;
         flags   = IG_RAY_FLAG_CAMERA;
+        if (a.cam.type == IG_CAMERA_ORTHOGONAL) {
+            // make_orthogonal_camera (camera/orthogonal.art:19-22)
+            org = mul33(view, f3{ a.sx * nx, a.sy * ny, 0 }) + org;
+            dir = cdir;
+        } else if (a.cam.type == IG_CAMERA_FISHLENS) {
+            // compute_d of make_fishlens_camera (camera/fishlens.art:39-53), fov = pi; (sx, sy) = (xasp, yasp)
+            const float fx    = nx * a.sx;
+            const float fy    = ny * a.sy;
+            const float r     = igm_sqrt(fx * fx + fy * fy);
+            const float theta = r * kPi / 2;
+            const float sT    = igm_sin(theta);
+            const float cT    = igm_cos(theta);
+            const float sP    = r < kFltEps ? 0 : fy / r;
+            const float cP    = r < kFltEps ? 0 : fx / r;
+            dir               = mul33(view, f3{ sT * cP, sT * sP, cT });
+            if (a.cam.fisheye_mask && r > 1) {
+                // no ray for this sample: the zero ray of gpu_generate_rays (mapping_gpu.art:655-658);
+                // it cannot hit anything and shade_vertex drops it
+                org  = f3{ 0, 0, 0 };
+                dir  = f3{ 0, 0, 0 };
+                tmin = 0;
+                tmax = 0;
+                flags = 0;
+            }
+        } else {
+            // make_perspective_camera (camera/perspective.art:29-42)
+            dir = normalize3(mul33(view, f3{ a.sx * nx, a.sy * ny, 1 }));
+            if (a.cam.aperture_radius > kFltEps) {
+                // gen_ray of make_perspective_dof_camera (camera/perspective.art:73-84)
+                const f3 focus = dir * a.cam.focal_length;
+                const float u0 = rnd.f32();
+                const float u1 = rnd.f32();
+                // square_to_concentric_disk (core/warp.art:2-22)
+                const float ca = 2 * u0 - 1;
+                const float cb = 2 * u1 - 1;
+                float ax = 0, ay = 0;
+                if (ca == 0 && cb == 0) {
+                } else if (ca * ca > cb * cb) {
+                    const float phi = (kPi / 4) * safe_div(cb, ca);
+                    ax              = igm_cos(phi) * ca;
+                    ay              = igm_sin(phi) * ca;
+                } else {
+                    const float phi = (kPi / 2) - (kPi / 4) * safe_div(ca, cb);
+                    ax              = igm_cos(phi) * cb;
+                    ay              = igm_sin(phi) * cb;
+                }
+                const f3 ap = mul33(view, f3{ ax * a.cam.aperture_radius, ay * a.cam.aperture_radius, 0 });
+                org         = org + ap;
+                dir         = normalize3(focus - ap);
+            }
+        }
     }
 
     a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);

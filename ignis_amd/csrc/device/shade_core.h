@@ -771,6 +771,10 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const bool nee          = tech.nee != 0;
 
     if (in.ent < 0) {
+        // a sample for which the camera had no ray (masked fishlens) carries the zero ray of
+        // gpu_generate_rays (mapping_gpu.art:655-658): it can only miss, and it is dropped here
+        if (in.dir.x == 0 && in.dir.y == 0 && in.dir.z == 0)
+            return;
         // ---- miss: on_miss (technique/pathtracer.art:141-168) over infinite, non-delta lights
         Col sum{ 0, 0, 0 };
         for (uint32_t li = 0; li < sc.infinite_light_count; ++li) {

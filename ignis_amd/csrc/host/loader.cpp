@@ -811,12 +811,36 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     cam.near_clip    = 0;
     cam.far_clip     = std::numeric_limits<float>::max();
     cam.aspect_ratio = -1;
+    cam.scale        = 1;
+    cam.focal_length = 1;
+    bool cam_has_transform = false;
     if (const JsonValue* c = doc.find("camera")) {
+        // LoaderCamera.cpp:31-36
         const std::string type = c->getString("type", "perspective");
-        if (type != "perspective")
-            fail("Camera '" + type + "' is not supported by the HIP backend (only 'perspective')");
-        if (c->getNumber("aperture_radius", 0.0f) > 1.1920928955e-07f)
-            fail("Depth of field cameras are not supported by the HIP backend");
+        if (type == "perspective")
+            cam.type = IG_CAMERA_PERSPECTIVE;
+        else if (type == "orthogonal")
+            cam.type = IG_CAMERA_ORTHOGONAL;
+        else if (type == "fishlens" || type == "fisheye")
+            cam.type = IG_CAMERA_FISHLENS;
+        else
+            fail("Camera '" + type + "' is not supported by the HIP backend (perspective, orthogonal, fishlens)");
+        if (cam.type == IG_CAMERA_PERSPECTIVE) {
+            // PerspectiveCamera.cpp:19-20,50: a lens when the aperture radius exceeds FltEps
+            cam.focal_length    = c->getNumber("focal_length", 1.0f);
+            cam.aperture_radius = c->getNumber("aperture_radius", 0.0f);
+        } else if (cam.type == IG_CAMERA_ORTHOGONAL) {
+            cam.scale = c->getNumber("scale", 1.0f); // OrthogonalCamera.cpp:16
+        } else {
+            // FishLensCamera.cpp:17-28
+            cam.fisheye_mask       = c->getBool("mask", false) ? 1 : 0;
+            std::string mode       = c->getString("mode", "circular");
+            for (char& ch : mode)
+                ch = (char)std::tolower((unsigned char)ch);
+            cam.fisheye_mode = mode == "cropped" ? IG_FISHEYE_CROPPED : (mode == "full" ? IG_FISHEYE_FULL : IG_FISHEYE_CIRCULAR);
+        }
+        // the orthogonal camera always takes its transform, identity when absent (OrthogonalCamera.cpp:10,54-62)
+        cam_has_transform = c->has("transform") || cam.type == IG_CAMERA_ORTHOGONAL;
         if (c->has("transform")) {
             const Affine T = getTransform(*c);
             const V3 eye   = T.point(V3(0, 0, 0));
@@ -1139,6 +1163,27 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.texture_count      = (uint32_t)sc->textures.size();
     t.texture_data       = sc->texture_data.data();
     t.texture_data_size  = sc->texture_data.size();
+    if (!cam_has_transform) {
+        // no transform: a view over the whole scene (PerspectiveCamera.cpp:77-101, FishLensCamera.cpp:76-101)
+        cam.dir[0] = 0, cam.dir[1] = 0, cam.dir[2] = -1;
+        cam.up[0] = 0, cam.up[1] = 1, cam.up[2] = 0;
+        cam.eye[0] = cam.eye[1] = cam.eye[2] = 0;
+        if (entityCount) {
+            const V3 diam = sceneBBox.diameter();
+            float a = diam.x / 2, b = diam.y / 2, half = 60.0f * Deg2Rad / 2;
+            if (cam.type == IG_CAMERA_PERSPECTIVE) {
+                const float aspect = cam.aspect_ratio > 0 ? cam.aspect_ratio : (float)width / (float)height;
+                a    = diam.x / (2 * (cam.fov_is_vertical ? aspect : 1));
+                b    = diam.y / (2 * (!cam.fov_is_vertical ? aspect : 1));
+                half = cam.fov / 2;
+            }
+            const float sn = std::sin(half);
+            const float d  = std::abs(sn) <= 1.1920928955e-07f ? 0 : std::max(a, b) * std::sqrt(1 / (sn * sn) - 1);
+            cam.eye[0]     = sceneBBox.center().x;
+            cam.eye[1]     = sceneBBox.center().y;
+            cam.eye[2]     = sceneBBox.max.z + d;
+        }
+    }
     t.camera             = cam;
     t.technique          = tech;
     for (int i = 0; i < 3; ++i) {

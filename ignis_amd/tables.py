@@ -42,7 +42,9 @@ class Light(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("fov", C.c_float),
                 ("fov_is_vertical", C.c_int32), ("near_clip", C.c_float), ("far_clip", C.c_float),
-                ("aspect_ratio", C.c_float)]
+                ("aspect_ratio", C.c_float), ("type", C.c_int32), ("fisheye_mode", C.c_int32),
+                ("fisheye_mask", C.c_int32), ("scale", C.c_float), ("aperture_radius", C.c_float),
+                ("focal_length", C.c_float)]
 
 
 class Technique(C.Structure):

@@ -169,6 +169,18 @@ enum ig_light_selector {
 
 /* ---- Camera / technique ----------------------------------------------- */
 
+enum ig_camera_type {
+    IG_CAMERA_PERSPECTIVE = 0, /* src/artic/camera/perspective.art:29-42; with aperture_radius > eps: :69-84 (depth of field) */
+    IG_CAMERA_ORTHOGONAL  = 1, /* src/artic/camera/orthogonal.art:14-26 */
+    IG_CAMERA_FISHLENS    = 2, /* src/artic/camera/fishlens.art:8-79 ("fishlens" / "fisheye") */
+};
+
+enum ig_fisheye_mode { /* FisheyeAspectMode, src/artic/camera/fishlens.art:1-5 */
+    IG_FISHEYE_CIRCULAR = 0,
+    IG_FISHEYE_CROPPED  = 1,
+    IG_FISHEYE_FULL     = 2,
+};
+
 typedef struct ig_camera {
     float eye[3];  /* T * 0,             src/runtime/camera/PerspectiveCamera.cpp:69-76 */
     float dir[3];  /* T.linear.col(2) */
@@ -177,6 +189,11 @@ typedef struct ig_camera {
     int32_t fov_is_vertical;
     float near_clip, far_clip;
     float aspect_ratio; /* <= 0: use width / height */
+    int32_t type;         /* enum ig_camera_type */
+    int32_t fisheye_mode; /* enum ig_fisheye_mode, FishLensCamera.cpp:22-28 */
+    int32_t fisheye_mask; /* FishLensCamera.cpp:17: samples with r > 1 carry no ray */
+    float scale;          /* orthogonal: OrthogonalCamera.cpp:16 (registry "__camera_scale") */
+    float aperture_radius, focal_length; /* PerspectiveCamera.cpp:19-20 */
 } ig_camera;
 
 typedef struct ig_technique {

@@ -142,6 +142,7 @@ int32_t igd_traverse(igd_device* dev, int64_t count, const float* rays, uint32_t
 /* The registry parameters IRenderDevice::render receives with every call (ParameterSet*, IRenderDevice.h:53;
  * filled by Runtime::setParameter / setCameraOrientation, Runtime.cpp:696-741) that this path reads:
  *   vec3 "__camera_eye" / "__camera_dir" / "__camera_up"   (PerspectiveCamera.cpp:69-76, camera/perspective.art)
+ *   f32  "__camera_scale"                                  (OrthogonalCamera.cpp:28,39)
  *   i32  "__tech_max_depth" / "__tech_min_depth", f32 "__tech_clamp"   (PathTechnique.cpp:38-40)
  * They take effect from the next igd_render. Other names are accepted and ignored, as the reference's registry
  * stores parameters no shader reads. */

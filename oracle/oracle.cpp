@@ -208,14 +208,43 @@ struct Counters {
 
 void camera_scale(const igd_scene& sc, int width, int height, float& sx, float& sy)
 {
-    // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13); aspect = width / height
-    // unless fixed by the scene (PerspectiveCamera.cpp:41-45)
-    const float aspect = sc.camera.aspect_ratio > 0 ? sc.camera.aspect_ratio : (float)width / (float)height;
-    if (sc.camera.fov_is_vertical) {
-        sy = std::tan(sc.camera.fov / 2);
+    const ig_camera& c = sc.camera;
+    if (c.type == IG_CAMERA_FISHLENS) {
+        // aspect handling of make_fishlens_camera (fishlens.art:12-37)
+        const float asp = (float)width / (float)height;
+        switch (c.fisheye_mode) {
+        default:
+        case IG_FISHEYE_CIRCULAR:
+            sx = asp < 1 ? 1 : asp;
+            sy = asp > 1 ? 1 : asp;
+            break;
+        case IG_FISHEYE_CROPPED:
+            sx = asp < 1 ? 1 / asp : 1;
+            sy = asp > 1 ? 1 / asp : 1;
+            break;
+        case IG_FISHEYE_FULL: {
+            const float diameter = std::sqrt(asp * asp + 1) * (float)height;
+            const float f        = diameter / (float)std::min(width, height);
+            sx                   = asp < 1 ? f : f / asp;
+            sy                   = asp > 1 ? f : f * asp;
+        } break;
+        }
+        return;
+    }
+    // aspect = width / height unless fixed by the scene (PerspectiveCamera.cpp:41-45, OrthogonalCamera.cpp:33-35)
+    const float aspect = c.aspect_ratio > 0 ? c.aspect_ratio : (float)width / (float)height;
+    if (c.type == IG_CAMERA_ORTHOGONAL) {
+        // make_vec2(camera_scale, camera_scale / aspect) (OrthogonalCamera.cpp:46)
+        sx = c.scale;
+        sy = c.scale / aspect;
+        return;
+    }
+    // compute_scale_from_hfov / _vfov (camera/perspective.art:2-13)
+    if (c.fov_is_vertical) {
+        sy = std::tan(c.fov / 2);
         sx = sy * aspect;
     } else {
-        sx = std::tan(sc.camera.fov / 2);
+        sx = std::tan(c.fov / 2);
         sy = sx / aspect;
     }
 }
@@ -255,9 +284,12 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                 const int x = xmin + in_tile_x, y = ymin + in_tile_y;
                 const int cur = current_size + i;
                 Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, x, y, cfg.seed), 1 };
-                const Ray ray = generate_camera_ray(cam, rnd, x, y, W, cfg.height);
+                Ray ray;
+                const bool valid = generate_camera_ray(cam, rnd, x, y, W, cfg.height, ray);
+                if (!valid)
+                    ray = make_ray(Vec3{ 0, 0, 0 }, Vec3{ 0, 0, 0 }, 0, 0, 0); // make_zero_ray, id -1 (mapping_cpu.art:352-355)
                 write_ray(primary, cur, ray);
-                primary.id[cur]  = (y * W + x) * spi + sample;
+                primary.id[cur]  = valid ? (y * W + x) * spi + sample : -1;
                 primary.rnd[cur] = rnd.counter;
                 write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1 }); // init_pt_raypayload (pathtracer.art:33-38)
             }
@@ -270,7 +302,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
             // only miss shading
             for (int i = 0; i < current_size; ++i) {
                 Color c;
-                if (pt_tech.on_miss(read_ray(primary, i), read_payload(primary, i), c))
+                if (primary.id[i] >= 0 && pt_tech.on_miss(read_ray(primary, i), read_payload(primary, i), c))
                     splat(primary.id[i], c);
             }
             current_size = 0;
@@ -348,6 +380,8 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
             const int begin = ray_ends[E - 1], last = ray_ends[E];
             (void)total_size;
             for (int i = begin; i < last; ++i) {
+                if (primary.id[i] < 0)
+                    continue; // sample without a camera ray (masked fishlens): dropped, see generate_camera_ray
                 Color c;
                 if (!pt_tech.on_miss(read_ray(primary, i), read_payload(primary, i), c))
                     c = Color{ 0, 0, 0 };
@@ -476,7 +510,9 @@ int oracle_generate_rays(const igd_scene* sc, const oracle_settings* cfg, int64_
         const int pixel   = (int)(id / cfg->spi);
         const int x = pixel % cfg->width, y = pixel / cfg->width;
         Rng rnd{ create_random_seed(sample, cfg->iteration, cfg->frame, x, y, cfg->seed), 1 };
-        const Ray r = generate_camera_ray(cam, rnd, x, y, cfg->width, cfg->height);
+        Ray r;
+        if (!generate_camera_ray(cam, rnd, x, y, cfg->width, cfg->height, r))
+            r = make_ray(Vec3{ 0, 0, 0 }, Vec3{ 0, 0, 0 }, 0, 0, 0); // no ray for this sample: make_zero_ray
         float* o    = rays + i * 8;
         o[0] = r.org.x, o[1] = r.org.y, o[2] = r.org.z;
         o[3] = r.dir.x, o[4] = r.dir.y, o[5] = r.dir.z;

@@ -71,22 +71,27 @@ struct Rng {
     }
 };
 
-// ---- camera/perspective.art + driver/camera.art + driver/emitter.art
+// ---- camera/{perspective,orthogonal,fishlens}.art + driver/camera.art + driver/emitter.art
 struct CameraSetup {
-    Vec3 eye;
+    Vec3 eye, dir;
     Mat3x3 view; // right, up, dir
-    float sx, sy;
+    float sx, sy; // perspective / orthogonal: scale; fishlens: (xasp, yasp)
     float tmin, tmax;
+    int type;
+    bool mask;
+    float aperture_radius, focal_length;
 };
 
-// make_perspective_camera (perspective.art:29-42); the scale comes from the host:
-// compute_scale_from_hfov / _vfov (perspective.art:2-13) evaluated with libm tanf.
+// make_perspective_camera (perspective.art:29-42), make_perspective_dof_camera (:69-84),
+// make_orthogonal_camera (orthogonal.art:14-26), make_fishlens_camera (fishlens.art:8-37).
+// (sx, sy) comes from the host (camera_scale in oracle.cpp), evaluated with libm.
 static inline CameraSetup make_camera(const ig_camera& c, float sx, float sy)
 {
     CameraSetup s;
     s.eye          = Vec3{ c.eye[0], c.eye[1], c.eye[2] };
     const Vec3 dir = Vec3{ c.dir[0], c.dir[1], c.dir[2] };
     const Vec3 up  = Vec3{ c.up[0], c.up[1], c.up[2] };
+    s.dir          = dir;
     s.view.col[0]  = vec3_normalize(vec3_cross(dir, up));
     s.view.col[1]  = up;
     s.view.col[2]  = dir;
@@ -94,19 +99,77 @@ static inline CameraSetup make_camera(const ig_camera& c, float sx, float sy)
     s.sy           = sy;
     s.tmin         = c.near_clip;
     s.tmax         = c.far_clip;
+    s.type         = c.type;
+    s.mask         = c.fisheye_mask != 0;
+    s.aperture_radius = c.aperture_radius;
+    s.focal_length    = c.focal_length;
     return s;
 }
 
+// square_to_concentric_disk (core/warp.art:2-22)
+static inline void square_to_concentric_disk(float px, float py, float& ox, float& oy)
+{
+    const float a = 2 * px - 1;
+    const float b = 2 * py - 1;
+    if (a == 0 && b == 0) {
+        ox = 0, oy = 0;
+    } else if (a * a > b * b) {
+        const float phi = (flt_pi / 4) * safe_div(b, a);
+        ox = igm_cos(phi) * a;
+        oy = igm_sin(phi) * a;
+    } else {
+        const float phi = (flt_pi / 2) - (flt_pi / 4) * safe_div(a, b);
+        ox = igm_cos(phi) * b;
+        oy = igm_sin(phi) * b;
+    }
+}
+
 // make_camera_emitter (emitter.art:6-16) + make_uniform_pixel_sampler (pixel_sampler.art:4-10)
-// + make_pixelcoord_from_xy (camera.art:21-29) + generate_ray (perspective.art:37-42)
-static inline Ray generate_camera_ray(const CameraSetup& cam, Rng& rnd, int x, int y, int w, int h)
+// + make_pixelcoord_from_xy (camera.art:21-29) + Camera::generate_ray. Returns false when the camera
+// yields no ray for the sample (masked fishlens, fishlens.art:44): cpu_generate_rays then stores a zero
+// ray with id -1 (mapping_cpu.art:352-355). The reference goes on to miss-shade that entry and splats
+// the result to pixel -1 / spi; the restatement (and the HIP device) drop the sample instead.
+static inline bool generate_camera_ray(const CameraSetup& cam, Rng& rnd, int x, int y, int w, int h, Ray& out)
 {
     const float rx = rnd.next_f32();
     const float ry = rnd.next_f32();
     const float nx = 2 * ((float)x + rx) / ((float)w) - 1;
     const float ny = 1 - 2 * ((float)y + ry) / ((float)h);
-    const Vec3 d   = vec3_normalize(mat3x3_mul(cam.view, make_vec3(cam.sx * nx, cam.sy * ny, 1)));
-    return make_ray(cam.eye, d, cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+    if (cam.type == IG_CAMERA_ORTHOGONAL) {
+        // orthogonal.art:19-22
+        const Vec3 pos = vec3_add(mat3x3_mul(cam.view, make_vec3(cam.sx * nx, cam.sy * ny, 0)), cam.eye);
+        out            = make_ray(pos, cam.dir, cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+        return true;
+    }
+    if (cam.type == IG_CAMERA_FISHLENS) {
+        // compute_d (fishlens.art:39-53), fov = pi
+        const float fx    = nx * cam.sx;
+        const float fy    = ny * cam.sy;
+        const float r     = igm_sqrt(fx * fx + fy * fy);
+        const float theta = r * flt_pi / 2;
+        if (cam.mask && r > 1)
+            return false;
+        const float sT = igm_sin(theta);
+        const float cT = igm_cos(theta);
+        const float sP = r < flt_eps ? 0 : fy / r;
+        const float cP = r < flt_eps ? 0 : fx / r;
+        out            = make_ray(cam.eye, mat3x3_mul(cam.view, make_vec3(sT * cP, sT * sP, cT)), cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+        return true;
+    }
+    const Vec3 d = vec3_normalize(mat3x3_mul(cam.view, make_vec3(cam.sx * nx, cam.sy * ny, 1)));
+    if (cam.aperture_radius > flt_eps) {
+        // gen_ray of make_perspective_dof_camera (perspective.art:73-84; chosen at PerspectiveCamera.cpp:50)
+        const Vec3 focus_pos = vec3_mulf(d, cam.focal_length);
+        const float u0       = rnd.next_f32();
+        const float u1       = rnd.next_f32();
+        float ax, ay;
+        square_to_concentric_disk(u0, u1, ax, ay);
+        const Vec3 ap = mat3x3_mul(cam.view, make_vec3(ax * cam.aperture_radius, ay * cam.aperture_radius, 0));
+        out           = make_ray(vec3_add(cam.eye, ap), vec3_normalize(vec3_sub(focus_pos, ap)), cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+        return true;
+    }
+    out = make_ray(cam.eye, d, cam.tmin, cam.tmax, IG_RAY_FLAG_CAMERA);
+    return true;
 }
 
 // ---- driver/entity.art:12-28

@@ -635,3 +635,48 @@ def test_mirror_and_smooth_conductor_vs_oracle(gpu_device):
     assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & 32) == 2  # IG_MAT_SMOOTH
     tot = _compare_with_oracle(gpu_device, sc, 128, 96, 4, seed=8)
     assert tot["bounce_rays"] > 0 and tot["shadow_rays"] == 0  # every surface is a delta reflector: no next event estimation
+
+
+_CAM_T = [-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 3.85, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("camera", [
+    {"type": "orthogonal", "scale": 1.2, "transform": _CAM_T},
+    {"type": "fishlens", "mode": "circular", "transform": _CAM_T},
+    {"type": "fisheye", "mode": "cropped", "transform": _CAM_T},
+    {"type": "fishlens", "mode": "full", "mask": True, "transform": _CAM_T},
+    {"type": "perspective", "fov": 40, "aperture_radius": 0.15, "focal_length": 3.4, "transform": _CAM_T},
+    {"type": "perspective", "vfov": 50},  # no transform: the view over the whole scene
+], ids=["orthogonal", "fishlens", "fisheye-cropped", "fishlens-full-masked", "depth-of-field", "default-view"])
+def test_cameras_vs_oracle(gpu_device, camera):
+    """Camera rays (bit-exact) and the rendered image for every camera of src/artic/camera; an environment light makes a
+    masked sample that got shaded show up."""
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    w, h = 96, 64
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["camera"] = camera
+    s["lights"] = [{"type": "env", "name": "sky", "radiance": [0.2, 0.25, 0.3]}]
+    s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    _compare_with_oracle(gpu_device, sc, w, h, 4, seed=11, iters=2)
+    if camera.get("mask"):
+        fb, _ = _render_gpu(gpu_device, sc, 4, w, h, seed=11)
+        assert fb[0, 0].sum() == 0 and fb[h - 1, w - 1].sum() == 0 and fb[h // 2, w // 2].sum() > 0
+
+
+def test_camera_scale_parameter(gpu_device):
+    """`__camera_scale` (OrthogonalCamera.cpp:28,39) is read from the registry at every render."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["camera"] = {"type": "orthogonal", "scale": 0.5, "transform": _CAM_T}
+    a = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    s["camera"]["scale"] = 1.25
+    b = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    ref, _ = _render_gpu(gpu_device, b, 2, 64, 64, seed=3)
+    gpu_device.assign_scene(a)
+    gpu_device.set_parameter("__camera_scale", 1.25)
+    gpu_device.resize(64, 64)
+    gpu_device.clear_framebuffer()
+    gpu_device.render(2, 64, 64, iteration=0, seed=3)
+    np.testing.assert_array_equal(gpu_device.framebuffer(), ref)

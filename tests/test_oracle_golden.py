@@ -5,13 +5,14 @@
  * RNG construction of src/artic/core/random.art (FNV-1a offset basis / prime, TEA rounds, [1,2)-1 float trick)
 """
 import json
+import os
 
 import numpy as np
 import pytest
 
 import oracle
 from ignis_amd.tables import LoadedScene
-from conftest import flat_scene
+from conftest import SCENES, flat_scene
 
 
 # ---- test_intersection.art: triangle v0=0, e1=(0,1,0), e2=(-1,0,0), n=(0,0,1)
@@ -346,3 +347,114 @@ def test_constant_image_equals_constant_reflectance(tmp_path):
     fb, _ = oracle.render(b, 4, 32, 32, seed=2)
     assert fa.mean() > 0
     np.testing.assert_array_equal(fa, fb)
+
+
+# ---- cameras (src/artic/camera/{perspective,orthogonal,fishlens}.art, src/runtime/camera/*.cpp)
+
+def _camera_scene(camera, size=(64, 48)):
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["camera"] = camera
+    s["film"] = {"size": list(size)}
+    return LoadedScene.from_string(json.dumps(s), SCENES, *size)
+
+
+_CAM_T = [-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 3.85, 0, 0, 0, 1]
+
+
+def test_orthogonal_camera_rays():
+    """orthogonal.art:19-22: parallel rays along the camera direction, origins on the (scale, scale / aspect) plane."""
+    w, h = 64, 48
+    sc = _camera_scene({"type": "orthogonal", "scale": 1.5, "transform": _CAM_T}, (w, h))
+    rays, _ = oracle.generate_rays(sc, 1, w, h, 0, w * h, seed=3)
+    np.testing.assert_array_equal(rays[:, 3:6], np.broadcast_to(np.float32([0, 0, -1]), (w * h, 3)))
+    org = rays[:, 0:3].reshape(h, w, 3)
+    assert np.all(org[..., 2] == np.float32(3.85))
+    # right = dir x up = (0,0,-1) x (0,1,0) = (1,0,0): x grows with nx, y falls with the row
+    assert -1.5 <= org[..., 0].min() < -1.4 and 1.4 < org[..., 0].max() <= 1.5
+    lim = 1.5 / (w / h)
+    assert -lim <= org[..., 1].min() < -lim * 0.9 and lim * 0.9 < org[..., 1].max() <= lim
+    assert np.all(np.diff(org[:, :, 0].mean(axis=0)) > 0) and np.all(np.diff(org[:, :, 1].mean(axis=1)) < 0)
+
+
+@pytest.mark.parametrize("mode", ["circular", "cropped", "full"])
+def test_fishlens_camera_rays(mode):
+    """fishlens.art:39-53 with fov = pi: theta = r * pi / 2 where r is the aspect-scaled film radius."""
+    w, h = 64, 32
+    sc = _camera_scene({"type": "fishlens", "mode": mode, "transform": _CAM_T}, (w, h))
+    rays, _ = oracle.generate_rays(sc, 1, w, h, 0, w * h, seed=3)
+    d = rays[:, 3:6].astype(np.float64).reshape(h, w, 3)
+    assert np.allclose(np.linalg.norm(d, axis=-1), 1, atol=1e-5)
+    # the angle to the view direction, against an independent restatement from pixel centres (+- half a pixel of jitter)
+    asp = w / h
+    if mode == "circular":
+        xa, ya = max(asp, 1), (1 if asp > 1 else asp)
+    elif mode == "cropped":
+        xa, ya = (1 / asp if asp < 1 else 1), (1 / asp if asp > 1 else 1)
+    else:
+        f = np.sqrt(asp * asp + 1) * h / min(w, h)
+        xa, ya = (f if asp < 1 else f / asp), (f if asp > 1 else f * asp)
+    ys, xs = np.mgrid[0:h, 0:w]
+    nx = (2 * (xs + 0.5) / w - 1) * xa
+    ny = (1 - 2 * (ys + 0.5) / h) * ya
+    theta = np.hypot(nx, ny) * np.pi / 2
+    got = np.arccos(np.clip(d @ np.float64([0, 0, -1]), -1, 1))
+    tol = np.hypot(xa / w, ya / h) * np.pi / 2 + 1e-4
+    inside = theta < np.pi - 0.2  # the angle folds over at pi
+    assert np.all(np.abs(got - theta)[inside] <= tol)
+
+
+def test_fishlens_mask_drops_samples_outside_the_circle():
+    w, h = 48, 48
+    cam = {"type": "fishlens", "mode": "full", "mask": True, "transform": _CAM_T}
+    s = flat_scene([{"type": "env", "name": "_light", "radiance": [1, 1, 1]}], size=(w, h))
+    s["camera"] = dict(cam, transform=s["camera"]["transform"])
+    s["entities"] = []
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    fb, st = oracle.render(sc, 4, w, h, seed=1)
+    assert st["camera_rays"] == w * h * 4  # counted like the reference: every slot generated (mapping_cpu.art:757)
+    ys, xs = np.mgrid[0:h, 0:w]
+    f = np.sqrt(2.0)
+    r_min = np.hypot((np.abs(2 * (xs + 0.5) / w - 1) - 1 / w) * f, (np.abs(1 - 2 * (ys + 0.5) / h) - 1 / h) * f)
+    r_max = np.hypot((np.abs(2 * (xs + 0.5) / w - 1) + 1 / w) * f, (np.abs(1 - 2 * (ys + 0.5) / h) + 1 / h) * f)
+    assert np.all(fb[r_min > 1] == 0)               # wholly outside the unit circle: nothing
+    assert np.allclose(fb[r_max < 1], 1, atol=1e-6) # wholly inside: the constant environment
+    assert fb[0, 0].sum() == 0 and np.isfinite(fb).all()
+
+
+def test_depth_of_field_rays_meet_on_the_focal_sphere():
+    """perspective.art:73-84: every sample of a pixel leaves the lens disk towards eye + dir_pixel * focal_length."""
+    w, h, spi = 8, 8, 16
+    cam = {"type": "perspective", "fov": 40, "aperture_radius": 0.2, "focal_length": 3.0, "transform": _CAM_T}
+    sc = _camera_scene(cam, (w, h))
+    rays, ctr = oracle.generate_rays(sc, spi, w, h, 0, w * h * spi, seed=5)
+    assert np.all(ctr == ctr[0]) and ctr[0] > 1
+    eye = np.float64([0, 0, 3.85])
+    org = rays[:, 0:3].astype(np.float64)
+    d = rays[:, 3:6].astype(np.float64)
+    lens = org - eye
+    assert np.allclose(lens[:, 2], 0, atol=1e-6) and np.hypot(lens[:, 0], lens[:, 1]).max() <= 0.2 + 1e-6
+    assert np.hypot(lens[:, 0], lens[:, 1]).max() > 0.15
+    # the point of each ray at distance |focus - lens| is on the sphere of radius focal_length around the eye
+    # (for a thin pixel all its samples nearly coincide there)
+    t = np.sqrt(np.maximum(0, 9.0 - (lens ** 2).sum(1) + ((lens * d).sum(1)) ** 2)) - (lens * d).sum(1)
+    focus = (org + d * t[:, None] - eye).reshape(h * w, spi, 3)
+    assert np.allclose(np.linalg.norm(focus, axis=-1), 3.0, atol=1e-4)
+    spread = np.linalg.norm(focus - focus.mean(axis=1, keepdims=True), axis=-1).max()
+    assert spread < 3.0 * 2 * np.tan(np.radians(20)) / w  # within about one pixel footprint at the focal distance
+
+
+def test_camera_without_transform_views_the_whole_scene():
+    """PerspectiveCamera.cpp:77-101: eye on +z in front of the bounding box, looking down -z."""
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["camera"] = {"type": "perspective", "fov": 60}
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    t = sc.tables.contents
+    cam = t.camera
+    lo, hi = np.float64(list(t.bbox_min)), np.float64(list(t.bbox_max))
+    assert list(cam.dir) == [0, 0, -1] and list(cam.up) == [0, 1, 0]
+    assert cam.eye[0] == pytest.approx((lo[0] + hi[0]) / 2, abs=1e-6) and cam.eye[1] == pytest.approx((lo[1] + hi[1]) / 2, abs=1e-6)
+    half = max(hi[0] - lo[0], hi[1] - lo[1]) / 2
+    assert cam.eye[2] == pytest.approx(hi[2] + half * np.sqrt(1 / np.sin(np.radians(30)) ** 2 - 1), rel=1e-5)
+    # every ray of the film's border still starts outside the box and the box fills the view's shorter side
+    fb, _ = oracle.render(sc, 2, 64, 64, seed=1)
+    assert fb.sum() > 0
