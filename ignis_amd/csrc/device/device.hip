@@ -26,11 +26,11 @@
 namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream);
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
-void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
+void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
-void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
+void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
 void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
 } // namespace igdev
@@ -316,6 +316,7 @@ struct igd_device {
     }
 
     int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
+    bool full_bsdfs = false; // the scene has a principled BSDF: k_shade<true> / k_tail<*, true>
     int shade_mult = 64; // workgroups per CU in the k_shade grid (each loops over windows); IGD_SHADE_GRID
     int shadeGrid() const { return num_cus * shade_mult; }
 
@@ -341,16 +342,18 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const ig_material& mat = s->materials[m];
-        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR)
+        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR && mat.bsdf_type != IG_BSDF_PRINCIPLED)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
-        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH))
+        const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL) : 0u;
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | principled_flags))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses the thin flag, which the HIP backend cannot shade yet" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
-        if ((mat.flags & IG_MAT_IMAGE) && (mat.bsdf_type != IG_BSDF_DIFFUSE || mat.tex_refl < 0 || mat.tex_refl >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
-            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: image-textured material " + std::to_string(m) + " has no valid texture or is not diffuse" };
-        if ((mat.flags & IG_MAT_CHECKER) && mat.bsdf_type != IG_BSDF_DIFFUSE)
-            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard reflectance is only lowered for diffuse BSDFs" };
+        const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED; // p[0..2] reflectance / base colour
+        if ((mat.flags & IG_MAT_IMAGE) && (!has_albedo || mat.tex_refl < 0 || mat.tex_refl >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: image-textured material " + std::to_string(m) + " has no valid texture or is neither diffuse nor principled" };
+        if ((mat.flags & IG_MAT_CHECKER) && !has_albedo)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard colours are only lowered for diffuse and principled BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material light id out of range" };
         if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE)
@@ -482,6 +485,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         ds.deep_tail_base = trav_lanes;
     }
     d->camera               = s->camera;
+    // scenes without a principled BSDF run the lean shading kernels
+    d->full_bsdfs = false;
+    for (uint32_t i = 0; i < s->material_count; ++i)
+        d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED;
     d->has_scene            = true;
 }
 
@@ -797,7 +804,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.frame     = frame;
             sa.inv_spi   = inv;
             timed(2, on, [&] {
-                launch_shade(sa, shade_grid, on);
+                launch_shade(sa, shade_grid, d->full_bsdfs, on);
                 launch_round_end(qs, in_slot, on);
             });
 
@@ -932,7 +939,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.work_counter = fl.tail_ctr.ptr + 2 * j + 1;
                     p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
                     p.count_paths  = j == 0;
-                    if (d->tail_wavefront) {
+                    if (d->tail_wavefront && !d->full_bsdfs) { // the experimental wave-local kernel exists in the lean variant only
                         // every wave gets a slice of the pass's input; the grid covers the upper bound `live`
                         p.work[0] = igd_device::colsAt(fl.tail_work[0].ptr, fl.tail_capacity);
                         p.work[1] = igd_device::colsAt(fl.tail_work[1].ptr, fl.tail_capacity);
@@ -947,7 +954,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                         p.slice = slice;
                         launch_tail_wave(p, counters, (int)((live + slice - 1) / slice), side);
                     } else {
-                        launch_tail(p, counters, tail_grid, side);
+                        launch_tail(p, counters, d->full_bsdfs, tail_grid, side);
                     }
                 }
             });

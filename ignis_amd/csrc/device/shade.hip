@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
 constexpr int kShadeThreads = 256;
 constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry per thread
 
+template <bool FULL>
 __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             in.ent     = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
-            shade_vertex(sc, fr, in, out);
+            shade_vertex<FULL>(sc, fr, in, out);
             if (out.has_radiance) {
                 // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
@@ -388,9 +389,15 @@ void launch_generate(const GenerateArgs& args, hipStream_t stream)
     hipLaunchKernelGGL(k_generate, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, args);
 }
 
-void launch_shade(const ShadeArgs& args, int grid_blocks, hipStream_t stream)
+template __global__ void k_shade<false>(const ShadeArgs);
+template __global__ void k_shade<true>(const ShadeArgs);
+
+void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_shade, dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    if (full_bsdfs)
+        hipLaunchKernelGGL((k_shade<true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL((k_shade<false>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
 }
 
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream) { hipLaunchKernelGGL(k_round_end, dim3(1), dim3(64), 0, stream, qs, in_slot); }

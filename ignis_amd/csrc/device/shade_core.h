@@ -461,6 +461,394 @@ IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& 
     return out;
 }
 
+// ---- principled BSDF (bsdf/principled.art); directions of the closure live in the shading frame
+IG_DEV float lerpf(float a, float b, float k) { return (1 - k) * a + k * b; }                  // core/common.art:237
+IG_DEV float luminance(Col c) { return c.r * 0.2126f + c.g * 0.7152f + c.b * 0.0722f; }       // core/color.art:29,81-83
+IG_DEV Col operator+(Col a, Col b) { return Col{ a.r + b.r, a.g + b.g, a.b + b.b }; }
+IG_DEV float schlick_approx(float f) // core/fresnel.art:88-91
+{
+    const float s = clampf(1 - f, 0, 1);
+    return (s * s) * (s * s) * s;
+}
+IG_DEV float schlick_r0(float eta) // core/fresnel.art:101-104
+{
+    const float factor = clampf((eta - 1) / (eta + 1), -1, 1);
+    return factor * factor;
+}
+IG_DEV float fresnel_dielectric(float eta, float cos_i) // core/math.art:120-123
+{
+    float cos_t, factor;
+    return fresnel(eta, cos_i, cos_t, factor) ? factor : 1.0f;
+}
+IG_DEV float refl_jacobian(float c) { return safe_div(1, 4 * c); } // core/shading.art:69
+IG_DEV float refr_jacobian(float eta, float cos_i, float cos_o)     // core/shading.art:71-74
+{
+    const float jacob_d = cos_i + cos_o * eta;
+    return safe_div(eta * eta * cos_i, jacob_d * jacob_d);
+}
+IG_DEV f3 halfway_refractive(f3 a, f3 b, float eta) { return normalize3(a + b * eta); }          // core/vector.art:142
+IG_DEV bool pos_hemi(f3 v) { return v.z >= 0; }                                                  // core/shading.art:62
+IG_DEV bool same_hemi(f3 a, f3 b) { return pos_hemi(a) == pos_hemi(b); }                         // core/shading.art:63
+IG_DEV f3 make_same_hemi(f3 a, f3 b) { return same_hemi(a, b) ? b : -b; }                        // core/shading.art:65
+IG_DEV f3 make_pos_hemi(f3 v) { return pos_hemi(v) ? v : -v; }                                   // core/shading.art:66
+
+struct Principled {
+    m33 local;
+    bool entering;
+    Col base;
+    float refl_ior, refr_ior, diff_trans, spec_trans, spec_tint;
+    float ru, rv, flatness, metallic, sheen, sheen_tint, clearcoat, cc_gloss, cc_rough;
+    bool thin, cc_top_only;
+    float refl_eta, refr_eta;
+
+    static constexpr float kMicroEps   = 1e-5f; // principled.art:243-244
+    static constexpr float kGrazingEps = 1e-5f;
+
+    // make_principled_bsdf (principled.art:236-268)
+    IG_DEV Principled(const ig_material& m, const m33& frame, bool is_entering, Col base_color)
+    {
+        local       = frame;
+        entering    = is_entering;
+        base        = base_color;
+        refl_ior    = m.p[3];
+        refr_ior    = m.p[4];
+        diff_trans  = m.p[5];
+        spec_trans  = m.p[6];
+        spec_tint   = m.p[7];
+        ru          = igm_max(1e-3f, m.p[8]);
+        rv          = igm_max(1e-3f, m.p[9]);
+        flatness    = m.p[10];
+        metallic    = m.r[0];
+        sheen       = m.r[1];
+        sheen_tint  = m.r[2];
+        clearcoat   = m.r[3];
+        cc_gloss    = m.r[4];
+        cc_rough    = m.r[5];
+        thin        = (m.flags & IG_MAT_THIN) != 0;
+        cc_top_only = (m.flags & IG_MAT_CLEARCOAT_ALL) == 0;
+        refl_eta    = (entering || thin) ? 1 / refl_ior : refl_ior;
+        refr_eta    = (entering || thin) ? 1 / refr_ior : refr_ior;
+    }
+
+    IG_DEV static m33 identity()
+    {
+        m33 m;
+        m.c0 = f3{ 1, 0, 0 }, m.c1 = f3{ 0, 1, 0 }, m.c2 = f3{ 0, 0, 1 };
+        return m;
+    }
+    IG_DEV f3 to_local(f3 v) const { return f3{ dot3(local.c0, v), dot3(local.c1, v), dot3(local.c2, v) }; }
+    IG_DEV f3 to_world(f3 v) const { return (local.c0 * v.x + local.c1 * v.y) + local.c2 * v.z; }
+
+    // tint_color (principled.art:52-59)
+    IG_DEV static Col tint(Col c)
+    {
+        const float lum = luminance(c);
+        return lum <= kFltEps ? Col{ 1, 1, 1 } : c * safe_div(1, lum);
+    }
+    // getMicro / getReflectionMicro / getRefractionMicro (principled.art:62-78)
+    IG_DEV static Ggx micro(float a, float b) { return Ggx{ identity(), igm_max(1e-3f, a * a), igm_max(1e-3f, b * b) }; }
+    IG_DEV Ggx refl_micro() const { return micro(ru, rv); }
+    IG_DEV Ggx refr_micro() const
+    {
+        if (thin)
+            return micro(clampf((0.65f * refr_ior - 0.35f) * ru, 0, 1), clampf((0.65f * refr_ior - 0.35f) * rv, 0, 1));
+        return micro(ru, rv);
+    }
+
+    // evalDisneyFresnelTerm (principled.art:80-95)
+    IG_DEV Col fresnel_term(f3 wo, f3 wi, f3 h) const
+    {
+        const float HdV = abs_cos(wo, h);
+        const float HdL = abs_cos(wi, h);
+        if (HdV * HdL <= kFltEps)
+            return Col{ 0, 0, 0 };
+        const float f1v = fresnel_dielectric(refl_eta, HdV);
+        const Col f1{ f1v, f1v, f1v };
+        const Col color = tint(base);
+        const Col a     = lerp_col(Col{ 1, 1, 1 }, color, spec_tint);
+        const Col r0    = lerp_col(a * schlick_r0(refl_eta), base, metallic);
+        const float s   = schlick_approx(HdL); // schlick(r0, white, HdL), core/fresnel.art:93-97
+        const Col f2{ r0.r + (1 - r0.r) * s, r0.g + (1 - r0.g) * s, r0.b + (1 - r0.b) * s };
+        return lerp_col(f1, f2, metallic);
+    }
+    // evalSubsurfaceTerm (principled.art:97-108)
+    IG_DEV float subsurface_term(f3 wo, f3 wi, f3 h) const
+    {
+        const float r2    = ru * rv;
+        const float HdotL = dot3(wi, h);
+        const float fss90 = HdotL * HdotL * r2;
+        const float aNdL  = igm_abs(wi.z);
+        const float aNdV  = igm_abs(wo.z);
+        const float lk    = schlick_approx(aNdL);
+        const float vk    = schlick_approx(aNdV);
+        const float fss   = (1 - lk + fss90 * lk) * (1 - vk + fss90 * vk);
+        return 1.25f * (fss * (1 / (aNdL + aNdV + 1e-5f) - 0.5f) + 0.5f);
+    }
+    // evalSheenTerm (principled.art:110-113)
+    IG_DEV Col sheen_term(f3 wi) const
+    {
+        const float lk = schlick_approx(igm_abs(wi.z));
+        return lerp_col(Col{ 1, 1, 1 }, tint(base), sheen_tint) * (sheen * lk * igm_abs(wi.z));
+    }
+    // evalDiffuseTerm (principled.art:115-128)
+    IG_DEV float diffuse_term(f3 wo, f3 wi, f3 h) const
+    {
+        const float lk    = schlick_approx(igm_abs(wi.z));
+        const float vk    = schlick_approx(igm_abs(wo.z));
+        const float diff  = (1 - 0.5f * lk) * (1 - 0.5f * vk);
+        const float VdotL = abs_cos(wi, wo);
+        const float rr    = (VdotL + 1) * (ru + rv) / 2;
+        const float retro = rr * (lk + vk + lk * vk * (rr - 1));
+        const float ss    = thin ? 1 - flatness + subsurface_term(wo, wi, h) * flatness : 1.0f;
+        return kInvPi * (diff + retro) * ss * igm_abs(wi.z);
+    }
+    // evalTranslucentTerm (principled.art:130-137)
+    IG_DEV float translucent_term(f3 wo, f3 wi) const
+    {
+        const float lk   = schlick_approx(igm_abs(wi.z));
+        const float vk   = schlick_approx(igm_abs(wo.z));
+        const float diff = (1 - 0.5f * lk) * (1 - 0.5f * vk);
+        return kInvPi * diff * igm_abs(wi.z);
+    }
+    // evalReflectionTerm (principled.art:139-148)
+    IG_DEV Col reflection_term(f3 wo, f3 wi, f3 h) const
+    {
+        const Ggx m       = refl_micro();
+        const Col F       = fresnel_term(wo, wi, h);
+        const float D     = m.D(h);
+        const float G     = m.G1(wi) * m.G1(wo);
+        const float jacob = refl_jacobian(wo.z);
+        return F * igm_abs(D * G * jacob);
+    }
+    // evalRefractionTerm (principled.art:150-176)
+    IG_DEV Col refraction_term(f3 wo, f3 wi, f3 h) const
+    {
+        if (thin) {
+            const float fterm = fresnel_dielectric(refr_eta, igm_abs(wo.z));
+            const float F     = fterm + (1 - fterm) * fterm / (fterm + 1);
+            return Col{ igm_sqrt(base.r), igm_sqrt(base.g), igm_sqrt(base.b) } * (1 - F);
+        }
+        const Ggx m       = refr_micro();
+        const float HdI   = dot3(wi, h);
+        const float HdO   = dot3(wo, h);
+        const float F     = fresnel_dielectric(refr_eta, igm_abs(HdO));
+        const float D     = m.D(h);
+        const float G     = m.G1(wi) * m.G1(wo);
+        const float jacob = refr_jacobian(refr_eta, HdI, HdO);
+        const float norm  = igm_abs(safe_div(HdO * jacob, wo.z));
+        return base * ((1 - F) * D * G * norm);
+    }
+    // evalClearcoatTerm (principled.art:178-191)
+    IG_DEV Col clearcoat_term(f3 wo, f3 wi, f3 h) const
+    {
+        const float F0   = 0.04f;
+        const float R    = 0.25f;
+        const float R2   = igm_max(0.001f, cc_rough * (1 - cc_gloss) + 0.01f * cc_gloss);
+        const float aHdL = abs_cos(wi, h);
+        const float d    = Ggx{ identity(), R2, R2 }.D(h);
+        const float f    = F0 + (1 - F0) * schlick_approx(aHdL); // schlick_f, core/fresnel.art:99
+        const Ggx gm{ identity(), R, R };
+        const float g     = gm.G1(wi) * gm.G1(wo);
+        const float jacob = refl_jacobian(wo.z);
+        const float v     = igm_abs(R * d * f * g * jacob * wi.z);
+        return Col{ v, v, v };
+    }
+
+    struct Lobes {
+        float diff_refl, diff_trans, spec_refl, spec_trans;
+    };
+    // calcLobeDistribution (principled.art:200-233)
+    IG_DEV Lobes lobes(f3 wo) const
+    {
+        const float metallic_in   = clampf(metallic, 0, 1);
+        const float diff_trans_in = clampf(diff_trans, 0, 1);
+        const float spec_trans_in = clampf(spec_trans, 0, 1);
+        const float abs_gen       = luminance(base);
+        const float abs_spec      = lerpf(1, luminance(tint(base)), spec_tint);
+        const float d_refl        = clampf(abs_gen * (1 - metallic_in) * (1 - spec_trans_in), 0, 1);
+        const float F             = fresnel_dielectric(refr_eta, igm_abs(wo.z));
+        const float s_refl        = clampf(abs_spec * (1 - F) + F, 0, 1);
+        const bool has_transmission = diff_trans_in > 0 || spec_trans_in > 0;
+        if (!has_transmission) {
+            const float norm = d_refl + s_refl;
+            if (norm > kFltEps)
+                return Lobes{ d_refl / norm, 0, s_refl / norm, 0 };
+            return Lobes{ 1, 0, 0, 0 };
+        }
+        const float d_trans = clampf(abs_gen * diff_trans_in * d_refl, 0, 1);
+        const float s_trans = clampf((1 - F) * abs_gen * (1 - metallic_in) * spec_trans_in, 0, 1);
+        const float norm    = d_refl + s_refl + d_trans + s_trans;
+        if (norm > kFltEps)
+            return Lobes{ d_refl / norm, d_trans / norm, s_refl / norm, s_trans / norm };
+        return Lobes{ 1, 0, 0, 0 };
+    }
+
+    // eval (principled.art:270-334)
+    IG_DEV Col eval(f3 in_dir, f3 out_dir) const
+    {
+        const f3 wo = to_local(out_dir);
+        const f3 wi = to_local(in_dir);
+        const bool is_transmission = !same_hemi(wi, wo);
+        const f3 h = make_same_hemi(wo, is_transmission ? halfway_refractive(wi, wo, refr_eta) : normalize3(wi + wo));
+        const bool in_front  = entering == pos_hemi(wi);
+        const bool out_front = entering == pos_hemi(wo);
+        const bool upper     = in_front && out_front;
+        if (igm_abs(wi.z) <= kGrazingEps)
+            return Col{ 0, 0, 0 };
+        Col contrib{ 0, 0, 0 };
+        const float diffuse_weight = (thin ? 1.0f : 1 - clampf(metallic, 0, 1)) * (1 - clampf(spec_trans, 0, 1));
+        const float trans_weight   = (1 - clampf(metallic, 0, 1)) * clampf(spec_trans, 0, 1);
+        const float spec_weight    = 1;
+        if (!is_transmission) {
+            if (diffuse_weight > 0)
+                contrib = contrib + base * (diffuse_term(wo, wi, h) * diffuse_weight);
+            if (sheen > 0)
+                contrib = contrib + sheen_term(wi) * diffuse_weight;
+            contrib = contrib + reflection_term(wo, wi, h) * spec_weight;
+            if ((!cc_top_only || upper) && clearcoat > 0)
+                contrib = contrib + clearcoat_term(wo, wi, h) * clearcoat;
+        } else {
+            if (thin && diff_trans > 0)
+                contrib = contrib + base * (translucent_term(wo, wi) * diff_trans);
+            if (spec_trans > 0)
+                contrib = contrib + refraction_term(wo, wi, h) * trans_weight;
+        }
+        return contrib;
+    }
+
+    // diffPdf_local / specReflPdf_local / specTransPdf_local (principled.art:336-359)
+    IG_DEV static float bound_spec_pdf(float v) { return v > kMicroEps ? v : 0.0f; }
+    IG_DEV static float diff_pdf_local(f3 wi) { return igm_abs(wi.z) / kPi; }
+    IG_DEV float spec_refl_pdf_local(f3 wo, f3 wi) const
+    {
+        const f3 pwo    = make_pos_hemi(wo);
+        const f3 pwi    = make_pos_hemi(wi);
+        const Ggx m     = refl_micro();
+        const f3 H      = normalize3(pwo + pwi);
+        const float cho = dot3(pwo, H);
+        return igm_abs(bound_spec_pdf(m.pdf(pwo, H)) * refl_jacobian(cho));
+    }
+    IG_DEV float spec_trans_pdf_local(f3 wo, f3 wi) const
+    {
+        const f3 pwo    = make_pos_hemi(wo);
+        const f3 pwi    = -make_pos_hemi(wi);
+        const Ggx m     = refr_micro();
+        const f3 H      = halfway_refractive(pwi, pwo, refr_eta);
+        const float chi = dot3(pwi, H);
+        const float cho = dot3(pwo, H);
+        return igm_abs(bound_spec_pdf(m.pdf(pwo, H)) * refr_jacobian(refr_eta, chi, cho));
+    }
+    // pdf (principled.art:361-377)
+    IG_DEV float pdf(f3 in_dir, f3 out_dir) const
+    {
+        const f3 wo = to_local(out_dir);
+        const f3 wi = to_local(in_dir);
+        if (igm_abs(wo.z) <= kGrazingEps || igm_abs(wi.z) <= kGrazingEps)
+            return 0;
+        const Lobes l        = lobes(wo);
+        const float diff_pdf = diff_pdf_local(wi);
+        if (same_hemi(wo, wi))
+            return l.diff_refl * diff_pdf + l.spec_refl * spec_refl_pdf_local(wo, wi);
+        if (thin)
+            return l.diff_trans * diff_pdf + l.spec_trans;
+        return l.diff_trans * diff_pdf + l.spec_trans * spec_trans_pdf_local(wo, wi);
+    }
+
+    // sample_cosine_hemisphere (core/sampling.art:62-70)
+    IG_DEV static f3 cosine_hemisphere(Tea& rnd, float& pdf_out)
+    {
+        const float u   = rnd.f32();
+        const float v   = rnd.f32();
+        const float c   = safe_sqrt(v);
+        const float s   = safe_sqrt(1 - v);
+        const float phi = 2 * kPi * u;
+        pdf_out         = c / kPi;
+        return f3{ s * igm_cos(phi), s * igm_sin(phi), c };
+    }
+
+    // sample (principled.art:382-476), adjoint = false; false = reject_bsdf_sample()
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta) const
+    {
+        const f3 wo = to_local(out_dir);
+        if (igm_abs(wo.z) <= kGrazingEps)
+            return false;
+        const Lobes l    = lobes(wo);
+        const float pick = rnd.f32();
+        f3 dir;
+        float spdf;
+        if (pick < l.diff_refl) {
+            float cpdf;
+            const f3 d = cosine_hemisphere(rnd, cpdf);
+            dir        = make_same_hemi(wo, d);
+            spdf       = cpdf * l.diff_refl + spec_refl_pdf_local(wo, dir) * l.spec_refl;
+        } else if (pick < l.diff_refl + l.diff_trans) {
+            float cpdf;
+            const f3 d = cosine_hemisphere(rnd, cpdf);
+            dir        = -make_same_hemi(wo, d);
+            spdf       = cpdf * l.diff_trans + spec_trans_pdf_local(wo, dir) * l.spec_trans;
+        } else if (pick < l.diff_refl + l.diff_trans + l.spec_trans) {
+            if (thin) {
+                dir  = -wo;
+                spdf = l.spec_trans;
+            } else {
+                const f3 pwo     = make_pos_hemi(wo);
+                const Ggx m      = refr_micro();
+                const f3 n       = m.sample(rnd, pwo);
+                const float mpdf = m.pdf(pwo, n);
+                if (mpdf <= kMicroEps || dot3(n, n) <= kFltEps)
+                    return false;
+                const f3 oH     = normalize3(n);
+                const f3 H      = igm_signbit(dot3(oH, pwo)) ? -oH : oH;
+                const float cho = dot3(pwo, H);
+                float cos_t, factor;
+                if (fresnel(refr_eta, cho, cos_t, factor)) {
+                    const f3 pwi = normalize3(H * (refr_eta * cho - cos_t) - pwo * refr_eta); // vec3_refract (core/vector.art:126)
+                    if (!same_hemi(pwo, pwi) && cho > kFltEps && -pwi.z > kGrazingEps) {
+                        dir  = -make_same_hemi(wo, pwi);
+                        spdf = igm_abs(mpdf * refr_jacobian(refr_eta, dot3(pwi, H), cho)) * l.spec_trans + diff_pdf_local(dir) * l.diff_trans;
+                    } else {
+                        return false;
+                    }
+                } else { // total reflection
+                    const f3 pwi = normalize3(H * (2 * dot3(H, pwo)) - pwo); // vec3_reflect (core/vector.art:123)
+                    if (same_hemi(pwo, pwi) && cho > kFltEps && pwi.z > kGrazingEps) {
+                        dir  = make_same_hemi(wo, pwi);
+                        spdf = mpdf * refl_jacobian(cho) * l.spec_trans + diff_pdf_local(dir) * l.diff_trans;
+                    } else {
+                        return false;
+                    }
+                }
+            }
+        } else {
+            const f3 pwo     = make_pos_hemi(wo);
+            const Ggx m      = refl_micro();
+            const f3 n       = m.sample(rnd, pwo);
+            const float mpdf = m.pdf(pwo, n);
+            if (mpdf <= kMicroEps || dot3(n, n) <= kFltEps)
+                return false;
+            const f3 oH     = normalize3(n);
+            const f3 H      = igm_signbit(dot3(oH, pwo)) ? -oH : oH;
+            const float cho = dot3(pwo, H);
+            const f3 pwi    = normalize3(H * (2 * dot3(H, pwo)) - pwo);
+            if (same_hemi(pwo, pwi) && cho > kFltEps && pwi.z > kGrazingEps) {
+                dir  = make_same_hemi(wo, pwi);
+                spdf = igm_abs(mpdf * refl_jacobian(cho)) * l.spec_refl + diff_pdf_local(dir) * l.diff_refl;
+            } else {
+                return false;
+            }
+        }
+        if (!(spdf > kFltEps && igm_abs(spdf) <= 3.402823466e+38f))
+            return false;
+        s_eta   = (thin || same_hemi(wo, dir)) ? 1.0f : refr_eta;
+        in_dir  = to_world(dir);
+        pdf_out = spdf;
+        color   = eval(in_dir, out_dir) * (1 / spdf);
+        return true;
+    }
+};
+
+// FULL = false leaves the principled BSDF out of the kernel (scenes without one run the lean variant)
+template <bool FULL>
 struct BsdfCtx {
     const ig_material* mat;
     Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
@@ -488,9 +876,15 @@ struct BsdfCtx {
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
+    IG_DEV Principled principled() const { return Principled(*mat, surf.local, surf.entering, kd); }
+
     IG_DEV Col eval(f3 in_dir, f3 out_dir) const
     {
         const f3 N = surf.local.c2;
+        if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+                return principled().eval(in_dir, out_dir);
+        }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return kd * (pos_cos(in_dir, N) * kInvPi);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -512,6 +906,10 @@ struct BsdfCtx {
     }
     IG_DEV float pdf(f3 in_dir, f3 out_dir) const
     {
+        if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+                return principled().pdf(in_dir, out_dir);
+        }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return pos_cos(in_dir, surf.local.c2) / kPi;
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -525,6 +923,12 @@ struct BsdfCtx {
     IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
     {
         const f3 N = surf.local.c2;
+        if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
+                sdelta = false;
+                return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
+            }
+        }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
             // make_lambertian_bsdf.sample (bsdf/diffuse.art:5-9), sample_cosine_hemisphere (core/sampling.art:62-70)
             const float u   = rnd.f32();
@@ -760,6 +1164,7 @@ IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, techniq
 
 // gpu_hit_shade / gpu_miss_shade body (driver/mapping_gpu.art:123-274) with the path tracer
 // callbacks on_hit / on_shadow / on_bounce / on_miss (technique/pathtracer.art:52-210).
+template <bool FULL>
 IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out)
 {
     out.has_radiance = false;
@@ -794,7 +1199,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
     const Surf surf = surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
-    const BsdfCtx bsdf(sc, mat, surf, in.dir);
+    const BsdfCtx<FULL> bsdf(sc, mat, surf, in.dir);
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 

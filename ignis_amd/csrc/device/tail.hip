@@ -22,7 +22,7 @@ namespace igdev {
 // workgroup's 48 KiB, which matters because the tail overlaps the next chunk's traversal launches.
 constexpr int kTailThreads = 64;
 
-template <bool STATS>
+template <bool STATS, bool FULL>
 __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
 {
     __shared__ StackOf<kTailThreads> s_stack;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
             }
 
             PathVertexOut out;
-            shade_vertex(sc, a.frame, in, out);
+            shade_vertex<FULL>(sc, a.frame, in, out);
             if (out.has_radiance) {
                 acc.x += out.radiance.r * a.inv_spi;
                 acc.y += out.radiance.g * a.inv_spi;
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail_wave(const TailArgs a)
                 in.ent     = (int)igm_bits(hit.x);
                 in.prim    = (int)igm_bits(hit.y);
                 in.t = hit.z, in.u = hit.w, in.v = src.hit_v[i];
-                shade_vertex(sc, a.frame, in, out);
+                shade_vertex<false>(sc, a.frame, in, out);
                 if (out.has_radiance) {
                     float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
                     float4 v    = *acc;
@@ -430,15 +430,25 @@ void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStre
         hipLaunchKernelGGL((k_tail_wave<false>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
 }
 
-template __global__ void k_tail<false>(const TailArgs);
-template __global__ void k_tail<true>(const TailArgs);
+template __global__ void k_tail<false, false>(const TailArgs);
+template __global__ void k_tail<true, false>(const TailArgs);
+template __global__ void k_tail<false, true>(const TailArgs);
+template __global__ void k_tail<true, true>(const TailArgs);
 
-void launch_tail(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream)
+void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream)
 {
-    if (stats)
-        hipLaunchKernelGGL((k_tail<true>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
-    else
-        hipLaunchKernelGGL((k_tail<false>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
+    const dim3 grid((unsigned)grid_blocks), block(kTailThreads);
+    if (full_bsdfs) {
+        if (stats)
+            hipLaunchKernelGGL((k_tail<true, true>), grid, block, 0, stream, args);
+        else
+            hipLaunchKernelGGL((k_tail<false, true>), grid, block, 0, stream, args);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((k_tail<true, false>), grid, block, 0, stream, args);
+        else
+            hipLaunchKernelGGL((k_tail<false, false>), grid, block, 0, stream, args);
+    }
 }
 
 } // namespace igdev

@@ -605,6 +605,57 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[10] = r * aspect;
         if (smooth || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
             m.flags |= IG_MAT_SMOOTH;
+    } else if (type == "principled") {
+        // PrincipledBSDF.cpp:14-98: numbers are constants here (the reference also accepts textures / expressions)
+        for (const char* key : { "reflective_ior_spec", "refractive_ior_spec", "ior_spec" })
+            if (bsdf->has(key))
+                fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
+        m.bsdf_type = IG_BSDF_PRINCIPLED;
+        const JsonValue* col = bsdf->find("base_color");
+        bool is_bitmap       = false;
+        if (col && col->isString())
+            for (const auto& t : textures.arr)
+                if (t.getString("name") == col->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
+                    is_bitmap = true;
+        if (is_bitmap) {
+            m.flags |= IG_MAT_IMAGE;
+            m.tex_refl = bank.get(col->str, name);
+        } else if (!(col && lowerCheckerboard(*col, textures, m, name))) {
+            const V3 c = getColor(*bsdf, "base_color", V3(0.8f, 0.8f, 0.8f), name);
+            m.p[0] = c.x, m.p[1] = c.y, m.p[2] = c.z;
+        }
+        const float bk7 = 1.5046f; // BSDF.cpp:9
+        if (bsdf->has("reflective_ior") || bsdf->has("refractive_ior")) {
+            m.p[3] = getConstNumber(*bsdf, "reflective_ior", bk7, name);
+            m.p[4] = getConstNumber(*bsdf, "refractive_ior", bk7, name);
+        } else {
+            m.p[3] = m.p[4] = getConstNumber(*bsdf, "ior", bk7, name);
+        }
+        m.p[5] = getConstNumber(*bsdf, "diffuse_transmission", 0.0f, name);
+        m.p[6] = getConstNumber(*bsdf, "specular_transmission", 0.0f, name);
+        m.p[7] = getConstNumber(*bsdf, "specular_tint", 0.0f, name);
+        if (bsdf->has("roughness_u") || bsdf->has("roughness_v")) {
+            m.p[8] = getConstNumber(*bsdf, "roughness_u", 0.5f, name);
+            m.p[9] = getConstNumber(*bsdf, "roughness_v", 0.5f, name);
+        } else {
+            // microfacet::compute_explicit (src/artic/core/microfacet.art:427-432)
+            const float r      = getConstNumber(*bsdf, "roughness", 0.5f, name);
+            const float an     = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
+            const float aspect = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+            m.p[8]             = r / aspect;
+            m.p[9]             = r * aspect;
+        }
+        m.p[10] = getConstNumber(*bsdf, "flatness", 0.0f, name);
+        m.r[0]  = getConstNumber(*bsdf, "metallic", 0.0f, name);
+        m.r[1]  = getConstNumber(*bsdf, "sheen", 0.0f, name);
+        m.r[2]  = getConstNumber(*bsdf, "sheen_tint", 0.0f, name);
+        m.r[3]  = getConstNumber(*bsdf, "clearcoat", 0.0f, name);
+        m.r[4]  = getConstNumber(*bsdf, "clearcoat_gloss", 0.0f, name);
+        m.r[5]  = getConstNumber(*bsdf, "clearcoat_roughness", 0.1f, name);
+        if (bsdf->getBool("thin", false))
+            m.flags |= IG_MAT_THIN;
+        if (!bsdf->getBool("clearcoat_top_only", true))
+            m.flags |= IG_MAT_CLEARCOAT_ALL;
     } else if (type == "bumpmap" || type == "normalmap") {
         // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
         // make_normalmap(ctx, inner, map colour, strength)

@@ -32,7 +32,8 @@ class LookupEntry(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("bsdf_type", C.c_int32), ("light_id", C.c_int32), ("flags", C.c_uint32), ("tex_id", C.c_int32),
-                ("p", C.c_float * 12), ("q", C.c_float * 8), ("tex_refl", C.c_int32), ("pad", C.c_int32 * 3)]
+                ("p", C.c_float * 12), ("q", C.c_float * 8), ("tex_refl", C.c_int32), ("pad", C.c_int32 * 3),
+                ("r", C.c_float * 8)]
 
 
 class Light(C.Structure):
@@ -79,7 +80,7 @@ class Scene(C.Structure):
 
 
 assert C.sizeof(Node8) == 256 and C.sizeof(Tri4) == 208 and C.sizeof(EntityLeaf1) == 96
-assert C.sizeof(Material) == 112 and C.sizeof(Light) == 112
+assert C.sizeof(Material) == 144 and C.sizeof(Light) == 112
 
 
 class HostOptions(C.Structure):

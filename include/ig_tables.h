@@ -86,6 +86,7 @@ enum ig_bsdf_type {
     IG_BSDF_DIFFUSE    = 0, /* src/artic/bsdf/diffuse.art:2-61,   runtime/bsdf/DiffuseBSDF.cpp:13-27 */
     IG_BSDF_DIELECTRIC = 1, /* src/artic/bsdf/dielectric.art:15-37, runtime/bsdf/DielectricBSDF.cpp:13-41 */
     IG_BSDF_CONDUCTOR  = 2, /* src/artic/bsdf/conductor.art:47-141, runtime/bsdf/ConductorBSDF.cpp:13-34 */
+    IG_BSDF_PRINCIPLED = 3, /* src/artic/bsdf/principled.art:236-481, runtime/bsdf/PrincipledBSDF.cpp:14-98 */
 };
 
 enum ig_material_flags {
@@ -95,11 +96,13 @@ enum ig_material_flags {
     IG_MAT_NORMALMAP  = 1u << 3, /* wrapped in a normalmap (src/artic/bsdf/map.art:36-42,55-61): tex_id, p[11] */
     IG_MAT_SMOOTH     = 1u << 5, /* conductor without roughness ("mirror", or roughness <= 1e-4): the delta branch of
                                   * make_rough_base_conductor_bsdf, src/artic/bsdf/conductor.art:56-68 */
-    IG_MAT_IMAGE      = 1u << 4, /* diffuse reflectance is the bitmap texture tex_refl (DiffuseBSDF.cpp:18, texture/image.art) */
+    IG_MAT_IMAGE      = 1u << 4, /* diffuse reflectance / principled base colour is the bitmap texture tex_refl
+                                  * (DiffuseBSDF.cpp:18, texture/image.art) */
+    IG_MAT_CLEARCOAT_ALL = 1u << 6, /* principled: clearcoat_top_only = false (PrincipledBSDF.cpp:56) */
 };
 
 /* One record per material (= unique bsdf / area-light entity,
- * src/runtime/loader/LoaderEntity.cpp:82-96). 112 bytes. */
+ * src/runtime/loader/LoaderEntity.cpp:82-96). 144 bytes. */
 typedef struct ig_material {
     int32_t bsdf_type;
     int32_t light_id; /* >= 0: emissive, index into lights (area light on this entity) */
@@ -112,11 +115,16 @@ typedef struct ig_material {
      * conductor:  p[0..2] eta, p[3..5] k, p[6..8] specular_reflectance,
      *             p[9] alpha_u, p[10] alpha_v
      * bump:       p[11] strength
-     * checker:    q[0..2] color0, q[3..5] color1, q[6] scale_x, q[7] scale_y */
+     * checker:    q[0..2] color0, q[3..5] color1, q[6] scale_x, q[7] scale_y
+     * principled: p[0..2] base_color (or checker / image like the diffuse reflectance), p[3] reflective_ior,
+     *             p[4] refractive_ior, p[5] diffuse_transmission, p[6] specular_transmission, p[7] specular_tint,
+     *             p[8] roughness_u, p[9] roughness_v, p[10] flatness; r[0] metallic, r[1] sheen, r[2] sheen_tint,
+     *             r[3] clearcoat, r[4] clearcoat_gloss, r[5] clearcoat_roughness; IG_MAT_THIN, IG_MAT_CLEARCOAT_ALL */
     float p[12];
     float q[8];
     int32_t tex_refl; /* bitmap texture index of the diffuse reflectance (IG_MAT_IMAGE), -1 = none */
     int32_t pad[3];
+    float r[8];
 } ig_material;
 
 /* ---- Bitmap textures --------------------------------------------------- */

@@ -204,5 +204,32 @@ def image_lookup(scene, tex_id, uv):
     return out
 
 
+def bsdf_eval(scene, mat_id, wo, wi, entering=True):
+    """eval (cosine included, as in the reference) and pdf of material `mat_id` on a flat surface with normal +z."""
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    wo = np.ascontiguousarray(wo, dtype=np.float32)
+    pdf = np.zeros(wi.shape[0], np.float32)
+    col = np.zeros((wi.shape[0], 3), np.float32)
+    rc = lib().oracle_bsdf_probe(scene.tables, C.c_int32(mat_id), C.c_int32(int(entering)), C.c_int32(0), _fp(wo),
+                                 C.c_int64(wi.shape[0]), C.c_uint32(0), _fp(wi), _fp(pdf), _fp(col), None)
+    if rc != 0:
+        raise RuntimeError("oracle_bsdf_probe failed")
+    return col, pdf
+
+
+def bsdf_sample(scene, mat_id, wo, n, seed=1, entering=True):
+    """n BSDF samples: directions, pdfs, weights (eval / pdf), eta; rejected samples have pdf 0."""
+    wo = np.ascontiguousarray(wo, dtype=np.float32)
+    wi = np.zeros((n, 3), np.float32)
+    pdf = np.zeros(n, np.float32)
+    col = np.zeros((n, 3), np.float32)
+    eta = np.ones(n, np.float32)
+    rc = lib().oracle_bsdf_probe(scene.tables, C.c_int32(mat_id), C.c_int32(int(entering)), C.c_int32(1), _fp(wo),
+                                 C.c_int64(n), C.c_uint32(seed), _fp(wi), _fp(pdf), _fp(col), _fp(eta))
+    if rc != 0:
+        raise RuntimeError("oracle_bsdf_probe failed")
+    return wi, pdf, col, eta
+
+
 def hardware_threads():
     return int(lib().oracle_hardware_threads())

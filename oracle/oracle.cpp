@@ -671,6 +671,51 @@ void oracle_image_lookup(const igd_scene* scene, int32_t tex_id, int64_t n, cons
     }
 }
 
+// BSDF probe for the tests: material `mat_id` of the scene on a flat surface with normal +z (shading frame = identity,
+// texture coordinate (0.5, 0.5)), `entering` as given. mode 0: eval + pdf for n pairs (wi[n][3], wo fixed);
+// mode 1: n samples from RNG seed `seed` (counter 1): wi, pdf, colour (weight = eval / pdf), eta; rejected samples get pdf 0.
+int oracle_bsdf_probe(const igd_scene* sc, int32_t mat_id, int32_t entering, int32_t mode, const float wo[3], int64_t n, uint32_t seed,
+                      float* wi, float* pdf, float* color, float* eta)
+{
+    if (!sc || mat_id < 0 || (uint32_t)mat_id >= sc->material_count)
+        return -1;
+    SurfaceElement surf{};
+    surf.is_entering  = entering != 0;
+    surf.point        = make_vec3(0, 0, 0);
+    surf.face_normal  = make_vec3(0, 0, 1);
+    surf.tex_coords   = Vec2{ 0.5f, 0.5f };
+    surf.local.col[0] = make_vec3(1, 0, 0);
+    surf.local.col[1] = make_vec3(0, 1, 0);
+    surf.local.col[2] = make_vec3(0, 0, 1);
+    const ig_material& mat = sc->materials[mat_id];
+    const Bsdf bsdf{ &mat, &surf, sc };
+    const Vec3 out_dir = make_vec3(wo[0], wo[1], wo[2]);
+    Rng rnd{ seed, 1 };
+    for (int64_t i = 0; i < n; ++i) {
+        if (mode == 0) {
+            const Vec3 in_dir = make_vec3(wi[i * 3], wi[i * 3 + 1], wi[i * 3 + 2]);
+            const Color c     = bsdf.eval(in_dir, out_dir);
+            color[i * 3] = c.r, color[i * 3 + 1] = c.g, color[i * 3 + 2] = c.b;
+            pdf[i] = bsdf.pdf(in_dir, out_dir);
+        } else {
+            BsdfSample bs{};
+            if (bsdf.sample(rnd, out_dir, bs)) {
+                wi[i * 3] = bs.in_dir.x, wi[i * 3 + 1] = bs.in_dir.y, wi[i * 3 + 2] = bs.in_dir.z;
+                pdf[i] = bs.pdf;
+                color[i * 3] = bs.color.r, color[i * 3 + 1] = bs.color.g, color[i * 3 + 2] = bs.color.b;
+                if (eta)
+                    eta[i] = bs.eta;
+            } else {
+                pdf[i] = 0;
+                color[i * 3] = color[i * 3 + 1] = color[i * 3 + 2] = 0;
+                if (eta)
+                    eta[i] = 1;
+            }
+        }
+    }
+    return 0;
+}
+
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 } // extern "C"

@@ -282,6 +282,7 @@ static inline SurfaceElement surface_element(const igd_scene& sc, const Entity& 
 // ---- colours (core/color.art:14-36)
 static inline Color color_mul(Color a, Color b) { return Color{ a.r * b.r, a.g * b.g, a.b * b.b }; }
 static inline Color color_mulf(Color c, float f) { return Color{ c.r * f, c.g * f, c.b * f }; }
+static inline Color color_add(Color a, Color b) { return Color{ a.r + b.r, a.g + b.g, a.b + b.b }; }
 static inline float color_average(Color c) { return (c.r + c.g + c.b) / 3; }
 static inline float color_max_component(Color c) { return igm_max(c.r, igm_max(c.g, c.b)); } // vec3_max_value, vector.art:38,113
 static inline Color color_saturate(Color a, float f) { return Color{ igm_min(a.r, f), igm_min(a.g, f), igm_min(a.b, f) }; }
@@ -562,6 +563,383 @@ static inline SurfaceElement bumped_surface(const igd_scene& sc, const ig_materi
     return out;
 }
 
+// ---- principled BSDF (bsdf/principled.art). All directions of the closure are in the shading frame.
+static inline float lerpf(float a, float b, float k) { return (1 - k) * a + k * b; } // common.art:237
+static inline float color_luminance(Color c) { return c.r * 0.2126f + c.g * 0.7152f + c.b * 0.0722f; } // color.art:29,81-83
+static inline float schlick_approx(float f) // fresnel.art:88-91
+{
+    const float s = clampf(1 - f, 0, 1);
+    return (s * s) * (s * s) * s;
+}
+static inline float schlick_r0(float eta) // fresnel.art:101-104
+{
+    const float factor = clampf((eta - 1) / (eta + 1), -1, 1);
+    return factor * factor;
+}
+static inline float fresnel_dielectric(float eta, float cos_i) // math.art:120-123
+{
+    float cos_t, factor;
+    return fresnel(eta, cos_i, cos_t, factor) ? factor : 1.0f;
+}
+static inline float halfway_reflective_jacobian(float c) { return safe_div(1, 4 * c); } // shading.art:69
+static inline float halfway_refractive_jacobian(float eta, float cos_i, float cos_o)    // shading.art:71-74
+{
+    const float jacob_d = cos_i + cos_o * eta;
+    return safe_div(eta * eta * cos_i, jacob_d * jacob_d);
+}
+static inline Vec3 vec3_halfway_refractive(Vec3 a, Vec3 b, float eta) { return vec3_normalize(vec3_add(a, vec3_mulf(b, eta))); } // vector.art:142
+static inline bool is_positive_hemisphere(Vec3 v) { return v.z >= 0; }                                                          // shading.art:62
+static inline bool is_same_hemisphere(Vec3 a, Vec3 b) { return is_positive_hemisphere(a) == is_positive_hemisphere(b); }        // shading.art:63
+static inline Vec3 make_same_hemisphere(Vec3 a, Vec3 b) { return is_same_hemisphere(a, b) ? b : vec3_neg(b); }                  // shading.art:65
+static inline Vec3 make_positive_hemisphere(Vec3 v) { return is_positive_hemisphere(v) ? v : vec3_neg(v); }                     // shading.art:66
+
+struct Principled {
+    // principled::Closure (principled.art:22-43)
+    Mat3x3 local;
+    bool is_entering;
+    Color base_color;
+    float reflective_ior, refractive_ior, diffuse_transmission, specular_transmission, specular_tint;
+    float roughness_u, roughness_v, flatness, metallic, sheen, sheen_tint, clearcoat, clearcoat_gloss, clearcoat_roughness;
+    bool thin, clearcoat_top_only;
+    float reflective_eta, refractive_eta;
+
+    static constexpr float micro_eps   = 1e-5f; // principled.art:243-244
+    static constexpr float grazing_eps = 1e-5f;
+
+    // make_principled_bsdf (principled.art:236-268)
+    Principled(const ig_material& m, const SurfaceElement& surf, Color base)
+    {
+        local                 = surf.local;
+        is_entering           = surf.is_entering;
+        base_color            = base;
+        reflective_ior        = m.p[3];
+        refractive_ior        = m.p[4];
+        diffuse_transmission  = m.p[5];
+        specular_transmission = m.p[6];
+        specular_tint         = m.p[7];
+        roughness_u           = igm_max(1e-3f, m.p[8]);
+        roughness_v           = igm_max(1e-3f, m.p[9]);
+        flatness              = m.p[10];
+        metallic              = m.r[0];
+        sheen                 = m.r[1];
+        sheen_tint            = m.r[2];
+        clearcoat             = m.r[3];
+        clearcoat_gloss       = m.r[4];
+        clearcoat_roughness   = m.r[5];
+        thin                  = (m.flags & IG_MAT_THIN) != 0;
+        clearcoat_top_only    = (m.flags & IG_MAT_CLEARCOAT_ALL) == 0;
+        reflective_eta        = (is_entering || thin) ? 1 / reflective_ior : reflective_ior;
+        refractive_eta        = (is_entering || thin) ? 1 / refractive_ior : refractive_ior;
+    }
+
+    static Mat3x3 identity()
+    {
+        Mat3x3 m;
+        m.col[0] = make_vec3(1, 0, 0), m.col[1] = make_vec3(0, 1, 0), m.col[2] = make_vec3(0, 0, 1);
+        return m;
+    }
+    Vec3 to_local(Vec3 v) const { return make_vec3(vec3_dot(local.col[0], v), vec3_dot(local.col[1], v), vec3_dot(local.col[2], v)); }
+    Vec3 to_world(Vec3 v) const { return vec3_add(vec3_add(vec3_mulf(local.col[0], v.x), vec3_mulf(local.col[1], v.y)), vec3_mulf(local.col[2], v.z)); }
+
+    // tint_color / sheen_tint_color (principled.art:52-60)
+    static Color tint_color(Color c)
+    {
+        const float lum = color_luminance(c);
+        return lum <= flt_eps ? Color{ 1, 1, 1 } : color_mulf(c, safe_div(1, lum));
+    }
+    // getMicro / getReflectionMicro / getRefractionMicro (principled.art:62-78)
+    static GGX micro(float ru, float rv) { return GGX{ identity(), igm_max(1e-3f, ru * ru), igm_max(1e-3f, rv * rv) }; }
+    GGX reflection_micro() const { return micro(roughness_u, roughness_v); }
+    GGX refraction_micro() const
+    {
+        if (thin)
+            return micro(clampf((0.65f * refractive_ior - 0.35f) * roughness_u, 0, 1), clampf((0.65f * refractive_ior - 0.35f) * roughness_v, 0, 1));
+        return micro(roughness_u, roughness_v);
+    }
+
+    // evalDisneyFresnelTerm (principled.art:80-95)
+    Color fresnel_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        const float HdV = absolute_cos(wo, h);
+        const float HdL = absolute_cos(wi, h);
+        if (HdV * HdL <= flt_eps)
+            return Color{ 0, 0, 0 };
+        const float f1v = fresnel_dielectric(reflective_eta, HdV);
+        const Color f1{ f1v, f1v, f1v };
+        const Color color = tint_color(base_color);
+        const Color a     = color_lerp(Color{ 1, 1, 1 }, color, specular_tint);
+        const Color r0    = color_lerp(color_mulf(a, schlick_r0(reflective_eta)), base_color, metallic);
+        const float s     = schlick_approx(HdL); // schlick(r0, white, HdL), fresnel.art:93-97
+        const Color f2{ r0.r + (1 - r0.r) * s, r0.g + (1 - r0.g) * s, r0.b + (1 - r0.b) * s };
+        return color_lerp(f1, f2, metallic);
+    }
+    // evalSubsurfaceTerm (principled.art:97-108)
+    float subsurface_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        const float r2    = roughness_u * roughness_v;
+        const float HdotL = vec3_dot(wi, h);
+        const float fss90 = HdotL * HdotL * r2;
+        const float aNdL  = igm_abs(wi.z);
+        const float aNdV  = igm_abs(wo.z);
+        const float lk    = schlick_approx(aNdL);
+        const float vk    = schlick_approx(aNdV);
+        const float fss   = (1 - lk + fss90 * lk) * (1 - vk + fss90 * vk);
+        return 1.25f * (fss * (1 / (aNdL + aNdV + 1e-5f) - 0.5f) + 0.5f);
+    }
+    // evalSheenTerm (principled.art:110-113)
+    Color sheen_term(Vec3 wi) const
+    {
+        const float lk = schlick_approx(igm_abs(wi.z));
+        return color_mulf(color_lerp(Color{ 1, 1, 1 }, tint_color(base_color), sheen_tint), sheen * lk * igm_abs(wi.z));
+    }
+    // evalDiffuseTerm (principled.art:115-128)
+    float diffuse_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        const float lk    = schlick_approx(igm_abs(wi.z));
+        const float vk    = schlick_approx(igm_abs(wo.z));
+        const float diff  = (1 - 0.5f * lk) * (1 - 0.5f * vk);
+        const float VdotL = absolute_cos(wi, wo);
+        const float rr    = (VdotL + 1) * (roughness_u + roughness_v) / 2;
+        const float retro = rr * (lk + vk + lk * vk * (rr - 1));
+        const float ss    = thin ? 1 - flatness + subsurface_term(wo, wi, h) * flatness : 1.0f;
+        return flt_inv_pi * (diff + retro) * ss * igm_abs(wi.z);
+    }
+    // evalTranslucentTerm (principled.art:130-137)
+    float translucent_term(Vec3 wo, Vec3 wi) const
+    {
+        const float lk   = schlick_approx(igm_abs(wi.z));
+        const float vk   = schlick_approx(igm_abs(wo.z));
+        const float diff = (1 - 0.5f * lk) * (1 - 0.5f * vk);
+        return flt_inv_pi * diff * igm_abs(wi.z);
+    }
+    // evalReflectionTerm (principled.art:139-148)
+    Color reflection_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        const GGX m       = reflection_micro();
+        const Color F     = fresnel_term(wo, wi, h);
+        const float D     = m.D(h);
+        const float G     = m.G1(wi) * m.G1(wo);
+        const float jacob = halfway_reflective_jacobian(wo.z);
+        return color_mulf(F, igm_abs(D * G * jacob));
+    }
+    // evalRefractionTerm (principled.art:150-176)
+    Color refraction_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        if (thin) {
+            const float fterm = fresnel_dielectric(refractive_eta, igm_abs(wo.z));
+            const float F     = fterm + (1 - fterm) * fterm / (fterm + 1);
+            return color_mulf(Color{ igm_sqrt(base_color.r), igm_sqrt(base_color.g), igm_sqrt(base_color.b) }, 1 - F);
+        }
+        const GGX m       = refraction_micro();
+        const float HdI   = vec3_dot(wi, h);
+        const float HdO   = vec3_dot(wo, h);
+        const float F     = fresnel_dielectric(refractive_eta, igm_abs(HdO));
+        const float D     = m.D(h);
+        const float G     = m.G1(wi) * m.G1(wo);
+        const float jacob = halfway_refractive_jacobian(refractive_eta, HdI, HdO);
+        const float norm  = igm_abs(safe_div(HdO * jacob, wo.z));
+        return color_mulf(base_color, (1 - F) * D * G * norm);
+    }
+    // evalClearcoatTerm (principled.art:178-191)
+    Color clearcoat_term(Vec3 wo, Vec3 wi, Vec3 h) const
+    {
+        const float F0   = 0.04f;
+        const float R    = 0.25f;
+        const float R2   = igm_max(0.001f, clearcoat_roughness * (1 - clearcoat_gloss) + 0.01f * clearcoat_gloss);
+        const float aHdL = absolute_cos(wi, h);
+        const float d    = GGX{ identity(), R2, R2 }.D(h);
+        const float f    = F0 + (1 - F0) * schlick_approx(aHdL); // schlick_f, fresnel.art:99
+        const GGX gm{ identity(), R, R };
+        const float g     = gm.G1(wi) * gm.G1(wo);
+        const float jacob = halfway_reflective_jacobian(wo.z);
+        const float v     = igm_abs(R * d * f * g * jacob * wi.z);
+        return Color{ v, v, v };
+    }
+
+    struct Lobes {
+        float diff_refl, diff_trans, spec_refl, spec_trans;
+    };
+    // calcLobeDistribution (principled.art:200-233)
+    Lobes lobes(Vec3 wo) const
+    {
+        const float metallic_in   = clampf(metallic, 0, 1);
+        const float diff_trans_in = clampf(diffuse_transmission, 0, 1);
+        const float spec_trans_in = clampf(specular_transmission, 0, 1);
+        const float abs_gen       = color_luminance(base_color);
+        const float abs_spec      = lerpf(1, color_luminance(tint_color(base_color)), specular_tint);
+        const float diff_refl     = clampf(abs_gen * (1 - metallic_in) * (1 - spec_trans_in), 0, 1);
+        const float F             = fresnel_dielectric(refractive_eta, igm_abs(wo.z));
+        const float spec_refl     = clampf(abs_spec * (1 - F) + F, 0, 1);
+        const bool has_transmission = diff_trans_in > 0 || spec_trans_in > 0;
+        if (!has_transmission) {
+            const float norm = diff_refl + spec_refl;
+            if (norm > flt_eps)
+                return Lobes{ diff_refl / norm, 0, spec_refl / norm, 0 };
+            return Lobes{ 1, 0, 0, 0 };
+        }
+        const float diff_trans = clampf(abs_gen * diff_trans_in * diff_refl, 0, 1);
+        const float spec_trans = clampf((1 - F) * abs_gen * (1 - metallic_in) * spec_trans_in, 0, 1);
+        const float norm       = diff_refl + spec_refl + diff_trans + spec_trans;
+        if (norm > flt_eps)
+            return Lobes{ diff_refl / norm, diff_trans / norm, spec_refl / norm, spec_trans / norm };
+        return Lobes{ 1, 0, 0, 0 };
+    }
+
+    // eval (principled.art:270-334)
+    Color eval(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const Vec3 wo = to_local(out_dir);
+        const Vec3 wi = to_local(in_dir);
+        const bool is_transmission = !is_same_hemisphere(wi, wo);
+        const Vec3 h = make_same_hemisphere(wo, is_transmission ? vec3_halfway_refractive(wi, wo, refractive_eta) : vec3_halfway(wi, wo));
+        const bool in_front         = is_entering == is_positive_hemisphere(wi);
+        const bool out_front        = is_entering == is_positive_hemisphere(wo);
+        const bool upper_hemisphere = in_front && out_front;
+        const float aNdL = igm_abs(wi.z);
+        if (aNdL <= grazing_eps)
+            return Color{ 0, 0, 0 };
+        Color contrib{ 0, 0, 0 };
+        const float diffuse_weight = (thin ? 1.0f : 1 - clampf(metallic, 0, 1)) * (1 - clampf(specular_transmission, 0, 1));
+        const float trans_weight   = (1 - clampf(metallic, 0, 1)) * clampf(specular_transmission, 0, 1);
+        const float spec_weight    = 1;
+        if (!is_transmission) {
+            if (diffuse_weight > 0)
+                contrib = color_add(contrib, color_mulf(base_color, diffuse_term(wo, wi, h) * diffuse_weight));
+            if (sheen > 0)
+                contrib = color_add(contrib, color_mulf(sheen_term(wi), diffuse_weight));
+            contrib = color_add(contrib, color_mulf(reflection_term(wo, wi, h), spec_weight));
+            if ((!clearcoat_top_only || upper_hemisphere) && clearcoat > 0)
+                contrib = color_add(contrib, color_mulf(clearcoat_term(wo, wi, h), clearcoat));
+        } else {
+            if (thin && diffuse_transmission > 0)
+                contrib = color_add(contrib, color_mulf(base_color, translucent_term(wo, wi) * diffuse_transmission));
+            if (specular_transmission > 0)
+                contrib = color_add(contrib, color_mulf(refraction_term(wo, wi, h), trans_weight));
+        }
+        return contrib;
+    }
+
+    // diffPdf_local / specReflPdf_local / specTransPdf_local (principled.art:336-359)
+    static float bound_spec_pdf(float v) { return v > micro_eps ? v : 0.0f; }
+    static float diff_pdf_local(Vec3 wi) { return cosine_hemisphere_pdf(igm_abs(wi.z)); }
+    float spec_refl_pdf_local(Vec3 wo, Vec3 wi) const
+    {
+        const Vec3 pwo      = make_positive_hemisphere(wo);
+        const Vec3 pwi      = make_positive_hemisphere(wi);
+        const GGX m         = reflection_micro();
+        const Vec3 H        = vec3_halfway(pwo, pwi);
+        const float cos_h_o = vec3_dot(pwo, H);
+        return igm_abs(bound_spec_pdf(m.pdf(pwo, H)) * halfway_reflective_jacobian(cos_h_o));
+    }
+    float spec_trans_pdf_local(Vec3 wo, Vec3 wi) const
+    {
+        const Vec3 pwo      = make_positive_hemisphere(wo);
+        const Vec3 pwi      = vec3_neg(make_positive_hemisphere(wi));
+        const GGX m         = refraction_micro();
+        const Vec3 H        = vec3_halfway_refractive(pwi, pwo, refractive_eta);
+        const float cos_h_i = vec3_dot(pwi, H);
+        const float cos_h_o = vec3_dot(pwo, H);
+        return igm_abs(bound_spec_pdf(m.pdf(pwo, H)) * halfway_refractive_jacobian(refractive_eta, cos_h_i, cos_h_o));
+    }
+    // pdf (principled.art:361-377)
+    float pdf(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const Vec3 wo = to_local(out_dir);
+        const Vec3 wi = to_local(in_dir);
+        if (igm_abs(wo.z) <= grazing_eps || igm_abs(wi.z) <= grazing_eps)
+            return 0;
+        const Lobes l        = lobes(wo);
+        const float diff_pdf = diff_pdf_local(wi);
+        if (is_same_hemisphere(wo, wi))
+            return l.diff_refl * diff_pdf + l.spec_refl * spec_refl_pdf_local(wo, wi);
+        if (thin)
+            return l.diff_trans * diff_pdf + l.spec_trans;
+        return l.diff_trans * diff_pdf + l.spec_trans * spec_trans_pdf_local(wo, wi);
+    }
+
+    // sample (principled.art:382-476), adjoint = false. Returns false for reject_bsdf_sample().
+    bool sample(Rng& rnd, Vec3 out_dir, Vec3& in_dir, float& pdf_out, Color& color, float& eta) const
+    {
+        const Vec3 wo = to_local(out_dir);
+        if (igm_abs(wo.z) <= grazing_eps)
+            return false;
+        const Lobes l    = lobes(wo);
+        const float pick = rnd.next_f32();
+        Vec3 dir;
+        float spdf;
+        if (pick < l.diff_refl) {
+            const float u     = rnd.next_f32();
+            const float v     = rnd.next_f32();
+            const DirSample s = sample_cosine_hemisphere(u, v);
+            dir               = make_same_hemisphere(wo, s.dir);
+            spdf              = s.pdf * l.diff_refl + spec_refl_pdf_local(wo, dir) * l.spec_refl;
+        } else if (pick < l.diff_refl + l.diff_trans) {
+            const float u     = rnd.next_f32();
+            const float v     = rnd.next_f32();
+            const DirSample s = sample_cosine_hemisphere(u, v);
+            dir               = vec3_neg(make_same_hemisphere(wo, s.dir));
+            spdf              = s.pdf * l.diff_trans + spec_trans_pdf_local(wo, dir) * l.spec_trans;
+        } else if (pick < l.diff_refl + l.diff_trans + l.spec_trans) {
+            if (thin) {
+                dir  = vec3_neg(wo);
+                spdf = l.spec_trans;
+            } else {
+                const Vec3 pwo   = make_positive_hemisphere(wo);
+                const GGX m      = refraction_micro();
+                const Vec3 n     = m.sample(rnd, pwo);
+                const float mpdf = m.pdf(pwo, n);
+                if (mpdf <= micro_eps || vec3_len2(n) <= flt_eps)
+                    return false;
+                const Vec3 oH       = vec3_normalize(n);
+                const Vec3 H        = igm_signbit(vec3_dot(oH, pwo)) ? vec3_neg(oH) : oH;
+                const float cos_h_o = vec3_dot(pwo, H);
+                float cos_t, factor;
+                if (fresnel(refractive_eta, cos_h_o, cos_t, factor)) {
+                    const Vec3 pwi = vec3_normalize(vec3_refract(pwo, H, refractive_eta, cos_h_o, cos_t));
+                    if (!is_same_hemisphere(pwo, pwi) && cos_h_o > flt_eps && -pwi.z > grazing_eps) {
+                        dir  = vec3_neg(make_same_hemisphere(wo, pwi));
+                        spdf = igm_abs(mpdf * halfway_refractive_jacobian(refractive_eta, vec3_dot(pwi, H), cos_h_o)) * l.spec_trans + diff_pdf_local(dir) * l.diff_trans;
+                    } else {
+                        return false;
+                    }
+                } else { // total reflection
+                    const Vec3 pwi = vec3_normalize(vec3_reflect(pwo, H));
+                    if (is_same_hemisphere(pwo, pwi) && cos_h_o > flt_eps && pwi.z > grazing_eps) {
+                        dir  = make_same_hemisphere(wo, pwi);
+                        spdf = mpdf * halfway_reflective_jacobian(cos_h_o) * l.spec_trans + diff_pdf_local(dir) * l.diff_trans;
+                    } else {
+                        return false;
+                    }
+                }
+            }
+        } else {
+            const Vec3 pwo   = make_positive_hemisphere(wo);
+            const GGX m      = reflection_micro();
+            const Vec3 n     = m.sample(rnd, pwo);
+            const float mpdf = m.pdf(pwo, n);
+            if (mpdf <= micro_eps || vec3_len2(n) <= flt_eps)
+                return false;
+            const Vec3 oH       = vec3_normalize(n);
+            const Vec3 H        = igm_signbit(vec3_dot(oH, pwo)) ? vec3_neg(oH) : oH;
+            const float cos_h_o = vec3_dot(pwo, H);
+            const Vec3 pwi      = vec3_normalize(vec3_reflect(pwo, H));
+            if (is_same_hemisphere(pwo, pwi) && cos_h_o > flt_eps && pwi.z > grazing_eps) {
+                dir  = make_same_hemisphere(wo, pwi);
+                spdf = igm_abs(mpdf * halfway_reflective_jacobian(cos_h_o)) * l.spec_refl + diff_pdf_local(dir) * l.diff_refl;
+            } else {
+                return false;
+            }
+        }
+        if (!(spdf > flt_eps && (igm_abs(spdf) <= 3.402823466e+38f)))
+            return false;
+        eta     = (thin || is_same_hemisphere(wo, dir)) ? 1.0f : refractive_eta;
+        in_dir  = to_world(dir);
+        pdf_out = spdf;
+        color   = color_mulf(eval(in_dir, out_dir), 1 / spdf);
+        return true;
+    }
+};
+
 // ---- BSDFs (driver/bsdf.art)
 struct BsdfSample {
     Vec3 in_dir;
@@ -598,6 +976,8 @@ struct Bsdf {
     // delta BSDFs evaluate to black (dielectric.art:16-17)
     Color eval(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+            return Principled(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return color_mulf(kd(), positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -621,6 +1001,8 @@ struct Bsdf {
     }
     float pdf(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+            return Principled(*mat, *surf, kd()).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return cosine_hemisphere_pdf(positive_cos(in_dir, surf->local.col[2]));
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -633,6 +1015,10 @@ struct Bsdf {
     }
     bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
     {
+        if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
+            s.is_delta = false;
+            return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta);
+        }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
             const float u      = rnd.next_f32();
             const float v      = rnd.next_f32();

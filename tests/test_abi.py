@@ -72,7 +72,7 @@ def test_loader_table_layouts(diamond_scene):
 def test_loader_refuses_what_it_cannot_lower():
     from ignis_amd.tables import LoadedScene
     bad = flat_scene()
-    bad["bsdfs"][0] = {"type": "principled", "name": "ground"}
+    bad["bsdfs"][0] = {"type": "tensortree", "name": "ground"}
     with pytest.raises(RuntimeError, match="not supported"):
         LoadedScene.from_string(json.dumps(bad))
     bad = flat_scene()
