@@ -340,6 +340,81 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
             fail("Shape '" + name + "': only .ply and .obj external meshes are supported by this loader (got '" + filename + "')");
         return load_ply(path);
     }
+    // procedural meshes (TriMeshProvider.cpp:48-103)
+    auto vec3Or = [&](const char* key, V3 def) { return elem.has(key) ? getVector3(*elem.find(key), key) : def; };
+    if (type == "icosphere")
+        return TriMesh::MakeIcoSphere(vec3Or("center", V3(0, 0, 0)), elem.getNumber("radius", 1.0f), (uint32_t)std::max(0, elem.getInt("subdivisions", 4)));
+    if (type == "uvsphere")
+        return TriMesh::MakeUVSphere(vec3Or("center", V3(0, 0, 0)), elem.getNumber("radius", 1.0f), (uint32_t)std::max(0, elem.getInt("stacks", 32)),
+                                     (uint32_t)std::max(0, elem.getInt("slices", 16)));
+    if (type == "cylinder") {
+        float base_radius, top_radius;
+        if (elem.has("radius")) {
+            base_radius = top_radius = elem.getNumber("radius", 1.0f);
+        } else {
+            base_radius = elem.getNumber("bottom_radius", 1.0f);
+            top_radius  = elem.getNumber("top_radius", base_radius);
+        }
+        return TriMesh::MakeCylinder(vec3Or("p0", V3(0, 0, 0)), base_radius, vec3Or("p1", V3(0, 0, 1)), top_radius,
+                                     (uint32_t)std::max(0, elem.getInt("sections", 32)), elem.getBool("filled", true));
+    }
+    if (type == "cone")
+        return TriMesh::MakeCone(vec3Or("p0", V3(0, 0, 0)), elem.getNumber("radius", 1.0f), vec3Or("p1", V3(0, 0, 1)),
+                                 (uint32_t)std::max(0, elem.getInt("sections", 32)), elem.getBool("filled", true));
+    if (type == "disk")
+        return TriMesh::MakeDisk(vec3Or("origin", V3(0, 0, 0)), vec3Or("normal", V3(0, 0, 1)), elem.getNumber("radius", 1.0f),
+                                 (uint32_t)std::max(0, elem.getInt("sections", 32)));
+    if (type == "inline") {
+        // TriMeshProvider.cpp:196-292: flat arrays "indices" (3 per face), "vertices" (3 per point), optional "normals", "texcoords"
+        auto numbers = [&](const char* key, std::vector<double>& out) {
+            const JsonValue* a = elem.find(key);
+            if (a && a->isObject()) // typed array property { "type": "integer" | "number", "values": [...] } (Parser.cpp)
+                a = a->find("values");
+            if (!a || !a->isArray())
+                return false;
+            for (const auto& v : a->arr) {
+                if (v.type != JsonValue::Number)
+                    fail("Shape '" + name + "': '" + key + "' must be an array of numbers");
+                out.push_back(v.num);
+            }
+            return true;
+        };
+        std::vector<double> ind, pos, nrm, tex;
+        if (!numbers("indices", ind))
+            fail("Shape '" + name + "': No indices given");
+        if (ind.size() % 3 != 0)
+            fail("Shape '" + name + "': Number of indices not multiple of 3. Only triangular faces are accepted");
+        if (!numbers("vertices", pos))
+            fail("Shape '" + name + "': No vertices given");
+        if (pos.size() % 3 != 0)
+            fail("Shape '" + name + "': Number of vertices not multiple of 3");
+        const bool has_normals = numbers("normals", nrm), has_tex = numbers("texcoords", tex);
+        if (has_normals && nrm.size() != pos.size())
+            fail("Shape '" + name + "': Number of normals does not match number of vertices");
+        if (has_tex && (tex.size() % 2 != 0 || tex.size() / 2 != pos.size() / 3))
+            fail("Shape '" + name + "': Number of texcoords does not match number of vertices");
+        TriMesh mesh;
+        const size_t points = pos.size() / 3;
+        for (size_t i = 0; i < ind.size(); i += 3) {
+            for (int k = 0; k < 3; ++k)
+                if (ind[i + k] < 0 || ind[i + k] >= (double)points)
+                    fail("Shape '" + name + "': vertex index out of range");
+            mesh.indices.insert(mesh.indices.end(), { (uint32_t)ind[i], (uint32_t)ind[i + 1], (uint32_t)ind[i + 2], 0u });
+        }
+        for (size_t i = 0; i < points; ++i)
+            mesh.vertices.push_back(V3((float)pos[3 * i], (float)pos[3 * i + 1], (float)pos[3 * i + 2]));
+        if (has_normals)
+            for (size_t i = 0; i < points; ++i)
+                mesh.normals.push_back(V3((float)nrm[3 * i], (float)nrm[3 * i + 1], (float)nrm[3 * i + 2]));
+        else
+            mesh.computeVertexNormals();
+        if (has_tex)
+            for (size_t i = 0; i < points; ++i)
+                mesh.texcoords.push_back(V2{ (float)tex[2 * i], (float)tex[2 * i + 1] });
+        else
+            mesh.makeTexCoordsNormalized();
+        return mesh;
+    }
     fail("Shape '" + name + "': Can not load shape type '" + type + "'");
 }
 
@@ -1150,8 +1225,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             // builds make_environment_light (uniform sphere sampling), not the CDF-sampled variant.
             if (l.has("radiance") && l.find("radiance")->isString() && l.find("radiance")->str.rfind("color(", 0) != 0)
                 fail("Environment light '" + lname + "': textured environment maps are not supported by the HIP backend");
-            if (l.has("transform"))
-                fail("Environment light '" + lname + "': a transform has no effect on a constant environment and is refused");
+            // a "transform" only rotates the lookup direction of make_environment_light_function_spherical (env.art:74-96:
+            // the sampled direction itself is not transformed), so it has no effect on a constant radiance
             const V3 radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
             const V3 scale    = getColor(l, "scale", V3(1, 1, 1), lname);
             out.type          = IG_LIGHT_ENV;
@@ -1263,6 +1338,90 @@ static thread_local std::string g_last_error;
 
 extern "C" {
 
+namespace igh {
+// "externals" (src/runtime/loader/Parser.cpp:395-463): other Ignis scene files are loaded first and the including file
+// then adds to / replaces what they define — named objects by name, camera / technique / film as a whole. File names of
+// an included object stay relative to the file that declared it, so they are made absolute while merging.
+static JsonValue mergeExternals(const JsonValue& doc, const std::string& base_dir, int depth)
+{
+    const JsonValue* exts = doc.find("externals");
+    if (!exts)
+        return doc;
+    if (!exts->isArray())
+        fail("Expected 'external' elements to be an array");
+    if (depth > 8)
+        fail("'externals' are nested too deeply");
+
+    JsonValue merged;
+    merged.type = JsonValue::Object;
+    auto member = [&](const std::string& key) -> JsonValue& {
+        for (auto& p : merged.obj)
+            if (p.first == key)
+                return p.second;
+        merged.obj.emplace_back(key, JsonValue{});
+        return merged.obj.back().second;
+    };
+    auto absorb = [&](const JsonValue& from, const std::string& dir, bool fix_paths) {
+        for (const auto& p : from.obj) {
+            if (p.first == "externals")
+                continue;
+            if (!p.second.isArray()) { // camera, technique, film, ...: the later definition wins as a whole
+                member(p.first) = p.second;
+                continue;
+            }
+            JsonValue& list = member(p.first);
+            list.type       = JsonValue::Array;
+            for (JsonValue item : p.second.arr) {
+                if (fix_paths && item.isObject())
+                    for (auto& q : item.obj)
+                        if (q.first == "filename" && q.second.isString() && !q.second.str.empty() && q.second.str[0] != '/')
+                            q.second.str = dir + "/" + q.second.str;
+                const std::string name = item.getString("name");
+                bool replaced          = false;
+                if (!name.empty())
+                    for (auto& existing : list.arr)
+                        if (existing.getString("name") == name) {
+                            existing = item;
+                            replaced = true;
+                            break;
+                        }
+                if (!replaced)
+                    list.arr.push_back(std::move(item));
+            }
+        }
+    };
+
+    for (const auto& e : exts->arr) {
+        if (!e.isObject())
+            fail("Expected 'external' element to be an object");
+        const std::string filename = e.getString("filename");
+        if (filename.empty())
+            fail("Expected a path for externals");
+        const std::string path = (filename[0] == '/' || base_dir.empty()) ? filename : base_dir + "/" + filename;
+        std::string type       = e.getString("type");
+        const size_t dot       = path.rfind('.');
+        std::string ext        = dot == std::string::npos ? "" : path.substr(dot);
+        for (auto& c : ext)
+            c = (char)std::tolower((unsigned char)c);
+        if (type.empty())
+            type = ext == ".json" ? "ignis" : "";
+        if (type != "ignis")
+            fail("External '" + filename + "': only Ignis scene files (.json) can be included by this loader");
+        std::ifstream f(path, std::ios::in | std::ios::binary);
+        if (!f)
+            fail("Could not find path '" + filename + "'");
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const size_t slash    = path.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? "." : path.substr(0, slash);
+        const JsonValue inner = mergeExternals(JsonParser(ss.str()).parse(), dir, depth + 1);
+        absorb(inner, dir, dir != base_dir);
+    }
+    absorb(doc, base_dir, false);
+    return merged;
+}
+} // namespace igh
+
 igh_scene* igh_load_string(const char* json, const char* base_dir, const igh_options* opts)
 {
     g_last_error.clear();
@@ -1273,8 +1432,9 @@ igh_scene* igh_load_string(const char* json, const char* base_dir, const igh_opt
     try {
         const std::string text(json);
         igh::JsonParser parser(text);
-        const igh::JsonValue doc = parser.parse();
-        auto sc                  = igh::buildScene(doc, base_dir ? base_dir : "", opts);
+        const std::string dir    = base_dir ? base_dir : "";
+        const igh::JsonValue doc = igh::mergeExternals(parser.parse(), dir, 0);
+        auto sc                  = igh::buildScene(doc, dir, opts);
         return new igh_scene{ std::move(sc) };
     } catch (const std::exception& e) {
         g_last_error = e.what();

@@ -252,6 +252,206 @@ TriMesh TriMesh::MakeBox(V3 origin, V3 xAxis, V3 yAxis, V3 zAxis)
     return m;
 }
 
+// ---------------------------------------------------------------- procedural shapes
+
+namespace {
+constexpr float kPiF = 3.14159265358979323846f;
+
+// Tangent::frame (src/runtime/math/Tangent.h:50-73): the branch-free basis of Duff et al., normalised
+void tangentFrame(V3 n, V3& tx, V3& ty)
+{
+    const float sg = std::copysign(1.0f, n.z);
+    const float a  = -1.0f / (sg + n.z);
+    const float b  = n.x * n.y * a;
+    tx             = normalized(V3(1.0f + sg * n.x * n.x * a, sg * b, -sg * n.x));
+    ty             = normalized(V3(b, sg + n.y * n.y * a, -n.y));
+}
+
+void pushTri(TriMesh& m, uint32_t a, uint32_t b, uint32_t c) { m.indices.insert(m.indices.end(), { a, b, c, 0u }); }
+
+// A ring of `count` vertices around `center` in the (tx, ty) plane, optionally preceded by the centre vertex and closed
+// by a triangle fan (TriMesh.cpp:819-852). Returns the index of the first ring vertex.
+uint32_t appendRing(TriMesh& m, V3 center, V3 n, V3 tx, V3 ty, float radius, uint32_t count, bool with_fan, bool reversed)
+{
+    const uint32_t hub = (uint32_t)m.vertices.size();
+    if (with_fan) {
+        m.vertices.push_back(center);
+        m.normals.push_back(n);
+        m.texcoords.push_back(V2{ 0, 0 });
+    }
+    const uint32_t first = (uint32_t)m.vertices.size();
+    const float step     = 1.0f / count;
+    for (uint32_t k = 0; k < count; ++k) {
+        const float c = std::cos(2 * kPiF * step * k);
+        const float s = std::sin(2 * kPiF * step * k);
+        m.vertices.push_back(tx * radius * c + ty * radius * s + center);
+        m.normals.push_back(n);
+        m.texcoords.push_back(V2{ 0.5f * (c + 1), 0.5f * (s + 1) });
+    }
+    if (with_fan)
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t cur = first + k, nxt = first + (k + 1) % count;
+            if (reversed)
+                pushTri(m, hub, nxt, cur);
+            else
+                pushTri(m, hub, cur, nxt);
+        }
+    return first;
+}
+} // namespace
+
+TriMesh TriMesh::MakeDisk(V3 center, V3 normal, float radius, uint32_t sections)
+{
+    TriMesh m;
+    V3 tx, ty;
+    tangentFrame(normal, tx, ty);
+    appendRing(m, center, normal, tx, ty, radius, std::max(3u, sections), true, false);
+    return m;
+}
+
+TriMesh TriMesh::MakeCone(V3 base_center, float base_radius, V3 tip, uint32_t sections, bool fill_cap)
+{
+    sections      = std::max(3u, sections);
+    const V3 axis = normalized(base_center - tip);
+    V3 tx, ty;
+    tangentFrame(axis, tx, ty);
+    TriMesh m;
+    const uint32_t ring = appendRing(m, base_center, axis, tx, ty, base_radius, sections, fill_cap, false);
+    const uint32_t apex = (uint32_t)m.vertices.size();
+    m.vertices.push_back(tip);
+    m.normals.push_back(axis);
+    m.texcoords.push_back(V2{ 0, 0 });
+    for (uint32_t k = 0; k < sections; ++k)
+        pushTri(m, ring + k, apex, ring + (k + 1) % sections);
+    m.computeVertexNormals(); // cap and mantle share the ring vertices (TriMesh.cpp:1101)
+    return m;
+}
+
+TriMesh TriMesh::MakeCylinder(V3 base_center, float base_radius, V3 top_center, float top_radius, uint32_t sections, bool fill_cap)
+{
+    sections      = std::max(3u, sections);
+    const V3 axis = normalized(base_center - top_center);
+    V3 tx, ty;
+    tangentFrame(axis, tx, ty);
+    TriMesh m;
+    const uint32_t lo = appendRing(m, base_center, axis, tx, ty, base_radius, sections, fill_cap, false);
+    const uint32_t hi = appendRing(m, top_center, axis, tx, ty, top_radius, sections, fill_cap, true);
+    for (uint32_t k = 0; k < sections; ++k) {
+        const uint32_t k1 = (k + 1) % sections;
+        pushTri(m, lo + k, hi + k, lo + k1);
+        pushTri(m, hi + k, hi + k1, lo + k1);
+    }
+    m.computeVertexNormals();
+    return m;
+}
+
+// Latitude / longitude sphere: (stacks + 1) rows of `slices` vertices, poles duplicated per slice (TriMesh.cpp:854-907)
+TriMesh TriMesh::MakeUVSphere(V3 center, float radius, uint32_t stacks, uint32_t slices)
+{
+    stacks = std::max(2u, stacks);
+    slices = std::max(2u, slices);
+    TriMesh m;
+    const float drho = kPiF / (float)stacks, dtheta = 2 * kPiF / (float)slices;
+    for (uint32_t row = 0; row <= stacks; ++row) {
+        const float rho = (float)row * drho;
+        const float sr = std::sin(rho), cr = std::cos(rho);
+        for (uint32_t col = 0; col < slices; ++col) {
+            const float theta = col * dtheta;
+            const V3 n(-std::sin(theta) * sr, std::cos(theta) * sr, cr);
+            m.vertices.push_back(n * radius + center);
+            m.normals.push_back(n);
+            m.texcoords.push_back(V2{ (float)(0.5 * theta / kPiF), rho / kPiF });
+        }
+    }
+    for (uint32_t row = 0; row < stacks; ++row) {
+        const uint32_t up = row * slices, dn = (row + 1) * slices;
+        for (uint32_t col = 0; col < slices; ++col) {
+            const uint32_t nc = (col + 1) % slices;
+            pushTri(m, dn + col, dn + nc, up + nc);
+            pushTri(m, dn + col, up + nc, up + col);
+        }
+    }
+    return m;
+}
+
+// Icosahedron from three golden rectangles, refined by splitting every edge at its spherical midpoint
+// (TriMesh.cpp:910-1025). Vertex numbering and face order follow the reference so the tessellation is the same.
+TriMesh TriMesh::MakeIcoSphere(V3 center, float radius, uint32_t subdivisions)
+{
+    TriMesh m;
+    const float phi = 1.618033989f;
+    // vertex (axis d, sign a, sign b) has phi * a on axis d + 1 and b on axis d + 2
+    auto corner = [](int d, int a, int b) { return (uint32_t)(d * 4 + (a + 1) + ((b + 1) >> 1)); };
+    for (int d = 0; d < 3; ++d)
+        for (int a = -1; a <= 1; a += 2)
+            for (int b = -1; b <= 1; b += 2) {
+                float v[3] = { 0, 0, 0 };
+                v[(d + 1) % 3] = phi * a;
+                v[(d + 2) % 3] = 1.0f * b;
+                m.vertices.push_back(normalized(V3(v[0], v[1], v[2])));
+            }
+    // 8 faces with one corner on each rectangle, then 12 faces with an edge on one rectangle
+    for (int a = -1; a <= 1; a += 2)
+        for (int b = -1; b <= 1; b += 2)
+            for (int c = -1; c <= 1; c += 2) {
+                const uint32_t i1 = corner(0, a, b), i2 = corner(1, b, c), i3 = corner(2, c, a);
+                if (a * b * c == -1)
+                    pushTri(m, i1, i3, i2);
+                else
+                    pushTri(m, i1, i2, i3);
+            }
+    for (int d = 0; d < 3; ++d)
+        for (int a = -1; a <= 1; a += 2)
+            for (int b = -1; b <= 1; b += 2) {
+                const uint32_t i1 = corner(d, a, +1), i2 = corner(d, a, -1), i3 = corner((d + 2) % 3, b, a);
+                if (a * b == 1)
+                    pushTri(m, i1, i3, i2);
+                else
+                    pushTri(m, i1, i2, i3);
+            }
+    for (uint32_t level = 0; level < subdivisions; ++level) {
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> midpoint;
+        const size_t faces = m.indices.size() / 4;
+        // midpoints are numbered in the order the directed edges (low -> high index) are met
+        for (size_t f = 0; f < faces; ++f)
+            for (int e = 0; e < 3; ++e) {
+                const uint32_t p = m.indices[4 * f + e], q = m.indices[4 * f + (e + 1) % 3];
+                if (p >= q)
+                    continue;
+                midpoint[{ p, q }] = (uint32_t)m.vertices.size();
+                m.vertices.push_back(normalized(m.vertices[p] + m.vertices[q]));
+            }
+        std::vector<uint32_t> finer;
+        finer.reserve(faces * 16);
+        for (size_t f = 0; f < faces; ++f) {
+            uint32_t corner_id[3], mid[3];
+            for (int e = 0; e < 3; ++e) {
+                corner_id[e]     = m.indices[4 * f + e];
+                const uint32_t q = m.indices[4 * f + (e + 1) % 3];
+                mid[e]           = midpoint.at({ std::min(corner_id[e], q), std::max(corner_id[e], q) });
+            }
+            finer.insert(finer.end(), { mid[0], mid[1], mid[2], 0u });
+            for (int e = 0; e < 3; ++e)
+                finer.insert(finer.end(), { corner_id[e], mid[e], mid[(e + 2) % 3], 0u });
+        }
+        m.indices.swap(finer);
+    }
+    m.normals.resize(m.vertices.size());
+    m.texcoords.resize(m.vertices.size());
+    for (size_t i = 0; i < m.vertices.size(); ++i) {
+        const V3 n   = normalized(m.vertices[i]);
+        m.normals[i] = n;
+        float lon    = std::atan2(-n.x, n.y);
+        if (lon < 0)
+            lon += 2 * kPiF;
+        m.texcoords[i] = V2{ lon / (2 * kPiF), std::acos(n.z) / kPiF };
+    }
+    // translate(center) * scale(radius); normals are unaffected by a uniform scale
+    for (auto& v : m.vertices)
+        v = v * radius + center;
+    return m;
+}
+
 // ---------------------------------------------------------------- PLY
 
 namespace {

@@ -38,6 +38,13 @@ struct TriMesh {
     static TriMesh MakeRectangle(V3 p0, V3 p1, V3 p2, V3 p3);      // TriMesh.cpp:1053-1059
     static TriMesh MakeTriangle(V3 p0, V3 p1, V3 p2);              // TriMesh.cpp:1046-1051
     static TriMesh MakeBox(V3 origin, V3 x_axis, V3 y_axis, V3 z_axis);
+    // procedural shapes of the "uvsphere", "icosphere", "disk", "cone" and "cylinder" plugins: the tessellations
+    // (triangle sets, shared vertices, normals, texture coordinates) of TriMesh.cpp:819-1131
+    static TriMesh MakeUVSphere(V3 center, float radius, uint32_t stacks, uint32_t slices);
+    static TriMesh MakeIcoSphere(V3 center, float radius, uint32_t subdivisions);
+    static TriMesh MakeDisk(V3 center, V3 normal, float radius, uint32_t sections);
+    static TriMesh MakeCone(V3 base_center, float base_radius, V3 tip, uint32_t sections, bool fill_cap);
+    static TriMesh MakeCylinder(V3 base_center, float base_radius, V3 top_center, float top_radius, uint32_t sections, bool fill_cap);
 };
 
 // Throws std::runtime_error with a message on malformed input.

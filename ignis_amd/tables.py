@@ -171,6 +171,22 @@ class LoadedScene:
         sc = self.scene
         return np.ctypeslib.as_array(C.cast(sc.scene_nodes, C.POINTER(C.c_float)), shape=(sc.scene_node_count, 64)).copy()
 
+    def shape_mesh(self, shape_id):
+        """(vertices [n, 3], normals [n, 3], indices [f, 3], texcoords [n, 2]) of a triangle-mesh shape, decoded from its
+        record in the "shapes" dyn-table (src/runtime/shape/TriMeshProvider.cpp:575-596)."""
+        import numpy as np
+        sc = self.scene
+        off = sc.shape_lookups[shape_id].offset
+        blob = np.ctypeslib.as_array(sc.shape_data, shape=(sc.shape_data_size,))
+        faces, nv, nn, nt = (int(x) for x in blob[off:off + 16].view(np.uint32))
+        f = blob[off:].view(np.float32)
+        v0 = 12
+        n0 = v0 + nv * 4
+        i0 = n0 + nn * 4
+        t0 = i0 + faces * 4
+        return (f[v0:n0].reshape(nv, 4)[:, :3].copy(), f[n0:i0].reshape(nn, 4)[:, :3].copy(),
+                f[i0:t0].view(np.int32).reshape(faces, 4)[:, :3].copy(), f[t0:t0 + nt * 2].reshape(nt, 2).copy())
+
     def primbvh_bytes(self):
         sc = self.scene
         return bytes(C.string_at(sc.primbvh, sc.primbvh_size))

@@ -293,3 +293,124 @@ def test_generated_plane_is_detected_as_plane_and_triangle_is_not():
     s["shapes"][-1] = {"type": "triangle", "name": "L", "p0": [0, 0, 0], "p1": [1, 0, 0], "p2": [0, 1, 0]}
     with pytest.raises(RuntimeError):
         LoadedScene.from_string(json.dumps(s))
+
+
+# ---- procedural shapes (src/runtime/mesh/TriMesh.cpp:819-1131) and "externals" (src/runtime/loader/Parser.cpp:395-463)
+
+def _shape_scene(shape):
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene()
+    s["shapes"] = [dict(shape, name="S")]
+    s["entities"] = [{"name": "E", "shape": "S", "bsdf": "ground"}]
+    return LoadedScene.from_string(json.dumps(s))
+
+
+def _edge_use(idx):
+    import collections
+    use = collections.Counter()
+    for a, b, c in idx:
+        for p, q in ((a, b), (b, c), (c, a)):
+            use[(int(p), int(q))] += 1
+    return use
+
+
+def _is_closed_and_consistently_wound(v, idx):
+    """Watertight after welding coincident vertices: every directed edge is used once and its reverse once."""
+    import numpy as np
+    key = {}
+    weld = np.array([key.setdefault(tuple(np.round(p, 5)), len(key)) for p in v])
+    faces = [f for f in weld[idx] if len(set(f)) == 3]  # pole triangles of the uv sphere collapse
+    use = _edge_use(faces)
+    return all(n == 1 and use.get((q, p), 0) == 1 for (p, q), n in use.items())
+
+
+def _volume(v, idx):
+    import numpy as np
+    a, b, c = (v[idx[:, k]].astype(np.float64) for k in range(3))
+    return float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum() / 6)
+
+
+@pytest.mark.parametrize("shape,faces", [
+    ({"type": "icosphere", "center": [1, 2, 3], "radius": 0.5, "subdivisions": 2}, 20 * 16),
+    ({"type": "uvsphere", "center": [1, 2, 3], "radius": 0.5, "stacks": 12, "slices": 10}, 12 * 10 * 2),
+])
+def test_procedural_spheres(shape, faces):
+    import numpy as np
+    sc = _shape_scene(shape)
+    v, n, idx, uv = sc.shape_mesh(0)
+    assert len(idx) == faces and len(n) == len(v) == len(uv)
+    c = np.float32(shape["center"])
+    np.testing.assert_allclose(np.linalg.norm(v - c, axis=1), 0.5, rtol=1e-5)
+    np.testing.assert_allclose(n, (v - c) / 0.5, atol=1e-5)          # outward unit normals
+    assert _is_closed_and_consistently_wound(v, idx)
+    vol = _volume(v - c, idx)
+    assert 0.85 * 4 / 3 * np.pi * 0.125 < vol < 4 / 3 * np.pi * 0.125  # inscribed, outward winding (positive volume)
+    assert uv.min() >= 0 and uv.max() <= 1
+
+
+def test_procedural_disk_cone_cylinder():
+    import numpy as np
+    n = 24
+    v, nrm, idx, _ = _shape_scene({"type": "disk", "origin": [0, 0, 1], "normal": [0, 0, 1], "radius": 2, "sections": n}).shape_mesh(0)
+    assert len(idx) == n and np.allclose(v[:, 2], 1) and np.allclose(nrm, [0, 0, 1])
+    a, b, c = (v[idx[:, k]].astype(np.float64) for k in range(3))
+    area = np.linalg.norm(np.cross(b - a, c - a), axis=1).sum() / 2
+    assert area == pytest.approx(n / 2 * 4 * np.sin(2 * np.pi / n), rel=1e-5)          # regular n-gon
+    assert np.all(np.cross(b - a, c - a)[:, 2] > 0)                                    # wound around the normal
+
+    v, nrm, idx, _ = _shape_scene({"type": "cylinder", "p0": [0, 0, 0], "p1": [0, 0, 3], "radius": 1, "sections": n}).shape_mesh(0)
+    assert len(idx) == 4 * n and _is_closed_and_consistently_wound(v, idx)
+    assert abs(_volume(v, idx)) == pytest.approx(3 * n / 2 * np.sin(2 * np.pi / n), rel=1e-5)  # prism over the n-gon
+    v2, _, idx2, _ = _shape_scene({"type": "cylinder", "p0": [0, 0, 0], "p1": [0, 0, 3], "bottom_radius": 1, "top_radius": 0.5,
+                                   "sections": n, "filled": False}).shape_mesh(0)
+    assert len(idx2) == 2 * n and len(v2) == 2 * n and np.allclose(np.hypot(v2[n:, 0], v2[n:, 1]), 0.5, atol=1e-6)
+
+    v, nrm, idx, _ = _shape_scene({"type": "cone", "p0": [0, 0, 0], "p1": [0, 0, 2], "radius": 1, "sections": n}).shape_mesh(0)
+    assert len(idx) == 2 * n and _is_closed_and_consistently_wound(v, idx)
+    assert abs(_volume(v, idx)) == pytest.approx(2 / 3 * n / 2 * np.sin(2 * np.pi / n), rel=1e-5)
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+
+
+def test_inline_mesh_and_typed_arrays():
+    import numpy as np
+    tri = {"type": "inline", "indices": {"type": "integer", "values": [0, 1, 2, 1, 3, 2]},
+           "vertices": {"type": "number", "values": [0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0]}}
+    v, n, idx, uv = _shape_scene(tri).shape_mesh(0)
+    assert idx.tolist() == [[0, 1, 2], [1, 3, 2]] and np.allclose(n, [0, 0, 1]) and v.shape == (4, 3)
+    plain = dict(tri, indices=[0, 1, 2, 1, 3, 2], vertices=[0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0], normals=[0, 0, -1] * 4,
+                 texcoords=[0, 0, 1, 0, 0, 1, 1, 1])
+    v, n, idx, uv = _shape_scene(plain).shape_mesh(0)
+    assert np.allclose(n, [0, 0, -1]) and uv.tolist() == [[0, 0], [1, 0], [0, 1], [1, 1]]
+    from ignis_amd.tables import LoadedScene
+    bad = flat_scene()
+    bad["shapes"] = [{"type": "inline", "name": "Bottom", "indices": [0, 1], "vertices": [0, 0, 0]}]
+    with pytest.raises(RuntimeError, match="multiple of 3"):
+        LoadedScene.from_string(json.dumps(bad))
+
+
+def test_externals_are_merged_and_overridden(tmp_path):
+    """The including file replaces named objects of the included one; file names stay relative to the declaring file."""
+    import numpy as np
+    import shutil
+    from ignis_amd.tables import LoadedScene
+    inc = tmp_path / "inc"
+    inc.mkdir()
+    shutil.copy(os.path.join(ROOT, "scenes", "meshes", "Bottom.ply"), inc / "floor.ply")
+    base = flat_scene()
+    base["shapes"] = [{"type": "ply", "name": "Bottom", "filename": "floor.ply"}]
+    base["bsdfs"] = [{"type": "diffuse", "name": "ground", "reflectance": [0.1, 0.2, 0.3]}]
+    (inc / "base.json").write_text(json.dumps(base))
+    top = {"externals": [{"filename": "inc/base.json"}],
+           "bsdfs": [{"type": "diffuse", "name": "ground", "reflectance": [0.9, 0.8, 0.7]}],
+           "film": {"size": [32, 16]}}
+    (tmp_path / "top.json").write_text(json.dumps(top))
+    sc = LoadedScene.from_file(str(tmp_path / "top.json"))
+    t = sc.scene
+    assert (t.entity_count, t.shape_count, t.material_count) == (1, 1, 1) and (t.film_width, t.film_height) == (32, 16)
+    assert list(t.materials[0].p[0:3]) == [np.float32(0.9), np.float32(0.8), np.float32(0.7)]
+    flat = dict(base, film=top["film"], bsdfs=top["bsdfs"])
+    flat["shapes"] = [{"type": "ply", "name": "Bottom", "filename": str(inc / "floor.ply")}]
+    ref = LoadedScene.from_string(json.dumps(flat))
+    assert sc.primbvh_bytes() == ref.primbvh_bytes()
+    with pytest.raises(RuntimeError, match="Could not find path"):
+        LoadedScene.from_string(json.dumps({"externals": [{"filename": "nope.json"}]}), str(tmp_path))
