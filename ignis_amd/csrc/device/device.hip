@@ -112,6 +112,7 @@ struct igd_device {
     DevBuf<float> light_hierarchy;
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
+    DevBuf<float> cdf_data;
     uint32_t tail_lanes = 0; // lanes of one tail grid (its share of the deep-stack columns)
     DevBuf<uint2> deep_stack; // kDeepStack entries for every lane that can be resident (traversal grid + tail grid)
     DevBuf<uint32_t> light_codes;
@@ -316,7 +317,7 @@ struct igd_device {
     }
 
     int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
-    bool full_bsdfs = false; // the scene has a principled BSDF: k_shade<true> / k_tail<*, true>
+    bool full_bsdfs = false; // the scene has a principled BSDF, a textured environment or a sun light: k_shade<true> / k_tail<*, true>
     int shade_mult = 64; // workgroups per CU in the k_shade grid (each loops over windows); IGD_SHADE_GRID
     int shadeGrid() const { return num_cus * shade_mult; }
 
@@ -366,10 +367,16 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t l = 0; l < s->light_count; ++l) {
         const bool inf = l < s->infinite_light_count;
         const int lt = s->lights[l].type;
-        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_DIRECTIONAL)
+        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_SUN)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
-        if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL))
-            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment lights" };
+        if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL || lt == IG_LIGHT_ENV_TEXTURED || lt == IG_LIGHT_SUN))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment, directional or sun lights" };
+        if (lt == IG_LIGHT_ENV_TEXTURED) {
+            uint32_t v[4];
+            std::memcpy(v, &s->lights[l].d[12], sizeof(v));
+            if (v[0] >= s->texture_count || !s->cdf_data || v[2] == 0 || v[3] == 0 || (uint64_t)v[1] + v[3] + (uint64_t)v[2] * v[3] > s->cdf_data_count)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: textured environment light " + std::to_string(l) + " has no valid texture / CDF table" };
+        }
     }
 
     // geometry blob: prim BVH fix table, then the scene BVH nodes
@@ -422,6 +429,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         td.resize(td.size() + 16);
         d->texture_data.upload(td.data(), td.size());
     }
+    d->cdf_data.upload(s->cdf_data, s->cdf_data ? s->cdf_data_count : 0);
 
     // material id per entity (entity table word 34, LoaderEntity.cpp:159)
     std::vector<int32_t> em(s->entity_count);
@@ -475,6 +483,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.scene_radius         = s->scene_radius;
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
+    ds.cdf_data             = d->cdf_data.ptr;
     {
         const uint32_t trav_lanes = (uint32_t)d->traverseGrid() * 256u;
         const uint32_t tail_lanes = (uint32_t)d->num_cus * (uint32_t)d->tail_waves_per_cu * 64u;
@@ -485,10 +494,12 @@ void assignScene(igd_device* d, const igd_scene* s)
         ds.deep_tail_base = trav_lanes;
     }
     d->camera               = s->camera;
-    // scenes without a principled BSDF run the lean shading kernels
+    // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED;
+    for (uint32_t i = 0; i < s->infinite_light_count; ++i)
+        d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN;
     d->has_scene            = true;
 }
 
@@ -1279,6 +1290,7 @@ int32_t igd_release_all(igd_device* dev)
         dev->light_codes.release();
         dev->textures.release();
         dev->texture_data.release();
+        dev->cdf_data.release();
         dev->has_scene = false;
     });
 }

@@ -38,6 +38,7 @@ struct DevScene {
     // bitmap textures (ig_material.tex_id)
     const ig_texture* textures;
     const uint8_t* texture_data;
+    const float* cdf_data; // sampling tables of textured environment lights (igd_scene.cdf_data)
     // deep traversal stacks: entry e of resident lane l at deep_stack[e * deep_stride + l]; the persistent traversal
     // grid uses lanes [0, deep_tail_base), the tail kernel's grid the lanes from deep_tail_base on (they overlap in time)
     uint2* deep_stack;

@@ -1001,6 +1001,147 @@ struct BsdfCtx {
     }
 };
 
+// ---------------------------------------------------------------- environment map sampling
+
+// make_cdf_1d over a buffer without the leading 0 (core/cdf.art:43-73), interval::binary_search (core/interval.art:7-23)
+struct Cdf1D {
+    const float* data;
+    int size;
+
+    IG_DEV float get(int i) const { return i == 0 ? 0.0f : data[i - 1]; }
+    IG_DEV float pdf_discrete(int x) const { return get(x + 1) - get(x); }
+    IG_DEV int sample_discrete(float u, float& pdf) const
+    {
+        int first = 0, len = size + 1;
+        while (len > 0) {
+            const int half   = len / 2;
+            const int middle = first + half;
+            if (get(middle) <= u) {
+                first = middle + 1;
+                len -= half + 1;
+            } else {
+                len = half;
+            }
+        }
+        const int found = min(max(first - 1, 0), size); // clamp(first - 1, 0, (size + 1) - 1)
+        const int off   = min(found, size - 1);
+        pdf             = pdf_discrete(off);
+        return off;
+    }
+    IG_DEV float pdf_continuous(float x, int& off) const
+    {
+        off = min(max((int)(x * (float)size), 0), size - 1);
+        return pdf_discrete(off) * (float)size;
+    }
+    IG_DEV float sample_continuous(float u, int& off, float& pdf) const
+    {
+        float dpdf;
+        off             = sample_discrete(u, dpdf);
+        const float rem = safe_div(u - get(off), dpdf);
+        pdf             = dpdf * (float)size;
+        return clampf(((float)off + rem) / (float)size, 0, 1);
+    }
+};
+
+// make_cdf_2d_from_buffer (core/cdf.art:108-159): marginal first, then one conditional per row
+struct Cdf2D {
+    const float* data;
+    int size_x, size_y;
+
+    IG_DEV Cdf1D marginal() const { return Cdf1D{ data, size_y }; }
+    IG_DEV Cdf1D conditional(int row) const { return Cdf1D{ data + size_y + (size_t)row * size_x, size_x }; }
+    IG_DEV f2 sample_continuous(float ux, float uy, float& pdf) const
+    {
+        int oy, ox;
+        float p1, p2;
+        const float py = marginal().sample_continuous(uy, oy, p1);
+        const float px = conditional(oy).sample_continuous(ux, ox, p2);
+        pdf            = p1 * p2;
+        return f2{ px, py };
+    }
+    IG_DEV float pdf_continuous(f2 pos) const
+    {
+        int oy, ox;
+        const float p1 = marginal().pdf_continuous(pos.y, oy);
+        const float p2 = conditional(oy).pdf_continuous(pos.x, ox);
+        return p1 * p2;
+    }
+};
+
+// light/env.art:11-21 (switch_env_up, map_env_uv), core/warp.art:44-48 (spherical_from_dir)
+IG_DEV f3 switch_env_up(f3 v) { return f3{ v.x, v.z, v.y }; }
+IG_DEV f2 map_env_uv(f3 dir)
+{
+    const float theta = igm_acos(dir.z);
+    float phi         = igm_atan2(dir.y, dir.x);
+    if (phi < 0)
+        phi = phi + 2 * kPi;
+    const float v = theta / kPi;
+    const float u = phi / (2 * kPi);
+    const float r = u + 0.25f;
+    return f2{ r - igm_floor(r), 1 - v };
+}
+
+// make_environment_light_textured (light/env.art:109-157)
+struct TexturedEnv {
+    const DevScene& sc;
+    Col scale;
+    m33 transform;
+    const ig_texture* tex;
+    Cdf2D cdf;
+
+    IG_DEV TexturedEnv(const DevScene& scene, const ig_light& L)
+        : sc(scene)
+    {
+        scale        = Col{ L.d[0], L.d[1], L.d[2] };
+        transform.c0 = f3{ L.d[3], L.d[4], L.d[5] };
+        transform.c1 = f3{ L.d[6], L.d[7], L.d[8] };
+        transform.c2 = f3{ L.d[9], L.d[10], L.d[11] };
+        tex          = &sc.textures[igm_bits(L.d[12])];
+        cdf          = Cdf2D{ sc.cdf_data + igm_bits(L.d[13]), (int)igm_bits(L.d[14]), (int)igm_bits(L.d[15]) };
+    }
+    // sample_dir (env.art:112-123): the intensity is the bare texture value, without `scale`
+    IG_DEV void sample_dir(Tea& rnd, f3& dir, Col& intensity, float& pdf_dir) const
+    {
+        const float u0 = rnd.f32();
+        const float u1 = rnd.f32();
+        float pdf;
+        const f2 pos      = cdf.sample_continuous(u0, u1, pdf);
+        intensity         = image_lookup(sc, *tex, pos);
+        const float theta = (1 - pos.y) * kPi;
+        const float phi   = (pos.x - 0.25f) * 2 * kPi;
+        const float st = igm_sin(theta), ct = igm_cos(theta);
+        const f3 d           = f3{ st * igm_cos(phi), st * igm_sin(phi), ct }; // dir_from_spherical (core/warp.art:50-57)
+        const float sinTheta = safe_sqrt(1 - d.z * d.z);
+        pdf_dir              = safe_div(pdf, sinTheta * kPi * kPi * 2);
+        const f3 e           = switch_env_up(d);
+        dir                  = f3{ dot3(transform.c0, e), dot3(transform.c1, e), dot3(transform.c2, e) }; // mat3x3_left_mul
+    }
+    IG_DEV f3 local_dir(f3 ray_dir) const { return switch_env_up(mul33(transform, ray_dir)); }
+    IG_DEV float pdf(f3 ray_dir) const
+    {
+        const f3 ldir        = local_dir(ray_dir);
+        const float sinTheta = safe_sqrt(1 - ldir.z * ldir.z);
+        return safe_div(cdf.pdf_continuous(map_env_uv(ldir)), sinTheta * kPi * kPi * 2);
+    }
+    IG_DEV Col emission(f3 ray_dir) const { return scale * image_lookup(sc, *tex, map_env_uv(local_dir(ray_dir))); }
+};
+
+// square_to_concentric_disk (core/warp.art:2-22)
+IG_DEV f2 concentric_disk(float px, float py)
+{
+    const float a = 2 * px - 1;
+    const float b = 2 * py - 1;
+    if (a == 0 && b == 0)
+        return f2{ 0, 0 };
+    if (a * a > b * b) {
+        const float phi = (kPi / 4) * safe_div(b, a);
+        return f2{ igm_cos(phi) * a, igm_sin(phi) * a };
+    }
+    const float phi = (kPi / 2) - (kPi / 4) * safe_div(a, b);
+    return f2{ igm_cos(phi) * b, igm_sin(phi) * b };
+}
+
 // ---------------------------------------------------------------- light selection
 
 // equal_area_square_to_sphere (core/warp.art:63-91)
@@ -1184,11 +1325,25 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         Col sum{ 0, 0, 0 };
         for (uint32_t li = 0; li < sc.infinite_light_count; ++li) {
             const ig_light& L = sc.lights[li];
-            if (L.type != IG_LIGHT_ENV)
-                continue;
-            const float pdf_s = 1 / (4 * kPi); // equal_area_sphere_pdf (light/env.art:101)
+            Col emit;
+            float pdf_s;
+            if (L.type == IG_LIGHT_ENV) {
+                emit  = Col{ L.d[0], L.d[1], L.d[2] };
+                pdf_s = 1 / (4 * kPi); // equal_area_sphere_pdf (light/env.art:101)
+            } else if (FULL && L.type == IG_LIGHT_ENV_TEXTURED) {
+                const TexturedEnv env(sc, L);
+                emit  = env.emission(in.dir);
+                pdf_s = env.pdf(in.dir);
+            } else if (FULL && L.type == IG_LIGHT_SUN) {
+                // make_sun_light.emission / pdf_direct (light/sun.art:31-45)
+                const bool hit = dot3(f3{ L.d[0], L.d[1], L.d[2] }, in.dir) >= L.d[3];
+                emit           = hit ? Col{ L.d[4], L.d[5], L.d[6] } : Col{ 0, 0, 0 };
+                pdf_s          = hit ? safe_div(1, 2 * kPi * (1 - L.d[3])) : 0.0f;
+            } else {
+                continue; // delta lights
+            }
             const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, (int)li, in.org) * pdf_s) : 1.0f;
-            const Col c       = clamp_color(tech, (in.contrib * Col{ L.d[0], L.d[1], L.d[2] }) * mis);
+            const Col c       = clamp_color(tech, (in.contrib * emit) * mis);
             sum               = Col{ sum.r + c.r, sum.g + c.g, sum.b + c.b };
         }
         out.has_radiance = true;
@@ -1288,6 +1443,35 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             ldist         = sc.scene_radius;
             delta         = true;
             infinite      = true;
+        } else if (FULL && L.type == IG_LIGHT_ENV_TEXTURED) {
+            // make_environment_light_textured.sample_direct (light/env.art:135-138)
+            const TexturedEnv env(sc, L);
+            Col intensity;
+            env.sample_dir(rnd, ldir, intensity, pdf_value);
+            lint     = intensity * (1 / pdf_value);
+            lpos     = surf.point + ldir * sc.scene_radius;
+            lcos     = 1.0f;
+            ldist    = sc.scene_radius;
+            infinite = true;
+        } else if (FULL && L.type == IG_LIGHT_SUN) {
+            // make_sun_light.sample_direct (light/sun.art:21-25), sample_uniform_cone (core/sampling.art:109-116)
+            const f3 sun_dir    = f3{ L.d[0], L.d[1], L.d[2] };
+            const float cos_a   = L.d[3];
+            const float ux      = rnd.f32();
+            const float uy      = rnd.f32();
+            const float c1      = 1 - cos_a;
+            const f2 p          = concentric_disk(ux, uy);
+            const float n2      = p.x * p.x + p.y * p.y;
+            const float z       = cos_a + c1 * (1 - n2);
+            const float k       = safe_sqrt(c1 * (2 - c1 * n2));
+            const f3 ndir       = mul33(orthonormal_basis(-sun_dir), f3{ p.x * k, p.y * k, z });
+            const float inv_pdf = 2 * kPi * (1 - cos_a);
+            ldir                = -ndir;
+            lint                = Col{ L.d[4], L.d[5], L.d[6] } * inv_pdf;
+            pdf_value           = safe_div(1, 2 * kPi * (1 - cos_a)); // uniform_cone_pdf
+            lcos                = z;
+            ldist               = __builtin_inff();
+            infinite            = true;
         } else {
             // constant environment: make_environment_light_function_spherical.sample_direct (light/env.art:89-93)
             const float ux = rnd.f32();

@@ -277,6 +277,7 @@ struct Scene {
     std::vector<std::string> material_names;
     std::vector<ig_texture> textures;
     std::vector<uint8_t> texture_data;
+    std::vector<float> cdf_data;
     igd_scene tables{};
 };
 
@@ -604,6 +605,110 @@ struct TextureBank {
         return id;
     }
 };
+
+// ---- environment maps: texture baking and the sampling tables
+// One lookup of a packed bitmap texture the way the device does it (src/artic/texture/image.art:9-156 with the identity
+// transform): used to bake the radiance of an environment light (src/artic/entrypoints/bake.art:1-26).
+static V3 lookupTexture(const ig_texture& t, const std::vector<uint8_t>& data, float u, float v)
+{
+    const int W = (int)t.width, H = (int)t.height;
+    auto border = [](uint32_t mode, int x, int w) {
+        if (mode == IG_WRAP_CLAMP)
+            return std::min(std::max(x, 0), w - 1);
+        if (mode == IG_WRAP_MIRROR) {
+            const int a = x < 0 ? -1 - x : x;
+            const int k = a % w;
+            return ((a / w) & 1) == 0 ? w - 1 - k : k;
+        }
+        const int r = x % w;
+        return r < 0 ? r + w : r;
+    };
+    auto texel = [&](int x, int y) {
+        x = border(t.wrap_u, x, W);
+        y = border(t.wrap_v, y, H);
+        const uint8_t* p = &data[t.offset];
+        if (t.channels == 1) {
+            const float g = (float)p[(size_t)y * W + x] / 255;
+            return V3(g, g, g);
+        }
+        p += ((size_t)y * W + x) * 4;
+        return V3((float)p[0] / 255, (float)p[1] / 255, (float)p[2] / 255);
+    };
+    if (t.filter == IG_TEX_NEAREST)
+        return texel((int)std::floor(u * (float)W), (int)std::floor(v * (float)H));
+    const float pu = u * (float)W - 0.5f, pv = v * (float)H - 0.5f;
+    const int ix = (int)std::floor(pu), iy = (int)std::floor(pv);
+    const float fx = pu - std::floor(pu), fy = pv - std::floor(pv);
+    auto mix = [](V3 a, V3 b, float k) { return a * (1 - k) + b * k; };
+    if (t.filter == IG_TEX_BILINEAR)
+        return mix(mix(texel(ix, iy), texel(ix + 1, iy), fx), mix(texel(ix, iy + 1), texel(ix + 1, iy + 1), fx), fy);
+    // bicubic B-spline from four bilinear-like taps
+    auto w0 = [](float a) { return (a * (a * (-a + 3) - 3) + 1) / 6; };
+    auto w1 = [](float a) { return (a * a * (3 * a - 6) + 4) / 6; };
+    auto w2 = [](float a) { return (a * (a * (-3 * a + 3) + 3) + 1) / 6; };
+    auto w3 = [](float a) { return (a * a * a) / 6; };
+    const float g0x = w0(fx) + w1(fx), g1x = w2(fx) + w3(fx), g0y = w0(fy) + w1(fy), g1y = w2(fy) + w3(fy);
+    const int x0 = (int)std::floor((float)ix + (w1(fx) / g0x - 1) + 0.5f), x1 = (int)std::floor((float)ix + (w3(fx) / g1x + 1) + 0.5f);
+    const int y0 = (int)std::floor((float)iy + (w1(fy) / g0y - 1) + 0.5f), y1 = (int)std::floor((float)iy + (w3(fy) / g1y + 1) + 0.5f);
+    return (texel(x0, y0) * (g0x * g0y) + texel(x1, y0) * (g1x * g0y)) + (texel(x0, y1) * (g0x * g1y) + texel(x1, y1) * (g1x * g1y));
+}
+
+// CDF::computeForImage (src/runtime/CDF.cpp:43-150): marginal over rows (weighted by sin(theta)), one conditional per
+// row, MIS compensation (the mean response is subtracted unless the image is constant). Appends height + width * height
+// floats to `out` and returns the offset of the table.
+static uint32_t appendEnvironmentCdf(std::vector<float>& out, const std::vector<float>& rgb, size_t width, size_t height, bool compensate)
+{
+    constexpr float MinEps = 1e-5f;
+    auto response = [](float r, float g, float b) { return (std::max(r, 0.0f) + std::max(g, 0.0f) + std::max(b, 0.0f)) / 3; };
+    float defect = 0;
+    if (compensate) {
+        float lowest = std::numeric_limits<float>::infinity();
+        for (size_t i = 0; i < width * height; ++i) {
+            const float r = response(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+            lowest        = std::min(lowest, r);
+            defect += r / (float)width;
+        }
+        defect /= (float)height;
+        if (std::abs(lowest - defect) < 1e-4f)
+            defect = 0;
+    }
+    const size_t offset = out.size();
+    out.resize(offset + height + width * height);
+    float* marginal    = &out[offset];
+    float* conditional = &out[offset + height];
+    for (size_t y = 0; y < height; ++y) {
+        const float* p = &rgb[y * width * 3];
+        float* cond    = &conditional[y * width];
+        cond[0]        = response(p[0] - defect, p[1] - defect, p[2] - defect);
+        for (size_t x = 1; x < width; ++x)
+            cond[x] = cond[x - 1] + response(p[x * 3] - defect, p[x * 3 + 1] - defect, p[x * 3 + 2] - defect);
+        const float sum = cond[width - 1];
+        marginal[y]     = sum * std::sin(Pi * ((float)y + 0.5f) / (float)height);
+        if (sum > MinEps) {
+            const float n = 1.0f / sum;
+            for (size_t x = 0; x < width; ++x)
+                cond[x] *= n;
+        } else {
+            const float n = 1.0f / (float)width;
+            for (size_t x = 1; x < width; ++x)
+                cond[x - 1] = (float)x * n;
+        }
+        cond[width - 1] = 1;
+    }
+    for (size_t y = 1; y < height; ++y)
+        marginal[y] += marginal[y - 1];
+    if (marginal[height - 1] > MinEps) {
+        const float n = 1.0f / marginal[height - 1];
+        for (size_t y = 0; y < height; ++y)
+            marginal[y] *= n;
+    } else {
+        const float n = 1.0f / (float)height;
+        for (size_t y = 1; y < height; ++y)
+            marginal[y - 1] = (float)y * n;
+    }
+    marginal[height - 1] = 1;
+    return (uint32_t)offset;
+}
 
 static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, TextureBank& bank, int depth = 0)
 {
@@ -1127,6 +1232,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     std::vector<ig_light> infinite, finite;
     std::vector<LightEntry> hier_entries; // position / direction / flux per finite light (Light::position, direction, computeFlux)
     std::map<std::string, int32_t> finite_index_of_entity;
+    TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {} };
     for (const auto& l : jlights.arr) {
         const std::string lname = l.getString("name");
         const std::string type  = l.getString("type");
@@ -1223,14 +1329,73 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         } else if (type == "env" || type == "constant") {
             // EnvironmentLight.cpp:40-98: a constant radiance bakes to a 1x1 texture, so the reference
             // builds make_environment_light (uniform sphere sampling), not the CDF-sampled variant.
-            if (l.has("radiance") && l.find("radiance")->isString() && l.find("radiance")->str.rfind("color(", 0) != 0)
-                fail("Environment light '" + lname + "': textured environment maps are not supported by the HIP backend");
+            const JsonValue* rad = l.find("radiance");
+            bool textured        = false;
+            if (rad && rad->isString())
+                for (const auto& t : textures.arr)
+                    if (t.getString("name") == rad->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
+                        textured = true;
+            if (textured) {
+                // EnvironmentLight.cpp:14-98: the radiance texture is baked at >= 1024 x 512 (bake.art:5-6: uv = pixel / (size - 1))
+                // and sampled through the marginal / conditional CDF of the baked image; "cdf": "none" keeps uniform sampling
+                std::string method = l.getString("cdf", "conditional");
+                for (char& ch : method)
+                    ch = (char)std::tolower((unsigned char)ch);
+                if (method != "conditional" && method != "")
+                    fail("Environment light '" + lname + "': cdf method '" + method + "' is not supported by the HIP backend (only 'conditional')");
+                const int tex_id    = bank.get(rad->str, lname);
+                const ig_texture tx = sc->textures[tex_id];
+                const size_t bw = std::max<size_t>(1024, tx.width), bh = std::max<size_t>(512, tx.height);
+                std::vector<float> baked(bw * bh * 3);
+                for (size_t y = 0; y < bh; ++y)
+                    for (size_t x = 0; x < bw; ++x) {
+                        const V3 c = lookupTexture(tx, sc->texture_data, (float)x / (float)(bw - 1), (float)y / (float)(bh - 1));
+                        baked[(y * bw + x) * 3] = c.x, baked[(y * bw + x) * 3 + 1] = c.y, baked[(y * bw + x) * 3 + 2] = c.z;
+                    }
+                const uint32_t cdf_off = appendEnvironmentCdf(sc->cdf_data, baked, bw, bh, l.getBool("compensate", true));
+                const V3 scale         = getColor(l, "scale", V3(1, 1, 1), lname);
+                // "_transform" = transform.linear().transpose().inverse() (EnvironmentLight.cpp:56)
+                const M3 T   = l.has("transform") ? inverse(transpose(getTransform(l).L)) : M3{};
+                out.type     = IG_LIGHT_ENV_TEXTURED;
+                out.d[0] = scale.x, out.d[1] = scale.y, out.d[2] = scale.z;
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < 3; ++r)
+                        out.d[3 + c * 3 + r] = T.m[r][c];
+                const uint32_t ints[4] = { (uint32_t)tex_id, cdf_off, (uint32_t)bw, (uint32_t)bh };
+                std::memcpy(&out.d[12], ints, sizeof(ints));
+                infinite.push_back(out);
+                continue;
+            }
+            if (rad && rad->isString() && rad->str.rfind("color(", 0) != 0)
+                fail("Environment light '" + lname + "': only constant colours and bitmap textures are supported as radiance by the HIP backend");
             // a "transform" only rotates the lookup direction of make_environment_light_function_spherical (env.art:74-96:
             // the sampled direction itself is not transformed), so it has no effect on a constant radiance
             const V3 radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
             const V3 scale    = getColor(l, "scale", V3(1, 1, 1), lname);
             out.type          = IG_LIGHT_ENV;
             out.d[0] = scale.x * radiance.x, out.d[1] = scale.y * radiance.y, out.d[2] = scale.z * radiance.z; // color_mul(scale, tex), env.art:163
+            infinite.push_back(out);
+        } else if (type == "sun") {
+            // SunLight.cpp:11-57, light/sun.art:1-48: an infinite cone light; direction = from the scene towards the sun
+            const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);
+            if (!key)
+                fail("Light '" + lname + "': only an explicit 'direction' / 'sun_direction' is supported by this loader");
+            V3 dir           = getVector3(*l.find(key), key);
+            const float dl   = std::sqrt(dot(dir, dir));
+            dir              = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
+            const float angle = getConstNumber(l, "angle", 0.533f, lname); // flt_sun_radius_deg
+            const float half  = angle / 2 * Deg2Rad;
+            V3 radiance;
+            if (l.has("radiance")) {
+                radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
+            } else {
+                // irradiance / sun_area_from_srad(rad(angle / 2)) (SunLight.cpp:51-52, sun.art:5)
+                radiance = getColor(l, "irradiance", V3(1, 1, 1), lname) * (1 / (Pi * half * half));
+            }
+            out.type = IG_LIGHT_SUN;
+            out.d[0] = dir.x, out.d[1] = dir.y, out.d[2] = dir.z;
+            out.d[3] = std::cos(half);
+            out.d[4] = radiance.x, out.d[5] = radiance.y, out.d[6] = radiance.z;
             infinite.push_back(out);
         } else {
             fail("Light '" + lname + "': type '" + type + "' is not supported by the HIP backend");
@@ -1240,7 +1405,6 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     sc->lights.insert(sc->lights.end(), finite.begin(), finite.end());
 
     // ---- materials
-    TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {} };
     for (size_t m = 0; m < mat_keys.size(); ++m) {
         ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures, bank);
         if (!mat_keys[m].light_entity.empty())
@@ -1289,6 +1453,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.texture_count      = (uint32_t)sc->textures.size();
     t.texture_data       = sc->texture_data.data();
     t.texture_data_size  = sc->texture_data.size();
+    t.cdf_data           = sc->cdf_data.empty() ? nullptr : sc->cdf_data.data();
+    t.cdf_data_count     = sc->cdf_data.size();
     if (!cam_has_transform) {
         // no transform: a view over the whole scene (PerspectiveCamera.cpp:77-101, FishLensCamera.cpp:76-101)
         cam.dir[0] = 0, cam.dir[1] = 0, cam.dir[2] = -1;

@@ -76,6 +76,7 @@ class Scene(C.Structure):
         ("film_width", C.c_int32), ("film_height", C.c_int32), ("scene_radius", C.c_float),
         ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
         ("texture_data", C.POINTER(C.c_uint8)), ("texture_data_size", C.c_uint64),
+        ("cdf_data", C.POINTER(C.c_float)), ("cdf_data_count", C.c_uint64),
     ]
 
 

@@ -178,4 +178,40 @@ IGM_FN float igm_acos(float x)
     return 1.5707963267948966192f - igm_asin(x);
 }
 
+/* ---- atan / atan2 (Cephes atanf): reduction to [0, tan(pi/8)] and a degree-4 minimax polynomial in z^2 ---- */
+IGM_FN float igm_atan_pos(float x) /* x >= 0 */
+{
+    float y, z;
+    if (x > 2.414213562373095f) { /* tan(3 pi / 8) */
+        y = 1.5707963267948966192f;
+        z = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) { /* tan(pi / 8) */
+        y = 0.7853981633974483096f;
+        z = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+        z = x;
+    }
+    const float w = z * z;
+    float p       = igm_fma(8.05374449538e-2f, w, -1.38776856032e-1f);
+    p             = igm_fma(p, w, 1.99777106478e-1f);
+    p             = igm_fma(p, w, -3.33329491539e-1f);
+    return y + igm_fma(p * w, z, z);
+}
+
+IGM_FN float igm_atan2(float y, float x)
+{
+    const float ax = igm_abs(x), ay = igm_abs(y);
+    float r;
+    if (ax == 0.0f && ay == 0.0f)
+        r = 0.0f;
+    else if (ax == 0.0f)
+        r = 1.5707963267948966192f;
+    else
+        r = igm_atan_pos(ay / ax);
+    if (igm_signbit(x))
+        r = 3.14159265358979323846f - r;
+    return igm_copysign(r, y);
+}
+
 #endif /* IG_DETMATH_H */

@@ -152,6 +152,14 @@ enum ig_light_type {
     IG_LIGHT_ENV   = 2, /* constant environment radiance, src/artic/light/env.art */
     IG_LIGHT_SPOT  = 3, /* "SimpleSpotLight", src/artic/light/spot.art:8-53, SpotLight.cpp:83-97 (finite, delta) */
     IG_LIGHT_DIRECTIONAL = 4, /* src/artic/light/directional.art:1-17, DirectionalLight.cpp (infinite, delta) */
+    /* environment map sampled through a marginal / conditional CDF (make_environment_light_textured, src/artic/light/
+     * env.art:109-157; EnvironmentLight.cpp:40-98): d[0..2] scale, d[3..11] the 3x3 "_transform" column by column,
+     * then as integer bits d[12] texture index, d[13] offset of the CDF in igd_scene.cdf_data (floats),
+     * d[14] CDF width, d[15] CDF height */
+    IG_LIGHT_ENV_TEXTURED = 5,
+    /* make_sun_light (src/artic/light/sun.art:8-48, SunLight.cpp:32-57; infinite, not delta): d[0..2] direction
+     * (scene to light, normalised), d[3] cos of the half angle, d[4..6] radiance */
+    IG_LIGHT_SUN = 6,
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
@@ -261,6 +269,11 @@ typedef struct igd_scene {
     uint32_t texture_count;
     const uint8_t* texture_data;
     uint64_t texture_data_size;
+    /* sampling tables of textured environment lights: per light the marginal CDF (height floats) followed by the
+     * conditional CDFs (width floats per row), without the leading zeros (src/runtime/CDF.cpp:71-150,
+     * src/artic/core/cdf.art:70-73,155-159) */
+    const float* cdf_data;
+    uint64_t cdf_data_count;
 } igd_scene;
 
 #ifdef __cplusplus

@@ -168,6 +168,10 @@ def random_sequence(seed, first_counter, count):
 
 def detmath(which, x):
     x = np.ascontiguousarray(x, dtype=np.float32)
+    if which == "atan2":  # x: [n, 2] pairs (y, x)
+        y = np.empty(x.shape[0], np.float32)
+        lib().oracle_detmath(4, C.c_int64(x.shape[0]), _fp(x), _fp(y))
+        return y
     y = np.empty_like(x)
     lib().oracle_detmath({"sin": 0, "cos": 1, "acos": 2, "asin": 3}[which], x.size, _fp(x), _fp(y))
     return y
@@ -229,6 +233,25 @@ def bsdf_sample(scene, mat_id, wo, n, seed=1, entering=True):
     if rc != 0:
         raise RuntimeError("oracle_bsdf_probe failed")
     return wi, pdf, col, eta
+
+
+def cdf1d(data, mode, u):
+    """core/cdf.art 1D CDF over `data` = [x1, ..., 1] (leading 0 implied). mode "discrete" / "continuous" / "pdf" ->
+    (off, pos, pdf)."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    off, pos, pdf = C.c_int32(0), C.c_float(0), C.c_float(0)
+    lib().oracle_cdf1d(_fp(data), C.c_int32(data.size), C.c_int32({"discrete": 0, "continuous": 1, "pdf": 2}[mode]), C.c_float(u),
+                       C.byref(off), C.byref(pos), C.byref(pdf))
+    return off.value, pos.value, pdf.value
+
+
+def cdf2d(table, size_x, size_y, mode, u):
+    """2D marginal / conditional CDF: "continuous" -> (pos [2], pdf) for u [2]; "pdf" -> pdf at position u."""
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    pos, pdf = np.zeros(2, np.float32), C.c_float(0)
+    lib().oracle_cdf2d(_fp(table), C.c_int32(size_x), C.c_int32(size_y), C.c_int32(1 if mode == "continuous" else 2), _fp(u), _fp(pos), C.byref(pdf))
+    return pos, pdf.value
 
 
 def hardware_threads():

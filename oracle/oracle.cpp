@@ -626,6 +626,7 @@ void oracle_detmath(int which, int64_t n, const float* x, float* y)
         case 0: y[i] = igm_sin(x[i]); break;
         case 1: y[i] = igm_cos(x[i]); break;
         case 2: y[i] = igm_acos(x[i]); break;
+        case 4: y[i] = igm_atan2(x[2 * i], x[2 * i + 1]); break; // x holds (y, x) pairs
         default: y[i] = igm_asin(x[i]); break;
         }
     }
@@ -714,6 +715,32 @@ int oracle_bsdf_probe(const igd_scene* sc, int32_t mat_id, int32_t entering, int
         }
     }
     return 0;
+}
+
+// CDF probes for the tests (core/cdf.art). `data` omits the leading zero, as the device buffers do.
+// mode 0: sample_discrete(u) -> off, pdf; 1: sample_continuous(u) -> off, pos, pdf; 2: pdf_continuous(x = u) -> off, pdf
+void oracle_cdf1d(const float* data, int32_t func_size, int32_t mode, float u, int32_t* off, float* pos, float* pdf)
+{
+    const Cdf1D cdf{ data, func_size };
+    *pos = 0;
+    if (mode == 0)
+        *off = cdf.sample_discrete(u, *pdf);
+    else if (mode == 1)
+        *pos = cdf.sample_continuous(u, *off, *pdf);
+    else
+        *pdf = cdf.pdf_continuous(u, *off);
+}
+
+// 2D: table = marginal (size_y) then conditionals (size_x per row). mode 1: sample_continuous(u) -> pos, pdf; 2: pdf_continuous(pos = u)
+void oracle_cdf2d(const float* data, int32_t size_x, int32_t size_y, int32_t mode, const float u[2], float pos[2], float* pdf)
+{
+    const Cdf2D cdf{ data, size_x, size_y };
+    if (mode == 1) {
+        const Vec2 p = cdf.sample_continuous(u[0], u[1], *pdf);
+        pos[0] = p.x, pos[1] = p.y;
+    } else {
+        *pdf = cdf.pdf_continuous(Vec2{ u[0], u[1] });
+    }
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

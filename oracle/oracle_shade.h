@@ -7,6 +7,10 @@
 
 #include "oracle_core.h"
 
+#include <algorithm>
+#include <functional>
+#include <limits>
+
 namespace oracle {
 
 // ---- core/random.art
@@ -1340,6 +1344,199 @@ static inline DirectLightSample sample_direct_env(const ig_light& l, Rng& rnd, c
     return s;
 }
 
+// ---- core/cdf.art:43-159 (marginal / conditional tables) and core/interval.art:7-23
+static inline int32_t interval_binary_search(int32_t size, const std::function<bool(int32_t)>& pred)
+{
+    int32_t first = 0, len = size;
+    while (len > 0) {
+        const int32_t half   = len / 2;
+        const int32_t middle = first + half;
+        if (pred(middle)) {
+            first = middle + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    return std::min(std::max(first - 1, 0), size - 1);
+}
+
+// make_cdf_1d over a buffer that omits the leading 0 (cdf.art:43-73)
+struct Cdf1D {
+    const float* data;
+    int32_t func_size;
+
+    float get(int32_t i) const { return i == 0 ? 0.0f : data[i - 1]; }
+    float pdf_discrete(int32_t x) const { return get(x + 1) - get(x); }
+    int32_t sample_discrete(float u, float& pdf) const
+    {
+        const int32_t off = std::min(interval_binary_search(func_size + 1, [&](int32_t i) { return get(i) <= u; }), func_size - 1);
+        pdf               = pdf_discrete(off);
+        return off;
+    }
+    float pdf_continuous(float x, int32_t& off) const
+    {
+        off = std::min(std::max((int32_t)(x * (float)func_size), 0), func_size - 1);
+        return pdf_discrete(off) * (float)func_size;
+    }
+    // returns the position in [0, 1]
+    float sample_continuous(float u, int32_t& off, float& pdf) const
+    {
+        float dpdf;
+        off             = sample_discrete(u, dpdf);
+        const float rem = safe_div(u - get(off), dpdf);
+        pdf             = dpdf * (float)func_size;
+        return clampf(((float)off + rem) / (float)func_size, 0, 1);
+    }
+};
+
+// make_cdf_2d_from_buffer (cdf.art:108-159): the marginal (size_y entries) comes first, then one conditional per row
+struct Cdf2D {
+    const float* data;
+    int32_t size_x, size_y;
+
+    Cdf1D marginal() const { return Cdf1D{ data, size_y }; }
+    Cdf1D conditional(int32_t row) const { return Cdf1D{ data + size_y + (size_t)row * size_x, size_x }; }
+    Vec2 sample_continuous(float ux, float uy, float& pdf) const
+    {
+        int32_t oy, ox;
+        float p1, p2;
+        const float py = marginal().sample_continuous(uy, oy, p1);
+        const float px = conditional(oy).sample_continuous(ux, ox, p2);
+        pdf            = p1 * p2;
+        return Vec2{ px, py };
+    }
+    float pdf_continuous(Vec2 pos) const
+    {
+        int32_t oy, ox;
+        const float p1 = marginal().pdf_continuous(pos.y, oy);
+        const float p2 = conditional(oy).pdf_continuous(pos.x, ox);
+        return p1 * p2;
+    }
+};
+
+// ---- light/env.art:11-21,109-157 (make_environment_light_textured), core/warp.art:44-57
+static inline Vec3 switch_env_up(Vec3 v) { return make_vec3(v.x, v.z, v.y); }
+static inline Vec2 map_env_uv(Vec3 dir)
+{
+    const float theta = igm_acos(dir.z); // spherical_from_dir
+    float phi         = igm_atan2(dir.y, dir.x);
+    if (phi < 0)
+        phi = phi + 2 * flt_pi;
+    const float v = theta / flt_pi;
+    const float u = phi / (2 * flt_pi);
+    const float r = u + 0.25f;
+    return Vec2{ r - igm_floor(r), 1 - v };
+}
+
+struct TexturedEnv {
+    const igd_scene& sc;
+    Color scale;
+    Mat3x3 transform;
+    const ig_texture* tex;
+    Cdf2D cdf;
+
+    TexturedEnv(const igd_scene& scene, const ig_light& l)
+        : sc(scene)
+    {
+        scale = Color{ l.d[0], l.d[1], l.d[2] };
+        for (int c = 0; c < 3; ++c)
+            transform.col[c] = make_vec3(l.d[3 + c * 3], l.d[4 + c * 3], l.d[5 + c * 3]);
+        uint32_t ints[4];
+        std::memcpy(ints, &l.d[12], sizeof(ints));
+        tex = &sc.textures[ints[0]];
+        cdf = Cdf2D{ sc.cdf_data + ints[1], (int32_t)ints[2], (int32_t)ints[3] };
+    }
+    // sample_dir (env.art:112-123): note that the intensity is the bare texture value, without `scale`
+    void sample_dir(Rng& rnd, Vec3& dir, Color& intensity, float& pdf_dir) const
+    {
+        const float u0 = rnd.next_f32();
+        const float u1 = rnd.next_f32();
+        float pdf;
+        const Vec2 pos    = cdf.sample_continuous(u0, u1, pdf);
+        intensity         = image_lookup(sc, *tex, pos);
+        const float theta = (1 - pos.y) * flt_pi;
+        const float phi   = (pos.x - 0.25f) * 2 * flt_pi;
+        const float st = igm_sin(theta), ct = igm_cos(theta);
+        const Vec3 d   = make_vec3(st * igm_cos(phi), st * igm_sin(phi), ct); // dir_from_spherical
+        const float sinTheta = safe_sqrt(1 - d.z * d.z);                      // shading::sin_theta
+        pdf_dir              = safe_div(pdf, sinTheta * flt_pi * flt_pi * 2);
+        const Vec3 e         = switch_env_up(d);
+        dir = make_vec3(vec3_dot(transform.col[0], e), vec3_dot(transform.col[1], e), vec3_dot(transform.col[2], e)); // mat3x3_left_mul
+    }
+    Vec3 local_dir(Vec3 ray_dir) const { return switch_env_up(mat3x3_mul(transform, ray_dir)); }
+    float pdf(Vec3 ray_dir) const // env.art:125-131
+    {
+        const Vec3 ldir      = local_dir(ray_dir);
+        const float sinTheta = safe_sqrt(1 - ldir.z * ldir.z);
+        return safe_div(cdf.pdf_continuous(map_env_uv(ldir)), sinTheta * flt_pi * flt_pi * 2);
+    }
+    Color emission(Vec3 ray_dir) const // env.art:145-150
+    {
+        return color_mul(scale, image_lookup(sc, *tex, map_env_uv(local_dir(ray_dir))));
+    }
+};
+
+static inline DirectLightSample sample_direct_env_textured(const igd_scene& sc, const ig_light& l, Rng& rnd, const SurfaceElement& from_surf)
+{
+    const TexturedEnv env(sc, l);
+    Vec3 dir;
+    Color intensity;
+    float pdf_dir;
+    env.sample_dir(rnd, dir, intensity, pdf_dir);
+    DirectLightSample s;
+    s.pos          = vec3_add(from_surf.point, vec3_mulf(dir, sc.scene_radius));
+    s.dir          = dir;
+    s.intensity    = color_mulf(intensity, 1 / pdf_dir);
+    s.pdf_value    = pdf_dir;
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = false;
+    s.cos          = 1.0f;
+    s.dist         = sc.scene_radius;
+    return s;
+}
+
+// ---- light/sun.art:8-48 (make_sun_light, not handled as delta), core/sampling.art:106-116
+struct SunLight {
+    Vec3 dir; // scene to light
+    float cos_angle;
+    Color radiance;
+    explicit SunLight(const ig_light& l)
+        : dir(make_vec3(l.d[0], l.d[1], l.d[2]))
+        , cos_angle(l.d[3])
+        , radiance(Color{ l.d[4], l.d[5], l.d[6] })
+    {
+    }
+    float dir_pdf() const { return safe_div(1, 2 * flt_pi * (1 - cos_angle)); } // uniform_cone_pdf
+    bool hits(Vec3 towards_light) const { return vec3_dot(dir, towards_light) >= cos_angle; }
+};
+
+static inline DirectLightSample sample_direct_sun(const ig_light& l, Rng& rnd)
+{
+    const SunLight sun(l);
+    const float u  = rnd.next_f32();
+    const float v  = rnd.next_f32();
+    const float c1 = 1 - sun.cos_angle; // sample_uniform_cone
+    float px, py;
+    square_to_concentric_disk(u, v, px, py);
+    const float n2 = px * px + py * py;
+    const float z  = sun.cos_angle + c1 * (1 - n2);
+    const float k  = safe_sqrt(c1 * (2 - c1 * n2));
+    const Vec3 local = make_vec3(px * k, py * k, z);
+    const Vec3 ndir  = mat3x3_mul(make_orthonormal_mat3x3(vec3_neg(sun.dir)), local);
+    const float inv_pdf = 2 * flt_pi * (1 - sun.cos_angle);
+    DirectLightSample s;
+    s.pos          = make_vec3(0, 0, 0);
+    s.dir          = vec3_neg(ndir);
+    s.intensity    = color_mulf(sun.radiance, inv_pdf);
+    s.pdf_value    = sun.dir_pdf();
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = false;
+    s.cos          = local.z;
+    s.dist         = std::numeric_limits<float>::infinity();
+    return s;
+}
+
 // ---- light/light_hierarchy.art:14-96 over the table built by the host (LightHierarchy.cpp)
 struct HierEntry {
     Vec3 pos, dir;
@@ -1531,6 +1728,14 @@ struct PathTracer {
             delta    = true;
             infinite = true;
             break;
+        case IG_LIGHT_ENV_TEXTURED:
+            ls       = sample_direct_env_textured(sc, light, rnd, surf);
+            infinite = true;
+            break;
+        case IG_LIGHT_SUN:
+            ls       = sample_direct_sun(light, rnd);
+            infinite = true;
+            break;
         default:
             ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);
             infinite = true;
@@ -1593,11 +1798,24 @@ struct PathTracer {
         Color color   = Color{ 0, 0, 0 };
         for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
             const ig_light& light = sc.lights[i];
-            if (light.type != IG_LIGHT_ENV)
-                continue;
+            if (light.type != IG_LIGHT_ENV && light.type != IG_LIGHT_ENV_TEXTURED && light.type != IG_LIGHT_SUN)
+                continue; // delta lights
             ++inflights;
-            const Color emit  = Color{ light.d[0], light.d[1], light.d[2] };
-            const float pdf_s = 1 / (4 * flt_pi); // equal_area_sphere_pdf (env.art:101)
+            Color emit;
+            float pdf_s;
+            if (light.type == IG_LIGHT_ENV_TEXTURED) {
+                const TexturedEnv env(sc, light);
+                emit  = env.emission(ray.dir);
+                pdf_s = env.pdf(ray.dir);
+            } else if (light.type == IG_LIGHT_SUN) {
+                const SunLight sun(light); // sun.art:31-45
+                const bool hit = sun.hits(ray.dir);
+                emit           = hit ? sun.radiance : Color{ 0, 0, 0 };
+                pdf_s          = hit ? sun.dir_pdf() : 0.0f;
+            } else {
+                emit  = Color{ light.d[0], light.d[1], light.d[2] };
+                pdf_s = 1 / (4 * flt_pi); // equal_area_sphere_pdf (env.art:101)
+            }
             const float mis   = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf((int32_t)i, ray.org) * pdf_s) : 1.0f;
             const Color c     = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
             color             = Color{ color.r + c.r, color.g + c.g, color.b + c.b };

@@ -733,3 +733,54 @@ def test_principled_with_textured_base_color_and_tail(tmp_path, gpu_device):
         _compare_with_oracle(dev, lean, 64, 64, 4, seed=5)
     finally:
         dev.close()
+
+
+def _write_png_rgb(path, img):
+    import struct
+    import zlib
+    h, w, _ = img.shape
+    raw = b"".join(b"\x00" + img[y].astype(np.uint8).tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("filt,transform", [("nearest", None), ("bilinear", [{"rotate": [20, 40, 0]}]), ("bicubic", None)])
+def test_textured_environment_vs_oracle(gpu_device, tmp_path, filt, transform):
+    """make_environment_light_textured: CDF-sampled next event estimation, emission and MIS pdf on escaping rays, all three
+    texture filters, a rotated environment; the diamonds make long specular chains end on the environment."""
+    from ignis_amd.tables import LoadedScene
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 60, (16, 32, 3)).astype(np.uint8)
+    img[3:6, 20:24] = [255, 240, 200]
+    img[9:11, 2:5] = [40, 90, 255]
+    _write_png_rgb(str(tmp_path / "env.png"), img)
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    for sh in s["shapes"]:
+        if "filename" in sh:
+            sh["filename"] = os.path.join(SCENES, sh["filename"])
+    s["textures"] = [{"type": "image", "name": "envtex", "filename": "env.png", "filter_type": filt}]
+    light = {"type": "env", "name": "sky", "radiance": "envtex", "scale": [1.5, 1.5, 1.5]}
+    if transform:
+        light["transform"] = transform
+    s["lights"] = [light]
+    s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top", "AreaLight")]
+    sc = LoadedScene.from_string(json.dumps(s), str(tmp_path), 96, 64)
+    tot = _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=21, iters=2)
+    assert tot["shadow_rays"] > 0 and tot["unoccluded"] > 0
+
+
+def test_sun_light_with_other_lights_vs_oracle(gpu_device):
+    """make_sun_light next to a constant environment and point lights (uniform and hierarchy selectors)."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s["lights"] = s["lights"][:4] + [
+        {"type": "sun", "name": "Sun", "direction": [0.3, 0.8, 0.5], "irradiance": [3, 2.8, 2.5], "angle": 4.0},
+        {"type": "env", "name": "Sky", "radiance": [0.1, 0.15, 0.2]},
+    ]
+    for sel in ("uniform", "hierarchy"):
+        s["technique"]["light_selector"] = sel
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 96)
+        _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=8)

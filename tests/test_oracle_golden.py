@@ -540,3 +540,140 @@ def test_principled_loader_defaults(principled_scene):
     m3 = principled_scene.tables.contents.materials[3]
     aspect = np.sqrt(np.float32(1) - np.float32(0.6) * np.float32(0.99))  # microfacet.art:427-432
     assert m3.p[8] == pytest.approx(0.4 / aspect, rel=1e-6) and m3.p[9] == pytest.approx(0.4 * aspect, rel=1e-6)
+
+
+# ---- core/cdf.art pinned by src/tests/artic/test_cdf.art:1-165 (data [0, .1, .2, .4, .4, .8, 1], func_size 6)
+
+_CDF = [0.1, 0.2, 0.4, 0.4, 0.8, 1.0]  # the buffers omit the leading 0 (cdf.art:70-73)
+
+
+def test_cdf_1d_known_answers():
+    off, _, pdf = oracle.cdf1d(_CDF, "discrete", 0.0)
+    assert off == 0 and pdf == np.float32(0.1)                                  # test_cdf_1d_sample_disc_u_0
+    off, _, pdf = oracle.cdf1d(_CDF, "discrete", 1.0)
+    assert off == 5 and pdf == np.float32(1.0) - np.float32(0.8)                # ..._disc_u_1
+    off, pos, pdf = oracle.cdf1d(_CDF, "continuous", 0.0)
+    assert (off, pos) == (0, 0.0) and pdf == oracle.cdf1d(_CDF, "pdf", pos)[2]  # ..._cont_u_0
+    off, pos, pdf = oracle.cdf1d(_CDF, "continuous", 1.0)
+    assert (off, pos) == (5, 1.0) and pdf == oracle.cdf1d(_CDF, "pdf", pos)[2]  # ..._cont_u_1
+    off, pos, pdf = oracle.cdf1d(_CDF, "continuous", 0.79)
+    assert off == 4 and pdf == oracle.cdf1d(_CDF, "pdf", pos)[2]                # ..._cont_u_079
+    off, pos, pdf = oracle.cdf1d(_CDF, "continuous", 0.8)
+    assert off == 5 and pdf == oracle.cdf1d(_CDF, "pdf", pos)[2]                # ..._cont_u_08
+    assert oracle.cdf1d(_CDF, "discrete", 0.57)[0] == oracle.cdf1d(_CDF, "continuous", 0.57)[0]  # ..._cont_disc
+
+
+def test_cdf_2d_sampling_follows_the_table():
+    """Positions drawn through the marginal / conditional tables are distributed like the table's density."""
+    rng = np.random.default_rng(3)
+    w, h = 8, 4
+    f = rng.uniform(0.1, 1.0, (h, w)).astype(np.float32)
+    f[2, 5] = 20
+    cond = np.cumsum(f, 1) / f.sum(1, keepdims=True)
+    marg = np.cumsum(f.sum(1)) / f.sum()
+    table = np.concatenate([marg, cond.ravel()]).astype(np.float32)
+    hist = np.zeros((h, w))
+    n = 40000
+    for u in rng.uniform(0, 1, (n, 2)).astype(np.float32):
+        pos, pdf = oracle.cdf2d(table, w, h, "continuous", u)
+        x, y = min(int(pos[0] * w), w - 1), min(int(pos[1] * h), h - 1)
+        hist[y, x] += 1
+        assert pdf == pytest.approx(oracle.cdf2d(table, w, h, "pdf", pos)[1], rel=1e-5)
+        assert pdf == pytest.approx(f[y, x] / f.sum() * w * h, rel=1e-3)
+    np.testing.assert_allclose(hist / n, f / f.sum(), atol=4 * np.sqrt(f / f.sum() / n).max())
+
+
+def _write_png_rgb(path, img):
+    import struct
+    import zlib
+    h, w, _ = img.shape
+    raw = b"".join(b"\x00" + img[y].astype(np.uint8).tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _env_scene(tmp_path, img, entities=True, light=None, size=(32, 32), filt="nearest"):
+    _write_png_rgb(str(tmp_path / "env.png"), img)
+    s = flat_scene([dict({"type": "env", "name": "sky", "radiance": "envtex"}, **(light or {}))], max_depth=2, size=size)
+    s["textures"] = [{"type": "image", "name": "envtex", "filename": "env.png", "filter_type": filt, "linear": True}]
+    if not entities:
+        s["entities"] = []
+    return LoadedScene.from_string(json.dumps(s), str(tmp_path), *size)
+
+
+def test_environment_cdf_table_matches_numpy_restatement(tmp_path):
+    """CDF::computeForImage (src/runtime/CDF.cpp:43-150) on the image baked at 1024 x 512 with uv = pixel / (size - 1)
+    (bake.art:5-6), nearest lookup, MIS compensation."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (10, 20, 3)).astype(np.uint8)
+    sc = _env_scene(tmp_path, img)
+    t = sc.scene
+    assert t.lights[0].type == 5
+    tex, off, bw, bh = np.array(list(t.lights[0].d[12:16]), np.float32).view(np.uint32)
+    assert (tex, off, bw, bh) == (0, 0, 1024, 512) and t.cdf_data_count == 512 + 1024 * 512
+    table = np.ctypeslib.as_array(t.cdf_data, shape=(t.cdf_data_count,))
+    flipped = img[::-1].astype(np.float32) / np.float32(255)         # rows bottom to top in the packed texture
+    xs = np.floor(np.arange(bw, dtype=np.float32) / np.float32(bw - 1) * np.float32(20)).astype(int) % 20
+    ys = np.floor(np.arange(bh, dtype=np.float32) / np.float32(bh - 1) * np.float32(10)).astype(int) % 10
+    baked = flipped[ys][:, xs].astype(np.float64)
+    resp = baked.mean(-1)
+    resp = np.maximum(baked - resp.mean(), 0).mean(-1)               # compensation: subtract the mean response per channel
+    cond = np.cumsum(resp, 1)
+    marg = np.cumsum(cond[:, -1] * np.sin(np.pi * (np.arange(bh) + 0.5) / bh))
+    np.testing.assert_allclose(table[:bh], marg / marg[-1], atol=1e-4)  # float32 running sums over up to 1024 entries
+    ok = cond[:, -1] > 1e-5
+    np.testing.assert_allclose(table[bh:].reshape(bh, bw)[ok], (cond / np.maximum(cond[:, -1:], 1e-30))[ok], atol=1e-4)
+    assert np.all(table[bh:].reshape(bh, bw)[:, -1] == 1) and table[bh - 1] == 1
+
+
+def test_textured_environment_seen_by_the_camera(tmp_path):
+    """emission (env.art:145-150): radiance = scale * texture(map_env_uv(direction)), (0.5, 0.5) is +y... the camera of the
+    integrator test scene looks along +z, so the film centre sees the texel at u = 0.5 (phi = 90 deg rotated by 0.25), v = 0.5."""
+    img = np.zeros((5, 7, 3), np.uint8)                              # odd sizes: (0.5, 0.5) is the middle of a texel
+    img[:, :, 0] = np.arange(7)[None, :] * 30
+    img[:, :, 1] = np.arange(5)[:, None] * 50
+    sc = _env_scene(tmp_path, img, entities=False, light={"scale": [2, 2, 2]}, size=(33, 33))
+    fb, st = oracle.render(sc, 1, 33, 33, seed=1)
+    assert st["shadow_rays"] == 0
+    centre = fb[16, 16]
+    # direction (0, 0, 1): local dir = switch_env_up -> (0, 1, 0): theta = pi / 2, phi = pi / 2 -> u = fract(0.25 + 0.25) = 0.5, v = 0.5
+    x, y = int(0.5 * 7), int(0.5 * 5)
+    want = 2 * np.float32([x * 30, (4 - y) * 50, 0]) / 255           # packed rows are bottom-up: v = 0.5 -> source row 4 - y
+    np.testing.assert_allclose(centre, want, rtol=1e-5)
+    # looking up (+y, film top) moves towards v = 1 = the first source row; right (+x) changes u
+    assert fb[0, 16, 1] <= centre[1] and not np.allclose(fb[16, 0], fb[16, 32])
+
+
+def test_textured_environment_illumination_is_unbiased(tmp_path):
+    """Direct light of a diffuse plane under an environment with one bright region: CDF-driven NEE (+ MIS with BSDF samples
+    that escape) converges to the same image mean as the estimate that only uses BSDF sampling (nee off)."""
+    img = np.full((8, 16, 3), 10, np.uint8)
+    img[3:5, 0:2] = 250   # around (u, v) = (0, 0.5): direction -z, the side the plane of the integrator scene faces
+    img[3:5, 15:16] = 250
+    sc_nee = _env_scene(tmp_path, img, size=(24, 24), light={"scale": [1, 1, 1]})
+    _write_png_rgb(str(tmp_path / "env.png"), img)
+    s = flat_scene([{"type": "env", "name": "sky", "radiance": "envtex"}], max_depth=2, size=(24, 24))
+    s["textures"] = [{"type": "image", "name": "envtex", "filename": "env.png", "filter_type": "nearest", "linear": True}]
+    s["technique"]["nee"] = False
+    sc_bsdf = LoadedScene.from_string(json.dumps(s), str(tmp_path), 24, 24)
+    a = np.mean([oracle.render(sc_nee, 64, 24, 24, iteration=i, seed=2)[0].mean() for i in range(4)])
+    b = np.mean([oracle.render(sc_bsdf, 64, 24, 24, iteration=i, seed=2)[0].mean() for i in range(16)])
+    assert a == pytest.approx(b, rel=0.03) and a > 0.05
+
+
+def test_sun_light_analytic_answer():
+    """sun.art:8-48: a cone light of irradiance E over a diffuse white plane gives radiance E cos / pi (the cone is 0.5 deg wide)."""
+    sun = flat_scene([{"type": "sun", "name": "_light", "direction": [0.6, 0, -0.8], "irradiance": [2, 2, 2]}])
+    sc = LoadedScene.from_string(json.dumps(sun), SCENES, 32, 32)
+    t = sc.scene
+    assert t.lights[0].type == 6 and t.infinite_light_count == 1
+    half = np.radians(0.533 / 2)
+    assert t.lights[0].d[3] == pytest.approx(np.cos(half), rel=1e-7) and t.lights[0].d[4] == pytest.approx(2 / (np.pi * half * half), rel=1e-5)
+    mean = np.mean([oracle.render(sc, 16, 32, 32, iteration=i, seed=4)[0].mean() for i in range(4)])
+    # "direction" points from the scene to the sun (sun.art:8); the integrator scene's plane faces -z: cos = 0.8
+    # inv_pdf * radiance = E * (2 pi (1 - cos a)) / (pi a^2) ~ E for small a
+    # ... up to the float32 cancellation in 1 - cos(0.27 deg) (6e-8 / 1.08e-5 = 0.55 %), which the reference has as well
+    assert mean == pytest.approx(2 * 0.8 / np.pi, rel=8e-3)
