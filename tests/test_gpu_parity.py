@@ -784,3 +784,11 @@ def test_sun_light_with_other_lights_vs_oracle(gpu_device):
         s["technique"]["light_selector"] = sel
         sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 96)
         _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=8)
+
+
+def test_showcase_scene_principled_with_sky(gpu_device):
+    """scenes/diamond_scene_principled.json (principled walls and diamonds, area light + the synthetic sky map of
+    tools/make_sky_png.py): the committed scene of the full kernel variant, against the oracle."""
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene_principled.json"), 120, 80)
+    _compare_with_oracle(gpu_device, sc, 120, 80, 4, seed=1, iters=2)
