@@ -343,14 +343,14 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const ig_material& mat = s->materials[m];
-        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR && mat.bsdf_type != IG_BSDF_PRINCIPLED)
+        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR && mat.bsdf_type != IG_BSDF_PRINCIPLED && mat.bsdf_type != IG_BSDF_PLASTIC)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
         const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL) : 0u;
         if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | principled_flags))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses the thin flag, which the HIP backend cannot shade yet" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
-        const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED; // p[0..2] reflectance / base colour
+        const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED || mat.bsdf_type == IG_BSDF_PLASTIC; // p[0..2] reflectance / base colour
         if ((mat.flags & IG_MAT_IMAGE) && (!has_albedo || mat.tex_refl < 0 || mat.tex_refl >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: image-textured material " + std::to_string(m) + " has no valid texture or is neither diffuse nor principled" };
         if ((mat.flags & IG_MAT_CHECKER) && !has_albedo)
@@ -497,7 +497,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
-        d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED;
+        d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC;
     for (uint32_t i = 0; i < s->infinite_light_count; ++i)
         d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN;
     d->has_scene            = true;

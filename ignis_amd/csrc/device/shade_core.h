@@ -847,6 +847,142 @@ struct Principled {
     }
 };
 
+// fresnel_diffuse_factor (core/fresnel.art:42-63)
+IG_DEV float fresnel_diffuse_factor(float eta)
+{
+    if (eta < 1)
+        return -1.4399f * (eta * eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
+    const float ieta1 = 1 / eta;
+    const float ieta2 = ieta1 * ieta1;
+    const float ieta3 = ieta2 * ieta1;
+    const float ieta4 = ieta3 * ieta1;
+    const float ieta5 = ieta4 * ieta1;
+    return 0.919317f - 3.4793f * ieta1 + 6.75335f * ieta2 - 7.80989f * ieta3 + 4.98554f * ieta4 - 1.36881f * ieta5;
+}
+
+// make_plastic_bsdf (bsdf/plastic.art:2-41) = make_join_bsdf (bsdf/mix.art:4-65) of lobe 0, a lambertian with the inner
+// scattering factor, and lobe 1, the conductor with eta = black / k = white (PlasticBSDF.cpp:36-39: rough,
+// conductor.art:47-116, or the mirror of conductor.art:2-10 without roughness), mixed by the Fresnel term of out_dir
+struct Plastic {
+    m33 local;
+    Col kd, ks;
+    float eta, fdr;
+    bool smooth;
+    Ggx micro;
+
+    IG_DEV Plastic(const ig_material& m, const m33& frame, Col diffuse)
+    {
+        local  = frame;
+        kd     = diffuse;
+        ks     = Col{ m.p[6], m.p[7], m.p[8] };
+        eta    = m.p[3] / m.p[4];
+        fdr    = fresnel_diffuse_factor(eta);
+        smooth = (m.flags & IG_MAT_SMOOTH) != 0;
+        micro  = Ggx{ frame, m.p[9], m.p[10] };
+    }
+    IG_DEV float diff_scattering(float cos_i) const
+    {
+        const float fi = fresnel_dielectric(eta, cos_i);
+        return (1 - fi) * eta * eta / (1 - fdr);
+    }
+    IG_DEV float mix(f3 out_dir) const { return fresnel_dielectric(eta, abs_cos(out_dir, local.c2)); }
+
+    IG_DEV Col lobe_eval(int lobe, f3 in_dir, f3 out_dir) const
+    {
+        const f3 N = local.c2;
+        if (lobe == 0)
+            return (kd * (pos_cos(in_dir, N) * kInvPi)) * diff_scattering(abs_cos(in_dir, N));
+        if (smooth)
+            return Col{ 0, 0, 0 };
+        const float cos_o = abs_cos(out_dir, N);
+        const float cos_i = abs_cos(in_dir, N);
+        if (cos_o <= kFltEps || cos_i <= kFltEps)
+            return Col{ 0, 0, 0 };
+        const f3 H    = normalize3(in_dir + out_dir);
+        const float D = micro.D(H);
+        const float G = micro.G1(in_dir) * micro.G1(out_dir);
+        const float f = conductor_factor(0, 1, abs_cos(out_dir, H));
+        const Col F{ f, f, f }, IF{ 1 - f, 1 - f, 1 - f };
+        const Col c{ 0.0f * IF.r + ks.r * F.r, 0.0f * IF.g + ks.g * F.g, 0.0f * IF.b + ks.b * F.b };
+        return c * (D * G / (4 * cos_o));
+    }
+    IG_DEV float lobe_pdf(int lobe, f3 in_dir, f3 out_dir) const
+    {
+        if (lobe == 0)
+            return pos_cos(in_dir, local.c2) / kPi;
+        if (smooth)
+            return 0;
+        const f3 H      = normalize3(in_dir + out_dir);
+        const float cho = abs_cos(out_dir, H);
+        return micro.pdf(out_dir, H) * safe_div(1, 4 * cho);
+    }
+    IG_DEV bool lobe_sample(int lobe, Tea& rnd, f3 out_dir, f3& in_dir, float& pdf, Col& color, bool& sdelta) const
+    {
+        const f3 N = local.c2;
+        sdelta     = false;
+        if (lobe == 0) {
+            const float u   = rnd.f32();
+            const float v   = rnd.f32();
+            const float c   = safe_sqrt(v);
+            const float s   = safe_sqrt(1 - v);
+            const float phi = 2 * kPi * u;
+            in_dir          = mul33(local, f3{ s * igm_cos(phi), s * igm_sin(phi), c });
+            pdf             = c / kPi;
+            color           = kd * diff_scattering(abs_cos(in_dir, N));
+            return true;
+        }
+        if (smooth) {
+            in_dir = N * (2 * dot3(N, out_dir)) - out_dir;
+            pdf    = 1;
+            color  = ks;
+            sdelta = true;
+            return true;
+        }
+        if (abs_cos(out_dir, N) <= kFltEps)
+            return false;
+        const f3 m       = micro.sample(rnd, out_dir);
+        const float mpdf = micro.pdf(out_dir, m);
+        if (dot3(m, m) <= kFltEps)
+            return false;
+        const f3 oH = normalize3(m);
+        const f3 H  = igm_signbit(dot3(oH, out_dir)) ? -oH : oH;
+        in_dir      = H * (2 * dot3(H, out_dir)) - out_dir;
+        if (abs_cos(in_dir, N) <= kFltEps)
+            return false;
+        const float jacob = 1 / (4 * abs_cos(out_dir, H));
+        pdf               = mpdf * jacob;
+        color             = lobe_eval(1, in_dir, out_dir) * safe_div(1, pdf);
+        return true;
+    }
+
+    IG_DEV Col eval(f3 in_dir, f3 out_dir) const { return lerp_col(lobe_eval(0, in_dir, out_dir), lobe_eval(1, in_dir, out_dir), mix(out_dir)); }
+    IG_DEV float pdf(f3 in_dir, f3 out_dir) const { return lerpf(lobe_pdf(0, in_dir, out_dir), lobe_pdf(1, in_dir, out_dir), mix(out_dir)); }
+    // sample_mat (mix.art:28-38)
+    IG_DEV bool sample_lobe(int first, float t, Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, bool& sdelta) const
+    {
+        if (!lobe_sample(first, rnd, out_dir, in_dir, pdf_out, color, sdelta))
+            return false;
+        const int second = 1 - first;
+        const float p    = lerpf(pdf_out, lobe_pdf(second, in_dir, out_dir), t);
+        const Col c      = lerp_col(color * pdf_out, lobe_eval(second, in_dir, out_dir), t);
+        pdf_out          = p;
+        color            = c * safe_div(1, p);
+        return true;
+    }
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, bool& sdelta) const // mix.art:40-55
+    {
+        const float k = mix(out_dir);
+        if (rnd.f32() < 1 - k) {
+            if (sample_lobe(0, k, rnd, out_dir, in_dir, pdf_out, color, sdelta))
+                return true;
+            return sample_lobe(1, k, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+        }
+        if (sample_lobe(1, 1 - k, rnd, out_dir, in_dir, pdf_out, color, sdelta))
+            return true;
+        return sample_lobe(0, 1 - k, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+    }
+};
+
 // FULL = false leaves the principled BSDF out of the kernel (scenes without one run the lean variant)
 template <bool FULL>
 struct BsdfCtx {
@@ -872,7 +1008,7 @@ struct BsdfCtx {
             kd = Col{ m.p[0], m.p[1], m.p[2] };
         }
     }
-    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->flags & IG_MAT_SMOOTH); }
+    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)); }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
@@ -884,6 +1020,8 @@ struct BsdfCtx {
         if constexpr (FULL) {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().eval(in_dir, out_dir);
+            if (mat->bsdf_type == IG_BSDF_PLASTIC)
+                return Plastic(*mat, surf.local, kd).eval(in_dir, out_dir);
         }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return kd * (pos_cos(in_dir, N) * kInvPi);
@@ -909,6 +1047,8 @@ struct BsdfCtx {
         if constexpr (FULL) {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().pdf(in_dir, out_dir);
+            if (mat->bsdf_type == IG_BSDF_PLASTIC)
+                return Plastic(*mat, surf.local, kd).pdf(in_dir, out_dir);
         }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return pos_cos(in_dir, surf.local.c2) / kPi;
@@ -927,6 +1067,10 @@ struct BsdfCtx {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
                 sdelta = false;
                 return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
+            }
+            if (mat->bsdf_type == IG_BSDF_PLASTIC) {
+                s_eta = 1;
+                return Plastic(*mat, surf.local, kd).sample(rnd, out_dir, in_dir, pdf_out, color, sdelta);
             }
         }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {

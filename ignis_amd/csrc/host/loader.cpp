@@ -785,6 +785,39 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[10] = r * aspect;
         if (smooth || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
             m.flags |= IG_MAT_SMOOTH;
+    } else if (type == "plastic" || type == "roughplastic") {
+        // PlasticBSDF.cpp:13-44: a diffuse base under a (rough) mirror-like coating, mixed by the dielectric Fresnel term
+        if (bsdf->has("ext_ior_material") || bsdf->has("int_ior_material"))
+            fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
+        if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
+            fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
+        m.bsdf_type = IG_BSDF_PLASTIC;
+        const JsonValue* col = bsdf->find("diffuse_reflectance");
+        bool is_bitmap       = false;
+        if (col && col->isString())
+            for (const auto& t : textures.arr)
+                if (t.getString("name") == col->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
+                    is_bitmap = true;
+        if (is_bitmap) {
+            m.flags |= IG_MAT_IMAGE;
+            m.tex_refl = bank.get(col->str, name);
+        } else if (!(col && lowerCheckerboard(*col, textures, m, name))) {
+            const V3 kd = getColor(*bsdf, "diffuse_reflectance", V3(0.8f, 0.8f, 0.8f), name);
+            m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
+        }
+        m.p[3]      = getConstNumber(*bsdf, "ext_ior", 1.0f, name);  // vacuum (BSDF.cpp:8)
+        m.p[4]      = getConstNumber(*bsdf, "int_ior", 1.49f, name); // polypropylene (BSDF.cpp:17)
+        const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
+        m.p[6] = ks.x, m.p[7] = ks.y, m.p[8] = ks.z;
+        // BSDF::setupRoughness (BSDF.cpp:53-99), as for the conductor
+        const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
+        const float r           = getConstNumber(*bsdf, rname, 0.1f, name);
+        const float an          = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
+        const float aspect      = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+        m.p[9]  = r / aspect;
+        m.p[10] = r * aspect;
+        if (!bsdf->has(rname) || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f)
+            m.flags |= IG_MAT_SMOOTH;
     } else if (type == "principled") {
         // PrincipledBSDF.cpp:14-98: numbers are constants here (the reference also accepts textures / expressions)
         for (const char* key : { "reflective_ior_spec", "refractive_ior_spec", "ior_spec" })

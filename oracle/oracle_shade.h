@@ -953,12 +953,155 @@ struct BsdfSample {
     bool is_delta;
 };
 
+// fresnel_diffuse_factor (core/fresnel.art:42-63)
+static inline float fresnel_diffuse_factor(float eta)
+{
+    if (eta < 1)
+        return -1.4399f * (eta * eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
+    const float ieta1 = 1 / eta;
+    const float ieta2 = ieta1 * ieta1;
+    const float ieta3 = ieta2 * ieta1;
+    const float ieta4 = ieta3 * ieta1;
+    const float ieta5 = ieta4 * ieta1;
+    return 0.919317f - 3.4793f * ieta1 + 6.75335f * ieta2 - 7.80989f * ieta3 + 4.98554f * ieta4 - 1.36881f * ieta5;
+}
+
+// make_plastic_bsdf (bsdf/plastic.art:2-41): make_join_bsdf (bsdf/mix.art:4-65) of a lambertian with an inner-scattering
+// factor and the conductor with eta = black, k = white (PlasticBSDF.cpp:36-39) — the rough conductor
+// (conductor.art:47-116) or, without roughness, the mirror (conductor.art:2-10, chosen at :131-135) —, mixed by the
+// dielectric Fresnel term of the outgoing direction.
+struct Plastic {
+    Mat3x3 local;
+    Color kd, ks;
+    float eta, fdr;
+    bool smooth;
+    GGX micro;
+
+    Plastic(const ig_material& m, const SurfaceElement& surf, Color diffuse)
+    {
+        local  = surf.local;
+        kd     = diffuse;
+        ks     = Color{ m.p[6], m.p[7], m.p[8] };
+        eta    = m.p[3] / m.p[4];
+        fdr    = fresnel_diffuse_factor(eta);
+        smooth = (m.flags & IG_MAT_SMOOTH) != 0;
+        micro  = GGX{ surf.local, m.p[9], m.p[10] };
+    }
+    Vec3 N() const { return local.col[2]; }
+    float diff_scattering(float cos_i) const
+    {
+        const float fi = fresnel_dielectric(eta, cos_i);
+        return (1 - fi) * eta * eta / (1 - fdr);
+    }
+    float mix(Vec3 out_dir) const { return fresnel_dielectric(eta, absolute_cos(out_dir, N())); }
+
+    // lobe 0: diffuse_extra, lobe 1: the coating
+    Color lobe_eval(int lobe, Vec3 in_dir, Vec3 out_dir) const
+    {
+        if (lobe == 0)
+            return color_mulf(color_mulf(kd, positive_cos(in_dir, N()) * flt_inv_pi), diff_scattering(absolute_cos(in_dir, N())));
+        if (smooth)
+            return Color{ 0, 0, 0 };
+        const float cos_o = absolute_cos(out_dir, N());
+        const float cos_i = absolute_cos(in_dir, N());
+        if (cos_o <= flt_eps || cos_i <= flt_eps)
+            return Color{ 0, 0, 0 };
+        const Vec3 H   = vec3_halfway(in_dir, out_dir);
+        const float D  = micro.D(H);
+        const float G  = micro.G1(in_dir) * micro.G1(out_dir);
+        const float f  = conductor_factor(0, 1, absolute_cos(out_dir, H));
+        const Color F{ f, f, f }, IF{ 1 - f, 1 - f, 1 - f };
+        const Color c{ 0.0f * IF.r + ks.r * F.r, 0.0f * IF.g + ks.g * F.g, 0.0f * IF.b + ks.b * F.b };
+        return color_mulf(c, D * G / (4 * cos_o));
+    }
+    float lobe_pdf(int lobe, Vec3 in_dir, Vec3 out_dir) const
+    {
+        if (lobe == 0)
+            return cosine_hemisphere_pdf(positive_cos(in_dir, N()));
+        if (smooth)
+            return 0;
+        const Vec3 H        = vec3_halfway(in_dir, out_dir);
+        const float cos_h_o = absolute_cos(out_dir, H);
+        return micro.pdf(out_dir, H) * safe_div(1, 4 * cos_h_o);
+    }
+    bool lobe_sample(int lobe, Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        if (lobe == 0) {
+            const float u      = rnd.next_f32();
+            const float v      = rnd.next_f32();
+            const DirSample ds = sample_cosine_hemisphere(u, v);
+            s.in_dir           = mat3x3_mul(local, ds.dir);
+            s.pdf              = ds.pdf;
+            s.color            = color_mulf(kd, diff_scattering(absolute_cos(s.in_dir, N())));
+            s.eta              = 1;
+            s.is_delta         = false;
+            return true;
+        }
+        if (smooth) {
+            s.in_dir   = vec3_reflect(out_dir, N());
+            s.pdf      = 1;
+            s.color    = ks;
+            s.eta      = 1;
+            s.is_delta = true;
+            return true;
+        }
+        const float cos_o = absolute_cos(out_dir, N());
+        if (cos_o <= flt_eps)
+            return false;
+        const Vec3 m     = micro.sample(rnd, out_dir);
+        const float mpdf = micro.pdf(out_dir, m);
+        if (vec3_len2(m) <= flt_eps)
+            return false;
+        const Vec3 oH     = vec3_normalize(m);
+        const Vec3 H      = igm_signbit(vec3_dot(oH, out_dir)) ? vec3_neg(oH) : oH;
+        const Vec3 in_dir = vec3_reflect(out_dir, H);
+        if (absolute_cos(in_dir, N()) <= flt_eps)
+            return false;
+        const float jacob = 1 / (4 * absolute_cos(out_dir, H));
+        s.in_dir   = in_dir;
+        s.pdf      = mpdf * jacob;
+        s.color    = color_mulf(lobe_eval(1, in_dir, out_dir), safe_div(1, s.pdf));
+        s.eta      = 1;
+        s.is_delta = false;
+        return true;
+    }
+
+    // make_join_bsdf with eval_f = color_lerp (mix.art:5-22)
+    Color eval(Vec3 in_dir, Vec3 out_dir) const { return color_lerp(lobe_eval(0, in_dir, out_dir), lobe_eval(1, in_dir, out_dir), mix(out_dir)); }
+    float pdf(Vec3 in_dir, Vec3 out_dir) const { return lerpf(lobe_pdf(0, in_dir, out_dir), lobe_pdf(1, in_dir, out_dir), mix(out_dir)); }
+    // sample_mat (mix.art:28-38)
+    bool sample_lobe(int first, float t, Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        if (!lobe_sample(first, rnd, out_dir, s))
+            return false;
+        const int second = 1 - first;
+        const float p    = lerpf(s.pdf, lobe_pdf(second, s.in_dir, out_dir), t);
+        const Color c    = color_lerp(color_mulf(s.color, s.pdf), lobe_eval(second, s.in_dir, out_dir), t);
+        s.pdf            = p;
+        s.color          = color_mulf(c, safe_div(1, p));
+        return true;
+    }
+    bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const // mix.art:40-55
+    {
+        const float k = mix(out_dir);
+        if (rnd.next_f32() < 1 - k) {
+            if (sample_lobe(0, k, rnd, out_dir, s))
+                return true;
+            return sample_lobe(1, k, rnd, out_dir, s);
+        }
+        if (sample_lobe(1, 1 - k, rnd, out_dir, s))
+            return true;
+        return sample_lobe(0, 1 - k, rnd, out_dir, s);
+    }
+};
+
 struct Bsdf {
     const ig_material* mat;
     const SurfaceElement* surf;
     const igd_scene* scene = nullptr; // bitmap reflectance lookups
 
-    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->flags & IG_MAT_SMOOTH); }
+    // plastic: mat1.is_all_delta & mat2.is_all_delta with a diffuse mat1 (mix.art:63)
+    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)); }
 
     Color kd() const
     {
@@ -982,6 +1125,8 @@ struct Bsdf {
     {
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).eval(in_dir, out_dir);
+        if (mat->bsdf_type == IG_BSDF_PLASTIC)
+            return Plastic(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return color_mulf(kd(), positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -1007,6 +1152,8 @@ struct Bsdf {
     {
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).pdf(in_dir, out_dir);
+        if (mat->bsdf_type == IG_BSDF_PLASTIC)
+            return Plastic(*mat, *surf, kd()).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return cosine_hemisphere_pdf(positive_cos(in_dir, surf->local.col[2]));
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -1023,6 +1170,8 @@ struct Bsdf {
             s.is_delta = false;
             return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta);
         }
+        if (mat->bsdf_type == IG_BSDF_PLASTIC)
+            return Plastic(*mat, *surf, kd()).sample(rnd, out_dir, s);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
             const float u      = rnd.next_f32();
             const float v      = rnd.next_f32();

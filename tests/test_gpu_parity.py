@@ -792,3 +792,19 @@ def test_showcase_scene_principled_with_sky(gpu_device):
     from ignis_amd.tables import LoadedScene
     sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene_principled.json"), 120, 80)
     _compare_with_oracle(gpu_device, sc, 120, 80, 4, seed=1, iters=2)
+
+
+def test_plastic_bsdf_vs_oracle(gpu_device):
+    """Rough, anisotropic and smooth (mirror-coated) plastic, one with a checkerboard base, in the diamond box."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["textures"] = [{"type": "checkerboard", "name": "check", "scale_x": 3, "scale_y": 3, "color0": [0.8, 0.8, 0.8], "color1": [0.7, 0.2, 0.2]}]
+    s["bsdfs"] = [
+        {"type": "diffuse", "name": "mat-Light", "reflectance": [0, 0, 0]},
+        {"type": "plastic", "name": "mat-GrayWall", "diffuse_reflectance": "check", "roughness": 0.3},
+        {"type": "plastic", "name": "mat-ColoredWall", "diffuse_reflectance": [0.106039, 0.195687, 0.8], "int_ior": 1.7},
+        {"type": "roughplastic", "name": "mat-Diamond", "diffuse_reflectance": [0.9, 0.6, 0.2], "roughness": 0.15, "anisotropic": 0.6,
+         "specular_reflectance": [1, 0.9, 0.8]},
+    ]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=17, iters=2)

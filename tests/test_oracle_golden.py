@@ -677,3 +677,59 @@ def test_sun_light_analytic_answer():
     # inv_pdf * radiance = E * (2 pi (1 - cos a)) / (pi a^2) ~ E for small a
     # ... up to the float32 cancellation in 1 - cos(0.27 deg) (6e-8 / 1.08e-5 = 0.55 %), which the reference has as well
     assert mean == pytest.approx(2 * 0.8 / np.pi, rel=8e-3)
+
+
+# ---- plastic (src/artic/bsdf/plastic.art over mix.art): coherence of the restatement
+
+PLASTIC = [
+    {"type": "plastic", "name": "m0", "diffuse_reflectance": [0.8, 0.3, 0.2], "roughness": 0.25},
+    {"type": "plastic", "name": "m1", "diffuse_reflectance": [0.2, 0.5, 0.8], "int_ior": 1.8, "specular_reflectance": [0.9, 0.9, 0.7]},
+    {"type": "roughplastic", "name": "m2", "diffuse_reflectance": [0.6, 0.6, 0.6], "roughness": 0.4, "anisotropic": 0.5},
+]
+
+
+@pytest.fixture(scope="module")
+def plastic_scene():
+    s = flat_scene([{"type": "point", "name": "l", "position": [0, 0, 2], "intensity": [1, 1, 1]}])
+    s["bsdfs"] = PLASTIC
+    s["shapes"] = [{"type": "rectangle", "name": "R%d" % i} for i in range(3)]
+    s["entities"] = [{"name": "E%d" % i, "shape": "R%d" % i, "bsdf": "m%d" % i, "transform": [{"translate": [3 * i, 0, 0]}]} for i in range(3)]
+    return LoadedScene.from_string(json.dumps(s), SCENES, 16, 16)
+
+
+@pytest.mark.parametrize("mat", [0, 2])
+def test_rough_plastic_is_a_consistent_mixture(plastic_scene, mat):
+    """make_join_bsdf: the pdf integrates to one, pdf(sampled direction) is the sample's pdf, importance sampling and sphere
+    quadrature agree on the albedo, which stays below one."""
+    rng = np.random.default_rng(0)
+    n = 300000
+    z, ph = rng.uniform(-1, 1, n), rng.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(1 - z * z)
+    wi_u = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+    wo = _unit([0.5, 0.1, 0.85])
+    col, pdf = oracle.bsdf_eval(plastic_scene, mat, wo, wi_u)
+    assert pdf.astype(np.float64).mean() * 4 * np.pi == pytest.approx(1, abs=0.02)
+    wi, spdf, w, eta = oracle.bsdf_sample(plastic_scene, mat, wo, 100000, seed=7)
+    assert np.all(spdf > 0) and np.all(eta == 1)
+    c2, p2 = oracle.bsdf_eval(plastic_scene, mat, wo, wi)
+    np.testing.assert_allclose(p2, spdf, rtol=1e-4)
+    np.testing.assert_allclose(c2, w * spdf[:, None], rtol=1e-4, atol=1e-7)
+    quad = col.astype(np.float64).mean(0) * 4 * np.pi
+    np.testing.assert_allclose(w.astype(np.float64).mean(0), quad, rtol=0.02)
+    assert np.all(quad < 1)
+
+
+def test_smooth_plastic_mixes_a_mirror_with_the_diffuse_base(plastic_scene):
+    """Without roughness the coating is the mirror BSDF (conductor.art:2-10): samples are either the exact reflection
+    (weight from lerp(ks, 0, .) / lerp(1, diffuse pdf, .)) or diffuse directions; about the Fresnel share are mirror samples."""
+    wo = _unit([0.3, 0.2, 0.93])
+    wi, spdf, w, _ = oracle.bsdf_sample(plastic_scene, 1, wo, 50000, seed=9)
+    mirror = np.all(np.isclose(wi, wo * np.float32([-1, -1, 1]), atol=1e-6), axis=1)
+    eta = 1 / 1.8
+    cos_t = np.sqrt(1 - (1 - wo[2] ** 2) * eta * eta)
+    rs, rp = (eta * wo[2] - cos_t) / (eta * wo[2] + cos_t), (wo[2] - eta * cos_t) / (wo[2] + eta * cos_t)
+    fresnel = (rs * rs + rp * rp) / 2
+    assert mirror.mean() == pytest.approx(fresnel, abs=0.01)
+    assert np.all(w[~mirror] > 0) and np.isfinite(w).all()
+    m = plastic_scene.scene.materials[1]
+    assert m.bsdf_type == 4 and m.flags & 32 and m.p[3] == 1 and m.p[4] == np.float32(1.8)
