@@ -325,7 +325,7 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
         const float depth  = elem.getNumber("depth", 2.0f);
         const V3 origin    = elem.has("origin") ? getVector3(*elem.find("origin"), "origin") : V3(-width / 2, -height / 2, -depth / 2);
         return TriMesh::MakeBox(origin, V3(1, 0, 0) * width, V3(0, 1, 0) * height, V3(0, 0, 1) * depth);
-    } else if (type == "ply" || type == "obj" || type == "external") {
+    } else if (type == "ply" || type == "obj" || type == "mitsuba" || type == "external") {
         const std::string filename = elem.getString("filename");
         if (filename.empty())
             fail("Shape '" + name + "': No filename given");
@@ -337,8 +337,10 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
         // ExternalShape dispatch by extension (TriMeshProvider.cpp:41-75)
         if (ext == ".obj" || (type == "obj" && ext != ".ply"))
             return load_obj(path);
+        if (ext == ".mts" || ext == ".serialized" || type == "mitsuba")
+            return load_serialized(path, (size_t)std::max(0, elem.getInt("shape_index", 0)));
         if (ext != ".ply")
-            fail("Shape '" + name + "': only .ply and .obj external meshes are supported by this loader (got '" + filename + "')");
+            fail("Shape '" + name + "': only .ply, .obj and Mitsuba serialized external meshes are supported by this loader (got '" + filename + "')");
         return load_ply(path);
     }
     // procedural meshes (TriMeshProvider.cpp:48-103)

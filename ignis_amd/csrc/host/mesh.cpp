@@ -1,5 +1,8 @@
 #include "mesh.h"
 
+#include <zlib.h>
+
+#include <iterator>
 #include <map>
 #include <sstream>
 #include <tuple>
@@ -757,6 +760,154 @@ TriMesh load_obj(const std::string& path)
     if (!has_norms)
         mesh.computeVertexNormals();
     if (!has_tex)
+        mesh.makeTexCoordsNormalized();
+    return mesh;
+}
+
+// Mitsuba "serialized" meshes (.serialized / .mts; src/runtime/mesh/MtsSerializedFile.cpp:167-317): a file holds several
+// sub-meshes, each {u16 0x041C, u16 version (3 or 4)} followed by one zlib stream {u32 flags, [v4: UTF-8 name, 0],
+// u64 vertices, u64 triangles, positions, [normals], [texture coordinates], [colours], indices}; the file ends with the
+// offsets of the sub-meshes (u64 each in v4, u32 in v3) and their u32 count.
+TriMesh load_serialized(const std::string& path, size_t shape_index)
+{
+    auto bad = [&](const std::string& why) { return std::runtime_error("Serialized mesh '" + path + "': " + why); };
+    std::ifstream in(path, std::ios::in | std::ios::binary);
+    if (!in)
+        throw bad("cannot open file");
+    const std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    auto rd = [&](size_t off, void* dst, size_t n) {
+        if (off + n > file.size())
+            throw bad("truncated file");
+        std::memcpy(dst, &file[off], n);
+    };
+    uint16_t ident = 0, version = 0;
+    rd(0, &ident, 2);
+    rd(2, &version, 2);
+    if (ident != 0x041C)
+        throw bad("not a Mitsuba serialized file");
+    if (version < 3)
+        throw bad("insufficient version number " + std::to_string(version) + " < 3");
+    uint32_t count = 0;
+    rd(file.size() - 4, &count, 4);
+    if (shape_index >= count)
+        throw bad("shape index " + std::to_string(shape_index) + " out of range (" + std::to_string(count) + " shapes)");
+    const size_t entry = version >= 4 ? 8 : 4;
+    auto offsetOf      = [&](size_t i) {
+        uint64_t v = 0;
+        rd(file.size() - 4 - entry * (count - i), &v, entry);
+        return (size_t)v;
+    };
+    const size_t begin = offsetOf(shape_index);
+    const size_t end   = shape_index + 1 == count ? file.size() - 4 - entry * count : offsetOf(shape_index + 1);
+    if (begin + 4 > end || end > file.size())
+        throw bad("corrupt shape dictionary");
+
+    // inflate the sub-mesh in one go, growing the output as needed
+    std::vector<uint8_t> raw((end - begin) * 4 + 1024);
+    {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, 15) != Z_OK)
+            throw bad("zlib initialisation failed");
+        zs.next_in  = const_cast<Bytef*>(&file[begin + 4]);
+        zs.avail_in = (uInt)(end - begin - 4);
+        size_t have = 0;
+        int rc      = Z_OK;
+        while (rc != Z_STREAM_END) {
+            if (have == raw.size())
+                raw.resize(raw.size() * 2);
+            const size_t chunk = std::min<size_t>(raw.size() - have, 1u << 30);
+            zs.next_out        = &raw[have];
+            zs.avail_out       = (uInt)chunk;
+            rc                 = inflate(&zs, Z_NO_FLUSH);
+            have += chunk - zs.avail_out;
+            if (rc != Z_OK && rc != Z_STREAM_END) {
+                inflateEnd(&zs);
+                throw bad("corrupt compressed data");
+            }
+            if (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0)
+                break; // input exhausted without an end marker: use what there is
+        }
+        inflateEnd(&zs);
+        raw.resize(have);
+    }
+    size_t pos = 0;
+    auto take  = [&](void* dst, size_t n) {
+        if (pos + n > raw.size())
+            throw bad("attempting to read past the end of the stream");
+        std::memcpy(dst, &raw[pos], n);
+        pos += n;
+    };
+    enum : uint32_t { HasNormals = 0x0001, HasTexCoords = 0x0002, HasColors = 0x0008, Double = 0x2000 };
+    uint32_t flags = 0;
+    take(&flags, 4);
+    if (version >= 4) {
+        uint8_t ch = 1;
+        while (ch != 0)
+            take(&ch, 1); // shape name
+    }
+    uint64_t n_vertices = 0, n_triangles = 0;
+    take(&n_vertices, 8);
+    take(&n_triangles, 8);
+    if (n_vertices == 0 || n_triangles == 0)
+        throw bad("has no valid mesh");
+    auto number = [&]() {
+        if (flags & Double) {
+            double d;
+            take(&d, 8);
+            return (float)d;
+        }
+        float f;
+        take(&f, 4);
+        return f;
+    };
+    TriMesh mesh;
+    mesh.vertices.resize(n_vertices);
+    for (auto& v : mesh.vertices) {
+        const float x = number(), y = number(), z = number();
+        v             = V3(x, y, z);
+    }
+    if (flags & HasNormals) {
+        mesh.normals.resize(n_vertices);
+        for (auto& n : mesh.normals) {
+            const float x = number(), y = number(), z = number();
+            n             = V3(x, y, z);
+        }
+    }
+    if (flags & HasTexCoords) {
+        mesh.texcoords.resize(n_vertices);
+        for (auto& t : mesh.texcoords) {
+            const float u = number(), v = number();
+            t             = V2{ u, v };
+        }
+    }
+    if (flags & HasColors)
+        for (uint64_t i = 0; i < n_vertices * 3; ++i)
+            (void)number();
+    mesh.indices.resize(n_triangles * 4);
+    for (uint64_t f = 0; f < n_triangles; ++f) {
+        for (int k = 0; k < 3; ++k) {
+            uint64_t id = 0;
+            take(&id, n_vertices > 0xFFFFFFFFull ? 8 : 4);
+            if (id >= n_vertices)
+                throw bad("vertex index out of range");
+            mesh.indices[f * 4 + k] = (uint32_t)id;
+        }
+        mesh.indices[f * 4 + 3] = 0;
+    }
+    if (!(flags & HasNormals)) {
+        mesh.computeVertexNormals();
+    } else {
+        // fixNormals (TriMesh.cpp:17-32)
+        for (auto& n : mesh.normals) {
+            const float len2 = dot(n, n);
+            if (len2 <= FltEps || std::isnan(len2))
+                n = V3(0, 1, 0);
+            else
+                n = n * (1 / std::sqrt(len2));
+        }
+    }
+    if (!(flags & HasTexCoords))
         mesh.makeTexCoordsNormalized();
     return mesh;
 }

@@ -50,5 +50,6 @@ struct TriMesh {
 // Throws std::runtime_error with a message on malformed input.
 TriMesh load_ply(const std::string& path);
 TriMesh load_obj(const std::string& path); // src/runtime/mesh/ObjFile.cpp
+TriMesh load_serialized(const std::string& path, size_t shape_index); // src/runtime/mesh/MtsSerializedFile.cpp
 
 } // namespace igh

@@ -414,3 +414,51 @@ def test_externals_are_merged_and_overridden(tmp_path):
     assert sc.primbvh_bytes() == ref.primbvh_bytes()
     with pytest.raises(RuntimeError, match="Could not find path"):
         LoadedScene.from_string(json.dumps({"externals": [{"filename": "nope.json"}]}), str(tmp_path))
+
+
+def _write_serialized(path, meshes, version=4, double=False):
+    """Mitsuba serialized mesh writer for the tests (format as documented with Mitsuba 0.5 and read by
+    src/runtime/mesh/MtsSerializedFile.cpp): meshes = [(vertices, normals or None, texcoords or None, triangles)]."""
+    import struct
+    import zlib
+    import numpy as np
+    blob, offsets = b"", []
+    ft = "<f8" if double else "<f4"
+    for v, n, t, tris in meshes:
+        flags = (0x2000 if double else 0x1000) | (1 if n is not None else 0) | (2 if t is not None else 0)
+        body = struct.pack("<I", flags) + (b"mesh\0" if version >= 4 else b"") + struct.pack("<QQ", len(v), len(tris))
+        body += np.asarray(v, ft).tobytes()
+        if n is not None:
+            body += np.asarray(n, ft).tobytes()
+        if t is not None:
+            body += np.asarray(t, ft).tobytes()
+        body += np.asarray(tris, "<u4").tobytes()
+        offsets.append(len(blob))
+        blob += struct.pack("<HH", 0x041C, version) + zlib.compress(body)
+    blob += b"".join(struct.pack("<Q" if version >= 4 else "<I", o) for o in offsets) + struct.pack("<I", len(offsets))
+    open(path, "wb").write(blob)
+
+
+@pytest.mark.parametrize("version,double", [(4, False), (3, True)])
+def test_mitsuba_serialized_meshes(tmp_path, version, double):
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    quad = ([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], [[0, 0, 2]] * 4, [[0, 0], [1, 0], [1, 1], [0, 1]], [[0, 1, 2], [0, 2, 3]])
+    tri = ([[0, 0, 1], [2, 0, 1], [0, 2, 1]], None, None, [[0, 1, 2]])
+    path = str(tmp_path / "two.serialized")
+    _write_serialized(path, [quad, tri], version, double)
+    s = flat_scene()
+    s["shapes"] = [{"type": "mitsuba", "name": "A", "filename": path}, {"type": "external", "name": "B", "filename": path, "shape_index": 1}]
+    s["entities"] = [{"name": "EA", "shape": "A", "bsdf": "ground"}, {"name": "EB", "shape": "B", "bsdf": "ground"}]
+    sc = LoadedScene.from_string(json.dumps(s))
+    v, n, idx, uv = sc.shape_mesh(0)
+    assert v.tolist() == quad[0] and idx.tolist() == quad[3] and uv.tolist() == quad[2]
+    assert np.allclose(n, [0, 0, 1])                     # given normals are normalised (fixNormals)
+    v, n, idx, uv = sc.shape_mesh(1)
+    assert v.tolist() == tri[0] and idx.tolist() == [[0, 1, 2]] and np.allclose(n, [0, 0, 1])  # computed normals
+    s["shapes"][1]["shape_index"] = 2
+    with pytest.raises(RuntimeError, match="out of range"):
+        LoadedScene.from_string(json.dumps(s))
+    open(path, "wb").write(b"\x00" * 32)
+    with pytest.raises(RuntimeError, match="not a Mitsuba serialized file"):
+        LoadedScene.from_string(json.dumps(s))
