@@ -127,6 +127,12 @@ def main():
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
         fb_tensor = torch.as_tensor(_Wrap(dev.framebuffer_device_ptr(), (H, W, 3)), device=torch.device("cuda", local_rank))
 
+    if dist is not None:
+        # RCCL sets up its channels / kernels for a message size on first use: do that outside the timed region
+        scratch = torch.zeros_like(fb_tensor)
+        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        del scratch
     barrier()
     t0 = time.perf_counter()
     run(dev, args.steps)  # calls return at once or when a wavefront's rounds are done; tails + resolves overlap the next one
