@@ -1271,6 +1271,81 @@ struct TexturedEnv {
     IG_DEV Col emission(f3 ray_dir) const { return scale * image_lookup(sc, *tex, map_env_uv(local_dir(ray_dir))); }
 };
 
+// CIE sky models (light/cie.art:1-41) as function environments (light/env.art:24-105); directions in the light's Y-up frame
+struct CieSky {
+    int kind;
+    bool has_ground;
+    Col zenith, ground, scale;
+    float ground_brightness, zenith_brightness, c2;
+    f3 sun_dir;
+    m33 transform;
+
+    IG_DEV explicit CieSky(const ig_light& L)
+    {
+        kind              = L.pad[0];
+        has_ground        = L.pad[1] != 0;
+        zenith            = Col{ L.d[0], L.d[1], L.d[2] };
+        ground            = Col{ L.d[3], L.d[4], L.d[5] };
+        ground_brightness = L.d[6];
+        zenith_brightness = L.d[7];
+        c2                = L.d[8];
+        sun_dir           = f3{ L.d[9], L.d[10], L.d[11] };
+        scale             = Col{ L.d[12], L.d[13], L.d[14] };
+        transform.c0      = f3{ L.d[15], L.d[16], L.d[17] };
+        transform.c1      = f3{ L.d[18], L.d[19], L.d[20] };
+        transform.c2      = f3{ L.d[21], L.d[22], L.d[23] };
+    }
+    // cie_wmean (cie.art:1-7); pow(x, 10) as x^8 * x^2
+    IG_DEV static Col wmean(float cos_theta, Col c1, Col c2)
+    {
+        const float x  = cos_theta + 1.01f;
+        const float x2 = x * x;
+        const float x4 = x2 * x2;
+        const float a  = (x4 * x4) * x2;
+        const float f1 = a * a / (a * a + 1);
+        const float f2 = 1 / (a * a + 1);
+        return c1 * f1 + c2 * f2;
+    }
+    IG_DEV Col radiance(f3 dir) const
+    {
+        const float cos_theta = dir.y;
+        if (!has_ground && cos_theta < 0)
+            return Col{ 0, 0, 0 };
+        if (kind == IG_CIE_UNIFORM || kind == IG_CIE_CLOUDY) {
+            const bool cloudy = kind == IG_CIE_CLOUDY;
+            const float c1    = cloudy ? (1 + 2 * cos_theta) / 3 : 1.0f;
+            const float k2    = cloudy ? 0.777777777f : 1.0f;
+            return wmean(cos_theta, zenith * c1, ground * (ground_brightness * k2));
+        }
+        const float cos_gamma = dot3(dir, sun_dir);
+        const float gamma     = igm_acos(clampf(cos_gamma, -1, 1));
+        float c1;
+        if (kind == IG_CIE_CLEAR) {
+            c1 = (0.91f + 10 * igm_exp(-3 * gamma) + 0.45f * cos_gamma * cos_gamma) * (cos_theta >= 0.01f ? 1 - igm_exp(-0.32f / cos_theta) : 1.0f);
+        } else {
+            const float theta  = igm_acos(clampf(cos_theta, -1, 1));
+            const float stheta = igm_acos(clampf(sun_dir.y, -1, 1));
+            c1 = ((1.35f * igm_sin(5.631f - 3.59f * theta) + 3.12f) * igm_sin(4.396f - 2.6f * stheta) + 6.37f - theta) / 2.326f
+                 * igm_exp(gamma * (-0.563f) * ((2.629f - theta) * (1.562f - stheta) + 0.812f));
+        }
+        return scale * wmean(cos_theta, zenith * (zenith_brightness * c1), ground * (ground_brightness * c2));
+    }
+    IG_DEV Col emission(f3 ray_dir) const
+    {
+        const f3 local_dir = mul33(transform, ray_dir);
+        if (!has_ground)
+            return local_dir.y > kFltEps ? radiance(local_dir) : Col{ 0, 0, 0 };
+        return radiance(local_dir);
+    }
+    IG_DEV float pdf(f3 ray_dir) const
+    {
+        if (has_ground)
+            return 1 / (4 * kPi);
+        const f3 local_dir = mul33(transform, ray_dir);
+        return local_dir.y > kFltEps ? local_dir.y / kPi : 0.0f;
+    }
+};
+
 // square_to_concentric_disk (core/warp.art:2-22)
 IG_DEV f2 concentric_disk(float px, float py)
 {
@@ -1478,6 +1553,10 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 const TexturedEnv env(sc, L);
                 emit  = env.emission(in.dir);
                 pdf_s = env.pdf(in.dir);
+            } else if (FULL && L.type == IG_LIGHT_CIE) {
+                const CieSky sky(L);
+                emit  = sky.emission(in.dir);
+                pdf_s = sky.pdf(in.dir);
             } else if (FULL && L.type == IG_LIGHT_SUN) {
                 // make_sun_light.emission / pdf_direct (light/sun.art:31-45)
                 const bool hit = dot3(f3{ L.d[0], L.d[1], L.d[2] }, in.dir) >= L.d[3];
@@ -1593,6 +1672,28 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             Col intensity;
             env.sample_dir(rnd, ldir, intensity, pdf_value);
             lint     = intensity * (1 / pdf_value);
+            lpos     = surf.point + ldir * sc.scene_radius;
+            lcos     = 1.0f;
+            ldist    = sc.scene_radius;
+            infinite = true;
+        } else if (FULL && L.type == IG_LIGHT_CIE) {
+            // make_environment_light_function_{hemi,spherical}.sample_direct (light/env.art:31-37,79-93)
+            const CieSky sky(L);
+            const float ux = rnd.f32();
+            const float uy = rnd.f32();
+            if (!sky.has_ground) {
+                const float c   = safe_sqrt(uy); // sample_cosine_hemisphere (core/sampling.art:62-70)
+                const float sn  = safe_sqrt(1 - uy);
+                const float phi = 2 * kPi * ux;
+                const f3 dir    = switch_env_up(f3{ sn * igm_cos(phi), sn * igm_sin(phi), c });
+                pdf_value       = c / kPi;
+                lint            = sky.radiance(dir) * (1 / pdf_value);
+                ldir            = f3{ dot3(sky.transform.c0, dir), dot3(sky.transform.c1, dir), dot3(sky.transform.c2, dir) };
+            } else {
+                ldir      = square_to_sphere(ux, uy);
+                pdf_value = 1 / (4 * kPi);
+                lint      = sky.radiance(mul33(sky.transform, ldir)) * (1 / pdf_value);
+            }
             lpos     = surf.point + ldir * sc.scene_radius;
             lcos     = 1.0f;
             ldist    = sc.scene_radius;

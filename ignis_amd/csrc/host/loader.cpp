@@ -1410,6 +1410,82 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             out.type          = IG_LIGHT_ENV;
             out.d[0] = scale.x * radiance.x, out.d[1] = scale.y * radiance.y, out.d[2] = scale.z * radiance.z; // color_mul(scale, tex), env.art:163
             infinite.push_back(out);
+        } else if (type.rfind("cie", 0) == 0) {
+            // CIELight.cpp:6-107, LoaderLight.cpp:55-97
+            int kind;
+            if (type == "cie_uniform" || type == "cieuniform")
+                kind = IG_CIE_UNIFORM;
+            else if (type == "cie_cloudy" || type == "ciecloudy")
+                kind = IG_CIE_CLOUDY;
+            else if (type == "cie_clear" || type == "cieclear")
+                kind = IG_CIE_CLEAR;
+            else if (type == "cie_intermediate" || type == "cieintermediate")
+                kind = IG_CIE_INTERMEDIATE;
+            else
+                fail("Light '" + lname + "': type '" + type + "' is not supported by the HIP backend");
+            const V3 scale  = getColor(l, "scale", V3(1, 1, 1), lname);
+            const V3 zenith = getColor(l, "zenith", V3(1, 1, 1), lname);
+            const V3 ground = getColor(l, "ground", V3(1, 1, 1), lname);
+            const float gb  = getConstNumber(l, "ground_brightness", 0.2f, lname);
+            out.type   = IG_LIGHT_CIE;
+            out.pad[0] = kind;
+            out.pad[1] = l.getBool("has_ground", true) ? 1 : 0;
+            out.d[0] = zenith.x, out.d[1] = zenith.y, out.d[2] = zenith.z;
+            out.d[3] = ground.x, out.d[4] = ground.y, out.d[5] = ground.z;
+            out.d[6] = gb;
+            V3 sun(0, 0, 1); // LoaderUtils::getEA default direction
+            if (kind == IG_CIE_CLEAR || kind == IG_CIE_INTERMEDIATE) {
+                const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);
+                if (!key && (l.has("elevation") || l.has("azimuth") || l.has("year") || l.has("hour") || l.has("latitude")))
+                    fail("Light '" + lname + "': only an explicit 'direction' / 'sun_direction' is supported by this loader");
+                if (key) {
+                    sun            = getVector3(*l.find(key), key);
+                    const float dl = std::sqrt(dot(sun, sun));
+                    sun            = dl > 0 ? sun * (1 / dl) : V3(0, 0, 1);
+                }
+                // ElevationAzimuth::fromDirectionYUp / toDirectionYUp (skysun/ElevationAzimuth.h:15-30)
+                float elevation     = Pi / 2 - std::acos(sun.y);
+                float azimuth       = std::atan2(-sun.x, -sun.z);
+                if (azimuth < 0)
+                    azimuth += 2 * Pi;
+                const V3 sun_dir(-std::cos(elevation) * std::sin(azimuth), std::sin(elevation), -std::cos(elevation) * std::cos(azimuth));
+                if (elevation > 87 * Deg2Rad)
+                    elevation = 87 * Deg2Rad;
+                const bool clear      = kind == IG_CIE_CLEAR;
+                const float turbidity = l.getNumber("turbidity", 2.45f);
+                const float SkyIllum  = 203;
+                float zb              = (1.376f * turbidity - 1.81f) * std::tan(elevation) + 0.38f;
+                if (!clear)
+                    zb = (zb + 8.6f * sun_dir.y + 0.123f) / 2;
+                zb = std::max(0.0f, zb * 1000 / SkyIllum);
+                float factor;
+                if (clear)
+                    factor = 0.274f * (0.91f + 10 * std::exp(-3 * (Pi / 2 - elevation)) + 0.45f * sun_dir.y * sun_dir.y);
+                else
+                    factor = (2.739f + 0.9891f * std::sin(0.3119f + 2.6f * elevation)) * std::exp(-(Pi / 2 - elevation) * (0.4441f + 1.48f * elevation));
+                // skylight_normalization_factor (CIELight.cpp:25-36)
+                const float cl[5] = { 2.766521f, 0.547665f, -0.369832f, 0.009237f, 0.059229f };
+                const float im[5] = { 3.5556f, -2.7152f, -1.3081f, 1.0660f, 0.60227f };
+                const float* arr  = clear ? cl : im;
+                const float x     = (elevation - Pi / 4) / (Pi / 4);
+                float nf          = arr[4];
+                for (int i = 3; i >= 0; --i)
+                    nf = nf * x + arr[i];
+                const float norm_factor     = nf * (1 / Pi) / factor;
+                const float SunIllum        = 208;
+                const float solarbrightness = 1.5e9f / SunIllum * (1.147f - 0.147f / std::max(sun_dir.y, 0.16f));
+                const float additive        = 6e-5f * (1 / Pi) * solarbrightness * sun_dir.y * (clear ? 1.0f : 0.15f);
+                out.d[7] = zb / factor;
+                out.d[8] = zb * norm_factor + additive;
+                sun      = sun_dir;
+            }
+            out.d[9] = sun.x, out.d[10] = sun.y, out.d[11] = sun.z;
+            out.d[12] = scale.x, out.d[13] = scale.y, out.d[14] = scale.z;
+            const M3 T = l.has("transform") ? inverse(transpose(getTransform(l).L)) : M3{};
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r)
+                    out.d[15 + c * 3 + r] = T.m[r][c];
+            infinite.push_back(out);
         } else if (type == "sun") {
             // SunLight.cpp:11-57, light/sun.art:1-48: an infinite cone light; direction = from the scene towards the sun
             const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);

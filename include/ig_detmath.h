@@ -214,4 +214,27 @@ IGM_FN float igm_atan2(float y, float x)
     return igm_copysign(r, y);
 }
 
+/* ---- exp (Cephes expf): x = n ln2 + r, |r| <= ln2 / 2, degree-5 polynomial, scaling by 2^n through the exponent ---- */
+IGM_FN float igm_exp(float x)
+{
+    if (x > 88.72283905206835f)
+        return igm_float(0x7F800000u); /* +inf */
+    if (x < -87.33654475055310898657f)
+        return 0.0f;
+    const float fn = igm_floor(igm_fma(x, 1.44269504088896341f, 0.5f));
+    float r        = igm_fma(-fn, 0.693359375f, x);
+    r              = igm_fma(-fn, -2.12194440e-4f, r);
+    const float z  = r * r;
+    float p        = igm_fma(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p              = igm_fma(p, r, 8.3334519073e-3f);
+    p              = igm_fma(p, r, 4.1665795894e-2f);
+    p              = igm_fma(p, r, 1.6666665459e-1f);
+    p              = igm_fma(p, r, 5.0000001201e-1f);
+    const float e  = igm_fma(p, z, r) + 1.0f;
+    const int n    = (int)fn; /* -126 <= n <= 128 here */
+    /* 2^n in two factors so that n = 128 and the subnormal end stay representable */
+    const int h    = n / 2;
+    return (e * igm_float((uint32_t)(h + 127) << 23)) * igm_float((uint32_t)(n - h + 127) << 23);
+}
+
 #endif /* IG_DETMATH_H */

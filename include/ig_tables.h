@@ -163,6 +163,12 @@ enum ig_light_type {
     /* make_sun_light (src/artic/light/sun.art:8-48, SunLight.cpp:32-57; infinite, not delta): d[0..2] direction
      * (scene to light, normalised), d[3] cos of the half angle, d[4..6] radiance */
     IG_LIGHT_SUN = 6,
+    /* CIE sky models as function environments (src/artic/light/cie.art:1-41 over env.art:24-105, CIELight.cpp:38-107):
+     * pad[0] = enum ig_cie_kind, pad[1] = has_ground; d[0..2] zenith, d[3..5] ground, d[6] ground_brightness,
+     * d[7] zenith brightness / factor (sunny kinds), d[8] c2 (sunny kinds), d[9..11] sun direction, d[12..14] scale,
+     * d[15..23] the 3x3 "_transform" column by column. Sampled over the sphere, or the cosine-weighted upper
+     * hemisphere when there is no ground. */
+    IG_LIGHT_CIE = 7,
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
@@ -180,6 +186,8 @@ typedef struct ig_light {
     int32_t pad[2];
     float d[24];
 } ig_light;
+
+enum ig_cie_kind { IG_CIE_UNIFORM = 0, IG_CIE_CLOUDY = 1, IG_CIE_CLEAR = 2, IG_CIE_INTERMEDIATE = 3 };
 
 enum ig_light_selector {
     IG_SELECTOR_UNIFORM   = 0, /* src/artic/light/light_selector.art:26-46 */

@@ -173,7 +173,7 @@ def detmath(which, x):
         lib().oracle_detmath(4, C.c_int64(x.shape[0]), _fp(x), _fp(y))
         return y
     y = np.empty_like(x)
-    lib().oracle_detmath({"sin": 0, "cos": 1, "acos": 2, "asin": 3}[which], x.size, _fp(x), _fp(y))
+    lib().oracle_detmath({"sin": 0, "cos": 1, "acos": 2, "asin": 3, "exp": 5}[which], x.size, _fp(x), _fp(y))
     return y
 
 

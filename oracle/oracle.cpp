@@ -627,6 +627,7 @@ void oracle_detmath(int which, int64_t n, const float* x, float* y)
         case 1: y[i] = igm_cos(x[i]); break;
         case 2: y[i] = igm_acos(x[i]); break;
         case 4: y[i] = igm_atan2(x[2 * i], x[2 * i + 1]); break; // x holds (y, x) pairs
+        case 5: y[i] = igm_exp(x[i]); break;
         default: y[i] = igm_asin(x[i]); break;
         }
     }

@@ -1645,6 +1645,112 @@ static inline DirectLightSample sample_direct_env_textured(const igd_scene& sc, 
     return s;
 }
 
+// ---- light/cie.art:1-41: CIE sky radiance functions (direction in the light's Y-up frame)
+struct CieSky {
+    int kind;
+    bool has_ground;
+    Color zenith, ground, scale;
+    float ground_brightness, zenith_brightness, c2;
+    Vec3 sun_dir;
+    Mat3x3 transform;
+
+    explicit CieSky(const ig_light& l)
+    {
+        kind              = l.pad[0];
+        has_ground        = l.pad[1] != 0;
+        zenith            = Color{ l.d[0], l.d[1], l.d[2] };
+        ground            = Color{ l.d[3], l.d[4], l.d[5] };
+        ground_brightness = l.d[6];
+        zenith_brightness = l.d[7];
+        c2                = l.d[8];
+        sun_dir           = make_vec3(l.d[9], l.d[10], l.d[11]);
+        scale             = Color{ l.d[12], l.d[13], l.d[14] };
+        for (int c = 0; c < 3; ++c)
+            transform.col[c] = make_vec3(l.d[15 + c * 3], l.d[16 + c * 3], l.d[17 + c * 3]);
+    }
+    // cie_wmean (cie.art:1-7); pow(x, 10) as x^8 * x^2 (exact products instead of libm powf)
+    static Color wmean(float cos_theta, Color c1, Color c2)
+    {
+        const float x  = cos_theta + 1.01f;
+        const float x2 = x * x;
+        const float x4 = x2 * x2;
+        const float a  = (x4 * x4) * x2;
+        const float f1 = a * a / (a * a + 1);
+        const float f2 = 1 / (a * a + 1);
+        return color_add(color_mulf(c1, f1), color_mulf(c2, f2));
+    }
+    Color radiance(Vec3 dir) const
+    {
+        const float cos_theta = dir.y;
+        if (!has_ground && cos_theta < 0)
+            return Color{ 0, 0, 0 };
+        if (kind == IG_CIE_UNIFORM || kind == IG_CIE_CLOUDY) {
+            // make_cie_sky_light (cie.art:13-21)
+            const bool cloudy = kind == IG_CIE_CLOUDY;
+            const float c1    = cloudy ? (1 + 2 * cos_theta) / 3 : 1.0f;
+            const float k2    = cloudy ? 0.777777777f : 1.0f;
+            return wmean(cos_theta, color_mulf(zenith, c1), color_mulf(ground, ground_brightness * k2));
+        }
+        // make_cie_sunny_light (cie.art:24-41)
+        const float cos_gamma = vec3_dot(dir, sun_dir);
+        const float gamma     = igm_acos(clampf(cos_gamma, -1, 1));
+        float c1;
+        if (kind == IG_CIE_CLEAR) {
+            c1 = (0.91f + 10 * igm_exp(-3 * gamma) + 0.45f * cos_gamma * cos_gamma) * (cos_theta >= 0.01f ? 1 - igm_exp(-0.32f / cos_theta) : 1.0f);
+        } else {
+            const float theta  = igm_acos(clampf(cos_theta, -1, 1));
+            const float stheta = igm_acos(clampf(sun_dir.y, -1, 1));
+            c1 = ((1.35f * igm_sin(5.631f - 3.59f * theta) + 3.12f) * igm_sin(4.396f - 2.6f * stheta) + 6.37f - theta) / 2.326f
+                 * igm_exp(gamma * (-0.563f) * ((2.629f - theta) * (1.562f - stheta) + 0.812f));
+        }
+        return color_mul(scale, wmean(cos_theta, color_mulf(zenith, zenith_brightness * c1), color_mulf(ground, ground_brightness * c2)));
+    }
+    // emission / pdf_direct of make_environment_light_function_{hemi,spherical} (env.art:24-105); half = !has_ground
+    Color emission(Vec3 ray_dir) const
+    {
+        const Vec3 local_dir = mat3x3_mul(transform, ray_dir);
+        if (!has_ground)
+            return local_dir.y > flt_eps ? radiance(local_dir) : Color{ 0, 0, 0 };
+        return radiance(local_dir);
+    }
+    float pdf(Vec3 ray_dir) const
+    {
+        if (has_ground)
+            return 1 / (4 * flt_pi);
+        const Vec3 local_dir = mat3x3_mul(transform, ray_dir);
+        return local_dir.y > flt_eps ? cosine_hemisphere_pdf(local_dir.y) : 0.0f;
+    }
+};
+
+static inline DirectLightSample sample_direct_cie(const igd_scene& sc, const ig_light& l, Rng& rnd, const SurfaceElement& from_surf)
+{
+    const CieSky sky(l);
+    const float u = rnd.next_f32();
+    const float v = rnd.next_f32();
+    DirectLightSample s;
+    if (!sky.has_ground) {
+        // hemi: cosine sample around Y, radiance looked up with the untransformed direction (env.art:31-37)
+        const DirSample ds = sample_cosine_hemisphere(u, v);
+        const Vec3 dir     = switch_env_up(ds.dir);
+        s.intensity        = color_mulf(sky.radiance(dir), 1 / ds.pdf);
+        s.dir              = make_vec3(vec3_dot(sky.transform.col[0], dir), vec3_dot(sky.transform.col[1], dir), vec3_dot(sky.transform.col[2], dir));
+        s.pdf_value        = ds.pdf;
+    } else {
+        // spherical (env.art:79-93)
+        const Vec3 dir  = equal_area_square_to_sphere(u, v);
+        const float pdf = 1 / (4 * flt_pi);
+        s.intensity     = color_mulf(sky.radiance(mat3x3_mul(sky.transform, dir)), 1 / pdf);
+        s.dir           = dir;
+        s.pdf_value     = pdf;
+    }
+    s.pos          = vec3_add(from_surf.point, vec3_mulf(s.dir, sc.scene_radius));
+    s.pdf_is_area  = false;
+    s.pdf_is_delta = false;
+    s.cos          = 1.0f;
+    s.dist         = sc.scene_radius;
+    return s;
+}
+
 // ---- light/sun.art:8-48 (make_sun_light, not handled as delta), core/sampling.art:106-116
 struct SunLight {
     Vec3 dir; // scene to light
@@ -1885,6 +1991,10 @@ struct PathTracer {
             ls       = sample_direct_sun(light, rnd);
             infinite = true;
             break;
+        case IG_LIGHT_CIE:
+            ls       = sample_direct_cie(sc, light, rnd, surf);
+            infinite = true;
+            break;
         default:
             ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);
             infinite = true;
@@ -1947,7 +2057,7 @@ struct PathTracer {
         Color color   = Color{ 0, 0, 0 };
         for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
             const ig_light& light = sc.lights[i];
-            if (light.type != IG_LIGHT_ENV && light.type != IG_LIGHT_ENV_TEXTURED && light.type != IG_LIGHT_SUN)
+            if (light.type != IG_LIGHT_ENV && light.type != IG_LIGHT_ENV_TEXTURED && light.type != IG_LIGHT_SUN && light.type != IG_LIGHT_CIE)
                 continue; // delta lights
             ++inflights;
             Color emit;
@@ -1956,6 +2066,10 @@ struct PathTracer {
                 const TexturedEnv env(sc, light);
                 emit  = env.emission(ray.dir);
                 pdf_s = env.pdf(ray.dir);
+            } else if (light.type == IG_LIGHT_CIE) {
+                const CieSky sky(light);
+                emit  = sky.emission(ray.dir);
+                pdf_s = sky.pdf(ray.dir);
             } else if (light.type == IG_LIGHT_SUN) {
                 const SunLight sun(light); // sun.art:31-45
                 const bool hit = sun.hits(ray.dir);

@@ -808,3 +808,18 @@ def test_plastic_bsdf_vs_oracle(gpu_device):
     ]
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=17, iters=2)
+
+
+@pytest.mark.parametrize("kind,extra", [
+    ("cie_uniform", {}), ("ciecloudy", {"has_ground": False, "transform": [{"rotate": [0, 0, 25]}]}),
+    ("cie_clear", {"direction": [0.3, 0.7, -0.5], "turbidity": 3.0, "scale": [1, 0.9, 0.8]}),
+    ("cieintermediate", {"sun_direction": [-0.4, 0.5, 0.3], "has_ground": False}),
+])
+def test_cie_sky_lights_vs_oracle(gpu_device, kind, extra):
+    """The four CIE sky models as function environments, sphere- or hemisphere-sampled, next to the area light."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["lights"] = s["lights"] + [dict({"type": kind, "name": "sky", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2]}, **extra)]
+    s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 64)
+    _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=23, iters=2)

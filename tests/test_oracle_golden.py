@@ -733,3 +733,55 @@ def test_smooth_plastic_mixes_a_mirror_with_the_diffuse_base(plastic_scene):
     assert np.all(w[~mirror] > 0) and np.isfinite(w).all()
     m = plastic_scene.scene.materials[1]
     assert m.bsdf_type == 4 and m.flags & 32 and m.p[3] == 1 and m.p[4] == np.float32(1.8)
+
+
+def test_detmath_exp_and_atan2_accuracy():
+    x = np.linspace(-87, 88.7, 400001).astype(np.float32)
+    y = oracle.detmath("exp", x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert (np.abs(y - ref) / ref).max() <= 1.5e-7
+    assert oracle.detmath("exp", np.float32([0, -200, 200])).tolist() == [1.0, 0.0, np.inf]
+    p = np.random.default_rng(1).normal(size=(200000, 2)).astype(np.float32)
+    p[:6] = [[0, 1], [0, -1], [1, 0], [-1, 0], [0, 0], [-1, -1]]
+    got = oracle.detmath("atan2", p)
+    assert np.abs(got - np.arctan2(p[:, 0].astype(np.float64), p[:, 1].astype(np.float64))).max() <= 4e-7
+
+
+# ---- CIE sky lights (src/artic/light/cie.art, src/runtime/light/CIELight.cpp)
+
+def test_cie_uniform_sky_white_furnace():
+    """cie_wmean blends zenith and ground * ground_brightness with weights that sum to one: with equal inputs the sky is a
+    constant environment and the white plane of the integrator scene returns exactly that radiance, with or without ground
+    (cosine-hemisphere or sphere sampling)."""
+    for has_ground, transform in ((True, None), (False, [{"rotate": [180, 0, 0]}])):
+        # the plane faces -z; without ground only the upper (+y) half of the sky shines: rotate it to cover the plane's side
+        light = {"type": "cie_uniform", "name": "sky", "zenith": [0.6, 0.6, 0.6], "ground": [3, 3, 3], "ground_brightness": 0.2, "has_ground": has_ground}
+        if transform:
+            light["transform"] = [{"rotate": [90, 0, 0]}]
+        s = flat_scene([light])
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 32, 32)
+        assert sc.scene.lights[0].type == 7 and sc.scene.lights[0].pad[1] == int(has_ground)
+        fbs = [oracle.render(sc, 16, 32, 32, iteration=i, seed=3)[0] for i in range(2)]
+        mean = float(np.mean(fbs))
+        if has_ground:
+            assert mean == pytest.approx(0.6, rel=2e-3)
+        else:
+            assert 0.25 < mean <= 0.6 * 1.002  # half a sky: between nothing and the full furnace, never more
+
+
+def test_cie_clear_sky_constants():
+    """CIELight.cpp:66-96 for a sun 40 degrees up, turbidity 2.45: the two host-side constants against a NumPy evaluation of
+    the same formulas; the brightest direction of the clear sky is towards the sun."""
+    el = np.radians(40.0)
+    sun = [0.0, float(np.sin(el)), float(-np.cos(el))]
+    s = flat_scene([{"type": "cie_clear", "name": "sky", "direction": sun}])
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 8, 8)
+    d = sc.scene.lights[0].d
+    zb = max(0.0, ((1.376 * 2.45 - 1.81) * np.tan(el) + 0.38) * 1000 / 203)
+    factor = 0.274 * (0.91 + 10 * np.exp(-3 * (np.pi / 2 - el)) + 0.45 * np.sin(el) ** 2)
+    x = (el - np.pi / 4) / (np.pi / 4)
+    nf = np.polyval([0.059229, 0.009237, -0.369832, 0.547665, 2.766521], x)
+    solar = 1.5e9 / 208 * (1.147 - 0.147 / max(np.sin(el), 0.16))
+    c2 = zb * nf / np.pi / factor + 6e-5 / np.pi * solar * np.sin(el)
+    assert d[7] == pytest.approx(zb / factor, rel=1e-5) and d[8] == pytest.approx(c2, rel=1e-5)
+    assert list(d[9:12]) == pytest.approx(sun, abs=1e-6)
