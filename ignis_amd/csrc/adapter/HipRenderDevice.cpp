@@ -37,6 +37,9 @@ public:
         setup.acquire_stats  = s.AcquireStats ? 1 : 0;
         setup.debug_trace    = s.DebugTrace ? 1 : 0;
         setup.is_interactive = s.IsInteractive ? 1 : 0;
+        // "Normals" / "Albedo" are asked for by name only when the runtime's denoiser is on; keeping them costs two film buffers and
+        // one extra camera-ray traversal at iteration 0
+        setup.info_aovs      = 1;
         mDev                 = igd_create(&setup);
         if (!mDev) {
             IG_LOG(L_FATAL) << "ig_device_hip: " << igd_last_error() << std::endl;

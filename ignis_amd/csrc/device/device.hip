@@ -30,6 +30,7 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipSt
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
+void launch_info(const InfoArgs& args, int grid_blocks, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
 void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
@@ -113,6 +114,12 @@ struct igd_device {
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
     DevBuf<float> cdf_data;
+    // info-buffer AOVs (igd_setup.info_aovs): [0] "Normals", [1] "Albedo", film-sized like the colour buffer
+    DevBuf<float> aov[2];
+    std::vector<float> aov_host[2];
+    bool aov_host_dirty[2] = { true, true };
+    DevBuf<float> info_tmp[2]; // per-sample values of one chunk (float4 each)
+    DevBuf<QueueState> info_qs;
     uint32_t tail_lanes = 0; // lanes of one tail grid (its share of the deep-stack columns)
     DevBuf<uint2> deep_stack; // kDeepStack entries for every lane that can be resident (traversal grid + tail grid)
     DevBuf<uint32_t> light_codes;
@@ -514,6 +521,14 @@ void resizeFb(igd_device* d, int w, int h)
     d->fb_h = h;
     d->fb_host.assign((size_t)w * h * 3, 0.0f);
     d->fb_host_dirty = true;
+    if (d->setup.info_aovs)
+        for (int k = 0; k < 2; ++k) {
+            d->aov[k].release();
+            d->aov[k].alloc((size_t)w * h * 3);
+            HIP_CHECK(hipMemset(d->aov[k].ptr, 0, (size_t)w * h * 3 * sizeof(float)));
+            d->aov_host[k].assign((size_t)w * h * 3, 0.0f);
+            d->aov_host_dirty[k] = true;
+        }
 }
 
 // Polls the queue sizes of the chunk in flight on the main stream (64 bytes, pinned).
@@ -725,6 +740,70 @@ void render(igd_device* d, const igd_render_settings* rs)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
     if (per_it > 0 && chunk_rays >= per_it)
         chunk_rays = (chunk_rays / per_it) * per_it;
+
+    if (d->setup.info_aovs && !list_mode && rs->iteration == 0) {
+        // wrap_infobuffer_renderer (technique/internal/infobuffer.art:4-30): normals and albedo of the camera rays' first hits of
+        // iteration 0. Run as a pass of its own in front of the wavefront — the same camera rays (same RNG), closest-hit
+        // traversal, k_info, per-pixel sums in sample order — so the shading kernels do not carry it.
+        const int64_t info_chunk = ((int64_t)d->capacity / rs->spi) * rs->spi;
+        d->info_qs.alloc(1);
+        d->info_tmp[0].alloc((size_t)std::min<int64_t>(info_chunk, per_it) * 4);
+        d->info_tmp[1].alloc((size_t)std::min<int64_t>(info_chunk, per_it) * 4);
+        QueueState* iq = d->info_qs.ptr;
+        for (int64_t first = 0; first < per_it; first += info_chunk) {
+            const uint32_t n = (uint32_t)std::min<int64_t>(info_chunk, per_it - first);
+            HIP_CHECK(hipMemsetAsync(iq, 0, sizeof(QueueState), st));
+            GenerateArgs ga{};
+            ga.out            = d->primaryCols(0);
+            ga.out_count      = &iq->q[0].primary;
+            ga.qs             = iq;
+            ga.cam            = d->camera;
+            ga.sx = sx, ga.sy = sy;
+            ga.width = rs->width, ga.height = rs->height, ga.spi = rs->spi;
+            ga.iteration = 0, ga.frame = rs->frame, ga.seed = rs->user_seed;
+            ga.row_offset = row_offset, ga.row_stride = row_stride;
+            ga.first_local_id     = first;
+            ga.rays_per_iteration = (int32_t)std::max<int64_t>(per_it, 1);
+            ga.n                  = n;
+            launch_generate(ga, st);
+            const PrimaryCols in = d->primaryCols(0);
+            TraverseArgs ta{};
+            ta.scene = d->dscene;
+            ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
+            ta.count        = &iq->q[0].primary;
+            ta.work_counter = &iq->work_counter[0];
+            ta.index_list   = d->deep_rays.ptr;
+            ta.index_count  = &iq->deep_count;
+            ta.qs           = iq;
+            ta.hit = in.hit, ta.hit_v = in.hit_v;
+            launch_traverse(ta, false, false, d->traverseGrid(), &iq->work_counter[1], st);
+            InfoArgs ia{};
+            ia.scene   = d->dscene;
+            ia.in      = in;
+            ia.count   = &iq->q[0].primary;
+            ia.normals = reinterpret_cast<float4*>(d->info_tmp[0].ptr);
+            ia.albedo  = reinterpret_cast<float4*>(d->info_tmp[1].ptr);
+            ia.id_base = first;
+            ia.inv_spi = inv;
+            launch_info(ia, d->num_cus * 8, st);
+            for (int k = 0; k < 2; ++k) {
+                ResolveArgs ra{};
+                ra.accum             = reinterpret_cast<const float4*>(d->info_tmp[k].ptr);
+                ra.fb                = d->aov[k].ptr;
+                ra.width             = rs->width;
+                ra.spi               = rs->spi;
+                ra.row_offset        = row_offset;
+                ra.row_stride        = row_stride;
+                ra.first_local_pixel = first / rs->spi;
+                ra.pixels            = n / (uint32_t)rs->spi;
+                ra.local_pixels      = (uint32_t)(per_it / rs->spi);
+                ra.iterations        = 1;
+                launch_resolve(ra, st);
+                d->aov_host_dirty[k] = true;
+            }
+        }
+        // the camera-ray counter of this extra pass is not part of the render's statistics (info_qs is never collected)
+    }
 
     d->fb_host_dirty = true;
     for (int64_t first = 0; first < total; first += chunk_rays) {
@@ -1115,6 +1194,26 @@ int guarded(const char* what, const std::function<void()>& fn)
 
 bool isColorName(const char* name) { return !name || !*name || std::strcmp(name, "Color") == 0 || std::strcmp(name, "Default") == 0; }
 
+// The film-sized buffer a framebuffer accessor addresses by name: the colour buffer or, with igd_setup.info_aovs, "Normals" /
+// "Albedo" (Device.cpp:1385-1451 looks AOVs up by name and logs unknown ones).
+struct FilmBuffer {
+    DevBuf<float>* dev        = nullptr;
+    std::vector<float>* host  = nullptr;
+    bool* dirty               = nullptr;
+};
+FilmBuffer filmBuffer(igd_device* d, const char* name)
+{
+    if (isColorName(name))
+        return FilmBuffer{ &d->fb, &d->fb_host, &d->fb_host_dirty };
+    if (d->setup.info_aovs) {
+        if (std::strcmp(name, "Normals") == 0)
+            return FilmBuffer{ &d->aov[0], &d->aov_host[0], &d->aov_host_dirty[0] };
+        if (std::strcmp(name, "Albedo") == 0)
+            return FilmBuffer{ &d->aov[1], &d->aov_host[1], &d->aov_host_dirty[1] };
+    }
+    throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
+}
+
 } // namespace
 
 extern "C" {
@@ -1250,6 +1349,11 @@ int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
         resizeFb(dev, width, height);
         HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float)));
         dev->fb_host_dirty = true;
+        for (int k = 0; k < 2; ++k)
+            if (dev->aov[k].ptr) {
+                HIP_CHECK(hipMemset(dev->aov[k].ptr, 0, (size_t)width * height * 3 * sizeof(float)));
+                dev->aov_host_dirty[k] = true;
+            }
     });
 }
 
@@ -1291,6 +1395,9 @@ int32_t igd_release_all(igd_device* dev)
         dev->textures.release();
         dev->texture_data.release();
         dev->cdf_data.release();
+        dev->info_tmp[0].release();
+        dev->info_tmp[1].release();
+        dev->info_qs.release();
         dev->has_scene = false;
     });
 }
@@ -1305,35 +1412,33 @@ const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t syn
     guarded("igd_framebuffer_host", [&] {
         if (!dev)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
-        if (!isColorName(name))
-            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" }; // Device.cpp:1391-1395
+        const FilmBuffer b = filmBuffer(dev, name); // unknown AOV -> error (Device.cpp:1391-1395)
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
-        if (!dev->fb.ptr)
+        if (!b.dev->ptr)
             throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (render or resize first)" };
-        if (sync && dev->fb_host_dirty) {
-            HIP_CHECK(hipMemcpy(dev->fb_host.data(), dev->fb.ptr, dev->fb_host.size() * sizeof(float), hipMemcpyDeviceToHost));
-            dev->fb_host_dirty = false;
+        if (sync && *b.dirty) {
+            HIP_CHECK(hipMemcpy(b.host->data(), b.dev->ptr, b.host->size() * sizeof(float), hipMemcpyDeviceToHost));
+            *b.dirty = false;
         }
-        result = dev->fb_host.data();
+        result = b.host->data();
     });
     return result;
 }
 
 float* igd_framebuffer_device(igd_device* dev, const char* name)
 {
-    g_error.clear();
-    if (!dev || !isColorName(name)) {
-        g_error = "igd_framebuffer_device: unknown AOV or NULL device";
-        return nullptr;
-    }
+    float* result = nullptr;
     // the pointer is about to be read by other device work: make the framebuffer final first
-    if (guarded("igd_framebuffer_device", [&] {
-            HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
-            finish(dev);
-        }) != IGD_OK)
-        return nullptr;
-    return dev->fb.ptr;
+    guarded("igd_framebuffer_device", [&] {
+        if (!dev)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
+        const FilmBuffer b = filmBuffer(dev, name);
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
+        result = b.dev->ptr;
+    });
+    return result;
 }
 
 int32_t igd_clear_framebuffer(igd_device* dev, const char* name)
@@ -1341,14 +1446,13 @@ int32_t igd_clear_framebuffer(igd_device* dev, const char* name)
     return guarded("igd_clear_framebuffer", [&] {
         if (!dev)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
-        if (!isColorName(name))
-            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
+        const FilmBuffer b = filmBuffer(dev, name);
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
-        if (dev->fb.ptr)
-            HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float)));
-        std::fill(dev->fb_host.begin(), dev->fb_host.end(), 0.0f);
-        dev->fb_host_dirty = true;
+        if (b.dev->ptr)
+            HIP_CHECK(hipMemset(b.dev->ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float)));
+        std::fill(b.host->begin(), b.host->end(), 0.0f);
+        *b.dirty = true;
     });
 }
 
@@ -1357,14 +1461,13 @@ int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const 
     return guarded("igd_sync_framebuffer_to_device", [&] {
         if (!dev || !data)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
-        if (!isColorName(name))
-            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
+        const FilmBuffer b = filmBuffer(dev, name);
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
-        if (!dev->fb.ptr)
+        if (!b.dev->ptr)
             throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet (resize first)" };
-        HIP_CHECK(hipMemcpy(dev->fb.ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
-        dev->fb_host_dirty = true;
+        HIP_CHECK(hipMemcpy(b.dev->ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
+        *b.dirty = true;
     });
 }
 

@@ -184,4 +184,16 @@ struct ResolveArgs {
     uint32_t iterations;       // > 1: accum holds that many whole iterations, one thread sums a pixel's iterations in order
 };
 
+// k_info: the "Normals" / "Albedo" AOVs of the info-buffer wrapper (technique/internal/infobuffer.art): per-sample values of the
+// camera rays' first hits, summed per pixel by k_resolve
+struct InfoArgs {
+    DevScene scene;
+    PrimaryCols in; // camera rays of one chunk of iteration 0, traversed
+    const uint32_t* count;
+    float4* normals; // [chunk samples]
+    float4* albedo;
+    int64_t id_base; // local ray id of sample 0 of the chunk
+    float inv_spi;
+};
+
 } // namespace igdev

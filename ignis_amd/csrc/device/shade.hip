@@ -322,6 +322,40 @@ __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
     }
 }
 
+// ---------------------------------------------------------------- k_info
+
+// wrap_infobuffer_renderer.on_hit (technique/internal/infobuffer.art:9-25): for the camera rays of iteration 0 the shading
+// normal and the saturated BSDF albedo of the first hit, times 1 / spi like every splat (driver/accumulator.art:4-30)
+__global__ void __launch_bounds__(256) k_info(const InfoArgs a)
+{
+    const uint32_t n = *a.count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int4 meta   = a.in.meta[i];
+        const float4 hit  = a.in.hit[i];
+        const int ent     = (int)igm_bits(hit.x);
+        float4 nrm = make_float4(0, 0, 0, 0), alb = make_float4(0, 0, 0, 0);
+        if (ent >= 0 && ((uint32_t)meta.y & IG_RAY_FLAG_CAMERA)) {
+            const float4 ra = a.in.rayA[i], rb = a.in.rayB[i];
+            const f3 org{ ra.x, ra.y, ra.z }, dir{ rb.x, rb.y, rb.z };
+            const ig_material& mat = a.scene.materials[a.scene.entity_material[ent]];
+            const Surf surf        = surface_element(a.scene, ent, (int)igm_bits(hit.y), org, dir, hit.z, hit.w, a.in.hit_v[i]);
+            const BsdfCtx<true> bsdf(a.scene, mat, surf, dir);
+            const Col al = bsdf.albedo(-dir);
+            const f3 N   = surf.local.c2;
+            nrm          = make_float4(N.x * a.inv_spi, N.y * a.inv_spi, N.z * a.inv_spi, 0);
+            alb          = make_float4(igm_min(al.r, 1.0f) * a.inv_spi, igm_min(al.g, 1.0f) * a.inv_spi, igm_min(al.b, 1.0f) * a.inv_spi, 0);
+        }
+        const int64_t slot = (int64_t)meta.x - a.id_base;
+        a.normals[slot]    = nrm;
+        a.albedo[slot]     = alb;
+    }
+}
+
+void launch_info(const InfoArgs& args, int grid_blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_info, dim3((unsigned)grid_blocks), dim3(256), 0, stream, args);
+}
+
 // ---------------------------------------------------------------- k_resolve
 
 // fb[pixel] += sum over samples of the per-sample accumulator, in sample order. The reference adds

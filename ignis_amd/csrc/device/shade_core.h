@@ -1014,6 +1014,34 @@ struct BsdfCtx {
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
     IG_DEV Principled principled() const { return Principled(*mat, surf.local, surf.entering, kd); }
 
+    // Bsdf::albedo of each model (the "Albedo" AOV of technique/internal/infobuffer.art:13-21)
+    IG_DEV Col albedo(f3 out_dir) const
+    {
+        const f3 N = surf.local.c2;
+        switch (mat->bsdf_type) {
+        case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf (bsdf/dielectric.art:35)
+            return lerp_col(Col{ mat->p[2], mat->p[3], mat->p[4] }, Col{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
+        case IG_BSDF_CONDUCTOR: { // compute_albedo (bsdf/conductor.art:50-56), kd = black
+            const float c = abs_cos(out_dir, N);
+            const Col F   = Col{ conductor_factor(mat->p[0], mat->p[3], c), conductor_factor(mat->p[1], mat->p[4], c), conductor_factor(mat->p[2], mat->p[5], c) };
+            const Col IF  = Col{ 1 - F.r, 1 - F.g, 1 - F.b };
+            return Col{ 0.0f * IF.r + mat->p[6] * F.r, 0.0f * IF.g + mat->p[7] * F.g, 0.0f * IF.b + mat->p[8] * F.b };
+        }
+        case IG_BSDF_PLASTIC: { // make_join_bsdf.albedo (bsdf/mix.art:56-61) over lambertian and mirror / conductor albedo
+            const Plastic pl(*mat, surf.local, kd);
+            const Col ks{ mat->p[6], mat->p[7], mat->p[8] };
+            Col coat = ks; // make_mirror_bsdf (bsdf/conductor.art:8)
+            if (!(mat->flags & IG_MAT_SMOOTH)) {
+                const float f = conductor_factor(0, 1, abs_cos(out_dir, N));
+                coat          = Col{ 0.0f * (1 - f) + ks.r * f, 0.0f * (1 - f) + ks.g * f, 0.0f * (1 - f) + ks.b * f };
+            }
+            return lerp_col(kd, coat, pl.mix(out_dir));
+        }
+        default: // lambertian kd (bsdf/diffuse.art:10), principled base colour (bsdf/principled.art:478)
+            return kd;
+        }
+    }
+
     IG_DEV Col eval(f3 in_dir, f3 out_dir) const
     {
         const f3 N = surf.local.c2;

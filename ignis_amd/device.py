@@ -13,7 +13,7 @@ from .tables import Scene, _LIB_DIR
 
 class Setup(C.Structure):
     _fields_ = [("gpu_index", C.c_int32), ("acquire_stats", C.c_int32), ("debug_trace", C.c_int32),
-                ("is_interactive", C.c_int32), ("stream_capacity", C.c_uint64)]
+                ("is_interactive", C.c_int32), ("stream_capacity", C.c_uint64), ("info_aovs", C.c_int32)]
 
 
 class RenderSettings(C.Structure):
@@ -125,10 +125,11 @@ def device_count():
 class Device:
     """One MI355X render device (IRenderDevice counterpart)."""
 
-    def __init__(self, gpu_index=0, acquire_stats=False, stream_capacity=0):
+    def __init__(self, gpu_index=0, acquire_stats=False, stream_capacity=0, info_aovs=False):
         # acquire_stats: False/0 off, 1 HIP-event stage timers, True/2 timers + traversal work counters
         level = 2 if acquire_stats is True else int(acquire_stats)
-        setup = Setup(int(gpu_index), level, 0, 0, int(stream_capacity))
+        # info_aovs: the "Normals" / "Albedo" AOVs of the denoiser's info buffer, read with framebuffer("Normals") / ("Albedo")
+        setup = Setup(int(gpu_index), level, 0, 0, int(stream_capacity), int(bool(info_aovs)))
         self._h = lib().igd_create(C.byref(setup))
         if not self._h:
             raise DeviceError(-2, lib().igd_last_error().decode())

@@ -27,6 +27,9 @@ class RuntimeOptions:
         self.OverrideFilmSize = (0, 0)
         self.StreamCapacity = 0       # rays in flight, 0 = device default
         self.IsTracer = False
+        # Denoiser.Enabled (RuntimeSettings.h): the runtime then wraps the technique with the info buffer and the device keeps the
+        # "Normals" / "Albedo" AOVs (InfoBufferTechnique.cpp, Runtime.cpp:246-264); the denoiser itself (OIDN) is not part of this path
+        self.EnableInfoAOVs = False
         # tile sharding across devices: this runtime renders rows offset, offset+stride, ...
         self.RowOffset = 0
         self.RowStride = 1
@@ -70,7 +73,7 @@ class Runtime:
         sc = scene.scene
         self._width, self._height = int(sc.film_width), int(sc.film_height)
         self._spi = opts.SPI if opts.SPI > 0 else recommend_spi(self._width, self._height)
-        self._device = Device(opts.Device, opts.AcquireStats, opts.StreamCapacity)
+        self._device = Device(opts.Device, opts.AcquireStats, opts.StreamCapacity, info_aovs=opts.EnableInfoAOVs and not opts.IsTracer)
         self._device.assign_scene(scene)
         self._iteration = 0
         self._samples = 0

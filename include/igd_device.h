@@ -47,6 +47,9 @@ typedef struct igd_setup {
     uint64_t stream_capacity; /* rays in flight, allocated as given at the first render; 0 = grow with the largest request up to
                                * one batch of iterations (2^27 rays); larger requests run in chunks (reference: 1 048 576,
                                * mapping_gpu.art:1119) */
+    int32_t info_aovs;        /* != 0: the "Normals" and "Albedo" AOVs of the info-buffer wrapper the runtime adds for the denoiser
+                               * (InfoBufferTechnique.cpp:6-18, technique/internal/infobuffer.art): first hits of the camera rays of
+                               * iteration 0; read them through the framebuffer accessors by name */
 } igd_setup;
 
 /* IRenderDevice::RenderSettings (IRenderDevice.h:30-40). `rays` != NULL selects the
@@ -110,7 +113,8 @@ int32_t igd_framebuffer_height(const igd_device* dev); /* IRenderDevice::framebu
 
 /* IRenderDevice::getFramebufferForHost(name, sync) (IRenderDevice.h:53, Device.cpp:1385-1417):
  * float[height][width][3], device -> host copy if dirty; pointer owned by the device, valid
- * until resize/destroy. name NULL or "" = colour buffer. Returns NULL for unknown AOVs. */
+ * until resize/destroy. name NULL or "" = colour buffer; "Normals" / "Albedo" with igd_setup.info_aovs. Returns NULL for
+ * unknown AOVs. */
 const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t sync);
 
 /* IRenderDevice::getFramebufferForDevice (IRenderDevice.h:54): device pointer (HBM). */

@@ -42,6 +42,8 @@ def lib():
         up = C.POINTER(C.c_uint32)
         l.oracle_render.restype = C.c_int
         l.oracle_render.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats)]
+        l.oracle_render_ex.restype = C.c_int
+        l.oracle_render_ex.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats), fp, fp]
         l.oracle_generate_rays.restype = C.c_int
         l.oracle_generate_rays.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int64, C.c_int64, fp, up]
         l.oracle_trace.restype = C.c_int
@@ -90,13 +92,21 @@ def make_settings(spi, width, height, iteration=0, frame=0, seed=0, threads=0, w
     return s
 
 
-def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None, rows=None):
-    """One iteration of the reference CPU pipeline; returns (fb[h,w,3] float32 accumulated, stats dict)."""
+def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None, rows=None, aovs=None):
+    """One iteration of the reference CPU pipeline; returns (fb[h,w,3] float32 accumulated, stats dict).
+    aovs: optional (normals, albedo) float32 [h, w, 3] arrays, accumulated by iteration 0 (the info-buffer AOVs)."""
     if fb is None:
         fb = np.zeros((height, width, 3), dtype=np.float32)
     assert fb.dtype == np.float32 and fb.flags.c_contiguous and fb.shape == (height, width, 3)
     cfg = make_settings(spi, width, height, iteration, frame, seed, threads, window, rows)
     st = Stats()
+    if aovs is not None:
+        for a in aovs:
+            assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (height, width, 3)
+        rc = lib().oracle_render_ex(_scene_ptr(scene), C.byref(cfg), _fp(fb), C.byref(st), _fp(aovs[0]), _fp(aovs[1]))
+        if rc != 0:
+            raise RuntimeError("oracle_render failed")
+        return fb, st.as_dict()
     rc = lib().oracle_render(_scene_ptr(scene), C.byref(cfg), _fp(fb), C.byref(st))
     if rc != 0:
         raise RuntimeError("oracle_render failed")

@@ -251,7 +251,7 @@ void camera_scale(const igd_scene& sc, int width, int height, float& sx, float& 
 
 // One tile of cpu_trace (mapping_cpu.art:731-857)
 void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSetup& cam, const PathTracer& pt_tech,
-                int xmin, int ymin, int xmax, int ymax, float* fb,
+                int xmin, int ymin, int xmax, int ymax, float* fb, float* aov_normals, float* aov_albedo,
                 PrimaryStream& primary, SecondaryStream& secondary, std::vector<int>& ray_begins, std::vector<int>& ray_ends, Counters& cnt)
 {
     const int spi      = cfg.spi;
@@ -343,6 +343,15 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     const SurfaceElement bsurf = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) ? bumped_surface(sc, mat, surf, ray) : surf;
                     const Bsdf bsdf{ &mat, &bsurf, &sc };
 
+                    // wrap_infobuffer_renderer.on_hit (technique/internal/infobuffer.art:9-25)
+                    if (aov_normals && cfg.iteration == 0 && (ray.flags & IG_RAY_FLAG_CAMERA)) {
+                        const Vec3 n   = surf.local.col[2];
+                        const Color al = color_saturate(bsdf.albedo(vec3_neg(ray.dir)), 1);
+                        const int px_l = ray_id / spi;
+                        aov_normals[px_l * 3 + 0] += n.x * inv_spi, aov_normals[px_l * 3 + 1] += n.y * inv_spi, aov_normals[px_l * 3 + 2] += n.z * inv_spi;
+                        aov_albedo[px_l * 3 + 0] += al.r * inv_spi, aov_albedo[px_l * 3 + 1] += al.g * inv_spi, aov_albedo[px_l * 3 + 2] += al.b * inv_spi;
+                    }
+
                     Color hit_color;
                     if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
                         hit_color = Color{ 0, 0, 0 };
@@ -425,7 +434,8 @@ extern "C" {
 // Renders ONE iteration into `fb` (float[height][width][3], accumulated with +=,
 // exactly like the reference framebuffer: Runtime divides by the iteration count on save,
 // src/runtime/Runtime.cpp:808-826).
-int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats)
+// aov_normals / aov_albedo: optional float[height][width][3] (accumulated with +=), the info-buffer AOVs of iteration 0
+int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats, float* aov_normals, float* aov_albedo)
 {
     if (!sc || !cfg || !fb || cfg->spi <= 0 || cfg->width <= 0 || cfg->height <= 0)
         return -1;
@@ -468,7 +478,7 @@ int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, or
             const int tx = tile % tiles_x, ty = tile / tiles_x;
             const int xmin = x0 + tx * tile_size, ymin = sharded ? rows[(size_t)ty] : y0 + ty * tile_size;
             const int xmax = std::min(xmin + tile_size, x1), ymax = sharded ? ymin + 1 : std::min(ymin + tile_size, y1);
-            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
+            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, aov_normals, aov_albedo, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
         }
     };
 
@@ -493,6 +503,11 @@ int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, or
         stats->threads_used = threads;
     }
     return 0;
+}
+
+int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats)
+{
+    return oracle_render_ex(sc, cfg, fb, stats, nullptr, nullptr);
 }
 
 // Camera rays for ray ids [first_id, first_id + count) of one iteration, id = (y*W + x)*spi + sample

@@ -1119,6 +1119,28 @@ struct Bsdf {
         return Color{ conductor_factor(mat->p[0], mat->p[3], cosTheta), conductor_factor(mat->p[1], mat->p[4], cosTheta), conductor_factor(mat->p[2], mat->p[5], cosTheta) };
     }
 
+    // Bsdf::albedo per model (what wrap_infobuffer_renderer splats, technique/internal/infobuffer.art:13-21)
+    Color albedo(Vec3 out_dir) const
+    {
+        const Vec3 N = surf->local.col[2];
+        if (mat->bsdf_type == IG_BSDF_DIELECTRIC) // make_pure_dielectric_bsdf (dielectric.art:35)
+            return color_lerp(Color{ mat->p[2], mat->p[3], mat->p[4] }, Color{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
+        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) { // compute_albedo (conductor.art:50-56), kd = black
+            const Color F = conductor_fresnel(absolute_cos(out_dir, N));
+            return Color{ 0.0f * (1 - F.r) + mat->p[6] * F.r, 0.0f * (1 - F.g) + mat->p[7] * F.g, 0.0f * (1 - F.b) + mat->p[8] * F.b };
+        }
+        if (mat->bsdf_type == IG_BSDF_PLASTIC) { // make_join_bsdf.albedo (mix.art:56-61)
+            const Plastic pl(*mat, *surf, kd());
+            Color coat = pl.ks; // make_mirror_bsdf (conductor.art:8)
+            if (!pl.smooth) {
+                const float f = conductor_factor(0, 1, absolute_cos(out_dir, N));
+                coat          = Color{ 0.0f * (1 - f) + pl.ks.r * f, 0.0f * (1 - f) + pl.ks.g * f, 0.0f * (1 - f) + pl.ks.b * f };
+            }
+            return color_lerp(kd(), coat, pl.mix(out_dir));
+        }
+        return kd(); // lambertian (diffuse.art:10), principled base colour (principled.art:478)
+    }
+
     // make_lambertian_bsdf (bsdf/diffuse.art:2-13); make_rough_base_conductor_bsdf (bsdf/conductor.art:70-84);
     // delta BSDFs evaluate to black (dielectric.art:16-17)
     Color eval(Vec3 in_dir, Vec3 out_dir) const

@@ -823,3 +823,39 @@ def test_cie_sky_lights_vs_oracle(gpu_device, kind, extra):
     s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 64)
     _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=23, iters=2)
+
+
+@pytest.mark.parametrize("scene_name,cap", [("diamond_scene.json", 0), ("diamond_scene_principled.json", 4096), ("many_point_lights_hip.json", 0)])
+def test_info_buffer_aovs_vs_oracle(scene_name, cap):
+    """The "Normals" / "Albedo" AOVs the runtime adds for its denoiser: first hits of iteration 0's camera rays, unchanged by
+    later iterations, cleared by name, refused when the device was created without them; the colour buffer is not affected."""
+    import oracle
+    from ignis_amd import Device, DeviceError
+    from ignis_amd.tables import LoadedScene
+    w, h, spi = 80, 56, 4
+    sc = LoadedScene.from_file(os.path.join(SCENES, scene_name), w, h)
+    ref = np.zeros((h, w, 3), np.float32)
+    nrm, alb = np.zeros_like(ref), np.zeros_like(ref)
+    for it in range(3):
+        oracle.render(sc, spi, w, h, iteration=it, seed=4, fb=ref, aovs=(nrm, alb))
+    dev = Device(0, stream_capacity=cap, info_aovs=True)
+    plain = Device(0)
+    try:
+        for d in (dev, plain):
+            d.assign_scene(sc)
+            d.resize(w, h)
+            for it in range(3):
+                d.render(spi, w, h, iteration=it, seed=4)
+        np.testing.assert_array_equal(dev.framebuffer(), plain.framebuffer())
+        assert _rel_l2(dev.framebuffer(), ref) <= RADIANCE_TOL
+        assert _rel_l2(dev.framebuffer("Normals"), nrm) <= 1e-6 and _rel_l2(dev.framebuffer("Albedo"), alb) <= 1e-6
+        assert np.abs(nrm).sum() > 0 and np.abs(alb).sum() > 0
+        with pytest.raises(DeviceError):
+            plain.framebuffer("Normals")
+        with pytest.raises(DeviceError):
+            dev.framebuffer("Depth")
+        dev.clear_framebuffer("Albedo")
+        assert dev.framebuffer("Albedo").sum() == 0 and np.abs(dev.framebuffer("Normals")).sum() > 0
+    finally:
+        dev.close()
+        plain.close()

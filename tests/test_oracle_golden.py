@@ -785,3 +785,17 @@ def test_cie_clear_sky_constants():
     c2 = zb * nf / np.pi / factor + 6e-5 / np.pi * solar * np.sin(el)
     assert d[7] == pytest.approx(zb / factor, rel=1e-5) and d[8] == pytest.approx(c2, rel=1e-5)
     assert list(d[9:12]) == pytest.approx(sun, abs=1e-6)
+
+
+def test_info_buffer_aovs_known_answers():
+    """wrap_infobuffer_renderer (technique/internal/infobuffer.art): on the integrator scene every camera ray hits the white
+    plane, whose shading normal faces the camera (-z): Normals = (0, 0, -1), Albedo = the reflectance, both once (iteration 0
+    only), independent of spi."""
+    s = flat_scene([{"type": "point", "name": "l", "position": [0, 0, -1], "intensity": [1, 1, 1]}])
+    s["bsdfs"][0]["reflectance"] = [0.25, 0.5, 2.0]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 16, 16)
+    nrm, alb = np.zeros((16, 16, 3), np.float32), np.zeros((16, 16, 3), np.float32)
+    for it in range(2):
+        oracle.render(sc, 4, 16, 16, iteration=it, seed=1, aovs=(nrm, alb))
+    np.testing.assert_allclose(nrm, np.broadcast_to(np.float32([0, 0, -1]), nrm.shape), atol=1e-6)
+    np.testing.assert_allclose(alb, np.broadcast_to(np.float32([0.25, 0.5, 1.0]), alb.shape), atol=1e-6)  # saturated at 1
