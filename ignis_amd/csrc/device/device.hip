@@ -364,8 +364,8 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard colours are only lowered for diffuse and principled BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material light id out of range" };
-        if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE)
-            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only planar area lights can be emissive entities" };
+        if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE && s->lights[mat.light_id].type != IG_LIGHT_MESH_AREA)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only area lights can be emissive entities" };
     }
     const uint32_t n_finite = s->light_count - s->infinite_light_count;
     const bool hierarchy    = s->technique.light_selector == IG_SELECTOR_HIERARCHY && n_finite > 0;
@@ -374,7 +374,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t l = 0; l < s->light_count; ++l) {
         const bool inf = l < s->infinite_light_count;
         const int lt = s->lights[l].type;
-        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_CIE)
+        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_MESH_AREA)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
         if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL || lt == IG_LIGHT_ENV_TEXTURED || lt == IG_LIGHT_SUN || lt == IG_LIGHT_CIE))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment, directional or sun lights" };
@@ -505,6 +505,13 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC;
+    for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
+        if (s->lights[i].type != IG_LIGHT_MESH_AREA)
+            continue;
+        d->full_bsdfs = true;
+        if (s->lights[i].entity_id < 0 || s->lights[i].entity_id >= (int32_t)s->entity_count)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: mesh area light without a valid entity" };
+    }
     for (uint32_t i = 0; i < s->infinite_light_count; ++i)
         d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN || s->lights[i].type == IG_LIGHT_CIE;
     d->has_scene            = true;

@@ -1299,6 +1299,62 @@ struct TexturedEnv {
     IG_DEV Col emission(f3 ray_dir) const { return scale * image_lookup(sc, *tex, map_env_uv(local_dir(ray_dir))); }
 };
 
+// make_shape_area_emitter (light/area.art:58-103) under make_area_light (area.art:10-43) with a constant colour: a uniformly
+// chosen triangle of the emissive entity's mesh, a uniform point on it
+struct MeshEmitter {
+    m34 global;
+    const float* verts;
+    const float* inds;
+    int num_tris;
+    Col radiance;
+
+    IG_DEV MeshEmitter(const DevScene& sc, const ig_light& L)
+    {
+        const int ent   = L.entity_id;
+        const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)ent * IG_ENTITY_FLOATS);
+        const float4 r3 = e[3], r4 = e[4], r5 = e[5];
+        global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
+        const uint4 ext = sc.entity_ext[ent];
+        verts           = reinterpret_cast<const float*>(sc.shape_data + ext.x);
+        inds            = reinterpret_cast<const float*>(sc.shape_data + ext.z);
+        num_tris        = (int)*reinterpret_cast<const uint32_t*>(sc.shape_data + ext.x - 48); // shape header: faces first
+        radiance        = Col{ L.d[0], L.d[1], L.d[2] };
+    }
+    // what the light needs of shape.surface_element_for_point (shapes/trimesh.art:41-68)
+    IG_DEV void surface(int f, float u, float v, f3& point, f3& face_normal, float& area) const
+    {
+        const int4 tri = *reinterpret_cast<const int4*>(inds + f * 4);
+        const f3 v0    = xform_point(global, ld3v(verts + tri.x * 4));
+        const f3 v1    = xform_point(global, ld3v(verts + tri.y * 4));
+        const f3 v2    = xform_point(global, ld3v(verts + tri.z * 4));
+        const f3 n     = stable_normal(v2 - v0, v0 - v1, v1 - v2);
+        const float nn = len3(n);
+        face_normal    = n * (1 / nn);
+        area           = nn / 2;
+        point          = f3{ lerp2(v0.x, v1.x, v2.x, u, v), lerp2(v0.y, v1.y, v2.y, u, v), lerp2(v0.z, v1.z, v2.z, u, v) };
+    }
+    IG_DEV void address(float uvx, float uvy, int& f, float& u, float& v) const
+    {
+        const float ux = uvx * (float)num_tris;
+        f              = min((int)ux, num_tris - 1);
+        const float a = ux - (float)f, b = uvy;
+        if (a + b > 1) // sample_triangle (core/sampling.art:34-36)
+            u = 1 - a, v = 1 - b;
+        else
+            u = a, v = b;
+    }
+    // pdf_direct(surf.prim_coords, .) (area.art:39,74-82): the hit's barycentrics go through the same addressing as a sample's uv
+    IG_DEV float pdf_area(float uvx, float uvy) const
+    {
+        int f;
+        float u, v, area;
+        f3 p, n;
+        address(uvx, uvy, f, u, v);
+        surface(f, u, v, p, n, area);
+        return safe_div(1, area) / (float)num_tris;
+    }
+};
+
 // CIE sky models (light/cie.art:1-41) as function environments (light/env.art:24-105); directions in the light's Y-up frame
 struct CieSky {
     int kind;
@@ -1622,11 +1678,21 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     if (mat.light_id >= 0 && surf.entering) {
         const float dcos = -dot3(in.dir, N);
         if (dcos > kFltEps) {
-            const PlaneLight pl(sc.lights[mat.light_id]);
-            const float pdf_s = pl.pdf(in.org);
+            const ig_light& EL = sc.lights[mat.light_id];
+            Col emit;
+            float pdf_s;
+            if (FULL && EL.type == IG_LIGHT_MESH_AREA) {
+                const MeshEmitter me(sc, EL);
+                emit  = me.radiance;
+                pdf_s = me.pdf_area(in.u, in.v) * (in.t * in.t) / dcos; // Pdf::as_solid (driver/pdf.art:19-38)
+            } else {
+                const PlaneLight pl(EL);
+                emit  = pl.radiance;
+                pdf_s = pl.pdf(in.org);
+            }
             const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
             out.has_radiance  = true;
-            out.radiance      = clamp_color(tech, (in.contrib * pl.radiance) * mis);
+            out.radiance      = clamp_color(tech, (in.contrib * emit) * mis);
         }
     }
 
@@ -1704,6 +1770,23 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             lcos     = 1.0f;
             ldist    = sc.scene_radius;
             infinite = true;
+        } else if (FULL && L.type == IG_LIGHT_MESH_AREA) {
+            // make_area_light.sample_direct over make_shape_area_emitter (light/area.art:12-26,62-71)
+            const MeshEmitter me(sc, L);
+            const float ux = rnd.f32();
+            const float uy = rnd.f32();
+            int f;
+            float u, v, area;
+            f3 fnorm;
+            me.address(ux, uy, f, u, v);
+            me.surface(f, u, v, lpos, fnorm, area);
+            pdf_value   = safe_div(1, area) / (float)me.num_tris;
+            pdf_area    = true;
+            const f3 d_ = lpos - surf.point;
+            ldist       = len3(d_);
+            ldir        = d_ * safe_div(1, ldist);
+            lcos        = dot3(ldir, fnorm) * (surf.entering ? -1.0f : 1.0f);
+            lint        = me.radiance * (area * (float)me.num_tris);
         } else if (FULL && L.type == IG_LIGHT_CIE) {
             // make_environment_light_function_{hemi,spherical}.sample_direct (light/env.art:31-37,79-93)
             const CieSky sky(L);

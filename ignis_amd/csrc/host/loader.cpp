@@ -1280,10 +1280,35 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             if (it == emissive.end())
                 fail("No entity named '" + ent + "' exists for area light '" + lname + "'");
             const ShapeRec& shape = shapes[it->second.shape_id];
-            if (!shape.plane.has_value() || !l.getBool("optimize", true))
-                fail("Area light '" + lname + "': only planar (rectangle) emitters are supported by the HIP backend");
+            if (!shape.plane.has_value() || !l.getBool("optimize", true)) {
+                // AreaLight.cpp:60-62,84-92,206-227: no specialised sampler -> make_shape_area_emitter over the entity's triangles.
+                // Position = centre of the bounding box, no direction (negative flux in the hierarchy), area = mesh area times
+                // the transform's approximate area scale (AreaLight.cpp:12-24).
+                const Affine& T = it->second.transform;
+                const V3 ls     = shape.bbox.diameter();
+                const float w   = norm(T.direction(V3(1, 0, 0) * ls.x));
+                const float h   = norm(T.direction(V3(0, 1, 0) * ls.y));
+                const float dd  = norm(T.direction(V3(0, 0, 1) * ls.z));
+                const float half_area = ls.x * ls.y + ls.x * ls.z + ls.y * ls.z; // BoundingBox::halfArea
+                const float area      = shape.area * ((w * h + w * dd + h * dd) / half_area);
+                V3 radiance, cache;
+                if (l.has("power")) {
+                    cache    = getColor(l, "power", V3(area * Pi, area * Pi, area * Pi), lname); // mColor_Cache (AreaLight.cpp:98-107)
+                    radiance = cache * ((1 / Pi) / area);                                          // color_mulf(power, flt_inv_pi / mArea)
+                } else {
+                    radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
+                    cache    = radiance * (area * Pi);
+                }
+                out.type      = IG_LIGHT_MESH_AREA;
+                out.entity_id = (int32_t)it->second.id;
+                out.d[0] = radiance.x, out.d[1] = radiance.y, out.d[2] = radiance.z;
+                finite_index_of_entity[ent] = (int32_t)finite.size();
+                hier_entries.push_back(LightEntry{ T.point(shape.bbox.center()), V3(0, 0, 1), -((cache.x + cache.y + cache.z) / 3), (int32_t)finite.size() });
+                finite.push_back(out);
+                continue;
+            }
             if (l.has("power"))
-                fail("Area light '" + lname + "': 'power' is not supported by this loader, use 'radiance'");
+                fail("Area light '" + lname + "': 'power' is not supported by this loader for planar emitters, use 'radiance'");
             // AreaLight.cpp:138-170 + "SimplePlaneLight" layout (light/area.art:416-440)
             const Affine& T    = it->second.transform;
             const V3 origin    = T.point(shape.plane->origin);

@@ -169,6 +169,10 @@ enum ig_light_type {
      * d[15..23] the 3x3 "_transform" column by column. Sampled over the sphere, or the cosine-weighted upper
      * hemisphere when there is no ground. */
     IG_LIGHT_CIE = 7,
+    /* area light over an arbitrary triangle mesh (make_shape_area_emitter, src/artic/light/area.art:44-103; AreaLight.cpp
+     * representation "None": non-planar meshes or "optimize": false): a uniformly chosen triangle, a uniform point on it.
+     * entity_id = the emissive entity, d[0..2] radiance. Finite, not delta. */
+    IG_LIGHT_MESH_AREA = 8,
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |

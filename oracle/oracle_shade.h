@@ -1667,6 +1667,82 @@ static inline DirectLightSample sample_direct_env_textured(const igd_scene& sc, 
     return s;
 }
 
+// ---- make_shape_area_emitter (light/area.art:58-103) under make_area_light (area.art:10-43) with a constant colour:
+// a uniformly chosen triangle of the emissive entity's mesh, a uniform point on it
+struct MeshEmitter {
+    Entity entity;
+    TriMeshView mesh;
+    Color radiance;
+
+    MeshEmitter(const igd_scene& sc, const ig_light& l)
+        : entity(load_entity(sc, l.entity_id))
+        , mesh(load_trimesh(sc, entity.shape_id))
+        , radiance(Color{ l.d[0], l.d[1], l.d[2] })
+    {
+    }
+    // shape.surface_element_for_point (shapes/trimesh.art:41-68): what the light needs of it
+    void surface(int32_t f, float u, float v, Vec3& point, Vec3& face_normal, float& area) const
+    {
+        const int32_t i0 = mesh.indices[f * 4 + 0], i1 = mesh.indices[f * 4 + 1], i2 = mesh.indices[f * 4 + 2];
+        auto vtx = [&](int32_t i) { return mat3x4_transform_point(entity.global_mat, Vec3{ mesh.vertices[i * 4], mesh.vertices[i * 4 + 1], mesh.vertices[i * 4 + 2] }); };
+        const Vec3 v0 = vtx(i0), v1 = vtx(i1), v2 = vtx(i2);
+        const Vec3 n   = compute_stable_triangle_normal(vec3_sub(v2, v0), vec3_sub(v0, v1), vec3_sub(v1, v2)); // make_triangle (core/triangle.art:12-44)
+        const float nn = vec3_len(n);
+        face_normal    = vec3_mulf(n, 1 / nn);
+        area           = nn / 2;
+        point          = vec3_lerp2(v0, v1, v2, u, v);
+    }
+    // the (triangle, barycentrics) a uv pair addresses (area.art:62-65)
+    void address(Vec2 uv, int32_t& f, float& u, float& v) const
+    {
+        const float ux = uv.x * (float)mesh.num_tris;
+        f              = std::min((int32_t)ux, mesh.num_tris - 1);
+        const float a = ux - (float)f, b = uv.y;
+        if (a + b > 1) // sample_triangle (core/sampling.art:34-36)
+            u = 1 - a, v = 1 - b;
+        else
+            u = a, v = b;
+    }
+    // pdf_direct(surf.prim_coords, .) (area.art:39,74-82): the reference feeds the hit's barycentrics through the same
+    // addressing as a sample's uv, which is what is restated here
+    float pdf_area(Vec2 uv) const
+    {
+        int32_t f;
+        float u, v, area;
+        Vec3 p, n;
+        address(uv, f, u, v);
+        surface(f, u, v, p, n, area);
+        return safe_div(1, area) / (float)mesh.num_tris;
+    }
+};
+
+static inline DirectLightSample sample_direct_mesh(const igd_scene& sc, const ig_light& l, Rng& rnd, const SurfaceElement& from_surf)
+{
+    const MeshEmitter me(sc, l);
+    const float ux = rnd.next_f32();
+    const float uy = rnd.next_f32();
+    int32_t f;
+    float u, v, area;
+    Vec3 point, face_normal;
+    me.address(Vec2{ ux, uy }, f, u, v);
+    me.surface(f, u, v, point, face_normal, area);
+    const float pdfv   = safe_div(1, area) / (float)me.mesh.num_tris;
+    const float weight = area * (float)me.mesh.num_tris;
+    const Vec3 dir_    = vec3_sub(point, from_surf.point);
+    const float dist   = vec3_len(dir_);
+    const Vec3 dir     = vec3_mulf(dir_, safe_div(1, dist));
+    DirectLightSample s;
+    s.pos          = point;
+    s.dir          = dir;
+    s.intensity    = color_mulf(me.radiance, weight);
+    s.pdf_value    = pdfv;
+    s.pdf_is_area  = true;
+    s.pdf_is_delta = false;
+    s.cos          = vec3_dot(dir, face_normal) * (from_surf.is_entering ? -1.0f : 1.0f);
+    s.dist         = dist;
+    return s;
+}
+
 // ---- light/cie.art:1-41: CIE sky radiance functions (direction in the light's Y-up frame)
 struct CieSky {
     int kind;
@@ -2017,6 +2093,9 @@ struct PathTracer {
             ls       = sample_direct_cie(sc, light, rnd, surf);
             infinite = true;
             break;
+        case IG_LIGHT_MESH_AREA:
+            ls = sample_direct_mesh(sc, light, rnd, surf);
+            break;
         default:
             ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);
             infinite = true;
@@ -2060,10 +2139,17 @@ struct PathTracer {
             const float dot = -vec3_dot(ray.dir, surf.local.col[2]);
             if (dot > flt_eps) {
                 const ig_light& light = sc.lights[mat.light_id];
-                const PlaneEmitter pe(light);
-                const Color emit  = pe.radiance;            // light.emission(ctx)
-                const float pdf_s = pe.pdf_direct(ray.org); // solid-angle pdf: as_solid is the identity
-                (void)hit;
+                Color emit;
+                float pdf_s;
+                if (light.type == IG_LIGHT_MESH_AREA) {
+                    const MeshEmitter me(sc, light);
+                    emit  = me.radiance;
+                    pdf_s = me.pdf_area(surf.prim_coords) * (hit.distance * hit.distance) / dot; // Pdf::as_solid (driver/pdf.art:19-38)
+                } else {
+                    const PlaneEmitter pe(light);
+                    emit  = pe.radiance;            // light.emission(ctx)
+                    pdf_s = pe.pdf_direct(ray.org); // solid-angle pdf: as_solid is the identity
+                }
                 const float mis = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf(mat.light_id, ray.org) * pdf_s) : 1.0f;
                 out             = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
                 return true;

@@ -859,3 +859,21 @@ def test_info_buffer_aovs_vs_oracle(scene_name, cap):
     finally:
         dev.close()
         plain.close()
+
+
+def test_mesh_area_lights_vs_oracle(gpu_device):
+    """Area lights over arbitrary meshes (an emissive icosphere, a planar emitter with "optimize": false) next to the
+    planar light of the diamond scene; uniform and hierarchy selectors; hits on the emitters go through the MIS pdf."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["shapes"] += [{"type": "icosphere", "name": "Ball", "radius": 0.12, "subdivisions": 2},
+                    {"type": "rectangle", "name": "Panel", "width": 0.4, "height": 0.3}]
+    s["entities"] += [{"name": "BallLamp", "shape": "Ball", "bsdf": "mat-Light", "transform": [{"translate": [0.5, 0.45, 0.3]}]},
+                      {"name": "PanelLamp", "shape": "Panel", "bsdf": "mat-Light", "transform": [{"translate": [-0.6, 0.3, -0.2]}, {"rotate": [0, 60, 0]}]}]
+    s["lights"] += [{"type": "area", "name": "BallLight", "entity": "BallLamp", "power": [30, 25, 20]},
+                    {"type": "area", "name": "PanelLight", "entity": "PanelLamp", "radiance": [8, 10, 12], "optimize": False}]
+    for sel in ("uniform", "hierarchy"):
+        s["technique"]["light_selector"] = sel
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+        assert sorted(l.type for l in sc.scene.lights[:3]) == [0, 8, 8]
+        _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=29, iters=2)

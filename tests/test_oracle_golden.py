@@ -799,3 +799,46 @@ def test_info_buffer_aovs_known_answers():
         oracle.render(sc, 4, 16, 16, iteration=it, seed=1, aovs=(nrm, alb))
     np.testing.assert_allclose(nrm, np.broadcast_to(np.float32([0, 0, -1]), nrm.shape), atol=1e-6)
     np.testing.assert_allclose(alb, np.broadcast_to(np.float32([0.25, 0.5, 1.0]), alb.shape), atol=1e-6)  # saturated at 1
+
+
+# ---- area lights over arbitrary meshes (make_shape_area_emitter, src/artic/light/area.art:44-103)
+
+def _emitter_scene(optimize, shape=None, radiance=(20, 20, 20)):
+    s = flat_scene([{"type": "area", "name": "L", "entity": "Lamp", "radiance": list(radiance), "optimize": optimize}], max_depth=3)
+    s["bsdfs"].append({"type": "diffuse", "name": "black", "reflectance": [0, 0, 0]})
+    s["shapes"].append(shape or {"type": "rectangle", "name": "LampShape", "width": 0.5, "height": 0.5})
+    s["shapes"][-1]["name"] = "LampShape"
+    # 0.6 in front of the plane (the plane faces -z), emitting towards it (+z)
+    s["entities"].append({"name": "Lamp", "shape": "LampShape", "bsdf": "black", "transform": [{"translate": [0, 0, -0.6]}]})
+    return s
+
+
+def test_mesh_area_light_agrees_with_the_plane_sampler():
+    """"optimize": false swaps the spherical-rectangle sampler of a planar emitter for the generic triangle sampler: the
+    light record changes type, the expected image does not."""
+    imgs = []
+    for optimize in (True, False):
+        sc = LoadedScene.from_string(json.dumps(_emitter_scene(optimize)), SCENES, 32, 32)
+        assert sc.scene.lights[0].type == (0 if optimize else 8) and sc.scene.materials[sc.scene.material_count - 1].light_id == 0
+        imgs.append(np.mean([oracle.render(sc, 32, 32, 32, iteration=i, seed=5)[0] for i in range(4)], axis=0))
+    assert imgs[0].mean() > 0.05
+    assert imgs[1].mean() == pytest.approx(imgs[0].mean(), rel=0.02)
+    np.testing.assert_allclose(imgs[1][8:24, 8:24].mean(), imgs[0][8:24, 8:24].mean(), rtol=0.03)
+
+
+def test_sphere_shaped_area_light_irradiance():
+    """An emissive icosphere of radius r and radiance L seen from distance d is a disc of solid-angle-projected area
+    pi (r / d)^2: a diffuse white plane right below it shows L (r / d)^2 at the foot point."""
+    r, d, L = 0.1, 0.6, 50.0
+    shape = {"type": "icosphere", "radius": r, "subdivisions": 3}
+    sc = LoadedScene.from_string(json.dumps(_emitter_scene(True, shape, (L, L, L))), SCENES, 33, 33)
+    assert sc.scene.lights[0].type == 8
+    img = np.mean([oracle.render(sc, 64, 33, 33, iteration=i, seed=6)[0] for i in range(4)], axis=0)
+    # the camera sits at z = -1 and looks past the lamp at the plane (fov 90, plane at distance 1: film coordinates = plane
+    # coordinates). At plane radius rho: E = L pi r^2 cos / D^2 with D = d / cos, so the radiance E / pi = L (r / d)^2 cos^3.
+    # Compare over the ring outside the lamp's silhouette (film radius 0.25).
+    c = (np.arange(33) + 0.5) / 33 * 2 - 1
+    rho = np.hypot(c[None, :], c[:, None])
+    ring = (rho > 0.35) & (rho < 0.65)
+    want = L * (r / d) ** 2 * (d / np.hypot(d, rho)) ** 3
+    assert img.mean(-1)[ring].mean() == pytest.approx(want[ring].mean(), rel=0.03)
