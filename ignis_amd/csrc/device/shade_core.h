@@ -847,6 +847,99 @@ struct Principled {
     }
 };
 
+// make_rough_dielectric_bsdf (bsdf/dielectric.art:64-191) over the VNDF-GGX distribution of the surface frame
+struct RoughDielectric {
+    f3 N;
+    float eta, pdf_eps;
+    Col ks, kt;
+    Ggx micro;
+    static constexpr float kCosEps = 1e-5f;
+
+    IG_DEV RoughDielectric(const ig_material& m, const m33& frame, bool entering)
+    {
+        N       = frame.c2;
+        eta     = entering ? m.p[0] / m.p[1] : m.p[1] / m.p[0];
+        pdf_eps = m.p[8];
+        ks      = Col{ m.p[2], m.p[3], m.p[4] };
+        kt      = Col{ m.p[5], m.p[6], m.p[7] };
+        micro   = Ggx{ frame, m.p[9], m.p[10] };
+    }
+    IG_DEV Col eval(f3 in_dir, f3 out_dir) const
+    {
+        const float cos_i = dot3(N, in_dir);
+        const float cos_o = dot3(N, out_dir);
+        if (igm_abs(cos_i * cos_o) <= kCosEps)
+            return Col{ 0, 0, 0 };
+        const bool is_transmission = igm_signbit(cos_i * cos_o);
+        const f3 H      = is_transmission ? halfway_refractive(in_dir, out_dir, eta) : normalize3(in_dir + out_dir);
+        const float chi = dot3(H, in_dir);
+        const float cho = dot3(H, out_dir);
+        if (igm_abs(chi * cho) <= kCosEps)
+            return Col{ 0, 0, 0 };
+        const float fterm = fresnel_dielectric(eta, igm_abs(cho));
+        const float D     = micro.D(H);
+        const float G     = micro.G1(in_dir) * micro.G1(out_dir);
+        if (!is_transmission)
+            return ks * (fterm * D * G * igm_abs(refl_jacobian(cos_o)));
+        const float jacob = refr_jacobian(eta, chi, cho);
+        const float norm  = igm_abs(safe_div(cho * jacob, cos_o));
+        return kt * ((1 - fterm) * D * G * norm);
+    }
+    IG_DEV float pdf(f3 in_dir, f3 out_dir) const
+    {
+        const float cos_i = dot3(N, in_dir);
+        const float cos_o = dot3(N, out_dir);
+        if (igm_abs(cos_i * cos_o) <= kCosEps)
+            return 0;
+        const bool is_transmission = igm_signbit(cos_i * cos_o);
+        const f3 H      = is_transmission ? halfway_refractive(in_dir, out_dir, eta) : normalize3(in_dir + out_dir);
+        const float chi = dot3(H, in_dir);
+        const float cho = dot3(H, out_dir);
+        if (igm_abs(chi * cho) <= kCosEps)
+            return 0;
+        const float fterm = fresnel_dielectric(eta, igm_abs(cho));
+        const float mpdf  = micro.pdf(out_dir, H);
+        if (mpdf <= pdf_eps)
+            return 0;
+        if (!is_transmission)
+            return fterm * mpdf * igm_abs(refl_jacobian(cho));
+        return (1 - fterm) * mpdf * igm_abs(refr_jacobian(eta, chi, cho));
+    }
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta) const
+    {
+        const float cos_o = dot3(N, out_dir);
+        if (igm_abs(cos_o) <= kCosEps)
+            return false;
+        const f3 m       = micro.sample(rnd, out_dir);
+        const float mpdf = micro.pdf(out_dir, m);
+        if (dot3(m, m) <= kFltEps || mpdf <= pdf_eps)
+            return false;
+        const f3 oH     = normalize3(m);
+        const f3 H      = igm_signbit(dot3(oH, out_dir)) ? -oH : oH;
+        const float cho = dot3(H, out_dir);
+        if (igm_abs(cho) <= kCosEps)
+            return false;
+        float cos_t = 0, factor = 1;
+        if (!fresnel(eta, cho, cos_t, factor)) {
+            cos_t  = 0;
+            factor = 1;
+        }
+        float sel_pdf;
+        if (rnd.f32() > factor) {
+            in_dir  = normalize3(H * (eta * cho - cos_t) - out_dir * eta); // vec3_refract (core/vector.art:126)
+            sel_pdf = (1 - factor) * igm_abs(refr_jacobian(eta, dot3(H, in_dir), cho));
+        } else {
+            in_dir  = normalize3(H * (2 * dot3(H, out_dir)) - out_dir); // vec3_reflect (core/vector.art:123)
+            sel_pdf = factor * igm_abs(refl_jacobian(cho));
+        }
+        const float cos_i = dot3(N, in_dir);
+        pdf_out           = mpdf * sel_pdf;
+        color             = eval(in_dir, out_dir) * safe_div(1, pdf_out);
+        s_eta             = !igm_signbit(cos_i * cos_o) ? 1.0f : eta;
+        return true;
+    }
+};
+
 // fresnel_diffuse_factor (core/fresnel.art:42-63)
 IG_DEV float fresnel_diffuse_factor(float eta)
 {
@@ -1019,7 +1112,8 @@ struct BsdfCtx {
     {
         const f3 N = surf.local.c2;
         switch (mat->bsdf_type) {
-        case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf (bsdf/dielectric.art:35)
+        case IG_BSDF_ROUGH_DIELECTRIC:
+        case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf / make_rough_dielectric_bsdf (bsdf/dielectric.art:35,190)
             return lerp_col(Col{ mat->p[2], mat->p[3], mat->p[4] }, Col{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
         case IG_BSDF_CONDUCTOR: { // compute_albedo (bsdf/conductor.art:50-56), kd = black
             const float c = abs_cos(out_dir, N);
@@ -1050,6 +1144,8 @@ struct BsdfCtx {
                 return principled().eval(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PLASTIC)
                 return Plastic(*mat, surf.local, kd).eval(in_dir, out_dir);
+            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+                return RoughDielectric(*mat, surf.local, surf.entering).eval(in_dir, out_dir);
         }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return kd * (pos_cos(in_dir, N) * kInvPi);
@@ -1077,6 +1173,8 @@ struct BsdfCtx {
                 return principled().pdf(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PLASTIC)
                 return Plastic(*mat, surf.local, kd).pdf(in_dir, out_dir);
+            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+                return RoughDielectric(*mat, surf.local, surf.entering).pdf(in_dir, out_dir);
         }
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return pos_cos(in_dir, surf.local.c2) / kPi;
@@ -1095,6 +1193,10 @@ struct BsdfCtx {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
                 sdelta = false;
                 return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
+            }
+            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) {
+                sdelta = false;
+                return RoughDielectric(*mat, surf.local, surf.entering).sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
             }
             if (mat->bsdf_type == IG_BSDF_PLASTIC) {
                 s_eta = 1;

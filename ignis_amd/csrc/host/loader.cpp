@@ -748,10 +748,10 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
         if (m.p[3] > 1.1920928955e-07f)
             fail("BSDF '" + name + "': rough (Oren-Nayar) diffuse is not supported by the HIP backend");
-    } else if (type == "dielectric" || type == "glass") {
+    } else if (type == "dielectric" || type == "glass" || type == "roughdielectric" || type == "thindielectric") {
         // DielectricBSDF.cpp:13-41; IOR table BSDF.cpp:7-30 (vacuum 1.0, bk7 1.5046)
-        if (bsdf->has("roughness") || bsdf->has("alpha") || bsdf->has("roughness_u") || bsdf->has("alpha_u"))
-            fail("BSDF '" + name + "': rough dielectrics are not supported by the HIP backend");
+        if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
+            fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
         if (bsdf->has("ext_ior_material") || bsdf->has("int_ior_material"))
             fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
         m.bsdf_type = IG_BSDF_DIELECTRIC;
@@ -761,8 +761,24 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         const V3 kt = getColor(*bsdf, "specular_transmittance", V3(1, 1, 1), name);
         m.p[2] = ks.x, m.p[3] = ks.y, m.p[4] = ks.z;
         m.p[5] = kt.x, m.p[6] = kt.y, m.p[7] = kt.z;
-        if (bsdf->getBool("thin", false))
-            m.flags |= IG_MAT_THIN;
+        {
+            // BSDF::setupRoughness (BSDF.cpp:53-99) -> make_dielectric_bsdf (dielectric.art:193-206): a rough interface unless the
+            // distribution is a delta one (no roughness given, or alpha <= 1e-4); rough + thin is rough (dielectric.art:202)
+            const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
+            const float r           = getConstNumber(*bsdf, rname, 0.1f, name);
+            const float an          = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
+            const float aspect      = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+            const float au = r / aspect, av = r * aspect;
+            if (bsdf->has(rname) && au > 1e-4f && av > 1e-4f) {
+                m.bsdf_type       = IG_BSDF_ROUGH_DIELECTRIC;
+                const float alpha = au < av ? au : av;
+                m.p[8]            = alpha <= 0.01f ? 1e-3f : (alpha <= 0.1f ? 1e-4f : 1e-5f); // pdf_eps (dielectric.art:67-82)
+                m.p[9]            = au;
+                m.p[10]           = av;
+            } else if (bsdf->getBool("thin", false)) {
+                m.flags |= IG_MAT_THIN;
+            }
+        }
     } else if (type == "conductor" || type == "roughconductor" || type == "mirror") {
         // ConductorBSDF.cpp:13-34 (defaults: material "none" = eta 0, k 1, BSDF.cpp:41), roughness via
         // BSDF::setupRoughness (BSDF.cpp:53-99): VNDF-GGX, compute_explicit(roughness, anisotropic)

@@ -87,6 +87,7 @@ enum ig_bsdf_type {
     IG_BSDF_DIELECTRIC = 1, /* src/artic/bsdf/dielectric.art:15-37, runtime/bsdf/DielectricBSDF.cpp:13-41 */
     IG_BSDF_CONDUCTOR  = 2, /* src/artic/bsdf/conductor.art:47-141, runtime/bsdf/ConductorBSDF.cpp:13-34 */
     IG_BSDF_PRINCIPLED = 3, /* src/artic/bsdf/principled.art:236-481, runtime/bsdf/PrincipledBSDF.cpp:14-98 */
+    IG_BSDF_ROUGH_DIELECTRIC = 5, /* src/artic/bsdf/dielectric.art:64-191 (make_dielectric_bsdf with a rough interface) */
     IG_BSDF_PLASTIC    = 4, /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */
 };
 
@@ -117,6 +118,7 @@ typedef struct ig_material {
      *             p[9] alpha_u, p[10] alpha_v
      * bump:       p[11] strength
      * checker:    q[0..2] color0, q[3..5] color1, q[6] scale_x, q[7] scale_y
+     * rough dielectric: as dielectric, plus p[8] pdf epsilon (dielectric.art:67-82), p[9] alpha_u, p[10] alpha_v
      * plastic:    p[0..2] diffuse_reflectance (or checker / image), p[3] ext_ior, p[4] int_ior,
      *             p[6..8] specular_reflectance, p[9] alpha_u, p[10] alpha_v (IG_MAT_SMOOTH: mirror coating)
      * principled: p[0..2] base_color (or checker / image like the diffuse reflectance), p[3] reflective_ior,

@@ -953,6 +953,108 @@ struct BsdfSample {
     bool is_delta;
 };
 
+// make_rough_dielectric_bsdf (bsdf/dielectric.art:64-191) over the VNDF-GGX distribution of the surface frame
+struct RoughDielectric {
+    Vec3 N;
+    float eta, pdf_eps;
+    Color ks, kt;
+    GGX micro;
+    static constexpr float cos_eps = 1e-5f;
+
+    RoughDielectric(const ig_material& m, const SurfaceElement& surf)
+    {
+        N       = surf.local.col[2];
+        eta     = surf.is_entering ? m.p[0] / m.p[1] : m.p[1] / m.p[0];
+        pdf_eps = m.p[8];
+        ks      = Color{ m.p[2], m.p[3], m.p[4] };
+        kt      = Color{ m.p[5], m.p[6], m.p[7] };
+        micro   = GGX{ surf.local, m.p[9], m.p[10] };
+    }
+    Color eval(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const float cos_i = vec3_dot(N, in_dir);
+        const float cos_o = vec3_dot(N, out_dir);
+        if (igm_abs(cos_i * cos_o) <= cos_eps)
+            return Color{ 0, 0, 0 };
+        const bool is_transmission = igm_signbit(cos_i * cos_o);
+        const Vec3 H        = is_transmission ? vec3_halfway_refractive(in_dir, out_dir, eta) : vec3_halfway(in_dir, out_dir);
+        const float cos_h_i = vec3_dot(H, in_dir);
+        const float cos_h_o = vec3_dot(H, out_dir);
+        if (igm_abs(cos_h_i * cos_h_o) <= cos_eps)
+            return Color{ 0, 0, 0 };
+        const float fterm = fresnel_dielectric(eta, igm_abs(cos_h_o));
+        const float D     = micro.D(H);
+        const float G     = micro.G1(in_dir) * micro.G1(out_dir);
+        if (!is_transmission) {
+            const float jacob = halfway_reflective_jacobian(cos_o);
+            return color_mulf(ks, fterm * D * G * igm_abs(jacob));
+        }
+        const float jacob = halfway_refractive_jacobian(eta, cos_h_i, cos_h_o);
+        const float norm  = igm_abs(safe_div(cos_h_o * jacob, cos_o));
+        return color_mulf(kt, (1 - fterm) * D * G * norm);
+    }
+    float pdf(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const float cos_i = vec3_dot(N, in_dir);
+        const float cos_o = vec3_dot(N, out_dir);
+        if (igm_abs(cos_i * cos_o) <= cos_eps)
+            return 0;
+        const bool is_transmission = igm_signbit(cos_i * cos_o);
+        const Vec3 H        = is_transmission ? vec3_halfway_refractive(in_dir, out_dir, eta) : vec3_halfway(in_dir, out_dir);
+        const float cos_h_i = vec3_dot(H, in_dir);
+        const float cos_h_o = vec3_dot(H, out_dir);
+        if (igm_abs(cos_h_i * cos_h_o) <= cos_eps)
+            return 0;
+        const float fterm = fresnel_dielectric(eta, igm_abs(cos_h_o));
+        const float mpdf  = micro.pdf(out_dir, H);
+        if (mpdf <= pdf_eps)
+            return 0;
+        if (!is_transmission)
+            return fterm * mpdf * igm_abs(halfway_reflective_jacobian(cos_h_o));
+        return (1 - fterm) * mpdf * igm_abs(halfway_refractive_jacobian(eta, cos_h_i, cos_h_o));
+    }
+    bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        const float cos_o = vec3_dot(N, out_dir);
+        if (igm_abs(cos_o) <= cos_eps)
+            return false;
+        const Vec3 m     = micro.sample(rnd, out_dir);
+        const float mpdf = micro.pdf(out_dir, m);
+        if (vec3_len2(m) <= flt_eps || mpdf <= pdf_eps)
+            return false;
+        const Vec3 oH       = vec3_normalize(m);
+        const Vec3 H        = igm_signbit(vec3_dot(oH, out_dir)) ? vec3_neg(oH) : oH;
+        const float cos_h_o = vec3_dot(H, out_dir);
+        if (igm_abs(cos_h_o) <= cos_eps)
+            return false;
+        float cos_t = 0, factor = 1;
+        if (!fresnel(eta, cos_h_o, cos_t, factor)) {
+            cos_t  = 0;
+            factor = 1;
+        }
+        Vec3 in_dir;
+        float sel_pdf;
+        if (rnd.next_f32() > factor) {
+            in_dir            = vec3_normalize(vec3_refract(out_dir, H, eta, cos_h_o, cos_t));
+            const float jacob = halfway_refractive_jacobian(eta, vec3_dot(H, in_dir), cos_h_o);
+            sel_pdf           = (1 - factor) * igm_abs(jacob);
+        } else {
+            in_dir            = vec3_normalize(vec3_reflect(out_dir, H));
+            const float jacob = halfway_reflective_jacobian(cos_h_o);
+            sel_pdf           = factor * igm_abs(jacob);
+        }
+        const float cos_i          = vec3_dot(N, in_dir);
+        const float f_pdf          = mpdf * sel_pdf;
+        const bool is_transmission = igm_signbit(cos_i * cos_o);
+        s.in_dir   = in_dir;
+        s.pdf      = f_pdf;
+        s.color    = color_mulf(eval(in_dir, out_dir), safe_div(1, f_pdf)); // adjoint = false
+        s.eta      = !is_transmission ? 1.0f : eta;
+        s.is_delta = false;
+        return true;
+    }
+};
+
 // fresnel_diffuse_factor (core/fresnel.art:42-63)
 static inline float fresnel_diffuse_factor(float eta)
 {
@@ -1123,7 +1225,7 @@ struct Bsdf {
     Color albedo(Vec3 out_dir) const
     {
         const Vec3 N = surf->local.col[2];
-        if (mat->bsdf_type == IG_BSDF_DIELECTRIC) // make_pure_dielectric_bsdf (dielectric.art:35)
+        if (mat->bsdf_type == IG_BSDF_DIELECTRIC || mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) // dielectric.art:35,190
             return color_lerp(Color{ mat->p[2], mat->p[3], mat->p[4] }, Color{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) { // compute_albedo (conductor.art:50-56), kd = black
             const Color F = conductor_fresnel(absolute_cos(out_dir, N));
@@ -1149,6 +1251,8 @@ struct Bsdf {
             return Principled(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
             return Plastic(*mat, *surf, kd()).eval(in_dir, out_dir);
+        if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+            return RoughDielectric(*mat, *surf).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return color_mulf(kd(), positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -1176,6 +1280,8 @@ struct Bsdf {
             return Principled(*mat, *surf, kd()).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
             return Plastic(*mat, *surf, kd()).pdf(in_dir, out_dir);
+        if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+            return RoughDielectric(*mat, *surf).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE)
             return cosine_hemisphere_pdf(positive_cos(in_dir, surf->local.col[2]));
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
@@ -1194,6 +1300,8 @@ struct Bsdf {
         }
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
             return Plastic(*mat, *surf, kd()).sample(rnd, out_dir, s);
+        if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+            return RoughDielectric(*mat, *surf).sample(rnd, out_dir, s);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
             const float u      = rnd.next_f32();
             const float v      = rnd.next_f32();

@@ -877,3 +877,17 @@ def test_mesh_area_lights_vs_oracle(gpu_device):
         sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
         assert sorted(l.type for l in sc.scene.lights[:3]) == [0, 8, 8]
         _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=29, iters=2)
+
+
+def test_rough_dielectric_vs_oracle(gpu_device):
+    """Frosted diamonds (rough and anisotropic dielectric interfaces, refraction in and out, total internal reflection)."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["bsdfs"][3] = {"type": "dielectric", "name": "mat-Diamond", "int_ior": 2.3, "roughness": 0.2, "anisotropic": 0.4}
+    s["bsdfs"].append({"type": "roughdielectric", "name": "mat-Frost", "int_ior": 1.5, "alpha": 0.06, "specular_transmittance": [0.8, 0.9, 1.0]})
+    for e in s["entities"]:
+        if e["name"] == "Diamond2":
+            e["bsdf"] = "mat-Frost"
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    tot = _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=31, iters=2)
+    assert tot["shadow_rays"] > tot["camera_rays"]  # rough interfaces take next event estimation, unlike the delta ones
