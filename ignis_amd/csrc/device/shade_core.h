@@ -1113,7 +1113,9 @@ struct BsdfCtx {
         const f3 N = surf.local.c2;
         switch (mat->bsdf_type) {
         case IG_BSDF_ROUGH_DIELECTRIC:
-        case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf / make_rough_dielectric_bsdf (bsdf/dielectric.art:35,190)
+        case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf / make_rough_dielectric_bsdf (bsdf/dielectric.art:35,190); thin: ks (:60)
+            if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN))
+                return Col{ mat->p[2], mat->p[3], mat->p[4] };
             return lerp_col(Col{ mat->p[2], mat->p[3], mat->p[4] }, Col{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
         case IG_BSDF_CONDUCTOR: { // compute_albedo (bsdf/conductor.art:50-56), kd = black
             const float c = abs_cos(out_dir, N);
@@ -1250,6 +1252,25 @@ struct BsdfCtx {
             s_eta           = 1;
             sdelta          = false;
             return true;
+        }
+        if constexpr (FULL) {
+            if (mat->flags & IG_MAT_THIN) {
+                // make_thin_dielectric_bsdf (bsdf/dielectric.art:40-61): always from outside to inside
+                const float kk    = mat->p[0] / mat->p[1];
+                const float fterm = fresnel_dielectric(kk, abs_cos(out_dir, N));
+                const float F     = fterm + (1 - fterm) * fterm / (fterm + 1);
+                if (rnd.f32() > F) {
+                    in_dir = -out_dir;
+                    color  = Col{ mat->p[5], mat->p[6], mat->p[7] };
+                } else {
+                    in_dir = normalize3(N * (2 * dot3(N, out_dir)) - out_dir);
+                    color  = Col{ mat->p[2], mat->p[3], mat->p[4] };
+                }
+                pdf_out = 1;
+                s_eta   = 1;
+                sdelta  = true;
+                return true;
+            }
         }
         // make_pure_dielectric_bsdf.sample (bsdf/dielectric.art:18-34); n1 = ext_ior, n2 = int_ior
         const float n1 = mat->p[0], n2 = mat->p[1];

@@ -1225,6 +1225,8 @@ struct Bsdf {
     Color albedo(Vec3 out_dir) const
     {
         const Vec3 N = surf->local.col[2];
+        if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN)) // make_thin_dielectric_bsdf (dielectric.art:60)
+            return Color{ mat->p[2], mat->p[3], mat->p[4] };
         if (mat->bsdf_type == IG_BSDF_DIELECTRIC || mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) // dielectric.art:35,190
             return color_lerp(Color{ mat->p[2], mat->p[3], mat->p[4] }, Color{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) { // compute_albedo (conductor.art:50-56), kd = black
@@ -1350,6 +1352,24 @@ struct Bsdf {
             s.color    = color_mulf(eval(in_dir, out_dir), safe_div(1, s.pdf));
             s.eta      = 1;
             s.is_delta = false;
+            return true;
+        }
+        if (mat->flags & IG_MAT_THIN) {
+            // make_thin_dielectric_bsdf (bsdf/dielectric.art:40-61): always from outside to inside
+            const float kk    = mat->p[0] / mat->p[1];
+            const Vec3 Nn     = surf->local.col[2];
+            const float fterm = fresnel_dielectric(kk, absolute_cos(out_dir, Nn));
+            const float F     = fterm + (1 - fterm) * fterm / (fterm + 1);
+            if (rnd.next_f32() > F) {
+                s.in_dir = vec3_neg(out_dir);
+                s.color  = Color{ mat->p[5], mat->p[6], mat->p[7] };
+            } else {
+                s.in_dir = vec3_normalize(vec3_reflect(out_dir, Nn));
+                s.color  = Color{ mat->p[2], mat->p[3], mat->p[4] };
+            }
+            s.pdf      = 1;
+            s.eta      = 1;
+            s.is_delta = true;
             return true;
         }
         // make_pure_dielectric_bsdf (bsdf/dielectric.art:15-37); n1 = ext_ior, n2 = int_ior

@@ -891,3 +891,13 @@ def test_rough_dielectric_vs_oracle(gpu_device):
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     tot = _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=31, iters=2)
     assert tot["shadow_rays"] > tot["camera_rays"]  # rough interfaces take next event estimation, unlike the delta ones
+
+
+def test_thin_dielectric_vs_oracle(gpu_device):
+    """make_thin_dielectric_bsdf: straight-through transmission or mirror reflection with the two-interface Fresnel term."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["bsdfs"][3] = {"type": "dielectric", "name": "mat-Diamond", "int_ior": 1.5, "thin": True, "specular_transmittance": [0.9, 1, 0.9]}
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sc.scene.materials[3].flags & 1
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=33, iters=2)

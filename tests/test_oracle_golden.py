@@ -875,3 +875,22 @@ def test_rough_dielectric_sampling_is_coherent():
         assert agree.mean() > (0.97 if entering else 0.85)  # measured 0.975 / 0.885 for alpha 0.3
         np.testing.assert_allclose(col, w[ok] * spdf[ok][:, None], rtol=2e-5, atol=1e-9)
         assert np.quantile(w[ok], 0.8) <= 1.3 and w[ok].mean() > 0.5  # VNDF sampling: weights stay near the transmittance / reflectance
+
+
+def test_thin_dielectric_samples():
+    """dielectric.art:40-61: either -out_dir with kt or the mirror direction with ks, the reflection share being
+    F + (1 - F) F / (F + 1) of the single-interface Fresnel term; eta stays 1."""
+    s = flat_scene()
+    s["bsdfs"] = [{"type": "thindielectric", "name": "ground", "int_ior": 1.5, "thin": True, "specular_reflectance": [1, 0.5, 0.25], "specular_transmittance": [0.2, 0.4, 0.8]}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 8, 8)
+    wo = _unit([0.6, 0.0, 0.8])
+    wi, pdf, w, eta = oracle.bsdf_sample(sc, 0, wo, 50000, seed=3)
+    assert np.all(pdf == 1) and np.all(eta == 1)
+    through = np.all(np.isclose(wi, -wo, atol=1e-6), axis=1)
+    mirror = np.all(np.isclose(wi, wo * np.float32([-1, -1, 1]), atol=1e-6), axis=1)
+    assert np.all(through | mirror)
+    assert np.all(w[through] == np.float32([0.2, 0.4, 0.8])) and np.all(w[mirror] == np.float32([1, 0.5, 0.25]))
+    k, c = 1 / 1.5, 0.8
+    ct = np.sqrt(1 - (1 - c * c) * k * k)
+    f = (((k * c - ct) / (k * c + ct)) ** 2 + ((c - k * ct) / (c + k * ct)) ** 2) / 2
+    assert mirror.mean() == pytest.approx(f + (1 - f) * f / (f + 1), abs=0.006)
