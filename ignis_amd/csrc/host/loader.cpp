@@ -194,6 +194,109 @@ static Affine getTransform(const JsonValue& parent, const char* key = "transform
 // The reference evaluates colour properties through PExpr (ShadingTree). Only
 // constants are lowered here: a number, [r,g,b], or the literal "color(r,g,b)"
 // form the in-tree scenes use; anything else is refused.
+// Constant PExpr expressions as the scene exporters write them ("color(r, g, b, a)", "(color(...) * 100.0)", "2 * 0.5"):
+// numbers, color(...) / vec3(...), + - * /, unary minus, parentheses; a scalar broadcasts. Anything with variables, textures
+// or other functions is not constant and is refused by the caller.
+struct ConstExpr {
+    const std::string& s;
+    size_t pos = 0;
+    bool ok    = true;
+    struct Val {
+        V3 v;
+        bool scalar;
+    };
+    explicit ConstExpr(const std::string& text)
+        : s(text)
+    {
+    }
+    bool eat(char c)
+    {
+        if (pos < s.size() && s[pos] == c) {
+            ++pos;
+            return true;
+        }
+        return false;
+    }
+    Val primary()
+    {
+        if (eat('(')) {
+            const Val v = sum();
+            ok &= eat(')');
+            return v;
+        }
+        for (const char* fn : { "color(", "vec3(" })
+            if (s.compare(pos, std::strlen(fn), fn) == 0) {
+                pos += std::strlen(fn);
+                float c[4] = { 0, 0, 0, 1 };
+                int n      = 0;
+                do {
+                    const Val a = sum();
+                    ok &= a.scalar && n < 4;
+                    if (n < 4)
+                        c[n] = a.v.x;
+                    ++n;
+                } while (ok && eat(','));
+                ok &= eat(')') && n >= 3;
+                return Val{ V3(c[0], c[1], c[2]), false };
+            }
+        const char* begin = s.c_str() + pos;
+        char* end         = nullptr;
+        const float f     = std::strtof(begin, &end);
+        if (end == begin || !(std::isdigit((unsigned char)*begin) || *begin == '.')) {
+            ok = false;
+            return Val{ V3(0, 0, 0), true };
+        }
+        pos += (size_t)(end - begin);
+        return Val{ V3(f, f, f), true };
+    }
+    Val unary()
+    {
+        if (eat('-')) {
+            const Val v = unary();
+            return Val{ V3(-v.v.x, -v.v.y, -v.v.z), v.scalar };
+        }
+        eat('+');
+        return primary();
+    }
+    Val product()
+    {
+        Val a = unary();
+        while (ok && pos < s.size() && (s[pos] == '*' || s[pos] == '/')) {
+            const char op = s[pos++];
+            const Val b   = unary();
+            a = op == '*' ? Val{ V3(a.v.x * b.v.x, a.v.y * b.v.y, a.v.z * b.v.z), a.scalar && b.scalar }
+                          : Val{ V3(a.v.x / b.v.x, a.v.y / b.v.y, a.v.z / b.v.z), a.scalar && b.scalar };
+        }
+        return a;
+    }
+    Val sum()
+    {
+        Val a = product();
+        while (ok && pos < s.size() && (s[pos] == '+' || s[pos] == '-')) {
+            const char op = s[pos++];
+            const Val b   = product();
+            a = op == '+' ? Val{ V3(a.v.x + b.v.x, a.v.y + b.v.y, a.v.z + b.v.z), a.scalar && b.scalar }
+                          : Val{ V3(a.v.x - b.v.x, a.v.y - b.v.y, a.v.z - b.v.z), a.scalar && b.scalar };
+        }
+        return a;
+    }
+    static bool evaluate(const std::string& text, V3& out)
+    {
+        std::string compact;
+        for (char c : text)
+            if (!std::isspace((unsigned char)c))
+                compact += c;
+        if (compact.empty())
+            return false;
+        ConstExpr e(compact);
+        const Val v = e.sum();
+        if (!e.ok || e.pos != compact.size())
+            return false;
+        out = v.v;
+        return true;
+    }
+};
+
 static bool parseConstColor(const JsonValue& v, V3& out)
 {
     if (v.isNumber()) {
@@ -204,29 +307,8 @@ static bool parseConstColor(const JsonValue& v, V3& out)
         out = V3((float)v.arr[0].num, (float)v.arr[1].num, (float)v.arr[2].num);
         return true;
     }
-    if (v.isString()) {
-        std::string s;
-        for (char c : v.str)
-            if (!std::isspace((unsigned char)c))
-                s += c;
-        if (s.rfind("color(", 0) == 0 && s.back() == ')') {
-            std::stringstream ss(s.substr(6, s.size() - 7));
-            std::string tok;
-            float vals[3];
-            int n = 0;
-            while (std::getline(ss, tok, ',') && n < 3) {
-                char* end = nullptr;
-                vals[n]   = std::strtof(tok.c_str(), &end);
-                if (end == tok.c_str() || *end != '\0')
-                    return false;
-                ++n;
-            }
-            if (n == 3 && !std::getline(ss, tok, ',')) {
-                out = V3(vals[0], vals[1], vals[2]);
-                return true;
-            }
-        }
-    }
+    if (v.isString())
+        return ConstExpr::evaluate(v.str, out);
     return false;
 }
 
@@ -497,6 +579,42 @@ static bool lowerCheckerboard(const JsonValue& prop, const JsonValue& textures, 
 {
     if (!prop.isString())
         return false;
+    {
+        // The exporters' inline form "select(checkerboard(uvw * S) == 1, A, B)": node_checkerboard3 (texture/checkerboard.art:2)
+        // with w = 0 is 1 exactly where the parities of floor(S u) and floor(S v) differ, i.e. make_checkerboard_texture with
+        // scale (S, S), color0 = A, color1 = B.
+        std::string e;
+        for (char c : prop.str)
+            if (!std::isspace((unsigned char)c))
+                e += c;
+        const std::string head = "select(checkerboard(uvw*";
+        if (e.compare(0, head.size(), head) == 0 && e.back() == ')') {
+            char* end         = nullptr;
+            const float scale = std::strtof(e.c_str() + head.size(), &end);
+            const std::string mid = ")==1,";
+            const size_t at       = (size_t)(end - e.c_str());
+            if (end != e.c_str() + head.size() && e.compare(at, mid.size(), mid) == 0) {
+                const std::string args = e.substr(at + mid.size(), e.size() - at - mid.size() - 1);
+                int depth = 0;
+                size_t comma = std::string::npos;
+                for (size_t i = 0; i < args.size(); ++i) {
+                    depth += args[i] == '(' ? 1 : (args[i] == ')' ? -1 : 0);
+                    if (args[i] == ',' && depth == 0) {
+                        comma = i;
+                        break;
+                    }
+                }
+                V3 a, b;
+                if (comma != std::string::npos && ConstExpr::evaluate(args.substr(0, comma), a) && ConstExpr::evaluate(args.substr(comma + 1), b)) {
+                    m.flags |= IG_MAT_CHECKER;
+                    m.q[0] = a.x, m.q[1] = a.y, m.q[2] = a.z;
+                    m.q[3] = b.x, m.q[4] = b.y, m.q[5] = b.z;
+                    m.q[6] = m.q[7] = scale;
+                    return true;
+                }
+            }
+        }
+    }
     for (const auto& t : textures.arr) {
         if (t.getString("name") != prop.str)
             continue;

@@ -462,3 +462,24 @@ def test_mitsuba_serialized_meshes(tmp_path, version, double):
     open(path, "wb").write(b"\x00" * 32)
     with pytest.raises(RuntimeError, match="not a Mitsuba serialized file"):
         LoadedScene.from_string(json.dumps(s))
+
+
+def test_constant_expressions_and_the_inline_checkerboard_idiom():
+    """Exporter-style strings: constant PExpr arithmetic is folded; "select(checkerboard(uvw * S) == 1, A, B)" is the checkerboard
+    texture with scale (S, S), color0 = A, color1 = B (texture/checkerboard.art:1-12); anything else is still refused."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene([{"type": "point", "name": "P", "position": [0, 0, -1], "intensity": "(color(1.0, 0.5, 0.25, 1.0) * 100.0) / 4 - 0.5"}])
+    s["bsdfs"][0]["reflectance"] = "select(checkerboard(uvw * 10.0) == 1, color(0.8, 0.7, 0.6, 1.0), color(0.2, 0.2, 0.2, 1.0) * 0.5)"
+    a = LoadedScene.from_string(json.dumps(s))
+    assert list(a.scene.lights[0].d[4:7]) == pytest.approx([24.5, 12.0, 5.75], rel=1e-6)
+    m = a.scene.materials[0]
+    assert m.flags & 4 and list(m.q) == pytest.approx([0.8, 0.7, 0.6, 0.1, 0.1, 0.1, 10, 10])
+    s["textures"] = [{"type": "checkerboard", "name": "chk", "scale_x": 10, "scale_y": 10, "color0": [0.8, 0.7, 0.6], "color1": [0.1, 0.1, 0.1]}]
+    s["bsdfs"][0]["reflectance"] = "chk"
+    b = LoadedScene.from_string(json.dumps(s))
+    assert bytes(a.scene.materials[0]) == bytes(b.scene.materials[0])
+    for bad in ("select(checkerboard(uvw * 10.0) == 1, some_texture, color(0,0,0,1))", "color(1, 1)", "uv.x * 2", "color(1,1,1,1) *"):
+        s["bsdfs"][0]["reflectance"] = bad
+        with pytest.raises(RuntimeError, match="not a constant colour"):
+            LoadedScene.from_string(json.dumps(s))
