@@ -726,6 +726,71 @@ struct TextureBank {
     }
 };
 
+// ---- sun position (LoaderUtils::getEA, src/runtime/loader/LoaderUtils.cpp:66-105)
+struct SunAngles {
+    float elevation, azimuth; // radians; azimuth west of south (skysun/ElevationAzimuth.h)
+    V3 direction() const      // toDirectionYUp (ElevationAzimuth.h:22-30)
+    {
+        return V3(-std::cos(elevation) * std::sin(azimuth), std::sin(elevation), -std::cos(elevation) * std::cos(azimuth));
+    }
+};
+
+// The PSA solar position algorithm (Blanco-Muriel et al., "Computing the Solar Vector", Solar Energy 70(5), 2001) as the
+// reference evaluates it (skysun/SunLocation.cpp:20-37,58-125): single-precision Julian date and decimal hours, the rest
+// in double; local time = UTC - timezone, longitude in degrees west.
+static SunAngles sunFromTimeAndPlace(int year, int month, int day, int hour, int minute, float seconds, float latitude, float longitude, float timezone)
+{
+    const float dec_hours = hour + timezone + (minute + seconds / 60.0f) / 60.0f;
+    const int m14         = (month - 14) / 12;
+    const int jdn = (1461 * (year + 4800 + m14)) / 4 + (367 * (month - 2 - 12 * m14)) / 12 - (3 * ((year + 4900 + m14) / 100)) / 4 + day - 32075;
+    const float julian = (float)jdn - 0.5f + dec_hours / 24.0f;
+    const double n     = julian - 2451545.0f; // days since noon, 1 January 2000
+    const double hours = dec_hours;
+
+    const double omega     = 2.1429 - 0.0010394594 * n;
+    const double mean_long = 4.8950630 + 0.017202791698 * n;
+    const double anomaly   = 6.2400600 + 0.0172019699 * n;
+    const double ecl_long  = mean_long + 0.03341607 * std::sin(anomaly) + 0.00034894 * std::sin(2 * anomaly) - 0.0001134 - 0.0000203 * std::sin(omega);
+    const double obliquity = 0.4090928 - 6.2140e-9 * n + 0.0000396 * std::cos(omega);
+
+    const double sin_long = std::sin(ecl_long);
+    double right_asc      = std::atan2(std::cos(obliquity) * sin_long, std::cos(ecl_long));
+    if (right_asc < 0)
+        right_asc += 2 * Pi;
+    const double declination = std::asin(std::sin(obliquity) * sin_long);
+
+    const double gmst       = 6.6974243242 + 0.0657098283 * n + hours;
+    const double lmst       = Deg2Rad * ((float)(gmst * 15 - longitude));
+    const double lat        = Deg2Rad * latitude;
+    const double hour_angle = lmst - right_asc;
+    double zenith           = std::acos(std::cos(lat) * std::cos(hour_angle) * std::cos(declination) + std::sin(declination) * std::sin(lat));
+    double azimuth          = std::atan2(-std::sin(hour_angle), std::tan(declination) * std::cos(lat) - std::sin(lat) * std::cos(hour_angle));
+    if (azimuth < 0)
+        azimuth += 2 * Pi;
+    zenith += (6371.01 / 149597890.0) * std::sin(zenith); // parallax
+    return SunAngles{ Pi / 2 - (float)zenith, std::fmod((float)azimuth + Pi, 2 * Pi) };
+}
+
+// direction / sun_direction (through elevation and azimuth, as the reference does), elevation + azimuth, or time and place
+static SunAngles getSunAngles(const JsonValue& l)
+{
+    const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);
+    if (key) {
+        V3 d           = getVector3(*l.find(key), key);
+        const float dl = std::sqrt(dot(d, d));
+        d              = dl > 0 ? d * (1 / dl) : V3(0, 0, 1);
+        float azimuth  = std::atan2(-d.x, -d.z); // fromDirectionYUp (ElevationAzimuth.h:15-20)
+        if (azimuth < 0)
+            azimuth += 2 * Pi;
+        return SunAngles{ Pi / 2 - std::acos(d.y), azimuth };
+    }
+    if (l.has("elevation") || l.has("azimuth"))
+        return SunAngles{ l.getNumber("elevation", 0.0f), l.getNumber("azimuth", 0.0f) };
+    return sunFromTimeAndPlace(l.getInt("year", 2020), l.getInt("month", 5), l.getInt("day", 6), l.getInt("hour", 12), l.getInt("minute", 0),
+                               l.getNumber("seconds", 0.0f), l.getNumber("latitude", 49.235422f), l.getNumber("longitude", -6.9965744f),
+                               l.getNumber("timezone", -2.0f));
+}
+
 // ---- environment maps: texture baking and the sampling tables
 // One lookup of a packed bitmap texture the way the device does it (src/artic/texture/image.art:9-156 with the identity
 // transform): used to bake the radiance of an environment light (src/artic/entrypoints/bake.art:1-26).
@@ -1594,20 +1659,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             out.d[6] = gb;
             V3 sun(0, 0, 1); // LoaderUtils::getEA default direction
             if (kind == IG_CIE_CLEAR || kind == IG_CIE_INTERMEDIATE) {
-                const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);
-                if (!key && (l.has("elevation") || l.has("azimuth") || l.has("year") || l.has("hour") || l.has("latitude")))
-                    fail("Light '" + lname + "': only an explicit 'direction' / 'sun_direction' is supported by this loader");
-                if (key) {
-                    sun            = getVector3(*l.find(key), key);
-                    const float dl = std::sqrt(dot(sun, sun));
-                    sun            = dl > 0 ? sun * (1 / dl) : V3(0, 0, 1);
-                }
-                // ElevationAzimuth::fromDirectionYUp / toDirectionYUp (skysun/ElevationAzimuth.h:15-30)
-                float elevation     = Pi / 2 - std::acos(sun.y);
-                float azimuth       = std::atan2(-sun.x, -sun.z);
-                if (azimuth < 0)
-                    azimuth += 2 * Pi;
-                const V3 sun_dir(-std::cos(elevation) * std::sin(azimuth), std::sin(elevation), -std::cos(elevation) * std::cos(azimuth));
+                const SunAngles ea = getSunAngles(l);
+                float elevation    = ea.elevation;
+                const V3 sun_dir   = ea.direction();
                 if (elevation > 87 * Deg2Rad)
                     elevation = 87 * Deg2Rad;
                 const bool clear      = kind == IG_CIE_CLEAR;
@@ -1647,10 +1701,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             infinite.push_back(out);
         } else if (type == "sun") {
             // SunLight.cpp:11-57, light/sun.art:1-48: an infinite cone light; direction = from the scene towards the sun
-            const char* key = l.has("direction") ? "direction" : (l.has("sun_direction") ? "sun_direction" : nullptr);
-            if (!key)
-                fail("Light '" + lname + "': only an explicit 'direction' / 'sun_direction' is supported by this loader");
-            V3 dir           = getVector3(*l.find(key), key);
+            V3 dir           = getSunAngles(l).direction();
             const float dl   = std::sqrt(dot(dir, dir));
             dir              = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
             const float angle = getConstNumber(l, "angle", 0.533f, lname); // flt_sun_radius_deg

@@ -483,3 +483,36 @@ def test_constant_expressions_and_the_inline_checkerboard_idiom():
         s["bsdfs"][0]["reflectance"] = bad
         with pytest.raises(RuntimeError, match="not a constant colour"):
             LoadedScene.from_string(json.dumps(s))
+
+
+def test_sun_position_from_time_and_place():
+    """LoaderUtils::getEA without a direction: the PSA algorithm on the light's date, time and place (defaults: 6 May 2020 12:00,
+    49.24 N, 7.00 E, UTC+2). Checked against textbook solar geometry (Cooper's declination, hour angle from UTC and longitude;
+    good to about a degree) and for the obvious symmetries."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+
+    def sun(**kw):
+        s = flat_scene([dict({"type": "cie_clear", "name": "sky"}, **kw)])
+        sc = LoadedScene.from_string(json.dumps(s))
+        d = np.float64(list(sc.scene.lights[0].d[9:12]))
+        return d
+
+    def textbook(day_of_year, utc_hours, lat, lon_east):
+        decl = np.radians(23.45) * np.sin(2 * np.pi * (284 + day_of_year) / 365)
+        b = 2 * np.pi * (day_of_year - 81) / 364
+        eot = 9.87 * np.sin(2 * b) - 7.53 * np.cos(b) - 1.5 * np.sin(b)  # minutes
+        h = np.radians(15 * (utc_hours + lon_east / 15 + eot / 60 - 12))
+        la = np.radians(lat)
+        return np.degrees(np.arcsin(np.sin(la) * np.sin(decl) + np.cos(la) * np.cos(decl) * np.cos(h)))
+
+    d = sun()
+    assert np.linalg.norm(d) == pytest.approx(1, abs=1e-6)
+    assert np.degrees(np.arcsin(d[1])) == pytest.approx(textbook(127, 10.0, 49.235422, 6.9965744), abs=1.0)
+    assert d[2] < 0 and d[0] > 0  # before solar noon: east of south (south = -z, east = +x in the Y-up sky frame of ElevationAzimuth.h:22-30)
+    noon = sun(hour=13, minute=33)  # about solar noon at 7 E in summer time
+    assert abs(noon[0]) < 0.03 and noon[1] > d[1]
+    winter = sun(month=12, day=21)
+    assert np.degrees(np.arcsin(winter[1])) == pytest.approx(textbook(355, 10.0, 49.235422, 6.9965744), abs=1.0)
+    ea = sun(elevation=0.5, azimuth=0.25)
+    np.testing.assert_allclose(ea, [-np.cos(0.5) * np.sin(0.25), np.sin(0.5), -np.cos(0.5) * np.cos(0.25)], atol=1e-6)
