@@ -1552,10 +1552,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             finite.push_back(out);
         } else if (type == "spot") {
             // SpotLight.cpp:13-97, light/spot.art: position, direction, cutoff / falloff (degrees), intensity or power
-            if (!l.has("direction") || l.has("elevation") || l.has("azimuth"))
-                fail("Light '" + lname + "': only an explicit 'direction' is supported by this loader");
             const V3 pos     = l.has("position") ? getVector3(*l.find("position"), "position") : V3(0, 0, 0);
-            V3 dir           = getVector3(*l.find("direction"), "direction");
+            V3 dir           = l.has("direction") ? getVector3(*l.find("direction"), "direction") : getSunAngles(l).direction();
             const float dl   = std::sqrt(dot(dir, dir));
             dir              = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
             const float cutoff  = getConstNumber(l, "cutoff", 30.0f, lname) * Deg2Rad;
@@ -1575,9 +1573,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             finite.push_back(out);
         } else if (type == "directional" || type == "direction" || type == "distant") {
             // DirectionalLight.cpp, light/directional.art: an infinite delta light
-            if (!l.has("direction") || l.has("elevation") || l.has("azimuth"))
-                fail("Light '" + lname + "': only an explicit 'direction' is supported by this loader");
-            V3 dir         = getVector3(*l.find("direction"), "direction");
+            // LoaderUtils::getDirection: an explicit vector, or elevation / azimuth, or the sun of a date, time and place
+            V3 dir         = l.has("direction") ? getVector3(*l.find("direction"), "direction") : getSunAngles(l).direction();
             const float dl = std::sqrt(dot(dir, dir));
             dir            = dl > 0 ? dir * (1 / dl) : V3(0, 0, 1);
             const V3 irr   = getColor(l, "irradiance", V3(1, 1, 1), lname);
