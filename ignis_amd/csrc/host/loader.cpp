@@ -161,8 +161,24 @@ static void applyTransformOps(Affine& transform, const JsonValue& obj)
             if (!val.isArray())
                 fail("Expected transform matrix to be an array");
             transform = transform * fromMatrixArray(val);
+        } else if (name == "qrotate") {
+            // a quaternion (w, x, y, z), taken as a rotation the way Eigen's Transform *= Quaternion does (Parser.cpp:99-108,195-196)
+            if (!val.isArray() || val.arr.size() != 4)
+                fail("Expected vector of length 4");
+            float q[4];
+            for (int i = 0; i < 4; ++i) {
+                if (!val.arr[i].isNumber())
+                    fail("Given vector is not only numbers");
+                q[i] = (float)val.arr[i].num;
+            }
+            const float w = q[0], x = q[1], y = q[2], z = q[3];
+            Affine r;
+            r.L.m[0][0] = 1 - 2 * (y * y + z * z), r.L.m[0][1] = 2 * (x * y - w * z), r.L.m[0][2] = 2 * (x * z + w * y);
+            r.L.m[1][0] = 2 * (x * y + w * z), r.L.m[1][1] = 1 - 2 * (x * x + z * z), r.L.m[1][2] = 2 * (y * z - w * x);
+            r.L.m[2][0] = 2 * (x * z - w * y), r.L.m[2][1] = 2 * (y * z + w * x), r.L.m[2][2] = 1 - 2 * (x * x + y * y);
+            transform = transform * r;
         } else {
-            fail("Transform property got unknown entry type '" + name + "' (qrotate is not supported by this loader)");
+            fail("Transform property got unknown entry type '" + name + "'");
         }
     }
 }
@@ -1375,8 +1391,15 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     for (const auto& e : entities.arr) {
         const std::string ename = e.getString("name");
         const std::string bname = e.getString("bsdf");
-        if (bname.empty())
-            fail("Entity " + ename + " has no bsdf");
+        // LoaderEntity.cpp:47-55,108-113: an entity without a (known) bsdf or shape is reported and left out; the scene still loads
+        bool known = !bname.empty() && shape_ids.count(e.getString("shape")) != 0;
+        if (known) {
+            known = false;
+            for (const auto& b : bsdfs.arr)
+                known |= b.getString("name") == bname;
+        }
+        if (!known)
+            continue;
         if (e.has("inner_medium") || e.has("outer_medium"))
             fail("Entity " + ename + ": participating media are not supported by the HIP backend");
         if (area_light_of_entity.count(ename)) {

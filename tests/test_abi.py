@@ -516,3 +516,20 @@ def test_sun_position_from_time_and_place():
     assert np.degrees(np.arcsin(winter[1])) == pytest.approx(textbook(355, 10.0, 49.235422, 6.9965744), abs=1.0)
     ea = sun(elevation=0.5, azimuth=0.25)
     np.testing.assert_allclose(ea, [-np.cos(0.5) * np.sin(0.25), np.sin(0.5), -np.cos(0.5) * np.cos(0.25)], atol=1e-6)
+
+
+def test_qrotate_and_entities_without_known_parts():
+    """"qrotate" is a (w, x, y, z) quaternion; entities naming a missing bsdf or shape are left out, the scene still loads."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    a, b = flat_scene(), flat_scene()
+    h = np.sqrt(0.5)
+    a["entities"][0]["transform"] = {"translate": [1, 2, 3], "qrotate": [h, 0, 0, h]}  # 90 degrees about z
+    b["entities"][0]["transform"] = {"translate": [1, 2, 3], "rotate": [0, 0, 90]}
+    sa, sb = LoadedScene.from_string(json.dumps(a)), LoadedScene.from_string(json.dumps(b))
+    ea = np.ctypeslib.as_array(sa.scene.entities, shape=(36,))[:33]
+    eb = np.ctypeslib.as_array(sb.scene.entities, shape=(36,))[:33]
+    np.testing.assert_allclose(ea, eb, atol=1e-6)
+    a["entities"] += [{"name": "NoBsdf", "shape": "Bottom", "bsdf": "missing"}, {"name": "NoShape", "shape": "missing", "bsdf": "ground"}]
+    sc = LoadedScene.from_string(json.dumps(a))
+    assert sc.scene.entity_count == 1 and sc.entity_name(0) == "Bottom"
