@@ -350,7 +350,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const ig_material& mat = s->materials[m];
-        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR && mat.bsdf_type != IG_BSDF_PRINCIPLED && mat.bsdf_type != IG_BSDF_PLASTIC && mat.bsdf_type != IG_BSDF_ROUGH_DIELECTRIC)
+        if (mat.bsdf_type != IG_BSDF_DIFFUSE && mat.bsdf_type != IG_BSDF_DIELECTRIC && mat.bsdf_type != IG_BSDF_CONDUCTOR && mat.bsdf_type != IG_BSDF_PRINCIPLED && mat.bsdf_type != IG_BSDF_PLASTIC && mat.bsdf_type != IG_BSDF_ROUGH_DIELECTRIC && mat.bsdf_type != IG_BSDF_BLEND)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
         const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL)
                                                                               : (mat.bsdf_type == IG_BSDF_DIELECTRIC ? (uint32_t)IG_MAT_THIN : 0u);
@@ -358,6 +358,11 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " carries flags its BSDF type does not define" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
+        if (mat.bsdf_type == IG_BSDF_BLEND)
+            for (int k = 0; k < 2; ++k)
+                if (mat.pad[k] < 0 || mat.pad[k] >= (int32_t)s->material_count || s->materials[mat.pad[k]].bsdf_type == IG_BSDF_BLEND
+                    || (s->materials[mat.pad[k]].flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+                    throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: blend material " + std::to_string(m) + " has no valid inner materials" };
         const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED || mat.bsdf_type == IG_BSDF_PLASTIC; // p[0..2] reflectance / base colour
         if ((mat.flags & IG_MAT_IMAGE) && (!has_albedo || mat.tex_refl < 0 || mat.tex_refl >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: image-textured material " + std::to_string(m) + " has no valid texture or is neither diffuse nor principled" };
@@ -505,7 +510,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
-        d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC
+        d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
         if (s->lights[i].type != IG_LIGHT_MESH_AREA)

@@ -4,6 +4,8 @@
 // expression (citations inline); transcendental functions come from include/ig_detmath.h.
 #pragma once
 
+#include <type_traits>
+
 #include "dev_math.h"
 #include "kernels.h"
 
@@ -1077,11 +1079,33 @@ struct Plastic {
 };
 
 // FULL = false leaves the principled BSDF out of the kernel (scenes without one run the lean variant)
-template <bool FULL>
+// TOP = false: the context of a BSDF inside a blend (same surface, no further nesting)
+struct BlendInner {
+    const ig_material* m[2];
+    Col kd[2];
+};
+struct NoBlendInner {
+};
+
+// constant, checkerboard or bitmap colour of a material (diffuse reflectance, principled base colour, ...)
+IG_DEV Col material_color(const DevScene& sc, const ig_material& m, const Surf& s)
+{
+    if (m.flags & IG_MAT_IMAGE)
+        return image_lookup(sc, sc.textures[m.tex_refl], s.tex);
+    if (m.flags & IG_MAT_CHECKER) {
+        const bool px = ((int)wrapf(s.tex.x * m.q[6], 0, 2) % 2) == 0;
+        const bool py = ((int)wrapf(s.tex.y * m.q[7], 0, 2) % 2) == 0;
+        return (px ^ py) ? Col{ m.q[0], m.q[1], m.q[2] } : Col{ m.q[3], m.q[4], m.q[5] };
+    }
+    return Col{ m.p[0], m.p[1], m.p[2] };
+}
+
+template <bool FULL, bool TOP = true>
 struct BsdfCtx {
     const ig_material* mat;
     Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
     Col kd;    // diffuse reflectance (constant or checkerboard)
+    std::conditional_t<FULL && TOP, BlendInner, NoBlendInner> blend;
 
     IG_DEV BsdfCtx(const DevScene& sc, const ig_material& m, const Surf& s, f3 ray_dir)
         : mat(&m)
@@ -1089,19 +1113,33 @@ struct BsdfCtx {
     {
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
             surf.local = bumped_frame(sc, m, s, ray_dir);
-        if (m.flags & IG_MAT_IMAGE) {
-            kd = image_lookup(sc, sc.textures[m.tex_refl], s.tex);
-            return;
-        }
-        if (m.flags & IG_MAT_CHECKER) {
-            const bool px = ((int)wrapf(s.tex.x * m.q[6], 0, 2) % 2) == 0;
-            const bool py = ((int)wrapf(s.tex.y * m.q[7], 0, 2) % 2) == 0;
-            kd            = (px ^ py) ? Col{ m.q[0], m.q[1], m.q[2] } : Col{ m.q[3], m.q[4], m.q[5] };
-        } else {
-            kd = Col{ m.p[0], m.p[1], m.p[2] };
+        kd = material_color(sc, m, s);
+        if constexpr (FULL && TOP) {
+            if (m.bsdf_type == IG_BSDF_BLEND) {
+                for (int i = 0; i < 2; ++i) {
+                    blend.m[i]  = &sc.materials[m.pad[i]];
+                    blend.kd[i] = material_color(sc, *blend.m[i], s);
+                }
+            }
         }
     }
-    IG_DEV bool all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)); }
+    // a BSDF inside a blend: it sees the blend's surface (make_mix_bsdf, bsdf/mix.art:4-68)
+    IG_DEV BsdfCtx(const ig_material& m, const Surf& s, Col color)
+        : mat(&m)
+        , surf(s)
+        , kd(color)
+    {
+    }
+    IG_DEV BsdfCtx<FULL, false> inner(int i) const { return BsdfCtx<FULL, false>(*blend.m[i], surf, blend.kd[i]); }
+
+    IG_DEV bool all_delta() const
+    {
+        if constexpr (FULL && TOP) {
+            if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
+                return inner(0).all_delta() && inner(1).all_delta();
+        }
+        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
+    }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
@@ -1133,6 +1171,10 @@ struct BsdfCtx {
             }
             return lerp_col(kd, coat, pl.mix(out_dir));
         }
+        case IG_BSDF_BLEND: // mix.art:56-61
+            if constexpr (FULL && TOP)
+                return lerp_col(inner(0).albedo(out_dir), inner(1).albedo(out_dir), mat->p[0]);
+            return kd;
         default: // lambertian kd (bsdf/diffuse.art:10), principled base colour (bsdf/principled.art:478)
             return kd;
         }
@@ -1141,6 +1183,10 @@ struct BsdfCtx {
     IG_DEV Col eval(f3 in_dir, f3 out_dir) const
     {
         const f3 N = surf.local.c2;
+        if constexpr (FULL && TOP) {
+            if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
+                return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
+        }
         if constexpr (FULL) {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().eval(in_dir, out_dir);
@@ -1170,6 +1216,16 @@ struct BsdfCtx {
     }
     IG_DEV float pdf(f3 in_dir, f3 out_dir) const
     {
+        if constexpr (FULL && TOP) {
+            if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
+                const float k = mat->p[0];
+                if (k <= 0)
+                    return inner(0).pdf(in_dir, out_dir);
+                if (k >= 1)
+                    return inner(1).pdf(in_dir, out_dir);
+                return lerpf(inner(0).pdf(in_dir, out_dir), inner(1).pdf(in_dir, out_dir), k);
+            }
+        }
         if constexpr (FULL) {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().pdf(in_dir, out_dir);
@@ -1191,6 +1247,26 @@ struct BsdfCtx {
     IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
     {
         const f3 N = surf.local.c2;
+        if constexpr (FULL && TOP) {
+            if (mat->bsdf_type == IG_BSDF_BLEND) {
+                // make_join_bsdf.sample (mix.art:27-55); sample_mat(first, second, t)
+                const float k    = mat->p[0];
+                const bool pick1 = rnd.f32() < 1 - k;
+                const float t    = pick1 ? k : 1 - k;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    const int first = (pick1 ? 0 : 1) ^ attempt;
+                    const BsdfCtx<FULL, false> a = inner(first), b = inner(first ^ 1);
+                    if (!a.sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta))
+                        continue;
+                    const float p = lerpf(pdf_out, b.pdf(in_dir, out_dir), t);
+                    const Col c   = lerp_col(color * pdf_out, b.eval(in_dir, out_dir), t);
+                    pdf_out       = p;
+                    color         = c * safe_div(1, p);
+                    return true;
+                }
+                return false;
+            }
+        }
         if constexpr (FULL) {
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
                 sdelta = false;

@@ -911,7 +911,14 @@ static uint32_t appendEnvironmentCdf(std::vector<float>& out, const std::vector<
     return (uint32_t)offset;
 }
 
-static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, TextureBank& bank, int depth = 0)
+// Inner materials of blends: appended to the material table after the entity-bound ones (index = aux_base + position)
+struct AuxMaterials {
+    std::vector<ig_material> list;
+    std::vector<std::string> names;
+    int32_t base = 0;
+};
+
+static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, TextureBank& bank, AuxMaterials& aux, int depth = 0)
 {
     const JsonValue* bsdf = nullptr;
     for (const auto& b : scene_bsdfs.arr)
@@ -1086,13 +1093,31 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             m.flags |= IG_MAT_THIN;
         if (!bsdf->getBool("clearcoat_top_only", true))
             m.flags |= IG_MAT_CLEARCOAT_ALL;
+    } else if (type == "blend" || type == "mix") {
+        // BlendBSDF.cpp:14-56: make_mix_bsdf(first, second, weight); the same bsdf twice is that bsdf
+        const std::string first = bsdf->getString("first"), second = bsdf->getString("second");
+        if (first.empty() || second.empty())
+            fail("BSDF '" + name + "': has no inner bsdfs given");
+        if (first == second)
+            return lowerBsdf(first, scene_bsdfs, textures, bank, aux, depth + 1);
+        m.bsdf_type = IG_BSDF_BLEND;
+        m.p[0]      = getConstNumber(*bsdf, "weight", 0.5f, name);
+        int slot    = 0;
+        for (const std::string& inner : { first, second }) {
+            const ig_material im = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
+            if (im.bsdf_type == IG_BSDF_BLEND || (im.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+                fail("BSDF '" + name + "': nested blends and bump / normal maps inside a blend are not supported by the HIP backend");
+            m.pad[slot++] = aux.base + (int32_t)aux.list.size();
+            aux.list.push_back(im);
+            aux.names.push_back(inner);
+        }
     } else if (type == "bumpmap" || type == "normalmap") {
         // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
         // make_normalmap(ctx, inner, map colour, strength)
         const std::string inner = bsdf->getString("bsdf");
         if (inner.empty())
             fail("BSDF '" + name + "': has no inner bsdf given");
-        m = lowerBsdf(inner, scene_bsdfs, textures, bank, depth + 1);
+        m = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
             fail("BSDF '" + name + "': nested bump / normal maps are not supported by the HIP backend");
         const JsonValue* map = bsdf->find("map");
@@ -1746,12 +1771,19 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     sc->lights.insert(sc->lights.end(), finite.begin(), finite.end());
 
     // ---- materials
+    AuxMaterials aux;
+    aux.base = (int32_t)mat_keys.size();
     for (size_t m = 0; m < mat_keys.size(); ++m) {
-        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures, bank);
+        ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures, bank, aux);
         if (!mat_keys[m].light_entity.empty())
             mat.light_id = (int32_t)infinite.size() + finite_index_of_entity.at(mat_keys[m].light_entity);
         sc->materials.push_back(mat);
         sc->material_names.push_back(mat_keys[m].bsdf);
+    }
+    for (size_t i = 0; i < aux.list.size(); ++i) {
+        sc->materials.push_back(aux.list[i]);
+        sc->material_names.push_back(aux.names[i]);
+        sc->entity_per_material.push_back(0);
     }
 
     // ---- light selector (LoaderLight.cpp:423-460: <= 1 light -> uniform)

@@ -88,7 +88,8 @@ enum ig_bsdf_type {
     IG_BSDF_CONDUCTOR  = 2, /* src/artic/bsdf/conductor.art:47-141, runtime/bsdf/ConductorBSDF.cpp:13-34 */
     IG_BSDF_PRINCIPLED = 3, /* src/artic/bsdf/principled.art:236-481, runtime/bsdf/PrincipledBSDF.cpp:14-98 */
     IG_BSDF_ROUGH_DIELECTRIC = 5, /* src/artic/bsdf/dielectric.art:64-191 (make_dielectric_bsdf with a rough interface) */
-    IG_BSDF_PLASTIC    = 4, /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */
+    IG_BSDF_PLASTIC    = 4,
+    IG_BSDF_BLEND      = 6, /* make_mix_bsdf (src/artic/bsdf/mix.art:4-68), runtime/bsdf/BlendBSDF.cpp:14-56 ("blend" / "mix") */ /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */
 };
 
 enum ig_material_flags {
@@ -121,6 +122,8 @@ typedef struct ig_material {
      * rough dielectric: as dielectric, plus p[8] pdf epsilon (dielectric.art:67-82), p[9] alpha_u, p[10] alpha_v
      * plastic:    p[0..2] diffuse_reflectance (or checker / image), p[3] ext_ior, p[4] int_ior,
      *             p[6..8] specular_reflectance, p[9] alpha_u, p[10] alpha_v (IG_MAT_SMOOTH: mirror coating)
+     * blend:      p[0] weight; pad[0], pad[1] = indices of the two inner materials, which follow the entity-bound ones in the
+     *             table (entity_per_material 0) and are not blends themselves
      * principled: p[0..2] base_color (or checker / image like the diffuse reflectance), p[3] reflective_ior,
      *             p[4] refractive_ior, p[5] diffuse_transmission, p[6] specular_transmission, p[7] specular_tint,
      *             p[8] roughness_u, p[9] roughness_v, p[10] flatness; r[0] metallic, r[1] sheen, r[2] sheen_tint,

@@ -1203,7 +1203,14 @@ struct Bsdf {
     const igd_scene* scene = nullptr; // bitmap reflectance lookups
 
     // plastic: mat1.is_all_delta & mat2.is_all_delta with a diffuse mat1 (mix.art:63)
-    bool is_all_delta() const { return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)); }
+    bool is_all_delta() const
+    {
+        if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
+            return inner(0).is_all_delta() && inner(1).is_all_delta();
+        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
+    }
+    // the two BSDFs a blend mixes (make_mix_bsdf, bsdf/mix.art:4-68); they see the same surface
+    Bsdf inner(int i) const { return Bsdf{ &scene->materials[mat->pad[i]], surf, scene }; }
 
     Color kd() const
     {
@@ -1242,6 +1249,8 @@ struct Bsdf {
             }
             return color_lerp(kd(), coat, pl.mix(out_dir));
         }
+        if (mat->bsdf_type == IG_BSDF_BLEND) // mix.art:56-61
+            return color_lerp(inner(0).albedo(out_dir), inner(1).albedo(out_dir), mat->p[0]);
         return kd(); // lambertian (diffuse.art:10), principled base colour (principled.art:478)
     }
 
@@ -1249,6 +1258,8 @@ struct Bsdf {
     // delta BSDFs evaluate to black (dielectric.art:16-17)
     Color eval(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
+            return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1278,6 +1289,14 @@ struct Bsdf {
     }
     float pdf(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
+            const float k = mat->p[0];
+            if (k <= 0)
+                return inner(0).pdf(in_dir, out_dir);
+            if (k >= 1)
+                return inner(1).pdf(in_dir, out_dir);
+            return lerpf(inner(0).pdf(in_dir, out_dir), inner(1).pdf(in_dir, out_dir), k);
+        }
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1296,6 +1315,23 @@ struct Bsdf {
     }
     bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
     {
+        if (mat->bsdf_type == IG_BSDF_BLEND) {
+            // make_join_bsdf.sample (mix.art:27-55)
+            const Bsdf m1 = inner(0), m2 = inner(1);
+            auto sample_mat = [&](const Bsdf& first, const Bsdf& second, float t) {
+                if (!first.sample(rnd, out_dir, s))
+                    return false;
+                const float p = lerpf(s.pdf, second.pdf(s.in_dir, out_dir), t);
+                const Color c = color_lerp(color_mulf(s.color, s.pdf), second.eval(s.in_dir, out_dir), t);
+                s.pdf         = p;
+                s.color       = color_mulf(c, safe_div(1, p));
+                return true;
+            };
+            const float k = mat->p[0];
+            if (rnd.next_f32() < 1 - k)
+                return sample_mat(m1, m2, k) || sample_mat(m2, m1, k);
+            return sample_mat(m2, m1, 1 - k) || sample_mat(m1, m2, 1 - k);
+        }
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
             s.is_delta = false;
             return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta);

@@ -901,3 +901,31 @@ def test_thin_dielectric_vs_oracle(gpu_device):
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     assert sc.scene.materials[3].flags & 1
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=33, iters=2)
+
+
+def test_blend_bsdf_vs_oracle(gpu_device):
+    """Blends of unlike parts: diffuse + rough conductor, principled + glass (a delta part), plastic + mirror; a blend under
+    a bump map."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    base = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    base["textures"] = s["textures"]
+    for t in base["textures"]:
+        if "filename" in t:
+            t["filename"] = os.path.join(SCENES, t["filename"])
+    bump_tex = next(t["name"] for t in base["textures"] if t.get("type") in ("image", "bitmap"))
+    base["bsdfs"] = [
+        {"type": "diffuse", "name": "mat-Light", "reflectance": [0, 0, 0]},
+        {"type": "diffuse", "name": "d", "reflectance": [0.7, 0.7, 0.7]},
+        {"type": "conductor", "name": "c", "roughness": 0.25, "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.2]},
+        {"type": "principled", "name": "p", "base_color": [0.2, 0.3, 0.9], "roughness": 0.4, "metallic": 0.3},
+        {"type": "dielectric", "name": "g", "int_ior": 1.6},
+        {"type": "plastic", "name": "pl", "diffuse_reflectance": [0.9, 0.5, 0.1], "roughness": 0.2},
+        {"type": "mirror", "name": "m"},
+        {"type": "blend", "name": "dc", "first": "d", "second": "c", "weight": 0.4},
+        {"type": "bumpmap", "name": "mat-GrayWall", "bsdf": "dc", "map": bump_tex, "strength": 0.5},
+        {"type": "blend", "name": "mat-ColoredWall", "first": "p", "second": "g", "weight": 0.25},
+        {"type": "mix", "name": "mat-Diamond", "first": "pl", "second": "m", "weight": 0.6},
+    ]
+    sc = LoadedScene.from_string(json.dumps(base), SCENES, 96, 72)
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=37, iters=2)

@@ -894,3 +894,40 @@ def test_thin_dielectric_samples():
     ct = np.sqrt(1 - (1 - c * c) * k * k)
     f = (((k * c - ct) / (k * c + ct)) ** 2 + ((c - k * ct) / (c + k * ct)) ** 2) / 2
     assert mirror.mean() == pytest.approx(f + (1 - f) * f / (f + 1), abs=0.006)
+
+
+# ---- blend (make_mix_bsdf, src/artic/bsdf/mix.art)
+
+def test_blend_bsdf_is_the_weighted_mixture():
+    """eval and pdf of a blend are the weighted means of its parts; samples carry weight * pdf = eval and the blend's pdf; the
+    inner materials sit behind the entity-bound ones; the same bsdf twice is that bsdf."""
+    s = flat_scene()
+    s["bsdfs"] = [{"type": "diffuse", "name": "a", "reflectance": [0.8, 0.2, 0.2]},
+                  {"type": "conductor", "name": "b", "roughness": 0.3, "eta": [0.2, 0.9, 1.1], "k": [3.9, 2.4, 2.2]},
+                  {"type": "blend", "name": "ground", "first": "a", "second": "b", "weight": 0.3},
+                  {"type": "mix", "name": "same", "first": "a", "second": "a"}]
+    s["shapes"].append({"type": "rectangle", "name": "R2"})
+    s["entities"] += [{"name": "E2", "shape": "R2", "bsdf": "same", "transform": [{"translate": [3, 0, 0]}]},
+                      {"name": "EA", "shape": "R2", "bsdf": "a", "transform": [{"translate": [6, 0, 0]}]},
+                      {"name": "EB", "shape": "R2", "bsdf": "b", "transform": [{"translate": [9, 0, 0]}]}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 8, 8)
+    t = sc.scene
+    names = [sc.material_name(i) for i in range(t.material_count)]
+    assert names == ["ground", "same", "a", "b", "a", "b"] and list(t.entity_per_material[:6]) == [1, 1, 1, 1, 0, 0]
+    assert t.materials[0].bsdf_type == 6 and list(t.materials[0].pad[:2]) == [4, 5] and t.materials[1].bsdf_type == 0
+    wo = _unit([0.3, 0.2, 0.93])
+    rng = np.random.default_rng(2)
+    z, ph = rng.uniform(0.05, 1, 2000), rng.uniform(0, 2 * np.pi, 2000)
+    r = np.sqrt(1 - z * z)
+    wi = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+    (ca, pa), (cb, pb), (cm, pm) = (oracle.bsdf_eval(sc, i, wo, wi) for i in (2, 3, 0))
+    np.testing.assert_allclose(cm, 0.7 * ca + 0.3 * cb, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pm, 0.7 * pa + 0.3 * pb, rtol=1e-5)
+    ws, ps, w, eta = oracle.bsdf_sample(sc, 0, wo, 60000, seed=3)
+    ok = ps > 0
+    c2, p2 = oracle.bsdf_eval(sc, 0, wo, ws[ok])
+    np.testing.assert_allclose(p2, ps[ok], rtol=1e-4)
+    np.testing.assert_allclose(c2, w[ok] * ps[ok][:, None], rtol=1e-4, atol=1e-7)
+    # one-sample estimate of the albedo = the same mixture of the parts' albedos
+    alb = [oracle.bsdf_sample(sc, i, wo, 60000, seed=4)[2].astype(np.float64).mean(0) for i in (2, 3)]
+    np.testing.assert_allclose(w.astype(np.float64).mean(0), 0.7 * alb[0] + 0.3 * alb[1], rtol=0.03)
