@@ -1081,8 +1081,7 @@ struct Plastic {
 // FULL = false leaves the principled BSDF out of the kernel (scenes without one run the lean variant)
 // TOP = false: the context of a BSDF inside a blend (same surface, no further nesting)
 struct BlendInner {
-    const ig_material* m[2];
-    Col kd[2];
+    const DevScene* sc; // the inner contexts are rebuilt where they are used, so a blend costs the other materials no registers
 };
 struct NoBlendInner {
 };
@@ -1114,14 +1113,8 @@ struct BsdfCtx {
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
             surf.local = bumped_frame(sc, m, s, ray_dir);
         kd = material_color(sc, m, s);
-        if constexpr (FULL && TOP) {
-            if (m.bsdf_type == IG_BSDF_BLEND) {
-                for (int i = 0; i < 2; ++i) {
-                    blend.m[i]  = &sc.materials[m.pad[i]];
-                    blend.kd[i] = material_color(sc, *blend.m[i], s);
-                }
-            }
-        }
+        if constexpr (FULL && TOP)
+            blend.sc = &sc;
     }
     // a BSDF inside a blend: it sees the blend's surface (make_mix_bsdf, bsdf/mix.art:4-68)
     IG_DEV BsdfCtx(const ig_material& m, const Surf& s, Col color)
@@ -1130,7 +1123,11 @@ struct BsdfCtx {
         , kd(color)
     {
     }
-    IG_DEV BsdfCtx<FULL, false> inner(int i) const { return BsdfCtx<FULL, false>(*blend.m[i], surf, blend.kd[i]); }
+    IG_DEV BsdfCtx<FULL, false> inner(int i) const
+    {
+        const ig_material& m = blend.sc->materials[mat->pad[i]];
+        return BsdfCtx<FULL, false>(m, surf, material_color(*blend.sc, m, surf));
+    }
 
     IG_DEV bool all_delta() const
     {
