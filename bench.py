@@ -82,9 +82,9 @@ def main():
 
     W, H, spi = args.width, args.height, args.spi
     scene = LoadedScene.from_file(args.scene, W, H)
-    # streams sized once for a full batch of iterations (2^27 camera rays, ~39 GB): the warm-up then pays for the
+    # streams sized once for a full batch of iterations (2^28 camera rays, ~78 GB): the warm-up then pays for the
     # allocation (and for the driver's scrubbing of memory a previous process just released), not the timed region
-    CAPACITY = 1 << 27
+    CAPACITY = int(os.environ.get("BENCH_CAPACITY", 1 << 28))
     dev = Device(local_rank, acquire_stats=0 if args.no_stage_timers else 1, stream_capacity=CAPACITY)
     dev.assign_scene(scene)
     dev.resize(W, H)
@@ -97,7 +97,7 @@ def main():
     by_rows = (world > 1 and args.sharding == "rows") or args.as_rank_of > 1
     shards = args.as_rank_of if args.as_rank_of > 1 else world
     # One igd_render per iteration, like Runtime::step. The device executes consecutive iterations as one wavefront
-    # (up to 2^27 camera rays, bit-identical to executing them one by one): that is what keeps a
+    # (up to 2^28 camera rays, bit-identical to executing them one by one): that is what keeps a
     # row-sharded rank, which owns 1 / N of every iteration, as efficient as a whole film on one GPU.
 
     steps_per_rank = max(args.steps, args.warmup)  # a rank's iterations are consecutive, so the device can batch them
