@@ -263,26 +263,56 @@ struct igd_device {
                                            : std::min(std::max<size_t>((size_t)1 << 24, (size_t)batch_rays), needed);
         return (cap + 255) & ~(size_t)255;
     }
-    bool streamsTooSmall(size_t needed) const { return !(wantedCapacity(needed) <= capacity && primary[0].ptr); }
+    bool mem_capped = false; // the streams are as large as free memory allowed (ensureStreams)
+    bool streamsTooSmall(size_t needed) const { return !((wantedCapacity(needed) <= capacity || mem_capped) && primary[0].ptr); }
 
+    void releaseStreams()
+    {
+        for (int s = 0; s < 2; ++s)
+            primary[s].release();
+        secondary.release();
+        deep_rays.release();
+        for (auto& f : flight)
+            f.accum.release();
+        capacity   = 0;
+        mem_capped = false;
+    }
+
+    // All-or-nothing: `capacity` names the new size only once every buffer of that size exists. If an allocation fails
+    // (the default batch asks for ~78 GB) everything is released and capacity is 0, so that the next call allocates
+    // again instead of launching on buffers that are not there. Without an explicit igd_setup.stream_capacity the size
+    // is also capped by what hipMemGetInfo reports as free.
     void ensureStreams(size_t needed)
     {
-        const size_t cap = wantedCapacity(needed);
-        if (cap <= capacity && primary[0].ptr)
+        size_t cap = wantedCapacity(needed);
+        if (!streamsTooSmall(needed))
             return;
-        capacity = cap;
-        for (int s = 0; s < 2; ++s) {
-            primary[s].release();
-            primary[s].alloc(capacity * kPrimaryCols);
+        releaseStreams();
+        bool capped = false;
+        const size_t bytes_per_ray = (size_t)(2 * kPrimaryCols + kSecondaryCols + 1 + 4 * n_flights) * sizeof(float);
+        if (!setup.stream_capacity) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t fit = (size_t)((double)free_b * 0.9 / (double)bytes_per_ray) & ~(size_t)255;
+                if (fit >= 256 && cap > fit) {
+                    cap    = fit; // larger requests are processed in chunks (render())
+                    capped = true;
+                }
+            }
         }
-        secondary.release();
-        secondary.alloc(capacity * kSecondaryCols);
-        deep_rays.release();
-        deep_rays.alloc(capacity);
-        for (int k = 0; k < n_flights; ++k) {
-            flight[k].accum.release();
-            flight[k].accum.alloc(capacity * 4);
+        try {
+            for (int s = 0; s < 2; ++s)
+                primary[s].alloc(cap * kPrimaryCols);
+            secondary.alloc(cap * kSecondaryCols);
+            deep_rays.alloc(cap);
+            for (int k = 0; k < n_flights; ++k)
+                flight[k].accum.alloc(cap * 4);
+        } catch (...) {
+            releaseStreams();
+            throw;
         }
+        capacity   = cap;
+        mem_capped = capped;
     }
 
     static SecondaryCols secAt(float* b, size_t c)
@@ -524,13 +554,21 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->has_scene            = true;
 }
 
+// Device-memory clears go through the render stream and are waited for: the render streams are non-blocking, i.e. not ordered
+// against the null stream, and a null-stream hipMemset of device memory need not be finished when it returns.
+void clearOnStream(hipStream_t st, void* ptr, int value, size_t bytes)
+{
+    HIP_CHECK(hipMemsetAsync(ptr, value, bytes, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
 void resizeFb(igd_device* d, int w, int h)
 {
     if (w == d->fb_w && h == d->fb_h && d->fb.ptr)
         return;
     d->fb.release();
     d->fb.alloc((size_t)w * h * 3);
-    HIP_CHECK(hipMemset(d->fb.ptr, 0, (size_t)w * h * 3 * sizeof(float)));
+    clearOnStream(d->stream, d->fb.ptr, 0, (size_t)w * h * 3 * sizeof(float));
     d->fb_w = w;
     d->fb_h = h;
     d->fb_host.assign((size_t)w * h * 3, 0.0f);
@@ -539,7 +577,7 @@ void resizeFb(igd_device* d, int w, int h)
         for (int k = 0; k < 2; ++k) {
             d->aov[k].release();
             d->aov[k].alloc((size_t)w * h * 3);
-            HIP_CHECK(hipMemset(d->aov[k].ptr, 0, (size_t)w * h * 3 * sizeof(float)));
+            clearOnStream(d->stream, d->aov[k].ptr, 0, (size_t)w * h * 3 * sizeof(float));
             d->aov_host[k].assign((size_t)w * h * 3, 0.0f);
             d->aov_host_dirty[k] = true;
         }
@@ -1118,7 +1156,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     deep_rays.alloc(n);
     in.upload(cols.data(), cols.size());
     out.alloc(n * 5);
-    HIP_CHECK(hipMemset(out.ptr, 0xFF, n * 5 * sizeof(float)));
+    clearOnStream(d->stream, out.ptr, 0xFF, n * 5 * sizeof(float));
 
     finish(d);
     hipStream_t st = d->stream;
@@ -1285,7 +1323,7 @@ igd_device* igd_create(const igd_setup* setup)
         }
         constexpr int F = igd_device::kMaxFlights;
         d->qs_store.alloc(F);
-        HIP_CHECK(hipMemset(d->qs_store.ptr, 0, F * sizeof(QueueState)));
+        clearOnStream(d->stream, d->qs_store.ptr, 0, F * sizeof(QueueState));
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->host_store), (F + 3) * sizeof(QueueState), hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d->host_store_dev), d->host_store, 0));
         std::memset(d->host_store, 0, (F + 3) * sizeof(QueueState));
@@ -1361,11 +1399,11 @@ int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
             dev->fb_w = dev->fb_h = 0;
         }
         resizeFb(dev, width, height);
-        HIP_CHECK(hipMemset(dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float)));
+        clearOnStream(dev->stream, dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float));
         dev->fb_host_dirty = true;
         for (int k = 0; k < 2; ++k)
             if (dev->aov[k].ptr) {
-                HIP_CHECK(hipMemset(dev->aov[k].ptr, 0, (size_t)width * height * 3 * sizeof(float)));
+                clearOnStream(dev->stream, dev->aov[k].ptr, 0, (size_t)width * height * 3 * sizeof(float));
                 dev->aov_host_dirty[k] = true;
             }
     });
@@ -1378,12 +1416,8 @@ int32_t igd_release_all(igd_device* dev)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL device" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
-        for (int s = 0; s < 2; ++s)
-            dev->primary[s].release();
-        dev->secondary.release();
-        dev->deep_rays.release();
+        dev->releaseStreams();
         for (auto& f : dev->flight) {
-            f.accum.release();
             f.tail_in.release();
             f.tail_long.release();
             f.side_secondary.release();
@@ -1393,7 +1427,6 @@ int32_t igd_release_all(igd_device* dev)
             f.tail_capacity = 0;
         }
         dev->list_rays.release();
-        dev->capacity = 0;
         dev->geom.release();
         dev->shape_data.release();
         dev->leaves.release();
@@ -1464,7 +1497,7 @@ int32_t igd_clear_framebuffer(igd_device* dev, const char* name)
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
         if (b.dev->ptr)
-            HIP_CHECK(hipMemset(b.dev->ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float)));
+            clearOnStream(dev->stream, b.dev->ptr, 0, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float));
         std::fill(b.host->begin(), b.host->end(), 0.0f);
         *b.dirty = true;
     });
@@ -1534,12 +1567,18 @@ int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
         // kernel arguments are captured by value at launch, so work already submitted keeps its parameters; iterations
         // that were only recorded so far are submitted first, with the old values
+        // -- and only when a value the device reads actually changes: a caller that re-sends its whole registry before every
+        // iteration (Runtime::stepVariant does) must not break the batch (IRenderDevice::render hands over the ParameterSet each call)
+        int32_t* dst = nullptr;
+        if (std::strcmp(name, "__tech_max_depth") == 0)
+            dst = &dev->dscene.tech.max_depth;
+        else if (std::strcmp(name, "__tech_min_depth") == 0)
+            dst = &dev->dscene.tech.min_depth;
+        if (!dst || *dst == value)
+            return;
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         flushPending(dev);
-        if (std::strcmp(name, "__tech_max_depth") == 0)
-            dev->dscene.tech.max_depth = value;
-        else if (std::strcmp(name, "__tech_min_depth") == 0)
-            dev->dscene.tech.min_depth = value;
+        *dst = value;
     });
 }
 
@@ -1548,12 +1587,16 @@ int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value)
     return guarded("igd_set_parameter_f32", [&] {
         if (!dev || !name)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        float* dst = nullptr;
+        if (std::strcmp(name, "__tech_clamp") == 0)
+            dst = &dev->dscene.tech.clamp;
+        else if (std::strcmp(name, "__camera_scale") == 0) // OrthogonalCamera.cpp:28,39
+            dst = &dev->camera.scale;
+        if (!dst || std::memcmp(dst, &value, sizeof(float)) == 0)
+            return;
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         flushPending(dev);
-        if (std::strcmp(name, "__tech_clamp") == 0)
-            dev->dscene.tech.clamp = value;
-        else if (std::strcmp(name, "__camera_scale") == 0) // OrthogonalCamera.cpp:28,39
-            dev->camera.scale = value;
+        *dst = value;
     });
 }
 
@@ -1562,8 +1605,6 @@ int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float va
     return guarded("igd_set_parameter_vec3", [&] {
         if (!dev || !name || !value)
             throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
-        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
-        flushPending(dev);
         float* dst = nullptr;
         if (std::strcmp(name, "__camera_eye") == 0)
             dst = dev->camera.eye;
@@ -1571,8 +1612,11 @@ int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float va
             dst = dev->camera.dir;
         else if (std::strcmp(name, "__camera_up") == 0)
             dst = dev->camera.up;
-        if (dst)
-            std::memcpy(dst, value, 3 * sizeof(float));
+        if (!dst || std::memcmp(dst, value, 3 * sizeof(float)) == 0)
+            return;
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        flushPending(dev);
+        std::memcpy(dst, value, 3 * sizeof(float));
     });
 }
 

@@ -161,6 +161,10 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
 
         // ---- workgroup-local counting sort by material (miss = bin M, out of range = bin M + 1)
         uint32_t j = base + tid;
+        // cleared here, in front of the sort's barriers (or the explicit one below when there is no sort): every wave's
+        // atomicAdd on s_bin is then ordered behind the clear, and the previous window's last barrier behind its reads
+        if (tid < 16)
+            s_bin[tid] = 0;
         if (do_sort) {
             const uint32_t i = base + tid;
             int key          = M + 1;
@@ -197,8 +201,6 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             __syncthreads();
         }
 
-        if (tid < 16)
-            s_bin[tid] = 0; // (ordered against its use below by the barriers of the sort / of the previous append)
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
         int ray_id = 0;
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
             int bkey       = 0;
             uint32_t brank = 0;
             if (!do_sort)
-                __syncthreads(); // s_bin was cleared above without a barrier in between
+                __syncthreads(); // s_bin was cleared at the top of the window; without the sort there is no barrier in between
             if (out.bounce) {
                 // rays that continue through a specular (dielectric) vertex start inside or on a refractive object and
                 // walk its BVH first; the others cross the room: two populations with different traversal shapes

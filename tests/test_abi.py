@@ -533,3 +533,98 @@ def test_qrotate_and_entities_without_known_parts():
     a["entities"] += [{"name": "NoBsdf", "shape": "Bottom", "bsdf": "missing"}, {"name": "NoShape", "shape": "missing", "bsdf": "ground"}]
     sc = LoadedScene.from_string(json.dumps(a))
     assert sc.scene.entity_count == 1 and sc.entity_name(0) == "Bottom"
+
+
+def _write_png(path, width, height, ctype, depth, rows, palette=None, trns=None):
+    """Minimal PNG writer for the reader's tests: `rows` are the packed sample bytes of each row (filter type 0)."""
+    import struct
+    import zlib
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + bytes(r) for r in rows)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    out += chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def _texture_scene(png_name):
+    return {
+        "technique": {"type": "path", "max_depth": 2},
+        "camera": {"type": "perspective", "fov": 40, "near_clip": 0.1, "far_clip": 100,
+                   "transform": [-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 3.85, 0, 0, 0, 1]},
+        "film": {"size": [16, 16]},
+        "textures": [{"type": "image", "name": "tex", "filename": png_name, "filter_type": "nearest", "linear": True}],
+        "bsdfs": [{"type": "diffuse", "name": "mat", "reflectance": "tex"}],
+        "shapes": [{"type": "rectangle", "name": "Bottom"}],
+        "entities": [{"name": "Bottom", "shape": "Bottom", "bsdf": "mat"}],
+        "lights": [{"type": "point", "name": "l", "position": [0, 0, 2], "intensity": [1, 1, 1]}],
+    }
+
+
+def _loaded_texels(tmp_path, name):
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_string(json.dumps(_texture_scene(name)), base_dir=str(tmp_path))
+    s = sc.scene
+    assert s.texture_count == 1
+    t = s.textures[0]
+    n = t.width * t.height * (1 if t.channels == 1 else 4)
+    from types import SimpleNamespace  # (the tables die with `sc`)
+    return (SimpleNamespace(width=int(t.width), height=int(t.height), channels=int(t.channels)),
+            np.ctypeslib.as_array(s.texture_data, shape=(s.texture_data_size,))[t.offset:t.offset + n].copy())
+
+
+def test_png_reader_palette_16bit_and_packed_gray(tmp_path):
+    """What stb_image (Image.cpp:714-808) yields for the PNG variants beyond 8-bit truecolour: palette indices expanded to RGB
+    (RGBA with tRNS), 16-bit samples reduced to their high byte, 1/2/4-bit gray scaled to 0..255. `linear: true` keeps the
+    bytes as they are (no sRGB decode), rows are stored bottom-up."""
+    import numpy as np
+    # 4x2 palette image, 2 bits per index, with transparency for index 1
+    pal = [10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 110, 120]
+    _write_png(tmp_path / "pal.png", 4, 2, 3, 2, [[0b00011011], [0b11100100]], palette=pal, trns=[255, 7])
+    t, px = _loaded_texels(tmp_path, "pal.png")
+    assert (t.width, t.height, t.channels) == (4, 2, 4)
+    px = px.reshape(2, 4, 4)
+    idx = np.array([[3, 2, 1, 0], [0, 1, 2, 3]])  # bottom row of the file first
+    want = np.array(pal).reshape(4, 3)[idx]
+    np.testing.assert_array_equal(px[..., :3], want)
+    np.testing.assert_array_equal(px[..., 3], np.where(idx == 1, 7, 255))
+
+    # 2x1 RGB, 16 bits per sample: the high byte survives
+    _write_png(tmp_path / "rgb16.png", 2, 1, 2, 16, [[0x12, 0x34, 0x56, 0x78, 0x9A, 0xBC, 0xFF, 0x00, 0x01, 0xFF, 0x80, 0x7F]])
+    t, px = _loaded_texels(tmp_path, "rgb16.png")
+    assert (t.width, t.height, t.channels) == (2, 1, 4)
+    np.testing.assert_array_equal(px.reshape(2, 4), [[0x12, 0x56, 0x9A, 255], [0xFF, 0x01, 0x80, 255]])
+
+    # 8x1 gray at 1 bit and 2x1 gray at 4 bits
+    _write_png(tmp_path / "g1.png", 8, 1, 0, 1, [[0b10110001]])
+    t, px = _loaded_texels(tmp_path, "g1.png")
+    assert t.channels == 1
+    np.testing.assert_array_equal(px, np.array([1, 0, 1, 1, 0, 0, 0, 1]) * 255)
+    _write_png(tmp_path / "g4.png", 2, 1, 0, 4, [[0x3C]])
+    t, px = _loaded_texels(tmp_path, "g4.png")
+    np.testing.assert_array_equal(px, [3 * 17, 12 * 17])
+
+
+def test_png_reader_rejects_hostile_headers(tmp_path):
+    """IHDR dimensions are untrusted: zero, huge and overflowing sizes fail with a message instead of a wrapped allocation."""
+    import struct
+    import zlib
+    from ignis_amd.tables import LoadedScene
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+    for w, h in ((0, 4), (0xFFFFFFFF, 0xFFFFFFFF), (70000, 2), (0x80000001, 2)):
+        data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        open(tmp_path / "bad.png", "wb").write(data)
+        with pytest.raises(RuntimeError, match="dimensions out of range"):
+            LoadedScene.from_string(json.dumps(_texture_scene("bad.png")), base_dir=str(tmp_path))
+    # palette index beyond the PLTE chunk
+    _write_png(tmp_path / "bad.png", 1, 1, 3, 8, [[5]], palette=[1, 2, 3])
+    with pytest.raises(RuntimeError, match="palette index"):
+        LoadedScene.from_string(json.dumps(_texture_scene("bad.png")), base_dir=str(tmp_path))
