@@ -1,0 +1,156 @@
+"""The reference's own end-to-end check, restated: renders of `scenes/evaluation/*.json` against the reference-held images of
+OTHER renderers (Mitsuba 2/3, Blender Cycles, Radiance) under `tests/golden/references/` (copied byte for byte from
+/root/reference/scenes/evaluation/references by tests/golden/make_ref_images.py).
+
+This is what turns "oracle == HIP" (two restatements by the same hand) into "agrees with what the reference is validated
+against": a misreading of the Artic sources shared by both would show up here.
+
+  * CPU (`-m "not gpu"`): the oracle at 256 x 256, 64 spp. Mean radiance within 1.5 % of the reference image and the
+    reference's error metric (`error_image`, scripts/RunEvaluations.py:86-95) on 8 x 8 box-filtered images (64 spp x 64
+    pixels per cell ~ the noise of 4096 spp) below 2e-3, per-scene exceptions stated with their reason.
+  * GPU (`-m gpu`): the HIP path at 256 x 256, 1024 spp — the sample count RunEvaluations.py defaults to — judged exactly as
+    the reference judges itself: `error_image` at full resolution below `predef_eps[scene]` or 1e-3 (RunEvaluations.py:98-123,
+    164,181-195), plus the 1 % mean bound of MakeHtml-style comparisons.
+
+Scenes whose reference image cannot pin anything are listed in EXCLUDED with the triage.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SCENES
+
+EVAL = os.path.join(SCENES, "evaluation")
+REFS = os.path.join(GOLDEN, "references")
+
+# scripts/RunEvaluations.py:98-123
+PREDEF_EPS = {"cbox-d1": 5e-3, "cbox-d6": 5e-3, "cycles-lights": 5e-2, "cycles-principled": 5e-2, "cycles-tex": 1e-2, "cycles-sun": 1e-2,
+              "cycles-mix-diff-trans": 5e-3, "room": 1e-3, "volume": 5e-3, "env4k": 2e-3, "multilight-uniform": 3e-4, "multilight-simple": 3e-4,
+              "multilight-hierarchy": 3e-4, "sphere-light-ico": 2e-3, "sphere-light-ico-nopt": 2e-3, "sphere-light-uv": 2e-3, "sphere-light-pure": 3e-3}
+DEFAULT_EPS = 1e-3
+
+# scene -> (mean tolerance, bound on the 8x8-filtered error at 64 spp); None = defaults (0.015, 2e-3)
+PINNED = {
+    "cbox-d1": None, "cbox-d6": None,                     # Mitsuba: plane area light (Urena), diffuse interreflection, depth 1 / 6
+    "cycles-box": None,                                   # Cycles: area light + diffuse box
+    "cycles-mix-diff-diff": None,                         # Cycles: blend of two diffuse BSDFs
+    "cycles-sun": (0.015, 8e-3),                          # Cycles: sun (cone) light; the penumbra differs slightly (reference's own eps: 1e-2)
+    "emissive-plane": None, "emissive-plane-nopt": None,  # Mitsuba: emissive-hit MIS, plane and mesh-area ("optimize": false) samplers
+    "emissive-plane-scale": None, "emissive-plane-scale-nopt": None,
+    "multilight": None, "multilight-uniform": None, "multilight-hierarchy": None,  # Mitsuba: many lights, light selectors
+    "plane-array-diffuse": None,                          # Radiance: sun + sky over diffuse planes
+    "plane-d1": None, "plane-d6": None,                   # Mitsuba: environment + plane
+    "point": None,                                        # Mitsuba: point light
+    "room": None,                                         # Mitsuba: room lit through a window
+    "sky-clear": None, "sky-cloudy": None, "sky-intermediate": None, "sky-uniform": None,  # Radiance gensky: the four CIE models
+    "sphere-light-ico": None, "sphere-light-ico-nopt": None,  # Mitsuba: sphere light as icosphere mesh emitter
+    "sphere-light-uv": (0.03, 3e-3),                      # the same with a coarse uv-sphere: the mesh has ~2 % less area than the sphere
+    "sun-on-plane": None,                                 # Radiance: sun over a plane
+}
+
+EXCLUDED = {
+    "env": "make_environment_light_textured.sample_dir (src/artic/light/env.art:112-113) returns tex(ctx) without `scale`, emission "
+           "(:139-144) multiplies by it: with scale 100 the NEE half of the estimator is 100x too dark. Restated as written (bug-compatible), "
+           "so the image cannot match Mitsuba's; with the scale folded into the texture NEE and BSDF-only sampling agree with each other "
+           "and sit a uniform 2.18x above the Mitsuba image (single bright texel: the texel -> direction convention is not pinned).",
+    "flipped-prim-diffuse": "background exact (0.8); the cylinder's unlit side is 0.640 here = albedo 0.8 x environment 0.8, the value a convex "
+                            "Lambertian body must show, while the Cycles image has 0.50 on body AND cap (i.e. an effective albedo of ~0.62: the "
+                            "JSON was edited by hand after the export, scenes/evaluation/README.md); the lit side is another factor ~pi up "
+                            "because the exporter writes Blender watts as Ignis `power` (scripts/blender_exporter/ignis_blender/light.py:57-66).",
+    "sun-on-plane-and-stick": "the sun of the JSON / .rad sits exactly on the horizon (direction z = 0) and lights the stick from the right; the "
+                              "Radiance image shows an evenly lit plane without a cast shadow and the stick lit from the left: image and scene disagree.",
+}
+
+
+def reference_for(stem):
+    """get_reference_path (scripts/RunEvaluations.py:16-36): shortest ref-<name>*.exr, dropping '-' sections if there is none."""
+    base = stem
+    for _ in range(3):
+        found = [str(p) for p in Path(REFS).glob(f"ref-{base}*.exr")]
+        if found:
+            return min(found, key=len)
+        if "-" not in base:
+            break
+        base = base[:base.rfind("-")]
+    return None
+
+
+def error_image(img, ref):
+    """scripts/RunEvaluations.py:86-95: relative squared error where the reference is non-zero, absolute squared error
+    elsewhere, clipped at the 99th percentile, averaged."""
+    mask = ref != 0
+    err = np.zeros_like(ref)
+    err[mask] = np.square((img[mask] - ref[mask]) / ref[mask])
+    err[~mask] = np.square(img[~mask])
+    top = np.percentile(err, 99)
+    return float(np.average(np.clip(err, 0, top)))
+
+
+def box(img, f):
+    h, w, c = img.shape
+    return img.reshape(h // f, f, w // f, f, c).mean(axis=(1, 3))
+
+
+def _load(stem):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import exr_decode
+    from ignis_amd.tables import LoadedScene
+    ref = exr_decode.read_rgb(reference_for(stem))
+    return LoadedScene.from_file(os.path.join(EVAL, stem + ".json"), 256, 256), ref
+
+
+def test_every_usable_reference_image_is_listed():
+    """Of the evaluation scenes the loader accepts, each one with a reference image is either pinned or excluded in writing."""
+    from ignis_amd.tables import LoadedScene
+    loadable = []
+    for p in sorted(Path(EVAL).glob("*.json")):
+        if "-base" in p.stem or reference_for(p.stem) is None:
+            continue
+        try:
+            LoadedScene.from_file(str(p), 32, 32)
+            loadable.append(p.stem)
+        except RuntimeError:
+            pass
+    assert sorted(loadable) == sorted(list(PINNED) + list(EXCLUDED))
+    assert len({reference_for(s) for s in PINNED}) >= 10  # distinct reference images
+
+
+@pytest.mark.parametrize("stem", sorted(PINNED))
+def test_oracle_matches_reference_image(stem):
+    import oracle
+    scene, ref = _load(stem)
+    fb = np.zeros((256, 256, 3), np.float32)
+    for it in range(4):
+        f, _ = oracle.render(scene, 16, 256, 256, iteration=it, seed=1)
+        fb += f
+    fb /= 4
+    assert np.isfinite(fb).all()
+    mean_tol, err_tol = PINNED[stem] or (0.015, 2e-3)
+    ratio = float(fb.mean() / ref.mean())
+    err = error_image(box(fb, 8), box(ref, 8))
+    assert abs(ratio - 1) <= mean_tol, f"{stem}: mean radiance {ratio:.4f} x the reference image"
+    assert err <= err_tol, f"{stem}: error_image on 8x8-filtered images {err:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stem", sorted(PINNED))
+def test_hip_matches_reference_image_as_the_reference_judges_itself(gpu_device, stem):
+    scene, ref = _load(stem)
+    gpu_device.assign_scene(scene)
+    gpu_device.resize(256, 256)
+    gpu_device.clear_framebuffer()
+    spi, iterations = 16, 64  # 1024 spp (RunEvaluations.py --spp default)
+    for it in range(iterations):
+        gpu_device.render(spi, 256, 256, iteration=it, seed=1)
+    fb = gpu_device.framebuffer() / iterations
+    assert np.isfinite(fb).all()
+    err = error_image(fb, ref)
+    eps = PREDEF_EPS.get(stem, DEFAULT_EPS)
+    ratio = float(fb.mean() / ref.mean())
+    mean_tol = (PINNED[stem] or (0.015, 0))[0]
+    print(f"{stem}: error_image {err:.3e} (eps {eps:g}), mean ratio {ratio:.4f}")
+    assert err < eps, f"{stem}: error_image {err:.3e} >= {eps:g} (the reference's own pass criterion)"
+    assert abs(ratio - 1) <= min(mean_tol, 0.01) or stem == "sphere-light-uv", f"{stem}: mean radiance {ratio:.4f} x the reference image"
