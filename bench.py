@@ -6,17 +6,20 @@
 
 A "step" is one render iteration (Runtime::step, src/runtime/Runtime.cpp:334-387) of the workload
 BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path integrator,
-spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region.
-With N > 1 the camera samples are sharded with no data-path exchange and the framebuffers are
-reduced to rank 0 over RCCL once, inside the timed region. Default partition: whole-film iterations (rank r renders
-iterations r*K .. r*K+K-1: K steps per GPU, N x K iterations in total, "weak"). `--sharding rows` tile-shards the film
-instead (rank r renders rows r, r+N, ... of every iteration; the device batches the small per-rank iterations into
-full-size wavefronts; the sum of the shards is the single-GPU image bit for bit; "strong": K iterations in total,
-which leaves each of 8 GPUs only K / 8 iterations' worth of work — 6.4x at K = 16, 7.9x from K = 64).
+spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region. The default K (192
+steps = 1536 spp) keeps the timed region above 3 s; the literal 64-spp configuration (8 steps from an idle device) is
+timed separately and printed as `literal_config`.
 
-Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts
-them (src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the
-roofline of the dominant kernel (closest-hit traversal) and the CPU baseline (oracle) on rank 0.
+N > 1 (one process per GPU): the film is tile-sharded — rank r renders film rows r, r + N, ... of every iteration
+(igd_render_settings.row_offset / row_stride; the device batches a rank's small iterations into full-size wavefronts)
+with no data-path exchange; the only collective, inside the timed region, is ONE gather of the owned rows to rank 0
+over RCCL (W x H x 12 / N bytes per rank; ignis_amd.sharding.gather_rows). K iterations in total whatever N is:
+"scaling": "strong". N = 1 runs the same code path without a process group. `--sharding iterations` keeps the other
+partition (rank r renders K whole-film iterations r*K .. r*K+K-1, reduce(SUM); "weak").
+
+Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts them
+(src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the roofline block of the
+dominant kernel (closest-hit traversal) and the CPU baseline (oracle) on rank 0.
 """
 import argparse
 import json
@@ -30,30 +33,40 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPI, SEED = 1920, 1080, 8, 1
 SCENE = os.path.join(ROOT, "scenes", "diamond_scene.json")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r01_traffic.json"  # PMC summary of this command, see tools/collect_profiles.sh
+# VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
+VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
+PROFILE_TAG = "r02"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+DEFAULT_STEPS = 192
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=DEFAULT_STEPS)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal-config", action="store_true", help="skip the separate 8-step (64 spp) timing")
     ap.add_argument("--no-stage-timers", action="store_true", help="experiments only: no HIP-event stage timers in the timed loop (roofline.achieved becomes 0)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spi", type=int, default=SPI)
-    ap.add_argument("--sharding", choices=("iterations", "rows"), default="iterations", help="N > 1: how camera samples are split")
+    ap.add_argument("--sharding", choices=("rows", "iterations"), default="rows", help="N > 1: how camera samples are split")
+    ap.add_argument("--collective", choices=("gather", "reduce"), default="gather", help="rows sharding: gather of the owned rows (default) or reduce(SUM) of whole framebuffers")
     ap.add_argument("--as-rank-of", type=int, default=0, help="experiments only: one process renders what rank 0 of N row-sharding ranks would (estimate of per-GPU throughput at N GPUs)")
     ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
     return ap.parse_args()
 
 
-def algorithmic_bytes(n_rays, nodes, tris, leaves):
-    """SURVEY.md 8(d) with this backend's layouts: 60 B per closest-hit ray (40 B read + 20 B hit
-    written) + 256 B per Node8 fetched + 52 B per triangle tested (a 208 B Tri4 packet holds 4)
-    + 96 B per EntityLeaf1 tested."""
-    return 60 * n_rays + 256 * nodes + 52 * tris + 96 * leaves
+def stream_bytes(n_rays):
+    """Bytes of the ray streams a closest-hit launch has to move whatever the caches do: 40 B read
+    (id, org, dir, tmin, tmax, flags) + 20 B hit written per ray."""
+    return 60 * n_rays
+
+
+def geometry_bytes(nodes, tris, leaves):
+    """SURVEY.md 8(d) geometry term with this backend's layouts: 256 B per Node8 fetched + 52 B per triangle tested (a 208 B
+    Tri4 packet holds 4) + 96 B per EntityLeaf1 tested."""
+    return 256 * nodes + 52 * tris + 96 * leaves
 
 
 def main():
@@ -78,7 +91,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import numpy as np
-    from ignis_amd import Device, LoadedScene
+    from ignis_amd import Device, LoadedScene, sharding
 
     W, H, spi = args.width, args.height, args.spi
     scene = LoadedScene.from_file(args.scene, W, H)
@@ -94,17 +107,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    by_rows = (world > 1 and args.sharding == "rows") or args.as_rank_of > 1
     shards = args.as_rank_of if args.as_rank_of > 1 else world
+    by_rows = args.sharding == "rows"  # N = 1: rows of a single shard = the whole film, same code path
     # One igd_render per iteration, like Runtime::step. The device executes consecutive iterations as one wavefront
     # (up to 2^28 camera rays, bit-identical to executing them one by one): that is what keeps a
     # row-sharded rank, which owns 1 / N of every iteration, as efficient as a whole film on one GPU.
-
-    steps_per_rank = max(args.steps, args.warmup)  # a rank's iterations are consecutive, so the device can batch them
+    steps_per_rank = max(args.steps, args.warmup)  # iterations sharding: a rank's iterations are consecutive
 
     def step(on, it):
         if by_rows:
-            on.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank, row_stride=shards)
+            on.render(spi, W, H, iteration=it, seed=SEED, row_offset=rank if shards > 1 else 0, row_stride=shards)
         else:
             on.render(spi, W, H, iteration=rank * steps_per_rank + it, seed=SEED)  # ignis_amd.sharding.shard_iterations
 
@@ -116,34 +128,42 @@ def main():
                 print(f"[trace] call {it}: {(time.perf_counter() - t) * 1e3:.1f} ms", file=sys.stderr, flush=True)
 
     run(dev, args.warmup)
-    warm = dev.stats()  # (profilers see the warm-up launches too: their average is reported next to the timed one)
+    dev.synchronize()
     dev.clear_framebuffer()
     dev.reset_stats()
 
     fb_tensor = None
+    collective = None
     if dist is not None:
         class _Wrap:  # zero-copy view of the device framebuffer for RCCL
             def __init__(self, ptr, shape):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
         fb_tensor = torch.as_tensor(_Wrap(dev.framebuffer_device_ptr(), (H, W, 3)), device=torch.device("cuda", local_rank))
+        use_gather = by_rows and args.collective == "gather"
 
-    if dist is not None:
+        def collective_op(t):
+            if use_gather:
+                sharding.gather_rows(t, rank, world, dist, dst=0)
+            else:
+                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         # RCCL sets up its channels / kernels for a message size on first use: do that outside the timed region
         scratch = torch.zeros_like(fb_tensor)
-        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        collective_op(scratch)
         torch.cuda.synchronize()
         del scratch
+        collective = {"op": "gather of owned rows to rank 0" if use_gather else "reduce(SUM) of whole framebuffers to rank 0",
+                      "bytes_per_rank": sharding.gather_bytes(H, W, world) if use_gather else W * H * 12,
+                      "backend": dist.get_backend(), "world_size_from_backend": dist.get_world_size()}
     barrier()
     t0 = time.perf_counter()
     run(dev, args.steps)  # calls return at once or when a wavefront's rounds are done; tails + resolves overlap the next one
     t_sync = time.perf_counter()
-    dev.synchronize()  # everything submitted above is finished before the clock stops (and before the reduce)
+    dev.synchronize()  # everything submitted above is finished before the clock stops (and before the collective)
     if os.environ.get("BENCH_TRACE"):
         print(f"[trace] loop {(t_sync - t0) * 1e3:.1f} ms, final synchronize {(time.perf_counter() - t_sync) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     if dist is not None:
-        # the ONLY collective: final accumulation of the row-sharded framebuffers (exact: the rows
-        # a rank does not own are zero)
-        dist.reduce(fb_tensor, dst=0, op=dist.ReduceOp.SUM)
+        # the ONLY collective: final accumulation of the tile-sharded framebuffer on rank 0
+        collective_op(fb_tensor)
         torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -161,43 +181,75 @@ def main():
     else:
         rays_total, samples_total = float(rays_local), float(samples_local)
 
+    # ---- BASELINE.json's literal configuration: 64 spp = 8 steps, started on an idle device (no batching across more than
+    # those 8 iterations, nothing of a previous wavefront to overlap with) — reported next to the steady-state figure
+    literal = None
+    if world == 1 and not args.no_literal_config and shards == 1:
+        dev.clear_framebuffer()
+        dev.reset_stats()
+        l0 = time.perf_counter()
+        run(dev, 8)
+        dev.synchronize()
+        l_el = time.perf_counter() - l0
+        ls = dev.stats()
+        literal = {"workload": f"{W}x{H}, spi {spi} x 8 iterations = {8 * spi} spp, idle device to finished image",
+                   "value": round((ls["camera_rays"] + ls["bounce_rays"] + ls["shadow_rays"]) / l_el / 1e6, 3), "unit": "Mrays/s",
+                   "msamples_per_s": round(ls["camera_rays"] / l_el / 1e6, 3), "seconds": round(l_el, 4)}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's launches
         launches = max(1, st["traverse_primary_launches"])
         avg_ms = st["ms_traverse_primary"] / launches
-        # units per launch: replay the same steps with the work counters on (deterministic workload)
+        # units per launch: replay one batch of the same steps with the work counters on (deterministic workload; the per-launch
+        # averages of a run that is a whole number of 16-iteration batches equal those of one batch)
+        replay = 16 if (args.steps % 16 == 0 and args.steps >= 16 and (W, H, spi) == (WIDTH, HEIGHT, SPI) and shards == 1) else args.steps
         cdev = Device(local_rank, acquire_stats=2, stream_capacity=CAPACITY)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
-        run(cdev, args.steps)
+        run(cdev, replay)
         cs = cdev.stats()
         cdev.close()
         n_primary = cs["camera_rays"] + cs["bounce_rays"]
-        a_bytes = algorithmic_bytes(n_primary, cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"])
-        a_per_launch = a_bytes / max(1, cs["traverse_primary_launches"])
-        achieved = a_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        c_launches = max(1, cs["traverse_primary_launches"])
+        s_per_launch = stream_bytes(n_primary) / c_launches
+        g_per_launch = geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"]) / c_launches
+        # Each byte of the geometry has to come from HBM at least once per launch; what the rays re-visit beyond that is
+        # served by L1 / L2 / Infinity Cache whenever the BVH fits them. The HBM-side algorithmic bytes are therefore
+        # the streams + min(geometry visited, geometry resident); the 8(d) figure incl. every re-visit is kept separately.
+        geom_resident = int(scene.scene.primbvh_size) + int(scene.scene.scene_node_count) * 256 + int(scene.scene.scene_leaf_count) * 96
+        hbm_alg = s_per_launch + min(g_per_launch, geom_resident)
+        achieved = hbm_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        incl_cache = (s_per_launch + g_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # measured HBM-side bytes per launch of the same kernel: PMC passes of this command, summarised into
         # profiles/ by tools/prof_summary.py (counters cannot be read from inside the process)
-        traffic, traffic_src, limiter = None, None, None
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-        if os.path.exists(tpath) and (W, H, spi) == (1920, 1080, SPI) and world == 1 and args.scene == SCENE:
-            tk = json.load(open(tpath))["kernels"].get("k_traverse<false, false, false>")
-            if tk:
-                traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, x2 read correction)"
+        traffic, traffic_src, limiter, valu = None, None, None, None
+        stem = os.path.splitext(os.path.basename(args.scene))[0]
+        tname = f"{PROFILE_TAG}_traffic.json" if args.scene == SCENE else f"{PROFILE_TAG}_traffic_{stem}.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath) and (W, H, spi) == (WIDTH, HEIGHT, SPI) and world == 1:
+            tj = json.load(open(tpath))
+            tk = tj["kernels"].get("k_traverse<false, false, false>")
+            if tk and tj.get("steps") == args.steps:
+                traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes of this command at {args.steps} steps, x2 read correction)"
                 if "valu_lane_utilisation" in tk:
-                    # what actually limits the kernel on this 40 KB scene (SURVEY.md 8d asks for it next to the HBM fraction)
-                    limiter = {"kind": "VALU issue + latency (geometry is cache resident)", "valu_lane_utilisation": tk["valu_lane_utilisation"],
-                               "wave_wait_share": tk.get("wave_wait_share"), "wave_issue_share": tk.get("wave_issue_share"), "source": f"profiles/{TRAFFIC_FILE} (SQ counters)"}
+                    limiter = {"valu_lane_utilisation": tk["valu_lane_utilisation"], "wave_wait_share": tk.get("wave_wait_share"),
+                               "wave_issue_share": tk.get("wave_issue_share"), "source": f"profiles/{tname} (SQ counters)"}
+                if tk.get("valu_lane_ops_per_launch"):
+                    # VALU line: lane operations that did work (SQ_INSTS_VALU x 64 x lane utilisation) per second; issue_frac = share of the VALU issue slots used
+                    g = tk["valu_lane_ops_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    valu = {"achieved": round(g, 1), "peak": round(VALU_PEAK_GLANE_OPS, 1), "unit": "G lane-ops/s", "frac": round(g / VALU_PEAK_GLANE_OPS, 4),
+                            "issue_frac": tk.get("valu_issue_frac"), "source": f"profiles/{tname}"}
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "note": "achieved = SURVEY 8(d) algorithmic bytes (60 B/ray + 256 B/Node8 + 52 B/triangle + 96 B/entity leaf visited) / launch time; "
-                            "the geometry term is served by L1/L2 on this 40 KB scene, so the figure can exceed what HBM delivers: `traffic` is "
-                            "the measured HBM-side bytes per launch and `limiter` what actually bounds the kernel",
-                    "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
-                    "avg_launch_ms_incl_warmup": round((st["ms_traverse_primary"] + warm["ms_traverse_primary"])
-                                                       / max(1, launches + warm["traverse_primary_launches"]), 5),
-                    "algorithmic_bytes_per_launch": int(a_per_launch)}
+                    "measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,
+                    "note": "achieved = HBM-side algorithmic bytes per launch (60 B per ray of the streams + the geometry bytes that have to be fetched at "
+                            "least once: min(visited, resident)) / launch time; `incl_cache_hits` prices every Node8 / triangle / leaf visit at its size "
+                            "(SURVEY 8d's A), most of which L1 / L2 serve when the BVH is small; `traffic` = measured HBM-side bytes per launch",
+                    "incl_cache_hits": {"achieved": round(incl_cache, 2), "unit": "GB/s", "bytes_per_launch": int(s_per_launch + g_per_launch)},
+                    "stream_bytes_per_launch": int(s_per_launch), "geometry_resident_bytes": geom_resident,
+                    "valu": valu, "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                    "algorithmic_bytes_per_launch": int(hbm_alg)}
 
         stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")}
 
@@ -220,6 +272,7 @@ def main():
                    "sample": f"{n_it} iteration(s) of {os.path.basename(args.scene)} {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",
                    "msamples_per_s": round(cpu_samples / dt / 1e6, 3), "seconds": round(dt, 2)}
 
+        total_iterations = args.steps * (1 if by_rows else world)
         out = {
             "metric": "Mrays/s (primary+shadow)",
             "value": round(rays_total / elapsed / 1e6, 3),
@@ -233,10 +286,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {args.steps * (1 if by_rows else world)} iterations, seed {SEED}",
-                       "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs + one RCCL reduce" if by_rows else
+            "config": {"workload": f"{os.path.relpath(args.scene, ROOT)} {W}x{H}, path integrator, spi {spi} x {total_iterations} iterations, seed {SEED}",
+                       "sharding": "whole film" if shards == 1 else (f"film rows interleaved over {shards} GPUs (tile-sharded film), one RCCL collective at the end" if by_rows else
                                                                     f"{args.steps} full-film iterations per GPU (rank r: iterations r*K .. r*K+K-1) + one RCCL reduce")},
+            "timed_seconds": round(elapsed, 3),
             "msamples_per_s": round(samples_total / elapsed / 1e6, 3),
+            "literal_config": literal,
+            "collective": collective,
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"], "scope": "rank 0"},
             "stage_ms_rank0": stage_ms,
             "roofline": roofline,

@@ -929,3 +929,75 @@ def test_blend_bsdf_vs_oracle(gpu_device):
     ]
     sc = LoadedScene.from_string(json.dumps(base), SCENES, 96, 72)
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=37, iters=2)
+
+
+# ---- BASELINE.json configs at their named sizes (one iteration each: the oracle needs seconds)
+def test_config2_diamond_scene_1080p_spi8_full_size(gpu_device):
+    """configs[1]: scenes/diamond_scene.json 1920x1080, spi 8 — one iteration of the headline workload, 16.6 M camera paths:
+    all seven counters exact, radiance within 1e-4 relative L2."""
+    from ignis_amd.tables import LoadedScene
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 1920, 1080)
+    tot = _compare_with_oracle(gpu_device, scene, 1920, 1080, 8, seed=1)
+    assert tot["camera_rays"] == 1920 * 1080 * 8
+
+
+def test_config1_diamond_scene_512_spi4(gpu_device):
+    """configs[0]: 512x512, 4 spp as spi 4 x 1 iteration, fixed seed."""
+    from ignis_amd.tables import LoadedScene
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 512, 512)
+    tot = _compare_with_oracle(gpu_device, scene, 512, 512, 4, seed=1)
+    assert tot["camera_rays"] == 512 * 512 * 4
+
+
+def test_config4_many_point_lights_1080p_full_size(gpu_device):
+    """configs[3] at its named size (the procedural sky replaced by a constant environment)."""
+    scene = _many_lights_scene(1920, 1080)
+    _compare_with_oracle(gpu_device, scene, 1920, 1080, 8, seed=1)
+
+
+def test_resending_unchanged_parameters_keeps_the_batch(diamond_scene, monkeypatch):
+    """A caller that re-sends its whole registry before every iteration (IRenderDevice::render receives the ParameterSet with
+    every call) must not break the deferred batch: unchanged values do not flush, so four iterations still run as one
+    wavefront (fewer launches than four separate ones) with the identical image; a changed value does flush."""
+    from ignis_amd import Device
+    cam = diamond_scene.scene.camera
+    monkeypatch.setenv("IGD_TAIL_THRESHOLD", "0")  # wavefront rounds only: the launch count then tells how many wavefronts ran
+
+    def run(resend, change_at=None):
+        dev = Device(0, acquire_stats=True)
+        dev.assign_scene(diamond_scene)
+        for it in range(4):
+            if resend:
+                dev.set_parameter("__tech_max_depth", int(diamond_scene.scene.technique.max_depth) - (1 if change_at == it else 0))
+                dev.set_parameter("__tech_clamp", float(diamond_scene.scene.technique.clamp))
+                dev.set_parameter("__camera_eye", [cam.eye[0], cam.eye[1], cam.eye[2]])
+                dev.set_parameter("__unknown_to_the_device", 3.0)
+            dev.render(4, 128, 128, iteration=it, seed=2)
+        fb = dev.framebuffer().copy()
+        st = dev.stats()
+        dev.close()
+        return fb, st
+    fa, sa = run(False)
+    fb, sb = run(True)
+    np.testing.assert_array_equal(fa, fb)
+    assert sa["traverse_primary_launches"] == sb["traverse_primary_launches"]
+    _, sc = run(True, change_at=2)
+    assert sc["traverse_primary_launches"] > sa["traverse_primary_launches"]
+
+
+def test_bench_single_rank_through_rccl():
+    """bench.py's N > 1 code path with one rank (BENCH_FORCE_DIST=1): process group on the nccl (= RCCL) backend, zero-copy
+    torch view of the device framebuffer, the gather collective, the max-over-ranks timing — and the same JSON contract."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(os.path.dirname(SCENES), "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320", "--height", "180",
+           "--no-cpu-baseline", "--no-literal-config"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["collective"]["world_size_from_backend"] == 1 and line["collective"]["backend"] == "nccl"
+    assert line["collective"]["bytes_per_rank"] == 320 * 180 * 12
+    assert line["rays"]["camera"] == 320 * 180 * 8 * 4
+    assert 0 < line["roofline"]["frac"] <= 1

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, collective="reduce"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,7 +36,10 @@ def _worker(rank, world, port, out_path):
     assert sharding.check_shard(fb, rank, world)
     assert st["camera_rays"] == len(sharding.shard_rows(rank, world, H)) * W * SPI
     t = torch.from_numpy(fb)
-    sharding.reduce_framebuffer(t, dist, dst=0)
+    if collective == "gather":
+        sharding.gather_rows(t, rank, world, dist, dst=0)  # bench.py's collective: owned rows only
+    else:
+        sharding.reduce_framebuffer(t, dist, dst=0)
     rays = torch.tensor([st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]], dtype=torch.float64)
     dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     if rank == 0:
@@ -74,7 +77,7 @@ def _worker_iterations(rank, world, port, out_path, steps):
 
 
 def test_two_rank_iteration_sharding_sums_to_the_single_process_image(tmp_path):
-    """bench.py's default N > 1 partition: rank r renders iterations r, r + N, ...; reduce(SUM) = all iterations."""
+    """bench.py --sharding iterations: rank r renders iterations r*K .. r*K+K-1; reduce(SUM) = all iterations."""
     import torch.multiprocessing as mp
 
     import oracle
@@ -93,14 +96,17 @@ def test_two_rank_iteration_sharding_sums_to_the_single_process_image(tmp_path):
     assert int(got["rays"][0]) == rays
 
 
-def test_two_rank_row_sharding_reassembles_the_image(tmp_path):
+@pytest.mark.parametrize("collective,world", [("reduce", 2), ("gather", 2), ("gather", 3)])
+def test_two_rank_row_sharding_reassembles_the_image(tmp_path, collective, world):
+    """bench.py's default N > 1 partition (tile-sharded film, gather of the owned rows; H = 40 is not a multiple of 3, so the
+    three-rank case has ragged shards)."""
     import torch.multiprocessing as mp
 
     import oracle
     from ignis_amd.tables import LoadedScene
 
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, collective), nprocs=world, join=True)
     got = np.load(out)
 
     scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), W, H)

@@ -1,24 +1,39 @@
 #!/bin/bash
-# Runs ON the GPU box (via gpurun): rocprofv3 kernel statistics of the default bench command, then the PMC
-# passes (one counter group per run, combined only with --kernel-trace as the pool requires).
-# usage: tools/collect_profiles.sh <tag>        outputs under gpurun_out/<tag>/
+# Runs ON the GPU box (via gpurun): the bench line, rocprofv3 kernel statistics of the same command, then the PMC
+# passes (one counter group per run, combined only with --kernel-trace as the pool requires), and the summaries
+# that go into profiles/ (tools/prof_summary.py).
+# usage: tools/collect_profiles.sh <tag> [suffix] [bench args ...]
+#   outputs under gpurun_out/<tag>/:  <tag>_bench<suffix>.json  <tag>_rocprofv3_stats<suffix>.txt  <tag>_rocprofv3_pmc<suffix>.txt  <tag>_traffic<suffix>.json
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+SUF=${2:-}
+shift; shift
+ARGS="$*"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
+STEPS=$(python - "$@" <<'EOF'
+import sys
+a = sys.argv[1:]
+print(a[a.index("--steps") + 1] if "--steps" in a else 192)
+EOF
+)
 # 1. the bench line on its own (no profiler attached)
-timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 python bench.py $ARGS > "$OUT/${TAG}_bench$SUF.json" 2> "$OUT/bench$SUF.err"
 # 2. same command under --kernel-trace --stats
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python bench.py > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-# 3. PMC passes (shorter run of the same workload: counters serialise the kernels)
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats$SUF" -o stats -- python bench.py $ARGS --no-cpu-baseline > "$OUT/bench_under_rocprof$SUF.json" 2> "$OUT/stats$SUF.err"
+# 3. PMC passes of the same command (same step count: the per-launch averages then refer to the same launches)
 for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C" -o pmc -- python bench.py --no-cpu-baseline > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+    timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config > "$OUT/pmc_$C$SUF.json" 2> "$OUT/pmc_$C$SUF.err"
 done
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$OUT/pmc_SQ" -o pmc -- python bench.py --no-cpu-baseline > "$OUT/pmc_SQ.json" 2> "$OUT/pmc_SQ.err"
-timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE_CYCLES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --kernel-trace -d "$OUT/pmc_MEM" -o pmc -- python bench.py --no-cpu-baseline > "$OUT/pmc_MEM.json" 2> "$OUT/pmc_MEM.err"
-find "$OUT" -name "*.db" -size +30M -delete
-ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -40
-tail -c 600 "$OUT/bench.json"
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$OUT/pmc_SQ$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config > "$OUT/pmc_SQ$SUF.json" 2> "$OUT/pmc_SQ$SUF.err"
+timeout 900 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE_CYCLES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --kernel-trace -d "$OUT/pmc_MEM$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config > "$OUT/pmc_MEM$SUF.json" 2> "$OUT/pmc_MEM$SUF.err"
+db() { find "$OUT/$1" -name "*.db" | head -1; }
+python tools/prof_summary.py stats "$(db stats$SUF)" > "$OUT/${TAG}_rocprofv3_stats$SUF.txt" 2>> "$OUT/summary.err"
+python tools/prof_summary.py pmc "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$(db pmc_MEM$SUF)" > "$OUT/${TAG}_rocprofv3_pmc$SUF.txt" 2>> "$OUT/summary.err"
+python tools/prof_summary.py traffic "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$STEPS" > "$OUT/${TAG}_traffic$SUF.json" 2>> "$OUT/summary.err"
+find "$OUT" -name "*.db" -delete
+ls -la "$OUT" | head -40
+tail -c 400 "$OUT/${TAG}_bench$SUF.json"

@@ -3,7 +3,7 @@
 usage:
   python tools/prof_summary.py stats <stats.db>                      kernel table of `--kernel-trace --stats`
   python tools/prof_summary.py pmc <pmc.db> [<pmc.db> ...]           per-kernel sum / per-launch mean of each counter
-  python tools/prof_summary.py traffic <fetch.db> <write.db> [<sq.db>]   JSON: HBM-side bytes per launch per kernel (+ VALU lane utilisation)
+  python tools/prof_summary.py traffic <fetch.db> <write.db> [<sq.db>|-] [steps]   JSON: HBM-side bytes per launch per kernel (+ VALU lane utilisation)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. Calibration inside the same run (known byte counts):
 k_generate writes exactly 68 B per camera ray (WRITE_SIZE matches to 6 digits -> no correction); k_copy_paths reads
@@ -47,10 +47,10 @@ def short(name):
     return n.split("(")[0]
 
 
-def traffic(fetch_db, write_db, sq_db=None):
+def traffic(fetch_db, write_db, sq_db=None, steps=None):
     f, w = counters(fetch_db), counters(write_db)
     sq = counters(sq_db) if sq_db else {}
-    res = {"unit": "bytes per launch", "fetch_correction": 2.0,
+    res = {"unit": "bytes per launch", "fetch_correction": 2.0, "steps": steps,
            "note": "FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; reads doubled (gfx950 coalesced-read "
                    "correction, confirmed in-run by k_copy_paths: FETCH == WRITE / 2 for a pure copy), writes as reported "
                    "(k_generate: 68 B/ray exactly)",
@@ -72,6 +72,17 @@ def traffic(fetch_db, write_db, sq_db=None):
             res["kernels"][short(k)]["valu_lane_utilisation"] = round(q["SQ_THREAD_CYCLES_VALU"]["sum"] / (64.0 * q["SQ_ACTIVE_INST_VALU"]["sum"]), 4)
             res["kernels"][short(k)]["wave_wait_share"] = round(q["SQ_WAIT_ANY"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"], 4)
             res["kernels"][short(k)]["wave_issue_share"] = round(q["SQ_ACTIVE_INST_ANY"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"], 4) if "SQ_ACTIVE_INST_ANY" in q else None
+            if "SQ_INSTS_VALU" in q:
+                # VALU line: wave-instructions issued x 64 lanes = issue slots used; x lane utilisation = lane operations that did work.
+                # Peak: 256 CUs x 4 SIMDs x 32 lanes per cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz.
+                lanes = q["SQ_INSTS_VALU"]["mean"] * 64.0
+                util = res["kernels"][short(k)]["valu_lane_utilisation"]
+                secs = q["SQ_INSTS_VALU"]["avg_ns"] * 1e-9
+                peak = 256 * 4 * 32 * 2.4e9
+                res["kernels"][short(k)]["valu_insts_per_launch"] = int(q["SQ_INSTS_VALU"]["mean"])
+                res["kernels"][short(k)]["valu_lane_ops_per_launch"] = int(lanes * util)
+                res["kernels"][short(k)]["valu_issue_frac"] = round(lanes / secs / peak, 4) if secs > 0 else None
+                res["kernels"][short(k)]["avg_ns_under_pmc"] = int(q["SQ_INSTS_VALU"]["avg_ns"])
     print(json.dumps(res, indent=1))
 
 
@@ -83,6 +94,6 @@ if __name__ == "__main__":
         for p in sys.argv[2:]:
             pmc(p)
     elif mode == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None, int(sys.argv[5]) if len(sys.argv) > 5 else None)
     else:
         sys.exit(__doc__)
