@@ -150,4 +150,24 @@ IG_DEV bool tri_test(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f3 e2,
     return true;
 }
 
+// The same test without branches, for predicated callers (traverse_core.h): every lane computes all of it, the result
+// counts only where the returned flag is set. Identical arithmetic, hence identical t / u / v where it is.
+IG_DEV bool tri_test_flat(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f3 e2, f3 n, float& t_out, float& u_out, float& v_out)
+{
+    const f3 c         = v0 - r.org;
+    const f3 rr        = cross3(c, r.dir);
+    const float det    = dot3(n, r.dir);
+    const float adet   = igm_abs(det);
+    const uint32_t sgn = igm_bits(det) & 0x80000000u;
+    const float u      = igm_float(igm_bits(dot3(rr, e1)) ^ sgn);
+    const float v      = igm_float(igm_bits(dot3(rr, e2)) ^ sgn);
+    const float t      = igm_float(igm_bits(dot3(c, n)) ^ sgn);
+    const bool ok      = (u >= 0) & (v >= 0) & (u + v <= adet) & (det != 0) & (t >= adet * tmin) & (t <= adet * tmax);
+    const float rcp    = 1 / adet;
+    t_out              = t * rcp;
+    u_out              = igm_max(u * rcp, 0.0f);
+    v_out              = igm_max(v * rcp, 0.0f);
+    return ok;
+}
+
 } // namespace igdev

@@ -25,6 +25,7 @@
 
 namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream);
+int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
@@ -353,7 +354,7 @@ struct igd_device {
         f.tail_capacity = paths;
     }
 
-    int traverseGrid() const { return num_cus * 3; } // ~150 VGPRs, 48 KiB LDS per workgroup -> 3 workgroups (12 waves) per CU
+    int traverseGrid() const { return num_cus * igdev::traverse_workgroups_per_cu(); } // as many persistent workgroups as fit a CU (VGPRs and the LDS stacks, traverse_core.h)
     bool full_bsdfs = false; // the scene has a principled BSDF, a textured environment or a sun light: k_shade<true> / k_tail<*, true>
     int shade_mult = 64; // workgroups per CU in the k_shade grid (each loops over windows); IGD_SHADE_GRID
     int shadeGrid() const { return num_cus * shade_mult; }

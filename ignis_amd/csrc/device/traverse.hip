@@ -13,7 +13,7 @@ constexpr int kRefillIdle = 16;  // refill when at least this many lanes of a wa
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS, bool DEEP>
-__global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArgs a)
+__global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
 
@@ -84,9 +84,10 @@ __global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArg
             continue;
         }
 
+        // every lane steps: a lane without a ray is `finished` in mode 0, which no section of step() acts on. (Wrapping the call
+        // in `if (has_ray)` made the compiler copy the whole traversal state at the merge, ~35 v_mov per pass.)
+        tr.step(a.scene, s_stack, tid);
         if (has_ray) {
-            tr.step(a.scene, s_stack, tid);
-
             if (tr.finished && tr.overflow) {
                 has_ray = false;
                 if (DEEP) {
@@ -139,6 +140,8 @@ __global__ void __launch_bounds__(kBlockThreads, 3) k_traverse(const TraverseArg
         }
     }
 }
+
+int traverse_workgroups_per_cu() { return kTraverseOcc; }
 
 template <bool DEEP>
 static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)

@@ -12,6 +12,12 @@
 // (src/artic/traversal/mapping_cpu.art:282-518), on the same Node8 / Tri4 / EntityLeaf1 bytes,
 // so hits AND the visited-node / tested-triangle counts equal the CPU oracle's
 // (DESIGN.md "Traversal order").
+//
+// Control flow is wave-uniform by construction: every branch and loop condition below is a __ballot / __any over the
+// wave, the lanes a section does not concern run it predicated (safe addresses, results merged with selects), and only
+// stores sit under per-lane conditions. Written with per-lane `if`s the same machine spends a third of its VALU
+// instructions on register copies: the compiler's structurizer versions the ~35 state registers at every divergent
+// region and copies them back at the merge (60 v_mov per settle() iteration, measured in the ISA).
 #pragma once
 
 #include "dev_math.h"
@@ -21,25 +27,40 @@ namespace igdev {
 
 constexpr int kPostponeNum   = 1;   // a section needs kPostponeNum / 2^kPostponeShift of the wave's active lanes
 constexpr int kPostponeShift = 1;   // (0 disables postponing)
-constexpr int kLdsStack     = 24;  // 24 entries * 256 threads * 8 B = 48 KiB per workgroup (3 workgroups per CU)
+#ifndef IG_LDS_STACK
+#define IG_LDS_STACK 20
+#endif
+#ifndef IG_TRAV_OCC
+#define IG_TRAV_OCC 3
+#endif
+constexpr int kLdsStack     = IG_LDS_STACK;  // 20 entries * 256 threads * 8 B = 40 KiB (+ 12 KiB of ray terms) per workgroup, 3 workgroups per CU
+constexpr int kTraverseOcc  = IG_TRAV_OCC;   // workgroups of 256 per CU = waves per SIMD the kernel is built for
 constexpr int kBlockThreads = 256;
 
-// per-lane traversal stacks of one workgroup of BLOCK lanes, entry-major so that a wave's accesses are conflict free
+// Per-lane LDS of one workgroup of BLOCK lanes. `e`: the traversal stacks, entry-major so that a wave's accesses are conflict
+// free. `g`: the scene-space ray terms (written once per ray by begin(), read by the entity-leaf section and by inner nodes of
+// the scene level) — twelve registers per lane that the shape-level sections, where a ray spends most of its steps, do not
+// have to carry: g[0] = (inv_dir, inv_org.x), g[1] = (inv_org.yz, org.xy), g[2] = (org.z, dir).
 template <int BLOCK>
-using StackOf = uint2[kLdsStack][BLOCK];
+struct StackOf {
+    uint2 e[kLdsStack][BLOCK];
+    float4 g[3][BLOCK];
+};
 using StackLds = StackOf<kBlockThreads>;
 
-// DEEP: entries above the LDS part spill to global memory (push_entry); the persistent kernels run without it
-// and re-traverse the rare rays that need it in a second, DEEP launch (traverse.hip), because the extra branch in
+IG_DEV int sel(bool c, int a, int b) { return c ? a : b; }
+IG_DEV uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+IG_DEV float sel(bool c, float a, float b) { return c ? a : b; }
+
+// DEEP: entries above the LDS part spill to global memory; the persistent kernels run without it
+// and re-traverse the rare rays that need it in a second, DEEP launch (traverse.hip), because the extra work in
 // every push / pop costs 5 % on scenes that never need it.
 template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     // ---- ray + hit
-    // `gray` (the ray in scene space) is never written after begin(); `loc` (the ray in the current shape's
-    // space) only when an entity leaf is entered. Nothing in settle() touches either, which keeps the twelve
-    // registers of each out of every control-flow merge of the state machine.
-    RayT gray, loc;
+    // `loc`: the ray in the current shape's space, written when an entity leaf is entered (the scene-space terms are in LDS)
+    RayT loc;
     float tmin, tmax; // tmax == distance of the accepted hit (ray.tmax shrinks with it)
     uint32_t rflags;
     float hit_u, hit_v;
@@ -67,7 +88,27 @@ struct Traverser {
     {
         overflow = false;
         st_nodes = st_tris = st_leaves = 0;
-        finished = true;
+        // a lane without a ray: finished, mode 0 -> step() leaves it alone
+        finished  = true;
+        mode      = 0;
+        level     = 0;
+        lterm     = false;
+        need_cull = false;
+        top_node  = 0;
+        top_tmin  = 0;
+        ptr       = 0;
+        ent_last  = true;
+        ent_cursor = tri_cursor = 0;
+        node_off = tri_off = 0;
+        cur_ent  = -1;
+        lbase    = 0;
+        tmin = tmax = 0;
+        rflags = 0;
+        hit_u = hit_v = 0;
+        hit_prim = hit_ent = -1;
+        ltmax = l_u = l_v = 0;
+        l_prim = -1;
+        loc    = RayT{ f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 } };
     }
 
     // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here the first
@@ -79,39 +120,47 @@ struct Traverser {
         deep        = lane_column;
         deep_stride = stride;
     }
-    IG_DEV void push_entry(Stack& st, int tid, int n, float t)
+
+    // `on` lanes push (n, t). Out of stack: the ray ends here (popping a clamped slot again and again would never
+    // terminate); the caller sees finished && overflow and re-traverses it with the DEEP variant or reports the error.
+    IG_DEV void push_entry(Stack& st, int tid, bool on, int n, float t)
     {
-        ++ptr;
+        ptr += on ? 1 : 0;
         const uint2 e = make_uint2((uint32_t)n, igm_bits(t));
-        if (ptr < kLdsStack)
-            st[ptr][tid] = e;
-        else if (DEEP && ptr < kLdsStack + kDeepStack)
-            deep[(size_t)(ptr - kLdsStack) * deep_stride] = e;
-        else {
-            // out of stack: the ray ends here (popping a clamped slot again and again would never terminate);
-            // the caller sees finished && overflow and re-traverses it with the DEEP variant or reports the error
-            overflow = true;
-            finished = true;
+        if (on && ptr < kLdsStack)
+            st.e[ptr][tid] = e;
+        if (DEEP) {
+            if (on && ptr >= kLdsStack && ptr < kLdsStack + kDeepStack)
+                deep[(size_t)(ptr - kLdsStack) * deep_stride] = e;
         }
+        const bool out = on & (ptr >= (DEEP ? kLdsStack + kDeepStack : kLdsStack));
+        overflow       = overflow | out;
+        finished       = finished | out;
     }
-    IG_DEV void pop_top(Stack& st, int tid)
+    // `on` lanes pop the top entry into (top_node, top_tmin)
+    IG_DEV void pop_top(Stack& st, int tid, bool on)
     {
-        uint2 e;
-        if (!DEEP)
-            e = st[ptr < kLdsStack ? ptr : kLdsStack - 1][tid];
-        else if (ptr < kLdsStack)
-            e = st[ptr][tid];
-        else
-            e = deep[(size_t)((ptr < kLdsStack + kDeepStack ? ptr : kLdsStack + kDeepStack - 1) - kLdsStack) * deep_stride];
-        top_node = (int)e.x;
-        top_tmin = igm_float(e.y);
-        --ptr;
+        const int lds_slot = ptr < 0 ? 0 : (ptr < kLdsStack ? ptr : kLdsStack - 1);
+        uint2 e            = st.e[lds_slot][tid];
+        if (DEEP) {
+            if (__any(on && ptr >= kLdsStack)) {
+                if (on && ptr >= kLdsStack)
+                    e = deep[(size_t)((ptr < kLdsStack + kDeepStack ? ptr : kLdsStack + kDeepStack - 1) - kLdsStack) * deep_stride];
+            }
+        }
+        top_node = sel(on, (int)e.x, top_node);
+        top_tmin = sel(on, igm_float(e.y), top_tmin);
+        ptr -= on ? 1 : 0;
     }
 
+    // Starts a ray on the calling lanes (callers wrap this in their refill condition).
     IG_DEV void begin(const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
     {
-        gray   = make_ray_terms(org, dir);
-        loc    = gray;
+        const RayT g = make_ray_terms(org, dir);
+        st.g[0][tid] = make_float4(g.inv_dir.x, g.inv_dir.y, g.inv_dir.z, g.inv_org.x);
+        st.g[1][tid] = make_float4(g.inv_org.y, g.inv_org.z, g.org.x, g.org.y);
+        st.g[2][tid] = make_float4(g.org.z, g.dir.x, g.dir.y, g.dir.z);
+        loc    = g;
         tmin   = tmin_;
         tmax   = tmax_;
         rflags = flags;
@@ -132,72 +181,63 @@ struct Traverser {
         node_off   = 0; // Node8[] of the entered shape; the scene level uses sc.scene_nodes_off
         // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
         ptr      = -1;
-        top_node = 0, top_tmin = kFltMax;
-        push_entry(st, tid, top_node, top_tmin);
+        push_entry(st, tid, true, 0, kFltMax);
         top_node = sc.scene_node_count ? 1 : 0;
         top_tmin = tmin;
     }
 
+    // a lane is settled when it waits for a section (or is done): only stack-driven lanes have transitions to make
+    IG_DEV bool unsettled() const { return (mode == 0) & !finished & !((top_node > 0) & !need_cull & !((level == 1) & lterm)); }
+
     // Cheap state transitions up to the next heavy action: an entity-leaf step (mode 2), an inner
     // node on top (mode 0, top_node > 0), a triangle packet (mode 1), or the end of the ray.
     // The cull points are exactly the reference's (mapping_cpu.art:326-347): at level entry, after
-    // a leaf and after an inner node that pushed nothing.
+    // a leaf and after an inner node that pushed nothing. Each pass of the loop makes the transitions that need at most
+    // one pop per lane:
+    //   unwind (any-hit: the shape-level traversal returned early)  -> falls into `ret`
+    //   cull   : the top starts behind the current hit              -> pop, stay culling
+    //   ret    : sentinel on top at shape level                     -> pop the saved scene top, accept the local hit, next leaf
+    //   fin    : sentinel on top at scene level                     -> the ray is done
+    //   leaf   : leaf on top                                        -> pop, enter its items (or cull on if it starts behind the hit)
     IG_DEV void settle(const DevScene& sc, Stack& st, int tid)
     {
-        while (mode == 0 && !finished) {
-            if (level == 1 && lterm) {
-                // any-hit: the shape-level traversal returned early; unwind its stack entries
-                ptr      = lbase;
-                top_node = 0;
-            } else if (need_cull) {
-                const float cull_t = level ? ltmax : tmax;
-                while (top_node != 0 && !(top_tmin <= cull_t))
-                    pop_top(st, tid);
-                need_cull = false;
-            }
-            if (top_node == 0) {
-                if (level == 1) {
-                    // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
-                    // accepted only if its (rounded) distance does not exceed the current one.
-                    level = 0;
-                    lterm = false;
-                    pop_top(st, tid); // saved scene-level top
-                    if (l_prim != -1 && ltmax <= tmax) {
-                        tmax     = ltmax;
-                        hit_u    = l_u;
-                        hit_v    = l_v;
-                        hit_prim = l_prim;
-                        hit_ent  = cur_ent;
-                        if (ANY_HIT)
-                            finished = true;
-                    }
-                    if (ent_last)
-                        need_cull = true;
-                    else
-                        mode = 2;
-                } else {
-                    finished = true;
-                }
-            } else if (top_node > 0) {
-                break; // inner node pending
-            } else {
-                // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
-                // hit is dropped, its items have no effect in the reference either
-                const bool active = top_tmin <= (level ? ltmax : tmax);
-                if (level)
-                    tri_cursor = ~top_node;
-                else
-                    ent_cursor = ~top_node;
-                pop_top(st, tid);
-                if (active)
-                    mode = level ? 1 : 2;
-                else
-                    need_cull = true;
-            }
+        while (__any(unsettled())) {
+            const bool run    = (mode == 0) & !finished;
+            const bool unwind = run & (level == 1) & lterm;
+            ptr      = sel(unwind, lbase, ptr);
+            top_node = sel(unwind, 0, top_node);
+            const float cull_t = level ? ltmax : tmax;
+            const bool behind  = !(top_tmin <= cull_t);
+            const bool culling = run & !unwind & need_cull & (top_node != 0) & behind;
+            need_cull          = need_cull & !(run & !unwind & !culling);
+            const bool rest = run & !culling;
+            const bool ret  = rest & (top_node == 0) & (level == 1);
+            const bool fin  = rest & (top_node == 0) & (level == 0);
+            const bool leaf = rest & (top_node < 0);
+            // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
+            // hit is dropped, its items have no effect in the reference either
+            tri_cursor = sel(leaf & (level == 1), ~top_node, tri_cursor);
+            ent_cursor = sel(leaf & (level == 0), ~top_node, ent_cursor);
+            pop_top(st, tid, culling | ret | leaf);
+            // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
+            // accepted only if its (rounded) distance does not exceed the current one.
+            const bool accept = ret & (l_prim != -1) & (ltmax <= tmax);
+            tmax     = sel(accept, ltmax, tmax);
+            hit_u    = sel(accept, l_u, hit_u);
+            hit_v    = sel(accept, l_v, hit_v);
+            hit_prim = sel(accept, l_prim, hit_prim);
+            hit_ent  = sel(accept, cur_ent, hit_ent);
+            finished = finished | fin | (ANY_HIT & accept);
+            lterm    = lterm & !ret;
+            // (an any-hit ray that just accepted its hit is done: it must not be taken for a lane waiting at its next leaf)
+            mode     = sel(leaf & !behind, level ? 1 : 2, sel(ret & !ent_last & !(ANY_HIT & accept), 2, mode));
+            need_cull = need_cull | (ret & ent_last) | (leaf & behind);
+            level     = sel(ret, 0, level);
         }
     }
 
-    // One pipeline pass: entity leaf -> inner node -> triangle packet. Call while !finished.
+    // One pipeline pass: entity leaf -> inner node -> triangle packet. Every lane of the wave calls it; lanes without
+    // a ray (finished) are left alone.
     IG_DEV void step(const DevScene& sc, Stack& st, int tid)
     {
         const uint8_t* geom = sc.geom;
@@ -208,9 +248,9 @@ struct Traverser {
         // quorum the threshold drops to one lane for this pass, which guarantees progress.
         int quorum = 1;
         if (kPostponeShift > 0) {
-            const int active = __popcll(__ballot(true));
+            const int active = __popcll(__ballot(!finished));
             const int n_ent  = __popcll(__ballot(mode == 2));
-            const int n_node = __popcll(__ballot(mode == 0 && !finished));
+            const int n_node = __popcll(__ballot((mode == 0) & !finished));
             const int n_tri  = __popcll(__ballot(mode == 1));
             const int most   = n_ent > n_node ? (n_ent > n_tri ? n_ent : n_tri) : (n_node > n_tri ? n_node : n_tri);
             quorum           = (active * kPostponeNum) >> kPostponeShift;
@@ -219,31 +259,42 @@ struct Traverser {
         }
 
         // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
-        if (mode == 2 && (quorum <= 1 || __popcll(__ballot(mode == 2)) >= quorum)) {
+        if (__popcll(__ballot(mode == 2)) >= quorum) {
+            const float4 g0 = st.g[0][tid], g1 = st.g[1][tid], g2 = st.g[2][tid];
+            RayT gray;
+            gray.inv_dir = f3{ g0.x, g0.y, g0.z };
+            gray.inv_org = f3{ g0.w, g1.x, g1.y };
+            gray.org     = f3{ g1.z, g1.w, g2.x };
+            gray.dir     = f3{ g2.y, g2.z, g2.w };
             // leaves whose box (or visibility mask) rejects the ray cost only this short loop
-            const float4* lf;
-            uint2 ext;
-            int entity_id;
-            bool enter;
-            do {
-                lf  = reinterpret_cast<const float4*>(sc.leaves + ent_cursor);
-                ext = sc.leaf_ext[ent_cursor];
-                ++ent_cursor;
+            const bool here = mode == 2;
+            bool scanning   = here;
+            bool enter      = false;
+            int enter_at    = 0;
+            int entity_id   = 0;
+            while (__any(scanning)) {
+                const int at     = scanning ? ent_cursor : 0;
+                const float4* lf = reinterpret_cast<const float4*>(sc.leaves + at);
                 const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
-                entity_id             = (int)igm_bits(l0.w);
+                ent_cursor += scanning ? 1 : 0;
+                const int id          = (int)igm_bits(l0.w);
                 const uint32_t lflags = igm_bits(l5.x);
-                ent_last              = entity_id < 0;
+                ent_last              = scanning ? (id < 0) : ent_last;
                 if (STATS)
-                    ++st_leaves;
-                enter = false;
+                    st_leaves += scanning ? 1u : 0u;
                 // check_ray_visibility (traversal/ray.art:51)
-                if ((rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK)) {
-                    float entry, exit;
-                    slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
-                    enter = (entry <= exit) & (exit >= 0) & (entry <= tmax);
-                }
-            } while (!enter && !ent_last);
-            if (enter) {
+                const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
+                float entry, exit;
+                slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
+                const bool inside = scanning & visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
+                enter             = enter | inside;
+                enter_at          = sel(inside, at, enter_at);
+                entity_id         = sel(inside, id, entity_id);
+                scanning          = scanning & !inside & !(id < 0);
+            }
+            if (__any(enter)) {
+                const float4* lf = reinterpret_cast<const float4*>(sc.leaves + enter_at);
+                const uint2 ext  = sc.leaf_ext[enter_at];
                 const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4];
                 m34 m;
                 m.c0 = f3{ l2.x, l2.y, l2.z };
@@ -251,41 +302,49 @@ struct Traverser {
                 m.c2 = f3{ l3.z, l3.w, l4.x };
                 m.c3 = f3{ l4.y, l4.z, l4.w };
                 // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                loc     = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
-                cur_ent = entity_id & 0x7FFFFFFF;
+                const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                loc.org.x = sel(enter, nl.org.x, loc.org.x), loc.org.y = sel(enter, nl.org.y, loc.org.y), loc.org.z = sel(enter, nl.org.z, loc.org.z);
+                loc.dir.x = sel(enter, nl.dir.x, loc.dir.x), loc.dir.y = sel(enter, nl.dir.y, loc.dir.y), loc.dir.z = sel(enter, nl.dir.z, loc.dir.z);
+                loc.inv_dir.x = sel(enter, nl.inv_dir.x, loc.inv_dir.x), loc.inv_dir.y = sel(enter, nl.inv_dir.y, loc.inv_dir.y), loc.inv_dir.z = sel(enter, nl.inv_dir.z, loc.inv_dir.z);
+                loc.inv_org.x = sel(enter, nl.inv_org.x, loc.inv_org.x), loc.inv_org.y = sel(enter, nl.inv_org.y, loc.inv_org.y), loc.inv_org.z = sel(enter, nl.inv_org.z, loc.inv_org.z);
+                cur_ent = sel(enter, entity_id & 0x7FFFFFFF, cur_ent);
                 // save the scene-level top, then a fresh stack: sentinel + shape root
-                push_entry(st, tid, top_node, top_tmin);
-                lbase  = ptr;
-                ltmax  = tmax; // invalid_hit(local_ray.tmax)
-                l_prim = -1;
-                lterm  = false;
-                push_entry(st, tid, 0, kFltMax);
-                top_node  = 1;
-                top_tmin  = tmin;
-                level     = 1;
-                mode      = 0;
-                need_cull = true;
-                node_off  = ext.x;
-                tri_off   = ext.y;
-            } else {
-                mode      = 0;
-                need_cull = true;
+                push_entry(st, tid, enter, top_node, top_tmin);
+                lbase  = sel(enter, ptr, lbase);
+                ltmax  = sel(enter, tmax, ltmax); // invalid_hit(local_ray.tmax)
+                l_prim = sel(enter, -1, l_prim);
+                lterm  = lterm & !enter;
+                push_entry(st, tid, enter, 0, kFltMax);
+                top_node = sel(enter, 1, top_node);
+                top_tmin = sel(enter, tmin, top_tmin);
+                level    = sel(enter, 1, level);
+                node_off = sel(enter, ext.x, node_off);
+                tri_off  = sel(enter, ext.y, tri_off);
             }
+            mode      = sel(here, 0, mode);
+            need_cull = need_cull | here;
             settle(sc, st, tid);
         }
 
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
-        if (mode == 0 && !finished && (quorum <= 1 || __popcll(__ballot(mode == 0 && !finished)) >= quorum)) {
-            const uint8_t* np = geom + (level ? node_off : sc.scene_nodes_off) + (uint32_t)(top_node - 1) * 256u;
-            pop_top(st, tid);
+        if (__popcll(__ballot((mode == 0) & !finished)) >= quorum) {
+            const bool here   = (mode == 0) & !finished; // settled: an inner node is on top
+            const uint8_t* np = geom + (level ? node_off : sc.scene_nodes_off) + (here ? (uint32_t)(top_node - 1) * 256u : 0u);
+            pop_top(st, tid, here);
             const float4* nf = reinterpret_cast<const float4*>(np);
             const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
             if (STATS)
-                ++st_nodes;
+                st_nodes += here ? 1u : 0u;
             bool pushed           = false;
             const float node_tmax = level ? ltmax : tmax;
-            const f3 inv = level ? loc.inv_dir : gray.inv_dir;
-            const f3 io  = level ? loc.inv_org : gray.inv_org;
+            f3 inv = loc.inv_dir, io = loc.inv_org;
+            if (__any(here & (level == 0))) { // scene-level node: the terms of the untransformed ray
+                const float4 g0 = st.g[0][tid];
+                const float2 g1 = *reinterpret_cast<const float2*>(&st.g[1][tid]);
+                const bool s    = level == 0;
+                inv = f3{ sel(s, g0.x, inv.x), sel(s, g0.y, inv.y), sel(s, g0.z, inv.z) };
+                io  = f3{ sel(s, g0.w, io.x), sel(s, g1.x, io.y), sel(s, g1.y, io.z) };
+            }
             // The slab test of the reference takes min / max of the two plane distances per axis
             // (intersection.art:38-58); which plane is the near one is decided by the sign of inv_dir alone
             // (fma is monotonic and lo <= hi), so the near / far rows are picked by address instead and six
@@ -295,75 +354,81 @@ struct Traverser {
             // two halves of four children keep the live register set small
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                const int4 c4 = nc[h];
+                if (h == 1 && !__any(here & ((c4.x | c4.y | c4.z | c4.w) != 0)))
+                    break; // no lane has a child in the second half
                 const float4 nx = nf[2 * ox + h], fx = nf[2 * (1 - ox) + h];
                 const float4 ny = nf[2 * (2 + oy) + h], fy = nf[2 * (3 - oy) + h];
                 const float4 nz = nf[2 * (4 + oz) + h], fz = nf[2 * (5 - oz) + h];
                 const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
                 const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
-                const int4 c4   = nc[h];
                 const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float entry = igm_max(igm_max(igm_fma(inv.x, nb[0][i], io.x), igm_fma(inv.y, nb[1][i], io.y)), igm_max(igm_fma(inv.z, nb[2][i], io.z), tmin));
                     const float exit  = igm_min(igm_min(igm_fma(inv.x, fb[0][i], io.x), igm_fma(inv.y, fb[1][i], io.y)), igm_min(igm_fma(inv.z, fb[2][i], io.z), node_tmax));
-                    const bool hit = (ch[i] != 0) & !(exit < entry);
-                    if (hit) {
-                        // push (becomes the top) if nearer than the current top, else push_after
-                        const bool front = ANY_HIT || (top_tmin > entry);
-                        push_entry(st, tid, front ? top_node : ch[i], front ? top_tmin : entry);
-                        if (front) {
-                            top_node = ch[i];
-                            top_tmin = entry;
-                        }
-                        pushed = true;
-                    }
+                    const bool hit = here & (ch[i] != 0) & !(exit < entry);
+                    // push (becomes the top) if nearer than the current top, else push_after
+                    const bool front = ANY_HIT || (top_tmin > entry);
+                    push_entry(st, tid, hit, front ? top_node : ch[i], front ? top_tmin : entry);
+                    top_node = sel(hit & front, ch[i], top_node);
+                    top_tmin = sel(hit & front, entry, top_tmin);
+                    pushed   = pushed | hit;
                 }
             }
-            if (!pushed)
-                need_cull = true;
+            need_cull = need_cull | (here & !pushed);
             settle(sc, st, tid);
         }
 
         // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
-        const bool run_tri = quorum <= 1 || __popcll(__ballot(mode == 1)) >= quorum;
-        while (run_tri && mode == 1) {
-            const uint8_t* tp = geom + tri_off + (uint32_t)tri_cursor * 208u;
-            ++tri_cursor;
-            const float4* tf = reinterpret_cast<const float4*>(tp);
-            float q[12][4];
+        if (__popcll(__ballot(mode == 1)) >= quorum) {
+            while (__any(mode == 1)) {
+                const bool here   = mode == 1;
+                const uint8_t* tp = geom + tri_off + (here ? (uint32_t)tri_cursor * 208u : 0u);
+                tri_cursor += here ? 1 : 0;
+                // two triangles of the packet at a time (8-byte halves of its twelve SoA rows): 24 live registers instead
+                // of 48, and the second half is not even fetched when no lane's packet holds more than two triangles
+                const int4 pid4  = reinterpret_cast<const int4*>(tp)[12];
+                const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
+                bool valid       = here;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const float4 x = tf[k];
-                q[k][0] = x.x, q[k][1] = x.y, q[k][2] = x.z, q[k][3] = x.w;
-            }
-            const int4 pid4  = reinterpret_cast<const int4*>(tp)[12];
-            const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
-            bool valid       = true;
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !__any(valid & (pid[2] != -1) & !(ANY_HIT & lterm)))
+                        break;
+                    const float2* tf = reinterpret_cast<const float2*>(tp) + h;
+                    float q[12][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                valid = valid & (pid[i] != -1);
-                if (valid && !(ANY_HIT && lterm)) {
-                    if (STATS)
-                        ++st_tris;
-                    float t, u, v;
-                    if (tri_test(loc, tmin, ltmax, f3{ q[0][i], q[1][i], q[2][i] }, f3{ q[3][i], q[4][i], q[5][i] },
-                                 f3{ q[6][i], q[7][i], q[8][i] }, f3{ q[9][i], q[10][i], q[11][i] }, t, u, v)) {
-                        ltmax  = t;
-                        l_u    = u;
-                        l_v    = v;
-                        l_prim = pid[i] & 0x7FFFFFFF;
+                    for (int k = 0; k < 12; ++k) {
+                        const float2 x = tf[2 * k];
+                        q[k][0] = x.x, q[k][1] = x.y;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int i   = 2 * h + j;
+                        valid         = valid & (pid[i] != -1);
+                        const bool on = valid & !(ANY_HIT & lterm);
+                        if (STATS)
+                            st_tris += on ? 1u : 0u;
+                        float t = 0, u = 0, v = 0;
+                        const bool ok = tri_test_flat(loc, tmin, ltmax, f3{ q[0][j], q[1][j], q[2][j] }, f3{ q[3][j], q[4][j], q[5][j] },
+                                                 f3{ q[6][j], q[7][j], q[8][j] }, f3{ q[9][j], q[10][j], q[11][j] }, t, u, v) & on;
+                        ltmax  = sel(ok, t, ltmax);
+                        l_u    = sel(ok, u, l_u);
+                        l_v    = sel(ok, v, l_v);
+                        l_prim = sel(ok, pid[i] & 0x7FFFFFFF, l_prim);
                         if (ANY_HIT)
-                            lterm = true;
+                            lterm = lterm | ok;
                     }
                 }
+                const bool leave = here & ((pid[3] < 0) | (ANY_HIT & lterm));
+                mode             = sel(leave, 0, mode);
+                need_cull        = need_cull | leave;
             }
-            if (pid[3] < 0 || (ANY_HIT && lterm)) {
-                mode      = 0;
-                need_cull = true;
+            if (ANY_HIT) {
+                if (__any(lterm))
+                    settle(sc, st, tid); // return to the scene level now: the hit may end the ray
             }
         }
-        if (ANY_HIT && lterm)
-            settle(sc, st, tid); // return to the scene level now: the hit may end the ray
     }
 };
 

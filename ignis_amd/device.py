@@ -55,7 +55,8 @@ def lib():
     """Loads libig_device_hip.so; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
-        path = os.path.join(_LIB_DIR, "libig_device_hip.so")
+        # IGD_LIBRARY: kernel-variant experiments only (tools/build_variant.sh); the product library is the in-tree one
+        path = os.environ.get("IGD_LIBRARY") or os.path.join(_LIB_DIR, "libig_device_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension must be built (__graft_entry__.build()); "
                                "ignis_amd has no CPU fallback")

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Kernel-variant experiments: builds ignis_amd/lib/var/libig_device_hip_<name>.so with extra -D flags.
+# usage: tools/build_variant.sh <name> [-DIG_TRAV_OCC=4 -DIG_LDS_STACK=20 ...]      run with IGD_LIBRARY=<that file>
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/ignis_amd/lib/var/$NAME
+mkdir -p "$OUT"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-parameter -I$ROOT/include"
+for f in traverse shade tail device; do
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c "$ROOT/ignis_amd/csrc/device/$f.hip" -o "$OUT/$f.o" &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OUT"/*.o -o "$ROOT/ignis_amd/lib/var/libig_device_hip_$NAME.so"
+rm -rf "$OUT"
+echo "$ROOT/ignis_amd/lib/var/libig_device_hip_$NAME.so"
