@@ -9,7 +9,10 @@
 
 namespace igdev {
 
-constexpr int kRefillIdle = 16;  // refill when at least this many lanes of a wave are idle
+#ifndef IG_REFILL_IDLE
+#define IG_REFILL_IDLE 32
+#endif
+constexpr int kRefillIdle = IG_REFILL_IDLE;  // refill when at least this many lanes of a wave are idle
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS, bool DEEP>
