@@ -1,141 +1,163 @@
-// HipRenderDevice.cpp — the C++ side of the drop-in: IG::IRenderDevice / IG::IDeviceInterface
-// implemented on top of the C ABI in include/igd_device.h, so the reference runtime's DeviceManager
-// (src/runtime/device/DeviceManager.cpp:65-258) can dlopen it as `ig_device_hip.so` and pick it for
-// `--gpu-arch amd` (GPUArchitecture::AMD_HSA, src/runtime/device/Target.cpp:43-54).
+// HipRenderDevice.cpp — the reference-facing shell of the drop-in: IG::IRenderDevice / IG::IDeviceInterface for the HIP
+// backend, so the reference runtime's DeviceManager (src/runtime/device/DeviceManager.cpp:65-258) can dlopen it as
+// `ig_device_hip.so` and pick it for `--gpu-arch amd` (GPUArchitecture::AMD_HSA, src/runtime/device/Target.cpp:43-54).
 //
-// This file is compiled ONLY inside a reference build tree (it needs the reference's headers, hence
-// the same Eigen / STL as libig_runtime): add it to src/device/CMakeLists.txt as shown in
-// INTEGRATION.md. It is not part of `make` in this repo (none of those headers exist here) and holds
-// no rendering logic: every method is one igd_* call.
-//
-// What cannot cross this boundary as-is: the reference hands materials / lights / camera / technique
-// to a device as JIT-compiled Artic (TechniqueVariantShaderSet of void* entry points). This backend
-// needs them as PODs (include/ig_tables.h), so the adapter asks the companion host library
-// (include/igh_host.h) to lower the scene FILE the runtime was given; the SceneDatabase tables the
-// runtime built (Node8/Tri4 for a vector-width-8 CPU target) are byte-compatible and could be passed
-// through instead once the loader exposes them for GPU targets.
+// UNCOMPILED IN THIS REPOSITORY. It includes the reference's headers, which all reach Eigen through IG_Config.h; Eigen is
+// not available here and no stand-in is written for it. Everything that could be written without those headers lives in
+// hip_adapter_core.{h,cpp} (compiled by `make`, unit-tested): this file only converts types —
+//   std::string / std::vector<uint8> tables of SceneDatabase  -> igadapter::DatabaseView (pointers + sizes)
+//   ParameterSet maps, Eigen vectors                           -> forwardInt / forwardFloat / forwardVector
+//   IG::Ray                                                    -> igadapter::PlainRay
+//   igadapter::StatsSink                                       -> IG::Statistics::increase / beginShaderLaunch
+// Build: add to src/device/CMakeLists.txt as INTEGRATION.md shows, linking libig_adapter_core, libig_device_hip, libig_host.
 #include "device/IDeviceInterface.h" // reference: src/runtime/device/IDeviceInterface.h
 #include "device/IRenderDevice.h"    // reference: src/runtime/device/IRenderDevice.h
 #include "Logger.h"
 #include "Statistics.h"
 #include "table/SceneDatabase.h"
 
-#include "igd_device.h"
-#include "igh_host.h"
+#include "hip_adapter_core.h"
 
 #include <cstdlib>
 
 namespace IG {
 
-class HipRenderDevice final : public IRenderDevice {
+// The one addition the reference runtime needs: IRenderDevice has no channel for the scene DESCRIPTION —
+// devices receive materials / lights / camera / technique as JIT-compiled Artic — so Runtime::loadFromFile / loadFromString
+// hand it to devices that implement this interface (dynamic_cast) before assignScene().
+class ISceneDescriptionSink {
+public:
+    virtual ~ISceneDescriptionSink()                                                       = default;
+    virtual bool setSceneFile(const Path& path)                                            = 0;
+    virtual bool setSceneString(const std::string& json, const Path& base_dir)             = 0;
+};
+
+class HipRenderDevice final : public IRenderDevice, public ISceneDescriptionSink {
 public:
     explicit HipRenderDevice(const SetupSettings& s)
         : mSetup(s)
+        , mCore((int)s.target.device(), s.AcquireStats, s.DebugTrace, s.IsInteractive)
     {
-        igd_setup setup{};
-        setup.gpu_index      = (int32_t)s.target.device();
-        setup.acquire_stats  = s.AcquireStats ? 1 : 0;
-        setup.debug_trace    = s.DebugTrace ? 1 : 0;
-        setup.is_interactive = s.IsInteractive ? 1 : 0;
-        // "Normals" / "Albedo" are asked for by name only when the runtime's denoiser is on; keeping them costs two film buffers and
-        // one extra camera-ray traversal at iteration 0
-        setup.info_aovs      = 1;
-        mDev                 = igd_create(&setup);
-        if (!mDev) {
-            IG_LOG(L_FATAL) << "ig_device_hip: " << igd_last_error() << std::endl;
+        if (!mCore.ok()) {
+            IG_LOG(L_FATAL) << "ig_device_hip: " << mCore.error() << std::endl;
             std::abort(); // the reference aborts on unrecoverable device errors (Device.cpp:303-306)
         }
     }
-    ~HipRenderDevice() override
-    {
-        igd_destroy(mDev);
-        igh_free(mScene);
-    }
 
-    // The runtime exports the path of the scene it loaded through IG_HIP_SCENE_FILE (one-line patch in
-    // Runtime::loadFromFile); the tables in settings.database stay untouched.
-    void assignScene(const SceneSettings&) override
+    bool setSceneFile(const Path& path) override { return report(mCore.setSceneFile(path.generic_string())); }
+    bool setSceneString(const std::string& json, const Path& base_dir) override { return report(mCore.setSceneString(json, base_dir.generic_string())); }
+
+    void assignScene(const SceneSettings& settings) override
     {
-        const char* path = std::getenv("IG_HIP_SCENE_FILE");
-        igh_free(mScene);
-        mScene = path ? igh_load_file(path, nullptr) : nullptr;
-        if (!mScene) {
-            IG_LOG(L_ERROR) << "ig_device_hip: " << (path ? igh_last_error() : "IG_HIP_SCENE_FILE is not set") << std::endl;
-            return;
+        igadapter::DatabaseView view;
+        const igadapter::DatabaseView* db = nullptr;
+        if (settings.database) {
+            const SceneDatabase& d = *settings.database;
+            auto fix               = [&](const char* n) { const auto it = d.FixTables.find(n); return it == d.FixTables.end() ? igadapter::Bytes{} : igadapter::Bytes{ it->second.data().data(), it->second.data().size() }; };
+            view.entities          = fix("entities");
+            view.primbvh           = fix("trimesh_primbvh");
+            if (const auto it = d.DynTables.find("shapes"); it != d.DynTables.end()) {
+                view.shape_lookups = { reinterpret_cast<const uint8_t*>(it->second.lookups().data()), it->second.lookups().size() * sizeof(LookupEntry) };
+                view.shape_data    = { it->second.data().data(), it->second.data().size() };
+            }
+            if (const auto it = d.SceneBVHs.find("trimesh"); it != d.SceneBVHs.end()) {
+                view.scene_nodes  = { it->second.Nodes.data(), it->second.Nodes.size() };
+                view.scene_leaves = { it->second.Leaves.data(), it->second.Leaves.size() };
+            }
+            if (settings.entity_per_material) {
+                view.entity_per_material = settings.entity_per_material->data();
+                view.material_count      = settings.entity_per_material->size();
+            }
+            view.scene_radius = d.SceneRadius;
+            db                = &view;
         }
-        if (igd_assign_scene(mDev, igh_tables(mScene)) != IGD_OK)
-            IG_LOG(L_ERROR) << "ig_device_hip: " << igd_last_error() << std::endl;
+        if (report(mCore.assignScene(db)) && db && !mCore.usedRuntimeTables())
+            IG_LOG(L_DEBUG) << "ig_device_hip: " << mCore.error() << std::endl;
     }
 
     void render(const TechniqueVariantShaderSet&, const RenderSettings& rs, ParameterSet* params) override
     {
-        if (params) { // the global registry of this iteration (Runtime.cpp:366-387)
+        if (params) { // the global registry of this iteration (Runtime.cpp:366-387); unchanged values do not break the device's batch
             for (const auto& p : params->IntParameters)
-                igd_set_parameter_i32(mDev, p.first.c_str(), p.second);
+                mCore.forwardInt(p.first.c_str(), p.second);
             for (const auto& p : params->FloatParameters)
-                igd_set_parameter_f32(mDev, p.first.c_str(), p.second);
-            for (const auto& p : params->VectorParameters) {
-                const float v[3] = { p.second.x(), p.second.y(), p.second.z() };
-                igd_set_parameter_vec3(mDev, p.first.c_str(), v);
-            }
+                mCore.forwardFloat(p.first.c_str(), p.second);
+            for (const auto& p : params->VectorParameters)
+                mCore.forwardVector(p.first.c_str(), p.second.x(), p.second.y(), p.second.z());
         }
-        igd_render_settings s{};
-        std::vector<float> rays;
-        if (rs.rays) { // Runtime::trace: width = #rays, height = 1 (Runtime.cpp:389-446)
-            rays.resize(rs.width * 8);
+        std::vector<igadapter::PlainRay> rays;
+        if (rs.rays) {
+            rays.resize(rs.width);
             for (size_t i = 0; i < rs.width; ++i) {
-                const Vector3f d = rs.rays[i].Direction.normalized(); // Device.cpp:602-643
-                float* o         = rays.data() + i * 8;
-                o[0] = rs.rays[i].Origin.x(), o[1] = rs.rays[i].Origin.y(), o[2] = rs.rays[i].Origin.z();
-                o[3] = d.x(), o[4] = d.y(), o[5] = d.z();
-                o[6] = rs.rays[i].Range.x(), o[7] = rs.rays[i].Range.y();
+                const Ray& r = rs.rays[i];
+                rays[i]      = igadapter::PlainRay{ { r.Origin.x(), r.Origin.y(), r.Origin.z() }, { r.Direction.x(), r.Direction.y(), r.Direction.z() }, { r.Range.x(), r.Range.y() } };
             }
-            s.rays = rays.data();
         }
-        s.spi = (int32_t)rs.spi, s.width = (int32_t)rs.width, s.height = (int32_t)rs.height;
-        s.iteration = (int32_t)rs.iteration, s.frame = (int32_t)rs.frame, s.user_seed = (int32_t)rs.user_seed;
-        s.row_offset = 0, s.row_stride = 1;
-        if (igd_render(mDev, &s) != IGD_OK)
-            IG_LOG(L_ERROR) << "ig_device_hip: " << igd_last_error() << std::endl;
+        report(mCore.render(rs.rays ? rays.data() : nullptr, rs.spi, rs.width, rs.height, rs.iteration, rs.frame, rs.user_seed));
     }
 
-    void resize(size_t w, size_t h) override { igd_resize(mDev, (int32_t)w, (int32_t)h); }
-    void releaseAll() override { igd_release_all(mDev); }
+    void resize(size_t w, size_t h) override { mCore.resize(w, h); }
+    void releaseAll() override { mCore.releaseAll(); }
 
     Target target() const override { return mSetup.target; }
-    size_t framebufferWidth() const override { return (size_t)igd_framebuffer_width(mDev); }
-    size_t framebufferHeight() const override { return (size_t)igd_framebuffer_height(mDev); }
+    size_t framebufferWidth() const override { return mCore.framebufferWidth(); }
+    size_t framebufferHeight() const override { return mCore.framebufferHeight(); }
     bool isInteractive() const override { return mSetup.IsInteractive; }
 
-    AOVAccessor getFramebufferForHost(const std::string& name, bool sync) override
-    {
-        return AOVAccessor{ const_cast<float*>(igd_framebuffer_host(mDev, name.c_str(), sync ? 1 : 0)) };
-    }
-    AOVAccessor getFramebufferForDevice(const std::string& name, bool) override { return AOVAccessor{ igd_framebuffer_device(mDev, name.c_str()) }; }
-    void clearFramebuffer(const std::string& name) override { igd_clear_framebuffer(mDev, name.c_str()); }
-    void clearAllFramebuffer() override { igd_clear_framebuffer(mDev, nullptr); }
-    void syncFramebufferHostToDevice(const std::string& name) override
-    {
-        if (const float* host = igd_framebuffer_host(mDev, name.c_str(), 0))
-            igd_sync_framebuffer_to_device(mDev, name.c_str(), host);
-    }
-    void syncAllFramebufferHostToDevice() override { syncFramebufferHostToDevice({}); }
+    AOVAccessor getFramebufferForHost(const std::string& name, bool sync) override { return AOVAccessor{ mCore.framebufferForHost(name, sync) }; }
+    AOVAccessor getFramebufferForDevice(const std::string& name, bool) override { return AOVAccessor{ mCore.framebufferForDevice(name) }; }
+    void clearFramebuffer(const std::string& name) override { mCore.clearFramebuffer(name); }
+    void clearAllFramebuffer() override { mCore.clearAllFramebuffer(); }
+    void syncFramebufferHostToDevice(const std::string& name) override { mCore.syncFramebufferHostToDevice(name); }
+    void syncAllFramebufferHostToDevice() override { mCore.syncFramebufferHostToDevice({}); }
 
-    // Named buffers, tonemap, imageinfo, bake and runPass are JIT entry points outside the hot path
-    // (OUT); the reference's own error behaviour for unknown names is "log + empty".
-    size_t getBufferSizeInBytes(const std::string&) override { return 0; }
-    bool copyBufferToHost(const std::string&, void*, size_t) override { return false; }
-    BufferAccessor getBufferForDevice(const std::string&) override { return BufferAccessor{ nullptr, 0 }; }
-    const Statistics* getStatistics() override { return nullptr; }
+    size_t getBufferSizeInBytes(const std::string& name) override { return mCore.bufferSizeInBytes(name); }
+    bool copyBufferToHost(const std::string& name, void* dst, size_t max_bytes) override { return mCore.copyBufferToHost(name, dst, max_bytes); }
+    BufferAccessor getBufferForDevice(const std::string& name) override
+    {
+        size_t n = 0;
+        void* p  = mCore.bufferForDevice(name, &n);
+        return BufferAccessor{ p, n };
+    }
+
+    const Statistics* getStatistics() override
+    {
+        // Statistics::dump (igcli --stats, Statistics.cpp:286-290) reads the three quantities and the per-shader launch counts /
+        // workloads; its times come from its own host timers around begin / endShaderLaunch, so device times go to the log
+        struct Sink final : igadapter::StatsSink {
+            Statistics* s;
+            void quantity(int q, uint64_t v) override { s->increase((Quantity)q, v); }
+            void shader(int t, uint64_t launches, uint64_t workload, double ms) override
+            {
+                for (uint64_t i = 0; i < launches; ++i) {
+                    s->beginShaderLaunch((ShaderType)t, (size_t)(workload / launches), 0);
+                    s->endShaderLaunch((ShaderType)t, 0);
+                }
+                if (launches)
+                    IG_LOG(L_DEBUG) << "ig_device_hip: shader type " << t << ": " << ms << " ms of device time in " << launches << " launches" << std::endl;
+            }
+        } sink;
+        sink.s = &mStatistics;
+        mCore.drainStatistics(sink);
+        return &mStatistics;
+    }
+
+    // JIT entry points outside the hot path (OUT)
     void tonemap(uint32_t*, const TonemapSettings&) override { IG_LOG(L_ERROR) << "ig_device_hip: tonemap is not part of the HIP backend" << std::endl; }
     ImageInfoOutput imageinfo(const ImageInfoSettings&) override { return ImageInfoOutput{}; }
     void bake(const ShaderOutput<void*>&, const std::vector<std::string>*, float*) override {}
     void runPass(const ShaderOutput<void*>&) override {}
 
 private:
+    bool report(bool ok)
+    {
+        if (!ok)
+            IG_LOG(L_ERROR) << "ig_device_hip: " << mCore.error() << std::endl;
+        return ok;
+    }
     SetupSettings mSetup;
-    igd_device* mDev  = nullptr;
-    igh_scene* mScene = nullptr;
+    igadapter::Core mCore;
+    Statistics mStatistics;
 };
 
 // ICompilerDevice: nothing is compiled at run time (kernels are AOT-built for gfx950); a non-null token

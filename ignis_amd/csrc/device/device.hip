@@ -103,6 +103,7 @@ struct igd_device {
     // scene
     bool has_scene = false;
     DevBuf<uint8_t> geom, shape_data;
+    size_t primbvh_bytes = 0; // the "trimesh_primbvh" fix table at the start of geom
     DevBuf<ig_entity_leaf1> leaves;
     DevBuf<uint2> leaf_ext;
     DevBuf<float> entities;
@@ -433,6 +434,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: BVH blob exceeds 4 GiB (32-bit node offsets)" };
     blob.resize(blob.size() + 256); // tail padding: vector loads never run past the allocation
     d->geom.upload(blob.data(), blob.size());
+    d->primbvh_bytes = (size_t)s->primbvh_size;
 
     // per scene leaf: where its shape's Node8[] / Tri4[] start (EntityLeaf1.user = offset in floats,
     // shapes/trimesh.art:201-219: header {node_count, tri_count, pad, pad}, nodes, tris)
@@ -691,6 +693,12 @@ void submit(igd_device* d, const igd_render_settings* rs)
 {
     validateSettings(d, rs);
     const int cnt = std::max(1, rs->iterations);
+    if (d->setup.blocking_render) { // the reference's contract: complete, errors included, when the call returns
+        flushPending(d);
+        render(d, rs);
+        finish(d);
+        return;
+    }
     if (rs->rays != nullptr || d->setup.is_interactive || d->batch_rays == 0) {
         flushPending(d);
         render(d, rs);
@@ -1269,6 +1277,42 @@ FilmBuffer filmBuffer(igd_device* d, const char* name)
 
 } // namespace
 
+namespace {
+struct NamedBuffer {
+    void* ptr      = nullptr;
+    uint64_t bytes = 0;
+};
+// device-resident tables under the names the reference uses for them (SceneDatabase tables, film buffers)
+NamedBuffer namedBuffer(igd_device* d, const char* name)
+{
+    if (!name)
+        return {};
+    const std::string n(name);
+    auto of = [](auto& b) { return NamedBuffer{ b.ptr, (uint64_t)b.count * sizeof(*b.ptr) }; };
+    if (n == "entities")
+        return of(d->entities);
+    if (n == "shapes")
+        return NamedBuffer{ d->shape_data.ptr, d->shape_data.count ? (uint64_t)d->shape_data.count - 64 : 0 }; // (64 bytes of tail padding)
+    if (n == "trimesh_primbvh")
+        return NamedBuffer{ d->geom.ptr, d->geom.ptr ? (uint64_t)d->primbvh_bytes : 0 };
+    if (n == "scene_bvh_nodes")
+        return NamedBuffer{ d->geom.ptr ? d->geom.ptr + d->dscene.scene_nodes_off : nullptr, (uint64_t)d->dscene.scene_node_count * sizeof(ig_node8) };
+    if (n == "scene_bvh_leaves")
+        return of(d->leaves);
+    if (n == "materials")
+        return of(d->materials);
+    if (n == "lights")
+        return of(d->lights);
+    if (n == "Color" || n == "Default")
+        return of(d->fb);
+    if (d->setup.info_aovs && n == "Normals")
+        return of(d->aov[0]);
+    if (d->setup.info_aovs && n == "Albedo")
+        return of(d->aov[1]);
+    return {};
+}
+} // namespace
+
 extern "C" {
 
 uint32_t igd_get_abi_version(void) { return IGD_ABI_VERSION; }
@@ -1517,6 +1561,50 @@ int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const 
         HIP_CHECK(hipMemcpy(b.dev->ptr, data, (size_t)dev->fb_w * dev->fb_h * 3 * sizeof(float), hipMemcpyHostToDevice));
         *b.dirty = true;
     });
+}
+
+uint64_t igd_buffer_size(igd_device* dev, const char* name)
+{
+    g_error.clear();
+    if (!dev)
+        return 0;
+    return dev->has_scene || (name && (std::strcmp(name, "Color") == 0 || std::strcmp(name, "Default") == 0)) ? namedBuffer(dev, name).bytes : 0;
+}
+
+int32_t igd_buffer_copy(igd_device* dev, const char* name, void* dst, uint64_t max_bytes)
+{
+    return guarded("igd_buffer_copy", [&] {
+        if (!dev || !name || (!dst && max_bytes))
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
+        const NamedBuffer b = namedBuffer(dev, name);
+        if (!b.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown buffer '") + name + "'" };
+        const uint64_t n = std::min(b.bytes, max_bytes);
+        if (n)
+            HIP_CHECK(hipMemcpy(dst, b.ptr, n, hipMemcpyDeviceToHost));
+    });
+}
+
+void* igd_buffer_ptr(igd_device* dev, const char* name, uint64_t* size_in_bytes)
+{
+    void* result = nullptr;
+    if (size_in_bytes)
+        *size_in_bytes = 0;
+    guarded("igd_buffer_ptr", [&] {
+        if (!dev || !name)
+            throw HipError{ IGD_ERR_INVALID_ARG, "NULL argument" };
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev);
+        const NamedBuffer b = namedBuffer(dev, name);
+        if (!b.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown buffer '") + name + "'" };
+        result = b.ptr;
+        if (size_in_bytes)
+            *size_in_bytes = b.bytes;
+    });
+    return result;
 }
 
 int32_t igd_get_stats(igd_device* dev, igd_stats* out)

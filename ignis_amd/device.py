@@ -13,7 +13,8 @@ from .tables import Scene, _LIB_DIR
 
 class Setup(C.Structure):
     _fields_ = [("gpu_index", C.c_int32), ("acquire_stats", C.c_int32), ("debug_trace", C.c_int32),
-                ("is_interactive", C.c_int32), ("stream_capacity", C.c_uint64), ("info_aovs", C.c_int32)]
+                ("is_interactive", C.c_int32), ("stream_capacity", C.c_uint64), ("info_aovs", C.c_int32),
+                ("blocking_render", C.c_int32)]
 
 
 class RenderSettings(C.Structure):
@@ -45,7 +46,7 @@ EXPORTS = [
     "igd_resize", "igd_release_all", "igd_framebuffer_width", "igd_framebuffer_height", "igd_framebuffer_host",
     "igd_framebuffer_device", "igd_clear_framebuffer", "igd_sync_framebuffer_to_device", "igd_get_stats",
     "igd_reset_stats", "igd_traverse", "igd_set_parameter_i32", "igd_set_parameter_f32", "igd_set_parameter_vec3",
-    "igd_synchronize", "igd_last_error",
+    "igd_synchronize", "igd_last_error", "igd_buffer_size", "igd_buffer_copy", "igd_buffer_ptr",
 ]
 
 _lib = None
@@ -104,6 +105,12 @@ def lib():
         l.igd_synchronize.restype = C.c_int32
         l.igd_synchronize.argtypes = [C.c_void_p]
         l.igd_last_error.restype = C.c_char_p
+        l.igd_buffer_size.restype = C.c_uint64
+        l.igd_buffer_size.argtypes = [C.c_void_p, C.c_char_p]
+        l.igd_buffer_copy.restype = C.c_int32
+        l.igd_buffer_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        l.igd_buffer_ptr.restype = C.c_void_p
+        l.igd_buffer_ptr.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
         _lib = l
     return _lib
 
@@ -126,11 +133,12 @@ def device_count():
 class Device:
     """One MI355X render device (IRenderDevice counterpart)."""
 
-    def __init__(self, gpu_index=0, acquire_stats=False, stream_capacity=0, info_aovs=False):
+    def __init__(self, gpu_index=0, acquire_stats=False, stream_capacity=0, info_aovs=False, blocking_render=False, interactive=False):
         # acquire_stats: False/0 off, 1 HIP-event stage timers, True/2 timers + traversal work counters
         level = 2 if acquire_stats is True else int(acquire_stats)
         # info_aovs: the "Normals" / "Albedo" AOVs of the denoiser's info buffer, read with framebuffer("Normals") / ("Albedo")
-        setup = Setup(int(gpu_index), level, 0, 0, int(stream_capacity), int(bool(info_aovs)))
+        # blocking_render: every render() call completes before it returns (the reference's contract) instead of being deferred
+        setup = Setup(int(gpu_index), level, 0, int(bool(interactive)), int(stream_capacity), int(bool(info_aovs)), int(bool(blocking_render)))
         self._h = lib().igd_create(C.byref(setup))
         if not self._h:
             raise DeviceError(-2, lib().igd_last_error().decode())
@@ -173,6 +181,22 @@ class Device:
             if v.size != 3:
                 raise ValueError("vector parameters have 3 components here")
             _check(lib().igd_set_parameter_vec3(self._h, n, v.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def buffer(self, name):
+        """Device-resident table by name (IRenderDevice::copyBufferToHost): uint8 array, or None for an unknown name."""
+        n = name.encode()
+        size = int(lib().igd_buffer_size(self._h, n))
+        if size == 0:
+            return None
+        out = np.empty(size, np.uint8)
+        _check(lib().igd_buffer_copy(self._h, n, out.ctypes.data_as(C.c_void_p), size))
+        return out
+
+    def buffer_device_ptr(self, name):
+        """(device pointer, size in bytes) of a named buffer (IRenderDevice::getBufferForDevice); (None, 0) if unknown."""
+        size = C.c_uint64(0)
+        p = lib().igd_buffer_ptr(self._h, name.encode(), C.byref(size))
+        return (int(p) if p else None), int(size.value)
 
     def synchronize(self):
         """Waits for the part of the last render that overlaps the next one (tail paths + resolve) and reports

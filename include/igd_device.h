@@ -50,6 +50,9 @@ typedef struct igd_setup {
     int32_t info_aovs;        /* != 0: the "Normals" and "Albedo" AOVs of the info-buffer wrapper the runtime adds for the denoiser
                                * (InfoBufferTechnique.cpp:6-18, technique/internal/infobuffer.art): first hits of the camera rays of
                                * iteration 0; read them through the framebuffer accessors by name */
+    int32_t blocking_render;  /* != 0: igd_render executes its iteration and returns when it is complete, like the reference's
+                               * IRenderDevice::render (SURVEY.md 8b "Threading"), errors included. 0 (default): igd_render records
+                               * and defers, see igd_render below. is_interactive implies immediate execution (not completion). */
 } igd_setup;
 
 /* IRenderDevice::RenderSettings (IRenderDevice.h:30-40). `rays` != NULL selects the
@@ -99,7 +102,15 @@ void igd_destroy(igd_device* dev);
  * The scene is copied to HBM; the host pointers need not outlive this call. */
 int32_t igd_assign_scene(igd_device* dev, const igd_scene* scene);
 
-/* IRenderDevice::render (IRenderDevice.h:44, Device.cpp:1672-1682): one iteration, blocking. */
+/* IRenderDevice::render (IRenderDevice.h:44, Device.cpp:1672-1682).
+ * CONTRACT (differs from the reference unless igd_setup.blocking_render is set): the call validates its arguments — those
+ * errors are returned here — and RECORDS the iteration; it may return before anything has run. Consecutive iterations of the
+ * same film / spi / seed / sharding are executed together as one wavefront (see igd_synchronize below for when). What a caller
+ * can observe is unchanged: every accessor of results (framebuffer, statistics, buffers) first executes and drains what is
+ * pending, and the image is bit-identical to executing every call on its own. What a caller must NOT assume: that the time
+ * spent inside igd_render is the iteration's render time, or that an error of the execution (device fault, traversal stack
+ * overflow) is returned by the igd_render that caused it — it is returned by the next call that drains (any accessor,
+ * igd_synchronize). With igd_setup.blocking_render != 0 the call executes and completes the iteration before it returns. */
 int32_t igd_render(igd_device* dev, const igd_render_settings* settings);
 
 /* IRenderDevice::resize (IRenderDevice.h:45): reallocates and clears the framebuffer. */
@@ -126,6 +137,15 @@ int32_t igd_clear_framebuffer(igd_device* dev, const char* name);
 /* IRenderDevice::syncFramebufferHostToDevice (IRenderDevice.h:58): uploads `data`
  * (float[height][width][3]) into the device framebuffer (checkpoint resume). */
 int32_t igd_sync_framebuffer_to_device(igd_device* dev, const char* name, const float* data);
+
+/* IRenderDevice::getBufferSizeInBytes / copyBufferToHost / getBufferForDevice (IRenderDevice.h:62-64): the device-resident
+ * tables by the names the reference gives them — "entities", "shapes", "trimesh_primbvh" (SceneDatabase tables,
+ * src/runtime/table/SceneDatabase.h), "scene_bvh_nodes", "scene_bvh_leaves" — plus "materials", "lights" (ig_tables.h PODs) and
+ * the film buffers "Color" / "Normals" / "Albedo". Unknown names: size 0, copy returns IGD_ERR_INVALID_ARG, ptr NULL (the
+ * reference logs and returns an empty accessor, Device.cpp:1391-1395). The accessors drain pending work first. */
+uint64_t igd_buffer_size(igd_device* dev, const char* name);
+int32_t igd_buffer_copy(igd_device* dev, const char* name, void* dst, uint64_t max_bytes);
+void* igd_buffer_ptr(igd_device* dev, const char* name, uint64_t* size_in_bytes);
 
 /* IRenderDevice::getStatistics (IRenderDevice.h:66): cumulative since igd_reset_stats. */
 int32_t igd_get_stats(igd_device* dev, igd_stats* out);
