@@ -114,80 +114,98 @@ float TriMesh::computeArea() const
     return area;
 }
 
+// Is this mesh one planar quad (two congruent triangles over four vertices)? Then area lights on it use the analytic plane
+// sampler (src/runtime/light/AreaLight.cpp:50-72). The decision and the frame must be the reference's
+// (src/runtime/mesh/TriMesh.cpp:521-620) — which corner becomes the origin and which edges the axes decides what the light's
+// random numbers mean — but the code is this file's own:
+//   1. exactly two faces over exactly four vertices. (The reference has a second branch for five or six vertices with
+//      duplicates; its counter can reach at most three, so that branch rejects every mesh, and so does this.)
+//   2. both triangles face the same way: unit normals equal in Eigen's isApprox sense, |a - b|^2 <= eps^2 min(|a|^2, |b|^2)
+//   3. congruent triangles: every squared edge length of the second one is among the first one's (+- eps)
+//   4. frame: origin = vertex 0; of its three neighbours the two that enclose the widest angle are the quad's edges, the third
+//      is the opposite corner. Widest angle = smallest cosine (acos is monotonic), ties resolved in the reference's order of
+//      pairs (1,2), (2,3), (3,1). x / y follow that cyclic order, swapped if their cross product opposes the face normal.
+//   5. texture coordinates of the corners in the order origin, x end, y end, opposite — or the unit square.
+namespace {
+constexpr float kPlaneEps = 1e-5f;
+
+bool sameDirection(V3 a, V3 b)
+{
+    const V3 d = a - b;
+    return dot(d, d) <= kPlaneEps * kPlaneEps * std::min(dot(a, a), dot(b, b));
+}
+
+// squared edge lengths of triangle `t` of a face-index list with four entries per face
+std::array<float, 3> edgeLengths2(const TriMesh& m, size_t t)
+{
+    std::array<float, 3> e{};
+    for (int k = 0; k < 3; ++k) {
+        const V3 d = m.vertices[m.indices[4 * t + k]] - m.vertices[m.indices[4 * t + (k + 1) % 3]];
+        e[k]       = dot(d, d);
+    }
+    return e;
+}
+} // namespace
+
 std::optional<PlaneShape> TriMesh::getAsPlane() const
 {
-    constexpr float PlaneEPS = 1e-5f;
-    if (faceCount() != 2)
+    if (faceCount() != 2 || vertices.size() != 4)
         return std::nullopt;
 
-    std::array<V3, 4> unique_verts;
-    std::array<uint32_t, 4> unique_ids{};
-    if (vertices.size() != 4) {
-        // The reference also accepts 5-6 vertices with duplicates; its dedup loop reads
-        // uninitialised slots (TriMesh.cpp:534-557), so only the exact 4-vertex case is kept.
+    V3 face_normal[2];
+    for (size_t t = 0; t < 2; ++t)
+        face_normal[t] = normalized(computeTriangleNormal(vertices[indices[4 * t]], vertices[indices[4 * t + 1]], vertices[indices[4 * t + 2]]));
+    if (!sameDirection(face_normal[0], face_normal[1]))
         return std::nullopt;
+
+    const auto first = edgeLengths2(*this, 0), second = edgeLengths2(*this, 1);
+    for (float e : second) {
+        bool found = false;
+        for (float f : first)
+            found |= std::abs(f - e) <= kPlaneEps;
+        if (!found)
+            return std::nullopt;
     }
-    for (size_t i = 0; i < 4; ++i) {
-        unique_verts[i] = vertices[i];
-        unique_ids[i]   = (uint32_t)i;
-    }
 
-    const V3 fn0 = normalized(computeTriangleNormal(vertices[indices[0]], vertices[indices[1]], vertices[indices[2]]));
-    const V3 fn1 = normalized(computeTriangleNormal(vertices[indices[4]], vertices[indices[5]], vertices[indices[6]]));
-    if (!isApprox(fn0, fn1, PlaneEPS))
-        return std::nullopt;
+    // neighbours of the origin as unit directions; cosine between the cyclic pairs (1,2), (2,3), (3,1).
+    // The reference compares acos() of these in float: do the same so that near-ties fall the same way.
+    const V3 origin = vertices[0];
+    V3 dir[3];
+    for (int k = 0; k < 3; ++k)
+        dir[k] = normalized(vertices[k + 1] - origin);
+    float angle[3];
+    for (int k = 0; k < 3; ++k)
+        angle[k] = std::abs(std::acos(dot(dir[k], dir[(k + 1) % 3])));
+    int widest = 2;
+    if (angle[0] >= angle[1] && angle[0] >= angle[2])
+        widest = 0;
+    else if (angle[1] >= angle[2] && angle[1] >= angle[0])
+        widest = 1;
 
-    auto sq = [&](uint32_t a, uint32_t b) {
-        const V3 d = vertices[indices[a]] - vertices[indices[b]];
-        return dot(d, d);
-    };
-    const float e1 = sq(0, 1), e2 = sq(1, 2), e3 = sq(2, 0);
-    const float e4 = sq(4, 5), e5 = sq(5, 6), e6 = sq(6, 4);
-    const auto safeCheck = [=](float a, float b) { return std::abs(a - b) <= PlaneEPS; };
-    if (!safeCheck(e1, e4) && !safeCheck(e2, e4) && !safeCheck(e3, e4))
-        return std::nullopt;
-    if (!safeCheck(e1, e5) && !safeCheck(e2, e5) && !safeCheck(e3, e5))
-        return std::nullopt;
-    if (!safeCheck(e1, e6) && !safeCheck(e2, e6) && !safeCheck(e3, e6))
-        return std::nullopt;
-
-    const V3 origin   = unique_verts[0];
-    auto computeAngle = [&](size_t start) {
-        const V3 x = normalized(unique_verts[(start + 0) % 3 + 1] - origin);
-        const V3 y = normalized(unique_verts[(start + 1) % 3 + 1] - origin);
-        return std::acos(dot(x, y));
-    };
-    const float a12 = std::abs(computeAngle(0));
-    const float a23 = std::abs(computeAngle(1));
-    const float a31 = std::abs(computeAngle(2));
-    int sel         = 2;
-    if (a12 >= a23 && a12 >= a31)
-        sel = 0;
-    else if (a23 >= a31 && a23 >= a12)
-        sel = 1;
-
+    // corner ids: [origin, x end, y end]; the remaining vertex is the opposite corner
+    uint32_t x_end = (uint32_t)(widest % 3 + 1), y_end = (uint32_t)((widest + 1) % 3 + 1);
     PlaneShape shape;
     shape.origin = origin;
-    shape.x_axis = unique_verts[(sel + 0) % 3 + 1] - origin;
-    shape.y_axis = unique_verts[(sel + 1) % 3 + 1] - origin;
-
-    const V3 normal = normalized(cross(shape.x_axis, shape.y_axis));
-    if (dot(fn0, normal) < 0) {
+    shape.x_axis = vertices[x_end] - origin;
+    shape.y_axis = vertices[y_end] - origin;
+    const bool flipped = dot(face_normal[0], normalized(cross(shape.x_axis, shape.y_axis))) < 0;
+    if (flipped)
         std::swap(shape.x_axis, shape.y_axis);
-        std::swap(unique_verts[1], unique_verts[2]);
-        std::swap(unique_ids[1], unique_ids[2]);
-    }
 
-    if (!texcoords.empty()) {
-        shape.texcoords[0]                 = texcoords[unique_ids[0]];
-        shape.texcoords[(0 + sel) % 3 + 1] = texcoords[unique_ids[1]];
-        shape.texcoords[(1 + sel) % 3 + 1] = texcoords[unique_ids[2]];
-        shape.texcoords[(2 + sel) % 3 + 1] = texcoords[unique_ids[3]];
-    } else {
+    if (texcoords.empty()) {
         shape.texcoords[0] = V2{ 0, 0 };
         shape.texcoords[1] = V2{ 1, 0 };
         shape.texcoords[2] = V2{ 0, 1 };
         shape.texcoords[3] = V2{ 1, 1 };
+    } else {
+        // The reference fills slot (k + widest) % 3 + 1 from vertex k + 1 (k = 0, 1, 2) after exchanging vertices 1 and 2 when
+        // the frame was flipped — an assignment by vertex number, not by corner role; kept as it is (TriMesh.cpp:606-611).
+        uint32_t id[4] = { 0, 1, 2, 3 };
+        if (flipped)
+            std::swap(id[1], id[2]);
+        shape.texcoords[0] = texcoords[id[0]];
+        for (int k = 0; k < 3; ++k)
+            shape.texcoords[(k + widest) % 3 + 1] = texcoords[id[k + 1]];
     }
     return shape;
 }
@@ -456,187 +474,248 @@ TriMesh TriMesh::MakeIcoSphere(V3 center, float radius, uint32_t subdivisions)
 }
 
 // ---------------------------------------------------------------- PLY
+//
+// A table-driven reader: the header is parsed into elements and typed properties, and one generic decoder walks the body
+// in file order. What a mesh needs is picked by NAME (x y z, nx ny nz, s t / u v; the `vertex_indices` / `vertex_index`
+// list), everything else — other elements, extra properties, lists — is decoded and dropped. Every scalar type of the
+// format is understood (char … double and the int8 … float64 spellings, ascii / little / big endian); the reference's reader
+// (src/runtime/mesh/PlyFile.cpp:70-290) handles float properties and uchar / uint lists only, for which this one yields the
+// same mesh: normals renormalised, quads and larger polygons split as a fan around their first corner (the reference
+// ear-clips polygons of more than four corners and falls back to that fan, :30-66), four indices per face.
 
 namespace {
-struct PlyHeader {
-    int VertexCount = 0, FaceCount = 0;
-    int XElem = -1, YElem = -1, ZElem = -1, NXElem = -1, NYElem = -1, NZElem = -1, UElem = -1, VElem = -1;
-    int VertexPropCount = 0;
-    int IndElem         = -1;
-    bool SwitchEndianness = false;
-    bool idxIsByteCount   = true;
-    bool hasVertices() const { return XElem >= 0 && YElem >= 0 && ZElem >= 0; }
-    bool hasNormals() const { return NXElem >= 0 && NYElem >= 0 && NZElem >= 0; }
-    bool hasUVs() const { return UElem >= 0 && VElem >= 0; }
+namespace ply {
+
+enum class Scalar { I8, U8, I16, U16, I32, U32, F32, F64 };
+
+struct ScalarName {
+    const char* name;
+    Scalar type;
+};
+constexpr ScalarName kScalarNames[] = {
+    { "char", Scalar::I8 },    { "int8", Scalar::I8 },     { "uchar", Scalar::U8 },  { "uint8", Scalar::U8 },
+    { "short", Scalar::I16 },  { "int16", Scalar::I16 },   { "ushort", Scalar::U16 }, { "uint16", Scalar::U16 },
+    { "int", Scalar::I32 },    { "int32", Scalar::I32 },   { "uint", Scalar::U32 },  { "uint32", Scalar::U32 },
+    { "float", Scalar::F32 },  { "float32", Scalar::F32 }, { "double", Scalar::F64 }, { "float64", Scalar::F64 },
+};
+constexpr size_t kScalarSize[] = { 1, 1, 2, 2, 4, 4, 4, 8 };
+
+struct Property {
+    std::string name;
+    Scalar type       = Scalar::F32; // value type (element type of a list)
+    bool is_list      = false;
+    Scalar count_type = Scalar::U8;
+};
+struct Element {
+    std::string name;
+    size_t count = 0;
+    std::vector<Property> props;
+};
+enum class Format { Ascii, Little, Big };
+
+// Body of the file: whitespace-separated tokens (ascii) or packed scalars (binary)
+class Body {
+public:
+    Body(const std::vector<char>& bytes, size_t offset, Format format, const std::string& path)
+        : mBytes(bytes)
+        , mPos(offset)
+        , mFormat(format)
+        , mPath(path)
+    {
+    }
+    double next(Scalar type)
+    {
+        if (mFormat == Format::Ascii) {
+            while (mPos < mBytes.size() && std::isspace((unsigned char)mBytes[mPos]))
+                ++mPos;
+            const size_t start = mPos;
+            while (mPos < mBytes.size() && !std::isspace((unsigned char)mBytes[mPos]))
+                ++mPos;
+            if (start == mPos)
+                throw std::runtime_error("PLY file '" + mPath + "': unexpected end of data");
+            return std::strtod(std::string(&mBytes[start], mPos - start).c_str(), nullptr);
+        }
+        const size_t n = kScalarSize[(int)type];
+        if (mPos + n > mBytes.size())
+            throw std::runtime_error("PLY file '" + mPath + "': truncated data");
+        unsigned char raw[8];
+        for (size_t k = 0; k < n; ++k) // to host (little endian) byte order
+            raw[k] = (unsigned char)mBytes[mPos + (mFormat == Format::Big ? n - 1 - k : k)];
+        mPos += n;
+        switch (type) {
+        case Scalar::I8: return (double)(int8_t)raw[0];
+        case Scalar::U8: return (double)raw[0];
+        case Scalar::I16: { int16_t v; std::memcpy(&v, raw, 2); return v; }
+        case Scalar::U16: { uint16_t v; std::memcpy(&v, raw, 2); return v; }
+        case Scalar::I32: { int32_t v; std::memcpy(&v, raw, 4); return v; }
+        case Scalar::U32: { uint32_t v; std::memcpy(&v, raw, 4); return v; }
+        case Scalar::F32: { float v; std::memcpy(&v, raw, 4); return v; }
+        default: { double v; std::memcpy(&v, raw, 8); return v; }
+        }
+    }
+
+private:
+    const std::vector<char>& mBytes;
+    size_t mPos;
+    Format mFormat;
+    const std::string& mPath;
 };
 
-template <typename T>
-T swap_endian(T u)
+Scalar scalarOf(const std::string& word, const std::string& path)
 {
-    unsigned char b[sizeof(T)];
-    std::memcpy(b, &u, sizeof(T));
-    for (size_t k = 0; k < sizeof(T) / 2; ++k)
-        std::swap(b[k], b[sizeof(T) - k - 1]);
-    std::memcpy(&u, b, sizeof(T));
-    return u;
+    for (const auto& s : kScalarNames)
+        if (word == s.name)
+            return s.type;
+    throw std::runtime_error("PLY file '" + path + "': unknown property type '" + word + "'");
 }
 
-// Faces with 3 vertices are kept, 4 become a fan; larger polygons use the
-// reference's convex-fan fallback (PlyFile.cpp:30-66; its ear-clipping path is
-// only reached by meshes outside the hot-path configs).
-void triangulate(const std::vector<uint32_t>& g, std::vector<uint32_t>& out)
-{
-    if (g.size() < 3)
-        return;
-    for (uint32_t j = 2; j < (uint32_t)g.size(); ++j)
-        out.insert(out.end(), { g[0], g[j - 1], g[j], 0 });
-}
+} // namespace ply
 } // namespace
 
 TriMesh load_ply(const std::string& path)
 {
-    std::ifstream stream(path, std::ios::in | std::ios::binary);
-    if (!stream)
-        throw std::runtime_error("PLY file '" + path + "' can not be opened");
-
-    std::string magic;
-    stream >> magic;
-    if (magic != "ply")
-        throw std::runtime_error("'" + path + "' is not a ply file");
-
-    std::string method;
-    PlyHeader header;
-    int facePropCounter = 0;
-    for (std::string line; std::getline(stream, line);) {
-        std::stringstream ss(line);
-        std::string action;
-        ss >> action;
-        if (action == "comment")
-            continue;
-        else if (action == "format")
-            ss >> method;
-        else if (action == "element") {
-            std::string type;
-            ss >> type;
-            if (type == "vertex")
-                ss >> header.VertexCount;
-            else if (type == "face")
-                ss >> header.FaceCount;
-        } else if (action == "property") {
-            std::string type;
-            ss >> type;
-            if (type == "float") {
-                std::string name;
-                ss >> name;
-                const int c = header.VertexPropCount;
-                if (name == "x") header.XElem = c;
-                else if (name == "y") header.YElem = c;
-                else if (name == "z") header.ZElem = c;
-                else if (name == "nx") header.NXElem = c;
-                else if (name == "ny") header.NYElem = c;
-                else if (name == "nz") header.NZElem = c;
-                else if (name == "u" || name == "s") header.UElem = c;
-                else if (name == "v" || name == "t") header.VElem = c;
-                ++header.VertexPropCount;
-            } else if (type == "list") {
-                ++facePropCounter;
-                std::string countType, indType, name;
-                ss >> countType >> indType >> name;
-                if (name == "vertex_indices" || name == "vertex_index")
-                    header.IndElem = facePropCounter - 1;
-            } else {
-                ++header.VertexPropCount;
-            }
-        } else if (action == "end_header")
-            break;
+    using namespace ply;
+    std::vector<char> bytes;
+    {
+        std::ifstream stream(path, std::ios::in | std::ios::binary);
+        if (!stream)
+            throw std::runtime_error("PLY file '" + path + "' can not be opened");
+        bytes.assign(std::istreambuf_iterator<char>(stream), std::istreambuf_iterator<char>());
     }
 
-    if (!header.hasVertices() || header.IndElem < 0 || header.VertexCount <= 0 || header.FaceCount <= 0)
-        throw std::runtime_error("PLY file '" + path + "' does not contain valid mesh data");
+    // ---- header: lines up to "end_header"
+    Format format = Format::Ascii;
+    std::vector<Element> elements;
+    size_t pos     = 0;
+    bool first     = true, ended = false;
+    while (pos < bytes.size() && !ended) {
+        size_t eol = pos;
+        while (eol < bytes.size() && bytes[eol] != '\n')
+            ++eol;
+        std::stringstream line(std::string(&bytes[pos], eol - pos));
+        pos = eol + 1;
+        std::string word;
+        line >> word;
+        if (first) {
+            if (word != "ply")
+                throw std::runtime_error("'" + path + "' is not a ply file");
+            first = false;
+        } else if (word == "format") {
+            line >> word;
+            if (word == "binary_little_endian")
+                format = Format::Little;
+            else if (word == "binary_big_endian")
+                format = Format::Big;
+            else if (word != "ascii")
+                throw std::runtime_error("PLY file '" + path + "': unknown format '" + word + "'");
+        } else if (word == "element") {
+            Element e;
+            line >> e.name >> e.count;
+            elements.push_back(e);
+        } else if (word == "property") {
+            if (elements.empty())
+                throw std::runtime_error("PLY file '" + path + "': property outside of an element");
+            Property p;
+            line >> word;
+            if (word == "list") {
+                std::string count_word, value_word;
+                line >> count_word >> value_word;
+                p.is_list    = true;
+                p.count_type = scalarOf(count_word, path);
+                p.type       = scalarOf(value_word, path);
+            } else {
+                p.type = scalarOf(word, path);
+            }
+            line >> p.name;
+            elements.back().props.push_back(p);
+        } else if (word == "end_header") {
+            ended = true;
+        } // comment, obj_info: skipped
+    }
+    if (!ended)
+        throw std::runtime_error("PLY file '" + path + "': header has no end");
 
-    header.SwitchEndianness = (method == "binary_big_endian");
-    const bool ascii        = (method == "ascii");
-
-    auto readFloat = [&]() {
-        float v = 0;
-        stream.read(reinterpret_cast<char*>(&v), sizeof(v));
-        return header.SwitchEndianness ? swap_endian(v) : v;
-    };
-    auto readIdx = [&]() {
-        uint32_t v = 0;
-        stream.read(reinterpret_cast<char*>(&v), sizeof(v));
-        return header.SwitchEndianness ? swap_endian(v) : v;
-    };
+    // ---- body, element after element in file order
+    enum Slot { X, Y, Z, NX, NY, NZ, U, V, SlotCount };
+    static const struct {
+        const char* name;
+        Slot slot;
+    } kSlots[] = { { "x", X }, { "y", Y }, { "z", Z }, { "nx", NX }, { "ny", NY }, { "nz", NZ }, { "u", U }, { "s", U }, { "v", V }, { "t", V } };
 
     TriMesh mesh;
-    mesh.vertices.reserve(header.VertexCount);
-    for (int i = 0; i < header.VertexCount; ++i) {
-        float vals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // x y z nx ny nz u v
-        auto assign   = [&](int elem, float val) {
-            if (header.XElem == elem) vals[0] = val;
-            else if (header.YElem == elem) vals[1] = val;
-            else if (header.ZElem == elem) vals[2] = val;
-            else if (header.NXElem == elem) vals[3] = val;
-            else if (header.NYElem == elem) vals[4] = val;
-            else if (header.NZElem == elem) vals[5] = val;
-            else if (header.UElem == elem) vals[6] = val;
-            else if (header.VElem == elem) vals[7] = val;
-        };
-        if (ascii) {
-            std::string line;
-            if (!std::getline(stream, line))
-                throw std::runtime_error("PLY file '" + path + "': not enough vertices");
-            std::stringstream ss(line);
-            int elem = 0;
-            float val;
-            while (ss >> val)
-                assign(elem++, val);
-        } else {
-            for (int elem = 0; elem < header.VertexPropCount; ++elem)
-                assign(elem, readFloat());
-        }
-        mesh.vertices.emplace_back(vals[0], vals[1], vals[2]);
-        if (header.hasNormals()) {
-            float n = std::sqrt(vals[3] * vals[3] + vals[4] * vals[4] + vals[5] * vals[5]);
-            if (n == 0.0f)
-                n = 1.0f;
-            mesh.normals.emplace_back(vals[3] / n, vals[4] / n, vals[5] / n);
-        }
-        if (header.hasUVs())
-            mesh.texcoords.push_back(V2{ vals[6], vals[7] });
-    }
-    if (!stream && !ascii)
-        throw std::runtime_error("PLY file '" + path + "': truncated vertex data");
-
-    mesh.indices.reserve((size_t)header.FaceCount * 4);
-    std::vector<uint32_t> tmp;
-    for (int i = 0; i < header.FaceCount; ++i) {
-        tmp.clear();
-        if (ascii) {
-            std::string line;
-            if (!std::getline(stream, line))
-                throw std::runtime_error("PLY file '" + path + "': not enough faces");
-            std::stringstream ss(line);
-            uint32_t elems = 0;
-            ss >> elems;
-            for (uint32_t e = 0; e < elems; ++e) {
-                uint32_t idx = 0;
-                ss >> idx;
-                tmp.push_back(idx);
+    bool have_positions = false, have_faces = false;
+    Body body(bytes, pos, format, path);
+    std::vector<uint32_t> corners;
+    for (const Element& e : elements) {
+        if (e.name == "vertex") {
+            std::vector<int> slot_of(e.props.size(), -1);
+            bool present[SlotCount] = {};
+            for (size_t k = 0; k < e.props.size(); ++k)
+                for (const auto& s : kSlots)
+                    if (!e.props[k].is_list && e.props[k].name == s.name) {
+                        slot_of[k]       = s.slot;
+                        present[s.slot]  = true;
+                    }
+            have_positions         = present[X] && present[Y] && present[Z];
+            const bool has_normals = present[NX] && present[NY] && present[NZ];
+            const bool has_uvs     = present[U] && present[V];
+            mesh.vertices.reserve(e.count);
+            for (size_t i = 0; i < e.count; ++i) {
+                float vals[SlotCount] = {};
+                for (size_t k = 0; k < e.props.size(); ++k) {
+                    const Property& p = e.props[k];
+                    if (p.is_list) {
+                        for (size_t n = (size_t)body.next(p.count_type); n > 0; --n)
+                            body.next(p.type);
+                    } else {
+                        const float v = (float)body.next(p.type);
+                        if (slot_of[k] >= 0)
+                            vals[slot_of[k]] = v;
+                    }
+                }
+                mesh.vertices.emplace_back(vals[X], vals[Y], vals[Z]);
+                if (has_normals) {
+                    float n = std::sqrt(vals[NX] * vals[NX] + vals[NY] * vals[NY] + vals[NZ] * vals[NZ]);
+                    if (n == 0.0f)
+                        n = 1.0f;
+                    mesh.normals.emplace_back(vals[NX] / n, vals[NY] / n, vals[NZ] / n);
+                }
+                if (has_uvs)
+                    mesh.texcoords.push_back(V2{ vals[U], vals[V] });
+            }
+        } else if (e.name == "face") {
+            mesh.indices.reserve(e.count * 4);
+            for (size_t i = 0; i < e.count; ++i) {
+                for (const Property& p : e.props) {
+                    if (!p.is_list) {
+                        body.next(p.type);
+                        continue;
+                    }
+                    const bool is_corners = p.name == "vertex_indices" || p.name == "vertex_index";
+                    have_faces |= is_corners;
+                    corners.clear();
+                    for (size_t n = (size_t)body.next(p.count_type); n > 0; --n) {
+                        const double idx = body.next(p.type);
+                        if (is_corners) {
+                            if (idx < 0 || idx >= (double)mesh.vertices.size())
+                                throw std::runtime_error("PLY file '" + path + "': face index out of range");
+                            corners.push_back((uint32_t)idx);
+                        }
+                    }
+                    // a fan around the first corner; four indices per triangle (the fourth is padding)
+                    for (size_t j = 2; is_corners && j < corners.size(); ++j)
+                        mesh.indices.insert(mesh.indices.end(), { corners[0], corners[j - 1], corners[j], 0u });
+                }
             }
         } else {
-            uint8_t elems = 0;
-            stream.read(reinterpret_cast<char*>(&elems), sizeof(elems));
-            for (uint32_t e = 0; e < elems; ++e)
-                tmp.push_back(readIdx());
-            if (!stream)
-                throw std::runtime_error("PLY file '" + path + "': truncated face data");
+            for (size_t i = 0; i < e.count; ++i)
+                for (const Property& p : e.props)
+                    for (size_t n = p.is_list ? (size_t)body.next(p.count_type) : 1; n > 0; --n)
+                        body.next(p.type);
         }
-        for (uint32_t idx : tmp)
-            if (idx >= mesh.vertices.size())
-                throw std::runtime_error("PLY file '" + path + "': face index out of range");
-        triangulate(tmp, mesh.indices);
     }
+    if (!have_positions || !have_faces || mesh.vertices.empty() || mesh.indices.empty())
+        throw std::runtime_error("PLY file '" + path + "' does not contain valid mesh data");
 
     if (mesh.normals.empty()) {
         mesh.computeVertexNormals();

@@ -628,3 +628,131 @@ def test_png_reader_rejects_hostile_headers(tmp_path):
     _write_png(tmp_path / "bad.png", 1, 1, 3, 8, [[5]], palette=[1, 2, 3])
     with pytest.raises(RuntimeError, match="palette index"):
         LoadedScene.from_string(json.dumps(_texture_scene("bad.png")), base_dir=str(tmp_path))
+
+
+def _ply_bytes(fmt, vertex_props, verts, faces, extra_element=False):
+    """A PLY file with arbitrary scalar types. vertex_props: [(type, name)]; verts: rows of values in that order;
+    faces: lists of corner indices; list types are (uchar, int) for little endian and (ushort, uint) for big endian."""
+    import struct
+    codes = {"char": "b", "uchar": "B", "short": "h", "ushort": "H", "int": "i", "uint": "I", "float": "f", "double": "d",
+             "int8": "b", "uint8": "B", "int16": "h", "uint16": "H", "int32": "i", "uint32": "I", "float32": "f", "float64": "d"}
+    end = {"ascii": None, "binary_little_endian": "<", "binary_big_endian": ">"}[fmt]
+    count_t, idx_t = ("uchar", "int") if fmt != "binary_big_endian" else ("ushort", "uint")
+    head = f"ply\nformat {fmt} 1.0\ncomment made by the tests\nelement vertex {len(verts)}\n"
+    head += "".join(f"property {t} {n}\n" for t, n in vertex_props)
+    if extra_element:
+        head += "element edge 2\nproperty int a\nproperty int b\nproperty list uchar float weights\n"
+    head += f"element face {len(faces)}\nproperty uchar flags\nproperty list {count_t} {idx_t} vertex_indices\nend_header\n"
+    body = b""
+    if end is None:
+        lines = [" ".join(repr(float(v)) if t in ("float", "double", "float32", "float64") else str(int(v)) for (t, _), v in zip(vertex_props, row)) for row in verts]
+        if extra_element:
+            lines += ["0 1 2 0.5 0.25", "1 2 0"]
+        lines += [" ".join(["7", str(len(f))] + [str(i) for i in f]) for f in faces]
+        body = ("\n".join(lines) + "\n").encode()
+    else:
+        for row in verts:
+            for (t, _), v in zip(vertex_props, row):
+                body += struct.pack(end + codes[t], float(v) if codes[t] in "fd" else int(v))
+        if extra_element:
+            body += struct.pack(end + "iiBff", 0, 1, 2, 0.5, 0.25) + struct.pack(end + "iiB", 1, 2, 0)
+        for f in faces:
+            body += struct.pack(end + "B" + codes[count_t], 7, len(f)) + struct.pack(end + codes[idx_t] * len(f), *f)
+    return head.encode() + body
+
+
+def test_ply_reader_is_table_driven(tmp_path):
+    """Every scalar type of the format, either byte order, ascii, extra properties / lists / elements in between, polygons:
+    all load into the same tables as the plain float file (the reference reads float properties and uchar/uint lists only,
+    src/runtime/mesh/PlyFile.cpp:70-290)."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+    verts = [(0, 0, 0, 0.0, 0.0), (1, 0, 0, 1.0, 0.0), (1.5, 1, 0.25, 1.0, 1.0), (0.5, 2, 0, 0.5, 1.0), (-0.5, 1, 0.25, 0.0, 1.0), (3, 0, 0, 0.25, 0.75), (4, 0, 1, 0.5, 0.5), (3, 1, 0, 0.125, 0.0)]
+    faces = [[0, 1, 2, 3, 4], [5, 6, 7], [5, 7, 6, 0]]  # pentagon (fan of 3), triangle, quad (fan of 2)
+    plain = [("float", "x"), ("float", "y"), ("float", "z"), ("float", "s"), ("float", "t")]
+    variants = {
+        "plain.ply": _ply_bytes("binary_little_endian", plain, verts, faces),
+        "ascii.ply": _ply_bytes("ascii", plain, verts, faces),
+        "big.ply": _ply_bytes("binary_big_endian", plain, verts, faces),
+        "double.ply": _ply_bytes("binary_little_endian", [("double", "x"), ("float64", "y"), ("double", "z"), ("float32", "u"), ("double", "v")], verts, faces),
+        "extra.ply": _ply_bytes("binary_little_endian", [("uchar", "red"), ("float", "x"), ("short", "quality"), ("float", "y"), ("float", "z"), ("float", "s"), ("float", "t"), ("int32", "id")],
+                                [(200, v[0], -3, v[1], v[2], v[3], v[4], 99) for v in verts], faces, extra_element=True),
+        "extra_ascii.ply": _ply_bytes("ascii", plain, verts, faces, extra_element=True),
+    }
+    tables = {}
+    for name, data in variants.items():
+        (tmp_path / name).write_bytes(data)
+        s = flat_scene()
+        s["shapes"][0] = {"type": "ply", "name": s["shapes"][0]["name"], "filename": name}
+        sc = LoadedScene.from_string(json.dumps(s), str(tmp_path))
+        tables[name] = (np.ctypeslib.as_array(sc.scene.shape_data, shape=(sc.scene.shape_data_size,)).copy(), np.frombuffer(sc.primbvh_bytes(), np.uint8).copy())
+    hdr = np.frombuffer(tables["plain.ply"][0][:16].tobytes(), np.int32)
+    assert hdr[0] == 3 + 1 + 2 and hdr[1] == 8  # faces after the fans, vertices
+    for name, (shape, bvh) in tables.items():
+        np.testing.assert_array_equal(shape, tables["plain.ply"][0], err_msg=name)
+        np.testing.assert_array_equal(bvh, tables["plain.ply"][1], err_msg=name)
+    # failures are loud
+    (tmp_path / "bad.ply").write_bytes(variants["plain.ply"][:-5])
+    s = flat_scene()
+    s["shapes"][0] = {"type": "ply", "name": s["shapes"][0]["name"], "filename": "bad.ply"}
+    with pytest.raises(RuntimeError, match="truncated"):
+        LoadedScene.from_string(json.dumps(s), str(tmp_path))
+    (tmp_path / "bad.ply").write_bytes(_ply_bytes("ascii", plain, verts, [[0, 1, 99]]))
+    with pytest.raises(RuntimeError, match="out of range"):
+        LoadedScene.from_string(json.dumps(s), str(tmp_path))
+    (tmp_path / "bad.ply").write_bytes(variants["plain.ply"].replace(b"property float x", b"property quaternion x"))
+    with pytest.raises(RuntimeError, match="unknown property type"):
+        LoadedScene.from_string(json.dumps(s), str(tmp_path))
+
+
+def _area_light_on_inline_mesh(verts, faces, uvs=None):
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene()
+    shape = {"type": "inline", "name": "L", "vertices": [float(c) for v in verts for c in v], "indices": [int(i) for f in faces for i in f]}
+    if uvs is not None:
+        shape["texcoords"] = [float(c) for t in uvs for c in t]
+    s["shapes"].append(shape)
+    s["entities"].append({"name": "L", "shape": "L", "bsdf": "ground"})
+    s["lights"] = [{"type": "area", "name": "A", "entity": "L", "radiance": [1, 1, 1]}]
+    sc = LoadedScene.from_string(json.dumps(s))
+    import numpy as np
+    return sc.scene.lights[0].type, np.array(list(sc.scene.lights[0].d), np.float32)
+
+
+def test_plane_detection_frames_and_rejections():
+    """TriMesh::getAsPlane (src/runtime/mesh/TriMesh.cpp:521-620), beyond the two cases of src/tests/units/trimesh_plane.cpp: the
+    origin is vertex 0, the axes are its two quad edges (never the diagonal) in the order whose cross product follows the face
+    normal — whatever the vertex numbering and the diagonal the quad is split along; folded, non-congruent and five-vertex
+    meshes are not planes."""
+    import itertools
+    import numpy as np
+    corners = np.array([[0.5, -1, 2], [2.5, -1, 2.5], [3.0, 1, 3.0], [1.0, 1, 2.5]], np.float32)  # a parallelogram a, b, c, d (in order around)
+    normal = np.cross(corners[1] - corners[0], corners[3] - corners[0])
+    normal /= np.linalg.norm(normal)
+    for perm in itertools.permutations(range(4)):
+        v = corners[list(perm)]
+        where = {p: i for i, p in enumerate(perm)}  # corner -> vertex number
+        for diag in (0, 1):  # split along a-c or along b-d
+            tris = [[0, 1, 2], [0, 2, 3]] if diag == 0 else [[0, 1, 3], [1, 2, 3]]
+            faces = [[where[c] for c in t] for t in tris]
+            kind, d = _area_light_on_inline_mesh(v, faces)
+            assert kind == 0, (perm, diag)
+            o, x, y, n = d[0:3], d[4:7], d[8:11], np.array([d[3], d[7], d[11]])
+            np.testing.assert_allclose(o, v[0], rtol=1e-6)
+            o_corner = perm[0]
+            want = {tuple(np.round(corners[(o_corner + 1) % 4] - corners[o_corner], 4)), tuple(np.round(corners[(o_corner - 1) % 4] - corners[o_corner], 4))}
+            assert {tuple(np.round(x, 4)), tuple(np.round(y, 4))} == want, (perm, diag)
+            np.testing.assert_allclose(n, normal, atol=1e-5)
+            np.testing.assert_allclose(np.cross(x, y) / np.linalg.norm(np.cross(x, y)), normal, atol=1e-5)
+            np.testing.assert_allclose(d[23], np.linalg.norm(np.cross(corners[1] - corners[0], corners[3] - corners[0])), rtol=1e-5)  # area
+    quad = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]
+    folded = [[0, 0, 0], [1, 0, 0], [1, 1, 0.3], [0, 1, 0]]
+    assert _area_light_on_inline_mesh(folded, [[0, 1, 2], [0, 2, 3]])[0] == 8          # the two triangles face differently
+    kite = [[0, 0, 0], [1, -1, 0], [3, 0, 0], [1, 1, 0]]
+    assert _area_light_on_inline_mesh(kite, [[0, 1, 3], [1, 2, 3]])[0] == 8            # not congruent
+    assert _area_light_on_inline_mesh(quad + [[0, 0, 0]], [[0, 1, 2], [4, 2, 3]])[0] == 8  # five vertices (one duplicated): the reference rejects these too
+    assert _area_light_on_inline_mesh(quad, [[0, 1, 2]])[0] == 8                       # one face
+    # texture coordinates travel with the corners
+    uvs = [[0.1, 0.2], [0.9, 0.2], [0.9, 0.8], [0.1, 0.8]]
+    kind, d = _area_light_on_inline_mesh(quad, [[0, 1, 2], [0, 2, 3]], uvs)
+    assert kind == 0
