@@ -104,8 +104,9 @@ struct igd_device {
     bool has_scene = false;
     DevBuf<uint8_t> geom, shape_data;
     size_t primbvh_bytes = 0; // the "trimesh_primbvh" fix table at the start of geom
-    DevBuf<ig_entity_leaf1> leaves;
-    DevBuf<uint2> leaf_ext;
+    DevBuf<ig_entity_leaf1> leaves, sphere_leaves;
+    DevBuf<uint2> leaf_ext, sphere_leaf_ext;
+    DevBuf<float> secondary_hit; // scenes with spheres: occlusion verdict of the triangle pass for the sphere pass (float4 per shadow ray)
     DevBuf<float> entities;
     DevBuf<uint64_t> shape_offsets;
     DevBuf<ig_material> materials;
@@ -378,7 +379,8 @@ int guarded(const char* what, const std::function<void()>& fn);
 
 void assignScene(igd_device* d, const igd_scene* s)
 {
-    if (s->entity_count > 0 && (!s->entities || !s->scene_nodes || !s->scene_leaves || !s->primbvh || !s->shape_data))
+    if (s->entity_count > 0 && (!s->entities || !s->shape_data || (s->scene_node_count > 0 && (!s->scene_nodes || !s->scene_leaves || !s->primbvh))
+                                || (s->sphere_node_count > 0 && (!s->sphere_nodes || !s->sphere_leaves))))
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: scene tables are incomplete" };
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const ig_material& mat = s->materials[m];
@@ -402,7 +404,7 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard colours are only lowered for diffuse and principled BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material light id out of range" };
-        if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE && s->lights[mat.light_id].type != IG_LIGHT_MESH_AREA)
+        if (mat.light_id >= 0 && s->lights[mat.light_id].type != IG_LIGHT_PLANE && s->lights[mat.light_id].type != IG_LIGHT_MESH_AREA && s->lights[mat.light_id].type != IG_LIGHT_SPHERE)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: only area lights can be emissive entities" };
     }
     const uint32_t n_finite = s->light_count - s->infinite_light_count;
@@ -412,7 +414,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t l = 0; l < s->light_count; ++l) {
         const bool inf = l < s->infinite_light_count;
         const int lt = s->lights[l].type;
-        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_MESH_AREA)
+        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_SPHERE)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
         if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL || lt == IG_LIGHT_ENV_TEXTURED || lt == IG_LIGHT_SUN || lt == IG_LIGHT_CIE))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment, directional or sun lights" };
@@ -430,6 +432,12 @@ void assignScene(igd_device* d, const igd_scene* s)
     const uint32_t scene_nodes_off = (uint32_t)blob.size();
     const uint8_t* sn              = reinterpret_cast<const uint8_t*>(s->scene_nodes);
     blob.insert(blob.end(), sn, sn + (size_t)s->scene_node_count * sizeof(ig_node8));
+    // the scene BVH of the analytic spheres (igd_scene.sphere_*) follows
+    const uint32_t sphere_nodes_off = (uint32_t)blob.size();
+    if (s->sphere_node_count) {
+        const uint8_t* pn = reinterpret_cast<const uint8_t*>(s->sphere_nodes);
+        blob.insert(blob.end(), pn, pn + (size_t)s->sphere_node_count * sizeof(ig_node8));
+    }
     if (blob.size() >= ((size_t)1 << 32))
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: BVH blob exceeds 4 GiB (32-bit node offsets)" };
     blob.resize(blob.size() + 256); // tail padding: vector loads never run past the allocation
@@ -450,6 +458,19 @@ void assignScene(igd_device* d, const igd_scene* s)
     }
     d->leaf_ext.upload(ext.data(), ext.size());
     d->leaves.upload(s->scene_leaves, s->scene_leaf_count);
+    {
+        // per sphere leaf: where its {centre, radius} record sits in the "shapes" blob
+        std::vector<uint2> sext(s->sphere_leaf_count);
+        for (uint32_t i = 0; i < s->sphere_leaf_count; ++i) {
+            const int32_t shape_id = s->sphere_leaves[i].shape_id;
+            if (shape_id < 0 || (uint32_t)shape_id >= s->shape_count || s->shape_lookups[shape_id].type_id != IG_SHAPE_SPHERE
+                || s->shape_lookups[shape_id].offset + 16 > s->shape_data_size)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: sphere leaf without a valid sphere shape" };
+            sext[i] = make_uint2((uint32_t)s->shape_lookups[shape_id].offset, 0u);
+        }
+        d->sphere_leaf_ext.upload(sext.data(), sext.size());
+        d->sphere_leaves.upload(s->sphere_leaves, s->sphere_leaf_count);
+    }
 
     d->entities.upload(s->entities, (size_t)s->entity_count * IG_ENTITY_FLOATS);
     std::vector<uint8_t> sd(s->shape_data, s->shape_data + s->shape_data_size);
@@ -494,6 +515,12 @@ void assignScene(igd_device* d, const igd_scene* s)
         if (shape_id >= s->shape_count)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: entity shape id out of range" };
         const uint64_t base = s->shape_lookups[shape_id].offset;
+        if (s->shape_lookups[shape_id].type_id == IG_SHAPE_SPHERE) {
+            if (base + 16 > s->shape_data_size || base >= ((uint64_t)1 << 32))
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape offset out of range" };
+            ext4[e] = make_uint4((uint32_t)base, 0xFFFFFFFFu, 0u, 0u); // surface_element(): .y marks the analytic sphere
+            continue;
+        }
         if (base + 48 > s->shape_data_size)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape offset out of range" };
         int32_t hdr[4]; // faces, vertices, normals, texcoords
@@ -511,6 +538,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.scene_node_count     = s->scene_node_count;
     ds.leaves               = d->leaves.ptr;
     ds.leaf_ext             = d->leaf_ext.ptr;
+    ds.sphere_nodes_off     = sphere_nodes_off;
+    ds.sphere_node_count    = s->sphere_node_count;
+    ds.sphere_leaves        = d->sphere_leaves.ptr;
+    ds.sphere_leaf_ext      = d->sphere_leaf_ext.ptr;
     ds.entities             = d->entities.ptr;
     ds.shape_data           = d->shape_data.ptr;
     ds.shape_offsets        = d->shape_offsets.ptr;
@@ -545,12 +576,13 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
+    d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
-        if (s->lights[i].type != IG_LIGHT_MESH_AREA)
+        if (s->lights[i].type != IG_LIGHT_MESH_AREA && s->lights[i].type != IG_LIGHT_SPHERE)
             continue;
         d->full_bsdfs = true;
         if (s->lights[i].entity_id < 0 || s->lights[i].entity_id >= (int32_t)s->entity_count)
-            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: mesh area light without a valid entity" };
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: mesh / sphere area light without a valid entity" };
     }
     for (uint32_t i = 0; i < s->infinite_light_count; ++i)
         d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN || s->lights[i].type == IG_LIGHT_CIE;
@@ -749,6 +781,11 @@ void render(igd_device* d, const igd_render_settings* rs)
         finish(d);
     d->ensureStreams((size_t)std::max<int64_t>(total, 256));
 
+    if (d->dscene.sphere_node_count && d->secondary_hit.count < d->capacity * 4) {
+        finish(d);
+        d->secondary_hit.release();
+        d->secondary_hit.alloc(d->capacity * 4);
+    }
     if (list_mode)
         d->list_rays.upload(rs->rays, (size_t)rs->width * 8);
 
@@ -837,6 +874,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.index_count  = &iq->deep_count;
             ta.qs           = iq;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
+            ta.sphere_work_counter = &iq->work_counter[4];
             launch_traverse(ta, false, false, d->traverseGrid(), &iq->work_counter[1], st);
             InfoArgs ia{};
             ia.scene   = d->dscene;
@@ -928,6 +966,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             PrimaryCols prim[2];
             SecondaryCols sec;
             uint32_t* deep_rays;
+            float4* sec_hit;
         };
         auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror) {
             const PrimaryCols in = b.prim[in_slot];
@@ -940,6 +979,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.index_count  = &qs->deep_count;
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
+            ta.sphere_work_counter = &qs->work_counter[4];
             timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on); });
 
             ShadeArgs sa{};
@@ -969,6 +1009,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.index_count   = &qs->deep_count;
             tb.qs            = qs;
             tb.col     = b.sec.col;
+            tb.hit     = b.sec_hit; // only with a sphere pass (null otherwise)
+            tb.sphere_work_counter = &qs->work_counter[5];
             tb.accum   = accum;
             tb.id_base = first;
             tb.inv_spi = inv;
@@ -981,7 +1023,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             d->stats.traverse_secondary_launches++;
         };
 
-        const RoundBufs main_bufs{ { d->primaryCols(0), d->primaryCols(1) }, d->secondaryCols(), d->deep_rays.ptr };
+        const RoundBufs main_bufs{ { d->primaryCols(0), d->primaryCols(1) }, d->secondaryCols(), d->deep_rays.ptr,
+                                   d->dscene.sphere_node_count ? reinterpret_cast<float4*>(d->secondary_hit.ptr) : nullptr };
         // The host runs one round ahead of what it knows: the queue sizes after round r are copied back
         // asynchronously and looked at only after round r + 1 has been submitted, so the stream never drains while
         // the host waits. The hand-over decision therefore uses the size one round old — an upper bound of the
@@ -1037,6 +1080,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
+            if (d->tail_wavefront && d->dscene.sphere_node_count)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: IGD_TAIL_WAVEFRONT is not available for scenes with analytic spheres" };
             if (d->tail_wavefront) {
                 d->ensureTailWork(fl);
                 d->ensureSideStreams(fl);
@@ -1064,6 +1109,9 @@ void render(igd_device* d, const igd_render_settings* rs)
             sb.prim[1]   = igd_device::colsAt(in_slot == 0 ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity);
             sb.sec       = igd_device::secAt(fl.side_secondary.ptr, fl.tail_capacity);
             sb.deep_rays = fl.side_deep_rays.ptr;
+            sb.sec_hit   = nullptr;
+            if (d->dscene.sphere_node_count)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: IGD_SIDE_ROUNDS is not available for scenes with analytic spheres" };
             const int tg = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
             const int sg = std::max(1, std::min(d->shadeGrid(), (int)((live + 255) / 256)));
             for (int r = 0; r < rounds; ++r) {
@@ -1187,6 +1235,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     ta.qs            = qs;
     ta.hit           = reinterpret_cast<float4*>(out.ptr);
     ta.hit_v         = out.ptr + n * 4;
+    ta.sphere_work_counter = &qs->work_counter[any_hit ? 5 : 4];
 
     const bool stats = d->setup.acquire_stats >= 2;
     if (repeat < 1)
@@ -1476,6 +1525,9 @@ int32_t igd_release_all(igd_device* dev)
         dev->shape_data.release();
         dev->leaves.release();
         dev->leaf_ext.release();
+        dev->sphere_leaves.release();
+        dev->sphere_leaf_ext.release();
+        dev->secondary_hit.release();
         dev->entities.release();
         dev->shape_offsets.release();
         dev->materials.release();

@@ -41,6 +41,12 @@ struct DevScene {
     const float* cdf_data; // sampling tables of textured environment lights (igd_scene.cdf_data)
     // deep traversal stacks: entry e of resident lane l at deep_stack[e * deep_stride + l]; the persistent traversal
     // grid uses lanes [0, deep_tail_base), the tail kernel's grid the lanes from deep_tail_base on (they overlap in time)
+    // analytic spheres (igd_scene.sphere_*): their scene BVH's nodes inside geom, leaves, and per leaf {byte offset of the
+    // sphere's {centre, radius} record in shape_data, 0}. sphere_node_count == 0: no spheres, no sphere pass
+    uint32_t sphere_nodes_off;
+    uint32_t sphere_node_count;
+    const ig_entity_leaf1* sphere_leaves;
+    const uint2* sphere_leaf_ext;
     uint2* deep_stack;
     uint32_t deep_stride;
     uint32_t deep_tail_base; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)
@@ -79,7 +85,7 @@ struct QueueState {
         uint32_t primary, secondary;
     };
     alignas(8) Counts q[2];
-    uint32_t work_counter[4];  // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch
+    uint32_t work_counter[6];  // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch, [4] / [5] the sphere passes
     uint32_t deep_count;       // rays of the traversal launch in flight whose stack outgrew LDS (re-traversed by the DEEP launch)
     // ---- from here on: cleared once per igd_render, not per chunk
     uint32_t error_flags;      // bit 0: traversal stack overflow
@@ -111,6 +117,10 @@ struct TraverseArgs {
     float4* accum;
     int64_t id_base;
     float inv_spi;
+    // scenes with analytic spheres: the launch over the triangle BVH is followed by one over the sphere BVH that starts from its
+    // hits. 0: single pass; 1: first of two (any-hit: the hit must be stored and the splat is left to the second); 2: the sphere pass
+    int32_t sphere_pass;
+    uint32_t* sphere_work_counter; // zero before launch
 };
 
 struct GenerateArgs {

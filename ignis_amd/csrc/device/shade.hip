@@ -302,6 +302,8 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
         qs->work_counter[1]        = 0;
         qs->work_counter[2]        = 0;
         qs->work_counter[3]        = 0;
+        qs->work_counter[4]        = 0;
+        qs->work_counter[5]        = 0;
         qs->deep_count             = 0;
     }
 }
@@ -316,6 +318,7 @@ __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
         qs->q[slot].secondary = 0;
         qs->work_counter[2] = 0;
         qs->work_counter[3] = 0;
+        qs->work_counter[5] = 0;
         qs->deep_count      = 0;
         if (mirror) {
             *mirror = *qs;
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256) k_info(const InfoArgs a)
             const float4 ra = a.in.rayA[i], rb = a.in.rayB[i];
             const f3 org{ ra.x, ra.y, ra.z }, dir{ rb.x, rb.y, rb.z };
             const ig_material& mat = a.scene.materials[a.scene.entity_material[ent]];
-            const Surf surf        = surface_element(a.scene, ent, (int)igm_bits(hit.y), org, dir, hit.z, hit.w, a.in.hit_v[i]);
+            const Surf surf        = surface_element<true>(a.scene, ent, (int)igm_bits(hit.y), org, dir, hit.z, hit.w, a.in.hit_v[i]);
             const BsdfCtx<true> bsdf(a.scene, mat, surf, dir);
             const Col al = bsdf.albedo(-dir);
             const f3 N   = surf.local.c2;

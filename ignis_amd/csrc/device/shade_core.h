@@ -94,6 +94,7 @@ IG_DEV f3 ld3v(const float* p) // 16-byte aligned (x, y, z, pad) record
 
 // make_trimesh_shape.surface_element (shapes/trimesh.art:14-40), entity table (driver/entity.art:12-28),
 // point mappers (driver/pointmapper.art:28-36)
+template <bool SPHERES>
 IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org, f3 dir, float t, float u, float v)
 {
     // entity record = 9 x 16 bytes; words 12..35 hold toGlobal 3x4, the normal 3x3, shape id, material id
@@ -106,6 +107,21 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     // shape arrays (header {faces, vertices, normals, texcoords}, then vertices, normals, indices, texcoords:
     // TriMeshProvider.cpp:575-596) through the offsets igd_assign_scene precomputed per entity
     const uint4 ext    = sc.entity_ext[ent_id];
+    if (SPHERES && ext.y == 0xFFFFFFFFu) {
+        // analytic sphere: make_sphere_shape.surface_element (shapes/sphere.art:52-73); ext.x = its {centre, radius} record.
+        // (only in the full kernel variants, which igd_assign_scene selects for scenes with spheres)
+        const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x);
+        Surf s;
+        s.point         = org + dir * t;
+        const f3 d      = s.point - xform_point(global, f3{ sp.x, sp.y, sp.z });
+        const float len = len3(d);
+        const f3 n      = d * (1 / len);
+        s.tex           = f2{ u, v };
+        s.entering      = true;
+        s.face_normal   = n;
+        s.local         = orthonormal_basis(n);
+        return s;
+    }
     const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
     const float* norms = reinterpret_cast<const float*>(sc.shape_data + ext.y);
     const float* inds  = reinterpret_cast<const float*>(sc.shape_data + ext.z);
@@ -1551,6 +1567,50 @@ struct MeshEmitter {
     }
 };
 
+IG_DEV f3 square_to_sphere(float px, float py);
+
+// make_sphere_area_emitter (light/area.art:259-317) for IG_LIGHT_SPHERE: d = centre (shape space), radius, radiance, area
+struct SphereEmitter {
+    m34 global;
+    m33 nmat;
+    f3 origin;
+    float radius, area;
+    Col radiance;
+
+    IG_DEV SphereEmitter(const DevScene& sc, const ig_light& L)
+    {
+        const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)L.entity_id * IG_ENTITY_FLOATS);
+        const float4 r3 = e[3], r4 = e[4], r5 = e[5], r6 = e[6], r7 = e[7], r8 = e[8];
+        global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
+        nmat.c0 = f3{ r6.x, r6.y, r6.z }, nmat.c1 = f3{ r6.w, r7.x, r7.y }, nmat.c2 = f3{ r7.z, r7.w, r8.x };
+        origin   = f3{ L.d[0], L.d[1], L.d[2] };
+        radius   = L.d[3];
+        radiance = Col{ L.d[4], L.d[5], L.d[6] };
+        area     = L.d[7];
+    }
+    // sphere_compute_surface_element_for_normal (shapes/sphere.art:30-46): point and face normal
+    IG_DEV void surface(f3 normal, f3& point, f3& face_normal) const
+    {
+        face_normal = normalize3(mul33(nmat, normal));
+        point       = xform_point(global, origin + normal * radius);
+    }
+    // sample_direct (area.art:268-294): a uniform point; one on the far side is mirrored through the centre and mapped back
+    // with pmset.to_local_normal exactly as written (driver/pointmapper.art:31: not a unit vector)
+    IG_DEV void sample(float ux, float uy, f3 from, f3& point, f3& face_normal) const
+    {
+        const f3 glb_org = xform_point(global, origin);
+        surface(square_to_sphere(ux, uy), point, face_normal);
+        const f3 os = from - glb_org, ps = from - point;
+        if (!(dot3(ps, ps) <= dot3(os, os))) {
+            const f3 np   = point + (glb_org - point) * 2;
+            const f3 norm = normalize3(np - glb_org);
+            const f3 diag = f3{ nmat.c0.x, nmat.c1.y, nmat.c2.z };
+            const f3 ln   = f3{ dot3(nmat.c0, norm), dot3(nmat.c1, norm), dot3(nmat.c2, norm) } * (1 / dot3(diag, diag));
+            surface(ln, point, face_normal);
+        }
+    }
+};
+
 // CIE sky models (light/cie.art:1-41) as function environments (light/env.art:24-105); directions in the light's Y-up frame
 struct CieSky {
     int kind;
@@ -1856,7 +1916,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
 
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
-    const Surf surf = surface_element(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    const Surf surf = surface_element<FULL>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
     const BsdfCtx<FULL> bsdf(sc, mat, surf, in.dir);
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
@@ -1881,6 +1941,9 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 const MeshEmitter me(sc, EL);
                 emit  = me.radiance;
                 pdf_s = me.pdf_area(in.u, in.v) * (in.t * in.t) / dcos; // Pdf::as_solid (driver/pdf.art:19-38)
+            } else if (FULL && EL.type == IG_LIGHT_SPHERE) {
+                emit  = Col{ EL.d[4], EL.d[5], EL.d[6] };
+                pdf_s = safe_div(1, EL.d[7]) * (in.t * in.t) / dcos; // make_area_pdf(inv_area).as_solid
             } else {
                 const PlaneLight pl(EL);
                 emit  = pl.radiance;
@@ -1983,6 +2046,20 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             ldir        = d_ * safe_div(1, ldist);
             lcos        = dot3(ldir, fnorm) * (surf.entering ? -1.0f : 1.0f);
             lint        = me.radiance * (area * (float)me.num_tris);
+        } else if (FULL && L.type == IG_LIGHT_SPHERE) {
+            // make_area_light.sample_direct over make_sphere_area_emitter (light/area.art:12-26,268-294)
+            const SphereEmitter se(sc, L);
+            const float ux = rnd.f32();
+            const float uy = rnd.f32();
+            f3 fnorm;
+            se.sample(ux, uy, surf.point, lpos, fnorm);
+            pdf_value   = safe_div(1, se.area);
+            pdf_area    = true;
+            const f3 d_ = lpos - surf.point;
+            ldist       = len3(d_);
+            ldir        = d_ * safe_div(1, ldist);
+            lcos        = dot3(ldir, fnorm) * (surf.entering ? -1.0f : 1.0f);
+            lint        = se.radiance * se.area;
         } else if (FULL && L.type == IG_LIGHT_CIE) {
             // make_environment_light_function_{hemi,spherical}.sample_direct (light/env.art:31-37,79-93)
             const CieSky sky(L);

@@ -97,6 +97,23 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
                     c_tris[0] += tr.st_tris;
                     c_leaves[0] += tr.st_leaves;
                 }
+                if (sc.sphere_node_count) {
+                    // the sphere geometry, from the hit so far (traverse.hip launches it as a second pass)
+                    Traverser<false, STATS, kTailThreads, false, true> tp;
+                    tp.init_counters();
+                    tp.begin(sc, s_stack, tid, in.org, in.dir, tmin, in.t, flags);
+                    tp.set_initial_hit(in.ent, in.prim, in.u, in.v);
+                    while (!tp.finished)
+                        tp.step(sc, s_stack, tid);
+                    in.ent  = tp.hit_ent;
+                    in.prim = tp.hit_prim;
+                    in.t = tp.tmax, in.u = tp.hit_u, in.v = tp.hit_v;
+                    overflow |= tp.overflow;
+                    if (STATS) {
+                        c_nodes[0] += tp.st_nodes;
+                        c_leaves[0] += tp.st_leaves;
+                    }
+                }
             }
 
             PathVertexOut out;
@@ -121,7 +138,22 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
                     c_tris[1] += ts.st_tris;
                     c_leaves[1] += ts.st_leaves;
                 }
-                if (ts.hit_prim < 0) {
+                bool occluded = ts.hit_prim >= 0;
+                if (sc.sphere_node_count) {
+                    Traverser<true, STATS, kTailThreads, false, true> tq;
+                    tq.init_counters();
+                    tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, IG_RAY_FLAG_SHADOW);
+                    tq.set_initial_hit(ts.hit_ent, ts.hit_prim, 0, 0);
+                    while (!tq.finished)
+                        tq.step(sc, s_stack, tid);
+                    occluded = tq.hit_prim >= 0;
+                    overflow |= tq.overflow;
+                    if (STATS) {
+                        c_nodes[1] += tq.st_nodes;
+                        c_leaves[1] += tq.st_leaves;
+                    }
+                }
+                if (!occluded) {
                     ++c_unoccluded;
                     acc.x += out.s_col.r * a.inv_spi;
                     acc.y += out.s_col.g * a.inv_spi;

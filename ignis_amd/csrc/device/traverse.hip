@@ -15,7 +15,7 @@ namespace igdev {
 constexpr int kRefillIdle = IG_REFILL_IDLE;  // refill when at least this many lanes of a wave are idle
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
-template <bool ANY_HIT, bool STATS, bool DEEP>
+template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false>
 __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
     uint32_t last_base         = 0; // where the previous reservation of this wave started
 
-    Traverser<ANY_HIT, STATS, kBlockThreads, DEEP> tr;
+    Traverser<ANY_HIT, STATS, kBlockThreads, DEEP, SPHERES> tr;
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
     bool has_ray          = false;
@@ -74,8 +74,16 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 ray_idx = idx;
                 has_ray = true;
                 const float4 ra = a.rayA[idx], rb = a.rayB[idx];
-                tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
-                         a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
+                if (SPHERES) {
+                    // init_hit = what the triangle pass found; its distance is the ray's tmax from here on
+                    const float4 h = a.hit[idx];
+                    tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, h.z,
+                             a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
+                    tr.set_initial_hit((int)igm_bits(h.x), (int)igm_bits(h.y), h.w, ANY_HIT ? 0.0f : a.hit_v[idx]);
+                } else {
+                    tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
+                             a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
+                }
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
@@ -93,7 +101,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         if (has_ray) {
             if (tr.finished && tr.overflow) {
                 has_ray = false;
-                if (DEEP) {
+                if (DEEP || SPHERES) {
                     fatal = true; // deeper than LDS + global part together
                 } else {
                     // hand the ray to the DEEP launch; what this lane counted for it does not count
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 if (ANY_HIT) {
                     if (a.hit)
                         a.hit[ray_idx] = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
-                    if (tr.hit_prim < 0) {
+                    if (tr.hit_prim < 0 && a.sphere_pass != 1) { // (with a sphere pass to come, the verdict is its)
                         if (STATS)
                             ++st_unoccluded;
                         if (a.accum) {
@@ -146,33 +154,44 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
 
 int traverse_workgroups_per_cu() { return kTraverseOcc; }
 
-template <bool DEEP>
+template <bool DEEP, bool SPHERES = false>
 static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)
 {
     const dim3 grid((unsigned)grid_blocks), block(kBlockThreads);
     if (any_hit) {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<true, true, DEEP>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, true, DEEP, SPHERES>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<true, false, DEEP>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, false, DEEP, SPHERES>), grid, block, 0, stream, args);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<false, true, DEEP>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, true, DEEP, SPHERES>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<false, false, DEEP>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, false, DEEP, SPHERES>), grid, block, 0, stream, args);
     }
 }
 
 // Two launches: the LDS-stack kernel over the whole stream, then the DEEP kernel over the rays the first one
 // could not finish (almost always none: it reads one counter and exits). `deep_work_counter` must be zero.
-void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream)
+void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream)
 {
+    TraverseArgs args = args_in;
+    const bool spheres = args.scene.sphere_node_count != 0;
+    args.sphere_pass   = spheres ? 1 : 0;
     launch_one<false>(args, any_hit, stats, grid_blocks, stream);
     TraverseArgs deep = args;
     deep.count        = args.index_count;
     deep.work_counter = deep_work_counter;
     // a small grid: every workgroup of it waits for a free 48 KiB LDS slot, even if it only reads the empty counter
     launch_one<true>(deep, any_hit, stats, grid_blocks < 8 ? grid_blocks : 8, stream);
+    if (spheres) {
+        // the other SceneGeometry (driver/mapping_cpu.art:385-403): the sphere BVH, starting from the hits of the pass above.
+        // Its stack never leaves LDS (a BVH over entities, not triangles); a ray that would need more raises the error flag.
+        TraverseArgs sp = args;
+        sp.sphere_pass  = 2;
+        sp.work_counter = args.sphere_work_counter;
+        launch_one<false, true>(sp, any_hit, stats, grid_blocks, stream);
+    }
 }
 
 } // namespace igdev

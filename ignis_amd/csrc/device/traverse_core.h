@@ -61,7 +61,10 @@ IG_DEV float sel(bool c, float a, float b) { return c ? a : b; }
 // DEEP: entries above the LDS part spill to global memory; the persistent kernels run without it
 // and re-traverse the rare rays that need it in a second, DEEP launch (traverse.hip), because the extra work in
 // every push / pop costs 5 % on scenes that never need it.
-template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false>
+// SPHERES: the scene BVH over the analytic-sphere entities (igd_scene.sphere_*): its leaves are intersected right in the
+// entity-leaf section (make_scene_local_handler_sphere, shapes/sphere.art:139-148), there is no shape level and no triangle
+// section, and the ray starts from the hit the triangle pass left (driver/mapping_cpu.art:385-403).
+template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false, bool SPHERES = false>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     // ---- ray + hit
@@ -188,8 +191,18 @@ struct Traverser {
         // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
         ptr      = -1;
         push_entry(st, tid, true, 0, kFltMax);
-        top_node = sc.scene_node_count ? 1 : 0;
+        top_node = (SPHERES ? sc.sphere_node_count : sc.scene_node_count) ? 1 : 0;
         top_tmin = tmin;
+    }
+    // init_hit of a later geometry pass: the hit found so far (tmax passed to begin() is its distance)
+    IG_DEV void set_initial_hit(int ent, int prim, float u, float v)
+    {
+        hit_ent  = ent;
+        hit_prim = prim;
+        hit_u    = u;
+        hit_v    = v;
+        if (ANY_HIT)
+            finished = finished | (prim >= 0); // already occluded: nothing left to find
     }
 
     // a lane is settled when it waits for a section (or is done): only stack-driven lanes have transitions to make
@@ -280,7 +293,7 @@ struct Traverser {
             int entity_id   = 0;
             while (__any(scanning)) {
                 const int at     = scanning ? ent_cursor : 0;
-                const float4* lf = reinterpret_cast<const float4*>(sc.leaves + at);
+                const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + at);
                 const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
                 ent_cursor += scanning ? 1 : 0;
                 const int id          = (int)igm_bits(l0.w);
@@ -299,43 +312,83 @@ struct Traverser {
                 scanning          = scanning & !inside & !(id < 0);
             }
             if (__any(enter)) {
-                const float4* lf = reinterpret_cast<const float4*>(sc.leaves + enter_at);
-                const uint2 ext  = sc.leaf_ext[enter_at];
+                const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at);
+                const uint2 ext  = (SPHERES ? sc.sphere_leaf_ext : sc.leaf_ext)[enter_at];
                 const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4];
                 m34 m;
                 m.c0 = f3{ l2.x, l2.y, l2.z };
                 m.c1 = f3{ l2.w, l3.x, l3.y };
                 m.c2 = f3{ l3.z, l3.w, l4.x };
                 m.c3 = f3{ l4.y, l4.z, l4.w };
-                // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
-                loc.org.x = sel(enter, nl.org.x, loc.org.x), loc.org.y = sel(enter, nl.org.y, loc.org.y), loc.org.z = sel(enter, nl.org.z, loc.org.z);
-                loc.dir.x = sel(enter, nl.dir.x, loc.dir.x), loc.dir.y = sel(enter, nl.dir.y, loc.dir.y), loc.dir.z = sel(enter, nl.dir.z, loc.dir.z);
-                loc.inv_dir.x = sel(enter, nl.inv_dir.x, loc.inv_dir.x), loc.inv_dir.y = sel(enter, nl.inv_dir.y, loc.inv_dir.y), loc.inv_dir.z = sel(enter, nl.inv_dir.z, loc.inv_dir.z);
-                loc.inv_org.x = sel(enter, nl.inv_org.x, loc.inv_org.x), loc.inv_org.y = sel(enter, nl.inv_org.y, loc.inv_org.y), loc.inv_org.z = sel(enter, nl.inv_org.z, loc.inv_org.z);
-                cur_ent = sel(enter, entity_id & 0x7FFFFFFF, cur_ent);
-                // save the scene-level top, then a fresh stack: sentinel + shape root
-                push_entry(st, tid, enter, top_node, top_tmin);
-                lbase  = sel(enter, ptr, lbase);
-                ltmax  = sel(enter, tmax, ltmax); // invalid_hit(local_ray.tmax)
-                l_prim = sel(enter, -1, l_prim);
-                lterm  = lterm & !enter;
-                push_entry(st, tid, enter, 0, kFltMax);
-                top_node = sel(enter, 1, top_node);
-                top_tmin = sel(enter, tmin, top_tmin);
-                level    = sel(enter, 1, level);
-                node_off = sel(enter, ext.x, node_off);
-                tri_off  = sel(enter, ext.y, tri_off);
+                if (SPHERES) {
+                    // intersect_sphere (shapes/sphere.art:107-137) with the ray in shape space: direction not normalised, t global
+                    const f3 lorg = xform_point(m, gray.org), ldir = xform_dir(m, gray.dir);
+                    const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x); // centre, radius
+                    const f3 L     = lorg - f3{ sp.x, sp.y, sp.z };
+                    const float S  = -dot3(L, ldir);
+                    const float D2 = dot3(ldir, ldir);
+                    const float L2 = dot3(L, L);
+                    const float R2 = sp.w * sp.w * D2;
+                    const float M2 = L2 * D2 - S * S;
+                    const float Q   = igm_sqrt(R2 - M2);
+                    const float t0_ = (S - Q) / D2;
+                    const float t1_ = (S + Q) / D2;
+                    const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
+                    const float th = t0 < tmin ? t1 : t0;
+                    // accepted if in range (local_hit.distance <= hit.distance is implied by th <= tmax)
+                    const bool ok = enter & !((S < 0) | (M2 > R2)) & (th >= tmin) & (th <= tmax);
+                    // sphere_map_uv (sphere.art:1-6)
+                    const f3 n        = (L + ldir * th) * (1 / sp.w);
+                    const float theta = igm_acos(n.z);
+                    float phi         = igm_atan2(-n.x, n.y);
+                    phi               = phi < 0 ? phi + 2 * kPi : phi;
+                    tmax     = sel(ok, th, tmax);
+                    hit_u    = sel(ok, phi / (2 * kPi), hit_u);
+                    hit_v    = sel(ok, theta / kPi, hit_v);
+                    hit_prim = sel(ok, 0, hit_prim);
+                    hit_ent  = sel(ok, entity_id & 0x7FFFFFFF, hit_ent);
+                    if (ANY_HIT)
+                        finished = finished | ok;
+                } else {
+                    // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
+                    const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                    loc.org.x = sel(enter, nl.org.x, loc.org.x), loc.org.y = sel(enter, nl.org.y, loc.org.y), loc.org.z = sel(enter, nl.org.z, loc.org.z);
+                    loc.dir.x = sel(enter, nl.dir.x, loc.dir.x), loc.dir.y = sel(enter, nl.dir.y, loc.dir.y), loc.dir.z = sel(enter, nl.dir.z, loc.dir.z);
+                    loc.inv_dir.x = sel(enter, nl.inv_dir.x, loc.inv_dir.x), loc.inv_dir.y = sel(enter, nl.inv_dir.y, loc.inv_dir.y), loc.inv_dir.z = sel(enter, nl.inv_dir.z, loc.inv_dir.z);
+                    loc.inv_org.x = sel(enter, nl.inv_org.x, loc.inv_org.x), loc.inv_org.y = sel(enter, nl.inv_org.y, loc.inv_org.y), loc.inv_org.z = sel(enter, nl.inv_org.z, loc.inv_org.z);
+                    cur_ent = sel(enter, entity_id & 0x7FFFFFFF, cur_ent);
+                    // save the scene-level top, then a fresh stack: sentinel + shape root
+                    push_entry(st, tid, enter, top_node, top_tmin);
+                    lbase  = sel(enter, ptr, lbase);
+                    ltmax  = sel(enter, tmax, ltmax); // invalid_hit(local_ray.tmax)
+                    l_prim = sel(enter, -1, l_prim);
+                    lterm  = lterm & !enter;
+                    push_entry(st, tid, enter, 0, kFltMax);
+                    top_node = sel(enter, 1, top_node);
+                    top_tmin = sel(enter, tmin, top_tmin);
+                    level    = sel(enter, 1, level);
+                    node_off = sel(enter, ext.x, node_off);
+                    tri_off  = sel(enter, ext.y, tri_off);
+                }
             }
-            mode      = sel(here, 0, mode);
-            need_cull = need_cull | here;
-            settle(sc, st, tid);
+            if (SPHERES) {
+                // a leaf run continues after a sphere test (the shape level of the triangle pass comes back through settle()'s
+                // `ret`; here the run is resumed directly): lanes that entered and have leaves left scan on in the next pass
+                const bool more = here & enter & !ent_last & !finished;
+                mode            = sel(here & !more, 0, mode);
+                need_cull       = need_cull | (here & !more);
+                settle(sc, st, tid);
+            } else {
+                mode      = sel(here, 0, mode);
+                need_cull = need_cull | here;
+                settle(sc, st, tid);
+            }
         }
 
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
         if (__popcll(__ballot((mode == 0) & !finished)) >= quorum) {
             const bool here   = (mode == 0) & !finished; // settled: an inner node is on top
-            const uint8_t* np = geom + (level ? node_off : sc.scene_nodes_off) + (here ? (uint32_t)(top_node - 1) * 256u : 0u);
+            const uint8_t* np = geom + (SPHERES ? sc.sphere_nodes_off : (level ? node_off : sc.scene_nodes_off)) + (here ? (uint32_t)(top_node - 1) * 256u : 0u);
             pop_top(st, tid, here);
             const float4* nf = reinterpret_cast<const float4*>(np);
             const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
@@ -387,7 +440,7 @@ struct Traverser {
         }
 
         // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
-        if (__popcll(__ballot(mode == 1)) >= quorum) {
+        if (!SPHERES && __popcll(__ballot(mode == 1)) >= quorum) {
             while (__any(mode == 1)) {
                 const bool here   = mode == 1;
                 const uint8_t* tp = geom + tri_off + (here ? (uint32_t)tri_cursor * 208u : 0u);

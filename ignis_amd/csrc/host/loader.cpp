@@ -357,6 +357,9 @@ struct ShapeRec {
     int32_t user1 = 0, user2 = 0; // prim-BVH offset in floats, split (TriMeshProvider.cpp:598)
     std::optional<PlaneShape> plane;
     float area = 0;
+    // analytic sphere ("sphere" shapes, SphereProvider.cpp) or a mesh that tessellates one (TriMesh::getAsSphere)
+    std::optional<SphereShape> sphere;
+    bool analytic = false; // no triangles: intersected as a sphere, lives in the sphere scene BVH
 };
 
 struct Scene {
@@ -366,6 +369,8 @@ struct Scene {
     std::vector<uint8_t> primbvh;
     std::vector<ig_node8> scene_nodes;
     std::vector<ig_entity_leaf1> scene_leaves;
+    std::vector<ig_node8> sphere_nodes;
+    std::vector<ig_entity_leaf1> sphere_leaves;
     std::vector<ig_material> materials;
     std::vector<int32_t> entity_per_material;
     std::vector<ig_light> lights;
@@ -519,8 +524,36 @@ static TriMesh loadShapeMesh(const std::string& name, const JsonValue& elem, con
     fail("Shape '" + name + "': Can not load shape type '" + type + "'");
 }
 
+// SphereProvider::handle (src/runtime/shape/SphereProvider.cpp:10-53): centre + radius as four floats in the "shapes" table, a
+// bounding box through the six axis extremes, no triangles
+static void handleSphere(Scene& sc, std::vector<ShapeRec>& shapes, const std::string& name, const JsonValue& elem)
+{
+    const V3 origin    = elem.has("center") ? getVector3(*elem.find("center"), "center") : V3(0, 0, 0);
+    const float radius = elem.getNumber("radius", 1.0f);
+    if (radius <= 0)
+        fail("Shape '" + name + "': While loading shape type 'sphere' an invalid radius of " + std::to_string(radius) + " was given");
+    BBox bbox;
+    for (const V3 axis : { V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1) }) {
+        bbox.extend(origin + axis * radius);
+        bbox.extend(origin - axis * radius);
+    }
+    bbox.inflate(1e-5f);
+    padTo(sc.shape_data, Pack4Alignment);
+    sc.shape_lookups.push_back(ig_lookup_entry{ IG_SHAPE_SPHERE, 0, (uint64_t)sc.shape_data.size() });
+    const float rec4[4] = { origin.x, origin.y, origin.z, radius };
+    appendBytes(sc.shape_data, rec4, 4);
+    ShapeRec rec;
+    rec.name     = name;
+    rec.bbox     = bbox;
+    rec.sphere   = SphereShape{ origin, radius };
+    rec.analytic = true;
+    shapes.push_back(rec);
+}
+
 static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::string& name, const JsonValue& elem, const std::string& base_dir)
 {
+    if (elem.getString("type") == "sphere")
+        return handleSphere(sc, shapes, name, elem);
     TriMesh mesh = loadShapeMesh(name, elem, base_dir);
     if (mesh.vertices.empty())
         fail("Shape '" + name + "': no vertices were generated");
@@ -560,7 +593,7 @@ static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::str
 
     // Mesh -> dyn table "shapes" (TriMeshProvider.cpp:575-596)
     padTo(sc.shape_data, Pack4Alignment);
-    sc.shape_lookups.push_back(ig_lookup_entry{ 0 /* trimesh provider */, 0, (uint64_t)sc.shape_data.size() });
+    sc.shape_lookups.push_back(ig_lookup_entry{ IG_SHAPE_TRIMESH, 0, (uint64_t)sc.shape_data.size() });
     const uint32_t mheader[4] = { (uint32_t)mesh.faceCount(), (uint32_t)mesh.vertices.size(), (uint32_t)mesh.normals.size(), (uint32_t)mesh.texcoords.size() };
     appendBytes(sc.shape_data, mheader, 4);
     const float bb[8] = { bbox.min.x, bbox.min.y, bbox.min.z, 0, bbox.max.x, bbox.max.y, bbox.max.z, 0 };
@@ -586,6 +619,8 @@ static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::str
     rec.user2 = (int32_t)(uint32_t)((bvh_offset >> 32) & 0xFFFFFFFFu);
     rec.plane = mesh.getAsPlane();
     rec.area  = mesh.computeArea();
+    if (!rec.plane.has_value())
+        rec.sphere = mesh.getAsSphere(); // TriMeshProvider.cpp:561: "if not a plane, it might be a simple sphere"
     shapes.push_back(rec);
 }
 
@@ -1449,7 +1484,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         Affine transform;
     };
     std::map<std::string, EmissiveEntity> emissive;
-    std::vector<EntityObject> objs;
+    std::vector<EntityObject> objs, sphere_objs; // one scene BVH per shape provider (SceneBVHAdapter.h:110-129 per provider)
     BBox sceneBBox;
     uint32_t entityCount = 0;
     for (size_t materialID = 0; materialID < groups.size(); ++materialID) {
@@ -1499,7 +1534,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             obj.local[9]  = invTransform.t.x;
             obj.local[10] = invTransform.t.y;
             obj.local[11] = invTransform.t.z;
-            objs.push_back(obj);
+            (shape.analytic ? sphere_objs : objs).push_back(obj);
 
             sc->entity_names.push_back(ename);
             ++entityCount;
@@ -1507,8 +1542,10 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         sc->entity_per_material.push_back((int32_t)groups[materialID].size());
     }
 
-    if (entityCount > 0)
+    if (!objs.empty())
         build_scene_bvh8(objs, sc->scene_nodes, sc->scene_leaves);
+    if (!sphere_objs.empty())
+        build_scene_bvh8(sphere_objs, sc->sphere_nodes, sc->sphere_leaves);
 
     // ---- lights: infinite first, then finite (light_selector.art:26-46 id convention)
     std::vector<ig_light> infinite, finite;
@@ -1527,7 +1564,43 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             if (it == emissive.end())
                 fail("No entity named '" + ent + "' exists for area light '" + lname + "'");
             const ShapeRec& shape = shapes[it->second.shape_id];
-            if (!shape.plane.has_value() || !l.getBool("optimize", true)) {
+            // AreaLight.cpp:50-62: the specialised samplers are used unless "optimize" is off (always for non-triangle shapes)
+            const bool opt = l.getBool("optimize", true) || shape.analytic;
+            if (opt && !shape.plane.has_value() && shape.sphere.has_value()) {
+                // make_sphere_area_emitter (light/area.art:259-317). Area: compute_ellipsoid_area (shapes/sphere.art:21-28) over the
+                // entity's toGlobal matrix — vec3_len2, i.e. SQUARED lengths, go into Knud Thomsen's formula there with p = 1.6,
+                // which still gives 4 pi r^2 for a uniform scale; evaluated here once instead of per sample on the device.
+                const Affine& T    = it->second.transform;
+                const float r      = shape.sphere->radius;
+                auto len2          = [&](V3 axis) { const V3 d = T.direction(axis * r); return dot(d, d); };
+                const float l1 = len2(V3(1, 0, 0)), l2 = len2(V3(0, 1, 0)), l3 = len2(V3(0, 0, 1));
+                const float P       = 1.6f;
+                const float area    = 4 * Pi * std::pow((std::pow(l1 * l2, P / 2) + std::pow(l1 * l3, P / 2) + std::pow(l2 * l3, P / 2)) / 3, 1 / P);
+                // the host's own area (flux, "power" -> radiance): approximate_ellipsoid_area, AreaLight.cpp:26-35
+                const float w = norm(T.direction(V3(1, 0, 0) * r)), h = norm(T.direction(V3(0, 1, 0) * r)), dd = norm(T.direction(V3(0, 0, 1) * r));
+                const float PH     = 1.6075f;
+                const float m_area = 4 * Pi * std::pow((std::pow(w * h, PH) + std::pow(w * dd, PH) + std::pow(h * dd, PH)) / 3, 1 / PH);
+                V3 radiance, cache;
+                if (l.has("power")) {
+                    cache    = getColor(l, "power", V3(m_area * Pi, m_area * Pi, m_area * Pi), lname);
+                    radiance = cache * ((1 / Pi) / m_area);
+                } else {
+                    radiance = getColor(l, "radiance", V3(1, 1, 1), lname);
+                    cache    = radiance * (m_area * Pi);
+                }
+                out.type      = IG_LIGHT_SPHERE;
+                out.entity_id = (int32_t)it->second.id;
+                out.d[0] = shape.sphere->origin.x, out.d[1] = shape.sphere->origin.y, out.d[2] = shape.sphere->origin.z, out.d[3] = r;
+                out.d[4] = radiance.x, out.d[5] = radiance.y, out.d[6] = radiance.z, out.d[7] = area;
+                finite_index_of_entity[ent] = (int32_t)finite.size();
+                // AreaLight.cpp:73-82: position = the transformed centre, no direction
+                hier_entries.push_back(LightEntry{ T.point(shape.sphere->origin), V3(0, 0, 1), -((cache.x + cache.y + cache.z) / 3), (int32_t)finite.size() });
+                finite.push_back(out);
+                continue;
+            }
+            if (!shape.plane.has_value() || !opt) {
+                if (shape.analytic)
+                    fail("Area light '" + lname + "': Given entity '" + ent + "' primitive type is not triangular"); // AreaLight.cpp:93
                 // AreaLight.cpp:60-62,84-92,206-227: no specialised sampler -> make_shape_area_emitter over the entity's triangles.
                 // Position = centre of the bounding box, no direction (negative flux in the hierarchy), area = mesh area times
                 // the transform's approximate area scale (AreaLight.cpp:12-24).
@@ -1554,8 +1627,6 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
                 finite.push_back(out);
                 continue;
             }
-            if (l.has("power"))
-                fail("Area light '" + lname + "': 'power' is not supported by this loader for planar emitters, use 'radiance'");
             // AreaLight.cpp:138-170 + "SimplePlaneLight" layout (light/area.art:416-440)
             const Affine& T    = it->second.transform;
             const V3 origin    = T.point(shape.plane->origin);
@@ -1564,7 +1635,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             const V3 cr        = cross(x_axis, y_axis);
             const V3 normal    = normalized(cr);
             const float area   = norm(cr);
-            const V3 radiance  = getColor(l, "radiance", V3(1, 1, 1), lname);
+            // "power" -> color_mulf(power, flt_inv_pi / mArea) (AreaLight.cpp:222-225)
+            const V3 radiance  = l.has("power") ? getColor(l, "power", V3(area * Pi, area * Pi, area * Pi), lname) * ((1 / Pi) / area) : getColor(l, "radiance", V3(1, 1, 1), lname);
             const auto& tc     = shape.plane->texcoords;
             const float d[24]  = { origin.x, origin.y, origin.z, normal.x,
                                    x_axis.x, x_axis.y, x_axis.z, normal.y,
@@ -1812,6 +1884,10 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.scene_node_count   = (uint32_t)sc->scene_nodes.size();
     t.scene_leaves       = sc->scene_leaves.data();
     t.scene_leaf_count   = (uint32_t)sc->scene_leaves.size();
+    t.sphere_nodes       = sc->sphere_nodes.data();
+    t.sphere_node_count  = (uint32_t)sc->sphere_nodes.size();
+    t.sphere_leaves      = sc->sphere_leaves.data();
+    t.sphere_leaf_count  = (uint32_t)sc->sphere_leaves.size();
     t.materials          = sc->materials.data();
     t.material_count     = (uint32_t)sc->materials.size();
     t.entity_per_material = sc->entity_per_material.data();

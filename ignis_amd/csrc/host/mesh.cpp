@@ -210,6 +210,61 @@ std::optional<PlaneShape> TriMesh::getAsPlane() const
     return shape;
 }
 
+// Does this mesh tessellate a sphere? Then an area light on it is sampled as the analytic sphere (AreaLight.cpp:60-62). The
+// criteria are the reference's (TriMesh.cpp:637-731), checked in this order:
+//   at least 32 faces; a bounding box with volume whose three extents agree to 1e-4 (relative); all vertices at one squared
+//   distance from the box centre (mean, +- 1e-4 absolute); no two faces that share an edge are perpendicular and none of those
+//   is degenerate (this is what keeps the default cylinder out); vertices in all eight octants around the centre.
+std::optional<SphereShape> TriMesh::getAsSphere() const
+{
+    constexpr float kSphereEps = 1e-4f, kPerpendicularEps = 1e-7f;
+    if (faceCount() < 32)
+        return std::nullopt;
+    const BBox box  = computeBBox();
+    const V3 extent = box.diameter();
+    const V3 centre = box.center();
+    if (extent.x * extent.y * extent.z <= kSphereEps)
+        return std::nullopt;
+    auto differ = [&](float a, float b) { return std::abs((a - b) / std::max(1e-5f, a + b)) > kSphereEps; };
+    if (differ(extent.x, extent.y) || differ(extent.x, extent.z) || differ(extent.y, extent.z))
+        return std::nullopt;
+
+    float radius2 = 0;
+    for (const V3& v : vertices)
+        radius2 += dot(centre - v, centre - v);
+    radius2 /= (float)vertices.size();
+    if (radius2 <= kSphereEps)
+        return std::nullopt;
+    bool octant[8] = {};
+    for (const V3& v : vertices) {
+        const V3 d = centre - v;
+        if (std::abs(dot(d, d) - radius2) > kSphereEps)
+            return std::nullopt;
+        octant[(d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)] = true;
+    }
+
+    // faces across every shared edge: directed edge (a, b) of one face and (b, a) of another
+    std::map<std::pair<uint32_t, uint32_t>, size_t> face_of_edge;
+    for (size_t f = 0; f < faceCount(); ++f)
+        for (int k = 0; k < 3; ++k)
+            face_of_edge[{ indices[4 * f + k], indices[4 * f + (k + 1) % 3] }] = f;
+    auto unit_normal = [&](size_t f) { return normalized(computeTriangleNormal(vertices[indices[4 * f]], vertices[indices[4 * f + 1]], vertices[indices[4 * f + 2]])); };
+    auto has_nan     = [](V3 n) { return std::isnan(n.x) || std::isnan(n.y) || std::isnan(n.z); };
+    for (size_t f = 0; f < faceCount(); ++f)
+        for (int k = 0; k < 3; ++k) {
+            const auto twin = face_of_edge.find({ indices[4 * f + (k + 1) % 3], indices[4 * f + k] });
+            if (twin == face_of_edge.end())
+                continue;
+            const V3 n1 = unit_normal(f), n2 = unit_normal(twin->second);
+            if (has_nan(n1) || has_nan(n2) || std::abs(dot(n1, n2)) <= kPerpendicularEps)
+                return std::nullopt;
+        }
+    for (bool seen : octant)
+        if (!seen)
+            return std::nullopt;
+    return SphereShape{ centre, std::sqrt(radius2) };
+}
+
 static void addTriangle(TriMesh& mesh, V3 origin, V3 xAxis, V3 yAxis)
 {
     const V3 N         = normalized(cross(xAxis, yAxis));

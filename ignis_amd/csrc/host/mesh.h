@@ -17,6 +17,11 @@ struct PlaneShape {
     std::array<V2, 4> texcoords;
 };
 
+struct SphereShape {
+    V3 origin;
+    float radius = 0;
+};
+
 struct TriMesh {
     std::vector<V3> vertices;
     std::vector<V3> normals;
@@ -33,6 +38,7 @@ struct TriMesh {
     BBox computeBBox() const;           // TriMesh.cpp:144-150
     float computeArea() const;          // TriMesh.cpp:199-209
     std::optional<PlaneShape> getAsPlane() const; // TriMesh.cpp:521-633
+    std::optional<SphereShape> getAsSphere() const; // TriMesh.cpp:637-731
 
     static TriMesh MakePlane(V3 origin, V3 x_axis, V3 y_axis);     // TriMesh.cpp:783-817,1039-1044
     static TriMesh MakeRectangle(V3 p0, V3 p1, V3 p2, V3 p3);      // TriMesh.cpp:1053-1059

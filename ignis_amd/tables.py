@@ -77,6 +77,8 @@ class Scene(C.Structure):
         ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
         ("texture_data", C.POINTER(C.c_uint8)), ("texture_data_size", C.c_uint64),
         ("cdf_data", C.POINTER(C.c_float)), ("cdf_data_count", C.c_uint64),
+        ("sphere_nodes", C.POINTER(Node8)), ("sphere_node_count", C.c_uint32),
+        ("sphere_leaves", C.POINTER(EntityLeaf1)), ("sphere_leaf_count", C.c_uint32),
     ]
 
 

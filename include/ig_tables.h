@@ -73,6 +73,11 @@ typedef struct ig_lookup_entry {
 
 #define IG_ENTITY_FLOATS 36 /* toLocal 3x4 | toGlobal 3x4 | normal 3x3 | shape | mat | pad */
 
+/* ig_lookup_entry.type_id of the "shapes" dyn table: which provider wrote the record (ShapeProvider::id in the reference).
+ * A sphere record is 4 floats {centre.xyz, radius} (src/runtime/shape/SphereProvider.cpp:38-47, src/artic/shapes/sphere.art:96-103). */
+#define IG_SHAPE_TRIMESH 0u
+#define IG_SHAPE_SPHERE 1u
+
 /* Ray visibility flags, src/artic/traversal/ray.art:21-25 */
 #define IG_RAY_FLAG_CAMERA 0x1u
 #define IG_RAY_FLAG_LIGHT 0x2u
@@ -178,6 +183,11 @@ enum ig_light_type {
      * representation "None": non-planar meshes or "optimize": false): a uniformly chosen triangle, a uniform point on it.
      * entity_id = the emissive entity, d[0..2] radiance. Finite, not delta. */
     IG_LIGHT_MESH_AREA = 8,
+    /* area light on a sphere (make_sphere_area_emitter, src/artic/light/area.art:259-317; AreaLight.cpp representation
+     * "Sphere": an analytic sphere shape, or a mesh TriMesh::getAsSphere recognises as one): entity_id = the emissive entity,
+     * d[0..2] centre in shape space, d[3] radius, d[4..6] radiance, d[7] area of the ellipsoid the entity transform makes of
+     * it (compute_ellipsoid_area, src/artic/shapes/sphere.art:21-28, evaluated by the loader). Finite, not delta. */
+    IG_LIGHT_SPHERE = 9,
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
@@ -294,6 +304,13 @@ typedef struct igd_scene {
      * src/artic/core/cdf.art:70-73,155-159) */
     const float* cdf_data;
     uint64_t cdf_data_count;
+    /* SceneBVHs["sphere"]: the entities whose shape is an analytic sphere have a scene BVH of their own, traversed after
+     * the triangle one with its result as the initial hit (one SceneGeometry per shape provider, TraversalShader.cpp:73-95,
+     * src/artic/driver/mapping_cpu.art:385-403). Leaves: EntityLeaf1 with user = 0. Counts 0 when the scene has no spheres. */
+    const ig_node8* sphere_nodes;
+    uint32_t sphere_node_count;
+    const ig_entity_leaf1* sphere_leaves;
+    uint32_t sphere_leaf_count;
 } igd_scene;
 
 #ifdef __cplusplus

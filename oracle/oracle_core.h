@@ -389,12 +389,61 @@ static inline Mat3x4 leaf_local(const ig_entity_leaf1& l)
     return m;
 }
 
-// cpu_traverse_helper, traversal/mapping_cpu.art:421-518 with vector_width = 1
-static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, TraversalStats& st)
+// sphere_map_uv (shapes/sphere.art:1-6) over spherical_from_dir (core/common.art: theta = acos(z), phi = atan2(y, x) in [0, 2 pi))
+static inline void sphere_map_uv(Vec3 dir, float& u, float& v)
 {
-    Hit hit         = invalid_hit(ray.tmax);
+    const Vec3 d      = make_vec3(dir.y, -dir.x, dir.z);
+    const float theta = igm_acos(d.z);
+    float phi         = igm_atan2(d.y, d.x);
+    if (phi < 0)
+        phi += 2 * flt_pi;
+    v = theta / flt_pi;
+    u = phi / (2 * flt_pi);
+}
+
+// intersect_sphere (shapes/sphere.art:107-137): the ray direction need not be normalised
+static inline Hit intersect_sphere(Vec3 origin, float radius, const Ray& ray)
+{
+    const Vec3 L   = vec3_sub(ray.org, origin);
+    const float S  = -vec3_dot(L, ray.dir);
+    const float D2 = vec3_len2(ray.dir);
+    const float L2 = vec3_len2(L);
+    const float R2 = radius * radius * D2;
+    const float M2 = L2 * D2 - S * S;
+    if ((S < 0) || (M2 > R2))
+        return invalid_hit(ray.tmax);
+    const float Q   = igm_sqrt(R2 - M2);
+    const float t0_ = (S - Q) / D2;
+    const float t1_ = (S + Q) / D2;
+    const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
+    const float tmin = t0 < ray.tmin ? t1 : t0;
+    if (tmin >= ray.tmin && tmin <= ray.tmax) {
+        const Vec3 dir = vec3_mulf(vec3_add(L, vec3_mulf(ray.dir, tmin)), 1 / radius);
+        Hit h;
+        h.distance = tmin;
+        sphere_map_uv(dir, h.u, h.v);
+        h.prim_id = 0;
+        h.ent_id  = -1; // InvalidHitId, set by the scene traversal
+        return h;
+    }
+    return invalid_hit(ray.tmax);
+}
+
+// One SceneGeometry of the scene (driver/scene.art, TraversalShader.cpp:73-95): a scene BVH over the entities of one shape
+// provider and that provider's local handler. kind 0: triangle meshes (prim BVH traversal), kind 1: analytic spheres.
+struct SceneGeometry {
+    const ig_node8* nodes;
+    uint32_t node_count;
+    const ig_entity_leaf1* leaves;
+    int kind;
+};
+
+// cpu_traverse_helper, traversal/mapping_cpu.art:421-518 with vector_width = 1; `hit` = init_hit (invalid_hit(ray.tmax) for the
+// first geometry, the previous geometry's result afterwards, driver/mapping_cpu.art:385-403)
+static inline Hit traverse_geometry(const igd_scene& sc, const SceneGeometry& geom, Ray ray, Hit hit, bool any_hit, TraversalStats& st)
+{
     bool terminated = false;
-    if (sc.scene_node_count == 0)
+    if (geom.node_count == 0)
         return hit;
 
     Stack stack;
@@ -422,7 +471,7 @@ static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, Tra
             int32_t node_id;
             float node_t;
             stack.pop(node_id, node_t);
-            const ig_node8& node = sc.scene_nodes[node_id - 1];
+            const ig_node8& node = geom.nodes[node_id - 1];
             ++st.nodes;
 
             bool pushed = false;
@@ -459,7 +508,7 @@ static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, Tra
             int32_t ref_id = ~leaf_ref;
             // Inactive run: the reference still calls handle_local but discards the result.
             while (active) {
-                const ig_entity_leaf1& leaf = sc.scene_leaves[ref_id++];
+                const ig_entity_leaf1& leaf = geom.leaves[ref_id++];
                 ++st.leaves;
                 if (check_ray_visibility(ray, leaf.flags)) {
                     // intersect_ray_box_single_section, intersection.art:247-256
@@ -468,8 +517,15 @@ static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, Tra
                     if ((entry <= exit) & (exit >= 0)) {
                         if (entry <= hit.distance) {
                             const Ray local_ray  = transform_ray(ray, leaf_local(leaf));
-                            const uint64_t off   = ((uint64_t)(uint32_t)leaf.user[1] << 32) | (uint64_t)(uint32_t)leaf.user[0];
-                            const Hit local_hit  = traverse_prim(local_ray, prim_bvh_at(sc, off), any_hit, st);
+                            Hit local_hit;
+                            if (geom.kind == 1) {
+                                // make_scene_local_handler_sphere (shapes/sphere.art:139-148)
+                                const float* sp = reinterpret_cast<const float*>(sc.shape_data + sc.shape_lookups[leaf.shape_id].offset);
+                                local_hit       = intersect_sphere(make_vec3(sp[0], sp[1], sp[2]), sp[3], local_ray);
+                            } else {
+                                const uint64_t off = ((uint64_t)(uint32_t)leaf.user[1] << 32) | (uint64_t)(uint32_t)leaf.user[0];
+                                local_hit          = traverse_prim(local_ray, prim_bvh_at(sc, off), any_hit, st);
+                            }
                             if (active) {
                                 if (local_hit.prim_id != -1) {
                                     if (local_hit.distance <= hit.distance) {
@@ -496,6 +552,20 @@ static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, Tra
 done:
     if (stack.max_ptr > st.max_stack)
         st.max_stack = stack.max_ptr;
+    return hit;
+}
+
+// cpu_traverse_primary / _secondary (driver/mapping_cpu.art:377-435): every geometry in turn, each starting from the hit so far.
+// Triangle meshes first, then spheres (the reference iterates an unordered container of providers; the order only matters
+// for exactly equal distances).
+static inline Hit traverse_scene(const igd_scene& sc, Ray ray, bool any_hit, TraversalStats& st)
+{
+    Hit hit = invalid_hit(ray.tmax);
+    hit     = traverse_geometry(sc, SceneGeometry{ sc.scene_nodes, sc.scene_node_count, sc.scene_leaves, 0 }, ray, hit, any_hit, st);
+    if (sc.sphere_node_count != 0 && !(any_hit && hit.prim_id != -1)) {
+        ray.tmax = hit.distance; // ray.tmax follows the hit inside a traversal; carried over here as the reference re-reads the hit
+        hit      = traverse_geometry(sc, SceneGeometry{ sc.sphere_nodes, sc.sphere_node_count, sc.sphere_leaves, 1 }, ray, hit, any_hit, st);
+    }
     return hit;
 }
 

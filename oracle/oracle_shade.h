@@ -249,8 +249,56 @@ static inline Vec3 compute_stable_triangle_normal(Vec3 e1, Vec3 e2, Vec3 e3)
 
 // make_trimesh_shape.surface_element (trimesh.art:14-40) with
 // make_standard_pointmapperset (pointmapper.art:28-36) and make_triangle (triangle.art:12-29)
+// ---- shapes/sphere.art
+struct Sphere {
+    Vec3 origin;
+    float radius;
+};
+static inline Sphere load_sphere(const igd_scene& sc, int32_t shape_id) // sphere.art:96-103
+{
+    const float* f = reinterpret_cast<const float*>(sc.shape_data + sc.shape_lookups[shape_id].offset);
+    return Sphere{ make_vec3(f[0], f[1], f[2]), f[3] };
+}
+// sphere_unmap_uv (sphere.art:8-13) over dir_from_spherical (theta from +z, phi in the xy plane)
+static inline Vec3 sphere_unmap_uv(Vec2 uv)
+{
+    const float theta = uv.y * flt_pi;
+    const float phi   = uv.x * 2 * flt_pi;
+    const float st    = igm_sin(theta);
+    const Vec3 dir    = make_vec3(st * igm_cos(phi), st * igm_sin(phi), igm_cos(theta));
+    return make_vec3(dir.y, -dir.x, dir.z);
+}
+// sphere_compute_surface_element_for_normal (sphere.art:30-46); `area` = compute_ellipsoid_area, evaluated by the loader
+static inline void sphere_surface_for_normal(const Entity& entity, const Sphere& sphere, Vec3 normal, Vec3& point, Vec3& face_normal)
+{
+    const Vec3 p = vec3_add(sphere.origin, vec3_mulf(normal, sphere.radius));
+    face_normal  = vec3_normalize(mat3x3_mul(entity.normal_mat, normal));
+    point        = mat3x4_transform_point(entity.global_mat, p);
+}
+
+// make_sphere_shape.surface_element (sphere.art:52-73). The area is only read by area lights, which carry their own.
+static inline SurfaceElement sphere_surface_element(const igd_scene& sc, const Entity& entity, const Ray& ray, const Hit& hit)
+{
+    const Sphere sphere = load_sphere(sc, entity.shape_id);
+    SurfaceElement s;
+    s.point          = vec3_add(ray.org, vec3_mulf(ray.dir, hit.distance));
+    const Vec3 dir   = vec3_sub(s.point, mat3x4_transform_point(entity.global_mat, sphere.origin));
+    const float len  = vec3_len(dir);
+    const Vec3 n     = vec3_mulf(dir, 1 / len);
+    s.is_entering    = true;
+    s.face_normal    = n;
+    s.area           = 0;
+    s.inv_area       = 0;
+    s.prim_coords    = Vec2{ hit.u, hit.v };
+    s.tex_coords     = s.prim_coords;
+    s.local          = make_orthonormal_mat3x3(n);
+    return s;
+}
+
 static inline SurfaceElement surface_element(const igd_scene& sc, const Entity& entity, const Ray& ray, const Hit& hit)
 {
+    if (sc.shape_lookups[entity.shape_id].type_id == IG_SHAPE_SPHERE)
+        return sphere_surface_element(sc, entity, ray, hit);
     const TriMeshView mesh = load_trimesh(sc, entity.shape_id);
     const int32_t i0 = mesh.indices[hit.prim_id * 4 + 0], i1 = mesh.indices[hit.prim_id * 4 + 1], i2 = mesh.indices[hit.prim_id * 4 + 2];
     auto vtx = [&](int32_t i) { return Vec3{ mesh.vertices[i * 4], mesh.vertices[i * 4 + 1], mesh.vertices[i * 4 + 2] }; };
@@ -1907,6 +1955,60 @@ static inline DirectLightSample sample_direct_mesh(const igd_scene& sc, const ig
     return s;
 }
 
+// make_sphere_area_emitter (light/area.art:259-317) for IG_LIGHT_SPHERE
+struct SphereEmitter {
+    Entity entity;
+    Sphere sphere;
+    Color radiance;
+    float area, inv_area;
+    SphereEmitter(const igd_scene& sc, const ig_light& l)
+        : entity(load_entity(sc, l.entity_id))
+        , sphere(Sphere{ make_vec3(l.d[0], l.d[1], l.d[2]), l.d[3] })
+        , radiance(Color{ l.d[4], l.d[5], l.d[6] })
+        , area(l.d[7])
+        , inv_area(safe_div(1, l.d[7]))
+    {
+    }
+};
+
+static inline DirectLightSample sample_direct_sphere(const igd_scene& sc, const ig_light& l, Rng& rnd, const SurfaceElement& from_surf)
+{
+    const SphereEmitter se(sc, l);
+    const float ux = rnd.next_f32();
+    const float uy = rnd.next_f32();
+    const Vec3 glb_org = mat3x4_transform_point(se.entity.global_mat, se.sphere.origin);
+    // a uniform point on the sphere, mirrored to the near side when it fell on the far one (area.art:268-294)
+    Vec3 point, face_normal;
+    sphere_surface_for_normal(se.entity, se.sphere, equal_area_square_to_sphere(ux, uy), point, face_normal);
+    const float los = vec3_len2(vec3_sub(from_surf.point, glb_org));
+    const float lps = vec3_len2(vec3_sub(from_surf.point, point));
+    if (!(lps <= los)) {
+        const Vec3 po   = vec3_sub(glb_org, point);
+        const Vec3 np   = vec3_add(point, vec3_mulf(po, 2));
+        const Vec3 norm = vec3_normalize(vec3_sub(np, glb_org));
+        // pmset.to_local_normal (driver/pointmapper.art:31): mat3x3_left_mul(normal_mat, n) / |diag(normal_mat)|^2 — as written
+        // there ("TODO: Really? Invalid scaling..."): the result is not a unit vector, so the mirrored point lies INSIDE the
+        // sphere (at a third of the radius for an unscaled entity) and its shadow ray is stopped by the sphere itself
+        const Mat3x3& m = se.entity.normal_mat;
+        const Vec3 diag = make_vec3(m.col[0].x, m.col[1].y, m.col[2].z);
+        const Vec3 ln   = vec3_mulf(make_vec3(vec3_dot(norm, m.col[0]), vec3_dot(norm, m.col[1]), vec3_dot(norm, m.col[2])), 1 / vec3_len2(diag));
+        sphere_surface_for_normal(se.entity, se.sphere, ln, point, face_normal);
+    }
+    const Vec3 dir_  = vec3_sub(point, from_surf.point);
+    const float dist = vec3_len(dir_);
+    const Vec3 dir   = vec3_mulf(dir_, safe_div(1, dist));
+    DirectLightSample s;
+    s.pos          = point;
+    s.dir          = dir;
+    s.intensity    = color_mulf(se.radiance, se.area);
+    s.pdf_value    = se.inv_area;
+    s.pdf_is_area  = true;
+    s.pdf_is_delta = false;
+    s.cos          = vec3_dot(dir, face_normal) * (from_surf.is_entering ? -1.0f : 1.0f);
+    s.dist         = dist;
+    return s;
+}
+
 // ---- light/cie.art:1-41: CIE sky radiance functions (direction in the light's Y-up frame)
 struct CieSky {
     int kind;
@@ -2260,6 +2362,9 @@ struct PathTracer {
         case IG_LIGHT_MESH_AREA:
             ls = sample_direct_mesh(sc, light, rnd, surf);
             break;
+        case IG_LIGHT_SPHERE:
+            ls = sample_direct_sphere(sc, light, rnd, surf);
+            break;
         default:
             ls       = sample_direct_env(light, rnd, surf, sc.scene_radius);
             infinite = true;
@@ -2309,6 +2414,9 @@ struct PathTracer {
                     const MeshEmitter me(sc, light);
                     emit  = me.radiance;
                     pdf_s = me.pdf_area(surf.prim_coords) * (hit.distance * hit.distance) / dot; // Pdf::as_solid (driver/pdf.art:19-38)
+                } else if (light.type == IG_LIGHT_SPHERE) {
+                    emit  = Color{ light.d[4], light.d[5], light.d[6] };
+                    pdf_s = safe_div(1, light.d[7]) * (hit.distance * hit.distance) / dot; // make_area_pdf(inv_area).as_solid
                 } else {
                     const PlaneEmitter pe(light);
                     emit  = pe.radiance;            // light.emission(ctx)

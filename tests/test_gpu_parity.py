@@ -875,7 +875,7 @@ def test_mesh_area_lights_vs_oracle(gpu_device):
     for sel in ("uniform", "hierarchy"):
         s["technique"]["light_selector"] = sel
         sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
-        assert sorted(l.type for l in sc.scene.lights[:3]) == [0, 8, 8]
+        assert sorted(l.type for l in sc.scene.lights[:3]) == [0, 8, 9]  # plane sampler, mesh ("optimize": false), sphere (the icosphere is recognised)
         _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=29, iters=2)
 
 
@@ -1001,3 +1001,96 @@ def test_bench_single_rank_through_rccl():
     assert line["collective"]["bytes_per_rank"] == 320 * 180 * 12
     assert line["rays"]["camera"] == 320 * 180 * 8 * 4
     assert 0 < line["roofline"]["frac"] <= 1
+
+
+# ---- analytic spheres (src/artic/shapes/sphere.art, src/runtime/shape/SphereProvider.cpp) and the sphere area emitter
+def _sphere_scene(w, h, emissive=True):
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene(max_depth=5, size=(w, h))
+    s["camera"]["transform"] = [{"lookat": {"origin": [0.4, -2.6, 1.6], "target": [0, 0, 0.35], "up": [0, 0, 1]}}]
+    s["camera"]["fov"] = 55
+    s["bsdfs"] += [{"type": "diffuse", "name": "red", "reflectance": [0.8, 0.2, 0.2]}, {"type": "conductor", "name": "metal", "roughness": 0.2},
+                   {"type": "dielectric", "name": "glass", "int_ior": 1.5}, {"type": "diffuse", "name": "black", "reflectance": [0, 0, 0]}]
+    s["shapes"] += [{"type": "sphere", "name": "unit"}, {"type": "sphere", "name": "small", "center": [0.1, -0.2, 0.05], "radius": 0.25},
+                    {"type": "cube", "name": "box", "width": 0.5, "height": 0.5, "depth": 0.5}]
+    s["entities"] += [
+        {"name": "s0", "shape": "unit", "bsdf": "red", "transform": [{"translate": [-0.9, 0.3, 0.35]}, {"scale": 0.35}]},
+        {"name": "s1", "shape": "unit", "bsdf": "metal", "transform": [{"translate": [0.5, 0.6, 0.3]}, {"scale": [0.45, 0.3, 0.3]}]},  # an ellipsoid
+        {"name": "s2", "shape": "small", "bsdf": "glass", "transform": [{"translate": [0.0, -0.6, 0.3]}, {"rotate": [20, 30, 40]}]},
+        {"name": "b0", "shape": "box", "bsdf": "ground", "transform": [{"translate": [0.9, -0.5, 0.25]}]},
+        {"name": "lamp", "shape": "small", "bsdf": "black", "transform": [{"translate": [-0.2, 0.1, 1.4]}, {"scale": 0.4}]},
+    ]
+    s["lights"] = [{"type": "area", "name": "L", "entity": "lamp", "radiance": [40, 38, 35]}] if emissive else [{"type": "point", "name": "p", "position": [0, 0, 2], "intensity": [5, 5, 5]}]
+    return LoadedScene.from_string(json.dumps(s), "", w, h)
+
+
+def test_analytic_spheres_hits_vs_oracle(gpu_device):
+    """Closest and any hit over the two scene geometries (triangle BVH, then the sphere BVH from its hits): ids, distances and
+    the sphere's (u, v) bit-exact, node / leaf counters equal."""
+    import oracle
+    scene = _sphere_scene(96, 96)
+    assert scene.scene.sphere_leaf_count == 4 and scene.scene.scene_leaf_count == 2
+    gpu_device.assign_scene(scene)
+    rays, _ = oracle.generate_rays(scene, 1, 96, 96, 0, 96 * 96, seed=2)
+    rng = np.random.default_rng(5)
+    n = 1 << 15
+    org = rng.uniform(-1, 1, (n, 3)).astype(np.float32) * np.float32(1.2) + np.array([0, 0, 0.6], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inc = np.concatenate([org, d, np.full((n, 1), 1e-3, np.float32), np.full((n, 1), 3.4e38, np.float32)], axis=1).astype(np.float32)
+    for batch, flags in ((rays, 1), (inc, 4)):
+        gpu_device.reset_stats()
+        got = gpu_device.traverse(batch, flags=flags)
+        st = gpu_device.stats()
+        ref = oracle.trace(scene, batch, flags=flags)
+        _assert_hits_equal(ref, got)
+        assert (ref["ent_id"] >= 2).any() and (ref["ent_id"] == 1).any() or flags == 4  # spheres and the box are hit
+        for k in ("nodes", "tris", "leaves"):
+            assert st[k] == ref["stats"][k], k
+    seg = inc.copy()
+    seg[:, 3:6] = rng.uniform(-1, 1, (n, 3)).astype(np.float32) - org
+    seg[:, 7] = 1 - 1e-3
+    got_any = gpu_device.traverse(seg, flags=8, any_hit=True)
+    ref_any = oracle.trace(scene, seg, flags=8, any_hit=True)
+    np.testing.assert_array_equal(got_any["prim_id"] >= 0, ref_any["prim_id"] >= 0)
+
+
+@pytest.mark.parametrize("emissive", [True, False])
+def test_analytic_spheres_radiance_vs_oracle(gpu_device, emissive):
+    """Sphere surface elements under diffuse / rough conductor / dielectric BSDFs, the sphere area emitter (NEE + emissive-hit
+    MIS) or a point light: radiance and every counter against the oracle."""
+    scene = _sphere_scene(128, 96, emissive)
+    if emissive:
+        assert scene.scene.lights[0].type == 9  # IG_LIGHT_SPHERE
+    _compare_with_oracle(gpu_device, scene, 128, 96, 4, seed=3, iters=2)
+
+
+def test_analytic_spheres_tail_schedules_agree(monkeypatch):
+    """The per-lane tail follows paths through both geometries like the wavefront rounds do."""
+    from ignis_amd import Device
+    scene = _sphere_scene(96, 64)
+    images = []
+    for thr in ("0", "100000000", "2000"):
+        monkeypatch.setenv("IGD_TAIL_THRESHOLD", thr)
+        dev = Device(0, acquire_stats=True)
+        fb, st = _render_gpu(dev, scene, 4, 96, 64, iters=2, seed=7)
+        images.append((fb, {k: st[k] for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves")}))
+        dev.close()
+    for fb, st in images[1:]:
+        np.testing.assert_array_equal(fb, images[0][0])
+        assert st == images[0][1]
+
+
+def test_mesh_sphere_light_uses_the_sphere_emitter(gpu_device):
+    """An icosphere mesh is recognised by TriMesh::getAsSphere (TriMesh.cpp:637-731) and its area light sampled as the analytic
+    sphere (AreaLight.cpp:60-62); with "optimize": false it stays a mesh light."""
+    from ignis_amd.tables import LoadedScene
+    for optimize, kind in ((True, 9), (False, 8)):
+        s = flat_scene(max_depth=3, size=(64, 64))
+        s["shapes"].append({"type": "icosphere", "name": "ico", "radius": 0.2, "subdivisions": 2})
+        s["bsdfs"].append({"type": "diffuse", "name": "black", "reflectance": [0, 0, 0]})
+        s["entities"].append({"name": "lamp", "shape": "ico", "bsdf": "black", "transform": [{"translate": [0.1, 0.2, -0.5]}]})
+        s["lights"] = [{"type": "area", "name": "L", "entity": "lamp", "radiance": [10, 10, 10], "optimize": optimize}]
+        scene = LoadedScene.from_string(json.dumps(s), "", 64, 64)
+        assert scene.scene.lights[0].type == kind
+        _compare_with_oracle(gpu_device, scene, 64, 64, 4, seed=5)

@@ -826,13 +826,24 @@ def test_mesh_area_light_agrees_with_the_plane_sampler():
     np.testing.assert_allclose(imgs[1][8:24, 8:24].mean(), imgs[0][8:24, 8:24].mean(), rtol=0.03)
 
 
-def test_sphere_shaped_area_light_irradiance():
+def _emitter_scene_opt(optimize, shape, radiance):
+    s = _emitter_scene(True, shape, radiance)
+    s["lights"][0]["optimize"] = optimize
+    return s
+
+
+@pytest.mark.parametrize("optimize,kind", [(True, 9), (False, 8)])
+def test_sphere_shaped_area_light_irradiance(optimize, kind):
     """An emissive icosphere of radius r and radiance L seen from distance d is a disc of solid-angle-projected area
-    pi (r / d)^2: a diffuse white plane right below it shows L (r / d)^2 at the foot point."""
+    pi (r / d)^2: a diffuse white plane right below it shows L (r / d)^2 at the foot point. The mesh is recognised as a sphere
+    (TriMesh::getAsSphere) and sampled with make_sphere_area_emitter — or, with "optimize": false, triangle by triangle."""
     r, d, L = 0.1, 0.6, 50.0
     shape = {"type": "icosphere", "radius": r, "subdivisions": 3}
-    sc = LoadedScene.from_string(json.dumps(_emitter_scene(True, shape, (L, L, L))), SCENES, 33, 33)
-    assert sc.scene.lights[0].type == 8
+    sc = LoadedScene.from_string(json.dumps(_emitter_scene_opt(optimize, shape, (L, L, L))), SCENES, 33, 33)
+    assert sc.scene.lights[0].type == kind
+    if kind == 9:
+        np.testing.assert_allclose(list(sc.scene.lights[0].d)[3], r, rtol=1e-5)                     # detected radius
+        np.testing.assert_allclose(list(sc.scene.lights[0].d)[7], 4 * np.pi * r * r, rtol=1e-4)      # compute_ellipsoid_area
     img = np.mean([oracle.render(sc, 64, 33, 33, iteration=i, seed=6)[0] for i in range(4)], axis=0)
     # the camera sits at z = -1 and looks past the lamp at the plane (fov 90, plane at distance 1: film coordinates = plane
     # coordinates). At plane radius rho: E = L pi r^2 cos / D^2 with D = d / cos, so the radiance E / pi = L (r / d)^2 cos^3.
@@ -931,3 +942,39 @@ def test_blend_bsdf_is_the_weighted_mixture():
     # one-sample estimate of the albedo = the same mixture of the parts' albedos
     alb = [oracle.bsdf_sample(sc, i, wo, 60000, seed=4)[2].astype(np.float64).mean(0) for i in (2, 3)]
     np.testing.assert_allclose(w.astype(np.float64).mean(0), 0.7 * alb[0] + 0.3 * alb[1], rtol=0.03)
+
+
+def test_oracle_sphere_intersection_known_answers():
+    """intersect_sphere / sphere_map_uv (src/artic/shapes/sphere.art:1-6,107-137) through the scene traversal: closed forms for a
+    unit sphere at the origin, a scaled + translated one (the ray is transformed, t stays global), hits from inside, misses."""
+    import json
+    import oracle
+    from conftest import flat_scene
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene()
+    s["shapes"] = [{"type": "sphere", "name": "unit"}]
+    s["entities"] = [{"name": "a", "shape": "unit", "bsdf": "ground"},
+                     {"name": "b", "shape": "unit", "bsdf": "ground", "transform": [{"translate": [5, 0, 0]}, {"scale": 0.5}]}]
+    scene = LoadedScene.from_string(json.dumps(s))
+    assert scene.scene.sphere_leaf_count == 2 and scene.scene.scene_leaf_count == 0
+    F = 3.4e38
+    rays = np.array([
+        [0, 0, -3, 0, 0, 1, 0, F],      # front hit at t = 2, point (0, 0, -1)
+        [0, 0, 0, 0, 0, 1, 0, F],       # from inside: exits at t = 1, point (0, 0, 1)
+        [0, 0, -3, 0, 0, 2, 0, F],      # direction of length 2: t = 1
+        [0, 2, -3, 0, 0, 1, 0, F],      # passes by
+        [0, 0, 3, 0, 0, 1, 0, F],       # sphere behind the origin
+        [5, 0, -3, 1e-3, 1e-3, 1, 0, F],  # the scaled, translated one: radius 0.5 around (5, 0, 0) -> t = 2.5 (a ray exactly along an axis
+                                          # away from the origin turns the slab test into inf - inf, in the reference as here)
+        [0, 0, -3, 0, 0, 1, 0, 1.5],    # tmax in front of the sphere
+        [-3, 0, 0, 1, 0, 0, 0, F],      # along +x: the first sphere at t = 2 wins over the second at t = 7.5
+    ], np.float32)
+    h = oracle.trace(scene, rays, flags=1)
+    np.testing.assert_array_equal(h["ent_id"], [0, 0, 0, -1, -1, 1, -1, 0])
+    np.testing.assert_array_equal(h["prim_id"], [0, 0, 0, -1, -1, 0, -1, 0])
+    np.testing.assert_allclose(h["t"][[0, 1, 2, 7]], [2, 1, 1, 2], rtol=1e-6)
+    np.testing.assert_allclose(h["t"][5], 2.5, rtol=1e-4)
+    # sphere_map_uv: v = acos(z) / pi; u = atan2(-x, y) / 2 pi (+1 if negative)
+    np.testing.assert_allclose(h["v"][[0, 1]], [1.0, 0.0], atol=1e-6)
+    np.testing.assert_allclose([h["u"][7], h["v"][7]], [0.25, 0.5], atol=1e-6)  # point (-1, 0, 0): atan2(1, 0) = pi / 2
+    assert oracle.trace(scene, rays, flags=8, any_hit=True)["prim_id"].tolist() == [0, 0, 0, -1, -1, 0, -1, 0]
