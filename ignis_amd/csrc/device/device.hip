@@ -577,6 +577,9 @@ void assignScene(igd_device* d, const igd_scene* s)
         d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
+    d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO;
+    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO)
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
         if (s->lights[i].type != IG_LIGHT_MESH_AREA && s->lights[i].type != IG_LIGHT_SPHERE)
             continue;
@@ -1002,7 +1005,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             TraverseArgs tb{};
             tb.scene = d->dscene;
             tb.rayA = b.sec.rayA, tb.rayB = b.sec.rayB, tb.meta = nullptr;
-            tb.uniform_flags = IG_RAY_FLAG_SHADOW;
+            tb.uniform_flags = d->dscene.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW; // aotracer.art:13
             tb.count         = &qs->q[in_slot ^ 1].secondary; // generated by this round's k_shade
             tb.work_counter  = &qs->work_counter[2];
             tb.index_list    = b.deep_rays;

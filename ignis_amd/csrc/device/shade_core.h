@@ -1880,6 +1880,8 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         // gpu_generate_rays (mapping_gpu.art:655-658): it can only miss, and it is dropped here
         if (in.dir.x == 0 && in.dir.y == 0 && in.dir.z == 0)
             return;
+        if (FULL && tech.type == IG_TECHNIQUE_AO)
+            return; // make_ao_renderer has no on_miss
         // ---- miss: on_miss (technique/pathtracer.art:141-168) over infinite, non-delta lights
         Col sum{ 0, 0, 0 };
         for (uint32_t li = 0; li < sc.infinite_light_count; ++li) {
@@ -1929,6 +1931,20 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const int px     = lpix % fr.width;
     const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
+
+    if (FULL && tech.type == IG_TECHNIQUE_AO) {
+        // make_ao_renderer.on_shadow (technique/aotracer.art:7-19): a cosine-distributed direction around the surface frame
+        // (make_lambertian_bsdf(ctx.surf, white).sample), traced as a "shadow" ray with the bounce visibility flag and no far
+        // end; its colour (kd = white) is splatted where it escapes. Nothing else: no emission, no bounce.
+        float cpdf;
+        const f3 d   = Principled::cosine_hemisphere(rnd, cpdf);
+        out.shadow   = true;
+        out.s_org    = surf.point;
+        out.s_dir    = mul33(surf.local, d);
+        out.s_tmax   = kFltMax;
+        out.s_col    = Col{ 1, 1, 1 };
+        return;
+    }
 
     // ---- on_hit (technique/pathtracer.art:119-139): emission with MIS
     if (mat.light_id >= 0 && surf.entering) {

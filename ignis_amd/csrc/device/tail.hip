@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
                 Traverser<true, STATS, kTailThreads, true> ts;
                 ts.init_counters();
                 ts.attach_deep(deep_col, sc.deep_stride);
-                ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, IG_RAY_FLAG_SHADOW);
+                ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
                 while (!ts.finished)
                     ts.step(sc, s_stack, tid);
                 overflow |= ts.overflow;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
                 if (sc.sphere_node_count) {
                     Traverser<true, STATS, kTailThreads, false, true> tq;
                     tq.init_counters();
-                    tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, IG_RAY_FLAG_SHADOW);
+                    tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
                     tq.set_initial_hit(ts.hit_ent, ts.hit_prim, 0, 0);
                     while (!tq.finished)
                         tq.step(sc, s_stack, tid);

@@ -1309,12 +1309,14 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     auto sc = std::make_unique<Scene>();
 
     // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
-    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM };
+    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH };
     std::string selector;
     if (const JsonValue* t = doc.find("technique")) {
         const std::string type = t->getString("type", "path");
-        if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path')");
+        if (type == "ao")
+            tech.type = IG_TECHNIQUE_AO; // AOTechnique.cpp: no parameters
+        else if (type != "path")
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path' and 'ao')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
         tech.clamp     = t->getNumber("clamp", 0.0f);

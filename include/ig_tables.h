@@ -242,12 +242,20 @@ typedef struct ig_camera {
     float aperture_radius, focal_length; /* PerspectiveCamera.cpp:19-20 */
 } ig_camera;
 
+enum ig_technique_type {
+    IG_TECHNIQUE_PATH = 0, /* make_path_renderer, src/artic/technique/pathtracer.art:40-228 */
+    /* ambient occlusion (make_ao_renderer, src/artic/technique/aotracer.art:1-24, AOTechnique.cpp): at every camera-ray hit one
+     * cosine-distributed ray with the visibility flag of a bounce ray and no far end; white where it escapes. No bounces. */
+    IG_TECHNIQUE_AO = 1,
+};
+
 typedef struct ig_technique {
     int32_t max_depth;      /* src/runtime/technique/PathTechnique.cpp:11 (default 64) */
     int32_t min_depth;      /* default 2 */
     float clamp;            /* 0 = off */
     int32_t nee;            /* default 1 */
     int32_t light_selector; /* enum ig_light_selector */
+    int32_t type;           /* enum ig_technique_type */
 } ig_technique;
 
 /* ---- Scene ------------------------------------------------------------ */

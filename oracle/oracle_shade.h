@@ -2250,8 +2250,11 @@ struct PathTracer {
         , min_path_len(s.technique.min_depth)
         , clamp_value(s.technique.clamp)
         , enable_nee(s.technique.nee != 0)
+        , ambient_occlusion(s.technique.type == IG_TECHNIQUE_AO)
     {
     }
+    // make_ao_renderer (technique/aotracer.art:1-24): only on_shadow does anything
+    bool ambient_occlusion;
 
     Color handle_color(Color c) const { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; }
 
@@ -2315,6 +2318,17 @@ struct PathTracer {
     // on_shadow (pathtracer.art:52-117)
     ShadowRayOut on_shadow(const Ray& ray, const SurfaceElement& surf, Rng& rnd, const PTRayPayload& pt, const Bsdf& bsdf) const
     {
+        if (ambient_occlusion) {
+            // a sample of make_lambertian_bsdf(ctx.surf, white) (bsdf/diffuse.art:2-12): colour = kd, whatever the direction
+            ShadowRayOut ao;
+            const float u       = rnd.next_f32();
+            const float v       = rnd.next_f32();
+            const DirSample smp = sample_cosine_hemisphere(u, v);
+            ao.valid            = true;
+            ao.color            = Color{ 1, 1, 1 };
+            ao.ray              = make_ray(surf.point, mat3x3_mul(surf.local, smp.dir), offset, flt_max, IG_RAY_FLAG_BOUNCE);
+            return ao;
+        }
         ShadowRayOut out;
         out.valid = false;
         if (!enable_nee)
@@ -2404,6 +2418,8 @@ struct PathTracer {
     // on_hit (pathtracer.art:119-139) with make_emissive_material (driver/material.art:22-30)
     bool on_hit(const Ray& ray, const Hit& hit, const SurfaceElement& surf, const PTRayPayload& pt, const ig_material& mat, Color& out) const
     {
+        if (ambient_occlusion)
+            return false;
         if (mat.light_id >= 0 && surf.is_entering) {
             const float dot = -vec3_dot(ray.dir, surf.local.col[2]);
             if (dot > flt_eps) {
@@ -2433,6 +2449,8 @@ struct PathTracer {
     // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
     bool on_miss(const Ray& ray, const PTRayPayload& pt, Color& out) const
     {
+        if (ambient_occlusion)
+            return false;
         int inflights = 0;
         Color color   = Color{ 0, 0, 0 };
         for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
@@ -2473,6 +2491,8 @@ struct PathTracer {
     // on_bounce (pathtracer.art:170-210)
     bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, Ray& new_ray) const
     {
+        if (ambient_occlusion)
+            return false;
         if (pt.depth + 1 > max_path_len)
             return false;
 

@@ -1094,3 +1094,27 @@ def test_mesh_sphere_light_uses_the_sphere_emitter(gpu_device):
         scene = LoadedScene.from_string(json.dumps(s), "", 64, 64)
         assert scene.scene.lights[0].type == kind
         _compare_with_oracle(gpu_device, scene, 64, 64, 4, seed=5)
+
+
+@pytest.mark.parametrize("base", ["diamond", "spheres"])
+def test_ambient_occlusion_vs_oracle(gpu_device, base):
+    """technique "ao" (src/artic/technique/aotracer.art): camera hit -> one cosine-distributed ray with the bounce visibility
+    flag -> white where unoccluded. Both traversal kernels as they are, no bounces."""
+    from ignis_amd.tables import LoadedScene
+    if base == "diamond":
+        d = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+        d["technique"] = {"type": "ao"}
+        scene = LoadedScene.from_string(json.dumps(d), SCENES, 128, 96)
+    else:
+        scene = _sphere_scene(128, 96)
+        d = None
+    if d is None:
+        import ctypes
+        s = flat_scene(max_depth=3, size=(128, 96))
+        s["technique"] = {"type": "ao"}
+        s["shapes"] += [{"type": "sphere", "name": "ball", "radius": 0.4}, {"type": "cube", "name": "box", "width": 0.5, "height": 0.5, "depth": 0.5}]
+        s["entities"] += [{"name": "ball", "shape": "ball", "bsdf": "ground", "transform": [{"translate": [-0.3, 0.1, -0.4]}]},
+                          {"name": "box", "shape": "box", "bsdf": "ground", "transform": [{"translate": [0.5, -0.3, -0.25]}], "bounce_visible": False}]
+        scene = LoadedScene.from_string(json.dumps(s), "", 128, 96)
+    tot = _compare_with_oracle(gpu_device, scene, 128, 96, 4, seed=13, iters=2)
+    assert tot["bounce_rays"] == 0 and tot["shadow_rays"] > 0 and 0 < tot["unoccluded"] < tot["shadow_rays"]

@@ -978,3 +978,31 @@ def test_oracle_sphere_intersection_known_answers():
     np.testing.assert_allclose(h["v"][[0, 1]], [1.0, 0.0], atol=1e-6)
     np.testing.assert_allclose([h["u"][7], h["v"][7]], [0.25, 0.5], atol=1e-6)  # point (-1, 0, 0): atan2(1, 0) = pi / 2
     assert oracle.trace(scene, rays, flags=8, any_hit=True)["prim_id"].tolist() == [0, 0, 0, -1, -1, 0, -1, 0]
+
+
+def test_ambient_occlusion_known_answers():
+    """make_ao_renderer (src/artic/technique/aotracer.art): one cosine-distributed ray per camera hit, white where it escapes.
+    An open plane shows exactly 1 wherever the camera sees it (nothing can block), the floor of a closed box exactly 0, and a
+    plane under a large parallel blocker at height h over a disc of radius R the cosine-weighted escape fraction h^2 / (h^2 + R^2)
+    at the centre."""
+    s = flat_scene(max_depth=8, size=(32, 32))
+    s["technique"] = {"type": "ao"}
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 32, 32)
+    assert sc.scene.technique.type == 1
+    img, st = oracle.render(sc, 8, 32, 32, seed=3)
+    assert st["bounce_rays"] == 0 and st["shadow_rays"] == st["camera_rays"] == st["unoccluded"]
+    np.testing.assert_allclose(img, 1.0, rtol=1e-6)
+
+    s["shapes"].append({"type": "cube", "name": "room", "width": 4, "height": 4, "depth": 4})
+    s["entities"].append({"name": "room", "shape": "room", "bsdf": "ground", "transform": [{"translate": [0, 0, -1.5]}]})
+    closed = LoadedScene.from_string(json.dumps(s), SCENES, 32, 32)
+    img, st = oracle.render(closed, 8, 32, 32, seed=3)
+    assert st["unoccluded"] == 0 and not img.any()
+
+    # blocker: a disc of radius R parallel to the plane, h above its centre (the plane faces -z, the camera sits at z = -1)
+    h, R = 0.5, 0.75
+    s["shapes"][-1] = {"type": "disk", "name": "room", "radius": R, "normal": [0, 0, 1], "sections": 256}
+    s["entities"][-1] = {"name": "room", "shape": "room", "bsdf": "ground", "transform": [{"translate": [0, 0, -h]}], "camera_visible": False}
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 33, 33)
+    img = np.mean([oracle.render(sc, 64, 33, 33, iteration=i, seed=4)[0] for i in range(16)], axis=0)
+    assert img[15:18, 15:18].mean() == pytest.approx(h * h / (h * h + R * R), rel=0.04)  # 9 216 samples: sigma = 1.5 %
