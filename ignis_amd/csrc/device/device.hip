@@ -113,7 +113,7 @@ struct igd_device {
     DevBuf<int32_t> entity_material;
     DevBuf<uint4> entity_ext;
     DevBuf<ig_light> lights;
-    DevBuf<float> light_hierarchy;
+    DevBuf<float> light_hierarchy, light_cdf;
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
     DevBuf<float> cdf_data;
@@ -484,6 +484,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->lights.upload(s->lights, s->light_count);
     d->light_hierarchy.upload(s->light_hierarchy, (size_t)s->light_hierarchy_nodes * 8);
     d->light_codes.upload(s->light_codes, s->light_codes ? n_finite : 0);
+    const bool simple_selector = s->technique.light_selector == IG_SELECTOR_SIMPLE && n_finite > 0;
+    if (simple_selector && (!s->light_cdf || s->light_cdf_count != n_finite))
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: 'simple' light selector without a flux CDF over the finite lights" };
+    d->light_cdf.upload(s->light_cdf, simple_selector ? n_finite : 0);
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
         const uint64_t bytes = (uint64_t)t.width * t.height * (t.channels == 1 ? 1 : 4);
@@ -557,6 +561,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_hierarchy      = d->light_hierarchy.ptr;
     ds.light_codes          = d->light_codes.ptr;
     ds.use_hierarchy        = hierarchy ? 1u : 0u;
+    ds.light_cdf            = simple_selector ? d->light_cdf.ptr : nullptr;
     ds.scene_radius         = s->scene_radius;
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
@@ -578,6 +583,7 @@ void assignScene(igd_device* d, const igd_scene* s)
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO;
+    d->full_bsdfs |= simple_selector;
     if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
@@ -1539,6 +1545,7 @@ int32_t igd_release_all(igd_device* dev)
         dev->lights.release();
         dev->light_hierarchy.release();
         dev->light_codes.release();
+        dev->light_cdf.release();
         dev->textures.release();
         dev->texture_data.release();
         dev->cdf_data.release();

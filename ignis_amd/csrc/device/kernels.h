@@ -31,6 +31,7 @@ struct DevScene {
     const float* light_hierarchy;
     const uint32_t* light_codes;
     uint32_t use_hierarchy;
+    const float* light_cdf; // IG_SELECTOR_SIMPLE: CDF over the finite lights' flux (null otherwise)
     float scene_radius;
     // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
     // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)

@@ -1781,9 +1781,41 @@ IG_DEV float hier_pdf(const DevScene& sc, int finite_id, f3 pos)
 // LightSelector (light/light_selector.art): uniform (:26-46) or hierarchy (:80-110)
 IG_DEV int pick_light_id(Tea& rnd, int num) { return num <= 1 ? 0 : rnd.range(0, num - 1); }
 
+// make_cdf_light_selector (light/light_selector.art:48-78): finite lights by the CDF over their flux
+template <bool FULL>
+IG_DEV int select_light_cdf(const DevScene& sc, Tea& rnd, float& pdf)
+{
+    const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    const Cdf1D cdf{ sc.light_cdf, n_fin };
+    if (n_inf == 0)
+        return cdf.sample_discrete(rnd.f32(), pdf);
+    const float q = rnd.f32();
+    if (q < 0.5f) {
+        const int id = pick_light_id(rnd, n_inf);
+        pdf          = (1 / (float)n_inf) * 0.5f;
+        return id;
+    }
+    float p;
+    const int fid = cdf.sample_discrete(rnd.f32(), p);
+    pdf           = p * (1 - 0.5f);
+    return n_inf + fid;
+}
+template <bool FULL>
+IG_DEV float select_pdf_cdf(const DevScene& sc, int li)
+{
+    const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    const Cdf1D cdf{ sc.light_cdf, n_fin };
+    if (n_inf == 0)
+        return cdf.pdf_discrete(li);
+    return li < n_inf ? (1 / (float)n_inf) * 0.5f : cdf.pdf_discrete(li - n_inf) * (1 - 0.5f);
+}
+
+template <bool FULL>
 IG_DEV int select_light(const DevScene& sc, Tea& rnd, f3 from_pos, float& pdf)
 {
     const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    if (FULL && sc.light_cdf)
+        return select_light_cdf<FULL>(sc, rnd, pdf);
     if (!sc.use_hierarchy) {
         const int num = (int)sc.light_count;
         pdf           = num == 0 ? 1.0f : 1 / (float)num;
@@ -1811,9 +1843,12 @@ IG_DEV int select_light(const DevScene& sc, Tea& rnd, f3 from_pos, float& pdf)
     return n_inf + fid;
 }
 
+template <bool FULL>
 IG_DEV float select_pdf(const DevScene& sc, int li, f3 from_pos)
 {
     const int n_inf = (int)sc.infinite_light_count, n_fin = (int)(sc.light_count - sc.infinite_light_count);
+    if (FULL && sc.light_cdf)
+        return select_pdf_cdf<FULL>(sc, li);
     if (!sc.use_hierarchy)
         return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
     if (n_inf == 0)
@@ -1907,7 +1942,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             } else {
                 continue; // delta lights
             }
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, (int)li, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf<FULL>(sc, (int)li, in.org) * pdf_s) : 1.0f;
             const Col c       = clamp_color(tech, (in.contrib * emit) * mis);
             sum               = Col{ sum.r + c.r, sum.g + c.g, sum.b + c.b };
         }
@@ -1965,7 +2000,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 emit  = pl.radiance;
                 pdf_s = pl.pdf(in.org);
             }
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf<FULL>(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
             out.has_radiance  = true;
             out.radiance      = clamp_color(tech, (in.contrib * emit) * mis);
         }
@@ -1974,7 +2009,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     // ---- on_shadow (technique/pathtracer.art:52-117): next event estimation
     if (nee && !bsdf.all_delta() && sc.light_count != 0 && in.depth + 1 <= tech.max_depth) {
         float sel_pdf;
-        const int lid     = select_light(sc, rnd, surf.point, sel_pdf);
+        const int lid     = select_light<FULL>(sc, rnd, surf.point, sel_pdf);
         const ig_light& L = sc.lights[lid];
         f3 lpos{}, ldir{};
         Col lint{ 0, 0, 0 };

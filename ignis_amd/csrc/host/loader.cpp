@@ -376,6 +376,7 @@ struct Scene {
     std::vector<ig_light> lights;
     std::vector<float> light_hierarchy;
     std::vector<uint32_t> light_codes;
+    std::vector<float> light_cdf;
     std::vector<std::string> entity_names;
     std::vector<std::string> material_names;
     std::vector<ig_texture> textures;
@@ -1863,10 +1864,31 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     // ---- light selector (LoaderLight.cpp:423-460: <= 1 light -> uniform)
     tech.light_selector = IG_SELECTOR_UNIFORM;
     if (sc->lights.size() > 1 && !selector.empty() && selector != "uniform") {
-        if (selector != "hierarchy")
-            fail("Light selector '" + selector + "' is not supported by the HIP backend (only 'uniform' and 'hierarchy')");
+        if (selector == "simple") {
+            // LoaderLight.cpp:440-447,455-478: CDF::computeForArray over computeFlux of the finite lights (CDF.cpp:14-44). Without
+            // finite lights there is nothing to build a CDF from: uniform.
+            if (!finite.empty()) {
+                tech.light_selector = IG_SELECTOR_SIMPLE;
+                std::vector<float>& cdf = sc->light_cdf;
+                cdf.resize(finite.size());
+                for (size_t i = 0; i < finite.size(); ++i)
+                    cdf[i] = (i ? cdf[i - 1] : 0.0f) + std::abs(hier_entries[i].flux); // (a light without direction carries its flux negated)
+                const float sum = cdf.back();
+                if (sum > 1e-5f) {
+                    const float n = 1.0f / sum;
+                    for (float& v : cdf)
+                        v *= n;
+                } else {
+                    const float n = 1.0f / (float)cdf.size();
+                    for (size_t x = 1; x < cdf.size(); ++x)
+                        cdf[x - 1] = (float)x * n;
+                }
+                cdf.back() = 1;
+            }
+        } else if (selector != "hierarchy")
+            fail("Light selector '" + selector + "' is not supported by the HIP backend (only 'uniform', 'simple' and 'hierarchy')");
         // make_hierarchy_light_selector falls back to uniform without finite lights (light_selector.art:81-83)
-        if (!finite.empty()) {
+        else if (!finite.empty()) {
             tech.light_selector = IG_SELECTOR_HIERARCHY;
             buildLightHierarchy(hier_entries, sc->light_hierarchy, sc->light_codes);
         }
@@ -1890,6 +1912,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.sphere_node_count  = (uint32_t)sc->sphere_nodes.size();
     t.sphere_leaves      = sc->sphere_leaves.data();
     t.sphere_leaf_count  = (uint32_t)sc->sphere_leaves.size();
+    t.light_cdf          = sc->light_cdf.data();
+    t.light_cdf_count    = (uint32_t)sc->light_cdf.size();
     t.materials          = sc->materials.data();
     t.material_count     = (uint32_t)sc->materials.size();
     t.entity_per_material = sc->entity_per_material.data();

@@ -79,6 +79,7 @@ class Scene(C.Structure):
         ("cdf_data", C.POINTER(C.c_float)), ("cdf_data_count", C.c_uint64),
         ("sphere_nodes", C.POINTER(Node8)), ("sphere_node_count", C.c_uint32),
         ("sphere_leaves", C.POINTER(EntityLeaf1)), ("sphere_leaf_count", C.c_uint32),
+        ("light_cdf", C.POINTER(C.c_float)), ("light_cdf_count", C.c_uint32),
     ]
 
 

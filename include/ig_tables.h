@@ -211,6 +211,7 @@ enum ig_cie_kind { IG_CIE_UNIFORM = 0, IG_CIE_CLOUDY = 1, IG_CIE_CLEAR = 2, IG_C
 enum ig_light_selector {
     IG_SELECTOR_UNIFORM   = 0, /* src/artic/light/light_selector.art:26-46 */
     IG_SELECTOR_HIERARCHY = 1, /* src/artic/light/light_selector.art:80-110 */
+    IG_SELECTOR_SIMPLE    = 2, /* make_cdf_light_selector (:48-78): finite lights by a CDF over their flux (igd_scene.light_cdf) */
 };
 
 /* ---- Camera / technique ----------------------------------------------- */
@@ -319,6 +320,10 @@ typedef struct igd_scene {
     uint32_t sphere_node_count;
     const ig_entity_leaf1* sphere_leaves;
     uint32_t sphere_leaf_count;
+    /* IG_SELECTOR_SIMPLE: the CDF over the finite lights' flux as CDF::computeForArray writes it (src/runtime/CDF.cpp:14-44,
+     * LoaderLight.cpp:455-478): one float per finite light, without the leading zero, last entry 1 */
+    const float* light_cdf;
+    uint32_t light_cdf_count;
 } igd_scene;
 
 #ifdef __cplusplus

@@ -2268,8 +2268,31 @@ struct PathTracer {
     // LightSelector::sample: make_uniform_light_selector (light_selector.art:26-46) or
     // make_hierarchy_light_selector (:80-110) + make_light_hierarchy (light_hierarchy.art:103-123).
     // Returns the index into sc.lights.
+    bool use_cdf() const { return sc.technique.light_selector == IG_SELECTOR_SIMPLE && n_fin() > 0 && sc.light_cdf != nullptr; }
+    // make_cdf_light_selector (light_selector.art:48-78)
+    int32_t select_light_cdf(Rng& rnd, float& pdf) const
+    {
+        const Cdf1D cdf{ sc.light_cdf, n_fin() };
+        if (n_inf() == 0)
+            return cdf.sample_discrete(rnd.next_f32(), pdf);
+        const float pdf_infinite = 1 / (float)n_inf();
+        const float ratio        = 0.5f;
+        const float q            = rnd.next_f32();
+        if (q < ratio) {
+            const int32_t id = pick_light_id(rnd, n_inf());
+            pdf              = pdf_infinite * ratio;
+            return id;
+        }
+        float p;
+        const int32_t fid = cdf.sample_discrete(rnd.next_f32(), p);
+        pdf               = p * (1 - ratio);
+        return n_inf() + fid;
+    }
+
     int32_t select_light(Rng& rnd, Vec3 from_pos, float& pdf) const
     {
+        if (use_cdf())
+            return select_light_cdf(rnd, pdf);
         if (!use_hierarchy()) {
             const int32_t num = (int32_t)sc.light_count;
             pdf               = num == 0 ? 1.0f : 1 / (float)num;
@@ -2303,6 +2326,12 @@ struct PathTracer {
     // LightSelector::pdf for light index `li` seen from `from_pos`
     float select_pdf(int32_t li, Vec3 from_pos) const
     {
+        if (use_cdf()) {
+            const Cdf1D cdf{ sc.light_cdf, n_fin() };
+            if (n_inf() == 0)
+                return cdf.pdf_discrete(li);
+            return li < n_inf() ? (1 / (float)n_inf()) * 0.5f : cdf.pdf_discrete(li - n_inf()) * (1 - 0.5f);
+        }
         if (!use_hierarchy())
             return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
         const bool infinite = li < n_inf();

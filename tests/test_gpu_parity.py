@@ -281,7 +281,7 @@ def test_many_point_lights_radiance_vs_oracle(gpu_device):
         assert st[k] == tot[k], k
 
 
-@pytest.mark.parametrize("selector", ["uniform", "hierarchy"])
+@pytest.mark.parametrize("selector", ["uniform", "hierarchy", "simple"])
 def test_selectors_and_env_vs_oracle(gpu_device, selector):
     import oracle
     from ignis_amd.tables import LoadedScene

@@ -43,7 +43,7 @@ PINNED = {
     "cycles-sun": (0.015, 8e-3),                          # Cycles: sun (cone) light; the penumbra differs slightly (reference's own eps: 1e-2)
     "emissive-plane": None, "emissive-plane-nopt": None,  # Mitsuba: emissive-hit MIS, plane and mesh-area ("optimize": false) samplers
     "emissive-plane-scale": None, "emissive-plane-scale-nopt": None,
-    "multilight": None, "multilight-uniform": None, "multilight-hierarchy": None,  # Mitsuba: many lights, light selectors
+    "multilight": None, "multilight-uniform": None, "multilight-hierarchy": None, "multilight-simple": None,  # Mitsuba: many lights; uniform / hierarchy / flux-CDF selectors
     "plane-array-diffuse": None,                          # Radiance: sun + sky over diffuse planes
     "plane-d1": None, "plane-d6": None,                   # Mitsuba: environment + plane
     "point": None,                                        # Mitsuba: point light
