@@ -6,8 +6,8 @@
 
 A "step" is one render iteration (Runtime::step, src/runtime/Runtime.cpp:334-387) of the workload
 BASELINE.json's metric is quoted on: scenes/diamond_scene.json, 1920x1080, path integrator,
-spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region. The default K (192
-steps = 1536 spp) keeps the timed region above 3 s; the literal 64-spp configuration (8 steps from an idle device) is
+spi 8 (64 spp = 8 steps). Inputs (scene tables) are resident in HBM before the timed region. The default K (256
+steps = 2048 spp, 8 wavefronts of 32 iterations) keeps the timed region above 3 s; the literal 64-spp configuration (8 steps from an idle device) is
 timed separately and printed as `literal_config`.
 
 N > 1 (one process per GPU): the film is tile-sharded — rank r renders film rows r, r + N, ... of every iteration
@@ -36,14 +36,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
 VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
 PROFILE_TAG = "r02"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
-DEFAULT_STEPS = 192
+DEFAULT_STEPS = 256
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=DEFAULT_STEPS)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal-config", action="store_true", help="skip the separate 8-step (64 spp) timing")
     ap.add_argument("--no-stage-timers", action="store_true", help="experiments only: no HIP-event stage timers in the timed loop (roofline.achieved becomes 0)")
@@ -95,9 +95,9 @@ def main():
 
     W, H, spi = args.width, args.height, args.spi
     scene = LoadedScene.from_file(args.scene, W, H)
-    # streams sized once for a full batch of iterations (2^28 camera rays, ~78 GB): the warm-up then pays for the
+    # streams sized once for a full batch of iterations (2^29 camera rays, ~157 GB of the 288 GB): the warm-up then pays for the
     # allocation (and for the driver's scrubbing of memory a previous process just released), not the timed region
-    CAPACITY = int(os.environ.get("BENCH_CAPACITY", 1 << 28))
+    CAPACITY = int(os.environ.get("BENCH_CAPACITY", 1 << 29))
     dev = Device(local_rank, acquire_stats=0 if args.no_stage_timers else 1, stream_capacity=CAPACITY)
     dev.assign_scene(scene)
     dev.resize(W, H)
@@ -110,7 +110,7 @@ def main():
     shards = args.as_rank_of if args.as_rank_of > 1 else world
     by_rows = args.sharding == "rows"  # N = 1: rows of a single shard = the whole film, same code path
     # One igd_render per iteration, like Runtime::step. The device executes consecutive iterations as one wavefront
-    # (up to 2^28 camera rays, bit-identical to executing them one by one): that is what keeps a
+    # (up to 2^29 camera rays, bit-identical to executing them one by one): that is what keeps a
     # row-sharded rank, which owns 1 / N of every iteration, as efficient as a whole film on one GPU.
     steps_per_rank = max(args.steps, args.warmup)  # iterations sharding: a rank's iterations are consecutive
 
@@ -202,8 +202,9 @@ def main():
         launches = max(1, st["traverse_primary_launches"])
         avg_ms = st["ms_traverse_primary"] / launches
         # units per launch: replay one batch of the same steps with the work counters on (deterministic workload; the per-launch
-        # averages of a run that is a whole number of 16-iteration batches equal those of one batch)
-        replay = 16 if (args.steps % 16 == 0 and args.steps >= 16 and (W, H, spi) == (WIDTH, HEIGHT, SPI) and shards == 1) else args.steps
+        # averages of a run that is a whole number of 32-iteration batches equal those of one batch)
+        replay = 32 if (args.steps % 32 == 0 and args.steps >= 32 and (W, H, spi) == (WIDTH, HEIGHT, SPI) and shards == 1) else args.steps
+        dev.close()  # (its streams would not fit beside a second set at the larger capacities)
         cdev = Device(local_rank, acquire_stats=2, stream_capacity=CAPACITY)
         cdev.assign_scene(scene)
         cdev.resize(W, H)
@@ -299,7 +300,7 @@ def main():
             "cpu_baseline": cpu,
         }
 
-    dev.close()
+    dev.close()  # (idempotent: rank 0 closed it before the counter replay)
     # RCCL writes a version banner to the C stdout buffer of the ranks; every rank pushes its buffer out before rank 0
     # prints, so that the JSON line is the LAST line of the job's stdout
     import ctypes

@@ -167,7 +167,7 @@ struct igd_device {
         igd_render_settings rs{};
         int count = 0;
     } pending;
-    uint64_t batch_rays = (uint64_t)1 << 28; // 16 iterations of 1080p x spi 8: +4 % over 2^27 at 16 steps, +5.5 % at 32 (2^27: +26 % over single iterations)
+    uint64_t batch_rays = (uint64_t)1 << 29; // 32 iterations of 1080p x spi 8 (157 GB of streams): +2.5 % over 2^28 at 192 steps, which was +4 % over 2^27 (2^27: +26 % over single iterations)
     uint64_t chunk_seq     = 0;
     bool async_tail        = true; // IGD_ASYNC_TAIL=0: drain the side stream at the end of every igd_render
 

@@ -45,7 +45,7 @@ typedef struct igd_setup {
     int32_t debug_trace;
     int32_t is_interactive;
     uint64_t stream_capacity; /* rays in flight, allocated as given at the first render; 0 = grow with the largest request up to
-                               * one batch of iterations (2^28 rays); larger requests run in chunks (reference: 1 048 576,
+                               * one batch of iterations (2^29 rays, or what free device memory allows); larger requests run in chunks (reference: 1 048 576,
                                * mapping_gpu.art:1119) */
     int32_t info_aovs;        /* != 0: the "Normals" and "Albedo" AOVs of the info-buffer wrapper the runtime adds for the denoiser
                                * (InfoBufferTechnique.cpp:6-18, technique/internal/infobuffer.art): first hits of the camera rays of
@@ -175,7 +175,7 @@ int32_t igd_set_parameter_f32(igd_device* dev, const char* name, float value);
 int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float value[3]);
 
 /* igd_render validates its arguments and records the request; consecutive iterations of the same film, spi, seed and
- * sharding are executed together as one wavefront of up to 2^28 camera rays (the result is bit-identical to executing each
+ * sharding are executed together as one wavefront of up to 2^29 camera rays (the result is bit-identical to executing each
  * call on its own; IGD_BATCH_RAYS=0 in the environment or igd_setup.is_interactive make every call execute immediately).
  * The long-path tail and the framebuffer resolve of a wavefront run on other HIP streams under the next one (the
  * reference's render() is followed by getFramebufferForHost(), which is where it syncs, Device.cpp:1385-1425). Every

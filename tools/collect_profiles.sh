@@ -17,7 +17,7 @@ cd "$ROOT"
 STEPS=$(python - "$@" <<'EOF'
 import sys
 a = sys.argv[1:]
-print(a[a.index("--steps") + 1] if "--steps" in a else 192)
+print(a[a.index("--steps") + 1] if "--steps" in a else 256)
 EOF
 )
 # 1. the bench line on its own (no profiler attached)
