@@ -135,8 +135,14 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
 constexpr int kShadeThreads = 256;
 constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry per thread
 
+// Waves per SIMD the full variant is built for. Its natural register demand is 252 VGPRs (215 without the principled BSDF, 196
+// without blends, 174 with the lean BSDFs but every light model): 4 waves (128 VGPRs) spill 532 B, 3 waves (168) 300 B, 2 waves
+// (256) nothing. Measured on diamond_scene_principled (32 steps): 149 / 135 / 139 ms of shading at 4 / 3 / 2 waves.
+#ifndef IG_SHADE_OCC_FULL
+#define IG_SHADE_OCC_FULL 3
+#endif
 template <bool FULL>
-__global__ void __launch_bounds__(kShadeThreads, 4) k_shade(const ShadeArgs a)
+__global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : 4) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
