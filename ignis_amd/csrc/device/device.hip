@@ -282,9 +282,8 @@ struct igd_device {
     }
 
     // All-or-nothing: `capacity` names the new size only once every buffer of that size exists. If an allocation fails
-    // (the default batch asks for ~78 GB) everything is released and capacity is 0, so that the next call allocates
-    // again instead of launching on buffers that are not there. Without an explicit igd_setup.stream_capacity the size
-    // is also capped by what hipMemGetInfo reports as free.
+    // (the default batch asks for ~157 GB) everything is released and capacity is 0, so that the next call allocates
+    // again instead of launching on buffers that are not there. The size is also capped by what hipMemGetInfo reports as free.
     void ensureStreams(size_t needed)
     {
         size_t cap = wantedCapacity(needed);
@@ -293,12 +292,13 @@ struct igd_device {
         releaseStreams();
         bool capped = false;
         const size_t bytes_per_ray = (size_t)(2 * kPrimaryCols + kSecondaryCols + 1 + 4 * n_flights) * sizeof(float);
-        if (!setup.stream_capacity) {
+        {
+            // (an explicit igd_setup.stream_capacity is an upper bound too: what does not fit is processed in chunks, render())
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t fit = (size_t)((double)free_b * 0.9 / (double)bytes_per_ray) & ~(size_t)255;
                 if (fit >= 256 && cap > fit) {
-                    cap    = fit; // larger requests are processed in chunks (render())
+                    cap    = fit;
                     capped = true;
                 }
             }
