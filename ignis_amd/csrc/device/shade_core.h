@@ -1151,7 +1151,7 @@ struct BsdfCtx {
             if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
                 return inner(0).all_delta() && inner(1).all_delta();
         }
-        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
+        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (FULL && mat->bsdf_type == IG_BSDF_TRANSPARENT) || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
@@ -1163,6 +1163,8 @@ struct BsdfCtx {
     {
         const f3 N = surf.local.c2;
         switch (mat->bsdf_type) {
+        case IG_BSDF_TRANSPARENT: // make_perfect_refraction_bsdf: kt (bsdf/dielectric.art:9)
+            return Col{ mat->p[0], mat->p[1], mat->p[2] };
         case IG_BSDF_ROUGH_DIELECTRIC:
         case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf / make_rough_dielectric_bsdf (bsdf/dielectric.art:35,190); thin: ks (:60)
             if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN))
@@ -1281,6 +1283,14 @@ struct BsdfCtx {
             }
         }
         if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_TRANSPARENT) { // make_perfect_refraction_bsdf.sample (bsdf/dielectric.art:6-8)
+                in_dir  = -out_dir;
+                pdf_out = 1;
+                color   = Col{ mat->p[0], mat->p[1], mat->p[2] };
+                s_eta   = 1;
+                sdelta  = true;
+                return true;
+            }
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
                 sdelta = false;
                 return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);

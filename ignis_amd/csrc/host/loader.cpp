@@ -1021,6 +1021,11 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
                 m.flags |= IG_MAT_THIN;
             }
         }
+    } else if (type == "transparent" || type == "passthrough") {
+        // TransparentBSDF.cpp:13-22 (tinted), PassthroughBSDF.cpp (white): the ray goes straight on
+        m.bsdf_type = IG_BSDF_TRANSPARENT;
+        const V3 c  = type == "transparent" ? getColor(*bsdf, "color", V3(1, 1, 1), name) : V3(1, 1, 1);
+        m.p[0] = c.x, m.p[1] = c.y, m.p[2] = c.z;
     } else if (type == "conductor" || type == "roughconductor" || type == "mirror") {
         // ConductorBSDF.cpp:13-34 (defaults: material "none" = eta 0, k 1, BSDF.cpp:41), roughness via
         // BSDF::setupRoughness (BSDF.cpp:53-99): VNDF-GGX, compute_explicit(roughness, anisotropic)

@@ -94,6 +94,7 @@ enum ig_bsdf_type {
     IG_BSDF_PRINCIPLED = 3, /* src/artic/bsdf/principled.art:236-481, runtime/bsdf/PrincipledBSDF.cpp:14-98 */
     IG_BSDF_ROUGH_DIELECTRIC = 5, /* src/artic/bsdf/dielectric.art:64-191 (make_dielectric_bsdf with a rough interface) */
     IG_BSDF_PLASTIC    = 4,
+    IG_BSDF_TRANSPARENT = 7, /* make_perfect_refraction_bsdf (src/artic/bsdf/dielectric.art:1-11; runtime/bsdf/TransparentBSDF.cpp "transparent", PassthroughBSDF.cpp "passthrough" = white): p[0..2] colour */
     IG_BSDF_BLEND      = 6, /* make_mix_bsdf (src/artic/bsdf/mix.art:4-68), runtime/bsdf/BlendBSDF.cpp:14-56 ("blend" / "mix") */ /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */
 };
 

@@ -1255,7 +1255,7 @@ struct Bsdf {
     {
         if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
             return inner(0).is_all_delta() && inner(1).is_all_delta();
-        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
+        return mat->bsdf_type == IG_BSDF_DIELECTRIC || mat->bsdf_type == IG_BSDF_TRANSPARENT || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     // the two BSDFs a blend mixes (make_mix_bsdf, bsdf/mix.art:4-68); they see the same surface
     Bsdf inner(int i) const { return Bsdf{ &scene->materials[mat->pad[i]], surf, scene }; }
@@ -1280,6 +1280,8 @@ struct Bsdf {
     Color albedo(Vec3 out_dir) const
     {
         const Vec3 N = surf->local.col[2];
+        if (mat->bsdf_type == IG_BSDF_TRANSPARENT) // make_perfect_refraction_bsdf: kt (dielectric.art:9)
+            return Color{ mat->p[0], mat->p[1], mat->p[2] };
         if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN)) // make_thin_dielectric_bsdf (dielectric.art:60)
             return Color{ mat->p[2], mat->p[3], mat->p[4] };
         if (mat->bsdf_type == IG_BSDF_DIELECTRIC || mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) // dielectric.art:35,190
@@ -1379,6 +1381,14 @@ struct Bsdf {
             if (rnd.next_f32() < 1 - k)
                 return sample_mat(m1, m2, k) || sample_mat(m2, m1, k);
             return sample_mat(m2, m1, 1 - k) || sample_mat(m1, m2, 1 - k);
+        }
+        if (mat->bsdf_type == IG_BSDF_TRANSPARENT) { // make_perfect_refraction_bsdf.sample (dielectric.art:6-8)
+            s.in_dir   = vec3_neg(out_dir);
+            s.pdf      = 1;
+            s.color    = Color{ mat->p[0], mat->p[1], mat->p[2] };
+            s.eta      = 1;
+            s.is_delta = true;
+            return true;
         }
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
             s.is_delta = false;

@@ -1118,3 +1118,24 @@ def test_ambient_occlusion_vs_oracle(gpu_device, base):
         scene = LoadedScene.from_string(json.dumps(s), "", 128, 96)
     tot = _compare_with_oracle(gpu_device, scene, 128, 96, 4, seed=13, iters=2)
     assert tot["bounce_rays"] == 0 and tot["shadow_rays"] > 0 and 0 < tot["unoccluded"] < tot["shadow_rays"]
+
+
+def test_transparent_bsdf_in_blends_vs_oracle(gpu_device):
+    """"transparent" / "passthrough" (make_perfect_refraction_bsdf, src/artic/bsdf/dielectric.art:1-11) on their own and inside
+    blends with a diffuse and with each other (a delta BSDF inside make_mix_bsdf)."""
+    from ignis_amd.tables import LoadedScene
+    s = flat_scene([{"type": "point", "name": "p", "position": [0.2, 0.3, -1.5], "intensity": [4, 4, 4]},
+                    {"type": "env", "name": "e", "radiance": [0.2, 0.25, 0.3]}], max_depth=6, size=(96, 96))
+    s["bsdfs"] += [{"type": "transparent", "name": "tint", "color": [0.2, 0.4, 1.0]}, {"type": "passthrough", "name": "pass"},
+                   {"type": "diffuse", "name": "white", "reflectance": [0.8, 0.8, 0.8]},
+                   {"type": "blend", "name": "half", "first": "white", "second": "tint", "weight": 0.5},
+                   {"type": "blend", "name": "tt", "first": "tint", "second": "pass", "weight": 0.3}]
+    s["shapes"] += [{"type": "rectangle", "name": "pane", "width": 0.8, "height": 0.8}]
+    s["entities"] += [{"name": "a", "shape": "pane", "bsdf": "tint", "transform": [{"translate": [-0.5, -0.5, -0.3]}]},
+                      {"name": "b", "shape": "pane", "bsdf": "half", "transform": [{"translate": [0.5, -0.5, -0.4]}]},
+                      {"name": "c", "shape": "pane", "bsdf": "tt", "transform": [{"translate": [0.5, 0.5, -0.5]}]},
+                      {"name": "d", "shape": "pane", "bsdf": "pass", "transform": [{"translate": [-0.5, 0.5, -0.6]}]}]
+    scene = LoadedScene.from_string(json.dumps(s), "", 96, 96)
+    types = sorted(scene.scene.materials[i].bsdf_type for i in range(scene.scene.material_count))
+    assert types.count(7) >= 2 and types.count(6) == 2
+    _compare_with_oracle(gpu_device, scene, 96, 96, 4, seed=21, iters=2)

@@ -40,6 +40,7 @@ PINNED = {
                                                           # reference's own bound for the two cbox scenes is 5e-3 instead of 1e-3
     "cycles-box": None,                                   # Cycles: area light + diffuse box
     "cycles-mix-diff-diff": None,                         # Cycles: blend of two diffuse BSDFs
+    "cycles-mix-diff-trans": None, "cycles-mix-trans-trans": None,  # Cycles: blends with tinted transparent BSDFs (delta inside a mix)
     "cycles-sun": (0.015, 8e-3),                          # Cycles: sun (cone) light; the penumbra differs slightly (reference's own eps: 1e-2)
     "emissive-plane": None, "emissive-plane-nopt": None,  # Mitsuba: emissive-hit MIS, plane and mesh-area ("optimize": false) samplers
     "emissive-plane-scale": None, "emissive-plane-scale-nopt": None,
