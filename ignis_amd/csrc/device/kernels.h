@@ -137,6 +137,10 @@ struct GenerateArgs {
     int32_t rays_per_iteration;     // local pixels * spi (multi-iteration calls: iteration += id / rays_per_iteration)
     uint32_t n;                     // rays to generate
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
+    // Halton pixel sampler (sampler/pixel_sampler.art:101-150): what setup_halton_pixel_sampler derives from the film
+    // size, filled by launch_generate; the per-pixel offset it keeps in "__halton_offset" is recomputed per sample
+    uint32_t halton_scale_x, halton_scale_y, halton_exp_x, halton_exp_y;
+    int32_t halton_inv_x, halton_inv_y;
 };
 
 struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-11)

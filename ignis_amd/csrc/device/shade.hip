@@ -21,6 +21,63 @@ namespace igdev {
 
 // ---------------------------------------------------------------- k_generate
 
+// permute_element (core/common.art:302-335)
+IG_DEV uint32_t permute_element(uint32_t i, uint32_t l, uint32_t seed)
+{
+    uint32_t w = l - 1;
+    if (w == 0)
+        return 0;
+    w |= w >> 1, w |= w >> 2, w |= w >> 4, w |= w >> 8, w |= w >> 16;
+    do {
+        i ^= seed;
+        i *= 0xe170893du;
+        i ^= seed >> 16;
+        i ^= (i & w) >> 4;
+        i ^= seed >> 8;
+        i *= 0x0929eb3fu;
+        i ^= seed >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1 | seed >> 27;
+        i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + seed) % l;
+}
+
+// radical_inverse (sampler/pixel_sampler.art:37-54)
+IG_DEV float radical_inverse(uint32_t index, uint32_t base)
+{
+    const uint32_t limit = 0xFFFFFFFFu / base - base;
+    const float inv_base = 1.0f / (float)base;
+    float inv_base_n     = 1;
+    uint32_t reversed    = 0;
+    while (index != 0 && reversed < limit) {
+        const uint32_t next = index / base;
+        reversed            = reversed * base + (index - next * base);
+        inv_base_n *= inv_base;
+        index = next;
+    }
+    return igm_min((float)reversed * inv_base_n, 1 - kFltEps);
+}
+
+// inverse_radical_inverse (:56-64)
+IG_DEV uint32_t inverse_radical_inverse(uint32_t inv, uint32_t base, uint32_t digits)
+{
+    uint32_t index = 0;
+    for (uint32_t i = 0; i < digits; ++i) {
+        index = index * base + inv % base;
+        inv /= base;
+    }
+    return index;
+}
+
 __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,10 +110,39 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         tmax  = r[7];
         flags = 0;
     } else {
-        // make_camera_emitter (driver/emitter.art:6-16), uniform pixel sampler (sampler/pixel_sampler.art:4-10),
+        // make_camera_emitter (driver/emitter.art:6-16), the film's pixel sampler (sampler/pixel_sampler.art),
         // make_pixelcoord_from_xy (driver/camera.art:21-29), then Camera::generate_ray of the scene's camera
-        const float rx = rnd.f32();
-        const float ry = rnd.f32();
+        float rx, ry;
+        const uint32_t index = (uint32_t)((a.iteration + it_local) * a.spi + sample); // emitter.art:9
+        if (a.cam.pixel_sampler == IG_PIXEL_SAMPLER_MJITT) {
+            // make_mjitt_pixel_sampler(4, 4) (:13-34)
+            const uint32_t seed = fnv_step(fnv_step(0x811C9DC5u, (uint32_t)x), (uint32_t)y);
+            const float sx      = (float)permute_element(index % 4u, 4u, seed * 0xa511e9b3u);
+            const float sy      = (float)permute_element(index / 4u, 4u, seed * 0x63d83595u);
+            const float jx      = rnd.f32();
+            const float jy      = rnd.f32();
+            rx                  = (sx + (sy + jx) / 4.0f) / 4.0f;
+            ry                  = (sy + (sx + jy) / 4.0f) / 4.0f;
+        } else if (a.cam.pixel_sampler == IG_PIXEL_SAMPLER_HALTON) {
+            // make_halton_pixel_sampler (:152-167) over the offset of setup_halton_pixel_sampler (:127-140); i32 arithmetic
+            // wraps and the remainder is the signed one, as written there. The generator is not advanced.
+            const uint32_t stride = a.halton_scale_x * a.halton_scale_y;
+            int32_t offset        = 0;
+            if (stride > 1) {
+                const uint32_t dx = inverse_radical_inverse((uint32_t)x, 2, a.halton_exp_x);
+                const uint32_t dy = inverse_radical_inverse((uint32_t)y, 3, a.halton_exp_y);
+                const uint32_t s0 = (dx * (stride / a.halton_scale_x)) * (uint32_t)a.halton_inv_x;
+                const uint32_t s1 = (dy * (stride / a.halton_scale_y)) * (uint32_t)a.halton_inv_y;
+                offset            = (int32_t)(s0 + s1) % (int32_t)stride;
+            }
+            const uint32_t hindex = (uint32_t)offset + index * stride;
+            rx                    = radical_inverse(hindex >> a.halton_exp_x, 2);
+            ry                    = radical_inverse(hindex / a.halton_scale_y, 3);
+        } else {
+            // make_uniform_pixel_sampler (:4-10)
+            rx = rnd.f32();
+            ry = rnd.f32();
+        }
         const float nx = 2 * ((float)x + rx) / ((float)a.width) - 1;
         const float ny = 1 - 2 * ((float)y + ry) / ((float)a.height);
         const f3 cdir  = f3{ a.cam.dir[0], a.cam.dir[1], a.cam.dir[2] };
@@ -428,8 +514,36 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveArgs a)
     }
 }
 
-void launch_generate(const GenerateArgs& args, hipStream_t stream)
+// extended_gcd (sampler/pixel_sampler.art:77-85)
+static void extended_gcd(uint32_t a, uint32_t b, int32_t& x, int32_t& y)
 {
+    if (b == 0) {
+        x = 1, y = 0;
+        return;
+    }
+    int32_t xx, yy;
+    extended_gcd(b, a % b, xx, yy);
+    x = yy;
+    y = (int32_t)((uint32_t)xx - (a / b) * (uint32_t)yy);
+}
+
+void launch_generate(const GenerateArgs& in, hipStream_t stream)
+{
+    GenerateArgs args = in;
+    if (args.cam.pixel_sampler == IG_PIXEL_SAMPLER_HALTON) {
+        // compute_halton_base_info + multiplicative_inverse of setup_halton_pixel_sampler (:66-75,87-90,107-111)
+        args.halton_scale_x = 1, args.halton_exp_x = 0;
+        while (args.halton_scale_x < (uint32_t)args.width)
+            args.halton_scale_x *= 2, ++args.halton_exp_x;
+        args.halton_scale_y = 1, args.halton_exp_y = 0;
+        while (args.halton_scale_y < (uint32_t)args.height)
+            args.halton_scale_y *= 3, ++args.halton_exp_y;
+        int32_t x, y;
+        extended_gcd(args.halton_scale_x, args.halton_scale_y, x, y);
+        args.halton_inv_x = x % (int32_t)args.halton_scale_y;
+        extended_gcd(args.halton_scale_y, args.halton_scale_x, x, y);
+        args.halton_inv_y = x % (int32_t)args.halton_scale_x;
+    }
     const unsigned blocks = (args.n + 255u) / 256u;
     hipLaunchKernelGGL(k_generate, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, args);
 }

@@ -1341,9 +1341,6 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             film_w = (float)size->arr[0].num;
             film_h = (float)size->arr[1].num;
         }
-        const std::string sampler = film->getString("sampler", "independent");
-        if (sampler != "independent" && sampler != "uniform")
-            fail("Pixel sampler '" + sampler + "' is not supported by the HIP backend");
     }
     int width  = (opts && opts->film_width > 0) ? opts->film_width : (int)film_w;
     int height = (opts && opts->film_height > 0) ? opts->film_height : (int)film_h;
@@ -1362,6 +1359,13 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     cam.aspect_ratio = -1;
     cam.scale        = 1;
     cam.focal_length = 1;
+    if (const JsonValue* film = doc.find("film")) {
+        // Runtime.cpp:51-53 + RayGenerationShader.cpp:40-48: "halton", "mjitt", everything else is the uniform sampler
+        std::string ps = film->getString("sampler", "independent");
+        for (char& ch : ps)
+            ch = (char)std::tolower((unsigned char)ch);
+        cam.pixel_sampler = ps == "halton" ? IG_PIXEL_SAMPLER_HALTON : (ps == "mjitt" ? IG_PIXEL_SAMPLER_MJITT : IG_PIXEL_SAMPLER_UNIFORM);
+    }
     bool cam_has_transform = false;
     if (const JsonValue* c = doc.find("camera")) {
         // LoaderCamera.cpp:31-36

@@ -45,7 +45,7 @@ class Camera(C.Structure):
                 ("fov_is_vertical", C.c_int32), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("aspect_ratio", C.c_float), ("type", C.c_int32), ("fisheye_mode", C.c_int32),
                 ("fisheye_mask", C.c_int32), ("scale", C.c_float), ("aperture_radius", C.c_float),
-                ("focal_length", C.c_float)]
+                ("focal_length", C.c_float), ("pixel_sampler", C.c_int32)]
 
 
 class Technique(C.Structure):

@@ -229,6 +229,13 @@ enum ig_fisheye_mode { /* FisheyeAspectMode, src/artic/camera/fishlens.art:1-5 *
     IG_FISHEYE_FULL     = 2,
 };
 
+/* Where in its pixel a camera sample lies (RayGenerationShader::generatePixelSampler, src/runtime/shader/RayGenerationShader.cpp:36-50) */
+enum ig_pixel_sampler {
+    IG_PIXEL_SAMPLER_UNIFORM = 0, /* make_uniform_pixel_sampler, src/artic/sampler/pixel_sampler.art:4-10 ("independent" and anything else) */
+    IG_PIXEL_SAMPLER_MJITT   = 1, /* make_mjitt_pixel_sampler(4, 4), :13-34: correlated multi-jittered 4 x 4 */
+    IG_PIXEL_SAMPLER_HALTON  = 2, /* setup_/make_halton_pixel_sampler, :97-167: bases 2 and 3, per-pixel index offset */
+};
+
 typedef struct ig_camera {
     float eye[3];  /* T * 0,             src/runtime/camera/PerspectiveCamera.cpp:69-76 */
     float dir[3];  /* T.linear.col(2) */
@@ -242,6 +249,7 @@ typedef struct ig_camera {
     int32_t fisheye_mask; /* FishLensCamera.cpp:17: samples with r > 1 carry no ray */
     float scale;          /* orthogonal: OrthogonalCamera.cpp:16 (registry "__camera_scale") */
     float aperture_radius, focal_length; /* PerspectiveCamera.cpp:19-20 */
+    int32_t pixel_sampler; /* enum ig_pixel_sampler: "film": {"sampler": ...} (src/runtime/Runtime.cpp:51-53) */
 } ig_camera;
 
 enum ig_technique_type {

@@ -285,7 +285,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                 const int cur = current_size + i;
                 Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, x, y, cfg.seed), 1 };
                 Ray ray;
-                const bool valid = generate_camera_ray(cam, rnd, x, y, W, cfg.height, ray);
+                const bool valid = generate_camera_ray(cam, rnd, cfg.iteration * spi + sample, x, y, W, cfg.height, ray);
                 if (!valid)
                     ray = make_ray(Vec3{ 0, 0, 0 }, Vec3{ 0, 0, 0 }, 0, 0, 0); // make_zero_ray, id -1 (mapping_cpu.art:352-355)
                 write_ray(primary, cur, ray);
@@ -526,7 +526,7 @@ int oracle_generate_rays(const igd_scene* sc, const oracle_settings* cfg, int64_
         const int x = pixel % cfg->width, y = pixel / cfg->width;
         Rng rnd{ create_random_seed(sample, cfg->iteration, cfg->frame, x, y, cfg->seed), 1 };
         Ray r;
-        if (!generate_camera_ray(cam, rnd, x, y, cfg->width, cfg->height, r))
+        if (!generate_camera_ray(cam, rnd, cfg->iteration * cfg->spi + sample, x, y, cfg->width, cfg->height, r))
             r = make_ray(Vec3{ 0, 0, 0 }, Vec3{ 0, 0, 0 }, 0, 0, 0); // no ray for this sample: make_zero_ray
         float* o    = rays + i * 8;
         o[0] = r.org.x, o[1] = r.org.y, o[2] = r.org.z;

@@ -84,7 +84,150 @@ struct CameraSetup {
     int type;
     bool mask;
     float aperture_radius, focal_length;
+    int pixel_sampler;
 };
+
+// ---- sampler/pixel_sampler.art
+// permute_element (core/common.art:302-335): Kensler's hashed permutation of [0, l)
+static inline uint32_t permute_element(uint32_t i, uint32_t l, uint32_t seed)
+{
+    uint32_t w = l - 1;
+    if (w == 0)
+        return 0;
+    w |= w >> 1;
+    w |= w >> 2;
+    w |= w >> 4;
+    w |= w >> 8;
+    w |= w >> 16;
+    do {
+        i ^= seed;
+        i *= 0xe170893du;
+        i ^= seed >> 16;
+        i ^= (i & w) >> 4;
+        i ^= seed >> 8;
+        i *= 0x0929eb3fu;
+        i ^= seed >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1 | seed >> 27;
+        i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + seed) % l;
+}
+
+// radical_inverse (pixel_sampler.art:37-54)
+static inline float radical_inverse(uint32_t index, uint32_t base)
+{
+    const uint32_t limit  = 0xFFFFFFFFu / base - base;
+    const float inv_base  = 1.0f / (float)base;
+    float inv_base_n      = 1;
+    uint32_t reversed     = 0;
+    while (index != 0 && reversed < limit) {
+        const uint32_t next  = index / base;
+        const uint32_t digit = index - next * base;
+        reversed             = reversed * base + digit;
+        inv_base_n *= inv_base;
+        index = next;
+    }
+    return igm_min((float)reversed * inv_base_n, 1 - flt_eps);
+}
+
+// inverse_radical_inverse (:56-64)
+static inline uint32_t inverse_radical_inverse(uint32_t inv, uint32_t base, uint32_t digits)
+{
+    uint32_t index = 0;
+    for (uint32_t i = 0; i < digits; ++i) {
+        const uint32_t digit = inv % base;
+        inv /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+
+// extended_gcd / multiplicative_inverse (:77-90): the remainder is the signed one, as written
+static inline void extended_gcd(uint32_t a, uint32_t b, int32_t& x, int32_t& y)
+{
+    if (b == 0) {
+        x = 1, y = 0;
+        return;
+    }
+    const int32_t d = (int32_t)(a / b);
+    int32_t xx, yy;
+    extended_gcd(b, a % b, xx, yy);
+    x = yy;
+    y = (int32_t)((uint32_t)xx - (uint32_t)d * (uint32_t)yy);
+}
+
+struct HaltonSetup { // :92-99 (bases 2 and 3), without the buffer: halton_offset() recomputes what it holds
+    uint32_t scale_x, scale_y, exp_x, exp_y;
+    int32_t mul_inv_x, mul_inv_y;
+};
+
+static inline HaltonSetup setup_halton(int width, int height)
+{
+    HaltonSetup h;
+    // compute_halton_base_info (:66-75)
+    h.scale_x = 1, h.exp_x = 0;
+    while (h.scale_x < (uint32_t)width)
+        h.scale_x *= 2, ++h.exp_x;
+    h.scale_y = 1, h.exp_y = 0;
+    while (h.scale_y < (uint32_t)height)
+        h.scale_y *= 3, ++h.exp_y;
+    int32_t x, y;
+    extended_gcd(h.scale_x, h.scale_y, x, y);
+    h.mul_inv_x = x % (int32_t)h.scale_y;
+    extended_gcd(h.scale_y, h.scale_x, x, y);
+    h.mul_inv_y = x % (int32_t)h.scale_x;
+    return h;
+}
+
+// the value setup_halton_pixel_sampler stores in "__halton_offset" for pixel (x, y) (:127-140); i32 arithmetic wraps
+static inline int32_t halton_offset(const HaltonSetup& h, int x, int y)
+{
+    const uint32_t stride = h.scale_x * h.scale_y;
+    if (stride <= 1)
+        return 0;
+    const uint32_t dx = inverse_radical_inverse((uint32_t)x, 2, h.exp_x);
+    const uint32_t dy = inverse_radical_inverse((uint32_t)y, 3, h.exp_y);
+    const uint32_t a  = (dx * (stride / h.scale_x)) * (uint32_t)h.mul_inv_x;
+    const uint32_t b  = (dy * (stride / h.scale_y)) * (uint32_t)h.mul_inv_y;
+    return (int32_t)(a + b) % (int32_t)stride;
+}
+
+// PixelSampler (:1): position of sample `index` (= iter * spi + sample, emitter.art:9) inside pixel (x, y)
+static inline void pixel_sample(int sampler, Rng& rnd, int index, int x, int y, int width, int height, float& rx, float& ry)
+{
+    if (sampler == IG_PIXEL_SAMPLER_MJITT) {
+        // make_mjitt_pixel_sampler(4, 4) (:13-34)
+        const uint32_t bin_x = 4, bin_y = 4;
+        const uint32_t seed  = hash_combine(hash_combine(0x811C9DC5u, (uint32_t)x), (uint32_t)y);
+        const uint32_t idx   = (uint32_t)index;
+        const float sx       = (float)permute_element(idx % bin_x, bin_x, seed * 0xa511e9b3u);
+        const float sy       = (float)permute_element(idx / bin_x, bin_y, seed * 0x63d83595u);
+        const float jx       = rnd.next_f32();
+        const float jy       = rnd.next_f32();
+        rx                   = (sx + (sy + jx) / (float)bin_y) / (float)bin_x;
+        ry                   = (sy + (sx + jy) / (float)bin_x) / (float)bin_y;
+    } else if (sampler == IG_PIXEL_SAMPLER_HALTON) {
+        // make_halton_pixel_sampler (:152-167); the generator is not advanced
+        const HaltonSetup h   = setup_halton(width, height);
+        const uint32_t stride = h.scale_x * h.scale_y;
+        const uint32_t hindex = (uint32_t)(halton_offset(h, x, y) + (int32_t)((uint32_t)index * stride));
+        rx                    = radical_inverse(hindex >> h.exp_x, 2);
+        ry                    = radical_inverse(hindex / h.scale_y, 3);
+    } else {
+        // make_uniform_pixel_sampler (:4-10)
+        rx = rnd.next_f32();
+        ry = rnd.next_f32();
+    }
+}
 
 // make_perspective_camera (perspective.art:29-42), make_perspective_dof_camera (:69-84),
 // make_orthogonal_camera (orthogonal.art:14-26), make_fishlens_camera (fishlens.art:8-37).
@@ -107,6 +250,7 @@ static inline CameraSetup make_camera(const ig_camera& c, float sx, float sy)
     s.mask         = c.fisheye_mask != 0;
     s.aperture_radius = c.aperture_radius;
     s.focal_length    = c.focal_length;
+    s.pixel_sampler   = c.pixel_sampler;
     return s;
 }
 
@@ -128,15 +272,15 @@ static inline void square_to_concentric_disk(float px, float py, float& ox, floa
     }
 }
 
-// make_camera_emitter (emitter.art:6-16) + make_uniform_pixel_sampler (pixel_sampler.art:4-10)
+// make_camera_emitter (emitter.art:6-16) + the pixel sampler (pixel_sampler.art)
 // + make_pixelcoord_from_xy (camera.art:21-29) + Camera::generate_ray. Returns false when the camera
 // yields no ray for the sample (masked fishlens, fishlens.art:44): cpu_generate_rays then stores a zero
 // ray with id -1 (mapping_cpu.art:352-355). The reference goes on to miss-shade that entry and splats
 // the result to pixel -1 / spi; the restatement (and the HIP device) drop the sample instead.
-static inline bool generate_camera_ray(const CameraSetup& cam, Rng& rnd, int x, int y, int w, int h, Ray& out)
+static inline bool generate_camera_ray(const CameraSetup& cam, Rng& rnd, int index, int x, int y, int w, int h, Ray& out)
 {
-    const float rx = rnd.next_f32();
-    const float ry = rnd.next_f32();
+    float rx, ry;
+    pixel_sample(cam.pixel_sampler, rnd, index, x, y, w, h, rx, ry);
     const float nx = 2 * ((float)x + rx) / ((float)w) - 1;
     const float ny = 1 - 2 * ((float)y + ry) / ((float)h);
     if (cam.type == IG_CAMERA_ORTHOGONAL) {

@@ -665,6 +665,27 @@ def test_cameras_vs_oracle(gpu_device, camera):
         assert fb[0, 0].sum() == 0 and fb[h - 1, w - 1].sum() == 0 and fb[h // 2, w // 2].sum() > 0
 
 
+@pytest.mark.parametrize("sampler,size", [("mjitt", (96, 64)), ("halton", (96, 64)), ("halton", (2048, 768)), ("MJitt", (33, 17))])
+def test_pixel_samplers_vs_oracle(gpu_device, sampler, size):
+    """"film": {"sampler": ...} (sampler/pixel_sampler.art): multi-jittered 4 x 4 and the Halton sampler as written, over several
+    iterations (the sample index continues, emitter.art:9) and a film wide enough for the i32 products of the offset to wrap."""
+    from ignis_amd.tables import LoadedScene
+    w, h = size
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["film"] = {"size": [w, h], "sampler": sampler}
+    big = w * h > 1 << 20  # scale_x * scale_y^2 > 2^31: the i32 products of the offset wrap; kept cheap for the oracle
+    if big:
+        s["technique"]["max_depth"] = 2
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    assert sc.scene.camera.pixel_sampler == (1 if sampler.lower() == "mjitt" else 2)
+    _compare_with_oracle(gpu_device, sc, w, h, 1 if big else 4, seed=13, iters=1 if big else 3)
+    s["film"]["sampler"] = "independent"
+    plain = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    a, _ = _render_gpu(gpu_device, sc, 4, w, h, seed=13)
+    b, _ = _render_gpu(gpu_device, plain, 4, w, h, seed=13)
+    assert not np.array_equal(a, b)
+
+
 def test_camera_scale_parameter(gpu_device):
     """`__camera_scale` (OrthogonalCamera.cpp:28,39) is read from the registry at every render."""
     from ignis_amd.tables import LoadedScene

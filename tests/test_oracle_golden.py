@@ -376,6 +376,115 @@ def test_orthogonal_camera_rays():
     assert np.all(np.diff(org[:, :, 0].mean(axis=0)) > 0) and np.all(np.diff(org[:, :, 1].mean(axis=1)) < 0)
 
 
+# ---- pixel samplers (src/artic/sampler/pixel_sampler.art; "film": {"sampler": ...}, src/runtime/Runtime.cpp:51-53)
+
+def _pixel_offsets(sampler, w, h, spi, iteration=0, seed=3):
+    """(h, w, spi, 2): where each camera sample lies inside its pixel, recovered from the origins of an orthogonal camera."""
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["camera"] = {"type": "orthogonal", "scale": 1.0, "transform": _CAM_T}
+    s["film"] = {"size": [w, h], "sampler": sampler}
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    rays, ctr = oracle.generate_rays(sc, spi, w, h, 0, w * h * spi, iteration=iteration, seed=seed)
+    org = rays[:, 0:3].astype(np.float64).reshape(h, w, spi, 3)
+    ys, xs = np.mgrid[0:h, 0:w]
+    fx = (org[..., 0] / 1.0 + 1) / 2 * w - xs[..., None]             # nx = 2 (x + rx) / w - 1, right = +x
+    fy = (1 - org[..., 1] / (1.0 / (w / h))) / 2 * h - ys[..., None]  # ny = 1 - 2 (y + ry) / h, sy = scale / aspect
+    return np.stack([fx, fy], -1), ctr.reshape(h, w, spi)
+
+
+def test_uniform_pixel_sampler_is_the_default():
+    a, ca = _pixel_offsets("independent", 16, 12, 4)
+    b, cb = _pixel_offsets("anything-else", 16, 12, 4)
+    np.testing.assert_array_equal(a, b)
+    assert np.all(ca == 3) and a.min() >= -1e-5 and a.max() <= 1 + 1e-5  # two draws from the generator (counter starts at 1)
+
+
+def test_mjitt_pixel_sampler_stratifies_4x4():
+    """make_mjitt_pixel_sampler(4, 4) (pixel_sampler.art:13-34): the 16 samples of one pixel occupy each of the 4 x 4 cells once
+    AND each of the 16 columns / rows of the 16 x 16 sub-grid once (correlated multi-jitter); pixels are permuted independently."""
+    off, ctr = _pixel_offsets("mjitt", 8, 8, 16)
+    assert np.all(ctr == 3)
+    cells = np.floor(off * 4).astype(int).clip(0, 3)
+    code = cells[..., 0] * 4 + cells[..., 1]
+    assert np.all(np.sort(code, axis=-1) == np.arange(16))
+    fine = np.floor(off * 16).astype(int).clip(0, 15)
+    assert np.all(np.sort(fine[..., 0], axis=-1) == np.arange(16)) and np.all(np.sort(fine[..., 1], axis=-1) == np.arange(16))
+    orders = {tuple(c) for c in code.reshape(-1, 16)}
+    assert len(orders) > 32  # per-pixel seed: (x, y) hashed
+    # the second iteration continues the index (iter * spi + sample, emitter.art:9): cell = permute(index / 4) with index / 4 >= 4
+    off2, _ = _pixel_offsets("mjitt", 8, 8, 16, iteration=1)
+    assert off2.min() >= -1e-4 and np.floor(off2[..., 0] * 4 - 1e-4).max() <= 3
+
+
+def _phi(i, base):
+    from fractions import Fraction
+    f, r = Fraction(1), Fraction(0)
+    while i:
+        f /= base
+        r += f * (i % base)
+        i //= base
+    return r
+
+
+def _egcd(a, b):
+    if b == 0:
+        return 1, 0
+    x, y = _egcd(b, a % b)
+    return y, x - (a // b) * y
+
+
+def _srem(a, n):  # the i32 remainder of Artic / C: sign of the dividend
+    return int(np.fmod(a, n))
+
+
+def _digits_reversed(v, base, digits):
+    r = 0
+    for _ in range(digits):
+        r = r * base + v % base
+        v //= base
+    return r
+
+
+def _radical_inverse_f32(index, base):
+    limit = 0xFFFFFFFF // base - base
+    inv, inv_n, rev = np.float32(1) / np.float32(base), np.float32(1), 0
+    while index != 0 and rev < limit:
+        rev = rev * base + index % base
+        inv_n = np.float32(inv_n * inv)
+        index //= base
+    return min(np.float32(np.float32(rev) * inv_n), np.float32(1) - np.float32(1.1920928955e-07))
+
+
+@pytest.mark.parametrize("size", [(8, 9), (16, 12), (5, 7), (64, 48)])
+def test_halton_pixel_sampler_enumerates_the_halton_sequence(size):
+    """setup_/make_halton_pixel_sampler (pixel_sampler.art:101-167), against an independent restatement of the arithmetic AS
+    WRITTEN. The construction is pbrt's (sample k of a pixel = the point of the (2, 3) Halton sequence with index in
+    [k * stride, (k + 1) * stride) that falls into that pixel), but the reference passes the two scales to
+    multiplicative_inverse in the opposite order (:110-111) and takes signed remainders (:87-90, :134-137), so apart from pixel
+    (0, 0) the points are well-defined members of [0, 1)^2 that are not the Halton ones (negative offsets wrap as u32). Restated
+    bug-compatibly; pixel (0, 0) is checked against the true sequence."""
+    w, h = size
+    spi = 3
+    off, ctr = _pixel_offsets("halton", w, h, spi)
+    assert np.all(ctr == 1)  # the generator is not advanced
+    ex, ey = int(np.ceil(np.log2(w))), 0
+    while 3 ** ey < h:
+        ey += 1
+    sx, sy = 1 << ex, 3 ** ey
+    stride = sx * sy
+    inv_x, inv_y = _srem(_egcd(sx, sy)[0], sy), _srem(_egcd(sy, sx)[0], sx)
+    for y in range(h):
+        for x in range(w):
+            offset = _srem(_digits_reversed(x, 2, ex) * sy * inv_x + _digits_reversed(y, 3, ey) * sx * inv_y, stride)
+            for k in range(spi):
+                hindex = (offset + k * stride) & 0xFFFFFFFF
+                want = (_radical_inverse_f32(hindex >> ex, 2), _radical_inverse_f32(hindex // sy, 3))
+                np.testing.assert_allclose(off[y, x, k], want, atol=2e-5, err_msg=f"pixel ({x}, {y}) sample {k}")
+    assert off.min() >= -1e-5 and off.max() < 1 + 1e-5
+    for k in range(spi):
+        np.testing.assert_allclose(off[0, 0, k], (float(_phi(k * stride, 2) * sx), float(_phi(k * stride, 3) * sy)), atol=2e-5)
+
+
 @pytest.mark.parametrize("mode", ["circular", "cropped", "full"])
 def test_fishlens_camera_rays(mode):
     """fishlens.art:39-53 with fov = pi: theta = r * pi / 2 where r is the aspect-scaled film radius."""
