@@ -414,9 +414,9 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t l = 0; l < s->light_count; ++l) {
         const bool inf = l < s->infinite_light_count;
         const int lt = s->lights[l].type;
-        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_SPHERE)
+        if (lt < IG_LIGHT_PLANE || lt > IG_LIGHT_PEREZ)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
-        if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL || lt == IG_LIGHT_ENV_TEXTURED || lt == IG_LIGHT_SUN || lt == IG_LIGHT_CIE))
+        if (inf != (lt == IG_LIGHT_ENV || lt == IG_LIGHT_DIRECTIONAL || lt == IG_LIGHT_ENV_TEXTURED || lt == IG_LIGHT_SUN || lt == IG_LIGHT_CIE || lt == IG_LIGHT_PEREZ))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: infinite lights must come first and be environment, directional or sun lights" };
         if (lt == IG_LIGHT_ENV_TEXTURED) {
             uint32_t v[4];
@@ -594,7 +594,7 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: mesh / sphere area light without a valid entity" };
     }
     for (uint32_t i = 0; i < s->infinite_light_count; ++i)
-        d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN || s->lights[i].type == IG_LIGHT_CIE;
+        d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN || s->lights[i].type == IG_LIGHT_CIE || s->lights[i].type == IG_LIGHT_PEREZ;
     d->has_scene            = true;
 }
 

@@ -1659,6 +1659,15 @@ struct CieSky {
     IG_DEV Col radiance(f3 dir) const
     {
         const float cos_theta = dir.y;
+        if (kind == IG_CIE_PEREZ) {
+            // sky_function of make_perez_light_raw over perez::eval (light/perez.art:235-242,293-298); the explicit parameters
+            // (a, b, c, d, e) travel in ground_brightness, zenith_brightness, c2, scale.r, scale.g
+            const float cos_sun = clampf(dot3(dir, sun_dir), -1, 1);
+            const float sun_a   = igm_acos(cos_sun);
+            const float A       = 1 + ground_brightness * igm_exp(zenith_brightness / igm_max(1e-5f, cos_theta));
+            const float B       = 1 + c2 * igm_exp(scale.r * sun_a) + scale.g * cos_sun * cos_sun;
+            return wmean(cos_theta, zenith * (A * B), ground);
+        }
         if (!has_ground && cos_theta < 0)
             return Col{ 0, 0, 0 };
         if (kind == IG_CIE_UNIFORM || kind == IG_CIE_CLOUDY) {
@@ -1949,6 +1958,13 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 const bool hit = dot3(f3{ L.d[0], L.d[1], L.d[2] }, in.dir) >= L.d[3];
                 emit           = hit ? Col{ L.d[4], L.d[5], L.d[6] } : Col{ 0, 0, 0 };
                 pdf_s          = hit ? safe_div(1, 2 * kPi * (1 - L.d[3])) : 0.0f;
+            } else if (FULL && L.type == IG_LIGHT_PEREZ) {
+                // make_perez_light_raw with a sun (light/perez.art:301-317): the sun's emission plus the sky function, the sun's pdf
+                const CieSky sky(L);
+                const bool hit = dot3(f3{ L.d[27], L.d[28], L.d[29] }, in.dir) >= L.d[14];
+                const f3 d     = f3{ dot3(sky.transform.c0, in.dir), dot3(sky.transform.c1, in.dir), dot3(sky.transform.c2, in.dir) };
+                emit           = (hit ? Col{ L.d[24], L.d[25], L.d[26] } : Col{ 0, 0, 0 }) + sky.radiance(d);
+                pdf_s          = hit ? safe_div(1, 2 * kPi * (1 - L.d[14])) : 0.0f;
             } else {
                 continue; // delta lights
             }
@@ -2143,10 +2159,12 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             lcos     = 1.0f;
             ldist    = sc.scene_radius;
             infinite = true;
-        } else if (FULL && L.type == IG_LIGHT_SUN) {
-            // make_sun_light.sample_direct (light/sun.art:21-25), sample_uniform_cone (core/sampling.art:109-116)
-            const f3 sun_dir    = f3{ L.d[0], L.d[1], L.d[2] };
-            const float cos_a   = L.d[3];
+        } else if (FULL && (L.type == IG_LIGHT_SUN || L.type == IG_LIGHT_PEREZ)) {
+            // make_sun_light.sample_direct (light/sun.art:21-25), sample_uniform_cone (core/sampling.art:109-116); the sun of a
+            // Perez sky keeps its terms further back in the record
+            const bool perez    = L.type == IG_LIGHT_PEREZ;
+            const f3 sun_dir    = perez ? f3{ L.d[27], L.d[28], L.d[29] } : f3{ L.d[0], L.d[1], L.d[2] };
+            const float cos_a   = perez ? L.d[14] : L.d[3];
             const float ux      = rnd.f32();
             const float uy      = rnd.f32();
             const float c1      = 1 - cos_a;
@@ -2157,8 +2175,14 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             const f3 ndir       = mul33(orthonormal_basis(-sun_dir), f3{ p.x * k, p.y * k, z });
             const float inv_pdf = 2 * kPi * (1 - cos_a);
             ldir                = -ndir;
-            lint                = Col{ L.d[4], L.d[5], L.d[6] } * inv_pdf;
+            lint                = (perez ? Col{ L.d[24], L.d[25], L.d[26] } : Col{ L.d[4], L.d[5], L.d[6] }) * inv_pdf;
             pdf_value           = safe_div(1, 2 * kPi * (1 - cos_a)); // uniform_cone_pdf
+            if (perez) {
+                // make_perez_light_raw.sample_direct (light/perez.art:304-308): plus the sky seen in the sampled direction
+                const CieSky sky(L);
+                const f3 d = f3{ dot3(sky.transform.c0, ldir), dot3(sky.transform.c1, ldir), dot3(sky.transform.c2, ldir) };
+                lint       = lint + sky.radiance(d) * (1 / pdf_value);
+            }
             lcos                = z;
             ldist               = __builtin_inff();
             infinite            = true;

@@ -843,6 +843,139 @@ static SunAngles getSunAngles(const JsonValue& l)
                                l.getNumber("timezone", -2.0f));
 }
 
+// ---- Perez all-weather sky (src/artic/light/perez.art): the part the reference evaluates once per light — the model from
+// (brightness, clearness) or irradiances, the explicit parameters (a, b, c, d, e), the normalisation against the integral over
+// Radiance's 145 sky patches and the ground / sun radiances of make_perez_light_from_model. Coefficients: R. Perez, R. Seals,
+// J. Michalsky, "All-weather model for sky luminance distribution", Solar Energy 50(3), 1993 (the tables of gendaylit).
+namespace perez {
+constexpr float SolarE = 1367, SolarL = 127500, PreciWater = 2;
+constexpr int Bins     = 8;
+const float Ranges[9]  = { 1.000f, 1.065f, 1.230f, 1.500f, 1.950f, 2.800f, 4.500f, 6.200f, 12.01f };
+const float PA[32] = { 1.3525f, -0.2576f, -0.2690f, -1.4366f, -1.2219f, -0.7730f, 1.4148f, 1.1016f, -1.1000f, -0.2515f, 0.8952f, 0.0156f,
+                       -0.5484f, -0.6654f, -0.2672f, 0.7117f, -0.6000f, -0.3566f, -2.5000f, 2.3250f, -1.0156f, -0.3670f, 1.0078f, 1.4051f,
+                       -1.0000f, 0.0211f, 0.5025f, -0.5119f, -1.0500f, 0.0289f, 0.4260f, 0.3590f };
+const float PB[32] = { -0.7670f, 0.0007f, 1.2734f, -0.1233f, -0.2054f, 0.0367f, -3.9128f, 0.9156f, 0.2782f, -0.1812f, -4.5000f, 1.1766f,
+                       0.7234f, -0.6219f, -5.6812f, 2.6297f, 0.2937f, 0.0496f, -5.6812f, 1.8415f, 0.2875f, -0.5328f, -3.8500f, 3.3750f,
+                       -0.3000f, 0.1922f, 0.7023f, -1.6317f, -0.3250f, 0.1156f, 0.7781f, 0.0025f };
+const float PC[32] = { 2.8000f, 0.6004f, 1.2375f, 1.0000f, 6.9750f, 0.1774f, 6.4477f, -0.1239f, 24.7219f, -13.0812f, -37.7000f, 34.8438f,
+                       33.3389f, -18.3000f, -62.2500f, 52.0781f, 21.0000f, -4.7656f, -21.5906f, 7.2492f, 14.0000f, -0.9999f, -7.1406f, 7.5469f,
+                       19.0000f, -5.0000f, 1.2438f, -1.9094f, 31.0625f, -14.5000f, -46.1148f, 55.3750f };
+const float PD[32] = { 1.8734f, 0.6297f, 0.9738f, 0.2809f, -1.5798f, -0.5081f, -1.7812f, 0.1080f, -5.0000f, 1.5218f, 3.9229f, -2.6204f,
+                       -3.5000f, 0.0016f, 1.1477f, 0.1062f, -3.5000f, -0.1554f, 1.4062f, 0.3988f, -3.4000f, -0.1078f, -1.0750f, 1.5702f,
+                       -4.0000f, 0.0250f, 0.3844f, 0.2656f, -7.2312f, 0.4050f, 13.3500f, 0.6234f };
+const float PE[32] = { 0.0356f, -0.1246f, -0.5718f, 0.9938f, 0.2624f, 0.0672f, -0.2190f, -0.4285f, -0.0156f, 0.1597f, 0.4199f, -0.5562f,
+                       0.4659f, -0.3296f, -0.0876f, -0.0329f, 0.0032f, 0.0766f, -0.0656f, -0.1294f, -0.0672f, 0.4016f, 0.3017f, -0.4844f,
+                       1.0468f, -0.3788f, -2.4517f, 1.4656f, 1.5000f, -0.6426f, 1.8564f, 0.5636f };
+const float DiffuseEff[4][8] = { { 97.24f, 107.22f, 104.97f, 102.39f, 100.71f, 106.42f, 141.88f, 152.23f },
+                                 { -0.46f, 1.15f, 2.96f, 5.59f, 5.94f, 3.83f, 1.90f, 0.35f },
+                                 { 12.00f, 0.59f, -5.53f, -13.95f, -22.75f, -36.15f, -53.24f, -45.27f },
+                                 { -8.91f, -3.95f, -8.77f, -13.90f, -23.74f, -28.83f, -14.03f, -7.98f } };
+const float DirectEff[4][8]  = { { 57.20f, 98.99f, 109.83f, 110.34f, 106.36f, 107.19f, 105.75f, 101.18f },
+                                 { -4.55f, -3.46f, -4.90f, -5.84f, -3.97f, -1.25f, 0.77f, 1.58f },
+                                 { -2.98f, -1.21f, -1.71f, -1.99f, -1.75f, -1.51f, -1.26f, -1.10f },
+                                 { 117.12f, 12.38f, -8.81f, -4.56f, -6.16f, -26.73f, -34.44f, -8.29f } };
+
+struct Model {
+    float brightness, clearness, direct_irrad, diffuse_irrad, direct_illum, diffuse_illum;
+    float params[5];
+};
+
+static float clampf(float v, float lo, float hi) { return std::min(std::max(v, lo), hi); }
+static float eccentricity(float day)
+{
+    const float a = 2 * Pi * clampf(day / 365, 0.0f, 1.0f); // perez.art:168-171
+    return 1.00011f + 0.034221f * std::cos(a) + 0.00128f * std::sin(a) + 0.000719f * std::cos(2 * a) + 0.000077f * std::sin(2 * a);
+}
+static float airMass(float zenith) { return 1 / (std::cos(zenith) + 0.15f * std::exp(std::log(93.885f - zenith / Deg2Rad) * -1.253f)); } // :173
+static int category(float clearness)                                                                                                     // :175-182
+{
+    for (int bin = 0; bin < Bins; ++bin)
+        if (clearness >= Ranges[bin] && clearness < Ranges[bin + 1])
+            return bin;
+    return Bins - 1;
+}
+static void explicitParameters(float brightness, float clearness, float zenith, float out[5]) // :198-233
+{
+    if (clearness > 1.065f && clearness < 2.8f && brightness < 0.2f)
+        brightness = 0.2f;
+    auto std4 = [&](const float* p) { return p[0] + p[1] * zenith + brightness * (p[2] + p[3] * zenith); };
+    const int bin = category(clearness);
+    out[0] = std4(&PA[bin * 4]);
+    out[1] = std4(&PB[bin * 4]);
+    out[4] = std4(&PE[bin * 4]);
+    if (bin == 0) {
+        out[2] = std::exp(std::pow(brightness * (PC[0] + PC[1] * zenith), PC[2])) - PC[3];
+        out[3] = -std::exp(brightness * (PD[0] + PD[1] * zenith)) + PD[2] + brightness * PD[3];
+    } else {
+        out[2] = std4(&PC[bin * 4]);
+        out[3] = std4(&PD[bin * 4]);
+    }
+}
+static Model finish(float brightness, float clearness, float direct_irrad, float diffuse_irrad, float zenith)
+{
+    Model m{ brightness, clearness, direct_irrad, diffuse_irrad, 0, 0, {} };
+    const int bin = category(clearness);
+    // compute_direct_efficacy / compute_diffuse_efficacy (:184-196)
+    m.direct_illum  = direct_irrad * std::max(0.0f, DirectEff[0][bin] + DirectEff[1][bin] * PreciWater + DirectEff[2][bin] * std::exp(5.73f * zenith - 5) + DirectEff[3][bin] * brightness);
+    m.diffuse_illum = diffuse_irrad * (DiffuseEff[0][bin] + DiffuseEff[1][bin] * PreciWater + DiffuseEff[2][bin] * std::cos(zenith) + DiffuseEff[3][bin] * std::log(brightness));
+    explicitParameters(brightness, clearness, zenith, m.params);
+    return m;
+}
+// make_model_from_brightness_clearness (gendaylit -P, :94-111)
+static Model fromBrightnessClearness(float brightness, float clearness, float zenith, float day)
+{
+    brightness            = clampf(brightness, 0.01f, 0.6f);
+    clearness             = clampf(clearness, 1.0f, 12.0f - 0.001f);
+    const float diffuse0  = brightness * SolarE * eccentricity(day) / airMass(zenith);
+    const float c         = 1.041f * zenith * zenith * zenith;
+    const float direct    = clampf((clearness * (1 + c) - c) * diffuse0 - diffuse0, 0.0f, SolarE);
+    return finish(brightness, clearness, direct, std::max(diffuse0, 0.0f), zenith);
+}
+// make_model_from_irradiance (gendaylit -W, :113-130); the two check_ functions are applied crosswise, as written there
+static Model fromIrradiance(float diffuse_irrad, float direct_irrad, float zenith, float day)
+{
+    diffuse_irrad          = clampf(diffuse_irrad, 0.0f, SolarE);
+    direct_irrad           = std::max(direct_irrad, 0.0f);
+    const float brightness = clampf(diffuse_irrad * airMass(zenith) / (SolarE * eccentricity(day)), 0.01f, 0.6f);
+    const float c          = 1.041f * zenith * zenith * zenith;
+    const float clearness  = clampf(((diffuse_irrad + direct_irrad) / diffuse_irrad + c) / (1 + c), 1.0f, 12.0f - 0.001f);
+    return finish(brightness, clearness, direct_irrad, diffuse_irrad, zenith);
+}
+// perez::eval (:235-242)
+static float eval(float cos_sun, float cos_theta, const float p[5])
+{
+    const float sun_a = std::acos(cos_sun);
+    const float A     = 1 + p[0] * std::exp(p[1] / std::max(1e-5f, cos_theta));
+    const float B     = 1 + p[2] * std::exp(p[3] * sun_a) + p[4] * cos_sun * cos_sun;
+    return A * B;
+}
+// perez::integrate (:267-290) over the Tregenza patch centres (:244-265): 30, 30, 24, 24, 18, 12, 6 patches on rings
+// 12 degrees apart, then the zenith patch
+static float integrate(float zenith, const float p[5])
+{
+    const float cs = std::cos(zenith), sn = std::sin(zenith);
+    const int ring_count[8] = { 30, 30, 24, 24, 18, 12, 6, 1 };
+    float sum               = 0;
+    for (int r = 0; r < 8; ++r) {
+        const float theta = Deg2Rad * (float)(84 - 12 * r);
+        const float ct = std::cos(theta), st = std::sin(theta);
+        for (int k = 0; k < ring_count[r]; ++k) {
+            const float phi     = Deg2Rad * (float)(k * (360 / ring_count[r]));
+            const float cos_sun = std::min(1.0f, cs * ct + sn * st * std::cos(phi));
+            sum += eval(cos_sun, ct, p) * ct;
+        }
+    }
+    return 2 * Pi * sum / 145;
+}
+static int dayOfTheYear(int year, int month, int day) // TimePoint::dayOfTheYear (skysun/SunLocation.cpp:7-18): tm_yday, 0-based
+{
+    static const int before[12] = { 0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334 };
+    const bool leap             = (year % 4 == 0 && year % 100 != 0) || year % 400 == 0;
+    const int m                 = std::min(std::max(month, 1), 12);
+    return before[m - 1] + (leap && m > 2 ? 1 : 0) + day - 1;
+}
+} // namespace perez
+
 // ---- environment maps: texture baking and the sampling tables
 // One lookup of a packed bitmap texture the way the device does it (src/artic/texture/image.art:9-156 with the identity
 // transform): used to bake the radiance of an environment light (src/artic/entrypoints/bake.art:1-26).
@@ -1827,6 +1960,99 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             for (int c = 0; c < 3; ++c)
                 for (int r = 0; r < 3; ++r)
                     out.d[15 + c * 3 + r] = T.m[r][c];
+            infinite.push_back(out);
+        } else if (type == "perez") {
+            // PerezLight.cpp:10-136 + make_perez_light_from_model / make_perez_light_raw (light/perez.art:292-388)
+            const bool has_ground = l.getBool("has_ground", true);
+            const bool has_sun    = l.getBool("has_sun", true);
+            std::string mode      = l.getString("output", "visibleradiance");
+            for (char& ch : mode)
+                ch = (char)std::tolower((unsigned char)ch);
+            const int output = mode == "visibleradiance" ? 0 : (mode == "solarradiance" ? 1 : 2);
+            const V3 ground  = getColor(l, "ground", V3(0.2f, 0.2f, 0.2f), lname);
+            const V3 tint    = getColor(l, "color", V3(1, 1, 1), lname);
+            V3 sun_dir       = getSunAngles(l).direction(); // "Scene to Light (Local)"
+            {
+                const float dl = std::sqrt(dot(sun_dir, sun_dir));
+                sun_dir        = dl > 0 ? sun_dir * (1 / dl) : V3(0, 0, 1);
+            }
+            const float day = l.has("day_of_the_year") ? getConstNumber(l, "day_of_the_year", 0.0f, lname)
+                                                       : (float)perez::dayOfTheYear(l.getInt("year", 2020), l.getInt("month", 5), l.getInt("day", 6));
+            const float sin_altitude   = std::min(std::max(sun_dir.y, -1.0f), 1.0f);
+            const float solar_altitude = std::asin(sin_altitude);
+            const float solar_zenith   = Pi / 2 - solar_altitude;
+            perez::Model model;
+            if (l.has("direct_irradiance") || l.has("diffuse_irradiance")) {
+                const float diffuse = getConstNumber(l, "diffuse_irradiance", 1.0f, lname);
+                if (l.has("direct_horizontal_irradiance") && !l.has("direct_irradiance"))
+                    model = perez::fromIrradiance(diffuse, getConstNumber(l, "direct_horizontal_irradiance", 1.0f, lname) / std::cos(solar_zenith), solar_zenith, day);
+                else
+                    model = perez::fromIrradiance(diffuse, getConstNumber(l, "direct_irradiance", 1.0f, lname), solar_zenith, day);
+            } else {
+                model = perez::fromBrightnessClearness(getConstNumber(l, "brightness", 0.2f, lname), getConstNumber(l, "clearness", 1.0f, lname), solar_zenith, day);
+            }
+            const float WhiteEfficiency = 179; // color_builtins::white_efficiency (core/color.art:78)
+            auto safeDiv                = [](float a, float b) { return std::fabs(b) <= 1.1920928955e-07f ? 0.0f : a / b; }; // safe_div, core/common.art:263
+            const float integrand       = perez::integrate(solar_zenith, model.params);
+            const float diffnorm        = safeDiv(output == 0 ? model.diffuse_illum / WhiteEfficiency : (output == 1 ? model.diffuse_irrad : model.diffuse_illum), integrand);
+            const float half_angle      = Deg2Rad * (0.533f / 2); // flt_sun_radius_deg
+            const float sun_factor      = 2 * Pi * (1 - std::cos(half_angle));
+            const V3 sun_color          = tint * (output == 0 ? model.direct_illum / WhiteEfficiency : (output == 1 ? model.direct_irrad : model.direct_illum));
+            const V3 sky_color          = tint * diffnorm;
+            const V3 zenith             = sky_color * perez::eval(sin_altitude, 1, model.params);
+            float normfactor;
+            if (model.clearness == 1) {
+                normfactor = 0.777778f;
+            } else if (model.clearness < 6) {
+                const float f2 = (2.739f + 0.9891f * std::sin(0.3119f + 2.6f * solar_altitude)) * std::exp(-solar_zenith * (0.4441f + 1.48f * solar_altitude));
+                const float x  = solar_altitude / (Pi / 4) - 1;
+                const float nc = (((0.60227f * x + 1.0660f) * x - 1.3081f) * x - 2.7152f) * x + 3.5556f;
+                normfactor     = safeDiv(nc, f2) / Pi;
+            } else {
+                const float f2 = 0.274f * (0.91f + 10 * std::exp(-3 * solar_zenith) + 0.45f * sin_altitude * sin_altitude);
+                const float x  = solar_altitude / (Pi / 4) - 1;
+                const float nc = (((0.059229f * x + 0.009237f) * x - 0.369832f) * x + 0.547665f) * x + 2.766521f;
+                normfactor     = safeDiv(nc, f2) / Pi;
+            }
+            const bool sun_on      = has_sun && model.clearness > 1;
+            const V3 sun_part      = sun_on ? sun_color * (std::fabs(sin_altitude) / Pi) : V3(0, 0, 0);
+            const V3 sum           = sun_part + zenith * normfactor;
+            const V3 actual_ground = V3(ground.x * sum.x, ground.y * sum.y, ground.z * sum.z);
+            const V3 actual_sun    = sun_on ? sun_color * (1 / sun_factor) : V3(0, 0, 0);
+            // "_transform" (PerezLight.cpp:48-51) or make_cie_sky_transform(up) = make_orthonormal_mat3x3_y (core/matrix.art:34-42)
+            M3 T;
+            if (l.has("transform")) {
+                T = inverse(transpose(getTransform(l).L));
+            } else {
+                V3 n = l.has("up") ? getVector3(*l.find("up"), "up") : V3(0, 1, 0);
+                n    = n * (1 / std::sqrt(dot(n, n)));
+                const float sign = std::copysign(1.0f, n.y);
+                const float a    = -1 / (sign + n.y);
+                const float b    = n.x * n.z * a;
+                const V3 t(1 + sign * n.x * n.x * a, -sign * n.x, sign * b);
+                const V3 bt(b, -n.z, sign + n.z * n.z * a);
+                const V3 cols[3] = { t, n, bt };
+                for (int c = 0; c < 3; ++c)
+                    T.m[0][c] = cols[c].x, T.m[1][c] = cols[c].y, T.m[2][c] = cols[c].z;
+            }
+            // the record of a function environment (IG_LIGHT_CIE, kind IG_CIE_PEREZ); with a sun the same plus the sun terms
+            out.type   = has_sun ? IG_LIGHT_PEREZ : IG_LIGHT_CIE;
+            out.pad[0] = IG_CIE_PEREZ;
+            out.pad[1] = has_ground ? 1 : 0;
+            out.d[0] = sky_color.x, out.d[1] = sky_color.y, out.d[2] = sky_color.z;
+            out.d[3] = actual_ground.x, out.d[4] = actual_ground.y, out.d[5] = actual_ground.z;
+            out.d[6] = model.params[0], out.d[7] = model.params[1], out.d[8] = model.params[2];
+            out.d[9] = sun_dir.x, out.d[10] = sun_dir.y, out.d[11] = sun_dir.z;
+            out.d[12] = model.params[3], out.d[13] = model.params[4];
+            out.d[14] = std::cos(half_angle);
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r)
+                    out.d[15 + c * 3 + r] = T.m[r][c];
+            if (has_sun) {
+                const V3 g = T * sun_dir; // mat3x3_mul(transform, l_sun_dir): the sun model works in scene space
+                out.d[24] = actual_sun.x, out.d[25] = actual_sun.y, out.d[26] = actual_sun.z;
+                out.d[27] = g.x, out.d[28] = g.y, out.d[29] = g.z;
+            }
             infinite.push_back(out);
         } else if (type == "sun") {
             // SunLight.cpp:11-57, light/sun.art:1-48: an infinite cone light; direction = from the scene towards the sun

@@ -37,7 +37,7 @@ class Material(C.Structure):
 
 
 class Light(C.Structure):
-    _fields_ = [("type", C.c_int32), ("entity_id", C.c_int32), ("pad", C.c_int32 * 2), ("d", C.c_float * 24)]
+    _fields_ = [("type", C.c_int32), ("entity_id", C.c_int32), ("pad", C.c_int32 * 2), ("d", C.c_float * 32)]
 
 
 class Camera(C.Structure):
@@ -84,7 +84,7 @@ class Scene(C.Structure):
 
 
 assert C.sizeof(Node8) == 256 and C.sizeof(Tri4) == 208 and C.sizeof(EntityLeaf1) == 96
-assert C.sizeof(Material) == 144 and C.sizeof(Light) == 112
+assert C.sizeof(Material) == 144 and C.sizeof(Light) == 144
 
 
 class HostOptions(C.Structure):

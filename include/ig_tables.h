@@ -189,6 +189,10 @@ enum ig_light_type {
      * d[0..2] centre in shape space, d[3] radius, d[4..6] radiance, d[7] area of the ellipsoid the entity transform makes of
      * it (compute_ellipsoid_area, src/artic/shapes/sphere.art:21-28, evaluated by the loader). Finite, not delta. */
     IG_LIGHT_SPHERE = 9,
+    /* the Perez sky WITH its sun (make_perez_light_raw, src/artic/light/perez.art:301-317: make_sun_light whose samples and
+     * emission also carry the sky function): the IG_CIE_PEREZ record above, plus d[14] cos of the sun's half angle, d[24..26] sun
+     * radiance, d[27..29] sun direction in scene space ("_transform" * d[9..11]). Infinite, not delta. */
+    IG_LIGHT_PEREZ = 10,
 };
 
 /* d[] for PLANE: origin.xyz, normal.x | x_axis.xyz, normal.y | y_axis.xyz, normal.z |
@@ -204,10 +208,17 @@ typedef struct ig_light {
     int32_t type;
     int32_t entity_id; /* emissive entity for area lights, -1 otherwise */
     int32_t pad[2];
-    float d[24];
+    float d[32];
 } ig_light;
 
-enum ig_cie_kind { IG_CIE_UNIFORM = 0, IG_CIE_CLOUDY = 1, IG_CIE_CLEAR = 2, IG_CIE_INTERMEDIATE = 3 };
+enum ig_cie_kind {
+    IG_CIE_UNIFORM = 0, IG_CIE_CLOUDY = 1, IG_CIE_CLEAR = 2, IG_CIE_INTERMEDIATE = 3,
+    /* the Perez all-weather sky as a function environment (sky_function of make_perez_light_raw, src/artic/light/perez.art:292-299;
+     * "has_sun": false): d[0..2] sky colour (tint * diffuse normalisation), d[3..5] ground radiance, the explicit parameters
+     * (a, b, c) in d[6..8] and (d, e) in d[12..13], d[9..11] sun direction in the light's frame, d[15..23] "_transform".
+     * The model behind these numbers (perez.art:94-290,321-375) is evaluated by the loader. */
+    IG_CIE_PEREZ = 4,
+};
 
 enum ig_light_selector {
     IG_SELECTOR_UNIFORM   = 0, /* src/artic/light/light_selector.art:26-46 */

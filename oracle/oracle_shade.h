@@ -2197,9 +2197,23 @@ struct CieSky {
         const float f2 = 1 / (a * a + 1);
         return color_add(color_mulf(c1, f1), color_mulf(c2, f2));
     }
+    // perez::eval (perez.art:235-242)
+    static float perez_eval(float cos_sun, float cos_theta, const float p[5])
+    {
+        const float sun_a = igm_acos(cos_sun);
+        const float A     = 1 + p[0] * igm_exp(p[1] / igm_max(1e-5f, cos_theta));
+        const float B     = 1 + p[2] * igm_exp(p[3] * sun_a) + p[4] * cos_sun * cos_sun;
+        return A * B;
+    }
     Color radiance(Vec3 dir) const
     {
         const float cos_theta = dir.y;
+        if (kind == IG_CIE_PEREZ) {
+            // sky_function of make_perez_light_raw (perez.art:293-298): (a, b, c) sit in the three brightness slots, (d, e) in `scale`
+            const float p[5]  = { ground_brightness, zenith_brightness, c2, scale.r, scale.g };
+            const float sun_c = clampf(vec3_dot(dir, sun_dir), -1, 1);
+            return wmean(cos_theta, color_mulf(zenith, perez_eval(sun_c, cos_theta, p)), ground);
+        }
         if (!has_ground && cos_theta < 0)
             return Color{ 0, 0, 0 };
         if (kind == IG_CIE_UNIFORM || kind == IG_CIE_CLOUDY) {
@@ -2284,9 +2298,18 @@ struct SunLight {
     bool hits(Vec3 towards_light) const { return vec3_dot(dir, towards_light) >= cos_angle; }
 };
 
-static inline DirectLightSample sample_direct_sun(const ig_light& l, Rng& rnd)
+// the sun of make_perez_light_raw (perez.art:301-317): direction in scene space d[27..29], half-angle cosine d[14], radiance d[24..26]
+static inline SunLight perez_sun(const ig_light& l)
 {
-    const SunLight sun(l);
+    ig_light s = l;
+    s.d[0] = l.d[27], s.d[1] = l.d[28], s.d[2] = l.d[29];
+    s.d[3] = l.d[14];
+    s.d[4] = l.d[24], s.d[5] = l.d[25], s.d[6] = l.d[26];
+    return SunLight(s);
+}
+
+static inline DirectLightSample sample_direct_sun(const SunLight& sun, Rng& rnd)
+{
     const float u  = rnd.next_f32();
     const float v  = rnd.next_f32();
     const float c1 = 1 - sun.cos_angle; // sample_uniform_cone
@@ -2549,9 +2572,18 @@ struct PathTracer {
             infinite = true;
             break;
         case IG_LIGHT_SUN:
-            ls       = sample_direct_sun(light, rnd);
+            ls       = sample_direct_sun(SunLight(light), rnd);
             infinite = true;
             break;
+        case IG_LIGHT_PEREZ: {
+            // sample_direct of make_perez_light_raw (perez.art:304-308): the sun's sample, carrying the sky seen in its direction too
+            const CieSky sky(light);
+            ls           = sample_direct_sun(perez_sun(light), rnd);
+            const Vec3 d = make_vec3(vec3_dot(sky.transform.col[0], ls.dir), vec3_dot(sky.transform.col[1], ls.dir), vec3_dot(sky.transform.col[2], ls.dir));
+            ls.intensity = color_add(ls.intensity, color_mulf(sky.radiance(d), 1 / ls.pdf_value));
+            infinite     = true;
+            break;
+        }
         case IG_LIGHT_CIE:
             ls       = sample_direct_cie(sc, light, rnd, surf);
             infinite = true;
@@ -2638,7 +2670,7 @@ struct PathTracer {
         Color color   = Color{ 0, 0, 0 };
         for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
             const ig_light& light = sc.lights[i];
-            if (light.type != IG_LIGHT_ENV && light.type != IG_LIGHT_ENV_TEXTURED && light.type != IG_LIGHT_SUN && light.type != IG_LIGHT_CIE)
+            if (light.type != IG_LIGHT_ENV && light.type != IG_LIGHT_ENV_TEXTURED && light.type != IG_LIGHT_SUN && light.type != IG_LIGHT_CIE && light.type != IG_LIGHT_PEREZ)
                 continue; // delta lights
             ++inflights;
             Color emit;
@@ -2651,6 +2683,14 @@ struct PathTracer {
                 const CieSky sky(light);
                 emit  = sky.emission(ray.dir);
                 pdf_s = sky.pdf(ray.dir);
+            } else if (light.type == IG_LIGHT_PEREZ) {
+                // emission / pdf_direct of make_perez_light_raw (perez.art:314 over sun.art:31-45)
+                const SunLight sun = perez_sun(light);
+                const CieSky sky(light);
+                const bool hit = sun.hits(ray.dir);
+                const Vec3 d   = make_vec3(vec3_dot(sky.transform.col[0], ray.dir), vec3_dot(sky.transform.col[1], ray.dir), vec3_dot(sky.transform.col[2], ray.dir));
+                emit           = color_add(hit ? sun.radiance : Color{ 0, 0, 0 }, sky.radiance(d));
+                pdf_s          = hit ? sun.dir_pdf() : 0.0f;
             } else if (light.type == IG_LIGHT_SUN) {
                 const SunLight sun(light); // sun.art:31-45
                 const bool hit = sun.hits(ray.dir);

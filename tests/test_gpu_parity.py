@@ -846,6 +846,25 @@ def test_cie_sky_lights_vs_oracle(gpu_device, kind, extra):
     _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=23, iters=2)
 
 
+@pytest.mark.parametrize("extra", [
+    {"clearness": 8, "brightness": 0.1},                                                        # sun + sky, time and place defaults
+    {"clearness": 1, "brightness": 0.3, "direction": [0.3, 0.7, -0.5], "ground": [0.3, 0.2, 0.1]},  # overcast: no sun radiance
+    {"clearness": 3, "brightness": 0.2, "has_sun": False, "direction": [-0.4, 0.5, 0.3], "color": [1, 0.9, 0.8]},
+    {"diffuse_irradiance": 120, "direct_irradiance": 600, "has_sun": False, "has_ground": False, "up": [0.1, 1, 0.05]},
+    {"diffuse_irradiance": 90, "direct_horizontal_irradiance": 300, "output": "solarradiance", "transform": [{"rotate": [0, 0, 20]}]},
+], ids=["sun-sky", "overcast", "sky-only", "irradiance-hemisphere", "horizontal-irradiance-transform"])
+def test_perez_sky_vs_oracle(gpu_device, extra):
+    """The Perez all-weather sky (light/perez.art): with its sun (make_sun_light carrying the sky function) and as a function
+    environment, sphere- or hemisphere-sampled, from every parametrisation, next to the area light."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["lights"] = s["lights"] + [dict({"type": "perez", "name": "sky"}, **extra)]
+    s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 64)
+    assert sc.scene.lights[0].type == (7 if extra.get("has_sun") is False else 10)
+    _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=29, iters=2)
+
+
 @pytest.mark.parametrize("scene_name,cap", [("diamond_scene.json", 0), ("diamond_scene_principled.json", 4096), ("many_point_lights_hip.json", 0)])
 def test_info_buffer_aovs_vs_oracle(scene_name, cap):
     """The "Normals" / "Albedo" AOVs the runtime adds for its denoiser: first hits of iteration 0's camera rays, unchanged by

@@ -50,6 +50,7 @@ PINNED = {
     "point": None,                                        # Mitsuba: point light
     "room": None,                                         # Mitsuba: room lit through a window
     "sky-clear": None, "sky-cloudy": None, "sky-intermediate": None, "sky-uniform": None,  # Radiance gensky: the four CIE models
+    "sky-perez1": None, "sky-perez2": None, "sky-perez3": None,  # Radiance gendaylit -P: Perez all-weather sky with its sun (clear, overcast, intermediate)
     "sphere-light-ico": None, "sphere-light-ico-nopt": None,  # Mitsuba: sphere light; the icosphere mesh is recognised as a sphere (getAsSphere) / sampled as a mesh
     "sphere-light-pure": None,                            # Mitsuba: the analytic sphere shape with the sphere emitter
     "sphere-light-uv": (0.03, 3e-3),                      # the same with a coarse uv-sphere: the mesh has ~2 % less area than the sphere
