@@ -421,7 +421,8 @@ void assignScene(igd_device* d, const igd_scene* s)
         if (lt == IG_LIGHT_ENV_TEXTURED) {
             uint32_t v[4];
             std::memcpy(v, &s->lights[l].d[12], sizeof(v));
-            if (v[0] >= s->texture_count || !s->cdf_data || v[2] == 0 || v[3] == 0 || (uint64_t)v[1] + v[3] + (uint64_t)v[2] * v[3] > s->cdf_data_count)
+            const bool no_table = v[2] == 0 && v[3] == 0; // "cdf": "none"
+            if (v[0] >= s->texture_count || (!no_table && (!s->cdf_data || v[2] == 0 || v[3] == 0 || (uint64_t)v[1] + v[3] + (uint64_t)v[2] * v[3] > s->cdf_data_count)))
                 throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: textured environment light " + std::to_string(l) + " has no valid texture / CDF table" };
         }
     }
@@ -490,8 +491,9 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->light_cdf.upload(s->light_cdf, simple_selector ? n_finite : 0);
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
-        const uint64_t bytes = (uint64_t)t.width * t.height * (t.channels == 1 ? 1 : 4);
-        if (t.width == 0 || t.height == 0 || (t.channels != 1 && t.channels != 4) || t.offset + bytes > s->texture_data_size)
+        const uint32_t nc    = t.channels & ~IG_TEX_FLOAT_BIT;
+        const uint64_t bytes = (uint64_t)t.width * t.height * nc * ((t.channels & IG_TEX_FLOAT_BIT) ? sizeof(float) : 1);
+        if (t.width == 0 || t.height == 0 || (nc != 1 && nc != 4) || (t.offset & 15) || t.offset + bytes > s->texture_data_size)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: texture " + std::to_string(i) + " is malformed" };
     }
     d->textures.upload(s->textures, s->texture_count);

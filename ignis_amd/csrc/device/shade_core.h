@@ -333,6 +333,14 @@ IG_DEV float wrapf(float v, float mn, float mx)
 IG_DEV Col image_pixel(const DevScene& sc, const ig_texture& t, int x, int y)
 {
     const uint8_t* base = sc.texture_data + t.offset;
+    if (t.channels & IG_TEX_FLOAT_BIT) { // float images (driver/image.art:1-7 over device.load_image): as stored
+        if ((t.channels & 0xFFu) == 1) {
+            const float g = reinterpret_cast<const float*>(base)[y * (int)t.width + x];
+            return Col{ g, g, g };
+        }
+        const float4 c = reinterpret_cast<const float4*>(base)[y * (int)t.width + x];
+        return Col{ c.x, c.y, c.z };
+    }
     if (t.channels == 1) {
         const float g = (float)base[y * (int)t.width + x] / 255;
         return Col{ g, g, g };
@@ -1477,6 +1485,8 @@ IG_DEV f2 map_env_uv(f3 dir)
 }
 
 // make_environment_light_textured (light/env.art:109-157)
+IG_DEV f3 square_to_sphere(float px, float py);
+
 struct TexturedEnv {
     const DevScene& sc;
     Col scale;
@@ -1499,6 +1509,14 @@ struct TexturedEnv {
     {
         const float u0 = rnd.f32();
         const float u1 = rnd.f32();
+        if (cdf.size_x == 0) {
+            // "cdf": "none" -> make_environment_light (env.art:161-164) over make_environment_light_function_spherical
+            // (:79-93): a uniform direction, the function value includes `scale`
+            dir       = square_to_sphere(u0, u1);
+            intensity = emission(dir);
+            pdf_dir   = 1 / (4 * kPi);
+            return;
+        }
         float pdf;
         const f2 pos      = cdf.sample_continuous(u0, u1, pdf);
         intensity         = image_lookup(sc, *tex, pos);
@@ -1514,6 +1532,8 @@ struct TexturedEnv {
     IG_DEV f3 local_dir(f3 ray_dir) const { return switch_env_up(mul33(transform, ray_dir)); }
     IG_DEV float pdf(f3 ray_dir) const
     {
+        if (cdf.size_x == 0)
+            return 1 / (4 * kPi); // equal_area_sphere_pdf (env.art:101)
         const f3 ldir        = local_dir(ray_dir);
         const float sinTheta = safe_sqrt(1 - ldir.z * ldir.z);
         return safe_div(cdf.pdf_continuous(map_env_uv(ldir)), sinTheta * kPi * kPi * 2);

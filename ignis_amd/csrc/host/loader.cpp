@@ -20,6 +20,7 @@
 #include "mesh.h"
 #include "png.h"
 #include "exr.h"
+#include "floatimage.h"
 
 #include <cstring>
 #include <fstream>
@@ -726,14 +727,20 @@ struct TextureBank {
         if (filename.empty())
             fail("Texture '" + tex_name + "': no filename");
         const std::string path = (filename[0] == '/' || base_dir.empty()) ? filename : base_dir + "/" + filename;
-        if (path.size() < 4 || path.substr(path.size() - 4) != ".png")
-            fail("Texture '" + tex_name + "': only PNG files are supported by this loader");
-        const PngImage png = readPng(path);
-        const bool linear  = def->getBool("linear", false);
+        const bool is_float = isFloatImagePath(path);
+        if (!is_float && (path.size() < 4 || path.substr(path.size() - 4) != ".png"))
+            fail("Texture '" + tex_name + "': only PNG, OpenEXR and Radiance HDR files are supported by this loader");
+        PngImage png;
+        FloatImage fimg;
+        if (is_float)
+            fimg = readFloatImage(path); // Image::load (Image.cpp:497-712): kept as floats, never packed (Image.cpp:717-721)
+        else
+            png = readPng(path);
+        const bool linear = def->getBool("linear", false);
 
         ig_texture rec{};
-        rec.width  = png.width;
-        rec.height = png.height;
+        rec.width  = is_float ? fimg.width : png.width;
+        rec.height = is_float ? fimg.height : png.height;
         // ImagePattern.cpp:25-29: anything but "bilinear" / "nearest" (e.g. the scenes' "trilinear") is bicubic
         const std::string filter = def->getString("filter_type", "bicubic");
         rec.filter               = filter == "bilinear" ? IG_TEX_BILINEAR : (filter == "nearest" ? IG_TEX_NEAREST : IG_TEX_BICUBIC);
@@ -746,8 +753,15 @@ struct TextureBank {
         data.resize((data.size() + 15) & ~(size_t)15);
         rec.offset = data.size();
         // rows bottom to top (stbi_set_flip_vertically_on_load, Image.cpp:724)
-        const size_t n = (size_t)png.width * png.height;
-        if (png.channels == 1) {
+        const size_t n = (size_t)rec.width * rec.height;
+        if (is_float) {
+            // 32-bit floats, one or four per texel, no colour-space conversion; Image::flipY (Image.cpp:108-121,709)
+            rec.channels = IG_TEX_FLOAT_BIT | fimg.channels;
+            const size_t row = (size_t)rec.width * fimg.channels * sizeof(float);
+            data.resize(rec.offset + n * fimg.channels * sizeof(float));
+            for (uint32_t y = 0; y < rec.height; ++y)
+                std::memcpy(&data[rec.offset + (size_t)y * row], &fimg.pixels[(size_t)(rec.height - 1 - y) * rec.width * fimg.channels], row);
+        } else if (png.channels == 1) {
             rec.channels = 1;
             data.resize(rec.offset + n);
             for (uint32_t y = 0; y < png.height; ++y)
@@ -997,6 +1011,12 @@ static V3 lookupTexture(const ig_texture& t, const std::vector<uint8_t>& data, f
         x = border(t.wrap_u, x, W);
         y = border(t.wrap_v, y, H);
         const uint8_t* p = &data[t.offset];
+        if (t.channels & IG_TEX_FLOAT_BIT) {
+            const uint32_t nc = t.channels & 0xFFu;
+            float c[4];
+            std::memcpy(c, p + ((size_t)y * W + x) * nc * sizeof(float), nc * sizeof(float));
+            return nc == 1 ? V3(c[0], c[0], c[0]) : V3(c[0], c[1], c[2]);
+        }
         if (t.channels == 1) {
             const float g = (float)p[(size_t)y * W + x] / 255;
             return V3(g, g, g);
@@ -1862,18 +1882,23 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
                 std::string method = l.getString("cdf", "conditional");
                 for (char& ch : method)
                     ch = (char)std::tolower((unsigned char)ch);
-                if (method != "conditional" && method != "")
-                    fail("Environment light '" + lname + "': cdf method '" + method + "' is not supported by the HIP backend (only 'conditional')");
+                if (method != "conditional" && method != "" && method != "none")
+                    fail("Environment light '" + lname + "': cdf method '" + method + "' is not supported by the HIP backend (only 'conditional' and 'none')");
                 const int tex_id    = bank.get(rad->str, lname);
                 const ig_texture tx = sc->textures[tex_id];
-                const size_t bw = std::max<size_t>(1024, tx.width), bh = std::max<size_t>(512, tx.height);
-                std::vector<float> baked(bw * bh * 3);
-                for (size_t y = 0; y < bh; ++y)
-                    for (size_t x = 0; x < bw; ++x) {
-                        const V3 c = lookupTexture(tx, sc->texture_data, (float)x / (float)(bw - 1), (float)y / (float)(bh - 1));
-                        baked[(y * bw + x) * 3] = c.x, baked[(y * bw + x) * 3 + 1] = c.y, baked[(y * bw + x) * 3 + 2] = c.z;
-                    }
-                const uint32_t cdf_off = appendEnvironmentCdf(sc->cdf_data, baked, bw, bh, l.getBool("compensate", true));
+                size_t bw = std::max<size_t>(1024, tx.width), bh = std::max<size_t>(512, tx.height);
+                uint32_t cdf_off = 0;
+                if (method == "none") {
+                    bw = bh = 0; // no table: the device samples directions uniformly (make_environment_light, env.art:161-164)
+                } else {
+                    std::vector<float> baked(bw * bh * 3);
+                    for (size_t y = 0; y < bh; ++y)
+                        for (size_t x = 0; x < bw; ++x) {
+                            const V3 c = lookupTexture(tx, sc->texture_data, (float)x / (float)(bw - 1), (float)y / (float)(bh - 1));
+                            baked[(y * bw + x) * 3] = c.x, baked[(y * bw + x) * 3 + 1] = c.y, baked[(y * bw + x) * 3 + 2] = c.z;
+                        }
+                    cdf_off = appendEnvironmentCdf(sc->cdf_data, baked, bw, bh, l.getBool("compensate", true));
+                }
                 const V3 scale         = getColor(l, "scale", V3(1, 1, 1), lname);
                 // "_transform" = transform.linear().transpose().inverse() (EnvironmentLight.cpp:56)
                 const M3 T   = l.has("transform") ? inverse(transpose(getTransform(l).L)) : M3{};
@@ -2366,6 +2391,26 @@ int32_t igh_save_exr(const char* path, const float* rgb, int32_t width, int32_t 
         for (const char* const* m = meta; m && m[0] && m[1]; m += 2)
             attrs.emplace_back(m[0], m[1]);
         igh::writeExr(path, rgb, width, height, scale, attrs);
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t igh_read_float_image(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, float* pixels, uint64_t capacity)
+{
+    g_last_error.clear();
+    try {
+        if (!path || !width || !height || !channels)
+            throw std::runtime_error("igh_read_float_image: NULL argument");
+        const igh::FloatImage img = igh::readFloatImage(path);
+        *width = img.width, *height = img.height, *channels = img.channels;
+        if (pixels) {
+            if (capacity < img.pixels.size())
+                throw std::runtime_error("igh_read_float_image: buffer too small");
+            std::memcpy(pixels, img.pixels.data(), img.pixels.size() * sizeof(float));
+        }
         return 0;
     } catch (const std::exception& e) {
         g_last_error = e.what();

@@ -150,9 +150,12 @@ typedef struct ig_material {
 enum ig_tex_filter { IG_TEX_NEAREST = 0, IG_TEX_BILINEAR = 1, IG_TEX_BICUBIC = 2 }; /* src/artic/texture/image.art:85-156 */
 enum ig_tex_wrap { IG_WRAP_REPEAT = 0, IG_WRAP_MIRROR = 1, IG_WRAP_CLAMP = 2 };      /* image.art:9-40 */
 
+#define IG_TEX_FLOAT_BIT 0x100u
+
 typedef struct ig_texture {
     uint32_t width, height;
-    uint32_t channels; /* 1 or 4 */
+    uint32_t channels; /* 1 or 4 packed 8-bit values per texel (LDR files, Image::loadAsPacked); with IG_TEX_FLOAT_BIT set, 1 or 4
+                        * 32-bit floats per texel (OpenEXR / Radiance HDR files, Image::load: src/runtime/Image.cpp:497-712) */
     uint32_t filter;   /* enum ig_tex_filter */
     uint32_t wrap_u, wrap_v;
     uint64_t offset;   /* bytes into texture_data, 16-byte aligned */
@@ -169,7 +172,8 @@ enum ig_light_type {
     /* environment map sampled through a marginal / conditional CDF (make_environment_light_textured, src/artic/light/
      * env.art:109-157; EnvironmentLight.cpp:40-98): d[0..2] scale, d[3..11] the 3x3 "_transform" column by column,
      * then as integer bits d[12] texture index, d[13] offset of the CDF in igd_scene.cdf_data (floats),
-     * d[14] CDF width, d[15] CDF height */
+     * d[14] CDF width, d[15] CDF height. Width = height = 0 ("cdf": "none"): no table, directions are sampled uniformly over the
+     * sphere and the sample carries scale * texture (make_environment_light, env.art:161-164) */
     IG_LIGHT_ENV_TEXTURED = 5,
     /* make_sun_light (src/artic/light/sun.art:8-48, SunLight.cpp:32-57; infinite, not delta): d[0..2] direction
      * (scene to light, normalised), d[3] cos of the half angle, d[4..6] radiance */

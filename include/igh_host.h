@@ -50,6 +50,12 @@ void igh_free(igh_scene* scene);
  * ImageMetaData). Returns 0 on success. */
 int32_t igh_save_exr(const char* path, const float* rgb, int32_t width, int32_t height, float scale, const char* const* meta);
 
+/* Image::load for floating-point files (src/runtime/Image.cpp:497-712): an OpenEXR (.exr: scanline, NONE / RLE / ZIPS / ZIP /
+ * PIZ) or Radiance (.hdr) picture as 32-bit floats, rows top to bottom, `*channels` = 1 (a lone Y or A channel) or 4 (R, G, B, A;
+ * A = 1 when the file has none). Call with pixels == NULL to query the size, then with a buffer of width * height * channels
+ * floats (`capacity` in floats). Returns 0 on success. */
+int32_t igh_read_float_image(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, float* pixels, uint64_t capacity);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

@@ -613,6 +613,13 @@ static inline Color checkerboard(const ig_material& mat, Vec2 uv)
 static inline Color image_pixel(const igd_scene& sc, const ig_texture& t, int32_t x, int32_t y)
 {
     const uint8_t* base = sc.texture_data + t.offset;
+    if (t.channels & IG_TEX_FLOAT_BIT) {
+        // unpacked images (driver/image.art:1-7: the floats device.load_image returns, one or four per pixel)
+        const uint32_t nc = t.channels & 0xFFu;
+        float c[4];
+        std::memcpy(c, base + sizeof(float) * nc * (size_t)(y * (int32_t)t.width + x), sizeof(float) * nc);
+        return nc == 1 ? Color{ c[0], c[0], c[0] } : Color{ c[0], c[1], c[2] };
+    }
     if (t.channels == 1) {
         const float g = (float)base[y * (int32_t)t.width + x] / 255; // image_mono_unpack
         return Color{ g, g, g };
@@ -1989,6 +1996,14 @@ struct TexturedEnv {
     {
         const float u0 = rnd.next_f32();
         const float u1 = rnd.next_f32();
+        if (cdf.size_x == 0) {
+            // "cdf": "none" (EnvironmentLight.cpp:60,89-96): make_environment_light (env.art:161-164), i.e. the spherical function
+            // environment (:79-93) over scale * tex: uniform directions, `scale` included
+            dir       = equal_area_square_to_sphere(u0, u1);
+            intensity = emission(dir);
+            pdf_dir   = 1 / (4 * flt_pi);
+            return;
+        }
         float pdf;
         const Vec2 pos    = cdf.sample_continuous(u0, u1, pdf);
         intensity         = image_lookup(sc, *tex, pos);
@@ -2004,6 +2019,8 @@ struct TexturedEnv {
     Vec3 local_dir(Vec3 ray_dir) const { return switch_env_up(mat3x3_mul(transform, ray_dir)); }
     float pdf(Vec3 ray_dir) const // env.art:125-131
     {
+        if (cdf.size_x == 0)
+            return 1 / (4 * flt_pi); // equal_area_sphere_pdf (env.art:101)
         const Vec3 ldir      = local_dir(ray_dir);
         const float sinTheta = safe_sqrt(1 - ldir.z * ldir.z);
         return safe_div(cdf.pdf_continuous(map_env_uv(ldir)), sinTheta * flt_pi * flt_pi * 2);
