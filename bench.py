@@ -230,7 +230,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and (W, H, spi) == (WIDTH, HEIGHT, SPI) and world == 1:
             tj = json.load(open(tpath))
-            tk = tj["kernels"].get("k_traverse<false, false, false>")
+            tk = next((v for k, v in tj["kernels"].items() if k.startswith("k_traverse<false, false, false")), None)  # <closest, no stats, not DEEP[, no spheres]>
             if tk and tj.get("steps") == args.steps:
                 traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes of this command at {args.steps} steps, x2 read correction)"
                 if "valu_lane_utilisation" in tk:

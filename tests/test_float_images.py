@@ -287,11 +287,12 @@ def test_environment_without_cdf_vs_oracle(gpu_device, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("gray", [False, True])
 def test_float_environment_map_vs_oracle(gpu_device, tmp_path, gray):
-    """An HDR environment with a bright spot (radiance 5000, far beyond what 8 bits hold), CDF-sampled: HIP == oracle."""
+    """An HDR environment with bright spots (radiance 5000, far beyond what 8 bits hold), CDF-sampled: HIP == oracle."""
     import oracle
     rng = np.random.default_rng(2)
     img = (rng.random((32, 64, 3)) * 0.5).astype(np.float32)
-    img[6:9, 40:44] = (5000, 4000, 3000)
+    for r, c in ((6, 40), (24, 10), (15, 25), (20, 55)):
+        img[r:r + 3, c:c + 4] = (5000, 4000, 3000)
     if gray:
         from ignis_amd.tables import LoadedScene
         _write_exr(str(tmp_path / "env.exr"), [("Y", 1, img[..., 0].astype(np.float16))], 2, 64, 32)
@@ -309,5 +310,5 @@ def test_float_environment_map_vs_oracle(gpu_device, tmp_path, gray):
         gpu_device.render(8, 64, 48, iteration=it, seed=4)
         oracle.render(sc, 8, 64, 48, iteration=it, seed=4, fb=ref)
     fb = gpu_device.framebuffer()
-    assert fb.max() > 100
+    assert fb.mean() > 20  # the spots light the plane: far more than 8-bit texels could carry
     assert np.linalg.norm(fb - ref) / np.linalg.norm(ref) <= 1e-4
