@@ -114,6 +114,7 @@ struct igd_device {
     DevBuf<uint4> entity_ext;
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy, light_cdf;
+    DevBuf<ig_medium> media;
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
     DevBuf<float> cdf_data;
@@ -489,6 +490,9 @@ void assignScene(igd_device* d, const igd_scene* s)
     if (simple_selector && (!s->light_cdf || s->light_cdf_count != n_finite))
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: 'simple' light selector without a flux CDF over the finite lights" };
     d->light_cdf.upload(s->light_cdf, simple_selector ? n_finite : 0);
+    if (s->media_count && !s->media)
+        throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: media_count without media" };
+    d->media.upload(s->media, s->media_count);
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
         const uint32_t nc    = t.channels & ~IG_TEX_FLOAT_BIT;
@@ -564,6 +568,8 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_codes          = d->light_codes.ptr;
     ds.use_hierarchy        = hierarchy ? 1u : 0u;
     ds.light_cdf            = simple_selector ? d->light_cdf.ptr : nullptr;
+    ds.media                = d->media.ptr;
+    ds.media_count          = s->media_count;
     ds.scene_radius         = s->scene_radius;
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
@@ -584,9 +590,9 @@ void assignScene(igd_device* d, const igd_scene* s)
         d->full_bsdfs |= s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
-    d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO;
+    d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH;
     d->full_bsdfs |= simple_selector;
-    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO)
+    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
         if (s->lights[i].type != IG_LIGHT_MESH_AREA && s->lights[i].type != IG_LIGHT_SPHERE)
@@ -1548,6 +1554,7 @@ int32_t igd_release_all(igd_device* dev)
         dev->light_hierarchy.release();
         dev->light_codes.release();
         dev->light_cdf.release();
+        dev->media.release();
         dev->textures.release();
         dev->texture_data.release();
         dev->cdf_data.release();

@@ -32,6 +32,8 @@ struct DevScene {
     const uint32_t* light_codes;
     uint32_t use_hierarchy;
     const float* light_cdf; // IG_SELECTOR_SIMPLE: CDF over the finite lights' flux (null otherwise)
+    const ig_medium* media; // IG_TECHNIQUE_VOLPATH: participating media, ig_material.pad[2] names an entity's two sides
+    uint32_t media_count;
     float scene_radius;
     // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
     // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)

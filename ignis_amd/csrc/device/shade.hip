@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : 4) k
                 os += s_wave_cnt[1][w];
             if (out.bounce) {
                 const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
-                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, kRayOffset);
+                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, out.b_tmin);
                 a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
                 a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
                 a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);

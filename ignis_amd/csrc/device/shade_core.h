@@ -1899,13 +1899,83 @@ IG_DEV float select_pdf(const DevScene& sc, int li, f3 from_pos)
 
 // ---------------------------------------------------------------- one path vertex
 
+// make_homogeneous_medium / make_vacuum_medium (medium/homogeneous.art:1-58, driver/medium.art) with the Henyey-Greenstein phase
+// function (phase/henyeygreenstein.art) for the volumetric path tracer
+struct Medium {
+    bool vacuum, scattering;
+    Col sigma_t;
+    int sigma_ind;
+    float sigma_t_p, g;
+
+    IG_DEV Medium(const DevScene& sc, int id)
+    {
+        vacuum     = id < 0 || (uint32_t)id >= sc.media_count || sc.media[id].type == IG_MEDIUM_VACUUM; // unknown ids: vacuum (LoaderMedium.cpp:104)
+        scattering = false;
+        sigma_t    = Col{ 0, 0, 0 };
+        sigma_ind  = 0;
+        sigma_t_p  = 0;
+        g          = 0;
+        if (!vacuum) {
+            const ig_medium& m = sc.media[id];
+            sigma_t    = Col{ m.sigma_a[0] + m.sigma_s[0], m.sigma_a[1] + m.sigma_s[1], m.sigma_a[2] + m.sigma_s[2] };
+            scattering = !(igm_abs(m.sigma_s[0]) <= 1e-4f && igm_abs(m.sigma_s[1]) <= 1e-4f && igm_abs(m.sigma_s[2]) <= 1e-4f);
+            sigma_ind  = sigma_t.r < sigma_t.g ? (sigma_t.r < sigma_t.b ? 0 : 2) : (sigma_t.g < sigma_t.b ? 1 : 2); // vec3_min_index
+            sigma_t_p  = sigma_ind == 0 ? sigma_t.r : (sigma_ind == 1 ? sigma_t.g : sigma_t.b);
+            g          = m.g;
+        }
+    }
+    IG_DEV Col eval_tr(float t) const { return Col{ igm_exp(-sigma_t.r * t), igm_exp(-sigma_t.g * t), igm_exp(-sigma_t.b * t) }; }
+    IG_DEV Col eval(f3 a, f3 b) const { return vacuum ? Col{ 1, 1, 1 } : eval_tr(len3(b - a)); }
+    IG_DEV Col eval_inf() const
+    {
+        if (vacuum)
+            return Col{ 1, 1, 1 };
+        const bool clear = igm_abs(sigma_t.r) <= 1e-4f && igm_abs(sigma_t.g) <= 1e-4f && igm_abs(sigma_t.b) <= 1e-4f;
+        return (!scattering && clear) ? Col{ 1, 1, 1 } : Col{ 0, 0, 0 };
+    }
+    // sample (homogeneous.art:38-52): a distance along the segment, or nothing (no random number drawn without scattering)
+    IG_DEV bool sample(Tea& rnd, f3 p_start, f3 p_end, f3& pos, Col& weight) const
+    {
+        if (vacuum || !scattering)
+            return false;
+        const f3 dir_u    = p_end - p_start;
+        const float dist  = len3(dir_u);
+        const float ndist = igm_min(dist, -igm_log(1 - rnd.f32() * 0.99999f) / sigma_t_p);
+        if (igm_abs(dist - ndist) <= 1e-3f)
+            return false;
+        pos             = p_start + (dir_u * safe_div(1, dist)) * ndist;
+        const Col tr    = eval_tr(ndist);
+        const float pdf = (sigma_ind == 0 ? tr.r : (sigma_ind == 1 ? tr.g : tr.b)) * sigma_t_p;
+        weight          = Col{ tr.r / pdf, tr.g / pdf, tr.b / pdf };
+        return true;
+    }
+    // make_henyeygreenstein_phase(g).sample (henyeygreenstein.art:20-38), weight 1; the anisotropic direction is returned in the
+    // sampling frame, as written there
+    IG_DEV f3 sample_phase(Tea& rnd) const
+    {
+        if (igm_abs(g) <= 1e-3f) {
+            const float u   = rnd.f32();
+            const float v   = rnd.f32();
+            const float c   = 2 * v - 1;
+            const float sn  = safe_sqrt(1 - c * c);
+            const float phi = 2 * kPi * u;
+            return f3{ sn * igm_cos(phi), sn * igm_sin(phi), c };
+        }
+        const float sqr_term  = (1 - g * g) / (1 + g - 2 * g * rnd.f32());
+        const float cos_theta = -(1 + g * g - sqr_term * sqr_term) / (2 * g);
+        const float sin_theta = igm_sqrt(igm_max(0.0f, 1 - cos_theta * cos_theta));
+        const float phi       = 2 * kPi * rnd.f32();
+        return f3{ sin_theta * igm_cos(phi), sin_theta * igm_sin(phi), cos_theta };
+    }
+};
+
 struct PathVertexIn {
     int ray_id;
     f3 org, dir;
     uint32_t rnd;
     float inv_pdf;
     Col contrib;
-    int depth;
+    int depth; // low 16 bits: path depth; high 16 bits: current medium + 1 (volumetric path tracer: VPTRayPayload.medium)
     float eta;
     // hit (ent < 0: miss)
     int ent, prim;
@@ -1921,6 +1991,7 @@ struct PathVertexOut {
     Col s_col;
     bool bounce;       // continued path
     f3 b_org, b_dir;
+    float b_tmin;
     uint32_t b_rnd;
     float b_inv_pdf, b_eta;
     Col b_contrib;
@@ -1948,6 +2019,11 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
 
     const ig_technique tech = sc.tech;
     const bool nee          = tech.nee != 0;
+    // make_volume_path_renderer (technique/volpathtracer.art:37-260): the same callbacks with a current medium in the payload
+    const bool volumetric = FULL && tech.type == IG_TECHNIQUE_VOLPATH;
+    const int depth       = FULL ? (in.depth & 0xFFFF) : in.depth;
+    const int medium_id   = FULL ? (in.depth >> 16) - 1 : -1;
+    const float mis_inv_pdf = volumetric ? igm_max(0.0f, in.inv_pdf) : in.inv_pdf; // "ignore medium interactions" (volpathtracer.art:101,134)
 
     if (in.ent < 0) {
         // a sample for which the camera had no ray (masked fishlens) carries the zero ray of
@@ -1988,7 +2064,9 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             } else {
                 continue; // delta lights
             }
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf<FULL>(sc, (int)li, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? 1 / (1 + mis_inv_pdf * select_pdf<FULL>(sc, (int)li, in.org) * pdf_s) : 1.0f;
+            if (volumetric)
+                emit = emit * Medium(sc, medium_id).eval_inf(); // volpathtracer.art:135
             const Col c       = clamp_color(tech, (in.contrib * emit) * mis);
             sum               = Col{ sum.r + c.r, sum.g + c.g, sum.b + c.b };
         }
@@ -2046,14 +2124,16 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 emit  = pl.radiance;
                 pdf_s = pl.pdf(in.org);
             }
-            const float mis   = nee ? 1 / (1 + in.inv_pdf * select_pdf<FULL>(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? 1 / (1 + mis_inv_pdf * select_pdf<FULL>(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
+            if (volumetric)
+                emit = emit * Medium(sc, medium_id).eval(in.org, surf.point); // volpathtracer.art:104-105
             out.has_radiance  = true;
             out.radiance      = clamp_color(tech, (in.contrib * emit) * mis);
         }
     }
 
     // ---- on_shadow (technique/pathtracer.art:52-117): next event estimation
-    if (nee && !bsdf.all_delta() && sc.light_count != 0 && in.depth + 1 <= tech.max_depth) {
+    if (nee && !bsdf.all_delta() && sc.light_count != 0 && depth + 1 <= tech.max_depth) {
         float sel_pdf;
         const int lid     = select_light<FULL>(sc, rnd, surf.point, sel_pdf);
         const ig_light& L = sc.lights[lid];
@@ -2222,7 +2302,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         const float pdf_l_s = (pdf_area ? pdf_value * dist2 / lcos : pdf_value) * sel_pdf; // driver/pdf.art:19-38
         if (pdf_l_s > kFltEps && lcos > kFltEps) {
             float mis = 1;
-            if (!delta)
+            if (!delta && !(volumetric && igm_signbit(in.inv_pdf))) // was_medium_interaction (volpathtracer.art:39,53)
                 mis = 1 / (1 + bsdf.pdf(ldir, out_dir) / pdf_l_s);
             const float factor = pdf_value / pdf_l_s;
             const Col c        = clamp_color(tech, (lint * (in.contrib * bsdf.eval(ldir, out_dir))) * (mis * factor));
@@ -2232,20 +2312,52 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 out.s_dir  = infinite ? ldir : lpos - surf.point;
                 out.s_tmax = infinite ? kFltMax : 1 - kRayOffset;
                 out.s_col  = c;
+                if (volumetric) {
+                    // volpathtracer.art:41,71-83: the current medium from the ray origin to the hit and on towards the light
+                    const Medium medium(sc, medium_id);
+                    out.s_col = c * (medium.eval(in.org, surf.point) * (infinite ? medium.eval_inf() : medium.eval(surf.point, lpos)));
+                }
             }
         }
     }
 
-    // ---- on_bounce (technique/pathtracer.art:170-210)
-    if (in.depth + 1 <= tech.max_depth) {
+    // ---- on_bounce (technique/pathtracer.art:170-210; technique/volpathtracer.art:155-247)
+    if (depth + 1 <= tech.max_depth) {
+        out.b_tmin = kRayOffset;
+        Col path_contrib = in.contrib;
+        if (volumetric) {
+            // try the medium first: a scattering event between the ray origin and the hit replaces the surface bounce
+            const Medium medium(sc, medium_id);
+            f3 mpos;
+            Col mweight;
+            if (medium.sample(rnd, in.org, surf.point, mpos, mweight)) {
+                const f3 pdir       = medium.sample_phase(rnd);
+                const Col nc        = in.contrib * mweight;
+                const float e2      = in.eta * in.eta;
+                const float rr_prob = (depth + 1 > tech.min_depth) ? clampf(igm_max(nc.r * e2, igm_max(nc.g * e2, nc.b * e2)), 0.05f, 0.95f) : 1.0f;
+                if (!(rnd.f32() >= rr_prob)) {
+                    out.bounce    = true;
+                    out.b_org     = mpos;
+                    out.b_dir     = pdir;
+                    out.b_tmin    = 0;
+                    out.b_rnd     = rnd.counter;
+                    out.b_inv_pdf = -1; // "the last interaction was a medium"
+                    out.b_contrib = nc * (1 / rr_prob);
+                    out.b_depth   = (depth + 1) | ((medium_id + 1) << 16);
+                    out.b_eta     = in.eta;
+                }
+                return;
+            }
+            path_contrib = medium.eval(in.org, surf.point) * in.contrib;
+        }
         f3 in_dir;
         float pdf, s_eta;
         Col color;
         bool sdelta;
         if (bsdf.sample(rnd, out_dir, in_dir, pdf, color, s_eta, sdelta) && pdf > kFltEps) {
-            const Col nc        = in.contrib * color;
+            const Col nc        = path_contrib * color;
             const float e2      = in.eta * in.eta;
-            const float rr_prob = (in.depth + 1 > tech.min_depth) ? clampf(igm_max(nc.r * e2, igm_max(nc.g * e2, nc.b * e2)), 0.05f, 0.95f) : 1.0f;
+            const float rr_prob = (depth + 1 > tech.min_depth) ? clampf(igm_max(nc.r * e2, igm_max(nc.g * e2, nc.b * e2)), 0.05f, 0.95f) : 1.0f;
             if (!(rnd.f32() >= rr_prob)) {
                 out.bounce    = true;
                 out.b_org     = surf.point;
@@ -2253,8 +2365,15 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 out.b_rnd     = rnd.counter;
                 out.b_inv_pdf = sdelta ? 0 : 1 / pdf;
                 out.b_contrib = nc * (1 / rr_prob);
-                out.b_depth   = in.depth + 1;
+                out.b_depth   = depth + 1;
                 out.b_eta     = in.eta * s_eta;
+                if (volumetric) {
+                    // a transmission continues in the medium on the other side (make_medium_interface.pick, driver/medium.art:34-38)
+                    const bool transmission = igm_signbit(dot3(N, in_dir));
+                    const int inner = (mat.pad[2] & 0xFFFF) - 1, outer = ((mat.pad[2] >> 16) & 0xFFFF) - 1;
+                    const int next  = transmission ? (surf.entering ? inner : outer) : medium_id;
+                    out.b_depth     = (depth + 1) | ((next + 1) << 16);
+                }
             }
         }
     }

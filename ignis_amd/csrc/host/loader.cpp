@@ -378,6 +378,7 @@ struct Scene {
     std::vector<float> light_hierarchy;
     std::vector<uint32_t> light_codes;
     std::vector<float> light_cdf;
+    std::vector<ig_medium> media;
     std::vector<std::string> entity_names;
     std::vector<std::string> material_names;
     std::vector<ig_texture> textures;
@@ -1474,8 +1475,10 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         const std::string type = t->getString("type", "path");
         if (type == "ao")
             tech.type = IG_TECHNIQUE_AO; // AOTechnique.cpp: no parameters
+        else if (type == "volpath")
+            tech.type = IG_TECHNIQUE_VOLPATH; // VolumePathTechnique.cpp: the parameters of the path tracer
         else if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path' and 'ao')");
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath' and 'ao')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
         tech.clamp     = t->getNumber("clamp", 0.0f);
@@ -1598,8 +1601,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         fail("Expected 'textures' to be an array");
     if (!bsdfs.isArray() || !jlights.isArray() || !entities.isArray())
         fail("Expected 'bsdfs', 'lights' and 'entities' to be arrays");
-    if (doc.has("media") && !doc.find("media")->arr.empty())
-        fail("Participating media are not supported by the HIP backend");
+    if (doc.has("media") && !doc.find("media")->isArray())
+        fail("Expected 'media' to be an array");
 
     // ---- which entities are area lights (LoaderLight::setupAreaLights)
     std::map<std::string, std::string> area_light_of_entity; // entity -> light name
@@ -1610,6 +1613,41 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     // ---- group entities by material (LoaderEntity.cpp:43-97)
     struct MatKey {
         std::string bsdf, light_entity;
+        int medium_inner = -1, medium_outer = -1;
+    };
+    // media are numbered in the order entities name them (LoaderMedium::acquire, LoaderMedium.cpp:113-121)
+    const JsonValue no_media;
+    const JsonValue& media_defs = doc.find("media") ? *doc.find("media") : no_media;
+    std::vector<std::string> acquired_media;
+    auto acquireMedium = [&](const std::string& ename, const std::string& mname) -> int {
+        if (mname.empty())
+            return -1;
+        const JsonValue* def = nullptr;
+        if (media_defs.isArray())
+            for (const auto& m : media_defs.arr)
+                if (m.getString("name") == mname)
+                    def = &m;
+        if (!def)
+            fail("Entity " + ename + " has unknown medium " + mname);
+        for (size_t i = 0; i < acquired_media.size(); ++i)
+            if (acquired_media[i] == mname)
+                return (int)i;
+        const std::string mtype = def->getString("type");
+        ig_medium med{};
+        if (mtype == "homogeneous" || mtype == "constant") {
+            const V3 sa = getColor(*def, "sigma_a", V3(0, 0, 0), mname), ss = getColor(*def, "sigma_s", V3(0, 0, 0), mname);
+            med.sigma_a[0] = sa.x, med.sigma_a[1] = sa.y, med.sigma_a[2] = sa.z;
+            med.sigma_s[0] = ss.x, med.sigma_s[1] = ss.y, med.sigma_s[2] = ss.z;
+            med.g    = getConstNumber(*def, "g", 0.0f, mname);
+            med.type = IG_MEDIUM_HOMOGENEOUS;
+        } else if (mtype == "vacuum") {
+            med.type = IG_MEDIUM_VACUUM;
+        } else {
+            fail("No medium type '" + mtype + "' available");
+        }
+        acquired_media.push_back(mname);
+        sc->media.push_back(med);
+        return (int)acquired_media.size() - 1;
     };
     std::vector<MatKey> mat_keys;
     std::vector<std::vector<const JsonValue*>> groups;
@@ -1625,18 +1663,19 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         }
         if (!known)
             continue;
-        if (e.has("inner_medium") || e.has("outer_medium"))
-            fail("Entity " + ename + ": participating media are not supported by the HIP backend");
+        // the medium interface is part of the material (LoaderEntity.cpp:57-96)
+        const int m_in  = acquireMedium(ename, e.getString("inner_medium"));
+        const int m_out = acquireMedium(ename, e.getString("outer_medium"));
         if (area_light_of_entity.count(ename)) {
-            mat_keys.push_back(MatKey{ bname, ename });
+            mat_keys.push_back(MatKey{ bname, ename, m_in, m_out });
             groups.emplace_back().push_back(&e);
         } else {
             size_t id = 0;
             for (; id < mat_keys.size(); ++id)
-                if (mat_keys[id].bsdf == bname && mat_keys[id].light_entity.empty())
+                if (mat_keys[id].bsdf == bname && mat_keys[id].light_entity.empty() && mat_keys[id].medium_inner == m_in && mat_keys[id].medium_outer == m_out)
                     break;
             if (id == mat_keys.size()) {
-                mat_keys.push_back(MatKey{ bname, "" });
+                mat_keys.push_back(MatKey{ bname, "", m_in, m_out });
                 groups.emplace_back();
             }
             groups[id].push_back(&e);
@@ -2112,6 +2151,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         ig_material mat = lowerBsdf(mat_keys[m].bsdf, bsdfs, textures, bank, aux);
         if (!mat_keys[m].light_entity.empty())
             mat.light_id = (int32_t)infinite.size() + finite_index_of_entity.at(mat_keys[m].light_entity);
+        mat.pad[2] = ((mat_keys[m].medium_inner + 1) & 0xFFFF) | ((mat_keys[m].medium_outer + 1) << 16);
         sc->materials.push_back(mat);
         sc->material_names.push_back(mat_keys[m].bsdf);
     }
@@ -2174,6 +2214,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.sphere_leaf_count  = (uint32_t)sc->sphere_leaves.size();
     t.light_cdf          = sc->light_cdf.data();
     t.light_cdf_count    = (uint32_t)sc->light_cdf.size();
+    t.media              = sc->media.data();
+    t.media_count        = (uint32_t)sc->media.size();
     t.materials          = sc->materials.data();
     t.material_count     = (uint32_t)sc->materials.size();
     t.entity_per_material = sc->entity_per_material.data();

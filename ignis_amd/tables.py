@@ -58,6 +58,10 @@ class Texture(C.Structure):
                 ("wrap_u", C.c_uint32), ("wrap_v", C.c_uint32), ("offset", C.c_uint64)]
 
 
+class Medium(C.Structure):
+    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("type", C.c_int32)]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("entities", C.POINTER(C.c_float)), ("entity_count", C.c_uint32),
@@ -80,6 +84,7 @@ class Scene(C.Structure):
         ("sphere_nodes", C.POINTER(Node8)), ("sphere_node_count", C.c_uint32),
         ("sphere_leaves", C.POINTER(EntityLeaf1)), ("sphere_leaf_count", C.c_uint32),
         ("light_cdf", C.POINTER(C.c_float)), ("light_cdf_count", C.c_uint32),
+        ("media", C.POINTER(Medium)), ("media_count", C.c_uint32),
     ]
 
 

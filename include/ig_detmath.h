@@ -14,7 +14,7 @@
  * This header plays the role of libm for BOTH the product (HIP kernels) and
  * the test oracle; it holds no rendering algorithm.
  *
- * Polynomials: Cephes single-precision sinf/cosf/asinf (public domain, S. Moshier).
+ * Polynomials: Cephes single-precision sinf/cosf/asinf/expf/logf (public domain, S. Moshier).
  */
 #ifndef IG_DETMATH_H
 #define IG_DETMATH_H
@@ -235,6 +235,46 @@ IGM_FN float igm_exp(float x)
     /* 2^n in two factors so that n = 128 and the subnormal end stay representable */
     const int h    = n / 2;
     return (e * igm_float((uint32_t)(h + 127) << 23)) * igm_float((uint32_t)(n - h + 127) << 23);
+}
+
+/* ---- log (Cephes logf): x = m 2^e with sqrt(1/2) <= m < sqrt(2), degree-9 polynomial in m - 1 ---- */
+IGM_FN float igm_log(float x)
+{
+    if (x != x || x < 0.0f)
+        return igm_float(0x7FC00000u); /* NaN */
+    if (x == 0.0f)
+        return igm_float(0xFF800000u); /* -inf */
+    if (x == igm_float(0x7F800000u))
+        return x;
+    int e = 0;
+    uint32_t b = igm_bits(x);
+    if ((b & 0x7F800000u) == 0) { /* subnormal: scale by 2^23 first */
+        x = x * 8388608.0f;
+        b = igm_bits(x);
+        e = -23;
+    }
+    e += (int)(b >> 23) - 126;                               /* frexp: m in [0.5, 1) */
+    float m = igm_float((b & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p       = igm_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
+    p             = igm_fma(p, m, 1.1676998740e-1f);
+    p             = igm_fma(p, m, -1.2420140846e-1f);
+    p             = igm_fma(p, m, 1.4249322787e-1f);
+    p             = igm_fma(p, m, -1.6668057665e-1f);
+    p             = igm_fma(p, m, 2.0000714765e-1f);
+    p             = igm_fma(p, m, -2.4999993993e-1f);
+    p             = igm_fma(p, m, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float y        = (p * m) * z;
+    y              = igm_fma(-2.12194440e-4f, fe, y);
+    y              = igm_fma(-0.5f, z, y);
+    return igm_fma(0.693359375f, fe, m + y);
 }
 
 #endif /* IG_DETMATH_H */

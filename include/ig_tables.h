@@ -137,7 +137,9 @@ typedef struct ig_material {
     float p[12];
     float q[8];
     int32_t tex_refl; /* bitmap texture index of the diffuse reflectance (IG_MAT_IMAGE), -1 = none */
-    int32_t pad[3];
+    int32_t pad[3];   /* pad[0], pad[1]: blend; pad[2]: the medium interface of the entities that use this material
+                       * (make_medium_interface, src/artic/driver/medium.art:27-44; LoaderEntity.cpp:57-80):
+                       * (inner + 1) | (outer + 1) << 16, so 0 = no_medium_interface */
     float r[8];
 } ig_material;
 
@@ -272,7 +274,22 @@ enum ig_technique_type {
     /* ambient occlusion (make_ao_renderer, src/artic/technique/aotracer.art:1-24, AOTechnique.cpp): at every camera-ray hit one
      * cosine-distributed ray with the visibility flag of a bounce ray and no far end; white where it escapes. No bounces. */
     IG_TECHNIQUE_AO = 1,
+    /* volumetric path tracing (make_volume_path_renderer, src/artic/technique/volpathtracer.art:37-260, VolumePathTechnique.cpp):
+     * the path tracer with a current medium in the payload — transmittance on every segment, distance sampling and phase-function
+     * scattering in on_bounce, the medium changing at transmissions through entities with a medium interface. */
+    IG_TECHNIQUE_VOLPATH = 2,
 };
+
+/* One record per medium, in the order entities acquire them (LoaderMedium::acquire, src/runtime/loader/LoaderMedium.cpp:113-121;
+ * HomogeneousMedium.cpp: "homogeneous" / "constant"; VacuumMedium.cpp). The device builds make_homogeneous_medium
+ * (src/artic/medium/homogeneous.art:1-58) with a Henyey-Greenstein phase function (src/artic/phase/henyeygreenstein.art). */
+enum ig_medium_type { IG_MEDIUM_HOMOGENEOUS = 0, IG_MEDIUM_VACUUM = 1 };
+typedef struct ig_medium {
+    float sigma_a[3];
+    float sigma_s[3];
+    float g;
+    int32_t type; /* enum ig_medium_type */
+} ig_medium;
 
 typedef struct ig_technique {
     int32_t max_depth;      /* src/runtime/technique/PathTechnique.cpp:11 (default 64) */
@@ -348,6 +365,9 @@ typedef struct igd_scene {
      * LoaderLight.cpp:455-478): one float per finite light, without the leading zero, last entry 1 */
     const float* light_cdf;
     uint32_t light_cdf_count;
+    /* participating media (IG_TECHNIQUE_VOLPATH); ig_material.pad[2] names the two sides of an entity's surface */
+    const ig_medium* media;
+    uint32_t media_count;
 } igd_scene;
 
 #ifdef __cplusplus

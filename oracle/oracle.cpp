@@ -62,7 +62,7 @@ struct PrimaryStream {
         ent_id.resize(cap);
         prim_id.resize(cap);
         rnd.resize(cap);
-        payload.resize((size_t)cap * 6);
+        payload.resize((size_t)cap * 7); // 6 floats of the path tracer, 7 of the volumetric one (volpathtracer.art:1-25)
     }
 };
 
@@ -105,6 +105,7 @@ inline PTRayPayload read_payload(const PrimaryStream& s, int i)
     p.contrib = Color{ s.payload[c + i], s.payload[2 * c + i], s.payload[3 * c + i] };
     p.depth   = (int32_t)s.payload[4 * c + i];
     p.eta     = s.payload[5 * c + i];
+    p.medium  = (int32_t)s.payload[6 * c + i];
     return p;
 }
 
@@ -117,6 +118,7 @@ inline void write_payload(PrimaryStream& s, int i, const PTRayPayload& p)
     s.payload[3 * c + i] = p.contrib.b;
     s.payload[4 * c + i] = (float)p.depth;
     s.payload[5 * c + i] = p.eta;
+    s.payload[6 * c + i] = (float)p.medium;
 }
 
 template <typename T>
@@ -130,7 +132,7 @@ void swap_primary(PrimaryStream& s, int a, int b)
     swp(s.dir_x, a, b), swp(s.dir_y, a, b), swp(s.dir_z, a, b);
     swp(s.tmin, a, b), swp(s.tmax, a, b), swp(s.flags, a, b);
     swp(s.ent_id, a, b), swp(s.prim_id, a, b), swp(s.t, a, b), swp(s.u, a, b), swp(s.v, a, b), swp(s.rnd, a, b);
-    for (int c = 0; c < 6; ++c)
+    for (int c = 0; c < 7; ++c)
         std::swap(s.payload[(size_t)c * s.capacity + a], s.payload[(size_t)c * s.capacity + b]);
 }
 
@@ -175,7 +177,7 @@ int compact_primary(PrimaryStream& s, int size)
             s.dir_x[k] = s.dir_x[i], s.dir_y[k] = s.dir_y[i], s.dir_z[k] = s.dir_z[i];
             s.tmin[k] = s.tmin[i], s.tmax[k] = s.tmax[i], s.flags[k] = s.flags[i];
             s.rnd[k] = s.rnd[i];
-            for (int c = 0; c < 6; ++c)
+            for (int c = 0; c < 7; ++c)
                 s.payload[(size_t)c * s.capacity + k] = s.payload[(size_t)c * s.capacity + i];
             ++k;
         }
@@ -291,7 +293,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                 write_ray(primary, cur, ray);
                 primary.id[cur]  = valid ? (y * W + x) * spi + sample : -1;
                 primary.rnd[cur] = rnd.counter;
-                write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1 }); // init_pt_raypayload (pathtracer.art:33-38)
+                write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1, -1 }); // init_pt_raypayload (pathtracer.art:33-38), init_vpt_raypayload (volpathtracer.art:27-33)
             }
             current_size += n;
             id += n;
@@ -372,7 +374,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     }
 
                     Ray new_ray;
-                    if (pt_tech.on_bounce(ray, surf, rnd, payload, bsdf, new_ray)) {
+                    if (pt_tech.on_bounce(ray, surf, rnd, payload, bsdf, mat, new_ray)) {
                         write_ray(primary, i, new_ray);
                         primary.rnd[i] = rnd.counter;
                         write_payload(primary, i, payload);

@@ -2421,6 +2421,89 @@ struct PTRayPayload {
     Color contrib;
     int32_t depth;
     float eta;
+    int32_t medium; // VPTRayPayload (volpathtracer.art:1-7); the path tracer does not use it
+};
+
+// ---- medium/homogeneous.art:1-58, driver/medium.art (make_vacuum_medium), phase/henyeygreenstein.art
+struct MediumSampleOut {
+    Vec3 pos;
+    Color color; // transmittance / pdf
+};
+struct Medium {
+    bool vacuum     = true;
+    bool scattering = false;
+    Color sigma_t{ 0, 0, 0 };
+    int sigma_ind   = 0;
+    float sigma_t_p = 0;
+    float g         = 0;
+
+    Medium() = default;
+    explicit Medium(const ig_medium& m)
+    {
+        vacuum = m.type == IG_MEDIUM_VACUUM;
+        if (vacuum)
+            return;
+        const Color sigma_a{ m.sigma_a[0], m.sigma_a[1], m.sigma_a[2] }, sigma_s{ m.sigma_s[0], m.sigma_s[1], m.sigma_s[2] };
+        sigma_t    = color_add(sigma_a, sigma_s);
+        scattering = !(igm_abs(sigma_s.r) <= 1e-4f && igm_abs(sigma_s.g) <= 1e-4f && igm_abs(sigma_s.b) <= 1e-4f); // is_black_eps(sigma_s, 1e-4)
+        // vec3_min_index (core/vector.art:110)
+        sigma_ind = sigma_t.r < sigma_t.g ? (sigma_t.r < sigma_t.b ? 0 : 2) : (sigma_t.g < sigma_t.b ? 1 : 2);
+        sigma_t_p = sigma_ind == 0 ? sigma_t.r : (sigma_ind == 1 ? sigma_t.g : sigma_t.b);
+        g         = m.g;
+    }
+    Color eval_tr(float t) const { return Color{ igm_exp(-sigma_t.r * t), igm_exp(-sigma_t.g * t), igm_exp(-sigma_t.b * t) }; }
+    Color eval(Vec3 p_start, Vec3 p_end) const
+    {
+        if (vacuum)
+            return Color{ 1, 1, 1 };
+        return eval_tr(vec3_len(vec3_sub(p_end, p_start)));
+    }
+    Color eval_inf() const
+    {
+        if (vacuum)
+            return Color{ 1, 1, 1 };
+        if (!scattering) {
+            const bool clear = igm_abs(sigma_t.r) <= 1e-4f && igm_abs(sigma_t.g) <= 1e-4f && igm_abs(sigma_t.b) <= 1e-4f;
+            return clear ? Color{ 1, 1, 1 } : Color{ 0, 0, 0 };
+        }
+        return Color{ 0, 0, 0 };
+    }
+    // sample (homogeneous.art:38-52); vacuum and non-scattering media reject without touching the generator
+    bool sample(Rng& rnd, Vec3 p_start, Vec3 p_end, MediumSampleOut& out) const
+    {
+        if (vacuum || !scattering)
+            return false;
+        const float eps   = 1e-3f;
+        const Vec3 dir_u  = vec3_sub(p_end, p_start);
+        const float dist  = vec3_len(dir_u);
+        const float ndist = igm_min(dist, -igm_log(1 - rnd.next_f32() * 0.99999f) / sigma_t_p);
+        if (igm_abs(dist - ndist) <= eps)
+            return false;
+        const Vec3 dir  = vec3_mulf(dir_u, safe_div(1, dist));
+        out.pos         = vec3_add(p_start, vec3_mulf(dir, ndist));
+        const Color tr  = eval_tr(ndist);
+        const float pdf = (sigma_ind == 0 ? tr.r : (sigma_ind == 1 ? tr.g : tr.b)) * sigma_t_p;
+        out.color       = Color{ tr.r / pdf, tr.g / pdf, tr.b / pdf };
+        return true;
+    }
+    // make_henyeygreenstein_phase(g).sample (henyeygreenstein.art:20-38): weight 1; the anisotropic branch returns the direction
+    // in the sampling frame itself (it is not rotated about out_dir), as written there
+    Vec3 sample_phase(Rng& rnd) const
+    {
+        if (igm_abs(g) <= 1e-3f) {
+            const float u = rnd.next_f32();
+            const float v = rnd.next_f32();
+            const float c = 2 * v - 1; // sample_uniform_sphere (core/sampling.art:42-47)
+            const float sn = safe_sqrt(1 - c * c);
+            const float phi = 2 * flt_pi * u;
+            return make_vec3(sn * igm_cos(phi), sn * igm_sin(phi), c);
+        }
+        const float sqr_term  = (1 - g * g) / (1 + g - 2 * g * rnd.next_f32());
+        const float cos_theta = -(1 + g * g - sqr_term * sqr_term) / (2 * g);
+        const float sin_theta = igm_sqrt(igm_max(0.0f, 1 - cos_theta * cos_theta));
+        const float phi       = 2 * flt_pi * rnd.next_f32();
+        return make_vec3(sin_theta * igm_cos(phi), sin_theta * igm_sin(phi), cos_theta);
+    }
 };
 
 static inline float russian_roulette_pbrt(Color c, float clamp) { return clampf(color_max_component(c), 0.05f, clamp); } // pathtracer.art:5
@@ -2445,8 +2528,13 @@ struct PathTracer {
         , clamp_value(s.technique.clamp)
         , enable_nee(s.technique.nee != 0)
         , ambient_occlusion(s.technique.type == IG_TECHNIQUE_AO)
+        , volumetric(s.technique.type == IG_TECHNIQUE_VOLPATH)
     {
     }
+    // make_volume_path_renderer (technique/volpathtracer.art:37-260): the same callbacks with a current medium
+    bool volumetric;
+    // get_medium (volpathtracer.art:46-49) over the media table of LoaderMedium::generate (LoaderMedium.cpp:89-111): unknown ids are vacuum
+    Medium get_medium(int32_t id) const { return (volumetric && id >= 0 && (uint32_t)id < sc.media_count) ? Medium(sc.media[id]) : Medium(); }
     // make_ao_renderer (technique/aotracer.art:1-24): only on_shadow does anything
     bool ambient_occlusion;
 
@@ -2624,9 +2712,14 @@ struct PathTracer {
         const Vec3 in_dir  = ls.dir;
         const Vec3 out_dir = vec3_neg(ray.dir);
 
+        // volpathtracer.art:39-41: the last interaction was a medium one; transmittance from the ray origin to this hit
+        const bool was_medium_interaction = volumetric && igm_signbit(pt.inv_pdf);
+        const Medium medium               = get_medium(pt.medium);
+        const Color hitvol                = medium.eval(ray.org, surf.point);
+
         if (ls.cos > flt_eps) {
             float mis;
-            if (delta) {
+            if (delta || was_medium_interaction) {
                 mis = 1;
             } else {
                 const float pdf_e_s = bsdf.pdf(in_dir, out_dir);
@@ -2643,6 +2736,8 @@ struct PathTracer {
                 out.ray = make_ray(surf.point, in_dir, offset, flt_max, IG_RAY_FLAG_SHADOW);
             else
                 out.ray = make_ray(surf.point, vec3_sub(ls.pos, surf.point), offset, 1 - offset, IG_RAY_FLAG_SHADOW);
+            if (volumetric) // volpathtracer.art:71-83: the medium the path is in, up to the hit and on towards the light
+                out.color = color_mul(contrib, color_mul(hitvol, infinite ? medium.eval_inf() : medium.eval(surf.point, ls.pos)));
         }
         return out;
     }
@@ -2669,6 +2764,14 @@ struct PathTracer {
                     const PlaneEmitter pe(light);
                     emit  = pe.radiance;            // light.emission(ctx)
                     pdf_s = pe.pdf_direct(ray.org); // solid-angle pdf: as_solid is the identity
+                }
+                if (volumetric) {
+                    // volpathtracer.art:97-109: medium interactions (negative inv_pdf) count as pdf-less, the emission is attenuated
+                    const float inv_pdf = igm_max(0.0f, pt.inv_pdf);
+                    const float mis     = enable_nee ? 1 / (1 + inv_pdf * select_pdf(mat.light_id, ray.org) * pdf_s) : 1.0f;
+                    const Color vol     = get_medium(pt.medium).eval(ray.org, surf.point);
+                    out                 = handle_color(color_mulf(color_mul(pt.contrib, color_mul(emit, vol)), mis));
+                    return true;
                 }
                 const float mis = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf(mat.light_id, ray.org) * pdf_s) : 1.0f;
                 out             = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
@@ -2717,6 +2820,13 @@ struct PathTracer {
                 emit  = Color{ light.d[0], light.d[1], light.d[2] };
                 pdf_s = 1 / (4 * flt_pi); // equal_area_sphere_pdf (env.art:101)
             }
+            if (volumetric) {
+                // volpathtracer.art:131-138
+                const float mis = enable_nee ? 1 / (1 + igm_max(0.0f, pt.inv_pdf) * select_pdf((int32_t)i, ray.org) * pdf_s) : 1.0f;
+                const Color c   = handle_color(color_mulf(color_mul(pt.contrib, color_mul(emit, get_medium(pt.medium).eval_inf())), mis));
+                color           = color_add(color, c);
+                continue;
+            }
             const float mis   = enable_nee ? 1 / (1 + pt.inv_pdf * select_pdf((int32_t)i, ray.org) * pdf_s) : 1.0f;
             const Color c     = handle_color(color_mulf(color_mul(pt.contrib, emit), mis));
             color             = Color{ color.r + c.r, color.g + c.g, color.b + c.b };
@@ -2729,7 +2839,7 @@ struct PathTracer {
     }
 
     // on_bounce (pathtracer.art:170-210)
-    bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, Ray& new_ray) const
+    bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, const ig_material& mat, Ray& new_ray) const
     {
         if (ambient_occlusion)
             return false;
@@ -2737,6 +2847,43 @@ struct PathTracer {
             return false;
 
         const Vec3 out_dir = vec3_neg(ray.dir);
+        if (volumetric) {
+            // on_bounce of make_volume_path_renderer (volpathtracer.art:155-247)
+            const Medium medium = get_medium(pt.medium);
+            MediumSampleOut msmp;
+            if (medium.sample(rnd, ray.org, surf.point, msmp)) {
+                const Vec3 in_dir   = medium.sample_phase(rnd);
+                const Color contrib = color_mul(pt.contrib, msmp.color); // phase weight 1
+                const float rr_prob = (pt.depth + 1 > min_path_len) ? russian_roulette_pbrt(color_mulf(contrib, pt.eta * pt.eta), 0.95f) : 1.0f;
+                if (rnd.next_f32() >= rr_prob)
+                    return false;
+                pt.inv_pdf = -1; // "the last interaction was a medium"
+                pt.contrib = color_mulf(contrib, 1 / rr_prob);
+                pt.depth   = pt.depth + 1;
+                new_ray    = make_ray(msmp.pos, in_dir, 0, flt_max, IG_RAY_FLAG_BOUNCE);
+                return true;
+            }
+            BsdfSample ms;
+            if (!bsdf.sample(rnd, out_dir, ms))
+                return false;
+            if (ms.pdf <= flt_eps)
+                return false;
+            const Color vol_contrib = color_mul(medium.eval(ray.org, surf.point), pt.contrib);
+            const Color contrib     = color_mul(vol_contrib, ms.color);
+            const float rr_prob     = (pt.depth + 1 > min_path_len) ? russian_roulette_pbrt(color_mulf(contrib, pt.eta * pt.eta), 0.95f) : 1.0f;
+            if (rnd.next_f32() >= rr_prob)
+                return false;
+            // a transmission enters the medium on the other side of the interface (make_medium_interface.pick, driver/medium.art:34-38)
+            const bool is_transmission = igm_signbit(vec3_dot(surf.local.col[2], ms.in_dir));
+            const int32_t inner = (mat.pad[2] & 0xFFFF) - 1, outer = ((mat.pad[2] >> 16) & 0xFFFF) - 1;
+            pt.medium  = is_transmission ? (surf.is_entering ? inner : outer) : pt.medium;
+            pt.inv_pdf = ms.is_delta ? 0 : 1 / ms.pdf;
+            pt.contrib = color_mulf(contrib, 1 / rr_prob);
+            pt.depth   = pt.depth + 1;
+            pt.eta     = pt.eta * ms.eta;
+            new_ray    = make_ray(surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+            return true;
+        }
         BsdfSample ms;
         if (!bsdf.sample(rnd, out_dir, ms))
             return false;

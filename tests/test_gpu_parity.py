@@ -865,6 +865,35 @@ def test_perez_sky_vs_oracle(gpu_device, extra):
     _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=29, iters=2)
 
 
+@pytest.mark.parametrize("media,nee", [
+    ([{"type": "homogeneous", "name": "fog", "sigma_a": [0.65, 1.0, 0.75], "sigma_s": 0}], True),
+    ([{"type": "constant", "name": "fog", "sigma_a": [0.1, 0.2, 0.3], "sigma_s": [1.5, 1.0, 0.5], "g": 0.0}], True),
+    ([{"type": "homogeneous", "name": "fog", "sigma_a": 0.05, "sigma_s": [0.8, 0.9, 1.2], "g": 0.6}], True),
+    ([{"type": "homogeneous", "name": "fog", "sigma_a": 0.2, "sigma_s": 0.7, "g": -0.4}, {"type": "vacuum", "name": "hole"}], False),
+], ids=["absorbing", "isotropic", "forward-hg", "backward-hg-vacuum-bubble-no-nee"])
+def test_volume_path_tracer_vs_oracle(gpu_device, media, nee):
+    """make_volume_path_renderer (technique/volpathtracer.art): diamond_scene with a fog-filled box around one diamond (passthrough
+    boundary, inner medium), optionally a vacuum bubble inside it (outer_medium names what lies around it), lit by the area light and a
+    sky: transmittance on NEE / emission / miss, distance sampling, Henyey-Greenstein scattering, medium changes at transmissions."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["technique"] = {"type": "volpath", "max_depth": 12, "nee": nee}
+    s["media"] = media
+    s["bsdfs"].append({"type": "passthrough", "name": "null"})
+    s["shapes"].append({"type": "cube", "name": "fogbox", "width": 1.2, "height": 1.0, "depth": 1.2})
+    s["entities"].append({"name": "fogbox", "shape": "fogbox", "bsdf": "null", "inner_medium": "fog", "transform": [{"translate": [0, -0.45, 0]}]})
+    if len(media) > 1:
+        s["shapes"].append({"type": "icosphere", "name": "bubble", "radius": 0.25, "subdivions": 2})
+        s["entities"].append({"name": "bubble", "shape": "bubble", "bsdf": "null", "inner_medium": "hole", "outer_medium": "fog",
+                              "transform": [{"translate": [0.3, -0.4, 0.3]}]})
+    s["lights"] = s["lights"] + [{"type": "env", "name": "sky", "radiance": [0.3, 0.35, 0.4]}]
+    s["entities"] = [e for e in s["entities"] if e["name"] != "Back"]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 64)
+    assert sc.scene.technique.type == 2 and sc.scene.media_count == len(media)
+    tot = _compare_with_oracle(gpu_device, sc, 96, 64, 4, seed=31, iters=2)
+    assert tot["bounce_rays"] > tot["camera_rays"]
+
+
 @pytest.mark.parametrize("scene_name,cap", [("diamond_scene.json", 0), ("diamond_scene_principled.json", 4096), ("many_point_lights_hip.json", 0)])
 def test_info_buffer_aovs_vs_oracle(scene_name, cap):
     """The "Normals" / "Albedo" AOVs the runtime adds for its denoiser: first hits of iteration 0's camera rays, unchanged by
