@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SCENES, flat_scene
+from conftest import GOLDEN, ROOT, SCENES, flat_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -1208,3 +1208,57 @@ def test_transparent_bsdf_in_blends_vs_oracle(gpu_device):
     types = sorted(scene.scene.materials[i].bsdf_type for i in range(scene.scene.material_count))
     assert types.count(7) >= 2 and types.count(6) == 2
     _compare_with_oracle(gpu_device, scene, 96, 96, 4, seed=21, iters=2)
+
+
+def test_reference_like_bvh_build_vs_oracle():
+    """`IGH_BVH_REFERENCE=1` builds the BVHs with the reference's parameters (madmann91/bvh defaults: leaves of up to 4 primitives,
+    collapse by SAH cost) instead of the <8, 4>-tuned default; the switch is read once per process, so this runs in a child.
+    Hits, radiance and every counter equal the oracle's on the same tables, and the tables differ from the default build."""
+    import subprocess
+    import sys
+    code = r"""
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import oracle
+from ignis_amd import Device
+from ignis_amd.tables import LoadedScene
+sc = LoadedScene.from_file(os.path.join("scenes", "diamond_scene.json"), 160, 120)
+dev = Device(0, acquire_stats=1)
+dev.assign_scene(sc)
+ref = np.zeros((120, 160, 3), np.float32)
+tot = {}
+for it in range(2):
+    dev.render(4, 160, 120, iteration=it, seed=9)
+    _, st = oracle.render(sc, 4, 160, 120, iteration=it, seed=9, fb=ref)
+    for k, v in st.items():
+        tot[k] = tot.get(k, 0) + v
+fb, st = dev.framebuffer(), dev.stats()
+dev.close()
+print(json.dumps({"l2": float(np.linalg.norm(fb - ref) / np.linalg.norm(ref)), "nodes": int(sc.scene.primbvh_size),
+                  "counters": {k: [int(st[k]), int(tot[k])] for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves")}}))
+"""
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, IGH_BVH_REFERENCE=flag)
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out[flag]["l2"] <= RADIANCE_TOL
+        for k, (got, want) in out[flag]["counters"].items():
+            assert got == want, (flag, k)
+    assert out["1"]["nodes"] != out["0"]["nodes"]  # the two builds really differ
+    assert out["1"]["counters"]["nodes"][0] != out["0"]["counters"]["nodes"][0]
+
+
+def test_request_sizes_beyond_the_ray_id_range_are_refused(gpu_device, diamond_scene):
+    """Ray ids are i32 like the reference's (id = pixel * spi + sample, mapping_gpu.art:655): a call whose width * height * spi *
+    iterations reaches 2^31 is refused up front with a message, the device stays usable."""
+    from ignis_amd import DeviceError
+    gpu_device.assign_scene(diamond_scene)
+    with pytest.raises(DeviceError, match="2\\^31"):
+        gpu_device.render(128, 4096, 4096, iteration=0, seed=1)
+    gpu_device.resize(64, 64)
+    gpu_device.clear_framebuffer()
+    gpu_device.render(2, 64, 64, iteration=0, seed=1)
+    assert np.isfinite(gpu_device.framebuffer()).all()
