@@ -256,6 +256,49 @@ struct ConstExpr {
                 ok &= eat(')') && n >= 3;
                 return Val{ V3(c[0], c[1], c[2]), false };
             }
+        // the constants and a few of the scalar functions of the expression language (Transpiler.cpp:338-372,644-700)
+        struct Named {
+            const char* name;
+            float value;
+        };
+        for (const Named& c : { Named{ "Pi", Pi }, Named{ "Eps", 1.1920928955e-07f }, Named{ "E", 2.718281828459045f } }) {
+            const size_t n = std::strlen(c.name);
+            if (s.compare(pos, n, c.name) == 0 && (pos + n >= s.size() || !(std::isalnum((unsigned char)s[pos + n]) || s[pos + n] == '_' || s[pos + n] == '('))) {
+                pos += n;
+                return Val{ V3(c.value, c.value, c.value), true };
+            }
+        }
+        for (const char* fn : { "sqrt(", "abs(", "sin(", "cos(", "tan(", "exp(", "log(", "rad(", "deg(", "min(", "max(", "pow(", "clamp(" })
+            if (s.compare(pos, std::strlen(fn), fn) == 0) {
+                const std::string name(fn, std::strlen(fn) - 1);
+                pos += std::strlen(fn);
+                float a[3] = { 0, 0, 0 };
+                int n      = 0;
+                do {
+                    const Val v = sum();
+                    ok &= v.scalar && n < 3;
+                    if (n < 3)
+                        a[n] = v.v.x;
+                    ++n;
+                } while (ok && eat(','));
+                const int want = (name == "min" || name == "max" || name == "pow") ? 2 : (name == "clamp" ? 3 : 1);
+                ok &= eat(')') && n == want;
+                float r = 0;
+                if (name == "sqrt") r = std::sqrt(a[0]);
+                else if (name == "abs") r = std::fabs(a[0]);
+                else if (name == "sin") r = std::sin(a[0]);
+                else if (name == "cos") r = std::cos(a[0]);
+                else if (name == "tan") r = std::tan(a[0]);
+                else if (name == "exp") r = std::exp(a[0]);
+                else if (name == "log") r = std::log(a[0]);
+                else if (name == "rad") r = a[0] * Deg2Rad;
+                else if (name == "deg") r = a[0] / Deg2Rad;
+                else if (name == "min") r = std::min(a[0], a[1]);
+                else if (name == "max") r = std::max(a[0], a[1]);
+                else if (name == "pow") r = std::pow(a[0], a[1]);
+                else r = std::min(std::max(a[0], a[1]), a[2]);
+                return Val{ V3(r, r, r), true };
+            }
         const char* begin = s.c_str() + pos;
         char* end         = nullptr;
         const float f     = std::strtof(begin, &end);
@@ -266,6 +309,16 @@ struct ConstExpr {
         pos += (size_t)(end - begin);
         return Val{ V3(f, f, f), true };
     }
+    // `^` is PExpr's power operator: tighter than a sign, right-associative
+    Val power()
+    {
+        const Val a = primary();
+        if (ok && eat('^')) {
+            const Val b = unary();
+            return Val{ V3(std::pow(a.v.x, b.v.x), std::pow(a.v.y, b.v.y), std::pow(a.v.z, b.v.z)), a.scalar && b.scalar };
+        }
+        return a;
+    }
     Val unary()
     {
         if (eat('-')) {
@@ -273,7 +326,7 @@ struct ConstExpr {
             return Val{ V3(-v.v.x, -v.v.y, -v.v.z), v.scalar };
         }
         eat('+');
-        return primary();
+        return power();
     }
     Val product()
     {
@@ -345,6 +398,11 @@ static float getConstNumber(const JsonValue& obj, const std::string& key, float 
     const JsonValue* v = obj.find(key);
     if (!v)
         return def;
+    if (v->isString()) { // a constant expression such as "(0.175)^2" (the Blender exporter writes roughness that way)
+        V3 c;
+        if (ConstExpr::evaluate(v->str, c) && c.x == c.y && c.y == c.z)
+            return c.x;
+    }
     if (!v->isNumber())
         fail("'" + owner + "': property '" + key + "' is not a constant number; expressions and textures here are not supported by the HIP backend");
     return (float)v->num;

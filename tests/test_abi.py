@@ -756,3 +756,27 @@ def test_plane_detection_frames_and_rejections():
     uvs = [[0.1, 0.2], [0.9, 0.2], [0.9, 0.8], [0.1, 0.8]]
     kind, d = _area_light_on_inline_mesh(quad, [[0, 1, 2], [0, 2, 3]], uvs)
     assert kind == 0
+
+
+def test_constant_expressions_in_number_and_colour_properties():
+    """The exporters write numbers as expressions (`"roughness": "(0.175)^2"`); constant ones are folded by the loader: PExpr's power
+    operator (tighter than a sign, right-associative), Pi / E / Eps, a few scalar functions; anything with variables is refused."""
+    import json
+    from conftest import SCENES, flat_scene
+    from ignis_amd.tables import LoadedScene
+
+    def material(bsdf):
+        s = flat_scene([{"type": "env", "name": "sky", "radiance": [1, 1, 1]}])
+        s["bsdfs"] = [dict({"name": "ground"}, **bsdf)]
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 16, 16)
+        m = sc.scene.materials[0]
+        return [float(x) for x in m.p]
+
+    p = material({"type": "dielectric", "roughness": "(0.17499999701976776)^2", "int_ior": "1 + 0.55"})
+    assert p[9] == pytest.approx(0.175 ** 2, rel=1e-6) and p[10] == p[9] and p[1] == pytest.approx(1.55)
+    p = material({"type": "diffuse", "reflectance": "color(0.5, 0.25, 1) * -2^2 * -0.25"})  # -(2^2)
+    assert p[0:3] == pytest.approx([0.5, 0.25, 1.0])
+    p = material({"type": "diffuse", "reflectance": "color(cos(Pi), 2^3^2 / 512, sqrt(max(4, 1)))"})
+    assert p[0:3] == pytest.approx([-1.0, 1.0, 2.0], abs=1e-6)
+    with pytest.raises(RuntimeError, match="not a constant number"):
+        material({"type": "dielectric", "roughness": "uv.x * 0.5"})

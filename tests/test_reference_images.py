@@ -75,6 +75,10 @@ EXCLUDED = {
                             "Lambertian body must show, while the Cycles image has 0.50 on body AND cap (i.e. an effective albedo of ~0.62: the "
                             "JSON was edited by hand after the export, scenes/evaluation/README.md); the lit side is another factor ~pi up "
                             "because the exporter writes Blender watts as Ignis `power` (scripts/blender_exporter/ignis_blender/light.py:57-66).",
+    "flipped-prim-glass": "the same base scene as flipped-prim-diffuse with a rough-glass cylinder: the background is exact (ratio 1.00 along the "
+                          "image border), the cylinder is lit by the same 1000 W point light whose Blender-watt convention makes an Ignis render ~pi "
+                          "brighter than the Cycles image, and what the point light sends through the rough glass arrives as fireflies (8 x 8 blocks up to "
+                          "60x at 128 spp).",
     "sun-on-plane-and-stick": "the sun of the JSON / .rad sits exactly on the horizon (direction z = 0) and lights the stick from the right; the "
                               "Radiance image shows an evenly lit plane without a cast shadow and the stick lit from the left: image and scene disagree.",
     "three-planes-dielectric": "the camera looks through a single dielectric interface (ior 1.55) at a plane and a light INSIDE the medium. The image "
