@@ -119,9 +119,10 @@ struct igd_device {
     DevBuf<uint8_t> texture_data;
     DevBuf<float> cdf_data;
     // info-buffer AOVs (igd_setup.info_aovs): [0] "Normals", [1] "Albedo", film-sized like the colour buffer
-    DevBuf<float> aov[2];
-    std::vector<float> aov_host[2];
-    bool aov_host_dirty[2] = { true, true };
+    // [2] "Direct Weights", [3] "NEE Weights": path tracer with ig_technique.aov_mis (allocated when such a scene is assigned)
+    DevBuf<float> aov[4];
+    std::vector<float> aov_host[4];
+    bool aov_host_dirty[4] = { true, true, true, true };
     DevBuf<float> info_tmp[2]; // per-sample values of one chunk (float4 each)
     DevBuf<QueueState> info_qs;
     uint32_t tail_lanes = 0; // lanes of one tail grid (its share of the deep-stack columns)
@@ -141,6 +142,7 @@ struct igd_device {
     // rounds of chunk k + 1. Everything a chunk's second half touches therefore exists once per flight slot.
     struct Flight {
         DevBuf<float> accum;     // per-sample radiance accumulators of the chunk
+        DevBuf<float> accum_mis[2]; // the same for "Direct Weights" / "NEE Weights" (aov_mis), allocated on demand
         DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
         DevBuf<float> tail_long; // those still alive after a pass (the two buffers alternate)
         DevBuf<uint32_t> tail_ctr; // per pass: [2 * j] output count, [2 * j + 1] fetch counter
@@ -276,8 +278,11 @@ struct igd_device {
             primary[s].release();
         secondary.release();
         deep_rays.release();
-        for (auto& f : flight)
+        for (auto& f : flight) {
             f.accum.release();
+            f.accum_mis[0].release();
+            f.accum_mis[1].release();
+        }
         capacity   = 0;
         mem_capped = false;
     }
@@ -616,23 +621,28 @@ void clearOnStream(hipStream_t st, void* ptr, int value, size_t bytes)
 
 void resizeFb(igd_device* d, int w, int h)
 {
-    if (w == d->fb_w && h == d->fb_h && d->fb.ptr)
-        return;
-    d->fb.release();
-    d->fb.alloc((size_t)w * h * 3);
-    clearOnStream(d->stream, d->fb.ptr, 0, (size_t)w * h * 3 * sizeof(float));
-    d->fb_w = w;
-    d->fb_h = h;
-    d->fb_host.assign((size_t)w * h * 3, 0.0f);
-    d->fb_host_dirty = true;
-    if (d->setup.info_aovs)
-        for (int k = 0; k < 2; ++k) {
-            d->aov[k].release();
-            d->aov[k].alloc((size_t)w * h * 3);
-            clearOnStream(d->stream, d->aov[k].ptr, 0, (size_t)w * h * 3 * sizeof(float));
-            d->aov_host[k].assign((size_t)w * h * 3, 0.0f);
-            d->aov_host_dirty[k] = true;
-        }
+    const bool same = w == d->fb_w && h == d->fb_h && d->fb.ptr;
+    if (!same) {
+        d->fb.release();
+        d->fb.alloc((size_t)w * h * 3);
+        clearOnStream(d->stream, d->fb.ptr, 0, (size_t)w * h * 3 * sizeof(float));
+        d->fb_w = w;
+        d->fb_h = h;
+        d->fb_host.assign((size_t)w * h * 3, 0.0f);
+        d->fb_host_dirty = true;
+    }
+    for (int k = 0; k < 4; ++k) {
+        const bool wanted = k < 2 ? d->setup.info_aovs != 0 : (d->has_scene && d->dscene.tech.aov_mis != 0);
+        if (same && (wanted == (d->aov[k].ptr != nullptr)))
+            continue; // (the MIS AOVs come and go with the scene's technique)
+        d->aov[k].release();
+        if (!wanted)
+            continue;
+        d->aov[k].alloc((size_t)w * h * 3);
+        clearOnStream(d->stream, d->aov[k].ptr, 0, (size_t)w * h * 3 * sizeof(float));
+        d->aov_host[k].assign((size_t)w * h * 3, 0.0f);
+        d->aov_host_dirty[k] = true;
+    }
 }
 
 // Polls the queue sizes of the chunk in flight on the main stream (64 bytes, pinned).
@@ -934,6 +944,14 @@ void render(igd_device* d, const igd_render_settings* rs)
         ++d->chunk_seq;
         QueueState* qs = fl.qs;
         float4* accum  = reinterpret_cast<float4*>(fl.accum.ptr);
+        // "Direct Weights" / "NEE Weights" (ig_technique.aov_mis): two more accumulators per sample, resolved like the colour
+        const bool mis_aovs = d->dscene.tech.aov_mis != 0;
+        float4* accum_mis[2] = { nullptr, nullptr };
+        if (mis_aovs)
+            for (int k = 0; k < 2; ++k) {
+                fl.accum_mis[k].alloc((size_t)n * 4);
+                accum_mis[k] = reinterpret_cast<float4*>(fl.accum_mis[k].ptr);
+            }
 
         auto timed = [&](int kind, hipStream_t on, const std::function<void()>& fn) {
             if (!stats) {
@@ -950,6 +968,9 @@ void render(igd_device* d, const igd_render_settings* rs)
         fl.pending = true; // from here on the slot owns work that collect() has to wait for
         HIP_CHECK(hipEventRecord(fl.done, st)); // placeholder so that an early throw leaves a valid event
         HIP_CHECK(hipMemsetAsync(fl.accum.ptr, 0, (size_t)n * 4 * sizeof(float), st));
+        for (int k = 0; k < 2; ++k)
+            if (accum_mis[k])
+                HIP_CHECK(hipMemsetAsync(accum_mis[k], 0, (size_t)n * 4 * sizeof(float), st));
         HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
 
         int in_slot = 0;
@@ -1011,6 +1032,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.id_base   = first;
             sa.frame     = frame;
             sa.inv_spi   = inv;
+            sa.accum_direct = accum_mis[0];
             timed(2, on, [&] {
                 launch_shade(sa, shade_grid, d->full_bsdfs, on);
                 launch_round_end(qs, in_slot, on);
@@ -1029,6 +1051,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.hit     = b.sec_hit; // only with a sphere pass (null otherwise)
             tb.sphere_work_counter = &qs->work_counter[5];
             tb.accum   = accum;
+            tb.accum_nee = accum_mis[1];
             tb.id_base = first;
             tb.inv_spi = inv;
             timed(3, on, [&] {
@@ -1051,7 +1074,7 @@ void render(igd_device* d, const igd_render_settings* rs)
         for (int round = 0;; ++round) {
             if (known_live == 0)
                 break;
-            if (known_live <= d->tail_threshold) {
+            if (known_live <= d->tail_threshold && !mis_aovs) { // (the tail kernels keep one accumulator per path: rounds to the end instead)
                 live     = known_live;
                 run_tail = true;
                 break;
@@ -1191,6 +1214,14 @@ void render(igd_device* d, const igd_render_settings* rs)
         if (prev.used && &prev != &fl)
             HIP_CHECK(hipStreamWaitEvent(side, prev.resolved, 0));
         timed(4, side, [&] { launch_resolve(ra, side); });
+        for (int k = 0; k < 2; ++k)
+            if (accum_mis[k]) {
+                ResolveArgs rm = ra;
+                rm.accum       = accum_mis[k];
+                rm.fb          = d->aov[2 + k].ptr;
+                launch_resolve(rm, side);
+                d->aov_host_dirty[2 + k] = true;
+            }
         HIP_CHECK(hipEventRecord(fl.resolved, side));
         fl.used = true;
         HIP_CHECK(hipMemcpyAsync(fl.host, qs, sizeof(QueueState), hipMemcpyDeviceToHost, side));
@@ -1338,6 +1369,12 @@ FilmBuffer filmBuffer(igd_device* d, const char* name)
         if (std::strcmp(name, "Albedo") == 0)
             return FilmBuffer{ &d->aov[1], &d->aov_host[1], &d->aov_host_dirty[1] };
     }
+    if (d->has_scene && d->dscene.tech.aov_mis) { // PathTechnique.cpp:24-25
+        if (std::strcmp(name, "Direct Weights") == 0)
+            return FilmBuffer{ &d->aov[2], &d->aov_host[2], &d->aov_host_dirty[2] };
+        if (std::strcmp(name, "NEE Weights") == 0)
+            return FilmBuffer{ &d->aov[3], &d->aov_host[3], &d->aov_host_dirty[3] };
+    }
     throw HipError{ IGD_ERR_INVALID_ARG, std::string("unknown AOV '") + name + "'" };
 }
 
@@ -1375,6 +1412,10 @@ NamedBuffer namedBuffer(igd_device* d, const char* name)
         return of(d->aov[0]);
     if (d->setup.info_aovs && n == "Albedo")
         return of(d->aov[1]);
+    if (d->dscene.tech.aov_mis && n == "Direct Weights")
+        return of(d->aov[2]);
+    if (d->dscene.tech.aov_mis && n == "NEE Weights")
+        return of(d->aov[3]);
     return {};
 }
 } // namespace
@@ -1512,7 +1553,7 @@ int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
         resizeFb(dev, width, height);
         clearOnStream(dev->stream, dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float));
         dev->fb_host_dirty = true;
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 4; ++k)
             if (dev->aov[k].ptr) {
                 clearOnStream(dev->stream, dev->aov[k].ptr, 0, (size_t)width * height * 3 * sizeof(float));
                 dev->aov_host_dirty[k] = true;

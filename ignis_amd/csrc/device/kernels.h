@@ -118,6 +118,7 @@ struct TraverseArgs {
     // any-hit epilogue (shadow rays): unoccluded rays add col.rgb into accum[id - id_base], id = bits(col.w)
     const float4* col;
     float4* accum;
+    float4* accum_nee; // "NEE Weights" (ig_technique.aov_mis): the same splat once more, or null
     int64_t id_base;
     float inv_spi;
     // scenes with analytic spheres: the launch over the triangle BVH is followed by one over the sphere BVH that starts from its
@@ -161,6 +162,7 @@ struct ShadeArgs {
     uint32_t* out_count;
     QueueState* qs;
     float4* accum;   // per-sample radiance accumulators, (r, g, b, unused)
+    float4* accum_direct; // "Direct Weights" (ig_technique.aov_mis): the emission of surfaces hit, or null
     int64_t id_base; // local ray id of accum[0]
     ShadeFrame frame;
     float inv_spi;

@@ -320,6 +320,14 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : 4) k
                 v.y += out.radiance.g * a.inv_spi;
                 v.z += out.radiance.b * a.inv_spi;
                 *acc = v;
+                if (a.accum_direct && in.ent >= 0) { // aov_di.splat in on_hit (technique/pathtracer.art:133); on_miss has none
+                    float4* di = a.accum_direct + ((int64_t)ray_id - a.id_base);
+                    float4 w   = *di;
+                    w.x += out.radiance.r * a.inv_spi;
+                    w.y += out.radiance.g * a.inv_spi;
+                    w.z += out.radiance.b * a.inv_spi;
+                    *di = w;
+                }
             }
         }
 

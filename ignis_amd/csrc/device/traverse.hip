@@ -127,6 +127,14 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             v.y += c.y * a.inv_spi;
                             v.z += c.z * a.inv_spi;
                             *dst = v;
+                            if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
+                                float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
+                                float4 w   = *nd;
+                                w.x += c.x * a.inv_spi;
+                                w.y += c.y * a.inv_spi;
+                                w.z += c.z * a.inv_spi;
+                                *nd = w;
+                            }
                         }
                     }
                 } else {

@@ -1527,7 +1527,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     auto sc = std::make_unique<Scene>();
 
     // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
-    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH };
+    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0 };
     std::string selector;
     if (const JsonValue* t = doc.find("technique")) {
         const std::string type = t->getString("type", "path");
@@ -1542,8 +1542,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         tech.clamp     = t->getNumber("clamp", 0.0f);
         tech.nee       = t->getBool("nee", true) ? 1 : 0;
         selector       = t->getString("light_selector");
-        if (t->getBool("aov_mis", false))
-            fail("Technique option 'aov_mis' (advanced shadow handling) is not supported by the HIP backend");
+        tech.aov_mis = (tech.type == IG_TECHNIQUE_PATH && t->getBool("aov_mis", false)) ? 1 : 0; // PathTechnique.cpp:16
     }
 
     // ---- film (Runtime.cpp:38-54)

@@ -298,6 +298,9 @@ typedef struct ig_technique {
     int32_t nee;            /* default 1 */
     int32_t light_selector; /* enum ig_light_selector */
     int32_t type;           /* enum ig_technique_type */
+    int32_t aov_mis;        /* path tracer only (PathTechnique.cpp:16-27,56-61): also accumulate the AOVs "Direct Weights" (the MIS-weighted
+                             * emission of surfaces a path hits, pathtracer.art:119-139) and "NEE Weights" (the next-event
+                             * contributions of unoccluded shadow rays, on_shadow_miss :212-218) */
 } ig_technique;
 
 /* ---- Scene ------------------------------------------------------------ */

@@ -44,6 +44,8 @@ def lib():
         l.oracle_render.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats)]
         l.oracle_render_ex.restype = C.c_int
         l.oracle_render_ex.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats), fp, fp]
+        l.oracle_render_aovs.restype = C.c_int
+        l.oracle_render_aovs.argtypes = [C.c_void_p, C.POINTER(Settings), fp, C.POINTER(Stats), fp, fp, fp, fp]
         l.oracle_generate_rays.restype = C.c_int
         l.oracle_generate_rays.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int64, C.c_int64, fp, up]
         l.oracle_trace.restype = C.c_int
@@ -92,14 +94,22 @@ def make_settings(spi, width, height, iteration=0, frame=0, seed=0, threads=0, w
     return s
 
 
-def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None, rows=None, aovs=None):
+def render(scene, spi, width, height, iteration=0, frame=0, seed=0, threads=0, fb=None, window=None, rows=None, aovs=None, mis_aovs=None):
     """One iteration of the reference CPU pipeline; returns (fb[h,w,3] float32 accumulated, stats dict).
-    aovs: optional (normals, albedo) float32 [h, w, 3] arrays, accumulated by iteration 0 (the info-buffer AOVs)."""
+    aovs: optional (normals, albedo) float32 [h, w, 3] arrays, accumulated by iteration 0 (the info-buffer AOVs).
+    mis_aovs: optional ("Direct Weights", "NEE Weights") arrays of a path tracer with aov_mis, accumulated like fb."""
     if fb is None:
         fb = np.zeros((height, width, 3), dtype=np.float32)
     assert fb.dtype == np.float32 and fb.flags.c_contiguous and fb.shape == (height, width, 3)
     cfg = make_settings(spi, width, height, iteration, frame, seed, threads, window, rows)
     st = Stats()
+    if mis_aovs is not None:
+        for a in mis_aovs:
+            assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (height, width, 3)
+        rc = lib().oracle_render_aovs(_scene_ptr(scene), C.byref(cfg), _fp(fb), C.byref(st), None, None, _fp(mis_aovs[0]), _fp(mis_aovs[1]))
+        if rc != 0:
+            raise RuntimeError("oracle_render failed")
+        return fb, st.as_dict()
     if aovs is not None:
         for a in aovs:
             assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (height, width, 3)

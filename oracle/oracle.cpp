@@ -253,7 +253,7 @@ void camera_scale(const igd_scene& sc, int width, int height, float& sx, float& 
 
 // One tile of cpu_trace (mapping_cpu.art:731-857)
 void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSetup& cam, const PathTracer& pt_tech,
-                int xmin, int ymin, int xmax, int ymax, float* fb, float* aov_normals, float* aov_albedo,
+                int xmin, int ymin, int xmax, int ymax, float* fb, float* aov_normals, float* aov_albedo, float* aov_direct, float* aov_nee,
                 PrimaryStream& primary, SecondaryStream& secondary, std::vector<int>& ray_begins, std::vector<int>& ray_ends, Counters& cnt)
 {
     const int spi      = cfg.spi;
@@ -265,6 +265,15 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
     const float inv_spi = 1 / (float)spi; // make_standard_accumulator (driver/accumulator.art:23-30)
     (void)H;
 
+    // aov_di.splat / aov_nee.splat of the path tracer with "aov_mis" (pathtracer.art:133,216): standard accumulators too
+    auto splat_aov = [&](float* aov, int ray_id, Color c) {
+        if (!aov || !sc.technique.aov_mis)
+            return;
+        const int pixel = ray_id / spi;
+        aov[pixel * 3 + 0] += c.r * inv_spi;
+        aov[pixel * 3 + 1] += c.g * inv_spi;
+        aov[pixel * 3 + 2] += c.b * inv_spi;
+    };
     auto splat = [&](int ray_id, Color c) {
         const int pixel = ray_id / spi;
         fb[pixel * 3 + 0] += c.r * inv_spi;
@@ -357,6 +366,8 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     Color hit_color;
                     if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
                         hit_color = Color{ 0, 0, 0 };
+                    else
+                        splat_aov(aov_direct, ray_id, hit_color);
                     splat(ray_id, hit_color);
 
                     const ShadowRayOut sh = pt_tech.on_shadow(ray, surf, rnd, payload, bsdf);
@@ -422,6 +433,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
             for (int i = 0; i < secondary_size; ++i) {
                 if (secondary.mat_id[i] < 0) {
                     splat(secondary.id[i], Color{ secondary.color_r[i], secondary.color_g[i], secondary.color_b[i] });
+                    splat_aov(aov_nee, secondary.id[i], Color{ secondary.color_r[i], secondary.color_g[i], secondary.color_b[i] });
                     ++cnt.unoccluded;
                 }
             }
@@ -437,7 +449,9 @@ extern "C" {
 // exactly like the reference framebuffer: Runtime divides by the iteration count on save,
 // src/runtime/Runtime.cpp:808-826).
 // aov_normals / aov_albedo: optional float[height][width][3] (accumulated with +=), the info-buffer AOVs of iteration 0
-int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats, float* aov_normals, float* aov_albedo)
+// aov_direct / aov_nee: optional float[height][width][3], the "Direct Weights" / "NEE Weights" AOVs of a path tracer with aov_mis
+int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats, float* aov_normals, float* aov_albedo,
+                       float* aov_direct, float* aov_nee)
 {
     if (!sc || !cfg || !fb || cfg->spi <= 0 || cfg->width <= 0 || cfg->height <= 0)
         return -1;
@@ -480,7 +494,7 @@ int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb,
             const int tx = tile % tiles_x, ty = tile / tiles_x;
             const int xmin = x0 + tx * tile_size, ymin = sharded ? rows[(size_t)ty] : y0 + ty * tile_size;
             const int xmax = std::min(xmin + tile_size, x1), ymax = sharded ? ymin + 1 : std::min(ymin + tile_size, y1);
-            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, aov_normals, aov_albedo, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
+            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, aov_normals, aov_albedo, aov_direct, aov_nee, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
         }
     };
 
@@ -507,9 +521,14 @@ int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb,
     return 0;
 }
 
+int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats, float* aov_normals, float* aov_albedo)
+{
+    return oracle_render_aovs(sc, cfg, fb, stats, aov_normals, aov_albedo, nullptr, nullptr);
+}
+
 int oracle_render(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats)
 {
-    return oracle_render_ex(sc, cfg, fb, stats, nullptr, nullptr);
+    return oracle_render_aovs(sc, cfg, fb, stats, nullptr, nullptr, nullptr, nullptr);
 }
 
 // Camera rays for ray ids [first_id, first_id + count) of one iteration, id = (y*W + x)*spi + sample

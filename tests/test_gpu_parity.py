@@ -1262,3 +1262,36 @@ def test_request_sizes_beyond_the_ray_id_range_are_refused(gpu_device, diamond_s
     gpu_device.clear_framebuffer()
     gpu_device.render(2, 64, 64, iteration=0, seed=1)
     assert np.isfinite(gpu_device.framebuffer()).all()
+
+
+def test_aov_mis_weights_vs_oracle(gpu_device):
+    """The path tracer's "aov_mis" option: "Direct Weights" and "NEE Weights" accumulate next to the image (which they do not
+    change), over several deferred iterations, and go away again with the next scene."""
+    import oracle
+    from ignis_amd import DeviceError
+    from ignis_amd.tables import LoadedScene
+    w, h, spi = 96, 64, 4
+    sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene_uniform.json"), w, h)
+    assert sc.scene.technique.aov_mis == 1
+    gpu_device.assign_scene(sc)
+    gpu_device.resize(w, h)
+    gpu_device.clear_framebuffer()
+    ref, di, nee = (np.zeros((h, w, 3), np.float32) for _ in range(3))
+    for it in range(3):
+        gpu_device.render(spi, w, h, iteration=it, seed=21)
+        oracle.render(sc, spi, w, h, iteration=it, seed=21, fb=ref, mis_aovs=(di, nee))
+    fb = gpu_device.framebuffer()
+    assert _rel_l2(fb, ref) <= RADIANCE_TOL
+    assert _rel_l2(gpu_device.framebuffer("Direct Weights"), di) <= RADIANCE_TOL
+    assert _rel_l2(gpu_device.framebuffer("NEE Weights"), nee) <= RADIANCE_TOL
+    assert gpu_device.buffer("NEE Weights").view(np.float32).size == w * h * 3
+    gpu_device.clear_framebuffer("NEE Weights")
+    assert not gpu_device.framebuffer("NEE Weights").any() and gpu_device.framebuffer("Direct Weights").any()
+    # the same scene without the option: same image, no such AOVs
+    s = json.load(open(os.path.join(SCENES, "diamond_scene_uniform.json")))
+    s["technique"]["aov_mis"] = False
+    plain = LoadedScene.from_string(json.dumps(s), SCENES, w, h)
+    img, _ = _render_gpu(gpu_device, plain, spi, w, h, iters=3, seed=21)
+    np.testing.assert_array_equal(img, fb)
+    with pytest.raises(DeviceError, match="unknown AOV"):
+        gpu_device.framebuffer("Direct Weights")

@@ -1172,3 +1172,39 @@ def test_volume_path_tracer_scattering_as_written():
     img_d = np.mean([oracle.render(deep, 64, 33, 33, iteration=i, seed=6)[0] for i in range(4)], axis=0)
     c = img_d[15:18, 15:18].mean(axis=(0, 1))
     assert np.all(c > want * 1.02) and np.isfinite(img_d).all()
+
+
+def test_aov_mis_weights_split_the_image():
+    """"aov_mis" (PathTechnique.cpp:16-27, pathtracer.art:133,212-218): "Direct Weights" collects the MIS-weighted emission of the
+    surfaces paths hit, "NEE Weights" the unoccluded next-event contributions. In a scene without infinite lights the two add up to the
+    image; with an environment the rest is what on_miss adds. Without NEE there are no NEE weights and every hit counts fully."""
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["technique"]["aov_mis"] = True
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 64, 48)
+    assert sc.scene.technique.aov_mis == 1
+    fb = np.zeros((48, 64, 3), np.float32)
+    di, nee = np.zeros_like(fb), np.zeros_like(fb)
+    for it in range(2):
+        oracle.render(sc, 8, 64, 48, iteration=it, seed=7, fb=fb, mis_aovs=(di, nee))
+    assert di.sum() > 0 and nee.sum() > 0
+    np.testing.assert_allclose(di + nee, fb, rtol=1e-5, atol=1e-6)
+    # the AOVs do not change the image
+    plain = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    ref = np.zeros_like(fb)
+    for it in range(2):
+        oracle.render(LoadedScene.from_string(json.dumps(plain), SCENES, 64, 48), 8, 64, 48, iteration=it, seed=7, fb=ref)
+    np.testing.assert_array_equal(fb, ref)
+    # an environment light adds to neither
+    s["lights"].append({"type": "env", "name": "sky", "radiance": [0.5, 0.5, 0.5]})
+    s["entities"] = [e for e in s["entities"] if e["name"] != "Back"]
+    sky = LoadedScene.from_string(json.dumps(s), SCENES, 64, 48)
+    fb2, di2, nee2 = np.zeros_like(fb), np.zeros_like(fb), np.zeros_like(fb)
+    oracle.render(sky, 8, 64, 48, seed=7, fb=fb2, mis_aovs=(di2, nee2))
+    assert np.all(fb2 - di2 - nee2 >= -1e-5) and (fb2 - di2 - nee2).sum() > 1
+    # no NEE: nothing in "NEE Weights", all of the image in "Direct Weights"
+    s2 = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s2["technique"].update({"aov_mis": True, "nee": False})
+    fb3, di3, nee3 = np.zeros_like(fb), np.zeros_like(fb), np.zeros_like(fb)
+    oracle.render(LoadedScene.from_string(json.dumps(s2), SCENES, 64, 48), 8, 64, 48, seed=7, fb=fb3, mis_aovs=(di3, nee3))
+    assert not nee3.any()
+    np.testing.assert_array_equal(di3, fb3)
