@@ -1224,7 +1224,7 @@ import oracle
 from ignis_amd import Device
 from ignis_amd.tables import LoadedScene
 sc = LoadedScene.from_file(os.path.join("scenes", "diamond_scene.json"), 160, 120)
-dev = Device(0, acquire_stats=1)
+dev = Device(0, acquire_stats=True)
 dev.assign_scene(sc)
 ref = np.zeros((120, 160, 3), np.float32)
 tot = {}
