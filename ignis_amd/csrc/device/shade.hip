@@ -227,8 +227,11 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_FULL
 #define IG_SHADE_OCC_FULL 3
 #endif
+#ifndef IG_SHADE_OCC_LEAN
+#define IG_SHADE_OCC_LEAN 4
+#endif
 template <bool FULL>
-__global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : 4) k_shade(const ShadeArgs a)
+__global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
