@@ -24,7 +24,7 @@
 #include "kernels.h"
 
 namespace igdev {
-void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream);
+void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20);
 int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream);
@@ -365,6 +365,10 @@ struct igd_device {
     int traverseGrid() const { return num_cus * igdev::traverse_workgroups_per_cu(); } // as many persistent workgroups as fit a CU (VGPRs and the LDS stacks, traverse_core.h)
     bool full_bsdfs = false; // the scene has a principled BSDF, a textured environment or a sun light: k_shade<true> / k_tail<*, true>
     int shade_mult = 64; // workgroups per CU in the k_shade grid (each loops over windows); IGD_SHADE_GRID
+    // workgroups of a DEEP traversal launch (IGD_DEEP_GRID): the whole traversal grid. Eight were enough for the odd ray of a small
+    // scene, but the 16 M-triangle stand-in sends enough rays there that the full grid is +9 % on it, and an empty full-grid launch
+    // costs nothing measurable on diamond_scene (profiles/r02_experiment_ab.txt)
+    int deep_grid = 1 << 20;
     int shadeGrid() const { return num_cus * shade_mult; }
 
     hipEvent_t event(size_t i)
@@ -1018,7 +1022,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.sphere_work_counter = &qs->work_counter[4];
-            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on); });
+            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid); });
 
             ShadeArgs sa{};
             sa.scene     = d->dscene;
@@ -1055,7 +1059,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.id_base = first;
             tb.inv_spi = inv;
             timed(3, on, [&] {
-                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on);
+                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid);
                 launch_secondary_end(qs, in_slot ^ 1, mirror, on);
             });
             d->stats.rounds++;
@@ -1490,6 +1494,8 @@ igd_device* igd_create(const igd_setup* setup)
         }
         if (const char* e = std::getenv("IGD_SHADE_GRID"))
             d->shade_mult = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("IGD_DEEP_GRID"))
+            d->deep_grid = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_BATCH_RAYS"))
             d->batch_rays = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))

@@ -181,7 +181,7 @@ static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int g
 
 // Two launches: the LDS-stack kernel over the whole stream, then the DEEP kernel over the rays the first one
 // could not finish (almost always none: it reads one counter and exits). `deep_work_counter` must be zero.
-void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream)
+void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks)
 {
     TraverseArgs args = args_in;
     const bool spheres = args.scene.sphere_node_count != 0;
@@ -190,8 +190,8 @@ void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int 
     TraverseArgs deep = args;
     deep.count        = args.index_count;
     deep.work_counter = deep_work_counter;
-    // a small grid: every workgroup of it waits for a free 48 KiB LDS slot, even if it only reads the empty counter
-    launch_one<true>(deep, any_hit, stats, grid_blocks < 8 ? grid_blocks : 8, stream);
+    // (normally the same grid: the workgroups of an empty DEEP launch only read the counter)
+    launch_one<true>(deep, any_hit, stats, grid_blocks < deep_grid_blocks ? grid_blocks : deep_grid_blocks, stream);
     if (spheres) {
         // the other SceneGeometry (driver/mapping_cpu.art:385-403): the sphere BVH, starting from the hits of the pass above.
         // Its stack never leaves LDS (a BVH over entities, not triangles); a ray that would need more raises the error flag.
