@@ -1163,6 +1163,51 @@ struct BsdfCtx {
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
+    // fastpow = fastpow2(p * fastlog2(x)) (core/common.art:71-90): float and integer arithmetic only
+    IG_DEV static float fastpow(float x, float p)
+    {
+        const uint32_t vx = igm_bits(x);
+        const float z     = igm_float((vx & 0x007FFFFFu) | 0x3f000000u);
+        const float y     = (float)vx * 1.1920928955078125e-7f;
+        const float lg    = y - 124.22551499f - 1.498030302f * z - 1.72587999f / (0.3520887068f + z);
+        const float q     = p * lg;
+        const float off   = q < 0 ? 1.0f : 0.0f;
+        const float clipp = q < -126 ? -126.0f : q;
+        const int w       = (int)clipp;
+        const float zz    = clipp - (float)w + off;
+        const int v       = (int)((float)(1u << 23) * (clipp + 121.2740575f + 27.7280233f / (4.84252568f - zz) - 1.49012907f * zz));
+        return igm_float((uint32_t)v);
+    }
+    // make_phong_bsdf (bsdf/phong.art:1-22): p[0..2] ks, p[3] ns
+    IG_DEV Col phong_eval(f3 in_dir, f3 out_dir) const
+    {
+        const f3 N     = surf.local.c2;
+        const float ns = mat->p[3];
+        const f3 refl  = N * (2 * dot3(N, out_dir)) - out_dir; // vec3_reflect (core/vector.art:123)
+        return Col{ mat->p[0], mat->p[1], mat->p[2] } * (pos_cos(in_dir, N) * fastpow(pos_cos(in_dir, refl), ns) * (ns + 2) / (2 * kPi));
+    }
+    IG_DEV float phong_pdf(f3 in_dir, f3 out_dir) const
+    {
+        const f3 N     = surf.local.c2;
+        const float ns = mat->p[3];
+        const f3 refl  = N * (2 * dot3(N, out_dir)) - out_dir;
+        return fastpow(pos_cos(in_dir, refl), ns) * (ns + 1) * (1 / (2 * kPi)); // cosine_power_hemisphere_pdf (core/sampling.art:79-81)
+    }
+    IG_DEV void phong_sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color) const
+    {
+        const f3 N      = surf.local.c2;
+        const float ns  = mat->p[3];
+        const f3 refl   = N * (2 * dot3(N, out_dir)) - out_dir;
+        const float u   = rnd.f32();
+        const float v   = rnd.f32();
+        const float c   = igm_min(fastpow(v, 1 / (ns + 1)), 1.0f); // sample_cosine_power_hemisphere (core/sampling.art:84-96)
+        const float sn  = igm_sqrt(1 - c * c);
+        const float phi = 2 * kPi * u;
+        pdf_out         = (c != 0 ? v / c : 0.0f) * (ns + 1) * (1 / (2 * kPi));
+        in_dir          = mul33(orthonormal_basis(refl), f3{ sn * igm_cos(phi), sn * igm_sin(phi), c });
+        color           = Col{ mat->p[0], mat->p[1], mat->p[2] } * (pos_cos(in_dir, N) * (ns + 2) / (ns + 1));
+    }
+
     // lambertian (bsdf/diffuse.art:3), rough conductor (bsdf/conductor.art:70-84)
     IG_DEV Principled principled() const { return Principled(*mat, surf.local, surf.entering, kd); }
 
@@ -1171,6 +1216,7 @@ struct BsdfCtx {
     {
         const f3 N = surf.local.c2;
         switch (mat->bsdf_type) {
+        case IG_BSDF_PHONG:       // ks (bsdf/phong.art:20)
         case IG_BSDF_TRANSPARENT: // make_perfect_refraction_bsdf: kt (bsdf/dielectric.art:9)
             return Col{ mat->p[0], mat->p[1], mat->p[2] };
         case IG_BSDF_ROUGH_DIELECTRIC:
@@ -1211,6 +1257,8 @@ struct BsdfCtx {
                 return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         }
         if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PHONG)
+                return phong_eval(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().eval(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1250,6 +1298,8 @@ struct BsdfCtx {
             }
         }
         if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PHONG)
+                return phong_pdf(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
                 return principled().pdf(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1291,6 +1341,12 @@ struct BsdfCtx {
             }
         }
         if constexpr (FULL) {
+            if (mat->bsdf_type == IG_BSDF_PHONG) {
+                phong_sample(rnd, out_dir, in_dir, pdf_out, color);
+                s_eta  = 1;
+                sdelta = false;
+                return true;
+            }
             if (mat->bsdf_type == IG_BSDF_TRANSPARENT) { // make_perfect_refraction_bsdf.sample (bsdf/dielectric.art:6-8)
                 in_dir  = -out_dir;
                 pdf_out = 1;

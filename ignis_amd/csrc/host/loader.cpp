@@ -1364,6 +1364,38 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             aux.list.push_back(im);
             aux.names.push_back(inner);
         }
+    } else if (type == "mask" || type == "cutoff") {
+        // MaskBSDF.cpp:17-57: make_mix_bsdf(masked, passthrough, weight) ("inverted": the other way round); "cutoff" turns the
+        // weight into 0 / 1 against a threshold. Constant weights only (the reference's scenes drive it with noise expressions).
+        const std::string masked = bsdf->getString("bsdf");
+        if (masked.empty())
+            fail("BSDF '" + name + "': has no inner bsdf given");
+        float weight = getConstNumber(*bsdf, "weight", 0.5f, name);
+        if (type == "cutoff")
+            weight = weight < getConstNumber(*bsdf, "cutoff", 0.5f, name) ? 0.0f : 1.0f;
+        const bool inverted = bsdf->getBool("inverted", false);
+        ig_material inner   = lowerBsdf(masked, scene_bsdfs, textures, bank, aux, depth + 1);
+        if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+            fail("BSDF '" + name + "': blends and bump / normal maps inside a mask are not supported by the HIP backend");
+        ig_material through{};
+        through.bsdf_type = IG_BSDF_TRANSPARENT; // make_passthrough_bsdf = white perfect refraction
+        through.light_id  = -1;
+        through.tex_id = through.tex_refl = -1;
+        through.p[0] = through.p[1] = through.p[2] = 1;
+        m.bsdf_type = IG_BSDF_BLEND;
+        m.p[0]      = weight;
+        for (int slot = 0; slot < 2; ++slot) {
+            const bool is_inner = (slot == 0) != inverted;
+            m.pad[slot]         = aux.base + (int32_t)aux.list.size();
+            aux.list.push_back(is_inner ? inner : through);
+            aux.names.push_back(is_inner ? masked : "passthrough");
+        }
+    } else if (type == "phong") {
+        // PhongBSDF.cpp:16-17
+        m.bsdf_type = IG_BSDF_PHONG;
+        const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
+        m.p[0] = ks.x, m.p[1] = ks.y, m.p[2] = ks.z;
+        m.p[3] = getConstNumber(*bsdf, "exponent", 30.0f, name);
     } else if (type == "bumpmap" || type == "normalmap") {
         // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
         // make_normalmap(ctx, inner, map colour, strength)

@@ -95,6 +95,8 @@ enum ig_bsdf_type {
     IG_BSDF_ROUGH_DIELECTRIC = 5, /* src/artic/bsdf/dielectric.art:64-191 (make_dielectric_bsdf with a rough interface) */
     IG_BSDF_PLASTIC    = 4,
     IG_BSDF_TRANSPARENT = 7, /* make_perfect_refraction_bsdf (src/artic/bsdf/dielectric.art:1-11; runtime/bsdf/TransparentBSDF.cpp "transparent", PassthroughBSDF.cpp "passthrough" = white): p[0..2] colour */
+    IG_BSDF_PHONG      = 8, /* make_phong_bsdf (src/artic/bsdf/phong.art:1-22, runtime/bsdf/PhongBSDF.cpp): p[0..2] specular_reflectance, p[3] exponent;
+                             * powers through the reference's own fastpow (core/common.art:71-90), which is plain float / integer arithmetic */
     IG_BSDF_BLEND      = 6, /* make_mix_bsdf (src/artic/bsdf/mix.art:4-68), runtime/bsdf/BlendBSDF.cpp:14-56 ("blend" / "mix") */ /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */
 };
 

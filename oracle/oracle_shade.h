@@ -1427,10 +1427,63 @@ struct Bsdf {
         return Color{ conductor_factor(mat->p[0], mat->p[3], cosTheta), conductor_factor(mat->p[1], mat->p[4], cosTheta), conductor_factor(mat->p[2], mat->p[5], cosTheta) };
     }
 
+    // fastlog2 / fastpow2 / fastpow (core/common.art:71-90): bit tricks over float and integer arithmetic only
+    static float fastpow(float x, float p)
+    {
+        const uint32_t vx = igm_bits(x);
+        const float z     = igm_float((vx & 0x007FFFFFu) | 0x3f000000u);
+        const float y     = (float)vx * 1.1920928955078125e-7f;
+        const float lg    = y - 124.22551499f - 1.498030302f * z - 1.72587999f / (0.3520887068f + z);
+        const float q     = p * lg;
+        const float off   = q < 0 ? 1.0f : 0.0f;
+        const float clipp = q < -126 ? -126.0f : q;
+        const int w       = (int)clipp;
+        const float zz    = clipp - (float)w + off;
+        const int v       = (int)((float)(1u << 23) * (clipp + 121.2740575f + 27.7280233f / (4.84252568f - zz) - 1.49012907f * zz));
+        return igm_float((uint32_t)v);
+    }
+    // make_phong_bsdf (bsdf/phong.art:1-22): p[0..2] ks, p[3] ns
+    Color phong_eval(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const Vec3 N     = surf->local.col[2];
+        const float ns   = mat->p[3];
+        const float cosI = positive_cos(in_dir, N);
+        const float c    = positive_cos(in_dir, vec3_reflect(out_dir, N));
+        return color_mulf(Color{ mat->p[0], mat->p[1], mat->p[2] }, cosI * fastpow(c, ns) * (ns + 2) / (2 * flt_pi));
+    }
+    float phong_pdf(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const float ns = mat->p[3];
+        const float c  = positive_cos(in_dir, vec3_reflect(out_dir, surf->local.col[2]));
+        return fastpow(c, ns) * (ns + 1) * (1 / (2 * flt_pi)); // cosine_power_hemisphere_pdf (core/sampling.art:79-81)
+    }
+    bool phong_sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        const Vec3 N    = surf->local.col[2];
+        const float ns  = mat->p[3];
+        const Vec3 refl = vec3_reflect(out_dir, N);
+        const float u   = rnd.next_f32();
+        const float v   = rnd.next_f32();
+        // sample_cosine_power_hemisphere (core/sampling.art:84-96)
+        const float c   = igm_min(fastpow(v, 1 / (ns + 1)), 1.0f);
+        const float sn  = igm_sqrt(1 - c * c);
+        const float phi = 2 * flt_pi * u;
+        const float pck = c != 0 ? v / c : 0.0f;
+        s.pdf           = pck * (ns + 1) * (1 / (2 * flt_pi));
+        s.in_dir        = mat3x3_mul(make_orthonormal_mat3x3(refl), make_vec3(sn * igm_cos(phi), sn * igm_sin(phi), c));
+        const float cs  = positive_cos(s.in_dir, N);
+        s.color         = color_mulf(Color{ mat->p[0], mat->p[1], mat->p[2] }, cs * (ns + 2) / (ns + 1));
+        s.eta           = 1;
+        s.is_delta      = false;
+        return true;
+    }
+
     // Bsdf::albedo per model (what wrap_infobuffer_renderer splats, technique/internal/infobuffer.art:13-21)
     Color albedo(Vec3 out_dir) const
     {
         const Vec3 N = surf->local.col[2];
+        if (mat->bsdf_type == IG_BSDF_PHONG) // ks (phong.art:20)
+            return Color{ mat->p[0], mat->p[1], mat->p[2] };
         if (mat->bsdf_type == IG_BSDF_TRANSPARENT) // make_perfect_refraction_bsdf: kt (dielectric.art:9)
             return Color{ mat->p[0], mat->p[1], mat->p[2] };
         if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN)) // make_thin_dielectric_bsdf (dielectric.art:60)
@@ -1461,6 +1514,8 @@ struct Bsdf {
     {
         if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
             return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
+        if (mat->bsdf_type == IG_BSDF_PHONG)
+            return phong_eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1498,6 +1553,8 @@ struct Bsdf {
                 return inner(1).pdf(in_dir, out_dir);
             return lerpf(inner(0).pdf(in_dir, out_dir), inner(1).pdf(in_dir, out_dir), k);
         }
+        if (mat->bsdf_type == IG_BSDF_PHONG)
+            return phong_pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
             return Principled(*mat, *surf, kd()).pdf(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
@@ -1541,6 +1598,8 @@ struct Bsdf {
             s.is_delta = true;
             return true;
         }
+        if (mat->bsdf_type == IG_BSDF_PHONG)
+            return phong_sample(rnd, out_dir, s);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
             s.is_delta = false;
             return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta);

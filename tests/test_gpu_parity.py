@@ -1295,3 +1295,24 @@ def test_aov_mis_weights_vs_oracle(gpu_device):
     np.testing.assert_array_equal(img, fb)
     with pytest.raises(DeviceError, match="unknown AOV"):
         gpu_device.framebuffer("Direct Weights")
+
+
+def test_phong_and_mask_bsdfs_vs_oracle(gpu_device):
+    """diamond_scene with Phong walls (fastpow restated bit for bit), a half-masked diamond and a cut-off one."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    by_name = {b["name"]: b for b in s["bsdfs"]}
+    by_name["mat-GrayWall"].clear()
+    by_name["mat-GrayWall"].update({"type": "phong", "name": "mat-GrayWall", "specular_reflectance": [0.8, 0.8, 0.7], "exponent": 12})
+    s["bsdfs"] += [{"type": "diffuse", "name": "inner", "reflectance": [0.7, 0.3, 0.2]},
+                   {"type": "mask", "name": "masked", "bsdf": "inner", "weight": 0.4},
+                   {"type": "cutoff", "name": "cut", "bsdf": "inner", "weight": 0.3, "cutoff": 0.5, "inverted": True}]
+    for e in s["entities"]:
+        if e["name"] == "Diamond2":
+            e["bsdf"] = "masked"
+        if e["name"] == "Diamond3":
+            e["bsdf"] = "cut"
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    types = [sc.scene.materials[i].bsdf_type for i in range(sc.scene.material_count)]
+    assert 8 in types and types.count(6) == 2
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=27, iters=2)
