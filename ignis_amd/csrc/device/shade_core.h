@@ -1163,6 +1163,20 @@ struct BsdfCtx {
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
 
+    // make_orennayar_bsdf.eval (bsdf/diffuse.art:28-39): p[3] alpha
+    IG_DEV Col orennayar_eval(f3 in_dir, f3 out_dir) const
+    {
+        const f3 N     = surf.local.c2;
+        const float a2 = mat->p[3] * mat->p[3];
+        const float p1 = pos_cos(in_dir, N);
+        const float p2 = pos_cos(out_dir, N);
+        const float sv = -p1 * p2 + pos_cos(out_dir, in_dir);
+        const float t  = sv <= kFltEps ? 1.0f : igm_max(kFltEps, igm_max(p1, p2));
+        const float A  = 1 - 0.5f * a2 / (a2 + 0.33f);
+        const float B  = 0.45f * a2 / (a2 + 0.09f);
+        const float C  = 0.17f * a2 / (a2 + 0.13f);
+        return (kd * ((A + (B * sv / t)) / kPi) + kd * (kd * (C / kPi))) * p1;
+    }
     // fastpow = fastpow2(p * fastlog2(x)) (core/common.art:71-90): float and integer arithmetic only
     IG_DEV static float fastpow(float x, float p)
     {
@@ -1266,8 +1280,11 @@ struct BsdfCtx {
             if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
                 return RoughDielectric(*mat, surf.local, surf.entering).eval(in_dir, out_dir);
         }
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+            if (FULL && mat->p[3] > kFltEps) // make_diffuse_bsdf (bsdf/diffuse.art:52-58): a roughness selects Oren-Nayar
+                return orennayar_eval(in_dir, out_dir);
             return kd * (pos_cos(in_dir, N) * kInvPi);
+        }
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
             const float cos_o = abs_cos(out_dir, N);
             const float cos_i = abs_cos(in_dir, N);
@@ -1378,6 +1395,8 @@ struct BsdfCtx {
             in_dir          = mul33(surf.local, f3{ s * igm_cos(phi), s * igm_sin(phi), c });
             pdf_out         = c / kPi;
             color           = kd;
+            if (FULL && mat->p[3] > kFltEps)
+                color = orennayar_eval(in_dir, out_dir) * (1 / pdf_out); // bsdf/diffuse.art:46
             s_eta           = 1;
             sdelta          = false;
             return true;

@@ -1200,8 +1200,6 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
         }
         m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
-        if (m.p[3] > 1.1920928955e-07f)
-            fail("BSDF '" + name + "': rough (Oren-Nayar) diffuse is not supported by the HIP backend");
     } else if (type == "dielectric" || type == "glass" || type == "roughdielectric" || type == "thindielectric") {
         // DielectricBSDF.cpp:13-41; IOR table BSDF.cpp:7-30 (vacuum 1.0, bk7 1.5046)
         if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))

@@ -1427,6 +1427,21 @@ struct Bsdf {
         return Color{ conductor_factor(mat->p[0], mat->p[3], cosTheta), conductor_factor(mat->p[1], mat->p[4], cosTheta), conductor_factor(mat->p[2], mat->p[5], cosTheta) };
     }
 
+    // make_orennayar_bsdf.eval (bsdf/diffuse.art:28-39): p[3] alpha
+    Color orennayar_eval(Vec3 in_dir, Vec3 out_dir) const
+    {
+        const Vec3 N   = surf->local.col[2];
+        const float a2 = mat->p[3] * mat->p[3];
+        const float p1 = positive_cos(in_dir, N);
+        const float p2 = positive_cos(out_dir, N);
+        const float sv = -p1 * p2 + positive_cos(out_dir, in_dir);
+        const float t  = sv <= flt_eps ? 1.0f : igm_max(flt_eps, igm_max(p1, p2));
+        const float A  = 1 - 0.5f * a2 / (a2 + 0.33f);
+        const float B  = 0.45f * a2 / (a2 + 0.09f);
+        const float C  = 0.17f * a2 / (a2 + 0.13f);
+        const Color k  = kd();
+        return color_mulf(color_add(color_mulf(k, (A + (B * sv / t)) / flt_pi), color_mul(k, color_mulf(k, C / flt_pi))), p1);
+    }
     // fastlog2 / fastpow2 / fastpow (core/common.art:71-90): bit tricks over float and integer arithmetic only
     static float fastpow(float x, float p)
     {
@@ -1522,8 +1537,11 @@ struct Bsdf {
             return Plastic(*mat, *surf, kd()).eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
             return RoughDielectric(*mat, *surf).eval(in_dir, out_dir);
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+            if (mat->p[3] > flt_eps) // make_diffuse_bsdf (diffuse.art:52-58): a roughness selects Oren-Nayar
+                return orennayar_eval(in_dir, out_dir);
             return color_mulf(kd(), positive_cos(in_dir, surf->local.col[2]) * flt_inv_pi);
+        }
         if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
             const Vec3 N      = surf->local.col[2];
             const float cos_o = absolute_cos(out_dir, N);
@@ -1614,7 +1632,7 @@ struct Bsdf {
             const DirSample ds = sample_cosine_hemisphere(u, v);
             s.in_dir           = mat3x3_mul(surf->local, ds.dir);
             s.pdf              = ds.pdf;
-            s.color            = kd();
+            s.color            = mat->p[3] > flt_eps ? color_mulf(orennayar_eval(s.in_dir, out_dir), 1 / ds.pdf) : kd(); // diffuse.art:46
             s.eta              = 1;
             s.is_delta         = false;
             return true;

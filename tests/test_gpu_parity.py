@@ -1298,12 +1298,13 @@ def test_aov_mis_weights_vs_oracle(gpu_device):
 
 
 def test_phong_and_mask_bsdfs_vs_oracle(gpu_device):
-    """diamond_scene with Phong walls (fastpow restated bit for bit), a half-masked diamond and a cut-off one."""
+    """diamond_scene with Phong and Oren-Nayar walls (fastpow restated bit for bit), a half-masked diamond and a cut-off one."""
     from ignis_amd.tables import LoadedScene
     s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
     by_name = {b["name"]: b for b in s["bsdfs"]}
     by_name["mat-GrayWall"].clear()
     by_name["mat-GrayWall"].update({"type": "phong", "name": "mat-GrayWall", "specular_reflectance": [0.8, 0.8, 0.7], "exponent": 12})
+    by_name["mat-ColoredWall"]["roughness"] = 0.7  # Oren-Nayar (bsdf/diffuse.art:22-58)
     s["bsdfs"] += [{"type": "diffuse", "name": "inner", "reflectance": [0.7, 0.3, 0.2]},
                    {"type": "mask", "name": "masked", "bsdf": "inner", "weight": 0.4},
                    {"type": "cutoff", "name": "cut", "bsdf": "inner", "weight": 0.3, "cutoff": 0.5, "inverted": True}]

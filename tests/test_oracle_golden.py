@@ -1252,3 +1252,21 @@ def test_mask_and_cutoff_bsdfs_are_blends_with_passthrough():
     np.testing.assert_allclose(cut, 1.0, rtol=1e-5)
     half, _ = render([{"type": "mask", "name": "ground", "bsdf": "inner", "weight": 0.5}])
     assert plain.mean() < half.mean() < 1
+
+
+def test_orennayar_diffuse_known_answer():
+    """make_diffuse_bsdf (bsdf/diffuse.art:22-58): a roughness turns the Lambertian into the Oren-Nayar model. Lit and viewed
+    along the normal (point light at the camera), s = 0 and the reflected radiance is (A kd + C kd^2) / pi * I / d^2."""
+    alpha, kd = 0.6, np.float64([0.8, 0.5, 0.2])
+    s = flat_scene([{"type": "point", "name": "lamp", "position": [0, 0, -1], "intensity": [2, 2, 2]}], max_depth=2, size=(33, 33))
+    s["bsdfs"] = [{"type": "diffuse", "name": "ground", "reflectance": list(kd), "roughness": alpha}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 33, 33)
+    assert sc.scene.materials[0].p[3] == np.float32(alpha)
+    img, _ = oracle.render(sc, 16, 33, 33, seed=2)
+    a2 = alpha * alpha
+    A, C = 1 - 0.5 * a2 / (a2 + 0.33), 0.17 * a2 / (a2 + 0.13)
+    np.testing.assert_allclose(img[16, 16], (A * kd + C * kd * kd) / np.pi * 2, rtol=3e-3)  # the centre pixel spans +- 1.7 degrees
+    # no roughness: Lambert
+    s["bsdfs"][0]["roughness"] = 0
+    lam, _ = oracle.render(LoadedScene.from_string(json.dumps(s), SCENES, 33, 33), 16, 33, 33, seed=2)
+    np.testing.assert_allclose(lam[16, 16], kd / np.pi * 2, rtol=3e-3)
