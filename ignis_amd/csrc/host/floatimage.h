@@ -191,8 +191,11 @@ inline bool hufDecode(const uint8_t* data, size_t size, std::vector<uint16_t>& o
     }
     int max_len = 0;
     for (int l = 1; l <= 58; ++l)
-        if (count[l])
+        if (count[l]) {
+            if (l > 56 || first[l] + count[l] > (1ull << l))
+                return false; // not a prefix code (corrupt table); codes beyond 56 bits do not occur in real files
             max_len = l;
+        }
     // direct table for codes of at most Fast bits
     constexpr int Fast = 12;
     std::vector<int32_t> fsym(1u << Fast, -1);

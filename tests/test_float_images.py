@@ -158,6 +158,32 @@ def test_exr_errors_are_reported(tmp_path):
         _read(tmp_path / "missing.exr")
 
 
+def test_corrupt_files_are_refused_not_crashed_on(tmp_path):
+    """Byte flips, truncations and damaged headers of a PIZ and a ZIP file (the sanitizer run of tools/fuzz_float_images.cpp, here
+    without the sanitizers): the reader returns an image or raises, e.g. for a Huffman table that is not a prefix code."""
+    rng = np.random.default_rng(11)
+    for name in ("ref-cbox-d1-4096.exr", "ref-cycles-mix-trans-trans-4096.exr"):
+        base = np.frombuffer(Path(GOLDEN, "references", name).read_bytes(), np.uint8)
+        raised = 0
+        for it in range(120):
+            b = base.copy()
+            if it % 3 == 0:
+                b[rng.integers(0, b.size, 6)] = rng.integers(0, 256, 6)
+            elif it % 3 == 1:
+                b = b[:rng.integers(1, b.size)]
+            else:
+                idx = 320 + rng.integers(0, b.size - 320, 16)
+                b[idx] ^= (1 << rng.integers(0, 8, 16)).astype(np.uint8)
+            p = tmp_path / "m.exr"
+            p.write_bytes(b.tobytes())
+            try:
+                img = _read(p)
+                assert img.ndim == 3
+            except RuntimeError:
+                raised += 1
+        assert raised > 20
+
+
 # ---- Radiance RGBE
 
 def _write_hdr(path, rgbe, rle):
