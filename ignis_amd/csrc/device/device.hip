@@ -599,9 +599,9 @@ void assignScene(igd_device* d, const igd_scene* s)
         d->full_bsdfs |= (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
-    d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH;
+    d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
     d->full_bsdfs |= simple_selector;
-    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH)
+    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH && s->technique.type != IG_TECHNIQUE_DEBUG)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
         if (s->lights[i].type != IG_LIGHT_MESH_AREA && s->lights[i].type != IG_LIGHT_SPHERE)
@@ -1779,6 +1779,8 @@ int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value)
         int32_t* dst = nullptr;
         if (std::strcmp(name, "__tech_max_depth") == 0)
             dst = &dev->dscene.tech.max_depth;
+        else if (std::strcmp(name, "__debug_mode") == 0) // DebugTechnique.cpp:27-31 (igview switches the view through it)
+            dst = &dev->dscene.tech.debug_mode;
         else if (std::strcmp(name, "__tech_min_depth") == 0)
             dst = &dev->dscene.tech.min_depth;
         if (!dst || *dst == value)

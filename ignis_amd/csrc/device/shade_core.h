@@ -2073,6 +2073,132 @@ struct PathVertexOut {
     int b_depth;
 };
 
+// colormap::palette (core/colormap.art:68-92)
+IG_DEV Col debug_palette(int i)
+{
+    const float c[23][3] = {
+        { 0.450000f, 0.376630f, 0.112500f }, { 0.112500f, 0.450000f, 0.405978f }, { 0.112500f, 0.450000f, 0.229891f }, { 0.450000f, 0.112500f, 0.376630f },
+        { 0.435326f, 0.450000f, 0.112500f }, { 0.112500f, 0.141848f, 0.450000f }, { 0.435326f, 0.112500f, 0.450000f }, { 0.112500f, 0.450000f, 0.141848f },
+        { 0.347283f, 0.450000f, 0.112500f }, { 0.450000f, 0.112500f, 0.200543f }, { 0.112500f, 0.229891f, 0.450000f }, { 0.450000f, 0.288587f, 0.112500f },
+        { 0.347283f, 0.112500f, 0.450000f }, { 0.450000f, 0.112500f, 0.288587f }, { 0.450000f, 0.112500f, 0.112500f }, { 0.450000f, 0.200543f, 0.112500f },
+        { 0.171196f, 0.450000f, 0.112500f }, { 0.112500f, 0.450000f, 0.317935f }, { 0.259239f, 0.450000f, 0.112500f }, { 0.259239f, 0.112500f, 0.450000f },
+        { 0.112500f, 0.405978f, 0.450000f }, { 0.171196f, 0.112500f, 0.450000f }, { 0.112500f, 0.317935f, 0.450000f }
+    };
+    const int k = i % 23;
+    return Col{ c[k][0], c[k][1], c[k][2] };
+}
+
+// on_hit of make_debug_renderer (technique/debugtracer.art:3-140) over the point mappers of driver/pointmapper.art:28-36
+template <bool FULL>
+IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, const Surf& surf, const BsdfCtx<FULL>& bsdf, const ig_material& mat, int mat_id)
+{
+    const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)in.ent * IG_ENTITY_FLOATS);
+    auto absv       = [](f3 n) { return Col{ igm_abs(n.x), igm_abs(n.y), igm_abs(n.z) }; };
+    auto local_n    = [&](f3 n) { // to_local_normal: mat3x3_left_mul(normal_mat, n) / |diag(normal_mat)|^2
+        const float4 r6 = e[6], r7 = e[7], r8 = e[8];
+        const f3 c0{ r6.x, r6.y, r6.z }, c1{ r6.w, r7.x, r7.y }, c2{ r7.z, r7.w, r8.x };
+        const f3 d{ c0.x, c1.y, c2.z };
+        return normalize3(f3{ dot3(c0, n), dot3(c1, n), dot3(c2, n) } * (1 / dot3(d, d)));
+    };
+    auto local_p = [&](f3 p) { // to_local_point: entity.local_mat
+        const float4 r0 = e[0], r1 = e[1], r2 = e[2];
+        m34 local;
+        local.c0 = f3{ r0.x, r0.y, r0.z }, local.c1 = f3{ r0.w, r1.x, r1.y }, local.c2 = f3{ r1.z, r1.w, r2.x }, local.c3 = f3{ r2.y, r2.z, r2.w };
+        return xform_point(local, p);
+    };
+    const Col yes{ 0, 0, 1 }, no{ 1, 0, 0 }; // true_color = blue, false_color = red (core/color.art:74-75)
+    const uint4 ext   = sc.entity_ext[in.ent];
+    const bool sphere = ext.y == 0xFFFFFFFFu;
+    const int inner = (mat.pad[2] & 0xFFFF) - 1, outer = ((mat.pad[2] >> 16) & 0xFFFF) - 1;
+    switch (mode) {
+    case 1: return absv(surf.local.c0);
+    case 2: return absv(surf.local.c1);
+    case 3: return absv(surf.face_normal);
+    case 4: return absv(local_n(surf.local.c2));
+    case 5: return absv(local_n(surf.local.c0));
+    case 6: return absv(local_n(surf.local.c1));
+    case 7: return absv(local_n(surf.face_normal));
+    case 8: return Col{ igm_abs(surf.tex.x), igm_abs(surf.tex.y), 0 };
+    case 9: return Col{ igm_abs(in.u), igm_abs(in.v), 0 };
+    case 10: return Col{ surf.point.x, surf.point.y, surf.point.z };
+    case 11: {
+        const f3 p = local_p(surf.point);
+        return Col{ p.x, p.y, p.z };
+    }
+    case 12: { // to_normalized_point: the shape's bounding box (floats 4..6 / 8..10 of a mesh header; a sphere's centre +- radius)
+        const f3 lp = local_p(surf.point);
+        f3 lo, hi;
+        if (sphere) {
+            const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x);
+            lo = f3{ sp.x - sp.w, sp.y - sp.w, sp.z - sp.w };
+            hi = f3{ sp.x + sp.w, sp.y + sp.w, sp.z + sp.w };
+        } else {
+            const float* hdr = reinterpret_cast<const float*>(sc.shape_data + ext.x) - 12; // the vertices follow the 12-float header
+            lo = f3{ hdr[4], hdr[5], hdr[6] };
+            hi = f3{ hdr[8], hdr[9], hdr[10] };
+        }
+        return Col{ safe_div(lp.x - lo.x, hi.x - lo.x), safe_div(lp.y - lo.y, hi.y - lo.y), safe_div(lp.z - lo.z, hi.z - lo.z) };
+    }
+    case 13: return Col{ in.t, in.t, in.t };
+    case 14: { // surf.area: the triangle in scene space (core/triangle.art:12-29), or compute_ellipsoid_area (shapes/sphere.art:21-28)
+        const float4 r3 = e[3], r4 = e[4], r5 = e[5];
+        m34 global;
+        global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
+        float area;
+        if (sphere) {
+            const float r  = reinterpret_cast<const float4*>(sc.shape_data + ext.x)->w;
+            const f3 a = global.c0 * r, b = global.c1 * r, c = global.c2 * r;
+            const float l1 = dot3(a, a), l2 = dot3(b, b), l3 = dot3(c, c);
+            const float P  = 1.6f;
+            area = 4 * kPi * igm_pow((igm_pow(l1 * l2, P / 2) + igm_pow(l1 * l3, P / 2) + igm_pow(l2 * l3, P / 2)) / 3, 1 / P);
+        } else {
+            const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
+            const int4 tri     = *reinterpret_cast<const int4*>(reinterpret_cast<const float*>(sc.shape_data + ext.z) + in.prim * 4);
+            const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4)), v1 = xform_point(global, ld3v(verts + tri.y * 4)), v2 = xform_point(global, ld3v(verts + tri.z * 4));
+            area = len3(stable_normal(v2 - v0, v0 - v1, v1 - v2)) / 2;
+        }
+        return Col{ area, area, area };
+    }
+    case 15: return Col{ (float)in.prim, (float)in.prim, (float)in.prim };
+    case 16: return debug_palette(in.prim);
+    case 17: return Col{ (float)in.ent, (float)in.ent, (float)in.ent };
+    case 18: return debug_palette(in.ent);
+    case 19: return Col{ (float)mat_id, (float)mat_id, (float)mat_id };
+    case 20: return debug_palette(mat_id);
+    case 21: return mat.light_id >= 0 ? yes : no;
+    case 22: return bsdf.all_delta() ? yes : no;
+    case 23: return surf.entering ? yes : no;
+    case 24: { // DEBUG_CHECK_BSDF: red / orange / yellow / blue = neither / only the pdf / only the weight / both agree; pink = no sample
+        const Col verdict[4] = { Col{ 1, 0, 0 }, Col{ 1, 0.5f, 0 }, Col{ 1, 1, 0 }, Col{ 0, 0, 1 } };
+        const f3 N = surf.local.c2, out_dir = -in.dir;
+        if (bsdf.all_delta()) {
+            const f3 r       = N * (2 * dot3(N, out_dir)) - out_dir;
+            const Col evl    = bsdf.eval(r, out_dir);
+            const float pdf  = bsdf.pdf(r, out_dir);
+            const int pdf_ok = igm_abs(0 - pdf) <= kFltEps ? 1 : 0;
+            const int w_ok   = igm_abs(0 - evl.r) + igm_abs(0 - evl.g) + igm_abs(0 - evl.b) <= kFltEps ? 1 : 0;
+            return verdict[(w_ok << 1) | pdf_ok];
+        }
+        Tea tmp{ fnv_step(fnv_step(fnv_step(0x811C9DC5u, igm_bits(in.t)), igm_bits(in.u)), igm_bits(in.v)), 1 };
+        f3 in_dir;
+        float spdf, s_eta;
+        Col scol;
+        bool sdelta;
+        if (!bsdf.sample(tmp, out_dir, in_dir, spdf, scol, s_eta, sdelta))
+            return Col{ 1, 0, 1 };
+        const float pdf  = bsdf.pdf(in_dir, out_dir);
+        const Col evl    = bsdf.eval(in_dir, out_dir) * safe_div(1, pdf);
+        const int pdf_ok = igm_abs(spdf - pdf) <= 0.001f ? 1 : 0;
+        const int w_ok   = igm_abs(scol.r - evl.r) + igm_abs(scol.g - evl.g) + igm_abs(scol.b - evl.b) <= 0.001f ? 1 : 0;
+        return verdict[(w_ok << 1) | pdf_ok];
+    }
+    case 25: return bsdf.albedo(-in.dir);
+    case 26: return inner < 0 ? Col{ 0, 0, 0 } : debug_palette(inner);
+    case 27: return outer < 0 ? Col{ 0, 0, 0 } : debug_palette(outer);
+    default: return absv(surf.local.c2);
+    }
+}
+
 constexpr float kRayOffset = 0.001f; // technique/pathtracer.art:41
 
 IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, technique/pathtracer.art:46-50
@@ -2105,8 +2231,8 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         // gpu_generate_rays (mapping_gpu.art:655-658): it can only miss, and it is dropped here
         if (in.dir.x == 0 && in.dir.y == 0 && in.dir.z == 0)
             return;
-        if (FULL && tech.type == IG_TECHNIQUE_AO)
-            return; // make_ao_renderer has no on_miss
+        if (FULL && (tech.type == IG_TECHNIQUE_AO || tech.type == IG_TECHNIQUE_DEBUG))
+            return; // make_ao_renderer and make_debug_renderer have no on_miss
         // ---- miss: on_miss (technique/pathtracer.art:141-168) over infinite, non-delta lights
         Col sum{ 0, 0, 0 };
         for (uint32_t li = 0; li < sc.infinite_light_count; ++li) {
@@ -2166,6 +2292,12 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
+    if (FULL && tech.type == IG_TECHNIQUE_DEBUG) {
+        // on_hit of make_debug_renderer (technique/debugtracer.art:3-140): one of 28 properties of the first hit; nothing else
+        out.has_radiance = true;
+        out.radiance     = debug_color<FULL>(sc, tech.debug_mode, in, surf, bsdf, mat, sc.entity_material[in.ent]);
+        return;
+    }
     if (FULL && tech.type == IG_TECHNIQUE_AO) {
         // make_ao_renderer.on_shadow (technique/aotracer.art:7-19): a cosine-distributed direction around the surface frame
         // (make_lambertian_bsdf(ctx.surf, white).sample), traced as a "shadow" ray with the bounce visibility flag and no far

@@ -1557,7 +1557,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     auto sc = std::make_unique<Scene>();
 
     // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
-    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0 };
+    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0, 0 };
     std::string selector;
     if (const JsonValue* t = doc.find("technique")) {
         const std::string type = t->getString("type", "path");
@@ -1565,8 +1565,22 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             tech.type = IG_TECHNIQUE_AO; // AOTechnique.cpp: no parameters
         else if (type == "volpath")
             tech.type = IG_TECHNIQUE_VOLPATH; // VolumePathTechnique.cpp: the parameters of the path tracer
-        else if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath' and 'ao')");
+        else if (type == "debug") {
+            // DebugTechnique.cpp:6-14, DebugMode.cpp:5-34: the mode by name (case-insensitive), "normal" when unknown
+            tech.type = IG_TECHNIQUE_DEBUG;
+            static const char* const modes[] = { "normal", "tangent", "bitangent", "geometric normal", "local normal", "local tangent", "local bitangent",
+                                                 "local geometric normal", "texture coords", "prim coords", "point", "local point", "generated coords",
+                                                 "hit distance", "area", "raw prim id", "prim id", "raw entity id", "entity id", "raw material id",
+                                                 "material id", "is emissive", "is specular", "is entering", "check bsdf", "albedo", "medium inner",
+                                                 "medium outer" };
+            std::string mode = t->getString("mode", "");
+            for (char& ch : mode)
+                ch = (char)std::tolower((unsigned char)ch);
+            for (int i = 0; i < 28; ++i)
+                if (mode == modes[i])
+                    tech.debug_mode = i;
+        } else if (type != "path")
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao' and 'debug')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
         tech.clamp     = t->getNumber("clamp", 0.0f);

@@ -277,4 +277,7 @@ IGM_FN float igm_log(float x)
     return igm_fma(0.693359375f, fe, m + y);
 }
 
+/* x^p for x > 0 as exp(p log x) (relative error ~ |p log x| * 1e-7: for display values, not for sampling) */
+IGM_FN float igm_pow(float x, float p) { return x <= 0.0f ? 0.0f : igm_exp(p * igm_log(x)); }
+
 #endif /* IG_DETMATH_H */

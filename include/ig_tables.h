@@ -280,6 +280,10 @@ enum ig_technique_type {
      * the path tracer with a current medium in the payload — transmittance on every segment, distance sampling and phase-function
      * scattering in on_bounce, the medium changing at transmissions through entities with a medium interface. */
     IG_TECHNIQUE_VOLPATH = 2,
+    /* the debug views (make_debug_renderer, src/artic/technique/debugtracer.art:1-151, DebugTechnique.cpp): the first hit of a
+     * camera ray shown as one of 28 properties (ig_technique.debug_mode = enum DebugMode, src/runtime/technique/DebugMode.h:6-35;
+     * registry parameter "__debug_mode"); no shadow rays, no bounces, nothing on a miss. */
+    IG_TECHNIQUE_DEBUG = 3,
 };
 
 /* One record per medium, in the order entities acquire them (LoaderMedium::acquire, src/runtime/loader/LoaderMedium.cpp:113-121;
@@ -303,6 +307,7 @@ typedef struct ig_technique {
     int32_t aov_mis;        /* path tracer only (PathTechnique.cpp:16-27,56-61): also accumulate the AOVs "Direct Weights" (the MIS-weighted
                              * emission of surfaces a path hits, pathtracer.art:119-139) and "NEE Weights" (the next-event
                              * contributions of unoccluded shadow rays, on_shadow_miss :212-218) */
+    int32_t debug_mode;     /* IG_TECHNIQUE_DEBUG: 0 normal, 1 tangent, ... 27 medium outer (DebugMode.h:6-35) */
 } ig_technique;
 
 /* ---- Scene ------------------------------------------------------------ */

@@ -364,7 +364,9 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     }
 
                     Color hit_color;
-                    if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
+                    if (pt_tech.debug)
+                        hit_color = pt_tech.debug_hit(ray, hit, surf, entity, bsdf, mat, entity.mat_id);
+                    else if (!pt_tech.on_hit(ray, hit, surf, payload, mat, hit_color))
                         hit_color = Color{ 0, 0, 0 };
                     else
                         splat_aov(aov_direct, ray_id, hit_color);

@@ -2606,8 +2606,10 @@ struct PathTracer {
         , enable_nee(s.technique.nee != 0)
         , ambient_occlusion(s.technique.type == IG_TECHNIQUE_AO)
         , volumetric(s.technique.type == IG_TECHNIQUE_VOLPATH)
+        , debug(s.technique.type == IG_TECHNIQUE_DEBUG)
     {
     }
+    bool debug; // make_debug_renderer: only on_hit
     // make_volume_path_renderer (technique/volpathtracer.art:37-260): the same callbacks with a current medium
     bool volumetric;
     // get_medium (volpathtracer.art:46-49) over the media table of LoaderMedium::generate (LoaderMedium.cpp:89-111): unknown ids are vacuum
@@ -2706,6 +2708,11 @@ struct PathTracer {
     // on_shadow (pathtracer.art:52-117)
     ShadowRayOut on_shadow(const Ray& ray, const SurfaceElement& surf, Rng& rnd, const PTRayPayload& pt, const Bsdf& bsdf) const
     {
+        if (debug) {
+            ShadowRayOut none;
+            none.valid = false;
+            return none;
+        }
         if (ambient_occlusion) {
             // a sample of make_lambertian_bsdf(ctx.surf, white) (bsdf/diffuse.art:2-12): colour = kd, whatever the direction
             ShadowRayOut ao;
@@ -2819,10 +2826,119 @@ struct PathTracer {
         return out;
     }
 
+    // colormap::palette (core/colormap.art:68-92)
+    static Color palette(int32_t i)
+    {
+        static const float c[23][3] = {
+            { 0.450000f, 0.376630f, 0.112500f }, { 0.112500f, 0.450000f, 0.405978f }, { 0.112500f, 0.450000f, 0.229891f }, { 0.450000f, 0.112500f, 0.376630f },
+            { 0.435326f, 0.450000f, 0.112500f }, { 0.112500f, 0.141848f, 0.450000f }, { 0.435326f, 0.112500f, 0.450000f }, { 0.112500f, 0.450000f, 0.141848f },
+            { 0.347283f, 0.450000f, 0.112500f }, { 0.450000f, 0.112500f, 0.200543f }, { 0.112500f, 0.229891f, 0.450000f }, { 0.450000f, 0.288587f, 0.112500f },
+            { 0.347283f, 0.112500f, 0.450000f }, { 0.450000f, 0.112500f, 0.288587f }, { 0.450000f, 0.112500f, 0.112500f }, { 0.450000f, 0.200543f, 0.112500f },
+            { 0.171196f, 0.450000f, 0.112500f }, { 0.112500f, 0.450000f, 0.317935f }, { 0.259239f, 0.450000f, 0.112500f }, { 0.259239f, 0.112500f, 0.450000f },
+            { 0.112500f, 0.405978f, 0.450000f }, { 0.171196f, 0.112500f, 0.450000f }, { 0.112500f, 0.317935f, 0.450000f }
+        };
+        const int k = i % 23;
+        return Color{ c[k][0], c[k][1], c[k][2] };
+    }
+    // on_hit of make_debug_renderer (technique/debugtracer.art:3-140); the other callbacks do nothing
+    Color debug_hit(const Ray& ray, const Hit& hit, const SurfaceElement& surf, const Entity& entity, const Bsdf& bsdf, const ig_material& mat, int32_t mat_id) const
+    {
+        auto absv    = [](Vec3 n) { return Color{ igm_abs(n.x), igm_abs(n.y), igm_abs(n.z) }; };
+        // to_local_normal of make_standard_pointmapperset (driver/pointmapper.art:31)
+        auto local_n = [&](Vec3 n) {
+            const Vec3 d = make_vec3(entity.normal_mat.col[0].x, entity.normal_mat.col[1].y, entity.normal_mat.col[2].z);
+            const Vec3 v = make_vec3(vec3_dot(entity.normal_mat.col[0], n), vec3_dot(entity.normal_mat.col[1], n), vec3_dot(entity.normal_mat.col[2], n));
+            return vec3_normalize(vec3_mulf(v, 1 / vec3_dot(d, d)));
+        };
+        const Color yes{ 0, 0, 1 }, no{ 1, 0, 0 }; // true_color = blue, false_color = red (core/color.art:74-75)
+        const int32_t inner = (mat.pad[2] & 0xFFFF) - 1, outer = ((mat.pad[2] >> 16) & 0xFFFF) - 1;
+        switch (sc.technique.debug_mode) {
+        case 1: return absv(surf.local.col[0]);
+        case 2: return absv(surf.local.col[1]);
+        case 3: return absv(surf.face_normal);
+        case 4: return absv(local_n(surf.local.col[2]));
+        case 5: return absv(local_n(surf.local.col[0]));
+        case 6: return absv(local_n(surf.local.col[1]));
+        case 7: return absv(local_n(surf.face_normal));
+        case 8: return Color{ igm_abs(surf.tex_coords.x), igm_abs(surf.tex_coords.y), 0 };
+        case 9: return Color{ igm_abs(hit.u), igm_abs(hit.v), 0 };
+        case 10: return Color{ surf.point.x, surf.point.y, surf.point.z };
+        case 11: {
+            const Vec3 p = mat3x4_transform_point(entity.local_mat, surf.point);
+            return Color{ p.x, p.y, p.z };
+        }
+        case 12: { // make_normalized_pointmapper (pointmapper.art:4-8) over the shape's bounding box (trimesh.art:89, sphere.art:74)
+            const Vec3 lp = mat3x4_transform_point(entity.local_mat, surf.point);
+            Vec3 lo, hi;
+            const uint8_t* base = sc.shape_data + sc.shape_lookups[entity.shape_id].offset;
+            if (sc.shape_lookups[entity.shape_id].type_id == IG_SHAPE_SPHERE) {
+                float d[4];
+                std::memcpy(d, base, 16); // origin, radius: make_centered_bbox(origin, 2 * radius)
+                lo = make_vec3(d[0] - d[3], d[1] - d[3], d[2] - d[3]);
+                hi = make_vec3(d[0] + d[3], d[1] + d[3], d[2] + d[3]);
+            } else {
+                float d[12];
+                std::memcpy(d, base, 48);
+                lo = make_vec3(d[4], d[5], d[6]);
+                hi = make_vec3(d[8], d[9], d[10]);
+            }
+            return Color{ safe_div(lp.x - lo.x, hi.x - lo.x), safe_div(lp.y - lo.y, hi.y - lo.y), safe_div(lp.z - lo.z, hi.z - lo.z) };
+        }
+        case 13: return Color{ hit.distance, hit.distance, hit.distance };
+        case 14: {
+            float area = surf.area;
+            if (sc.shape_lookups[entity.shape_id].type_id == IG_SHAPE_SPHERE) {
+                // compute_ellipsoid_area (shapes/sphere.art:21-28), which the sphere's surface element carries
+                const Sphere sp = load_sphere(sc, entity.shape_id);
+                const float l1  = vec3_len2(vec3_mulf(entity.global_mat.col[0], sp.radius));
+                const float l2  = vec3_len2(vec3_mulf(entity.global_mat.col[1], sp.radius));
+                const float l3  = vec3_len2(vec3_mulf(entity.global_mat.col[2], sp.radius));
+                const float P   = 1.6f;
+                area = 4 * flt_pi * igm_pow((igm_pow(l1 * l2, P / 2) + igm_pow(l1 * l3, P / 2) + igm_pow(l2 * l3, P / 2)) / 3, 1 / P);
+            }
+            return Color{ area, area, area };
+        }
+        case 15: return Color{ (float)hit.prim_id, (float)hit.prim_id, (float)hit.prim_id };
+        case 16: return palette(hit.prim_id);
+        case 17: return Color{ (float)hit.ent_id, (float)hit.ent_id, (float)hit.ent_id };
+        case 18: return palette(hit.ent_id);
+        case 19: return Color{ (float)mat_id, (float)mat_id, (float)mat_id };
+        case 20: return palette(mat_id);
+        case 21: return mat.light_id >= 0 ? yes : no;
+        case 22: return bsdf.is_all_delta() ? yes : no;
+        case 23: return surf.is_entering ? yes : no;
+        case 24: { // DEBUG_CHECK_BSDF: red / orange / yellow / blue = neither / only the pdf / only the weight / both agree; pink = no sample
+            const Color verdict[4] = { Color{ 1, 0, 0 }, Color{ 1, 0.5f, 0 }, Color{ 1, 1, 0 }, Color{ 0, 0, 1 } };
+            const Vec3 out_dir     = vec3_neg(ray.dir);
+            if (bsdf.is_all_delta()) {
+                const Vec3 r      = vec3_reflect(out_dir, surf.local.col[2]);
+                const Color evl   = bsdf.eval(r, out_dir);
+                const float pdf   = bsdf.pdf(r, out_dir);
+                const int pdf_ok  = igm_abs(0 - pdf) <= flt_eps ? 1 : 0;
+                const int w_ok    = igm_abs(0 - evl.r) + igm_abs(0 - evl.g) + igm_abs(0 - evl.b) <= flt_eps ? 1 : 0;
+                return verdict[(w_ok << 1) | pdf_ok];
+            }
+            Rng tmp{ hash_combine(hash_combine(hash_combine(0x811C9DC5u, igm_bits(hit.distance)), igm_bits(hit.u)), igm_bits(hit.v)), 1 };
+            BsdfSample ms;
+            if (!bsdf.sample(tmp, out_dir, ms))
+                return Color{ 1, 0, 1 };
+            const float pdf  = bsdf.pdf(ms.in_dir, out_dir);
+            const Color evl  = color_mulf(bsdf.eval(ms.in_dir, out_dir), safe_div(1, pdf));
+            const int pdf_ok = igm_abs(ms.pdf - pdf) <= 0.001f ? 1 : 0;
+            const int w_ok   = igm_abs(ms.color.r - evl.r) + igm_abs(ms.color.g - evl.g) + igm_abs(ms.color.b - evl.b) <= 0.001f ? 1 : 0;
+            return verdict[(w_ok << 1) | pdf_ok];
+        }
+        case 25: return bsdf.albedo(vec3_neg(ray.dir));
+        case 26: return inner < 0 ? Color{ 0, 0, 0 } : palette(inner);
+        case 27: return outer < 0 ? Color{ 0, 0, 0 } : palette(outer);
+        default: return absv(surf.local.col[2]);
+        }
+    }
+
     // on_hit (pathtracer.art:119-139) with make_emissive_material (driver/material.art:22-30)
     bool on_hit(const Ray& ray, const Hit& hit, const SurfaceElement& surf, const PTRayPayload& pt, const ig_material& mat, Color& out) const
     {
-        if (ambient_occlusion)
+        if (ambient_occlusion || debug)
             return false;
         if (mat.light_id >= 0 && surf.is_entering) {
             const float dot = -vec3_dot(ray.dir, surf.local.col[2]);
@@ -2861,7 +2977,7 @@ struct PathTracer {
     // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
     bool on_miss(const Ray& ray, const PTRayPayload& pt, Color& out) const
     {
-        if (ambient_occlusion)
+        if (ambient_occlusion || debug)
             return false;
         int inflights = 0;
         Color color   = Color{ 0, 0, 0 };
@@ -2918,7 +3034,7 @@ struct PathTracer {
     // on_bounce (pathtracer.art:170-210)
     bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, const ig_material& mat, Ray& new_ray) const
     {
-        if (ambient_occlusion)
+        if (ambient_occlusion || debug)
             return false;
         if (pt.depth + 1 > max_path_len)
             return false;

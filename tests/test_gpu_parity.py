@@ -1317,3 +1317,34 @@ def test_phong_and_mask_bsdfs_vs_oracle(gpu_device):
     types = [sc.scene.materials[i].bsdf_type for i in range(sc.scene.material_count)]
     assert 8 in types and types.count(6) == 2
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=27, iters=2)
+
+
+@pytest.mark.parametrize("mode", list(range(28)))
+def test_debug_views_vs_oracle(gpu_device, mode):
+    """All 28 debug views on a scene with meshes, an analytic sphere, an emitter, delta and rough materials, a fog box: the HIP
+    image equals the oracle's (the views are deterministic functions of the first hit); the mode is a registry parameter."""
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["technique"] = {"type": "debug", "mode": "normal"}
+    s["media"] = [{"type": "homogeneous", "name": "fog", "sigma_a": 0.5, "sigma_s": 0}, {"type": "vacuum", "name": "hole"}]
+    s["bsdfs"] += [{"type": "passthrough", "name": "null"}, {"type": "conductor", "name": "metal", "roughness": 0.2}]
+    s["shapes"] += [{"type": "cube", "name": "fogbox", "width": 0.6, "height": 0.5, "depth": 0.6}, {"type": "sphere", "name": "ball", "radius": 0.25}]
+    s["entities"] += [{"name": "fogbox", "shape": "fogbox", "bsdf": "null", "inner_medium": "fog", "outer_medium": "hole", "transform": [{"translate": [0.5, -0.6, 0.3]}]},
+                      {"name": "ball", "shape": "ball", "bsdf": "metal", "transform": [{"translate": [-0.5, -0.5, 0.4]}, {"scale": [1, 1.5, 0.8]}]}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    gpu_device.assign_scene(sc)
+    gpu_device.set_parameter("__debug_mode", mode)
+    gpu_device.resize(96, 72)
+    gpu_device.clear_framebuffer()
+    gpu_device.render(4, 96, 72, iteration=0, seed=33)
+    fb = gpu_device.framebuffer()
+    sc.scene.technique.debug_mode = mode  # the oracle reads the table
+    ref, st = oracle.render(sc, 4, 96, 72, iteration=0, seed=33)
+    assert st["bounce_rays"] == 0 and st["shadow_rays"] == 0
+    assert np.isfinite(ref).all() and ref.any()
+    if mode == 24:
+        # DEBUG_CHECK_BSDF thresholds a float comparison at 1e-3: a pixel may flip between two verdict colours
+        assert np.mean(np.any(np.abs(fb - ref) > 1e-4, axis=-1)) < 0.01
+    else:
+        np.testing.assert_allclose(fb, ref, rtol=2e-5, atol=2e-6)

@@ -1270,3 +1270,52 @@ def test_orennayar_diffuse_known_answer():
     s["bsdfs"][0]["roughness"] = 0
     lam, _ = oracle.render(LoadedScene.from_string(json.dumps(s), SCENES, 33, 33), 16, 33, 33, seed=2)
     np.testing.assert_allclose(lam[16, 16], kd / np.pi * 2, rtol=3e-3)
+
+
+# ---- the debug views (src/artic/technique/debugtracer.art, src/runtime/technique/DebugMode.cpp)
+
+def _debug_scene(mode, size=(32, 32)):
+    s = flat_scene(size=size)
+    s["technique"] = {"type": "debug", "mode": mode}
+    return LoadedScene.from_string(json.dumps(s), SCENES, *size)
+
+
+def test_debug_technique_known_answers():
+    """The first hit of every camera ray as a property; the integrator plane (z = 0, normal -z after flip_normals, 2 x 2, one
+    unit in front of a 90 degree camera) makes them checkable by hand."""
+    names = ["Normal", "tangent", "Bitangent", "geometric normal", "local normal", "local tangent", "local bitangent", "local geometric normal",
+             "texture coords", "prim coords", "point", "local point", "generated coords", "hit distance", "area", "raw prim id", "prim id",
+             "raw entity id", "entity id", "raw material id", "material id", "is emissive", "is specular", "is entering", "check bsdf", "albedo",
+             "medium inner", "medium outer"]
+    for i, n in enumerate(names):
+        assert _debug_scene(n).scene.technique.debug_mode == i
+    assert _debug_scene("no such mode").scene.technique.debug_mode == 0
+    ys, xs = np.mgrid[0:32, 0:32]
+    px, py = (xs + 0.5) / 16 - 1, 1 - (ys + 0.5) / 16
+
+    def img(mode, spi=16):
+        sc = _debug_scene(mode)
+        assert sc.scene.technique.type == 3
+        fb, st = oracle.render(sc, spi, 32, 32, seed=4)
+        assert st["bounce_rays"] == 0 and st["shadow_rays"] == 0
+        return fb
+    np.testing.assert_allclose(img("normal"), np.broadcast_to([0, 0, 1], (32, 32, 3)), atol=1e-6)  # |n|
+    np.testing.assert_allclose(img("geometric normal"), np.broadcast_to([0, 0, 1], (32, 32, 3)), atol=1e-6)
+    pt = img("point")
+    np.testing.assert_allclose(pt[..., 0], -px, atol=0.04)  # right = dir x up = -x; pixel centre +- half a pixel of jitter (1 / 32)
+    np.testing.assert_allclose(pt[..., 1], py, atol=0.04)
+    np.testing.assert_allclose(pt[..., 2], 0, atol=1e-6)
+    np.testing.assert_allclose(img("hit distance")[..., 0], np.sqrt(px * px + py * py + 1), atol=0.03)
+    np.testing.assert_allclose(img("area"), 2.0, rtol=1e-6)  # two triangles of a 2 x 2 rectangle
+    gen = img("generated coords")
+    np.testing.assert_allclose(gen[..., 0], (1 - px) / 2, atol=0.02)  # position inside the shape's bounding box
+    assert np.all(img("raw entity id") == 0) and np.all(img("raw material id") == 0)
+    assert set(np.unique(img("raw prim id", spi=1))) <= {0.0, 1.0}
+    np.testing.assert_allclose(img("entity id"), np.broadcast_to([0.45, 0.37663, 0.1125], (32, 32, 3)), rtol=1e-6)  # palette(0)
+    np.testing.assert_allclose(img("is emissive"), np.broadcast_to([1, 0, 0], (32, 32, 3)))  # false = red
+    np.testing.assert_allclose(img("is entering"), np.broadcast_to([0, 0, 1], (32, 32, 3)))  # true = blue
+    np.testing.assert_allclose(img("check bsdf"), np.broadcast_to([0, 0, 1], (32, 32, 3)))   # sample agrees with eval / pdf
+    np.testing.assert_allclose(img("albedo"), 1.0)
+    assert not img("medium inner").any()
+    uv = img("texture coords")
+    assert 0 <= uv.min() and uv.max() <= 1 and uv[..., 2].max() == 0
