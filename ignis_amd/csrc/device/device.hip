@@ -1078,7 +1078,8 @@ void render(igd_device* d, const igd_render_settings* rs)
         for (int round = 0;; ++round) {
             if (known_live == 0)
                 break;
-            if (known_live <= d->tail_threshold && !mis_aovs) { // (the tail kernels keep one accumulator per path: rounds to the end instead)
+            // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
+            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG) {
                 live     = known_live;
                 run_tail = true;
                 break;

@@ -230,7 +230,7 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
-template <bool FULL>
+template <bool FULL, bool DEBUG_VIEWS = false>
 __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_S
             in.ent     = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
-            shade_vertex<FULL>(sc, fr, in, out);
+            shade_vertex<FULL, DEBUG_VIEWS>(sc, fr, in, out);
             if (out.has_radiance) {
                 // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_S
                 os += s_wave_cnt[1][w];
             if (out.bounce) {
                 const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
-                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, out.b_tmin);
+                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, FULL ? out.b_tmin : kRayOffset);
                 a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
                 a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
                 a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
@@ -561,10 +561,13 @@ void launch_generate(const GenerateArgs& in, hipStream_t stream)
 
 template __global__ void k_shade<false>(const ShadeArgs);
 template __global__ void k_shade<true>(const ShadeArgs);
+template __global__ void k_shade<true, true>(const ShadeArgs);
 
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream)
 {
-    if (full_bsdfs)
+    if (args.scene.tech.type == IG_TECHNIQUE_DEBUG) // (no bounces: the tail kernels never see this technique)
+        hipLaunchKernelGGL((k_shade<true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    else if (full_bsdfs)
         hipLaunchKernelGGL((k_shade<true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else
         hipLaunchKernelGGL((k_shade<false>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);

@@ -2073,19 +2073,19 @@ struct PathVertexOut {
     int b_depth;
 };
 
-// colormap::palette (core/colormap.art:68-92)
-IG_DEV Col debug_palette(int i)
-{
-    const float c[23][3] = {
+// colormap::palette (core/colormap.art:68-92); in constant memory: as a local array it would live in scratch
+__device__ __constant__ const float kDebugPalette[23][3] = {
         { 0.450000f, 0.376630f, 0.112500f }, { 0.112500f, 0.450000f, 0.405978f }, { 0.112500f, 0.450000f, 0.229891f }, { 0.450000f, 0.112500f, 0.376630f },
         { 0.435326f, 0.450000f, 0.112500f }, { 0.112500f, 0.141848f, 0.450000f }, { 0.435326f, 0.112500f, 0.450000f }, { 0.112500f, 0.450000f, 0.141848f },
         { 0.347283f, 0.450000f, 0.112500f }, { 0.450000f, 0.112500f, 0.200543f }, { 0.112500f, 0.229891f, 0.450000f }, { 0.450000f, 0.288587f, 0.112500f },
         { 0.347283f, 0.112500f, 0.450000f }, { 0.450000f, 0.112500f, 0.288587f }, { 0.450000f, 0.112500f, 0.112500f }, { 0.450000f, 0.200543f, 0.112500f },
         { 0.171196f, 0.450000f, 0.112500f }, { 0.112500f, 0.450000f, 0.317935f }, { 0.259239f, 0.450000f, 0.112500f }, { 0.259239f, 0.112500f, 0.450000f },
         { 0.112500f, 0.405978f, 0.450000f }, { 0.171196f, 0.112500f, 0.450000f }, { 0.112500f, 0.317935f, 0.450000f }
-    };
+};
+IG_DEV Col debug_palette(int i)
+{
     const int k = i % 23;
-    return Col{ c[k][0], c[k][1], c[k][2] };
+    return Col{ kDebugPalette[k][0], kDebugPalette[k][1], kDebugPalette[k][2] };
 }
 
 // on_hit of make_debug_renderer (technique/debugtracer.art:3-140) over the point mappers of driver/pointmapper.art:28-36
@@ -2169,7 +2169,9 @@ IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, con
     case 22: return bsdf.all_delta() ? yes : no;
     case 23: return surf.entering ? yes : no;
     case 24: { // DEBUG_CHECK_BSDF: red / orange / yellow / blue = neither / only the pdf / only the weight / both agree; pink = no sample
-        const Col verdict[4] = { Col{ 1, 0, 0 }, Col{ 1, 0.5f, 0 }, Col{ 1, 1, 0 }, Col{ 0, 0, 1 } };
+        auto verdict = [](int index) { // [red, orange, yellow, blue](index)
+            return index == 0 ? Col{ 1, 0, 0 } : (index == 1 ? Col{ 1, 0.5f, 0 } : (index == 2 ? Col{ 1, 1, 0 } : Col{ 0, 0, 1 }));
+        };
         const f3 N = surf.local.c2, out_dir = -in.dir;
         if (bsdf.all_delta()) {
             const f3 r       = N * (2 * dot3(N, out_dir)) - out_dir;
@@ -2177,7 +2179,7 @@ IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, con
             const float pdf  = bsdf.pdf(r, out_dir);
             const int pdf_ok = igm_abs(0 - pdf) <= kFltEps ? 1 : 0;
             const int w_ok   = igm_abs(0 - evl.r) + igm_abs(0 - evl.g) + igm_abs(0 - evl.b) <= kFltEps ? 1 : 0;
-            return verdict[(w_ok << 1) | pdf_ok];
+            return verdict((w_ok << 1) | pdf_ok);
         }
         Tea tmp{ fnv_step(fnv_step(fnv_step(0x811C9DC5u, igm_bits(in.t)), igm_bits(in.u)), igm_bits(in.v)), 1 };
         f3 in_dir;
@@ -2190,7 +2192,7 @@ IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, con
         const Col evl    = bsdf.eval(in_dir, out_dir) * safe_div(1, pdf);
         const int pdf_ok = igm_abs(spdf - pdf) <= 0.001f ? 1 : 0;
         const int w_ok   = igm_abs(scol.r - evl.r) + igm_abs(scol.g - evl.g) + igm_abs(scol.b - evl.b) <= 0.001f ? 1 : 0;
-        return verdict[(w_ok << 1) | pdf_ok];
+        return verdict((w_ok << 1) | pdf_ok);
     }
     case 25: return bsdf.albedo(-in.dir);
     case 26: return inner < 0 ? Col{ 0, 0, 0 } : debug_palette(inner);
@@ -2210,7 +2212,9 @@ IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, techniq
 
 // gpu_hit_shade / gpu_miss_shade body (driver/mapping_gpu.art:123-274) with the path tracer
 // callbacks on_hit / on_shadow / on_bounce / on_miss (technique/pathtracer.art:52-210).
-template <bool FULL>
+// DEBUG_VIEWS: the instantiation for the debug technique (its 28 views, with a second copy of the BSDF code for the BSDF check,
+// cost the ordinary full kernel ten times its spills when they were a run-time branch of it)
+template <bool FULL, bool DEBUG_VIEWS = false>
 IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out)
 {
     out.has_radiance = false;
@@ -2292,7 +2296,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
-    if (FULL && tech.type == IG_TECHNIQUE_DEBUG) {
+    if constexpr (FULL && DEBUG_VIEWS) {
         // on_hit of make_debug_renderer (technique/debugtracer.art:3-140): one of 28 properties of the first hit; nothing else
         out.has_radiance = true;
         out.radiance     = debug_color<FULL>(sc, tech.debug_mode, in, surf, bsdf, mat, sc.entity_material[in.ent]);

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
                 in.contrib = out.b_contrib;
                 in.depth   = out.b_depth;
                 in.eta     = out.b_eta;
-                tmin       = out.b_tmin;
+                tmin       = FULL ? out.b_tmin : kRayOffset;
                 tmax       = kFltMax;
                 flags      = IG_RAY_FLAG_BOUNCE;
                 ++hops;
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(kTailThreads, 3) k_tail_wave(const TailArgs a)
             const unsigned long long mb = __ballot(out.bounce), ms = __ballot(out.shadow);
             if (out.bounce) {
                 const uint32_t o = n_out + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                dst.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, out.b_tmin);
+                dst.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, kRayOffset); // (lean variant: no medium bounces)
                 dst.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
                 dst.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
                 dst.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
