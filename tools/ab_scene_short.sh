@@ -1,0 +1,14 @@
+#!/bin/bash
+# tools/ab_scene_short.sh <scene> <steps> <name> ...: ab_scene.sh with 16 warm-up steps
+SCENE=$1; STEPS=$2; shift; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+for rep in 1 2; do
+for n in "$@"; do
+  if [ "$n" = base ]; then unset IGD_LIBRARY; else export IGD_LIBRARY=$ROOT/ignis_amd/lib/var/libig_device_hip_$n.so; fi
+  timeout 600 python $ROOT/bench.py --scene $SCENE --steps $STEPS --warmup 16 --no-cpu-baseline --no-literal-config 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+s = d['stage_ms_rank0']
+print('%-14s %8.1f Mrays/s   trav1 %7.1f  shade %7.1f  trav2 %7.1f  tail %6.1f' % ('$n', d['value'], s['ms_traverse_primary'], s['ms_shade'], s['ms_traverse_secondary'], s['ms_tail']))"
+done
+done
