@@ -501,6 +501,9 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->light_cdf.upload(s->light_cdf, simple_selector ? n_finite : 0);
     if (s->media_count && !s->media)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: media_count without media" };
+    // the volumetric path tracer keeps depth and current medium in one word of the stream (16 bits each)
+    if (s->technique.type == IG_TECHNIQUE_VOLPATH && (s->media_count > 0xFFFEu || s->technique.max_depth > 0xFFFF))
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the volumetric path tracer supports at most 65534 media and a max_depth of 65535" };
     d->media.upload(s->media, s->media_count);
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
@@ -1786,6 +1789,8 @@ int32_t igd_set_parameter_i32(igd_device* dev, const char* name, int32_t value)
             dst = &dev->dscene.tech.min_depth;
         if (!dst || *dst == value)
             return;
+        if (dst == &dev->dscene.tech.max_depth && dev->dscene.tech.type == IG_TECHNIQUE_VOLPATH && value > 0xFFFF)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "__tech_max_depth: the volumetric path tracer supports a max_depth of at most 65535" };
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         flushPending(dev);
         *dst = value;
