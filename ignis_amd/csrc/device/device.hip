@@ -691,6 +691,8 @@ void collect(igd_device* d, igd_device::Flight& f)
     d->stats.nodes_primary += q.nodes[0], d->stats.nodes_secondary += q.nodes[1];
     d->stats.tris_primary += q.tris[0], d->stats.tris_secondary += q.tris[1];
     d->stats.leaves_primary += q.leaves[0], d->stats.leaves_secondary += q.leaves[1];
+    for (int k = 0; k < 6; ++k)
+        d->stats.section_passes[k] += q.section_passes[k], d->stats.section_lanes[k] += q.section_lanes[k];
     for (const auto& sp : f.spans) {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, sp.second.first, sp.second.second));

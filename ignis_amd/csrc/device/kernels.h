@@ -96,6 +96,7 @@ struct QueueState {
     // statistics (Statistics.h:57-64)
     unsigned long long camera_rays, bounce_rays, shadow_rays, unoccluded;
     unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches
+    unsigned long long section_passes[6], section_lanes[6]; // igd_stats: wave-level section executions and the lanes with work in them
 };
 
 struct TraverseArgs {

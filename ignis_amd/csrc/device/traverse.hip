@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             atomicAdd(&a.qs->leaves[ANY_HIT], (unsigned long long)l);
             if (ANY_HIT)
                 atomicAdd(&a.qs->unoccluded, (unsigned long long)uo);
+            for (int k = 0; k < 3; ++k) {
+                atomicAdd(&a.qs->section_passes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)tr.sec_pass[k]);
+                atomicAdd(&a.qs->section_lanes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)tr.sec_lane[k]);
+            }
         }
     }
 }

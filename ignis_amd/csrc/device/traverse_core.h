@@ -92,11 +92,14 @@ struct Traverser {
     uint2* deep; // this lane's column of the deep-stack buffer
     uint32_t deep_stride;
     uint32_t st_nodes, st_tris, st_leaves;
+    uint32_t sec_pass[3], sec_lane[3]; // STATS: executions of the three sections by this wave / lanes that had work in them (wave-uniform)
 
     IG_DEV void init_counters()
     {
         overflow = false;
         st_nodes = st_tris = st_leaves = 0;
+        for (int k = 0; k < 3; ++k)
+            sec_pass[k] = sec_lane[k] = 0;
         // a lane without a ray: finished, mode 0 -> step() leaves it alone
         finished  = true;
         mode      = 0;
@@ -287,6 +290,8 @@ struct Traverser {
             gray.dir     = f3{ g2.y, g2.z, g2.w };
             // leaves whose box (or visibility mask) rejects the ray cost only this short loop
             const bool here = mode == 2;
+            if (STATS)
+                sec_pass[0] += 1, sec_lane[0] += (uint32_t)__popcll(__ballot(here));
             bool scanning   = here;
             bool enter      = false;
             int enter_at    = 0;
@@ -392,8 +397,10 @@ struct Traverser {
             pop_top(st, tid, here);
             const float4* nf = reinterpret_cast<const float4*>(np);
             const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
-            if (STATS)
+            if (STATS) {
                 st_nodes += here ? 1u : 0u;
+                sec_pass[1] += 1, sec_lane[1] += (uint32_t)__popcll(__ballot(here));
+            }
             bool pushed           = false;
             const float node_tmax = level ? ltmax : tmax;
             f3 inv = loc.inv_dir, io = loc.inv_org;
@@ -443,6 +450,8 @@ struct Traverser {
         if (!SPHERES && __popcll(__ballot(mode == 1)) >= quorum) {
             while (__any(mode == 1)) {
                 const bool here   = mode == 1;
+                if (STATS)
+                    sec_pass[2] += 1, sec_lane[2] += (uint32_t)__popcll(__ballot(here));
                 const uint8_t* tp = geom + tri_off + (here ? (uint32_t)tri_cursor * 208u : 0u);
                 tri_cursor += here ? 1 : 0;
                 // two triangles of the packet at a time (8-byte halves of its twelve SoA rows): 24 live registers instead

@@ -86,6 +86,10 @@ typedef struct igd_stats {
     uint32_t pad;
     uint64_t tail_rays; /* paths finished by the single-launch tail kernel instead of more rounds */
     double ms_tail;
+    /* k_traverse executes its three sections (0 entity leaf, 1 inner node, 2 triangle packet) for whole waves under predicates:
+     * section_passes counts wave-level executions, section_lanes the lanes that had work in them, [0..2] closest-hit launches,
+     * [3..5] any-hit launches; lanes / (64 * passes) is the useful share of the issued section instructions (acquire_stats >= 2) */
+    uint64_t section_passes[6], section_lanes[6];
 } igd_stats;
 
 /* IDeviceInterface::getVersion (IDeviceInterface.h:11) */

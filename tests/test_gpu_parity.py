@@ -1348,3 +1348,22 @@ def test_debug_views_vs_oracle(gpu_device, mode):
         assert np.mean(np.any(np.abs(fb - ref) > 1e-4, axis=-1)) < 0.01
     else:
         np.testing.assert_allclose(fb, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_section_counters_are_consistent(diamond_scene, monkeypatch):
+    """igd_stats.section_passes / section_lanes (the useful share of k_traverse's predicated sections): with the tail kernels off,
+    the lanes of the inner-node section are exactly the nodes counter, those of the entity-leaf section at most the leaves counter
+    (one execution scans several rejected leaves), and no section reports more than 64 lanes per execution."""
+    from ignis_amd import Device
+    monkeypatch.setenv("IGD_TAIL_THRESHOLD", "0")
+    dev = Device(0, acquire_stats=True)
+    dev.assign_scene(diamond_scene)
+    for it in range(2):
+        dev.render(4, 256, 192, iteration=it, seed=3)
+    st = dev.stats()
+    dev.close()
+    p, l = st["section_passes"], st["section_lanes"]
+    assert all(0 < l[k] <= 64 * p[k] for k in range(6))
+    assert l[1] == st["nodes_primary"] and l[4] == st["nodes_secondary"]
+    assert l[0] <= st["leaves_primary"] and l[3] <= st["leaves_secondary"]
+    assert 0.3 < sum(l[:3]) / (64.0 * sum(p[:3])) < 1
