@@ -1129,6 +1129,9 @@ struct BsdfCtx {
     Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
     Col kd;    // diffuse reflectance (constant or checkerboard)
     std::conditional_t<FULL && TOP, BlendInner, NoBlendInner> blend;
+    // make_doublesided_bsdf (bsdf/common.art:28-46) on a surface hit from behind: the BSDF is built as if entered and every
+    // direction is negated on the way in, the sampled one on the way out (full variant, outermost wrapper only)
+    bool ds_flip = false;
 
     IG_DEV BsdfCtx(const DevScene& sc, const ig_material& m, const Surf& s, f3 ray_dir)
         : mat(&m)
@@ -1137,8 +1140,12 @@ struct BsdfCtx {
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
             surf.local = bumped_frame(sc, m, s, ray_dir);
         kd = material_color(sc, m, s);
-        if constexpr (FULL && TOP)
+        if constexpr (FULL && TOP) {
             blend.sc = &sc;
+            ds_flip  = (m.flags & IG_MAT_DOUBLESIDED) && !s.entering;
+            if (ds_flip)
+                surf.entering = true;
+        }
     }
     // a BSDF inside a blend: it sees the blend's surface (make_mix_bsdf, bsdf/mix.art:4-68)
     IG_DEV BsdfCtx(const ig_material& m, const Surf& s, Col color)
@@ -1228,6 +1235,8 @@ struct BsdfCtx {
     // Bsdf::albedo of each model (the "Albedo" AOV of technique/internal/infobuffer.art:13-21)
     IG_DEV Col albedo(f3 out_dir) const
     {
+        if constexpr (FULL && TOP)
+            out_dir = ds_flip ? -out_dir : out_dir;
         const f3 N = surf.local.c2;
         switch (mat->bsdf_type) {
         case IG_BSDF_PHONG:       // ks (bsdf/phong.art:20)
@@ -1267,6 +1276,8 @@ struct BsdfCtx {
     {
         const f3 N = surf.local.c2;
         if constexpr (FULL && TOP) {
+            in_dir  = ds_flip ? -in_dir : in_dir;
+            out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
                 return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         }
@@ -1305,6 +1316,8 @@ struct BsdfCtx {
     IG_DEV float pdf(f3 in_dir, f3 out_dir) const
     {
         if constexpr (FULL && TOP) {
+            in_dir  = ds_flip ? -in_dir : in_dir;
+            out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
                 const float k = mat->p[0];
                 if (k <= 0)
@@ -1335,6 +1348,16 @@ struct BsdfCtx {
     }
     // returns false when the sample is rejected
     IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
+    {
+        if constexpr (FULL && TOP) {
+            const bool ok = sample_inner(rnd, ds_flip ? -out_dir : out_dir, in_dir, pdf_out, color, s_eta, sdelta);
+            in_dir        = ds_flip ? -in_dir : in_dir;
+            return ok;
+        } else {
+            return sample_inner(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta);
+        }
+    }
+    IG_DEV bool sample_inner(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
     {
         const f3 N = surf.local.c2;
         if constexpr (FULL && TOP) {

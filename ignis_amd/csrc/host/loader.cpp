@@ -1362,6 +1362,15 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             aux.list.push_back(im);
             aux.names.push_back(inner);
         }
+    } else if (type == "twosided" || type == "doublesided") {
+        // DoubleSidedBSDF.cpp:16-35: make_doublesided_bsdf around the inner BSDF (the outermost wrapper only)
+        const std::string inner = bsdf->getString("bsdf");
+        if (inner.empty())
+            fail("BSDF '" + name + "': has no inner bsdf given");
+        if (depth > 0)
+            fail("BSDF '" + name + "': a two-sided BSDF inside another BSDF is not supported by the HIP backend");
+        m = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
+        m.flags |= IG_MAT_DOUBLESIDED;
     } else if (type == "mask" || type == "cutoff") {
         // MaskBSDF.cpp:17-57: make_mix_bsdf(masked, passthrough, weight) ("inverted": the other way round); "cutoff" turns the
         // weight into 0 / 1 against a threshold. Constant weights only (the reference's scenes drive it with noise expressions).

@@ -110,6 +110,8 @@ enum ig_material_flags {
     IG_MAT_IMAGE      = 1u << 4, /* diffuse reflectance / principled base colour is the bitmap texture tex_refl
                                   * (DiffuseBSDF.cpp:18, texture/image.art) */
     IG_MAT_CLEARCOAT_ALL = 1u << 6, /* principled: clearcoat_top_only = false (PrincipledBSDF.cpp:56) */
+    IG_MAT_DOUBLESIDED = 1u << 7, /* wrapped in make_doublesided_bsdf (src/artic/bsdf/common.art:28-46; DoubleSidedBSDF.cpp "twosided" /
+                                    * "doublesided"): hit from behind, the BSDF is built as if entered and used with both directions negated */
 };
 
 /* One record per material (= unique bsdf / area-light entity,

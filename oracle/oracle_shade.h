@@ -1400,6 +1400,15 @@ struct Bsdf {
     const ig_material* mat;
     const SurfaceElement* surf;
     const igd_scene* scene = nullptr; // bitmap reflectance lookups
+    // make_doublesided_bsdf (bsdf/common.art:28-46) on a surface hit from behind: `surf` already has is_entering = true (the
+    // caller's copy), every direction is negated on the way in and the sampled one on the way out
+    bool flip = false;
+    Bsdf unflipped() const
+    {
+        Bsdf b = *this;
+        b.flip = false;
+        return b;
+    }
 
     // plastic: mat1.is_all_delta & mat2.is_all_delta with a diffuse mat1 (mix.art:63)
     bool is_all_delta() const
@@ -1496,6 +1505,8 @@ struct Bsdf {
     // Bsdf::albedo per model (what wrap_infobuffer_renderer splats, technique/internal/infobuffer.art:13-21)
     Color albedo(Vec3 out_dir) const
     {
+        if (flip)
+            return unflipped().albedo(vec3_neg(out_dir));
         const Vec3 N = surf->local.col[2];
         if (mat->bsdf_type == IG_BSDF_PHONG) // ks (phong.art:20)
             return Color{ mat->p[0], mat->p[1], mat->p[2] };
@@ -1527,6 +1538,8 @@ struct Bsdf {
     // delta BSDFs evaluate to black (dielectric.art:16-17)
     Color eval(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (flip)
+            return unflipped().eval(vec3_neg(in_dir), vec3_neg(out_dir));
         if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
             return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         if (mat->bsdf_type == IG_BSDF_PHONG)
@@ -1563,6 +1576,8 @@ struct Bsdf {
     }
     float pdf(Vec3 in_dir, Vec3 out_dir) const
     {
+        if (flip)
+            return unflipped().pdf(vec3_neg(in_dir), vec3_neg(out_dir));
         if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
             const float k = mat->p[0];
             if (k <= 0)
@@ -1591,6 +1606,12 @@ struct Bsdf {
     }
     bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
     {
+        if (flip) {
+            if (!unflipped().sample(rnd, vec3_neg(out_dir), s))
+                return false;
+            s.in_dir = vec3_neg(s.in_dir);
+            return true;
+        }
         if (mat->bsdf_type == IG_BSDF_BLEND) {
             // make_join_bsdf.sample (mix.art:27-55)
             const Bsdf m1 = inner(0), m2 = inner(1);

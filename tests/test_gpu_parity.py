@@ -1367,3 +1367,22 @@ def test_section_counters_are_consistent(diamond_scene, monkeypatch):
     assert l[1] == st["nodes_primary"] and l[4] == st["nodes_secondary"]
     assert l[0] <= st["leaves_primary"] and l[3] <= st["leaves_secondary"]
     assert 0.3 < sum(l[:3]) / (64.0 * sum(p[:3])) < 1
+
+
+def test_twosided_bsdf_vs_oracle(gpu_device):
+    """"twosided" around diffuse, principled and rough-dielectric BSDFs, on walls seen from inside and on open diamonds whose back
+    faces paths hit from behind (make_doublesided_bsdf, bsdf/common.art:28-46)."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    for b in s["bsdfs"]:
+        if b["name"] in ("mat-GrayWall", "mat-ColoredWall", "mat-Diamond"):
+            b["name"] += "-inner"
+    s["bsdfs"] += [{"type": "twosided", "name": "mat-GrayWall", "bsdf": "mat-GrayWall-inner"},
+                   {"type": "principled", "name": "p-inner", "base_color": [0.2, 0.6, 0.9], "roughness": 0.4, "specular_transmission": 0.5, "ior": 1.4},
+                   {"type": "doublesided", "name": "mat-ColoredWall", "bsdf": "p-inner"},
+                   {"type": "twosided", "name": "mat-Diamond", "bsdf": "mat-Diamond-inner"}]
+    s["entities"] = [e for e in s["entities"] if e["name"] != "Back"]
+    s["lights"].append({"type": "env", "name": "sky", "radiance": [0.4, 0.4, 0.5]})
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 7)) >= 3
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=37, iters=2)

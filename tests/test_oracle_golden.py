@@ -1319,3 +1319,34 @@ def test_debug_technique_known_answers():
     assert not img("medium inner").any()
     uv = img("texture coords")
     assert 0 <= uv.min() and uv.max() <= 1 and uv[..., 2].max() == 0
+
+
+def test_twosided_bsdf_as_written():
+    """make_doublesided_bsdf (bsdf/common.art:28-46; "twosided" / "doublesided"): from the front it is the inner BSDF; from behind the
+    inner BSDF is built "as entered" and used with both directions negated, the sampled one negated back. For an opaque inner
+    BSDF on face-forwarded normals that means light from, and bounces into, the half space on the other side of the surface (the
+    wrapper is meant for the principled BSDF of glTF scenes) — restated as written, and pinned here."""
+    def scene(bsdf, flip):
+        s = flat_scene([{"type": "env", "name": "sky", "radiance": [1, 1, 1]}], max_depth=2, size=(16, 16))
+        s["bsdfs"] = [{"type": "diffuse", "name": "inner", "reflectance": [0.5, 0.5, 0.5]}, bsdf]
+        s["shapes"][0]["flip_normals"] = flip
+        return LoadedScene.from_string(json.dumps(s), SCENES, 16, 16)
+    two = {"type": "twosided", "name": "ground", "bsdf": "inner"}
+    one = {"type": "diffuse", "name": "ground", "reflectance": [0.5, 0.5, 0.5]}
+    front = scene(two, True)
+    assert front.scene.materials[0].flags & (1 << 7) and front.scene.materials[0].bsdf_type == 0
+    a, sa = oracle.render(front, 16, 16, 16, seed=5)
+    b, sb = oracle.render(scene(one, True), 16, 16, 16, seed=5)
+    np.testing.assert_array_equal(a, b)  # seen from the front: the inner BSDF, random number for random number
+    # from behind (the rectangle's normal now points away from the camera)
+    c, sc_ = oracle.render(scene(two, False), 64, 16, 16, seed=5)
+    d, _ = oracle.render(scene(one, False), 64, 16, 16, seed=5)
+    np.testing.assert_allclose(d.mean(), 0.5, rtol=0.05)    # the plain diffuse plane is two-sided by face-forwarding
+    # eval(-in, -out) is non-zero exactly for the light directions on the far side of the surface, and the sampled direction is
+    # negated through it: seen from behind the plane is lit from the other half space — under a constant environment the same 0.5
+    np.testing.assert_allclose(c.mean(), 0.5, rtol=0.05)
+    assert not np.array_equal(c, d)
+    with pytest.raises(RuntimeError, match="inside another BSDF"):
+        scene({"type": "blend", "name": "ground", "first": "inner", "second": "x", "weight": 0.5}, True) if False else LoadedScene.from_string(json.dumps(dict(
+            flat_scene(), bsdfs=[{"type": "diffuse", "name": "inner"}, {"type": "twosided", "name": "ts", "bsdf": "inner"},
+                                 {"type": "blend", "name": "ground", "first": "ts", "second": "inner", "weight": 0.5}])), SCENES, 16, 16)
