@@ -22,6 +22,7 @@
 
 #include "igd_device.h"
 #include "kernels.h"
+#include "ig_expr.h"
 
 namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20);
@@ -115,6 +116,7 @@ struct igd_device {
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy, light_cdf;
     DevBuf<ig_medium> media;
+    DevBuf<uint32_t> expr_code;
     DevBuf<ig_texture> textures;
     DevBuf<uint8_t> texture_data;
     DevBuf<float> cdf_data;
@@ -398,18 +400,24 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
         const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL)
                                                                               : (mat.bsdf_type == IG_BSDF_DIELECTRIC ? (uint32_t)IG_MAT_THIN : 0u);
-        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | principled_flags))
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | principled_flags))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " carries flags its BSDF type does not define" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
         if (mat.bsdf_type == IG_BSDF_BLEND)
             for (int k = 0; k < 2; ++k)
                 if (mat.pad[k] < 0 || mat.pad[k] >= (int32_t)s->material_count || s->materials[mat.pad[k]].bsdf_type == IG_BSDF_BLEND
-                    || (s->materials[mat.pad[k]].flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+                    || (s->materials[mat.pad[k]].flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_COLOR)))
                     throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: blend material " + std::to_string(m) + " has no valid inner materials" };
         const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED || mat.bsdf_type == IG_BSDF_PLASTIC; // p[0..2] reflectance / base colour
         if ((mat.flags & IG_MAT_IMAGE) && (!has_albedo || mat.tex_refl < 0 || mat.tex_refl >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: image-textured material " + std::to_string(m) + " has no valid texture or is neither diffuse nor principled" };
+        if ((mat.flags & IG_MAT_EXPR_COLOR) && (!has_albedo || (mat.flags & (IG_MAT_IMAGE | IG_MAT_CHECKER)) || mat.tex_refl < 0 || !s->expr_code
+                                                || !ige_validate(s->expr_code, s->expr_code_count, (uint32_t)mat.tex_refl, s->textures && s->texture_data ? s->texture_count : 0u)))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material " + std::to_string(m) + " names no valid colour expression program" };
+        if ((mat.flags & IG_MAT_EXPR_NORMAL) && ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) || mat.tex_id < 0 || !s->expr_code
+                                                 || !ige_validate(s->expr_code, s->expr_code_count, (uint32_t)mat.tex_id, s->textures && s->texture_data ? s->texture_count : 0u)))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material " + std::to_string(m) + " names no valid normal expression program" };
         if ((mat.flags & IG_MAT_CHECKER) && !has_albedo)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard colours are only lowered for diffuse and principled BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
@@ -505,6 +513,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     if (s->technique.type == IG_TECHNIQUE_VOLPATH && (s->media_count > 0xFFFEu || s->technique.max_depth > 0xFFFF))
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the volumetric path tracer supports at most 65534 media and a max_depth of 65535" };
     d->media.upload(s->media, s->media_count);
+    d->expr_code.upload(s->expr_code, s->expr_code ? s->expr_code_count : 0);
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
         const uint32_t nc    = t.channels & ~IG_TEX_FLOAT_BIT;
@@ -582,6 +591,13 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.light_cdf            = simple_selector ? d->light_cdf.ptr : nullptr;
     ds.media                = d->media.ptr;
     ds.media_count          = s->media_count;
+    {
+        // the shading kernel with the expression interpreter runs only where a material names a program
+        bool any_expr = false;
+        for (uint32_t i = 0; i < s->material_count; ++i)
+            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL)) != 0;
+        ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
+    }
     ds.scene_radius         = s->scene_radius;
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
@@ -599,7 +615,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
-        d->full_bsdfs |= (s->materials[i].flags & IG_MAT_DOUBLESIDED) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
+        d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
@@ -1084,7 +1100,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             if (known_live == 0)
                 break;
             // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
-            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG) {
+            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && !d->dscene.expr_code) {
                 live     = known_live;
                 run_tail = true;
                 break;
@@ -1608,6 +1624,7 @@ int32_t igd_release_all(igd_device* dev)
         dev->light_codes.release();
         dev->light_cdf.release();
         dev->media.release();
+        dev->expr_code.release();
         dev->textures.release();
         dev->texture_data.release();
         dev->cdf_data.release();

@@ -34,6 +34,7 @@ struct DevScene {
     const float* light_cdf; // IG_SELECTOR_SIMPLE: CDF over the finite lights' flux (null otherwise)
     const ig_medium* media; // IG_TECHNIQUE_VOLPATH: participating media, ig_material.pad[2] names an entity's two sides
     uint32_t media_count;
+    const uint32_t* expr_code; // programs of IG_MAT_EXPR_COLOR / IG_MAT_EXPR_NORMAL materials (include/ig_expr.h)
     float scene_radius;
     // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
     // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)

@@ -230,8 +230,8 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
-template <bool FULL, bool DEBUG_VIEWS = false>
-__global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false>
+__global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? IG_SHADE_OCC_FULL : IG_S
             in.ent     = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
-            shade_vertex<FULL, DEBUG_VIEWS>(sc, fr, in, out);
+            shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out);
             if (out.has_radiance) {
                 // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) k_info(const InfoArgs a)
             const f3 org{ ra.x, ra.y, ra.z }, dir{ rb.x, rb.y, rb.z };
             const ig_material& mat = a.scene.materials[a.scene.entity_material[ent]];
             const Surf surf        = surface_element<true>(a.scene, ent, (int)igm_bits(hit.y), org, dir, hit.z, hit.w, a.in.hit_v[i]);
-            const BsdfCtx<true> bsdf(a.scene, mat, surf, dir);
+            const BsdfCtx<true> bsdf(a.scene, mat, surf, dir, std::true_type{});
             const Col al = bsdf.albedo(-dir);
             const f3 N   = surf.local.c2;
             nrm          = make_float4(N.x * a.inv_spi, N.y * a.inv_spi, N.z * a.inv_spi, 0);
@@ -561,12 +561,15 @@ void launch_generate(const GenerateArgs& in, hipStream_t stream)
 
 template __global__ void k_shade<false>(const ShadeArgs);
 template __global__ void k_shade<true>(const ShadeArgs);
-template __global__ void k_shade<true, true>(const ShadeArgs);
+template __global__ void k_shade<true, true, true>(const ShadeArgs);
+template __global__ void k_shade<true, false, true>(const ShadeArgs);
 
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream)
 {
     if (args.scene.tech.type == IG_TECHNIQUE_DEBUG) // (no bounces: the tail kernels never see this technique)
-        hipLaunchKernelGGL((k_shade<true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+        hipLaunchKernelGGL((k_shade<true, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    else if (args.scene.expr_code) // materials with shading expressions: the instantiation with the interpreter (no tail kernels either)
+        hipLaunchKernelGGL((k_shade<true, false, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else if (full_bsdfs)
         hipLaunchKernelGGL((k_shade<true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else

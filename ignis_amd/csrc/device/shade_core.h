@@ -8,6 +8,7 @@
 
 #include "dev_math.h"
 #include "kernels.h"
+#include "ig_expr.h"
 
 namespace igdev {
 
@@ -456,13 +457,58 @@ IG_DEV m33 align_vectors(f3 a, f3 b) // core/matrix.art:261-284
     m.c2 = f3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
     return m;
 }
+// ---- shading expressions (PExpr strings compiled by the loader into the bytecode of include/ig_expr.h; the reference
+// transpiles them to Artic instead, src/runtime/loader/Transpiler.cpp). The variables are those of sInternalVariables
+// (Transpiler.cpp:338-363) this backend carries; texture alpha reads as 1 (Col has no alpha).
+struct ExprCtx {
+    const DevScene* sc;
+    const Surf* s;
+    f3 view; // "V" / "Rd": -ctx.ray.dir
+    IG_DEV static ige_v4 v3(f3 a) { return ige_v4{ { a.x, a.y, a.z, 0.0f } }; }
+    IG_DEV ige_v4 var(int id) const
+    {
+        switch (id) {
+        case IGE_VAR_UVW: return ige_v4{ { s->tex.x, s->tex.y, 0.0f, 0.0f } };
+        case IGE_VAR_P: return v3(s->point);
+        case IGE_VAR_V: return v3(view);
+        case IGE_VAR_N: return v3(s->local.c2);
+        case IGE_VAR_NG: return v3(s->face_normal);
+        case IGE_VAR_NX: return v3(s->local.c0);
+        case IGE_VAR_NY: return v3(s->local.c1);
+        default: { // IGE_VAR_FRONT
+            const float f = s->entering ? 1.0f : 0.0f;
+            return ige_v4{ { f, f, f, f } };
+        }
+        }
+    }
+    IG_DEV ige_v4 tex(uint32_t id, float u, float v) const
+    {
+        const Col c = image_lookup(*sc, sc->textures[id], f2{ u, v });
+        return ige_v4{ { c.r, c.g, c.b, 1.0f } };
+    }
+    IG_DEV ige_v4 evr(ige_v4 ng, ige_v4 v, ige_v4 n) const
+    {
+        return v3(ensure_valid_reflection(f3{ ng.v[0], ng.v[1], ng.v[2] }, f3{ v.v[0], v.v[1], v.v[2] }, f3{ n.v[0], n.v[1], n.v[2] }));
+    }
+};
+// a call, not inlined: the interpreter's registers are a scratch array, and only materials with an expression pay for it
+__attribute__((noinline)) IG_DEV f3 eval_expr(const DevScene& sc, int32_t start, const Surf& s, f3 view)
+{
+    const ige_v4 r = ige_run(sc.expr_code + start, ExprCtx{ &sc, &s, view });
+    return f3{ r.v[0], r.v[1], r.v[2] };
+}
+
 // the local frame the inner BSDF of a bump-mapped material sees (make_bumpmap -> make_normal_set; camera paths
 // are not adjoint, so nothing else of transform_surf_bsdf applies)
+template <bool EXPR>
 IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& s, f3 ray_dir)
 {
-    const ig_texture& t = sc.textures[mat.tex_id];
     f3 N;
-    if (mat.flags & IG_MAT_NORMALMAP) {
+    if (EXPR && (mat.flags & IG_MAT_EXPR_NORMAL)) {
+        // "transform" BSDF: make_normal_set(ctx, inner, normal expression) (TransformBSDF.cpp:43-46, bsdf/map.art:36-42)
+        N = eval_expr(sc, mat.tex_id, s, -ray_dir);
+    } else if (mat.flags & IG_MAT_NORMALMAP) {
+        const ig_texture& t = sc.textures[mat.tex_id];
         // make_normalmap (bsdf/map.art:55-61): normal given as [0, 1] RGB; mat3x3_left_mul = (col_i . v)
         const Col c    = image_lookup(sc, t, s.tex);
         const f3 nt    = normalize3(f3{ 2 * c.r - 1, 2 * c.g - 1, 2 * c.b - 1 });
@@ -470,6 +516,7 @@ IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& 
         const float st = mat.p[11];
         N = st != 1 ? normalize3(s.local.c2 + (oN - s.local.c2) * st) : oN;
     } else {
+        const ig_texture& t = sc.textures[mat.tex_id];
         const float delta = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
         const Col c0      = image_lookup(sc, t, s.tex);
         const Col cx      = image_lookup(sc, t, f2{ s.tex.x + delta, s.tex.y });
@@ -1111,8 +1158,17 @@ struct NoBlendInner {
 };
 
 // constant, checkerboard or bitmap colour of a material (diffuse reflectance, principled base colour, ...)
-IG_DEV Col material_color(const DevScene& sc, const ig_material& m, const Surf& s)
+// EXPR: the kernel instantiation for scenes with shading expressions (as a run-time branch of the ordinary full kernel the
+// interpreter call cost it its occupancy: 226 VGPRs / 1584 B of scratch against 168 / 472)
+template <bool EXPR>
+IG_DEV Col material_color(const DevScene& sc, const ig_material& m, const Surf& s, f3 view)
 {
+    if constexpr (EXPR) {
+        if (m.flags & IG_MAT_EXPR_COLOR) { // vec4_to_color / vec3_to_color of the expression (Transpiler.cpp:1297-1302), a number as grey
+            const f3 c = eval_expr(sc, m.tex_refl, s, view);
+            return Col{ c.x, c.y, c.z };
+        }
+    }
     if (m.flags & IG_MAT_IMAGE)
         return image_lookup(sc, sc.textures[m.tex_refl], s.tex);
     if (m.flags & IG_MAT_CHECKER) {
@@ -1133,13 +1189,14 @@ struct BsdfCtx {
     // direction is negated on the way in, the sampled one on the way out (full variant, outermost wrapper only)
     bool ds_flip = false;
 
-    IG_DEV BsdfCtx(const DevScene& sc, const ig_material& m, const Surf& s, f3 ray_dir)
+    template <bool EXPR = false>
+    IG_DEV BsdfCtx(const DevScene& sc, const ig_material& m, const Surf& s, f3 ray_dir, std::bool_constant<EXPR> = {})
         : mat(&m)
         , surf(s)
     {
-        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
-            surf.local = bumped_frame(sc, m, s, ray_dir);
-        kd = material_color(sc, m, s);
+        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | (EXPR ? IG_MAT_EXPR_NORMAL : 0)))
+            surf.local = bumped_frame<EXPR>(sc, m, s, ray_dir);
+        kd = material_color<EXPR>(sc, m, surf, -ray_dir); // an expression sees the surface the BSDF is built on (bsdf_inner(ctx.{surf = surf2}))
         if constexpr (FULL && TOP) {
             blend.sc = &sc;
             ds_flip  = (m.flags & IG_MAT_DOUBLESIDED) && !s.entering;
@@ -1157,7 +1214,7 @@ struct BsdfCtx {
     IG_DEV BsdfCtx<FULL, false> inner(int i) const
     {
         const ig_material& m = blend.sc->materials[mat->pad[i]];
-        return BsdfCtx<FULL, false>(m, surf, material_color(*blend.sc, m, surf));
+        return BsdfCtx<FULL, false>(m, surf, material_color<false>(*blend.sc, m, surf, f3{ 0, 0, 0 })); // the loader keeps expressions out of blends
     }
 
     IG_DEV bool all_delta() const
@@ -2237,7 +2294,8 @@ IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, techniq
 // callbacks on_hit / on_shadow / on_bounce / on_miss (technique/pathtracer.art:52-210).
 // DEBUG_VIEWS: the instantiation for the debug technique (its 28 views, with a second copy of the BSDF code for the BSDF check,
 // cost the ordinary full kernel ten times its spills when they were a run-time branch of it)
-template <bool FULL, bool DEBUG_VIEWS = false>
+// EXPR: the instantiation for scenes whose materials carry shading expressions (include/ig_expr.h)
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false>
 IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out)
 {
     out.has_radiance = false;
@@ -2306,7 +2364,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
     const Surf surf = surface_element<FULL>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
-    const BsdfCtx<FULL> bsdf(sc, mat, surf, in.dir);
+    const BsdfCtx<FULL> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 

@@ -22,11 +22,13 @@
 #include "exr.h"
 #include "floatimage.h"
 #include "jpeg.h"
+#include "pexpr.h"
 
 #include <cstring>
 #include <fstream>
 #include <functional>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 
@@ -443,6 +445,7 @@ struct Scene {
     std::vector<ig_texture> textures;
     std::vector<uint8_t> texture_data;
     std::vector<float> cdf_data;
+    std::vector<uint32_t> expr_code; // programs of the shading expressions (include/ig_expr.h)
     igd_scene tables{};
 };
 
@@ -755,6 +758,34 @@ struct TextureBank {
     std::vector<ig_texture>& recs;
     std::vector<uint8_t>& data;
     std::map<std::string, int> ids;
+    // shading expressions: compiled once per use into Scene::expr_code (pexpr.h)
+    std::vector<uint32_t>* expr_code = nullptr;
+    std::map<std::string, igh::pexpr::Param> params; // the scene's "parameters" section
+
+    bool has(const std::string& tex_name) const
+    {
+        for (const auto& t : defs.arr)
+            if (t.getString("name") == tex_name)
+                return true;
+        return false;
+    }
+    igh::pexpr::Program compileExpr(const std::string& src, const std::string& owner)
+    {
+        igh::pexpr::Env env;
+        env.params  = params;
+        env.texture = [&](const std::string& n) { return has(n) ? get(n, owner) : -1; };
+        try {
+            return igh::pexpr::compile(src, env);
+        } catch (const std::runtime_error& e) {
+            fail("'" + owner + "': expression \"" + src + "\": " + e.what());
+        }
+    }
+    int32_t addProgram(const igh::pexpr::Program& prog)
+    {
+        const int32_t at = (int32_t)expr_code->size();
+        expr_code->insert(expr_code->end(), prog.code.begin(), prog.code.end());
+        return at;
+    }
 
     static uint8_t toLinear(uint8_t c)
     {
@@ -1172,6 +1203,63 @@ static uint32_t appendEnvironmentCdf(std::vector<float>& out, const std::vector<
     return (uint32_t)offset;
 }
 
+// A colour property of a BSDF (ShadingTree::addColor, src/runtime/loader/ShadingTree.cpp): a constant, a bitmap or checkerboard
+// texture by name, or a PExpr string, which becomes a program of the expression table unless it folds to a constant.
+static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const JsonValue& textures, TextureBank& bank, ig_material& m, const std::string& name)
+{
+    const JsonValue* col = bsdf.find(key);
+    if (col && col->isString())
+        for (const auto& t : textures.arr)
+            if (t.getString("name") == col->str && (t.getString("type") == "image" || t.getString("type") == "bitmap")) {
+                m.flags |= IG_MAT_IMAGE;
+                m.tex_refl = bank.get(col->str, name);
+                return;
+            }
+    if (col && lowerCheckerboard(*col, textures, m, name))
+        return;
+    V3 c = def;
+    if (col && !parseConstColor(*col, c)) {
+        if (!col->isString())
+            fail("'" + name + "': property '" + key + "' is neither a colour nor an expression");
+        const igh::pexpr::Program prog = bank.compileExpr(col->str, name);
+        using igh::pexpr::Type;
+        if (prog.type == Type::Bool || prog.type == Type::Vec2) // "Expression does not return a number or color" (Transpiler.cpp:1303-1306)
+            fail("'" + name + "': expression of property '" + key + "' is a " + igh::pexpr::typeName(prog.type) + ", not a number or colour");
+        if (!prog.is_const) {
+            m.flags |= IG_MAT_EXPR_COLOR;
+            m.tex_refl = bank.addProgram(prog);
+            return;
+        }
+        c = V3(prog.value[0], prog.value[1], prog.value[2]);
+    }
+    m.p[0] = c.x, m.p[1] = c.y, m.p[2] = c.z;
+}
+
+// the "parameters" section (docs/src/scene/pexpr.rst "Scene Parameters"): number / vector / color constants expressions may name
+static void loadParameters(const JsonValue& doc, std::map<std::string, igh::pexpr::Param>& out)
+{
+    const JsonValue* params = doc.find("parameters");
+    if (!params || !params->isArray())
+        return;
+    for (const auto& p : params->arr) {
+        const std::string pname = p.getString("name"), type = p.getString("type");
+        const JsonValue* v      = p.find("value");
+        if (pname.empty() || !v)
+            continue;
+        igh::pexpr::Param out_p{};
+        if (type == "number" && v->isNumber()) {
+            out_p.type  = igh::pexpr::Type::Num;
+            out_p.value = { (float)v->num, (float)v->num, (float)v->num, (float)v->num };
+        } else if ((type == "vector" || type == "color") && v->isArray() && v->arr.size() == 3 && v->arr[0].isNumber() && v->arr[1].isNumber() && v->arr[2].isNumber()) {
+            out_p.type  = type == "vector" ? igh::pexpr::Type::Vec3 : igh::pexpr::Type::Vec4;
+            out_p.value = { (float)v->arr[0].num, (float)v->arr[1].num, (float)v->arr[2].num, type == "color" ? 1.0f : 0.0f };
+        } else {
+            fail("Parameter '" + pname + "': expected a number, or three numbers for a vector / color");
+        }
+        out[pname] = out_p;
+    }
+}
+
 // Inner materials of blends: appended to the material table after the entity-bound ones (index = aux_base + position)
 struct AuxMaterials {
     std::vector<ig_material> list;
@@ -1199,19 +1287,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
     const std::string type = bsdf->getString("type");
     if (type == "diffuse" || type == "roughdiffuse") {
         m.bsdf_type = IG_BSDF_DIFFUSE;
-        const JsonValue* refl = bsdf->find("reflectance");
-        bool is_bitmap        = false;
-        if (refl && refl->isString())
-            for (const auto& t : textures.arr)
-                if (t.getString("name") == refl->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
-                    is_bitmap = true;
-        if (is_bitmap) {
-            m.flags |= IG_MAT_IMAGE;
-            m.tex_refl = bank.get(refl->str, name);
-        } else if (!(refl && lowerCheckerboard(*refl, textures, m, name))) {
-            const V3 kd = getColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), name);
-            m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
-        }
+        lowerColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
         m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
     } else if (type == "dielectric" || type == "glass" || type == "roughdielectric" || type == "thindielectric") {
         // DielectricBSDF.cpp:13-41; IOR table BSDF.cpp:7-30 (vacuum 1.0, bk7 1.5046)
@@ -1280,19 +1356,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
             fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
         m.bsdf_type = IG_BSDF_PLASTIC;
-        const JsonValue* col = bsdf->find("diffuse_reflectance");
-        bool is_bitmap       = false;
-        if (col && col->isString())
-            for (const auto& t : textures.arr)
-                if (t.getString("name") == col->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
-                    is_bitmap = true;
-        if (is_bitmap) {
-            m.flags |= IG_MAT_IMAGE;
-            m.tex_refl = bank.get(col->str, name);
-        } else if (!(col && lowerCheckerboard(*col, textures, m, name))) {
-            const V3 kd = getColor(*bsdf, "diffuse_reflectance", V3(0.8f, 0.8f, 0.8f), name);
-            m.p[0] = kd.x, m.p[1] = kd.y, m.p[2] = kd.z;
-        }
+        lowerColor(*bsdf, "diffuse_reflectance", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
         m.p[3]      = getConstNumber(*bsdf, "ext_ior", 1.0f, name);  // vacuum (BSDF.cpp:8)
         m.p[4]      = getConstNumber(*bsdf, "int_ior", 1.49f, name); // polypropylene (BSDF.cpp:17)
         const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
@@ -1312,19 +1376,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             if (bsdf->has(key))
                 fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
         m.bsdf_type = IG_BSDF_PRINCIPLED;
-        const JsonValue* col = bsdf->find("base_color");
-        bool is_bitmap       = false;
-        if (col && col->isString())
-            for (const auto& t : textures.arr)
-                if (t.getString("name") == col->str && (t.getString("type") == "image" || t.getString("type") == "bitmap"))
-                    is_bitmap = true;
-        if (is_bitmap) {
-            m.flags |= IG_MAT_IMAGE;
-            m.tex_refl = bank.get(col->str, name);
-        } else if (!(col && lowerCheckerboard(*col, textures, m, name))) {
-            const V3 c = getColor(*bsdf, "base_color", V3(0.8f, 0.8f, 0.8f), name);
-            m.p[0] = c.x, m.p[1] = c.y, m.p[2] = c.z;
-        }
+        lowerColor(*bsdf, "base_color", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
         const float bk7 = 1.5046f; // BSDF.cpp:9
         if (bsdf->has("reflective_ior") || bsdf->has("refractive_ior")) {
             m.p[3] = getConstNumber(*bsdf, "reflective_ior", bk7, name);
@@ -1369,8 +1421,10 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         int slot    = 0;
         for (const std::string& inner : { first, second }) {
             const ig_material im = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
-            if (im.bsdf_type == IG_BSDF_BLEND || (im.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+            if (im.bsdf_type == IG_BSDF_BLEND || (im.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
                 fail("BSDF '" + name + "': nested blends and bump / normal maps inside a blend are not supported by the HIP backend");
+            if (im.flags & IG_MAT_EXPR_COLOR)
+                fail("BSDF '" + name + "': expressions inside a blend are not supported by the HIP backend");
             m.pad[slot++] = aux.base + (int32_t)aux.list.size();
             aux.list.push_back(im);
             aux.names.push_back(inner);
@@ -1395,8 +1449,10 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             weight = weight < getConstNumber(*bsdf, "cutoff", 0.5f, name) ? 0.0f : 1.0f;
         const bool inverted = bsdf->getBool("inverted", false);
         ig_material inner   = lowerBsdf(masked, scene_bsdfs, textures, bank, aux, depth + 1);
-        if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)))
+        if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
             fail("BSDF '" + name + "': blends and bump / normal maps inside a mask are not supported by the HIP backend");
+        if (inner.flags & IG_MAT_EXPR_COLOR)
+            fail("BSDF '" + name + "': expressions inside a mask are not supported by the HIP backend");
         ig_material through{};
         through.bsdf_type = IG_BSDF_TRANSPARENT; // make_passthrough_bsdf = white perfect refraction
         through.light_id  = -1;
@@ -1423,7 +1479,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (inner.empty())
             fail("BSDF '" + name + "': has no inner bsdf given");
         m = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
-        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP))
+        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL))
             fail("BSDF '" + name + "': nested bump / normal maps are not supported by the HIP backend");
         const JsonValue* map = bsdf->find("map");
         if (!map || !map->isString())
@@ -1431,6 +1487,31 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.flags |= type == "bumpmap" ? IG_MAT_BUMP : IG_MAT_NORMALMAP;
         m.tex_id = bank.get(map->str, name);
         m.p[11]  = getConstNumber(*bsdf, "strength", 1.0f, name);
+    } else if (type == "transform") {
+        // TransformBSDF.cpp:17-49: make_normal_set(ctx, inner, normal) with the "normal" vector property (default +Z, as written);
+        // the "tangent" form (make_normal_tangent_set) is not carried
+        const std::string inner = bsdf->getString("bsdf");
+        if (inner.empty())
+            fail("BSDF '" + name + "': has no inner bsdf given");
+        if (bsdf->has("tangent"))
+            fail("BSDF '" + name + "': the 'tangent' form of the transform BSDF is not supported by the HIP backend");
+        m = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
+        if (m.bsdf_type == IG_BSDF_BLEND || (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL | IG_MAT_DOUBLESIDED)))
+            fail("BSDF '" + name + "': blends, two-sided BSDFs and nested normal changes inside a transform BSDF are not supported by the HIP backend");
+        std::string src = "vec3(0, 0, 1)";
+        if (const JsonValue* nv = bsdf->find("normal")) {
+            if (nv->isString())
+                src = nv->str;
+            else if (nv->isArray() && nv->arr.size() == 3 && nv->arr[0].isNumber() && nv->arr[1].isNumber() && nv->arr[2].isNumber())
+                src = "vec3(" + std::to_string(nv->arr[0].num) + ", " + std::to_string(nv->arr[1].num) + ", " + std::to_string(nv->arr[2].num) + ")";
+            else
+                fail("BSDF '" + name + "': 'normal' is neither a vector nor an expression");
+        }
+        const igh::pexpr::Program prog = bank.compileExpr(src, name);
+        if (prog.type != igh::pexpr::Type::Vec3)
+            fail("BSDF '" + name + "': expression of property 'normal' is a " + igh::pexpr::typeName(prog.type) + ", not a vec3");
+        m.flags |= IG_MAT_EXPR_NORMAL;
+        m.tex_id = bank.addProgram(prog);
     } else {
         fail("BSDF '" + name + "': type '" + type + "' is not supported by the HIP backend");
     }
@@ -1878,7 +1959,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     std::vector<ig_light> infinite, finite;
     std::vector<LightEntry> hier_entries; // position / direction / flux per finite light (Light::position, direction, computeFlux)
     std::map<std::string, int32_t> finite_index_of_entity;
-    TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {} };
+    TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {}, &sc->expr_code, {} };
+    loadParameters(doc, bank.params);
     for (const auto& l : jlights.arr) {
         const std::string lname = l.getString("name");
         const std::string type  = l.getString("type");
@@ -2339,6 +2421,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     t.light_cdf_count    = (uint32_t)sc->light_cdf.size();
     t.media              = sc->media.data();
     t.media_count        = (uint32_t)sc->media.size();
+    t.expr_code          = sc->expr_code.empty() ? nullptr : sc->expr_code.data();
+    t.expr_code_count    = (uint32_t)sc->expr_code.size();
     t.materials          = sc->materials.data();
     t.material_count     = (uint32_t)sc->materials.size();
     t.entity_per_material = sc->entity_per_material.data();
@@ -2606,6 +2690,33 @@ int32_t igh_read_image8(const char* path, uint32_t* width, uint32_t* height, uin
                 throw std::runtime_error("igh_read_image8: buffer too small");
             std::memcpy(pixels, img.data.data(), img.data.size());
         }
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
+    }
+}
+
+int32_t igh_eval_expression(const char* source, const float* vars, float result[4], int32_t* type, uint32_t* words)
+{
+    g_last_error.clear();
+    try {
+        if (!source || !result)
+            throw std::runtime_error("igh_eval_expression: NULL argument");
+        struct Vars {
+            const float* v;
+            ige_v4 var(int id) const { return v ? ige_v4{ { v[id * 4], v[id * 4 + 1], v[id * 4 + 2], v[id * 4 + 3] } } : ige_v4{}; }
+            ige_v4 tex(uint32_t, float, float) const { return ige_v4{}; }
+            ige_v4 evr(ige_v4, ige_v4, ige_v4 n) const { return n; } // (ensure_valid_reflection lives with the shading code)
+        };
+        igh::pexpr::Env env;
+        const igh::pexpr::Program prog = igh::pexpr::compile(source, env);
+        const ige_v4 r                 = ige_run(prog.code.data(), Vars{ vars });
+        std::memcpy(result, r.v, sizeof(r.v));
+        if (type)
+            *type = (int32_t)prog.type;
+        if (words)
+            *words = (uint32_t)prog.code.size();
         return 0;
     } catch (const std::exception& e) {
         g_last_error = e.what();

@@ -85,6 +85,7 @@ class Scene(C.Structure):
         ("sphere_leaves", C.POINTER(EntityLeaf1)), ("sphere_leaf_count", C.c_uint32),
         ("light_cdf", C.POINTER(C.c_float)), ("light_cdf_count", C.c_uint32),
         ("media", C.POINTER(Medium)), ("media_count", C.c_uint32),
+        ("expr_code", C.POINTER(C.c_uint32)), ("expr_code_count", C.c_uint32),
     ]
 
 
@@ -125,6 +126,8 @@ def host_lib():
         lib.igh_read_float_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_uint64]
         lib.igh_read_image8.restype = C.c_int32
         lib.igh_read_image8.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_uint64]
+        lib.igh_eval_expression.restype = C.c_int32
+        lib.igh_eval_expression.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
         lib.igh_last_error.restype = C.c_char_p
         _host = lib
     return _host
@@ -143,6 +146,35 @@ def save_exr(path, rgb, scale=1.0, meta=None):
     rc = host_lib().igh_save_exr(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0], float(scale), arr)
     if rc != 0:
         raise RuntimeError(host_lib().igh_last_error().decode())
+
+
+EXPR_VARS = ("uvw", "P", "V", "N", "Ng", "Nx", "Ny", "frontside")  # enum ige_var (include/ig_expr.h)
+EXPR_TYPES = ("bool", "int", "num", "vec2", "vec3", "vec4", "str")
+
+
+def eval_expression(source, **variables):
+    """igh_eval_expression: compile a PExpr string as the loader does and run it once; returns (type name, value) with the value
+    a bool / int / float or a tuple of the vector's components. Variables (uvw, P, V, N, Ng, Nx, Ny, frontside) default to zero."""
+    import numpy as np
+    vals = np.zeros((len(EXPR_VARS), 4), np.float32)
+    for k, v in variables.items():
+        row = EXPR_VARS.index(k)
+        a = np.atleast_1d(np.asarray(v, np.float32))
+        vals[row, :] = a[0] if a.size == 1 else 0
+        if a.size > 1:
+            vals[row, :a.size] = a
+    out = (C.c_float * 4)()
+    ty, words = C.c_int32(), C.c_uint32()
+    if host_lib().igh_eval_expression(source.encode(), vals.ctypes.data_as(C.POINTER(C.c_float)), out, ty, words) != 0:
+        raise RuntimeError(host_lib().igh_last_error().decode())
+    name = EXPR_TYPES[ty.value]
+    if name == "bool":
+        return name, out[0] != 0
+    if name == "int":
+        return name, int(out[0])
+    if name == "num":
+        return name, float(out[0])
+    return name, tuple(float(out[i]) for i in range(int(name[-1])))
 
 
 def read_image8(path):

@@ -1,0 +1,442 @@
+/* ig_expr.h — register bytecode for the shading expressions of a scene (PExpr strings) and its interpreter.
+ *
+ * The reference transpiles every PExpr string of a scene ("reflectance": "mix(tex(uv), color(1,0,0), 0.5)") into Artic
+ * source and JIT-compiles it into the shading kernel (src/runtime/loader/Transpiler.cpp:960-1230,
+ * src/runtime/loader/ShadingTree.cpp). This backend has no run-time compiler: the host loader compiles the same strings
+ * (ignis_amd/csrc/host/pexpr.h) into the bytecode below, the table travels as igd_scene.expr_code, and the shading kernel
+ * interprets it where a material names a program (IG_MAT_EXPR_COLOR / IG_MAT_EXPR_NORMAL).
+ *
+ * Like ig_detmath.h this header is arithmetic shared by the product (HIP kernels, host constant folding) and the test
+ * oracle; the functions are the ones Transpiler.cpp:602-922 maps the PExpr names to, cited per opcode.
+ *
+ * Value model: every value is four floats. bool / int / num live splatted in all four lanes (bool as 0 / 1, int as the
+ * float of its value: exact to 2^24), vec2 / vec3 in the leading lanes. A scalar * vector product is therefore the plain
+ * lane-wise product (vec3_mulf = vec3_mul with the expanded scalar, core/vector.art:84-85).
+ *
+ * Instruction word: op | dst << 8 | a << 12 | b << 16 | c << 20 | imm << 24; IGE_CONST is followed by four float words,
+ * IGE_TEX by the texture index, IGE_BUMP by a word holding three more registers (d | e << 4 | f << 8).
+ */
+#ifndef IG_EXPR_H
+#define IG_EXPR_H
+
+#include "ig_detmath.h"
+
+#define IGE_REGS 12
+
+enum ige_op {
+    IGE_END = 0,  /* result = r[a] */
+    IGE_CONST,    /* r[dst] = the next four words */
+    IGE_VAR,      /* r[dst] = variable imm (enum ige_var) */
+    IGE_ADD,      /* vecN_add; onAddSub / onMulDiv / onScale: lane-wise (Transpiler.cpp:1027-1070) */
+    IGE_SUB,
+    IGE_MUL,
+    IGE_DIV,
+    IGE_NEG,
+    IGE_SWZ,      /* r[dst].i = r[a].(imm >> 2 i & 3) (onAccess, Transpiler.cpp:1152-1196) */
+    IGE_LT,       /* onRelOp: scalars */
+    IGE_GT,
+    IGE_LE,
+    IGE_GE,
+    IGE_EQ,       /* onEqual: all of the leading imm lanes equal */
+    IGE_NOT,
+    IGE_AND,
+    IGE_OR,
+    IGE_SELECT,   /* r[a] ? r[b] : r[c] */
+    IGE_MIX,      /* lerp / vecN_lerp (core/common.art:237, core/vector.art:145-146): (1 - k) a + k b, k = r[c] */
+    IGE_MIN,      /* math_builtins::fmin / fmax lane-wise */
+    IGE_MAX,
+    IGE_CLAMP,    /* clampf(v, l, u) = fmin(u, fmax(l, v)) (core/common.art:285) */
+    IGE_F1,       /* lane-wise function imm (enum ige_f1) */
+    IGE_POW,      /* math_builtins::pow lane-wise (a ^ f and pow(a, b)) */
+    IGE_DOT,      /* over the leading imm lanes */
+    IGE_LENGTH,
+    IGE_NORM,     /* vecN_normalize = v * (1 / len) (core/vector.art:137-139) */
+    IGE_CROSS,    /* core/vector.art:104-107 */
+    IGE_SUM,
+    IGE_AVG,
+    IGE_LUMINANCE, /* color_luminance (core/color.art:29,81-83) */
+    IGE_REFLECT,  /* vec3_reflect(v, n) = n * (2 n.v) - v (core/vector.art:124) */
+    IGE_TEX,      /* bitmap texture (next word) looked up at r[a].xy */
+    IGE_CHECKER,  /* node_checkerboard2 / 3 (texture/checkerboard.art:1-2), imm = 2 / 3 */
+    IGE_BUMP,     /* node_bump(r[a], r[b], r[c], r[d].x, r[e].x, r[f].x) (texture/bump.art:3-11) */
+    IGE_EVR,      /* ensure_valid_reflection(r[a], r[b], r[c]) (core/sampling.art:118-166) */
+    IGE_IMOD,     /* int % int */
+    IGE_IDIV,     /* int / int */
+    IGE_ATAN2,
+    IGE_FMOD,     /* math::fmod (core/math.art:79) */
+    IGE_WRAP,     /* math::wrap(v, min, max) (core/math.art:88-91) */
+    IGE_DIST,
+    IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
+    IGE_OP_COUNT
+};
+
+enum ige_var {
+    IGE_VAR_UVW = 0, /* ctx.uvw = (tex_coords, 0) (driver/shading_context.art:38); "uv" is its .xy */
+    IGE_VAR_P,       /* ctx.surf.point */
+    IGE_VAR_V,       /* -ctx.ray.dir ("V", "Rd") */
+    IGE_VAR_N,       /* ctx.surf.local.col(2) */
+    IGE_VAR_NG,      /* ctx.surf.face_normal */
+    IGE_VAR_NX,      /* ctx.surf.local.col(0) */
+    IGE_VAR_NY,      /* ctx.surf.local.col(1) */
+    IGE_VAR_FRONT,   /* ctx.surf.is_entering */
+    IGE_VAR_COUNT
+};
+
+enum ige_f1 {
+    IGE_F_SIN = 0, IGE_F_COS, IGE_F_TAN, IGE_F_ASIN, IGE_F_ACOS, IGE_F_ATAN, IGE_F_EXP, IGE_F_EXP2, IGE_F_LOG, IGE_F_LOG2, IGE_F_LOG10,
+    IGE_F_FLOOR, IGE_F_CEIL, IGE_F_ROUND, IGE_F_FRACT, IGE_F_TRUNC, IGE_F_SQRT, IGE_F_ABS, IGE_F_SIGN, IGE_F_RAD, IGE_F_DEG,
+    IGE_F_SMOOTHSTEP, IGE_F_SMOOTHERSTEP, IGE_F_COUNT
+};
+
+#define IGE_INS(op, dst, a, b, c, imm) ((uint32_t)(op) | (uint32_t)(dst) << 8 | (uint32_t)(a) << 12 | (uint32_t)(b) << 16 | (uint32_t)(c) << 20 | (uint32_t)(imm) << 24)
+
+#ifdef __cplusplus
+
+struct ige_v4 {
+    float v[4];
+};
+
+IGM_FN float ige_f1_apply(int f, float x)
+{
+    switch (f) {
+    case IGE_F_SIN: return igm_sin(x);
+    case IGE_F_COS: return igm_cos(x);
+    case IGE_F_TAN: return igm_sin(x) / igm_cos(x);
+    case IGE_F_ASIN: return igm_asin(x);
+    case IGE_F_ACOS: return igm_acos(x);
+    case IGE_F_ATAN: return igm_atan2(x, 1.0f);
+    case IGE_F_EXP: return igm_exp(x);
+    case IGE_F_EXP2: return igm_exp(x * 0.6931471805599453f);
+    case IGE_F_LOG: return igm_log(x);
+    case IGE_F_LOG2: return igm_log(x) * 1.4426950408889634f;
+    case IGE_F_LOG10: return igm_log(x) * 0.4342944819032518f;
+    case IGE_F_FLOOR: return igm_floor(x);
+    case IGE_F_CEIL: return -igm_floor(-x);
+    case IGE_F_ROUND: return igm_copysign(igm_floor(igm_abs(x) + 0.5f), x); /* roundf: halfway cases away from zero */
+    case IGE_F_FRACT: return x - igm_floor(x);                               /* math::fract (core/math.art:74) */
+    case IGE_F_TRUNC: return (float)(int)x;                                  /* math::trunc (core/math.art:73) */
+    case IGE_F_SQRT: return igm_sqrt(x);
+    case IGE_F_ABS: return igm_abs(x);
+    case IGE_F_SIGN: return x == 0 ? 0.0f : (igm_signbit(x) ? -1.0f : 1.0f); /* math::signf (core/math.art:76) */
+    case IGE_F_RAD: return x * (IGM_PI / 180.0f);                             /* core/common.art rad / deg */
+    case IGE_F_DEG: return x * (180.0f / IGM_PI);
+    case IGE_F_SMOOTHSTEP: return x * x * (3 - 2 * x);                        /* core/common.art:241-242 */
+    case IGE_F_SMOOTHERSTEP: return x * x * x * (x * (x * 6 - 15) + 10);
+    default: return 0.0f;
+    }
+}
+
+/* powf for the cases a shading expression meets: negative bases only with integral exponents */
+IGM_FN float ige_pow(float x, float p)
+{
+    if (p == 0.0f)
+        return 1.0f;
+    if (x > 0.0f)
+        return igm_pow(x, p);
+    if (x == 0.0f)
+        return p > 0.0f ? 0.0f : __builtin_inff();
+    const float ip = igm_floor(p);
+    if (ip != p)
+        return __builtin_nanf("");
+    const float m   = igm_pow(-x, p);
+    const bool  odd = (ip - 2 * igm_floor(ip * 0.5f)) != 0.0f;
+    return odd ? -m : m;
+}
+
+IGM_FN float ige_wrap(float v, float lo, float hi) /* math::wrap (core/math.art:88-91) */
+{
+    const float range = hi - lo;
+    return range <= IGM_FLT_EPS ? lo : v - (range * igm_floor((v - lo) / range));
+}
+
+IGM_FN int ige_parity(float v) { return (int)ige_wrap(v, 0.0f, 2.0f) % 2; }
+
+/* Ctx supplies: ige_v4 var(int id), ige_v4 tex(uint32_t id, float u, float v), ige_v4 evr(ige_v4 ng, ige_v4 v, ige_v4 n) */
+template <class Ctx>
+IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
+{
+    ige_v4 r[IGE_REGS] = {};
+    for (;;) {
+        const uint32_t w   = *code++;
+        const uint32_t op  = w & 0xFFu;
+        const uint32_t dst = (w >> 8) & 0xFu;
+        const uint32_t ia = (w >> 12) & 0xFu, ib = (w >> 16) & 0xFu, ic = (w >> 20) & 0xFu;
+        const uint32_t imm = w >> 24;
+        const ige_v4 a = r[ia], b = r[ib], c = r[ic];
+        ige_v4 o = a;
+        switch (op) {
+        case IGE_END:
+            return a;
+        case IGE_CONST:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = igm_float(*code++);
+            break;
+        case IGE_VAR:
+            o = ctx.var((int)imm);
+            break;
+        case IGE_ADD:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[i] + b.v[i];
+            break;
+        case IGE_SUB:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[i] - b.v[i];
+            break;
+        case IGE_MUL:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[i] * b.v[i];
+            break;
+        case IGE_DIV:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[i] / b.v[i];
+            break;
+        case IGE_NEG:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = -a.v[i];
+            break;
+        case IGE_SWZ:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[(imm >> (2 * i)) & 3u];
+            break;
+        case IGE_LT:
+        case IGE_GT:
+        case IGE_LE:
+        case IGE_GE: {
+            const bool t = op == IGE_LT ? a.v[0] < b.v[0] : (op == IGE_GT ? a.v[0] > b.v[0] : (op == IGE_LE ? a.v[0] <= b.v[0] : a.v[0] >= b.v[0]));
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = t ? 1.0f : 0.0f;
+            break;
+        }
+        case IGE_EQ: {
+            bool t = true;
+            for (uint32_t i = 0; i < imm; ++i)
+                t = t && a.v[i] == b.v[i];
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = t ? 1.0f : 0.0f;
+            break;
+        }
+        case IGE_NOT:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[0] != 0 ? 0.0f : 1.0f;
+            break;
+        case IGE_AND:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = (a.v[0] != 0 && b.v[0] != 0) ? 1.0f : 0.0f;
+            break;
+        case IGE_OR:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = (a.v[0] != 0 || b.v[0] != 0) ? 1.0f : 0.0f;
+            break;
+        case IGE_SELECT:
+            o = a.v[0] != 0 ? b : c;
+            break;
+        case IGE_MIX:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = (1 - c.v[0]) * a.v[i] + c.v[0] * b.v[i];
+            break;
+        case IGE_MIN:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = igm_min(a.v[i], b.v[i]);
+            break;
+        case IGE_MAX:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = igm_max(a.v[i], b.v[i]);
+            break;
+        case IGE_CLAMP:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = igm_clamp(a.v[i], b.v[i], c.v[i]);
+            break;
+        case IGE_F1:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = ige_f1_apply((int)imm, a.v[i]);
+            break;
+        case IGE_POW:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = ige_pow(a.v[i], b.v[i]);
+            break;
+        case IGE_ATAN2:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = igm_atan2(a.v[i], b.v[i]);
+            break;
+        case IGE_FMOD: /* x - trunc(x / n) * n */
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = a.v[i] - (float)(int)(a.v[i] / b.v[i]) * b.v[i];
+            break;
+        case IGE_WRAP:
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = ige_wrap(a.v[i], b.v[i], c.v[i]);
+            break;
+        case IGE_IMOD: {
+            const int d = (int)b.v[0];
+            const float m = d == 0 ? 0.0f : (float)((int)a.v[0] % d);
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = m;
+            break;
+        }
+        case IGE_IDIV: {
+            const int d = (int)b.v[0];
+            const float m = d == 0 ? 0.0f : (float)((int)a.v[0] / d);
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = m;
+            break;
+        }
+        case IGE_DOT:
+        case IGE_LENGTH:
+        case IGE_NORM:
+        case IGE_DIST:
+        case IGE_SUM:
+        case IGE_AVG: {
+            /* vecN_dot = fmaf(x, x', fmaf(y, y', z z')) and vecN_reduce = f(x, f(y, z)): both fold from the last lane
+             * (core/vector.art:37-39,95-97) */
+            ige_v4 p = a, q = b;
+            if (op == IGE_LENGTH || op == IGE_NORM)
+                q = a;
+            if (op == IGE_DIST) {
+                for (int i = 0; i < 4; ++i)
+                    p.v[i] = b.v[i] - a.v[i];
+                q = p;
+            }
+            float s = 0;
+            for (int i = (int)imm - 1; i >= 0; --i) {
+                if (op == IGE_SUM || op == IGE_AVG)
+                    s = i == (int)imm - 1 ? p.v[i] : p.v[i] + s;
+                else
+                    s = i == (int)imm - 1 ? p.v[i] * q.v[i] : igm_fma(p.v[i], q.v[i], s);
+            }
+            if (op == IGE_LENGTH || op == IGE_NORM || op == IGE_DIST)
+                s = igm_sqrt(s);
+            if (op == IGE_AVG)
+                s = s / (float)imm;
+            if (op == IGE_NORM) {
+                const float inv = 1 / s;
+                for (int i = 0; i < 4; ++i)
+                    o.v[i] = a.v[i] * inv;
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    o.v[i] = s;
+            }
+            break;
+        }
+        case IGE_CROSS:
+            o.v[0] = a.v[1] * b.v[2] - a.v[2] * b.v[1];
+            o.v[1] = a.v[2] * b.v[0] - a.v[0] * b.v[2];
+            o.v[2] = a.v[0] * b.v[1] - a.v[1] * b.v[0];
+            o.v[3] = 0;
+            break;
+        case IGE_LUMINANCE: {
+            const float l = a.v[0] * 0.2126f + a.v[1] * 0.7152f + a.v[2] * 0.0722f;
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = l;
+            break;
+        }
+        case IGE_REFLECT: { /* a = v, b = n */
+            const float d = 2 * igm_fma(b.v[0], a.v[0], igm_fma(b.v[1], a.v[1], b.v[2] * a.v[2]));
+            for (int i = 0; i < 3; ++i)
+                o.v[i] = b.v[i] * d - a.v[i];
+            o.v[3] = 0;
+            break;
+        }
+        case IGE_TEX:
+            o = ctx.tex(*code++, a.v[0], a.v[1]);
+            break;
+        case IGE_CHECKER: {
+            const bool xy = ige_parity(a.v[0]) == ige_parity(a.v[1]);
+            const bool t  = imm == 2 ? xy : (xy == (ige_parity(a.v[2]) == 1));
+            for (int i = 0; i < 4; ++i)
+                o.v[i] = t ? 1.0f : 0.0f;
+            break;
+        }
+        case IGE_BUMP: {
+            const uint32_t x = *code++;
+            const float dist = r[x & 0xFu].v[0], sdx = r[(x >> 4) & 0xFu].v[0], sdy = r[(x >> 8) & 0xFu].v[0];
+            /* a = input, b = Nx, c = Ny */
+            const float rx[3] = { c.v[1] * a.v[2] - c.v[2] * a.v[1], c.v[2] * a.v[0] - c.v[0] * a.v[2], c.v[0] * a.v[1] - c.v[1] * a.v[0] };
+            const float ry[3] = { a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0] };
+            const float det   = igm_fma(b.v[0], rx[0], igm_fma(b.v[1], rx[1], b.v[2] * rx[2]));
+            const float sg    = (det == 0 ? 0.0f : (igm_signbit(det) ? -1.0f : 1.0f)) * dist;
+            float n[3];
+            for (int i = 0; i < 3; ++i) {
+                const float grad = rx[i] * sdx + ry[i] * sdy;
+                n[i]             = a.v[i] * igm_abs(det) - grad * sg;
+            }
+            const float inv = 1 / igm_sqrt(igm_fma(n[0], n[0], igm_fma(n[1], n[1], n[2] * n[2])));
+            for (int i = 0; i < 3; ++i)
+                o.v[i] = n[i] * inv;
+            o.v[3] = 0;
+            break;
+        }
+        case IGE_EVR:
+            o = ctx.evr(a, b, c);
+            break;
+        case IGE_PACK:
+            o.v[0] = a.v[0], o.v[1] = b.v[0], o.v[2] = c.v[0], o.v[3] = r[imm & 0xFu].v[0];
+            break;
+        default:
+            break;
+        }
+        r[dst] = o;
+    }
+}
+
+/* Walks the program that starts at word `start`: every opcode known, every register below IGE_REGS, every texture
+ * below texture_count, and an IGE_END before the table ends. The device checks each program a material names. */
+IGM_FN bool ige_validate(const uint32_t* code, uint32_t count, uint32_t start, uint32_t texture_count)
+{
+    uint32_t pc = start;
+    while (pc < count) {
+        const uint32_t w  = code[pc++];
+        const uint32_t op = w & 0xFFu;
+        if (op >= IGE_OP_COUNT)
+            return false;
+        if (((w >> 8) & 0xFu) >= IGE_REGS || ((w >> 12) & 0xFu) >= IGE_REGS || ((w >> 16) & 0xFu) >= IGE_REGS || ((w >> 20) & 0xFu) >= IGE_REGS)
+            return false;
+        const uint32_t imm = w >> 24;
+        switch (op) {
+        case IGE_END:
+            return true;
+        case IGE_CONST:
+            pc += 4;
+            break;
+        case IGE_VAR:
+            if (imm >= IGE_VAR_COUNT)
+                return false;
+            break;
+        case IGE_F1:
+            if (imm >= IGE_F_COUNT)
+                return false;
+            break;
+        case IGE_EQ:
+        case IGE_DOT:
+        case IGE_LENGTH:
+        case IGE_NORM:
+        case IGE_DIST:
+        case IGE_SUM:
+        case IGE_AVG:
+            if (imm < 1 || imm > 4)
+                return false;
+            break;
+        case IGE_PACK:
+            if ((imm & 0xFu) >= IGE_REGS)
+                return false;
+            break;
+        case IGE_TEX:
+            if (pc >= count || code[pc++] >= texture_count)
+                return false;
+            break;
+        case IGE_BUMP: {
+            if (pc >= count)
+                return false;
+            const uint32_t x = code[pc++];
+            if ((x & 0xFu) >= IGE_REGS || ((x >> 4) & 0xFu) >= IGE_REGS || ((x >> 8) & 0xFu) >= IGE_REGS)
+                return false;
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    return false;
+}
+
+#endif /* __cplusplus */
+#endif /* IG_EXPR_H */

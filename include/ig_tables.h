@@ -112,6 +112,11 @@ enum ig_material_flags {
     IG_MAT_CLEARCOAT_ALL = 1u << 6, /* principled: clearcoat_top_only = false (PrincipledBSDF.cpp:56) */
     IG_MAT_DOUBLESIDED = 1u << 7, /* wrapped in make_doublesided_bsdf (src/artic/bsdf/common.art:28-46; DoubleSidedBSDF.cpp "twosided" /
                                     * "doublesided"): hit from behind, the BSDF is built as if entered and used with both directions negated */
+    IG_MAT_EXPR_COLOR  = 1u << 8, /* the colour material_color resolves (diffuse reflectance, plastic diffuse reflectance, principled base
+                                   * colour) is the shading expression whose program starts at igd_scene.expr_code[tex_refl]
+                                   * (include/ig_expr.h; ShadingTree::addColor with a PExpr string, src/runtime/loader/ShadingTree.cpp) */
+    IG_MAT_EXPR_NORMAL = 1u << 9, /* wrapped in a "transform" BSDF (TransformBSDF.cpp:17-49, make_normal_set src/artic/bsdf/map.art:36-42)
+                                   * whose normal is the program at igd_scene.expr_code[tex_id] */
 };
 
 /* One record per material (= unique bsdf / area-light entity,
@@ -380,6 +385,10 @@ typedef struct igd_scene {
     /* participating media (IG_TECHNIQUE_VOLPATH); ig_material.pad[2] names the two sides of an entity's surface */
     const ig_medium* media;
     uint32_t media_count;
+    /* programs of the scene's shading expressions (include/ig_expr.h), one after the other, each ending in IGE_END;
+     * IG_MAT_EXPR_COLOR / IG_MAT_EXPR_NORMAL materials name the word a program starts at */
+    const uint32_t* expr_code;
+    uint32_t expr_code_count;
 } igd_scene;
 
 #ifdef __cplusplus

@@ -61,6 +61,14 @@ int32_t igh_read_float_image(const char* path, uint32_t* width, uint32_t* height
  * pixels == NULL queries the size. Returns 0 on success. */
 int32_t igh_read_image8(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, uint64_t capacity);
 
+/* Compiles one PExpr string as the loader does for a BSDF property (ignis_amd/csrc/host/pexpr.h; the reference's counterpart is
+ * Transpiler::transpile, src/runtime/loader/Transpiler.cpp:1262-1322) and evaluates it once with the interpreter the shading
+ * kernel uses (include/ig_expr.h). `vars`: IGE_VAR_COUNT rows of four floats in enum ige_var order (uvw, P, V, N, Ng, Nx, Ny,
+ * frontside), NULL = all zero. Without a scene there are no textures: a name that is not a variable is an error. `*type`
+ * receives the expression's type (0 bool, 1 int, 2 num, 3 vec2, 4 vec3, 5 vec4), `*words` the length of its program. Returns 0
+ * on success; compile errors are reported through igh_last_error. */
+int32_t igh_eval_expression(const char* source, const float* vars, float result[4], int32_t* type, uint32_t* words);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

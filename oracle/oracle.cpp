@@ -351,12 +351,12 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     PTRayPayload payload      = read_payload(primary, i);
                     const SurfaceElement surf = surface_element(sc, entity, ray, hit);
                     // a bump-mapped material hands its inner BSDF a re-oriented surface (bsdf/map.art:64-67)
-                    const SurfaceElement bsurf = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) ? bumped_surface(sc, mat, surf, ray) : surf;
+                    const SurfaceElement bsurf = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)) ? bumped_surface(sc, mat, surf, ray) : surf;
                     // make_doublesided_bsdf (bsdf/common.art:28-46): from behind, the BSDF is built on the surface "as entered"
                     const bool ds_flip = (mat.flags & IG_MAT_DOUBLESIDED) && !surf.is_entering;
                     SurfaceElement dsurf = bsurf;
                     dsurf.is_entering    = true;
-                    const Bsdf bsdf{ &mat, ds_flip ? &dsurf : &bsurf, &sc, ds_flip };
+                    const Bsdf bsdf{ &mat, ds_flip ? &dsurf : &bsurf, &sc, ds_flip, vec3_neg(ray.dir) };
 
                     // wrap_infobuffer_renderer.on_hit (technique/internal/infobuffer.art:9-25)
                     if (aov_normals && cfg.iteration == 0 && (ray.flags & IG_RAY_FLAG_CAMERA)) {

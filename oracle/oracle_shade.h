@@ -6,6 +6,7 @@
 #pragma once
 
 #include "oracle_core.h"
+#include "ig_expr.h"
 
 #include <algorithm>
 #include <functional>
@@ -735,13 +736,56 @@ static inline Mat3x3 mat3x3_align_vectors(Vec3 a, Vec3 b)
     m.col[2] = Vec3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
     return m;
 }
+// ---- shading expressions: the scene's PExpr strings, compiled by the loader into the bytecode of include/ig_expr.h
+// (the reference transpiles them into the shader instead, src/runtime/loader/Transpiler.cpp:960-1230). The variables
+// are those of sInternalVariables (Transpiler.cpp:338-363) the table format carries; texture alpha reads as 1.
+struct ExprContext {
+    const igd_scene* scene;
+    const SurfaceElement* surf;
+    Vec3 view; // "V" / "Rd" = vec3_neg(ctx.ray.dir)
+    static ige_v4 pack(Vec3 a) { return ige_v4{ { a.x, a.y, a.z, 0.0f } }; }
+    ige_v4 var(int id) const
+    {
+        switch (id) {
+        case IGE_VAR_UVW: return ige_v4{ { surf->tex_coords.x, surf->tex_coords.y, 0.0f, 0.0f } }; // vec2_to_3(surf.tex_coords, 0), shading_context.art:38
+        case IGE_VAR_P: return pack(surf->point);
+        case IGE_VAR_V: return pack(view);
+        case IGE_VAR_N: return pack(surf->local.col[2]);
+        case IGE_VAR_NG: return pack(surf->face_normal);
+        case IGE_VAR_NX: return pack(surf->local.col[0]);
+        case IGE_VAR_NY: return pack(surf->local.col[1]);
+        default: {
+            const float f = surf->is_entering ? 1.0f : 0.0f;
+            return ige_v4{ { f, f, f, f } };
+        }
+        }
+    }
+    ige_v4 tex(uint32_t id, float u, float v) const
+    {
+        const Color c = image_lookup(*scene, scene->textures[id], Vec2{ u, v });
+        return ige_v4{ { c.r, c.g, c.b, 1.0f } };
+    }
+    ige_v4 evr(ige_v4 ng, ige_v4 v, ige_v4 n) const
+    {
+        return pack(ensure_valid_reflection(make_vec3(ng.v[0], ng.v[1], ng.v[2]), make_vec3(v.v[0], v.v[1], v.v[2]), make_vec3(n.v[0], n.v[1], n.v[2])));
+    }
+};
+static inline Vec3 eval_expression(const igd_scene& sc, int32_t start, const SurfaceElement& surf, Vec3 view)
+{
+    const ige_v4 r = ige_run(sc.expr_code + start, ExprContext{ &sc, &surf, view });
+    return make_vec3(r.v[0], r.v[1], r.v[2]);
+}
+
 // The surface the inner BSDF of a bump-mapped material sees: make_bumpmap -> make_normal_set (adjoint == false
 // on camera paths, so transform_surf_bsdf changes nothing else).
 static inline SurfaceElement bumped_surface(const igd_scene& sc, const ig_material& mat, const SurfaceElement& surf, const Ray& ray)
 {
-    const ig_texture& t = sc.textures[mat.tex_id];
     Vec3 N;
-    if (mat.flags & IG_MAT_NORMALMAP) {
+    if (mat.flags & IG_MAT_EXPR_NORMAL) {
+        // "transform" BSDF (TransformBSDF.cpp:43-46): make_normal_set with the normal expression
+        N = eval_expression(sc, mat.tex_id, surf, vec3_neg(ray.dir));
+    } else if (mat.flags & IG_MAT_NORMALMAP) {
+        const ig_texture& t = sc.textures[mat.tex_id];
         // make_normalmap (bsdf/map.art:55-61): normal given as [0, 1] RGB; mat3x3_left_mul = (col_i . v)
         const Color c  = image_lookup(sc, t, surf.tex_coords);
         const Vec3 nt  = vec3_normalize(make_vec3(2 * c.r - 1, 2 * c.g - 1, 2 * c.b - 1));
@@ -749,6 +793,7 @@ static inline SurfaceElement bumped_surface(const igd_scene& sc, const ig_materi
         const float st = mat.p[11];
         N = st != 1 ? vec3_normalize(vec3_add(surf.local.col[2], vec3_mulf(vec3_sub(oN, surf.local.col[2]), st))) : oN;
     } else {
+        const ig_texture& t = sc.textures[mat.tex_id];
         const float delta = 0.001f; // texture_dx / texture_dy (texture/common.art:33-43)
         const Color c0    = image_lookup(sc, t, surf.tex_coords);
         const Color cx    = image_lookup(sc, t, Vec2{ surf.tex_coords.x + delta, surf.tex_coords.y });
@@ -1403,6 +1448,7 @@ struct Bsdf {
     // make_doublesided_bsdf (bsdf/common.art:28-46) on a surface hit from behind: `surf` already has is_entering = true (the
     // caller's copy), every direction is negated on the way in and the sampled one on the way out
     bool flip = false;
+    Vec3 view{ 0, 0, 0 }; // -ray.dir for the "V" of a colour expression (zero inside a blend: the loader keeps V out of those)
     Bsdf unflipped() const
     {
         Bsdf b = *this;
@@ -1422,6 +1468,10 @@ struct Bsdf {
 
     Color kd() const
     {
+        if (mat->flags & IG_MAT_EXPR_COLOR) { // vec4_to_color / vec3_to_color of the expression, a number as grey (Transpiler.cpp:1290-1302)
+            const Vec3 c = eval_expression(*scene, mat->tex_refl, *surf, view);
+            return Color{ c.x, c.y, c.z };
+        }
         if (mat->flags & IG_MAT_IMAGE)
             return image_lookup(*scene, scene->textures[mat->tex_refl], surf->tex_coords);
         if (mat->flags & IG_MAT_CHECKER)

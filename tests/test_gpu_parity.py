@@ -1386,3 +1386,34 @@ def test_twosided_bsdf_vs_oracle(gpu_device):
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 7)) >= 3
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=37, iters=2)
+
+
+@pytest.mark.parametrize("stem", ["cycles-roughness-rxry", "cycles-normalmap", "cycles-bumpmap"])
+def test_shading_expressions_of_the_cycles_scenes_vs_oracle(gpu_device, stem):
+    """PExpr colours and "transform" normals (textures at shifted coordinates, bump(), ensure_valid_reflection()) through the
+    kernel instantiation with the interpreter (k_shade<true, false, true>) against the oracle's interpreter."""
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", stem + ".json"), 96, 96)
+    flags = [sc.scene.materials[i].flags for i in range(sc.scene.material_count)]
+    assert any(f & (1 << 8) for f in flags) and (stem == "cycles-roughness-rxry" or any(f & (1 << 9) for f in flags))
+    _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=41, iters=2)
+
+
+def test_shading_expressions_with_every_variable_vs_oracle(gpu_device):
+    """Expressions over uv, P, V, N, Ng, Nx, Ny and frontside with transcendental functions on the walls and a transform BSDF on
+    the diamonds of diamond_scene."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-GrayWall":
+            b["reflectance"] = "clamp(color(0.5 + 0.4 * sin(P.x * 7), fract(uv.y * 3), abs(dot(N, V)) ^ 2, 1) * select(frontside, 1.0, 0.5), color(0.05), color(0.95))"
+        if b["name"] == "mat-ColoredWall":
+            b["reflectance"] = "mix(vec3(0.8, 0.2, 0.1), abs(Ng) * 0.9, smoothstep(fract(length(P.xy) * 2))) * (0.6 + 0.4 * cos(atan2(Nx.x, Ny.y + 1.5)))"
+    s["bsdfs"] += [{"type": "principled", "name": "shiny", "base_color": "color(0.9, 0.6, 0.2) * (0.5 + 0.5 * checkerboard(P * 3))", "metallic": 0.8, "roughness": 0.3},
+                   {"type": "transform", "name": "wobbly", "bsdf": "shiny", "normal": "norm(N + 0.3 * Nx * sin(P.y * 20) + 0.3 * Ny * cos(P.x * 20))"}]
+    for e in s["entities"]:
+        if e["bsdf"] == "mat-Diamond":
+            e["bsdf"] = "wobbly"
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sc.scene.expr_code_count > 50
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=43, iters=2)

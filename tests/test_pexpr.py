@@ -1,0 +1,192 @@
+"""Shading expressions: the PExpr compiler of the loader (ignis_amd/csrc/host/pexpr.h) and the interpreter shared by the shading
+kernel and the oracle (include/ig_expr.h), through the C ABI (igh_eval_expression) against numpy float32 restatements of the
+functions the reference's transpiler maps the names to (src/runtime/loader/Transpiler.cpp:602-922), and through the loader.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+from ignis_amd.tables import LoadedScene, eval_expression as ev
+
+F = np.float32
+
+
+def near(a, b, tol=2e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1, np.abs(b)))
+
+
+@pytest.mark.parametrize("src,ty,val", [
+    ("1+2*3", "int", 7), ("(1+2)*3", "int", 9), ("7 % 3 + 7/2", "int", 4), ("7/2.0", "num", 3.5), ("-2^2", "int", -4), ("2^3^2", "int", 512),
+    ("(0.175)^2", "num", float(F(0.175) * F(0.175))), ("1 + 2.5", "num", 3.5), ("1e2 + .5", "num", 100.5), ("--3", "int", 3), ("+3", "int", 3),
+    ("1 < 2", "bool", True), ("2 <= 1", "bool", False), ("1 == 1.0", "bool", True), ("1 != 2", "bool", True), ("!(1 > 2) && true || false", "bool", True),
+    ("vec3(1,2,3) == vec3(1,2,3)", "bool", True), ("vec3(1,2,3) != vec3(1,2,4)", "bool", True),
+    ("Pi", "num", float(F(3.14159265359))), ("Eps", "num", float(np.finfo(F).eps)),
+])
+def test_scalars_and_operators(src, ty, val):
+    t, v = ev(src)
+    assert t == ty
+    assert near(v, val) if ty != "bool" else v == val
+
+
+def test_vectors_swizzles_and_constructors():
+    assert ev("vec3(1,2,3).zyxx") == ("vec4", (3, 2, 1, 1))
+    assert ev("vec2(4).yx") == ("vec2", (4, 4))
+    assert ev("color(0.1, 0.2, 0.3)") == ("vec4", tuple(float(F(x)) for x in (0.1, 0.2, 0.3, 1)))  # make_vec4(r, g, b, 1)
+    assert ev("color(0.5).a") == ("num", 0.5)
+    assert ev("vec4(1,2,3,4).rgb + vec3(1)") == ("vec3", (2, 3, 4))
+    assert ev("2 * vec3(1,2,3) / 4") == ("vec3", (0.5, 1, 1.5))           # onScale both ways, int -> num
+    assert ev("vec3(1,2,3) * vec3(2)") == ("vec3", (2, 4, 6))
+    assert ev("-vec2(1,-2)") == ("vec2", (-1, 2))
+    assert ev("uv", uvw=(0.25, 0.75, 0)) == ("vec2", (0.25, 0.75))
+    assert ev("uvw.zy", uvw=(0.25, 0.75, 0)) == ("vec2", (0, 0.75))
+    assert ev("(N + Nx * 2 - Ny).xzy", N=(0, 0, 1), Nx=(1, 0, 0), Ny=(0, 1, 0)) == ("vec3", (2, 1, -1))
+    assert ev("select(frontside, 1, 2.5)", frontside=1) == ("num", 1.0)
+    assert ev("select(frontside, vec2(1), vec2(2))", frontside=0) == ("vec2", (2, 2))
+
+
+@pytest.mark.parametrize("name,fn", [
+    ("sin", np.sin), ("cos", np.cos), ("tan", np.tan), ("asin", np.arcsin), ("acos", np.arccos), ("atan", np.arctan), ("exp", np.exp),
+    ("exp2", np.exp2), ("log", np.log), ("log2", np.log2), ("log10", np.log10), ("sqrt", np.sqrt), ("floor", np.floor), ("ceil", np.ceil),
+    ("abs", np.abs), ("fract", lambda x: x - np.floor(x)), ("trunc", np.trunc), ("sign", np.sign), ("rad", np.radians), ("deg", np.degrees),
+    ("smoothstep", lambda x: x * x * (3 - 2 * x)), ("smootherstep", lambda x: x * x * x * (x * (x * 6 - 15) + 10)),
+])
+def test_lanewise_functions(name, fn):
+    for x in (0.1, 0.37, 0.5, 0.93):
+        t, v = ev(f"{name}(P.x)", P=(x, 0, 0))
+        assert t == "num" and near(v, fn(np.float64(F(x))), 3e-6), (name, x, v)
+    if name not in ("smoothstep", "smootherstep"):
+        t, v = ev(f"{name}(P)", P=(0.2, 0.4, 0.8))
+        assert t == "vec3" and near(v, fn(np.array([0.2, 0.4, 0.8], F).astype(np.float64)), 3e-6)
+
+
+def test_round_negative_floor_and_int_functions():
+    assert ev("round(P.x)", P=(2.5, 0, 0))[1] == 3 and ev("round(P.x)", P=(-2.5, 0, 0))[1] == -3
+    assert ev("floor(P.x)", P=(-0.5, 0, 0))[1] == -1 and ev("ceil(P.x)", P=(-0.5, 0, 0))[1] == 0
+    assert ev("abs(-3)") == ("int", 3) and ev("sign(-3)") == ("int", -1) and ev("int(3.9)") == ("int", 3) and ev("num(3) / 2") == ("num", 1.5)
+    assert ev("min(3, 5)") == ("int", 3) and ev("max(3, 5.5)") == ("num", 5.5) and ev("clamp(7, 0, 5)") == ("int", 5)
+
+
+def test_binary_and_ternary_functions():
+    p, q = np.array([0.3, -1.2, 2.0], F), np.array([1.5, 0.4, -0.7], F)
+    kw = dict(P=p, V=q)
+    assert near(ev("min(P, V)", **kw)[1], np.minimum(p, q)) and near(ev("max(P, V)", **kw)[1], np.maximum(p, q))
+    assert near(ev("dot(P, V)", **kw)[1], np.dot(p.astype(np.float64), q)) and near(ev("cross(P, V)", **kw)[1], np.cross(p, q))
+    assert near(ev("length(P)", **kw)[1], np.linalg.norm(p)) and near(ev("norm(P)", **kw)[1], p / np.linalg.norm(p))
+    assert near(ev("dist(P, V)", **kw)[1], np.linalg.norm(p - q)) and near(ev("sum(P)", **kw)[1], p.sum()) and near(ev("avg(P)", **kw)[1], p.mean())
+    n = q / np.linalg.norm(q)
+    assert near(ev("reflect(P, norm(V))", **kw)[1], n * 2 * np.dot(n, p) - p, 1e-5)  # vec3_reflect(v, n) (core/vector.art:124)
+    assert near(ev("mix(P, V, 0.25)", **kw)[1], 0.75 * p + 0.25 * q) and near(ev("mix(1, 3, 0.5)")[1], 2.0)
+    assert near(ev("clamp(P, vec3(0), vec3(1))", **kw)[1], np.clip(p, 0, 1))
+    assert near(ev("pow(abs(P), vec3(2.5))", **kw)[1], np.abs(p).astype(np.float64) ** 2.5, 5e-6) and near(ev("P.x ^ 3", **kw)[1], float(p[0]) ** 3, 5e-6)
+    assert near(ev("P.y ^ 3", **kw)[1], float(p[1]) ** 3, 5e-6) and near(ev("P.y ^ 2", **kw)[1], float(p[1]) ** 2, 5e-6)  # negative base, integral exponent
+    assert near(ev("atan2(P.x, V.x)", **kw)[1], math.atan2(p[0], q[0]), 5e-6)
+    assert near(ev("fmod(P.z, 0.75)", **kw)[1], math.fmod(2.0, 0.75)) and near(ev("wrap(P.y, 0, 1)", **kw)[1], float(p[1]) - math.floor(p[1]))
+    assert near(ev("luminance(color(0.2, 0.5, 0.9))")[1], 0.2 * 0.2126 + 0.5 * 0.7152 + 0.9 * 0.0722)  # color_luminance (core/color.art:29)
+
+
+def _parity(v):
+    rng = 2.0
+    return int(v - rng * math.floor(v / rng)) % 2
+
+
+def test_checkerboard_matches_the_texture_node():
+    """node_checkerboard2 / 3 (src/artic/texture/checkerboard.art:1-2) over a grid of coordinates, negative ones included."""
+    for x in np.linspace(-2.3, 2.3, 13):
+        for y in np.linspace(-1.7, 2.9, 11):
+            xy = _parity(float(F(x))) == _parity(float(F(y)))
+            assert ev("checkerboard(P.xy)", P=(x, y, 0)) == ("int", int(xy))
+            assert ev("checkerboard(P)", P=(x, y, 1.5)) == ("int", int(xy == (_parity(1.5) == 1)))
+            assert ev("checkerboard(P)", P=(x, y, 0)) == ("int", int(not xy))  # w = 0: 1 where the parities differ
+
+
+def test_bump_node():
+    """node_bump (src/artic/texture/bump.art:3-11) restated in float64."""
+    n, nx, ny = np.array([0, 0, 1.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    for dist, dx, dy in ((1.0, 0.3, -0.2), (0.5, -1.5, 0.7)):
+        rx, ry = np.cross(ny, n), np.cross(n, nx)
+        det = np.dot(nx, rx)
+        grad = rx * dx + ry * dy
+        want = n * abs(det) - grad * np.sign(det) * dist
+        want /= np.linalg.norm(want)
+        got = ev(f"bump(N, Nx, Ny, {dist}, {dx}, {dy})", N=n, Nx=nx, Ny=ny)
+        assert got[0] == "vec3" and near(got[1], want, 1e-6)
+
+
+@pytest.mark.parametrize("src,what", [
+    ("foo", "unknown variable 'foo'"), ("perlin(uv)", "'perlin' is not supported"), ("entity_id", "'entity_id' is not supported"),
+    ("uv.z", "outside of vec2"), ("1 +", "end of expression"), ("vec3(1,2) ", "no function vec3(int, int)"), ("1 && 2", "expects bool"),
+    ("vec3(1) < vec3(2)", "expects int or num"), ("vec2(1) + vec3(1)", "cannot add vec2 and vec3"), ("3 % 2.0", "'%' expects int"),
+    ("2 / vec3(1)", "cannot divide int and vec3"), ("'text'", "string"), ("(1", "expected ')'"), ("1 $ 2", "unexpected character"),
+    ("P.x" + "".join(" * (1 + P.x" for _ in range(14)) + ")" * 14, "too deeply nested"),
+])
+def test_errors_name_the_problem(src, what):
+    with pytest.raises(RuntimeError, match=what.replace("(", r"\(").replace(")", r"\)").replace("$", r"\$").replace("+", r"\+")):
+        ev(src)
+
+
+def _scene(bsdf, extra=None):
+    s = {"technique": {"type": "path", "max_depth": 4}, "camera": {"type": "perspective", "fov": 40, "near_clip": 0.1, "far_clip": 100,
+                                                                    "transform": [{"lookat": {"origin": [0, 0, 3], "target": [0, 0, 0], "up": [0, 1, 0]}}]},
+         "film": {"size": [64, 64]}, "bsdfs": [bsdf], "shapes": [{"type": "rectangle", "name": "quad", "width": 2, "height": 2}],
+         "entities": [{"name": "quad", "shape": "quad", "bsdf": bsdf["name"]}], "lights": [{"type": "env", "name": "sky", "radiance": [1, 1, 1]}]}
+    s.update(extra or {})
+    return s
+
+
+def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
+    sc = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "mix(color(1,0,0), color(0,0,1), 0.25) * k"},
+                                                   {"parameters": [{"name": "k", "type": "number", "value": 0.5}]})), SCENES, 64, 64)
+    m = sc.scene.materials[0]
+    assert m.flags & (1 << 8) == 0 and sc.scene.expr_code_count == 0 and near(list(m.p[0:3]), [0.375, 0, 0.125])
+    sc = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "color(uv.x, uv.y, 0.5) * tint"},
+                                                   {"parameters": [{"name": "tint", "type": "color", "value": [1, 0.5, 0.25]}]})), SCENES, 64, 64)
+    m = sc.scene.materials[0]
+    assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
+    assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
+    for bad, what in (("perlin(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+        with pytest.raises(RuntimeError, match=what):
+            LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
+    with pytest.raises(RuntimeError, match="inside a blend"):
+        s = _scene({"type": "blend", "name": "m", "first": "a", "second": "b", "weight": 0.5})
+        s["bsdfs"] += [{"type": "diffuse", "name": "a", "reflectance": "color(uv.x)"}, {"type": "diffuse", "name": "b"}]
+        LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+
+
+def test_oracle_expression_checkerboard_equals_the_lowered_checkerboard():
+    """The exporters' checkerboard idiom is lowered into the material record; written the other way round it runs through the
+    interpreter. Same pixels."""
+    import oracle
+    a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "select(checkerboard(uvw * 4.0) == 1, color(0.8,0.7,0.1,1), color(0.2,0.2,0.2,1))"})), SCENES, 64, 64)
+    b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "select(1 == checkerboard(uvw * 4.0), color(0.8,0.7,0.1,1), color(0.2,0.2,0.2,1))"})), SCENES, 64, 64)
+    assert a.scene.materials[0].flags & (1 << 2) and b.scene.materials[0].flags & (1 << 8)
+    fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+    fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+    assert np.array_equal(fa, fb) and fa.max() > 0.5
+
+
+def test_oracle_transform_bsdf_with_the_plain_normal_changes_nothing_and_a_tilted_one_does():
+    """make_normal_set (bsdf/map.art:36-42) with normal = N aligns the frame with itself; tilting the normal re-weights the cosine."""
+    import oracle
+    base = {"type": "diffuse", "name": "inner", "reflectance": [0.8, 0.8, 0.8]}
+    light = {"lights": [{"type": "directional", "name": "d", "direction": [0, 0, -1], "irradiance": [3, 3, 3]}]}
+
+    def render(normal):
+        s = _scene({"type": "transform", "name": "m", "bsdf": "inner", "normal": normal}, light)
+        s["bsdfs"].append(base)
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+        assert sc.scene.materials[0].flags & (1 << 9)
+        return oracle.render(sc, 4, 64, 64, iteration=0, seed=5)[0]
+    s0 = _scene(dict(base, name="m"), light)
+    plain = oracle.render(LoadedScene.from_string(json.dumps(s0), SCENES, 64, 64), 4, 64, 64, iteration=0, seed=5)[0]
+    same = render("N")
+    assert np.allclose(same, plain, rtol=1e-5, atol=1e-6)
+    tilted = render("norm(N + Nx)")  # 45 degrees: the directional light's cosine drops to 1 / sqrt(2)
+    c = slice(24, 40)
+    assert abs(tilted[c, c].mean() / plain[c, c].mean() - math.sqrt(0.5)) < 0.01
+    const = render([1, 0, 1])  # a constant world-space vector works as well
+    assert np.allclose(const[c, c].mean(), tilted[c, c].mean(), rtol=1e-3)
