@@ -370,6 +370,28 @@ struct ConstExpr {
     }
 };
 
+// The scene's "parameters" while a scene is being built: an expression over them and constants only ("color_point * scale_point",
+// scenes/parameter_plane.json) is a constant to this backend, which has no run-time parameter registry
+// (registry::get_global_parameter_*, ShadingTree.cpp:30-60).
+static thread_local const std::map<std::string, igh::pexpr::Param>* g_scene_params = nullptr;
+
+static bool evaluateWithParameters(const std::string& src, V3& out)
+{
+    if (!g_scene_params)
+        return false;
+    try {
+        igh::pexpr::Env env;
+        env.params                    = *g_scene_params;
+        const igh::pexpr::Program prog = igh::pexpr::compile(src, env);
+        if (!prog.is_const || prog.type == igh::pexpr::Type::Bool || prog.type == igh::pexpr::Type::Vec2)
+            return false;
+        out = V3(prog.value[0], prog.value[1], prog.value[2]);
+        return true;
+    } catch (const std::runtime_error&) {
+        return false;
+    }
+}
+
 static bool parseConstColor(const JsonValue& v, V3& out)
 {
     if (v.isNumber()) {
@@ -381,7 +403,7 @@ static bool parseConstColor(const JsonValue& v, V3& out)
         return true;
     }
     if (v.isString())
-        return ConstExpr::evaluate(v.str, out);
+        return ConstExpr::evaluate(v.str, out) || evaluateWithParameters(v.str, out);
     return false;
 }
 
@@ -403,7 +425,7 @@ static float getConstNumber(const JsonValue& obj, const std::string& key, float 
         return def;
     if (v->isString()) { // a constant expression such as "(0.175)^2" (the Blender exporter writes roughness that way)
         V3 c;
-        if (ConstExpr::evaluate(v->str, c) && c.x == c.y && c.y == c.z)
+        if ((ConstExpr::evaluate(v->str, c) || evaluateWithParameters(v->str, c)) && c.x == c.y && c.y == c.z)
             return c.x;
     }
     if (!v->isNumber())
@@ -1246,13 +1268,19 @@ static void loadParameters(const JsonValue& doc, std::map<std::string, igh::pexp
         const JsonValue* v      = p.find("value");
         if (pname.empty() || !v)
             continue;
+        // ShadingTree::handleGlobalParameterNumber / Vector / Color (ShadingTree.cpp:63-106): "int" and "integer" are numbers here,
+        // a single number fills a vector or colour, a colour's alpha is 1
         igh::pexpr::Param out_p{};
-        if (type == "number" && v->isNumber()) {
+        const bool triple = v->isArray() && v->arr.size() == 3 && v->arr[0].isNumber() && v->arr[1].isNumber() && v->arr[2].isNumber();
+        if ((type == "number" || type == "int" || type == "integer") && v->isNumber()) {
             out_p.type  = igh::pexpr::Type::Num;
             out_p.value = { (float)v->num, (float)v->num, (float)v->num, (float)v->num };
-        } else if ((type == "vector" || type == "color") && v->isArray() && v->arr.size() == 3 && v->arr[0].isNumber() && v->arr[1].isNumber() && v->arr[2].isNumber()) {
+        } else if ((type == "vector" || type == "color") && (triple || v->isNumber())) {
             out_p.type  = type == "vector" ? igh::pexpr::Type::Vec3 : igh::pexpr::Type::Vec4;
-            out_p.value = { (float)v->arr[0].num, (float)v->arr[1].num, (float)v->arr[2].num, type == "color" ? 1.0f : 0.0f };
+            const float x = triple ? (float)v->arr[0].num : (float)v->num, y = triple ? (float)v->arr[1].num : x, z = triple ? (float)v->arr[2].num : x;
+            out_p.value = { x, y, z, type == "color" ? 1.0f : 0.0f };
+        } else if (type == "string") {
+            continue; // no expression can name it
         } else {
             fail("Parameter '" + pname + "': expected a number, or three numbers for a vector / color");
         }
@@ -1659,6 +1687,13 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
 
     auto sc = std::make_unique<Scene>();
 
+    std::map<std::string, igh::pexpr::Param> parameters;
+    loadParameters(doc, parameters);
+    struct ParamScope {
+        ParamScope(const std::map<std::string, igh::pexpr::Param>* p) { g_scene_params = p; }
+        ~ParamScope() { g_scene_params = nullptr; }
+    } param_scope(&parameters);
+
     // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
     ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0, 0 };
     std::string selector;
@@ -1960,7 +1995,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     std::vector<LightEntry> hier_entries; // position / direction / flux per finite light (Light::position, direction, computeFlux)
     std::map<std::string, int32_t> finite_index_of_entity;
     TextureBank bank{ textures, base_dir, sc->textures, sc->texture_data, {}, &sc->expr_code, {} };
-    loadParameters(doc, bank.params);
+    bank.params = parameters;
     for (const auto& l : jlights.arr) {
         const std::string lname = l.getString("name");
         const std::string type  = l.getString("type");

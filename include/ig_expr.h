@@ -96,6 +96,18 @@ struct ige_v4 {
     float v[4];
 };
 
+/* float -> int as v_cvt_i32_f32 does it (saturating, NaN -> 0), so that the oracle on x86 agrees for any input */
+IGM_FN int ige_ftoi(float x)
+{
+    if (x != x)
+        return 0;
+    if (x >= 2147483648.0f)
+        return 2147483647;
+    if (x <= -2147483648.0f)
+        return -2147483647 - 1;
+    return (int)x;
+}
+
 IGM_FN float ige_f1_apply(int f, float x)
 {
     switch (f) {
@@ -114,7 +126,7 @@ IGM_FN float ige_f1_apply(int f, float x)
     case IGE_F_CEIL: return -igm_floor(-x);
     case IGE_F_ROUND: return igm_copysign(igm_floor(igm_abs(x) + 0.5f), x); /* roundf: halfway cases away from zero */
     case IGE_F_FRACT: return x - igm_floor(x);                               /* math::fract (core/math.art:74) */
-    case IGE_F_TRUNC: return (float)(int)x;                                  /* math::trunc (core/math.art:73) */
+    case IGE_F_TRUNC: return (float)ige_ftoi(x);                                 /* math::trunc (core/math.art:73) */
     case IGE_F_SQRT: return igm_sqrt(x);
     case IGE_F_ABS: return igm_abs(x);
     case IGE_F_SIGN: return x == 0 ? 0.0f : (igm_signbit(x) ? -1.0f : 1.0f); /* math::signf (core/math.art:76) */
@@ -149,7 +161,7 @@ IGM_FN float ige_wrap(float v, float lo, float hi) /* math::wrap (core/math.art:
     return range <= IGM_FLT_EPS ? lo : v - (range * igm_floor((v - lo) / range));
 }
 
-IGM_FN int ige_parity(float v) { return (int)ige_wrap(v, 0.0f, 2.0f) % 2; }
+IGM_FN int ige_parity(float v) { return ige_ftoi(ige_wrap(v, 0.0f, 2.0f)) % 2; }
 
 /* Ctx supplies: ige_v4 var(int id), ige_v4 tex(uint32_t id, float u, float v), ige_v4 evr(ige_v4 ng, ige_v4 v, ige_v4 n) */
 template <class Ctx>
@@ -260,22 +272,22 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
             break;
         case IGE_FMOD: /* x - trunc(x / n) * n */
             for (int i = 0; i < 4; ++i)
-                o.v[i] = a.v[i] - (float)(int)(a.v[i] / b.v[i]) * b.v[i];
+                o.v[i] = a.v[i] - (float)ige_ftoi(a.v[i] / b.v[i]) * b.v[i];
             break;
         case IGE_WRAP:
             for (int i = 0; i < 4; ++i)
                 o.v[i] = ige_wrap(a.v[i], b.v[i], c.v[i]);
             break;
         case IGE_IMOD: {
-            const int d = (int)b.v[0];
-            const float m = d == 0 ? 0.0f : (float)((int)a.v[0] % d);
+            const int d = ige_ftoi(b.v[0]);
+            const float m = (d == 0 || d == -1) ? 0.0f : (float)(ige_ftoi(a.v[0]) % d);
             for (int i = 0; i < 4; ++i)
                 o.v[i] = m;
             break;
         }
         case IGE_IDIV: {
-            const int d = (int)b.v[0];
-            const float m = d == 0 ? 0.0f : (float)((int)a.v[0] / d);
+            const int d = ige_ftoi(b.v[0]);
+            const float m = d == 0 ? 0.0f : (d == -1 ? -a.v[0] : (float)(ige_ftoi(a.v[0]) / d));
             for (int i = 0; i < 4; ++i)
                 o.v[i] = m;
             break;

@@ -77,7 +77,7 @@ def test_loader_refuses_what_it_cannot_lower():
         LoadedScene.from_string(json.dumps(bad))
     bad = flat_scene()
     bad["bsdfs"][0]["reflectance"] = "some_texture"
-    with pytest.raises(RuntimeError, match="not a constant colour"):
+    with pytest.raises(RuntimeError, match="unknown variable 'some_texture'"):
         LoadedScene.from_string(json.dumps(bad))
     with pytest.raises(RuntimeError, match="JSON error"):
         LoadedScene.from_string("{ not json")
@@ -479,10 +479,13 @@ def test_constant_expressions_and_the_inline_checkerboard_idiom():
     s["bsdfs"][0]["reflectance"] = "chk"
     b = LoadedScene.from_string(json.dumps(s))
     assert bytes(a.scene.materials[0]) == bytes(b.scene.materials[0])
-    for bad in ("select(checkerboard(uvw * 10.0) == 1, some_texture, color(0,0,0,1))", "color(1, 1)", "uv.x * 2", "color(1,1,1,1) *"):
+    for bad, what in (("select(checkerboard(uvw * 10.0) == 1, some_texture, color(0,0,0,1))", "unknown variable 'some_texture'"),
+                      ("color(1, 1)", "no function color"), ("color(1,1,1,1) *", "end of expression")):
         s["bsdfs"][0]["reflectance"] = bad
-        with pytest.raises(RuntimeError, match="not a constant colour"):
+        with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(s))
+    s["bsdfs"][0]["reflectance"] = "uv.x * 2"  # what is not constant becomes a program of the expression table (tests/test_pexpr.py)
+    assert LoadedScene.from_string(json.dumps(s)).scene.materials[0].flags & (1 << 8)
 
 
 def test_sun_position_from_time_and_place():
