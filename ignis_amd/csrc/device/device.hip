@@ -28,6 +28,7 @@ namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20);
 int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
+void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
@@ -599,6 +600,8 @@ void assignScene(igd_device* d, const igd_scene* s)
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
     ds.scene_radius         = s->scene_radius;
+    for (int k = 0; k < 3; ++k)
+        ds.scene_center[k] = s->bbox_min[k] + (s->bbox_max[k] - s->bbox_min[k]) * 0.5f; // bbox_center (core/bbox.art:22)
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
     ds.cdf_data             = d->cdf_data.ptr;
@@ -620,8 +623,22 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
     d->full_bsdfs |= simple_selector;
-    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH && s->technique.type != IG_TECHNIQUE_DEBUG)
+    if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH && s->technique.type != IG_TECHNIQUE_DEBUG
+        && s->technique.type != IG_TECHNIQUE_LIGHTTRACER)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
+    if (s->technique.type == IG_TECHNIQUE_LIGHTTRACER) {
+        // Light::sample_emission and Camera::sample_pixel exist for these light types and the pinhole camera (lt_core.h)
+        for (uint32_t i = 0; i < s->light_count; ++i) {
+            const int lt = s->lights[i].type;
+            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer samples emission of point, spot, area, directional and constant environment lights only" };
+        }
+        if (s->camera.type != IG_CAMERA_PERSPECTIVE || s->camera.aperture_radius > 1.1920928955e-07f)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer connects to the perspective camera without depth of field only" };
+        if (s->sphere_node_count)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer is not lowered for scenes with analytic spheres" };
+        d->full_bsdfs = true;
+    }
     for (uint32_t i = s->infinite_light_count; i < s->light_count; ++i) {
         if (s->lights[i].type != IG_LIGHT_MESH_AREA && s->lights[i].type != IG_LIGHT_SPHERE)
             continue;
@@ -890,6 +907,10 @@ void render(igd_device* d, const igd_render_settings* rs)
         throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: stream capacity is smaller than spi" };
     if (per_it > 0 && chunk_rays >= per_it)
         chunk_rays = (chunk_rays / per_it) * per_it;
+    const bool light_tracer = d->dscene.tech.type == IG_TECHNIQUE_LIGHTTRACER;
+    if (light_tracer && (row_stride != 1 || row_offset != 0 || list_mode || chunk_rays < per_it || d->setup.info_aovs))
+        // a connection lands in any pixel of the film: its accumulator slot has to exist in the chunk that traces the path
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the light tracer needs the whole film in one wavefront (no row sharding, no ray lists, no info AOVs, stream capacity >= width * height * spi)" };
 
     if (d->setup.info_aovs && !list_mode && rs->iteration == 0) {
         // wrap_infobuffer_renderer (technique/internal/infobuffer.art:4-30): normals and albedo of the camera rays' first hits of
@@ -1018,7 +1039,24 @@ void render(igd_device* d, const igd_render_settings* rs)
         ga.rays_per_iteration = (int32_t)std::max<int64_t>(per_it, 1);
         ga.n              = n;
         ga.list_rays      = list_mode ? d->list_rays.ptr : nullptr;
-        timed(0, st, [&] { launch_generate(ga, st); });
+        if (light_tracer) {
+            GenerateLightArgs gl{};
+            gl.scene     = d->dscene;
+            gl.out       = ga.out;
+            gl.out_count = ga.out_count;
+            gl.qs        = qs;
+            gl.width     = rs->width;
+            gl.spi       = rs->spi;
+            gl.iteration = rs->iteration;
+            gl.frame     = rs->frame;
+            gl.seed      = rs->user_seed;
+            gl.first_local_id     = first;
+            gl.rays_per_iteration = ga.rays_per_iteration;
+            gl.n                  = n;
+            timed(0, st, [&] { launch_generate_light(gl, st); });
+        } else {
+            timed(0, st, [&] { launch_generate(ga, st); });
+        }
 
         const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1) };
         uint32_t live          = n;
@@ -1058,6 +1096,20 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.frame     = frame;
             sa.inv_spi   = inv;
             sa.accum_direct = accum_mis[0];
+            if (light_tracer) {
+                // make_perspective_camera (camera/perspective.art:29-31): view = (normalize(dir x up), up, dir)
+                const ig_camera& c = d->camera;
+                const float r[3]   = { c.dir[1] * c.up[2] - c.dir[2] * c.up[1], c.dir[2] * c.up[0] - c.dir[0] * c.up[2], c.dir[0] * c.up[1] - c.dir[1] * c.up[0] };
+                const float rl     = 1 / std::sqrt(std::fma(r[0], r[0], std::fma(r[1], r[1], r[2] * r[2])));
+                for (int k = 0; k < 3; ++k) {
+                    sa.lt_cam.eye[k]      = c.eye[k];
+                    sa.lt_cam.view[k]     = r[k] * rl;
+                    sa.lt_cam.view[3 + k] = c.up[k];
+                    sa.lt_cam.view[6 + k] = c.dir[k];
+                }
+                sa.lt_cam.sx = sx, sa.lt_cam.sy = sy;
+                sa.lt_cam.width = rs->width, sa.lt_cam.height = rs->height;
+            }
             timed(2, on, [&] {
                 launch_shade(sa, shade_grid, d->full_bsdfs, on);
                 launch_round_end(qs, in_slot, on);
@@ -1079,6 +1131,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.accum_nee = accum_mis[1];
             tb.id_base = first;
             tb.inv_spi = inv;
+            tb.atomic_splat = light_tracer ? 1 : 0;
             timed(3, on, [&] {
                 launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid);
                 launch_secondary_end(qs, in_slot ^ 1, mirror, on);
@@ -1100,7 +1153,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             if (known_live == 0)
                 break;
             // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
-            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && !d->dscene.expr_code) {
+            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && !d->dscene.expr_code) {
                 live     = known_live;
                 run_tail = true;
                 break;

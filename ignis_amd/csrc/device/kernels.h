@@ -36,6 +36,7 @@ struct DevScene {
     uint32_t media_count;
     const uint32_t* expr_code; // programs of IG_MAT_EXPR_COLOR / IG_MAT_EXPR_NORMAL materials (include/ig_expr.h)
     float scene_radius;
+    float scene_center[3]; // bbox_center(scene_bbox): env_sample_pos of the light tracer (light/env.art:2-6)
     // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
     // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)
     const uint4* entity_ext;
@@ -123,10 +124,24 @@ struct TraverseArgs {
     float4* accum_nee; // "NEE Weights" (ig_technique.aov_mis): the same splat once more, or null
     int64_t id_base;
     float inv_spi;
+    int32_t atomic_splat; // light tracer: the slot col.w names belongs to another path's pixel, so the splat is atomic
     // scenes with analytic spheres: the launch over the triangle BVH is followed by one over the sphere BVH that starts from its
     // hits. 0: single pass; 1: first of two (any-hit: the hit must be stored and the splat is left to the second); 2: the sphere pass
     int32_t sphere_pass;
     uint32_t* sphere_work_counter; // zero before launch
+};
+
+// k_generate_light: make_lt_emitter (technique/lighttracer.art:35-62), one light path per ray id
+struct GenerateLightArgs {
+    DevScene scene;
+    PrimaryCols out;
+    uint32_t* out_count;
+    QueueState* qs;
+    int32_t width, spi;
+    int32_t iteration, frame, seed;
+    int64_t first_local_id;
+    int32_t rays_per_iteration;
+    uint32_t n;
 };
 
 struct GenerateArgs {
@@ -155,6 +170,14 @@ struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-
     int32_t rays_per_iteration; // local pixels * spi: ray ids of a multi-iteration call continue across iterations
 };
 
+// the pinhole camera of the light tracer's connections (Camera::sample_pixel, camera/perspective.art:16-57)
+struct LtCameraArgs {
+    float eye[3];
+    float view[9]; // right, up, dir
+    float sx, sy;
+    int32_t width, height;
+};
+
 struct ShadeArgs {
     DevScene scene;
     PrimaryCols in;
@@ -168,6 +191,7 @@ struct ShadeArgs {
     int64_t id_base; // local ray id of accum[0]
     ShadeFrame frame;
     float inv_spi;
+    LtCameraArgs lt_cam; // IG_TECHNIQUE_LIGHTTRACER
 };
 
 struct TailArgs {

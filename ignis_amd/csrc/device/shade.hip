@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "shade_core.h"
+#include "lt_core.h"
 
 namespace igdev {
 
@@ -216,6 +217,51 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
     a.out.eta[i]  = 1;
 }
 
+// make_lt_emitter (technique/lighttracer.art:35-62): the light selector at position 0, Light::sample_emission, payload
+// (contrib = intensity * |cos| / light_pdf, depth 1, eta 1). A sample without a ray gets the zero ray, which can only miss.
+__global__ void __launch_bounds__(256) k_generate_light(const GenerateLightArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        *a.out_count = a.n;
+        atomicAdd(&a.qs->camera_rays, (unsigned long long)a.n);
+    }
+    if (i >= a.n)
+        return;
+    const int64_t lid    = a.first_local_id + i;
+    const int it_local   = (int)(lid / a.rays_per_iteration);
+    const int64_t within = lid % a.rays_per_iteration;
+    const int sample     = (int)(within % a.spi);
+    const int64_t lpixel = within / a.spi;
+    const int x          = (int)(lpixel % a.width);
+    const int y          = (int)(lpixel / a.width);
+    Tea rnd{ make_seed(sample, a.iteration + it_local, a.frame, x, y, a.seed), 1 };
+
+    f3 org{ 0, 0, 0 }, dir{ 0, 0, 0 };
+    float tmin = 0, tmax = 0;
+    uint32_t flags = 0;
+    Col contrib{ 0, 0, 0 };
+    const DevScene& sc = a.scene;
+    if (sc.light_count > 0) {
+        float light_pdf;
+        const int li = select_light<true>(sc, rnd, f3{ 0, 0, 0 }, light_pdf);
+        EmissionSample es;
+        if (sample_emission(sc, sc.lights[li], rnd, es)) {
+            org     = es.pos;
+            dir     = es.dir;
+            tmin    = (uint32_t)li < sc.infinite_light_count ? 0.0f : kRayOffset;
+            tmax    = kFltMax;
+            flags   = IG_RAY_FLAG_LIGHT;
+            contrib = es.intensity * safe_div(igm_abs(es.cos), light_pdf * 1.0f);
+        }
+    }
+    a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
+    a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
+    a.out.meta[i] = make_int4((int32_t)lid, (int32_t)flags, (int32_t)rnd.counter, 1);
+    a.out.pay[i]  = make_float4(0, contrib.r, contrib.g, contrib.b);
+    a.out.eta[i]  = 1;
+}
+
 // ---------------------------------------------------------------- k_shade
 
 constexpr int kShadeThreads = 256;
@@ -230,7 +276,8 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
-template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false>
+// LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false>
 __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
     __shared__ uint32_t s_hist[kShadeThreads];
@@ -299,6 +346,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
         int ray_id = 0;
+        int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
         if (j < n) {
             PathVertexIn in;
             const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], pay = a.in.pay[j], hit = a.in.hit[j];
@@ -314,7 +362,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             in.ent     = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
-            shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out);
+            if constexpr (LT)
+                shade_vertex_lt(sc, fr, LtCamera(a.lt_cam), in, out, s_slot);
+            else
+                shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out);
             if (out.has_radiance) {
                 // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
@@ -385,7 +436,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
                 a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
                 a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
-                a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)ray_id));
+                a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
             }
             __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
         }
@@ -563,10 +614,19 @@ template __global__ void k_shade<false>(const ShadeArgs);
 template __global__ void k_shade<true>(const ShadeArgs);
 template __global__ void k_shade<true, true, true>(const ShadeArgs);
 template __global__ void k_shade<true, false, true>(const ShadeArgs);
+template __global__ void k_shade<true, false, true, true>(const ShadeArgs);
+
+void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream)
+{
+    const unsigned blocks = (args.n + 255u) / 256u;
+    hipLaunchKernelGGL(k_generate_light, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, args);
+}
 
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream)
 {
-    if (args.scene.tech.type == IG_TECHNIQUE_DEBUG) // (no bounces: the tail kernels never see this technique)
+    if (args.scene.tech.type == IG_TECHNIQUE_LIGHTTRACER)
+        hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    else if (args.scene.tech.type == IG_TECHNIQUE_DEBUG) // (no bounces: the tail kernels never see this technique)
         hipLaunchKernelGGL((k_shade<true, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else if (args.scene.expr_code) // materials with shading expressions: the instantiation with the interpreter (no tail kernels either)
         hipLaunchKernelGGL((k_shade<true, false, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);

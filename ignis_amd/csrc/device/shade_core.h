@@ -840,7 +840,7 @@ struct Principled {
     }
 
     // sample (principled.art:382-476), adjoint = false; false = reject_bsdf_sample()
-    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta) const
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool adjoint = false) const
     {
         const f3 wo = to_local(out_dir);
         if (igm_abs(wo.z) <= kGrazingEps)
@@ -915,7 +915,9 @@ struct Principled {
         s_eta   = (thin || same_hemi(wo, dir)) ? 1.0f : refr_eta;
         in_dir  = to_world(dir);
         pdf_out = spdf;
-        color   = eval(in_dir, out_dir) * (1 / spdf);
+        // light paths carry 1 / eta^2 across a refraction (principled.art:471)
+        const float spread = (adjoint && !thin && !same_hemi(wo, dir)) ? 1 / (refr_eta * refr_eta) : 1.0f;
+        color   = eval(in_dir, out_dir) * (spread / spdf);
         return true;
     }
 };
@@ -978,7 +980,7 @@ struct RoughDielectric {
             return fterm * mpdf * igm_abs(refl_jacobian(cho));
         return (1 - fterm) * mpdf * igm_abs(refr_jacobian(eta, chi, cho));
     }
-    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta) const
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool adjoint = false) const
     {
         const float cos_o = dot3(N, out_dir);
         if (igm_abs(cos_o) <= kCosEps)
@@ -1007,7 +1009,7 @@ struct RoughDielectric {
         }
         const float cos_i = dot3(N, in_dir);
         pdf_out           = mpdf * sel_pdf;
-        color             = eval(in_dir, out_dir) * safe_div(1, pdf_out);
+        color             = eval(in_dir, out_dir) * safe_div((igm_signbit(cos_i * cos_o) && adjoint) ? 1 / (eta * eta) : 1.0f, pdf_out); // dielectric.art:181-185
         s_eta             = !igm_signbit(cos_i * cos_o) ? 1.0f : eta;
         return true;
     }
@@ -1404,17 +1406,18 @@ struct BsdfCtx {
         return 0;
     }
     // returns false when the sample is rejected
-    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
+    // adjoint: bsdf.sample(rnd, out_dir, true) of light paths (the light tracer)
+    IG_DEV bool sample(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta, bool adjoint = false) const
     {
         if constexpr (FULL && TOP) {
-            const bool ok = sample_inner(rnd, ds_flip ? -out_dir : out_dir, in_dir, pdf_out, color, s_eta, sdelta);
+            const bool ok = sample_inner(rnd, ds_flip ? -out_dir : out_dir, in_dir, pdf_out, color, s_eta, sdelta, adjoint);
             in_dir        = ds_flip ? -in_dir : in_dir;
             return ok;
         } else {
-            return sample_inner(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta);
+            return sample_inner(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta, adjoint);
         }
     }
-    IG_DEV bool sample_inner(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta) const
+    IG_DEV bool sample_inner(Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, float& s_eta, bool& sdelta, bool adjoint = false) const
     {
         const f3 N = surf.local.c2;
         if constexpr (FULL && TOP) {
@@ -1426,7 +1429,7 @@ struct BsdfCtx {
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     const int first = (pick1 ? 0 : 1) ^ attempt;
                     const BsdfCtx<FULL, false> a = inner(first), b = inner(first ^ 1);
-                    if (!a.sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta))
+                    if (!a.sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, sdelta, adjoint))
                         continue;
                     const float p = lerpf(pdf_out, b.pdf(in_dir, out_dir), t);
                     const Col c   = lerp_col(color * pdf_out, b.eval(in_dir, out_dir), t);
@@ -1454,11 +1457,11 @@ struct BsdfCtx {
             }
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
                 sdelta = false;
-                return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
+                return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, adjoint);
             }
             if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) {
                 sdelta = false;
-                return RoughDielectric(*mat, surf.local, surf.entering).sample(rnd, out_dir, in_dir, pdf_out, color, s_eta);
+                return RoughDielectric(*mat, surf.local, surf.entering).sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, adjoint);
             }
             if (mat->bsdf_type == IG_BSDF_PLASTIC) {
                 s_eta = 1;
@@ -1545,7 +1548,7 @@ struct BsdfCtx {
         }
         if (rnd.f32() > F) {
             in_dir = N * (k * cos_o - cos_t) - out_dir * k; // vec3_refract (core/vector.art:126)
-            color  = Col{ mat->p[5], mat->p[6], mat->p[7] } * 1.0f;
+            color  = Col{ mat->p[5], mat->p[6], mat->p[7] } * (adjoint ? k * k : 1.0f); // adjoint_term (dielectric.art:28)
             s_eta  = k;
         } else {
             in_dir = N * (2 * dot3(N, out_dir)) - out_dir; // vec3_reflect (core/vector.art:123)

@@ -122,11 +122,19 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             // accumulator: plain read-modify-write, the slot is owned by this ray.
                             const float4 c = a.col[ray_idx];
                             float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                            float4 v       = *dst;
-                            v.x += c.x * a.inv_spi;
-                            v.y += c.y * a.inv_spi;
-                            v.z += c.z * a.inv_spi;
-                            *dst = v;
+                            if (a.atomic_splat) {
+                                // the light tracer's connections (on_advanced_shadow_miss, technique/lighttracer.art:116-120): many paths
+                                // add into the slots of one pixel
+                                atomicAdd(&dst->x, c.x * a.inv_spi);
+                                atomicAdd(&dst->y, c.y * a.inv_spi);
+                                atomicAdd(&dst->z, c.z * a.inv_spi);
+                            } else {
+                                float4 v = *dst;
+                                v.x += c.x * a.inv_spi;
+                                v.y += c.y * a.inv_spi;
+                                v.z += c.z * a.inv_spi;
+                                *dst = v;
+                            }
                             if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
                                 float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
                                 float4 w   = *nd;

@@ -1717,10 +1717,16 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             for (int i = 0; i < 28; ++i)
                 if (mode == modes[i])
                     tech.debug_mode = i;
-        } else if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao' and 'debug')");
+        } else if (type == "lt" || type == "lighttracer")
+            tech.type = IG_TECHNIQUE_LIGHTTRACER; // LightTracerTechnique.cpp:10-17
+        else if (type != "path")
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao', 'debug' and 'lt')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
+        if (tech.type == IG_TECHNIQUE_LIGHTTRACER) { // "max_depth" else "max_light_depth", "min_depth" else "min_light_depth"
+            tech.max_depth = t->has("max_depth") ? tech.max_depth : t->getInt("max_light_depth", 64);
+            tech.min_depth = t->has("min_depth") ? tech.min_depth : t->getInt("min_light_depth", 2);
+        }
         tech.clamp     = t->getNumber("clamp", 0.0f);
         tech.nee       = t->getBool("nee", true) ? 1 : 0;
         selector       = t->getString("light_selector");
@@ -2497,6 +2503,15 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     }
     t.camera             = cam;
     t.technique          = tech;
+    if (tech.type == IG_TECHNIQUE_LIGHTTRACER) {
+        // the light tracer needs Light::sample_emission and Camera::sample_pixel: lowered for these light types and the pinhole camera
+        for (const ig_light& l : sc->lights)
+            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_DIRECTIONAL
+                && l.type != IG_LIGHT_ENV)
+                fail("Technique 'lt': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional and constant environment lights are)");
+        if (cam.type != IG_CAMERA_PERSPECTIVE || cam.aperture_radius > 0)
+            fail("Technique 'lt': only the perspective camera without depth of field is supported by the HIP backend");
+    }
     for (int i = 0; i < 3; ++i) {
         t.bbox_min[i] = entityCount ? sceneBBox.min[i] : 0;
         t.bbox_max[i] = entityCount ? sceneBBox.max[i] : 0;

@@ -291,6 +291,12 @@ enum ig_technique_type {
      * camera ray shown as one of 28 properties (ig_technique.debug_mode = enum DebugMode, src/runtime/technique/DebugMode.h:6-35;
      * registry parameter "__debug_mode"); no shadow rays, no bounces, nothing on a miss. */
     IG_TECHNIQUE_DEBUG = 3,
+    /* the light tracer (make_lt_emitter / make_lt_renderer, src/artic/technique/lighttracer.art:35-167, LightTracerTechnique.cpp): every
+     * (pixel, sample) index starts one path on a light chosen by the light selector; each non-delta vertex is connected to the
+     * pinhole camera and, unoccluded, splatted into the pixel it projects to; bounces sample the BSDF with adjoint = true.
+     * max_depth, min_depth, clamp, light_selector as for the path tracer. Perspective cameras without depth of field; point, spot,
+     * plane / mesh area, directional and constant environment lights. */
+    IG_TECHNIQUE_LIGHTTRACER = 4,
 };
 
 /* One record per medium, in the order entities acquire them (LoaderMedium::acquire, src/runtime/loader/LoaderMedium.cpp:113-121;

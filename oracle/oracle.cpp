@@ -447,6 +447,63 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
     }
 }
 
+// The light tracer (technique/lighttracer.art) path by path: a path's random numbers, vertices and splats are those of the wavefront
+// pipeline (emitter -> primary traversal -> hit shading with on_shadow / on_bounce -> any-hit traversal -> on_advanced_shadow_miss
+// splat), only the order in which different paths add into a pixel differs, so sums agree to rounding. One thread: splats go anywhere.
+void trace_light_paths(const igd_scene& sc, const oracle_settings& cfg, const CameraSetup& cam, float* fb, Counters& cnt)
+{
+    const LightTracer lt(sc);
+    const int spi = cfg.spi, W = cfg.width, H = cfg.height;
+    const float inv_spi = 1 / (float)spi;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int sample = 0; sample < spi; ++sample) {
+                Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, x, y, cfg.seed), 1 };
+                Ray ray;
+                PTRayPayload payload;
+                ++cnt.camera;
+                if (!lt.emit(rnd, ray, payload) || sc.entity_count == 0)
+                    continue;
+                for (;;) {
+                    const Hit hit = traverse_scene(sc, ray, false, cnt.trav);
+                    if (hit.prim_id < 0)
+                        break; // TechniqueNoMissFunction
+                    const Entity entity        = load_entity(sc, hit.ent_id);
+                    const ig_material& mat     = sc.materials[entity.mat_id];
+                    const SurfaceElement surf  = surface_element(sc, entity, ray, hit);
+                    const bool bumped          = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)) != 0;
+                    const SurfaceElement bsurf = bumped ? bumped_surface(sc, mat, surf, ray) : surf;
+                    const bool ds_flip         = (mat.flags & IG_MAT_DOUBLESIDED) && !surf.is_entering;
+                    SurfaceElement dsurf       = bsurf;
+                    dsurf.is_entering          = true;
+                    Bsdf bsdf{ &mat, ds_flip ? &dsurf : &bsurf, &sc, ds_flip, vec3_neg(ray.dir) };
+                    bsdf.adjoint    = true;
+                    bsdf.bumped     = bumped;
+                    bsdf.old_normal = surf.local.col[2];
+
+                    float nx = 0, ny = 0;
+                    // (ctx.surf of the callbacks is the hit's surface element; the BSDF may sit on a re-oriented one)
+                    const ShadowRayOut sh = lt.on_shadow(cam, ray, surf, payload, bsdf, nx, ny);
+                    if (sh.valid) {
+                        ++cnt.shadow;
+                        const Hit occluder = traverse_scene(sc, sh.ray, true, cnt.trav);
+                        if (occluder.prim_id < 0) {
+                            ++cnt.unoccluded;
+                            const int pixel = LightTracer::pixel_from_normalized(nx, ny, W, H);
+                            fb[pixel * 3 + 0] += sh.color.r * inv_spi;
+                            fb[pixel * 3 + 1] += sh.color.g * inv_spi;
+                            fb[pixel * 3 + 2] += sh.color.b * inv_spi;
+                        }
+                    }
+                    Ray new_ray;
+                    if (!lt.on_bounce(ray, surf, rnd, payload, bsdf, new_ray))
+                        break;
+                    ray = new_ray;
+                    ++cnt.bounce;
+                }
+            }
+}
+
 } // namespace
 
 extern "C" {
@@ -465,6 +522,24 @@ int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* f
     float sx, sy;
     camera_scale(*sc, cfg->width, cfg->height, sx, sy);
     const CameraSetup cam = make_camera(sc->camera, sx, sy);
+    if (sc->technique.type == IG_TECHNIQUE_LIGHTTRACER) {
+        if (cfg->row_stride > 1 || cfg->xmax > 0 || cfg->ymax > 0)
+            return -1; // splats land anywhere on the film: whole-film renders only
+        Counters c;
+        trace_light_paths(*sc, *cfg, cam, fb, c);
+        if (stats) {
+            stats->camera_rays += c.camera;
+            stats->bounce_rays += c.bounce;
+            stats->shadow_rays += c.shadow;
+            stats->unoccluded += c.unoccluded;
+            stats->nodes += c.trav.nodes;
+            stats->tris += c.trav.tris;
+            stats->leaves += c.trav.leaves;
+            stats->max_stack = std::max(stats->max_stack, c.trav.max_stack);
+            stats->threads_used = 1;
+        }
+        return 0;
+    }
     const PathTracer pt(*sc);
 
     const int tile_size = 16; // ShaderUtils.cpp:37

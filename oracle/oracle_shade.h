@@ -1105,8 +1105,8 @@ struct Principled {
         return l.diff_trans * diff_pdf + l.spec_trans * spec_trans_pdf_local(wo, wi);
     }
 
-    // sample (principled.art:382-476), adjoint = false. Returns false for reject_bsdf_sample().
-    bool sample(Rng& rnd, Vec3 out_dir, Vec3& in_dir, float& pdf_out, Color& color, float& eta) const
+    // sample (principled.art:382-476). Returns false for reject_bsdf_sample().
+    bool sample(Rng& rnd, Vec3 out_dir, Vec3& in_dir, float& pdf_out, Color& color, float& eta, bool adjoint = false) const
     {
         const Vec3 wo = to_local(out_dir);
         if (igm_abs(wo.z) <= grazing_eps)
@@ -1183,7 +1183,9 @@ struct Principled {
         eta     = (thin || is_same_hemisphere(wo, dir)) ? 1.0f : refractive_eta;
         in_dir  = to_world(dir);
         pdf_out = spdf;
-        color   = color_mulf(eval(in_dir, out_dir), 1 / spdf);
+        // principled.art:471: light paths carry 1 / eta^2 across a refraction
+        const float spread = (adjoint && !thin && !is_same_hemisphere(wo, dir)) ? 1 / (refractive_eta * refractive_eta) : 1.0f;
+        color   = color_mulf(eval(in_dir, out_dir), spread / spdf);
         return true;
     }
 };
@@ -1257,7 +1259,7 @@ struct RoughDielectric {
             return fterm * mpdf * igm_abs(halfway_reflective_jacobian(cos_h_o));
         return (1 - fterm) * mpdf * igm_abs(halfway_refractive_jacobian(eta, cos_h_i, cos_h_o));
     }
-    bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s, bool adjoint = false) const
     {
         const float cos_o = vec3_dot(N, out_dir);
         if (igm_abs(cos_o) <= cos_eps)
@@ -1292,7 +1294,7 @@ struct RoughDielectric {
         const bool is_transmission = igm_signbit(cos_i * cos_o);
         s.in_dir   = in_dir;
         s.pdf      = f_pdf;
-        s.color    = color_mulf(eval(in_dir, out_dir), safe_div(1, f_pdf)); // adjoint = false
+        s.color    = color_mulf(eval(in_dir, out_dir), safe_div((is_transmission && adjoint) ? 1 / (eta * eta) : 1.0f, f_pdf)); // dielectric.art:181-185
         s.eta      = !is_transmission ? 1.0f : eta;
         s.is_delta = false;
         return true;
@@ -1449,6 +1451,10 @@ struct Bsdf {
     // caller's copy), every direction is negated on the way in and the sampled one on the way out
     bool flip = false;
     Vec3 view{ 0, 0, 0 }; // -ray.dir for the "V" of a colour expression (zero inside a blend: the loader keeps V out of those)
+    // light paths (the light tracer): bsdf.sample(rnd, out_dir, adjoint = true); `bumped`: the BSDF sits on a re-oriented surface
+    // (transform_surf_bsdf, bsdf/map.art:16-32) whose original shading normal was old_normal
+    bool adjoint = false, bumped = false;
+    Vec3 old_normal{ 0, 0, 0 };
     Bsdf unflipped() const
     {
         Bsdf b = *this;
@@ -1464,7 +1470,12 @@ struct Bsdf {
         return mat->bsdf_type == IG_BSDF_DIELECTRIC || mat->bsdf_type == IG_BSDF_TRANSPARENT || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     // the two BSDFs a blend mixes (make_mix_bsdf, bsdf/mix.art:4-68); they see the same surface
-    Bsdf inner(int i) const { return Bsdf{ &scene->materials[mat->pad[i]], surf, scene }; }
+    Bsdf inner(int i) const
+    {
+        Bsdf b{ &scene->materials[mat->pad[i]], surf, scene };
+        b.adjoint = adjoint;
+        return b;
+    }
 
     Color kd() const
     {
@@ -1654,12 +1665,27 @@ struct Bsdf {
         }
         return 0;
     }
+    // shading_normal_adjoint (bsdf/map.art:1-7)
+    static float shading_normal_adjoint(Vec3 in_dir, Vec3 out_dir, Vec3 ns, Vec3 ng)
+    {
+        const float ons = positive_cos(out_dir, ns), ins = positive_cos(in_dir, ns);
+        const float ong = positive_cos(out_dir, ng), ing = positive_cos(in_dir, ng);
+        return (ins <= flt_eps || ong <= flt_eps) ? 0.0f : (ons / ins) * (ing / ong);
+    }
     bool sample(Rng& rnd, Vec3 out_dir, BsdfSample& s) const
     {
         if (flip) {
             if (!unflipped().sample(rnd, vec3_neg(out_dir), s))
                 return false;
             s.in_dir = vec3_neg(s.in_dir);
+            return true;
+        }
+        if (adjoint && bumped) { // transform_surf_bsdf.sample with adjoint (bsdf/map.art:19-30)
+            Bsdf plain   = *this;
+            plain.bumped = false;
+            if (!plain.sample(rnd, out_dir, s))
+                return false;
+            s.color = color_mulf(s.color, shading_normal_adjoint(s.in_dir, out_dir, surf->local.col[2], old_normal));
             return true;
         }
         if (mat->bsdf_type == IG_BSDF_BLEND) {
@@ -1691,12 +1717,12 @@ struct Bsdf {
             return phong_sample(rnd, out_dir, s);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
             s.is_delta = false;
-            return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta);
+            return Principled(*mat, *surf, kd()).sample(rnd, out_dir, s.in_dir, s.pdf, s.color, s.eta, adjoint);
         }
         if (mat->bsdf_type == IG_BSDF_PLASTIC)
             return Plastic(*mat, *surf, kd()).sample(rnd, out_dir, s);
         if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
-            return RoughDielectric(*mat, *surf).sample(rnd, out_dir, s);
+            return RoughDielectric(*mat, *surf).sample(rnd, out_dir, s, adjoint);
         if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
             const float u      = rnd.next_f32();
             const float v      = rnd.next_f32();
@@ -1781,7 +1807,7 @@ struct Bsdf {
         if (rnd.next_f32() > factor) {
             s.in_dir = vec3_refract(out_dir, n, k, cos_o, cos_t);
             s.pdf    = 1;
-            s.color  = color_mulf(kt, 1); // adjoint = false
+            s.color  = color_mulf(kt, adjoint ? k * k : 1.0f); // adjoint_term (dielectric.art:28)
             s.eta    = k;
         } else {
             s.in_dir = vec3_reflect(out_dir, n);
@@ -3164,6 +3190,235 @@ struct PathTracer {
 
         pt.inv_pdf = inv_pdf;
         pt.contrib = new_contrib;
+        pt.depth   = pt.depth + 1;
+        pt.eta     = pt.eta * ms.eta;
+        new_ray    = make_ray(surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+        return true;
+    }
+};
+
+// ================================================================================================================
+// Light tracer (technique/lighttracer.art): paths start on a light (make_lt_emitter, :35-62), every non-delta vertex is
+// connected to the camera (on_shadow, :75-113) and the unoccluded connection is splatted into the pixel the vertex projects
+// to (on_advanced_shadow_miss, :116-120; the "advanced" shadow kernels of driver/mapping_gpu.art:293-333 only exist to hand
+// that callback its secondary payload). Bounces sample the BSDF with adjoint = true (:123-163).
+
+struct EmissionSample { // make_emission_sample (light/light.art)
+    Vec3 pos, dir;
+    Color intensity;
+    float pdf_area, pdf_dir, cos;
+};
+
+// env_sample_pos (light/env.art:2-6): a point of the disc of radius scene_radius that faces the scene from direction `dir`
+static inline void env_sample_pos(const igd_scene& sc, Rng& rnd, Vec3 dir, Vec3& pos, float& pdf)
+{
+    const float r = sc.scene_radius; // bbox_radius(scene_bbox) * 1.01
+    const float u = rnd.next_f32();
+    const float v = rnd.next_f32();
+    float dx, dy;
+    square_to_concentric_disk(u, v, dx, dy); // sample_uniform_disk (core/sampling.art:101-103)
+    const Vec3 bmin = make_vec3(sc.bbox_min[0], sc.bbox_min[1], sc.bbox_min[2]), bmax = make_vec3(sc.bbox_max[0], sc.bbox_max[1], sc.bbox_max[2]);
+    const Vec3 center = vec3_add(bmin, vec3_mulf(vec3_sub(bmax, bmin), 0.5f)); // bbox_center (core/bbox.art:22)
+    pos = vec3_add(center, vec3_add(vec3_mulf(dir, r), mat3x3_mul(make_orthonormal_mat3x3(dir), make_vec3(dx * r, dy * r, 0))));
+    pdf = 1 / (flt_pi * r * r);
+}
+
+// Light::sample_emission of the light types the light tracer is lowered for
+static inline bool sample_emission(const igd_scene& sc, const ig_light& l, Rng& rnd, EmissionSample& e)
+{
+    switch (l.type) {
+    case IG_LIGHT_POINT: { // light/point.art:9-12
+        const float u = rnd.next_f32();
+        const float v = rnd.next_f32();
+        const float c = 2 * v - 1, sn = safe_sqrt(1 - c * c), phi = 2 * flt_pi * u; // sample_uniform_sphere (core/sampling.art:42-47)
+        const float pdf = 1 / (4 * flt_pi);
+        e = EmissionSample{ make_vec3(l.d[0], l.d[1], l.d[2]), make_vec3(sn * igm_cos(phi), sn * igm_sin(phi), c), color_mulf(Color{ l.d[4], l.d[5], l.d[6] }, 1 / pdf), 1, pdf, 1 };
+        return true;
+    }
+    case IG_LIGHT_SPOT: { // light/spot.art:8-47
+        const Vec3 pos = make_vec3(l.d[0], l.d[1], l.d[2]), dir = make_vec3(l.d[4], l.d[5], l.d[6]);
+        const float cosCutoffAngle = l.d[3], cosFalloffAngle = l.d[7];
+        const float blendRange  = cosFalloffAngle - cosCutoffAngle;
+        const float spot_radius = igm_sqrt(1 - cosCutoffAngle * cosCutoffAngle) / cosCutoffAngle;
+        const float spot_area   = flt_pi * spot_radius * spot_radius;
+        const float u = rnd.next_f32();
+        const float v = rnd.next_f32();
+        const float c1 = 1 - cosCutoffAngle; // sample_uniform_cone (core/sampling.art:109-116)
+        float px, py;
+        square_to_concentric_disk(u, v, px, py);
+        const float n2  = px * px + py * py;
+        const float z   = cosCutoffAngle + c1 * (1 - n2);
+        const float sc2 = safe_sqrt(c1 * (2 - c1 * n2));
+        const float pdf = safe_div(1, 2 * flt_pi * (1 - cosCutoffAngle));
+        const Vec3 out_dir    = mat3x3_mul(make_orthonormal_mat3x3(dir), make_vec3(px * sc2, py * sc2, z));
+        const float cos_angle = vec3_dot(out_dir, dir);
+        float factor;
+        if (blendRange <= flt_eps) {
+            factor = cos_angle <= cosCutoffAngle ? 0.0f : 1.0f;
+        } else {
+            const float x = clampf((cos_angle - cosCutoffAngle) / blendRange, 0, 1);
+            factor        = x * x * (3 - 2 * x);
+        }
+        const Color color = color_mulf(color_mulf(Color{ l.d[8], l.d[9], l.d[10] }, factor), 1 / (spot_area * pdf));
+        e = EmissionSample{ pos, out_dir, color, 1, spot_area * pdf, z };
+        return true;
+    }
+    case IG_LIGHT_PLANE:
+    case IG_LIGHT_MESH_AREA: { // make_area_light.sample_emission (light/area.art:26-37)
+        const float u0 = rnd.next_f32();
+        const float u1 = rnd.next_f32();
+        Vec3 point, normal;
+        float area_pdf;
+        Color radiance;
+        if (l.type == IG_LIGHT_PLANE) { // make_plane_area_emitter.sample (area.art:230-250)
+            const PlaneEmitter pe(l);
+            point    = vec3_add(vec3_add(vec3_mulf(pe.x_axis, u0), vec3_mulf(pe.y_axis, u1)), pe.origin);
+            normal   = pe.normal;
+            area_pdf = pe.inv_area;
+            radiance = pe.radiance;
+        } else { // make_shape_area_emitter.sample (area.art:62-72) over shape.surface_element_for_point (shapes/trimesh.art:41-68)
+            const MeshEmitter me(sc, l);
+            int32_t f;
+            float bu, bv, area;
+            Vec3 fn;
+            me.address(Vec2{ u0, u1 }, f, bu, bv);
+            me.surface(f, bu, bv, point, fn, area);
+            const int32_t i0 = me.mesh.indices[f * 4 + 0], i1 = me.mesh.indices[f * 4 + 1], i2 = me.mesh.indices[f * 4 + 2];
+            auto nrm = [&](int32_t i) { return Vec3{ me.mesh.normals[i * 4], me.mesh.normals[i * 4 + 1], me.mesh.normals[i * 4 + 2] }; };
+            normal   = vec3_normalize(mat3x3_mul(me.entity.normal_mat, vec3_lerp2(nrm(i0), nrm(i1), nrm(i2), bu, bv)));
+            area_pdf = safe_div(1, area) / (float)me.mesh.num_tris;
+            radiance = me.radiance;
+        }
+        const float u2 = rnd.next_f32();
+        const float u3 = rnd.next_f32();
+        const DirSample smp = sample_cosine_hemisphere(u2, u3);
+        const float weight  = safe_div(1, area_pdf * smp.pdf);
+        e = EmissionSample{ point, mat3x3_mul(make_orthonormal_mat3x3(normal), smp.dir), color_mulf(radiance, weight), area_pdf, smp.pdf, smp.dir.z };
+        return true;
+    }
+    case IG_LIGHT_DIRECTIONAL: { // light/directional.art:7-10
+        const Vec3 dir = make_vec3(l.d[0], l.d[1], l.d[2]);
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, vec3_neg(dir), pos, pos_pdf);
+        e = EmissionSample{ pos, dir, color_mulf(Color{ l.d[4], l.d[5], l.d[6] }, safe_div(1, pos_pdf)), pos_pdf, 1, 1 };
+        return true;
+    }
+    case IG_LIGHT_ENV: { // make_environment_light_function_spherical.sample_emission (light/env.art:87-93), constant colour, identity transform
+        const float u   = rnd.next_f32();
+        const float v   = rnd.next_f32();
+        const Vec3 dir  = equal_area_square_to_sphere(u, v);
+        const float pdf = 1 / (4 * flt_pi);
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, dir, pos, pos_pdf);
+        e = EmissionSample{ pos, vec3_neg(dir), color_mulf(Color{ l.d[0], l.d[1], l.d[2] }, safe_div(1, pos_pdf * pdf)), pos_pdf, pdf, 1.0f };
+        return true;
+    }
+    default:
+        return false; // (the loader refuses the light tracer for the other light types)
+    }
+}
+
+struct LightTracer {
+    const igd_scene& sc;
+    const PathTracer selector; // light selection only
+    int32_t max_path_len, min_path_len;
+    float clamp_value;
+    static constexpr float offset = 0.001f;
+
+    explicit LightTracer(const igd_scene& s)
+        : sc(s)
+        , selector(s)
+        , max_path_len(s.technique.max_depth)
+        , min_path_len(s.technique.min_depth)
+        , clamp_value(s.technique.clamp)
+    {
+    }
+    Color handle_color(Color c) const { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; }
+
+    // make_lt_emitter (lighttracer.art:35-62); false: no ray for this sample
+    bool emit(Rng& rnd, Ray& ray, PTRayPayload& payload) const
+    {
+        if (sc.light_count == 0)
+            return false;
+        float light_pdf;
+        const int32_t li  = selector.select_light(rnd, make_vec3(0, 0, 0), light_pdf);
+        const ig_light& l = sc.lights[li];
+        EmissionSample es;
+        if (!sample_emission(sc, l, rnd, es))
+            return false;
+        const bool infinite = li < (int32_t)sc.infinite_light_count;
+        ray                 = make_ray(es.pos, es.dir, infinite ? 0.0f : offset, flt_max, IG_RAY_FLAG_LIGHT);
+        payload             = PTRayPayload{ 0, color_mulf(es.intensity, safe_div(igm_abs(es.cos), light_pdf * 1.0f)), 1, 1, -1 };
+        return true;
+    }
+
+    // camera.sample_pixel of make_perspective_camera (camera/perspective.art:16-26,43-57): no test for points behind the eye, as written
+    static bool sample_pixel(const CameraSetup& cam, Vec3 pos, Vec3& dir, float& nx, float& ny)
+    {
+        if (cam.type != IG_CAMERA_PERSPECTIVE || cam.aperture_radius > 0)
+            return false;
+        const Vec3 d  = vec3_sub(pos, cam.eye);
+        const Vec3 un = make_vec3(vec3_dot(cam.view.col[0], d), vec3_dot(cam.view.col[1], d), vec3_dot(cam.view.col[2], d)); // mat3x3_left_mul
+        nx = un.x / (un.z * cam.sx);
+        ny = un.y / (un.z * cam.sy);
+        if (!(nx >= -1 && nx <= 1 && ny >= -1 && ny <= 1))
+            return false;
+        dir = vec3_sub(cam.eye, pos);
+        return true;
+    }
+    // make_pixelcoord_from_normalized (driver/camera.art:45-57)
+    static int pixel_from_normalized(float nx, float ny, int w, int h)
+    {
+        const int x = std::min((int)igm_floor((float)w * (nx + 1) / 2), w - 1);
+        const int y = std::min((int)igm_floor((float)h * (1 - ny) / 2), h - 1);
+        return y * w + x;
+    }
+
+    // on_shadow (lighttracer.art:75-113)
+    ShadowRayOut on_shadow(const CameraSetup& cam, const Ray& ray, const SurfaceElement& surf, const PTRayPayload& pt, const Bsdf& bsdf, float& nx, float& ny) const
+    {
+        ShadowRayOut out;
+        out.valid = false;
+        if (bsdf.is_all_delta())
+            return out;
+        if (pt.depth + 1 > max_path_len)
+            return out;
+        Vec3 cam_dir;
+        if (!sample_pixel(cam, surf.point, cam_dir, nx, ny))
+            return out;
+        const Vec3 in_dir  = vec3_normalize(cam_dir);
+        const Vec3 out_dir = vec3_neg(ray.dir);
+        const float cos_o  = vec3_dot(out_dir, surf.local.col[2]);
+        const float cos_i  = vec3_dot(in_dir, surf.local.col[2]);
+        if (!(cos_o * cos_i > flt_eps))
+            return out;
+        const float d2     = vec3_len2(cam_dir);
+        const float factor = safe_div(cos_i, cos_o * d2);
+        // camera_sample.weight = make_gray_color(image_area) with image_area = 1 (perspective.art:36,47-51)
+        out.color = handle_color(color_mulf(color_mul(Color{ 1, 1, 1 }, color_mul(pt.contrib, bsdf.eval(out_dir, in_dir))), factor));
+        out.ray   = make_ray(surf.point, cam_dir, offset, 1 - offset, IG_RAY_FLAG_SHADOW);
+        out.valid = true;
+        return out;
+    }
+
+    // on_bounce (lighttracer.art:123-163): the path tracer's with adjoint = true (the Bsdf carries the flag)
+    bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, Ray& new_ray) const
+    {
+        if (pt.depth + 1 > max_path_len)
+            return false;
+        const Vec3 out_dir = vec3_neg(ray.dir);
+        BsdfSample ms;
+        if (!bsdf.sample(rnd, out_dir, ms))
+            return false;
+        if (ms.pdf <= flt_eps)
+            return false;
+        const Color contrib = color_mul(pt.contrib, ms.color);
+        const float rr_prob = (pt.depth + 1 > min_path_len) ? russian_roulette_pbrt(color_mulf(contrib, pt.eta * pt.eta), 0.95f) : 1.0f;
+        if (rnd.next_f32() >= rr_prob)
+            return false;
+        pt.contrib = color_mulf(contrib, 1 / rr_prob);
         pt.depth   = pt.depth + 1;
         pt.eta     = pt.eta * ms.eta;
         new_ray    = make_ray(surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);

@@ -1,0 +1,116 @@
+"""The light tracer (src/artic/technique/lighttracer.art): loader, oracle, and — marked gpu — the HIP path against the oracle."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+from ignis_amd.tables import LoadedScene
+
+
+def _plane_scene(technique, fov=10.0, lights=None, bsdf=None):
+    return {"technique": technique,
+            "camera": {"type": "perspective", "fov": fov, "near_clip": 0.01, "far_clip": 100,
+                       "transform": [{"lookat": {"origin": [0, 0, 6], "target": [0, 0, 0], "up": [0, 1, 0]}}]},
+            "film": {"size": [64, 64]}, "bsdfs": [bsdf or {"type": "diffuse", "name": "m", "reflectance": [0.7, 0.6, 0.5]}],
+            "shapes": [{"type": "rectangle", "name": "quad", "width": 4, "height": 4}],
+            "entities": [{"name": "quad", "shape": "quad", "bsdf": "m"}],
+            "lights": lights or [{"type": "point", "name": "p", "position": [0.3, -0.2, 2], "intensity": [5, 5, 5]}]}
+
+
+def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
+    sc = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_light_depth": 7, "min_depth": 3, "clamp": 2.5})), SCENES, 64, 64)
+    t = sc.scene.technique
+    assert (t.type, t.max_depth, t.min_depth, t.clamp) == (4, 7, 3, 2.5)
+    assert LoadedScene.from_string(json.dumps(_plane_scene({"type": "lighttracer"})), SCENES, 64, 64).scene.technique.max_depth == 64
+    with pytest.raises(RuntimeError, match="emission sampling"):
+        LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "sun", "name": "s", "direction": [0, 0, -1]}])), SCENES, 64, 64)
+    bad = _plane_scene({"type": "lt"})
+    bad["camera"]["type"] = "fishlens"
+    with pytest.raises(RuntimeError, match="perspective camera"):
+        LoadedScene.from_string(json.dumps(bad), SCENES, 64, 64)
+
+
+@pytest.mark.parametrize("lights", [
+    [{"type": "point", "name": "p", "position": [0.3, -0.2, 2], "intensity": [5, 5, 5]}],
+    [{"type": "spot", "name": "s", "position": [0.2, 0.1, 3], "direction": [0, 0, -1], "cutoff": 40, "falloff": 30, "intensity": [8, 8, 8]}],
+    [{"type": "directional", "name": "d", "direction": [0.2, 0.1, -1], "irradiance": [2, 2, 2]}],
+    [{"type": "env", "name": "e", "radiance": [1, 1, 1]}],
+])
+def test_oracle_light_tracer_agrees_with_the_path_tracer_up_to_the_pixel_measure(lights):
+    """As written the camera connection weighs a vertex with image_area = 1 (camera/perspective.art:36,47-51) instead of the
+    pixel's importance 1 / (A cos^3), A = 4 sx sy the area of the image plane at distance 1: with a narrow field of view
+    (cos^3 > 0.988 at 10 degrees) a light-tracer image is the path tracer's direct lighting times A."""
+    import oracle
+    fov = 10.0
+    a = LoadedScene.from_string(json.dumps(_plane_scene({"type": "path", "max_depth": 2}, fov, lights)), SCENES, 64, 64)
+    b = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_depth": 2}, fov, lights)), SCENES, 64, 64)
+    pt = np.zeros((64, 64, 3), np.float32)
+    lt = np.zeros((64, 64, 3), np.float32)
+    n_lt = 64 if lights[0]["type"] in ("directional", "env", "point") else 16
+    for it in range(4):
+        oracle.render(a, 8, 64, 64, iteration=it, seed=2, fb=pt)
+    for it in range(n_lt):
+        oracle.render(b, 16, 64, 64, iteration=it, seed=2, fb=lt)
+    pt /= 4
+    lt /= n_lt
+    sx = math.tan(math.radians(fov) / 2)
+    area = 4 * sx * sx  # square film
+    c = slice(8, 56)
+    ratio = lt[c, c].mean() / (pt[c, c].mean() * area)
+    if lights[0]["type"] == "spot":
+        # make_spot_light.sample_emission (light/spot.art:41-47) divides the intensity by spot_area * pdf and the emitter multiplies
+        # by the sample's cosine, where sample_direct of the same light has neither: as written, a spot light's light-tracer image
+        # is 1 / spot_area = 1 / (pi tan^2(cutoff)) of its path-tracer image near the axis. Restated as written.
+        ratio *= math.pi * math.tan(math.radians(lights[0]["cutoff"])) ** 2
+    assert pt[c, c].mean() > 1e-3 and abs(ratio - 1) < 0.05, ratio
+
+
+def test_oracle_light_tracer_only_counts_connections_it_traces():
+    import oracle
+    sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", "cycles-lights-lt.json"), 64, 64)
+    fb, st = oracle.render(sc, 4, 64, 64, iteration=0, seed=1)
+    assert np.isfinite(fb).all() and fb.mean() > 0.01
+    assert st["camera_rays"] == 64 * 64 * 4 and 0 < st["unoccluded"] <= st["shadow_rays"] and st["bounce_rays"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cycles-lights", "diamond", "diamond-principled-bump"])
+def test_light_tracer_vs_oracle(gpu_device, case):
+    """The path set (counters) is the oracle's exactly; the pixel sums agree to the rounding of their summation order (the device adds
+    connections with float atomics)."""
+    import oracle
+    if case == "cycles-lights":
+        sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", "cycles-lights-lt.json"), 96, 96)
+        w, h = 96, 96
+    else:
+        s = json.load(open(os.path.join(SCENES, "diamond_scene_principled.json" if "principled" in case else "diamond_scene.json")))
+        s["technique"] = {"type": "lt", "max_depth": 8, "light_selector": "uniform"}
+        s["lights"] += [{"type": "env", "name": "sky", "radiance": [0.3, 0.3, 0.4]}, {"type": "directional", "name": "d", "direction": [0.3, -1, 0.2], "irradiance": [1, 1, 1]},
+                        {"type": "point", "name": "p", "position": [0, 1.2, 0], "intensity": [1, 1, 1]}]
+        if "bump" in case:
+            s["textures"] = [{"type": "image", "name": "bumps", "filename": "textures/bumpmap.png"}]
+            for b in s["bsdfs"]:
+                if b["name"] == "mat-GrayWall":
+                    b["name"] = "wall-inner"
+            s["bsdfs"].append({"type": "bumpmap", "name": "mat-GrayWall", "bsdf": "wall-inner", "map": "bumps", "strength": 0.5})
+        sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+        w, h = 96, 72
+    gpu_device.assign_scene(sc)
+    gpu_device.resize(w, h)
+    gpu_device.clear_framebuffer()
+    ref = np.zeros((h, w, 3), np.float32)
+    tot = {}
+    for it in range(2):
+        gpu_device.render(4, w, h, iteration=it, seed=17)
+        _, st = oracle.render(sc, 4, w, h, iteration=it, seed=17, fb=ref)
+        for k, v in st.items():
+            tot[k] = tot.get(k, 0) + v
+    fb = gpu_device.framebuffer()
+    gst = gpu_device.stats()
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded"):
+        assert gst[k] == tot[k], k
+    assert ref.mean() > 1e-3
+    assert np.linalg.norm(fb - ref) / np.linalg.norm(ref) < 1e-5
