@@ -86,7 +86,7 @@ def test_light_tracer_vs_oracle(gpu_device, case):
         sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", "cycles-lights-lt.json"), 96, 96)
         w, h = 96, 96
     else:
-        s = json.load(open(os.path.join(SCENES, "diamond_scene_principled.json" if "principled" in case else "diamond_scene.json")))
+        s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
         s["technique"] = {"type": "lt", "max_depth": 8, "light_selector": "uniform"}
         s["lights"] += [{"type": "env", "name": "sky", "radiance": [0.3, 0.3, 0.4]}, {"type": "directional", "name": "d", "direction": [0.3, -1, 0.2], "irradiance": [1, 1, 1]},
                         {"type": "point", "name": "p", "position": [0, 1.2, 0], "intensity": [1, 1, 1]}]
@@ -95,12 +95,19 @@ def test_light_tracer_vs_oracle(gpu_device, case):
             for b in s["bsdfs"]:
                 if b["name"] == "mat-GrayWall":
                     b["name"] = "wall-inner"
+                if b["name"] == "mat-Diamond":  # refracting principled BSDF: the 1 / eta^2 of light paths (principled.art:471)
+                    b.clear()
+                    b.update({"type": "principled", "name": "mat-Diamond", "base_color": [0.9, 0.95, 1.0], "roughness": 0.15, "specular_transmission": 0.9, "ior": 1.5})
+                if b["name"] == "mat-ColoredWall":  # rough dielectric: dielectric.art:181
+                    b.clear()
+                    b.update({"type": "roughdielectric", "name": "mat-ColoredWall", "roughness": 0.3, "int_ior": 1.4, "ext_ior": 1.0})
             s["bsdfs"].append({"type": "bumpmap", "name": "mat-GrayWall", "bsdf": "wall-inner", "map": "bumps", "strength": 0.5})
         sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
         w, h = 96, 72
     gpu_device.assign_scene(sc)
     gpu_device.resize(w, h)
     gpu_device.clear_framebuffer()
+    gpu_device.reset_stats()
     ref = np.zeros((h, w, 3), np.float32)
     tot = {}
     for it in range(2):
