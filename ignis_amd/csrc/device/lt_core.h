@@ -88,13 +88,19 @@ IG_DEV bool sample_emission(const DevScene& sc, const ig_light& L, Tea& rnd, Emi
         return true;
     }
     case IG_LIGHT_PLANE:
+    case IG_LIGHT_SPHERE:
     case IG_LIGHT_MESH_AREA: { // make_area_light.sample_emission (light/area.art:26-37)
         const float u0 = rnd.f32();
         const float u1 = rnd.f32();
         f3 point, normal;
         float area_pdf;
         Col radiance;
-        if (L.type == IG_LIGHT_PLANE) { // make_plane_area_emitter.sample (area.art:230-250)
+        if (L.type == IG_LIGHT_SPHERE) { // make_sphere_area_emitter.sample_emission (area.art:296-299)
+            const SphereEmitter se(sc, L);
+            se.surface(square_to_sphere(u0, u1), point, normal);
+            area_pdf = safe_div(1, se.area);
+            radiance = se.radiance;
+        } else if (L.type == IG_LIGHT_PLANE) { // make_plane_area_emitter.sample (area.art:230-250)
             const float* d = L.d;
             point    = (f3{ d[4], d[5], d[6] } * u0 + f3{ d[8], d[9], d[10] } * u1) + f3{ d[0], d[1], d[2] };
             normal   = f3{ d[3], d[7], d[11] };

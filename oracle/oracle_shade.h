@@ -3264,13 +3264,19 @@ static inline bool sample_emission(const igd_scene& sc, const ig_light& l, Rng& 
         return true;
     }
     case IG_LIGHT_PLANE:
+    case IG_LIGHT_SPHERE:
     case IG_LIGHT_MESH_AREA: { // make_area_light.sample_emission (light/area.art:26-37)
         const float u0 = rnd.next_f32();
         const float u1 = rnd.next_f32();
         Vec3 point, normal;
         float area_pdf;
         Color radiance;
-        if (l.type == IG_LIGHT_PLANE) { // make_plane_area_emitter.sample (area.art:230-250)
+        if (l.type == IG_LIGHT_SPHERE) { // make_sphere_area_emitter.sample_emission (area.art:296-299): local frame around the face normal
+            const SphereEmitter se(sc, l);
+            sphere_surface_for_normal(se.entity, se.sphere, equal_area_square_to_sphere(u0, u1), point, normal);
+            area_pdf = se.inv_area;
+            radiance = se.radiance;
+        } else if (l.type == IG_LIGHT_PLANE) { // make_plane_area_emitter.sample (area.art:230-250)
             const PlaneEmitter pe(l);
             point    = vec3_add(vec3_add(vec3_mulf(pe.x_axis, u0), vec3_mulf(pe.y_axis, u1)), pe.origin);
             normal   = pe.normal;

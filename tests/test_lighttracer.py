@@ -77,13 +77,19 @@ def test_oracle_light_tracer_only_counts_connections_it_traces():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cycles-lights", "diamond", "diamond-principled-bump"])
+@pytest.mark.parametrize("case", ["cycles-lights", "sphere-light", "diamond", "diamond-principled-bump"])
 def test_light_tracer_vs_oracle(gpu_device, case):
     """The path set (counters) is the oracle's exactly; the pixel sums agree to the rounding of their summation order (the device adds
     connections with float atomics)."""
     import oracle
     if case == "cycles-lights":
         sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", "cycles-lights-lt.json"), 96, 96)
+        w, h = 96, 96
+    elif case == "sphere-light":  # an icosphere mesh recognised as a sphere: make_sphere_area_emitter.sample_emission
+        s = json.load(open(os.path.join(SCENES, "evaluation", "sphere-light-ico.json")))
+        s["technique"] = {"type": "lt", "max_depth": 6}
+        sc = LoadedScene.from_string(json.dumps(s), os.path.join(SCENES, "evaluation"), 96, 96)
+        assert any(sc.scene.lights[i].type == 9 for i in range(sc.scene.light_count))
         w, h = 96, 96
     else:
         s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
