@@ -624,8 +624,13 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
     d->full_bsdfs |= simple_selector;
     if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH && s->technique.type != IG_TECHNIQUE_DEBUG
-        && s->technique.type != IG_TECHNIQUE_LIGHTTRACER)
+        && s->technique.type != IG_TECHNIQUE_LIGHTTRACER && s->technique.type != IG_TECHNIQUE_WIREFRAME)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
+    if (s->technique.type == IG_TECHNIQUE_WIREFRAME) {
+        if ((s->camera.type != IG_CAMERA_PERSPECTIVE && s->camera.type != IG_CAMERA_ORTHOGONAL) || s->sphere_node_count)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the wireframe technique is lowered for perspective / orthogonal cameras and triangle meshes" };
+        d->full_bsdfs = true;
+    }
     if (s->technique.type == IG_TECHNIQUE_LIGHTTRACER) {
         // Light::sample_emission and Camera::sample_pixel exist for these light types and the pinhole camera (lt_core.h)
         for (uint32_t i = 0; i < s->light_count; ++i) {
@@ -1058,7 +1063,19 @@ void render(igd_device* d, const igd_render_settings* rs)
             timed(0, st, [&] { launch_generate(ga, st); });
         }
 
-        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1) };
+        float wire_footprint = 0;
+        if (d->dscene.tech.type == IG_TECHNIQUE_WIREFRAME) {
+            // camera.differential: (right scale.x, up scale.y) (camera/perspective.art:59-64), (right, up) (orthogonal.art:38-43);
+            // right = normalize(dir x up); footprint_u = |dx x dy| with vec3_len = sqrt of the fma chain of vec3_dot
+            const ig_camera& c = d->camera;
+            const float r[3]   = { c.dir[1] * c.up[2] - c.dir[2] * c.up[1], c.dir[2] * c.up[0] - c.dir[0] * c.up[2], c.dir[0] * c.up[1] - c.dir[1] * c.up[0] };
+            const float rl     = 1 / std::sqrt(std::fma(r[0], r[0], std::fma(r[1], r[1], r[2] * r[2])));
+            const float kx = c.type == IG_CAMERA_ORTHOGONAL ? 1.0f : sx, ky = c.type == IG_CAMERA_ORTHOGONAL ? 1.0f : sy;
+            const float dx[3] = { (r[0] * rl) * kx, (r[1] * rl) * kx, (r[2] * rl) * kx }, dy[3] = { c.up[0] * ky, c.up[1] * ky, c.up[2] * ky };
+            const float cr[3] = { dx[1] * dy[2] - dx[2] * dy[1], dx[2] * dy[0] - dx[0] * dy[2], dx[0] * dy[1] - dx[1] * dy[0] };
+            wire_footprint    = std::sqrt(std::fma(cr[0], cr[0], std::fma(cr[1], cr[1], cr[2] * cr[2])));
+        }
+        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1), wire_footprint };
         uint32_t live          = n;
         bool run_tail          = false;
         // One bounce round on stream `on` over the given stream buffers: closest-hit traversal (K2) -> sort +
@@ -1153,7 +1170,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             if (known_live == 0)
                 break;
             // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
-            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && !d->dscene.expr_code) {
+            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && d->dscene.tech.type != IG_TECHNIQUE_WIREFRAME && !d->dscene.expr_code) {
                 live     = known_live;
                 run_tail = true;
                 break;

@@ -168,6 +168,7 @@ struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-
     int32_t iteration, frame, seed;
     int32_t row_offset, row_stride;
     int32_t rays_per_iteration; // local pixels * spi: ray ids of a multi-iteration call continue across iterations
+    float wire_footprint;       // IG_TECHNIQUE_WIREFRAME: |dx x dy| of camera.differential (technique/wireframe.art:25-26)
 };
 
 // the pinhole camera of the light tracer's connections (Camera::sample_pixel, camera/perspective.art:16-57)

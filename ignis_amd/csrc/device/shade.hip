@@ -626,7 +626,7 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipSt
 {
     if (args.scene.tech.type == IG_TECHNIQUE_LIGHTTRACER)
         hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
-    else if (args.scene.tech.type == IG_TECHNIQUE_DEBUG) // (no bounces: the tail kernels never see this technique)
+    else if (args.scene.tech.type == IG_TECHNIQUE_DEBUG || args.scene.tech.type == IG_TECHNIQUE_WIREFRAME) // (the tail kernels never see these techniques)
         hipLaunchKernelGGL((k_shade<true, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else if (args.scene.expr_code) // materials with shading expressions: the instantiation with the interpreter (no tail kernels either)
         hipLaunchKernelGGL((k_shade<true, false, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);

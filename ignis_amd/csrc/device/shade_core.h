@@ -73,6 +73,7 @@ struct Surf { // driver/surface_element.art
     f3 point, face_normal;
     f2 tex;
     m33 local;
+    float inv_area; // of the triangle (make_triangle, core/triangle.art:12-29); only the wireframe technique reads it
 };
 
 IG_DEV f3 stable_normal(f3 e1, f3 e2, f3 e3) // core/triangle.art:31-44
@@ -121,6 +122,7 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
         s.entering      = true;
         s.face_normal   = n;
         s.local         = orthonormal_basis(n);
+        s.inv_area      = 0;
         return s;
     }
     const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
@@ -149,6 +151,7 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     s.point       = org + dir * t;
     s.face_normal = s.entering ? fn : -fn;
     s.local       = orthonormal_basis(s.entering ? sn : -sn);
+    s.inv_area    = safe_div(1, nn / 2);
     return s;
 }
 
@@ -2319,8 +2322,8 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         // gpu_generate_rays (mapping_gpu.art:655-658): it can only miss, and it is dropped here
         if (in.dir.x == 0 && in.dir.y == 0 && in.dir.z == 0)
             return;
-        if (FULL && (tech.type == IG_TECHNIQUE_AO || tech.type == IG_TECHNIQUE_DEBUG))
-            return; // make_ao_renderer and make_debug_renderer have no on_miss
+        if (FULL && (tech.type == IG_TECHNIQUE_AO || tech.type == IG_TECHNIQUE_DEBUG || tech.type == IG_TECHNIQUE_WIREFRAME))
+            return; // make_ao_renderer, make_debug_renderer and make_wireframe_renderer have no on_miss
         // ---- miss: on_miss (technique/pathtracer.art:141-168) over infinite, non-delta lights
         Col sum{ 0, 0, 0 };
         for (uint32_t li = 0; li < sc.infinite_light_count; ++li) {
@@ -2381,6 +2384,29 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
     if constexpr (FULL && DEBUG_VIEWS) {
+        if (tech.type == IG_TECHNIQUE_WIREFRAME) {
+            // make_wireframe_renderer (technique/wireframe.art:21-73); the payload's distance travels in the inv_pdf slot.
+            // is_edge_hit (:24-31): clampf(0, 1, 1 - u - v) as written = min(1 - u - v, 1)
+            const float w      = clampf(0, 1, 1 - in.u - in.v);
+            const float edge_t = igm_min(in.u, igm_min(in.v, w));
+            const float cond   = 0.01f * ((in.t + in.inv_pdf) * fr.wire_footprint) * igm_sqrt(surf.inv_area);
+            if (edge_t <= cond) { // on_hit: color_lerp(white, black, t); no bounce
+                const float c    = (1 - edge_t) * 1.0f + edge_t * 0.0f;
+                out.has_radiance = true;
+                out.radiance     = Col{ c, c, c };
+            } else { // on_bounce: straight on
+                out.bounce    = true;
+                out.b_org     = surf.point;
+                out.b_dir     = in.dir;
+                out.b_tmin    = kRayOffset;
+                out.b_rnd     = in.rnd;
+                out.b_inv_pdf = in.inv_pdf + in.t;
+                out.b_contrib = in.contrib;
+                out.b_depth   = depth + 1;
+                out.b_eta     = in.eta;
+            }
+            return;
+        }
         // on_hit of make_debug_renderer (technique/debugtracer.art:3-140): one of 28 properties of the first hit; nothing else
         out.has_radiance = true;
         out.radiance     = debug_color<FULL>(sc, tech.debug_mode, in, surf, bsdf, mat, sc.entity_material[in.ent]);

@@ -1719,8 +1719,10 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
                     tech.debug_mode = i;
         } else if (type == "lt" || type == "lighttracer")
             tech.type = IG_TECHNIQUE_LIGHTTRACER; // LightTracerTechnique.cpp:10-17
+        else if (type == "wireframe")
+            tech.type = IG_TECHNIQUE_WIREFRAME; // WireframeTechnique.cpp: no parameters
         else if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao', 'debug' and 'lt')");
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao', 'debug', 'lt' and 'wireframe')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
         if (tech.type == IG_TECHNIQUE_LIGHTTRACER) { // "max_depth" else "max_light_depth", "min_depth" else "min_light_depth"
@@ -2503,6 +2505,8 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     }
     t.camera             = cam;
     t.technique          = tech;
+    if (tech.type == IG_TECHNIQUE_WIREFRAME && cam.type != IG_CAMERA_PERSPECTIVE && cam.type != IG_CAMERA_ORTHOGONAL)
+        fail("Technique 'wireframe': the camera differential of this camera type is not supported by the HIP backend");
     if (tech.type == IG_TECHNIQUE_LIGHTTRACER) {
         // the light tracer needs Light::sample_emission and Camera::sample_pixel: lowered for these light types and the pinhole camera
         for (const ig_light& l : sc->lights)

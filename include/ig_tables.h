@@ -297,6 +297,10 @@ enum ig_technique_type {
      * max_depth, min_depth, clamp, light_selector as for the path tracer. Perspective cameras without depth of field; point, spot,
      * plane / mesh / sphere area, directional and constant environment lights. */
     IG_TECHNIQUE_LIGHTTRACER = 4,
+    /* make_wireframe_renderer (src/artic/technique/wireframe.art:21-73, WireframeTechnique.cpp): a hit closer to a triangle edge than
+     * the pixel's footprint (camera.differential) shows white fading to black, any other hit lets the ray continue straight on; no
+     * parameters. Perspective and orthogonal cameras, triangle meshes. */
+    IG_TECHNIQUE_WIREFRAME = 5,
 };
 
 /* One record per medium, in the order entities acquire them (LoaderMedium::acquire, src/runtime/loader/LoaderMedium.cpp:113-121;

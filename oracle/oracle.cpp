@@ -302,7 +302,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                 write_ray(primary, cur, ray);
                 primary.id[cur]  = valid ? (y * W + x) * spi + sample : -1;
                 primary.rnd[cur] = rnd.counter;
-                write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1, -1 }); // init_pt_raypayload (pathtracer.art:33-38), init_vpt_raypayload (volpathtracer.art:27-33)
+                write_payload(primary, cur, PTRayPayload{ 0, Color{ 1, 1, 1 }, 1, 1, -1 }); // (init_wireframe_raypayload: depth 1, distance 0 in the inv_pdf slot) // init_pt_raypayload (pathtracer.art:33-38), init_vpt_raypayload (volpathtracer.art:27-33)
             }
             current_size += n;
             id += n;
@@ -391,7 +391,7 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
                     }
 
                     Ray new_ray;
-                    if (pt_tech.on_bounce(ray, surf, rnd, payload, bsdf, mat, new_ray)) {
+                    if (pt_tech.wireframe ? pt_tech.wire_bounce(ray, hit, surf, payload, new_ray) : pt_tech.on_bounce(ray, surf, rnd, payload, bsdf, mat, new_ray)) {
                         write_ray(primary, i, new_ray);
                         primary.rnd[i] = rnd.counter;
                         write_payload(primary, i, payload);
@@ -540,7 +540,13 @@ int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* f
         }
         return 0;
     }
-    const PathTracer pt(*sc);
+    PathTracer pt(*sc);
+    if (pt.wireframe) {
+        // camera.differential (camera/perspective.art:59-64, orthogonal.art:38-43) -> footprint_u = |dx x dy| (wireframe.art:25-26)
+        const bool ortho = sc->camera.type == IG_CAMERA_ORTHOGONAL;
+        const Vec3 dx = vec3_mulf(cam.view.col[0], ortho ? 1.0f : sx), dy = vec3_mulf(cam.view.col[1], ortho ? 1.0f : sy);
+        pt.wire_footprint = vec3_len(vec3_cross(dx, dy));
+    }
 
     const int tile_size = 16; // ShaderUtils.cpp:37
     const int x0 = cfg->xmax > 0 ? cfg->xmin : 0, y0 = cfg->ymax > 0 ? cfg->ymin : 0;

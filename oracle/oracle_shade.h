@@ -2704,9 +2704,23 @@ struct PathTracer {
         , ambient_occlusion(s.technique.type == IG_TECHNIQUE_AO)
         , volumetric(s.technique.type == IG_TECHNIQUE_VOLPATH)
         , debug(s.technique.type == IG_TECHNIQUE_DEBUG)
+        , wireframe(s.technique.type == IG_TECHNIQUE_WIREFRAME)
     {
     }
     bool debug; // make_debug_renderer: only on_hit
+    // make_wireframe_renderer (technique/wireframe.art:21-73): on_hit and on_bounce; footprint_u = |dx x dy| of camera.differential
+    // (perspective: (right scale.x, up scale.y), orthogonal: (right, up)), set by the caller that knows the film's scale
+    bool wireframe;
+    float wire_footprint = 0;
+    // is_edge_hit (wireframe.art:24-31); the payload's distance travels in PTRayPayload.inv_pdf
+    bool is_edge_hit(const Hit& hit, const SurfaceElement& surf, float add_distance, float& edge_t) const
+    {
+        const float w  = clampf(0, 1, 1 - hit.u - hit.v); // clampf(v = 0, l = 1, u = ...) as written: min(1 - u - v, 1)
+        edge_t         = igm_min(hit.u, igm_min(hit.v, w)); // vec3_min_value
+        const float fp = (hit.distance + add_distance) * wire_footprint;
+        const float cond = 0.01f * fp * igm_sqrt(surf.inv_area);
+        return edge_t <= cond;
+    }
     // make_volume_path_renderer (technique/volpathtracer.art:37-260): the same callbacks with a current medium
     bool volumetric;
     // get_medium (volpathtracer.art:46-49) over the media table of LoaderMedium::generate (LoaderMedium.cpp:89-111): unknown ids are vacuum
@@ -2805,7 +2819,7 @@ struct PathTracer {
     // on_shadow (pathtracer.art:52-117)
     ShadowRayOut on_shadow(const Ray& ray, const SurfaceElement& surf, Rng& rnd, const PTRayPayload& pt, const Bsdf& bsdf) const
     {
-        if (debug) {
+        if (debug || wireframe) {
             ShadowRayOut none;
             none.valid = false;
             return none;
@@ -3037,6 +3051,14 @@ struct PathTracer {
     {
         if (ambient_occlusion || debug)
             return false;
+        if (wireframe) { // wireframe.art:33-43: color_lerp(white, black, t)
+            float t;
+            if (!is_edge_hit(hit, surf, pt.inv_pdf, t))
+                return false;
+            const float c = (1 - t) * 1.0f + t * 0.0f;
+            out           = Color{ c, c, c };
+            return true;
+        }
         if (mat.light_id >= 0 && surf.is_entering) {
             const float dot = -vec3_dot(ray.dir, surf.local.col[2]);
             if (dot > flt_eps) {
@@ -3074,7 +3096,7 @@ struct PathTracer {
     // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
     bool on_miss(const Ray& ray, const PTRayPayload& pt, Color& out) const
     {
-        if (ambient_occlusion || debug)
+        if (ambient_occlusion || debug || wireframe)
             return false;
         int inflights = 0;
         Color color   = Color{ 0, 0, 0 };
@@ -3129,6 +3151,18 @@ struct PathTracer {
     }
 
     // on_bounce (pathtracer.art:170-210)
+    // on_bounce of make_wireframe_renderer (wireframe.art:45-63): past a hit that is not on an edge the ray goes straight on
+    bool wire_bounce(const Ray& ray, const Hit& hit, const SurfaceElement& surf, PTRayPayload& pt, Ray& new_ray) const
+    {
+        float t;
+        if (is_edge_hit(hit, surf, pt.inv_pdf, t))
+            return false;
+        pt.depth   = pt.depth + 1;
+        pt.inv_pdf = pt.inv_pdf + hit.distance;
+        new_ray    = make_ray(surf.point, ray.dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+        return true;
+    }
+
     bool on_bounce(const Ray& ray, const SurfaceElement& surf, Rng& rnd, PTRayPayload& pt, const Bsdf& bsdf, const ig_material& mat, Ray& new_ray) const
     {
         if (ambient_occlusion || debug)

@@ -127,3 +127,45 @@ def test_light_tracer_vs_oracle(gpu_device, case):
         assert gst[k] == tot[k], k
     assert ref.mean() > 1e-3
     assert np.linalg.norm(fb - ref) / np.linalg.norm(ref) < 1e-5
+
+
+# ---- the wireframe technique (src/artic/technique/wireframe.art)
+
+def test_oracle_wireframe_shows_triangle_edges_and_nothing_else():
+    import oracle
+    s = _plane_scene({"type": "wireframe"}, fov=40.0)
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    assert sc.scene.technique.type == 5
+    fb, st = oracle.render(sc, 8, 64, 64, iteration=0, seed=3)
+    g = fb.mean(axis=2)
+    # the quad is two triangles: its diagonal and its outline are lit, the faces stay black (the ray goes on and misses)
+    assert g.max() > 0.5 and (g < 1e-3).mean() > 0.6 and (g > 0.05).mean() > 0.02
+    assert g[32, 32] > 0.05 or g[31, 32] > 0.05 or g[32, 31] > 0.05  # the diagonal passes the centre
+    assert st["shadow_rays"] == 0 and st["bounce_rays"] > 0
+    bad = _plane_scene({"type": "wireframe"})
+    bad["camera"]["type"] = "fishlens"
+    with pytest.raises(RuntimeError, match="camera differential"):
+        LoadedScene.from_string(json.dumps(bad), SCENES, 64, 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("camera", ["perspective", "orthogonal"])
+def test_wireframe_vs_oracle(gpu_device, camera):
+    import oracle
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["technique"] = {"type": "wireframe"}
+    if camera == "orthogonal":
+        s["camera"]["type"] = "orthogonal"
+        s["camera"]["scale"] = 1.2
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 128, 96)
+    gpu_device.assign_scene(sc)
+    gpu_device.resize(128, 96)
+    gpu_device.clear_framebuffer()
+    gpu_device.reset_stats()
+    gpu_device.render(4, 128, 96, iteration=0, seed=5)
+    fb = gpu_device.framebuffer()
+    ref, st = oracle.render(sc, 4, 128, 96, iteration=0, seed=5)
+    gst = gpu_device.stats()
+    for k in ("camera_rays", "bounce_rays", "shadow_rays"):
+        assert gst[k] == st[k], k
+    assert ref.max() > 0.5 and np.linalg.norm(fb - ref) / np.linalg.norm(ref) < 1e-6  # (a pixel's samples are summed in another order)
