@@ -635,8 +635,8 @@ void assignScene(igd_device* d, const igd_scene* s)
         // Light::sample_emission and Camera::sample_pixel exist for these light types and the pinhole camera (lt_core.h)
         for (uint32_t i = 0; i < s->light_count; ++i) {
             const int lt = s->lights[i].type;
-            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_SPHERE && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
-                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer samples emission of point, spot, area, directional and constant environment lights only" };
+            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_SPHERE && lt != IG_LIGHT_SUN && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer samples emission of point, spot, area, directional, sun and constant environment lights only" };
         }
         if (s->camera.type != IG_CAMERA_PERSPECTIVE || s->camera.aperture_radius > 1.1920928955e-07f)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer connects to the perspective camera without depth of field only" };

@@ -142,6 +142,25 @@ IG_DEV bool sample_emission(const DevScene& sc, const ig_light& L, Tea& rnd, Emi
         e.cos       = 1;
         return true;
     }
+    case IG_LIGHT_SUN: { // make_sun_light.sample_emission (light/sun.art:24-29)
+        const f3 sun_dir  = f3{ L.d[0], L.d[1], L.d[2] };
+        const float cos_a = L.d[3];
+        const float u  = rnd.f32();
+        const float v  = rnd.f32();
+        const float c1 = 1 - cos_a;
+        const f2 p     = concentric_disk(u, v);
+        const float n2 = p.x * p.x + p.y * p.y;
+        const float z  = cos_a + c1 * (1 - n2);
+        const float k  = safe_sqrt(c1 * (2 - c1 * n2));
+        const f3 ndir  = mul33(orthonormal_basis(-sun_dir), f3{ p.x * k, p.y * k, z });
+        const float inv_pdf = 2 * kPi * (1 - cos_a);
+        float pos_pdf;
+        e.pos       = env_sample_pos(sc, rnd, -ndir, pos_pdf);
+        e.dir       = ndir;
+        e.intensity = Col{ L.d[4], L.d[5], L.d[6] } * safe_div(inv_pdf, pos_pdf);
+        e.cos       = z;
+        return true;
+    }
     case IG_LIGHT_ENV: { // make_environment_light_function_spherical.sample_emission (light/env.art:87-93), constant colour
         const float u   = rnd.f32();
         const float v   = rnd.f32();

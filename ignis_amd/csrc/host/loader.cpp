@@ -2510,9 +2510,9 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     if (tech.type == IG_TECHNIQUE_LIGHTTRACER) {
         // the light tracer needs Light::sample_emission and Camera::sample_pixel: lowered for these light types and the pinhole camera
         for (const ig_light& l : sc->lights)
-            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_SPHERE && l.type != IG_LIGHT_DIRECTIONAL
+            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_SPHERE && l.type != IG_LIGHT_SUN && l.type != IG_LIGHT_DIRECTIONAL
                 && l.type != IG_LIGHT_ENV)
-                fail("Technique 'lt': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional and constant environment lights are)");
+                fail("Technique 'lt': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional, sun and constant environment lights are)");
         if (cam.type != IG_CAMERA_PERSPECTIVE || cam.aperture_radius > 0)
             fail("Technique 'lt': only the perspective camera without depth of field is supported by the HIP backend");
     }

@@ -295,7 +295,7 @@ enum ig_technique_type {
      * (pixel, sample) index starts one path on a light chosen by the light selector; each non-delta vertex is connected to the
      * pinhole camera and, unoccluded, splatted into the pixel it projects to; bounces sample the BSDF with adjoint = true.
      * max_depth, min_depth, clamp, light_selector as for the path tracer. Perspective cameras without depth of field; point, spot,
-     * plane / mesh / sphere area, directional and constant environment lights. */
+     * plane / mesh / sphere area, directional, sun and constant environment lights. */
     IG_TECHNIQUE_LIGHTTRACER = 4,
     /* make_wireframe_renderer (src/artic/technique/wireframe.art:21-73, WireframeTechnique.cpp): a hit closer to a triangle edge than
      * the pixel's footprint (camera.differential) shows white fading to black, any other hit lets the ray continue straight on; no

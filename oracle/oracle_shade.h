@@ -3344,6 +3344,24 @@ static inline bool sample_emission(const igd_scene& sc, const ig_light& l, Rng& 
         e = EmissionSample{ pos, dir, color_mulf(Color{ l.d[4], l.d[5], l.d[6] }, safe_div(1, pos_pdf)), pos_pdf, 1, 1 };
         return true;
     }
+    case IG_LIGHT_SUN: { // make_sun_light.sample_emission (light/sun.art:24-29)
+        const SunLight sun(l);
+        const float u  = rnd.next_f32();
+        const float v  = rnd.next_f32();
+        const float c1 = 1 - sun.cos_angle; // sample_uniform_cone
+        float px, py;
+        square_to_concentric_disk(u, v, px, py);
+        const float n2 = px * px + py * py;
+        const float z  = sun.cos_angle + c1 * (1 - n2);
+        const float k  = safe_sqrt(c1 * (2 - c1 * n2));
+        const Vec3 ndir     = mat3x3_mul(make_orthonormal_mat3x3(vec3_neg(sun.dir)), make_vec3(px * k, py * k, z));
+        const float inv_pdf = 2 * flt_pi * (1 - sun.cos_angle);
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, vec3_neg(ndir), pos, pos_pdf);
+        e = EmissionSample{ pos, ndir, color_mulf(sun.radiance, safe_div(inv_pdf, pos_pdf)), pos_pdf, sun.dir_pdf(), z };
+        return true;
+    }
     case IG_LIGHT_ENV: { // make_environment_light_function_spherical.sample_emission (light/env.art:87-93), constant colour, identity transform
         const float u   = rnd.next_f32();
         const float v   = rnd.next_f32();

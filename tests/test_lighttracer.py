@@ -26,7 +26,7 @@ def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
     assert (t.type, t.max_depth, t.min_depth, t.clamp) == (4, 7, 3, 2.5)
     assert LoadedScene.from_string(json.dumps(_plane_scene({"type": "lighttracer"})), SCENES, 64, 64).scene.technique.max_depth == 64
     with pytest.raises(RuntimeError, match="emission sampling"):
-        LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "sun", "name": "s", "direction": [0, 0, -1]}])), SCENES, 64, 64)
+        LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "cie_cloudy", "name": "s"}])), SCENES, 64, 64)
     bad = _plane_scene({"type": "lt"})
     bad["camera"]["type"] = "fishlens"
     with pytest.raises(RuntimeError, match="perspective camera"):
@@ -38,6 +38,7 @@ def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
     [{"type": "spot", "name": "s", "position": [0.2, 0.1, 3], "direction": [0, 0, -1], "cutoff": 40, "falloff": 30, "intensity": [8, 8, 8]}],
     [{"type": "directional", "name": "d", "direction": [0.2, 0.1, -1], "irradiance": [2, 2, 2]}],
     [{"type": "env", "name": "e", "radiance": [1, 1, 1]}],
+    [{"type": "sun", "name": "s", "direction": [-0.1, -0.2, 1], "irradiance": [2, 2, 2], "angle": 4}],
 ])
 def test_oracle_light_tracer_agrees_with_the_path_tracer_up_to_the_pixel_measure(lights):
     """As written the camera connection weighs a vertex with image_area = 1 (camera/perspective.art:36,47-51) instead of the
@@ -49,7 +50,7 @@ def test_oracle_light_tracer_agrees_with_the_path_tracer_up_to_the_pixel_measure
     b = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_depth": 2}, fov, lights)), SCENES, 64, 64)
     pt = np.zeros((64, 64, 3), np.float32)
     lt = np.zeros((64, 64, 3), np.float32)
-    n_lt = 64 if lights[0]["type"] in ("directional", "env", "point") else 16
+    n_lt = 64 if lights[0]["type"] in ("directional", "env", "point", "sun") else 16
     for it in range(4):
         oracle.render(a, 8, 64, 64, iteration=it, seed=2, fb=pt)
     for it in range(n_lt):
@@ -95,6 +96,7 @@ def test_light_tracer_vs_oracle(gpu_device, case):
         s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
         s["technique"] = {"type": "lt", "max_depth": 8, "light_selector": "uniform"}
         s["lights"] += [{"type": "env", "name": "sky", "radiance": [0.3, 0.3, 0.4]}, {"type": "directional", "name": "d", "direction": [0.3, -1, 0.2], "irradiance": [1, 1, 1]},
+                        {"type": "sun", "name": "sun", "direction": [0.2, 1, -0.1], "irradiance": [1, 1, 1], "angle": 3},
                         {"type": "point", "name": "p", "position": [0, 1.2, 0], "intensity": [1, 1, 1]}]
         if "bump" in case:
             s["textures"] = [{"type": "image", "name": "bumps", "filename": "textures/bumpmap.png"}]
