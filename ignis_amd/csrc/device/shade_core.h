@@ -1154,6 +1154,117 @@ struct Plastic {
     }
 };
 
+// ---- Radiance's BRTDfunc with constant arguments and the Roos glazing model on top of it (bsdf/rad.art:7-56): make_add_bsdf
+// (bsdf/mix.art:68) = make_join_bsdf with colour addition, two levels deep over four leaf BSDFs
+struct RadLeaf {
+    int kind; // 0 make_lambertian_bsdf (diffuse.art:2-12), 1 make_lambertian_transmission_bsdf (:14-24), 2 make_mirror_bsdf (conductor.art:2-10),
+              // 3 make_perfect_refraction_bsdf (dielectric.art:3-11)
+    Col c;
+    IG_DEV static float neg_cos(f3 a, f3 b)
+    {
+        const float cs = dot3(a, b);
+        return cs <= 0 ? cs : 0.0f; // core/common.art:265-268
+    }
+    IG_DEV Col eval(const m33& local, f3 in_dir) const
+    {
+        if (kind == 0)
+            return c * (pos_cos(in_dir, local.c2) * kInvPi);
+        if (kind == 1)
+            return c * (-neg_cos(in_dir, local.c2) * kInvPi);
+        return Col{ 0, 0, 0 };
+    }
+    IG_DEV float pdf(const m33& local, f3 in_dir) const
+    {
+        if (kind == 0)
+            return pos_cos(in_dir, local.c2) / kPi; // cosine_hemisphere_pdf
+        if (kind == 1)
+            return -neg_cos(in_dir, local.c2) / kPi;
+        return 0;
+    }
+    IG_DEV void sample(const m33& local, Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, bool& sdelta) const
+    {
+        color = c;
+        if (kind <= 1) {
+            const float u   = rnd.f32();
+            const float v   = rnd.f32();
+            const float cs  = safe_sqrt(v); // sample_cosine_hemisphere (core/sampling.art:65-73)
+            const float sn  = safe_sqrt(1 - v);
+            const float phi = 2 * kPi * u;
+            const f3 gdir   = mul33(local, f3{ sn * igm_cos(phi), sn * igm_sin(phi), cs });
+            in_dir  = kind == 0 ? gdir : -gdir;
+            pdf_out = cs / kPi;
+            sdelta  = false;
+        } else {
+            in_dir  = kind == 2 ? local.c2 * (2 * dot3(local.c2, out_dir)) - out_dir : -out_dir;
+            pdf_out = 1;
+            sdelta  = true;
+        }
+    }
+};
+template <class A, class B>
+struct RadAdd {
+    A a;
+    B b;
+    float k;
+    IG_DEV Col eval(const m33& l, f3 in_dir) const { return a.eval(l, in_dir) + b.eval(l, in_dir); }
+    IG_DEV float pdf(const m33& l, f3 in_dir) const
+    {
+        if (k <= 0)
+            return a.pdf(l, in_dir);
+        if (k >= 1)
+            return b.pdf(l, in_dir);
+        return lerpf(a.pdf(l, in_dir), b.pdf(l, in_dir), k);
+    }
+    template <class F, class S>
+    IG_DEV static void sample_mat(const F& first, const S& second, float t, const m33& l, Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, bool& sdelta)
+    {
+        first.sample(l, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+        const float p = lerpf(pdf_out, second.pdf(l, in_dir), t);
+        const Col c   = color * pdf_out + second.eval(l, in_dir);
+        pdf_out       = p;
+        color         = c * safe_div(1, p);
+    }
+    IG_DEV void sample(const m33& l, Tea& rnd, f3 out_dir, f3& in_dir, float& pdf_out, Col& color, bool& sdelta) const
+    {
+        if (rnd.f32() < 1 - k)
+            sample_mat(a, b, k, l, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+        else
+            sample_mat(b, a, 1 - k, l, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+    }
+};
+using RadBrtd = RadAdd<RadAdd<RadLeaf, RadLeaf>, RadAdd<RadLeaf, RadLeaf>>;
+IG_DEV float col_avg(Col c) { return (c.r + c.g + c.b) / 3; } // color_average (core/color.art:28)
+IG_DEV RadBrtd make_rad_brtd(bool entering, Col refl_spec, Col trns_spec, Col refl_f, Col refl_b, Col trns_diff)
+{
+    const Col refl_diff = entering ? refl_f : refl_b;
+    RadBrtd r;
+    r.b.a = RadLeaf{ 2, refl_spec };
+    r.b.b = RadLeaf{ 3, trns_spec };
+    r.b.k = safe_div(col_avg(trns_spec), col_avg(refl_spec) + col_avg(trns_spec));
+    r.a.a = RadLeaf{ 0, refl_diff };
+    r.a.b = RadLeaf{ 1, trns_diff };
+    r.a.k = safe_div(col_avg(trns_diff), col_avg(refl_diff) + col_avg(trns_diff));
+    const float sum_spec = col_avg(refl_spec + trns_spec);
+    const float sum_diff = col_avg(refl_diff + trns_diff);
+    r.k = safe_div(sum_spec, sum_diff + sum_spec);
+    return r;
+}
+// make_rad_roos_bsdf (rad.art:36-56): specular reflection (x) and transmission (y) from the cosine between ray and shading normal
+IG_DEV f2 rad_roos_factors(const ig_material& m, float cosN)
+{
+    const float trns_w = m.p[0], trns_p = m.p[1], trns_q = m.p[2], refl_w = m.p[3], refl_p = m.p[4], refl_q = m.p[5];
+    const float a = 8, beta = 2;
+    const float bq    = 0.25f / trns_q;
+    const float cq    = 1 - a - bq;
+    const float alpha = 5.2f + 0.7f * trns_q;
+    const float gt    = (5.26f + 0.06f * trns_p) + (0.73f + 0.04f * trns_p) * trns_q;
+    const float gr    = (5.26f + 0.06f * refl_p) + (0.73f + 0.04f * refl_p) * refl_q;
+    const float z     = igm_acos(igm_abs(clampf(cosN, -1, 1))) * 0.636619772368f;
+    const float tau   = trns_w * (1 - a * igm_pow(z, alpha) - bq * igm_pow(z, beta) - cq * igm_pow(z, gt));
+    const float rf    = refl_w + (1 - refl_w) * igm_pow(z, gr);
+    return f2{ rf, tau };
+}
+
 // FULL = false leaves the principled BSDF out of the kernel (scenes without one run the lean variant)
 // TOP = false: the context of a BSDF inside a blend (same surface, no further nesting)
 struct BlendInner {
@@ -1202,6 +1313,12 @@ struct BsdfCtx {
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | (EXPR ? IG_MAT_EXPR_NORMAL : 0)))
             surf.local = bumped_frame<EXPR>(sc, m, s, ray_dir);
         kd = material_color<EXPR>(sc, m, surf, -ray_dir); // an expression sees the surface the BSDF is built on (bsdf_inner(ctx.{surf = surf2}))
+        if constexpr (FULL) {
+            if (m.bsdf_type == IG_BSDF_RAD_ROOS) { // cosN = -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28); kd carries (rf, tau)
+                const f2 ft = rad_roos_factors(m, -dot3(ray_dir, surf.local.c2));
+                kd          = Col{ ft.x, ft.y, 0 };
+            }
+        }
         if constexpr (FULL && TOP) {
             blend.sc = &sc;
             ds_flip  = (m.flags & IG_MAT_DOUBLESIDED) && !s.entering;
@@ -1231,6 +1348,18 @@ struct BsdfCtx {
         return mat->bsdf_type == IG_BSDF_DIELECTRIC || (FULL && mat->bsdf_type == IG_BSDF_TRANSPARENT) || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
+    IG_DEV bool is_rad() const { return FULL && (mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS); }
+    // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record
+    IG_DEV RadBrtd rad() const
+    {
+        const Col td{ mat->q[0], mat->q[1], mat->q[2] };
+        const Col rf{ mat->p[6], mat->p[7], mat->p[8] }, rb{ mat->p[9], mat->p[10], mat->p[11] };
+        if (mat->bsdf_type == IG_BSDF_RAD_ROOS) {
+            const Col black{ 0, 0, 0 };
+            return make_rad_brtd(surf.entering, Col{ kd.r, kd.r, kd.r }, Col{ kd.g, kd.g, kd.g }, rf + black, rb + black, td);
+        }
+        return make_rad_brtd(surf.entering, Col{ mat->p[0], mat->p[1], mat->p[2] }, Col{ mat->p[3], mat->p[4], mat->p[5] }, rf, rb, td);
+    }
 
     // make_orennayar_bsdf.eval (bsdf/diffuse.art:28-39): p[3] alpha
     IG_DEV Col orennayar_eval(f3 in_dir, f3 out_dir) const
@@ -1300,6 +1429,10 @@ struct BsdfCtx {
         if constexpr (FULL && TOP)
             out_dir = ds_flip ? -out_dir : out_dir;
         const f3 N = surf.local.c2;
+        if (is_rad()) { // make_join_bsdf.albedo (mix.art:56-61): colour lerps of the leaves' colours
+            const RadBrtd r = rad();
+            return lerp_col(lerp_col(r.a.a.c, r.a.b.c, r.a.k), lerp_col(r.b.a.c, r.b.b.c, r.b.k), r.k);
+        }
         switch (mat->bsdf_type) {
         case IG_BSDF_PHONG:       // ks (bsdf/phong.art:20)
         case IG_BSDF_TRANSPARENT: // make_perfect_refraction_bsdf: kt (bsdf/dielectric.art:9)
@@ -1344,6 +1477,8 @@ struct BsdfCtx {
                 return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         }
         if constexpr (FULL) {
+            if (is_rad())
+                return rad().eval(surf.local, in_dir);
             if (mat->bsdf_type == IG_BSDF_PHONG)
                 return phong_eval(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
@@ -1390,6 +1525,8 @@ struct BsdfCtx {
             }
         }
         if constexpr (FULL) {
+            if (is_rad())
+                return rad().pdf(surf.local, in_dir);
             if (mat->bsdf_type == IG_BSDF_PHONG)
                 return phong_pdf(in_dir, out_dir);
             if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
@@ -1444,6 +1581,11 @@ struct BsdfCtx {
             }
         }
         if constexpr (FULL) {
+            if (is_rad()) {
+                rad().sample(surf.local, rnd, out_dir, in_dir, pdf_out, color, sdelta);
+                s_eta = 1;
+                return true;
+            }
             if (mat->bsdf_type == IG_BSDF_PHONG) {
                 phong_sample(rnd, out_dir, in_dir, pdf_out, color);
                 s_eta  = 1;

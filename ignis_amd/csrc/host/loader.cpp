@@ -1515,6 +1515,31 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.flags |= type == "bumpmap" ? IG_MAT_BUMP : IG_MAT_NORMALMAP;
         m.tex_id = bank.get(map->str, name);
         m.p[11]  = getConstNumber(*bsdf, "strength", 1.0f, name);
+    } else if (type == "rad_brtdfunc") {
+        // RadBRTDFuncBSDF.cpp:15-20: six colours, constants here
+        m.bsdf_type    = IG_BSDF_RAD_BRTD;
+        const V3 rs    = getColor(*bsdf, "reflection_specular", V3(1, 1, 1), name);
+        const V3 ts    = getColor(*bsdf, "transmission_specular", V3(0, 0, 0), name);
+        const V3 dd    = getColor(*bsdf, "direct_diffuse", V3(0, 0, 0), name);
+        const V3 rf    = getColor(*bsdf, "reflection_front_diffuse", V3(0, 0, 0), name);
+        const V3 rb    = getColor(*bsdf, "reflection_back_diffuse", V3(0, 0, 0), name);
+        const V3 td    = getColor(*bsdf, "transmission_diffuse", V3(0, 0, 0), name);
+        const V3 rfd = rf + dd, rbd = rb + dd; // color_add(select(is_entering, front, back), dir_diff) (bsdf/rad.art:13)
+        const float v[15] = { rs.x, rs.y, rs.z, ts.x, ts.y, ts.z, rfd.x, rfd.y, rfd.z, rbd.x, rbd.y, rbd.z, td.x, td.y, td.z };
+        std::memcpy(m.p, v, 12 * sizeof(float));
+        std::memcpy(m.q, v + 12, 3 * sizeof(float));
+    } else if (type == "rad_roos") {
+        // RadRoosBSDF.cpp:15-38. The C++ side hands (refl_w, refl_p, refl_q, trns_w, trns_p, trns_q) to make_rad_roos_bsdf(surf, cosN,
+        // trns_w, trns_p, trns_q, refl_w, refl_p, refl_q, ...) (bsdf/rad.art:36-39): the "refl_*" properties drive the transmission
+        // and vice versa. Restated as written: p[0..2] is what the Artic function calls trns_*, p[3..5] what it calls refl_*.
+        m.bsdf_type = IG_BSDF_RAD_ROOS;
+        m.p[0] = getConstNumber(*bsdf, "refl_w", 0.0f, name), m.p[1] = getConstNumber(*bsdf, "refl_p", 0.0f, name), m.p[2] = getConstNumber(*bsdf, "refl_q", 0.0f, name);
+        m.p[3] = getConstNumber(*bsdf, "trns_w", 0.0f, name), m.p[4] = getConstNumber(*bsdf, "trns_p", 0.0f, name), m.p[5] = getConstNumber(*bsdf, "trns_q", 0.0f, name);
+        const V3 rf = getColor(*bsdf, "reflection_front_diffuse", V3(0, 0, 0), name);
+        const V3 rb = getColor(*bsdf, "reflection_back_diffuse", V3(0, 0, 0), name);
+        const V3 td = getColor(*bsdf, "transmission_diffuse", V3(0, 0, 0), name);
+        m.p[6] = rf.x, m.p[7] = rf.y, m.p[8] = rf.z, m.p[9] = rb.x, m.p[10] = rb.y, m.p[11] = rb.z;
+        m.q[0] = td.x, m.q[1] = td.y, m.q[2] = td.z;
     } else if (type == "transform") {
         // TransformBSDF.cpp:17-49: make_normal_set(ctx, inner, normal) with the "normal" vector property (default +Z, as written);
         // the "tangent" form (make_normal_tangent_set) is not carried

@@ -95,6 +95,16 @@ enum ig_bsdf_type {
     IG_BSDF_ROUGH_DIELECTRIC = 5, /* src/artic/bsdf/dielectric.art:64-191 (make_dielectric_bsdf with a rough interface) */
     IG_BSDF_PLASTIC    = 4,
     IG_BSDF_TRANSPARENT = 7, /* make_perfect_refraction_bsdf (src/artic/bsdf/dielectric.art:1-11; runtime/bsdf/TransparentBSDF.cpp "transparent", PassthroughBSDF.cpp "passthrough" = white): p[0..2] colour */
+    /* make_rad_brtdfunc_bsdf (src/artic/bsdf/rad.art:7-29, RadBRTDFuncBSDF.cpp "rad_brtdfunc"): Radiance's BRTDfunc with constant
+     * arguments = add(add(lambertian, lambertian transmission), add(mirror, perfect refraction)) over make_add_bsdf (bsdf/mix.art:68).
+     * p[0..2] reflection_specular, p[3..5] transmission_specular, p[6..8] reflection_front_diffuse + direct_diffuse,
+     * p[9..11] reflection_back_diffuse + direct_diffuse, q[0..2] transmission_diffuse */
+    IG_BSDF_RAD_BRTD = 9,
+    /* make_rad_roos_bsdf (rad.art:36-56, RadRoosBSDF.cpp "rad_roos"): the Roos model for coated glazing on top of it; specular
+     * reflection and transmission follow from the angle of incidence. p[0..2] (w, p, q) of the transmission, p[3..5] (w, p, q) of the
+     * reflection AS THE ARTIC FUNCTION RECEIVES THEM (the C++ side passes the "refl_*" properties into the trns_* arguments and vice
+     * versa; restated as written), p[6..8] reflection_front_diffuse, p[9..11] reflection_back_diffuse, q[0..2] transmission_diffuse */
+    IG_BSDF_RAD_ROOS = 10,
     IG_BSDF_PHONG      = 8, /* make_phong_bsdf (src/artic/bsdf/phong.art:1-22, runtime/bsdf/PhongBSDF.cpp): p[0..2] specular_reflectance, p[3] exponent;
                              * powers through the reference's own fastpow (core/common.art:71-90), which is plain float / integer arithmetic */
     IG_BSDF_BLEND      = 6, /* make_mix_bsdf (src/artic/bsdf/mix.art:4-68), runtime/bsdf/BlendBSDF.cpp:14-56 ("blend" / "mix") */ /* src/artic/bsdf/plastic.art:2-41 over mix.art:4-65, runtime/bsdf/PlasticBSDF.cpp:13-44 */

@@ -1443,6 +1443,116 @@ struct Plastic {
     }
 };
 
+// ---- Radiance's BRTDfunc with constant arguments and the Roos glazing model on top of it (bsdf/rad.art:7-56):
+// make_add_bsdf (bsdf/mix.art:68) = make_join_bsdf with colour addition, nested two levels deep over four leaf BSDFs.
+struct RadLeaf {
+    int kind; // 0 make_lambertian_bsdf (diffuse.art:2-12), 1 make_lambertian_transmission_bsdf (:14-24), 2 make_mirror_bsdf (conductor.art:2-10),
+              // 3 make_perfect_refraction_bsdf (dielectric.art:3-11)
+    Color c;
+    static float negative_cos(Vec3 a, Vec3 b)
+    {
+        const float cs = vec3_dot(a, b);
+        return cs <= 0 ? cs : 0.0f; // core/common.art:265-268
+    }
+    Color eval(const Mat3x3& local, Vec3 in_dir) const
+    {
+        if (kind == 0)
+            return color_mulf(c, positive_cos(in_dir, local.col[2]) * flt_inv_pi);
+        if (kind == 1)
+            return color_mulf(c, -negative_cos(in_dir, local.col[2]) * flt_inv_pi);
+        return Color{ 0, 0, 0 };
+    }
+    float pdf(const Mat3x3& local, Vec3 in_dir) const
+    {
+        if (kind == 0)
+            return positive_cos(in_dir, local.col[2]) / flt_pi; // cosine_hemisphere_pdf
+        if (kind == 1)
+            return -negative_cos(in_dir, local.col[2]) / flt_pi;
+        return 0;
+    }
+    void sample(const Mat3x3& local, Rng& rnd, Vec3 out_dir, BsdfSample& s) const
+    {
+        s.eta = 1;
+        if (kind <= 1) {
+            const float u       = rnd.next_f32();
+            const float v       = rnd.next_f32();
+            const DirSample smp = sample_cosine_hemisphere(u, v);
+            const Vec3 gdir     = mat3x3_mul(local, smp.dir);
+            s.in_dir   = kind == 0 ? gdir : vec3_neg(gdir);
+            s.pdf      = smp.pdf;
+            s.color    = c;
+            s.is_delta = false;
+        } else {
+            s.in_dir   = kind == 2 ? vec3_reflect(out_dir, local.col[2]) : vec3_neg(out_dir);
+            s.pdf      = 1;
+            s.color    = c;
+            s.is_delta = true;
+        }
+    }
+};
+// make_join_bsdf (mix.art:4-65) with eval_f = color_add and a constant sampling probability
+template <class A, class B>
+struct RadAdd {
+    A a;
+    B b;
+    float k;
+    Color eval(const Mat3x3& l, Vec3 in_dir) const { return color_add(a.eval(l, in_dir), b.eval(l, in_dir)); }
+    float pdf(const Mat3x3& l, Vec3 in_dir) const
+    {
+        if (k <= 0)
+            return a.pdf(l, in_dir);
+        if (k >= 1)
+            return b.pdf(l, in_dir);
+        return lerpf(a.pdf(l, in_dir), b.pdf(l, in_dir), k);
+    }
+    template <class F, class S>
+    static void sample_mat(const F& first, const S& second, float t, const Mat3x3& l, Rng& rnd, Vec3 out_dir, BsdfSample& s)
+    {
+        first.sample(l, rnd, out_dir, s);
+        const float p = lerpf(s.pdf, second.pdf(l, s.in_dir), t);
+        const Color c = color_add(color_mulf(s.color, s.pdf), second.eval(l, s.in_dir));
+        s.pdf         = p;
+        s.color       = color_mulf(c, safe_div(1, p));
+    }
+    void sample(const Mat3x3& l, Rng& rnd, Vec3 out_dir, BsdfSample& s) const // (every leaf always delivers a sample: no fallback to the other side)
+    {
+        if (rnd.next_f32() < 1 - k)
+            sample_mat(a, b, k, l, rnd, out_dir, s);
+        else
+            sample_mat(b, a, 1 - k, l, rnd, out_dir, s);
+    }
+};
+using RadBrtd = RadAdd<RadAdd<RadLeaf, RadLeaf>, RadAdd<RadLeaf, RadLeaf>>;
+static inline RadBrtd make_rad_brtd(bool is_entering, Color refl_spec, Color trns_spec, Color refl_f_diff_plus_direct, Color refl_b_diff_plus_direct, Color trns_diff)
+{
+    const Color refl_diff = is_entering ? refl_f_diff_plus_direct : refl_b_diff_plus_direct;
+    RadBrtd r;
+    r.b.a = RadLeaf{ 2, refl_spec };
+    r.b.b = RadLeaf{ 3, trns_spec };
+    r.b.k = safe_div(color_average(trns_spec), color_average(refl_spec) + color_average(trns_spec));
+    r.a.a = RadLeaf{ 0, refl_diff };
+    r.a.b = RadLeaf{ 1, trns_diff };
+    r.a.k = safe_div(color_average(trns_diff), color_average(refl_diff) + color_average(trns_diff));
+    const float sum_spec = color_average(color_add(refl_spec, trns_spec));
+    const float sum_diff = color_average(color_add(refl_diff, trns_diff));
+    r.k = safe_div(sum_spec, sum_diff + sum_spec);
+    return r;
+}
+// make_rad_roos_bsdf (rad.art:36-56): (tau, rf) from the cosine between ray and shading normal
+static inline void rad_roos_factors(const ig_material& m, float cosN, float& rf, float& tau)
+{
+    const float trns_w = m.p[0], trns_p = m.p[1], trns_q = m.p[2], refl_w = m.p[3], refl_p = m.p[4], refl_q = m.p[5];
+    const float a = 8;
+    auto b     = [](float q) { return 0.25f / q; };
+    auto c     = [&](float, float q) { return 1 - a - b(q); };
+    auto alpha = [](float q) { return 5.2f + 0.7f * q; };
+    const float beta = 2;
+    auto gamma = [](float p, float q) { return (5.26f + 0.06f * p) + (0.73f + 0.04f * p) * q; };
+    const float z = igm_acos(igm_abs(clampf(cosN, -1, 1))) * 0.636619772368f;
+    tau = trns_w * (1 - a * igm_pow(z, alpha(trns_q)) - b(trns_q) * igm_pow(z, beta) - c(trns_p, trns_q) * igm_pow(z, gamma(trns_p, trns_q)));
+    rf  = refl_w + (1 - refl_w) * igm_pow(z, gamma(refl_p, refl_q));
+}
+
 struct Bsdf {
     const ig_material* mat;
     const SurfaceElement* surf;
@@ -1463,6 +1573,22 @@ struct Bsdf {
     }
 
     // plastic: mat1.is_all_delta & mat2.is_all_delta with a diffuse mat1 (mix.art:63)
+    bool is_rad() const { return mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS; }
+    // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record; the Roos model's cosN is
+    // -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28)
+    RadBrtd rad() const
+    {
+        const Color td{ mat->q[0], mat->q[1], mat->q[2] };
+        if (mat->bsdf_type == IG_BSDF_RAD_ROOS) {
+            float rf, tau;
+            rad_roos_factors(*mat, vec3_dot(view, surf->local.col[2]), rf, tau);
+            const Color black{ 0, 0, 0 };
+            return make_rad_brtd(surf->is_entering, Color{ rf, rf, rf }, Color{ tau, tau, tau }, color_add(Color{ mat->p[6], mat->p[7], mat->p[8] }, black),
+                                 color_add(Color{ mat->p[9], mat->p[10], mat->p[11] }, black), td);
+        }
+        return make_rad_brtd(surf->is_entering, Color{ mat->p[0], mat->p[1], mat->p[2] }, Color{ mat->p[3], mat->p[4], mat->p[5] }, Color{ mat->p[6], mat->p[7], mat->p[8] },
+                             Color{ mat->p[9], mat->p[10], mat->p[11] }, td);
+    }
     bool is_all_delta() const
     {
         if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
@@ -1568,6 +1694,10 @@ struct Bsdf {
     {
         if (flip)
             return unflipped().albedo(vec3_neg(out_dir));
+        if (is_rad()) { // make_join_bsdf.albedo (mix.art:56-61): colour lerps of the leaves' colours
+            const RadBrtd r = rad();
+            return color_lerp(color_lerp(r.a.a.c, r.a.b.c, r.a.k), color_lerp(r.b.a.c, r.b.b.c, r.b.k), r.k);
+        }
         const Vec3 N = surf->local.col[2];
         if (mat->bsdf_type == IG_BSDF_PHONG) // ks (phong.art:20)
             return Color{ mat->p[0], mat->p[1], mat->p[2] };
@@ -1601,6 +1731,8 @@ struct Bsdf {
     {
         if (flip)
             return unflipped().eval(vec3_neg(in_dir), vec3_neg(out_dir));
+        if (is_rad())
+            return rad().eval(surf->local, in_dir);
         if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
             return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
         if (mat->bsdf_type == IG_BSDF_PHONG)
@@ -1639,6 +1771,8 @@ struct Bsdf {
     {
         if (flip)
             return unflipped().pdf(vec3_neg(in_dir), vec3_neg(out_dir));
+        if (is_rad())
+            return rad().pdf(surf->local, in_dir);
         if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
             const float k = mat->p[0];
             if (k <= 0)
@@ -1704,6 +1838,10 @@ struct Bsdf {
             if (rnd.next_f32() < 1 - k)
                 return sample_mat(m1, m2, k) || sample_mat(m2, m1, k);
             return sample_mat(m2, m1, 1 - k) || sample_mat(m1, m2, 1 - k);
+        }
+        if (is_rad()) {
+            rad().sample(surf->local, rnd, out_dir, s);
+            return true;
         }
         if (mat->bsdf_type == IG_BSDF_TRANSPARENT) { // make_perfect_refraction_bsdf.sample (dielectric.art:6-8)
             s.in_dir   = vec3_neg(out_dir);

@@ -485,7 +485,8 @@ def test_constant_expressions_and_the_inline_checkerboard_idiom():
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(s))
     s["bsdfs"][0]["reflectance"] = "uv.x * 2"  # what is not constant becomes a program of the expression table (tests/test_pexpr.py)
-    assert LoadedScene.from_string(json.dumps(s)).scene.materials[0].flags & (1 << 8)
+    prog = LoadedScene.from_string(json.dumps(s))  # (keep the owner of the tables alive)
+    assert prog.scene.materials[0].flags & (1 << 8)
 
 
 def test_sun_position_from_time_and_place():

@@ -1417,3 +1417,13 @@ def test_shading_expressions_with_every_variable_vs_oracle(gpu_device):
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     assert sc.scene.expr_code_count > 50
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=43, iters=2)
+
+
+@pytest.mark.parametrize("stem", ["two-planes-brtdfunc1", "two-planes-brtdfunc2", "three-planes-brtdfunc1", "three-planes-roos"])
+def test_radiance_brtdfunc_and_roos_bsdfs_vs_oracle(gpu_device, stem):
+    """make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art): nested make_add_bsdf over mirror, perfect transmission and two Lambertian
+    lobes, seen from both sides of the pane (three-planes-*: diffuse transmission, angle-dependent Roos factors)."""
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", stem + ".json"), 96, 96)
+    assert any(sc.scene.materials[i].bsdf_type in (9, 10) for i in range(sc.scene.material_count))
+    _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=47, iters=2)

@@ -24,7 +24,8 @@ def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
     sc = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_light_depth": 7, "min_depth": 3, "clamp": 2.5})), SCENES, 64, 64)
     t = sc.scene.technique
     assert (t.type, t.max_depth, t.min_depth, t.clamp) == (4, 7, 3, 2.5)
-    assert LoadedScene.from_string(json.dumps(_plane_scene({"type": "lighttracer"})), SCENES, 64, 64).scene.technique.max_depth == 64
+    other = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lighttracer"})), SCENES, 64, 64)  # (keep the owner of the tables alive)
+    assert other.scene.technique.max_depth == 64
     with pytest.raises(RuntimeError, match="emission sampling"):
         LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "cie_cloudy", "name": "s"}])), SCENES, 64, 64)
     bad = _plane_scene({"type": "lt"})

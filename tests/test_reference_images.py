@@ -28,6 +28,7 @@ REFS = os.path.join(GOLDEN, "references")
 # scripts/RunEvaluations.py:98-123
 PREDEF_EPS = {"two-planes-mirror": 2e-2,  # (not in the reference's table: the mirror caustic, see PINNED)
               "two-planes-plastic": 2e-3,  # (not in the table either: 1.2e-3 at 1024 spp against a Radiance image with visible ambient-cache blotches)
+              "two-planes-brtdfunc1": 2e-3, "two-planes-brtdfunc2": 2e-3, "two-planes-brtdfunc3": 2e-3,  # (as two-planes-plastic: the same Radiance setup)
               "cbox-d1": 5e-3, "cbox-d6": 5e-3, "cycles-lights": 5e-2, "cycles-principled": 5e-2, "cycles-tex": 1e-2, "cycles-sun": 1e-2,
               "cycles-mix-diff-trans": 5e-3, "room": 1e-3, "volume": 5e-3, "env4k": 2e-3, "multilight-uniform": 3e-4, "multilight-simple": 3e-4,
               "multilight-hierarchy": 3e-4, "sphere-light-ico": 2e-3, "sphere-light-ico-nopt": 2e-3, "sphere-light-uv": 2e-3, "sphere-light-pure": 3e-3}
@@ -60,6 +61,8 @@ PINNED = {
     "volume": (0.045, 3e-3),                              # Mitsuba: an absorbing sphere in a room (volumetric path tracer). A uniform +3.3 % over the
                                                           # whole image, walls included; the reference's own bound for this scene is 5e-3, i.e. it
                                                           # expects a bias of this size itself (at 1e-3 a 3.3 % offset alone would fail)
+    "two-planes-brtdfunc1": None, "two-planes-brtdfunc2": None, "two-planes-brtdfunc3": None,  # Radiance BRTDfunc with constant arguments: mirror +
+                                                          # perfect transmission + diffuse reflection in three mixtures (make_add_bsdf, bsdf/rad.art:7-29)
     "two-planes-plastic": None,                           # Radiance: a 1 cm sphere light (analytic sphere) over two diffuse planes
     "two-planes-mirror": (0.015, 2.5e-2),                 # Radiance: the same with a mirror; the caustic the mirror throws on the floor reaches a
                                                           # path tracer only through BSDF-sampled hits of the 1 cm emitter (fireflies; Radiance
@@ -87,6 +90,13 @@ def lit_median_ratio(img, ref):
 
 
 EXCLUDED = {
+    "three-planes-brtdfunc1": "as three-planes-glass: the light sits behind the BRTDfunc pane, whose specular transmission lets no shadow ray through "
+                              "(a delta lobe inside a non-delta BSDF), so the floor in front of the pane gets its direct light only from BSDF-sampled hits of "
+                              "the 1 cm emitter; mean 0.94 x the Radiance image, error_image 2.5e-2 on 8 x 8 cells at 64 spp. The BSDF itself is pinned by "
+                              "two-planes-brtdfunc1..3 (means within 0.8 %, error_image < 1e-3).",
+    "three-planes-roos": "the same geometry with the Roos glazing model; in addition RadRoosBSDF.cpp hands its refl_* properties to the trns_* "
+                         "arguments of make_rad_roos_bsdf and vice versa (bsdf/rad.art:36-39), restated as written: the pane reflects what it should "
+                         "transmit (mean 1.19 x the Radiance image).",
     "cycles-lights-lt": "the light tracer as written is not normalised to the path tracer: camera connections are weighted with image_area = 1 "
                         "instead of the pixel's importance (src/artic/camera/perspective.art:36,47-51), so the image is the direct + indirect lighting "
                         "times the area of the image plane at distance 1 (4 sx sy), and a spot light's emission carries another 1 / spot_area "
