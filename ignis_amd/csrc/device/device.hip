@@ -401,7 +401,7 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
         const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL)
                                                                               : (mat.bsdf_type == IG_BSDF_DIELECTRIC ? (uint32_t)IG_MAT_THIN : 0u);
-        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | principled_flags))
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | (mat.bsdf_type == IG_BSDF_BLEND ? (uint32_t)IG_MAT_EXPR_WEIGHT : 0u) | principled_flags))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " carries flags its BSDF type does not define" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
@@ -419,6 +419,9 @@ void assignScene(igd_device* d, const igd_scene* s)
         if ((mat.flags & IG_MAT_EXPR_NORMAL) && ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) || mat.tex_id < 0 || !s->expr_code
                                                  || !ige_validate(s->expr_code, s->expr_code_count, (uint32_t)mat.tex_id, s->textures && s->texture_data ? s->texture_count : 0u)))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material " + std::to_string(m) + " names no valid normal expression program" };
+        if ((mat.flags & IG_MAT_EXPR_WEIGHT) && (mat.tex_id < 0 || !s->expr_code
+                                                 || !ige_validate(s->expr_code, s->expr_code_count, (uint32_t)mat.tex_id, s->textures && s->texture_data ? s->texture_count : 0u)))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: blend material " + std::to_string(m) + " names no valid weight expression program" };
         if ((mat.flags & IG_MAT_CHECKER) && !has_albedo)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: checkerboard colours are only lowered for diffuse and principled BSDFs" };
         if (mat.light_id >= (int32_t)s->light_count)
@@ -596,7 +599,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         // the shading kernel with the expression interpreter runs only where a material names a program
         bool any_expr = false;
         for (uint32_t i = 0; i < s->material_count; ++i)
-            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL)) != 0;
+            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0;
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
     ds.scene_radius         = s->scene_radius;
@@ -618,7 +621,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
     for (uint32_t i = 0; i < s->material_count; ++i)
-        d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
+        d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;

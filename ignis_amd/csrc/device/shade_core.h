@@ -1313,6 +1313,11 @@ struct BsdfCtx {
         if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | (EXPR ? IG_MAT_EXPR_NORMAL : 0)))
             surf.local = bumped_frame<EXPR>(sc, m, s, ray_dir);
         kd = material_color<EXPR>(sc, m, surf, -ray_dir); // an expression sees the surface the BSDF is built on (bsdf_inner(ctx.{surf = surf2}))
+        if constexpr (FULL && TOP) {
+            // a blend's weight travels in kd.r (= p[0] for a constant one: material_color of a blend is its p[0..2])
+            if (EXPR && (m.flags & IG_MAT_EXPR_WEIGHT))
+                kd.r = eval_expr(sc, m.tex_id, surf, -ray_dir).x;
+        }
         if constexpr (FULL) {
             if (m.bsdf_type == IG_BSDF_RAD_ROOS) { // cosN = -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28); kd carries (rf, tau)
                 const f2 ft = rad_roos_factors(m, -dot3(ray_dir, surf.local.c2));
@@ -1460,7 +1465,7 @@ struct BsdfCtx {
         }
         case IG_BSDF_BLEND: // mix.art:56-61
             if constexpr (FULL && TOP)
-                return lerp_col(inner(0).albedo(out_dir), inner(1).albedo(out_dir), mat->p[0]);
+                return lerp_col(inner(0).albedo(out_dir), inner(1).albedo(out_dir), kd.r);
             return kd;
         default: // lambertian kd (bsdf/diffuse.art:10), principled base colour (bsdf/principled.art:478)
             return kd;
@@ -1474,7 +1479,7 @@ struct BsdfCtx {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
-                return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
+                return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), kd.r);
         }
         if constexpr (FULL) {
             if (is_rad())
@@ -1516,7 +1521,7 @@ struct BsdfCtx {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
-                const float k = mat->p[0];
+                const float k = kd.r;
                 if (k <= 0)
                     return inner(0).pdf(in_dir, out_dir);
                 if (k >= 1)
@@ -1563,7 +1568,7 @@ struct BsdfCtx {
         if constexpr (FULL && TOP) {
             if (mat->bsdf_type == IG_BSDF_BLEND) {
                 // make_join_bsdf.sample (mix.art:27-55); sample_mat(first, second, t)
-                const float k    = mat->p[0];
+                const float k    = kd.r;
                 const bool pick1 = rnd.f32() < 1 - k;
                 const float t    = pick1 ? k : 1 - k;
                 for (int attempt = 0; attempt < 2; ++attempt) {

@@ -1288,6 +1288,36 @@ static void loadParameters(const JsonValue& doc, std::map<std::string, igh::pexp
     }
 }
 
+// The weight of a blend / mask (ShadingTree::addNumber): a constant, or a number expression that becomes a program of the expression
+// table; cutoff: compared with the "cutoff" threshold into 0 / 1.
+static void lowerWeight(const JsonValue& bsdf, TextureBank& bank, ig_material& m, const std::string& name, bool cutoff)
+{
+    const JsonValue* w = bsdf.find("weight");
+    const float threshold = cutoff ? getConstNumber(bsdf, "cutoff", 0.5f, name) : 0.0f;
+    if (!w || w->isNumber()) {
+        const float weight = w ? (float)w->num : 0.5f;
+        m.p[0]             = cutoff ? (weight < threshold ? 0.0f : 1.0f) : weight;
+        return;
+    }
+    if (!w->isString())
+        fail("'" + name + "': property 'weight' is neither a number nor an expression");
+    std::string src = w->str;
+    if (cutoff) { // select(weight < cutoff, 0, 1) (MaskBSDF.cpp:51-54)
+        char num[48];
+        std::snprintf(num, sizeof(num), "%.9g", (double)threshold);
+        src = "select((" + src + ") < " + num + ", 0.0, 1.0)";
+    }
+    const igh::pexpr::Program prog = bank.compileExpr(src, name);
+    if (!igh::pexpr::isScalar(prog.type))
+        fail("'" + name + "': expression of property 'weight' is a " + igh::pexpr::typeName(prog.type) + ", not a number");
+    if (prog.is_const) {
+        m.p[0] = prog.value[0];
+        return;
+    }
+    m.flags |= IG_MAT_EXPR_WEIGHT;
+    m.tex_id = bank.addProgram(prog);
+}
+
 // Inner materials of blends: appended to the material table after the entity-bound ones (index = aux_base + position)
 struct AuxMaterials {
     std::vector<ig_material> list;
@@ -1445,7 +1475,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (first == second)
             return lowerBsdf(first, scene_bsdfs, textures, bank, aux, depth + 1);
         m.bsdf_type = IG_BSDF_BLEND;
-        m.p[0]      = getConstNumber(*bsdf, "weight", 0.5f, name);
+        lowerWeight(*bsdf, bank, m, name, false);
         int slot    = 0;
         for (const std::string& inner : { first, second }) {
             const ig_material im = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
@@ -1472,9 +1502,6 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         const std::string masked = bsdf->getString("bsdf");
         if (masked.empty())
             fail("BSDF '" + name + "': has no inner bsdf given");
-        float weight = getConstNumber(*bsdf, "weight", 0.5f, name);
-        if (type == "cutoff")
-            weight = weight < getConstNumber(*bsdf, "cutoff", 0.5f, name) ? 0.0f : 1.0f;
         const bool inverted = bsdf->getBool("inverted", false);
         ig_material inner   = lowerBsdf(masked, scene_bsdfs, textures, bank, aux, depth + 1);
         if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
@@ -1487,7 +1514,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         through.tex_id = through.tex_refl = -1;
         through.p[0] = through.p[1] = through.p[2] = 1;
         m.bsdf_type = IG_BSDF_BLEND;
-        m.p[0]      = weight;
+        lowerWeight(*bsdf, bank, m, name, type == "cutoff"); // "cutoff" turns the weight into 0 / 1 against a threshold
         for (int slot = 0; slot < 2; ++slot) {
             const bool is_inner = (slot == 0) != inverted;
             m.pad[slot]         = aux.base + (int32_t)aux.list.size();
@@ -1507,8 +1534,8 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (inner.empty())
             fail("BSDF '" + name + "': has no inner bsdf given");
         m = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
-        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL))
-            fail("BSDF '" + name + "': nested bump / normal maps are not supported by the HIP backend");
+        if (m.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT))
+            fail("BSDF '" + name + "': nested bump / normal maps and maps around a blend with an expression weight are not supported by the HIP backend");
         const JsonValue* map = bsdf->find("map");
         if (!map || !map->isString())
             fail("BSDF '" + name + "': 'map' must name a bitmap texture");
@@ -1556,7 +1583,11 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             if (nv->isString())
                 src = nv->str;
             else if (nv->isArray() && nv->arr.size() == 3 && nv->arr[0].isNumber() && nv->arr[1].isNumber() && nv->arr[2].isNumber())
-                src = "vec3(" + std::to_string(nv->arr[0].num) + ", " + std::to_string(nv->arr[1].num) + ", " + std::to_string(nv->arr[2].num) + ")";
+            {
+                char buf[160];
+                std::snprintf(buf, sizeof(buf), "vec3(%.9g, %.9g, %.9g)", (double)(float)nv->arr[0].num, (double)(float)nv->arr[1].num, (double)(float)nv->arr[2].num);
+                src = buf;
+            }
             else
                 fail("BSDF '" + name + "': 'normal' is neither a vector nor an expression");
         }

@@ -125,6 +125,8 @@ enum ig_material_flags {
     IG_MAT_EXPR_COLOR  = 1u << 8, /* the colour material_color resolves (diffuse reflectance, plastic diffuse reflectance, principled base
                                    * colour) is the shading expression whose program starts at igd_scene.expr_code[tex_refl]
                                    * (include/ig_expr.h; ShadingTree::addColor with a PExpr string, src/runtime/loader/ShadingTree.cpp) */
+    IG_MAT_EXPR_WEIGHT = 1u << 10, /* blend / mask: the weight is the number expression at igd_scene.expr_code[tex_id] (BlendBSDF.cpp:40,
+                                    * MaskBSDF.cpp:30-55 with ShadingTree::addNumber), p[0] is unused */
     IG_MAT_EXPR_NORMAL = 1u << 9, /* wrapped in a "transform" BSDF (TransformBSDF.cpp:17-49, make_normal_set src/artic/bsdf/map.art:36-42)
                                    * whose normal is the program at igd_scene.expr_code[tex_id] */
 };

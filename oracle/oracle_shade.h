@@ -1573,6 +1573,8 @@ struct Bsdf {
     }
 
     // plastic: mat1.is_all_delta & mat2.is_all_delta with a diffuse mat1 (mix.art:63)
+    // the weight of a blend / mask: a constant or a number expression (BlendBSDF.cpp:40, MaskBSDF.cpp:30-55)
+    float weight() const { return (mat->flags & IG_MAT_EXPR_WEIGHT) ? eval_expression(*scene, mat->tex_id, *surf, view).x : mat->p[0]; }
     bool is_rad() const { return mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS; }
     // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record; the Roos model's cosN is
     // -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28)
@@ -1721,7 +1723,7 @@ struct Bsdf {
             return color_lerp(kd(), coat, pl.mix(out_dir));
         }
         if (mat->bsdf_type == IG_BSDF_BLEND) // mix.art:56-61
-            return color_lerp(inner(0).albedo(out_dir), inner(1).albedo(out_dir), mat->p[0]);
+            return color_lerp(inner(0).albedo(out_dir), inner(1).albedo(out_dir), weight());
         return kd(); // lambertian (diffuse.art:10), principled base colour (principled.art:478)
     }
 
@@ -1734,7 +1736,7 @@ struct Bsdf {
         if (is_rad())
             return rad().eval(surf->local, in_dir);
         if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
-            return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), mat->p[0]);
+            return color_lerp(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), weight());
         if (mat->bsdf_type == IG_BSDF_PHONG)
             return phong_eval(in_dir, out_dir);
         if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
@@ -1774,7 +1776,7 @@ struct Bsdf {
         if (is_rad())
             return rad().pdf(surf->local, in_dir);
         if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
-            const float k = mat->p[0];
+            const float k = weight();
             if (k <= 0)
                 return inner(0).pdf(in_dir, out_dir);
             if (k >= 1)
@@ -1834,7 +1836,7 @@ struct Bsdf {
                 s.color       = color_mulf(c, safe_div(1, p));
                 return true;
             };
-            const float k = mat->p[0];
+            const float k = weight();
             if (rnd.next_f32() < 1 - k)
                 return sample_mat(m1, m2, k) || sample_mat(m2, m1, k);
             return sample_mat(m2, m1, 1 - k) || sample_mat(m1, m2, 1 - k);

@@ -1427,3 +1427,19 @@ def test_radiance_brtdfunc_and_roos_bsdfs_vs_oracle(gpu_device, stem):
     sc = LoadedScene.from_file(os.path.join(SCENES, "evaluation", stem + ".json"), 96, 96)
     assert any(sc.scene.materials[i].bsdf_type in (9, 10) for i in range(sc.scene.material_count))
     _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=47, iters=2)
+
+
+def test_expression_weights_of_blend_and_cutoff_vs_oracle(gpu_device):
+    """Blend and mask weights as number expressions (IG_MAT_EXPR_WEIGHT): a procedural blend on the walls, a texture-driven cutoff on the diamonds."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    for b in s["bsdfs"]:
+        if b["name"] in ("mat-GrayWall", "mat-Diamond"):
+            b["name"] += "-inner"
+    s["textures"] = [{"type": "image", "name": "grid", "filename": "textures/grid_weight.png"}]
+    s["bsdfs"] += [{"type": "conductor", "name": "gold", "eta": [0.2, 0.4, 1.4], "k": [3.9, 2.4, 1.6], "roughness": 0.2},
+                   {"type": "blend", "name": "mat-GrayWall", "first": "mat-GrayWall-inner", "second": "gold", "weight": "smoothstep(fract(P.x * 2 + P.y))"},
+                   {"type": "cutoff", "name": "mat-Diamond", "bsdf": "mat-Diamond-inner", "weight": "grid(P.xy * 3).r + select(frontside, 0.2, 0.0)", "cutoff": 0.4}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 10)) == 2
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=53, iters=2)

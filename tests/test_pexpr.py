@@ -190,3 +190,29 @@ def test_oracle_transform_bsdf_with_the_plain_normal_changes_nothing_and_a_tilte
     assert abs(tilted[c, c].mean() / plain[c, c].mean() - math.sqrt(0.5)) < 0.01
     const = render([1, 0, 1])  # a constant world-space vector works as well
     assert np.allclose(const[c, c].mean(), tilted[c, c].mean(), rtol=1e-3)
+
+
+def test_blend_and_mask_weights_can_be_expressions():
+    """BlendBSDF.cpp:40 / MaskBSDF.cpp:30-55: "weight" goes through ShadingTree::addNumber; "cutoff" compares it with a threshold."""
+    import oracle
+    s = _scene({"type": "blend", "name": "m", "first": "a", "second": "b", "weight": "uv.x"})
+    s["bsdfs"] += [{"type": "diffuse", "name": "a", "reflectance": [0, 0, 0]}, {"type": "diffuse", "name": "b", "reflectance": [1, 1, 1]}]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    m = sc.scene.materials[0]
+    assert m.bsdf_type == 6 and m.flags & (1 << 10) and m.tex_id >= 0
+    fb, _ = oracle.render(sc, 16, 64, 64, iteration=0, seed=3)
+    g = fb.mean(axis=2)
+    left, right = g[24:40, 12:20].mean(), g[24:40, 44:52].mean()
+    assert right > left * 2 > 0  # the white side of the blend grows with u
+    s["bsdfs"][0]["weight"] = "0.25 * 2"
+    folded = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    assert folded.scene.materials[0].flags & (1 << 10) == 0 and folded.scene.materials[0].p[0] == 0.5
+    s["bsdfs"][0] = {"type": "cutoff", "name": "m", "bsdf": "a", "weight": "fract(uv.y * 4)", "cutoff": 0.5}
+    cut = LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+    assert cut.scene.materials[0].flags & (1 << 10)
+    fb, _ = oracle.render(cut, 8, 64, 64, iteration=0, seed=3)
+    col = fb.mean(axis=(1, 2))[12:52]
+    assert (col < 0.2).mean() > 0.3 and (col > 0.9).mean() > 0.3  # stripes: the black masked BSDF where the weight is below the threshold, see-through to the white environment elsewhere
+    s["bsdfs"][0] = {"type": "mask", "name": "m", "bsdf": "a", "weight": "uv"}
+    with pytest.raises(RuntimeError, match="not a number"):
+        LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
