@@ -408,6 +408,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         if (mat.bsdf_type == IG_BSDF_BLEND)
             for (int k = 0; k < 2; ++k)
                 if (mat.pad[k] < 0 || mat.pad[k] >= (int32_t)s->material_count || s->materials[mat.pad[k]].bsdf_type == IG_BSDF_BLEND
+                    || s->materials[mat.pad[k]].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[mat.pad[k]].bsdf_type == IG_BSDF_RAD_ROOS
                     || (s->materials[mat.pad[k]].flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_COLOR)))
                     throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: blend material " + std::to_string(m) + " has no valid inner materials" };
         const bool has_albedo = mat.bsdf_type == IG_BSDF_DIFFUSE || mat.bsdf_type == IG_BSDF_PRINCIPLED || mat.bsdf_type == IG_BSDF_PLASTIC; // p[0..2] reflectance / base colour
@@ -517,7 +518,12 @@ void assignScene(igd_device* d, const igd_scene* s)
     if (s->technique.type == IG_TECHNIQUE_VOLPATH && (s->media_count > 0xFFFEu || s->technique.max_depth > 0xFFFF))
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the volumetric path tracer supports at most 65534 media and a max_depth of 65535" };
     d->media.upload(s->media, s->media_count);
-    d->expr_code.upload(s->expr_code, s->expr_code ? s->expr_code_count : 0);
+    if (s->expr_code && s->expr_code_count) {
+        d->expr_code.upload(s->expr_code, s->expr_code_count);
+    } else {
+        const uint32_t end_only = 0; // IGE_END: DevScene.expr_code doubles as the switch to the instantiation with the rare shading code
+        d->expr_code.upload(&end_only, 1);
+    }
     for (uint32_t i = 0; i < s->texture_count; ++i) {
         const ig_texture& t = s->textures[i];
         const uint32_t nc    = t.channels & ~IG_TEX_FLOAT_BIT;
@@ -599,7 +605,8 @@ void assignScene(igd_device* d, const igd_scene* s)
         // the shading kernel with the expression interpreter runs only where a material names a program
         bool any_expr = false;
         for (uint32_t i = 0; i < s->material_count; ++i)
-            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0;
+            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0 || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD
+                        || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS; // the Radiance BSDFs live in that instantiation too
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
     ds.scene_radius         = s->scene_radius;

@@ -200,7 +200,7 @@ IG_DEV void shade_vertex_lt(const DevScene& sc, const ShadeFrame& fr, const LtCa
 
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     const Surf surf        = surface_element<true>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
-    const BsdfCtx<true> bsdf(sc, mat, surf, in.dir, std::true_type{});
+    const BsdfCtx<true, true, true> bsdf(sc, mat, surf, in.dir, std::true_type{});
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 

@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256) k_info(const InfoArgs a)
             const f3 org{ ra.x, ra.y, ra.z }, dir{ rb.x, rb.y, rb.z };
             const ig_material& mat = a.scene.materials[a.scene.entity_material[ent]];
             const Surf surf        = surface_element<true>(a.scene, ent, (int)igm_bits(hit.y), org, dir, hit.z, hit.w, a.in.hit_v[i]);
-            const BsdfCtx<true> bsdf(a.scene, mat, surf, dir, std::true_type{});
+            const BsdfCtx<true, true, true> bsdf(a.scene, mat, surf, dir, std::true_type{});
             const Col al = bsdf.albedo(-dir);
             const f3 N   = surf.local.c2;
             nrm          = make_float4(N.x * a.inv_spi, N.y * a.inv_spi, N.z * a.inv_spi, 0);

@@ -1295,7 +1295,9 @@ IG_DEV Col material_color(const DevScene& sc, const ig_material& m, const Surf& 
     return Col{ m.p[0], m.p[1], m.p[2] };
 }
 
-template <bool FULL, bool TOP = true>
+// RARE: the BSDFs only the instantiation for scenes with expressions / Radiance materials carries (k_shade<true, *, true>): in the
+// ordinary full kernel the BRTDfunc / Roos code cost diamond_scene_principled 3 % of its shading time
+template <bool FULL, bool TOP = true, bool RARE = false>
 struct BsdfCtx {
     const ig_material* mat;
     Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
@@ -1318,7 +1320,7 @@ struct BsdfCtx {
             if (EXPR && (m.flags & IG_MAT_EXPR_WEIGHT))
                 kd.r = eval_expr(sc, m.tex_id, surf, -ray_dir).x;
         }
-        if constexpr (FULL) {
+        if constexpr (FULL && RARE) {
             if (m.bsdf_type == IG_BSDF_RAD_ROOS) { // cosN = -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28); kd carries (rf, tau)
                 const f2 ft = rad_roos_factors(m, -dot3(ray_dir, surf.local.c2));
                 kd          = Col{ ft.x, ft.y, 0 };
@@ -1353,7 +1355,7 @@ struct BsdfCtx {
         return mat->bsdf_type == IG_BSDF_DIELECTRIC || (FULL && mat->bsdf_type == IG_BSDF_TRANSPARENT) || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
-    IG_DEV bool is_rad() const { return FULL && (mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS); }
+    IG_DEV bool is_rad() const { return FULL && RARE && (mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS); }
     // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record
     IG_DEV RadBrtd rad() const
     {
@@ -2322,8 +2324,8 @@ IG_DEV Col debug_palette(int i)
 }
 
 // on_hit of make_debug_renderer (technique/debugtracer.art:3-140) over the point mappers of driver/pointmapper.art:28-36
-template <bool FULL>
-IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, const Surf& surf, const BsdfCtx<FULL>& bsdf, const ig_material& mat, int mat_id)
+template <bool FULL, class Ctx>
+IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, const Surf& surf, const Ctx& bsdf, const ig_material& mat, int mat_id)
 {
     const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)in.ent * IG_ENTITY_FLOATS);
     auto absv       = [](f3 n) { return Col{ igm_abs(n.x), igm_abs(n.y), igm_abs(n.z) }; };
@@ -2517,7 +2519,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
     const Surf surf = surface_element<FULL>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
-    const BsdfCtx<FULL> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
+    const BsdfCtx<FULL, true, EXPR> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 

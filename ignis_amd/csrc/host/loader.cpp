@@ -1481,8 +1481,8 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             const ig_material im = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
             if (im.bsdf_type == IG_BSDF_BLEND || (im.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
                 fail("BSDF '" + name + "': nested blends and bump / normal maps inside a blend are not supported by the HIP backend");
-            if (im.flags & IG_MAT_EXPR_COLOR)
-                fail("BSDF '" + name + "': expressions inside a blend are not supported by the HIP backend");
+            if ((im.flags & IG_MAT_EXPR_COLOR) || im.bsdf_type == IG_BSDF_RAD_BRTD || im.bsdf_type == IG_BSDF_RAD_ROOS)
+                fail("BSDF '" + name + "': expressions and Radiance BSDFs inside a blend are not supported by the HIP backend");
             m.pad[slot++] = aux.base + (int32_t)aux.list.size();
             aux.list.push_back(im);
             aux.names.push_back(inner);
@@ -1506,8 +1506,8 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         ig_material inner   = lowerBsdf(masked, scene_bsdfs, textures, bank, aux, depth + 1);
         if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
             fail("BSDF '" + name + "': blends and bump / normal maps inside a mask are not supported by the HIP backend");
-        if (inner.flags & IG_MAT_EXPR_COLOR)
-            fail("BSDF '" + name + "': expressions inside a mask are not supported by the HIP backend");
+        if ((inner.flags & IG_MAT_EXPR_COLOR) || inner.bsdf_type == IG_BSDF_RAD_BRTD || inner.bsdf_type == IG_BSDF_RAD_ROOS)
+            fail("BSDF '" + name + "': expressions and Radiance BSDFs inside a mask are not supported by the HIP backend");
         ig_material through{};
         through.bsdf_type = IG_BSDF_TRANSPARENT; // make_passthrough_bsdf = white perfect refraction
         through.light_id  = -1;
