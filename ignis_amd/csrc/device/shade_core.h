@@ -1355,6 +1355,8 @@ struct BsdfCtx {
         return mat->bsdf_type == IG_BSDF_DIELECTRIC || (FULL && mat->bsdf_type == IG_BSDF_TRANSPARENT) || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
+    // the weight of a blend: p[0], or (instantiation with expressions only) the value the constructor left in kd.r
+    IG_DEV float blend_weight() const { return RARE ? kd.r : mat->p[0]; }
     IG_DEV bool is_rad() const { return FULL && RARE && (mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS); }
     // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record
     IG_DEV RadBrtd rad() const
@@ -1467,7 +1469,7 @@ struct BsdfCtx {
         }
         case IG_BSDF_BLEND: // mix.art:56-61
             if constexpr (FULL && TOP)
-                return lerp_col(inner(0).albedo(out_dir), inner(1).albedo(out_dir), kd.r);
+                return lerp_col(inner(0).albedo(out_dir), inner(1).albedo(out_dir), blend_weight());
             return kd;
         default: // lambertian kd (bsdf/diffuse.art:10), principled base colour (bsdf/principled.art:478)
             return kd;
@@ -1481,7 +1483,7 @@ struct BsdfCtx {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
-                return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), kd.r);
+                return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), blend_weight());
         }
         if constexpr (FULL) {
             if (is_rad())
@@ -1523,7 +1525,7 @@ struct BsdfCtx {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
             if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
-                const float k = kd.r;
+                const float k = blend_weight();
                 if (k <= 0)
                     return inner(0).pdf(in_dir, out_dir);
                 if (k >= 1)
@@ -1570,7 +1572,7 @@ struct BsdfCtx {
         if constexpr (FULL && TOP) {
             if (mat->bsdf_type == IG_BSDF_BLEND) {
                 // make_join_bsdf.sample (mix.art:27-55); sample_mat(first, second, t)
-                const float k    = kd.r;
+                const float k    = blend_weight();
                 const bool pick1 = rnd.f32() < 1 - k;
                 const float t    = pick1 ? k : 1 - k;
                 for (int attempt = 0; attempt < 2; ++attempt) {
