@@ -73,7 +73,6 @@ struct Surf { // driver/surface_element.art
     f3 point, face_normal;
     f2 tex;
     m33 local;
-    float inv_area; // of the triangle (make_triangle, core/triangle.art:12-29); only the wireframe technique reads it
 };
 
 IG_DEV f3 stable_normal(f3 e1, f3 e2, f3 e3) // core/triangle.art:31-44
@@ -122,7 +121,6 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
         s.entering      = true;
         s.face_normal   = n;
         s.local         = orthonormal_basis(n);
-        s.inv_area      = 0;
         return s;
     }
     const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
@@ -151,8 +149,26 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     s.point       = org + dir * t;
     s.face_normal = s.entering ? fn : -fn;
     s.local       = orthonormal_basis(s.entering ? sn : -sn);
-    s.inv_area    = safe_div(1, nn / 2);
     return s;
+}
+
+// SurfaceElement.inv_area of a triangle hit (make_triangle, core/triangle.art:12-29: area = |n| / 2), for the wireframe technique only:
+// kept out of Surf so that the other kernels do not carry it
+IG_DEV float triangle_inv_area(const DevScene& sc, int ent_id, int prim_id)
+{
+    const float4* e = reinterpret_cast<const float4*>(sc.entities + (size_t)ent_id * IG_ENTITY_FLOATS);
+    const float4 r3 = e[3], r4 = e[4], r5 = e[5];
+    m34 global;
+    global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
+    const uint4 ext    = sc.entity_ext[ent_id];
+    const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
+    const float* inds  = reinterpret_cast<const float*>(sc.shape_data + ext.z);
+    const int4 tri     = *reinterpret_cast<const int4*>(inds + prim_id * 4);
+    const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4));
+    const f3 v1 = xform_point(global, ld3v(verts + tri.y * 4));
+    const f3 v2 = xform_point(global, ld3v(verts + tri.z * 4));
+    const float nn = len3(stable_normal(v2 - v0, v0 - v1, v1 - v2));
+    return safe_div(1, nn / 2);
 }
 
 struct Col {
@@ -2540,7 +2556,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             // is_edge_hit (:24-31): clampf(0, 1, 1 - u - v) as written = min(1 - u - v, 1)
             const float w      = clampf(0, 1, 1 - in.u - in.v);
             const float edge_t = igm_min(in.u, igm_min(in.v, w));
-            const float cond   = 0.01f * ((in.t + in.inv_pdf) * fr.wire_footprint) * igm_sqrt(surf.inv_area);
+            const float cond   = 0.01f * ((in.t + in.inv_pdf) * fr.wire_footprint) * igm_sqrt(triangle_inv_area(sc, in.ent, in.prim));
             if (edge_t <= cond) { // on_hit: color_lerp(white, black, t); no bounce
                 const float c    = (1 - edge_t) * 1.0f + edge_t * 0.0f;
                 out.has_radiance = true;
