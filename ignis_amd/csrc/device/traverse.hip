@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(a.work_counter, (uint32_t)kRayBatch);
-                base       = __shfl(base, 0);
+                base       = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); // wave-uniform by construction: keeps the batch bookkeeping (and the loop) scalar
                 last_base  = base;
                 batch_next = base < count ? base : count;
                 batch_end  = base + kRayBatch < count ? base + kRayBatch : count;
@@ -89,11 +89,10 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             }
             batch_next += take;
         }
-        if (!__any(has_ray)) {
-            if (exhausted && batch_next >= batch_end)
-                break;
-            continue;
-        }
+        // (no `continue` for the wave that got no ray out of a refill: a second back edge made the compiler rotate the ~30 state
+        // registers through copies at the end of every pass; an empty step() costs one settle body and happens once per launch)
+        if (!__any(has_ray) && exhausted && batch_next >= batch_end)
+            break;
 
         // every lane steps: a lane without a ray is `finished` in mode 0, which no section of step() acts on. (Wrapping the call
         // in `if (has_ray)` made the compiler copy the whole traversal state at the merge, ~35 v_mov per pass.)

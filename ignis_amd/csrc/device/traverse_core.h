@@ -223,7 +223,9 @@ struct Traverser {
     //   leaf   : leaf on top                                        -> pop, enter its items (or cull on if it starts behind the hit)
     IG_DEV void settle(const DevScene& sc, Stack& st, int tid)
     {
-        while (__any(unsettled())) {
+        // (a do-while on purpose: the body leaves settled lanes alone, so running it once too often is harmless, while the
+        // rotated `while` form made the compiler copy the fourteen loop-carried state registers in every iteration's header)
+        do {
             const bool run    = (mode == 0) & !finished;
             const bool unwind = run & (level == 1) & lterm;
             ptr      = sel(unwind, lbase, ptr);
@@ -255,7 +257,7 @@ struct Traverser {
             mode     = sel(leaf & !behind, level ? 1 : 2, sel(ret & !ent_last & !(ANY_HIT & accept), 2, mode));
             need_cull = need_cull | (ret & ent_last) | (leaf & behind);
             level     = sel(ret, 0, level);
-        }
+        } while (__any(unsettled()));
     }
 
     // One pipeline pass: entity leaf -> inner node -> triangle packet. Every lane of the wave calls it; lanes without
@@ -296,7 +298,7 @@ struct Traverser {
             bool enter      = false;
             int enter_at    = 0;
             int entity_id   = 0;
-            while (__any(scanning)) {
+            do { // (at least one lane is scanning: the quorum is >= 1)
                 const int at     = scanning ? ent_cursor : 0;
                 const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + at);
                 const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
@@ -315,7 +317,7 @@ struct Traverser {
                 enter_at          = sel(inside, at, enter_at);
                 entity_id         = sel(inside, id, entity_id);
                 scanning          = scanning & !inside & !(id < 0);
-            }
+            } while (__any(scanning));
             if (__any(enter)) {
                 const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at);
                 const uint2 ext  = (SPHERES ? sc.sphere_leaf_ext : sc.leaf_ext)[enter_at];
@@ -448,7 +450,7 @@ struct Traverser {
 
         // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
         if (!SPHERES && __popcll(__ballot(mode == 1)) >= quorum) {
-            while (__any(mode == 1)) {
+            do { // (at least one lane is in a triangle leaf: the quorum is >= 1)
                 const bool here   = mode == 1;
                 if (STATS)
                     sec_pass[2] += 1, sec_lane[2] += (uint32_t)__popcll(__ballot(here));
@@ -491,7 +493,7 @@ struct Traverser {
                 const bool leave = here & ((pid[3] < 0) | (ANY_HIT & lterm));
                 mode             = sel(leave, 0, mode);
                 need_cull        = need_cull | leave;
-            }
+            } while (__any(mode == 1));
             if (ANY_HIT) {
                 if (__any(lterm))
                     settle(sc, st, tid); // return to the scene level now: the hit may end the ray

@@ -96,6 +96,8 @@ inline void emit(const Node& n, uint32_t base, std::vector<uint32_t>& out)
         error("expression too deeply nested for the " + std::to_string(IGE_REGS) + " registers of the interpreter");
     for (size_t i = 0; i < n.args.size(); ++i)
         emit(*n.args[i], base + (uint32_t)i, out);
+    // operand fields beyond the node's arity name `base` (a register the instruction owns), never a register past the file
+    const auto r = [&](size_t i) { return i < n.args.size() ? base + (uint32_t)i : base; };
     switch (n.op) {
     case IGE_CONST:
         out.push_back(IGE_INS(IGE_CONST, base, 0, 0, 0, 0));
@@ -113,14 +115,14 @@ inline void emit(const Node& n, uint32_t base, std::vector<uint32_t>& out)
         out.push_back(n.tex);
         break;
     case IGE_BUMP:
-        out.push_back(IGE_INS(IGE_BUMP, base, base, base + 1, base + 2, 0));
-        out.push_back((base + 3) | (base + 4) << 4 | (base + 5) << 8);
+        out.push_back(IGE_INS(IGE_BUMP, base, r(0), r(1), r(2), 0));
+        out.push_back(r(3) | r(4) << 4 | r(5) << 8);
         break;
     case IGE_PACK:
-        out.push_back(IGE_INS(IGE_PACK, base, base, base + 1, base + 2, base + 3));
+        out.push_back(IGE_INS(IGE_PACK, base, r(0), r(1), r(2), r(3)));
         break;
     default:
-        out.push_back(IGE_INS(n.op, base, base, base + 1, base + 2, n.imm));
+        out.push_back(IGE_INS(n.op, base, r(0), r(1), r(2), n.imm));
         break;
     }
 }
@@ -195,6 +197,7 @@ private:
     Env& mEnv;
     Program& mProg;
     size_t mPos = 0;
+    int mDepth  = 0;
     Token mTok;
 
     void next()
@@ -388,8 +391,20 @@ private:
         }
         return a;
     }
+    // every cycle of the grammar (parentheses, function arguments, unary chains, '^') passes through here
+    struct DepthGuard {
+        int& d;
+        explicit DepthGuard(int& depth)
+            : d(depth)
+        {
+            if (++d > 128)
+                error("expression too deeply nested");
+        }
+        ~DepthGuard() { --d; }
+    };
     NodeP parseUnary()
     {
+        const DepthGuard guard(mDepth);
         if (accept("+")) {
             NodeP a = parseUnary();
             if (!isArith(a->type))
