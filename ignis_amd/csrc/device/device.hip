@@ -25,7 +25,7 @@
 #include "ig_expr.h"
 
 namespace igdev {
-void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20);
+void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20, bool deep_primary = false);
 int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
@@ -372,6 +372,17 @@ struct igd_device {
     // scene, but the 16 M-triangle stand-in sends enough rays there that the full grid is +9 % on it, and an empty full-grid launch
     // costs nothing measurable on diamond_scene (profiles/r02_experiment_ab.txt)
     int deep_grid = 1 << 20;
+    // Rays of this scene outgrow the LDS stack often enough (> 1 % of the rays of a chunk, QueueState::deep_total) that the DEEP
+    // instantiation runs as the primary traversal kernel: its lanes spill to their HBM columns instead of being listed and
+    // re-traversed from the root by a second launch. Decided from the counts the device reads back anyway; results do not depend
+    // on it. IGD_DEEP_PRIMARY=0 / 1 fixes it.
+    bool deep_primary = false;
+    int deep_primary_mode = -1; // -1 adaptive, 0 never, 1 always
+    void noteDeep(unsigned long long deep_total, unsigned long long rays)
+    {
+        if (deep_primary_mode < 0 && !deep_primary && deep_total * 100ull > rays)
+            deep_primary = true;
+    }
     int shadeGrid() const { return num_cus * shade_mult; }
 
     hipEvent_t event(size_t i)
@@ -478,7 +489,19 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: prim BVH offset out of range" };
         uint32_t node_count;
         std::memcpy(&node_count, s->primbvh + off, 4);
-        ext[i] = make_uint2((uint32_t)(off + 16), (uint32_t)(off + 16 + (uint64_t)node_count * sizeof(ig_node8)));
+        if ((off & 3u) || off + 16 + (uint64_t)node_count * sizeof(ig_node8) > s->primbvh_size)
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: prim BVH table is misaligned or truncated" };
+        // bit 0 of .x: the shape's BVH is one node whose only child (slot 0) is a triangle leaf; the entity-leaf section of
+        // k_traverse then does that node's visit itself (traverse_core.h)
+        uint32_t one_leaf = 0;
+        if (node_count == 1) {
+            ig_node8 root;
+            std::memcpy(&root, s->primbvh + off + 16, sizeof(root));
+            one_leaf = root.child[0] < 0;
+            for (int c = 1; c < 8; ++c)
+                one_leaf &= root.child[c] == 0 ? 1u : 0u;
+        }
+        ext[i] = make_uint2((uint32_t)(off + 16) | one_leaf, (uint32_t)(off + 16 + (uint64_t)node_count * sizeof(ig_node8)));
     }
     d->leaf_ext.upload(ext.data(), ext.size());
     d->leaves.upload(s->scene_leaves, s->scene_leaf_count);
@@ -627,6 +650,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->camera               = s->camera;
     // scenes without a principled BSDF, textured environment or sun light run the lean shading kernels
     d->full_bsdfs = false;
+    d->deep_primary = d->deep_primary_mode == 1; // a new scene starts with the LDS-stack kernels again
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
@@ -736,6 +760,7 @@ void collect(igd_device* d, igd_device::Flight& f)
     d->stats.shadow_rays += q.shadow_rays;
     d->stats.unoccluded += q.unoccluded;
     d->stats.tail_rays += q.tail_rays;
+    d->noteDeep(q.deep_total, q.camera_rays + q.bounce_rays + q.shadow_rays);
     d->stats.nodes_primary += q.nodes[0], d->stats.nodes_secondary += q.nodes[1];
     d->stats.tris_primary += q.tris[0], d->stats.tris_secondary += q.tris[1];
     d->stats.leaves_primary += q.leaves[0], d->stats.leaves_secondary += q.leaves[1];
@@ -963,7 +988,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.qs           = iq;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.sphere_work_counter = &iq->work_counter[4];
-            launch_traverse(ta, false, false, d->traverseGrid(), &iq->work_counter[1], st);
+            launch_traverse(ta, false, false, d->traverseGrid(), &iq->work_counter[1], st, d->deep_grid, d->deep_primary);
             InfoArgs ia{};
             ia.scene   = d->dscene;
             ia.in      = in;
@@ -1108,7 +1133,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.sphere_work_counter = &qs->work_counter[4];
-            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid); });
+            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid, d->deep_primary); });
 
             ShadeArgs sa{};
             sa.scene     = d->dscene;
@@ -1160,7 +1185,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.inv_spi = inv;
             tb.atomic_splat = light_tracer ? 1 : 0;
             timed(3, on, [&] {
-                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid);
+                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid, d->deep_primary);
                 launch_secondary_end(qs, in_slot ^ 1, mirror, on);
             });
             d->stats.rounds++;
@@ -1196,6 +1221,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 if (hq.error_flags & 1u)
                     break; // reported by collect()
                 known_live = hq.q[(r & 1) ^ 1].primary; // in_slot after round r (starts at 0, flips every round)
+                d->noteDeep(hq.deep_total, (unsigned long long)n + hq.bounce_rays + hq.shadow_rays);
             }
             live = known_live;
             if (round > d->dscene.tech.max_depth + 8)
@@ -1398,7 +1424,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     for (int r = 0; r < repeat; ++r) {
         HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, sizeof(qs->work_counter) + sizeof(qs->deep_count), st));
         HIP_CHECK(hipEventRecord(d->event(0), st));
-        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st);
+        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st, d->deep_grid, d->deep_primary);
         HIP_CHECK(hipEventRecord(d->event(1), st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms = 0;
@@ -1598,6 +1624,10 @@ igd_device* igd_create(const igd_setup* setup)
             d->shade_mult = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_DEEP_GRID"))
             d->deep_grid = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("IGD_DEEP_PRIMARY")) {
+            d->deep_primary_mode = std::atoi(e) ? 1 : 0;
+            d->deep_primary      = d->deep_primary_mode == 1;
+        }
         if (const char* e = std::getenv("IGD_BATCH_RAYS"))
             d->batch_rays = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_THRESHOLD"))

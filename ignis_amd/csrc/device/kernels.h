@@ -95,6 +95,7 @@ struct QueueState {
     // ---- from here on: cleared once per igd_render, not per chunk
     uint32_t error_flags;      // bit 0: traversal stack overflow
     uint32_t tail_rays;        // paths handed to the tail kernel (tail.hip)
+    uint32_t deep_total;       // sum of deep_count over the chunk's launches: the host switches to DEEP-as-primary launches on it
     // statistics (Statistics.h:57-64)
     unsigned long long camera_rays, bounce_rays, shadow_rays, unoccluded;
     unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches

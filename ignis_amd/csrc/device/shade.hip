@@ -458,6 +458,7 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
         qs->work_counter[3]        = 0;
         qs->work_counter[4]        = 0;
         qs->work_counter[5]        = 0;
+        qs->deep_total += qs->deep_count;
         qs->deep_count             = 0;
     }
 }
@@ -473,6 +474,7 @@ __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
         qs->work_counter[2] = 0;
         qs->work_counter[3] = 0;
         qs->work_counter[5] = 0;
+        qs->deep_total += qs->deep_count;
         qs->deep_count      = 0;
         if (mirror) {
             *mirror = *qs;

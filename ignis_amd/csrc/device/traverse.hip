@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             const uint32_t take  = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
             const uint32_t rank  = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!has_ray && rank < take) {
-                const uint32_t idx = DEEP ? a.index_list[batch_next + rank] : batch_next + rank;
+                const uint32_t idx = (DEEP && a.index_list) ? a.index_list[batch_next + rank] : batch_next + rank; // (DEEP as the primary kernel: no list)
                 ray_idx = idx;
                 has_ray = true;
                 const float4 ra = a.rayA[idx], rb = a.rayB[idx];
@@ -192,17 +192,26 @@ static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int g
 
 // Two launches: the LDS-stack kernel over the whole stream, then the DEEP kernel over the rays the first one
 // could not finish (almost always none: it reads one counter and exits). `deep_work_counter` must be zero.
-void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks)
+// `deep_primary`: the scene's rays are known to outgrow the LDS stack (device.hip watches the overflow counts): ONE launch of the
+// DEEP instantiation over the whole stream, whose lanes spill into their HBM columns as they go, instead of finishing most rays,
+// listing the rest and re-traversing those from the root.
+void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks, bool deep_primary)
 {
     TraverseArgs args = args_in;
     const bool spheres = args.scene.sphere_node_count != 0;
     args.sphere_pass   = spheres ? 1 : 0;
-    launch_one<false>(args, any_hit, stats, grid_blocks, stream);
-    TraverseArgs deep = args;
-    deep.count        = args.index_count;
-    deep.work_counter = deep_work_counter;
-    // (normally the same grid: the workgroups of an empty DEEP launch only read the counter)
-    launch_one<true>(deep, any_hit, stats, grid_blocks < deep_grid_blocks ? grid_blocks : deep_grid_blocks, stream);
+    if (deep_primary) {
+        TraverseArgs all = args;
+        all.index_list   = nullptr;
+        launch_one<true>(all, any_hit, stats, grid_blocks, stream);
+    } else {
+        launch_one<false>(args, any_hit, stats, grid_blocks, stream);
+        TraverseArgs deep = args;
+        deep.count        = args.index_count;
+        deep.work_counter = deep_work_counter;
+        // (normally the same grid: the workgroups of an empty DEEP launch only read the counter)
+        launch_one<true>(deep, any_hit, stats, grid_blocks < deep_grid_blocks ? grid_blocks : deep_grid_blocks, stream);
+    }
     if (spheres) {
         // the other SceneGeometry (driver/mapping_cpu.art:385-403): the sphere BVH, starting from the hits of the pass above.
         // Its stack never leaves LDS (a BVH over entities, not triangles); a ray that would need more raises the error flag.

@@ -34,14 +34,21 @@ namespace igdev {
 constexpr int kPostponeNum   = IG_POSTPONE_NUM;   // a section needs kPostponeNum / 2^kPostponeShift of the wave's active lanes
 constexpr int kPostponeShift = IG_POSTPONE_SHIFT; // (0 disables postponing)
 #ifndef IG_LDS_STACK
-#define IG_LDS_STACK 20
+#define IG_LDS_STACK 14
 #endif
 #ifndef IG_TRAV_OCC
-#define IG_TRAV_OCC 3
+#define IG_TRAV_OCC 4
 #endif
-constexpr int kLdsStack     = IG_LDS_STACK;  // 20 entries * 256 threads * 8 B = 40 KiB (+ 12 KiB of ray terms) per workgroup, 3 workgroups per CU
+// 14 entries * 256 threads * 8 B = 28 KiB (+ 12 KiB of ray terms) = 40 KiB per workgroup: four workgroups fill the 160 KiB of a CU, and
+// the kernels need 103 - 112 VGPRs (<= 128) since the loop restructuring of round 3. Scenes whose rays need more than 14 entries
+// (diamond_scene: 11) run the DEEP instantiation as their primary kernel (device.hip decides from the overflow counts it reads back).
+constexpr int kLdsStack     = IG_LDS_STACK;
 constexpr int kTraverseOcc  = IG_TRAV_OCC;   // workgroups of 256 per CU = waves per SIMD the kernel is built for
 constexpr int kBlockThreads = 256;
+#ifndef IG_MASK_LOADS
+#define IG_MASK_LOADS 1
+#endif
+constexpr bool kMaskLoads = IG_MASK_LOADS != 0; // experiments: 0 = every lane loads (from a safe address where the section does not concern it)
 
 // Per-lane LDS of one workgroup of BLOCK lanes. `e`: the traversal stacks, entry-major so that a wave's accesses are conflict
 // free. `g`: the scene-space ray terms (written once per ray by begin(), read by the entity-leaf section and by inner nodes of
@@ -53,6 +60,17 @@ struct StackOf {
     float4 g[3][BLOCK];
 };
 using StackLds = StackOf<kBlockThreads>;
+
+// An unspecified value that costs no instruction: what a register that is loaded under a per-lane condition holds in the other
+// lanes. (Left uninitialised in C++, such a register becomes a loop-carried value the compiler zero-fills with v_mov's.)
+IG_DEV float any_float()
+{
+    float u;
+    asm volatile("" : "=v"(u));
+    return u;
+}
+IG_DEV float4 any_float4() { return make_float4(any_float(), any_float(), any_float(), any_float()); }
+IG_DEV int4 any_int4() { return make_int4((int)igm_bits(any_float()), (int)igm_bits(any_float()), (int)igm_bits(any_float()), (int)igm_bits(any_float())); }
 
 IG_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 IG_DEV uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
@@ -290,106 +308,151 @@ struct Traverser {
             gray.inv_org = f3{ g0.w, g1.x, g1.y };
             gray.org     = f3{ g1.z, g1.w, g2.x };
             gray.dir     = f3{ g2.y, g2.z, g2.w };
-            // leaves whose box (or visibility mask) rejects the ray cost only this short loop
             const bool here = mode == 2;
             if (STATS)
                 sec_pass[0] += 1, sec_lane[0] += (uint32_t)__popcll(__ballot(here));
-            bool scanning   = here;
-            bool enter      = false;
-            int enter_at    = 0;
-            int entity_id   = 0;
-            do { // (at least one lane is scanning: the quorum is >= 1)
-                const int at     = scanning ? ent_cursor : 0;
-                const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + at);
-                const float4 l0 = lf[0], l1 = lf[1], l5 = lf[5];
-                ent_cursor += scanning ? 1 : 0;
-                const int id          = (int)igm_bits(l0.w);
-                const uint32_t lflags = igm_bits(l5.x);
-                ent_last              = scanning ? (id < 0) : ent_last;
-                if (STATS)
-                    st_leaves += scanning ? 1u : 0u;
-                // check_ray_visibility (traversal/ray.art:51)
-                const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
-                float entry, exit;
-                slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
-                const bool inside = scanning & visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
-                enter             = enter | inside;
-                enter_at          = sel(inside, at, enter_at);
-                entity_id         = sel(inside, id, entity_id);
-                scanning          = scanning & !inside & !(id < 0);
-            } while (__any(scanning));
-            if (__any(enter)) {
-                const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at);
-                const uint2 ext  = (SPHERES ? sc.sphere_leaf_ext : sc.leaf_ext)[enter_at];
-                const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4];
-                m34 m;
-                m.c0 = f3{ l2.x, l2.y, l2.z };
-                m.c1 = f3{ l2.w, l3.x, l3.y };
-                m.c2 = f3{ l3.z, l3.w, l4.x };
-                m.c3 = f3{ l4.y, l4.z, l4.w };
-                if (SPHERES) {
-                    // intersect_sphere (shapes/sphere.art:107-137) with the ray in shape space: direction not normalised, t global
-                    const f3 lorg = xform_point(m, gray.org), ldir = xform_dir(m, gray.dir);
-                    const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x); // centre, radius
-                    const f3 L     = lorg - f3{ sp.x, sp.y, sp.z };
-                    const float S  = -dot3(L, ldir);
-                    const float D2 = dot3(ldir, ldir);
-                    const float L2 = dot3(L, L);
-                    const float R2 = sp.w * sp.w * D2;
-                    const float M2 = L2 * D2 - S * S;
-                    const float Q   = igm_sqrt(R2 - M2);
-                    const float t0_ = (S - Q) / D2;
-                    const float t1_ = (S + Q) / D2;
-                    const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
-                    const float th = t0 < tmin ? t1 : t0;
-                    // accepted if in range (local_hit.distance <= hit.distance is implied by th <= tmax)
-                    const bool ok = enter & !((S < 0) | (M2 > R2)) & (th >= tmin) & (th <= tmax);
-                    // sphere_map_uv (sphere.art:1-6)
-                    const f3 n        = (L + ldir * th) * (1 / sp.w);
-                    const float theta = igm_acos(n.z);
-                    float phi         = igm_atan2(-n.x, n.y);
-                    phi               = phi < 0 ? phi + 2 * kPi : phi;
-                    tmax     = sel(ok, th, tmax);
-                    hit_u    = sel(ok, phi / (2 * kPi), hit_u);
-                    hit_v    = sel(ok, theta / kPi, hit_v);
-                    hit_prim = sel(ok, 0, hit_prim);
-                    hit_ent  = sel(ok, entity_id & 0x7FFFFFFF, hit_ent);
-                    if (ANY_HIT)
-                        finished = finished | ok;
-                } else {
-                    // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                    const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
-                    loc.org.x = sel(enter, nl.org.x, loc.org.x), loc.org.y = sel(enter, nl.org.y, loc.org.y), loc.org.z = sel(enter, nl.org.z, loc.org.z);
-                    loc.dir.x = sel(enter, nl.dir.x, loc.dir.x), loc.dir.y = sel(enter, nl.dir.y, loc.dir.y), loc.dir.z = sel(enter, nl.dir.z, loc.dir.z);
-                    loc.inv_dir.x = sel(enter, nl.inv_dir.x, loc.inv_dir.x), loc.inv_dir.y = sel(enter, nl.inv_dir.y, loc.inv_dir.y), loc.inv_dir.z = sel(enter, nl.inv_dir.z, loc.inv_dir.z);
-                    loc.inv_org.x = sel(enter, nl.inv_org.x, loc.inv_org.x), loc.inv_org.y = sel(enter, nl.inv_org.y, loc.inv_org.y), loc.inv_org.z = sel(enter, nl.inv_org.z, loc.inv_org.z);
-                    cur_ent = sel(enter, entity_id & 0x7FFFFFFF, cur_ent);
-                    // save the scene-level top, then a fresh stack: sentinel + shape root
-                    push_entry(st, tid, enter, top_node, top_tmin);
-                    lbase  = sel(enter, ptr, lbase);
-                    ltmax  = sel(enter, tmax, ltmax); // invalid_hit(local_ray.tmax)
-                    l_prim = sel(enter, -1, l_prim);
-                    lterm  = lterm & !enter;
-                    push_entry(st, tid, enter, 0, kFltMax);
-                    top_node = sel(enter, 1, top_node);
-                    top_tmin = sel(enter, tmin, top_tmin);
-                    level    = sel(enter, 1, level);
-                    node_off = sel(enter, ext.x, node_off);
-                    tri_off  = sel(enter, ext.y, tri_off);
+            bool scanning = here;
+            bool in_tris  = false; // entered a one-leaf shape whose only box the ray hits: straight on to its triangles
+            bool entered  = false; // SPHERES: the lane tested a sphere in this pass
+            // (the outer loop repeats only when a lane's one-leaf shape was missed inside its entity box and the run has leaves left)
+            do {
+                // leaves whose box (or visibility mask) rejects the ray cost only this short loop
+                bool enter    = false;
+                int enter_at  = 0;
+                int entity_id = 0;
+                do { // (at least one lane is scanning: the quorum is >= 1)
+                    const int at     = scanning ? ent_cursor : 0;
+                    const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + at);
+                    // (loads sit under per-lane conditions, like stores: a lane the section does not concern issues no memory
+                    // request — the L1 / texture path, not the VALU, is what this kernel keeps busiest, profiles/r03_pmc_*.txt —
+                    // and what it then computes from the undefined registers is discarded by the selects below)
+                    float4 l0 = any_float4(), l1 = any_float4(), l5 = any_float4();
+                    if (!kMaskLoads || scanning)
+                        l0 = lf[0], l1 = lf[1], l5 = lf[5];
+                    ent_cursor += scanning ? 1 : 0;
+                    const int id          = (int)igm_bits(l0.w);
+                    const uint32_t lflags = igm_bits(l5.x);
+                    ent_last              = scanning ? (id < 0) : ent_last;
+                    if (STATS)
+                        st_leaves += scanning ? 1u : 0u;
+                    // check_ray_visibility (traversal/ray.art:51)
+                    const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
+                    float entry, exit;
+                    slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
+                    const bool inside = scanning & visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
+                    enter             = enter | inside;
+                    enter_at          = sel(inside, at, enter_at);
+                    entity_id         = sel(inside, id, entity_id);
+                    scanning          = scanning & !inside & !(id < 0);
+                } while (__any(scanning));
+                if (__any(enter)) {
+                    const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at);
+                    uint2 ext = make_uint2(igm_bits(any_float()), igm_bits(any_float()));
+                    float4 l2 = any_float4(), l3 = any_float4(), l4 = any_float4();
+                    if (!kMaskLoads || enter) {
+                        ext = (SPHERES ? sc.sphere_leaf_ext : sc.leaf_ext)[enter_at];
+                        l2 = lf[2], l3 = lf[3], l4 = lf[4];
+                    }
+                    m34 m;
+                    m.c0 = f3{ l2.x, l2.y, l2.z };
+                    m.c1 = f3{ l2.w, l3.x, l3.y };
+                    m.c2 = f3{ l3.z, l3.w, l4.x };
+                    m.c3 = f3{ l4.y, l4.z, l4.w };
+                    if (SPHERES) {
+                        // intersect_sphere (shapes/sphere.art:107-137) with the ray in shape space: direction not normalised, t global
+                        const f3 lorg = xform_point(m, gray.org), ldir = xform_dir(m, gray.dir);
+                        const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + (enter ? ext.x : 0u)); // centre, radius
+                        const f3 L     = lorg - f3{ sp.x, sp.y, sp.z };
+                        const float S  = -dot3(L, ldir);
+                        const float D2 = dot3(ldir, ldir);
+                        const float L2 = dot3(L, L);
+                        const float R2 = sp.w * sp.w * D2;
+                        const float M2 = L2 * D2 - S * S;
+                        const float Q   = igm_sqrt(R2 - M2);
+                        const float t0_ = (S - Q) / D2;
+                        const float t1_ = (S + Q) / D2;
+                        const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
+                        const float th = t0 < tmin ? t1 : t0;
+                        // accepted if in range (local_hit.distance <= hit.distance is implied by th <= tmax)
+                        const bool ok = enter & !((S < 0) | (M2 > R2)) & (th >= tmin) & (th <= tmax);
+                        // sphere_map_uv (sphere.art:1-6)
+                        const f3 n        = (L + ldir * th) * (1 / sp.w);
+                        const float theta = igm_acos(n.z);
+                        float phi         = igm_atan2(-n.x, n.y);
+                        phi               = phi < 0 ? phi + 2 * kPi : phi;
+                        tmax     = sel(ok, th, tmax);
+                        hit_u    = sel(ok, phi / (2 * kPi), hit_u);
+                        hit_v    = sel(ok, theta / kPi, hit_v);
+                        hit_prim = sel(ok, 0, hit_prim);
+                        hit_ent  = sel(ok, entity_id & 0x7FFFFFFF, hit_ent);
+                        if (ANY_HIT)
+                            finished = finished | ok;
+                        entered = enter;
+                    } else {
+                        // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
+                        const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                        // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of leaf_ext.x by
+                        // igd_assign_scene) skips the inner-node section: its root visit is the slab test of that one child, done here
+                        // with the operations of the inner-node section. Hit: the state the root visit and the pop of the leaf
+                        // would have left (saved scene top on the stack, sentinel on top, in the triangle leaf). Miss: the state
+                        // `ret` would have restored, i.e. as if the entity's box had rejected the ray, and the run is scanned on.
+                        const bool single = enter & ((ext.x & 1u) != 0);
+                        bool missed       = false;
+                        int only_leaf     = 0;
+                        if (__any(single)) {
+                            const float* rn = reinterpret_cast<const float*>(geom + (single ? (ext.x & ~1u) : 0u));
+                            const int ox = nl.inv_dir.x < 0 ? 1 : 0, oy = nl.inv_dir.y < 0 ? 1 : 0, oz = nl.inv_dir.z < 0 ? 1 : 0;
+                            float nx = any_float(), fx = any_float(), ny = any_float(), fy = any_float(), nz = any_float(), fz = any_float();
+                            if (!kMaskLoads || single) {
+                                nx = rn[8 * ox], fx = rn[8 * (1 - ox)];
+                                ny = rn[8 * (2 + oy)], fy = rn[8 * (3 - oy)];
+                                nz = rn[8 * (4 + oz)], fz = rn[8 * (5 - oz)];
+                                only_leaf = reinterpret_cast<const int*>(rn)[48];
+                            }
+                            const float entry = igm_max(igm_max(igm_fma(nl.inv_dir.x, nx, nl.inv_org.x), igm_fma(nl.inv_dir.y, ny, nl.inv_org.y)), igm_max(igm_fma(nl.inv_dir.z, nz, nl.inv_org.z), tmin));
+                            const float exit  = igm_min(igm_min(igm_fma(nl.inv_dir.x, fx, nl.inv_org.x), igm_fma(nl.inv_dir.y, fy, nl.inv_org.y)), igm_min(igm_fma(nl.inv_dir.z, fz, nl.inv_org.z), tmax));
+                            missed     = single & (exit < entry);
+                            if (STATS)
+                                st_nodes += single ? 1u : 0u;
+                        }
+                        const bool go   = enter & !missed;
+                        const bool tris = single & !missed;
+                        loc.org.x = sel(go, nl.org.x, loc.org.x), loc.org.y = sel(go, nl.org.y, loc.org.y), loc.org.z = sel(go, nl.org.z, loc.org.z);
+                        loc.dir.x = sel(go, nl.dir.x, loc.dir.x), loc.dir.y = sel(go, nl.dir.y, loc.dir.y), loc.dir.z = sel(go, nl.dir.z, loc.dir.z);
+                        loc.inv_dir.x = sel(go, nl.inv_dir.x, loc.inv_dir.x), loc.inv_dir.y = sel(go, nl.inv_dir.y, loc.inv_dir.y), loc.inv_dir.z = sel(go, nl.inv_dir.z, loc.inv_dir.z);
+                        loc.inv_org.x = sel(go, nl.inv_org.x, loc.inv_org.x), loc.inv_org.y = sel(go, nl.inv_org.y, loc.inv_org.y), loc.inv_org.z = sel(go, nl.inv_org.z, loc.inv_org.z);
+                        cur_ent = sel(go, entity_id & 0x7FFFFFFF, cur_ent);
+                        // save the scene-level top, then a fresh stack: sentinel + shape root (one-leaf shapes: the sentinel is already
+                        // back on top, the root and its leaf entry have come and gone)
+                        push_entry(st, tid, go, top_node, top_tmin);
+                        lbase  = sel(go, ptr, lbase);
+                        ltmax  = sel(go, tmax, ltmax); // invalid_hit(local_ray.tmax)
+                        l_prim = sel(go, -1, l_prim);
+                        lterm  = lterm & !go;
+                        push_entry(st, tid, go & !tris, 0, kFltMax);
+                        top_node = sel(go, tris ? 0 : 1, top_node);
+                        top_tmin = sel(go, tris ? kFltMax : tmin, top_tmin);
+                        level    = sel(go, 1, level);
+                        node_off = sel(go, ext.x & ~1u, node_off);
+                        tri_off  = sel(go, ext.y, tri_off);
+                        tri_cursor = sel(tris, ~only_leaf, tri_cursor);
+                        in_tris    = in_tris | tris;
+                        // the one-leaf shape was missed: on with the run, if it has leaves left
+                        scanning = missed & !ent_last;
+                    }
                 }
-            }
+            } while (!SPHERES && __any(scanning));
             if (SPHERES) {
                 // a leaf run continues after a sphere test (the shape level of the triangle pass comes back through settle()'s
                 // `ret`; here the run is resumed directly): lanes that entered and have leaves left scan on in the next pass
-                const bool more = here & enter & !ent_last & !finished;
+                const bool more = here & entered & !ent_last & !finished;
                 mode            = sel(here & !more, 0, mode);
                 need_cull       = need_cull | (here & !more);
-                settle(sc, st, tid);
             } else {
-                mode      = sel(here, 0, mode);
-                need_cull = need_cull | here;
-                settle(sc, st, tid);
+                mode      = sel(here, in_tris ? 1 : 0, mode);
+                need_cull = need_cull | (here & !in_tris);
             }
+            settle(sc, st, tid);
         }
 
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
@@ -420,14 +483,20 @@ struct Traverser {
             // (empty slots are masked by child == 0).
             const int ox = inv.x < 0 ? 1 : 0, oy = inv.y < 0 ? 1 : 0, oz = inv.z < 0 ? 1 : 0;
             // two halves of four children keep the live register set small
+            int4 c4lo = any_int4(), c4hi = any_int4(); // both halves' child ids with the first batch of loads: the test for the second half does not cost a round trip of its own
+            if (!kMaskLoads || here)
+                c4lo = nc[0], c4hi = nc[1];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int4 c4 = nc[h];
+                const int4 c4 = h ? c4hi : c4lo;
                 if (h == 1 && !__any(here & ((c4.x | c4.y | c4.z | c4.w) != 0)))
                     break; // no lane has a child in the second half
-                const float4 nx = nf[2 * ox + h], fx = nf[2 * (1 - ox) + h];
-                const float4 ny = nf[2 * (2 + oy) + h], fy = nf[2 * (3 - oy) + h];
-                const float4 nz = nf[2 * (4 + oz) + h], fz = nf[2 * (5 - oz) + h];
+                float4 nx = any_float4(), fx = any_float4(), ny = any_float4(), fy = any_float4(), nz = any_float4(), fz = any_float4();
+                if (!kMaskLoads || here) {
+                    nx = nf[2 * ox + h], fx = nf[2 * (1 - ox) + h];
+                    ny = nf[2 * (2 + oy) + h], fy = nf[2 * (3 - oy) + h];
+                    nz = nf[2 * (4 + oz) + h], fz = nf[2 * (5 - oz) + h];
+                }
                 const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
                 const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
                 const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
@@ -458,7 +527,9 @@ struct Traverser {
                 tri_cursor += here ? 1 : 0;
                 // two triangles of the packet at a time (8-byte halves of its twelve SoA rows): 24 live registers instead
                 // of 48, and the second half is not even fetched when no lane's packet holds more than two triangles
-                const int4 pid4  = reinterpret_cast<const int4*>(tp)[12];
+                int4 pid4 = any_int4();
+                if (!kMaskLoads || here)
+                    pid4 = reinterpret_cast<const int4*>(tp)[12];
                 const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
                 bool valid       = here;
 #pragma unroll
@@ -468,9 +539,14 @@ struct Traverser {
                     const float2* tf = reinterpret_cast<const float2*>(tp) + h;
                     float q[12][2];
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        const float2 x = tf[2 * k];
-                        q[k][0] = x.x, q[k][1] = x.y;
+                    for (int k = 0; k < 12; ++k)
+                        q[k][0] = any_float(), q[k][1] = any_float();
+                    if (!kMaskLoads || here) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) {
+                            const float2 x = tf[2 * k];
+                            q[k][0] = x.x, q[k][1] = x.y;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
