@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "igd_device.h"
@@ -107,7 +108,9 @@ struct igd_device {
     DevBuf<uint8_t> geom, shape_data;
     size_t primbvh_bytes = 0; // the "trimesh_primbvh" fix table at the start of geom
     DevBuf<ig_entity_leaf1> leaves, sphere_leaves;
-    DevBuf<uint2> leaf_ext, sphere_leaf_ext;
+    DevBuf<float4> dev_leaves, dev_sphere_leaves; // DevScene::leaves / sphere_leaves (packed records)
+    std::vector<std::pair<uint64_t, uint32_t>> tri_spans; // where igd_assign_scene re-ordered triangle packets inside geom: (byte offset, packets)
+    DevBuf<uint8_t> geom_ref; // "trimesh_primbvh" in the reference's Tri4 layout, rebuilt from geom when the named buffer is asked for
     DevBuf<float> secondary_hit; // scenes with spheres: occlusion verdict of the triangle pass for the sphere pass (float4 per shadow ray)
     DevBuf<float> entities;
     DevBuf<uint64_t> shape_offsets;
@@ -463,6 +466,23 @@ void assignScene(igd_device* d, const igd_scene* s)
 
     // geometry blob: prim BVH fix table, then the scene BVH nodes
     std::vector<uint8_t> blob(s->primbvh, s->primbvh + s->primbvh_size);
+    // Triangle packets in the order the triangle section reads them: the two halves of a packet (triangles 0-1, 2-3) are 96
+    // contiguous bytes each — six 16-byte loads per half instead of twelve 8-byte ones — followed by the prim ids:
+    //   half h, float 2 k + j = row k (v0.xyz, e1.xyz, e2.xyz, n.xyz) of triangle 2 h + j.
+    auto repackTris = [&](uint64_t off, uint32_t node_count, uint32_t tri_count) {
+        uint8_t* base = blob.data() + off + 16 + (size_t)node_count * sizeof(ig_node8);
+        for (uint32_t t = 0; t < tri_count; ++t) {
+            float src[48], dst[48];
+            std::memcpy(src, base + (size_t)t * sizeof(ig_tri4), sizeof(src));
+            for (int h = 0; h < 2; ++h)
+                for (int k = 0; k < 12; ++k)
+                    for (int j = 0; j < 2; ++j)
+                        dst[h * 24 + k * 2 + j] = src[k * 4 + 2 * h + j];
+            std::memcpy(base + (size_t)t * sizeof(ig_tri4), dst, sizeof(dst));
+        }
+    };
+    std::unordered_set<uint64_t> packed_shapes;
+    d->tri_spans.clear();
     blob.resize((blob.size() + 255) & ~(size_t)255);
     const uint32_t scene_nodes_off = (uint32_t)blob.size();
     const uint8_t* sn              = reinterpret_cast<const uint8_t*>(s->scene_nodes);
@@ -476,46 +496,68 @@ void assignScene(igd_device* d, const igd_scene* s)
     if (blob.size() >= ((size_t)1 << 32))
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: BVH blob exceeds 4 GiB (32-bit node offsets)" };
     blob.resize(blob.size() + 256); // tail padding: vector loads never run past the allocation
-    d->geom.upload(blob.data(), blob.size());
     d->primbvh_bytes = (size_t)s->primbvh_size;
+    d->geom_ref.release();
 
-    // per scene leaf: where its shape's Node8[] / Tri4[] start (EntityLeaf1.user = offset in floats,
-    // shapes/trimesh.art:201-219: header {node_count, tri_count, pad, pad}, nodes, tris)
-    std::vector<uint2> ext(s->scene_leaf_count);
+    // per scene leaf: its packed record (DevScene::leaves). Where its shape's Node8[] / Tri4[] start comes from EntityLeaf1.user
+    // (offset in floats, shapes/trimesh.art:201-219: header {node_count, tri_count, pad, pad}, nodes, tris).
+    auto packLeaf = [](const ig_entity_leaf1& l, float4* r) {
+        r[0] = make_float4(l.min[0], l.min[1], l.min[2], igm_float((uint32_t)l.entity_id));
+        r[1] = make_float4(l.max[0], l.max[1], l.max[2], igm_float(l.flags));
+        r[2] = make_float4(l.local[0], l.local[1], l.local[2], l.local[3]);
+        r[3] = make_float4(l.local[4], l.local[5], l.local[6], l.local[7]);
+        r[4] = make_float4(l.local[8], l.local[9], l.local[10], l.local[11]);
+        r[5] = r[6] = r[7] = make_float4(0, 0, 0, 0);
+    };
+    std::vector<float4> dl((size_t)s->scene_leaf_count * kDevLeafRows + kDevLeafRows); // (+ one record of padding)
     for (uint32_t i = 0; i < s->scene_leaf_count; ++i) {
         const ig_entity_leaf1& l = s->scene_leaves[i];
         const uint64_t off       = (((uint64_t)(uint32_t)l.user[1] << 32) | (uint64_t)(uint32_t)l.user[0]) * 4;
         if (off + 16 > s->primbvh_size)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: prim BVH offset out of range" };
-        uint32_t node_count;
-        std::memcpy(&node_count, s->primbvh + off, 4);
-        if ((off & 3u) || off + 16 + (uint64_t)node_count * sizeof(ig_node8) > s->primbvh_size)
+        uint32_t hdr[2]; // node_count, tri_count
+        std::memcpy(hdr, s->primbvh + off, 8);
+        const uint64_t tris_at = off + 16 + (uint64_t)hdr[0] * sizeof(ig_node8);
+        if ((off & 3u) || tris_at + (uint64_t)hdr[1] * sizeof(ig_tri4) > s->primbvh_size)
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: prim BVH table is misaligned or truncated" };
-        // bit 0 of .x: the shape's BVH is one node whose only child (slot 0) is a triangle leaf; the entity-leaf section of
-        // k_traverse then does that node's visit itself (traverse_core.h)
+        if (packed_shapes.insert(off).second) {
+            repackTris(off, hdr[0], hdr[1]);
+            d->tri_spans.emplace_back(tris_at, hdr[1]);
+        }
+        float4* r = dl.data() + (size_t)i * kDevLeafRows;
+        packLeaf(l, r);
+        // bit 0 of the node offset: the shape's BVH is one node whose only child (slot 0) is a triangle leaf; the entity-leaf
+        // section of k_traverse then does that node's visit itself (traverse_core.h) from rows 6 and 7
         uint32_t one_leaf = 0;
-        if (node_count == 1) {
+        int32_t child0    = 0;
+        if (hdr[0] == 1) {
             ig_node8 root;
             std::memcpy(&root, s->primbvh + off + 16, sizeof(root));
             one_leaf = root.child[0] < 0;
             for (int c = 1; c < 8; ++c)
                 one_leaf &= root.child[c] == 0 ? 1u : 0u;
+            child0 = root.child[0];
+            r[6]   = make_float4(root.bounds[0][0], root.bounds[2][0], root.bounds[4][0], 0);
+            r[7]   = make_float4(root.bounds[1][0], root.bounds[3][0], root.bounds[5][0], 0);
         }
-        ext[i] = make_uint2((uint32_t)(off + 16) | one_leaf, (uint32_t)(off + 16 + (uint64_t)node_count * sizeof(ig_node8)));
+        r[5] = make_float4(igm_float((uint32_t)(off + 16) | one_leaf), igm_float((uint32_t)tris_at), igm_float((uint32_t)child0), 0);
     }
-    d->leaf_ext.upload(ext.data(), ext.size());
-    d->leaves.upload(s->scene_leaves, s->scene_leaf_count);
+    d->geom.upload(blob.data(), blob.size());
+    d->dev_leaves.upload(dl.data(), dl.size());
+    d->leaves.upload(s->scene_leaves, s->scene_leaf_count); // (reference layout: the "scene_bvh_leaves" named buffer)
     {
-        // per sphere leaf: where its {centre, radius} record sits in the "shapes" blob
-        std::vector<uint2> sext(s->sphere_leaf_count);
+        // sphere leaves: row 5 = where the {centre, radius} record sits in the "shapes" blob
+        std::vector<float4> sl((size_t)s->sphere_leaf_count * kDevLeafRows + kDevLeafRows);
         for (uint32_t i = 0; i < s->sphere_leaf_count; ++i) {
             const int32_t shape_id = s->sphere_leaves[i].shape_id;
             if (shape_id < 0 || (uint32_t)shape_id >= s->shape_count || s->shape_lookups[shape_id].type_id != IG_SHAPE_SPHERE
                 || s->shape_lookups[shape_id].offset + 16 > s->shape_data_size)
                 throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: sphere leaf without a valid sphere shape" };
-            sext[i] = make_uint2((uint32_t)s->shape_lookups[shape_id].offset, 0u);
+            float4* r = sl.data() + (size_t)i * kDevLeafRows;
+            packLeaf(s->sphere_leaves[i], r);
+            r[5] = make_float4(igm_float((uint32_t)s->shape_lookups[shape_id].offset), 0, 0, 0);
         }
-        d->sphere_leaf_ext.upload(sext.data(), sext.size());
+        d->dev_sphere_leaves.upload(sl.data(), sl.size());
         d->sphere_leaves.upload(s->sphere_leaves, s->sphere_leaf_count);
     }
 
@@ -600,12 +642,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.geom                 = d->geom.ptr;
     ds.scene_nodes_off      = scene_nodes_off;
     ds.scene_node_count     = s->scene_node_count;
-    ds.leaves               = d->leaves.ptr;
-    ds.leaf_ext             = d->leaf_ext.ptr;
+    ds.leaves               = d->dev_leaves.ptr;
     ds.sphere_nodes_off     = sphere_nodes_off;
     ds.sphere_node_count    = s->sphere_node_count;
-    ds.sphere_leaves        = d->sphere_leaves.ptr;
-    ds.sphere_leaf_ext      = d->sphere_leaf_ext.ptr;
+    ds.sphere_leaves        = d->dev_sphere_leaves.ptr;
     ds.entities             = d->entities.ptr;
     ds.shape_data           = d->shape_data.ptr;
     ds.shape_offsets        = d->shape_offsets.ptr;
@@ -1528,8 +1568,28 @@ NamedBuffer namedBuffer(igd_device* d, const char* name)
         return of(d->entities);
     if (n == "shapes")
         return NamedBuffer{ d->shape_data.ptr, d->shape_data.count ? (uint64_t)d->shape_data.count - 64 : 0 }; // (64 bytes of tail padding)
-    if (n == "trimesh_primbvh")
-        return NamedBuffer{ d->geom.ptr, d->geom.ptr ? (uint64_t)d->primbvh_bytes : 0 };
+    if (n == "trimesh_primbvh") {
+        // the device keeps the table with its triangle packets re-ordered (igd_assign_scene); whoever asks for the named table gets
+        // the reference's bytes, rebuilt once per scene
+        if (d->geom.ptr && d->primbvh_bytes && !d->geom_ref.ptr) {
+            std::vector<uint8_t> host(d->primbvh_bytes);
+            HIP_CHECK(hipMemcpy(host.data(), d->geom.ptr, host.size(), hipMemcpyDeviceToHost));
+            for (const auto& span : d->tri_spans) { // (byte offset of the first packet, packets)
+                for (uint32_t t = 0; t < span.second; ++t) {
+                    float dev[48], ref[48];
+                    uint8_t* at = host.data() + span.first + (size_t)t * sizeof(ig_tri4);
+                    std::memcpy(dev, at, sizeof(dev));
+                    for (int h = 0; h < 2; ++h)
+                        for (int k = 0; k < 12; ++k)
+                            for (int j = 0; j < 2; ++j)
+                                ref[k * 4 + 2 * h + j] = dev[h * 24 + k * 2 + j];
+                    std::memcpy(at, ref, sizeof(ref));
+                }
+            }
+            d->geom_ref.upload(host.data(), host.size());
+        }
+        return NamedBuffer{ d->geom_ref.ptr, d->geom_ref.ptr ? (uint64_t)d->primbvh_bytes : 0 };
+    }
     if (n == "scene_bvh_nodes")
         return NamedBuffer{ d->geom.ptr ? d->geom.ptr + d->dscene.scene_nodes_off : nullptr, (uint64_t)d->dscene.scene_node_count * sizeof(ig_node8) };
     if (n == "scene_bvh_leaves")
@@ -1720,9 +1780,10 @@ int32_t igd_release_all(igd_device* dev)
         dev->geom.release();
         dev->shape_data.release();
         dev->leaves.release();
-        dev->leaf_ext.release();
+        dev->dev_leaves.release();
+        dev->geom_ref.release();
         dev->sphere_leaves.release();
-        dev->sphere_leaf_ext.release();
+        dev->dev_sphere_leaves.release();
         dev->secondary_hit.release();
         dev->entities.release();
         dev->shape_offsets.release();

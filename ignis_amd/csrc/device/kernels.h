@@ -12,12 +12,21 @@ namespace igdev {
 // BVH node / Tri4 packet is addressed as geom + 32-bit byte offset (SGPR base + VGPR offset).
 constexpr int kDeepStack = 104; // traversal stack entries per lane beyond the LDS part, in DevScene::deep_stack
 
+constexpr int kDevLeafRows = 8; // float4 rows per packed scene-BVH leaf (DevScene::leaves)
+
 struct DevScene {
     const uint8_t* geom;
     uint32_t scene_nodes_off;      // byte offset of SceneBVH nodes inside geom
     uint32_t scene_node_count;     // 0: empty scene
-    const ig_entity_leaf1* leaves; // SceneBVH leaves
-    const uint2* leaf_ext;         // per leaf: {byte offset of its shape's Node8[], byte offset of its Tri4[]}
+    // SceneBVH leaves as the entity-leaf section of k_traverse reads them (kDevLeafRows rows of 16 bytes per leaf, packed by
+    // igd_assign_scene from the EntityLeaf1 table: the L1 / texture path is priced per load instruction and lane, so a leaf is
+    // scanned with two loads instead of three and a one-leaf shape's box comes with two instead of seven):
+    //   0: (min.xyz, entity_id)  1: (max.xyz, flags)            the scan of a run
+    //   2-4: the 3x4 to-local matrix                            entering
+    //   5: (byte offset of the shape's Node8[] | bit 0: the shape's BVH is one node with one triangle leaf in slot 0,
+    //       byte offset of its Tri4 packets, that leaf's child word, 0); spheres: (byte offset of {centre, radius} in shape_data, 0, 0, 0)
+    //   6, 7: (lo.xyz, 0), (hi.xyz, 0) of that one child box
+    const float4* leaves;
     // shading tables
     const float* entities;         // 36 floats each
     const uint8_t* shape_data;     // dyn table "shapes" blob
@@ -50,8 +59,7 @@ struct DevScene {
     // sphere's {centre, radius} record in shape_data, 0}. sphere_node_count == 0: no spheres, no sphere pass
     uint32_t sphere_nodes_off;
     uint32_t sphere_node_count;
-    const ig_entity_leaf1* sphere_leaves;
-    const uint2* sphere_leaf_ext;
+    const float4* sphere_leaves; // same record layout as `leaves`
     uint2* deep_stack;
     uint32_t deep_stride;
     uint32_t deep_tail_base; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)

@@ -322,16 +322,16 @@ struct Traverser {
                 int entity_id = 0;
                 do { // (at least one lane is scanning: the quorum is >= 1)
                     const int at     = scanning ? ent_cursor : 0;
-                    const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + at);
+                    const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + at * kDevLeafRows;
                     // (loads sit under per-lane conditions, like stores: a lane the section does not concern issues no memory
                     // request — the L1 / texture path, not the VALU, is what this kernel keeps busiest, profiles/r03_pmc_*.txt —
                     // and what it then computes from the undefined registers is discarded by the selects below)
-                    float4 l0 = any_float4(), l1 = any_float4(), l5 = any_float4();
+                    float4 l0 = any_float4(), l1 = any_float4();
                     if (!kMaskLoads || scanning)
-                        l0 = lf[0], l1 = lf[1], l5 = lf[5];
+                        l0 = lf[0], l1 = lf[1];
                     ent_cursor += scanning ? 1 : 0;
                     const int id          = (int)igm_bits(l0.w);
-                    const uint32_t lflags = igm_bits(l5.x);
+                    const uint32_t lflags = igm_bits(l1.w);
                     ent_last              = scanning ? (id < 0) : ent_last;
                     if (STATS)
                         st_leaves += scanning ? 1u : 0u;
@@ -346,13 +346,11 @@ struct Traverser {
                     scanning          = scanning & !inside & !(id < 0);
                 } while (__any(scanning));
                 if (__any(enter)) {
-                    const float4* lf = reinterpret_cast<const float4*>((SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at);
-                    uint2 ext = make_uint2(igm_bits(any_float()), igm_bits(any_float()));
-                    float4 l2 = any_float4(), l3 = any_float4(), l4 = any_float4();
-                    if (!kMaskLoads || enter) {
-                        ext = (SPHERES ? sc.sphere_leaf_ext : sc.leaf_ext)[enter_at];
-                        l2 = lf[2], l3 = lf[3], l4 = lf[4];
-                    }
+                    const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at * kDevLeafRows;
+                    float4 l2 = any_float4(), l3 = any_float4(), l4 = any_float4(), l5 = any_float4();
+                    if (!kMaskLoads || enter)
+                        l2 = lf[2], l3 = lf[3], l4 = lf[4], l5 = lf[5];
+                    const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
                     m34 m;
                     m.c0 = f3{ l2.x, l2.y, l2.z };
                     m.c1 = f3{ l2.w, l3.x, l3.y };
@@ -391,7 +389,7 @@ struct Traverser {
                     } else {
                         // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
                         const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
-                        // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of leaf_ext.x by
+                        // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of row 5 of its leaf record by
                         // igd_assign_scene) skips the inner-node section: its root visit is the slab test of that one child, done here
                         // with the operations of the inner-node section. Hit: the state the root visit and the pop of the leaf
                         // would have left (saved scene top on the stack, sentinel on top, in the triangle leaf). Miss: the state
@@ -400,15 +398,15 @@ struct Traverser {
                         bool missed       = false;
                         int only_leaf     = 0;
                         if (__any(single)) {
-                            const float* rn = reinterpret_cast<const float*>(geom + (single ? (ext.x & ~1u) : 0u));
-                            const int ox = nl.inv_dir.x < 0 ? 1 : 0, oy = nl.inv_dir.y < 0 ? 1 : 0, oz = nl.inv_dir.z < 0 ? 1 : 0;
-                            float nx = any_float(), fx = any_float(), ny = any_float(), fy = any_float(), nz = any_float(), fz = any_float();
-                            if (!kMaskLoads || single) {
-                                nx = rn[8 * ox], fx = rn[8 * (1 - ox)];
-                                ny = rn[8 * (2 + oy)], fy = rn[8 * (3 - oy)];
-                                nz = rn[8 * (4 + oz)], fz = rn[8 * (5 - oz)];
-                                only_leaf = reinterpret_cast<const int*>(rn)[48];
-                            }
+                            float4 blo = any_float4(), bhi = any_float4();
+                            if (!kMaskLoads || single)
+                                blo = lf[6], bhi = lf[7];
+                            only_leaf = (int)igm_bits(l5.z);
+                            // (near / far plane by the sign of the inverse direction, as the inner-node section picks its rows)
+                            const bool ox = nl.inv_dir.x < 0, oy = nl.inv_dir.y < 0, oz = nl.inv_dir.z < 0;
+                            const float nx = sel(ox, bhi.x, blo.x), fx = sel(ox, blo.x, bhi.x);
+                            const float ny = sel(oy, bhi.y, blo.y), fy = sel(oy, blo.y, bhi.y);
+                            const float nz = sel(oz, bhi.z, blo.z), fz = sel(oz, blo.z, bhi.z);
                             const float entry = igm_max(igm_max(igm_fma(nl.inv_dir.x, nx, nl.inv_org.x), igm_fma(nl.inv_dir.y, ny, nl.inv_org.y)), igm_max(igm_fma(nl.inv_dir.z, nz, nl.inv_org.z), tmin));
                             const float exit  = igm_min(igm_min(igm_fma(nl.inv_dir.x, fx, nl.inv_org.x), igm_fma(nl.inv_dir.y, fy, nl.inv_org.y)), igm_min(igm_fma(nl.inv_dir.z, fz, nl.inv_org.z), tmax));
                             missed     = single & (exit < entry);
@@ -525,7 +523,7 @@ struct Traverser {
                     sec_pass[2] += 1, sec_lane[2] += (uint32_t)__popcll(__ballot(here));
                 const uint8_t* tp = geom + tri_off + (here ? (uint32_t)tri_cursor * 208u : 0u);
                 tri_cursor += here ? 1 : 0;
-                // two triangles of the packet at a time (8-byte halves of its twelve SoA rows): 24 live registers instead
+                // two triangles of the packet at a time (a 96-byte half of the re-ordered packet): 24 live registers instead
                 // of 48, and the second half is not even fetched when no lane's packet holds more than two triangles
                 int4 pid4 = any_int4();
                 if (!kMaskLoads || here)
@@ -536,18 +534,22 @@ struct Traverser {
                 for (int h = 0; h < 2; ++h) {
                     if (h == 1 && !__any(valid & (pid[2] != -1) & !(ANY_HIT & lterm)))
                         break;
-                    const float2* tf = reinterpret_cast<const float2*>(tp) + h;
-                    float q[12][2];
+                    // half h of the packet: 96 contiguous bytes, float 2 k + j = row k of triangle 2 h + j (igd_assign_scene re-orders the
+                    // reference's Tri4 that way): six 16-byte loads per half
+                    const float4* th = reinterpret_cast<const float4*>(tp) + 6 * h;
+                    float4 c[6];
 #pragma unroll
-                    for (int k = 0; k < 12; ++k)
-                        q[k][0] = any_float(), q[k][1] = any_float();
+                    for (int m = 0; m < 6; ++m)
+                        c[m] = any_float4();
                     if (!kMaskLoads || here) {
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) {
-                            const float2 x = tf[2 * k];
-                            q[k][0] = x.x, q[k][1] = x.y;
-                        }
+                        for (int m = 0; m < 6; ++m)
+                            c[m] = th[m];
                     }
+                    float q[12][2];
+#pragma unroll
+                    for (int m = 0; m < 6; ++m)
+                        q[2 * m][0] = c[m].x, q[2 * m][1] = c[m].y, q[2 * m + 1][0] = c[m].z, q[2 * m + 1][1] = c[m].w;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int i   = 2 * h + j;
