@@ -35,7 +35,9 @@ SCENE = os.path.join(ROOT, "scenes", "diamond_scene.json")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
 VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
-PROFILE_TAG = "r02"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+VALU_CYCLES_PER_INST = 3.5  # profiles/r03_valu_calibration.txt: 2.4 (2-source fp32 / logic) ... 4.4 (min / max / compare / 3-source), k_traverse's mix
+SHADER_GHZ = 2.1            # effective shader clock of the traversal launches (GRBM_GUI_ACTIVE / duration; 2.4 GHz is the boost limit)
+PROFILE_TAG = "r03"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
 DEFAULT_STEPS = 256
 
 
@@ -231,16 +233,29 @@ def main():
         if os.path.exists(tpath) and (W, H, spi) == (WIDTH, HEIGHT, SPI) and world == 1:
             tj = json.load(open(tpath))
             tk = next((v for k, v in tj["kernels"].items() if k.startswith("k_traverse<false, false, false")), None)  # <closest, no stats, not DEEP[, no spheres]>
-            if tk and tj.get("steps") == args.steps:
-                traffic, traffic_src = int(tk["hbm_bytes"]), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes of this command at {args.steps} steps, x2 read correction)"
+            pr = tj.get("closest_hit_per_ray")
+            rays_per_launch = n_primary / c_launches
+            if tk and (pr or tj.get("steps") == args.steps):
+                # The counters were collected on this command at tj["steps"] steps. Per launch they scale with the rays a launch
+                # traverses (the per-ray work of a deterministic workload does not depend on the wavefront size), so a run at another
+                # step count prices its own launches with the profiled per-ray figures.
+                scale = (rays_per_launch / pr["rays_per_launch_profiled"]) if pr else 1.0
+                traffic = int(pr["hbm_bytes"] * rays_per_launch) if pr else int(tk["hbm_bytes"])
+                traffic_src = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes of this command at {tj.get('steps')} steps, x2 read correction; "
+                               f"per-ray figure x the {rays_per_launch:.0f} rays per launch of this run)")
                 if "valu_lane_utilisation" in tk:
                     limiter = {"valu_lane_utilisation": tk["valu_lane_utilisation"], "wave_wait_share": tk.get("wave_wait_share"),
                                "wave_issue_share": tk.get("wave_issue_share"), "source": f"profiles/{tname} (SQ counters)"}
                 if tk.get("valu_lane_ops_per_launch"):
-                    # VALU line: lane operations that did work (SQ_INSTS_VALU x 64 x lane utilisation) per second; issue_frac = share of the VALU issue slots used
-                    g = tk["valu_lane_ops_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    # VALU line: wave64 VALU instructions per second against the issue slots of 1024 SIMDs; a slot is priced at the 2.4 - 4.4
+                    # cycles profiles/r03_valu_calibration.txt measured (3.5 for this kernel's mix of selects, compares, min / max and fma)
+                    insts = tk["valu_insts_per_launch"] * scale
+                    g = tk["valu_lane_ops_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
                     valu = {"achieved": round(g, 1), "peak": round(VALU_PEAK_GLANE_OPS, 1), "unit": "G lane-ops/s", "frac": round(g / VALU_PEAK_GLANE_OPS, 4),
-                            "issue_frac": tk.get("valu_issue_frac"), "source": f"profiles/{tname}"}
+                            "insts_per_ray": round(insts * 64.0 / rays_per_launch, 1),
+                            "issue_frac": round(insts * VALU_CYCLES_PER_INST / (1024 * SHADER_GHZ * 1e9 * avg_ms * 1e-3), 4),
+                            "issue_frac_note": f"{VALU_CYCLES_PER_INST} cycles per wave64 instruction (calibrated mix), {SHADER_GHZ} GHz under load",
+                            "source": f"profiles/{tname}"}
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,

@@ -2,6 +2,7 @@
 #include "hip_adapter_core.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace igadapter {
@@ -16,9 +17,12 @@ Core::Core(int gpu_index, bool acquire_stats, bool debug_trace, bool is_interact
     // "Normals" / "Albedo" are asked for by name only when the runtime's denoiser is on; keeping them costs two film buffers and
     // one extra camera-ray traversal at iteration 0
     setup.info_aovs = 1;
-    // igcli / igtrace call render() and read results much later: deferral (igd_device.h) is what batches their iterations.
-    // An interactive frontend (igview) wants every frame now.
-    setup.blocking_render = 0;
+    // IRenderDevice::render returns when the iteration is done (SURVEY 8b Threading; the runtime's Statistics timers sit around
+    // the call), so the adapter blocks like the reference's devices do. A frontend that only reads results at the end can opt
+    // into deferral — consecutive iterations batched into one wavefront (igd_device.h), +25 % on the headline workload — with
+    // IG_HIP_DEFERRED_RENDER=1. Interactive setups are never deferred by the device anyway.
+    const char* deferred  = std::getenv("IG_HIP_DEFERRED_RENDER");
+    setup.blocking_render = (deferred && *deferred && *deferred != '0') ? 0 : 1;
     mDev                  = igd_create(&setup);
     if (!mDev)
         mError = igd_last_error();

@@ -377,10 +377,13 @@ struct igd_device {
     int deep_grid = 1 << 20;
     // Rays of this scene outgrow the LDS stack often enough (> 1 % of the rays of a chunk, QueueState::deep_total) that the DEEP
     // instantiation runs as the primary traversal kernel: its lanes spill to their HBM columns instead of being listed and
-    // re-traversed from the root by a second launch. Decided from the counts the device reads back anyway; results do not depend
-    // on it. IGD_DEEP_PRIMARY=0 / 1 fixes it.
+    // re-traversed from the root by a second launch. Results do not depend on it. IGD_DEEP_PRIMARY=auto decides from the counts the
+    // device reads back anyway.
     bool deep_primary = false;
-    int deep_primary_mode = -1; // -1 adaptive, 0 never, 1 always
+    // -1 adaptive, 0 never, 1 always. Default: never — on the 16 M-triangle stand-in (16 - 24 entries needed, 14 in LDS) listing the
+    // overflowing rays and re-traversing them with the whole grid measured 1 409 Mrays/s against 1 375 with the DEEP kernel as primary
+    // (profiles/r03_experiment_standin.txt): the spill code in every push and pop costs all rays more than the re-traversal costs a few.
+    int deep_primary_mode = 0;
     void noteDeep(unsigned long long deep_total, unsigned long long rays)
     {
         if (deep_primary_mode < 0 && !deep_primary && deep_total * 100ull > rays)
@@ -988,11 +991,12 @@ void render(igd_device* d, const igd_render_settings* rs)
     if (per_it > 0 && chunk_rays >= per_it)
         chunk_rays = (chunk_rays / per_it) * per_it;
     const bool light_tracer = d->dscene.tech.type == IG_TECHNIQUE_LIGHTTRACER;
-    if (light_tracer && (row_stride != 1 || row_offset != 0 || list_mode || chunk_rays < per_it || d->setup.info_aovs))
+    if (light_tracer && (row_stride != 1 || row_offset != 0 || list_mode || chunk_rays < per_it))
         // a connection lands in any pixel of the film: its accumulator slot has to exist in the chunk that traces the path
-        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the light tracer needs the whole film in one wavefront (no row sharding, no ray lists, no info AOVs, stream capacity >= width * height * spi)" };
+        throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the light tracer needs the whole film in one wavefront (no row sharding, no ray lists, stream capacity >= width * height * spi)" };
 
-    if (d->setup.info_aovs && !list_mode && rs->iteration == 0) {
+    // (the light tracer has no camera-flagged rays, so the wrapper below never splats for it: "Normals" / "Albedo" stay zero)
+    if (d->setup.info_aovs && !list_mode && rs->iteration == 0 && !light_tracer) {
         // wrap_infobuffer_renderer (technique/internal/infobuffer.art:4-30): normals and albedo of the camera rays' first hits of
         // iteration 0. Run as a pass of its own in front of the wavefront — the same camera rays (same RNG), closest-hit
         // traversal, k_info, per-pixel sums in sample order — so the shading kernels do not carry it.
@@ -1684,8 +1688,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->shade_mult = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_DEEP_GRID"))
             d->deep_grid = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("IGD_DEEP_PRIMARY")) {
-            d->deep_primary_mode = std::atoi(e) ? 1 : 0;
+        if (const char* e = std::getenv("IGD_DEEP_PRIMARY")) { // 0 never (default), 1 always, -1 / auto: from the overflow counts
+            d->deep_primary_mode = (e[0] == 'a' || e[0] == '-') ? -1 : (std::atoi(e) ? 1 : 0);
             d->deep_primary      = d->deep_primary_mode == 1;
         }
         if (const char* e = std::getenv("IGD_BATCH_RAYS"))

@@ -23,6 +23,7 @@
 #include "floatimage.h"
 #include "jpeg.h"
 #include "pexpr.h"
+#include "hosek.h"
 
 #include <cstring>
 #include <fstream>
@@ -2441,6 +2442,64 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             out.d[3] = std::cos(half);
             out.d[4] = radiance.x, out.d[5] = radiance.y, out.d[6] = radiance.z;
             infinite.push_back(out);
+        } else if (type == "sky") {
+            // SkyLight.cpp:30-75 + skysun/SkyModel.cpp:9-54: the Hosek-Wilkie model (hosek.h) evaluated on the upper hemisphere into a
+            // 512 x 256 RGBA float image (row = angle from the zenith, column = azimuth shifted by pi / 4), which then is an ordinary
+            // textured environment light: bilinear filter, repeat border, marginal / conditional CDF of the image itself (no
+            // baking, no MIS compensation: setup_cdf2d(ctx, path, true, false)). As written there, what the model is handed as
+            // "solar elevation" is pi / 2 - elevation.
+            const SunAngles ea    = getSunAngles(l);
+            const V3 ground       = l.has("ground") ? getVector3(*l.find("ground"), "ground") : V3(0.8f, 0.8f, 0.8f);
+            const float turbidity = getConstNumber(l, "turbidity", 3.0f, lname);
+            constexpr size_t ResAz = 512, ResEl = 256; // skysun/SkySunConfig.h
+            const float solar_elevation = Pi / 2 - ea.elevation;
+            const float sun_se = std::sin(solar_elevation), sun_ce = std::cos(solar_elevation);
+            const hosek::ChannelState state[3] = { hosek::init(0, turbidity, ground.x, solar_elevation), hosek::init(1, turbidity, ground.y, solar_elevation),
+                                                   hosek::init(2, turbidity, ground.z, solar_elevation) };
+            // The reference writes the image to an EXR file (rows top to bottom, alpha dropped) and loads it back through Image::load,
+            // which gives RGB files an alpha of 1 and flips the rows (Image.cpp:108-121,709): row y of the model is row ResEl - 1 - y of
+            // the texture and of the image the CDF is computed from.
+            std::vector<float> rgba(ResAz * ResEl * 4), rgb(ResAz * ResEl * 3);
+            for (size_t y = 0; y < ResEl; ++y) {
+                const float theta = (Pi / 2) * y / (float)ResEl; // ELEVATION_RANGE * y / count
+                const float st = std::sin(theta), ct = std::cos(theta);
+                for (size_t x = 0; x < ResAz; ++x) {
+                    float azimuth = (2 * Pi) * x / (float)ResAz - Pi / 4;
+                    if (azimuth < 0)
+                        azimuth += 2 * Pi;
+                    const float cos_gamma = ct * sun_ce + st * sun_se * std::cos(azimuth - ea.azimuth);
+                    const float gamma     = std::acos(std::min(1.0f, std::max(-1.0f, cos_gamma)));
+                    const size_t at       = (ResEl - 1 - y) * ResAz + x;
+                    for (int k = 0; k < 3; ++k) {
+                        constexpr float CIEYSum = 106.856980f;
+                        const float radiance    = (float)hosek::radiance(state[k], theta, gamma) / CIEYSum;
+                        rgba[at * 4 + k] = rgb[at * 3 + k] = std::max(0.0f, radiance);
+                    }
+                    rgba[at * 4 + 3] = 1;
+                }
+            }
+            ig_texture rec{};
+            rec.width = (uint32_t)ResAz, rec.height = (uint32_t)ResEl;
+            rec.channels = IG_TEX_FLOAT_BIT | 4;
+            rec.filter   = IG_TEX_BILINEAR;
+            rec.wrap_u = rec.wrap_v = IG_WRAP_REPEAT;
+            sc->texture_data.resize((sc->texture_data.size() + 15) & ~(size_t)15);
+            rec.offset = sc->texture_data.size();
+            sc->texture_data.resize(rec.offset + rgba.size() * sizeof(float));
+            std::memcpy(&sc->texture_data[rec.offset], rgba.data(), rgba.size() * sizeof(float));
+            const int tex_id = (int)sc->textures.size();
+            sc->textures.push_back(rec);
+            const uint32_t cdf_off = appendEnvironmentCdf(sc->cdf_data, rgb, ResAz, ResEl, false);
+            const V3 scale         = getColor(l, "scale", V3(1, 1, 1), lname);
+            const M3 T             = l.has("transform") ? inverse(transpose(getTransform(l).L)) : M3{}; // SkyLight.cpp:58
+            out.type               = IG_LIGHT_ENV_TEXTURED;
+            out.d[0] = scale.x, out.d[1] = scale.y, out.d[2] = scale.z;
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r)
+                    out.d[3 + c * 3 + r] = T.m[r][c];
+            const uint32_t ints[4] = { (uint32_t)tex_id, cdf_off, (uint32_t)ResAz, (uint32_t)ResEl };
+            std::memcpy(&out.d[12], ints, sizeof(ints));
+            infinite.push_back(out);
         } else {
             fail("Light '" + lname + "': type '" + type + "' is not supported by the HIP backend");
         }
@@ -2832,6 +2891,13 @@ int32_t igh_eval_expression(const char* source, const float* vars, float result[
         g_last_error = e.what();
         return -1;
     }
+}
+
+double igh_eval_sky(int32_t channel, double turbidity, double albedo, double elevation, double theta, double gamma)
+{
+    if (channel < 0 || channel > 2 || !(turbidity >= 1 && turbidity <= 10))
+        return 0;
+    return igh::hosek::radiance(igh::hosek::init(channel, turbidity, albedo, elevation), theta, gamma);
 }
 
 const char* igh_last_error(void) { return g_last_error.c_str(); }

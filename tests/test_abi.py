@@ -105,10 +105,10 @@ def test_loader_bitmap_texture_matches_an_independent_png_decode():
     import zlib
     import numpy as np
     from ignis_amd.tables import LoadedScene
-    sc = LoadedScene.from_file(os.path.join(ROOT, "scenes", "many_point_lights_hip.json"), 64, 64)
+    sc = LoadedScene.from_file(os.path.join(ROOT, "scenes", "many_point_lights.json"), 64, 64)
     s = sc.scene
-    assert s.texture_count == 1
-    t = s.textures[0]
+    assert s.texture_count == 2  # [0] the sky light's model image (512 x 256 floats), [1] the bump map
+    t = s.textures[1]
     raw = open(os.path.join(ROOT, "scenes", "textures", "bumpmap.png"), "rb").read()
     pos, idat, hdr = 8, b"", None
     while pos < len(raw):

@@ -115,6 +115,12 @@ def test_adapter_core_renders_from_runtime_tables(diamond_scene):
     for it in range(3):
         dev.render(4, 128, 128, iteration=it, seed=5)
     np.testing.assert_array_equal(fb, dev.framebuffer())
+    # ... and to the oracle's image of the same three iterations (the adapter is one more way into the HIP path, checked like the others)
+    import oracle
+    ref = np.zeros((128, 128, 3), np.float32)
+    for it in range(3):
+        ref += oracle.render(diamond_scene, 4, 128, 128, iteration=it, seed=5)[0]
+    assert float(np.linalg.norm(fb - ref) / np.linalg.norm(ref)) <= 1e-4
     st = dev.stats()
     assert (stats[0], stats[1], stats[2]) == (st["camera_rays"], st["shadow_rays"], st["bounce_rays"])
     assert stats[4] == st["camera_rays"] + st["bounce_rays"] and stats[6] == st["shadow_rays"]
@@ -156,3 +162,31 @@ def test_blocking_render_contract(diamond_scene):
     np.testing.assert_array_equal(a.framebuffer(), b.framebuffer())
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_adapter_core_renders_the_light_tracer():
+    """The adapter keeps the "Normals" / "Albedo" film buffers (igd_setup.info_aovs) for the runtime's denoiser; a light tracer scene
+    renders through it all the same (no camera-flagged ray ever reaches the info-buffer wrapper, technique/internal/infobuffer.art:13,
+    so both stay zero) and gives the image of the direct C ABI."""
+    from ignis_amd import Device, LoadedScene
+    l = _lib()
+    path = os.path.join(SCENES, "evaluation", "cycles-lights-lt.json")
+    core = l.iga_create(0, 1, 0)
+    assert l.iga_ok(core), l.iga_error(core)
+    assert l.iga_set_scene_file(core, str(path).encode()), l.iga_error(core)
+    assert l.iga_assign_scene(core, None, None, None, 0), l.iga_error(core)  # (no database: the host library's tables)
+    for it in range(2):
+        assert l.iga_render(core, None, 4, 96, 96, it, 0, 7), l.iga_error(core)
+    fb = np.ctypeslib.as_array(l.iga_framebuffer_host(core, b""), shape=(96, 96, 3)).copy()
+    nrm = np.ctypeslib.as_array(l.iga_framebuffer_host(core, b"Normals"), shape=(96, 96, 3)).copy()
+    assert fb.sum() > 0 and not nrm.any()
+    sc = LoadedScene.from_file(str(path), 96, 96)
+    dev = Device(0, acquire_stats=1)
+    dev.assign_scene(sc)
+    for it in range(2):
+        dev.render(4, 96, 96, iteration=it, seed=7)
+    ref = dev.framebuffer()
+    dev.close()
+    assert float(np.linalg.norm(fb - ref) / np.linalg.norm(ref)) <= 1e-5  # (float atomics in the connection splats: order dependent)
+    l.iga_destroy(core)

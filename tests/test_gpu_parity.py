@@ -220,7 +220,7 @@ def test_analytic_integrator_answers(gpu_device):
 def test_spot_and_directional_lights_vs_oracle(gpu_device):
     """Spot lights (in the light hierarchy, with a soft falloff band) and a directional light next to point lights."""
     from ignis_amd.tables import LoadedScene
-    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s = json.load(open(os.path.join(SCENES, "many_point_lights.json")))
     s["lights"] = [l for l in s["lights"] if l["type"] != "env"][:4] + [
         {"type": "spot", "name": "S1", "position": [0.8, 1.5, 0.8], "direction": [-0.4, -1, -0.4], "cutoff": 35, "falloff": 20, "intensity": [6, 5, 4]},
         {"type": "spot", "name": "S2", "position": [-1.0, 0.5, 1.2], "direction": [1, -0.6, -1], "cutoff": 25, "falloff": 25, "power": [20, 20, 30]},
@@ -261,7 +261,7 @@ def test_error_paths(gpu_device):
 # checkerboard reflectance (a13, a14)
 def _many_lights_scene(w, h):
     from ignis_amd.tables import LoadedScene
-    return LoadedScene.from_file(os.path.join(SCENES, "many_point_lights_hip.json"), w, h)
+    return LoadedScene.from_file(os.path.join(SCENES, "many_point_lights.json"), w, h)
 
 
 def test_many_point_lights_radiance_vs_oracle(gpu_device):
@@ -348,7 +348,7 @@ def _compare_with_oracle(dev, scene, w, h, spi, seed, iters=1):
 
 
 def test_deep_bvh_spills_the_stack_to_hbm(tmp_path):
-    """A triangle soup whose boxes all overlap needs more stack entries than the 24 that live in LDS; the
+    """A triangle soup whose boxes all overlap needs more stack entries than the 14 that live in LDS; the
     rest goes to the per-lane global columns. Same hits, radiance and counters as the oracle (whose stack, like
     the reference's, has 64 entries)."""
     from ignis_amd import Device
@@ -369,12 +369,15 @@ def test_deep_bvh_spills_the_stack_to_hbm(tmp_path):
              "lights": [{"type": "point", "name": "p", "position": [0, 0, 5], "intensity": [10, 10, 10]}]}
     (tmp_path / "deep.json").write_text(json.dumps(scene))
     sc = LoadedScene.from_file(str(tmp_path / "deep.json"), 64, 64)
-    for env_tail in ("0", "100000000"):  # wavefront kernels / tail kernel
+    # wavefront kernels (overflowing rays listed and re-traversed / the DEEP kernel as primary) and the tail kernel
+    for env_tail, deep_primary in (("0", "0"), ("0", "1"), ("100000000", "0")):
         os.environ["IGD_TAIL_THRESHOLD"] = env_tail
+        os.environ["IGD_DEEP_PRIMARY"] = deep_primary
         try:
             dev = Device(0, acquire_stats=True)
         finally:
             del os.environ["IGD_TAIL_THRESHOLD"]
+            del os.environ["IGD_DEEP_PRIMARY"]
         tot = _compare_with_oracle(dev, sc, 64, 64, 2, seed=4)
         dev.close()
         assert tot["max_stack"] > 24  # otherwise this test does not reach the global part
@@ -449,7 +452,7 @@ def test_cli_renders_and_saves_the_mean_image(tmp_path, capsys):
 def test_multiple_runtimes_in_one_process():
     """src/tests/multiple_runtimes/main.cpp: several runtimes, one after another (and two alive at once), 8 spp each."""
     import ignis_amd
-    scenes = [os.path.join(SCENES, n) for n in ("diamond_scene.json", "many_point_lights_hip.json", "diamond_scene.json")]
+    scenes = [os.path.join(SCENES, n) for n in ("diamond_scene.json", "many_point_lights.json", "diamond_scene.json")]
     opts = ignis_amd.RuntimeOptions.makeDefault()
     opts.OverrideFilmSize = (64, 64)
     opts.SPI = 4
@@ -472,7 +475,7 @@ def test_multiple_runtimes_in_one_process():
 def test_image_reflectance_and_normal_map_vs_oracle(gpu_device, tmp_path):
     """Bitmap-textured diffuse reflectance (texture/image.art) and a normal-mapped conductor (bsdf/map.art:55-61)."""
     from ignis_amd.tables import LoadedScene
-    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s = json.load(open(os.path.join(SCENES, "many_point_lights.json")))
     s["textures"].append({"type": "bitmap", "name": "ntex", "filename": "textures/bumpmap.png", "filter_type": "bilinear", "linear": True,
                           "wrap_mode": "mirror"})
     for b in s["bsdfs"]:
@@ -537,7 +540,7 @@ def test_randomised_configurations_vs_oracle(monkeypatch):
     from ignis_amd import Device
     from ignis_amd.tables import LoadedScene
     rng = np.random.default_rng(2024)
-    scene_files = ["diamond_scene.json", "many_point_lights_hip.json"]
+    scene_files = ["diamond_scene.json", "many_point_lights.json"]
     for case in range(10):
         w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
         spi = int(rng.choice([1, 2, 3, 5, 8, 16]))
@@ -572,7 +575,7 @@ def test_device_reuse_across_sizes_and_scenes(diamond_scene):
     fresh device's (nothing leaks from the chunks still in flight when the change arrives)."""
     from ignis_amd import Device
     from ignis_amd.tables import LoadedScene
-    other = LoadedScene.from_file(os.path.join(SCENES, "many_point_lights_hip.json"), 80, 60)
+    other = LoadedScene.from_file(os.path.join(SCENES, "many_point_lights.json"), 80, 60)
     plan = [(diamond_scene, 64, 64, 4), (diamond_scene, 96, 32, 2), (other, 80, 60, 8), (diamond_scene, 33, 47, 1), (other, 64, 64, 4)]
     dev = Device(0)
     for scene, w, h, spi in plan:
@@ -624,7 +627,7 @@ def test_mirror_and_smooth_conductor_vs_oracle(gpu_device):
     """Conductors without roughness ("mirror", or roughness <= 1e-4): the delta branch of the conductor BSDF
     (bsdf/conductor.art:56-68) — no NEE at the vertex, Fresnel-weighted perfect reflection."""
     from ignis_amd.tables import LoadedScene
-    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s = json.load(open(os.path.join(SCENES, "many_point_lights.json")))
     for b in s["bsdfs"]:
         if b["name"] == "mat-Inner":
             b.clear()
@@ -796,7 +799,7 @@ def test_textured_environment_vs_oracle(gpu_device, tmp_path, filt, transform):
 def test_sun_light_with_other_lights_vs_oracle(gpu_device):
     """make_sun_light next to a constant environment and point lights (uniform and hierarchy selectors)."""
     from ignis_amd.tables import LoadedScene
-    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s = json.load(open(os.path.join(SCENES, "many_point_lights.json")))
     s["lights"] = s["lights"][:4] + [
         {"type": "sun", "name": "Sun", "direction": [0.3, 0.8, 0.5], "irradiance": [3, 2.8, 2.5], "angle": 4.0},
         {"type": "env", "name": "Sky", "radiance": [0.1, 0.15, 0.2]},
@@ -894,7 +897,7 @@ def test_volume_path_tracer_vs_oracle(gpu_device, media, nee):
     assert tot["bounce_rays"] > tot["camera_rays"]
 
 
-@pytest.mark.parametrize("scene_name,cap", [("diamond_scene.json", 0), ("diamond_scene_principled.json", 4096), ("many_point_lights_hip.json", 0)])
+@pytest.mark.parametrize("scene_name,cap", [("diamond_scene.json", 0), ("diamond_scene_principled.json", 4096), ("many_point_lights.json", 0)])
 def test_info_buffer_aovs_vs_oracle(scene_name, cap):
     """The "Normals" / "Albedo" AOVs the runtime adds for its denoiser: first hits of iteration 0's camera rays, unchanged by
     later iterations, cleared by name, refused when the device was created without them; the colour buffer is not affected."""
@@ -976,7 +979,7 @@ def test_blend_bsdf_vs_oracle(gpu_device):
     """Blends of unlike parts: diffuse + rough conductor, principled + glass (a delta part), plastic + mirror; a blend under
     a bump map."""
     from ignis_amd.tables import LoadedScene
-    s = json.load(open(os.path.join(SCENES, "many_point_lights_hip.json")))
+    s = json.load(open(os.path.join(SCENES, "many_point_lights.json")))
     base = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
     base["textures"] = s["textures"]
     for t in base["textures"]:

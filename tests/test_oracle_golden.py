@@ -153,7 +153,7 @@ def test_hierarchy_selector_is_unbiased():
 def test_light_hierarchy_table_layout():
     """LightHierarchy.cpp: 2n-1 nodes for n lights, leaves carry light ids, codes retrace the path."""
     import numpy as np
-    sc = LoadedScene.from_file(__import__("os").path.join(__import__("conftest").SCENES, "many_point_lights_hip.json"))
+    sc = LoadedScene.from_file(__import__("os").path.join(__import__("conftest").SCENES, "many_point_lights.json"))
     s = sc.scene
     n = s.light_count - s.infinite_light_count
     assert n == 10 and s.light_hierarchy_nodes == 2 * n - 1

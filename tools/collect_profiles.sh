@@ -5,7 +5,7 @@
 # usage: tools/collect_profiles.sh <tag> [suffix] [bench args ...]
 #   outputs under gpurun_out/<tag>/:  <tag>_bench<suffix>.json  <tag>_rocprofv3_stats<suffix>.txt  <tag>_rocprofv3_pmc<suffix>.txt  <tag>_traffic<suffix>.json
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 SUF=${2:-}
 shift; shift
 ARGS="$*"
@@ -33,7 +33,7 @@ timeout 900 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_B
 db() { find "$OUT/$1" -name "*.db" | head -1; }
 python tools/prof_summary.py stats "$(db stats$SUF)" > "$OUT/${TAG}_rocprofv3_stats$SUF.txt" 2>> "$OUT/summary.err"
 python tools/prof_summary.py pmc "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$(db pmc_MEM$SUF)" > "$OUT/${TAG}_rocprofv3_pmc$SUF.txt" 2>> "$OUT/summary.err"
-python tools/prof_summary.py traffic "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$STEPS" > "$OUT/${TAG}_traffic$SUF.json" 2>> "$OUT/summary.err"
+python tools/prof_summary.py traffic "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$STEPS" "$OUT/${TAG}_bench$SUF.json" > "$OUT/${TAG}_traffic$SUF.json" 2>> "$OUT/summary.err"
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT" | head -40
 tail -c 400 "$OUT/${TAG}_bench$SUF.json"

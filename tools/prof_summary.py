@@ -3,7 +3,7 @@
 usage:
   python tools/prof_summary.py stats <stats.db>                      kernel table of `--kernel-trace --stats`
   python tools/prof_summary.py pmc <pmc.db> [<pmc.db> ...]           per-kernel sum / per-launch mean of each counter
-  python tools/prof_summary.py traffic <fetch.db> <write.db> [<sq.db>|-] [steps]   JSON: HBM-side bytes per launch per kernel (+ VALU lane utilisation)
+  python tools/prof_summary.py traffic <fetch.db> <write.db> [<sq.db>|-] [steps] [bench.json]   JSON: HBM-side bytes per launch per kernel (+ VALU lane utilisation)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. Calibration inside the same run (known byte counts):
 k_generate writes exactly 68 B per camera ray (WRITE_SIZE matches to 6 digits -> no correction); k_copy_paths reads
@@ -47,7 +47,7 @@ def short(name):
     return n.split("(")[0]
 
 
-def traffic(fetch_db, write_db, sq_db=None, steps=None):
+def traffic(fetch_db, write_db, sq_db=None, steps=None, bench_json=None):
     f, w = counters(fetch_db), counters(write_db)
     sq = counters(sq_db) if sq_db else {}
     res = {"unit": "bytes per launch", "fetch_correction": 2.0, "steps": steps,
@@ -83,6 +83,21 @@ def traffic(fetch_db, write_db, sq_db=None, steps=None):
                 res["kernels"][short(k)]["valu_lane_ops_per_launch"] = int(lanes * util)
                 res["kernels"][short(k)]["valu_issue_frac"] = round(lanes / secs / peak, 4) if secs > 0 else None
                 res["kernels"][short(k)]["avg_ns_under_pmc"] = int(q["SQ_INSTS_VALU"]["avg_ns"])
+    # per-ray figures of the closest-hit traversal kernel, so that bench.py can scale them to whatever step count it is run with
+    # (the driver's --steps differs from the profiled one): rays per launch of the profiled command from its own bench line
+    if bench_json:
+        try:
+            b = json.loads(open(bench_json).read().strip().split("\n")[-1])
+            rays = b["rays"]["camera"] + b["rays"]["bounce"]
+            launches = b["roofline"]["launches"]
+            tk = next((v for k, v in res["kernels"].items() if k.startswith("k_traverse<false, false, false")), None)
+            if tk and launches and rays:
+                rpl = rays / launches
+                res["closest_hit_per_ray"] = {"rays_per_launch_profiled": rpl, "hbm_bytes": tk["hbm_bytes"] / rpl,
+                                              "valu_insts": tk.get("valu_insts_per_launch", 0) / rpl,
+                                              "valu_lane_ops": tk.get("valu_lane_ops_per_launch", 0) / rpl}
+        except Exception as e:  # noqa: BLE001
+            res["closest_hit_per_ray_error"] = str(e)
     print(json.dumps(res, indent=1))
 
 
@@ -94,6 +109,7 @@ if __name__ == "__main__":
         for p in sys.argv[2:]:
             pmc(p)
     elif mode == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None, int(sys.argv[5]) if len(sys.argv) > 5 else None)
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None, int(sys.argv[5]) if len(sys.argv) > 5 else None,
+                sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         sys.exit(__doc__)
