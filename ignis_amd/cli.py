@@ -2,9 +2,18 @@
 samples per pixel and write the EXR, printing the reference's statistics lines (ray counts, min/med/max Msamples/s).
 
     python -m ignis_amd.cli scenes/diamond_scene.json --spp 64 -o out.exr [--width W --height H --spi N --seed S --stats]
+    python -m ignis_amd.cli scenes/diamond_scene.json --spp 1024 --gpus 8 -o out.exr
+
+`--gpus N`: one process per GPU (spawned here, or by torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment). The film is tile-sharded — rank r renders rows r, r + N, ... of every iteration (igd_render_settings.row_offset /
+row_stride), scene replicated, no data-path exchange — and the only collective is ONE gather of the owned rows to rank 0 over RCCL
+(xGMI) when rendering is done (ignis_amd/sharding.py); rank 0 writes the EXR. The image is the single-GPU one bit for bit.
 """
 import argparse
 import math
+import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -16,7 +25,21 @@ def beautiful_time(ms):
     return f"{s:.3f}s" if s < 60 else f"{int(s // 60)}m {s % 60:.1f}s"
 
 
-def main(argv=None):
+def _spawn_ranks(argv, gpus):
+    """The launcher half of --gpus N: N copies of this command, one per GPU, rendezvous on 127.0.0.1."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "ignis_amd.cli"] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
+
+def main(argv=None, load=loadFromFile):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser(prog="ignis_amd.cli", description=__doc__.splitlines()[0])
     ap.add_argument("scene")
     ap.add_argument("-o", "--output", default="output.exr")
@@ -30,9 +53,34 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="iterations rendered as one wavefront per call (0 = as many as fill the GPU, 1 = like the reference)")
     ap.add_argument("--stats", action="store_true", help="acquire ray statistics and stage timers")
     ap.add_argument("--full-stats", action="store_true", help="also count traversal work (slower kernels)")
+    ap.add_argument("--gpus", type=int, default=1, help="tile-shard the film over this many GPUs of the node (one process each, one RCCL gather at the end)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend of --gpus N (nccl = RCCL over xGMI)")
     args = ap.parse_args(argv)
     if args.spp is None and args.time is None:
         args.spp = 64
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return _spawn_ranks(argv, args.gpus)
+    if world != max(1, args.gpus):
+        print(f"--gpus {args.gpus} does not match WORLD_SIZE {world}", file=sys.stderr)
+        return 2
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    sharded = world > 1 or bool(os.environ.get("IGNIS_CLI_FORCE_DIST"))  # (the variable: a single rank through the whole RCCL path, for tests)
+    if sharded:
+        if args.time is not None:
+            print("--time is not available with --gpus N (ranks must render the same iterations)", file=sys.stderr)
+            return 2
+        import torch  # first: its HIP runtime and RCCL are the ones the device library binds to in this process
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        args.gpu = local_rank
+    chatty = rank == 0
 
     t_all = time.perf_counter()
     opts = RuntimeOptions.makeDefault()
@@ -41,22 +89,27 @@ def main(argv=None):
     opts.Seed = args.seed
     opts.OverrideFilmSize = (args.width, args.height)
     opts.AcquireStats = True if args.full_stats else (1 if args.stats else False)
+    if sharded:
+        from . import sharding
+        opts.RowOffset, opts.RowStride = sharding.shard_settings(rank, world)
     t0 = time.perf_counter()
-    rt = loadFromFile(args.scene, opts)
+    rt = load(args.scene, opts)
     t_loading = time.perf_counter() - t0
 
     spi = rt.SPI
     desired_iter = int(math.ceil((args.spp or 0) / spi))
     if args.spp and args.spp % spi:
-        print(f"Given spp {args.spp} is not a multiple of the spi {spi}. Using spp {desired_iter * spi} instead", file=sys.stderr)
-    print("Started rendering...", file=sys.stderr)
+        if chatty:
+            print(f"Given spp {args.spp} is not a multiple of the spi {spi}. Using spp {desired_iter * spi} instead", file=sys.stderr)
+    if chatty:
+        print("Started rendering..." + (f" ({world} GPUs, film rows interleaved)" if world > 1 else ""), file=sys.stderr)
     samples_sec, t_render = [], 0.0
     batch = args.batch if args.batch > 0 else rt.recommendedBatch()
     while True:
         count = batch if desired_iter <= 0 else min(batch, desired_iter - rt.IterationCount)
         t0 = time.perf_counter()
         rt.stepMany(count)
-        rt._device.synchronize()  # per-call timing like the reference's blocking step()
+        rt.synchronize()  # per-call timing like the reference's blocking step()
         dt = time.perf_counter() - t0
         t_render += dt
         samples_sec += [spi * rt.FramebufferWidth * rt.FramebufferHeight * count / dt] * count
@@ -65,13 +118,39 @@ def main(argv=None):
         if args.time is not None and t_render > args.time:
             break
 
-    t0 = time.perf_counter()
-    ok = rt.saveFramebuffer(args.output)
-    t_saving = time.perf_counter() - t0
-    print(f"Result saved to {args.output}" if ok else f"Failed to save EXR file {args.output}", file=sys.stderr)
+    gathered = None
+    st = rt.getStatistics() if (args.stats or args.full_stats) else None
+    if sharded:
+        # the ONLY collective: the rows each rank owns, to rank 0 (W x H x 12 / world bytes per rank)
+        from . import sharding
+        t0 = time.perf_counter()
+        fb = rt.framebufferTensor(torch, on_device=args.backend == "nccl")
+        sharding.gather_rows(fb, rank, world, dist, dst=0)
+        if args.backend == "nccl":
+            torch.cuda.synchronize()
+        t_render += time.perf_counter() - t0
+        if rank == 0:
+            gathered = fb.cpu().numpy()
+        if st is not None:
+            keys = [k for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes", "tris", "leaves") if k in st]
+            c = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device=fb.device)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            st = dict(st, **{k: int(v) for k, v in zip(keys, c.tolist())})
+    ok = True
+    t_saving = 0.0
+    if rank == 0:
+        t0 = time.perf_counter()
+        ok = rt.saveFramebuffer(args.output, gathered)
+        t_saving = time.perf_counter() - t0
+        print(f"Result saved to {args.output}" if ok else f"Failed to save EXR file {args.output}", file=sys.stderr)
     ms_all = (time.perf_counter() - t_all) * 1e3
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        rt.shutdown()
+        return 0
     if args.stats or args.full_stats:
-        st = rt.getStatistics()
         total = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
         print("Statistics:\n"
               f"  Ray Count: {total}\n    Camera: {st['camera_rays']}\n    Bounce: {st['bounce_rays']}\n    Shadow: {st['shadow_rays']}\n"

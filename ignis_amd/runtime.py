@@ -186,8 +186,9 @@ class Runtime:
     InitialCameraOrientation = property(lambda self: self._initial_orientation)
 
     # -- Runtime::saveFramebuffer (Runtime.cpp:794-876): mean over the iterations so far, channels B, G, R
-    def saveFramebuffer(self, path):
-        fb = self._device.framebuffer()
+    def saveFramebuffer(self, path, fb=None):
+        """`fb`: the accumulated film to write instead of this device's own (the multi-GPU CLI hands rank 0 the gathered one)."""
+        fb = self._device.framebuffer() if fb is None else np.asarray(fb, dtype=np.float32)
         if self._opts.IsTracer:
             fb = fb.reshape(1, -1, 3)
         o = self.getCameraOrientation() if "__camera_eye" in self.VectorParameters else self._initial_orientation
@@ -199,6 +200,23 @@ class Runtime:
             return True
         except RuntimeError:
             return False
+
+    def synchronize(self):
+        """Everything submitted so far (deferred iterations, overlapped tails, resolves) has reached the framebuffer."""
+        self._device.synchronize()
+
+    def framebufferTensor(self, torch, on_device=True):
+        """The accumulated film as a torch tensor [H, W, 3] for the one collective of the tile-sharded path (ignis_amd/sharding.py):
+        a zero-copy view of the device framebuffer for the RCCL backend, a host copy for gloo."""
+        self._device.synchronize()
+        if not on_device:
+            return torch.from_numpy(np.ascontiguousarray(self._device.framebuffer()))
+
+        class _View:  # __cuda_array_interface__ over the device pointer (no copy)
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (self._height, self._width, 3), "typestr": "<f4", "data": (self._device.framebuffer_device_ptr(), False), "version": 2}
+        return torch.as_tensor(v, device=torch.device("cuda", self._opts.Device))
 
     def incFrameCount(self):
         self._frame += 1

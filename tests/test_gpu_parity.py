@@ -1448,3 +1448,22 @@ def test_expression_weights_of_blend_and_cutoff_vs_oracle(gpu_device):
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 10)) == 2
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=53, iters=2)
+
+
+def test_cli_single_rank_through_rccl(tmp_path):
+    """`python -m ignis_amd.cli --gpus N` with N = 1 forced through the whole sharded path (process group on the RCCL backend, zero-copy
+    torch view of the device framebuffer, gather of the owned rows, rank 0 writes): the EXR of the plain command, bit for bit."""
+    import subprocess
+    import sys
+    from test_abi import _read_exr
+    base = [sys.executable, "-m", "ignis_amd.cli", os.path.join(SCENES, "diamond_scene.json"), "--spp", "8", "--spi", "4", "--width", "64", "--height", "48", "--seed", "5"]
+    a, b = str(tmp_path / "plain.exr"), str(tmp_path / "rccl.exr")
+    root = os.path.dirname(SCENES)
+    subprocess.run(base + ["-o", a], check=True, cwd=root, capture_output=True)
+    env = dict(os.environ, IGNIS_CLI_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(base + ["-o", b, "--gpus", "1"], cwd=root, capture_output=True, env=env, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pa, _ = _read_exr(a)
+    pb, _ = _read_exr(b)
+    for ch in "RGB":
+        np.testing.assert_array_equal(pa[ch], pb[ch])

@@ -123,3 +123,83 @@ def test_shard_rows_partition():
         assert sorted(rows.tolist()) == list(range(37))
     with pytest.raises(ValueError):
         sharding.shard_rows(2, 2, 10)
+
+
+class _OracleRuntime:
+    """What ignis_amd.cli needs of a Runtime, with the oracle standing in for the device: the test is about the CLI's sharding,
+    its one collective and what rank 0 writes — not about the kernels (no GPU here)."""
+
+    def __init__(self, path, opts):
+        import oracle
+        from ignis_amd.tables import LoadedScene
+        self._oracle = oracle
+        w, h = opts.OverrideFilmSize
+        self._scene = LoadedScene.from_file(path, w, h)
+        self._opts = opts
+        self.FramebufferWidth, self.FramebufferHeight = w, h
+        self.SPI = opts.SPI
+        self.IterationCount = self.SampleCount = 0
+        self._fb = np.zeros((h, w, 3), np.float32)
+        self._stats = {"camera_rays": 0, "bounce_rays": 0, "shadow_rays": 0}
+
+    def recommendedBatch(self):
+        return 2
+
+    def stepMany(self, count):
+        for _ in range(count):
+            _, st = self._oracle.render(self._scene, self.SPI, self.FramebufferWidth, self.FramebufferHeight, iteration=self.IterationCount,
+                                        seed=self._opts.Seed, threads=2, fb=self._fb, rows=(self._opts.RowOffset, self._opts.RowStride))
+            for k in self._stats:
+                self._stats[k] += st[k]
+            self.IterationCount += 1
+            self.SampleCount += self.SPI
+
+    def synchronize(self):
+        pass
+
+    def framebufferTensor(self, torch, on_device=True):
+        assert not on_device
+        return torch.from_numpy(self._fb)
+
+    def getStatistics(self):
+        return dict(self._stats)
+
+    def saveFramebuffer(self, path, fb=None):
+        from ignis_amd.tables import save_exr
+        save_exr(path, self._fb if fb is None else np.asarray(fb, np.float32), 1.0 / max(1, self.IterationCount), {"igSPP": self.SampleCount})
+        return True
+
+    def shutdown(self):
+        self._scene.close()
+
+
+def _cli_rank(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ignis_amd import cli
+    rc = cli.main([os.path.join(SCENES, "diamond_scene.json"), "--spp", str(3 * SPI), "--spi", str(SPI), "--width", str(W), "--height", str(H),
+                   "--seed", str(SEED), "-o", out_path, "--gpus", str(world), "--backend", "gloo", "--stats"], load=_OracleRuntime)
+    assert rc == 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cli_gpus_n_entry_point_over_gloo(tmp_path, world):
+    """`python -m ignis_amd.cli --gpus N` (the product entry point of the tile-sharded path): every rank runs cli.main with its
+    RANK / WORLD_SIZE, renders the rows it owns, ONE gather of the owned rows, rank 0 alone writes the EXR = mean over the
+    iterations of the single-process image."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    from test_abi import _read_exr
+
+    out = str(tmp_path / "sharded.exr")
+    mp.spawn(_cli_rank, args=(world, _free_port(), out), nprocs=world, join=True)
+    planes, attrs = _read_exr(out)
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), W, H)
+    ref = np.zeros((H, W, 3), np.float32)
+    for it in range(3):
+        oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=ref)
+    np.testing.assert_allclose(got, ref / np.float32(3), rtol=2e-5, atol=1e-6)
+    assert attrs["igSPP"][1] == str(3 * SPI).encode()
