@@ -24,6 +24,7 @@
 #include "igd_device.h"
 #include "kernels.h"
 #include "ig_expr.h"
+#include "ig_photon.h"
 
 namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20, bool deep_primary = false);
@@ -38,6 +39,11 @@ void launch_info(const InfoArgs& args, int grid_blocks, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
 void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
+// photon.hip (IG_TECHNIQUE_PPM)
+void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
+size_t photon_grid_temp_bytes(uint32_t n);
+void build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count, uint32_t* cell_offset, unsigned long long* keys, uint32_t* valid,
+                       void* temp, size_t temp_bytes, hipStream_t stream);
 } // namespace igdev
 
 using namespace igdev;
@@ -110,6 +116,14 @@ struct igd_device {
     DevBuf<ig_entity_leaf1> leaves, sphere_leaves;
     DevBuf<float4> dev_leaves, dev_sphere_leaves; // DevScene::leaves / sphere_leaves (packed records)
     std::vector<std::pair<uint64_t, uint32_t>> tri_spans; // where igd_assign_scene re-ordered triangle packets inside geom: (byte offset, packets)
+    // photon mapper (IG_TECHNIQUE_PPM): photons by light path index, the same in grid order, sort keys, cell counts / offsets
+    DevBuf<igp_photon> ppm_photons, ppm_sorted;
+    DevBuf<unsigned long long> ppm_keys;
+    DevBuf<uint32_t> ppm_cell_count, ppm_cell_offset, ppm_valid;
+    DevBuf<uint8_t> ppm_temp;
+    DevBuf<QueueState> ppm_qs;
+    uint32_t ppm_valid_host = 0;
+    float scene_bbox[6] = {}; // igd_scene.bbox_min / bbox_max (the photon grid's extent)
     DevBuf<uint8_t> geom_ref; // "trimesh_primbvh" in the reference's Tri4 layout, rebuilt from geom when the named buffer is asked for
     DevBuf<float> secondary_hit; // scenes with spheres: occlusion verdict of the triangle pass for the sphere pass (float4 per shadow ray)
     DevBuf<float> entities;
@@ -676,8 +690,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
     ds.scene_radius         = s->scene_radius;
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k) {
         ds.scene_center[k] = s->bbox_min[k] + (s->bbox_max[k] - s->bbox_min[k]) * 0.5f; // bbox_center (core/bbox.art:22)
+        d->scene_bbox[k] = s->bbox_min[k], d->scene_bbox[3 + k] = s->bbox_max[k];
+    }
     ds.textures             = d->textures.ptr;
     ds.texture_data         = d->texture_data.ptr;
     ds.cdf_data             = d->cdf_data.ptr;
@@ -701,8 +717,21 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
     d->full_bsdfs |= simple_selector;
     if (s->technique.type != IG_TECHNIQUE_PATH && s->technique.type != IG_TECHNIQUE_AO && s->technique.type != IG_TECHNIQUE_VOLPATH && s->technique.type != IG_TECHNIQUE_DEBUG
-        && s->technique.type != IG_TECHNIQUE_LIGHTTRACER && s->technique.type != IG_TECHNIQUE_WIREFRAME)
+        && s->technique.type != IG_TECHNIQUE_LIGHTTRACER && s->technique.type != IG_TECHNIQUE_WIREFRAME && s->technique.type != IG_TECHNIQUE_PPM)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
+    if (s->technique.type == IG_TECHNIQUE_PPM) {
+        // the light pass samples emission like the light tracer (lt_core.h); photons per iteration bounded by what a launch can index
+        for (uint32_t i = 0; i < s->light_count; ++i) {
+            const int lt = s->lights[i].type;
+            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_SPHERE && lt != IG_LIGHT_SUN && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the photon mapper samples emission of point, spot, area, directional, sun and constant environment lights only" };
+        }
+        if (s->technique.photon_count < 1 || s->technique.photon_count > (1 << 28) || s->technique.max_light_depth < 0 || !(s->technique.merge_radius >= 0))
+            throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: photon mapper parameters out of range" };
+        if (s->sphere_node_count)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the photon mapper is not lowered for scenes with analytic spheres" };
+        d->full_bsdfs = true;
+    }
     if (s->technique.type == IG_TECHNIQUE_WIREFRAME) {
         if ((s->camera.type != IG_CAMERA_PERSPECTIVE && s->camera.type != IG_CAMERA_ORTHOGONAL) || s->sphere_node_count)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the wireframe technique is lowered for perspective / orthogonal cameras and triangle meshes" };
@@ -991,6 +1020,112 @@ void render(igd_device* d, const igd_render_settings* rs)
     if (per_it > 0 && chunk_rays >= per_it)
         chunk_rays = (chunk_rays / per_it) * per_it;
     const bool light_tracer = d->dscene.tech.type == IG_TECHNIQUE_LIGHTTRACER;
+    const bool ppm          = d->dscene.tech.type == IG_TECHNIQUE_PPM;
+    if (ppm) {
+        if (list_mode)
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the photon mapper renders camera films only (no ray lists)" };
+        chunk_rays = std::min(chunk_rays, per_it); // a chunk never spans two iterations: each has its own photon map
+    }
+    PpmArgs ppm_args{};
+    // The light pass of iteration `iteration` and its query structure (photonmapper.art: variant 0, then ppm_handle_before_iteration_camera),
+    // stream-ordered in front of that iteration's camera wavefront. Plain rounds: closest-hit traversal + k_shade<light pass>, no shadow
+    // rays, the live count read back after every round (a light path ends at its first non-delta surface: a handful of rounds).
+    auto photonPass = [&](int iteration) {
+        const ig_technique& tech = d->dscene.tech;
+        const uint32_t P         = (uint32_t)tech.photon_count;
+        d->ppm_photons.alloc(P);
+        d->ppm_sorted.alloc(P);
+        d->ppm_keys.alloc((size_t)P * 2);
+        d->ppm_cell_count.alloc(IGP_GRID_CELLS + 1);
+        d->ppm_cell_offset.alloc(IGP_GRID_CELLS + 1);
+        d->ppm_valid.alloc(1);
+        d->ppm_qs.alloc(1);
+        const size_t temp_bytes = photon_grid_temp_bytes(P);
+        d->ppm_temp.alloc(temp_bytes);
+        QueueState* lq = d->ppm_qs.ptr;
+        HIP_CHECK(hipMemsetAsync(d->ppm_photons.ptr, 0xFF, (size_t)P * sizeof(igp_photon), st)); // light = -1: no photon
+        ppm_args.pass         = 1;
+        ppm_args.photons      = d->ppm_photons.ptr;
+        ppm_args.cell_offset  = d->ppm_cell_offset.ptr;
+        ppm_args.photon_count = (int32_t)P;
+        ppm_args.valid_count  = 0;
+        ppm_args.radius       = igp_compute_radius(tech.merge_radius, iteration);
+        for (int k = 0; k < 3; ++k)
+            ppm_args.bbox_min[k] = d->scene_bbox[k], ppm_args.bbox_max[k] = d->scene_bbox[3 + k];
+        const ShadeFrame lframe{ (int32_t)P, 1, iteration, rs->frame, rs->user_seed, 0, 1, (int32_t)P, 0.0f };
+        const uint32_t lchunk = (uint32_t)std::min<size_t>(d->capacity, P);
+        for (uint32_t lfirst = 0; lfirst < P; lfirst += lchunk) {
+            const uint32_t ln = std::min(lchunk, P - lfirst);
+            HIP_CHECK(hipMemsetAsync(lq, 0, sizeof(QueueState), st));
+            GenerateLightArgs gl{};
+            gl.scene     = d->dscene;
+            gl.out       = d->primaryCols(0);
+            gl.out_count = &lq->q[0].primary;
+            gl.qs        = lq;
+            gl.width     = (int32_t)P;
+            gl.spi       = 1;
+            gl.iteration = iteration;
+            gl.frame     = rs->frame;
+            gl.seed      = rs->user_seed;
+            gl.first_local_id     = lfirst;
+            gl.rays_per_iteration = (int32_t)P;
+            gl.n                  = ln;
+            gl.ppm                = 1;
+            launch_generate_light(gl, st);
+            int lslot = 0;
+            for (int round = 0; round < tech.max_light_depth + 2; ++round) {
+                const PrimaryCols in = d->primaryCols(lslot);
+                TraverseArgs ta{};
+                ta.scene = d->dscene;
+                ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
+                ta.count        = &lq->q[lslot].primary;
+                ta.work_counter = &lq->work_counter[0];
+                ta.index_list   = d->deep_rays.ptr;
+                ta.index_count  = &lq->deep_count;
+                ta.qs           = lq;
+                ta.hit = in.hit, ta.hit_v = in.hit_v;
+                ta.sphere_work_counter = &lq->work_counter[4];
+                launch_traverse(ta, false, counters, d->traverseGrid(), &lq->work_counter[1], st, d->deep_grid, d->deep_primary);
+                ShadeArgs sa{};
+                sa.scene     = d->dscene;
+                sa.in        = in;
+                sa.out       = d->primaryCols(lslot ^ 1);
+                sa.sec       = d->secondaryCols();
+                sa.in_count  = &lq->q[lslot].primary;
+                sa.out_count = &lq->q[lslot ^ 1].primary;
+                sa.qs        = lq;
+                sa.accum     = reinterpret_cast<float4*>(d->flight[0].accum.ptr); // (the light pass never splats)
+                sa.id_base   = 0;
+                sa.frame     = lframe;
+                sa.inv_spi   = 1;
+                sa.ppm       = ppm_args;
+                launch_shade_ppm(sa, d->shadeGrid(), st);
+                launch_round_end(lq, lslot, st);
+                lslot ^= 1;
+                uint32_t alive = 0;
+                HIP_CHECK(hipMemcpyAsync(&alive, &lq->q[lslot].primary, sizeof(alive), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (alive == 0)
+                    break;
+            }
+            QueueState host{};
+            HIP_CHECK(hipMemcpyAsync(&host, lq, sizeof(QueueState), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (host.error_flags & 1u)
+                throw HipError{ IGD_ERR_DEVICE, "traversal stack overflow (BVH deeper than the LDS stack)" };
+            d->stats.camera_rays += host.camera_rays; // the emitter's rays count as the variant's camera rays (mapping_gpu.art:763)
+            d->stats.bounce_rays += host.bounce_rays;
+            d->stats.nodes_primary += host.nodes[0], d->stats.tris_primary += host.tris[0], d->stats.leaves_primary += host.leaves[0];
+        }
+        build_photon_grid(d->ppm_photons.ptr, P, ppm_args, d->ppm_sorted.ptr, d->ppm_cell_count.ptr, d->ppm_cell_offset.ptr, d->ppm_keys.ptr, d->ppm_valid.ptr,
+                          d->ppm_temp.ptr, temp_bytes, st);
+        HIP_CHECK(hipMemcpyAsync(&d->ppm_valid_host, d->ppm_valid.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipGetLastError());
+        ppm_args.pass        = 2;
+        ppm_args.photons     = d->ppm_sorted.ptr;
+        ppm_args.valid_count = (int32_t)d->ppm_valid_host;
+    };
     if (light_tracer && (row_stride != 1 || row_offset != 0 || list_mode || chunk_rays < per_it))
         // a connection lands in any pixel of the film: its accumulator slot has to exist in the chunk that traces the path
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the light tracer needs the whole film in one wavefront (no row sharding, no ray lists, stream capacity >= width * height * spi)" };
@@ -1103,6 +1238,9 @@ void render(igd_device* d, const igd_render_settings* rs)
                 HIP_CHECK(hipMemsetAsync(accum_mis[k], 0, (size_t)n * 4 * sizeof(float), st));
         HIP_CHECK(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
 
+        if (ppm && per_it > 0 && first % per_it == 0)
+            photonPass(rs->iteration + (int)(first / per_it));
+
         int in_slot = 0;
         GenerateArgs ga{};
         ga.out            = d->primaryCols(in_slot);
@@ -1206,8 +1344,12 @@ void render(igd_device* d, const igd_render_settings* rs)
                 sa.lt_cam.sx = sx, sa.lt_cam.sy = sy;
                 sa.lt_cam.width = rs->width, sa.lt_cam.height = rs->height;
             }
+            sa.ppm = ppm_args;
             timed(2, on, [&] {
-                launch_shade(sa, shade_grid, d->full_bsdfs, on);
+                if (ppm)
+                    launch_shade_ppm(sa, shade_grid, on);
+                else
+                    launch_shade(sa, shade_grid, d->full_bsdfs, on);
                 launch_round_end(qs, in_slot, on);
             });
 
@@ -1249,7 +1391,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             if (known_live == 0)
                 break;
             // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
-            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && d->dscene.tech.type != IG_TECHNIQUE_WIREFRAME && !d->dscene.expr_code) {
+            if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && d->dscene.tech.type != IG_TECHNIQUE_WIREFRAME && !ppm && !d->dscene.expr_code) {
                 live     = known_live;
                 run_tail = true;
                 break;

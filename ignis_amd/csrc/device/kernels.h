@@ -151,6 +151,7 @@ struct GenerateLightArgs {
     int64_t first_local_id;
     int32_t rays_per_iteration;
     uint32_t n;
+    int32_t ppm; // make_ppm_light_emitter instead of make_lt_emitter: the payload carries the light's id (radius_or_light)
 };
 
 struct GenerateArgs {
@@ -188,6 +189,18 @@ struct LtCameraArgs {
     int32_t width, height;
 };
 
+// IG_TECHNIQUE_PPM (ppm_core.h): the photon array — light pass: slot = light path index, written; camera pass: sorted by
+// (grid cell, index), read through cell_offset[cell] .. cell_offset[cell + 1]
+struct PpmArgs {
+    int32_t pass; // 0 not the photon mapper, 1 light pass, 2 camera pass
+    void* photons; // igp_photon[] (include/ig_photon.h), 32 bytes each
+    const uint32_t* cell_offset; // IGP_GRID_CELLS + 1 entries
+    int32_t photon_count;        // light paths per iteration: the normalisation of a gather (light_cache.max_count)
+    int32_t valid_count;         // photons actually stored (light_cache.count)
+    float radius;                // ppm_compute_radius(merge radius, iteration)
+    float bbox_min[3], bbox_max[3];
+};
+
 struct ShadeArgs {
     DevScene scene;
     PrimaryCols in;
@@ -202,6 +215,7 @@ struct ShadeArgs {
     ShadeFrame frame;
     float inv_spi;
     LtCameraArgs lt_cam; // IG_TECHNIQUE_LIGHTTRACER
+    PpmArgs ppm;         // IG_TECHNIQUE_PPM
 };
 
 struct TailArgs {

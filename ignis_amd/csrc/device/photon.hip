@@ -1,0 +1,78 @@
+// photon.hip — the photon mapper's kernels (src/artic/technique/photonmapper.art): the two k_shade instantiations of its light and
+// camera pass (ppm_core.h) and the construction of the query structure between them.
+//
+// ppm_handle_before_iteration_camera (:433-518) counts photons per cell of a 128^3 grid (Morton-linearised), scans the counts with
+// 21 Hillis-Steele passes over two ping-pong buffers and scatters the photons with one atomic per photon — an unstable sort, so the
+// order inside a cell depends on scheduling. Here: one 64-bit key (cell, light path index) per stored photon, ONE device radix sort
+// (hipCUB), a gather of the photons into that order, counts by atomics (an integer result is order-independent) and one exclusive
+// scan. The order inside a cell is the photons' index order: gathers sum in a fixed order and the image is reproducible.
+#include <hipcub/hipcub.hpp>
+
+#include "shade_kernel.h"
+
+namespace igdev {
+
+template __global__ void k_shade<true, false, true, false, 1>(const ShadeArgs);
+template __global__ void k_shade<true, false, true, false, 2>(const ShadeArgs);
+
+void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream)
+{
+    if (args.ppm.pass == 1)
+        hipLaunchKernelGGL((k_shade<true, false, true, false, 1>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL((k_shade<true, false, true, false, 2>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+}
+
+// keys of the stored photons: (cell << 32) | index; a light path that left no photon (light == -1) gets the all-ones key and sorts last
+__global__ void __launch_bounds__(256) k_photon_keys(const igp_photon* photons, uint32_t n, PpmArgs grid, unsigned long long* keys, uint32_t* cell_count, uint32_t* valid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const igp_photon p = photons[i];
+    if (p.light < 0) {
+        keys[i] = ~0ull;
+        return;
+    }
+    const uint32_t cell = (uint32_t)igp_grid_cell(p.pos, grid.bbox_min, grid.bbox_max);
+    keys[i]             = ((unsigned long long)cell << 32) | i;
+    atomicAdd(&cell_count[cell], 1u);
+    atomicAdd(valid, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_photon_gather(const igp_photon* photons, const unsigned long long* sorted_keys, const uint32_t* valid, igp_photon* sorted)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *valid)
+        return;
+    const uint32_t src = (uint32_t)(sorted_keys[i] & 0xFFFFFFFFull);
+    const int4* s      = reinterpret_cast<const int4*>(photons) + 2 * (size_t)src;
+    int4* d            = reinterpret_cast<int4*>(sorted) + 2 * (size_t)i;
+    d[0] = s[0], d[1] = s[1];
+}
+
+// scratch sizes of the two library calls for n photons
+size_t photon_grid_temp_bytes(uint32_t n)
+{
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, IGP_GRID_CELLS + 1);
+    return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+}
+
+// photons[0 .. n) (slot = light path index) -> sorted[0 .. *valid) in (cell, index) order, cell_offset[0 .. IGP_GRID_CELLS]
+void build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count /* IGP_GRID_CELLS + 1 */,
+                       uint32_t* cell_offset /* IGP_GRID_CELLS + 1 */, unsigned long long* keys /* 2 n */, uint32_t* valid, void* temp, size_t temp_bytes, hipStream_t stream)
+{
+    hipMemsetAsync(cell_count, 0, (size_t)(IGP_GRID_CELLS + 1) * sizeof(uint32_t), stream);
+    hipMemsetAsync(valid, 0, sizeof(uint32_t), stream);
+    const unsigned blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_photon_keys, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, n, grid, keys, cell_count, valid);
+    size_t bytes = temp_bytes;
+    hipcub::DeviceRadixSort::SortKeys(temp, bytes, keys, keys + n, (int)n, 0, 64, stream);
+    hipLaunchKernelGGL(k_photon_gather, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, keys + n, valid, sorted);
+    bytes = temp_bytes;
+    hipcub::DeviceScan::ExclusiveSum(temp, bytes, cell_count, cell_offset, IGP_GRID_CELLS + 1, stream);
+}
+
+} // namespace igdev

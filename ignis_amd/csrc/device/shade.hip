@@ -15,8 +15,7 @@
 // (citations inline); transcendental functions come from include/ig_detmath.h.
 #include <algorithm>
 
-#include "shade_core.h"
-#include "lt_core.h"
+#include "shade_kernel.h"
 
 namespace igdev {
 
@@ -241,10 +240,12 @@ __global__ void __launch_bounds__(256) k_generate_light(const GenerateLightArgs 
     float tmin = 0, tmax = 0;
     uint32_t flags = 0;
     Col contrib{ 0, 0, 0 };
+    int li_used = 0;
     const DevScene& sc = a.scene;
     if (sc.light_count > 0) {
         float light_pdf;
         const int li = select_light<true>(sc, rnd, f3{ 0, 0, 0 }, light_pdf);
+        li_used      = li;
         EmissionSample es;
         if (sample_emission(sc, sc.lights[li], rnd, es)) {
             org     = es.pos;
@@ -258,189 +259,8 @@ __global__ void __launch_bounds__(256) k_generate_light(const GenerateLightArgs 
     a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
     a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
     a.out.meta[i] = make_int4((int32_t)lid, (int32_t)flags, (int32_t)rnd.counter, 1);
-    a.out.pay[i]  = make_float4(0, contrib.r, contrib.g, contrib.b);
+    a.out.pay[i]  = make_float4(a.ppm ? (float)li_used : 0.0f, contrib.r, contrib.g, contrib.b);
     a.out.eta[i]  = 1;
-}
-
-// ---------------------------------------------------------------- k_shade
-
-constexpr int kShadeThreads = 256;
-constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry per thread
-
-// Waves per SIMD the full variant is built for. Its natural register demand is 252 VGPRs (215 without the principled BSDF, 196
-// without blends, 174 with the lean BSDFs but every light model): 4 waves (128 VGPRs) spill 532 B, 3 waves (168) 300 B, 2 waves
-// (256) nothing. Measured on diamond_scene_principled (32 steps): 149 / 135 / 139 ms of shading at 4 / 3 / 2 waves.
-#ifndef IG_SHADE_OCC_FULL
-#define IG_SHADE_OCC_FULL 3
-#endif
-#ifndef IG_SHADE_OCC_LEAN
-#define IG_SHADE_OCC_LEAN 4
-#endif
-// LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's
-template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false>
-__global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
-{
-    __shared__ uint32_t s_hist[kShadeThreads];
-    __shared__ uint32_t s_scan[kShadeThreads];
-    __shared__ uint16_t s_perm[kShadeThreads];
-    __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
-    __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_bin[16], s_binoff[16]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
-
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-
-    const DevScene& sc = a.scene;
-    const uint32_t n   = *a.in_count;
-    const int M        = (int)sc.material_count;
-    const bool do_sort = (M + 2) <= kMaxSortBins;
-
-    const ShadeFrame fr = a.frame;
-
-    const uint32_t chunks = (n + kShadeThreads - 1) / kShadeThreads;
-    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        const uint32_t base = chunk * kShadeThreads;
-
-        // ---- workgroup-local counting sort by material (miss = bin M, out of range = bin M + 1)
-        uint32_t j = base + tid;
-        // cleared here, in front of the sort's barriers (or the explicit one below when there is no sort): every wave's
-        // atomicAdd on s_bin is then ordered behind the clear, and the previous window's last barrier behind its reads
-        if (tid < 16)
-            s_bin[tid] = 0;
-        if (do_sort) {
-            const uint32_t i = base + tid;
-            int key          = M + 1;
-            if (i < n) {
-                const int ent = (int)igm_bits(a.in.hit[i].x);
-                key           = ent < 0 ? M : sc.entity_material[ent];
-            }
-            s_hist[tid] = 0;
-            __syncthreads();
-            const uint32_t r = atomicAdd(&s_hist[key], 1u);
-            __syncthreads();
-            // inclusive scan over the 256 bins by the first wave: 4 bins per lane + wave shuffle scan
-            if (tid < 64) {
-                const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
-                const uint32_t local = h0 + h1 + h2 + h3;
-                uint32_t incl        = local;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t up = __shfl_up(incl, off);
-                    if (lane >= off)
-                        incl += up;
-                }
-                const uint32_t excl = incl - local;
-                s_scan[4 * tid]     = excl + h0;
-                s_scan[4 * tid + 1] = excl + h0 + h1;
-                s_scan[4 * tid + 2] = excl + h0 + h1 + h2;
-                s_scan[4 * tid + 3] = incl;
-            }
-            __syncthreads();
-            const uint32_t start = key ? s_scan[key - 1] : 0u;
-            s_perm[start + r]    = (uint16_t)tid;
-            __syncthreads();
-            j = base + s_perm[tid];
-            __syncthreads();
-        }
-
-        PathVertexOut out;
-        out.bounce = out.shadow = out.has_radiance = false;
-        int ray_id = 0;
-        int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
-        if (j < n) {
-            PathVertexIn in;
-            const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], pay = a.in.pay[j], hit = a.in.hit[j];
-            const int4 meta = a.in.meta[j];
-            in.ray_id  = ray_id = meta.x;
-            in.org     = f3{ ra.x, ra.y, ra.z };
-            in.dir     = f3{ rb.x, rb.y, rb.z };
-            in.rnd     = (uint32_t)meta.z;
-            in.inv_pdf = pay.x;
-            in.contrib = Col{ pay.y, pay.z, pay.w };
-            in.depth   = meta.w;
-            in.eta     = a.in.eta[j];
-            in.ent     = (int)igm_bits(hit.x);
-            in.prim    = (int)igm_bits(hit.y);
-            in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
-            if constexpr (LT)
-                shade_vertex_lt(sc, fr, LtCamera(a.lt_cam), in, out, s_slot);
-            else
-                shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out);
-            if (out.has_radiance) {
-                // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
-                float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
-                float4 v    = *acc;
-                v.x += out.radiance.r * a.inv_spi;
-                v.y += out.radiance.g * a.inv_spi;
-                v.z += out.radiance.b * a.inv_spi;
-                *acc = v;
-                if (a.accum_direct && in.ent >= 0) { // aov_di.splat in on_hit (technique/pathtracer.art:133); on_miss has none
-                    float4* di = a.accum_direct + ((int64_t)ray_id - a.id_base);
-                    float4 w   = *di;
-                    w.x += out.radiance.r * a.inv_spi;
-                    w.y += out.radiance.g * a.inv_spi;
-                    w.z += out.radiance.b * a.inv_spi;
-                    *di = w;
-                }
-            }
-        }
-
-        // ---- append survivors / shadow rays: ONE atomic per workgroup and queue (replaces K9). A single
-        // counter word sustains only ~88 atomics/us, so per-wave appends would serialise the kernel.
-        {
-            // Continuation rays leave grouped by the octant of their direction: rays of one octant visit BVH children
-            // in the same order, so the next round's traversal waves diverge less. (Order inside the stream is free:
-            // nothing downstream depends on it.)
-            const unsigned long long ms = __ballot(out.shadow);
-            const int wave              = tid >> 6;
-            if (lane == 0)
-                s_wave_cnt[1][wave] = (uint32_t)__popcll(ms);
-            int bkey       = 0;
-            uint32_t brank = 0;
-            if (!do_sort)
-                __syncthreads(); // s_bin was cleared at the top of the window; without the sort there is no barrier in between
-            if (out.bounce) {
-                // rays that continue through a specular (dielectric) vertex start inside or on a refractive object and
-                // walk its BVH first; the others cross the room: two populations with different traversal shapes
-                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0) | (out.b_inv_pdf == 0 ? 8 : 0);
-                brank = atomicAdd(&s_bin[bkey], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
-                uint32_t tb = 0;
-                for (int k = 0; k < 16; ++k) {
-                    s_binoff[k] = tb;
-                    tb += s_bin[k];
-                }
-                const uint32_t ts = s_wave_cnt[1][0] + s_wave_cnt[1][1] + s_wave_cnt[1][2] + s_wave_cnt[1][3];
-                unsigned long long old = 0;
-                if (tb | ts)
-                    old = atomicAdd(reinterpret_cast<unsigned long long*>(a.out_count), (unsigned long long)tb | ((unsigned long long)ts << 32));
-                s_base[0] = (uint32_t)old;
-                s_base[1] = (uint32_t)(old >> 32);
-            }
-            __syncthreads();
-            uint32_t os = s_base[1];
-            for (int w = 0; w < wave; ++w)
-                os += s_wave_cnt[1][w];
-            if (out.bounce) {
-                const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
-                a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, FULL ? out.b_tmin : kRayOffset);
-                a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
-                a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
-                a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
-                a.out.eta[o]  = out.b_eta;
-            }
-            if (out.shadow) {
-                const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-                a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
-                a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
-                a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
-            }
-            __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
-        }
-    }
 }
 
 // Bookkeeping between bounce rounds, one thread: statistics (Statistics.h:57-64; BounceRayCount

@@ -1752,7 +1752,7 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
     } param_scope(&parameters);
 
     // ---- technique (Runtime.cpp:20-36, PathTechnique.cpp:8-18)
-    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0, 0 };
+    ig_technique tech{ 64, 2, 0.0f, 1, IG_SELECTOR_UNIFORM, IG_TECHNIQUE_PATH, 0, 0, 0, 0, 0.0f, 0 };
     std::string selector;
     if (const JsonValue* t = doc.find("technique")) {
         const std::string type = t->getString("type", "path");
@@ -1778,10 +1778,20 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
             tech.type = IG_TECHNIQUE_LIGHTTRACER; // LightTracerTechnique.cpp:10-17
         else if (type == "wireframe")
             tech.type = IG_TECHNIQUE_WIREFRAME; // WireframeTechnique.cpp: no parameters
-        else if (type != "path")
-            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao', 'debug', 'lt' and 'wireframe')");
+        else if (type == "ppm" || type == "photonmapper") {
+            // PhotonMappingTechnique.cpp:11-22 (the merge radius becomes absolute once the scene's bounding box is known, below)
+            tech.type            = IG_TECHNIQUE_PPM;
+            tech.photon_count    = std::max(100, t->getInt("photons", 1000000));
+            tech.max_light_depth = t->getInt("max_light_depth", 8);
+            tech.merge_radius    = t->getNumber("radius", 0.01f);
+        } else if (type != "path")
+            fail("Technique '" + type + "' is not supported by the HIP backend (only 'path', 'volpath', 'ao', 'debug', 'lt', 'ppm' and 'wireframe')");
         tech.max_depth = t->getInt("max_depth", 64);
         tech.min_depth = t->getInt("min_depth", 2);
+        if (tech.type == IG_TECHNIQUE_PPM) { // "max_depth" else "max_camera_depth", "min_depth" else "min_camera_depth"
+            tech.max_depth = t->has("max_depth") ? tech.max_depth : t->getInt("max_camera_depth", 64);
+            tech.min_depth = t->has("min_depth") ? tech.min_depth : t->getInt("min_camera_depth", 2);
+        }
         if (tech.type == IG_TECHNIQUE_LIGHTTRACER) { // "max_depth" else "max_light_depth", "min_depth" else "min_light_depth"
             tech.max_depth = t->has("max_depth") ? tech.max_depth : t->getInt("max_light_depth", 64);
             tech.min_depth = t->has("min_depth") ? tech.min_depth : t->getInt("min_light_depth", 2);
@@ -2630,6 +2640,16 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
                 fail("Technique 'lt': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional, sun and constant environment lights are)");
         if (cam.type != IG_CAMERA_PERSPECTIVE || cam.aperture_radius > 0)
             fail("Technique 'lt': only the perspective camera without depth of field is supported by the HIP backend");
+    }
+    if (tech.type == IG_TECHNIQUE_PPM) {
+        // the light pass needs Light::sample_emission like the light tracer's emitter
+        for (const ig_light& l : sc->lights)
+            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_SPHERE && l.type != IG_LIGHT_SUN && l.type != IG_LIGHT_DIRECTIONAL
+                && l.type != IG_LIGHT_ENV)
+                fail("Technique 'ppm': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional, sun and constant environment lights are)");
+        // __tech_radius = radius * SceneDiameter, SceneDiameter = |bbox.max - bbox.min| (PhotonMappingTechnique.cpp:100, LoaderEntity.cpp:187)
+        const V3 size = entityCount ? sceneBBox.diameter() : V3(0, 0, 0);
+        t.technique.merge_radius = tech.merge_radius * std::sqrt(size.x * size.x + size.y * size.y + size.z * size.z);
     }
     for (int i = 0; i < 3; ++i) {
         t.bbox_min[i] = entityCount ? sceneBBox.min[i] : 0;

@@ -50,7 +50,8 @@ class Camera(C.Structure):
 
 class Technique(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("min_depth", C.c_int32), ("clamp", C.c_float), ("nee", C.c_int32),
-                ("light_selector", C.c_int32), ("type", C.c_int32), ("aov_mis", C.c_int32), ("debug_mode", C.c_int32)]
+                ("light_selector", C.c_int32), ("type", C.c_int32), ("aov_mis", C.c_int32), ("debug_mode", C.c_int32),
+                ("photon_count", C.c_int32), ("max_light_depth", C.c_int32), ("merge_radius", C.c_float), ("reserved", C.c_int32)]
 
 
 class Texture(C.Structure):

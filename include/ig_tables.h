@@ -313,6 +313,11 @@ enum ig_technique_type {
      * the pixel's footprint (camera.differential) shows white fading to black, any other hit lets the ray continue straight on; no
      * parameters. Perspective and orthogonal cameras, triangle meshes. */
     IG_TECHNIQUE_WIREFRAME = 5,
+    /* the photon mapper (src/artic/technique/photonmapper.art, PhotonMappingTechnique.cpp): per iteration a light pass of
+     * `photon_count` paths that leave one photon each at the first non-delta surface (LDE and LS*DE paths), then a camera pass
+     * that gathers them within the merge radius at every non-delta vertex instead of sampling lights. max_depth / min_depth =
+     * "max_depth" | "max_camera_depth", "min_depth" | "min_camera_depth"; lights as for the light tracer. */
+    IG_TECHNIQUE_PPM = 6,
 };
 
 /* One record per medium, in the order entities acquire them (LoaderMedium::acquire, src/runtime/loader/LoaderMedium.cpp:113-121;
@@ -337,6 +342,11 @@ typedef struct ig_technique {
                              * emission of surfaces a path hits, pathtracer.art:119-139) and "NEE Weights" (the next-event
                              * contributions of unoccluded shadow rays, on_shadow_miss :212-218) */
     int32_t debug_mode;     /* IG_TECHNIQUE_DEBUG: 0 normal, 1 tangent, ... 27 medium outer (DebugMode.h:6-35) */
+    /* IG_TECHNIQUE_PPM (PhotonMappingTechnique.cpp:14-22,96-101) */
+    int32_t photon_count;    /* "photons", default 1 000 000, at least 100 */
+    int32_t max_light_depth; /* "max_light_depth", default 8 */
+    float merge_radius;      /* "radius" (default 0.01) x the scene diameter: the registry's __tech_radius */
+    int32_t reserved;
 } ig_technique;
 
 /* ---- Scene ------------------------------------------------------------ */

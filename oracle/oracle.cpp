@@ -504,6 +504,230 @@ void trace_light_paths(const igd_scene& sc, const oracle_settings& cfg, const Ca
             }
 }
 
+// The photon mapper (technique/photonmapper.art) for one iteration: the light pass path by path (make_ppm_light_emitter :141-165,
+// make_ppm_light_renderer :169-245), the voxel grid (:60-110, 395-431), then the camera pass path by path (make_ppm_path_renderer
+// :262-388). A light path stores at most one photon, at the slot of its index; inside a grid cell photons keep index order (the
+// reference's order there is whatever its atomics produce), so that a gather's float sum is defined.
+void render_photon_mapped(const igd_scene& sc, const oracle_settings& cfg, const CameraSetup& cam, float* fb, Counters& cnt)
+{
+    const LightTracer lt(sc); // the emitter shares everything but the payload with make_lt_emitter
+    const ig_technique& tech = sc.technique;
+    const int P              = tech.photon_count;
+    constexpr float offset   = 0.001f;
+    struct BsdfSetup { // the material's BSDF over the hit's surface (bump / two-sided wrappers as in trace_light_paths)
+        SurfaceElement surf, bsurf, dsurf;
+        Bsdf bsdf;
+    };
+    auto make_bsdf = [&](BsdfSetup& b, const ig_material& mat, const Ray& ray, bool adjoint) {
+        const bool bumped = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)) != 0;
+        b.bsurf           = bumped ? bumped_surface(sc, mat, b.surf, ray) : b.surf;
+        const bool ds_flip = (mat.flags & IG_MAT_DOUBLESIDED) && !b.surf.is_entering;
+        b.dsurf             = b.bsurf;
+        b.dsurf.is_entering = true;
+        b.bsdf              = Bsdf{ &mat, ds_flip ? &b.dsurf : &b.bsurf, &sc, ds_flip, vec3_neg(ray.dir) };
+        b.bsdf.adjoint      = adjoint;
+        b.bsdf.bumped       = bumped;
+        b.bsdf.old_normal   = b.surf.local.col[2];
+    };
+
+    // ---- light pass
+    std::vector<igp_photon> photons((size_t)P);
+    for (auto& ph : photons)
+        ph.light = -1;
+    for (int x = 0; x < P; ++x) {
+        Rng rnd{ create_random_seed(0, cfg.iteration, cfg.frame, x, 0, cfg.seed), 1 };
+        Ray ray;
+        PTRayPayload pt;
+        int32_t light_id = 0;
+        ++cnt.camera;
+        if (!lt.emit(rnd, ray, pt, &light_id) || sc.entity_count == 0)
+            continue;
+        for (;;) {
+            const Hit hit = traverse_scene(sc, ray, false, cnt.trav);
+            if (hit.prim_id < 0)
+                break; // TechniqueNoMissFunction
+            const Entity entity    = load_entity(sc, hit.ent_id);
+            const ig_material& mat = sc.materials[entity.mat_id];
+            BsdfSetup b;
+            b.surf = surface_element(sc, entity, ray, hit);
+            make_bsdf(b, mat, ray, true);
+            const bool emissive = mat.light_id >= 0, all_delta = b.bsdf.is_all_delta();
+            const Vec3 out_dir = vec3_neg(ray.dir);
+            // on_hit (:172-195)
+            if (!emissive && !all_delta) {
+                const float cos_o = vec3_dot(out_dir, b.surf.local.col[2]);
+                if (cos_o > flt_eps) {
+                    igp_photon& ph = photons[(size_t)x];
+                    ph.dir   = igp_encode_normal_32(out_dir.x, out_dir.y, out_dir.z);
+                    ph.light = light_id;
+                    ph.power = igp_encode_rgbe(pt.contrib.r, pt.contrib.g, pt.contrib.b);
+                    ph.depth = pt.depth;
+                    ph.pos[0] = b.surf.point.x, ph.pos[1] = b.surf.point.y, ph.pos[2] = b.surf.point.z;
+                    ph.eta = pt.eta;
+                }
+            }
+            // on_bounce (:197-227)
+            if (!(all_delta && pt.depth + 2 <= tech.max_light_depth))
+                break;
+            BsdfSample ms;
+            if (!b.bsdf.sample(rnd, out_dir, ms))
+                break;
+            const Color contrib = color_mul(pt.contrib, ms.color);
+            if (!(color_average(contrib) > flt_eps))
+                break;
+            pt.contrib = contrib;
+            pt.depth   = pt.depth + 1;
+            pt.eta     = pt.eta * ms.eta;
+            ray        = make_ray(b.surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+            ++cnt.bounce;
+        }
+    }
+
+    // ---- grid: (cell, index) order, offsets per cell
+    std::vector<std::pair<uint64_t, uint32_t>> keys;
+    for (int x = 0; x < P; ++x)
+        if (photons[(size_t)x].light >= 0)
+            keys.push_back({ ((uint64_t)(uint32_t)igp_grid_cell(photons[(size_t)x].pos, sc.bbox_min, sc.bbox_max) << 32) | (uint32_t)x, (uint32_t)x });
+    std::sort(keys.begin(), keys.end());
+    std::vector<igp_photon> sorted(keys.size());
+    std::vector<uint32_t> cell_offset((size_t)IGP_GRID_CELLS + 1, 0);
+    for (size_t i = 0; i < keys.size(); ++i) {
+        sorted[i] = photons[keys[i].second];
+        ++cell_offset[(size_t)(keys[i].first >> 32) + 1];
+    }
+    for (size_t c = 1; c < cell_offset.size(); ++c)
+        cell_offset[c] += cell_offset[c - 1];
+
+    // ---- camera pass
+    const PathTracer pt_lights(sc); // infinite-light emission only
+    const float radius = igp_compute_radius(tech.merge_radius, cfg.iteration);
+    const int spi = cfg.spi, W = cfg.width, H = cfg.height;
+    const float inv_spi = 1 / (float)spi;
+    const float clamp_value = tech.clamp;
+    auto handle_color = [&](Color c) { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; };
+    for (int y = 0; y < H; ++y) {
+        if (cfg.row_stride > 1 && y % cfg.row_stride != cfg.row_offset)
+            continue;
+        for (int x = 0; x < W; ++x)
+            for (int sample = 0; sample < spi; ++sample) {
+                Rng rnd{ create_random_seed(sample, cfg.iteration, cfg.frame, x, y, cfg.seed), 1 };
+                Ray ray;
+                ++cnt.camera;
+                if (!generate_camera_ray(cam, rnd, cfg.iteration * spi + sample, x, y, W, H, ray))
+                    continue;
+                Color contrib{ 1, 1, 1 }; // init_ppm_raypayload (:131-137)
+                int depth = 1, path_type = 0;
+                float eta = 1, radius_payload = 0;
+                float* px = fb + ((size_t)y * W + x) * 3;
+                auto splat = [&](Color c) { px[0] += c.r * inv_spi, px[1] += c.g * inv_spi, px[2] += c.b * inv_spi; };
+                for (;;) {
+                    const Hit hit = sc.entity_count ? traverse_scene(sc, ray, false, cnt.trav) : Hit{ -1, -1, 0, 0, 0 };
+                    if (hit.prim_id < 0) {
+                        // on_miss (:333-360)
+                        if (path_type != 1) {
+                            int inflights = 0;
+                            Color color{ 0, 0, 0 };
+                            for (uint32_t i = 0; i < sc.infinite_light_count; ++i) {
+                                Color emit;
+                                if (!pt_lights.infinite_emission(sc.lights[i], ray.dir, emit))
+                                    continue;
+                                ++inflights;
+                                color = color_add(color, color_mul(contrib, emit));
+                            }
+                            if (inflights > 0)
+                                splat(handle_color(color));
+                        }
+                        break;
+                    }
+                    const Entity entity    = load_entity(sc, hit.ent_id);
+                    const ig_material& mat = sc.materials[entity.mat_id];
+                    BsdfSetup b;
+                    b.surf = surface_element(sc, entity, ray, hit);
+                    make_bsdf(b, mat, ray, false);
+                    const bool emissive = mat.light_id >= 0, all_delta = b.bsdf.is_all_delta();
+                    const Vec3 out_dir = vec3_neg(ray.dir);
+                    const Vec3 N       = b.surf.local.col[2];
+                    // get_radius (:275-283)
+                    const float actual_radius = depth > 1 ? radius_payload : igm_min(radius, hit.distance * 0.017455064f);
+                    // on_hit (:285-331)
+                    bool answered = false;
+                    if (path_type == 0 && emissive && b.surf.is_entering) {
+                        const float dot = vec3_dot(out_dir, N);
+                        if (dot > flt_eps) {
+                            const ig_light& light = sc.lights[mat.light_id];
+                            Color emit;
+                            if (light.type == IG_LIGHT_MESH_AREA)
+                                emit = MeshEmitter(sc, light).radiance;
+                            else if (light.type == IG_LIGHT_SPHERE)
+                                emit = Color{ light.d[4], light.d[5], light.d[6] };
+                            else
+                                emit = PlaneEmitter(light).radiance;
+                            splat(handle_color(color_mul(contrib, emit)));
+                            answered = true;
+                        }
+                    }
+                    if (!answered && depth + 1 <= tech.max_depth && !emissive && !all_delta) {
+                        const float cos_o = vec3_dot(out_dir, N);
+                        if (igm_abs(cos_o) > flt_eps) {
+                            Color total{ 0, 0, 0 };
+                            if (!(actual_radius <= flt_eps) && !sorted.empty()) {
+                                const float r2    = actual_radius * actual_radius;
+                                const float lo[3] = { b.surf.point.x - actual_radius, b.surf.point.y - actual_radius, b.surf.point.z - actual_radius };
+                                const float hi[3] = { b.surf.point.x + actual_radius, b.surf.point.y + actual_radius, b.surf.point.z + actual_radius };
+                                int32_t cmin[3], cmax[3];
+                                igp_grid_pos(lo, sc.bbox_min, sc.bbox_max, cmin);
+                                igp_grid_pos(hi, sc.bbox_min, sc.bbox_max, cmax);
+                                for (int iz = cmin[2]; iz <= cmax[2]; ++iz)
+                                    for (int iy = cmin[1]; iy <= cmax[1]; ++iy)
+                                        for (int ix = cmin[0]; ix <= cmax[0]; ++ix) {
+                                            const int32_t cell = igp_morton_3d(ix, iy, iz);
+                                            Color cc{ 0, 0, 0 };
+                                            for (uint32_t i = cell_offset[(size_t)cell]; i < cell_offset[(size_t)cell + 1]; ++i) {
+                                                const igp_photon& ph = sorted[i];
+                                                const Vec3 d      = vec3_sub(b.surf.point, make_vec3(ph.pos[0], ph.pos[1], ph.pos[2]));
+                                                const float dist2 = vec3_dot(d, d);
+                                                if (!(dist2 <= r2))
+                                                    continue;
+                                                float dir[3], pw[3];
+                                                igp_decode_normal_32(ph.dir, dir);
+                                                const Vec3 in_dir = make_vec3(dir[0], dir[1], dir[2]);
+                                                const float cos_i = vec3_dot(in_dir, N);
+                                                if (depth + ph.depth <= tech.max_depth && cos_o * cos_i > flt_eps) {
+                                                    igp_decode_rgbe(ph.power, pw);
+                                                    const float kf  = igp_kernel(r2, dist2);
+                                                    const Color mc  = b.bsdf.eval(in_dir, out_dir);
+                                                    cc = color_add(cc, color_mulf(color_mul(Color{ pw[0], pw[1], pw[2] }, mc), safe_div(kf, igm_abs(cos_i))));
+                                                }
+                                            }
+                                            total = color_add(total, cc);
+                                        }
+                            }
+                            const float n = (float)P;
+                            splat(handle_color(color_mul(contrib, Color{ total.r / n, total.g / n, total.b / n })));
+                        }
+                    }
+                    // on_bounce (:362-399)
+                    if (depth + 1 > tech.max_depth)
+                        break;
+                    BsdfSample ms;
+                    if (!b.bsdf.sample(rnd, out_dir, ms) || ms.pdf <= flt_eps)
+                        break;
+                    const Color nc      = color_mul(contrib, ms.color);
+                    const float rr_prob = (depth + 1 > tech.min_depth) ? russian_roulette_pbrt(color_mulf(nc, eta * eta), 0.95f) : 1.0f;
+                    if (rnd.next_f32() >= rr_prob)
+                        break;
+                    contrib        = color_mulf(nc, 1 / rr_prob);
+                    depth          = depth + 1;
+                    eta            = eta * ms.eta;
+                    radius_payload = actual_radius;
+                    path_type      = ms.is_delta ? path_type : 1;
+                    ray            = make_ray(b.surf.point, ms.in_dir, offset, flt_max, IG_RAY_FLAG_BOUNCE);
+                    ++cnt.bounce;
+                }
+            }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -532,6 +756,22 @@ int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* f
             stats->bounce_rays += c.bounce;
             stats->shadow_rays += c.shadow;
             stats->unoccluded += c.unoccluded;
+            stats->nodes += c.trav.nodes;
+            stats->tris += c.trav.tris;
+            stats->leaves += c.trav.leaves;
+            stats->max_stack = std::max(stats->max_stack, c.trav.max_stack);
+            stats->threads_used = 1;
+        }
+        return 0;
+    }
+    if (sc->technique.type == IG_TECHNIQUE_PPM) {
+        if (cfg->xmax > 0 || cfg->ymax > 0)
+            return -1;
+        Counters c;
+        render_photon_mapped(*sc, *cfg, cam, fb, c);
+        if (stats) {
+            stats->camera_rays += c.camera;
+            stats->bounce_rays += c.bounce;
             stats->nodes += c.trav.nodes;
             stats->tris += c.trav.tris;
             stats->leaves += c.trav.leaves;
@@ -607,6 +847,18 @@ int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* f
     }
     return 0;
 }
+
+// ig_photon.h on its own, for the tests' independent restatements: a photon's direction and power through their encodings, and the
+// grid cell of a position
+void oracle_photon_codec(const float dir[3], const float power[3], int32_t* enc_dir, int32_t* enc_power, float out_dir[3], float out_power[3])
+{
+    *enc_dir   = igp_encode_normal_32(dir[0], dir[1], dir[2]);
+    *enc_power = igp_encode_rgbe(power[0], power[1], power[2]);
+    igp_decode_normal_32(*enc_dir, out_dir);
+    igp_decode_rgbe(*enc_power, out_power);
+}
+int32_t oracle_photon_cell(const float pos[3], const float bmin[3], const float bmax[3]) { return igp_grid_cell(pos, bmin, bmax); }
+float oracle_photon_radius(float max_radius, int32_t iteration) { return igp_compute_radius(max_radius, iteration); }
 
 int oracle_render_ex(const igd_scene* sc, const oracle_settings* cfg, float* fb, oracle_stats* stats, float* aov_normals, float* aov_albedo)
 {

@@ -7,6 +7,7 @@
 
 #include "oracle_core.h"
 #include "ig_expr.h"
+#include "ig_photon.h"
 
 #include <algorithm>
 #include <functional>
@@ -3233,6 +3234,29 @@ struct PathTracer {
         return false;
     }
 
+    // Light::emission of an infinite, non-delta light (what on_miss evaluates); false: delta light
+    bool infinite_emission(const ig_light& light, Vec3 dir, Color& emit) const
+    {
+        if (light.type == IG_LIGHT_ENV_TEXTURED) {
+            emit = TexturedEnv(sc, light).emission(dir);
+        } else if (light.type == IG_LIGHT_CIE) {
+            emit = CieSky(light).emission(dir);
+        } else if (light.type == IG_LIGHT_PEREZ) {
+            const SunLight sun = perez_sun(light);
+            const CieSky sky(light);
+            const Vec3 d = make_vec3(vec3_dot(sky.transform.col[0], dir), vec3_dot(sky.transform.col[1], dir), vec3_dot(sky.transform.col[2], dir));
+            emit         = color_add(sun.hits(dir) ? sun.radiance : Color{ 0, 0, 0 }, sky.radiance(d));
+        } else if (light.type == IG_LIGHT_SUN) {
+            const SunLight sun(light);
+            emit = sun.hits(dir) ? sun.radiance : Color{ 0, 0, 0 };
+        } else if (light.type == IG_LIGHT_ENV) {
+            emit = Color{ light.d[0], light.d[1], light.d[2] };
+        } else {
+            return false;
+        }
+        return true;
+    }
+
     // on_miss (pathtracer.art:141-168): sum over infinite, non-delta lights
     bool on_miss(const Ray& ray, const PTRayPayload& pt, Color& out) const
     {
@@ -3536,12 +3560,14 @@ struct LightTracer {
     Color handle_color(Color c) const { return clamp_value > 0 ? color_saturate(c, clamp_value) : c; }
 
     // make_lt_emitter (lighttracer.art:35-62); false: no ray for this sample
-    bool emit(Rng& rnd, Ray& ray, PTRayPayload& payload) const
+    bool emit(Rng& rnd, Ray& ray, PTRayPayload& payload, int32_t* light_id = nullptr) const
     {
         if (sc.light_count == 0)
             return false;
         float light_pdf;
         const int32_t li  = selector.select_light(rnd, make_vec3(0, 0, 0), light_pdf);
+        if (light_id)
+            *light_id = li; // make_ppm_light_emitter (photonmapper.art:141-165): the same emitter, the payload also names the light
         const ig_light& l = sc.lights[li];
         EmissionSample es;
         if (!sample_emission(sc, l, rnd, es))

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/ignis_amd/lib/var/$NAME
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-parameter -I$ROOT/include"
-for f in traverse shade tail device; do
+for f in traverse shade photon tail device; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$ROOT/ignis_amd/csrc/device/$f.hip" -o "$OUT/$f.o" &
 done
 wait
