@@ -42,8 +42,8 @@ for line in notes.split("\n"):
 print(f"# {os.path.relpath(lib, ROOT)}: gfx950 code-object metadata (llvm-readelf --notes)")
 print(f"{'kernel':78s} {'vgpr':>5s} {'spill':>6s} {'scratch_B':>9s} {'sgpr':>5s} {'lds_B':>7s} {'waves/SIMD':>10s}")
 for r in sorted(rows, key=lambda r: r.get("name", "")):
-    if "name" not in r:
-        continue
+    if "name" not in r or "rocprim" in r["name"] or "hipcub" in r["name"]:
+        continue  # (the library kernels of the photon grid's sort and scan: not ours)
     n = demangle(r["name"]).replace("void igdev::", "").replace("igdev::", "")
     n = re.sub(r"\(.*", "", n)
     vg = int(r.get("vgpr_count", 0)) + int(r.get("agpr_count", 0))
