@@ -42,7 +42,7 @@ void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uin
 // photon.hip (IG_TECHNIQUE_PPM)
 void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 size_t photon_grid_temp_bytes(uint32_t n);
-void build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count, uint32_t* cell_offset, unsigned long long* keys, uint32_t* valid,
+hipError_t build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count, uint32_t* cell_offset, unsigned long long* keys, uint32_t* valid,
                        void* temp, size_t temp_bytes, hipStream_t stream);
 } // namespace igdev
 
@@ -432,8 +432,29 @@ void assignScene(igd_device* d, const igd_scene* s)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " uses a BSDF the HIP backend cannot shade yet" };
         const uint32_t principled_flags = mat.bsdf_type == IG_BSDF_PRINCIPLED ? (uint32_t)(IG_MAT_THIN | IG_MAT_CLEARCOAT_ALL)
                                                                               : (mat.bsdf_type == IG_BSDF_DIELECTRIC ? (uint32_t)IG_MAT_THIN : 0u);
-        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | (mat.bsdf_type == IG_BSDF_BLEND ? (uint32_t)IG_MAT_EXPR_WEIGHT : 0u) | principled_flags))
+        if (mat.flags & ~(uint32_t)(IG_MAT_CHECKER | IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_IMAGE | IG_MAT_SMOOTH | IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_NUMBERS | (mat.bsdf_type == IG_BSDF_BLEND ? (uint32_t)IG_MAT_EXPR_WEIGHT : 0u) | principled_flags))
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " carries flags its BSDF type does not define" };
+        if (mat.flags & IG_MAT_EXPR_NUMBERS) {
+            // the number list: inside the expression table, every slot a float of the record, every program valid
+            uint32_t at;
+            std::memcpy(&at, &mat.r[7], 4);
+            const uint32_t ntex = s->textures && s->texture_data ? s->texture_count : 0u;
+            bool ok = s->expr_code && at < s->expr_code_count && mat.bsdf_type != IG_BSDF_BLEND;
+            const uint32_t n = ok ? s->expr_code[at] : 0u;
+            ok = ok && n >= 1 && n <= 32 && (uint64_t)at + 1 + 3ull * n <= s->expr_code_count;
+            for (uint32_t i = 0; ok && i < n; ++i) {
+                const uint32_t head = s->expr_code[at + 1 + 3 * i];
+                float aspect;
+                std::memcpy(&aspect, &s->expr_code[at + 2 + 3 * i], 4);
+                ok = (head & 0xFFu) <= IG_NUM_ROUGHNESS_DIELECTRIC && ((head >> 8) & 0xFFu) < 28 && ((head >> 16) & 0xFFu) < 28 && (head >> 24) == 0 && aspect > 0 && aspect <= 1
+                     && ige_validate(s->expr_code, s->expr_code_count, s->expr_code[at + 3 + 3 * i], ntex);
+            }
+            if (!ok)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: material " + std::to_string(m) + " names no valid number-expression list" };
+        }
+        // tex_id is a texture index for bump / normal maps and a program offset for an expression weight or normal: one use per record
+        if ((mat.flags & IG_MAT_EXPR_WEIGHT) && (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
+            throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: material " + std::to_string(m) + " combines an expression weight with a bump map, normal map or expression normal (they share tex_id)" };
         if ((mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP)) && (mat.tex_id < 0 || mat.tex_id >= (int32_t)s->texture_count || !s->textures || !s->texture_data))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: bump / normal-mapped material " + std::to_string(m) + " has no valid texture" };
         if (mat.bsdf_type == IG_BSDF_BLEND)
@@ -685,7 +706,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         // the shading kernel with the expression interpreter runs only where a material names a program
         bool any_expr = false;
         for (uint32_t i = 0; i < s->material_count; ++i)
-            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0 || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD
+            any_expr |= (s->materials[i].flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT | IG_MAT_EXPR_NUMBERS)) != 0 || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD
                         || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS; // the Radiance BSDFs live in that instantiation too
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
@@ -711,7 +732,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     d->full_bsdfs = false;
     d->deep_primary = d->deep_primary_mode == 1; // a new scene starts with the LDS-stack kernels again
     for (uint32_t i = 0; i < s->material_count; ++i)
-        d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
+        d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT | IG_MAT_EXPR_NUMBERS)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
@@ -1041,6 +1062,8 @@ void render(igd_device* d, const igd_render_settings* rs)
         d->ppm_valid.alloc(1);
         d->ppm_qs.alloc(1);
         const size_t temp_bytes = photon_grid_temp_bytes(P);
+        if (temp_bytes == 0)
+            throw HipError{ IGD_ERR_DEVICE, "igd_render: the photon grid's sort / scan could not be sized" };
         d->ppm_temp.alloc(temp_bytes);
         QueueState* lq = d->ppm_qs.ptr;
         HIP_CHECK(hipMemsetAsync(d->ppm_photons.ptr, 0xFF, (size_t)P * sizeof(igp_photon), st)); // light = -1: no photon
@@ -1117,8 +1140,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             d->stats.bounce_rays += host.bounce_rays;
             d->stats.nodes_primary += host.nodes[0], d->stats.tris_primary += host.tris[0], d->stats.leaves_primary += host.leaves[0];
         }
-        build_photon_grid(d->ppm_photons.ptr, P, ppm_args, d->ppm_sorted.ptr, d->ppm_cell_count.ptr, d->ppm_cell_offset.ptr, d->ppm_keys.ptr, d->ppm_valid.ptr,
-                          d->ppm_temp.ptr, temp_bytes, st);
+        HIP_CHECK(build_photon_grid(d->ppm_photons.ptr, P, ppm_args, d->ppm_sorted.ptr, d->ppm_cell_count.ptr, d->ppm_cell_offset.ptr, d->ppm_keys.ptr, d->ppm_valid.ptr,
+                                    d->ppm_temp.ptr, temp_bytes, st));
         HIP_CHECK(hipMemcpyAsync(&d->ppm_valid_host, d->ppm_valid.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         HIP_CHECK(hipGetLastError());

@@ -198,8 +198,9 @@ IG_DEV void shade_vertex_lt(const DevScene& sc, const ShadeFrame& fr, const LtCa
     const ig_technique tech = sc.tech;
     const int depth         = in.depth & 0xFFFF;
 
-    const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
-    const Surf surf        = surface_element<true>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    const Surf surf = surface_element<true>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    ig_material mat_local;
+    const ig_material& mat = resolve_material<true>(sc, sc.materials[sc.entity_material[in.ent]], surf, -in.dir, mat_local);
     const BsdfCtx<true, true, true> bsdf(sc, mat, surf, in.dir, std::true_type{});
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;

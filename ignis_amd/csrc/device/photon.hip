@@ -55,24 +55,30 @@ __global__ void __launch_bounds__(256) k_photon_gather(const igp_photon* photons
 size_t photon_grid_temp_bytes(uint32_t n)
 {
     size_t sort_bytes = 0, scan_bytes = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, IGP_GRID_CELLS + 1);
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n) != hipSuccess
+        || hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, IGP_GRID_CELLS + 1) != hipSuccess)
+        return 0;
     return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
 }
 
 // photons[0 .. n) (slot = light path index) -> sorted[0 .. *valid) in (cell, index) order, cell_offset[0 .. IGP_GRID_CELLS]
-void build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count /* IGP_GRID_CELLS + 1 */,
+hipError_t build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count /* IGP_GRID_CELLS + 1 */,
                        uint32_t* cell_offset /* IGP_GRID_CELLS + 1 */, unsigned long long* keys /* 2 n */, uint32_t* valid, void* temp, size_t temp_bytes, hipStream_t stream)
 {
-    hipMemsetAsync(cell_count, 0, (size_t)(IGP_GRID_CELLS + 1) * sizeof(uint32_t), stream);
-    hipMemsetAsync(valid, 0, sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(cell_count, 0, (size_t)(IGP_GRID_CELLS + 1) * sizeof(uint32_t), stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(valid, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
     const unsigned blocks = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_photon_keys, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, n, grid, keys, cell_count, valid);
     size_t bytes = temp_bytes;
-    hipcub::DeviceRadixSort::SortKeys(temp, bytes, keys, keys + n, (int)n, 0, 64, stream);
+    e = hipcub::DeviceRadixSort::SortKeys(temp, bytes, keys, keys + n, (int)n, 0, 64, stream);
+    if (e != hipSuccess)
+        return e;
     hipLaunchKernelGGL(k_photon_gather, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, keys + n, valid, sorted);
     bytes = temp_bytes;
-    hipcub::DeviceScan::ExclusiveSum(temp, bytes, cell_count, cell_offset, IGP_GRID_CELLS + 1, stream);
+    return hipcub::DeviceScan::ExclusiveSum(temp, bytes, cell_count, cell_offset, IGP_GRID_CELLS + 1, stream);
 }
 
 } // namespace igdev

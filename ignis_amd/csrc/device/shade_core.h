@@ -517,6 +517,24 @@ __attribute__((noinline)) IG_DEV f3 eval_expr(const DevScene& sc, int32_t start,
     return f3{ r.v[0], r.v[1], r.v[2] };
 }
 
+// IG_MAT_EXPR_NUMBERS (ig_tables.h): the material record with its number expressions evaluated at this hit — in a local copy; the
+// table's record otherwise. Numbers see the hit's own surface, like every parameter of the material the reference builds per hit.
+template <bool EXPR>
+IG_DEV const ig_material& resolve_material(const DevScene& sc, const ig_material& mat, const Surf& s, f3 view, ig_material& local)
+{
+    if constexpr (EXPR) {
+        if (mat.flags & IG_MAT_EXPR_NUMBERS) {
+            local               = mat;
+            const uint32_t* lst = sc.expr_code + igm_bits(mat.r[7]);
+            const uint32_t n    = lst[0];
+            for (uint32_t i = 0; i < n; ++i)
+                ig_material_set_number(&local, lst[1 + 3 * i], igm_float(lst[2 + 3 * i]), eval_expr(sc, (int32_t)lst[3 + 3 * i], s, view).x);
+            return local;
+        }
+    }
+    return mat;
+}
+
 // the local frame the inner BSDF of a bump-mapped material sees (make_bumpmap -> make_normal_set; camera paths
 // are not adjoint, so nothing else of transform_surf_bsdf applies)
 template <bool EXPR>
@@ -2481,7 +2499,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     // make_volume_path_renderer (technique/volpathtracer.art:37-260): the same callbacks with a current medium in the payload
     const bool volumetric = FULL && tech.type == IG_TECHNIQUE_VOLPATH;
     const int depth       = FULL ? (in.depth & 0xFFFF) : in.depth;
-    const int medium_id   = FULL ? (in.depth >> 16) - 1 : -1;
+    const int medium_id   = FULL ? (int)((uint32_t)in.depth >> 16) - 1 : -1; // (unsigned: medium ids up to 65 534 fill the upper half)
     const float mis_inv_pdf = volumetric ? igm_max(0.0f, in.inv_pdf) : in.inv_pdf; // "ignore medium interactions" (volpathtracer.art:101,134)
 
     if (in.ent < 0) {
@@ -2534,9 +2552,10 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         return;
     }
 
-    const ig_material& mat = sc.materials[sc.entity_material[in.ent]];
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
     const Surf surf = surface_element<FULL>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    ig_material mat_local;
+    const ig_material& mat = resolve_material<EXPR>(sc, sc.materials[sc.entity_material[in.ent]], surf, -in.dir, mat_local);
     const BsdfCtx<FULL, true, EXPR> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;

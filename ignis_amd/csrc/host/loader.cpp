@@ -1326,8 +1326,57 @@ struct AuxMaterials {
     int32_t base = 0;
 };
 
+// Number properties of a BSDF that are shading expressions (ShadingTree::addNumber / handlePropertyNumber / handleTexture,
+// src/runtime/loader/ShadingTree.cpp:211-251,811-840): a string that does not fold to a constant is compiled like a colour
+// expression — a colour-valued one counts as its average — and becomes an entry of the material's number list (ig_tables.h,
+// IG_MAT_EXPR_NUMBERS), evaluated per hit. The record keeps the property's default.
+struct NumberEntries {
+    std::vector<uint32_t> words; // {kind | slot_a << 8 | slot_b << 16, bits(aspect), program offset} per entry
+};
+static float lowerNumber(const JsonValue& bsdf, const std::string& key, float def, TextureBank& bank, const std::string& owner, NumberEntries& out,
+                         uint32_t kind, int slot_a, int slot_b = 0, float aspect = 1.0f)
+{
+    const JsonValue* v = bsdf.find(key);
+    if (!v)
+        return def;
+    if (v->isNumber())
+        return (float)v->num;
+    if (!v->isString())
+        fail("'" + owner + "': property '" + key + "' is neither a number nor an expression");
+    V3 c;
+    if ((ConstExpr::evaluate(v->str, c) || evaluateWithParameters(v->str, c)) && c.x == c.y && c.y == c.z)
+        return c.x;
+    using igh::pexpr::Type;
+    igh::pexpr::Program prog = bank.compileExpr(v->str, owner);
+    if (prog.type == Type::Bool || prog.type == Type::Vec2 || prog.type == Type::Str)
+        fail("'" + owner + "': expression of property '" + key + "' is a " + igh::pexpr::typeName(prog.type) + ", not a number");
+    if (!igh::pexpr::isScalar(prog.type)) // "Using average instead" (ShadingTree.cpp:835-836): color_average = (r + g + b) / 3
+        prog = bank.compileExpr("avg((" + v->str + ").xyz)", owner);
+    if (prog.is_const)
+        return prog.value[0];
+    uint32_t abits;
+    std::memcpy(&abits, &aspect, 4);
+    out.words.push_back(kind | (uint32_t)slot_a << 8 | (uint32_t)slot_b << 16);
+    out.words.push_back(abits);
+    out.words.push_back((uint32_t)bank.addProgram(prog));
+    return def;
+}
+// roughness (or alpha) + a constant anisotropy -> (alpha_u, alpha_v) (BSDF::setupRoughness, BSDF.cpp:53-99; microfacet::compute_explicit);
+// `dynamic`: the roughness is an expression, the pair is written per hit
+static void lowerRoughnessPair(const JsonValue& bsdf, const std::string& rname, float def, TextureBank& bank, const std::string& owner, NumberEntries& out, uint32_t kind,
+                               int slot_u, int slot_v, float& au, float& av, bool& dynamic)
+{
+    const float an     = getConstNumber(bsdf, "anisotropic", 0.0f, owner);
+    const float aspect = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+    const size_t before = out.words.size();
+    const float r       = lowerNumber(bsdf, rname, def, bank, owner, out, kind, slot_u, slot_v, aspect);
+    dynamic             = out.words.size() != before;
+    au = r / aspect, av = r * aspect;
+}
+
 static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsdfs, const JsonValue& textures, TextureBank& bank, AuxMaterials& aux, int depth = 0)
 {
+    NumberEntries numbers;
     const JsonValue* bsdf = nullptr;
     for (const auto& b : scene_bsdfs.arr)
         if (b.getString("name") == name)
@@ -1347,7 +1396,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
     if (type == "diffuse" || type == "roughdiffuse") {
         m.bsdf_type = IG_BSDF_DIFFUSE;
         lowerColor(*bsdf, "reflectance", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
-        m.p[3] = getConstNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, name);
+        m.p[3] = lowerNumber(*bsdf, bsdf->has("alpha") ? "alpha" : "roughness", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 3);
     } else if (type == "dielectric" || type == "glass" || type == "roughdielectric" || type == "thindielectric") {
         // DielectricBSDF.cpp:13-41; IOR table BSDF.cpp:7-30 (vacuum 1.0, bk7 1.5046)
         if (bsdf->has("distribution") || bsdf->has("roughness_u") || bsdf->has("roughness_v") || bsdf->has("alpha_u") || bsdf->has("alpha_v"))
@@ -1355,8 +1404,8 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         if (bsdf->has("ext_ior_material") || bsdf->has("int_ior_material"))
             fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
         m.bsdf_type = IG_BSDF_DIELECTRIC;
-        m.p[0]      = getConstNumber(*bsdf, "ext_ior", 1.0f, name);
-        m.p[1]      = getConstNumber(*bsdf, "int_ior", 1.5046f, name);
+        m.p[0]      = lowerNumber(*bsdf, "ext_ior", 1.0f, bank, name, numbers, IG_NUM_PLAIN, 0);
+        m.p[1]      = lowerNumber(*bsdf, "int_ior", 1.5046f, bank, name, numbers, IG_NUM_PLAIN, 1);
         const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
         const V3 kt = getColor(*bsdf, "specular_transmittance", V3(1, 1, 1), name);
         m.p[2] = ks.x, m.p[3] = ks.y, m.p[4] = ks.z;
@@ -1365,10 +1414,11 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             // BSDF::setupRoughness (BSDF.cpp:53-99) -> make_dielectric_bsdf (dielectric.art:193-206): a rough interface unless the
             // distribution is a delta one (no roughness given, or alpha <= 1e-4); rough + thin is rough (dielectric.art:202)
             const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
-            const float r           = getConstNumber(*bsdf, rname, 0.1f, name);
-            const float an          = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
-            const float aspect      = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
-            const float au = r / aspect, av = r * aspect;
+            float au, av;
+            bool dynamic;
+            lowerRoughnessPair(*bsdf, rname, 0.1f, bank, name, numbers, IG_NUM_ROUGHNESS_DIELECTRIC, 9, 10, au, av, dynamic);
+            if (dynamic && bsdf->getBool("thin", false))
+                m.flags |= IG_MAT_THIN; // (what the interface is where the expression yields a delta distribution)
             if (bsdf->has(rname) && au > 1e-4f && av > 1e-4f) {
                 m.bsdf_type       = IG_BSDF_ROUGH_DIELECTRIC;
                 const float alpha = au < av ? au : av;
@@ -1398,14 +1448,11 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         const V3 eta   = getColor(*bsdf, "eta", V3(0, 0, 0), name);
         const V3 k     = getColor(*bsdf, "k", V3(1, 1, 1), name);
         const V3 ks    = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
-        const float r  = getConstNumber(*bsdf, rname, 0.1f, name);
-        const float an = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
-        const float aspect = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
+        bool dynamic;
+        lowerRoughnessPair(*bsdf, rname, 0.1f, bank, name, numbers, IG_NUM_ROUGHNESS_DELTA, 9, 10, m.p[9], m.p[10], dynamic);
         m.p[0] = eta.x, m.p[1] = eta.y, m.p[2] = eta.z;
         m.p[3] = k.x, m.p[4] = k.y, m.p[5] = k.z;
         m.p[6] = ks.x, m.p[7] = ks.y, m.p[8] = ks.z;
-        m.p[9]  = r / aspect;
-        m.p[10] = r * aspect;
         if (smooth || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f) // check_if_delta_distribution (microfacet.art:298)
             m.flags |= IG_MAT_SMOOTH;
     } else if (type == "plastic" || type == "roughplastic") {
@@ -1416,54 +1463,50 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             fail("BSDF '" + name + "': only the default isotropic/anisotropic VNDF-GGX roughness form is supported");
         m.bsdf_type = IG_BSDF_PLASTIC;
         lowerColor(*bsdf, "diffuse_reflectance", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
-        m.p[3]      = getConstNumber(*bsdf, "ext_ior", 1.0f, name);  // vacuum (BSDF.cpp:8)
-        m.p[4]      = getConstNumber(*bsdf, "int_ior", 1.49f, name); // polypropylene (BSDF.cpp:17)
+        m.p[3]      = lowerNumber(*bsdf, "ext_ior", 1.0f, bank, name, numbers, IG_NUM_PLAIN, 3);  // vacuum (BSDF.cpp:8)
+        m.p[4]      = lowerNumber(*bsdf, "int_ior", 1.49f, bank, name, numbers, IG_NUM_PLAIN, 4); // polypropylene (BSDF.cpp:17)
         const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
         m.p[6] = ks.x, m.p[7] = ks.y, m.p[8] = ks.z;
         // BSDF::setupRoughness (BSDF.cpp:53-99), as for the conductor
         const std::string rname = bsdf->has("alpha") ? "alpha" : "roughness";
-        const float r           = getConstNumber(*bsdf, rname, 0.1f, name);
-        const float an          = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
-        const float aspect      = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
-        m.p[9]  = r / aspect;
-        m.p[10] = r * aspect;
+        bool dynamic;
+        lowerRoughnessPair(*bsdf, rname, 0.1f, bank, name, numbers, IG_NUM_ROUGHNESS_DELTA, 9, 10, m.p[9], m.p[10], dynamic);
         if (!bsdf->has(rname) || m.p[9] <= 1e-4f || m.p[10] <= 1e-4f)
             m.flags |= IG_MAT_SMOOTH;
     } else if (type == "principled") {
-        // PrincipledBSDF.cpp:14-98: numbers are constants here (the reference also accepts textures / expressions)
+        // PrincipledBSDF.cpp:14-98: every number may be an expression (the number list)
         for (const char* key : { "reflective_ior_spec", "refractive_ior_spec", "ior_spec" })
             if (bsdf->has(key))
                 fail("BSDF '" + name + "': named IOR materials are not supported by this loader");
         m.bsdf_type = IG_BSDF_PRINCIPLED;
         lowerColor(*bsdf, "base_color", V3(0.8f, 0.8f, 0.8f), textures, bank, m, name);
         const float bk7 = 1.5046f; // BSDF.cpp:9
+        // every number may be an expression or a texture (PrincipledBSDF.cpp:22-54: tree.addNumber)
         if (bsdf->has("reflective_ior") || bsdf->has("refractive_ior")) {
-            m.p[3] = getConstNumber(*bsdf, "reflective_ior", bk7, name);
-            m.p[4] = getConstNumber(*bsdf, "refractive_ior", bk7, name);
+            m.p[3] = lowerNumber(*bsdf, "reflective_ior", bk7, bank, name, numbers, IG_NUM_PLAIN, 3);
+            m.p[4] = lowerNumber(*bsdf, "refractive_ior", bk7, bank, name, numbers, IG_NUM_PLAIN, 4);
         } else {
-            m.p[3] = m.p[4] = getConstNumber(*bsdf, "ior", bk7, name);
+            m.p[3] = lowerNumber(*bsdf, "ior", bk7, bank, name, numbers, IG_NUM_PLAIN, 3);
+            m.p[4] = lowerNumber(*bsdf, "ior", bk7, bank, name, numbers, IG_NUM_PLAIN, 4);
         }
-        m.p[5] = getConstNumber(*bsdf, "diffuse_transmission", 0.0f, name);
-        m.p[6] = getConstNumber(*bsdf, "specular_transmission", 0.0f, name);
-        m.p[7] = getConstNumber(*bsdf, "specular_tint", 0.0f, name);
+        m.p[5] = lowerNumber(*bsdf, "diffuse_transmission", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 5);
+        m.p[6] = lowerNumber(*bsdf, "specular_transmission", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 6);
+        m.p[7] = lowerNumber(*bsdf, "specular_tint", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 7);
         if (bsdf->has("roughness_u") || bsdf->has("roughness_v")) {
-            m.p[8] = getConstNumber(*bsdf, "roughness_u", 0.5f, name);
-            m.p[9] = getConstNumber(*bsdf, "roughness_v", 0.5f, name);
+            m.p[8] = lowerNumber(*bsdf, "roughness_u", 0.5f, bank, name, numbers, IG_NUM_PLAIN, 8);
+            m.p[9] = lowerNumber(*bsdf, "roughness_v", 0.5f, bank, name, numbers, IG_NUM_PLAIN, 9);
         } else {
             // microfacet::compute_explicit (src/artic/core/microfacet.art:427-432)
-            const float r      = getConstNumber(*bsdf, "roughness", 0.5f, name);
-            const float an     = getConstNumber(*bsdf, "anisotropic", 0.0f, name);
-            const float aspect = an == 0 ? 1.0f : std::sqrt(1 - std::min(std::max(an, 0.0f), 1.0f) * 0.99f);
-            m.p[8]             = r / aspect;
-            m.p[9]             = r * aspect;
+            bool dynamic;
+            lowerRoughnessPair(*bsdf, "roughness", 0.5f, bank, name, numbers, IG_NUM_ROUGHNESS, 8, 9, m.p[8], m.p[9], dynamic);
         }
-        m.p[10] = getConstNumber(*bsdf, "flatness", 0.0f, name);
-        m.r[0]  = getConstNumber(*bsdf, "metallic", 0.0f, name);
-        m.r[1]  = getConstNumber(*bsdf, "sheen", 0.0f, name);
-        m.r[2]  = getConstNumber(*bsdf, "sheen_tint", 0.0f, name);
-        m.r[3]  = getConstNumber(*bsdf, "clearcoat", 0.0f, name);
-        m.r[4]  = getConstNumber(*bsdf, "clearcoat_gloss", 0.0f, name);
-        m.r[5]  = getConstNumber(*bsdf, "clearcoat_roughness", 0.1f, name);
+        m.p[10] = lowerNumber(*bsdf, "flatness", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 10);
+        m.r[0]  = lowerNumber(*bsdf, "metallic", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 20);
+        m.r[1]  = lowerNumber(*bsdf, "sheen", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 21);
+        m.r[2]  = lowerNumber(*bsdf, "sheen_tint", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 22);
+        m.r[3]  = lowerNumber(*bsdf, "clearcoat", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 23);
+        m.r[4]  = lowerNumber(*bsdf, "clearcoat_gloss", 0.0f, bank, name, numbers, IG_NUM_PLAIN, 24);
+        m.r[5]  = lowerNumber(*bsdf, "clearcoat_roughness", 0.1f, bank, name, numbers, IG_NUM_PLAIN, 25);
         if (bsdf->getBool("thin", false))
             m.flags |= IG_MAT_THIN;
         if (!bsdf->getBool("clearcoat_top_only", true))
@@ -1482,7 +1525,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
             const ig_material im = lowerBsdf(inner, scene_bsdfs, textures, bank, aux, depth + 1);
             if (im.bsdf_type == IG_BSDF_BLEND || (im.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
                 fail("BSDF '" + name + "': nested blends and bump / normal maps inside a blend are not supported by the HIP backend");
-            if ((im.flags & IG_MAT_EXPR_COLOR) || im.bsdf_type == IG_BSDF_RAD_BRTD || im.bsdf_type == IG_BSDF_RAD_ROOS)
+            if ((im.flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NUMBERS)) || im.bsdf_type == IG_BSDF_RAD_BRTD || im.bsdf_type == IG_BSDF_RAD_ROOS)
                 fail("BSDF '" + name + "': expressions and Radiance BSDFs inside a blend are not supported by the HIP backend");
             m.pad[slot++] = aux.base + (int32_t)aux.list.size();
             aux.list.push_back(im);
@@ -1507,7 +1550,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         ig_material inner   = lowerBsdf(masked, scene_bsdfs, textures, bank, aux, depth + 1);
         if (inner.bsdf_type == IG_BSDF_BLEND || (inner.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)))
             fail("BSDF '" + name + "': blends and bump / normal maps inside a mask are not supported by the HIP backend");
-        if ((inner.flags & IG_MAT_EXPR_COLOR) || inner.bsdf_type == IG_BSDF_RAD_BRTD || inner.bsdf_type == IG_BSDF_RAD_ROOS)
+        if ((inner.flags & (IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NUMBERS)) || inner.bsdf_type == IG_BSDF_RAD_BRTD || inner.bsdf_type == IG_BSDF_RAD_ROOS)
             fail("BSDF '" + name + "': expressions and Radiance BSDFs inside a mask are not supported by the HIP backend");
         ig_material through{};
         through.bsdf_type = IG_BSDF_TRANSPARENT; // make_passthrough_bsdf = white perfect refraction
@@ -1527,7 +1570,7 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.bsdf_type = IG_BSDF_PHONG;
         const V3 ks = getColor(*bsdf, "specular_reflectance", V3(1, 1, 1), name);
         m.p[0] = ks.x, m.p[1] = ks.y, m.p[2] = ks.z;
-        m.p[3] = getConstNumber(*bsdf, "exponent", 30.0f, name);
+        m.p[3] = lowerNumber(*bsdf, "exponent", 30.0f, bank, name, numbers, IG_NUM_PLAIN, 3);
     } else if (type == "bumpmap" || type == "normalmap") {
         // MapBSDF.cpp:17-52: make_bumpmap(ctx, inner, texture_dx(map).r, texture_dy(map).r, strength) /
         // make_normalmap(ctx, inner, map colour, strength)
@@ -1599,6 +1642,14 @@ static ig_material lowerBsdf(const std::string& name, const JsonValue& scene_bsd
         m.tex_id = bank.addProgram(prog);
     } else {
         fail("BSDF '" + name + "': type '" + type + "' is not supported by the HIP backend");
+    }
+    if (!numbers.words.empty()) {
+        // the material's number list: count, then the entries; its offset travels as the bits of r[7]
+        const uint32_t at = (uint32_t)bank.expr_code->size();
+        bank.expr_code->push_back((uint32_t)(numbers.words.size() / 3));
+        bank.expr_code->insert(bank.expr_code->end(), numbers.words.begin(), numbers.words.end());
+        m.flags |= IG_MAT_EXPR_NUMBERS;
+        std::memcpy(&m.r[7], &at, 4);
     }
     return m;
 }

@@ -267,6 +267,8 @@ def convert(scene):
 
     def with_textures(entry, o):
         for n, c in kids(o, "texture"):
+            if id(c) not in tex_id:  # a texture nested where the exporter does not collect them (media, emitters, shapes)
+                raise MtsError(f"<{o.tag} type=\"{o.plugin}\">: nested texture '{n}' is not supported there")
             entry[n if n is not None else "texture"] = tex_id[id(c)]
         return entry
 
@@ -363,7 +365,7 @@ def main(argv=None):
     defines = dict(d.split("=", 1) for d in args.define)
     try:
         data = convert_file(args.input, defines)
-    except (MtsError, ET.ParseError, OSError) as e:
+    except (MtsError, ET.ParseError, OSError, KeyError, ValueError) as e:  # (KeyError: a ref / alias naming an id nobody defines)
         print(f"error: {e}", file=sys.stderr)
         return 1
     dst = args.output or os.path.splitext(args.input)[0] + ".json"

@@ -127,8 +127,26 @@ enum ig_material_flags {
                                    * (include/ig_expr.h; ShadingTree::addColor with a PExpr string, src/runtime/loader/ShadingTree.cpp) */
     IG_MAT_EXPR_WEIGHT = 1u << 10, /* blend / mask: the weight is the number expression at igd_scene.expr_code[tex_id] (BlendBSDF.cpp:40,
                                     * MaskBSDF.cpp:30-55 with ShadingTree::addNumber), p[0] is unused */
+    IG_MAT_EXPR_NUMBERS = 1u << 11, /* some NUMBER properties (roughness, metallic, ...) are shading expressions evaluated per hit
+                                     * (ShadingTree::addNumber with a PExpr string or texture name, src/runtime/loader/ShadingTree.cpp:
+                                     * 211-251; a colour-valued one counts as its average). bits(r[7]) = offset in igd_scene.expr_code of
+                                     * the list: word 0 = count, then per entry three words {kind | slot_a << 8 | slot_b << 16,
+                                     * bits(aspect), program offset} (enum ig_number_kind). The record keeps each property's default as
+                                     * the value where no hit exists (the "Albedo" AOV). Not inside blends. */
     IG_MAT_EXPR_NORMAL = 1u << 9, /* wrapped in a "transform" BSDF (TransformBSDF.cpp:17-49, make_normal_set src/artic/bsdf/map.art:36-42)
                                    * whose normal is the program at igd_scene.expr_code[tex_id] */
+};
+
+/* Entries of a material's number list (IG_MAT_EXPR_NUMBERS). Slots index the record's floats: 0-11 p[], 12-19 q[], 20-27 r[]. */
+enum ig_number_kind {
+    IG_NUM_PLAIN = 0,       /* slot_a = value */
+    /* roughness with a constant anisotropy (microfacet::compute_explicit, src/artic/core/microfacet.art:427-432):
+     * slot_a = value / aspect, slot_b = value * aspect */
+    IG_NUM_ROUGHNESS = 1,
+    /* ... of a conductor / plastic coating: also IG_MAT_SMOOTH <=> either alpha <= 1e-4 (check_if_delta_distribution, :298) */
+    IG_NUM_ROUGHNESS_DELTA = 2,
+    /* ... of a dielectric interface: also bsdf_type rough <=> both alphas > 1e-4, p[8] = the pdf epsilon (dielectric.art:67-82) */
+    IG_NUM_ROUGHNESS_DIELECTRIC = 3,
 };
 
 /* One record per material (= unique bsdf / area-light entity,
@@ -163,6 +181,31 @@ typedef struct ig_material {
                        * (inner + 1) | (outer + 1) << 16, so 0 = no_medium_interface */
     float r[8];
 } ig_material;
+
+/* Writes one evaluated number into a (local copy of a) material record; shared by the HIP kernels and the oracle. */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline void ig_material_set_number(ig_material* m, uint32_t head, float aspect, float value)
+{
+    const uint32_t kind = head & 0xFFu, a = (head >> 8) & 0xFFu, b = (head >> 16) & 0xFFu;
+    float* slots[3]     = { m->p, m->q, m->r };
+    if (kind == IG_NUM_PLAIN) {
+        slots[a < 12 ? 0 : (a < 20 ? 1 : 2)][a < 12 ? a : (a < 20 ? a - 12 : a - 20)] = value;
+        return;
+    }
+    const float au = value / aspect, av = value * aspect;
+    slots[a < 12 ? 0 : (a < 20 ? 1 : 2)][a < 12 ? a : (a < 20 ? a - 12 : a - 20)] = au;
+    slots[b < 12 ? 0 : (b < 20 ? 1 : 2)][b < 12 ? b : (b < 20 ? b - 12 : b - 20)] = av;
+    if (kind == IG_NUM_ROUGHNESS_DELTA) {
+        m->flags = (au <= 1e-4f || av <= 1e-4f) ? (m->flags | IG_MAT_SMOOTH) : (m->flags & ~(uint32_t)IG_MAT_SMOOTH);
+    } else if (kind == IG_NUM_ROUGHNESS_DIELECTRIC) {
+        const int rough   = au > 1e-4f && av > 1e-4f;
+        const float alpha = au < av ? au : av;
+        m->bsdf_type      = rough ? IG_BSDF_ROUGH_DIELECTRIC : IG_BSDF_DIELECTRIC;
+        m->p[8]           = alpha <= 0.01f ? 1e-3f : (alpha <= 0.1f ? 1e-4f : 1e-5f);
+    }
+}
 
 /* ---- Bitmap textures --------------------------------------------------- */
 

@@ -337,8 +337,8 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
         for (int ent = 0, begin = 0; ent < E; ++ent) {
             const int end = ray_ends[ent];
             if (begin < end) {
-                const Entity entity    = load_entity(sc, ent);
-                const ig_material& mat = sc.materials[entity.mat_id];
+                const Entity entity         = load_entity(sc, ent);
+                const ig_material& mat_base = sc.materials[entity.mat_id];
                 for (int i = begin; i < end; ++i) {
                     const Ray ray     = read_ray(primary, i);
                     const Hit hit     = Hit{ primary.t[i], primary.u[i], primary.v[i], primary.prim_id[i], primary.ent_id[i] };
@@ -350,6 +350,8 @@ void trace_tile(const igd_scene& sc, const oracle_settings& cfg, const CameraSet
 
                     PTRayPayload payload      = read_payload(primary, i);
                     const SurfaceElement surf = surface_element(sc, entity, ray, hit);
+                    ig_material mat_local;
+                    const ig_material& mat = resolve_material(sc, mat_base, surf, vec3_neg(ray.dir), mat_local); // number expressions, per hit
                     // a bump-mapped material hands its inner BSDF a re-oriented surface (bsdf/map.art:64-67)
                     const SurfaceElement bsurf = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)) ? bumped_surface(sc, mat, surf, ray) : surf;
                     // make_doublesided_bsdf (bsdf/common.art:28-46): from behind, the BSDF is built on the surface "as entered"
@@ -469,8 +471,9 @@ void trace_light_paths(const igd_scene& sc, const oracle_settings& cfg, const Ca
                     if (hit.prim_id < 0)
                         break; // TechniqueNoMissFunction
                     const Entity entity        = load_entity(sc, hit.ent_id);
-                    const ig_material& mat     = sc.materials[entity.mat_id];
                     const SurfaceElement surf  = surface_element(sc, entity, ray, hit);
+                    ig_material mat_local;
+                    const ig_material& mat     = resolve_material(sc, sc.materials[entity.mat_id], surf, vec3_neg(ray.dir), mat_local);
                     const bool bumped          = (mat.flags & (IG_MAT_BUMP | IG_MAT_NORMALMAP | IG_MAT_EXPR_NORMAL)) != 0;
                     const SurfaceElement bsurf = bumped ? bumped_surface(sc, mat, surf, ray) : surf;
                     const bool ds_flip         = (mat.flags & IG_MAT_DOUBLESIDED) && !surf.is_entering;
@@ -546,10 +549,11 @@ void render_photon_mapped(const igd_scene& sc, const oracle_settings& cfg, const
             const Hit hit = traverse_scene(sc, ray, false, cnt.trav);
             if (hit.prim_id < 0)
                 break; // TechniqueNoMissFunction
-            const Entity entity    = load_entity(sc, hit.ent_id);
-            const ig_material& mat = sc.materials[entity.mat_id];
+            const Entity entity = load_entity(sc, hit.ent_id);
             BsdfSetup b;
             b.surf = surface_element(sc, entity, ray, hit);
+            ig_material mat_local;
+            const ig_material& mat = resolve_material(sc, sc.materials[entity.mat_id], b.surf, vec3_neg(ray.dir), mat_local);
             make_bsdf(b, mat, ray, true);
             const bool emissive = mat.light_id >= 0, all_delta = b.bsdf.is_all_delta();
             const Vec3 out_dir = vec3_neg(ray.dir);
@@ -639,10 +643,11 @@ void render_photon_mapped(const igd_scene& sc, const oracle_settings& cfg, const
                         }
                         break;
                     }
-                    const Entity entity    = load_entity(sc, hit.ent_id);
-                    const ig_material& mat = sc.materials[entity.mat_id];
+                    const Entity entity = load_entity(sc, hit.ent_id);
                     BsdfSetup b;
                     b.surf = surface_element(sc, entity, ray, hit);
+                    ig_material mat_local;
+                    const ig_material& mat = resolve_material(sc, sc.materials[entity.mat_id], b.surf, vec3_neg(ray.dir), mat_local);
                     make_bsdf(b, mat, ray, false);
                     const bool emissive = mat.light_id >= 0, all_delta = b.bsdf.is_all_delta();
                     const Vec3 out_dir = vec3_neg(ray.dir);

@@ -10,6 +10,7 @@
 #include "ig_photon.h"
 
 #include <algorithm>
+#include <cstring>
 #include <functional>
 #include <limits>
 
@@ -1552,6 +1553,24 @@ static inline void rad_roos_factors(const ig_material& m, float cosN, float& rf,
     const float z = igm_acos(igm_abs(clampf(cosN, -1, 1))) * 0.636619772368f;
     tau = trns_w * (1 - a * igm_pow(z, alpha(trns_q)) - b(trns_q) * igm_pow(z, beta) - c(trns_p, trns_q) * igm_pow(z, gamma(trns_p, trns_q)));
     rf  = refl_w + (1 - refl_w) * igm_pow(z, gamma(refl_p, refl_q));
+}
+
+// IG_MAT_EXPR_NUMBERS (ig_tables.h; ShadingTree::addNumber with an expression): the record with its number expressions evaluated at
+// this hit, in `local`
+static inline const ig_material& resolve_material(const igd_scene& sc, const ig_material& mat, const SurfaceElement& surf, Vec3 view, ig_material& local)
+{
+    if (!(mat.flags & IG_MAT_EXPR_NUMBERS))
+        return mat;
+    local = mat;
+    uint32_t at;
+    std::memcpy(&at, &mat.r[7], 4);
+    const uint32_t* lst = sc.expr_code + at;
+    for (uint32_t i = 0; i < lst[0]; ++i) {
+        float aspect;
+        std::memcpy(&aspect, &lst[2 + 3 * i], 4);
+        ig_material_set_number(&local, lst[1 + 3 * i], aspect, eval_expression(sc, (int32_t)lst[3 + 3 * i], surf, view).x);
+    }
+    return local;
 }
 
 struct Bsdf {

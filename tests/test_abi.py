@@ -764,7 +764,7 @@ def test_plane_detection_frames_and_rejections():
 
 def test_constant_expressions_in_number_and_colour_properties():
     """The exporters write numbers as expressions (`"roughness": "(0.175)^2"`); constant ones are folded by the loader: PExpr's power
-    operator (tighter than a sign, right-associative), Pi / E / Eps, a few scalar functions; anything with variables is refused."""
+    operator (tighter than a sign, right-associative), Pi / E / Eps, a few scalar functions. Numbers that vary over the surface become entries of the material's number list; the few that cannot are refused."""
     import json
     from conftest import SCENES, flat_scene
     from ignis_amd.tables import LoadedScene
@@ -783,4 +783,4 @@ def test_constant_expressions_in_number_and_colour_properties():
     p = material({"type": "diffuse", "reflectance": "color(cos(Pi), 2^3^2 / 512, sqrt(max(4, 1)))"})
     assert p[0:3] == pytest.approx([-1.0, 1.0, 2.0], abs=1e-6)
     with pytest.raises(RuntimeError, match="not a constant number"):
-        material({"type": "dielectric", "roughness": "uv.x * 0.5"})
+        material({"type": "conductor", "roughness": 0.2, "anisotropic": "uv.x * 0.5"})  # (roughness itself may vary: tests/test_number_expressions.py)
