@@ -38,8 +38,13 @@ IG_DEV uint32_t make_seed(int sample, int iter, int frame, int x, int y, int use
 IG_DEV uint32_t tea4(uint32_t v0, uint32_t v1) // random.art:15-24
 {
     uint32_t sum = 0;
+#ifdef IG_EXP_TEA_ROUNDS
+    constexpr int kRounds = IG_EXP_TEA_ROUNDS; // experiment (wrong images): the share of the generator in the shading kernels
+#else
+    constexpr int kRounds = 4;
+#endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kRounds; ++i) {
         sum += 0x9e3779b9u;
         v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
         v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
@@ -2245,6 +2250,32 @@ IG_DEV float select_pdf(const DevScene& sc, int li, f3 from_pos)
 
 // ---------------------------------------------------------------- one path vertex
 
+// Where does a wave of k_shade spend its cycles? A build with -DIG_SHADE_CLOCKS (tools/shade_clocks.py) reads the shader clock at
+// phase boundaries after draining the outstanding memory operations, so a phase is charged with the latencies of the loads it issued;
+// everywhere else the marks are empty.
+struct NoClock {
+    IG_DEV void mark(int) {}
+};
+#ifdef IG_SHADE_CLOCKS
+struct PhaseClock {
+    unsigned long long last;
+    unsigned long long acc[12];
+    IG_DEV void start()
+    {
+        for (int k = 0; k < 12; ++k)
+            acc[k] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    IG_DEV void mark(int k)
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[k] += now - last;
+        last = now;
+    }
+};
+#endif
+
 // make_homogeneous_medium / make_vacuum_medium (medium/homogeneous.art:1-58, driver/medium.art) with the Henyey-Greenstein phase
 // function (phase/henyeygreenstein.art) for the volumetric path tracer
 struct Medium {
@@ -2486,8 +2517,8 @@ IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, techniq
 // DEBUG_VIEWS: the instantiation for the debug technique (its 28 views, with a second copy of the BSDF code for the BSDF check,
 // cost the ordinary full kernel ten times its spills when they were a run-time branch of it)
 // EXPR: the instantiation for scenes whose materials carry shading expressions (include/ig_expr.h)
-template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false>
-IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out)
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, class CLK = NoClock>
+IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out, CLK&& clk = CLK{})
 {
     out.has_radiance = false;
     out.shadow       = false;
@@ -2554,9 +2585,11 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
 
     // the path tracer itself (emission, NEE geometry, ray offsets) keeps the unperturbed surface
     const Surf surf = surface_element<FULL>(sc, in.ent, in.prim, in.org, in.dir, in.t, in.u, in.v);
+    clk.mark(2);
     ig_material mat_local;
     const ig_material& mat = resolve_material<EXPR>(sc, sc.materials[sc.entity_material[in.ent]], surf, -in.dir, mat_local);
     const BsdfCtx<FULL, true, EXPR> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
+    clk.mark(3);
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 
@@ -2567,7 +2600,11 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const int lpix   = within / fr.spi;
     const int px     = lpix % fr.width;
     const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
+#ifdef IG_EXP_CHEAP_SEED // experiment: what do the seed hash and the three integer divisions in front of it cost? (wrong images)
+    Tea rnd{ (uint32_t)in.ray_id * 747796405u + 12345u, in.rnd };
+#else
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
+#endif
 
     if constexpr (FULL && DEBUG_VIEWS) {
         if (tech.type == IG_TECHNIQUE_WIREFRAME) {
@@ -2639,6 +2676,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         }
     }
 
+    clk.mark(4);
     // ---- on_shadow (technique/pathtracer.art:52-117): next event estimation
     if (nee && !bsdf.all_delta() && sc.light_count != 0 && depth + 1 <= tech.max_depth) {
         float sel_pdf;
@@ -2828,6 +2866,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         }
     }
 
+    clk.mark(5);
     // ---- on_bounce (technique/pathtracer.art:170-210; technique/volpathtracer.art:155-247)
     if (depth + 1 <= tech.max_depth) {
         out.b_tmin = kRayOffset;

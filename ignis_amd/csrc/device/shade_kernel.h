@@ -22,6 +22,14 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
+#ifndef IG_SHADE_SORT_LEAN
+#define IG_SHADE_SORT_LEAN 0
+#endif
+#ifndef IG_SHADE_ATOMIC_ACCUM
+#define IG_SHADE_ATOMIC_ACCUM 0
+#endif
+constexpr bool kSortLean          = IG_SHADE_SORT_LEAN != 0;
+constexpr bool kShadeAtomicAccum = IG_SHADE_ATOMIC_ACCUM != 0;
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
 template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false, int PPM = 0>
 __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
@@ -39,13 +47,23 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     const DevScene& sc = a.scene;
     const uint32_t n   = *a.in_count;
     const int M        = (int)sc.material_count;
-    const bool do_sort = (M + 2) <= kMaxSortBins;
+    // The lean variant has three BSDF models and waits for memory, not for issue slots (a TEA with one round instead of four changes its
+    // time by 1 %, profiles/r03_experiment_shade.txt): the sort's two dependent loads and five barriers in front of every window cost it
+    // more (4 %) than the divergence they remove. The full variants sort.
+    const bool do_sort = (FULL || kSortLean) && (M + 2) <= kMaxSortBins;
 
     const ShadeFrame fr = a.frame;
 
+#ifdef IG_SHADE_CLOCKS
+    PhaseClock clk;
+    clk.start();
+#else
+    NoClock clk;
+#endif
     const uint32_t chunks = (n + kShadeThreads - 1) / kShadeThreads;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         const uint32_t base = chunk * kShadeThreads;
+        clk.mark(10); // loop overhead (and, for the first window, the kernel's prologue)
 
         // ---- workgroup-local counting sort by material (miss = bin M, out of range = bin M + 1)
         uint32_t j = base + tid;
@@ -89,6 +107,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             __syncthreads();
         }
 
+        clk.mark(0); // the sort
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
         int ray_id = 0;
@@ -108,33 +127,53 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             in.ent     = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
+            clk.mark(1); // the ray's columns
             if constexpr (PPM != 0)
                 shade_vertex_ppm<PPM == 1>(sc, fr, a.ppm, in, out);
             else if constexpr (LT)
                 shade_vertex_lt(sc, fr, LtCamera(a.lt_cam), in, out, s_slot);
             else
-                shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out);
+                shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out, clk);
+            clk.mark(6); // on_bounce (a miss: everything)
             if (out.has_radiance) {
-                // per-sample accumulator: plain read-modify-write, the slot is owned by this ray
+                // per-sample accumulator; the slot is owned by this ray, so no-return float atomics (performed in L2) give the sum a
+                // read-modify-write gives, without the HBM round trip of the read at the end of nearly every window
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
-                float4 v    = *acc;
-                v.x += out.radiance.r * a.inv_spi;
-                v.y += out.radiance.g * a.inv_spi;
-                v.z += out.radiance.b * a.inv_spi;
-                *acc = v;
+                if (kShadeAtomicAccum) {
+                    unsafeAtomicAdd(&acc->x, out.radiance.r * a.inv_spi);
+                    unsafeAtomicAdd(&acc->y, out.radiance.g * a.inv_spi);
+                    unsafeAtomicAdd(&acc->z, out.radiance.b * a.inv_spi);
+                } else {
+                    float4 v = *acc;
+                    v.x += out.radiance.r * a.inv_spi;
+                    v.y += out.radiance.g * a.inv_spi;
+                    v.z += out.radiance.b * a.inv_spi;
+                    *acc = v;
+                }
                 if (a.accum_direct && in.ent >= 0) { // aov_di.splat in on_hit (technique/pathtracer.art:133); on_miss has none
                     float4* di = a.accum_direct + ((int64_t)ray_id - a.id_base);
-                    float4 w   = *di;
-                    w.x += out.radiance.r * a.inv_spi;
-                    w.y += out.radiance.g * a.inv_spi;
-                    w.z += out.radiance.b * a.inv_spi;
-                    *di = w;
+                    if (kShadeAtomicAccum) {
+                        unsafeAtomicAdd(&di->x, out.radiance.r * a.inv_spi);
+                        unsafeAtomicAdd(&di->y, out.radiance.g * a.inv_spi);
+                        unsafeAtomicAdd(&di->z, out.radiance.b * a.inv_spi);
+                    } else {
+                        float4 w = *di;
+                        w.x += out.radiance.r * a.inv_spi;
+                        w.y += out.radiance.g * a.inv_spi;
+                        w.z += out.radiance.b * a.inv_spi;
+                        *di = w;
+                    }
                 }
             }
         }
 
+        clk.mark(7); // the accumulator
         // ---- append survivors / shadow rays: ONE atomic per workgroup and queue (replaces K9). A single
         // counter word sustains only ~88 atomics/us, so per-wave appends would serialise the kernel.
+        // (Ranks from ballots instead of the LDS atomics, the counts scanned by one wave over a DPP row and the bookkeeping words used
+        // alternately, i.e. two barriers per window instead of four, measured no faster on the lean variant — 73.7 against 73.1 ms of
+        // shading per 20 steps — and 6 % slower on the full one, whose 64-bit lane masks became 22 more spilled registers:
+        // profiles/r03_experiment_shade.txt. What a window waits for here is the reservation's round trip.)
         {
             // Continuation rays leave grouped by the octant of their direction: rays of one octant visit BVH children
             // in the same order, so the next round's traversal waves diverge less. (Order inside the stream is free:
@@ -154,6 +193,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 brank = atomicAdd(&s_bin[bkey], 1u);
             }
             __syncthreads();
+            clk.mark(8); // ballots, bins, the barrier in front of the reservation
             if (tid == 0) {
                 // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
                 uint32_t tb = 0;
@@ -187,8 +227,17 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
             }
             __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
+            clk.mark(9); // the reservation, the stores, the last barrier
         }
     }
+#ifdef IG_SHADE_CLOCKS
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) {
+            atomicAdd(&a.qs->section_passes[k], clk.acc[k]);
+            atomicAdd(&a.qs->section_lanes[k], clk.acc[6 + k]);
+        }
+    }
+#endif
 }
 
 

@@ -13,6 +13,14 @@ namespace igdev {
 #define IG_REFILL_IDLE 32
 #endif
 constexpr int kRefillIdle = IG_REFILL_IDLE;  // refill when at least this many lanes of a wave are idle
+#ifndef IG_ATOMIC_SPLAT
+#define IG_ATOMIC_SPLAT 0
+#endif
+#ifndef IG_EARLY_SPLAT
+#define IG_EARLY_SPLAT 1
+#endif
+constexpr bool kAtomicSplat = IG_ATOMIC_SPLAT != 0; // sums into the per-sample accumulators as no-return float atomics
+constexpr bool kEarlySplat  = IG_EARLY_SPLAT != 0;  // any hit: the colour of a shadow ray is loaded with the ray
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false>
@@ -39,6 +47,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     bool has_ray          = false;
     uint32_t ray_idx      = 0;
     uint32_t st_unoccluded = 0;
+    float4 splat          = any_float4(); // any hit: the shadow ray's colour and slot, fetched with the ray (kEarlySplat)
     uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
     bool fatal = false;
 
@@ -84,6 +93,8 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
                              a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
                 }
+                if (ANY_HIT && kEarlySplat && a.accum)
+                    splat = a.col[idx];
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
@@ -119,14 +130,18 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                         if (a.accum) {
                             // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample
                             // accumulator: plain read-modify-write, the slot is owned by this ray.
-                            const float4 c = a.col[ray_idx];
+                            // The colour came with the ray and the sums are no-return float atomics performed in L2 (the slot is owned by
+                            // this ray, so the sum is the read-modify-write's): a finished lane costs its wave no round trip. As a load of
+                            // the colour, a dependent load of the slot and a store, each event held the whole wave for two HBM latencies,
+                            // in order in front of its next node loads (waves waiting 63 %, VALU issue 0.65, profiles/r03_rocprofv3_pmc.txt).
+                            const float4 c = kEarlySplat ? splat : a.col[ray_idx];
                             float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                            if (a.atomic_splat) {
-                                // the light tracer's connections (on_advanced_shadow_miss, technique/lighttracer.art:116-120): many paths
-                                // add into the slots of one pixel
-                                atomicAdd(&dst->x, c.x * a.inv_spi);
-                                atomicAdd(&dst->y, c.y * a.inv_spi);
-                                atomicAdd(&dst->z, c.z * a.inv_spi);
+                            // (the light tracer's connections, on_advanced_shadow_miss, technique/lighttracer.art:116-120, add into the
+                            // slots of one pixel from many paths: atomics for correctness there)
+                            if (kAtomicSplat || a.atomic_splat) {
+                                unsafeAtomicAdd(&dst->x, c.x * a.inv_spi);
+                                unsafeAtomicAdd(&dst->y, c.y * a.inv_spi);
+                                unsafeAtomicAdd(&dst->z, c.z * a.inv_spi);
                             } else {
                                 float4 v = *dst;
                                 v.x += c.x * a.inv_spi;
@@ -136,11 +151,17 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             }
                             if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
                                 float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                                float4 w   = *nd;
-                                w.x += c.x * a.inv_spi;
-                                w.y += c.y * a.inv_spi;
-                                w.z += c.z * a.inv_spi;
-                                *nd = w;
+                                if (kAtomicSplat) {
+                                    unsafeAtomicAdd(&nd->x, c.x * a.inv_spi);
+                                    unsafeAtomicAdd(&nd->y, c.y * a.inv_spi);
+                                    unsafeAtomicAdd(&nd->z, c.z * a.inv_spi);
+                                } else {
+                                    float4 w = *nd;
+                                    w.x += c.x * a.inv_spi;
+                                    w.y += c.y * a.inv_spi;
+                                    w.z += c.z * a.inv_spi;
+                                    *nd = w;
+                                }
                             }
                         }
                     }
