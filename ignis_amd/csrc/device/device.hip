@@ -131,6 +131,8 @@ struct igd_device {
     DevBuf<ig_material> materials;
     DevBuf<int32_t> entity_material;
     DevBuf<uint4> entity_ext;
+    DevBuf<uint32_t> entity_rec;
+    DevBuf<float4> prim_records;
     DevBuf<ig_light> lights;
     DevBuf<float> light_hierarchy, light_cdf;
     DevBuf<ig_medium> media;
@@ -676,6 +678,64 @@ void assignScene(igd_device* d, const igd_scene* s)
     }
     d->entity_ext.upload(ext4.data(), ext4.size());
 
+    // Per triangle of every mesh, what a hit on it reads (DevScene::prim_records): the three vertices, normals and texture
+    // coordinates behind its index record, gathered into six consecutive 16-byte rows. A hit then goes entity -> record (one or two
+    // cache lines) instead of entity -> indices -> ten lines of three attribute arrays: one dependent round trip and four load
+    // instructions fewer per shaded vertex, the same values through the same arithmetic. 96 bytes per triangle of HBM.
+    {
+        std::vector<uint32_t> shape_rec(s->shape_count, 0xFFFFFFFFu);
+        uint64_t rows = 0;
+        for (uint32_t i = 0; i < s->shape_count; ++i) {
+            if (s->shape_lookups[i].type_id == IG_SHAPE_SPHERE)
+                continue;
+            const uint64_t base = s->shape_lookups[i].offset;
+            if (base + 48 > s->shape_data_size)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape offset out of range" };
+            int32_t hdr[4];
+            std::memcpy(hdr, s->shape_data + base, 16);
+            if (hdr[0] < 0 || hdr[1] < 0 || hdr[2] < 0 || hdr[3] < 0)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: negative count in a shape header" };
+            shape_rec[i] = (uint32_t)rows;
+            rows += (uint64_t)hdr[0] * 6;
+            if (rows >= ((uint64_t)1 << 32))
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: more than 715 million triangles in the scene's meshes" };
+        }
+        std::vector<float4> rec((size_t)rows);
+        for (uint32_t i = 0; i < s->shape_count; ++i) {
+            if (shape_rec[i] == 0xFFFFFFFFu)
+                continue;
+            const uint64_t base = s->shape_lookups[i].offset;
+            int32_t hdr[4]; // faces, vertices, normals, texcoords
+            std::memcpy(hdr, s->shape_data + base, 16);
+            const uint64_t verts = base + 48, norms = verts + (uint64_t)hdr[1] * 16, inds = norms + (uint64_t)hdr[2] * 16, texs = inds + (uint64_t)hdr[0] * 16;
+            if (texs + (uint64_t)hdr[3] * 8 > s->shape_data_size)
+                throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: shape table is truncated" };
+            const uint8_t* sd = s->shape_data;
+            float4* out       = rec.data() + shape_rec[i];
+            for (int32_t f = 0; f < hdr[0]; ++f, out += 6) {
+                int32_t tri[4];
+                std::memcpy(tri, sd + inds + (uint64_t)f * 16, 16);
+                float tex[3][2];
+                for (int k = 0; k < 3; ++k) {
+                    if (tri[k] < 0 || tri[k] >= hdr[1] || tri[k] >= hdr[2] || tri[k] >= hdr[3])
+                        throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: a triangle's vertex index is outside of its shape's vertex, normal or texture coordinate array" };
+                    std::memcpy(&out[k], sd + verts + (uint64_t)tri[k] * 16, 12);
+                    std::memcpy(&out[3 + k], sd + norms + (uint64_t)tri[k] * 16, 12);
+                    std::memcpy(tex[k], sd + texs + (uint64_t)tri[k] * 8, 8);
+                }
+                out[0].w = tex[0][0], out[1].w = tex[0][1], out[2].w = tex[1][0], out[3].w = tex[1][1], out[4].w = tex[2][0], out[5].w = tex[2][1];
+            }
+        }
+        d->prim_records.upload(rec.data(), rec.size());
+        std::vector<uint32_t> er(s->entity_count);
+        for (uint32_t e = 0; e < s->entity_count; ++e) {
+            uint32_t shape_id;
+            std::memcpy(&shape_id, s->entities + (size_t)e * IG_ENTITY_FLOATS + 33, 4);
+            er[e] = shape_rec[shape_id];
+        }
+        d->entity_rec.upload(er.data(), er.size());
+    }
+
     DevScene& ds            = d->dscene;
     ds.geom                 = d->geom.ptr;
     ds.scene_nodes_off      = scene_nodes_off;
@@ -690,6 +750,8 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.materials            = d->materials.ptr;
     ds.entity_material      = d->entity_material.ptr;
     ds.entity_ext           = d->entity_ext.ptr;
+    ds.entity_rec           = d->entity_rec.ptr;
+    ds.prim_records         = d->prim_records.ptr;
     ds.lights               = d->lights.ptr;
     ds.entity_count         = s->entity_count;
     ds.material_count       = s->material_count;
@@ -1959,6 +2021,8 @@ int32_t igd_release_all(igd_device* dev)
         dev->materials.release();
         dev->entity_material.release();
         dev->entity_ext.release();
+        dev->entity_rec.release();
+        dev->prim_records.release();
         dev->lights.release();
         dev->light_hierarchy.release();
         dev->light_codes.release();

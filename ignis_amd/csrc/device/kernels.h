@@ -49,6 +49,10 @@ struct DevScene {
     // per entity: byte offsets of its shape's vertex / normal / index / texcoord arrays inside shape_data, so that the
     // shading chain is entity -> indices -> attributes (the reference walks entity -> shape table -> shape header first)
     const uint4* entity_ext;
+    // per entity: the first row of its shape's triangle records in prim_records (six 16-byte rows per triangle: v0 v1 v2 n0 n1 n2 with
+    // the three texture coordinates in the .w lanes), what surface_element() reads for a hit
+    const uint32_t* entity_rec;
+    const float4* prim_records;
     // bitmap textures (ig_material.tex_id)
     const ig_texture* textures;
     const uint8_t* texture_data;

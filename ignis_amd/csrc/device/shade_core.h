@@ -110,43 +110,42 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     global.c0 = f3{ r3.x, r3.y, r3.z }, global.c1 = f3{ r3.w, r4.x, r4.y }, global.c2 = f3{ r4.z, r4.w, r5.x }, global.c3 = f3{ r5.y, r5.z, r5.w };
     m33 nmat;
     nmat.c0 = f3{ r6.x, r6.y, r6.z }, nmat.c1 = f3{ r6.w, r7.x, r7.y }, nmat.c2 = f3{ r7.z, r7.w, r8.x };
-    // shape arrays (header {faces, vertices, normals, texcoords}, then vertices, normals, indices, texcoords:
-    // TriMeshProvider.cpp:575-596) through the offsets igd_assign_scene precomputed per entity
-    const uint4 ext    = sc.entity_ext[ent_id];
-    if (SPHERES && ext.y == 0xFFFFFFFFu) {
-        // analytic sphere: make_sphere_shape.surface_element (shapes/sphere.art:52-73); ext.x = its {centre, radius} record.
-        // (only in the full kernel variants, which igd_assign_scene selects for scenes with spheres)
-        const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x);
-        Surf s;
-        s.point         = org + dir * t;
-        const f3 d      = s.point - xform_point(global, f3{ sp.x, sp.y, sp.z });
-        const float len = len3(d);
-        const f3 n      = d * (1 / len);
-        s.tex           = f2{ u, v };
-        s.entering      = true;
-        s.face_normal   = n;
-        s.local         = orthonormal_basis(n);
-        return s;
+    if (SPHERES) {
+        const uint4 ext = sc.entity_ext[ent_id];
+        if (ext.y == 0xFFFFFFFFu) {
+            // analytic sphere: make_sphere_shape.surface_element (shapes/sphere.art:52-73); ext.x = its {centre, radius} record.
+            // (only in the full kernel variants, which igd_assign_scene selects for scenes with spheres)
+            const float4 sp = *reinterpret_cast<const float4*>(sc.shape_data + ext.x);
+            Surf s;
+            s.point         = org + dir * t;
+            const f3 d      = s.point - xform_point(global, f3{ sp.x, sp.y, sp.z });
+            const float len = len3(d);
+            const f3 n      = d * (1 / len);
+            s.tex           = f2{ u, v };
+            s.entering      = true;
+            s.face_normal   = n;
+            s.local         = orthonormal_basis(n);
+            return s;
+        }
     }
-    const float* verts = reinterpret_cast<const float*>(sc.shape_data + ext.x);
-    const float* norms = reinterpret_cast<const float*>(sc.shape_data + ext.y);
-    const float* inds  = reinterpret_cast<const float*>(sc.shape_data + ext.z);
-    const float* texs  = reinterpret_cast<const float*>(sc.shape_data + ext.w);
-    const int4 tri     = *reinterpret_cast<const int4*>(inds + prim_id * 4);
+    // the triangle's record (igd_assign_scene gathers what the shape's index record points at — header {faces, vertices, normals,
+    // texcoords}, then vertices, normals, indices, texcoords: TriMeshProvider.cpp:575-596 — into six rows per triangle)
+    const float4* rec = sc.prim_records + ((size_t)sc.entity_rec[ent_id] + (size_t)prim_id * 6);
+    const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4], a5 = rec[5];
 
-    const f3 v0 = xform_point(global, ld3v(verts + tri.x * 4));
-    const f3 v1 = xform_point(global, ld3v(verts + tri.y * 4));
-    const f3 v2 = xform_point(global, ld3v(verts + tri.z * 4));
+    const f3 v0 = xform_point(global, f3{ a0.x, a0.y, a0.z });
+    const f3 v1 = xform_point(global, f3{ a1.x, a1.y, a1.z });
+    const f3 v2 = xform_point(global, f3{ a2.x, a2.y, a2.z });
     const f3 e1 = v2 - v0, e2 = v0 - v1, e3 = v1 - v2;
     const f3 n  = stable_normal(e1, e2, e3); // make_triangle, core/triangle.art:12-29
     const float nn = len3(n);
     const f3 fn    = n * (1 / nn);
 
-    const f3 n0 = ld3v(norms + tri.x * 4), n1 = ld3v(norms + tri.y * 4), n2 = ld3v(norms + tri.z * 4);
+    const f3 n0 = f3{ a3.x, a3.y, a3.z }, n1 = f3{ a4.x, a4.y, a4.z }, n2 = f3{ a5.x, a5.y, a5.z };
     const f3 ln = f3{ lerp2(n0.x, n1.x, n2.x, u, v), lerp2(n0.y, n1.y, n2.y, u, v), lerp2(n0.z, n1.z, n2.z, u, v) };
     const f3 sn = normalize3(mul33(nmat, ln));
 
-    const f2 t0 = *reinterpret_cast<const f2*>(texs + tri.x * 2), t1 = *reinterpret_cast<const f2*>(texs + tri.y * 2), t2 = *reinterpret_cast<const f2*>(texs + tri.z * 2);
+    const f2 t0 = f2{ a0.w, a1.w }, t1 = f2{ a2.w, a3.w }, t2 = f2{ a4.w, a5.w };
 
     Surf s;
     s.tex         = f2{ lerp2(t0.x, t1.x, t2.x, u, v), lerp2(t0.y, t1.y, t2.y, u, v) };

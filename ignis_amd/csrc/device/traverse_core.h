@@ -48,6 +48,10 @@ constexpr int kBlockThreads = 256;
 #ifndef IG_MASK_LOADS
 #define IG_MASK_LOADS 1
 #endif
+#ifndef IG_REUSE_RCP
+#define IG_REUSE_RCP 1
+#endif
+constexpr bool kReuseRcp = IG_REUSE_RCP != 0; // entity-leaf section: scene-space reciprocals for instances that keep the direction
 constexpr bool kMaskLoads = IG_MASK_LOADS != 0; // experiments: 0 = every lane loads (from a safe address where the section does not concern it)
 
 // Per-lane LDS of one workgroup of BLOCK lanes. `e`: the traversal stacks, entry-major so that a wave's accesses are conflict
@@ -388,7 +392,17 @@ struct Traverser {
                         entered = enter;
                     } else {
                         // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                        const RayT nl = make_ray_terms(xform_point(m, gray.org), xform_dir(m, gray.dir));
+                        // A direction the matrix hands back bit for bit (an instance that is only translated: every entity of
+                        // diamond_scene) has the reciprocals the scene-space ray already has: the three IEEE divisions are run only
+                        // when some entering lane of the wave needs them.
+                        RayT nl;
+                        nl.org = xform_point(m, gray.org);
+                        nl.dir = xform_dir(m, gray.dir);
+                        const bool same_dir = (igm_bits(nl.dir.x) == igm_bits(gray.dir.x)) & (igm_bits(nl.dir.y) == igm_bits(gray.dir.y)) & (igm_bits(nl.dir.z) == igm_bits(gray.dir.z));
+                        nl.inv_dir = gray.inv_dir;
+                        if (!kReuseRcp || __any(enter & !same_dir))
+                            nl.inv_dir = f3{ safe_rcp(nl.dir.x), safe_rcp(nl.dir.y), safe_rcp(nl.dir.z) };
+                        nl.inv_org = -(nl.org * nl.inv_dir);
                         // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of row 5 of its leaf record by
                         // igd_assign_scene) skips the inner-node section: its root visit is the slab test of that one child, done here
                         // with the operations of the inner-node section. Hit: the state the root visit and the pop of the leaf
