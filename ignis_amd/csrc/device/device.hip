@@ -115,6 +115,7 @@ struct igd_device {
     size_t primbvh_bytes = 0; // the "trimesh_primbvh" fix table at the start of geom
     DevBuf<ig_entity_leaf1> leaves, sphere_leaves;
     DevBuf<float4> dev_leaves, dev_sphere_leaves; // DevScene::leaves / sphere_leaves (packed records)
+    DevBuf<float4> dev_leaf_scan, dev_sphere_leaf_scan; // DevScene::leaf_scan / sphere_leaf_scan
     std::vector<std::pair<uint64_t, uint32_t>> tri_spans; // where igd_assign_scene re-ordered triangle packets inside geom: (byte offset, packets)
     // photon mapper (IG_TECHNIQUE_PPM): photons by light path index, the same in grid order, sort keys, cell counts / offsets
     DevBuf<igp_photon> ppm_photons, ppm_sorted;
@@ -549,7 +550,7 @@ void assignScene(igd_device* d, const igd_scene* s)
         r[4] = make_float4(l.local[8], l.local[9], l.local[10], l.local[11]);
         r[5] = r[6] = r[7] = make_float4(0, 0, 0, 0);
     };
-    std::vector<float4> dl((size_t)s->scene_leaf_count * kDevLeafRows + kDevLeafRows); // (+ one record of padding)
+    std::vector<float4> dl((size_t)s->scene_leaf_count * kDevLeafRows + 4 * kDevLeafRows); // (+ four records of padding: a scan fetches up to four leaves ahead)
     for (uint32_t i = 0; i < s->scene_leaf_count; ++i) {
         const ig_entity_leaf1& l = s->scene_leaves[i];
         const uint64_t off       = (((uint64_t)(uint32_t)l.user[1] << 32) | (uint64_t)(uint32_t)l.user[0]) * 4;
@@ -584,10 +585,20 @@ void assignScene(igd_device* d, const igd_scene* s)
     }
     d->geom.upload(blob.data(), blob.size());
     d->dev_leaves.upload(dl.data(), dl.size());
+    auto scanRows = [](const std::vector<float4>& records) {
+        std::vector<float4> rows(records.size() / kDevLeafRows * 2);
+        for (size_t i = 0; i < rows.size() / 2; ++i)
+            rows[2 * i] = records[i * kDevLeafRows], rows[2 * i + 1] = records[i * kDevLeafRows + 1];
+        return rows;
+    };
+    {
+        const std::vector<float4> rows = scanRows(dl);
+        d->dev_leaf_scan.upload(rows.data(), rows.size());
+    }
     d->leaves.upload(s->scene_leaves, s->scene_leaf_count); // (reference layout: the "scene_bvh_leaves" named buffer)
     {
         // sphere leaves: row 5 = where the {centre, radius} record sits in the "shapes" blob
-        std::vector<float4> sl((size_t)s->sphere_leaf_count * kDevLeafRows + kDevLeafRows);
+        std::vector<float4> sl((size_t)s->sphere_leaf_count * kDevLeafRows + 4 * kDevLeafRows);
         for (uint32_t i = 0; i < s->sphere_leaf_count; ++i) {
             const int32_t shape_id = s->sphere_leaves[i].shape_id;
             if (shape_id < 0 || (uint32_t)shape_id >= s->shape_count || s->shape_lookups[shape_id].type_id != IG_SHAPE_SPHERE
@@ -598,6 +609,8 @@ void assignScene(igd_device* d, const igd_scene* s)
             r[5] = make_float4(igm_float((uint32_t)s->shape_lookups[shape_id].offset), 0, 0, 0);
         }
         d->dev_sphere_leaves.upload(sl.data(), sl.size());
+        const std::vector<float4> rows = scanRows(sl);
+        d->dev_sphere_leaf_scan.upload(rows.data(), rows.size());
         d->sphere_leaves.upload(s->sphere_leaves, s->sphere_leaf_count);
     }
 
@@ -741,9 +754,11 @@ void assignScene(igd_device* d, const igd_scene* s)
     ds.scene_nodes_off      = scene_nodes_off;
     ds.scene_node_count     = s->scene_node_count;
     ds.leaves               = d->dev_leaves.ptr;
+    ds.leaf_scan            = d->dev_leaf_scan.ptr;
     ds.sphere_nodes_off     = sphere_nodes_off;
     ds.sphere_node_count    = s->sphere_node_count;
     ds.sphere_leaves        = d->dev_sphere_leaves.ptr;
+    ds.sphere_leaf_scan     = d->dev_sphere_leaf_scan.ptr;
     ds.entities             = d->entities.ptr;
     ds.shape_data           = d->shape_data.ptr;
     ds.shape_offsets        = d->shape_offsets.ptr;
@@ -2012,6 +2027,8 @@ int32_t igd_release_all(igd_device* dev)
         dev->shape_data.release();
         dev->leaves.release();
         dev->dev_leaves.release();
+        dev->dev_leaf_scan.release();
+        dev->dev_sphere_leaf_scan.release();
         dev->geom_ref.release();
         dev->sphere_leaves.release();
         dev->dev_sphere_leaves.release();

@@ -27,6 +27,7 @@ struct DevScene {
     //       byte offset of its Tri4 packets, that leaf's child word, 0); spheres: (byte offset of {centre, radius} in shape_data, 0, 0, 0)
     //   6, 7: (lo.xyz, 0), (hi.xyz, 0) of that one child box
     const float4* leaves;
+    const float4* leaf_scan; // rows 0 and 1 of every record once more, two rows per leaf: what the scan of a run reads (four leaves per 128-byte line)
     // shading tables
     const float* entities;         // 36 floats each
     const uint8_t* shape_data;     // dyn table "shapes" blob
@@ -64,6 +65,7 @@ struct DevScene {
     uint32_t sphere_nodes_off;
     uint32_t sphere_node_count;
     const float4* sphere_leaves; // same record layout as `leaves`
+    const float4* sphere_leaf_scan;
     uint2* deep_stack;
     uint32_t deep_stride;
     uint32_t deep_tail_base; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)

@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     Traverser<ANY_HIT, STATS, kBlockThreads, DEEP, SPHERES> tr;
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
+    tr.clk_start();
     bool has_ray          = false;
     uint32_t ray_idx      = 0;
     uint32_t st_unoccluded = 0;
@@ -175,6 +176,12 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
 
     if (fatal)
         atomicOr(&a.qs->error_flags, 1u);
+#ifdef IG_TRAV_CLOCKS
+    tr.mark(0);
+    if (lane == 0 && !DEEP && !SPHERES)
+        for (int k = 0; k < 6; ++k)
+            atomicAdd(ANY_HIT ? &a.qs->section_lanes[k] : &a.qs->section_passes[k], tr.clk_acc[k]);
+#endif
 
     if (STATS) {
         const uint32_t n = wave_sum_u32(tr.st_nodes), t = wave_sum_u32(tr.st_tris), l = wave_sum_u32(tr.st_leaves), uo = wave_sum_u32(st_unoccluded);

@@ -48,6 +48,18 @@ constexpr int kBlockThreads = 256;
 #ifndef IG_MASK_LOADS
 #define IG_MASK_LOADS 1
 #endif
+#ifndef IG_LEAF_REPEAT
+#define IG_LEAF_REPEAT 0
+#endif
+#ifndef IG_LEAF_REPEAT_MIN
+#define IG_LEAF_REPEAT_MIN 1
+#endif
+constexpr bool kLeafRepeat   = IG_LEAF_REPEAT != 0; // the entity-leaf section repeats while a quorum of lanes is at a leaf run again
+constexpr int kLeafRepeatMin = IG_LEAF_REPEAT_MIN;  // ... and at least this many
+#ifndef IG_SCAN_LEAVES
+#define IG_SCAN_LEAVES 4
+#endif
+constexpr int kScanLeaves = IG_SCAN_LEAVES; // entity-leaf section: leaves of a run fetched per round trip
 #ifndef IG_REUSE_RCP
 #define IG_REUSE_RCP 1
 #endif
@@ -115,6 +127,26 @@ struct Traverser {
     uint32_t deep_stride;
     uint32_t st_nodes, st_tris, st_leaves;
     uint32_t sec_pass[3], sec_lane[3]; // STATS: executions of the three sections by this wave / lanes that had work in them (wave-uniform)
+#ifdef IG_TRAV_CLOCKS
+    // where a wave's cycles go (variant build, tools/trav_clocks.py): the shader clock at phase ends, memory counters drained first
+    unsigned long long clk_last, clk_acc[6];
+    IG_DEV void clk_start()
+    {
+        for (int k = 0; k < 6; ++k)
+            clk_acc[k] = 0;
+        clk_last = __builtin_readcyclecounter();
+    }
+    IG_DEV void mark(int k)
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        clk_acc[k] += now - clk_last;
+        clk_last = now;
+    }
+#else
+    IG_DEV void clk_start() {}
+    IG_DEV void mark(int) {}
+#endif
 
     IG_DEV void init_counters()
     {
@@ -287,6 +319,7 @@ struct Traverser {
     IG_DEV void step(const DevScene& sc, Stack& st, int tid)
     {
         const uint8_t* geom = sc.geom;
+        mark(0); // refill, epilogue, loop bookkeeping (traverse.hip)
         settle(sc, st, tid);
 
         // Postponing: a section runs only when enough lanes of the wave want it (they wait in their mode until
@@ -304,6 +337,7 @@ struct Traverser {
                 quorum = 1; // (falling back to the best filled section only measured no better: 528 vs 523 ms of traversal per 64 steps)
         }
 
+        mark(4); // settle + quorum
         // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
         if (__popcll(__ballot(mode == 2)) >= quorum) {
             const float4 g0 = st.g[0][tid], g1 = st.g[1][tid], g2 = st.g[2][tid];
@@ -312,6 +346,10 @@ struct Traverser {
             gray.inv_org = f3{ g0.w, g1.x, g1.y };
             gray.org     = f3{ g1.z, g1.w, g2.x };
             gray.dir     = f3{ g2.y, g2.z, g2.w };
+            // A run whose boxes all reject the ray ends in settle(), which often pops the next run: the section repeats while a
+            // quorum of lanes is at a leaf run again, instead of those lanes waiting a whole pass (both other sections, the refill
+            // test, the epilogue) for every run of the scene BVH they walk past — diamond_scene: 4.6 leaves in runs of one or two.
+            do {
             const bool here = mode == 2;
             if (STATS)
                 sec_pass[0] += 1, sec_lane[0] += (uint32_t)__popcll(__ballot(here));
@@ -326,28 +364,41 @@ struct Traverser {
                 int entity_id = 0;
                 do { // (at least one lane is scanning: the quorum is >= 1)
                     const int at     = scanning ? ent_cursor : 0;
-                    const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + at * kDevLeafRows;
+                    const float4* ls = (SPHERES ? sc.sphere_leaf_scan : sc.leaf_scan) + at * 2; // rows 0 and 1 of the records, packed: four leaves per 128-byte line
                     // (loads sit under per-lane conditions, like stores: a lane the section does not concern issues no memory
                     // request — the L1 / texture path, not the VALU, is what this kernel keeps busiest, profiles/r03_pmc_*.txt —
                     // and what it then computes from the undefined registers is discarded by the selects below)
-                    float4 l0 = any_float4(), l1 = any_float4();
-                    if (!kMaskLoads || scanning)
-                        l0 = lf[0], l1 = lf[1];
-                    ent_cursor += scanning ? 1 : 0;
-                    const int id          = (int)igm_bits(l0.w);
-                    const uint32_t lflags = igm_bits(l1.w);
-                    ent_last              = scanning ? (id < 0) : ent_last;
-                    if (STATS)
-                        st_leaves += scanning ? 1u : 0u;
-                    // check_ray_visibility (traversal/ray.art:51)
-                    const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
-                    float entry, exit;
-                    slab_test(gray, tmin, tmax, l0.x, l1.x, l0.y, l1.y, l0.z, l1.z, entry, exit);
-                    const bool inside = scanning & visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
-                    enter             = enter | inside;
-                    enter_at          = sel(inside, at, enter_at);
-                    entity_id         = sel(inside, id, entity_id);
-                    scanning          = scanning & !inside & !(id < 0);
+                    // kScanLeaves: the rows of the next leaves come with the same round trip (a scan is a chain of dependent loads, 4.6
+                    // leaves per ray on diamond_scene); they are looked at only if this one rejects the ray and the run goes on. The
+                    // records behind the last leaf of the table are padding.
+                    float4 lr[kScanLeaves][2];
+#pragma unroll
+                    for (int k = 0; k < kScanLeaves; ++k)
+                        lr[k][0] = any_float4(), lr[k][1] = any_float4();
+                    if (!kMaskLoads || scanning) {
+#pragma unroll
+                        for (int k = 0; k < kScanLeaves; ++k)
+                            lr[k][0] = ls[2 * k], lr[k][1] = ls[2 * k + 1];
+                    }
+#pragma unroll
+                    for (int half = 0; half < kScanLeaves; ++half) {
+                        const float4 r0 = lr[half][0], r1 = lr[half][1];
+                        ent_cursor += scanning ? 1 : 0;
+                        const int id          = (int)igm_bits(r0.w);
+                        const uint32_t lflags = igm_bits(r1.w);
+                        ent_last              = scanning ? (id < 0) : ent_last;
+                        if (STATS)
+                            st_leaves += scanning ? 1u : 0u;
+                        // check_ray_visibility (traversal/ray.art:51)
+                        const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
+                        float entry, exit;
+                        slab_test(gray, tmin, tmax, r0.x, r1.x, r0.y, r1.y, r0.z, r1.z, entry, exit);
+                        const bool inside = scanning & visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
+                        enter             = enter | inside;
+                        enter_at          = sel(inside, at + half, enter_at);
+                        entity_id         = sel(inside, id, entity_id);
+                        scanning          = scanning & !inside & !(id < 0);
+                    }
                 } while (__any(scanning));
                 if (__any(enter)) {
                     const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at * kDevLeafRows;
@@ -465,8 +516,10 @@ struct Traverser {
                 need_cull = need_cull | (here & !in_tris);
             }
             settle(sc, st, tid);
+            } while (kLeafRepeat && !SPHERES && __popcll(__ballot(mode == 2)) >= (quorum > kLeafRepeatMin ? quorum : kLeafRepeatMin));
         }
 
+        mark(1); // entity-leaf section (with its settle)
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
         if (__popcll(__ballot((mode == 0) & !finished)) >= quorum) {
             const bool here   = (mode == 0) & !finished; // settled: an inner node is on top
@@ -529,6 +582,7 @@ struct Traverser {
             settle(sc, st, tid);
         }
 
+        mark(2); // inner-node section (with its settle)
         // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410)
         if (!SPHERES && __popcll(__ballot(mode == 1)) >= quorum) {
             do { // (at least one lane is in a triangle leaf: the quorum is >= 1)
@@ -591,6 +645,7 @@ struct Traverser {
                     settle(sc, st, tid); // return to the scene level now: the hit may end the ray
             }
         }
+        mark(3); // triangle section
     }
 };
 
