@@ -12,7 +12,11 @@ namespace igdev {
 #ifndef IG_REFILL_IDLE
 #define IG_REFILL_IDLE 32
 #endif
-constexpr int kRefillIdle = IG_REFILL_IDLE;  // refill when at least this many lanes of a wave are idle
+#ifndef IG_REFILL_IDLE_ANY
+#define IG_REFILL_IDLE_ANY IG_REFILL_IDLE
+#endif
+constexpr int kRefillIdleClosest = IG_REFILL_IDLE;     // refill when at least this many lanes of a wave are idle
+constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit launches (shorter rays)
 #ifndef IG_ATOMIC_SPLAT
 #define IG_ATOMIC_SPLAT 0
 #endif
@@ -60,7 +64,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle              = __popcll(idle);
-        if (n_idle >= kRefillIdle && !(exhausted && batch_next >= batch_end)) {
+        if (n_idle >= (ANY_HIT ? kRefillIdleAny : kRefillIdleClosest) && !(exhausted && batch_next >= batch_end)) {
             if (batch_next >= batch_end) {
                 const uint32_t left = count > last_base ? count - last_base : 0u;
                 uint32_t kRayBatch  = left / (total_waves * 4u);

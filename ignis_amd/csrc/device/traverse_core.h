@@ -56,6 +56,10 @@ constexpr int kBlockThreads = 256;
 #endif
 constexpr bool kLeafRepeat   = IG_LEAF_REPEAT != 0; // the entity-leaf section repeats while a quorum of lanes is at a leaf run again
 constexpr int kLeafRepeatMin = IG_LEAF_REPEAT_MIN;  // ... and at least this many
+#ifndef IG_NODE_PUSH_FAST
+#define IG_NODE_PUSH_FAST 1
+#endif
+constexpr bool kNodePushFast = IG_NODE_PUSH_FAST != 0; // inner-node section: stack rows by address, one bound check per node
 #ifndef IG_SCAN_LEAVES
 #define IG_SCAN_LEAVES 4
 #endif
@@ -532,6 +536,10 @@ struct Traverser {
                 sec_pass[1] += 1, sec_lane[1] += (uint32_t)__popcll(__ballot(here));
             }
             bool pushed           = false;
+            // (after the pop: ptr names the row of the last entry, -1 for none)
+            const int slot_at  = (ptr * BLOCK + tid) * (int)sizeof(uint2); // (negative for an empty stack: signed comparisons)
+            const int slot_end = (kLdsStack * BLOCK + tid) * (int)sizeof(uint2);
+            int slot           = slot_at;
             const float node_tmax = level ? ltmax : tmax;
             f3 inv = loc.inv_dir, io = loc.inv_org;
             if (__any(here & (level == 0))) { // scene-level node: the terms of the untransformed ray
@@ -572,11 +580,29 @@ struct Traverser {
                     const bool hit = here & (ch[i] != 0) & !(exit < entry);
                     // push (becomes the top) if nearer than the current top, else push_after
                     const bool front = ANY_HIT || (top_tmin > entry);
-                    push_entry(st, tid, hit, front ? top_node : ch[i], front ? top_tmin : entry);
+                    if (kNodePushFast && !DEEP) {
+                        // the stack slot as an LDS address that moves up by one row per hit child; how far the node got, and whether that
+                        // was too far, is read off the address once after the eight children (push_entry keeps count, tests the bound and
+                        // flags the overflow per entry: 4 of its 10 instructions per child)
+                        slot += hit ? BLOCK * (int)sizeof(uint2) : 0;
+                        if (hit & (slot < slot_end)) {
+                            uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(&st.e[0][0]) + slot);
+                            w[0] = (uint32_t)(front ? top_node : ch[i]), w[1] = igm_bits(front ? top_tmin : entry);
+                        }
+                    } else {
+                        push_entry(st, tid, hit, front ? top_node : ch[i], front ? top_tmin : entry);
+                        pushed = pushed | hit;
+                    }
                     top_node = sel(hit & front, ch[i], top_node);
                     top_tmin = sel(hit & front, entry, top_tmin);
-                    pushed   = pushed | hit;
                 }
+            }
+            if (kNodePushFast && !DEEP) {
+                pushed         = slot != slot_at;
+                ptr += (slot - slot_at) / (BLOCK * (int)sizeof(uint2)); // (lanes the section does not concern: + 0)
+                const bool out = here & (slot >= slot_end); // out of stack: the ray ends here (see push_entry)
+                overflow       = overflow | out;
+                finished       = finished | out;
             }
             need_cull = need_cull | (here & !pushed);
             settle(sc, st, tid);
