@@ -20,6 +20,8 @@
 // region and copies them back at the merge (60 v_mov per settle() iteration, measured in the ISA).
 #pragma once
 
+#include <type_traits>
+
 #include "dev_math.h"
 #include "kernels.h"
 
@@ -33,15 +35,21 @@ namespace igdev {
 #endif
 constexpr int kPostponeNum   = IG_POSTPONE_NUM;   // a section needs kPostponeNum / 2^kPostponeShift of the wave's active lanes
 constexpr int kPostponeShift = IG_POSTPONE_SHIFT; // (0 disables postponing)
+#ifndef IG_RAY_TERMS_LDS
+#define IG_RAY_TERMS_LDS 0
+#endif
 #ifndef IG_LDS_STACK
-#define IG_LDS_STACK 14
+#define IG_LDS_STACK (IG_RAY_TERMS_LDS ? 14 : 20)
 #endif
 #ifndef IG_TRAV_OCC
 #define IG_TRAV_OCC 4
 #endif
-// 14 entries * 256 threads * 8 B = 28 KiB (+ 12 KiB of ray terms) = 40 KiB per workgroup: four workgroups fill the 160 KiB of a CU, and
-// the kernels need 103 - 112 VGPRs (<= 128) since the loop restructuring of round 3. Scenes whose rays need more than 14 entries
-// (diamond_scene: 11) run the DEEP instantiation as their primary kernel (device.hip decides from the overflow counts it reads back).
+// 20 entries * 256 threads * 8 B = 40 KiB per workgroup: four workgroups fill the 160 KiB of a CU. The scene-space ray terms (12 floats per
+// lane) sat next to a 14-entry stack in LDS while the kernels needed 150 registers; since the loop restructuring of round 3 they need
+// 104 - 112, the terms fit into registers below the 128 of four waves per SIMD, and their 12 KiB are six more stack entries: the rays
+// of the 16 M-triangle stand-in need 16 - 24, so far fewer of them are listed and re-traversed by the DEEP launch (diamond_scene: 11).
+// IG_RAY_TERMS_LDS=1 is the old arrangement.
+constexpr bool kRayTermsLds = IG_RAY_TERMS_LDS != 0;
 constexpr int kLdsStack     = IG_LDS_STACK;
 constexpr int kTraverseOcc  = IG_TRAV_OCC;   // workgroups of 256 per CU = waves per SIMD the kernel is built for
 constexpr int kBlockThreads = 256;
@@ -75,9 +83,13 @@ constexpr bool kMaskLoads = IG_MASK_LOADS != 0; // experiments: 0 = every lane l
 // the scene level) — twelve registers per lane that the shape-level sections, where a ray spends most of its steps, do not
 // have to carry: g[0] = (inv_dir, inv_org.x), g[1] = (inv_org.yz, org.xy), g[2] = (org.z, dir).
 template <int BLOCK>
-struct StackOf {
-    uint2 e[kLdsStack][BLOCK];
+struct StackTerms {
     float4 g[3][BLOCK];
+};
+struct StackNoTerms {};
+template <int BLOCK>
+struct StackOf : std::conditional_t<kRayTermsLds, StackTerms<BLOCK>, StackNoTerms> {
+    uint2 e[kLdsStack][BLOCK];
 };
 using StackLds = StackOf<kBlockThreads>;
 
@@ -106,6 +118,7 @@ template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     // ---- ray + hit
+    RayT scene_ray; // the scene-space ray and its slab-test terms (in LDS instead with IG_RAY_TERMS_LDS)
     // `loc`: the ray in the current shape's space, written when an entity leaf is entered (the scene-space terms are in LDS)
     RayT loc;
     float tmin, tmax; // tmax == distance of the accepted hit (ray.tmax shrinks with it)
@@ -227,9 +240,13 @@ struct Traverser {
     IG_DEV void begin(const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
     {
         const RayT g = make_ray_terms(org, dir);
-        st.g[0][tid] = make_float4(g.inv_dir.x, g.inv_dir.y, g.inv_dir.z, g.inv_org.x);
-        st.g[1][tid] = make_float4(g.inv_org.y, g.inv_org.z, g.org.x, g.org.y);
-        st.g[2][tid] = make_float4(g.org.z, g.dir.x, g.dir.y, g.dir.z);
+        if constexpr (kRayTermsLds) {
+            st.g[0][tid] = make_float4(g.inv_dir.x, g.inv_dir.y, g.inv_dir.z, g.inv_org.x);
+            st.g[1][tid] = make_float4(g.inv_org.y, g.inv_org.z, g.org.x, g.org.y);
+            st.g[2][tid] = make_float4(g.org.z, g.dir.x, g.dir.y, g.dir.z);
+        } else {
+            scene_ray = g;
+        }
         loc    = g;
         tmin   = tmin_;
         tmax   = tmax_;
@@ -344,12 +361,14 @@ struct Traverser {
         mark(4); // settle + quorum
         // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
         if (__popcll(__ballot(mode == 2)) >= quorum) {
-            const float4 g0 = st.g[0][tid], g1 = st.g[1][tid], g2 = st.g[2][tid];
-            RayT gray;
-            gray.inv_dir = f3{ g0.x, g0.y, g0.z };
-            gray.inv_org = f3{ g0.w, g1.x, g1.y };
-            gray.org     = f3{ g1.z, g1.w, g2.x };
-            gray.dir     = f3{ g2.y, g2.z, g2.w };
+            RayT gray = scene_ray;
+            if constexpr (kRayTermsLds) {
+                const float4 g0 = st.g[0][tid], g1 = st.g[1][tid], g2 = st.g[2][tid];
+                gray.inv_dir = f3{ g0.x, g0.y, g0.z };
+                gray.inv_org = f3{ g0.w, g1.x, g1.y };
+                gray.org     = f3{ g1.z, g1.w, g2.x };
+                gray.dir     = f3{ g2.y, g2.z, g2.w };
+            }
             // A run whose boxes all reject the ray ends in settle(), which often pops the next run: the section repeats while a
             // quorum of lanes is at a leaf run again, instead of those lanes waiting a whole pass (both other sections, the refill
             // test, the epilogue) for every run of the scene BVH they walk past — diamond_scene: 4.6 leaves in runs of one or two.
@@ -543,11 +562,15 @@ struct Traverser {
             const float node_tmax = level ? ltmax : tmax;
             f3 inv = loc.inv_dir, io = loc.inv_org;
             if (__any(here & (level == 0))) { // scene-level node: the terms of the untransformed ray
-                const float4 g0 = st.g[0][tid];
-                const float2 g1 = *reinterpret_cast<const float2*>(&st.g[1][tid]);
-                const bool s    = level == 0;
-                inv = f3{ sel(s, g0.x, inv.x), sel(s, g0.y, inv.y), sel(s, g0.z, inv.z) };
-                io  = f3{ sel(s, g0.w, io.x), sel(s, g1.x, io.y), sel(s, g1.y, io.z) };
+                f3 ginv = scene_ray.inv_dir, gio = scene_ray.inv_org;
+                if constexpr (kRayTermsLds) {
+                    const float4 g0 = st.g[0][tid];
+                    const float2 g1 = *reinterpret_cast<const float2*>(&st.g[1][tid]);
+                    ginv = f3{ g0.x, g0.y, g0.z }, gio = f3{ g0.w, g1.x, g1.y };
+                }
+                const bool s = level == 0;
+                inv = f3{ sel(s, ginv.x, inv.x), sel(s, ginv.y, inv.y), sel(s, ginv.z, inv.z) };
+                io  = f3{ sel(s, gio.x, io.x), sel(s, gio.y, io.y), sel(s, gio.z, io.z) };
             }
             // The slab test of the reference takes min / max of the two plane distances per axis
             // (intersection.art:38-58); which plane is the near one is decided by the sign of inv_dir alone
