@@ -64,6 +64,10 @@ constexpr int kBlockThreads = 256;
 #endif
 constexpr bool kLeafRepeat   = IG_LEAF_REPEAT != 0; // the entity-leaf section repeats while a quorum of lanes is at a leaf run again
 constexpr int kLeafRepeatMin = IG_LEAF_REPEAT_MIN;  // ... and at least this many
+#ifndef IG_SINGLE_ROWS_EARLY
+#define IG_SINGLE_ROWS_EARLY 0
+#endif
+constexpr bool kSingleRowsEarly = IG_SINGLE_ROWS_EARLY != 0; // entity-leaf section: rows 6 / 7 of an entered leaf with rows 2 - 5
 #ifndef IG_NODE_PUSH_FAST
 #define IG_NODE_PUSH_FAST 1
 #endif
@@ -426,8 +430,12 @@ struct Traverser {
                 if (__any(enter)) {
                     const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at * kDevLeafRows;
                     float4 l2 = any_float4(), l3 = any_float4(), l4 = any_float4(), l5 = any_float4();
-                    if (!kMaskLoads || enter)
+                    float4 blo = any_float4(), bhi = any_float4(); // (the one child box of a one-leaf shape comes with the same round trip)
+                    if (!kMaskLoads || enter) {
                         l2 = lf[2], l3 = lf[3], l4 = lf[4], l5 = lf[5];
+                        if (!SPHERES && kSingleRowsEarly)
+                            blo = lf[6], bhi = lf[7];
+                    }
                     const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
                     m34 m;
                     m.c0 = f3{ l2.x, l2.y, l2.z };
@@ -486,9 +494,10 @@ struct Traverser {
                         bool missed       = false;
                         int only_leaf     = 0;
                         if (__any(single)) {
-                            float4 blo = any_float4(), bhi = any_float4();
-                            if (!kMaskLoads || single)
-                                blo = lf[6], bhi = lf[7];
+                            if (!kSingleRowsEarly) {
+                                if (!kMaskLoads || single)
+                                    blo = lf[6], bhi = lf[7];
+                            }
                             only_leaf = (int)igm_bits(l5.z);
                             // (near / far plane by the sign of the inverse direction, as the inner-node section picks its rows)
                             const bool ox = nl.inv_dir.x < 0, oy = nl.inv_dir.y < 0, oz = nl.inv_dir.z < 0;
