@@ -28,6 +28,10 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_ATOMIC_ACCUM
 #define IG_SHADE_ATOMIC_ACCUM 0
 #endif
+#ifndef IG_SHADE_SORT_FULL
+#define IG_SHADE_SORT_FULL 1
+#endif
+constexpr bool kSortFull          = IG_SHADE_SORT_FULL != 0;
 constexpr bool kSortLean          = IG_SHADE_SORT_LEAN != 0;
 constexpr bool kShadeAtomicAccum = IG_SHADE_ATOMIC_ACCUM != 0;
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
@@ -50,7 +54,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     // The lean variant has three BSDF models and waits for memory, not for issue slots (a TEA with one round instead of four changes its
     // time by 1 %, profiles/r03_experiment_shade.txt): the sort's two dependent loads and five barriers in front of every window cost it
     // more (4 %) than the divergence they remove. The full variants sort.
-    const bool do_sort = (FULL || kSortLean) && (M + 2) <= kMaxSortBins;
+    const bool do_sort = (FULL ? kSortFull : kSortLean) && (M + 2) <= kMaxSortBins;
 
     const ShadeFrame fr = a.frame;
 
@@ -209,6 +213,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 s_base[1] = (uint32_t)(old >> 32);
             }
             __syncthreads();
+            clk.mark(11); // the reservation: one thread's scan of the bins and its atomic with return, the barrier behind it
             uint32_t os = s_base[1];
             for (int w = 0; w < wave; ++w)
                 os += s_wave_cnt[1][w];
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
             }
             __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
-            clk.mark(9); // the reservation, the stores, the last barrier
+            clk.mark(9); // the stores (drained), the last barrier
         }
     }
 #ifdef IG_SHADE_CLOCKS

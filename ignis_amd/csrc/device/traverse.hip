@@ -23,6 +23,10 @@ constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit lau
 #ifndef IG_EARLY_SPLAT
 #define IG_EARLY_SPLAT 1
 #endif
+#ifndef IG_EARLY_ACCUM
+#define IG_EARLY_ACCUM 0
+#endif
+constexpr bool kEarlyAccum  = IG_EARLY_ACCUM != 0;  // any hit: the accumulator slot is read with the ray as well
 constexpr bool kAtomicSplat = IG_ATOMIC_SPLAT != 0; // sums into the per-sample accumulators as no-return float atomics
 constexpr bool kEarlySplat  = IG_EARLY_SPLAT != 0;  // any hit: the colour of a shadow ray is loaded with the ray
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
@@ -53,6 +57,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     uint32_t ray_idx      = 0;
     uint32_t st_unoccluded = 0;
     float4 splat          = any_float4(); // any hit: the shadow ray's colour and slot, fetched with the ray (kEarlySplat)
+    float4 slot_value     = any_float4(); // ... and what the slot holds (kEarlyAccum)
     uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
     bool fatal = false;
 
@@ -61,6 +66,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     bool exhausted = false;
 
     for (;;) {
+        tr.mark(0); // epilogue of the previous pass (hit stores / splat), loop bookkeeping
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle              = __popcll(idle);
@@ -98,8 +104,13 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
                              a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
                 }
-                if (ANY_HIT && kEarlySplat && a.accum)
+                if (ANY_HIT && kEarlySplat && a.accum) {
                     splat = a.col[idx];
+                    // ... and the accumulator slot it may be added to (the slot is this ray's alone for the length of the launch): one more
+                    // round trip per refill, shared by all the rays of the refill, instead of one per pass in which a lane finishes
+                    if (kEarlyAccum && !a.atomic_splat)
+                        slot_value = a.accum[(int64_t)(int32_t)igm_bits(splat.w) - a.id_base];
+                }
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
@@ -112,6 +123,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
 
         // every lane steps: a lane without a ray is `finished` in mode 0, which no section of step() acts on. (Wrapping the call
         // in `if (has_ray)` made the compiler copy the whole traversal state at the merge, ~35 v_mov per pass.)
+        tr.mark(5); // refill: batch reservation, ray loads, begin()
         tr.step(a.scene, s_stack, tid);
         if (has_ray) {
             if (tr.finished && tr.overflow) {
@@ -148,7 +160,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                                 unsafeAtomicAdd(&dst->y, c.y * a.inv_spi);
                                 unsafeAtomicAdd(&dst->z, c.z * a.inv_spi);
                             } else {
-                                float4 v = *dst;
+                                float4 v = (kEarlySplat && kEarlyAccum) ? slot_value : *dst;
                                 v.x += c.x * a.inv_spi;
                                 v.y += c.y * a.inv_spi;
                                 v.z += c.z * a.inv_spi;

@@ -344,7 +344,6 @@ struct Traverser {
     IG_DEV void step(const DevScene& sc, Stack& st, int tid)
     {
         const uint8_t* geom = sc.geom;
-        mark(0); // refill, epilogue, loop bookkeeping (traverse.hip)
         settle(sc, st, tid);
 
         // Postponing: a section runs only when enough lanes of the wave want it (they wait in their mode until
@@ -362,7 +361,7 @@ struct Traverser {
                 quorum = 1; // (falling back to the best filled section only measured no better: 528 vs 523 ms of traversal per 64 steps)
         }
 
-        mark(4); // settle + quorum
+        mark(4); // settle at the top of a pass + quorum
         // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515)
         if (__popcll(__ballot(mode == 2)) >= quorum) {
             RayT gray = scene_ray;

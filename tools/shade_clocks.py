@@ -20,7 +20,7 @@ dev.close()
 acc = list(st["section_passes"]) + list(st["section_lanes"])
 names = ["sort by material", "load the ray's columns", "surface element (entity, indices, vertices)", "material record + BSDF set-up", "emission (on_hit)",
          "next event estimation (on_shadow)", "bounce (on_bounce); a miss: all of it", "accumulator read-modify-write", "ballots / bins / first barrier of the append",
-         "reservation atomic, stores, last barrier", "loop overhead + prologue", "-"]
+         "the append's stores (drained) and last barrier", "loop overhead + prologue", "reservation: bin scan + atomic with return by one thread, barrier"]
 total = float(sum(acc)) or 1.0
 out = {"scene": os.path.basename(scene), "wave_cycles": int(total), "phases": {n: {"cycles": int(c), "share": round(c / total, 4)} for n, c in zip(names, acc) if n != "-"}}
 print(json.dumps(out, indent=1))

@@ -17,7 +17,7 @@ dev.assign_scene(sc)
 dev.render(spi, w, h, iteration=0, seed=1, iterations=its)
 st = dev.stats()
 dev.close()
-names = ["refill (ray loads), epilogue (hit stores / splat), loop bookkeeping", "entity-leaf section", "inner-node section", "triangle section", "settle + quorum at the top of a pass", "-"]
+names = ["epilogue (hit stores / splat), loop bookkeeping", "entity-leaf section", "inner-node section", "triangle section", "settle + quorum at the top of a pass", "refill (batch reservation, ray loads, begin())"]
 out = {"scene": os.path.basename(scene)}
 for kernel, acc in (("closest hit", st["section_passes"]), ("any hit", st["section_lanes"])):
     total = float(sum(acc)) or 1.0
