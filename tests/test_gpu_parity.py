@@ -1467,3 +1467,32 @@ def test_cli_single_rank_through_rccl(tmp_path):
     pb, _ = _read_exr(b)
     for ch in "RGB":
         np.testing.assert_array_equal(pa[ch], pb[ch])
+
+
+@pytest.mark.gpu
+def test_assign_scene_checks_the_indices_behind_the_hit_records():
+    """igd_assign_scene gathers a 96-byte record per triangle through the shapes' index records (DevScene::prim_records); an index
+    outside of the shape's vertex array is refused there instead of being read by a kernel."""
+    import ctypes as C
+    from ignis_amd import Device, DeviceError
+    from ignis_amd.tables import LoadedScene
+    sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 32, 32)
+    s = sc.scene
+    base = int(s.shape_lookups[0].offset)
+    blob = C.cast(s.shape_data, C.POINTER(C.c_uint8))
+    hdr = np.frombuffer(bytes(blob[base:base + 16]), np.int32)  # faces, vertices, normals, texcoords
+    first_index = base + 48 + int(hdr[1]) * 16 + int(hdr[2]) * 16
+    words = C.cast(C.addressof(blob.contents) + first_index, C.POINTER(C.c_int32))
+    keep = words[0]
+    dev = Device(0)
+    try:
+        dev.assign_scene(sc)  # as loaded: fine
+        words[0] = int(hdr[1])  # one past the last vertex
+        with pytest.raises(DeviceError, match="vertex index"):
+            dev.assign_scene(sc)
+        words[0] = -1
+        with pytest.raises(DeviceError, match="vertex index"):
+            dev.assign_scene(sc)
+    finally:
+        words[0] = keep
+        dev.close()
