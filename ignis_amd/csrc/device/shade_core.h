@@ -480,6 +480,9 @@ IG_DEV m33 align_vectors(f3 a, f3 b) // core/matrix.art:261-284
     m.c2 = f3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
     return m;
 }
+#ifndef IG_EXPR_REGS_LDS
+#define IG_EXPR_REGS_LDS 1
+#endif
 // ---- shading expressions (PExpr strings compiled by the loader into the bytecode of include/ig_expr.h; the reference
 // transpiles them to Artic instead, src/runtime/loader/Transpiler.cpp). The variables are those of sInternalVariables
 // (Transpiler.cpp:338-363) this backend carries; texture alpha reads as 1 (Col has no alpha).
@@ -514,10 +517,26 @@ struct ExprCtx {
         return v3(ensure_valid_reflection(f3{ ng.v[0], ng.v[1], ng.v[2] }, f3{ v.v[0], v.v[1], v.v[2] }, f3{ n.v[0], n.v[1], n.v[2] }));
     }
 };
-// a call, not inlined: the interpreter's registers are a scratch array, and only materials with an expression pay for it
+// The interpreter's register file in LDS: a program names its registers at run time, so a private array would be scratch memory
+// (1.1 KB per lane of the expression kernels in round 2). One column of 12 x 16 B per lane of the largest workgroup (48 KiB; the
+// kernels that evaluate expressions run at two waves per SIMD).
+constexpr int kExprLanes = 256;
+struct ExprLdsRegs {
+    ige_v4* column;
+    IG_DEV ige_v4& operator[](uint32_t i) const { return column[i * kExprLanes]; }
+};
+// a call, not inlined: only materials with an expression pay for it
 __attribute__((noinline)) IG_DEV f3 eval_expr(const DevScene& sc, int32_t start, const Surf& s, f3 view)
 {
+#if IG_EXPR_REGS_LDS
+    __shared__ ige_v4 s_expr_regs[IGE_REGS][kExprLanes];
+    const ExprLdsRegs regs{ &s_expr_regs[0][threadIdx.x] };
+    for (int i = 0; i < IGE_REGS; ++i)
+        regs[i] = ige_v4{ { 0, 0, 0, 0 } };
+    const ige_v4 r = ige_run(sc.expr_code + start, ExprCtx{ &sc, &s, view }, regs);
+#else
     const ige_v4 r = ige_run(sc.expr_code + start, ExprCtx{ &sc, &s, view });
+#endif
     return f3{ r.v[0], r.v[1], r.v[2] };
 }
 

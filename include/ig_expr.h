@@ -163,11 +163,32 @@ IGM_FN float ige_wrap(float v, float lo, float hi) /* math::wrap (core/math.art:
 
 IGM_FN int ige_parity(float v) { return ige_ftoi(ige_wrap(v, 0.0f, 2.0f)) % 2; }
 
+/* component k of v, chosen by comparisons: an index computed at run time would put v into scratch memory on the GPU */
+IGM_FN float ige_pick(const ige_v4& v, uint32_t k) { return k == 0 ? v.v[0] : (k == 1 ? v.v[1] : (k == 2 ? v.v[2] : v.v[3])); }
+
+/* The register file of a run. A plain array wherever private memory is cheap (host, oracle); the kernels hand in one that lives
+ * in LDS (`r[i]` = element i of a lane's column), because registers named by the program are indexed dynamically and a private
+ * array would be scratch memory. */
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define IGE_MEMBER __host__ __device__
+#else
+#define IGE_MEMBER
+#endif
+struct ige_private_regs {
+    ige_v4 r[IGE_REGS];
+    IGE_MEMBER ige_private_regs()
+    {
+        for (int i = 0; i < IGE_REGS; ++i)
+            for (int k = 0; k < 4; ++k)
+                r[i].v[k] = 0.0f;
+    }
+    IGE_MEMBER ige_v4& operator[](uint32_t i) { return r[i]; }
+};
+
 /* Ctx supplies: ige_v4 var(int id), ige_v4 tex(uint32_t id, float u, float v), ige_v4 evr(ige_v4 ng, ige_v4 v, ige_v4 n) */
-template <class Ctx>
-IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
+template <class Ctx, class Regs>
+IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
 {
-    ige_v4 r[IGE_REGS] = {};
     for (;;) {
         const uint32_t w   = *code++;
         const uint32_t op  = w & 0xFFu;
@@ -208,7 +229,7 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
             break;
         case IGE_SWZ:
             for (int i = 0; i < 4; ++i)
-                o.v[i] = a.v[(imm >> (2 * i)) & 3u];
+                o.v[i] = ige_pick(a, (imm >> (2 * i)) & 3u);
             break;
         case IGE_LT:
         case IGE_GT:
@@ -221,8 +242,8 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
         }
         case IGE_EQ: {
             bool t = true;
-            for (uint32_t i = 0; i < imm; ++i)
-                t = t && a.v[i] == b.v[i];
+            for (uint32_t i = 0; i < 4; ++i) /* the first imm components */
+                t = t && (i >= imm || a.v[i] == b.v[i]);
             for (int i = 0; i < 4; ++i)
                 o.v[i] = t ? 1.0f : 0.0f;
             break;
@@ -388,6 +409,12 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
         }
         r[dst] = o;
     }
+}
+
+template <class Ctx>
+IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx)
+{
+    return ige_run(code, ctx, ige_private_regs());
 }
 
 /* Walks the program that starts at word `start`: every opcode known, every register below IGE_REGS, every texture
