@@ -476,7 +476,15 @@ void build_scene_bvh8(const std::vector<EntityObject>& objs, std::vector<ig_node
         centers.push_back(o.bbox.center());
     }
 
-    const Bvh2 bvh2 = build_bvh2(bboxes, centers);
+    // Leaves of the scene BVH. The sweep builder stops splitting where the SAH sees no gain, which for the boxes of a room's walls (they
+    // all span the room) is at once: a leaf of several entities whose boxes are then scanned in storage order by every ray that reaches
+    // it. With one entity per leaf the wide node above them orders the entities by entry distance and the cull against the current hit
+    // works per entity; up to two per leaf where the SAH keeps them together (diamond_scene: 1 / 2 / 3 / 4 / 8 entities per leaf = 7 740 / 7 845 /
+    // 7 840 / 7 270 / 7 240 Mrays/s, profiles/r03_experiment_ab.txt). IGH_SCENE_MAX_LEAF overrides (8 = the library default the reference ends up with).
+    size_t max_leaf = referenceCollapse() ? 8 : 2;
+    if (const char* e = std::getenv("IGH_SCENE_MAX_LEAF"))
+        max_leaf = (size_t)std::max(1, std::atoi(e));
+    const Bvh2 bvh2 = build_bvh2(bboxes, centers, max_leaf);
 
     adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
         nodes[parent].child[child] = ~(int32_t)leaves.size();
