@@ -73,7 +73,7 @@ constexpr bool kSingleRowsEarly = IG_SINGLE_ROWS_EARLY != 0; // entity-leaf sect
 #endif
 constexpr bool kNodePushFast = IG_NODE_PUSH_FAST != 0; // inner-node section: stack rows by address, one bound check per node
 #ifndef IG_SCAN_LEAVES
-#define IG_SCAN_LEAVES 4
+#define IG_SCAN_LEAVES 2
 #endif
 constexpr int kScanLeaves = IG_SCAN_LEAVES; // entity-leaf section: leaves of a run fetched per round trip
 #ifndef IG_REUSE_RCP

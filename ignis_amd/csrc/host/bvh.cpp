@@ -439,7 +439,10 @@ void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vect
     size_t min_leaf = M;
     if (const char* e = std::getenv("IGH_MIN_LEAF"))
         min_leaf = (size_t)std::max(1, std::atoi(e)); // experiments
-    const Bvh2 bvh2 = build_bvh2(bboxes, centers, std::max<size_t>(8, min_leaf), referenceCollapse() ? 1 : min_leaf);
+    size_t max_leaf = 8;
+    if (const char* e = std::getenv("IGH_MAX_LEAF"))
+        max_leaf = (size_t)std::max(1, std::atoi(e)); // experiments
+    const Bvh2 bvh2 = build_bvh2(bboxes, centers, std::max<size_t>(max_leaf, min_leaf), referenceCollapse() ? 1 : min_leaf);
 
     adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
         nodes[parent].child[child] = ~(int32_t)tris.size();
