@@ -10,7 +10,7 @@
 namespace igdev {
 
 #ifndef IG_REFILL_IDLE
-#define IG_REFILL_IDLE 32
+#define IG_REFILL_IDLE 24
 #endif
 #ifndef IG_REFILL_IDLE_ANY
 #define IG_REFILL_IDLE_ANY IG_REFILL_IDLE
