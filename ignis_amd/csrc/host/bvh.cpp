@@ -10,6 +10,7 @@
 #include <queue>
 #include <stack>
 #include <stdexcept>
+#include <string>
 
 namespace igh {
 
@@ -321,6 +322,100 @@ void convertNode(const Bvh2& original, const Bvh2Node& node, NBvh& bvh, uint32_t
         convertNode(original, children[i], bvh, first + (uint32_t)i);
 }
 
+// Collapse that minimises the summed surface area of the wide inner nodes (the SAH cost of visiting them; the leaves are the binary
+// tree's and cost the same under every collapse): the dynamic programme of Ylitie, Karras and Laine, "Efficient Incoherent Ray Traversal
+// on GPUs Through Compressed Wide BVHs" (HPG 2017, section 3.1), without its leaf merging. T(n, i) = least cost of the subtree of n
+// presented to a parent as at most i children; T(n, 1) = area(n) + D(n, 8) makes n a wide node, D(n, j) = min over k of T(left, k) +
+// T(right, j - k) hands j slots to its two sides. The greedy collapse fills the nodes near the root and leaves the bottom of the tree as
+// nodes of two leaves (3.3 children per node on the stand-in terrain); this one trades slots between the sides.
+struct CollapsePlan {
+    struct Entry {
+        float t[N + 1];       // t[i], i = 1 .. N - 1 (t[N] unused)
+        uint8_t split[N + 1]; // for j = 2 .. N: slots handed to the left side by D(n, j)
+        uint8_t use[N + 1];   // for i = 1 .. N - 1: the number of slots T(n, i) really uses (1 = n is a wide node itself)
+    };
+    std::vector<Entry> e;
+
+    explicit CollapsePlan(const Bvh2& bvh)
+        : e(bvh.nodes.size())
+    {
+        // children have larger indices than their parent (build_bvh2 appends them): backwards = bottom-up
+        for (size_t n = bvh.nodes.size(); n-- > 0;) {
+            const Bvh2Node& node = bvh.nodes[n];
+            Entry& en            = e[n];
+            if (node.isLeaf()) {
+                for (size_t i = 0; i <= N; ++i)
+                    en.t[i] = 0, en.split[i] = 0, en.use[i] = 1;
+                continue;
+            }
+            const Entry &l = e[node.first], &r = e[node.first + 1];
+            float d[N + 1];
+            for (size_t j = 2; j <= N; ++j) {
+                d[j] = std::numeric_limits<float>::infinity();
+                for (size_t k = 1; k < j; ++k) {
+                    const size_t kl = std::min(k, N - 1), kr = std::min(j - k, N - 1);
+                    const float c = l.t[kl] + r.t[kr];
+                    if (c < d[j])
+                        d[j] = c, en.split[j] = (uint8_t)k;
+                }
+            }
+            const float* b = node.bounds;
+            const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+            en.t[1]   = (dx * dy + dy * dz + dz * dx) + d[N];
+            en.use[1] = 1;
+            for (size_t i = 2; i < N; ++i) {
+                if (d[i] < en.t[i - 1])
+                    en.t[i] = d[i], en.use[i] = (uint8_t)i;
+                else
+                    en.t[i] = en.t[i - 1], en.use[i] = en.use[i - 1];
+            }
+            en.t[N] = en.t[N - 1], en.use[N] = en.use[N - 1];
+        }
+    }
+
+    // the children node `n` contributes to its parent when it is given `slots` of them
+    void gather(const Bvh2& bvh, uint32_t n, size_t slots, std::vector<uint32_t>& out) const
+    {
+        const Bvh2Node& node = bvh.nodes[n];
+        const size_t used    = node.isLeaf() ? 1 : e[n].use[std::min(slots, N - 1)];
+        if (used <= 1) {
+            out.push_back(n);
+            return;
+        }
+        const size_t k = e[n].split[used];
+        gather(bvh, node.first, k, out);
+        gather(bvh, node.first + 1, used - k, out);
+    }
+    void childrenOf(const Bvh2& bvh, uint32_t n, std::vector<uint32_t>& out) const
+    {
+        const Bvh2Node& node = bvh.nodes[n];
+        const size_t k       = e[n].split[N];
+        gather(bvh, node.first, k, out);
+        gather(bvh, node.first + 1, N - k, out);
+    }
+};
+
+void convertNodeOptimal(const Bvh2& original, const CollapsePlan& plan, uint32_t n, NBvh& bvh, uint32_t cur_id)
+{
+    if (original.nodes[n].isLeaf())
+        return;
+    std::vector<uint32_t> children;
+    plan.childrenOf(original, n, children);
+    bvh.nodes[cur_id].primitive_or_child_count = (int32_t)children.size();
+    bvh.nodes[cur_id].first_child_or_primitive = (uint32_t)bvh.nodes.size();
+    for (uint32_t c : children)
+        bvh.nodes.push_back(cloneNode(original.nodes[c]));
+    const uint32_t first = bvh.nodes[cur_id].first_child_or_primitive;
+    for (size_t i = 0; i < children.size(); ++i)
+        convertNodeOptimal(original, plan, children[i], bvh, first + (uint32_t)i);
+}
+
+bool greedyCollapse()
+{
+    static const bool v = [] { const char* e = std::getenv("IGH_COLLAPSE"); return e && std::string(e) == "greedy"; }();
+    return v;
+}
+
 NBvh convertToNArity(const Bvh2& original)
 {
     NBvh bvh;
@@ -328,8 +423,10 @@ NBvh convertToNArity(const Bvh2& original)
     bvh.nodes.push_back(cloneNode(original.nodes[0]));
     if (referenceCollapse())
         convertNode(original, original.nodes[0], bvh, 0);
-    else
+    else if (greedyCollapse())
         convertNodeGreedy(original, original.nodes[0], bvh, 0);
+    else
+        convertNodeOptimal(original, CollapsePlan(original), 0, bvh, 0);
     bvh.primitive_indices = original.prim_ids;
     return bvh;
 }
