@@ -446,8 +446,28 @@ void writeNode(std::vector<ig_node8>& nodes, const NBvh& bvh, const NNode& node,
     if (count == 0 || count > N)
         throw std::runtime_error("BVH collapse produced an invalid node");
 
+    // Which child goes into which slot. The traversal pushes the children it hits in slot order; an any-hit query makes each of them the
+    // new top of the stack, i.e. looks at the LAST slot first, a closest-hit query keeps the nearest on top and the others in slot order.
+    // IGH_CHILD_ORDER: asis (the collapse's order) | reverse | area_asc (largest box in the last slot: first for a shadow ray) | area_desc
+    size_t order[N];
+    for (size_t i = 0; i < count; ++i)
+        order[i] = i;
+    static const std::string child_order = [] { const char* e = std::getenv("IGH_CHILD_ORDER"); return std::string(e ? e : "asis"); }();
+    if (child_order != "asis" && !referenceCollapse()) {
+        auto area = [&](size_t i) {
+            const float* b = bvh.nodes.at(node.first_child_or_primitive + i).bounds;
+            const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        if (child_order == "reverse")
+            std::reverse(order, order + count);
+        else if (child_order == "area_asc")
+            std::stable_sort(order, order + count, [&](size_t a, size_t b) { return area(a) < area(b); });
+        else if (child_order == "area_desc")
+            std::stable_sort(order, order + count, [&](size_t a, size_t b) { return area(a) > area(b); });
+    }
     for (size_t i = 0; i < count; ++i) {
-        const NNode src = bvh.nodes.at(node.first_child_or_primitive + i);
+        const NNode src = bvh.nodes.at(node.first_child_or_primitive + order[i]);
         for (int k = 0; k < 6; ++k)
             nodes[node_id].bounds[k][i] = src.bounds[k];
         if (src.isLeaf())
