@@ -68,6 +68,10 @@ constexpr int kLeafRepeatMin = IG_LEAF_REPEAT_MIN;  // ... and at least this man
 #define IG_SINGLE_ROWS_EARLY 0
 #endif
 constexpr bool kSingleRowsEarly = IG_SINGLE_ROWS_EARLY != 0; // entity-leaf section: rows 6 / 7 of an entered leaf with rows 2 - 5
+#ifndef IG_SETTLE_CULL_TWO
+#define IG_SETTLE_CULL_TWO 0
+#endif
+constexpr bool kSettleCullTwo = IG_SETTLE_CULL_TWO != 0; // settle(): two culled entries per trip
 #ifndef IG_NODE_PUSH_FAST
 #define IG_NODE_PUSH_FAST 1
 #endif
@@ -321,7 +325,21 @@ struct Traverser {
             // hit is dropped, its items have no effect in the reference either
             tri_cursor = sel(leaf & (level == 1), ~top_node, tri_cursor);
             ent_cursor = sel(leaf & (level == 0), ~top_node, ent_cursor);
-            pop_top(st, tid, culling | ret | leaf);
+            if (kSettleCullTwo && !DEEP) {
+                // pop_top, reading the entry below as well: when the entry that becomes the top is itself behind the hit (the
+                // siblings pushed behind a nearest child mostly are, once that child has produced a hit) it is culled in the same
+                // step instead of costing the wave another trip around this loop
+                const bool on     = culling | ret | leaf;
+                const int row1    = ptr < 0 ? 0 : (ptr < kLdsStack ? ptr : kLdsStack - 1);
+                const int row2    = row1 > 0 ? row1 - 1 : 0;
+                const uint2 e1    = st.e[row1][tid], e2 = st.e[row2][tid];
+                const bool second = culling & (ptr >= 1) & (e1.x != 0u) & !(igm_float(e1.y) <= cull_t);
+                top_node = sel(on, (int)(second ? e2.x : e1.x), top_node);
+                top_tmin = sel(on, igm_float(second ? e2.y : e1.y), top_tmin);
+                ptr -= on ? (second ? 2 : 1) : 0;
+            } else {
+                pop_top(st, tid, culling | ret | leaf);
+            }
             // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
             // accepted only if its (rounded) distance does not exceed the current one.
             const bool accept = ret & (l_prim != -1) & (ltmax <= tmax);
