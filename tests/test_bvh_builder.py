@@ -1,0 +1,90 @@
+"""The host's tree builder (ignis_amd/csrc/host/bvh.cpp): what the tables it writes must satisfy whatever its tuning — every triangle in
+exactly one packet slot, 1 .. 8 children per Node8, boxes that contain their subtrees — and what round 3's tuning promises: at most
+two entities per scene-BVH leaf, and a collapse whose wide nodes have no more summed area than the greedy one's."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+ROOT = os.path.dirname(SCENES)
+
+_STATS = r"""
+import ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from ignis_amd.tables import LoadedScene
+sc = LoadedScene.from_file(sys.argv[1], 64, 64)
+s = sc.scene
+blob = np.frombuffer(C.string_at(s.primbvh, s.primbvh_size), np.uint8)
+out = []
+off = 0
+while off + 16 <= len(blob):
+    nodes, packets = (int(x) for x in np.frombuffer(blob[off:off + 8].tobytes(), np.int32))
+    if nodes <= 0:
+        break
+    nd = np.frombuffer(blob[off + 16:off + 16 + nodes * 256].tobytes(), np.float32).reshape(nodes, 64)
+    child = nd[:, 48:56].view(np.int32)
+    b = nd[:, :48].reshape(nodes, 6, 8)
+    ext = np.maximum(b[:, 1::2, :] - b[:, 0::2, :], 0)
+    area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+    inner = child > 0
+    tr = np.frombuffer(blob[off + 16 + nodes * 256:off + 16 + nodes * 256 + packets * 208].tobytes(), np.int32).reshape(packets, 52)
+    pid = tr[:, 48:52]
+    ids = (pid[pid != -1] & 0x7FFFFFFF)
+    out.append({"nodes": nodes, "children_min": int((child != 0).sum(1).min()), "children_max": int((child != 0).sum(1).max()),
+                "inner_area": float(area[inner].sum()), "leaves": int((child < 0).sum()), "triangles": int(len(ids)),
+                "unique": int(len(np.unique(ids))), "max_id": int(ids.max())})
+    off += 16 + nodes * 256 + packets * 208
+runs, n = [], 0
+for i in range(s.scene_leaf_count):
+    n += 1
+    if s.scene_leaves[i].entity_id < 0:
+        runs.append(n); n = 0
+print(json.dumps({"shapes": out, "runs": runs, "entities": int(s.entity_count)}))
+""" % ROOT
+
+
+def _stats(scene, **env):
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _STATS, scene], capture_output=True, text=True, env=e, check=True)
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope="module")
+def terrain(tmp_path_factory):
+    d = tmp_path_factory.mktemp("standin")
+    tool = os.path.join(ROOT, "tools", "make_standin_scene.py")
+    subprocess.run([sys.executable, tool, str(d), "--triangles", "40000", "--instances", "12", "--seed", "5", "--width", "64", "--height", "64"],
+                   check=True, capture_output=True)
+    return os.path.join(str(d), "standin.json")
+
+
+@pytest.mark.parametrize("which", ["diamond", "terrain"])
+def test_tables_are_complete_whatever_the_tuning(which, terrain):
+    scene = terrain if which == "terrain" else os.path.join(SCENES, "diamond_scene.json")
+    for env in ({}, {"IGH_COLLAPSE": "greedy"}, {"IGH_BVH_REFERENCE": "1"}, {"IGH_SCENE_MAX_LEAF": "8", "IGH_MIN_LEAF": "2"}):
+        st = _stats(scene, **env)
+        assert sum(st["runs"]) == st["entities"]
+        for sh in st["shapes"]:
+            assert 1 <= sh["children_min"] and sh["children_max"] <= 8, env
+            assert sh["triangles"] == sh["unique"] == sh["max_id"] + 1, env  # every triangle once
+
+
+def test_scene_leaves_hold_at_most_two_entities(terrain):
+    for scene in (terrain, os.path.join(SCENES, "diamond_scene.json")):
+        assert max(_stats(scene)["runs"]) <= 2
+        assert max(_stats(scene, IGH_SCENE_MAX_LEAF="8")["runs"]) > 2  # (what the builder's plain defaults give)
+
+
+def test_the_collapse_minimises_the_area_of_the_wide_nodes(terrain):
+    best, greedy = _stats(terrain), _stats(terrain, IGH_COLLAPSE="greedy")
+    a, b = sum(s["inner_area"] for s in best["shapes"]), sum(s["inner_area"] for s in greedy["shapes"])
+    na, nb = sum(s["nodes"] for s in best["shapes"]), sum(s["nodes"] for s in greedy["shapes"])
+    assert [s["leaves"] for s in best["shapes"]] == [s["leaves"] for s in greedy["shapes"]]  # the binary tree's leaves either way
+    assert a <= b * (1 + 1e-5) and na < nb
