@@ -72,6 +72,18 @@ constexpr bool kSingleRowsEarly = IG_SINGLE_ROWS_EARLY != 0; // entity-leaf sect
 #define IG_SETTLE_CULL_TWO 0
 #endif
 constexpr bool kSettleCullTwo = IG_SETTLE_CULL_TWO != 0; // settle(): two culled entries per trip
+#ifndef IG_POSTPONE_FALLBACK_BEST
+#define IG_POSTPONE_FALLBACK_BEST 0
+#endif
+constexpr bool kFallbackBest = IG_POSTPONE_FALLBACK_BEST != 0;
+#ifndef IG_NODE_REPEAT
+#define IG_NODE_REPEAT 0
+#endif
+#ifndef IG_NODE_REPEAT_SHARE
+#define IG_NODE_REPEAT_SHARE 6
+#endif
+constexpr int kNodeRepeat      = IG_NODE_REPEAT;       // inner-node section: extra visits per pass while most of the wave wants one
+constexpr int kNodeRepeatShare = IG_NODE_REPEAT_SHARE; // ... in eighths of 64 lanes
 #ifndef IG_NODE_PUSH_FAST
 #define IG_NODE_PUSH_FAST 1
 #endif
@@ -376,7 +388,7 @@ struct Traverser {
             const int most   = n_ent > n_node ? (n_ent > n_tri ? n_ent : n_tri) : (n_node > n_tri ? n_node : n_tri);
             quorum           = (active * kPostponeNum) >> kPostponeShift;
             if (quorum < 1 || most < quorum)
-                quorum = 1; // (falling back to the best filled section only measured no better: 528 vs 523 ms of traversal per 64 steps)
+                quorum = kFallbackBest ? (most > 0 ? most : 1) : 1; // no section reaches the quorum: all of them run (or, kFallbackBest, the best filled one only)
         }
 
         mark(4); // settle at the top of a pass + quorum
@@ -571,6 +583,11 @@ struct Traverser {
         mark(1); // entity-leaf section (with its settle)
         // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377)
         if (__popcll(__ballot((mode == 0) & !finished)) >= quorum) {
+            // kNodeRepeat: where rays walk many nodes between leaves (deep trees) most lanes are at an inner node again after the visit;
+            // the section then repeats, up to kNodeRepeat more times, while at least kNodeRepeatShare / 8 of the wave is — without the trip
+            // through the other sections' tests, the quorum and the loop's refill / finish checks in between
+            int again = kNodeRepeat;
+            do {
             const bool here   = (mode == 0) & !finished; // settled: an inner node is on top
             const uint8_t* np = geom + (SPHERES ? sc.sphere_nodes_off : (level ? node_off : sc.scene_nodes_off)) + (here ? (uint32_t)(top_node - 1) * 256u : 0u);
             pop_top(st, tid, here);
@@ -655,6 +672,7 @@ struct Traverser {
             }
             need_cull = need_cull | (here & !pushed);
             settle(sc, st, tid);
+            } while (kNodeRepeat > 0 && again-- > 0 && __popcll(__ballot((mode == 0) & !finished)) >= kNodeRepeatShare * 8);
         }
 
         mark(2); // inner-node section (with its settle)
