@@ -520,7 +520,10 @@ struct ExprCtx {
 // The interpreter's register file in LDS: a program names its registers at run time, so a private array would be scratch memory
 // (1.1 KB per lane of the expression kernels in round 2). One column of 12 x 16 B per lane of the largest workgroup (48 KiB; the
 // kernels that evaluate expressions run at two waves per SIMD).
-constexpr int kExprLanes = 256;
+#ifndef IG_SHADE_THREADS
+#define IG_SHADE_THREADS 256
+#endif
+constexpr int kExprLanes = IG_SHADE_THREADS > 256 ? IG_SHADE_THREADS : 256;
 struct ExprLdsRegs {
     ige_v4* column;
     IG_DEV ige_v4& operator[](uint32_t i) const { return column[i * kExprLanes]; }

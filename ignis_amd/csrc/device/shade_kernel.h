@@ -10,7 +10,10 @@ namespace igdev {
 
 // ---------------------------------------------------------------- k_shade
 
-constexpr int kShadeThreads = 256;
+#ifndef IG_SHADE_THREADS
+#define IG_SHADE_THREADS 256 // (experiments: the expression kernels' LDS register file is sized for 256)
+#endif
+constexpr int kShadeThreads = IG_SHADE_THREADS;
 constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry per thread
 
 // Waves per SIMD the full variant is built for. Its natural register demand is 252 VGPRs (215 without the principled BSDF, 196
@@ -205,7 +208,9 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                     s_binoff[k] = tb;
                     tb += s_bin[k];
                 }
-                const uint32_t ts = s_wave_cnt[1][0] + s_wave_cnt[1][1] + s_wave_cnt[1][2] + s_wave_cnt[1][3];
+                uint32_t ts = 0;
+                for (int w = 0; w < kShadeThreads / 64; ++w)
+                    ts += s_wave_cnt[1][w];
                 unsigned long long old = 0;
                 if (tb | ts)
                     old = atomicAdd(reinterpret_cast<unsigned long long*>(a.out_count), (unsigned long long)tb | ((unsigned long long)ts << 32));
