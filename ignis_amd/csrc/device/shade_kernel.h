@@ -35,6 +35,10 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #define IG_SHADE_SORT_FULL 1
 #endif
 constexpr bool kSortFull          = IG_SHADE_SORT_FULL != 0;
+#ifndef IG_BIN_KEY
+#define IG_BIN_KEY 0 // how the bounce rays of a window are grouped (experiments: 1 octant only, 2 + starting half, 3 entity left)
+#endif
+constexpr int kBounceBins = IG_BIN_KEY >= 2 ? 32 : 16;
 constexpr bool kSortLean          = IG_SHADE_SORT_LEAN != 0;
 constexpr bool kShadeAtomicAccum = IG_SHADE_ATOMIC_ACCUM != 0;
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
@@ -46,7 +50,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     __shared__ uint16_t s_perm[kShadeThreads];
     __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
     __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_bin[16], s_binoff[16]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
+    __shared__ uint32_t s_bin[kBounceBins], s_binoff[kBounceBins]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         uint32_t j = base + tid;
         // cleared here, in front of the sort's barriers (or the explicit one below when there is no sort): every wave's
         // atomicAdd on s_bin is then ordered behind the clear, and the previous window's last barrier behind its reads
-        if (tid < 16)
+        if (tid < kBounceBins)
             s_bin[tid] = 0;
         if (do_sort) {
             const uint32_t i = base + tid;
@@ -118,6 +122,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
         int ray_id = 0;
+        int in_ent_for_bin = 0;
         int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
         if (j < n) {
             PathVertexIn in;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             in.contrib = Col{ pay.y, pay.z, pay.w };
             in.depth   = meta.w;
             in.eta     = a.in.eta[j];
-            in.ent     = (int)igm_bits(hit.x);
+            in.ent     = in_ent_for_bin = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
             clk.mark(1); // the ray's columns
@@ -196,7 +201,13 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             if (out.bounce) {
                 // rays that continue through a specular (dielectric) vertex start inside or on a refractive object and
                 // walk its BVH first; the others cross the room: two populations with different traversal shapes
-                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0) | (out.b_inv_pdf == 0 ? 8 : 0);
+                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0);
+                if (IG_BIN_KEY == 0)
+                    bkey |= out.b_inv_pdf == 0 ? 8 : 0;
+                if (IG_BIN_KEY == 2) // the half of the scene the ray starts in, along the axis it mostly travels
+                    bkey |= (out.b_inv_pdf == 0 ? 8 : 0) | ((igm_abs(out.b_dir.x) > igm_abs(out.b_dir.y) ? (igm_abs(out.b_dir.x) > igm_abs(out.b_dir.z) ? out.b_org.x < sc.scene_center[0] : out.b_org.z < sc.scene_center[2]) : (igm_abs(out.b_dir.y) > igm_abs(out.b_dir.z) ? out.b_org.y < sc.scene_center[1] : out.b_org.z < sc.scene_center[2])) ? 16 : 0);
+                if (IG_BIN_KEY == 3) // the entity the ray leaves
+                    bkey = ((out.b_inv_pdf == 0 ? 1 : 0) | ((in_ent_for_bin & 7) << 1)) | ((out.b_dir.y < 0 ? 1 : 0) << 4);
                 brank = atomicAdd(&s_bin[bkey], 1u);
             }
             __syncthreads();
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             if (tid == 0) {
                 // both queues' sizes live in one 64-bit word (QueueState::Counts): one reservation per window
                 uint32_t tb = 0;
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < kBounceBins; ++k) {
                     s_binoff[k] = tb;
                     tb += s_bin[k];
                 }
