@@ -39,6 +39,10 @@ constexpr bool kSortFull          = IG_SHADE_SORT_FULL != 0;
 #define IG_BIN_KEY 0 // how the bounce rays of a window are grouped (experiments: 1 octant only, 2 + starting half, 3 entity left)
 #endif
 constexpr int kBounceBins = IG_BIN_KEY >= 2 ? 32 : 16;
+#ifndef IG_SHADOW_BINS
+#define IG_SHADOW_BINS 0
+#endif
+constexpr bool kShadowBins = IG_SHADOW_BINS != 0; // the shadow rays of a window grouped by the octant of their direction as well
 constexpr bool kSortLean          = IG_SHADE_SORT_LEAN != 0;
 constexpr bool kShadeAtomicAccum = IG_SHADE_ATOMIC_ACCUM != 0;
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
@@ -50,7 +54,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     __shared__ uint16_t s_perm[kShadeThreads];
     __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
     __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_bin[kBounceBins], s_binoff[kBounceBins]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
+    __shared__ uint32_t s_bin[kBounceBins + 8], s_binoff[kBounceBins + 8]; // (the last eight: shadow rays by octant, kShadowBins) // bounce rays of a window are written grouped by (specular bounce, direction octant)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         uint32_t j = base + tid;
         // cleared here, in front of the sort's barriers (or the explicit one below when there is no sort): every wave's
         // atomicAdd on s_bin is then ordered behind the clear, and the previous window's last barrier behind its reads
-        if (tid < kBounceBins)
+        if (tid < kBounceBins + 8)
             s_bin[tid] = 0;
         if (do_sort) {
             const uint32_t i = base + tid;
@@ -210,6 +214,12 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                     bkey = ((out.b_inv_pdf == 0 ? 1 : 0) | ((in_ent_for_bin & 7) << 1)) | ((out.b_dir.y < 0 ? 1 : 0) << 4);
                 brank = atomicAdd(&s_bin[bkey], 1u);
             }
+            int skey       = 0;
+            uint32_t srank = 0;
+            if (kShadowBins && out.shadow) {
+                skey  = kBounceBins + ((out.s_dir.x < 0 ? 1 : 0) | (out.s_dir.y < 0 ? 2 : 0) | (out.s_dir.z < 0 ? 4 : 0));
+                srank = atomicAdd(&s_bin[skey], 1u);
+            }
             __syncthreads();
             clk.mark(8); // ballots, bins, the barrier in front of the reservation
             if (tid == 0) {
@@ -222,6 +232,13 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 uint32_t ts = 0;
                 for (int w = 0; w < kShadeThreads / 64; ++w)
                     ts += s_wave_cnt[1][w];
+                if (kShadowBins) {
+                    uint32_t t = 0;
+                    for (int k = kBounceBins; k < kBounceBins + 8; ++k) {
+                        s_binoff[k] = t;
+                        t += s_bin[k];
+                    }
+                }
                 unsigned long long old = 0;
                 if (tb | ts)
                     old = atomicAdd(reinterpret_cast<unsigned long long*>(a.out_count), (unsigned long long)tb | ((unsigned long long)ts << 32));
@@ -242,7 +259,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 a.out.eta[o]  = out.b_eta;
             }
             if (out.shadow) {
-                const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+                const uint32_t o = kShadowBins ? s_base[1] + s_binoff[skey] + srank : os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
                 a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
                 a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
                 a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
