@@ -23,11 +23,9 @@ sc = LoadedScene.from_file(sys.argv[1], 64, 64)
 s = sc.scene
 blob = np.frombuffer(C.string_at(s.primbvh, s.primbvh_size), np.uint8)
 out = []
-off = 0
-while off + 16 <= len(blob):
+offsets = sorted({((int(s.scene_leaves[i].user[1]) & 0xFFFFFFFF) << 32 | (int(s.scene_leaves[i].user[0]) & 0xFFFFFFFF)) * 4 for i in range(s.scene_leaf_count)})
+for off in offsets:  # where each shape's {header, Node8[], Tri4[]} starts: the scene leaves' user words, in floats
     nodes, packets = (int(x) for x in np.frombuffer(blob[off:off + 8].tobytes(), np.int32))
-    if nodes <= 0:
-        break
     nd = np.frombuffer(blob[off + 16:off + 16 + nodes * 256].tobytes(), np.float32).reshape(nodes, 64)
     child = nd[:, 48:56].view(np.int32)
     b = nd[:, :48].reshape(nodes, 6, 8)
@@ -40,7 +38,6 @@ while off + 16 <= len(blob):
     out.append({"nodes": nodes, "children_min": int((child != 0).sum(1).min()), "children_max": int((child != 0).sum(1).max()),
                 "inner_area": float(area[inner].sum()), "leaves": int((child < 0).sum()), "triangles": int(len(ids)),
                 "unique": int(len(np.unique(ids))), "max_id": int(ids.max())})
-    off += 16 + nodes * 256 + packets * 208
 runs, n = [], 0
 for i in range(s.scene_leaf_count):
     n += 1

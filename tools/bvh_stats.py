@@ -12,13 +12,12 @@ from ignis_amd.tables import LoadedScene  # noqa: E402
 sc = LoadedScene.from_file(sys.argv[1], 64, 64)
 s = sc.scene
 blob = np.frombuffer(C.string_at(s.primbvh, s.primbvh_size), np.uint8)
-off = 0
 tot_nodes = tot_children = tot_leaves = tot_packets = tot_tris = 0
 hist = np.zeros(9, np.int64)
-while off + 16 <= len(blob):
-    nodes, packets = np.frombuffer(blob[off:off + 8].tobytes(), np.int32)
-    if nodes <= 0:
-        break
+# where each shape's {header, Node8[], Tri4[]} starts: the scene leaves' user words (offset in floats, TriMeshProvider.cpp:598)
+offsets = sorted({((int(s.scene_leaves[i].user[1]) & 0xFFFFFFFF) << 32 | (int(s.scene_leaves[i].user[0]) & 0xFFFFFFFF)) * 4 for i in range(s.scene_leaf_count)})
+for off in offsets:
+    nodes, packets = (int(x) for x in np.frombuffer(blob[off:off + 8].tobytes(), np.int32))
     nd = np.frombuffer(blob[off + 16:off + 16 + nodes * 256].tobytes(), np.int32).reshape(nodes, 64)
     child = nd[:, 48:56]
     tr = np.frombuffer(blob[off + 16 + nodes * 256:off + 16 + nodes * 256 + packets * 208].tobytes(), np.int32).reshape(packets, 52)
@@ -28,8 +27,8 @@ while off + 16 <= len(blob):
     leaves = int((child < 0).sum())
     tris = int((pid != -1).sum())
     tot_nodes += nodes; tot_children += int(n_child.sum()); tot_leaves += leaves; tot_packets += packets; tot_tris += tris
-    off += 16 + nodes * 256 + packets * 208
-    off = (off + 15) // 16 * 16
+    if len(offsets) <= 16:
+        print("  shape at %8d: %5d nodes, %6d triangles in %5d leaves / %5d packets, children per node %.2f" % (off, nodes, tris, leaves, packets, n_child.mean()))
 print("shapes' BVHs: %d nodes, %.2f children per node, %d leaves, %.2f triangles and %.2f packets per leaf, %.2f triangles per packet" % (
     tot_nodes, tot_children / max(tot_nodes, 1), tot_leaves, tot_tris / max(tot_leaves, 1), tot_packets / max(tot_leaves, 1), tot_tris / max(tot_packets, 1)))
 print("children per node histogram (0..8):", hist.tolist())
