@@ -206,7 +206,7 @@ struct igd_device {
     // Once at most this many paths are alive the remaining bounces are followed per lane (tail.hip) on the
     // side stream. IGD_TAIL_THRESHOLD overrides (0 disables).
     uint32_t tail_threshold = 1048576;
-    int tail_waves_per_cu   = 8; // IGD_TAIL_WAVES
+    int tail_waves_per_cu   = 12; // IGD_TAIL_WAVES (12 = what fits a CU at three waves per SIMD; 8 until late in round 3: +0.8 %)
     // The tail runs as a sequence of launches: each follows its paths for at most this many bounces and hands
     // the survivors, compacted, to the next one. Path lengths are geometric (a path inside a dielectric survives
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
