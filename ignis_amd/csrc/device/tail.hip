@@ -20,10 +20,13 @@ namespace igdev {
 
 // One wave per workgroup: a straggling path then pins 12 KiB of LDS and one wave slot, not a 256-lane
 // workgroup's 48 KiB, which matters because the tail overlaps the next chunk's traversal launches.
+#ifndef IG_TAIL_OCC
+#define IG_TAIL_OCC 3 // waves per SIMD the tail kernels are built for (168 VGPRs)
+#endif
 constexpr int kTailThreads = 64;
 
 template <bool STATS, bool FULL>
-__global__ void __launch_bounds__(kTailThreads, 3) k_tail(const TailArgs a)
+__global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailArgs a)
 {
     __shared__ StackOf<kTailThreads> s_stack;
 
@@ -283,7 +286,7 @@ IG_DEV void traverse_slice(const DevScene& sc, StackOf<kTailThreads>& stack, int
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(kTailThreads, 3) k_tail_wave(const TailArgs a)
+__global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail_wave(const TailArgs a)
 {
     __shared__ StackOf<kTailThreads> s_stack;
 
