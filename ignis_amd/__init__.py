@@ -6,7 +6,8 @@ Layout (only what the path needs):
   tables.py / device.py   ctypes views of the two C ABIs
   runtime.py    mirror of the reference's Python `ignis` module API for this path
 """
-from .runtime import CameraOrientation, Ray, Runtime, RuntimeOptions, loadFromFile, loadFromString  # noqa: F401
+from .runtime import (CameraOrientation, DenoiserSettings, Ray, Runtime, RuntimeOptions, hasDenoiser, loadFromFile,  # noqa: F401
+                      loadFromString, registerDenoiser)  # noqa: F401
 from .device import Device, DeviceError, device_count  # noqa: F401
 from .tables import LoadedScene  # noqa: F401
 

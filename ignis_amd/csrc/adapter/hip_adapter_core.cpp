@@ -174,6 +174,8 @@ void Core::clearAllFramebuffer()
     igd_clear_framebuffer(mDev, nullptr);
     for (const char* n : { "Normals", "Albedo" })
         igd_clear_framebuffer(mDev, n);
+    if (igd_buffer_size(mDev, "Denoised")) // (exists once the runtime's denoiser has asked for it, extra/OIDN.cpp:106)
+        igd_clear_framebuffer(mDev, "Denoised");
 }
 void Core::syncFramebufferHostToDevice(const std::string& name)
 {

@@ -143,9 +143,12 @@ struct igd_device {
     DevBuf<float> cdf_data;
     // info-buffer AOVs (igd_setup.info_aovs): [0] "Normals", [1] "Albedo", film-sized like the colour buffer
     // [2] "Direct Weights", [3] "NEE Weights": path tracer with ig_technique.aov_mis (allocated when such a scene is assigned)
-    DevBuf<float> aov[4];
-    std::vector<float> aov_host[4];
-    bool aov_host_dirty[4] = { true, true, true, true };
+    // [4] "Denoised": never written by the device; the runtime's denoiser (extra/OIDN.cpp:103-104,135-138) fetches it by name, fills
+    // it and calls syncFramebufferHostToDevice("Denoised"). Allocated at the first access by name (denoised_wanted).
+    DevBuf<float> aov[5];
+    std::vector<float> aov_host[5];
+    bool aov_host_dirty[5] = { true, true, true, true, true };
+    bool denoised_wanted  = false;
     DevBuf<float> info_tmp[2]; // per-sample values of one chunk (float4 each)
     DevBuf<QueueState> info_qs;
     uint32_t tail_lanes = 0; // lanes of one tail grid (its share of the deep-stack columns)
@@ -880,8 +883,8 @@ void resizeFb(igd_device* d, int w, int h)
         d->fb_host.assign((size_t)w * h * 3, 0.0f);
         d->fb_host_dirty = true;
     }
-    for (int k = 0; k < 4; ++k) {
-        const bool wanted = k < 2 ? d->setup.info_aovs != 0 : (d->has_scene && d->dscene.tech.aov_mis != 0);
+    for (int k = 0; k < 5; ++k) {
+        const bool wanted = k == 4 ? (d->setup.info_aovs != 0 && d->denoised_wanted) : k < 2 ? d->setup.info_aovs != 0 : (d->has_scene && d->dscene.tech.aov_mis != 0);
         if (same && (wanted == (d->aov[k].ptr != nullptr)))
             continue; // (the MIS AOVs come and go with the scene's technique)
         d->aov[k].release();
@@ -1786,6 +1789,17 @@ FilmBuffer filmBuffer(igd_device* d, const char* name)
             return FilmBuffer{ &d->aov[0], &d->aov_host[0], &d->aov_host_dirty[0] };
         if (std::strcmp(name, "Albedo") == 0)
             return FilmBuffer{ &d->aov[1], &d->aov_host[1], &d->aov_host_dirty[1] };
+        if (std::strcmp(name, "Denoised") == 0) {
+            if (!d->aov[4].ptr && d->fb.ptr) { // first access: one more film-sized buffer, zeroed
+                HIP_CHECK(hipSetDevice(d->setup.gpu_index));
+                d->aov[4].alloc((size_t)d->fb_w * d->fb_h * 3);
+                clearOnStream(d->stream, d->aov[4].ptr, 0, (size_t)d->fb_w * d->fb_h * 3 * sizeof(float));
+                d->aov_host[4].assign((size_t)d->fb_w * d->fb_h * 3, 0.0f);
+                d->aov_host_dirty[4] = true;
+            }
+            d->denoised_wanted = true;
+            return FilmBuffer{ &d->aov[4], &d->aov_host[4], &d->aov_host_dirty[4] };
+        }
     }
     if (d->has_scene && d->dscene.tech.aov_mis) { // PathTechnique.cpp:24-25
         if (std::strcmp(name, "Direct Weights") == 0)
@@ -1850,6 +1864,8 @@ NamedBuffer namedBuffer(igd_device* d, const char* name)
         return of(d->aov[0]);
     if (d->setup.info_aovs && n == "Albedo")
         return of(d->aov[1]);
+    if (d->setup.info_aovs && n == "Denoised")
+        return of(d->aov[4]); // (empty until a framebuffer accessor has asked for it)
     if (d->dscene.tech.aov_mis && n == "Direct Weights")
         return of(d->aov[2]);
     if (d->dscene.tech.aov_mis && n == "NEE Weights")
@@ -1997,7 +2013,7 @@ int32_t igd_resize(igd_device* dev, int32_t width, int32_t height)
         resizeFb(dev, width, height);
         clearOnStream(dev->stream, dev->fb.ptr, 0, (size_t)width * height * 3 * sizeof(float));
         dev->fb_host_dirty = true;
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
             if (dev->aov[k].ptr) {
                 clearOnStream(dev->stream, dev->aov[k].ptr, 0, (size_t)width * height * 3 * sizeof(float));
                 dev->aov_host_dirty[k] = true;

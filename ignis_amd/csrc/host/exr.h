@@ -1,15 +1,21 @@
 // exr.h — minimal OpenEXR writer for Runtime::saveFramebuffer (src/runtime/Runtime.cpp:794-876, Image::save):
-// single-part scanline file, 32-bit float channels, ZIP-less (NO_COMPRESSION), channels "B", "G", "R" like the
-// reference's swizzle. Every OpenEXR reader accepts this form; the reference compresses, which changes bytes on
-// disk, not pixel values.
+// single-part scanline file, 32-bit float channels, channels "B", "G", "R" like the reference's swizzle. Compressed like the
+// reference's files for small films (Image.cpp:940-942: ZIP; it takes PIZ for larger ones -- both lossless for float, so the
+// choice changes bytes on disk, not pixel values): ZIP_COMPRESSION, blocks of 16 scanlines, bytes split into even / odd halves,
+// delta-predicted, deflated; a block that does not shrink is stored as is (the OpenEXR rule readers rely on).
+// IGH_EXR_COMPRESSION=none writes the uncompressed form.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 namespace igh {
 
@@ -45,7 +51,9 @@ inline void writeExr(const std::string& path, const float* rgb, int width, int h
         ch.push_back(0);
         attr("channels", "chlist", ch.data(), (int32_t)ch.size());
     }
-    const uint8_t compression = 0;
+    const char* want_comp     = std::getenv("IGH_EXR_COMPRESSION");
+    const bool zip            = !(want_comp && std::strcmp(want_comp, "none") == 0);
+    const uint8_t compression = zip ? 3 : 0; // ZIP_COMPRESSION (16 scanlines per block) : NO_COMPRESSION
     attr("compression", "compression", &compression, 1);
     const int32_t window[4] = { 0, 0, width - 1, height - 1 };
     attr("dataWindow", "box2i", window, 16);
@@ -63,20 +71,42 @@ inline void writeExr(const std::string& path, const float* rgb, int width, int h
     out.push_back(0); // end of header
 
     const size_t row_bytes   = (size_t)width * 3 * 4;
+    const int lines          = zip ? 16 : 1;
+    const int blocks         = (height + lines - 1) / lines;
     const size_t table_start = out.size();
-    const size_t data_start  = table_start + (size_t)height * 8;
-    out.resize(data_start + (size_t)height * (8 + row_bytes));
-    for (int y = 0; y < height; ++y) {
-        const uint64_t off = data_start + (size_t)y * (8 + row_bytes);
-        std::memcpy(&out[table_start + (size_t)y * 8], &off, 8);
-        const int32_t yy = y, sz = (int32_t)row_bytes;
-        std::memcpy(&out[off], &yy, 4);
-        std::memcpy(&out[off + 4], &sz, 4);
-        float* dst = reinterpret_cast<float*>(&out[off + 8]);
-        const float* src = rgb + (size_t)y * width * 3;
-        for (int c = 0; c < 3; ++c)      // B, G, R planes of the scanline
-            for (int x = 0; x < width; ++x)
-                dst[(size_t)c * width + x] = src[(size_t)x * 3 + (2 - c)] * scale;
+    out.resize(table_start + (size_t)blocks * 8);
+    std::vector<uint8_t> raw, shuffled, packed;
+    for (int b = 0; b < blocks; ++b) {
+        const int y0 = b * lines, ny = std::min(lines, height - y0);
+        raw.resize(row_bytes * (size_t)ny);
+        for (int r = 0; r < ny; ++r) {
+            float* dst       = reinterpret_cast<float*>(&raw[(size_t)r * row_bytes]);
+            const float* src = rgb + (size_t)(y0 + r) * width * 3;
+            for (int c = 0; c < 3; ++c) // B, G, R planes of the scanline
+                for (int x = 0; x < width; ++x)
+                    dst[(size_t)c * width + x] = src[(size_t)x * 3 + (2 - c)] * scale;
+        }
+        const uint8_t* payload = raw.data();
+        size_t payload_size    = raw.size();
+        if (zip) {
+            const size_t n = raw.size(), half = (n + 1) / 2;
+            shuffled.resize(n);
+            for (size_t i = 0; i < n; ++i) // even bytes first, odd bytes second
+                shuffled[(i & 1) ? half + i / 2 : i / 2] = raw[i];
+            for (size_t i = n - 1; i > 0; --i) // delta predictor, biased by 128
+                shuffled[i] = (uint8_t)((int)shuffled[i] - (int)shuffled[i - 1] + 128 + 256);
+            uLongf len = compressBound((uLong)n);
+            packed.resize(len);
+            if (compress2(packed.data(), &len, shuffled.data(), (uLong)n, Z_DEFAULT_COMPRESSION) != Z_OK)
+                throw std::runtime_error("EXR '" + path + "': deflate failed");
+            if (len < n)
+                payload = packed.data(), payload_size = (size_t)len;
+        }
+        const uint64_t off = out.size();
+        std::memcpy(&out[table_start + (size_t)b * 8], &off, 8);
+        put_i32(y0);
+        put_i32((int32_t)payload_size);
+        put(payload, payload_size);
     }
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f)

@@ -16,6 +16,34 @@ from .device import Device
 from .tables import LoadedScene, save_exr
 
 
+class DenoiserSettings:
+    """RuntimeSettings.h:6-10 (nanobind: src/frontend/python/runtime.cpp:152-156)."""
+
+    def __init__(self):
+        self.Enabled = False
+        self.HighQuality = True
+        self.Prefilter = False
+
+
+# Runtime::hasDenoiser (Runtime.cpp:756): the reference answers with its build flag IG_HAS_DENOISER; here a denoiser is a callable
+# registered once per process, `fn(color, normals, albedo, settings) -> denoised`, all float32 [height, width, 3] with the colour
+# already divided by the iteration count left to the callable (OIDN is handed the accumulated buffers too, extra/OIDN.cpp:103-126).
+_denoiser = None
+
+
+def registerDenoiser(fn):
+    """Installs (or with None removes) the process-wide denoiser the runtimes call after every step, where the reference's
+    build links OpenImageDenoise (extra/OIDN.cpp). This image has no OIDN: the hook is the boundary."""
+    global _denoiser
+    if fn is not None and not callable(fn):
+        raise TypeError("registerDenoiser expects a callable or None")
+    _denoiser = fn
+
+
+def hasDenoiser():
+    return _denoiser is not None
+
+
 class RuntimeOptions:
     """Subset of RuntimeOptions (src/runtime/RuntimeSettings.h:12-59) the hot path consumes."""
 
@@ -30,6 +58,7 @@ class RuntimeOptions:
         # Denoiser.Enabled (RuntimeSettings.h): the runtime then wraps the technique with the info buffer and the device keeps the
         # "Normals" / "Albedo" AOVs (InfoBufferTechnique.cpp, Runtime.cpp:246-264); the denoiser itself (OIDN) is not part of this path
         self.EnableInfoAOVs = False
+        self.Denoiser = DenoiserSettings()
         # tile sharding across devices: this runtime renders rows offset, offset+stride, ...
         self.RowOffset = 0
         self.RowStride = 1
@@ -73,7 +102,13 @@ class Runtime:
         sc = scene.scene
         self._width, self._height = int(sc.film_width), int(sc.film_height)
         self._spi = opts.SPI if opts.SPI > 0 else recommend_spi(self._width, self._height)
-        self._device = Device(opts.Device, opts.AcquireStats, opts.StreamCapacity, info_aovs=opts.EnableInfoAOVs and not opts.IsTracer)
+        # Runtime.cpp:247: lopts.Denoiser.Enabled = !IsTracer && Denoiser.Enabled && hasDenoiser(), with the warning of :260-262
+        self._denoise = bool(opts.Denoiser.Enabled) and not opts.IsTracer and hasDenoiser()
+        if opts.Denoiser.Enabled and not opts.IsTracer and not hasDenoiser():
+            import sys
+            print("[ignis_amd] warning: Trying to use denoiser but no denoiser is available", file=sys.stderr)
+        self._device = Device(opts.Device, opts.AcquireStats, opts.StreamCapacity,
+                              info_aovs=(opts.EnableInfoAOVs or self._denoise) and not opts.IsTracer)
         self._device.assign_scene(scene)
         self._iteration = 0
         self._samples = 0
@@ -110,6 +145,18 @@ class Runtime:
                             seed=self._opts.Seed, row_offset=self._opts.RowOffset, row_stride=self._opts.RowStride)
         self._samples += self._spi
         self._iteration += 1
+        if self._denoise and not ignoreDenoiser:
+            self._runDenoiser()
+
+    # -- OIDN::run on the host route (extra/OIDN.cpp:100-127): colour, "Normals", "Albedo" in, "Denoised" out and uploaded
+    def _runDenoiser(self):
+        color = self._device.framebuffer(None)
+        normals = self._device.framebuffer("Normals")
+        albedo = self._device.framebuffer("Albedo")
+        out = np.ascontiguousarray(_denoiser(color, normals, albedo, self._opts.Denoiser), dtype=np.float32)
+        if out.shape != color.shape:
+            raise ValueError(f"the denoiser returned an image of shape {out.shape}, expected {color.shape}")
+        self._device.upload_framebuffer(out, "Denoised")
 
     # -- several iterations as one wavefront (igd_render_settings.iterations): bit-identical to `count` step() calls, but
     # the launches are `count` times larger — what a small film needs to fill the GPU
@@ -121,6 +168,8 @@ class Runtime:
                             row_offset=self._opts.RowOffset, row_stride=self._opts.RowStride, iterations=count)
         self._samples += self._spi * count
         self._iteration += count
+        if self._denoise:
+            self._runDenoiser()
 
     def recommendedBatch(self):
         """Iterations per call that make a call about as large as a full 1080p iteration at spi 8 (16.6 M camera rays)."""

@@ -129,7 +129,11 @@ int32_t igd_framebuffer_height(const igd_device* dev); /* IRenderDevice::framebu
 /* IRenderDevice::getFramebufferForHost(name, sync) (IRenderDevice.h:53, Device.cpp:1385-1417):
  * float[height][width][3], device -> host copy if dirty; pointer owned by the device, valid
  * until resize/destroy. name NULL or "" = colour buffer; "Normals" / "Albedo" with igd_setup.info_aovs. Returns NULL for
- * unknown AOVs. */
+ * unknown AOVs.
+ * Denoiser hook: with igd_setup.info_aovs the name "Denoised" addresses one more film-sized buffer the device never writes
+ * (allocated zeroed at its first access). The runtime's denoiser reads the colour, "Normals" and "Albedo" buffers, writes its
+ * result there and, on the host route, calls igd_sync_framebuffer_to_device("Denoised") -- exactly the four accessor calls of
+ * extra/OIDN.cpp:103-106,123 (host) and :132-135 (device, OIDN's HIP device type shares the pointers), so OIDN.cpp needs no change. */
 const float* igd_framebuffer_host(igd_device* dev, const char* name, int32_t sync);
 
 /* IRenderDevice::getFramebufferForDevice (IRenderDevice.h:54): device pointer (HBM). */

@@ -41,6 +41,23 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
         Device(0)
 
 
+def test_denoiser_registration_is_host_logic_only():
+    """registerDenoiser / hasDenoiser (Runtime::hasDenoiser, Runtime.cpp:756) and DenoiserSettings' defaults (RuntimeSettings.h:6-10);
+    the render side of the hook is a GPU test."""
+    import ignis_amd
+    assert not ignis_amd.hasDenoiser()
+    d = ignis_amd.RuntimeOptions.makeDefault().Denoiser
+    assert (d.Enabled, d.HighQuality, d.Prefilter) == (False, True, False)
+    with pytest.raises(TypeError):
+        ignis_amd.registerDenoiser(3)
+    ignis_amd.registerDenoiser(lambda c, n, a, s: c)
+    try:
+        assert ignis_amd.hasDenoiser()
+    finally:
+        ignis_amd.registerDenoiser(None)
+    assert not ignis_amd.hasDenoiser()
+
+
 def test_product_does_not_touch_the_oracle():
     """The oracle is test infrastructure: nothing under ignis_amd/ may import, link or load it."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ignis_amd")):
@@ -155,7 +172,9 @@ def test_loader_bitmap_texture_matches_an_independent_png_decode():
 
 
 def _read_exr(path):
-    """Independent reader for the subset igh_save_exr writes: single-part scanline, uncompressed, float channels."""
+    """Independent reader for the subset igh_save_exr writes: single-part scanline, float channels, uncompressed or ZIP
+    (blocks of 16 scanlines: zlib stream -> undo the delta predictor -> interleave the two byte halves)."""
+    import zlib
     import struct
     import numpy as np
     d = open(path, "rb").read()
@@ -182,16 +201,30 @@ def _read_exr(path):
         cp = e + 1 + 16
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
-    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
-    offsets = struct.unpack_from(f"<{h}Q", d, pos)
+    assert attrs["compression"][1] in (b"\0", b"\3") and attrs["lineOrder"][1] == b"\0"
+    lines = 16 if attrs["compression"][1] == b"\3" else 1
+    blocks = (h + lines - 1) // lines
+    offsets = struct.unpack_from(f"<{blocks}Q", d, pos)
     planes = {c: np.zeros((h, w), np.float32) for c, _ in chans}
+    attrs["_stored_bytes"] = 0
     for off in offsets:
         y, size = struct.unpack_from("<ii", d, off)
-        assert size == w * 4 * len(chans)
-        row = np.frombuffer(d, np.float32, w * len(chans), off + 8).reshape(len(chans), w)
+        ny = min(lines, y1 - y + 1)
+        want = w * 4 * len(chans) * ny
+        attrs["_stored_bytes"] += size
+        raw = d[off + 8:off + 8 + size]
+        if size != want:  # a block that did not shrink is stored as is
+            t = np.frombuffer(zlib.decompress(raw), np.uint8)
+            assert t.size == want
+            t = (np.cumsum(t.astype(np.int64) - 128) + 128).astype(np.uint8)  # t[i] = t[i - 1] + d[i] - 128 (mod 256), t[0] = d[0]
+            half = (want + 1) // 2
+            out = np.empty(want, np.uint8)
+            out[0::2], out[1::2] = t[:half], t[half:]
+            raw = out.tobytes()
+        rows = np.frombuffer(raw, np.float32).reshape(ny, len(chans), w)
         for k, (c, t) in enumerate(chans):
             assert t == 2  # FLOAT
-            planes[c][y - y0] = row[k]
+            planes[c][y - y0:y - y0 + ny] = rows[:, k]
     return planes, attrs
 
 
@@ -209,6 +242,26 @@ def test_exr_writer_round_trip(tmp_path):
     assert attrs["igSeed"] == ("string", b"3") and attrs["igTechniqueType"][1] == b"path"
     with pytest.raises(RuntimeError):
         save_exr("/nonexistent_dir/x.exr", img)
+    # a film-like image (smooth, several 16-line blocks and a ragged last one) shrinks and comes back bit for bit, through the
+    # independent reader above and through the loader's own EXR reader; IGH_EXR_COMPRESSION=none keeps the uncompressed form
+    yy, xx = np.mgrid[0:37, 0:50].astype(np.float32)
+    film = np.stack([np.sin(xx * 0.1) + 2, yy * 0.01, np.float32(0.25) * np.ones_like(xx)], -1).astype(np.float32)
+    film[3, 4] = [np.inf, -0.0, 1e-40]
+    save_exr(p, film)
+    planes, attrs = _read_exr(p)
+    assert attrs["compression"][1] == b"\3" and attrs["_stored_bytes"] < film.nbytes // 2
+    for k, c in enumerate("RGB"):
+        np.testing.assert_array_equal(planes[c].view(np.uint32), film[..., k].view(np.uint32))
+    from ignis_amd.tables import read_float_image
+    np.testing.assert_array_equal(read_float_image(p)[..., :3].view(np.uint32), film.view(np.uint32))
+    os.environ["IGH_EXR_COMPRESSION"] = "none"
+    try:
+        save_exr(p, film)
+    finally:
+        del os.environ["IGH_EXR_COMPRESSION"]
+    planes, attrs = _read_exr(p)
+    assert attrs["compression"][1] == b"\0" and attrs["_stored_bytes"] == film.nbytes
+    np.testing.assert_array_equal(planes["G"], film[..., 1])
 
 
 def test_obj_loader_matches_the_same_mesh_as_ply(tmp_path):

@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 
 RADIANCE_TOL = 1e-4  # relative L2, BASELINE.json north_star
 
+def _free_port():
+    """A TCP port nobody listens on right now (two rendezvous tests may run side by side under pytest-xdist)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 
 def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
@@ -933,6 +940,81 @@ def test_info_buffer_aovs_vs_oracle(scene_name, cap):
         plain.close()
 
 
+def test_denoiser_hook_denoised_aov_and_runtime():
+    """The denoiser boundary (extra/OIDN.cpp:100-127, Runtime.cpp:247,334-361): "Denoised" is a film buffer of a device with the info
+    AOVs that only the denoiser writes -- zero at first, kept across renders, uploaded by name, cleared by name and by a resize,
+    refused without the info AOVs; a Runtime with Denoiser.Enabled hands colour / "Normals" / "Albedo" to the registered callable
+    after every step (not with ignoreDenoiser) and the colour buffer is what it is without a denoiser."""
+    import ignis_amd
+    from ignis_amd import Device, DeviceError
+    from ignis_amd.tables import LoadedScene
+    w, h, spi = 64, 48, 4
+    sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), w, h)
+    dev, plain = Device(0, info_aovs=True), Device(0)
+    try:
+        for d in (dev, plain):
+            d.assign_scene(sc)
+            d.resize(w, h)
+            d.render(spi, w, h, iteration=0, seed=4)
+        assert dev.buffer_device_ptr("Denoised")[1] == 0  # nobody asked for it yet: no memory spent
+        assert dev.framebuffer("Denoised").shape == (h, w, 3) and not dev.framebuffer("Denoised").any()
+        assert dev.buffer_device_ptr("Denoised")[1] == w * h * 12 and dev.framebuffer_device_ptr("Denoised")
+        img = np.random.default_rng(2).random((h, w, 3), dtype=np.float32)
+        dev.upload_framebuffer(img, "Denoised")
+        dev.render(spi, w, h, iteration=1, seed=4)
+        plain.render(spi, w, h, iteration=1, seed=4)
+        np.testing.assert_array_equal(dev.framebuffer("Denoised"), img)
+        np.testing.assert_array_equal(dev.framebuffer(), plain.framebuffer())
+        dev.clear_framebuffer("Denoised")
+        assert not dev.framebuffer("Denoised").any() and dev.framebuffer().any()
+        dev.upload_framebuffer(img, "Denoised")
+        dev.resize(w + 8, h)
+        assert dev.framebuffer("Denoised").shape == (h, w + 8, 3) and not dev.framebuffer("Denoised").any()
+        with pytest.raises(DeviceError):
+            plain.framebuffer("Denoised")
+    finally:
+        dev.close()
+        plain.close()
+
+    calls = []
+
+    def box_blur(color, normals, albedo, settings):
+        calls.append((color.copy(), normals.copy(), albedo.copy(), settings.HighQuality))
+        return 0.5 * color + 0.25 * albedo
+
+    opts = ignis_amd.RuntimeOptions.makeDefault()
+    opts.OverrideFilmSize = (w, h)
+    opts.SPI, opts.Seed = spi, 4
+    opts.Denoiser.Enabled = True
+    path = os.path.join(SCENES, "diamond_scene.json")
+    ignis_amd.registerDenoiser(box_blur)
+    try:
+        assert ignis_amd.hasDenoiser()
+        with ignis_amd.loadFromFile(path, opts) as rt, ignis_amd.loadFromFile(path, _without_denoiser(opts)) as ref:
+            rt.step()
+            ref.step()
+            assert len(calls) == 1 and calls[0][3] is True
+            np.testing.assert_array_equal(calls[0][0], ref.getFramebufferForHost())
+            np.testing.assert_array_equal(calls[0][1], rt.getFramebufferForHost("Normals"))
+            assert np.abs(calls[0][1]).sum() > 0 and np.abs(calls[0][2]).sum() > 0
+            np.testing.assert_array_equal(rt.getFramebufferForHost("Denoised"), 0.5 * calls[0][0] + 0.25 * calls[0][2])
+            rt.step(ignoreDenoiser=True)
+            ref.step()
+            assert len(calls) == 1
+            np.testing.assert_array_equal(rt.getFramebufferForHost(), ref.getFramebufferForHost())
+            rt.step()
+            assert len(calls) == 2 and rt.IterationCount == 3
+    finally:
+        ignis_amd.registerDenoiser(None)
+
+
+def _without_denoiser(opts):
+    import copy
+    o = copy.deepcopy(opts)
+    o.Denoiser.Enabled = False
+    return o
+
+
 def test_mesh_area_lights_vs_oracle(gpu_device):
     """Area lights over arbitrary meshes (an emissive icosphere, a planar emitter with "optimize": false) next to the
     planar light of the diamond scene; uniform and hierarchy selectors; hits on the emitters go through the MIS pdf."""
@@ -1062,7 +1144,7 @@ def test_bench_single_rank_through_rccl():
     torch view of the device framebuffer, the gather collective, the max-over-ranks timing — and the same JSON contract."""
     import subprocess
     import sys
-    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(os.path.dirname(SCENES), "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320", "--height", "180",
            "--no-cpu-baseline", "--no-literal-config"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -1460,7 +1542,7 @@ def test_cli_single_rank_through_rccl(tmp_path):
     a, b = str(tmp_path / "plain.exr"), str(tmp_path / "rccl.exr")
     root = os.path.dirname(SCENES)
     subprocess.run(base + ["-o", a], check=True, cwd=root, capture_output=True)
-    env = dict(os.environ, IGNIS_CLI_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, IGNIS_CLI_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(base + ["-o", b, "--gpus", "1"], cwd=root, capture_output=True, env=env, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     pa, _ = _read_exr(a)
