@@ -390,20 +390,25 @@ def test_deep_bvh_spills_the_stack_to_hbm(tmp_path):
         assert tot["max_stack"] > 24  # otherwise this test does not reach the global part
 
 
-@pytest.mark.parametrize("triangles,instances", [(60_000, 24), (1_000_000, 96)])
-def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances):
+@pytest.mark.parametrize("triangles,instances,width,height,spi,iters", [(60_000, 24, 192, 108, 2, 2), (1_000_000, 96, 192, 108, 2, 2),
+                                                                       (1_000_000, 96, 1920, 1080, 1, 1), (16_000_000, None, 1920, 1080, 1, 1)])
+def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances, width, height, spi, iters):
     """SURVEY.md 8d configs 3 / 5 (assets absent): the seeded procedural stand-in — >= 1 M unique triangles, 33
-    materials (diffuse / rough conductor / dielectric / checkerboard), 4 area lights, geometry far beyond L2."""
+    materials (diffuse / rough conductor / dielectric / checkerboard), 4 area lights, geometry far beyond L2. The last case is the
+    film size bench.py --scene runs it at (1920x1080: 2 M camera paths through 160 MB of BVH), hits, counters and radiance
+    against the oracle like the small ones; the very last one is the HBM-regime workload of tools/run_standin.sh itself
+    (16 M unique triangles, 1.6 GB of BVH: profiles/r03_*_standin.*)."""
     from ignis_amd import Device
     from ignis_amd.tables import LoadedScene
     import subprocess, sys
     tool = os.path.join(os.path.dirname(SCENES), "tools", "make_standin_scene.py")
-    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", str(triangles), "--instances", str(instances),
-                    "--seed", "7", "--width", "192", "--height", "108"], check=True, capture_output=True)
-    sc = LoadedScene.from_file(str(tmp_path / "standin.json"), 192, 108)
+    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", str(triangles), "--seed", "7", "--width", str(width), "--height", str(height)]
+                   + (["--instances", str(instances)] if instances else []), check=True, capture_output=True)  # (None: the tool's default, as tools/run_standin.sh)
+    sc = LoadedScene.from_file(str(tmp_path / "standin.json"), width, height)
     dev = Device(0, acquire_stats=True)
-    _compare_with_oracle(dev, sc, 192, 108, 2, seed=7, iters=2)
+    tot = _compare_with_oracle(dev, sc, width, height, spi, seed=7, iters=iters)
     dev.close()
+    assert tot["camera_rays"] == width * height * spi * iters
 
 
 def test_registry_parameters_camera_and_technique(gpu_device):
