@@ -7,8 +7,9 @@ Layout (only what the path needs):
   runtime.py    mirror of the reference's Python `ignis` module API for this path
 """
 from .runtime import (CameraOrientation, DenoiserSettings, Ray, Runtime, RuntimeOptions, hasDenoiser, loadFromFile,  # noqa: F401
-                      loadFromString, registerDenoiser)  # noqa: F401
+                      loadFromScene, loadFromString, registerDenoiser)  # noqa: F401
 from .device import Device, DeviceError, device_count  # noqa: F401
 from .tables import LoadedScene  # noqa: F401
+from .scene import Scene, SceneObject, SceneParser, SceneProperty  # noqa: F401
 
 __version__ = "0.1.0"

@@ -306,3 +306,22 @@ def loadFromString(text, opts=None, dir=""):
     opts = opts or RuntimeOptions.makeDefault()
     w, h = _film_override(opts)
     return Runtime(LoadedScene.from_string(text, str(dir), w, h), opts)
+
+
+def loadFromScene(scene, *args):
+    """ignis.loadFromScene(scene[, dir][, opts]) (runtime.cpp:340-350, Runtime::loadFromScene, Runtime.cpp:219): a scene assembled
+    or edited through ignis_amd.scene.Scene. The one loader of this backend reads JSON, so the scene is lowered to that text."""
+    import json
+    import os
+    from .scene import Scene
+    if not isinstance(scene, Scene):
+        raise TypeError("loadFromScene expects an ignis_amd.Scene")
+    opts, dir = None, ""
+    for a in args:
+        if isinstance(a, RuntimeOptions):
+            opts = a
+        elif isinstance(a, (str, os.PathLike)):
+            dir = os.fspath(a)
+        else:
+            raise TypeError("loadFromScene(scene[, dir][, opts])")
+    return loadFromString(json.dumps(scene.toJSON()), opts, dir)

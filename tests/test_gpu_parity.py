@@ -1020,6 +1020,71 @@ def _without_denoiser(opts):
     return o
 
 
+def test_load_from_scene_matches_the_file_and_builds_from_nothing():
+    """ignis.loadFromScene (runtime.cpp:340-350): a parsed scene renders the image of its file bit for bit; a scene assembled object
+    by object (rectangle + diffuse BSDF + point light, the way scripts/api builds them) equals the same description as JSON;
+    an empty scene steps to a black film (scripts/api/Empty.py)."""
+    import ignis_amd
+    from ignis_amd import Scene, SceneObject, SceneProperty
+    opts = ignis_amd.RuntimeOptions.makeDefault()
+    opts.OverrideFilmSize = (96, 64)
+    opts.SPI, opts.Seed = 4, 6
+    path = os.path.join(SCENES, "many_point_lights.json")
+    with ignis_amd.loadFromFile(path, opts) as a, ignis_amd.loadFromScene(Scene.loadFromFile(path), opts) as b:
+        for rt in (a, b):
+            rt.step()
+            rt.step()
+        assert a.getFramebufferForHost().any()
+        np.testing.assert_array_equal(a.getFramebufferForHost(), b.getFramebufferForHost())
+
+    sc = Scene()
+    cam = SceneObject(SceneObject.Type.Camera, "perspective")
+    cam["fov"] = SceneProperty.fromNumber(40)
+    cam["transform"] = SceneProperty.fromJSON([{"lookat": {"origin": [0, 0, 3], "target": [0, 0, 0], "up": [0, 1, 0]}}])
+    sc.camera = cam
+    tech = SceneObject(SceneObject.Type.Technique, "path")
+    tech["max_depth"] = SceneProperty.fromInteger(4)
+    sc.technique = tech
+    film = SceneObject(SceneObject.Type.Film, "")
+    film["size"] = SceneProperty.fromVector2([96, 64])
+    sc.film = film
+    bsdf = SceneObject(SceneObject.Type.Bsdf, "diffuse")
+    bsdf["reflectance"] = SceneProperty.fromVector3([0.8, 0.4, 0.2])
+    sc.addBSDF("wall", bsdf)
+    shape = SceneObject(SceneObject.Type.Shape, "rectangle")
+    shape["width"], shape["height"] = SceneProperty.fromNumber(2), SceneProperty.fromNumber(1.5)
+    sc.addShape("quad", shape)
+    ent = SceneObject(SceneObject.Type.Entity, "")
+    ent["shape"], ent["bsdf"] = SceneProperty.fromString("quad"), SceneProperty.fromString("wall")
+    ent["transform"] = SceneProperty.fromTransform(np.array([[1, 0, 0, 0.1], [0, 1, 0, 0], [0, 0, 1, -0.5], [0, 0, 0, 1]]))
+    sc.addEntity("Quad", ent)
+    light = SceneObject(SceneObject.Type.Light, "point")
+    light["position"], light["intensity"] = SceneProperty.fromVector3([0.3, 0.4, 1.5]), SceneProperty.fromVector3([5, 5, 5])
+    sc.addLight("lamp", light)
+    sc.addConstantEnvLight()
+    text = json.dumps({
+        "technique": {"type": "path", "max_depth": 4},
+        "camera": {"type": "perspective", "fov": 40.0, "transform": [{"lookat": {"origin": [0, 0, 3], "target": [0, 0, 0], "up": [0, 1, 0]}}]},
+        "film": {"size": [96, 64]},
+        "bsdfs": [{"type": "diffuse", "name": "wall", "reflectance": [0.8, 0.4, 0.2]}],
+        "shapes": [{"type": "rectangle", "name": "quad", "width": 2.0, "height": 1.5}],
+        "entities": [{"name": "Quad", "shape": "quad", "bsdf": "wall", "transform": [1, 0, 0, 0.1, 0, 1, 0, 0, 0, 0, 1, -0.5, 0, 0, 0, 1]}],
+        "lights": [{"type": "point", "name": "lamp", "position": [0.3, 0.4, 1.5], "intensity": [5, 5, 5]},
+                   {"type": "constant", "name": "__env", "radiance": 1.0}]})
+    with ignis_amd.loadFromScene(sc, "", opts) as a, ignis_amd.loadFromString(text, opts) as b:
+        for rt in (a, b):
+            rt.step()
+        img = a.getFramebufferForHost()
+        assert img.any() and np.isfinite(img).all()
+        assert not np.array_equal(img[32, 48], img[1, 1])  # the quad in the middle, the environment in the corner
+        np.testing.assert_array_equal(img, b.getFramebufferForHost())
+
+    with ignis_amd.loadFromScene(Scene(), opts) as rt:
+        while rt.SampleCount < 16:
+            rt.step()
+        assert rt.IterationCount == 4 and not rt.getFramebufferForHost().any()
+
+
 def test_mesh_area_lights_vs_oracle(gpu_device):
     """Area lights over arbitrary meshes (an emissive icosphere, a planar emitter with "optimize": false) next to the
     planar light of the diamond scene; uniform and hierarchy selectors; hits on the emitters go through the MIS pdf."""
