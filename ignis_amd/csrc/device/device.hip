@@ -215,6 +215,14 @@ struct igd_device {
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     int tail_split = 6;
+    // A wave of the tail kernel costs 62 ns to launch whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty
+    // passes with 256 / 1 024 / 3 072 waves, workgroups of one or four waves alike). Pass j of a chunk gets as many waves as twice the
+    // paths that pass j of the last collected chunk started with, scaled by the sizes of the two tails (one path per wave there,
+    // tail.hip). On diamond_scene a pass keeps 55 % of its paths, so only the passes after the last bounce (depth 64: two of eleven)
+    // shrink; scenes whose paths end early save more. Only the launch size depends on the guess: a pass that gets too few waves
+    // refills them from its counter. IGD_TAIL_ADAPT=0: full grids; IGD_TAIL_DEBUG=1 prints the sizes.
+    bool tail_adapt           = true;
+    double tail_share[24]     = {}; // paths at the start of pass j / paths at the start of pass 0, last collected chunk; [0] == 0: unknown
     // Wavefront rounds that continue on the side stream before the per-lane tail takes over: -1 = as many as it
     // takes to get from the hand-over size to ~8 K paths at the usual survival rate, 0 = none (default: measured
     // 3 % to 10 % slower than handing over directly, the small launches disturb the main stream more than the
@@ -861,6 +869,7 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t i = 0; i < s->infinite_light_count; ++i)
         d->full_bsdfs |= s->lights[i].type == IG_LIGHT_ENV_TEXTURED || s->lights[i].type == IG_LIGHT_SUN || s->lights[i].type == IG_LIGHT_CIE || s->lights[i].type == IG_LIGHT_PEREZ;
     d->has_scene            = true;
+    d->tail_share[0]        = 0; // (another scene: its tails decay at their own rate)
 }
 
 // Device-memory clears go through the render stream and are waited for: the render streams are non-blocking, i.e. not ordered
@@ -933,6 +942,9 @@ void collect(igd_device* d, igd_device::Flight& f)
     d->stats.shadow_rays += q.shadow_rays;
     d->stats.unoccluded += q.unoccluded;
     d->stats.tail_rays += q.tail_rays;
+    if (q.tail_pass_in[0]) // (a chunk without a tail leaves the table as it is)
+        for (int j = 0; j < 24; ++j)
+            d->tail_share[j] = (double)q.tail_pass_in[j] / (double)q.tail_pass_in[0];
     d->noteDeep(q.deep_total, q.camera_rays + q.bounce_rays + q.shadow_rays);
     d->stats.nodes_primary += q.nodes[0], d->stats.nodes_secondary += q.nodes[1];
     d->stats.tris_primary += q.tris[0], d->stats.tris_secondary += q.tris[1];
@@ -1599,6 +1611,13 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.work_counter = fl.tail_ctr.ptr + 2 * j + 1;
                     p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
                     p.count_paths  = j == 0;
+                    p.pass         = j;
+                    int pass_grid  = tail_grid;
+                    if (d->tail_adapt && j > 0 && d->tail_share[0] > 0)
+                        pass_grid = std::max(64, std::min(tail_grid, (int)std::ceil(2.0 * d->tail_share[j] * (double)live)));
+                    static const bool tail_debug = std::getenv("IGD_TAIL_DEBUG") != nullptr;
+                    if (tail_debug)
+                        std::fprintf(stderr, "[tail] pass %d: share %.6f live %llu grid %d of %d\n", j, d->tail_share[j], (unsigned long long)live, pass_grid, tail_grid);
                     if (d->tail_wavefront && !d->full_bsdfs) { // the experimental wave-local kernel exists in the lean variant only
                         // every wave gets a slice of the pass's input; the grid covers the upper bound `live`
                         p.work[0] = igd_device::colsAt(fl.tail_work[0].ptr, fl.tail_capacity);
@@ -1614,7 +1633,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                         p.slice = slice;
                         launch_tail_wave(p, counters, (int)((live + slice - 1) / slice), side);
                     } else {
-                        launch_tail(p, counters, d->full_bsdfs, tail_grid, side);
+                        launch_tail(p, counters, d->full_bsdfs, pass_grid, side);
                     }
                 }
             });
@@ -1964,6 +1983,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->side_rounds = std::atoi(e);
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_TAIL_ADAPT"))
+            d->tail_adapt = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_ASYNC_TAIL"))
             d->async_tail = std::atoi(e) != 0;
         dev = d.release();

@@ -114,6 +114,7 @@ struct QueueState {
     unsigned long long camera_rays, bounce_rays, shadow_rays, unoccluded;
     unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches
     unsigned long long section_passes[6], section_lanes[6]; // igd_stats: wave-level section executions and the lanes with work in them
+    uint32_t tail_pass_in[24]; // paths each pass of the chunk's tail started with (tail.hip): the host sizes the next chunk's passes by them
 };
 
 struct TraverseArgs {
@@ -240,6 +241,7 @@ struct TailArgs {
     PrimaryCols out;
     uint32_t* out_count;
     int32_t count_paths; // add the input size to qs->tail_rays
+    int32_t pass;        // index of this pass (qs->tail_pass_in)
     uint32_t deep_lane_base; // first deep-stack column of this launch's lanes
     // k_tail_wave: every wave owns `slice` consecutive paths of `in` and runs bounce rounds over them in its private
     // regions [wave * slice, (wave + 1) * slice) of work[0] / work[1] (continuation rays) and sec (shadow rays)

@@ -24,17 +24,27 @@ namespace igdev {
 #define IG_TAIL_OCC 3 // waves per SIMD the tail kernels are built for (168 VGPRs)
 #endif
 constexpr int kTailThreads = 64;
+#ifndef IG_TAIL_BLOCK
+#define IG_TAIL_BLOCK 64 // threads per workgroup of k_tail (its waves never meet: no barrier, LDS rows by thread)
+#endif
+constexpr int kTailBlock = IG_TAIL_BLOCK;
+#ifndef IG_TAIL_STATIC_FIRST
+#define IG_TAIL_STATIC_FIRST 1 // a wave's first paths by position (no atomic), the counter only for refills
+#endif
+#ifndef IG_TAIL_SPREAD
+#define IG_TAIL_SPREAD 1 // late passes: n / waves paths per wave instead of 64 (0: the first n / 64 waves take everything)
+#endif
 
 template <bool STATS, bool FULL>
-__global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailArgs a)
+__global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs a)
 {
-    __shared__ StackOf<kTailThreads> s_stack;
+    __shared__ StackOf<kTailBlock> s_stack;
 
     const int tid      = threadIdx.x;
     const int lane     = tid & 63;
     const DevScene& sc = a.scene;
     const uint32_t n   = *a.in_count;
-    uint2* deep_col    = sc.deep_stack + (a.deep_lane_base + blockIdx.x * kTailThreads + tid);
+    uint2* deep_col    = sc.deep_stack + (a.deep_lane_base + blockIdx.x * kTailBlock + tid);
 
     uint32_t c_bounce = 0, c_shadow = 0, c_unoccluded = 0;
     uint32_t c_nodes[2] = { 0, 0 }, c_tris[2] = { 0, 0 }, c_leaves[2] = { 0, 0 };
@@ -51,18 +61,37 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
     bool exhausted = false;
     int hops       = 0; // bounces this lane has followed its current path for
 
+    // Few paths, many waves (the late passes: 20 000 paths, then 3 000, ... for the 3 072 resident waves): a wave takes its share of
+    // the pass, n / waves paths at a time, instead of 64 -- the traversal sections and the shading branches are wave-uniform, so a
+    // wave with three paths in flight finishes a bounce in a fraction of the time of a full one, and what a pass costs is the
+    // serial chain of its longest path. Which wave follows a path changes nothing about the path (its accumulator slot is its own).
+    const uint32_t waves      = gridDim.x * (uint32_t)(kTailBlock / 64), wave_id = blockIdx.x * (uint32_t)(kTailBlock / 64) + (uint32_t)(tid >> 6);
+    const int cap             = IG_TAIL_SPREAD ? (int)min(64u, max(1u, (n + waves - 1) / waves)) : 64;
+    const uint32_t handed_out = waves * (uint32_t)cap; // paths the waves take by position, before the counter
+    bool first                = true;
+
     for (;;) {
         const unsigned long long idle = __ballot(!have);
-        if (idle && !exhausted) {
-            const int n_idle = __popcll(idle);
-            uint32_t base    = 0;
-            if (lane == 0)
-                base = atomicAdd(a.work_counter, (uint32_t)n_idle);
-            base = __shfl(base, 0);
-            if (base + (uint32_t)n_idle >= n)
-                exhausted = true;
-            const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!have && i < n) {
+        const int n_idle              = __popcll(idle);
+        const int want                = cap - (64 - n_idle); // paths this wave may add to the ones it follows
+        if (want > 0 && !exhausted) {
+            // The first `cap` paths of a wave are the wave's by position: no counter, so a pass that fits the grid (every late one)
+            // runs without a single atomic.
+            uint32_t base = wave_id * (uint32_t)cap;
+            if (IG_TAIL_STATIC_FIRST && first) {
+                first = false;
+                if (handed_out >= n)
+                    exhausted = true;
+            } else {
+                if (lane == 0)
+                    base = atomicAdd(a.work_counter, (uint32_t)want);
+                base = __shfl(base, 0) + (IG_TAIL_STATIC_FIRST ? handed_out : 0u);
+                if (base + (uint32_t)want >= n)
+                    exhausted = true;
+            }
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t i    = base + rank;
+            if (!have && rank < (uint32_t)want && i < n) {
                 have            = true;
                 const float4 ra = a.in.rayA[i], rb = a.in.rayB[i], pay = a.in.pay[i];
                 const int4 meta = a.in.meta[i];
@@ -85,7 +114,7 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
 
         if (have) {
             {
-                Traverser<false, STATS, kTailThreads, true> tr;
+                Traverser<false, STATS, kTailBlock, true> tr;
                 tr.init_counters();
                 tr.attach_deep(deep_col, sc.deep_stride);
                 tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
@@ -102,7 +131,7 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
                 }
                 if (sc.sphere_node_count) {
                     // the sphere geometry, from the hit so far (traverse.hip launches it as a second pass)
-                    Traverser<false, STATS, kTailThreads, false, true> tp;
+                    Traverser<false, STATS, kTailBlock, false, true> tp;
                     tp.init_counters();
                     tp.begin(sc, s_stack, tid, in.org, in.dir, tmin, in.t, flags);
                     tp.set_initial_hit(in.ent, in.prim, in.u, in.v);
@@ -129,7 +158,7 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
 
             if (out.shadow) {
                 ++c_shadow;
-                Traverser<true, STATS, kTailThreads, true> ts;
+                Traverser<true, STATS, kTailBlock, true> ts;
                 ts.init_counters();
                 ts.attach_deep(deep_col, sc.deep_stride);
                 ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
@@ -143,7 +172,7 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
                 }
                 bool occluded = ts.hit_prim >= 0;
                 if (sc.sphere_node_count) {
-                    Traverser<true, STATS, kTailThreads, false, true> tq;
+                    Traverser<true, STATS, kTailBlock, false, true> tq;
                     tq.init_counters();
                     tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
                     tq.set_initial_hit(ts.hit_ent, ts.hit_prim, 0, 0);
@@ -224,8 +253,11 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail(const TailAr
             }
         }
     }
-    if (a.count_paths && blockIdx.x == 0 && tid == 0)
-        a.qs->tail_rays += n;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (a.count_paths)
+            a.qs->tail_rays += n;
+        a.qs->tail_pass_in[a.pass] = n;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -472,7 +504,7 @@ template __global__ void k_tail<true, true>(const TailArgs);
 
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream)
 {
-    const dim3 grid((unsigned)grid_blocks), block(kTailThreads);
+    const dim3 grid((unsigned)((grid_blocks + kTailBlock / 64 - 1) / (kTailBlock / 64))), block(kTailBlock); // grid_blocks counts waves
     if (full_bsdfs) {
         if (stats)
             hipLaunchKernelGGL((k_tail<true, true>), grid, block, 0, stream, args);
