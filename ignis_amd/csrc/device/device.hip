@@ -222,6 +222,7 @@ struct igd_device {
     // shrink; scenes whose paths end early save more. Only the launch size depends on the guess: a pass that gets too few waves
     // refills them from its counter. IGD_TAIL_ADAPT=0: full grids; IGD_TAIL_DEBUG=1 prints the sizes.
     bool tail_adapt           = true;
+    double tail_density       = 0.5; // expected paths per launched wave of a pass after the first (IGD_TAIL_DENSITY)
     double tail_share[24]     = {}; // paths at the start of pass j / paths at the start of pass 0, last collected chunk; [0] == 0: unknown
     // Wavefront rounds that continue on the side stream before the per-lane tail takes over: -1 = as many as it
     // takes to get from the hand-over size to ~8 K paths at the usual survival rate, 0 = none (default: measured
@@ -1614,7 +1615,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.pass         = j;
                     int pass_grid  = tail_grid;
                     if (d->tail_adapt && j > 0 && d->tail_share[0] > 0)
-                        pass_grid = std::max(64, std::min(tail_grid, (int)std::ceil(2.0 * d->tail_share[j] * (double)live)));
+                        pass_grid = std::max(64, std::min(tail_grid, (int)std::ceil(d->tail_share[j] * (double)live / d->tail_density)));
                     static const bool tail_debug = std::getenv("IGD_TAIL_DEBUG") != nullptr;
                     if (tail_debug)
                         std::fprintf(stderr, "[tail] pass %d: share %.6f live %llu grid %d of %d\n", j, d->tail_share[j], (unsigned long long)live, pass_grid, tail_grid);
@@ -1985,6 +1986,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_split = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_ADAPT"))
             d->tail_adapt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("IGD_TAIL_DENSITY"))
+            d->tail_density = std::min(64.0, std::max(0.125, std::atof(e)));
         if (const char* e = std::getenv("IGD_ASYNC_TAIL"))
             d->async_tail = std::atoi(e) != 0;
         dev = d.release();
