@@ -215,8 +215,9 @@ struct igd_device {
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     int tail_split = 6;
-    // A wave of the tail kernel costs 62 ns to launch whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty
-    // passes with 256 / 1 024 / 3 072 waves, workgroups of one or four waves alike). Pass j of a chunk gets as many waves as twice the
+    // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
+    // with 256 / 1 024 / 3 072 waves, workgroups of one or four waves alike; a bare launch of that shape costs 1 ns per wave,
+    // tools/launch_cost.hip, so the kernel spends it -- where is open). Pass j of a chunk gets as many waves as twice the
     // paths that pass j of the last collected chunk started with, scaled by the sizes of the two tails (one path per wave there,
     // tail.hip). On diamond_scene a pass keeps 55 % of its paths, so only the passes after the last bounce (depth 64: two of eleven)
     // shrink; scenes whose paths end early save more. Only the launch size depends on the guess: a pass that gets too few waves
@@ -1944,8 +1945,11 @@ igd_device* igd_create(const igd_setup* setup)
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             if (const char* e = std::getenv("IGD_FLIGHTS"))
                 d->n_flights = std::min(igd_device::kMaxFlights, std::max(2, std::atoi(e)));
+            int prio = lo;
+            if (const char* e = std::getenv("IGD_SIDE_PRIORITY")) // "normal" / "high": experiments (the tail's launch rate under a low-priority queue)
+                prio = std::strcmp(e, "high") == 0 ? hi : std::strcmp(e, "normal") == 0 ? (lo + hi) / 2 : lo;
             for (int k = 0; k < d->n_flights; ++k)
-                HIP_CHECK(hipStreamCreateWithPriority(&d->side[k], hipStreamNonBlocking, lo));
+                HIP_CHECK(hipStreamCreateWithPriority(&d->side[k], hipStreamNonBlocking, prio));
         }
         constexpr int F = igd_device::kMaxFlights;
         d->qs_store.alloc(F);
