@@ -69,6 +69,15 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
     const int cap             = IG_TAIL_SPREAD ? (int)min(64u, max(1u, (n + waves - 1) / waves)) : 64;
     const uint32_t handed_out = waves * (uint32_t)cap; // paths the waves take by position, before the counter
     bool first                = true;
+    if (IG_TAIL_STATIC_FIRST && handed_out >= n && wave_id * (uint32_t)cap >= n) {
+        // nothing by position and nothing to refill from: this wave has no part in the pass
+        if (blockIdx.x == 0 && tid == 0) {
+            if (a.count_paths)
+                a.qs->tail_rays += n;
+            a.qs->tail_pass_in[a.pass] = n;
+        }
+        return;
+    }
 
     for (;;) {
         const unsigned long long idle = __ballot(!have);
