@@ -49,6 +49,17 @@ __global__ void __launch_bounds__(64) k_scratch(const unsigned* count, unsigned*
     }
 }
 
+// the same, but every wave really stores to and loads from its scratch (an idle k_tail wave walks past spill code)
+__global__ void __launch_bounds__(64) k_scratch_touch(const unsigned* count, unsigned* out)
+{
+    volatile unsigned priv[24];
+    const unsigned n = *count;
+    for (int i = 0; i < 24; ++i)
+        priv[i] = i + n;
+    if (priv[(n + threadIdx.x) % 24] == 0xFFFFFFFFu)
+        out[threadIdx.x] = 1;
+}
+
 __global__ void __launch_bounds__(64, 3) k_regs(const unsigned* count, unsigned* out) // 3 waves per SIMD -> a 168-register allocation
 {
     if (*count) {
@@ -122,6 +133,7 @@ int main()
     measure("plain, 1 wave / workgroup", 64, [&](int g) { hipLaunchKernelGGL(k_plain, dim3(g), dim3(64), 0, 0, count, out); });
     measure("10 KiB LDS per wave", 64, [&](int g) { hipLaunchKernelGGL(k_lds<64>, dim3(g), dim3(64), 0, 0, count, out); });
     measure("scratch", 64, [&](int g) { hipLaunchKernelGGL(k_scratch, dim3(g), dim3(64), 0, 0, count, out); });
+    measure("scratch, touched by every wave", 64, [&](int g) { hipLaunchKernelGGL(k_scratch_touch, dim3(g), dim3(64), 0, 0, count, out); });
     measure("168 registers", 64, [&](int g) { hipLaunchKernelGGL(k_regs, dim3(g), dim3(64), 0, 0, count, out); });
     measure("LDS + scratch + registers (k_tail)", 64, [&](int g) { hipLaunchKernelGGL(k_all<64>, dim3(g), dim3(64), 0, 0, count, out); });
     measure("the same, 4 waves / workgroup", 256, [&](int g) { hipLaunchKernelGGL(k_all<256>, dim3(g), dim3(256), 0, 0, count, out); });
