@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 tr.init_counters();
                 tr.attach_deep(deep_col, sc.deep_stride);
                 tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
-                while (!tr.finished)
+                while (!tr.finished())
                     tr.step(sc, s_stack, tid);
                 in.ent  = tr.hit_ent;
                 in.prim = tr.hit_prim;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                     tp.init_counters();
                     tp.begin(sc, s_stack, tid, in.org, in.dir, tmin, in.t, flags);
                     tp.set_initial_hit(in.ent, in.prim, in.u, in.v);
-                    while (!tp.finished)
+                    while (!tp.finished())
                         tp.step(sc, s_stack, tid);
                     in.ent  = tp.hit_ent;
                     in.prim = tp.hit_prim;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 ts.init_counters();
                 ts.attach_deep(deep_col, sc.deep_stride);
                 ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
-                while (!ts.finished)
+                while (!ts.finished())
                     ts.step(sc, s_stack, tid);
                 overflow |= ts.overflow;
                 if (STATS) {
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                     tq.init_counters();
                     tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
                     tq.set_initial_hit(ts.hit_ent, ts.hit_prim, 0, 0);
-                    while (!tq.finished)
+                    while (!tq.finished())
                         tq.step(sc, s_stack, tid);
                     occluded = tq.hit_prim >= 0;
                     overflow |= tq.overflow;
@@ -315,7 +315,7 @@ IG_DEV void traverse_slice(const DevScene& sc, StackOf<kTailThreads>& stack, int
         }
         if (has) {
             tr.step(sc, stack, tid);
-            if (tr.finished) {
+            if (tr.finished()) {
                 has = false;
                 overflow |= tr.overflow;
                 done(tr, idx);

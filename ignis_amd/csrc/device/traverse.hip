@@ -17,18 +17,6 @@ namespace igdev {
 #endif
 constexpr int kRefillIdleClosest = IG_REFILL_IDLE;     // refill when at least this many lanes of a wave are idle
 constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit launches (shorter rays)
-#ifndef IG_ATOMIC_SPLAT
-#define IG_ATOMIC_SPLAT 0
-#endif
-#ifndef IG_EARLY_SPLAT
-#define IG_EARLY_SPLAT 1
-#endif
-#ifndef IG_EARLY_ACCUM
-#define IG_EARLY_ACCUM 0
-#endif
-constexpr bool kEarlyAccum  = IG_EARLY_ACCUM != 0;  // any hit: the accumulator slot is read with the ray as well
-constexpr bool kAtomicSplat = IG_ATOMIC_SPLAT != 0; // sums into the per-sample accumulators as no-return float atomics
-constexpr bool kEarlySplat  = IG_EARLY_SPLAT != 0;  // any hit: the colour of a shadow ray is loaded with the ray
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false>
@@ -56,8 +44,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     bool has_ray          = false;
     uint32_t ray_idx      = 0;
     uint32_t st_unoccluded = 0;
-    float4 splat          = any_float4(); // any hit: the shadow ray's colour and slot, fetched with the ray (kEarlySplat)
-    float4 slot_value     = any_float4(); // ... and what the slot holds (kEarlyAccum)
+    float4 splat; // any hit: the shadow ray's colour and slot, fetched with the ray (one round trip per refill instead of one per finished lane)
     uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
     bool fatal = false;
 
@@ -104,29 +91,23 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
                              a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
                 }
-                if (ANY_HIT && kEarlySplat && a.accum) {
+                if (ANY_HIT && a.accum)
                     splat = a.col[idx];
-                    // ... and the accumulator slot it may be added to (the slot is this ray's alone for the length of the launch): one more
-                    // round trip per refill, shared by all the rays of the refill, instead of one per pass in which a lane finishes
-                    if (kEarlyAccum && !a.atomic_splat)
-                        slot_value = a.accum[(int64_t)(int32_t)igm_bits(splat.w) - a.id_base];
-                }
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
             batch_next += take;
         }
-        // (no `continue` for the wave that got no ray out of a refill: a second back edge made the compiler rotate the ~30 state
-        // registers through copies at the end of every pass; an empty step() costs one settle body and happens once per launch)
+        // (no `continue` for the wave that got no ray out of a refill: a second back edge makes the compiler rotate the loop-carried
+        // state registers through copies at the end of every pass; an empty step() costs three ballots and happens once per launch)
         if (!__any(has_ray) && exhausted && batch_next >= batch_end)
             break;
 
-        // every lane steps: a lane without a ray is `finished` in mode 0, which no section of step() acts on. (Wrapping the call
-        // in `if (has_ray)` made the compiler copy the whole traversal state at the merge, ~35 v_mov per pass.)
+        // every lane steps: a lane without a ray is in kDone, which no section of step() acts on
         tr.mark(5); // refill: batch reservation, ray loads, begin()
         tr.step(a.scene, s_stack, tid);
         if (has_ray) {
-            if (tr.finished && tr.overflow) {
+            if (tr.finished() && tr.overflow) {
                 has_ray = false;
                 if (DEEP || SPHERES) {
                     fatal = true; // deeper than LDS + global part together
@@ -136,7 +117,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     if (STATS)
                         tr.st_nodes = snap_nodes, tr.st_tris = snap_tris, tr.st_leaves = snap_leaves;
                 }
-            } else if (tr.finished) {
+            } else if (tr.finished()) {
                 has_ray = false;
                 if (ANY_HIT) {
                     if (a.hit)
@@ -145,22 +126,20 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                         if (STATS)
                             ++st_unoccluded;
                         if (a.accum) {
-                            // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample
-                            // accumulator: plain read-modify-write, the slot is owned by this ray.
-                            // The colour came with the ray and the sums are no-return float atomics performed in L2 (the slot is owned by
-                            // this ray, so the sum is the read-modify-write's): a finished lane costs its wave no round trip. As a load of
-                            // the colour, a dependent load of the slot and a store, each event held the whole wave for two HBM latencies,
-                            // in order in front of its next node loads (waves waiting 63 %, VALU issue 0.65, profiles/r03_rocprofv3_pmc.txt).
-                            const float4 c = kEarlySplat ? splat : a.col[ray_idx];
+                            // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample accumulator: a plain
+                            // read-modify-write, the slot is owned by this ray's sample for the length of the launch. The colour came
+                            // with the ray. (No-return float atomics instead are bit-identical but slower: the epilogue +25 %,
+                            // profiles/r03_experiment_shade.txt.)
+                            const float4 c = splat;
                             float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
                             // (the light tracer's connections, on_advanced_shadow_miss, technique/lighttracer.art:116-120, add into the
                             // slots of one pixel from many paths: atomics for correctness there)
-                            if (kAtomicSplat || a.atomic_splat) {
+                            if (a.atomic_splat) {
                                 unsafeAtomicAdd(&dst->x, c.x * a.inv_spi);
                                 unsafeAtomicAdd(&dst->y, c.y * a.inv_spi);
                                 unsafeAtomicAdd(&dst->z, c.z * a.inv_spi);
                             } else {
-                                float4 v = (kEarlySplat && kEarlyAccum) ? slot_value : *dst;
+                                float4 v = *dst;
                                 v.x += c.x * a.inv_spi;
                                 v.y += c.y * a.inv_spi;
                                 v.z += c.z * a.inv_spi;
@@ -168,17 +147,11 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             }
                             if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
                                 float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                                if (kAtomicSplat) {
-                                    unsafeAtomicAdd(&nd->x, c.x * a.inv_spi);
-                                    unsafeAtomicAdd(&nd->y, c.y * a.inv_spi);
-                                    unsafeAtomicAdd(&nd->z, c.z * a.inv_spi);
-                                } else {
-                                    float4 w = *nd;
-                                    w.x += c.x * a.inv_spi;
-                                    w.y += c.y * a.inv_spi;
-                                    w.z += c.z * a.inv_spi;
-                                    *nd = w;
-                                }
+                                float4 w   = *nd;
+                                w.x += c.x * a.inv_spi;
+                                w.y += c.y * a.inv_spi;
+                                w.z += c.z * a.inv_spi;
+                                *nd = w;
                             }
                         }
                     }
@@ -207,9 +180,12 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             atomicAdd(&a.qs->leaves[ANY_HIT], (unsigned long long)l);
             if (ANY_HIT)
                 atomicAdd(&a.qs->unoccluded, (unsigned long long)uo);
-            for (int k = 0; k < 3; ++k) {
-                atomicAdd(&a.qs->section_passes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)tr.sec_pass[k]);
-                atomicAdd(&a.qs->section_lanes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)tr.sec_lane[k]);
+        }
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t p = wave_sum_u32(tr.sec_pass[k]), q = wave_sum_u32(tr.sec_lane[k]);
+            if (lane == 0) {
+                atomicAdd(&a.qs->section_passes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)p);
+                atomicAdd(&a.qs->section_lanes[(ANY_HIT ? 3 : 0) + k], (unsigned long long)q);
             }
         }
     }
