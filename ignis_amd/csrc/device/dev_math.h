@@ -150,9 +150,13 @@ IG_DEV bool tri_test(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f3 e2,
     return true;
 }
 
-// The same test without branches, for predicated callers (traverse_core.h): every lane computes all of it, the result
-// counts only where the returned flag is set. Identical arithmetic, hence identical t / u / v where it is.
-IG_DEV bool tri_test_flat(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f3 e2, f3 n, float& t_out, float& u_out, float& v_out)
+// The same test in two parts, for callers that test under a lane mask (traverse_core.h): the first part is arithmetic every lane
+// of the region runs (identical operations, hence identical t / u / v where the test passes); the division and the three products
+// of the second part are run by the lanes that hit only.
+struct TriCandidate {
+    float t, u, v, adet; // not yet divided by |det|
+};
+IG_DEV bool tri_test_candidate(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f3 e2, f3 n, TriCandidate& c_out)
 {
     const f3 c         = v0 - r.org;
     const f3 rr        = cross3(c, r.dir);
@@ -162,12 +166,15 @@ IG_DEV bool tri_test_flat(const RayT& r, float tmin, float tmax, f3 v0, f3 e1, f
     const float u      = igm_float(igm_bits(dot3(rr, e1)) ^ sgn);
     const float v      = igm_float(igm_bits(dot3(rr, e2)) ^ sgn);
     const float t      = igm_float(igm_bits(dot3(c, n)) ^ sgn);
-    const bool ok      = (u >= 0) & (v >= 0) & (u + v <= adet) & (det != 0) & (t >= adet * tmin) & (t <= adet * tmax);
-    const float rcp    = 1 / adet;
-    t_out              = t * rcp;
-    u_out              = igm_max(u * rcp, 0.0f);
-    v_out              = igm_max(v * rcp, 0.0f);
-    return ok;
+    c_out              = TriCandidate{ t, u, v, adet };
+    return (u >= 0) & (v >= 0) & (u + v <= adet) & (det != 0) & (t >= adet * tmin) & (t <= adet * tmax);
+}
+IG_DEV void tri_test_finish(const TriCandidate& c, float& t_out, float& u_out, float& v_out)
+{
+    const float rcp = 1 / c.adet;
+    t_out           = c.t * rcp;
+    u_out           = igm_max(c.u * rcp, 0.0f);
+    v_out           = igm_max(c.v * rcp, 0.0f);
 }
 
 } // namespace igdev

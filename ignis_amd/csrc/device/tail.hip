@@ -121,87 +121,109 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         if (!__any(have))
             break;
 
-        if (have) {
-            {
-                Traverser<false, STATS, kTailBlock, true> tr;
-                tr.init_counters();
-                tr.attach_deep(deep_col, sc.deep_stride);
-                tr.begin(sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
-                while (!tr.finished())
-                    tr.step(sc, s_stack, tid);
+        // (the traversals are called by the whole wave with the mask of the lanes that take part, traverse_core.h; shading sits under `have`)
+        const mask_t have_m = lanes_where(have);
+        {
+            Traverser<false, STATS, kTailBlock, true> tr;
+            tr.init_counters();
+            tr.attach_deep(deep_col, sc.deep_stride);
+            tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
+            while (tr.active())
+                tr.step(sc, s_stack, tid);
+            if (have) {
                 in.ent  = tr.hit_ent;
                 in.prim = tr.hit_prim;
                 in.t = tr.tmax, in.u = tr.hit_u, in.v = tr.hit_v;
-                overflow |= tr.overflow;
+                overflow |= tr.overflowed();
                 if (STATS) {
                     c_nodes[0] += tr.st_nodes;
                     c_tris[0] += tr.st_tris;
                     c_leaves[0] += tr.st_leaves;
                 }
-                if (sc.sphere_node_count) {
-                    // the sphere geometry, from the hit so far (traverse.hip launches it as a second pass)
-                    Traverser<false, STATS, kTailBlock, false, true> tp;
-                    tp.init_counters();
-                    tp.begin(sc, s_stack, tid, in.org, in.dir, tmin, in.t, flags);
-                    tp.set_initial_hit(in.ent, in.prim, in.u, in.v);
-                    while (!tp.finished())
-                        tp.step(sc, s_stack, tid);
+            }
+            region_end();
+            if (sc.sphere_node_count) {
+                // the sphere geometry, from the hit so far (traverse.hip launches it as a second pass)
+                Traverser<false, STATS, kTailBlock, false, true> tp;
+                tp.init_counters();
+                tp.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, in.t, flags);
+                tp.set_initial_hit(have_m, in.ent, in.prim, in.u, in.v);
+                while (tp.active())
+                    tp.step(sc, s_stack, tid);
+                if (have) {
                     in.ent  = tp.hit_ent;
                     in.prim = tp.hit_prim;
                     in.t = tp.tmax, in.u = tp.hit_u, in.v = tp.hit_v;
-                    overflow |= tp.overflow;
+                    overflow |= tp.overflowed();
                     if (STATS) {
                         c_nodes[0] += tp.st_nodes;
                         c_leaves[0] += tp.st_leaves;
                     }
                 }
+                region_end();
             }
+        }
 
-            PathVertexOut out;
+        PathVertexOut out;
+        out.shadow = out.bounce = out.has_radiance = false;
+        if (have) {
             shade_vertex<FULL>(sc, a.frame, in, out);
             if (out.has_radiance) {
                 acc.x += out.radiance.r * a.inv_spi;
                 acc.y += out.radiance.g * a.inv_spi;
                 acc.z += out.radiance.b * a.inv_spi;
             }
+        }
+        region_end();
 
-            if (out.shadow) {
+        const bool shadow     = have && out.shadow;
+        const mask_t shadow_m = lanes_where(shadow);
+        if (shadow_m) {
+            const uint32_t sflags = sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW;
+            Traverser<true, STATS, kTailBlock, true> ts;
+            ts.init_counters();
+            ts.attach_deep(deep_col, sc.deep_stride);
+            ts.begin(shadow_m, sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sflags);
+            while (ts.active())
+                ts.step(sc, s_stack, tid);
+            bool occluded = ts.hit_prim >= 0;
+            if (shadow) {
                 ++c_shadow;
-                Traverser<true, STATS, kTailBlock, true> ts;
-                ts.init_counters();
-                ts.attach_deep(deep_col, sc.deep_stride);
-                ts.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
-                while (!ts.finished())
-                    ts.step(sc, s_stack, tid);
-                overflow |= ts.overflow;
+                overflow |= ts.overflowed();
                 if (STATS) {
                     c_nodes[1] += ts.st_nodes;
                     c_tris[1] += ts.st_tris;
                     c_leaves[1] += ts.st_leaves;
                 }
-                bool occluded = ts.hit_prim >= 0;
-                if (sc.sphere_node_count) {
-                    Traverser<true, STATS, kTailBlock, false, true> tq;
-                    tq.init_counters();
-                    tq.begin(sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW);
-                    tq.set_initial_hit(ts.hit_ent, ts.hit_prim, 0, 0);
-                    while (!tq.finished())
-                        tq.step(sc, s_stack, tid);
-                    occluded = tq.hit_prim >= 0;
-                    overflow |= tq.overflow;
+            }
+            region_end();
+            if (sc.sphere_node_count) {
+                Traverser<true, STATS, kTailBlock, false, true> tq;
+                tq.init_counters();
+                tq.begin(shadow_m, sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, ts.tmax, sflags);
+                tq.set_initial_hit(shadow_m, ts.hit_ent, ts.hit_prim, 0, 0);
+                while (tq.active())
+                    tq.step(sc, s_stack, tid);
+                occluded = tq.hit_prim >= 0;
+                if (shadow) {
+                    overflow |= tq.overflowed();
                     if (STATS) {
                         c_nodes[1] += tq.st_nodes;
                         c_leaves[1] += tq.st_leaves;
                     }
                 }
-                if (!occluded) {
-                    ++c_unoccluded;
-                    acc.x += out.s_col.r * a.inv_spi;
-                    acc.y += out.s_col.g * a.inv_spi;
-                    acc.z += out.s_col.b * a.inv_spi;
-                }
+                region_end();
             }
+            if (shadow && !occluded) {
+                ++c_unoccluded;
+                acc.x += out.s_col.r * a.inv_spi;
+                acc.y += out.s_col.g * a.inv_spi;
+                acc.z += out.s_col.b * a.inv_spi;
+            }
+            region_end();
+        }
 
+        if (have) {
             if (!out.bounce) {
                 a.accum[(int64_t)in.ray_id - a.id_base] = acc;
                 have                                    = false;
@@ -220,6 +242,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 ++hops;
             }
         }
+        region_end();
 
         // long paths leave this launch: they would pin the wave (and its registers / LDS) for milliseconds
         const bool spill               = have && a.max_bounces > 0 && hops >= a.max_bounces;
@@ -283,44 +306,49 @@ IG_DEV void wave_phase_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int AH, bool STATS, typename Begin, typename Done>
+template <int AH, bool STATS, typename Load, typename Done>
 IG_DEV void traverse_slice(const DevScene& sc, StackOf<kTailThreads>& stack, int tid, uint2* deep_col, uint32_t count, uint32_t* c_work,
-                           bool& overflow, Begin begin_ray, Done done)
+                           bool& overflow, Load load_ray, Done done)
 {
     Traverser<AH, STATS, kTailThreads, true> tr;
     tr.init_counters();
     tr.attach_deep(deep_col, sc.deep_stride);
-    const int lane = tid & 63;
-    bool has       = false;
-    uint32_t idx   = 0;
-    uint32_t next  = 0; // wave-uniform: first ray of the slice that no lane has taken yet
+    mask_t has    = 0;
+    uint32_t idx  = 0;
+    uint32_t next = 0; // wave-uniform: first ray of the slice that no lane has taken yet
     for (;;) {
-        const unsigned long long idle = __ballot(!has);
-        const uint32_t n_idle         = (uint32_t)__popcll(idle);
-        const uint32_t left           = count - next;
+        const mask_t idle     = ~has;
+        const uint32_t n_idle = (uint32_t)lanes_in(idle);
+        const uint32_t left   = count - next;
         if (left != 0 && n_idle >= (left >= 16u ? 16u : 1u)) {
             const uint32_t take = left < n_idle ? left : n_idle;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!has && rank < take) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const mask_t fill   = lanes_where(rank < take) & idle;
+            f3 org = f3{ 0, 0, 0 }, dir = org;
+            float tmin = 0, tmax = 0;
+            uint32_t flags = 0;
+            if (in(fill)) {
                 idx = next + rank;
-                has = true;
-                begin_ray(tr, idx);
+                load_ray(idx, org, dir, tmin, tmax, flags);
             }
+            region_end();
+            tr.begin(fill, sc, stack, tid, org, dir, tmin, tmax, flags);
+            has |= fill;
             next += take;
         }
-        if (!__any(has)) {
+        if (!has) {
             if (next >= count)
                 break;
             continue;
         }
-        if (has) {
-            tr.step(sc, stack, tid);
-            if (tr.finished()) {
-                has = false;
-                overflow |= tr.overflow;
-                done(tr, idx);
-            }
+        tr.step(sc, stack, tid);
+        const mask_t ended = has & ~tr.active();
+        has &= ~ended;
+        if (in(ended)) {
+            overflow |= tr.overflowed();
+            done(tr, idx);
         }
+        region_end();
     }
     if (STATS)
         c_work[0] += tr.st_nodes, c_work[1] += tr.st_tris, c_work[2] += tr.st_leaves;
@@ -361,9 +389,9 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail_wave(const T
         // ---- closest-hit traversal of the slice
         traverse_slice<0, STATS>(
             sc, s_stack, tid, deep_col, count, c_work[0], overflow,
-            [&](auto& tr, uint32_t i) {
+            [&](uint32_t i, f3& org, f3& dir, float& tmin, float& tmax, uint32_t& flags) {
                 const float4 ra = src.rayA[i], rb = src.rayB[i];
-                tr.begin(sc, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w, (uint32_t)src.meta[i].y);
+                org = f3{ ra.x, ra.y, ra.z }, dir = f3{ rb.x, rb.y, rb.z }, tmin = ra.w, tmax = rb.w, flags = (uint32_t)src.meta[i].y;
             },
             [&](auto& tr, uint32_t i) {
                 src.hit[i]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
@@ -432,9 +460,9 @@ __global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail_wave(const T
         // of this wave's earlier writes to it are complete: a wave's memory operations are ordered)
         traverse_slice<1, STATS>(
             sc, s_stack, tid, deep_col, n_sec, c_work[1], overflow,
-            [&](auto& tr, uint32_t i) {
+            [&](uint32_t i, f3& org, f3& dir, float& tmin, float& tmax, uint32_t& flags) {
                 const float4 ra = sec.rayA[i], rb = sec.rayB[i];
-                tr.begin(sc, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w, IG_RAY_FLAG_SHADOW);
+                org = f3{ ra.x, ra.y, ra.z }, dir = f3{ rb.x, rb.y, rb.z }, tmin = ra.w, tmax = rb.w, flags = IG_RAY_FLAG_SHADOW;
             },
             [&](auto& tr, uint32_t i) {
                 if (tr.hit_prim < 0) {

@@ -41,10 +41,11 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
     tr.clk_start();
-    bool has_ray          = false;
-    uint32_t ray_idx      = 0;
+    tr.prof_start();
+    mask_t has_ray         = 0; // lanes with a ray in flight (a lane mask in scalar registers, like the traverser's)
+    uint32_t ray_idx       = 0;
     uint32_t st_unoccluded = 0;
-    float4 splat; // any hit: the shadow ray's colour and slot, fetched with the ray (one round trip per refill instead of one per finished lane)
+    float4 splat           = make_float4(0, 0, 0, 0); // any hit: the shadow ray's colour and slot, fetched with the ray (one round trip per refill instead of one per finished lane)
     uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
     bool fatal = false;
 
@@ -54,9 +55,10 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
 
     for (;;) {
         tr.mark(0); // epilogue of the previous pass (hit stores / splat), loop bookkeeping
+        tr.prof(0);
         // ---- refill idle lanes
-        const unsigned long long idle = __ballot(!has_ray);
-        const int n_idle              = __popcll(idle);
+        const mask_t idle = ~has_ray;
+        const int n_idle  = lanes_in(idle);
         if (n_idle >= (ANY_HIT ? kRefillIdleAny : kRefillIdleClosest) && !(exhausted && batch_next >= batch_end)) {
             if (batch_next >= batch_end) {
                 const uint32_t left = count > last_base ? count - last_base : 0u;
@@ -73,52 +75,67 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 if (base + kRayBatch >= count)
                     exhausted = true;
             }
+            tr.prof(1);
             const uint32_t avail = batch_end - batch_next;
             const uint32_t take  = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
-            const uint32_t rank  = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!has_ray && rank < take) {
+            const uint32_t rank  = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
+            const mask_t fill    = lanes_where(rank < take) & idle;
+            float4 ra = make_float4(0, 0, 0, 0), rb = ra, h = ra;
+            uint32_t flags = a.uniform_flags;
+            float hv       = 0;
+            if (in(fill)) {
                 const uint32_t idx = (DEEP && a.index_list) ? a.index_list[batch_next + rank] : batch_next + rank; // (DEEP as the primary kernel: no list)
                 ray_idx = idx;
-                has_ray = true;
-                const float4 ra = a.rayA[idx], rb = a.rayB[idx];
+                tr.prof(2, true);
+                ra = a.rayA[idx], rb = a.rayB[idx];
+                if (a.meta)
+                    flags = (uint32_t)a.meta[idx].y;
                 if (SPHERES) {
-                    // init_hit = what the triangle pass found; its distance is the ray's tmax from here on
-                    const float4 h = a.hit[idx];
-                    tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, h.z,
-                             a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
-                    tr.set_initial_hit((int)igm_bits(h.x), (int)igm_bits(h.y), h.w, ANY_HIT ? 0.0f : a.hit_v[idx]);
-                } else {
-                    tr.begin(a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w,
-                             a.meta ? (uint32_t)a.meta[idx].y : a.uniform_flags);
+                    h  = a.hit[idx];
+                    hv = ANY_HIT ? 0.0f : a.hit_v[idx];
                 }
                 if (ANY_HIT && a.accum)
                     splat = a.col[idx];
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
+            region_end();
+            if (SPHERES) {
+                // init_hit = what the triangle pass found; its distance is the ray's tmax from here on
+                tr.begin(fill, a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, h.z, flags);
+                tr.set_initial_hit(fill, (int)igm_bits(h.x), (int)igm_bits(h.y), h.w, hv);
+            } else {
+                tr.begin(fill, a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w, flags);
+            }
+            has_ray |= fill;
             batch_next += take;
         }
         // (no `continue` for the wave that got no ray out of a refill: a second back edge makes the compiler rotate the loop-carried
-        // state registers through copies at the end of every pass; an empty step() costs three ballots and happens once per launch)
-        if (!__any(has_ray) && exhausted && batch_next >= batch_end)
+        // state registers through copies at the end of every pass; an empty step() is a few scalar instructions, once per launch)
+        if (!has_ray && exhausted && batch_next >= batch_end)
             break;
 
-        // every lane steps: a lane without a ray is in kDone, which no section of step() acts on
         tr.mark(5); // refill: batch reservation, ray loads, begin()
         tr.step(a.scene, s_stack, tid);
-        if (has_ray) {
-            if (tr.finished() && tr.overflow) {
-                has_ray = false;
-                if (DEEP || SPHERES) {
+
+        // ---- rays that ended in this pass
+        const mask_t ended = has_ray & ~tr.active();
+        const mask_t lost  = ended & tr.overflow;
+        has_ray &= ~ended;
+        if (ended) {
+            if (DEEP || SPHERES) {
+                if (lost)
                     fatal = true; // deeper than LDS + global part together
-                } else {
+            } else {
+                if (in(lost)) {
                     // hand the ray to the DEEP launch; what this lane counted for it does not count
                     a.index_list[atomicAdd(a.index_count, 1u)] = ray_idx;
                     if (STATS)
                         tr.st_nodes = snap_nodes, tr.st_tris = snap_tris, tr.st_leaves = snap_leaves;
                 }
-            } else if (tr.finished()) {
-                has_ray = false;
+                region_end();
+            }
+            if (in(ended & ~lost)) {
                 if (ANY_HIT) {
                     if (a.hit)
                         a.hit[ray_idx] = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
@@ -160,11 +177,21 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     a.hit_v[ray_idx] = tr.hit_v;
                 }
             }
+            region_end();
         }
     }
 
     if (fatal)
         atomicOr(&a.qs->error_flags, 1u);
+#ifdef IG_TRAV_PROFILE
+    if (!DEEP && !SPHERES && ANY_HIT == (IG_TRAV_PROFILE == 2)) {
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t n = wave_sum_u32(tr.ev[k]);
+            if (lane == 0)
+                atomicAdd(k < 6 ? &a.qs->section_passes[k] : &a.qs->section_lanes[k - 6], (unsigned long long)n);
+        }
+    }
+#endif
 #ifdef IG_TRAV_CLOCKS
     tr.mark(0);
     if (lane == 0 && !DEEP && !SPHERES)

@@ -13,11 +13,14 @@
 // so hits AND the visited-node / tested-triangle counts equal the CPU oracle's
 // (DESIGN.md "Traversal order").
 //
-// Control flow (round 4): WHETHER a section runs is decided per wave (__ballot against the quorum); INSIDE a section the
-// lanes it concerns run it under the hardware's EXEC mask — plain per-lane `if`s and loops — and update their state
-// registers in place. A lane that leaves a section is `settled`: the cheap stack transitions up to its next heavy action
-// (settle()) run inside the section, for its lanes only. Rounds 2 / 3 ran every section for all 64 lanes and merged with
-// selects (a fifth of the kernel's VALU instructions were v_cndmask, another tenth v_mov).
+// Control flow (round 4): every per-lane boolean of the machine — what a lane waits for, need_cull, the level, ... — is a 64-bit
+// lane mask in scalar registers (`mask_t`), combined on the scalar unit; every branch and loop is wave-uniform (a mask is or is
+// not empty); and the per-lane work of a section sits in flat regions `if (in(mask))`, i.e. under the hardware's EXEC mask,
+// where the lanes concerned update their state registers in place. A lane that leaves a section is `settled`: the cheap
+// stack transitions up to its next heavy action (settle(): a tight pop loop for culled entries, then one classification)
+// run right there, for those lanes only. Rounds 2 / 3 ran every section for all 64 lanes and merged with selects (a fifth of
+// the kernel's VALU instructions were v_cndmask, another tenth v_mov); per-lane `if`s around per-lane
+// loops make the structurizer version the state registers instead (measured in the ISA, tools/isa_histogram.py).
 #pragma once
 
 #include <type_traits>
@@ -61,18 +64,38 @@ using StackLds = StackOf<kBlockThreads>;
 // SPHERES: the scene BVH over the analytic-sphere entities (igd_scene.sphere_*): its leaves are intersected right in the
 // entity-leaf section (make_scene_local_handler_sphere, shapes/sphere.art:139-148), there is no shape level and no triangle
 // section, and the ray starts from the hit the triangle pass left (driver/mapping_cpu.art:385-403).
+using mask_t = unsigned long long;
+IG_DEV mask_t lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }          // the active lanes for which c holds
+IG_DEV bool in(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }           // is the calling lane in m (m wave-uniform)
+IG_DEV int lanes_in(mask_t m) { return __builtin_popcountll(m); }
+// Two rules keep the masks in scalar registers. The compiler's uniformity analysis calls every phi at the join of a divergent
+// branch divergent, and its CFG simplification folds an empty join block into the next one — the head of a loop, the join of a
+// wave-uniform `if` — whose phis carry the masks. So (i) a region `if (in(m)) { ... }` is closed by region_end(), an empty
+// volatile asm that keeps the region's join a block of its own, and (ii) masks are never assigned under any `if`: their updates
+// are unconditional scalar code (an empty region costs its two scalar instructions either way).
+IG_DEV void region_end() { asm volatile(""); }
+
+// 16 bytes at base + off + 16 * row: a wave-uniform base and a 32-bit per-lane byte offset, so the load takes its address as
+// SGPR pair + VGPR offset + immediate (no 64-bit address arithmetic per lane)
+IG_DEV float4 ld16(const void* base, uint32_t off, int row = 0) { return reinterpret_cast<const float4*>(static_cast<const uint8_t*>(base) + off)[row]; }
+IG_DEV int4 ld16i(const void* base, uint32_t off, int row = 0) { return reinterpret_cast<const int4*>(static_cast<const uint8_t*>(base) + off)[row]; }
+
 template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false, bool SPHERES = false>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     static constexpr int kRow    = BLOCK * (int)sizeof(uint2);  // bytes between two entries of a lane's stack
     static constexpr int kLdsEnd = kLdsStack * kRow;            // first byte offset (+ lane) behind the LDS part
-    // what a lane waits for
-    static constexpr int kNode = 0; // an inner node is on top of its stack
-    static constexpr int kTri  = 1; // inside a triangle leaf
-    static constexpr int kLeaf = 2; // inside an entity-leaf run
-    static constexpr int kDone = 3; // the ray ended (or the lane has none)
-    static constexpr int kSettle = 4; // stack driven, transitions pending (inside step() only)
 
+    // ---- what the lanes wait for (a lane with a ray is in exactly one of the three between two sections; in none: no ray, or done)
+    mask_t m_node; // an inner node is on top of the stack
+    mask_t m_tri;  // inside a triangle leaf
+    mask_t m_leaf; // inside an entity-leaf run
+    // ---- per-lane flags
+    mask_t need_cull; // the cull points of the reference (mapping_cpu.art:326-347): at level entry, after a leaf, after a node that pushed nothing
+    mask_t ent_last;  // the entity leaf scanned last ends its run
+    mask_t level1;    // in a shape BVH (else: the scene BVH)
+    mask_t lterm;     // any-hit: the shape-level traversal found its hit
+    mask_t overflow;  // the ray ran out of stack (it is in no mode mask any more)
     // ---- ray + hit
     RayT scene_ray;   // the scene-space ray and its slab-test terms
     f3 lorg, ldir;    // the ray in the current shape's space (triangle tests)
@@ -87,19 +110,14 @@ struct Traverser {
     float l_u, l_v; // hit of the shape-level traversal in flight
     int l_prim;
     int lbase;   // stack position of the saved scene-level top
-    bool lterm;  // any-hit: the shape-level traversal found its hit
     // ---- control
-    int top_node;
-    float top_tmin;
+    uint2 top;   // the cached top of the stack: (node, bits of its entry distance) — one register pair, so a pop is one ds_read_b64 into it
     int sp;      // byte offset of the entry below the top inside Stack::e (this lane's column): (entry * BLOCK + tid) * 8
     int sp_end;  // ... of the first entry this lane's stack does not have
-    int level;   // 0 scene BVH, 1 shape BVH
-    int mode;
     int ent_cursor, tri_cursor;
     uint32_t nodes_off; // Node8[] of the level the lane is on (byte offset inside geom)
     uint32_t tri_off;
     int cur_ent;
-    bool ent_last, need_cull, overflow;
     uint2* deep; // this lane's column of the deep-stack buffer
     uint32_t deep_stride;
     uint32_t st_nodes, st_tris, st_leaves;
@@ -124,27 +142,61 @@ struct Traverser {
     IG_DEV void clk_start() {}
     IG_DEV void mark(int) {}
 #endif
+#ifdef IG_TRAV_PROFILE
+    // how often each part of the kernel runs (variant build, tools/trav_events.py): event k counted once per execution by the
+    // calling lanes' first (so a block under a per-lane condition counts once per wave that enters it); `lanes` counts the callers
+    uint32_t ev[12];
+    IG_DEV void prof_start()
+    {
+        for (int k = 0; k < 12; ++k)
+            ev[k] = 0;
+    }
+    IG_DEV void prof(int k, bool lanes = false)
+    {
+        const mask_t m = lanes_where(true);
+        ev[k] += (lanes || __lane_id() == (unsigned)(__ffsll((long long)m) - 1)) ? 1u : 0u;
+    }
+#else
+    IG_DEV void prof_start() {}
+    IG_DEV void prof(int, bool = false) {}
+#endif
 
-    IG_DEV bool finished() const { return mode == kDone; }
+    IG_DEV mask_t active() const { return m_node | m_tri | m_leaf; } // lanes whose ray is not finished
+    IG_DEV bool finished() const { return !in(active()); }
+    IG_DEV bool overflowed() const { return in(overflow); }
 
     // STATS: one execution of section k by the calling lanes. The counters are per lane (callers sum them over the wave): every
     // calling lane counts itself, the first of them the execution.
     IG_DEV void count_section(int k)
     {
         if (STATS) {
-            const unsigned long long m = __ballot(true);
+            const mask_t m = lanes_where(true);
             sec_lane[k] += 1u;
             sec_pass[k] += (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) ? 1u : 0u;
         }
     }
 
+    // Once per kernel: no lane has a ray. (Every register of the state gets a value: lanes outside a region compute with theirs
+    // where a mask is formed from a comparison before it is restricted to the region.)
     IG_DEV void init_counters()
     {
-        overflow = false;
+        m_node = m_tri = m_leaf = 0;
+        need_cull = level1 = lterm = overflow = 0;
+        ent_last  = ~0ull;
         st_nodes = st_tris = st_leaves = 0;
         for (int k = 0; k < 3; ++k)
             sec_pass[k] = sec_lane[k] = 0;
-        mode = kDone; // a lane without a ray: no section of step() acts on it
+        scene_ray = RayT{ f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 } };
+        lorg = ldir = inv = io = f3{ 0, 0, 0 };
+        tmin = tmax = scene_tmax = 0;
+        rflags = 0;
+        hit_u = hit_v = l_u = l_v = 0;
+        hit_prim = hit_ent = l_prim = -1;
+        lbase = sp = sp_end = 0;
+        top = make_uint2(0u, 0u);
+        ent_cursor = tri_cursor = 0;
+        nodes_off = tri_off = 0;
+        cur_ent = -1;
     }
 
     // The reference's stack has 64 entries and no overflow check (traversal/stack.art:53-54). Here the first
@@ -159,16 +211,18 @@ struct Traverser {
 
     IG_DEV uint2& slot(Stack& st, int at) { return *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(&st.e[0][0]) + at); }
 
-    // push (n, t) below the cached top. Out of stack: the ray ends here (popping a clamped slot again and again would never
-    // terminate); the caller sees finished() && overflow and re-traverses it with the DEEP variant or reports the error.
-    IG_DEV void push_entry(Stack& st, int n, float t)
+    // (per lane, inside a region) push (n, t) below the cached top; returns true when the lane is out of stack: its ray ends
+    // there (popping a clamped slot again and again would never terminate), the caller takes it out of the mode masks and into
+    // `overflow`, and the kernel re-traverses it with the DEEP variant or reports the error.
+    IG_DEV bool push_entry(Stack& st, int n, float t)
     {
         sp += kRow;
         const uint2 e = make_uint2((uint32_t)n, igm_bits(t));
+        bool out      = false;
         if (sp < sp_end) {
             slot(st, sp) = e;
         } else {
-            bool out = true;
+            out = true;
             if (DEEP) {
                 const uint32_t k = (uint32_t)(sp - sp_end) / (uint32_t)kRow;
                 if (k < (uint32_t)kDeepStack) {
@@ -176,11 +230,10 @@ struct Traverser {
                     out                           = false;
                 }
             }
-            if (out)
-                overflow = true, mode = kDone;
         }
+        return out;
     }
-    // pop the entry below the top into (top_node, top_tmin)
+    // (per lane, inside a region) pop the entry below the top into (top_node, top_tmin)
     IG_DEV void pop_top(Stack& st)
     {
         uint2 e;
@@ -190,287 +243,322 @@ struct Traverser {
             const uint32_t k = (uint32_t)(sp - sp_end) / (uint32_t)kRow;
             e                = deep[(size_t)(k < (uint32_t)kDeepStack ? k : (uint32_t)kDeepStack - 1u) * deep_stride];
         }
-        top_node = (int)e.x;
-        top_tmin = igm_float(e.y);
+        top = e;
         sp -= kRow;
     }
 
-    // Starts a ray on the calling lanes (callers wrap this in their refill condition).
-    IG_DEV void begin(const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
+    // Starts a ray on the lanes of `lanes` (wave-uniform; called by the whole wave). The ray arguments need values on those lanes only.
+    IG_DEV void begin(mask_t lanes, const DevScene& sc, Stack& st, int tid, f3 org, f3 dir, float tmin_, float tmax_, uint32_t flags)
     {
-        scene_ray = make_ray_terms(org, dir);
-        inv       = scene_ray.inv_dir;
-        io        = scene_ray.inv_org;
-        tmin      = tmin_;
-        tmax      = tmax_;
-        rflags    = flags;
-        overflow  = false;
-        hit_u = hit_v = 0;
-        hit_prim = hit_ent = -1;
-        level     = 0;
-        ent_last  = true;
-        lterm     = false;
-        nodes_off = SPHERES ? sc.sphere_nodes_off : sc.scene_nodes_off;
-        // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
-        sp     = tid * (int)sizeof(uint2);
-        sp_end = sp + kLdsEnd;
-        slot(st, sp) = make_uint2(0u, igm_bits(kFltMax));
-        top_node = 1;
-        top_tmin = tmin;
-        // the cull at level entry (mapping_cpu.art:326-347): a root that starts behind tmax is popped, which leaves the sentinel
-        need_cull = false;
-        mode      = (((SPHERES ? sc.sphere_node_count : sc.scene_node_count) != 0) & (tmin_ <= tmax_)) ? kNode : kDone;
+        if (in(lanes)) {
+            scene_ray = make_ray_terms(org, dir);
+            inv       = scene_ray.inv_dir;
+            io        = scene_ray.inv_org;
+            tmin      = tmin_;
+            tmax      = tmax_;
+            rflags    = flags;
+            hit_u = hit_v = 0;
+            hit_prim = hit_ent = -1;
+            nodes_off = SPHERES ? sc.sphere_nodes_off : sc.scene_nodes_off;
+            // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
+            sp     = tid * (int)sizeof(uint2);
+            sp_end = sp + kLdsEnd;
+            slot(st, sp) = make_uint2(0u, igm_bits(kFltMax));
+            top = make_uint2(1u, igm_bits(tmin_));
+        }
+        region_end();
+        need_cull &= ~lanes;
+        level1 &= ~lanes;
+        lterm &= ~lanes;
+        overflow &= ~lanes;
+        ent_last |= lanes;
+        // the cull at level entry (mapping_cpu.art:326-347): a root that starts behind tmax is popped, which leaves the sentinel: done
+        const mask_t start = (SPHERES ? sc.sphere_node_count : sc.scene_node_count) != 0 ? (lanes_where(tmin_ <= tmax_) & lanes) : 0ull;
+        m_node             = (m_node & ~lanes) | start;
+        m_tri &= ~lanes;
+        m_leaf &= ~lanes;
     }
     // init_hit of a later geometry pass: the hit found so far (tmax passed to begin() is its distance)
-    IG_DEV void set_initial_hit(int ent, int prim, float u, float v)
+    IG_DEV void set_initial_hit(mask_t lanes, int ent, int prim, float u, float v)
     {
-        hit_ent  = ent;
-        hit_prim = prim;
-        hit_u    = u;
-        hit_v    = v;
-        if (ANY_HIT) {
-            if (prim >= 0)
-                mode = kDone; // already occluded: nothing left to find
+        if (in(lanes)) {
+            hit_ent  = ent;
+            hit_prim = prim;
+            hit_u    = u;
+            hit_v    = v;
         }
+        region_end();
+        if (ANY_HIT)
+            m_node &= ~(lanes_where(prim >= 0) & lanes); // already occluded: nothing left to find
     }
 
-    // Cheap state transitions of a stack-driven lane (mode kNode on entry) up to its next heavy action: an inner node on
-    // top (kNode), a triangle packet (kTri), an entity-leaf run (kLeaf), or the end of the ray (kDone).
+    // Cheap state transitions of the stack-driven lanes `work` (in no mode mask on entry) up to their next heavy action: an
+    // inner node on top (m_node), a triangle packet (m_tri), an entity-leaf run (m_leaf), or the end of the ray (no mask).
     // The cull points are exactly the reference's (mapping_cpu.art:326-347): at level entry, after
     // a leaf and after an inner node that pushed nothing.
     //   unwind (any-hit: the shape-level traversal returned early)  -> falls into `ret`
-    //   cull   : the top starts behind the current hit              -> pop, stay culling
-    //   ret    : sentinel on top at shape level                     -> pop the saved scene top, accept the local hit, next leaf
+    //   cull   : the top starts behind the current hit              -> pop, stay culling (the tight loop)
+    //   ret    : sentinel on top at shape level                     -> pop the saved scene top, accept the local hit, next leaf — or cull on at the scene level
     //   fin    : sentinel on top at scene level                     -> the ray is done
     //   leaf   : leaf on top                                        -> pop, enter its items (or cull on if it starts behind the hit)
-    IG_DEV void settle(const DevScene& sc, Stack& st)
+    IG_DEV void settle(const DevScene& sc, Stack& st, mask_t work)
     {
-        // (a wave-uniform loop around a loop-free per-lane body: with a per-lane loop here the structurizer versions the state
-        // registers the body may write — the return to the scene level writes a dozen — at the loop's header and exits)
-        do {
-            if (mode == kSettle)
-                settle_once(sc, st);
-        } while (__any(mode == kSettle));
-    }
-    IG_DEV void settle_once(const DevScene& sc, Stack& st)
-    {
-        // (decide, pop once, apply: one flat region per kind of transition, and the control words merged with selects, keep the
-        // compiler from versioning registers across nested regions)
         if (ANY_HIT) {
-            if ((level == 1) & lterm)
-                sp = lbase, top_node = 0;
+            if (in(work & level1 & lterm))
+                sp = lbase, top.x = 0u;
+            region_end();
         }
-        const bool sentinel = top_node == 0;
-        const bool ret      = sentinel & (level == 1);
-        const bool fin      = sentinel & (level == 0);
-        const bool behind   = !(top_tmin <= tmax);
-        const bool culling  = !sentinel & need_cull & behind;
-        const bool leaf     = !sentinel & !culling & (top_node < 0);
-        const bool node     = !sentinel & !culling & (top_node > 0);
-        const int cursor    = ~top_node;
-        if (culling | ret | leaf)
-            pop_top(st);
-        bool accept = false;
-        if (ret) {
+        while (work) {
+            prof(11);
+            // entries that start behind the current hit: a compare and a pop each
+            for (;;) {
+                const mask_t cull = lanes_where(top.x != 0u) & lanes_where(!(igm_float(top.y) <= tmax)) & work & need_cull; // (one compare per ballot: a ballot of a conjunction is materialised first)
+                if (!cull)
+                    break;
+                if (in(cull))
+                    pop_top(st);
+                region_end();
+            }
+            const mask_t behind   = lanes_where(!(igm_float(top.y) <= tmax)) & work; // (possible only for lanes that were not culling)
+            const mask_t sentinel = lanes_where(top.x == 0u) & work;
+            const mask_t leaf     = lanes_where((int)top.x < 0) & work;
+            const mask_t ret      = sentinel & level1;
+            // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
+            // hit is dropped, its items have no effect in the reference either
+            const mask_t enter = leaf & ~behind;
+            const mask_t tris = enter & level1, ents = enter & ~level1;
+            if (in(leaf)) {
+                const int cursor = (int)~top.x;
+                pop_top(st);
+                tri_cursor = in(tris) ? cursor : tri_cursor;
+                ent_cursor = in(ents) ? cursor : ent_cursor;
+            }
+            region_end();
             // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
             // accepted only if its (rounded) distance does not exceed the current one.
-            accept = (l_prim != -1) & (tmax <= scene_tmax);
-            hit_u    = accept ? l_u : hit_u;
-            hit_v    = accept ? l_v : hit_v;
-            hit_prim = accept ? l_prim : hit_prim;
-            hit_ent  = accept ? cur_ent : hit_ent;
-            tmax     = accept ? tmax : scene_tmax;
-            inv       = scene_ray.inv_dir;
-            io        = scene_ray.inv_org;
-            nodes_off = sc.scene_nodes_off;
-            level     = 0;
-            lterm     = false;
+            bool accept = false;
+            if (in(ret)) {
+                pop_top(st);
+                accept   = (l_prim != -1) & (tmax <= scene_tmax);
+                hit_u    = accept ? l_u : hit_u;
+                hit_v    = accept ? l_v : hit_v;
+                hit_prim = accept ? l_prim : hit_prim;
+                hit_ent  = accept ? cur_ent : hit_ent;
+                tmax     = accept ? tmax : scene_tmax;
+                inv       = scene_ray.inv_dir;
+                io        = scene_ray.inv_org;
+                nodes_off = sc.scene_nodes_off;
+            }
+            region_end();
+            // (an any-hit ray that just accepted its hit is done: it must not be taken for a lane waiting at its next leaf)
+            const mask_t on = ANY_HIT ? ret & ~lanes_where(accept) : ret;
+            m_node |= work & ~sentinel & ~leaf;
+            m_tri |= tris;
+            m_leaf |= ents | (on & ~ent_last); // a leaf to enter; on with the leaf run after a shape
+            level1 &= ~ret;
+            lterm &= ~ret;
+            // the lanes stop culling here, except: a leaf that was dropped; a shape whose run is over (on at the scene level)
+            const mask_t next = (leaf & behind) | (on & ent_last);
+            need_cull         = (need_cull & ~work) | next;
+            work              = next;
         }
-        // leaf on top (mapping_cpu.art:379-381): an entry that starts behind the current
-        // hit is dropped, its items have no effect in the reference either
-        const bool enter_leaf = leaf & !behind;
-        tri_cursor = (enter_leaf & (level != 0)) ? cursor : tri_cursor;
-        ent_cursor = (enter_leaf & (level == 0)) ? cursor : ent_cursor;
-        // (an any-hit ray that just accepted its hit is done: it must not be taken for a lane waiting at its next leaf)
-        const bool done = fin | (ANY_HIT & accept);
-        const bool next = ret & !done & !ent_last; // on with the leaf run
-        need_cull = (need_cull & culling) | (ret & !done & ent_last) | (leaf & behind);
-        mode      = done ? kDone : (next ? kLeaf : (enter_leaf ? (level ? kTri : kLeaf) : (node ? kNode : kSettle)));
     }
 
-    // The three sections below are called by the whole wave; all their loops are wave-uniform (conditions are __any over the wave),
-    // the per-lane work inside sits under per-lane conditions.
+    // The three sections below are called by the whole wave.
 
-    // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515); lanes in kLeaf
+    // ---- entity leaves of the current run, up to the first one the ray enters (mapping_cpu.art:481-515); the lanes of m_leaf
     IG_DEV void leaf_section(const DevScene& sc, Stack& st)
     {
-        const RayT& gray = scene_ray;
-        if (mode == kLeaf)
-            count_section(0);
-        bool scanning = mode == kLeaf;
+        const RayT& gray  = scene_ray;
+        const mask_t here = m_leaf;
+        if (STATS) {
+            if (in(here))
+                count_section(0);
+            region_end();
+        }
+        prof(3);
+        mask_t scanning  = here;
+        mask_t to_settle = 0, to_tri = 0;
         // (the outer loop repeats only when a lane's one-leaf shape was missed inside its entity box and the run has leaves left,
         // or, SPHERES, after a sphere test)
         do {
             // leaves whose box (or visibility mask) rejects the ray cost only this short loop
-            bool enter    = false;
+            mask_t enter  = 0;
             int enter_at  = 0;
             int entity_id = 0;
             do {
-                if (scanning) {
+                prof(4);
+                bool inside = false, last = false;
+                if (in(scanning)) {
                     // rows 0 and 1 of the records, packed: four leaves per 128-byte line. kScanLeaves: the rows of the next leaves come
                     // with the same round trip (a scan is a chain of dependent loads); they are looked at only if this one rejects the
                     // ray and the run goes on. The records behind the last leaf of the table are padding.
                     const int at     = ent_cursor;
-                    const float4* ls = (SPHERES ? sc.sphere_leaf_scan : sc.leaf_scan) + at * 2;
+                    const void* ls      = SPHERES ? sc.sphere_leaf_scan : sc.leaf_scan;
+                    const uint32_t lsat = (uint32_t)at * 32u;
                     float4 lr[kScanLeaves][2];
 #pragma unroll
                     for (int k = 0; k < kScanLeaves; ++k)
-                        lr[k][0] = ls[2 * k], lr[k][1] = ls[2 * k + 1];
+                        lr[k][0] = ld16(ls, lsat, 2 * k), lr[k][1] = ld16(ls, lsat, 2 * k + 1);
 #pragma unroll
                     for (int k = 0; k < kScanLeaves; ++k) {
-                        if (k == 0 || scanning) {
+                        if (k == 0 || (!inside & !last)) {
                             const float4 r0 = lr[k][0], r1 = lr[k][1];
                             ent_cursor += 1;
                             const int id          = (int)igm_bits(r0.w);
                             const uint32_t lflags = igm_bits(r1.w);
-                            ent_last              = id < 0;
+                            last                  = id < 0;
                             if (STATS)
                                 st_leaves += 1u;
                             // check_ray_visibility (traversal/ray.art:51)
                             const bool visible = (rflags & IG_RAY_FLAG_TYPE_MASK) == ((rflags & lflags) & IG_RAY_FLAG_TYPE_MASK);
                             float entry, exit;
                             slab_test(gray, tmin, tmax, r0.x, r1.x, r0.y, r1.y, r0.z, r1.z, entry, exit);
-                            const bool inside = visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
+                            inside = visible & (entry <= exit) & (exit >= 0) & (entry <= tmax);
                             if (inside)
-                                enter = true, enter_at = at + k, entity_id = id;
-                            scanning = !inside & !(id < 0);
+                                enter_at = at + k, entity_id = id;
                         }
                     }
                 }
-            } while (__any(scanning));
-            if (enter) {
-                const float4* lf = (SPHERES ? sc.sphere_leaves : sc.leaves) + enter_at * kDevLeafRows;
-                const float4 l2 = lf[2], l3 = lf[3], l4 = lf[4], l5 = lf[5];
-                const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
-                m34 m;
-                m.c0 = f3{ l2.x, l2.y, l2.z };
-                m.c1 = f3{ l2.w, l3.x, l3.y };
-                m.c2 = f3{ l3.z, l3.w, l4.x };
-                m.c3 = f3{ l4.y, l4.z, l4.w };
-                if (SPHERES) {
-                    // intersect_sphere (shapes/sphere.art:107-137) with the ray in shape space: direction not normalised, t global
-                    const f3 so = xform_point(m, gray.org), sd = xform_dir(m, gray.dir);
-                    const float4 sp4 = *reinterpret_cast<const float4*>(sc.shape_data + ext.x); // centre, radius
-                    const f3 L     = so - f3{ sp4.x, sp4.y, sp4.z };
-                    const float S  = -dot3(L, sd);
-                    const float D2 = dot3(sd, sd);
-                    const float L2 = dot3(L, L);
-                    const float R2 = sp4.w * sp4.w * D2;
-                    const float M2 = L2 * D2 - S * S;
-                    const float Q   = igm_sqrt(R2 - M2);
-                    const float t0_ = (S - Q) / D2;
-                    const float t1_ = (S + Q) / D2;
-                    const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
-                    const float th = t0 < tmin ? t1 : t0;
-                    // accepted if in range (local_hit.distance <= hit.distance is implied by th <= tmax)
-                    const bool ok = !((S < 0) | (M2 > R2)) & (th >= tmin) & (th <= tmax);
-                    if (ok) {
-                        // sphere_map_uv (sphere.art:1-6)
-                        const f3 n        = (L + sd * th) * (1 / sp4.w);
-                        const float theta = igm_acos(n.z);
-                        float phi         = igm_atan2(-n.x, n.y);
-                        phi               = phi < 0 ? phi + 2 * kPi : phi;
-                        tmax     = th;
-                        hit_u    = phi / (2 * kPi);
-                        hit_v    = theta / kPi;
-                        hit_prim = 0;
-                        hit_ent  = entity_id & 0x7FFFFFFF;
-                        if (ANY_HIT)
-                            mode = kDone;
-                    }
-                    // a leaf run continues after a sphere test (the shape level of the triangle pass comes back through settle()'s `ret`)
-                    scanning = !ent_last & !(ANY_HIT & ok);
-                } else {
-                    // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global
-                    // A direction the matrix hands back bit for bit (an instance that is only translated: every entity of
-                    // diamond_scene) has the reciprocals the scene-space ray already has: the three IEEE divisions are run only
-                    // when some entering lane of the wave needs them.
-                    // (written straight into the lane's shape-space ray: at the scene level nothing reads lorg / ldir, and the slab-test
-                    // terms are put back if the shape turns out to be missed)
-                    lorg = xform_point(m, gray.org);
-                    ldir = xform_dir(m, gray.dir);
-                    const bool same_dir = (igm_bits(ldir.x) == igm_bits(gray.dir.x)) & (igm_bits(ldir.y) == igm_bits(gray.dir.y)) & (igm_bits(ldir.z) == igm_bits(gray.dir.z));
-                    if (!same_dir)
-                        inv = f3{ safe_rcp(ldir.x), safe_rcp(ldir.y), safe_rcp(ldir.z) };
-                    io = -(lorg * inv);
-                    // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of row 5 of its leaf record by
-                    // igd_assign_scene) skips the inner-node section: its root visit is the slab test of that one child, done here
-                    // with the operations of the inner-node section. Hit: the state the root visit and the pop of the leaf
-                    // would have left (saved scene top on the stack, sentinel on top, in the triangle leaf). Miss: the state
-                    // `ret` would have restored, i.e. as if the entity's box had rejected the ray, and the run is scanned on.
-                    const bool single = (ext.x & 1u) != 0;
-                    bool missed       = false;
-                    if (single) {
-                        const float4 blo = lf[6], bhi = lf[7];
-                        // (near / far plane by the sign of the inverse direction, as the inner-node section picks its rows)
-                        const bool ox = inv.x < 0, oy = inv.y < 0, oz = inv.z < 0;
-                        const float nx = ox ? bhi.x : blo.x, fx = ox ? blo.x : bhi.x;
-                        const float ny = oy ? bhi.y : blo.y, fy = oy ? blo.y : bhi.y;
-                        const float nz = oz ? bhi.z : blo.z, fz = oz ? blo.z : bhi.z;
-                        const float entry = igm_max(igm_max(igm_fma(inv.x, nx, io.x), igm_fma(inv.y, ny, io.y)), igm_max(igm_fma(inv.z, nz, io.z), tmin));
-                        const float exit  = igm_min(igm_min(igm_fma(inv.x, fx, io.x), igm_fma(inv.y, fy, io.y)), igm_min(igm_fma(inv.z, fz, io.z), tmax));
-                        missed            = exit < entry;
-                        if (STATS)
-                            st_nodes += 1u;
-                    }
-                    if (!missed) {
-                        cur_ent = entity_id & 0x7FFFFFFF;
-                        // save the scene-level top, then a fresh stack: sentinel + shape root (one-leaf shapes: the sentinel is already
-                        // back on top, the root and its leaf entry have come and gone)
-                        mode = single ? kTri : kSettle; // (a push that runs out of stack makes it kDone)
-                        push_entry(st, top_node, top_tmin);
-                        lbase      = sp;
-                        scene_tmax = tmax; // invalid_hit(local_ray.tmax): the local distance starts from the scene level's
-                        l_prim     = -1;
-                        lterm      = false;
-                        level      = 1;
-                        nodes_off  = ext.x & ~1u;
-                        tri_off    = ext.y;
-                        if (single) {
-                            top_node   = 0;
-                            top_tmin   = kFltMax;
-                            tri_cursor = ~(int)igm_bits(l5.z);
-                        } else {
-                            push_entry(st, 0, kFltMax);
-                            top_node  = 1;
-                            top_tmin  = tmin;
-                            need_cull = true; // the cull at level entry
+                region_end();
+                const mask_t ins = lanes_where(inside) & scanning, lst = lanes_where(last) & scanning;
+                ent_last = (ent_last & ~scanning) | lst;
+                enter |= ins;
+                to_settle |= lst & ~ins; // the run is over and nothing was entered
+                scanning &= ~(ins | lst);
+            } while (scanning);
+            {
+                prof(5);
+                bool missed = false, single = false, out = false, ok = false;
+                if (in(enter)) {
+                    const void* lf      = SPHERES ? sc.sphere_leaves : sc.leaves;
+                    const uint32_t lfat = (uint32_t)enter_at * (uint32_t)(kDevLeafRows * 16);
+                    const float4 l2 = ld16(lf, lfat, 2), l3 = ld16(lf, lfat, 3), l4 = ld16(lf, lfat, 4), l5 = ld16(lf, lfat, 5);
+                    const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
+                    m34 m;
+                    m.c0 = f3{ l2.x, l2.y, l2.z };
+                    m.c1 = f3{ l2.w, l3.x, l3.y };
+                    m.c2 = f3{ l3.z, l3.w, l4.x };
+                    m.c3 = f3{ l4.y, l4.z, l4.w };
+                    if (SPHERES) {
+                        // intersect_sphere (shapes/sphere.art:107-137) with the ray in shape space: direction not normalised, t global
+                        const f3 so = xform_point(m, gray.org), sd = xform_dir(m, gray.dir);
+                        const float4 sp4 = *reinterpret_cast<const float4*>(sc.shape_data + ext.x); // centre, radius
+                        const f3 L     = so - f3{ sp4.x, sp4.y, sp4.z };
+                        const float S  = -dot3(L, sd);
+                        const float D2 = dot3(sd, sd);
+                        const float L2 = dot3(L, L);
+                        const float R2 = sp4.w * sp4.w * D2;
+                        const float M2 = L2 * D2 - S * S;
+                        const float Q   = igm_sqrt(R2 - M2);
+                        const float t0_ = (S - Q) / D2;
+                        const float t1_ = (S + Q) / D2;
+                        const float t0 = t0_ > t1_ ? t1_ : t0_, t1 = t0_ > t1_ ? t0_ : t1_;
+                        const float th = t0 < tmin ? t1 : t0;
+                        // accepted if in range (local_hit.distance <= hit.distance is implied by th <= tmax)
+                        ok = !((S < 0) | (M2 > R2)) & (th >= tmin) & (th <= tmax);
+                        if (ok) {
+                            // sphere_map_uv (sphere.art:1-6)
+                            const f3 n        = (L + sd * th) * (1 / sp4.w);
+                            const float theta = igm_acos(n.z);
+                            float phi         = igm_atan2(-n.x, n.y);
+                            phi               = phi < 0 ? phi + 2 * kPi : phi;
+                            tmax     = th;
+                            hit_u    = phi / (2 * kPi);
+                            hit_v    = theta / kPi;
+                            hit_prim = 0;
+                            hit_ent  = entity_id & 0x7FFFFFFF;
                         }
                     } else {
-                        // the one-leaf shape was missed: on with the run, if it has leaves left
-                        inv      = gray.inv_dir;
-                        io       = gray.inv_org;
-                        scanning = !ent_last;
+                        // transform_ray (traversal/ray.art:56-59): direction not normalised, t stays global.
+                        // (written straight into the lane's shape-space ray: at the scene level nothing reads lorg / ldir, and the slab-test
+                        // terms are put back if the shape turns out to be missed)
+                        lorg = xform_point(m, gray.org);
+                        ldir = xform_dir(m, gray.dir);
+                        // A direction the matrix hands back bit for bit (an instance that is only translated: every entity of
+                        // diamond_scene) has the reciprocals the scene-space ray already has: the three IEEE divisions are run only
+                        // by the lanes that need them.
+                        const bool same_dir = (igm_bits(ldir.x) == igm_bits(gray.dir.x)) & (igm_bits(ldir.y) == igm_bits(gray.dir.y)) & (igm_bits(ldir.z) == igm_bits(gray.dir.z));
+                        if (!same_dir)
+                            inv = f3{ safe_rcp(ldir.x), safe_rcp(ldir.y), safe_rcp(ldir.z) };
+                        io = -(lorg * inv);
+                        // A shape whose BVH is ONE node with ONE triangle leaf (a wall, a light quad; marked in bit 0 of row 5 of its leaf record by
+                        // igd_assign_scene) skips the inner-node section: its root visit is the slab test of that one child, done here
+                        // with the operations of the inner-node section. Hit: the state the root visit and the pop of the leaf
+                        // would have left (saved scene top on the stack, sentinel on top, in the triangle leaf). Miss: the state
+                        // `ret` would have restored, i.e. as if the entity's box had rejected the ray, and the run is scanned on.
+                        single = (ext.x & 1u) != 0;
+                        if (single) {
+                            const float4 blo = ld16(lf, lfat, 6), bhi = ld16(lf, lfat, 7);
+                            // (near / far plane by the sign of the inverse direction, as the inner-node section picks its rows)
+                            const bool ox = inv.x < 0, oy = inv.y < 0, oz = inv.z < 0;
+                            const float nx = ox ? bhi.x : blo.x, fx = ox ? blo.x : bhi.x;
+                            const float ny = oy ? bhi.y : blo.y, fy = oy ? blo.y : bhi.y;
+                            const float nz = oz ? bhi.z : blo.z, fz = oz ? blo.z : bhi.z;
+                            const float entry = igm_max(igm_max(igm_fma(inv.x, nx, io.x), igm_fma(inv.y, ny, io.y)), igm_max(igm_fma(inv.z, nz, io.z), tmin));
+                            const float exit  = igm_min(igm_min(igm_fma(inv.x, fx, io.x), igm_fma(inv.y, fy, io.y)), igm_min(igm_fma(inv.z, fz, io.z), tmax));
+                            missed            = exit < entry;
+                            if (STATS)
+                                st_nodes += 1u;
+                        }
+                        if (!missed) {
+                            cur_ent = entity_id & 0x7FFFFFFF;
+                            // save the scene-level top, then a fresh stack: sentinel + shape root (one-leaf shapes: the sentinel is already
+                            // back on top, the root and its leaf entry have come and gone)
+                            out        = push_entry(st, (int)top.x, igm_float(top.y));
+                            lbase      = sp;
+                            scene_tmax = tmax; // invalid_hit(local_ray.tmax): the local distance starts from the scene level's
+                            l_prim     = -1;
+                            nodes_off  = ext.x & ~1u;
+                            tri_off    = ext.y;
+                            if (single) {
+                                top        = make_uint2(0u, igm_bits(kFltMax));
+                                tri_cursor = ~(int)igm_bits(l5.z);
+                            } else {
+                                out |= push_entry(st, 0, kFltMax);
+                                top = make_uint2(1u, igm_bits(tmin));
+                            }
+                        } else {
+                            inv = gray.inv_dir;
+                            io  = gray.inv_org;
+                        }
                     }
                 }
+                region_end();
+                if (SPHERES) {
+                    // a leaf run continues after a sphere test (the shape level of the triangle pass comes back through settle()'s `ret`)
+                    const mask_t on = ANY_HIT ? enter & ~lanes_where(ok) : enter; // (an any-hit ray that found its hit is done)
+                    scanning        = on & ~ent_last;
+                    to_settle |= on & ent_last;
+                } else {
+                    const mask_t ms = lanes_where(missed) & enter, sg = lanes_where(single) & enter, o = lanes_where(out) & enter;
+                    const mask_t go = enter & ~ms;
+                    level1 |= go;
+                    lterm &= ~go;
+                    overflow |= o;
+                    to_tri |= go & sg & ~o;
+                    to_settle |= go & ~sg & ~o; // at the root of the entered shape: the cull at level entry
+                    // the one-leaf shape was missed: on with the run, if it has leaves left
+                    scanning = ms & ~ent_last;
+                    to_settle |= ms & ent_last;
+                }
             }
-        } while (__any(scanning));
-        if (mode == kLeaf) {
-            // the run is over and nothing was entered
-            mode      = kSettle;
-            need_cull = true;
-        }
-        settle(sc, st);
+        } while (scanning);
+        m_leaf &= ~here;
+        m_tri |= to_tri;
+        need_cull |= to_settle;
+        settle(sc, st, to_settle);
     }
 
-    // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377); lanes in kNode
+    // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377); the lanes of m_node
     IG_DEV void node_section(const DevScene& sc, Stack& st)
     {
-        if (mode == kNode) {
-            const uint8_t* np = sc.geom + nodes_off + (uint32_t)(top_node - 1) * 256u;
+        const mask_t here = m_node;
+        prof(6);
+        bool pushed = false, out = false;
+        if (in(here)) {
+            const uint32_t node_at = nodes_off + (top.x - 1u) * 256u; // byte offset of the Node8 inside geom
             pop_top(st);
-            const float4* nf = reinterpret_cast<const float4*>(np);
-            const int4* nc   = reinterpret_cast<const int4*>(np) + 12;
             if (STATS)
                 st_nodes += 1u;
             count_section(1);
@@ -480,9 +568,13 @@ struct Traverser {
             // (fma is monotonic and lo <= hi), so the near / far rows are picked by address instead and six
             // of the eighteen min / max per child disappear. Results are bit-identical for real children
             // (empty slots are masked by child == 0).
-            const int ox = inv.x < 0 ? 1 : 0, oy = inv.y < 0 ? 1 : 0, oz = inv.z < 0 ? 1 : 0;
+            // (rows of a Node8, 16 bytes each: x lo [0, 1], x hi [2, 3], y lo [4, 5], y hi [6, 7], z lo [8, 9], z hi [10, 11], child ids [12, 13])
+            const uint32_t sx = inv.x < 0 ? 32u : 0u, sy = inv.y < 0 ? 32u : 0u, sz = inv.z < 0 ? 32u : 0u;
+            const uint32_t near_x = node_at + sx, far_x = node_at + 32u - sx;
+            const uint32_t near_y = node_at + 64u + sy, far_y = node_at + 96u - sy;
+            const uint32_t near_z = node_at + 128u + sz, far_z = node_at + 160u - sz;
             // both halves' child ids with the first batch of loads: the test for the second half does not cost a round trip of its own
-            const int4 c4lo = nc[0], c4hi = nc[1];
+            const int4 c4lo = ld16i(sc.geom, node_at, 12), c4hi = ld16i(sc.geom, node_at, 13);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int4 c4 = h ? c4hi : c4lo;
@@ -490,9 +582,11 @@ struct Traverser {
                 // list, mapping_cpu.art:357)
                 if (h == 1 && c4.x == 0)
                     break;
-                const float4 nx = nf[2 * ox + h], fx = nf[2 * (1 - ox) + h];
-                const float4 ny = nf[2 * (2 + oy) + h], fy = nf[2 * (3 - oy) + h];
-                const float4 nz = nf[2 * (4 + oz) + h], fz = nf[2 * (5 - oz) + h];
+                if (h == 1)
+                    prof(7);
+                const float4 nx = ld16(sc.geom, near_x, h), fx = ld16(sc.geom, far_x, h);
+                const float4 ny = ld16(sc.geom, near_y, h), fy = ld16(sc.geom, far_y, h);
+                const float4 nz = ld16(sc.geom, near_z, h), fz = ld16(sc.geom, far_z, h);
                 const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
                 const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
                 const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
@@ -503,11 +597,11 @@ struct Traverser {
                     const bool hit    = (ch[i] != 0) & !(exit < entry);
                     if (hit) {
                         // push (becomes the top) if nearer than the current top, else push_after
-                        const bool front = ANY_HIT || (top_tmin > entry);
-                        const int pn     = front ? top_node : ch[i];
-                        const float pt   = front ? top_tmin : entry;
+                        const bool front = ANY_HIT || (igm_float(top.y) > entry);
+                        const int pn     = front ? (int)top.x : ch[i];
+                        const float pt   = front ? igm_float(top.y) : entry;
                         if (DEEP) {
-                            push_entry(st, pn, pt);
+                            out |= push_entry(st, pn, pt);
                         } else {
                             // (how far the node got, and whether that was too far, is read off the address once after the eight children)
                             sp += kRow;
@@ -515,49 +609,55 @@ struct Traverser {
                                 slot(st, sp) = make_uint2((uint32_t)pn, igm_bits(pt));
                         }
                         if (front)
-                            top_node = ch[i], top_tmin = entry;
+                            top = make_uint2((uint32_t)ch[i], igm_bits(entry));
                     }
                 }
             }
-            if (!DEEP) {
-                if (sp >= sp_end)
-                    overflow = true, mode = kDone; // out of stack: the ray ends here (see push_entry)
-            }
-            if (mode != kDone) {
-                need_cull = sp == sp_before; // nothing pushed: cull (mapping_cpu.art:377)
-                mode      = kSettle;
-            }
+            if (!DEEP)
+                out = sp >= sp_end; // out of stack: the ray ends here (see push_entry)
+            pushed = sp != sp_before;
         }
-        settle(sc, st);
+        region_end();
+        const mask_t o = lanes_where(out) & here, live = here & ~o;
+        overflow |= o;
+        need_cull |= live & ~lanes_where(pushed); // nothing pushed: cull (mapping_cpu.art:377)
+        m_node = 0;
+        settle(sc, st, live);
     }
 
-    // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410); lanes in kTri
+    // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410); the lanes of m_tri
     IG_DEV void tri_section(const DevScene& sc, Stack& st)
     {
         RayT lr;
         lr.org = lorg, lr.dir = ldir;
+        const mask_t here = m_tri;
+        mask_t work       = here;
+        prof(8);
         do {
-            if (mode == kTri) {
+            prof(9);
+            bool leave = false, found = false;
+            if (in(work)) {
                 count_section(2);
-                const uint8_t* tp = sc.geom + tri_off + (uint32_t)tri_cursor * 208u;
+                const uint32_t tri_at = tri_off + (uint32_t)tri_cursor * 208u; // byte offset of the packet inside geom
                 tri_cursor += 1;
                 // two triangles of the packet at a time (a 96-byte half of the re-ordered packet): 24 live registers instead
                 // of 48, and the second half is not even fetched when the packet holds no more than two triangles
-                const int4 pid4  = reinterpret_cast<const int4*>(tp)[12];
+                const int4 pid4  = ld16i(sc.geom, tri_at, 12);
                 const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    // (valid triangles are packed from slot 0: the first -1 ends the packet, mapping_cpu.art:386)
-                    // (the first half comes with the ids: a packet has at least one triangle)
-                    if (h == 1 && (pid[2] == -1 || (ANY_HIT && lterm)))
+                    // (valid triangles are packed from slot 0: the first -1 ends the packet, mapping_cpu.art:386; the first half comes
+                    // with the ids)
+                    if (h == 1 && (pid[2] == -1 || (ANY_HIT && found)))
                         break;
+                    if (h == 1)
+                        prof(10);
                     // half h of the packet: 96 contiguous bytes, float 2 k + j = row k of triangle 2 h + j (igd_assign_scene re-orders the
                     // reference's Tri4 that way): six 16-byte loads per half
-                    const float4* th = reinterpret_cast<const float4*>(tp) + 6 * h;
                     float4 c[6];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
-                        c[m] = th[m];
+                        c[m] = ld16(sc.geom, tri_at, 6 * h + m);
                     float q[12][2];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
@@ -565,34 +665,34 @@ struct Traverser {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int i   = 2 * h + j;
-                        const bool on = (pid[i] != -1) & !(ANY_HIT & lterm);
-                        if (on) {
-                            if (STATS)
-                                st_tris += 1u;
-                            float t, u, v;
-                            if (tri_test(lr, tmin, tmax, f3{ q[0][j], q[1][j], q[2][j] }, f3{ q[3][j], q[4][j], q[5][j] },
-                                         f3{ q[6][j], q[7][j], q[8][j] }, f3{ q[9][j], q[10][j], q[11][j] }, t, u, v)) {
-                                tmax   = t;
-                                l_u    = u;
-                                l_v    = v;
-                                l_prim = pid[i] & 0x7FFFFFFF;
-                                if (ANY_HIT)
-                                    lterm = true;
-                            }
+                        const bool on = (pid[i] != -1) & !(ANY_HIT & found);
+                        if (STATS)
+                            st_tris += on ? 1u : 0u;
+                        // (the test up to its verdict runs for every lane of the region, valid triangle or not: skipping it would pay off only
+                        // when no lane of the wave has one, and as straight-line code it keeps the loads above whole and in front)
+                        TriCandidate cand;
+                        const bool ok = tri_test_candidate(lr, tmin, tmax, f3{ q[0][j], q[1][j], q[2][j] }, f3{ q[3][j], q[4][j], q[5][j] },
+                                                           f3{ q[6][j], q[7][j], q[8][j] }, f3{ q[9][j], q[10][j], q[11][j] }, cand) & on;
+                        if (ok) {
+                            tri_test_finish(cand, tmax, l_u, l_v);
+                            l_prim = pid[i] & 0x7FFFFFFF;
+                            found  = true;
                         }
                     }
                 }
-                if ((pid[3] < 0) | (ANY_HIT & lterm)) {
-                    mode      = kSettle;
-                    need_cull = true;
-                }
+                leave = (pid[3] < 0) | (ANY_HIT & found);
             }
-        } while (__any(mode == kTri));
-        settle(sc, st);
+            region_end();
+            if (ANY_HIT)
+                lterm |= lanes_where(found) & work;
+            work &= ~lanes_where(leave);
+        } while (work);
+        m_tri = 0;
+        need_cull |= here;
+        settle(sc, st, here);
     }
 
-    // One pipeline pass: entity leaf -> inner node -> triangle packet. Every lane of the wave calls it; lanes without
-    // a ray (kDone) are left alone.
+    // One pipeline pass: entity leaf -> inner node -> triangle packet. The whole wave calls it; lanes without a ray are in no mask.
     IG_DEV void step(const DevScene& sc, Stack& st, int tid)
     {
         // Postponing: a section runs only when enough lanes of the wave want it (they wait in their mode until
@@ -600,24 +700,21 @@ struct Traverser {
         // quorum the threshold drops to one lane for this pass, which guarantees progress.
         int quorum = 1;
         if (kPostponeShift > 0) {
-            const int n_ent  = __popcll(__ballot(mode == kLeaf));
-            const int n_node = __popcll(__ballot(mode == kNode));
-            const int n_tri  = __popcll(__ballot(mode == kTri));
-            const int active = n_ent + n_node + n_tri; // (a lane with a ray waits in exactly one of the three)
-            const int most   = n_ent > n_node ? (n_ent > n_tri ? n_ent : n_tri) : (n_node > n_tri ? n_node : n_tri);
-            quorum           = (active * kPostponeNum) >> kPostponeShift;
+            const int n_ent = lanes_in(m_leaf), n_node = lanes_in(m_node), n_tri = lanes_in(m_tri);
+            const int most  = n_ent > n_node ? (n_ent > n_tri ? n_ent : n_tri) : (n_node > n_tri ? n_node : n_tri);
+            quorum          = ((n_ent + n_node + n_tri) * kPostponeNum) >> kPostponeShift;
             if (quorum < 1 || most < quorum)
                 quorum = 1; // no section reaches the quorum: all of them run
         }
         mark(4); // quorum at the top of a pass
-        if (__popcll(__ballot(mode == kLeaf)) >= quorum)
+        if (lanes_in(m_leaf) >= quorum)
             leaf_section(sc, st);
         mark(1); // entity-leaf section (with its settle)
-        if (__popcll(__ballot(mode == kNode)) >= quorum)
+        if (lanes_in(m_node) >= quorum)
             node_section(sc, st);
         mark(2); // inner-node section (with its settle)
         if (!SPHERES) {
-            if (__popcll(__ballot(mode == kTri)) >= quorum)
+            if (lanes_in(m_tri) >= quorum)
                 tri_section(sc, st);
         }
         mark(3); // triangle section
