@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         tr.mark(0); // epilogue of the previous pass (hit stores / splat), loop bookkeeping
         tr.prof(0);
         // ---- refill idle lanes
+        IG_MARK("pass.head");
         const mask_t idle = ~has_ray;
         const int n_idle  = lanes_in(idle);
         if (n_idle >= (ANY_HIT ? kRefillIdleAny : kRefillIdleClosest) && !(exhausted && batch_next >= batch_end)) {
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     exhausted = true;
             }
             tr.prof(1);
+            IG_MARK("refill");
             const uint32_t avail = batch_end - batch_next;
             const uint32_t take  = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
             const uint32_t rank  = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
@@ -109,6 +111,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             }
             has_ray |= fill;
             batch_next += take;
+            IG_MARK("refill.end");
         }
         // (no `continue` for the wave that got no ray out of a refill: a second back edge makes the compiler rotate the loop-carried
         // state registers through copies at the end of every pass; an empty step() is a few scalar instructions, once per launch)
@@ -119,6 +122,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         tr.step(a.scene, s_stack, tid);
 
         // ---- rays that ended in this pass
+        IG_MARK("epilogue");
         const mask_t ended = has_ray & ~tr.active();
         const mask_t lost  = ended & tr.overflow;
         has_ray &= ~ended;

@@ -50,6 +50,14 @@ constexpr int kLdsStack     = IG_LDS_STACK;
 constexpr int kTraverseOcc  = IG_TRAV_OCC;   // workgroups of 256 per CU = waves per SIMD the kernel is built for
 constexpr int kBlockThreads = 256;
 constexpr int kScanLeaves   = 2; // entity-leaf section: leaves of a run fetched per round trip (the host builder keeps runs <= 2)
+#ifndef IG_TRI_FULL
+#define IG_TRI_FULL 0
+#endif
+constexpr bool kTriFull = IG_TRI_FULL != 0; // triangle section: both halves of a packet fetched with its ids (one round trip, 24 more registers)
+#ifndef IG_LEAF_EARLY
+#define IG_LEAF_EARLY 1
+#endif
+constexpr bool kLeafEarly = IG_LEAF_EARLY != 0; // entity-leaf section: rows 2 - 7 of the first scanned leaf fetched with the scan rows
 
 // Per-lane LDS of one workgroup of BLOCK lanes: the traversal stacks, entry-major so that a wave's accesses are conflict free.
 template <int BLOCK>
@@ -74,6 +82,13 @@ IG_DEV int lanes_in(mask_t m) { return __builtin_popcountll(m); }
 // volatile asm that keeps the region's join a block of its own, and (ii) masks are never assigned under any `if`: their updates
 // are unconditional scalar code (an empty region costs its two scalar instructions either way).
 IG_DEV void region_end() { asm volatile(""); }
+// -DIG_ISA_MARKS: comment lines in the assembly at the borders of the kernel's parts, for tools/isa_regions.py (static
+// instructions per part; with the event counts of tools/trav_events.py: the dynamic mix). Analysis builds only.
+#ifdef IG_ISA_MARKS
+#define IG_MARK(name) asm volatile("; @@ " name)
+#else
+#define IG_MARK(name) ((void)0)
+#endif
 
 // 16 bytes at base + off + 16 * row: a wave-uniform base and a 32-bit per-lane byte offset, so the load takes its address as
 // SGPR pair + VGPR offset + immediate (no 64-bit address arithmetic per lane)
@@ -84,7 +99,8 @@ template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false
 struct Traverser {
     using Stack = StackOf<BLOCK>;
     static constexpr int kRow    = BLOCK * (int)sizeof(uint2);  // bytes between two entries of a lane's stack
-    static constexpr int kLdsEnd = kLdsStack * kRow;            // first byte offset (+ lane) behind the LDS part
+    // an entry's byte offset is entry * kRow + tid * 8 with tid * 8 < kRow, so `offset < kLdsEnd` says `entry < kLdsStack` for every lane
+    static constexpr int kLdsEnd = kLdsStack * kRow;
 
     // ---- what the lanes wait for (a lane with a ray is in exactly one of the three between two sections; in none: no ray, or done)
     mask_t m_node; // an inner node is on top of the stack
@@ -113,7 +129,6 @@ struct Traverser {
     // ---- control
     uint2 top;   // the cached top of the stack: (node, bits of its entry distance) — one register pair, so a pop is one ds_read_b64 into it
     int sp;      // byte offset of the entry below the top inside Stack::e (this lane's column): (entry * BLOCK + tid) * 8
-    int sp_end;  // ... of the first entry this lane's stack does not have
     int ent_cursor, tri_cursor;
     uint32_t nodes_off; // Node8[] of the level the lane is on (byte offset inside geom)
     uint32_t tri_off;
@@ -192,7 +207,7 @@ struct Traverser {
         rflags = 0;
         hit_u = hit_v = l_u = l_v = 0;
         hit_prim = hit_ent = l_prim = -1;
-        lbase = sp = sp_end = 0;
+        lbase = sp = 0;
         top = make_uint2(0u, 0u);
         ent_cursor = tri_cursor = 0;
         nodes_off = tri_off = 0;
@@ -219,12 +234,12 @@ struct Traverser {
         sp += kRow;
         const uint2 e = make_uint2((uint32_t)n, igm_bits(t));
         bool out      = false;
-        if (sp < sp_end) {
+        if (sp < kLdsEnd) {
             slot(st, sp) = e;
         } else {
             out = true;
             if (DEEP) {
-                const uint32_t k = (uint32_t)(sp - sp_end) / (uint32_t)kRow;
+                const uint32_t k = (uint32_t)(sp - kLdsEnd) / (uint32_t)kRow;
                 if (k < (uint32_t)kDeepStack) {
                     deep[(size_t)k * deep_stride] = e;
                     out                           = false;
@@ -237,10 +252,10 @@ struct Traverser {
     IG_DEV void pop_top(Stack& st)
     {
         uint2 e;
-        if (!DEEP || sp < sp_end) {
+        if (!DEEP || sp < kLdsEnd) {
             e = slot(st, sp);
         } else {
-            const uint32_t k = (uint32_t)(sp - sp_end) / (uint32_t)kRow;
+            const uint32_t k = (uint32_t)(sp - kLdsEnd) / (uint32_t)kRow;
             e                = deep[(size_t)(k < (uint32_t)kDeepStack ? k : (uint32_t)kDeepStack - 1u) * deep_stride];
         }
         top = e;
@@ -261,8 +276,7 @@ struct Traverser {
             hit_prim = hit_ent = -1;
             nodes_off = SPHERES ? sc.sphere_nodes_off : sc.scene_nodes_off;
             // stack.push(root, ray.tmin) on an empty stack: sentinel below, root on top
-            sp     = tid * (int)sizeof(uint2);
-            sp_end = sp + kLdsEnd;
+            sp = tid * (int)sizeof(uint2);
             slot(st, sp) = make_uint2(0u, igm_bits(kFltMax));
             top = make_uint2(1u, igm_bits(tmin_));
         }
@@ -310,6 +324,7 @@ struct Traverser {
         }
         while (work) {
             prof(11);
+            IG_MARK("settle.cull");
             // entries that start behind the current hit: a compare and a pop each
             for (;;) {
                 const mask_t cull = lanes_where(top.x != 0u) & lanes_where(!(igm_float(top.y) <= tmax)) & work & need_cull; // (one compare per ballot: a ballot of a conjunction is materialised first)
@@ -319,6 +334,7 @@ struct Traverser {
                     pop_top(st);
                 region_end();
             }
+            IG_MARK("settle.classify");
             const mask_t behind   = lanes_where(!(igm_float(top.y) <= tmax)) & work; // (possible only for lanes that were not culling)
             const mask_t sentinel = lanes_where(top.x == 0u) & work;
             const mask_t leaf     = lanes_where((int)top.x < 0) & work;
@@ -334,6 +350,7 @@ struct Traverser {
                 ent_cursor = in(ents) ? cursor : ent_cursor;
             }
             region_end();
+            IG_MARK("settle.ret");
             // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
             // accepted only if its (rounded) distance does not exceed the current one.
             bool accept = false;
@@ -361,6 +378,7 @@ struct Traverser {
             const mask_t next = (leaf & behind) | (on & ent_last);
             need_cull         = (need_cull & ~work) | next;
             work              = next;
+            IG_MARK("settle.end");
         }
     }
 
@@ -377,6 +395,7 @@ struct Traverser {
             region_end();
         }
         prof(3);
+        IG_MARK("leaf.scan");
         mask_t scanning  = here;
         mask_t to_settle = 0, to_tri = 0;
         // (the outer loop repeats only when a lane's one-leaf shape was missed inside its entity box and the run has leaves left,
@@ -386,6 +405,13 @@ struct Traverser {
             mask_t enter  = 0;
             int enter_at  = 0;
             int entity_id = 0;
+            float4 early[6]; // kLeafEarly: rows 2 - 7 of the leaf the scan looked at first
+            int early_at = -1;
+            if (kLeafEarly) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    early[k] = make_float4(0, 0, 0, 0);
+            }
             do {
                 prof(4);
                 bool inside = false, last = false;
@@ -400,6 +426,12 @@ struct Traverser {
 #pragma unroll
                     for (int k = 0; k < kScanLeaves; ++k)
                         lr[k][0] = ld16(ls, lsat, 2 * k), lr[k][1] = ld16(ls, lsat, 2 * k + 1);
+                    if (kLeafEarly && !SPHERES) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            early[k] = ld16(sc.leaves, (uint32_t)at * (uint32_t)(kDevLeafRows * 16), 2 + k);
+                        early_at = at;
+                    }
 #pragma unroll
                     for (int k = 0; k < kScanLeaves; ++k) {
                         if (k == 0 || (!inside & !last)) {
@@ -429,11 +461,18 @@ struct Traverser {
             } while (scanning);
             {
                 prof(5);
+                IG_MARK("leaf.enter");
                 bool missed = false, single = false, out = false, ok = false;
                 if (in(enter)) {
                     const void* lf      = SPHERES ? sc.sphere_leaves : sc.leaves;
                     const uint32_t lfat = (uint32_t)enter_at * (uint32_t)(kDevLeafRows * 16);
-                    const float4 l2 = ld16(lf, lfat, 2), l3 = ld16(lf, lfat, 3), l4 = ld16(lf, lfat, 4), l5 = ld16(lf, lfat, 5);
+                    float4 l2, l3, l4, l5, l6 = make_float4(0, 0, 0, 0), l7 = l6;
+                    const bool have_early = kLeafEarly && !SPHERES && enter_at == early_at;
+                    if (have_early) {
+                        l2 = early[0], l3 = early[1], l4 = early[2], l5 = early[3], l6 = early[4], l7 = early[5];
+                    } else {
+                        l2 = ld16(lf, lfat, 2), l3 = ld16(lf, lfat, 3), l4 = ld16(lf, lfat, 4), l5 = ld16(lf, lfat, 5);
+                    }
                     const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
                     m34 m;
                     m.c0 = f3{ l2.x, l2.y, l2.z };
@@ -489,7 +528,9 @@ struct Traverser {
                         // `ret` would have restored, i.e. as if the entity's box had rejected the ray, and the run is scanned on.
                         single = (ext.x & 1u) != 0;
                         if (single) {
-                            const float4 blo = ld16(lf, lfat, 6), bhi = ld16(lf, lfat, 7);
+                            float4 blo = l6, bhi = l7;
+                            if (!have_early)
+                                blo = ld16(lf, lfat, 6), bhi = ld16(lf, lfat, 7);
                             // (near / far plane by the sign of the inverse direction, as the inner-node section picks its rows)
                             const bool ox = inv.x < 0, oy = inv.y < 0, oz = inv.z < 0;
                             const float nx = ox ? bhi.x : blo.x, fx = ox ? blo.x : bhi.x;
@@ -547,7 +588,9 @@ struct Traverser {
         m_leaf &= ~here;
         m_tri |= to_tri;
         need_cull |= to_settle;
+        IG_MARK("leaf.settle");
         settle(sc, st, to_settle);
+        IG_MARK("leaf.end");
     }
 
     // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377); the lanes of m_node
@@ -555,6 +598,7 @@ struct Traverser {
     {
         const mask_t here = m_node;
         prof(6);
+        IG_MARK("node.half0");
         bool pushed = false, out = false;
         if (in(here)) {
             const uint32_t node_at = nodes_off + (top.x - 1u) * 256u; // byte offset of the Node8 inside geom
@@ -582,8 +626,10 @@ struct Traverser {
                 // list, mapping_cpu.art:357)
                 if (h == 1 && c4.x == 0)
                     break;
-                if (h == 1)
+                if (h == 1) {
                     prof(7);
+                    IG_MARK("node.half1");
+                }
                 const float4 nx = ld16(sc.geom, near_x, h), fx = ld16(sc.geom, far_x, h);
                 const float4 ny = ld16(sc.geom, near_y, h), fy = ld16(sc.geom, far_y, h);
                 const float4 nz = ld16(sc.geom, near_z, h), fz = ld16(sc.geom, far_z, h);
@@ -605,7 +651,7 @@ struct Traverser {
                         } else {
                             // (how far the node got, and whether that was too far, is read off the address once after the eight children)
                             sp += kRow;
-                            if (sp < sp_end)
+                            if (sp < kLdsEnd)
                                 slot(st, sp) = make_uint2((uint32_t)pn, igm_bits(pt));
                         }
                         if (front)
@@ -614,7 +660,7 @@ struct Traverser {
                 }
             }
             if (!DEEP)
-                out = sp >= sp_end; // out of stack: the ray ends here (see push_entry)
+                out = sp >= kLdsEnd; // out of stack: the ray ends here (see push_entry)
             pushed = sp != sp_before;
         }
         region_end();
@@ -622,7 +668,9 @@ struct Traverser {
         overflow |= o;
         need_cull |= live & ~lanes_where(pushed); // nothing pushed: cull (mapping_cpu.art:377)
         m_node = 0;
+        IG_MARK("node.settle");
         settle(sc, st, live);
+        IG_MARK("node.end");
     }
 
     // ---- the Tri4 packets of a leaf (mapping_cpu.art:379-410); the lanes of m_tri
@@ -635,6 +683,7 @@ struct Traverser {
         prof(8);
         do {
             prof(9);
+            IG_MARK("tri.half0");
             bool leave = false, found = false;
             if (in(work)) {
                 count_section(2);
@@ -644,20 +693,28 @@ struct Traverser {
                 // of 48, and the second half is not even fetched when the packet holds no more than two triangles
                 const int4 pid4  = ld16i(sc.geom, tri_at, 12);
                 const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
+                float4 call[2][6];
+                if (kTriFull) {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m)
+                        call[m / 6][m % 6] = ld16(sc.geom, tri_at, m);
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     // (valid triangles are packed from slot 0: the first -1 ends the packet, mapping_cpu.art:386; the first half comes
                     // with the ids)
                     if (h == 1 && (pid[2] == -1 || (ANY_HIT && found)))
                         break;
-                    if (h == 1)
+                    if (h == 1) {
                         prof(10);
+                        IG_MARK("tri.half1");
+                    }
                     // half h of the packet: 96 contiguous bytes, float 2 k + j = row k of triangle 2 h + j (igd_assign_scene re-orders the
                     // reference's Tri4 that way): six 16-byte loads per half
                     float4 c[6];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
-                        c[m] = ld16(sc.geom, tri_at, 6 * h + m);
+                        c[m] = kTriFull ? call[h][m] : ld16(sc.geom, tri_at, 6 * h + m);
                     float q[12][2];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
@@ -689,7 +746,9 @@ struct Traverser {
         } while (work);
         m_tri = 0;
         need_cull |= here;
+        IG_MARK("tri.settle");
         settle(sc, st, here);
+        IG_MARK("tri.end");
     }
 
     // One pipeline pass: entity leaf -> inner node -> triangle packet. The whole wave calls it; lanes without a ray are in no mask.
@@ -698,6 +757,7 @@ struct Traverser {
         // Postponing: a section runs only when enough lanes of the wave want it (they wait in their mode until
         // then), so the wave does not pay a whole section for a handful of lanes. If no section reaches the
         // quorum the threshold drops to one lane for this pass, which guarantees progress.
+        IG_MARK("pass.quorum");
         int quorum = 1;
         if (kPostponeShift > 0) {
             const int n_ent = lanes_in(m_leaf), n_node = lanes_in(m_node), n_tri = lanes_in(m_tri);
