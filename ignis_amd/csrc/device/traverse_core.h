@@ -630,14 +630,19 @@ struct Traverser {
                     prof(7);
                     IG_MARK("node.half1");
                 }
-                const float4 nx = ld16(sc.geom, near_x, h), fx = ld16(sc.geom, far_x, h);
-                const float4 ny = ld16(sc.geom, near_y, h), fy = ld16(sc.geom, far_y, h);
-                const float4 nz = ld16(sc.geom, near_z, h), fz = ld16(sc.geom, far_z, h);
+                // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
+                // between is materialised as a 64-bit pointer per lane)
+                const uint32_t hb = 16u * (uint32_t)h;
+                const float4 nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
+                const float4 ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
+                const float4 nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
                 const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
                 const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
                 const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    // (v_pk_fma_f32 for two children at once measured no faster: it issues like two fmas, and half of the scalar
+                    // operands end up in register pairs built with v_mov; profiles/r04_experiment_ab.txt)
                     const float entry = igm_max(igm_max(igm_fma(inv.x, nb[0][i], io.x), igm_fma(inv.y, nb[1][i], io.y)), igm_max(igm_fma(inv.z, nb[2][i], io.z), tmin));
                     const float exit  = igm_min(igm_min(igm_fma(inv.x, fb[0][i], io.x), igm_fma(inv.y, fb[1][i], io.y)), igm_min(igm_fma(inv.z, fb[2][i], io.z), tmax));
                     const bool hit    = (ch[i] != 0) & !(exit < entry);
