@@ -1314,8 +1314,14 @@ void render(igd_device* d, const igd_render_settings* rs)
     }
 
     d->fb_host_dirty = true;
-    for (int64_t first = 0; first < total; first += chunk_rays) {
-        const uint32_t n = (uint32_t)std::min<int64_t>(chunk_rays, total - first);
+    int64_t step = 0;
+    for (int64_t first = 0; first < total; first += step) {
+        step = std::min<int64_t>(chunk_rays, total - first);
+        // the photon mapper: a chunk ends at its iteration's end even when the capacity does not divide an iteration — each iteration
+        // has its own photon map and merge radius, and its light pass runs in front of the chunk that starts it
+        if (ppm && per_it > 0)
+            step = std::min<int64_t>(step, per_it - first % per_it);
+        const uint32_t n = (uint32_t)step;
 
         // this chunk's flight slot: wait (host side) until the chunk n_flights back has left it
         const int slot         = (int)(d->chunk_seq % (uint64_t)d->n_flights);

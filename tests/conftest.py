@@ -32,10 +32,24 @@ def diamond_scene():
     return LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 128, 128)
 
 
-@pytest.fixture(scope="session")
-def gpu_device():
+@pytest.fixture(scope="session", params=["tail", "rounds"])
+def gpu_device(request):
+    """The device every feature-parity test renders on, in two schedules. "tail": the product's default — a
+    stream of <= 1 Mi paths is handed to k_tail before round 0, which is where every small-film test ends up. "rounds":
+    IGD_TAIL_THRESHOLD=0, the same test through the wavefront kernels the benchmark runs (k_shade + k_traverse rounds to the
+    last path). The schedule is read when the device is created."""
     from ignis_amd import Device
-    dev = Device(0, acquire_stats=True)
+    old = os.environ.get("IGD_TAIL_THRESHOLD")
+    if request.param == "rounds":
+        os.environ["IGD_TAIL_THRESHOLD"] = "0"
+    try:
+        dev = Device(0, acquire_stats=True)
+    finally:
+        if request.param == "rounds":
+            if old is None:
+                del os.environ["IGD_TAIL_THRESHOLD"]
+            else:
+                os.environ["IGD_TAIL_THRESHOLD"] = old
     yield dev
     dev.close()
 

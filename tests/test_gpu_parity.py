@@ -411,6 +411,33 @@ def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances, widt
     assert tot["camera_rays"] == width * height * spi * iters
 
 
+def test_config5_film_shape_4096_rows_of_rank0_of_8(tmp_path):
+    """configs[4]'s shape (asset absent: the seeded stand-in): a 4096 x 4096 film, the rows rank 0 of 8 owns (row_offset 0,
+    row_stride 8: 512 rows = 2 Mi camera paths, twice the tail threshold, so wavefront rounds and the tail both run), one
+    iteration. Owned rows, counters and — rows of other ranks — untouched pixels against the oracle's rendering of the same rows."""
+    from ignis_amd import Device
+    from ignis_amd.tables import LoadedScene
+    import subprocess, sys
+    import oracle
+    w = h = 4096
+    tool = os.path.join(os.path.dirname(SCENES), "tools", "make_standin_scene.py")
+    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", "1000000", "--instances", "96", "--seed", "7", "--width", str(w), "--height", str(h)],
+                   check=True, capture_output=True)
+    sc = LoadedScene.from_file(str(tmp_path / "standin.json"), w, h)
+    dev = Device(0, acquire_stats=True)
+    fb, st = _render_gpu(dev, sc, 1, w, h, seed=5, row_offset=0, row_stride=8)
+    dev.close()
+    ref, tot = oracle.render(sc, 1, w, h, iteration=0, seed=5, rows=(0, 8))
+    assert tot["camera_rays"] == w * (h // 8) and st["camera_rays"] == tot["camera_rays"]
+    assert _rel_l2(fb[0::8], ref[0::8]) <= RADIANCE_TOL
+    others = np.ones(h, bool)
+    others[0::8] = False
+    assert not fb[others].any() and not ref[others].any()
+    for k in ("bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+        assert st[k] == tot[k], k
+    assert st["rounds"] > 0 and st["tail_rays"] > 0  # both halves of the scheduler took part
+
+
 def test_registry_parameters_camera_and_technique(gpu_device):
     """IRenderDevice::render's ParameterSet: __camera_eye/dir/up and __tech_max_depth take effect on the next
     iteration and give bit-identical images to a scene file that says the same thing."""
@@ -1174,7 +1201,7 @@ def test_config1_diamond_scene_512_spi4(gpu_device):
 
 
 def test_config4_many_point_lights_1080p_full_size(gpu_device):
-    """configs[3] at its named size (the procedural sky replaced by a constant environment)."""
+    """configs[3] at its named size: scenes/many_point_lights.json as the reference holds it (Hosek-Wilkie sky included)."""
     scene = _many_lights_scene(1920, 1080)
     _compare_with_oracle(gpu_device, scene, 1920, 1080, 8, seed=1)
 

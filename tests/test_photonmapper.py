@@ -122,7 +122,7 @@ def test_oracle_photon_mapper_agrees_with_the_path_tracer_where_the_encoding_let
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("photons,spi", [(50000, 4), (400, 2)])
-def test_photon_mapper_vs_oracle(gpu_device, photons, spi):
+def test_photon_mapper_vs_oracle(photons, spi):
     """Light pass, grid and camera pass on the GPU: photons land in the slot of their light path and are gathered in (cell, index)
     order, as in the oracle, so the image agrees like any other technique's."""
     from ignis_amd import Device
@@ -142,3 +142,27 @@ def test_photon_mapper_vs_oracle(gpu_device, photons, spi):
     assert ref.max() > 0
     assert float(np.linalg.norm(got - ref) / np.linalg.norm(ref)) <= 1e-4
     assert (ds["camera_rays"], ds["bounce_rays"], ds["shadow_rays"]) == (cam, bounce, 0)
+
+
+@pytest.mark.gpu
+def test_photon_mapper_chunks_end_at_iteration_boundaries():
+    """A stream capacity that does not divide an iteration (96 x 72 x 2 = 13 824 rays, capacity 5 000) and three iterations in one
+    call: every iteration must get its own light pass and merge radius, i.e. the image of three single-iteration calls on a
+    device whose streams hold a whole iteration (chunks used to start at 0, 5 000, 10 000, 15 000 ... so no chunk started
+    at 13 824 and iterations 1 and 2 were rendered with iteration 0's photon map)."""
+    from ignis_amd import Device
+    sc = _scene({"type": "ppm", "max_depth": 8, "photons": 20000, "radius": 0.02}, 96, 72)
+    whole = Device(0, acquire_stats=True)
+    whole.assign_scene(sc)
+    for it in range(3):
+        whole.render(2, 96, 72, iteration=it, seed=4)
+    want, want_st = whole.framebuffer(), whole.stats()
+    whole.close()
+    small = Device(0, acquire_stats=True, stream_capacity=5000)
+    small.assign_scene(sc)
+    small.render(2, 96, 72, iteration=0, seed=4, iterations=3)
+    got, got_st = small.framebuffer(), small.stats()
+    small.close()
+    np.testing.assert_array_equal(got, want)
+    for k in ("camera_rays", "bounce_rays", "shadow_rays"):
+        assert got_st[k] == want_st[k], k
