@@ -1,5 +1,6 @@
 #include "bvh.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #include <algorithm>
@@ -213,6 +214,202 @@ Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers,
 
     bvh.prim_ids = builder.prim_ids[0];
     return bvh;
+}
+
+// ---------------------------------------------------------------- reinsertion optimiser
+//
+// What bvh::v2::DefaultBuilder runs after the sweep at its default quality (High): Meister & Bittner, "Parallel Reinsertion for
+// Bounding Volume Hierarchy Optimization" (Eurographics 2018), in the batched sequential form — per iteration the nodes with
+// the largest surface area (a fixed share of the tree) each look for the position that shrinks the tree's summed area most
+// when the node's subtree is cut out and hung in there, the candidates are applied in order of gain, and a move that touches a
+// node an earlier move of the iteration touched is skipped. The search for one node is branch and bound: going up from the
+// node's parent it keeps what removing the node has saved so far, and descends into each sibling subtree on the way only
+// while that bound can still beat the best position found. Leaves keep their primitive ranges; only inner structure changes.
+namespace {
+
+struct Reinserter {
+    std::vector<Bvh2Node>& nodes;
+    std::vector<uint32_t> parent;
+
+    explicit Reinserter(Bvh2& bvh)
+        : nodes(bvh.nodes)
+        , parent(bvh.nodes.size(), 0)
+    {
+        for (uint32_t i = 0; i < (uint32_t)nodes.size(); ++i)
+            if (!nodes[i].isLeaf())
+                parent[nodes[i].first] = parent[nodes[i].first + 1] = i;
+    }
+
+    // (the root is node 0 and every split appends its two children together: pairs start at odd indices)
+    static uint32_t siblingOf(uint32_t i) { return (i & 1u) ? i + 1 : i - 1; }
+    float areaOf(uint32_t i) const { return getBounds(nodes[i]).halfArea(); }
+
+    struct Move {
+        uint32_t from = 0, to = 0;
+        float gain = 0;
+    };
+
+    Move bestMove(uint32_t node) const
+    {
+        Move best;
+        best.from              = node;
+        const BBox node_box    = getBounds(nodes[node]);
+        const float node_area  = node_box.halfArea();
+        const uint32_t up      = parent[node];
+        float saved            = areaOf(up); // the parent disappears: its sibling child takes its place
+        uint32_t side          = siblingOf(node);
+        BBox shrunk            = getBounds(nodes[side]); // box of the ancestor reached so far, without `node`
+        uint32_t pivot         = up;
+        std::vector<std::pair<float, uint32_t>> open;
+        do {
+            // positions inside the subtree that hangs beside the path at this height
+            open.emplace_back(saved, side);
+            while (!open.empty()) {
+                const auto [bound, at] = open.back();
+                open.pop_back();
+                if (bound - node_area <= best.gain)
+                    continue; // even a position whose box already holds `node` could not beat the best
+                const Bvh2Node& dst = nodes[at];
+                BBox merged         = getBounds(dst);
+                merged.extend(node_box);
+                const float here = bound - merged.halfArea(); // new parent of {dst, node} at dst's place
+                if (here > best.gain) {
+                    best.to   = at;
+                    best.gain = here;
+                }
+                if (!dst.isLeaf()) {
+                    const float below = here + getBounds(dst).halfArea(); // dst grows to `merged` instead of getting a new parent
+                    open.emplace_back(below, dst.first);
+                    open.emplace_back(below, dst.first + 1);
+                }
+            }
+            // one level up: that ancestor shrinks to what is left below it
+            if (pivot != up) {
+                shrunk.extend(getBounds(nodes[side]));
+                saved += areaOf(pivot) - shrunk.halfArea();
+            }
+            side  = siblingOf(pivot);
+            pivot = parent[pivot];
+        } while (pivot != 0);
+        if (best.to == siblingOf(best.from) || best.to == parent[best.from])
+            return Move{}; // the same tree
+        return best;
+    }
+
+    void refitFrom(uint32_t i)
+    {
+        do {
+            Bvh2Node& n = nodes[i];
+            if (!n.isLeaf()) {
+                BBox b = getBounds(nodes[n.first]);
+                b.extend(getBounds(nodes[n.first + 1]));
+                setBounds(n, b);
+            }
+            i = parent[i];
+        } while (i != 0);
+    }
+
+    // cut `from` out (its sibling moves into the parent's slot) and hang it beside `to`: the freed pair of slots {from, sibling} holds
+    // `from` and the old `to`, the slot of `to` becomes their parent
+    void apply(const Move& m)
+    {
+        const uint32_t sib = siblingOf(m.from), up = parent[m.from];
+        const Bvh2Node moved_sibling = nodes[sib], target = nodes[m.to];
+        nodes[m.to].first      = std::min(m.from, sib);
+        nodes[m.to].prim_count = 0;
+        nodes[sib]             = target;
+        nodes[up]              = moved_sibling;
+        if (!target.isLeaf())
+            parent[target.first] = parent[target.first + 1] = sib;
+        if (!moved_sibling.isLeaf())
+            parent[moved_sibling.first] = parent[moved_sibling.first + 1] = up;
+        parent[sib]    = m.to;
+        parent[m.from] = m.to;
+        refitFrom(m.to);
+        refitFrom(up);
+    }
+
+    void run(float batch_ratio, int iterations)
+    {
+        const size_t count = nodes.size();
+        if (count < 4)
+            return;
+        const size_t batch = std::max<size_t>(1, (size_t)((float)count * batch_ratio));
+        std::vector<uint32_t> order(count - 1);
+        std::vector<float> area(count);
+        std::vector<Move> moves;
+        std::vector<char> touched(count);
+        for (int it = 0; it < iterations; ++it) {
+            // the `batch` nodes of largest area (never the root)
+            for (uint32_t i = 0; i < (uint32_t)count; ++i)
+                area[i] = areaOf(i);
+            for (uint32_t i = 1; i < (uint32_t)count; ++i)
+                order[i - 1] = i;
+            const size_t take = std::min(batch, order.size());
+            std::partial_sort(order.begin(), order.begin() + (ptrdiff_t)take, order.end(), [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); });
+            moves.clear();
+            for (size_t k = 0; k < take; ++k) {
+                const Move m = bestMove(order[k]);
+                if (m.gain > 0)
+                    moves.push_back(m);
+            }
+            std::stable_sort(moves.begin(), moves.end(), [](const Move& a, const Move& b) { return a.gain > b.gain; });
+            std::fill(touched.begin(), touched.end(), 0);
+            size_t applied = 0;
+            double promised = 0;
+            for (const Move& m : moves) {
+                const uint32_t involved[5] = { m.to, m.from, siblingOf(m.from), parent[m.to], parent[m.from] };
+                bool clash = false;
+                for (uint32_t i : involved)
+                    clash |= touched[i] != 0;
+                if (clash)
+                    continue;
+                for (uint32_t i : involved)
+                    touched[i] = 1;
+                apply(m);
+                ++applied;
+                promised += m.gain;
+            }
+            if (std::getenv("IGH_BVH_DEBUG")) {
+                double inner = 0;
+                for (const Bvh2Node& n : nodes)
+                    if (!n.isLeaf())
+                        inner += getBounds(n).halfArea();
+                std::fprintf(stderr, "reinsertion pass %d: %zu of %zu nodes looked at, %zu moves found, %zu applied (gain %.6g), inner area now %.6g\n", it, take, count, moves.size(), applied, promised, inner);
+            }
+        }
+    }
+};
+
+} // namespace
+
+float bvh2_sah_cost(const Bvh2& bvh)
+{
+    // SAH cost with unit node and primitive costs, relative to the root's area
+    double cost = 0;
+    for (const Bvh2Node& n : bvh.nodes)
+        cost += (double)getBounds(n).halfArea() * (n.isLeaf() ? (double)n.prim_count : 1.0);
+    return (float)(cost / (double)getBounds(bvh.nodes[0]).halfArea());
+}
+
+void optimize_bvh2(Bvh2& bvh)
+{
+    // defaults of bvh::v2::ReinsertionOptimizer::Config (batch_size_ratio 0.05, max_iter_count 3); IGH_BVH_REINSERT=0 switches the pass off,
+    // IGH_BVH_REINSERT_ITERS / IGH_BVH_REINSERT_RATIO override (experiments, tools/bvh_stats.py)
+    int iterations = 3;
+    float ratio    = 0.05f;
+    if (const char* e = std::getenv("IGH_BVH_REINSERT"))
+        if (std::atoi(e) == 0)
+            return;
+    if (const char* e = std::getenv("IGH_BVH_REINSERT_ITERS"))
+        iterations = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("IGH_BVH_REINSERT_RATIO"))
+        ratio = std::min(1.0f, std::max(0.0f, (float)std::atof(e)));
+    Reinserter(bvh).run(ratio, iterations);
+    // the builder's convention again (largest-area child first: the order any-hit queries visit the children in), which the moves do not keep
+    for (Bvh2Node& n : bvh.nodes)
+        if (!n.isLeaf() && getBounds(bvh.nodes[n.first]).halfArea() < getBounds(bvh.nodes[n.first + 1]).halfArea())
+            std::swap(bvh.nodes[n.first], bvh.nodes[n.first + 1]);
 }
 
 // ---------------------------------------------------------------- N-ary collapse
@@ -559,7 +756,8 @@ void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vect
     size_t max_leaf = 8;
     if (const char* e = std::getenv("IGH_MAX_LEAF"))
         max_leaf = (size_t)std::max(1, std::atoi(e)); // experiments
-    const Bvh2 bvh2 = build_bvh2(bboxes, centers, std::max<size_t>(max_leaf, min_leaf), referenceCollapse() ? 1 : min_leaf);
+    Bvh2 bvh2 = build_bvh2(bboxes, centers, std::max<size_t>(max_leaf, min_leaf), referenceCollapse() ? 1 : min_leaf);
+    optimize_bvh2(bvh2);
 
     adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
         nodes[parent].child[child] = ~(int32_t)tris.size();
@@ -604,7 +802,8 @@ void build_scene_bvh8(const std::vector<EntityObject>& objs, std::vector<ig_node
     size_t max_leaf = referenceCollapse() ? 8 : 2;
     if (const char* e = std::getenv("IGH_SCENE_MAX_LEAF"))
         max_leaf = (size_t)std::max(1, std::atoi(e));
-    const Bvh2 bvh2 = build_bvh2(bboxes, centers, max_leaf);
+    Bvh2 bvh2 = build_bvh2(bboxes, centers, max_leaf);
+    optimize_bvh2(bvh2);
 
     adapt(nodes, bvh2, [&](const NBvh& bvh, const NNode& node, size_t parent, size_t child) {
         nodes[parent].child[child] = ~(int32_t)leaves.size();

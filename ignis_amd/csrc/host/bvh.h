@@ -6,9 +6,11 @@
 // sites src/runtime/bvh/TriBVHAdapter.h:216-220, SceneBVHAdapter.h:122-126 --
 // the `config` object built there is never passed, so library defaults apply:
 // sweep-SAH, min_leaf_size 1, max_leaf_size 8, cost_ratio 1). The library is
-// not available here, so its published top-down sweep-SAH algorithm is
-// restated; its post-build reinsertion optimiser is not. Tree topology is
-// therefore "parity unpinned" (the reference has no test that inspects it).
+// not available here, so its published algorithms are restated: the top-down
+// sweep-SAH build and the reinsertion optimiser DefaultBuilder runs behind it
+// at its default quality (Meister & Bittner 2018). Tree topology is "parity
+// unpinned" all the same (the reference has no test that inspects it, and the
+// dependency is pinned to a moving branch).
 //
 // Since the topology cannot be matched anyway, the default build is tuned for the <8,4> layout (bvh.cpp): triangle
 // leaves are at least one full Tri4 packet and the N-ary collapse opens children by surface area until a node has
@@ -44,6 +46,10 @@ struct Bvh2 {
 };
 
 Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers, size_t max_leaf_size = 8, size_t min_leaf_size = 1);
+// The reinsertion pass DefaultBuilder runs after the sweep at quality High (bvh.cpp); in place.
+void optimize_bvh2(Bvh2& bvh);
+// Sum over the nodes of area x (1 | primitives), relative to the root's area
+float bvh2_sah_cost(const Bvh2& bvh);
 
 // Triangle BVH of a mesh in the reference's <8,4> layout.
 void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vector<ig_tri4>& tris);
