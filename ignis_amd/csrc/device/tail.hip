@@ -79,7 +79,21 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         return;
     }
 
+#ifdef IG_TAIL_CLOCKS
+    // where a tail wave's cycles go (variant build, tools/tail_clocks.py): shader clock around the parts of a bounce, memory drained first
+    unsigned long long tclk[6] = { 0, 0, 0, 0, 0, 0 }, tclk_last = __builtin_readcyclecounter();
+#define TAIL_MARK(k)                                                    \
+    do {                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        tclk[k] += now_ - tclk_last;                                    \
+        tclk_last = now_;                                               \
+    } while (0)
+#else
+#define TAIL_MARK(k) ((void)0)
+#endif
     for (;;) {
+        TAIL_MARK(4); // loop, spill of long paths
         const unsigned long long idle = __ballot(!have);
         const int n_idle              = __popcll(idle);
         const int want                = cap - (64 - n_idle); // paths this wave may add to the ones it follows
@@ -122,14 +136,20 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             break;
 
         // (the traversals are called by the whole wave with the mask of the lanes that take part, traverse_core.h; shading sits under `have`)
+        TAIL_MARK(0); // refill
         const mask_t have_m = lanes_where(have);
         {
             Traverser<false, STATS, kTailBlock, true> tr;
             tr.init_counters();
             tr.attach_deep(deep_col, sc.deep_stride);
             tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
-            while (tr.active())
+            while (tr.active()) {
                 tr.step(sc, s_stack, tid);
+#ifdef IG_TAIL_CLOCKS
+                tclk[5] += 1; // passes of the closest-hit traversal
+#endif
+            }
+            TAIL_MARK(1); // closest-hit traversal
             if (have) {
                 in.ent  = tr.hit_ent;
                 in.prim = tr.hit_prim;
@@ -175,6 +195,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             }
         }
         region_end();
+        TAIL_MARK(2); // shading
 
         const bool shadow     = have && out.shadow;
         const mask_t shadow_m = lanes_where(shadow);
@@ -223,6 +244,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             region_end();
         }
 
+        TAIL_MARK(3); // any-hit traversal + splat
         if (have) {
             if (!out.bounce) {
                 a.accum[(int64_t)in.ray_id - a.id_base] = acc;
@@ -267,6 +289,16 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
 
     if (overflow)
         atomicOr(&a.qs->error_flags, 1u);
+#ifdef IG_TAIL_CLOCKS
+    // one pass is reported per build (-DIG_TAIL_CLOCKS=<pass index>): sums over the waves that took part, their count and the longest
+    // wave's total, in the section counters' words
+    if (lane == 0 && a.pass == IG_TAIL_CLOCKS) {
+        for (int k = 0; k < 6; ++k)
+            atomicAdd(&a.qs->section_passes[k], tclk[k]);
+        atomicAdd(&a.qs->section_lanes[0], 1ull);
+        atomicMax(&a.qs->section_lanes[1], tclk[0] + tclk[1] + tclk[2] + tclk[3] + tclk[4]);
+    }
+#endif
 
     const uint32_t b = wave_sum_u32(c_bounce), s = wave_sum_u32(c_shadow), u = wave_sum_u32(c_unoccluded);
     if (lane == 0) {

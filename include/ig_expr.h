@@ -169,7 +169,7 @@ IGM_FN float ige_pick(const ige_v4& v, uint32_t k) { return k == 0 ? v.v[0] : (k
 /* The register file of a run. A plain array wherever private memory is cheap (host, oracle); the kernels hand in one that lives
  * in LDS (`r[i]` = element i of a lane's column), because registers named by the program are indexed dynamically and a private
  * array would be scratch memory. */
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define IGE_MEMBER __host__ __device__
 #else
 #define IGE_MEMBER
