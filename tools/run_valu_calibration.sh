@@ -8,13 +8,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 BIN=$ROOT/ignis_amd/lib/valu_calibration
-[ -x "$BIN" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/valu_calibration.hip -o "$BIN"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/valu_calibration.hip -o "$BIN"
 F=$OUT/${TAG}_valu_calibration.txt
 {
   echo "## tools/valu_calibration.hip on $(/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"
-  timeout 300 "$BIN"
+  timeout 60 "$BIN"
 } > "$F" 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/cal_pmc" -o pmc -- "$BIN" > "$OUT/cal_pmc.out" 2> "$OUT/cal_pmc.err"
+timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/cal_pmc" -o pmc -- "$BIN" > "$OUT/cal_pmc.out" 2> "$OUT/cal_pmc.err"
 python - "$OUT" >> "$F" <<'PY'
 import sqlite3, sys, glob
 dbs = glob.glob(sys.argv[1] + "/cal_pmc/**/*.db", recursive=True)
