@@ -35,9 +35,17 @@ SCENE = os.path.join(ROOT, "scenes", "diamond_scene.json")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
 VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
-VALU_CYCLES_PER_INST = 3.5  # profiles/r03_valu_calibration.txt: 2.4 (2-source fp32 / logic) ... 4.4 (min / max / compare / 3-source), k_traverse's mix
 SHADER_GHZ = 2.1            # effective shader clock of the traversal launches (GRBM_GUI_ACTIVE / duration; 2.4 GHz is the boost limit)
-PROFILE_TAG = "r03"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+PROFILE_TAG = "r04"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+
+
+def valu_cycles_per_inst():
+    """SIMD cycles one wave64 VALU instruction of k_traverse<closest> occupies on average: the kernel's dynamic opcode histogram (static
+    counts of its parts x how often each runs, scaled to the measured SQ_INSTS_VALU) x the calibrated price of each opcode class —
+    profiles/<tag>_issue_accounting.json, written by tools/issue_accounting.py from profiles/<tag>_valu_calibration.txt,
+    _trav_events_closest.json and _traffic.json. None when that file is missing (the `valu.issue_frac` field is then left out)."""
+    p = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_issue_accounting.json")
+    return json.load(open(p))["valu_cycles_per_inst"] if os.path.exists(p) else None
 DEFAULT_STEPS = 256
 
 
@@ -248,13 +256,14 @@ def main():
                                "wave_issue_share": tk.get("wave_issue_share"), "source": f"profiles/{tname} (SQ counters)"}
                 if tk.get("valu_lane_ops_per_launch"):
                     # VALU line: wave64 VALU instructions per second against the issue slots of 1024 SIMDs; a slot is priced at the 2.4 - 4.4
-                    # cycles profiles/r03_valu_calibration.txt measured (3.5 for this kernel's mix of selects, compares, min / max and fma)
+                    # cycles profiles/r04_valu_calibration.txt measured, weighted with the kernel's dynamic opcode histogram (valu_cycles_per_inst())
                     insts = tk["valu_insts_per_launch"] * scale
                     g = tk["valu_lane_ops_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
+                    cpi = valu_cycles_per_inst()
                     valu = {"achieved": round(g, 1), "peak": round(VALU_PEAK_GLANE_OPS, 1), "unit": "G lane-ops/s", "frac": round(g / VALU_PEAK_GLANE_OPS, 4),
                             "insts_per_ray": round(insts * 64.0 / rays_per_launch, 1),
-                            "issue_frac": round(insts * VALU_CYCLES_PER_INST / (1024 * SHADER_GHZ * 1e9 * avg_ms * 1e-3), 4),
-                            "issue_frac_note": f"{VALU_CYCLES_PER_INST} cycles per wave64 instruction (calibrated mix), {SHADER_GHZ} GHz under load",
+                            "issue_frac": round(insts * cpi / (1024 * SHADER_GHZ * 1e9 * avg_ms * 1e-3), 4) if cpi else None,
+                            "issue_frac_note": f"{cpi} cycles per wave64 instruction (profiles/{PROFILE_TAG}_issue_accounting.json: dynamic opcode histogram x calibrated prices), {SHADER_GHZ} GHz under load",
                             "source": f"profiles/{tname}"}
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,

@@ -34,6 +34,20 @@ db() { find "$OUT/$1" -name "*.db" | head -1; }
 python tools/prof_summary.py stats "$(db stats$SUF)" > "$OUT/${TAG}_rocprofv3_stats$SUF.txt" 2>> "$OUT/summary.err"
 python tools/prof_summary.py pmc "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$(db pmc_MEM$SUF)" > "$OUT/${TAG}_rocprofv3_pmc$SUF.txt" 2>> "$OUT/summary.err"
 python tools/prof_summary.py traffic "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$STEPS" "$OUT/${TAG}_bench$SUF.json" > "$OUT/${TAG}_traffic$SUF.json" 2>> "$OUT/summary.err"
+if [ -z "$SUF" ]; then
+  # the issue accounting of the closest-hit traversal kernel (tools/issue_accounting.py): event counts of the profile build, the calibration,
+  # then the traffic summary once more so that its valu_issue_frac is priced with the derived cycles per instruction
+  V=$ROOT/ignis_amd/lib/var
+  if [ -f "$V/libig_device_hip_tprof1.so" ]; then
+    mkdir -p "$ROOT/profiles"
+    IGD_LIBRARY=$V/libig_device_hip_tprof1.so python tools/trav_events.py > "$OUT/${TAG}_trav_events_closest.json" 2>> "$OUT/summary.err"
+    IGD_LIBRARY=$V/libig_device_hip_tprof2.so python tools/trav_events.py > "$OUT/${TAG}_trav_events_any.json" 2>> "$OUT/summary.err"
+    [ -f "$ROOT/profiles/${TAG}_valu_calibration.txt" ] || timeout 240 bash tools/run_valu_calibration.sh "$TAG" > /dev/null 2>&1
+    for f in trav_events_closest.json traffic.json rocprofv3_pmc.txt valu_calibration.txt; do [ -f "$OUT/${TAG}_$f" ] && cp "$OUT/${TAG}_$f" "$ROOT/profiles/${TAG}_$f"; done
+    python tools/issue_accounting.py "$TAG" > /dev/null 2>> "$OUT/summary.err" && cp "$ROOT/profiles/${TAG}_issue_accounting.json" "$OUT/"
+    python tools/prof_summary.py traffic "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$STEPS" "$OUT/${TAG}_bench$SUF.json" > "$OUT/${TAG}_traffic$SUF.json" 2>> "$OUT/summary.err"
+  fi
+fi
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT" | head -40
 tail -c 400 "$OUT/${TAG}_bench$SUF.json"

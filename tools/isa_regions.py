@@ -1,7 +1,7 @@
 """Static instructions per part of k_traverse, from an assembly built with -DIG_ISA_MARKS (comment lines `; @@ name` at the
 borders of the parts, traverse_core.h IG_MARK). Instructions are attributed to the last mark seen in layout order; the hot
 loop is laid out in source order, cold blocks the compiler moved are attributed to whatever precedes them (small).
-usage: python tools/isa_regions.py [any|closest] [-D...]"""
+usage: python tools/isa_regions.py [any|closest] [--json] [-D...]      (--json: opcode counts per part, for tools/issue_accounting.py)"""
 import collections
 import os
 import re
@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wno-everything".split()
 which = "closest"
 extra = []
+as_json = False
 for a in sys.argv[1:]:
     if a in ("any", "closest"):
         which = a
+    elif a == "--json":
+        as_json = True
     else:
         extra.append(a)
 with tempfile.TemporaryDirectory() as tmp:
@@ -29,6 +32,7 @@ body = m.group(0)
 cur = "prologue"
 order = []
 cnt = collections.OrderedDict()
+ops_by_part = collections.OrderedDict()
 for line in body.split("\n"):
     mm = re.match(r"\s*; @@ (\S+)", line)
     if mm:
@@ -37,6 +41,7 @@ for line in body.split("\n"):
     mm = re.match(r"^\s+([a-z_0-9]+)(\s|$)", line)
     if mm and not line.strip().startswith((".", ";")):
         op = mm.group(1)
+        ops_by_part.setdefault(cur, collections.Counter())[op] += 1
         c = cnt.setdefault(cur, collections.Counter())
         kind = "valu" if op.startswith("v_") else "salu" if op.startswith("s_") and not op.startswith(("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_load", "s_endpgm")) else \
             "vmem" if op.startswith(("global_", "buffer_", "flat_")) else "lds" if op.startswith("ds_") else "other"
@@ -45,6 +50,10 @@ for line in body.split("\n"):
             c["cndmask"] += 1
         if op.startswith("v_mov"):
             c["mov"] += 1
+if as_json:
+    import json
+    print(json.dumps({"kernel": f"k_traverse<{which}>", "parts": {k: dict(v) for k, v in ops_by_part.items()}}))
+    sys.exit(0)
 print(f"# k_traverse<{which}>: static instructions by part (layout order)")
 print(f"{'part':18s} {'valu':>5s} {'salu':>5s} {'vmem':>5s} {'lds':>4s} {'other':>5s} {'cndmask':>7s} {'mov':>4s}")
 tot = collections.Counter()

@@ -11,6 +11,7 @@ what it writes (68 B per path, 16 B/lane coalesced loads) and FETCH_SIZE shows e
 the x2 correction MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 applies to our stream reads.
 """
 import json
+import os
 import sqlite3
 import sys
 
@@ -76,12 +77,21 @@ def traffic(fetch_db, write_db, sq_db=None, steps=None, bench_json=None):
                 # VALU line: wave-instructions issued x 64 lanes = issue slots used; x lane utilisation = lane operations that did work.
                 # Peak: 256 CUs x 4 SIMDs x 32 lanes per cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz.
                 lanes = q["SQ_INSTS_VALU"]["mean"] * 64.0
+                cycles_per_inst = 2.0
+                if bench_json:
+                    acc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.path.basename(bench_json).split("_")[0] + "_issue_accounting.json")
+                    if os.path.exists(acc):
+                        cycles_per_inst = json.load(open(acc))["valu_cycles_per_inst"]
                 util = res["kernels"][short(k)]["valu_lane_utilisation"]
                 secs = q["SQ_INSTS_VALU"]["avg_ns"] * 1e-9
                 peak = 256 * 4 * 32 * 2.4e9
                 res["kernels"][short(k)]["valu_insts_per_launch"] = int(q["SQ_INSTS_VALU"]["mean"])
                 res["kernels"][short(k)]["valu_lane_ops_per_launch"] = int(lanes * util)
-                res["kernels"][short(k)]["valu_issue_frac"] = round(lanes / secs / peak, 4) if secs > 0 else None
+                # issue share: instructions x the mix's cycles per instruction (profiles/<tag>_issue_accounting.json, tools/issue_accounting.py: the
+                # closest-hit traversal kernel's dynamic opcode histogram x calibrated prices) against 1024 SIMDs at the clock under load —
+                # the same formula and the same price bench.py uses. Without that file: 2 cycles per instruction (the guide's v_fma_f32).
+                res["kernels"][short(k)]["valu_issue_frac"] = round(q["SQ_INSTS_VALU"]["mean"] * cycles_per_inst / (1024 * 2.1e9 * secs), 4) if secs > 0 else None
+                res["kernels"][short(k)]["valu_issue_frac_cycles_per_inst"] = cycles_per_inst
                 res["kernels"][short(k)]["avg_ns_under_pmc"] = int(q["SQ_INSTS_VALU"]["avg_ns"])
     # per-ray figures of the closest-hit traversal kernel, so that bench.py can scale them to whatever step count it is run with
     # (the driver's --steps differs from the profiled one): rays per launch of the profiled command from its own bench line
