@@ -276,3 +276,8 @@ def cdf2d(table, size_x, size_y, mode, u):
 
 def hardware_threads():
     return int(lib().oracle_hardware_threads())
+
+
+def set_ppm_sound_directions(on):
+    """ORACLE-ONLY experiment switch (oracle.cpp): photon directions through a sound snorm16 pair instead of encode_normal_32 as written."""
+    lib().oracle_set_ppm_sound_directions(1 if on else 0)

@@ -15,6 +15,45 @@
 #include <thread>
 #include <vector>
 
+// ORACLE-ONLY switch (tests/test_photonmapper.py): store a photon's direction with a SOUND signed-normalised 16-bit encoding — scale
+// 32767, the second component masked to its half of the word — instead of encode_signed_norm_16 as written (core/common.art:186-197:
+// scale 65535 into an i16, which wraps beyond +-0.5, and a sign-extended second component that overwrites the first). Everything else
+// of the photon mapper stays as restated. Round 3 blamed this encoding for the photon mapper's dark green channel on cycles-lights; the
+// switch shows it is not: the image does not move (tests/test_photonmapper.py), a diffuse receiver only asks a photon's direction for the
+// sign of a cosine. What is dark is the spot light, whose sample_emission carries 1 / spot_area (light/spot.art:41-47), exactly as in the
+// light tracer. The product (ppm_core.h) has no such switch: it renders what the reference renders.
+static bool g_ppm_sound_directions = false;
+static int32_t sound_snorm16(float f)
+{
+    const float c = f < -1.0f ? -1.0f : (f > 1.0f ? 1.0f : f);
+    return (int32_t)igp_round(c * 32767.0f);
+}
+static int32_t sound_encode_normal_32(float x, float y, float z)
+{
+    const float a  = igm_abs(x) + igm_abs(y) + igm_abs(z);
+    const float ox = x / a, oy = y / a;
+    float px = ox, py = oy;
+    if (z < 0) {
+        px = (1 - igm_abs(oy)) * (ox >= 0 ? 1.0f : -1.0f);
+        py = (1 - igm_abs(ox)) * (oy >= 0 ? 1.0f : -1.0f);
+    }
+    return (int32_t)(((uint32_t)sound_snorm16(px) << 16) | ((uint32_t)sound_snorm16(py) & 0xFFFFu));
+}
+static void sound_decode_normal_32(int32_t val, float out[3])
+{
+    // decode_oct_proj as it is meant (the reflected branch with its parentheses): (1 - |y|) * sign(x)
+    const float dx = (float)(int16_t)(val >> 16) / 32767.0f, dy = (float)(int16_t)val / 32767.0f;
+    const float oz = 1 - igm_abs(dx) - igm_abs(dy);
+    float ox = dx, oy = dy;
+    if (oz < 0) {
+        ox = (1 - igm_abs(dy)) * (dx >= 0 ? 1.0f : -1.0f);
+        oy = (1 - igm_abs(dx)) * (dy >= 0 ? 1.0f : -1.0f);
+    }
+    const float inv = 1 / igm_sqrt(igm_fma(ox, ox, igm_fma(oy, oy, oz * oz)));
+    out[0] = ox * inv, out[1] = oy * inv, out[2] = oz * inv;
+}
+
+
 using namespace oracle;
 
 extern "C" {
@@ -562,7 +601,7 @@ void render_photon_mapped(const igd_scene& sc, const oracle_settings& cfg, const
                 const float cos_o = vec3_dot(out_dir, b.surf.local.col[2]);
                 if (cos_o > flt_eps) {
                     igp_photon& ph = photons[(size_t)x];
-                    ph.dir   = igp_encode_normal_32(out_dir.x, out_dir.y, out_dir.z);
+                    ph.dir   = g_ppm_sound_directions ? sound_encode_normal_32(out_dir.x, out_dir.y, out_dir.z) : igp_encode_normal_32(out_dir.x, out_dir.y, out_dir.z);
                     ph.light = light_id;
                     ph.power = igp_encode_rgbe(pt.contrib.r, pt.contrib.g, pt.contrib.b);
                     ph.depth = pt.depth;
@@ -694,7 +733,10 @@ void render_photon_mapped(const igd_scene& sc, const oracle_settings& cfg, const
                                                 if (!(dist2 <= r2))
                                                     continue;
                                                 float dir[3], pw[3];
-                                                igp_decode_normal_32(ph.dir, dir);
+                                                if (g_ppm_sound_directions)
+                                                    sound_decode_normal_32(ph.dir, dir);
+                                                else
+                                                    igp_decode_normal_32(ph.dir, dir);
                                                 const Vec3 in_dir = make_vec3(dir[0], dir[1], dir[2]);
                                                 const float cos_i = vec3_dot(in_dir, N);
                                                 if (depth + ph.depth <= tech.max_depth && cos_o * cos_i > flt_eps) {
@@ -862,6 +904,7 @@ void oracle_photon_codec(const float dir[3], const float power[3], int32_t* enc_
     igp_decode_normal_32(*enc_dir, out_dir);
     igp_decode_rgbe(*enc_power, out_power);
 }
+void oracle_set_ppm_sound_directions(int on) { g_ppm_sound_directions = on != 0; }
 int32_t oracle_photon_cell(const float pos[3], const float bmin[3], const float bmax[3]) { return igp_grid_cell(pos, bmin, bmax); }
 float oracle_photon_radius(float max_radius, int32_t iteration) { return igp_compute_radius(max_radius, iteration); }
 

@@ -105,19 +105,35 @@ def test_photon_encodings_and_grid_against_numpy():
     assert l.oracle_photon_radius(1e-9, 5) == pytest.approx(1e-5)
 
 
-def test_oracle_photon_mapper_agrees_with_the_path_tracer_where_the_encoding_lets_it():
-    """cycles-lights (point, spot and area light over a diffuse scene): direct light gathered from 300 k photons per iteration against
-    next-event estimation. Red and blue agree to a few per cent; green — the light whose photons arrive steeply, i.e. with an
-    octahedron component beyond 0.5 that encode_signed_norm_16 wraps — loses energy, as the technique is written."""
+def test_oracle_photon_mapper_agrees_with_the_path_tracer_up_to_the_spot_lights_emission():
+    """cycles-lights (blue point, green spot and red area light over a diffuse plane): direct light gathered from 300 k photons per
+    iteration against next-event estimation. Point and area light agree to a per cent. The spot light is darker by exactly the factor its
+    sample_emission carries and its sample_direct does not: 1 / spot_area = 1 / (pi tan^2 cutoff) (light/spot.art:13-14,41-47) — the
+    relation tests/test_lighttracer.py asserts for the light tracer. That pins the technique's light pass, grid, gather, radius and
+    kernel for all three light types; round 3 had blamed the green deficit on encode_signed_norm_16, which the second half refutes:
+    with photon directions stored through a sound 16-bit encoding (oracle-only switch) the image is the same to 1e-6."""
     a, b = _scene({"type": "path", "max_depth": 16}), _scene({"type": "ppm", "max_depth": 16, "photons": 300000})
-    fa, fb = np.zeros((64, 64, 3), np.float32), np.zeros((64, 64, 3), np.float32)
-    for it in range(6):
-        oracle.render(a, 8, 64, 64, iteration=it, seed=3, fb=fa)
-        _, st = oracle.render(b, 8, 64, 64, iteration=it, seed=3, fb=fb)
+
+    def run():
+        fa, fb = np.zeros((64, 64, 3), np.float32), np.zeros((64, 64, 3), np.float32)
+        for it in range(6):
+            oracle.render(a, 8, 64, 64, iteration=it, seed=3, fb=fa)
+            _, st = oracle.render(b, 8, 64, 64, iteration=it, seed=3, fb=fb)
+        return fa, fb, st
+
+    fa, fb, st = run()
     ma, mb = fa.mean(axis=(0, 1)), fb.mean(axis=(0, 1))
-    assert mb[0] == pytest.approx(ma[0], rel=0.03) and mb[2] == pytest.approx(ma[2], rel=0.03)
-    assert 0.3 * ma[1] < mb[1] < ma[1]
+    spot = next(l for l in json.load(open(os.path.join(EVAL, "cycles-lights.json")))["lights"] if l["type"] == "spot")
+    spot_area = np.pi * np.tan(np.radians(spot["cutoff"])) ** 2
+    assert mb[0] == pytest.approx(ma[0], rel=0.02) and mb[2] == pytest.approx(ma[2], rel=0.02)  # area light, point light
+    assert mb[1] * spot_area == pytest.approx(ma[1], rel=0.02)                                  # spot light: 0.54 x as written
     assert st["shadow_rays"] == 0 and st["camera_rays"] == 300000 + 64 * 64 * 8  # emitter rays + camera rays; no shadow rays at all
+    oracle.set_ppm_sound_directions(True)
+    try:
+        _, fs, _ = run()
+    finally:
+        oracle.set_ppm_sound_directions(False)
+    assert float(np.linalg.norm(fs - fb) / np.linalg.norm(fb)) < 1e-5
 
 
 @pytest.mark.gpu

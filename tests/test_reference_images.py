@@ -101,12 +101,13 @@ EXCLUDED = {
                         "instead of the pixel's importance (src/artic/camera/perspective.art:36,47-51), so the image is the direct + indirect lighting "
                         "times the area of the image plane at distance 1 (4 sx sy), and a spot light's emission carries another 1 / spot_area "
                         "(light/spot.art:41-47). Both relations are asserted against the path tracer in tests/test_lighttracer.py instead.",
-    "cycles-lights-ppm": "the photon mapper stores a photon's direction through encode_normal_32, whose encode_signed_norm_16 scales by (1 << 16) - 1 and "
-                         "narrows to i16 (src/artic/core/common.art:186-197): an octahedron component beyond +-0.5 wraps around and a negative second "
-                         "component overwrites the first, so photons that arrive steeply decode to directions that fail the cos_o * cos_i test of the "
-                         "gather (photonmapper.art:316-318). Restated as written: red and blue are 1.26 / 0.99 x the Cycles image exactly like the path "
-                         "tracer's cycles-lights (1.27 / 1.00), green — the light straight above the floor — is 0.54 x. tests/test_photonmapper.py "
-                         "pins the encodings against numpy and the red / blue agreement with the path tracer instead.",
+    "cycles-lights-ppm": "the photon mapper starts its light paths with Light::sample_emission, and the spot light's carries a factor 1 / spot_area = "
+                         "1 / (pi tan^2 cutoff) that its sample_direct does not (src/artic/light/spot.art:13-14,41-47; the same factor the light tracer "
+                         "shows, cycles-lights-lt): the green channel — the spot light — is 0.54 x the path tracer's and the Cycles image, red (area light) and "
+                         "blue (point light) are 1.26 / 0.99 x Cycles exactly like the path tracer's cycles-lights (1.27 / 1.00). "
+                         "tests/test_photonmapper.py asserts green x spot_area == path tracer's green within 2 %, and — with an oracle-only switch — that "
+                         "storing photon directions through a sound 16-bit encoding instead of encode_signed_norm_16 as written (core/common.art:186-197) "
+                         "does not change the image (round 3 had blamed that encoding).",
     "env": "make_environment_light_textured.sample_dir (src/artic/light/env.art:112-113) returns tex(ctx) without `scale`, emission "
            "(:139-144) multiplies by it: with scale 100 the NEE half of the estimator is 100x too dark. Restated as written (bug-compatible), "
            "so the image cannot match Mitsuba's; with the scale folded into the texture NEE and BSDF-only sampling agree with each other "
