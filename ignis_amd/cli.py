@@ -10,6 +10,7 @@ row_stride), scene replicated, no data-path exchange — and the only collective
 (xGMI) when rendering is done (ignis_amd/sharding.py); rank 0 writes the EXR. The image is the single-GPU one bit for bit.
 """
 import argparse
+import datetime
 import math
 import os
 import socket
@@ -35,7 +36,24 @@ def _spawn_ranks(argv, gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-m", "ignis_amd.cli"] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    # all ranks are watched together: the first one that fails (a negative code = killed by a signal counts) takes the others down, which
+    # would otherwise wait in the gather for a peer that is gone
+    failed = 0
+    while procs and not failed:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is not None:
+                procs.remove(p)
+                failed = failed or (1 if rc != 0 else 0)
+        time.sleep(0.05)
+    for p in procs:
+        p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return failed
 
 
 def main(argv=None, load=loadFromFile):
@@ -76,9 +94,9 @@ def main(argv=None, load=loadFromFile):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         args.gpu = local_rank
     chatty = rank == 0
 

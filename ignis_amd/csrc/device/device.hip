@@ -2098,6 +2098,16 @@ int32_t igd_release_all(igd_device* dev)
         dev->expr_code.release();
         dev->textures.release();
         dev->texture_data.release();
+        // the photon mapper's buffers (up to 32 + 32 + 16 bytes per photon) and the record of re-ordered packets
+        dev->ppm_photons.release();
+        dev->ppm_sorted.release();
+        dev->ppm_keys.release();
+        dev->ppm_cell_count.release();
+        dev->ppm_cell_offset.release();
+        dev->ppm_valid.release();
+        dev->ppm_temp.release();
+        dev->ppm_qs.release();
+        dev->tri_spans.clear();
         dev->cdf_data.release();
         dev->info_tmp[0].release();
         dev->info_tmp[1].release();
