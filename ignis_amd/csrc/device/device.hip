@@ -831,12 +831,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         && s->technique.type != IG_TECHNIQUE_LIGHTTRACER && s->technique.type != IG_TECHNIQUE_WIREFRAME && s->technique.type != IG_TECHNIQUE_PPM)
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown technique type" };
     if (s->technique.type == IG_TECHNIQUE_PPM) {
-        // the light pass samples emission like the light tracer (lt_core.h); photons per iteration bounded by what a launch can index
-        for (uint32_t i = 0; i < s->light_count; ++i) {
-            const int lt = s->lights[i].type;
-            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_SPHERE && lt != IG_LIGHT_SUN && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
-                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the photon mapper samples emission of point, spot, area, directional, sun and constant environment lights only" };
-        }
+        // the light pass samples emission like the light tracer (lt_core.h: every light type); photons per iteration bounded by what a launch can index
+        for (uint32_t i = 0; i < s->light_count; ++i)
+            if (s->lights[i].type < IG_LIGHT_PLANE || s->lights[i].type > IG_LIGHT_PEREZ)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
         if (s->technique.photon_count < 1 || s->technique.photon_count > (1 << 28) || s->technique.max_light_depth < 0 || !(s->technique.merge_radius >= 0))
             throw HipError{ IGD_ERR_INVALID_ARG, "igd_assign_scene: photon mapper parameters out of range" };
         if (s->sphere_node_count)
@@ -849,12 +847,10 @@ void assignScene(igd_device* d, const igd_scene* s)
         d->full_bsdfs = true;
     }
     if (s->technique.type == IG_TECHNIQUE_LIGHTTRACER) {
-        // Light::sample_emission and Camera::sample_pixel exist for these light types and the pinhole camera (lt_core.h)
-        for (uint32_t i = 0; i < s->light_count; ++i) {
-            const int lt = s->lights[i].type;
-            if (lt != IG_LIGHT_POINT && lt != IG_LIGHT_SPOT && lt != IG_LIGHT_PLANE && lt != IG_LIGHT_MESH_AREA && lt != IG_LIGHT_SPHERE && lt != IG_LIGHT_SUN && lt != IG_LIGHT_DIRECTIONAL && lt != IG_LIGHT_ENV)
-                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer samples emission of point, spot, area, directional, sun and constant environment lights only" };
-        }
+        // Light::sample_emission exists for every light type, Camera::sample_pixel for the pinhole camera (lt_core.h)
+        for (uint32_t i = 0; i < s->light_count; ++i)
+            if (s->lights[i].type < IG_LIGHT_PLANE || s->lights[i].type > IG_LIGHT_PEREZ)
+                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: unknown light type" };
         if (s->camera.type != IG_CAMERA_PERSPECTIVE || s->camera.aperture_radius > 1.1920928955e-07f)
             throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: the light tracer connects to the perspective camera without depth of field only" };
         if (s->sphere_node_count)

@@ -43,7 +43,7 @@ IG_DEV f3 env_sample_pos(const DevScene& sc, Tea& rnd, f3 dir, float& pdf)
     return f3{ sc.scene_center[0], sc.scene_center[1], sc.scene_center[2] } + (dir * r + mul33(orthonormal_basis(dir), f3{ d.x * r, d.y * r, 0 }));
 }
 
-// Light::sample_emission of the light types the light tracer is lowered for (igd_assign_scene refuses the others)
+// Light::sample_emission of every light type the loader lowers
 IG_DEV bool sample_emission(const DevScene& sc, const ig_light& L, Tea& rnd, EmissionSample& e)
 {
     switch (L.type) {
@@ -171,6 +171,68 @@ IG_DEV bool sample_emission(const DevScene& sc, const ig_light& L, Tea& rnd, Emi
         e.dir       = -dir;
         e.intensity = Col{ L.d[0], L.d[1], L.d[2] } * safe_div(1, pos_pdf * pdf);
         e.cos       = 1.0f;
+        return true;
+    }
+    case IG_LIGHT_ENV_TEXTURED: { // make_environment_light_textured.sample_emission (light/env.art:141-145); "cdf": "none" = the spherical function environment (:87-93)
+        const TexturedEnv env(sc, L);
+        f3 dir;
+        Col intensity;
+        float pdf_dir, pos_pdf;
+        env.sample_dir(rnd, dir, intensity, pdf_dir);
+        e.pos       = env_sample_pos(sc, rnd, dir, pos_pdf);
+        e.dir       = -dir;
+        e.intensity = intensity * safe_div(1, pos_pdf * pdf_dir);
+        e.cos       = 1.0f;
+        return true;
+    }
+    case IG_LIGHT_CIE: { // make_environment_light_function_{hemi, spherical}.sample_emission (light/env.art:38-46,87-93) over the sky function
+        const CieSky sky(L);
+        const float ux = rnd.f32();
+        const float uy = rnd.f32();
+        f3 gdir;
+        Col intensity;
+        float pdf;
+        if (!sky.has_ground) {
+            const float c   = safe_sqrt(uy); // sample_cosine_hemisphere (core/sampling.art:62-70)
+            const float sn  = safe_sqrt(1 - uy);
+            const float phi = 2 * kPi * ux;
+            const f3 dir    = switch_env_up(f3{ sn * igm_cos(phi), sn * igm_sin(phi), c });
+            pdf             = c / kPi;
+            intensity       = sky.radiance(dir);
+            gdir            = f3{ dot3(sky.transform.c0, dir), dot3(sky.transform.c1, dir), dot3(sky.transform.c2, dir) }; // mat3x3_left_mul
+        } else {
+            gdir      = square_to_sphere(ux, uy);
+            pdf       = 1 / (4 * kPi);
+            intensity = sky.radiance(mul33(sky.transform, gdir));
+        }
+        float pos_pdf;
+        e.pos       = env_sample_pos(sc, rnd, gdir, pos_pdf);
+        e.dir       = -gdir;
+        e.intensity = intensity * safe_div(1, pdf * pos_pdf);
+        e.cos       = 1.0f;
+        return true;
+    }
+    case IG_LIGHT_PEREZ: { // make_perez_light_raw.sample_emission (light/perez.art:309-313): the sun's sample (sun.art:24-29) plus the sky seen against it
+        const f3 sun_dir    = f3{ L.d[27], L.d[28], L.d[29] };
+        const float cos_a   = L.d[14];
+        const float u       = rnd.f32();
+        const float v       = rnd.f32();
+        const float c1      = 1 - cos_a;
+        const f2 p          = concentric_disk(u, v);
+        const float n2      = p.x * p.x + p.y * p.y;
+        const float z       = cos_a + c1 * (1 - n2);
+        const float k       = safe_sqrt(c1 * (2 - c1 * n2));
+        const f3 ndir       = mul33(orthonormal_basis(-sun_dir), f3{ p.x * k, p.y * k, z });
+        const float inv_pdf = 2 * kPi * (1 - cos_a);
+        const float dir_pdf = safe_div(1, 2 * kPi * (1 - cos_a)); // uniform_cone_pdf
+        float pos_pdf;
+        e.pos = env_sample_pos(sc, rnd, -ndir, pos_pdf);
+        e.dir = ndir;
+        const CieSky sky(L);
+        const f3 to_sky = -ndir;
+        const f3 d      = f3{ dot3(sky.transform.c0, to_sky), dot3(sky.transform.c1, to_sky), dot3(sky.transform.c2, to_sky) };
+        e.intensity     = Col{ L.d[24], L.d[25], L.d[26] } * safe_div(inv_pdf, pos_pdf) + sky.radiance(d) * (1 / (pos_pdf * dir_pdf));
+        e.cos           = z;
         return true;
     }
     default:

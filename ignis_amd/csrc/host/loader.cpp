@@ -2685,19 +2685,12 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         fail("Technique 'wireframe': the camera differential of this camera type is not supported by the HIP backend");
     if (tech.type == IG_TECHNIQUE_LIGHTTRACER) {
         // the light tracer needs Light::sample_emission and Camera::sample_pixel: lowered for these light types and the pinhole camera
-        for (const ig_light& l : sc->lights)
-            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_SPHERE && l.type != IG_LIGHT_SUN && l.type != IG_LIGHT_DIRECTIONAL
-                && l.type != IG_LIGHT_ENV)
-                fail("Technique 'lt': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional, sun and constant environment lights are)");
+        // (Light::sample_emission is lowered for every light type: lt_core.h)
         if (cam.type != IG_CAMERA_PERSPECTIVE || cam.aperture_radius > 0)
             fail("Technique 'lt': only the perspective camera without depth of field is supported by the HIP backend");
     }
     if (tech.type == IG_TECHNIQUE_PPM) {
         // the light pass needs Light::sample_emission like the light tracer's emitter
-        for (const ig_light& l : sc->lights)
-            if (l.type != IG_LIGHT_POINT && l.type != IG_LIGHT_SPOT && l.type != IG_LIGHT_PLANE && l.type != IG_LIGHT_MESH_AREA && l.type != IG_LIGHT_SPHERE && l.type != IG_LIGHT_SUN && l.type != IG_LIGHT_DIRECTIONAL
-                && l.type != IG_LIGHT_ENV)
-                fail("Technique 'ppm': emission sampling of this scene's light types is not supported by the HIP backend (point, spot, area, directional, sun and constant environment lights are)");
         // __tech_radius = radius * SceneDiameter, SceneDiameter = |bbox.max - bbox.min| (PhotonMappingTechnique.cpp:100, LoaderEntity.cpp:187)
         const V3 size = entityCount ? sceneBBox.diameter() : V3(0, 0, 0);
         t.technique.merge_radius = tech.merge_radius * std::sqrt(size.x * size.x + size.y * size.y + size.z * size.z);

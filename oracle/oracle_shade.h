@@ -3556,8 +3556,66 @@ static inline bool sample_emission(const igd_scene& sc, const ig_light& l, Rng& 
         e = EmissionSample{ pos, vec3_neg(dir), color_mulf(Color{ l.d[0], l.d[1], l.d[2] }, safe_div(1, pos_pdf * pdf)), pos_pdf, pdf, 1.0f };
         return true;
     }
+    case IG_LIGHT_ENV_TEXTURED: { // make_environment_light_textured.sample_emission (light/env.art:141-145); "cdf": "none": the spherical function environment (:87-93)
+        const TexturedEnv env(sc, l);
+        Vec3 dir;
+        Color intensity;
+        float pdf_dir;
+        env.sample_dir(rnd, dir, intensity, pdf_dir);
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, dir, pos, pos_pdf);
+        e = EmissionSample{ pos, vec3_neg(dir), color_mulf(intensity, safe_div(1, pos_pdf * pdf_dir)), pos_pdf, pdf_dir, 1.0f };
+        return true;
+    }
+    case IG_LIGHT_CIE: { // make_environment_light_function_{hemi, spherical}.sample_emission (light/env.art:38-46,87-93) over the sky function
+        const CieSky sky(l);
+        const float u = rnd.next_f32();
+        const float v = rnd.next_f32();
+        Vec3 gdir;
+        Color intensity;
+        float pdf;
+        if (!sky.has_ground) {
+            const DirSample ds = sample_cosine_hemisphere(u, v);
+            const Vec3 dir     = switch_env_up(ds.dir);
+            pdf                = ds.pdf;
+            intensity          = sky.radiance(dir);
+            gdir               = make_vec3(vec3_dot(sky.transform.col[0], dir), vec3_dot(sky.transform.col[1], dir), vec3_dot(sky.transform.col[2], dir));
+        } else {
+            gdir      = equal_area_square_to_sphere(u, v);
+            pdf       = 1 / (4 * flt_pi);
+            intensity = sky.radiance(mat3x3_mul(sky.transform, gdir));
+        }
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, gdir, pos, pos_pdf);
+        e = EmissionSample{ pos, vec3_neg(gdir), color_mulf(intensity, safe_div(1, pdf * pos_pdf)), pos_pdf, pdf, 1.0f };
+        return true;
+    }
+    case IG_LIGHT_PEREZ: { // make_perez_light_raw.sample_emission (light/perez.art:309-313): the sun's sample (sun.art:24-29) plus the sky seen against it
+        const SunLight sun = perez_sun(l);
+        const float u  = rnd.next_f32();
+        const float v  = rnd.next_f32();
+        const float c1 = 1 - sun.cos_angle;
+        float px, py;
+        square_to_concentric_disk(u, v, px, py);
+        const float n2 = px * px + py * py;
+        const float z  = sun.cos_angle + c1 * (1 - n2);
+        const float k  = safe_sqrt(c1 * (2 - c1 * n2));
+        const Vec3 ndir     = mat3x3_mul(make_orthonormal_mat3x3(vec3_neg(sun.dir)), make_vec3(px * k, py * k, z));
+        const float inv_pdf = 2 * flt_pi * (1 - sun.cos_angle);
+        Vec3 pos;
+        float pos_pdf;
+        env_sample_pos(sc, rnd, vec3_neg(ndir), pos, pos_pdf);
+        const CieSky sky(l);
+        const Vec3 to_sky = vec3_neg(ndir);
+        const Vec3 d      = make_vec3(vec3_dot(sky.transform.col[0], to_sky), vec3_dot(sky.transform.col[1], to_sky), vec3_dot(sky.transform.col[2], to_sky));
+        const Color c     = color_add(color_mulf(sun.radiance, safe_div(inv_pdf, pos_pdf)), color_mulf(sky.radiance(d), 1 / (pos_pdf * sun.dir_pdf())));
+        e = EmissionSample{ pos, ndir, c, pos_pdf, sun.dir_pdf(), z };
+        return true;
+    }
     default:
-        return false; // (the loader refuses the light tracer for the other light types)
+        return false;
     }
 }
 

@@ -20,14 +20,15 @@ def _plane_scene(technique, fov=10.0, lights=None, bsdf=None):
             "lights": lights or [{"type": "point", "name": "p", "position": [0.3, -0.2, 2], "intensity": [5, 5, 5]}]}
 
 
-def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
+def test_loader_lowers_the_technique_and_refuses_what_it_cannot_connect():
     sc = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_light_depth": 7, "min_depth": 3, "clamp": 2.5})), SCENES, 64, 64)
     t = sc.scene.technique
     assert (t.type, t.max_depth, t.min_depth, t.clamp) == (4, 7, 3, 2.5)
     other = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lighttracer"})), SCENES, 64, 64)  # (keep the owner of the tables alive)
     assert other.scene.technique.max_depth == 64
-    with pytest.raises(RuntimeError, match="emission sampling"):
-        LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "cie_cloudy", "name": "s"}])), SCENES, 64, 64)
+    # (every light type has its sample_emission since round 4: the sky models and textured environments too)
+    sky = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt"}, lights=[{"type": "cie_cloudy", "name": "s"}])), SCENES, 64, 64)
+    assert sky.scene.lights[0].type == 7
     bad = _plane_scene({"type": "lt"})
     bad["camera"]["type"] = "fishlens"
     with pytest.raises(RuntimeError, match="perspective camera"):
@@ -40,18 +41,29 @@ def test_loader_lowers_the_technique_and_refuses_what_has_no_emission_sampler():
     [{"type": "directional", "name": "d", "direction": [0.2, 0.1, -1], "irradiance": [2, 2, 2]}],
     [{"type": "env", "name": "e", "radiance": [1, 1, 1]}],
     [{"type": "sun", "name": "s", "direction": [-0.1, -0.2, 1], "irradiance": [2, 2, 2], "angle": 4}],
-])
+    [{"type": "cie_cloudy", "name": "sky", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2], "has_ground": False, "transform": [{"rotate": [70, 0, 0]}]}],
+    [{"type": "cie_clear", "name": "sky", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2], "direction": [0.3, 0.4, 0.8], "turbidity": 3.0}],
+    [{"type": "env", "name": "e", "radiance": "sky"}],  # (no `scale`: the CDF-sampled environment drops it in sample_dir, light/env.art:112-113)
+    [{"type": "env", "name": "e", "radiance": "sky", "cdf": "none", "transform": [{"rotate": [10, 20, 30]}]}],
+], ids=["point", "spot", "directional", "env", "sun", "cie-hemisphere", "cie-sphere", "env-cdf", "env-uniform"])
 def test_oracle_light_tracer_agrees_with_the_path_tracer_up_to_the_pixel_measure(lights):
     """As written the camera connection weighs a vertex with image_area = 1 (camera/perspective.art:36,47-51) instead of the
     pixel's importance 1 / (A cos^3), A = 4 sx sy the area of the image plane at distance 1: with a narrow field of view
-    (cos^3 > 0.988 at 10 degrees) a light-tracer image is the path tracer's direct lighting times A."""
+    (cos^3 > 0.988 at 10 degrees) a light-tracer image is the path tracer's direct lighting times A. (Not in the list: the Perez sky
+    with its sun. Its sample_emission, light/perez.art:309-313, draws directions inside the sun's cone only and adds the sky seen there, so a
+    light tracer never sees the rest of the sky the path tracer reaches through BSDF-sampled misses: 0.67 x on this scene, as written.)"""
     import oracle
     fov = 10.0
-    a = LoadedScene.from_string(json.dumps(_plane_scene({"type": "path", "max_depth": 2}, fov, lights)), SCENES, 64, 64)
-    b = LoadedScene.from_string(json.dumps(_plane_scene({"type": "lt", "max_depth": 2}, fov, lights)), SCENES, 64, 64)
+    def scene(technique):
+        s = _plane_scene(technique, fov, lights)
+        if lights[0].get("radiance") == "sky":
+            s["textures"] = [{"type": "image", "name": "sky", "filename": "textures/sky_gradient.png"}]
+        return LoadedScene.from_string(json.dumps(s), SCENES, 64, 64)
+
+    a, b = scene({"type": "path", "max_depth": 2}), scene({"type": "lt", "max_depth": 2})
     pt = np.zeros((64, 64, 3), np.float32)
     lt = np.zeros((64, 64, 3), np.float32)
-    n_lt = 64 if lights[0]["type"] in ("directional", "env", "point", "sun") else 16
+    n_lt = 16 if lights[0]["type"] == "spot" else 64
     for it in range(4):
         oracle.render(a, 8, 64, 64, iteration=it, seed=2, fb=pt)
     for it in range(n_lt):
@@ -79,7 +91,7 @@ def test_oracle_light_tracer_only_counts_connections_it_traces():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cycles-lights", "sphere-light", "diamond", "diamond-principled-bump"])
+@pytest.mark.parametrize("case", ["cycles-lights", "sphere-light", "diamond", "diamond-principled-bump", "diamond-skies"])
 def test_light_tracer_vs_oracle(gpu_device, case):
     """The path set (counters) is the oracle's exactly; the pixel sums agree to the rounding of their summation order (the device adds
     connections with float atomics)."""
@@ -99,6 +111,15 @@ def test_light_tracer_vs_oracle(gpu_device, case):
         s["lights"] += [{"type": "env", "name": "sky", "radiance": [0.3, 0.3, 0.4]}, {"type": "directional", "name": "d", "direction": [0.3, -1, 0.2], "irradiance": [1, 1, 1]},
                         {"type": "sun", "name": "sun", "direction": [0.2, 1, -0.1], "irradiance": [1, 1, 1], "angle": 3},
                         {"type": "point", "name": "p", "position": [0, 1.2, 0], "intensity": [1, 1, 1]}]
+        if "skies" in case:  # emission sampling of the sky models and textured environments (light/env.art:38-46,87-93,141-145, perez.art:309-313)
+            s["textures"] = [{"type": "image", "name": "sky", "filename": "textures/sky_gradient.png"}]
+            s["lights"] = s["lights"][:1] + [
+                {"type": "cie_cloudy", "name": "c1", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2], "has_ground": False, "transform": [{"rotate": [0, 0, 25]}]},
+                {"type": "cie_clear", "name": "c2", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2], "direction": [0.3, 0.7, -0.5], "turbidity": 3.0},
+                {"type": "perez", "name": "pz", "clearness": 8, "brightness": 0.1},
+                {"type": "env", "name": "e1", "radiance": "sky", "scale": [1, 0.8, 0.6]},
+                {"type": "env", "name": "e2", "radiance": "sky", "cdf": "none", "transform": [{"rotate": [10, 20, 30]}]}]
+            s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
         if "bump" in case:
             s["textures"] = [{"type": "image", "name": "bumps", "filename": "textures/bumpmap.png"}]
             for b in s["bsdfs"]:

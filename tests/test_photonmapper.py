@@ -39,8 +39,8 @@ def test_loader_lowers_the_technique():
     other = _scene({"type": "photonmapper", "photons": 7, "max_camera_depth": 5, "min_camera_depth": 3, "max_light_depth": 4, "radius": 0.5})
     t = other.scene.technique
     assert (t.photon_count, t.max_depth, t.min_depth, t.max_light_depth) == (100, 5, 3, 4)  # at least 100 photons
-    with pytest.raises(RuntimeError, match="emission sampling"):
-        LoadedScene.from_string(json.dumps({"technique": {"type": "ppm"}, "lights": [{"type": "cie_cloudy", "name": "s"}]}), "", 32, 32)
+    sky = LoadedScene.from_string(json.dumps({"technique": {"type": "ppm"}, "lights": [{"type": "cie_cloudy", "name": "s"}]}), "", 32, 32)
+    assert sky.scene.lights[0].type == 7  # (sky models and textured environments have their sample_emission since round 4)
 
 
 def _snorm16(f):
@@ -134,6 +134,35 @@ def test_oracle_photon_mapper_agrees_with_the_path_tracer_up_to_the_spot_lights_
     finally:
         oracle.set_ppm_sound_directions(False)
     assert float(np.linalg.norm(fs - fb) / np.linalg.norm(fb)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_photon_mapper_with_sky_lights_vs_oracle():
+    """The light pass from a hemisphere-sampled CIE sky, the Perez sky with its sun and a CDF-sampled textured environment."""
+    from ignis_amd import Device
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["technique"] = {"type": "ppm", "max_depth": 8, "photons": 40000, "radius": 0.03, "light_selector": "uniform"}
+    s["textures"] = [{"type": "image", "name": "sky", "filename": "textures/sky_gradient.png"}]
+    s["lights"] = s["lights"][:1] + [
+        {"type": "cie_cloudy", "name": "c1", "zenith": [0.5, 0.6, 0.9], "ground": [0.4, 0.3, 0.2], "has_ground": False},
+        {"type": "perez", "name": "pz", "clearness": 8, "brightness": 0.1},
+        {"type": "env", "name": "e1", "radiance": "sky", "scale": [1, 0.8, 0.6]}]
+    s["entities"] = [e for e in s["entities"] if e["name"] not in ("Back", "Top")]
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    dev = Device(0, acquire_stats=True)
+    dev.assign_scene(sc)
+    ref = np.zeros((72, 96, 3), np.float32)
+    cam = bounce = 0
+    for it in range(2):
+        dev.render(4, 96, 72, iteration=it, seed=5)
+        _, st = oracle.render(sc, 4, 96, 72, iteration=it, seed=5, fb=ref)
+        cam += st["camera_rays"]
+        bounce += st["bounce_rays"]
+    got, ds = dev.framebuffer(), dev.stats()
+    dev.close()
+    assert ref.max() > 0
+    assert float(np.linalg.norm(got - ref) / np.linalg.norm(ref)) <= 1e-4
+    assert (ds["camera_rays"], ds["bounce_rays"], ds["shadow_rays"]) == (cam, bounce, 0)
 
 
 @pytest.mark.gpu
