@@ -1422,11 +1422,17 @@ void render(igd_device* d, const igd_render_settings* rs)
             uint32_t* deep_rays;
             float4* sec_hit;
         };
-        auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror) {
+        auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror, bool bounce_rays_only) {
             const PrimaryCols in = b.prim[in_slot];
             TraverseArgs ta{};
             ta.scene = d->dscene;
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
+            if (bounce_rays_only) {
+                // every ray k_shade appends carries IG_RAY_FLAG_BOUNCE (shade_kernel.h): from round 1 on the traversal need not read the
+                // meta column for the visibility flags (16 of the 48 bytes it reads per ray)
+                ta.meta          = nullptr;
+                ta.uniform_flags = IG_RAY_FLAG_BOUNCE;
+            }
             ta.count        = &qs->q[in_slot].primary;
             ta.work_counter = &qs->work_counter[0];
             ta.index_list   = b.deep_rays;
@@ -1516,7 +1522,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 break;
             }
             // size after this round -> pinned slot (round & 1), written by the round's last kernel itself
-            launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid(), d->host_store_dev + igd_device::kMaxFlights + (round & 1));
+            launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid(), d->host_store_dev + igd_device::kMaxFlights + (round & 1), round > 0);
             in_slot ^= 1;
             HIP_CHECK(hipEventRecord(d->poll_event[round & 1], st));
             if (round >= 1) {
@@ -1592,7 +1598,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             const int tg = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
             const int sg = std::max(1, std::min(d->shadeGrid(), (int)((live + 255) / 256)));
             for (int r = 0; r < rounds; ++r) {
-                launchRound(side, sb, in_slot, tg, sg, nullptr);
+                launchRound(side, sb, in_slot, tg, sg, nullptr, true);
                 in_slot ^= 1;
             }
             tl.in       = sb.prim[in_slot];
