@@ -37,7 +37,6 @@ void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStrea
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_info(const InfoArgs& args, int grid_blocks, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
-void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream);
 void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
 // photon.hip (IG_TECHNIQUE_PPM)
 void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
@@ -172,9 +171,6 @@ struct igd_device {
         DevBuf<float> tail_in;   // the paths handed to the tail kernel (same columns as a primary stream)
         DevBuf<float> tail_long; // those still alive after a pass (the two buffers alternate)
         DevBuf<uint32_t> tail_ctr; // per pass: [2 * j] output count, [2 * j + 1] fetch counter
-        DevBuf<float> tail_work[2];       // k_tail_wave: per-wave private regions for the continuation rays
-        DevBuf<float> side_secondary;     // shadow rays of the side-stream rounds / of k_tail_wave
-        DevBuf<uint32_t> side_deep_rays;
         size_t tail_capacity = 0;
         QueueState* qs       = nullptr; // device
         QueueState* host     = nullptr; // pinned read-back of qs once the chunk is complete
@@ -225,16 +221,6 @@ struct igd_device {
     bool tail_adapt           = true;
     double tail_density       = 0.5; // expected paths per launched wave of a pass after the first (IGD_TAIL_DENSITY)
     double tail_share[24]     = {}; // paths at the start of pass j / paths at the start of pass 0, last collected chunk; [0] == 0: unknown
-    // Wavefront rounds that continue on the side stream before the per-lane tail takes over: -1 = as many as it
-    // takes to get from the hand-over size to ~8 K paths at the usual survival rate, 0 = none (default: measured
-    // 3 % to 10 % slower than handing over directly, the small launches disturb the main stream more than the
-    // per-lane passes do). IGD_SIDE_ROUNDS.
-    int side_rounds = 0;
-    // Tail kernel: 0 = one path per lane from start to end (k_tail, default), 1 = every wave runs a wavefront of its own
-    // over a slice of paths (k_tail_wave; better lane utilisation but a 2x longer dependent chain per wave: measured 9 %
-    // slower end to end). IGD_TAIL_WAVEFRONT. Slice = paths per wave (IGD_TAIL_SLICE, multiple of 64, <= 4096).
-    int tail_wavefront = 0;
-    int tail_slice     = 256;
 
     // statistics
     igd_stats stats{};
@@ -368,27 +354,10 @@ struct igd_device {
         q.col  = reinterpret_cast<float4*>(b + 8 * c);
         return q;
     }
-    void ensureTailWork(Flight& f)
-    {
-        for (auto& w : f.tail_work)
-            if (w.count < f.tail_capacity * kPrimaryCols) {
-                w.release();
-                w.alloc(f.tail_capacity * kPrimaryCols);
-            }
-    }
-    void ensureSideStreams(Flight& f)
-    {
-        if (f.side_secondary.count < f.tail_capacity * kSecondaryCols) {
-            f.side_secondary.release();
-            f.side_secondary.alloc(f.tail_capacity * kSecondaryCols);
-            f.side_deep_rays.release();
-            f.side_deep_rays.alloc(f.tail_capacity);
-        }
-    }
 
     void ensureTailInput(Flight& f, size_t paths)
     {
-        paths = ((paths + 4095) & ~(size_t)4095) + 4096; // room for whole slices of k_tail_wave (slice <= 4096)
+        paths = ((paths + 4095) & ~(size_t)4095) + 4096;
         if (paths <= f.tail_capacity && f.tail_in.ptr)
             return;
         f.tail_in.release();
@@ -1541,19 +1510,15 @@ void render(igd_device* d, const igd_render_settings* rs)
 
         // ---- second half of the chunk, on the side stream: the next chunk's rounds start meanwhile
         TailArgs tl{};
-        int tail_grid = 0, tail_in_first = 0;
-        (void)tail_in_first;
+        int tail_grid = 0;
         if (run_tail) {
             // few paths left: follow each to its end in one launch instead of ~50 more rounds. Its input is
             // moved out of the primary stream, which the next chunk overwrites.
             d->ensureTailInput(fl, live);
-            // the two tail buffers double as the primary streams of the side rounds: slot in_slot receives the paths
-            const PrimaryCols side_prim[2] = { igd_device::colsAt(in_slot == 0 ? fl.tail_in.ptr : fl.tail_long.ptr, fl.tail_capacity),
-                                               igd_device::colsAt(in_slot == 0 ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity) };
-            const PrimaryCols keep = side_prim[in_slot];
+            const PrimaryCols keep = igd_device::colsAt(fl.tail_in.ptr, fl.tail_capacity);
             launch_copy_paths(d->primaryCols(in_slot), keep, &qs->q[in_slot].primary, live, st);
             tl.scene        = d->dscene;
-            tl.in           = keep; // (replaced below when side rounds run first)
+            tl.in           = keep;
             tl.in_count     = &qs->q[in_slot].primary;
             tl.work_counter = nullptr; // set per pass
             tl.qs           = qs;
@@ -1563,12 +1528,6 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
-            if (d->tail_wavefront && d->dscene.sphere_node_count)
-                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: IGD_TAIL_WAVEFRONT is not available for scenes with analytic spheres" };
-            if (d->tail_wavefront) {
-                d->ensureTailWork(fl);
-                d->ensureSideStreams(fl);
-            }
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
             HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
             // one-wave workgroups, 2 waves/SIMD (VGPR bound) = 8 per CU; fewer when the stream is tiny
@@ -1576,41 +1535,12 @@ void render(igd_device* d, const igd_render_settings* rs)
         }
         HIP_CHECK(hipEventRecord(fl.rounds_done, st));
         HIP_CHECK(hipStreamWaitEvent(side, fl.rounds_done, 0));
-        if (run_tail && d->side_rounds != 0) {
-            // Wavefront rounds continue on the side stream (compacted, sorted: the efficient way to advance half a
-            // million paths) while the main stream starts the next chunk; only what is left after them goes to the
-            // per-lane tail. The stream decays geometrically, so the number of rounds is fixed up front.
-            int rounds = d->side_rounds;
-            if (rounds < 0) {
-                const double target = 8192.0, survive = 0.85;
-                rounds = live > target ? (int)std::ceil(std::log((double)live / target) / std::log(1.0 / survive)) : 0;
-            }
-            rounds = std::max(0, std::min(rounds, std::min(40, d->dscene.tech.max_depth + 2)));
-            d->ensureSideStreams(fl);
-            RoundBufs sb;
-            sb.prim[0]   = igd_device::colsAt(in_slot == 0 ? fl.tail_in.ptr : fl.tail_long.ptr, fl.tail_capacity);
-            sb.prim[1]   = igd_device::colsAt(in_slot == 0 ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity);
-            sb.sec       = igd_device::secAt(fl.side_secondary.ptr, fl.tail_capacity);
-            sb.deep_rays = fl.side_deep_rays.ptr;
-            sb.sec_hit   = nullptr;
-            if (d->dscene.sphere_node_count)
-                throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: IGD_SIDE_ROUNDS is not available for scenes with analytic spheres" };
-            const int tg = std::max(1, std::min(d->traverseGrid(), (int)((live + 255) / 256)));
-            const int sg = std::max(1, std::min(d->shadeGrid(), (int)((live + 255) / 256)));
-            for (int r = 0; r < rounds; ++r) {
-                launchRound(side, sb, in_slot, tg, sg, nullptr, true);
-                in_slot ^= 1;
-            }
-            tl.in       = sb.prim[in_slot];
-            tl.in_count = &qs->q[in_slot].primary;
-            tail_in_first = in_slot;
-        }
         if (run_tail)
             timed(5, side, [&] {
                 // pass j reads buffer j & 1 and appends its survivors to the other one; the last pass is unbounded
                 const int depth_left = std::max(1, d->dscene.tech.max_depth);
                 const int passes     = d->tail_split > 0 ? std::min(kMaxTailPasses, (depth_left + d->tail_split - 1) / d->tail_split) : 1;
-                const PrimaryCols other  = igd_device::colsAt(tl.in.rayA == reinterpret_cast<float4*>(fl.tail_in.ptr) ? fl.tail_long.ptr : fl.tail_in.ptr, fl.tail_capacity);
+                const PrimaryCols other  = igd_device::colsAt(fl.tail_long.ptr, fl.tail_capacity);
                 const PrimaryCols buf[2] = { tl.in, other };
                 for (int j = 0; j < passes; ++j) {
                     TailArgs p     = tl;
@@ -1628,23 +1558,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     static const bool tail_debug = std::getenv("IGD_TAIL_DEBUG") != nullptr;
                     if (tail_debug)
                         std::fprintf(stderr, "[tail] pass %d: share %.6f live %llu grid %d of %d\n", j, d->tail_share[j], (unsigned long long)live, pass_grid, tail_grid);
-                    if (d->tail_wavefront && !d->full_bsdfs) { // the experimental wave-local kernel exists in the lean variant only
-                        // every wave gets a slice of the pass's input; the grid covers the upper bound `live`
-                        p.work[0] = igd_device::colsAt(fl.tail_work[0].ptr, fl.tail_capacity);
-                        p.work[1] = igd_device::colsAt(fl.tail_work[1].ptr, fl.tail_capacity);
-                        p.sec     = igd_device::secAt(fl.side_secondary.ptr, fl.tail_capacity);
-                        // no more waves than the tail's share of the deep-stack columns (one column per lane)
-                        const uint32_t max_waves = std::max(1u, d->tail_lanes / 64u);
-                        uint32_t slice           = (uint32_t)d->tail_slice;
-                        while ((live + slice - 1) / slice > max_waves && slice < 4096u)
-                            slice *= 2;
-                        if ((live + slice - 1) / slice > max_waves)
-                            throw HipError{ IGD_ERR_INVALID_ARG, "igd_render: IGD_TAIL_THRESHOLD is too large for the wave-local tail kernel" };
-                        p.slice = slice;
-                        launch_tail_wave(p, counters, (int)((live + slice - 1) / slice), side);
-                    } else {
-                        launch_tail(p, counters, d->full_bsdfs, pass_grid, side);
-                    }
+                    launch_tail(p, counters, d->full_bsdfs, pass_grid, side);
                 }
             });
 
@@ -1988,12 +1902,6 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
         if (const char* e = std::getenv("IGD_TAIL_WAVES"))
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("IGD_TAIL_WAVEFRONT"))
-            d->tail_wavefront = std::atoi(e);
-        if (const char* e = std::getenv("IGD_TAIL_SLICE"))
-            d->tail_slice = std::min(4096, std::max(64, (std::atoi(e) + 63) / 64 * 64));
-        if (const char* e = std::getenv("IGD_SIDE_ROUNDS"))
-            d->side_rounds = std::atoi(e);
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_ADAPT"))
@@ -2068,10 +1976,6 @@ int32_t igd_release_all(igd_device* dev)
         for (auto& f : dev->flight) {
             f.tail_in.release();
             f.tail_long.release();
-            f.side_secondary.release();
-            f.side_deep_rays.release();
-            f.tail_work[0].release();
-            f.tail_work[1].release();
             f.tail_capacity = 0;
         }
         dev->list_rays.release();

@@ -243,11 +243,6 @@ struct TailArgs {
     int32_t count_paths; // add the input size to qs->tail_rays
     int32_t pass;        // index of this pass (qs->tail_pass_in)
     uint32_t deep_lane_base; // first deep-stack column of this launch's lanes
-    // k_tail_wave: every wave owns `slice` consecutive paths of `in` and runs bounce rounds over them in its private
-    // regions [wave * slice, (wave + 1) * slice) of work[0] / work[1] (continuation rays) and sec (shadow rays)
-    PrimaryCols work[2];
-    SecondaryCols sec;
-    uint32_t slice;
 };
 
 struct ResolveArgs {

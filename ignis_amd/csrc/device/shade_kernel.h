@@ -25,26 +25,7 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
-#ifndef IG_SHADE_SORT_LEAN
-#define IG_SHADE_SORT_LEAN 0
-#endif
-#ifndef IG_SHADE_ATOMIC_ACCUM
-#define IG_SHADE_ATOMIC_ACCUM 0
-#endif
-#ifndef IG_SHADE_SORT_FULL
-#define IG_SHADE_SORT_FULL 1
-#endif
-constexpr bool kSortFull          = IG_SHADE_SORT_FULL != 0;
-#ifndef IG_BIN_KEY
-#define IG_BIN_KEY 0 // how the bounce rays of a window are grouped (experiments: 1 octant only, 2 + starting half, 3 entity left)
-#endif
-constexpr int kBounceBins = IG_BIN_KEY >= 2 ? 32 : 16;
-#ifndef IG_SHADOW_BINS
-#define IG_SHADOW_BINS 0
-#endif
-constexpr bool kShadowBins = IG_SHADOW_BINS != 0; // the shadow rays of a window grouped by the octant of their direction as well
-constexpr bool kSortLean          = IG_SHADE_SORT_LEAN != 0;
-constexpr bool kShadeAtomicAccum = IG_SHADE_ATOMIC_ACCUM != 0;
+constexpr int kBounceBins = 16; // the bounce rays of a window leave grouped by (specular bounce, octant of the direction)
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
 template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false, int PPM = 0>
 __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
@@ -54,7 +35,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     __shared__ uint16_t s_perm[kShadeThreads];
     __shared__ uint32_t s_wave_cnt[2][kShadeThreads / 64];
     __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_bin[kBounceBins + 8], s_binoff[kBounceBins + 8]; // (the last eight: shadow rays by octant, kShadowBins) // bounce rays of a window are written grouped by (specular bounce, direction octant)
+    __shared__ uint32_t s_bin[kBounceBins], s_binoff[kBounceBins]; // bounce rays of a window are written grouped by (specular bounce, direction octant)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -65,7 +46,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     // The lean variant has three BSDF models and waits for memory, not for issue slots (a TEA with one round instead of four changes its
     // time by 1 %, profiles/r03_experiment_shade.txt): the sort's two dependent loads and five barriers in front of every window cost it
     // more (4 %) than the divergence they remove. The full variants sort.
-    const bool do_sort = (FULL ? kSortFull : kSortLean) && (M + 2) <= kMaxSortBins;
+    const bool do_sort = FULL && (M + 2) <= kMaxSortBins;
 
     const ShadeFrame fr = a.frame;
 
@@ -84,7 +65,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         uint32_t j = base + tid;
         // cleared here, in front of the sort's barriers (or the explicit one below when there is no sort): every wave's
         // atomicAdd on s_bin is then ordered behind the clear, and the previous window's last barrier behind its reads
-        if (tid < kBounceBins + 8)
+        if (tid < kBounceBins)
             s_bin[tid] = 0;
         if (do_sort) {
             const uint32_t i = base + tid;
@@ -152,33 +133,21 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out, clk);
             clk.mark(6); // on_bounce (a miss: everything)
             if (out.has_radiance) {
-                // per-sample accumulator; the slot is owned by this ray, so no-return float atomics (performed in L2) give the sum a
-                // read-modify-write gives, without the HBM round trip of the read at the end of nearly every window
+                // per-sample accumulator; the slot is owned by this ray: a plain read-modify-write (no-return float atomics give the same
+                // bits and are slower, profiles/r03_experiment_shade.txt)
                 float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
-                if (kShadeAtomicAccum) {
-                    unsafeAtomicAdd(&acc->x, out.radiance.r * a.inv_spi);
-                    unsafeAtomicAdd(&acc->y, out.radiance.g * a.inv_spi);
-                    unsafeAtomicAdd(&acc->z, out.radiance.b * a.inv_spi);
-                } else {
-                    float4 v = *acc;
-                    v.x += out.radiance.r * a.inv_spi;
-                    v.y += out.radiance.g * a.inv_spi;
-                    v.z += out.radiance.b * a.inv_spi;
-                    *acc = v;
-                }
+                float4 v    = *acc;
+                v.x += out.radiance.r * a.inv_spi;
+                v.y += out.radiance.g * a.inv_spi;
+                v.z += out.radiance.b * a.inv_spi;
+                *acc = v;
                 if (a.accum_direct && in.ent >= 0) { // aov_di.splat in on_hit (technique/pathtracer.art:133); on_miss has none
                     float4* di = a.accum_direct + ((int64_t)ray_id - a.id_base);
-                    if (kShadeAtomicAccum) {
-                        unsafeAtomicAdd(&di->x, out.radiance.r * a.inv_spi);
-                        unsafeAtomicAdd(&di->y, out.radiance.g * a.inv_spi);
-                        unsafeAtomicAdd(&di->z, out.radiance.b * a.inv_spi);
-                    } else {
-                        float4 w = *di;
-                        w.x += out.radiance.r * a.inv_spi;
-                        w.y += out.radiance.g * a.inv_spi;
-                        w.z += out.radiance.b * a.inv_spi;
-                        *di = w;
-                    }
+                    float4 w   = *di;
+                    w.x += out.radiance.r * a.inv_spi;
+                    w.y += out.radiance.g * a.inv_spi;
+                    w.z += out.radiance.b * a.inv_spi;
+                    *di = w;
                 }
             }
         }
@@ -205,20 +174,8 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             if (out.bounce) {
                 // rays that continue through a specular (dielectric) vertex start inside or on a refractive object and
                 // walk its BVH first; the others cross the room: two populations with different traversal shapes
-                bkey  = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0);
-                if (IG_BIN_KEY == 0)
-                    bkey |= out.b_inv_pdf == 0 ? 8 : 0;
-                if (IG_BIN_KEY == 2) // the half of the scene the ray starts in, along the axis it mostly travels
-                    bkey |= (out.b_inv_pdf == 0 ? 8 : 0) | ((igm_abs(out.b_dir.x) > igm_abs(out.b_dir.y) ? (igm_abs(out.b_dir.x) > igm_abs(out.b_dir.z) ? out.b_org.x < sc.scene_center[0] : out.b_org.z < sc.scene_center[2]) : (igm_abs(out.b_dir.y) > igm_abs(out.b_dir.z) ? out.b_org.y < sc.scene_center[1] : out.b_org.z < sc.scene_center[2])) ? 16 : 0);
-                if (IG_BIN_KEY == 3) // the entity the ray leaves
-                    bkey = ((out.b_inv_pdf == 0 ? 1 : 0) | ((in_ent_for_bin & 7) << 1)) | ((out.b_dir.y < 0 ? 1 : 0) << 4);
+                bkey = (out.b_dir.x < 0 ? 1 : 0) | (out.b_dir.y < 0 ? 2 : 0) | (out.b_dir.z < 0 ? 4 : 0) | (out.b_inv_pdf == 0 ? 8 : 0);
                 brank = atomicAdd(&s_bin[bkey], 1u);
-            }
-            int skey       = 0;
-            uint32_t srank = 0;
-            if (kShadowBins && out.shadow) {
-                skey  = kBounceBins + ((out.s_dir.x < 0 ? 1 : 0) | (out.s_dir.y < 0 ? 2 : 0) | (out.s_dir.z < 0 ? 4 : 0));
-                srank = atomicAdd(&s_bin[skey], 1u);
             }
             __syncthreads();
             clk.mark(8); // ballots, bins, the barrier in front of the reservation
@@ -232,13 +189,6 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 uint32_t ts = 0;
                 for (int w = 0; w < kShadeThreads / 64; ++w)
                     ts += s_wave_cnt[1][w];
-                if (kShadowBins) {
-                    uint32_t t = 0;
-                    for (int k = kBounceBins; k < kBounceBins + 8; ++k) {
-                        s_binoff[k] = t;
-                        t += s_bin[k];
-                    }
-                }
                 unsigned long long old = 0;
                 if (tb | ts)
                     old = atomicAdd(reinterpret_cast<unsigned long long*>(a.out_count), (unsigned long long)tb | ((unsigned long long)ts << 32));
@@ -259,7 +209,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 a.out.eta[o]  = out.b_eta;
             }
             if (out.shadow) {
-                const uint32_t o = kShadowBins ? s_base[1] + s_binoff[skey] + srank : os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+                const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
                 a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
                 a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
                 a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));

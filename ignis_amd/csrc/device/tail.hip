@@ -23,17 +23,10 @@ namespace igdev {
 #ifndef IG_TAIL_OCC
 #define IG_TAIL_OCC 3 // waves per SIMD the tail kernels are built for (168 VGPRs)
 #endif
-constexpr int kTailThreads = 64;
 #ifndef IG_TAIL_BLOCK
 #define IG_TAIL_BLOCK 64 // threads per workgroup of k_tail (its waves never meet: no barrier, LDS rows by thread)
 #endif
 constexpr int kTailBlock = IG_TAIL_BLOCK;
-#ifndef IG_TAIL_STATIC_FIRST
-#define IG_TAIL_STATIC_FIRST 1 // a wave's first paths by position (no atomic), the counter only for refills
-#endif
-#ifndef IG_TAIL_SPREAD
-#define IG_TAIL_SPREAD 1 // late passes: n / waves paths per wave instead of 64 (0: the first n / 64 waves take everything)
-#endif
 
 template <bool STATS, bool FULL>
 __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs a)
@@ -66,10 +59,10 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
     // wave with three paths in flight finishes a bounce in a fraction of the time of a full one, and what a pass costs is the
     // serial chain of its longest path. Which wave follows a path changes nothing about the path (its accumulator slot is its own).
     const uint32_t waves      = gridDim.x * (uint32_t)(kTailBlock / 64), wave_id = blockIdx.x * (uint32_t)(kTailBlock / 64) + (uint32_t)(tid >> 6);
-    const int cap             = IG_TAIL_SPREAD ? (int)min(64u, max(1u, (n + waves - 1) / waves)) : 64;
+    const int cap             = (int)min(64u, max(1u, (n + waves - 1) / waves));
     const uint32_t handed_out = waves * (uint32_t)cap; // paths the waves take by position, before the counter
     bool first                = true;
-    if (IG_TAIL_STATIC_FIRST && handed_out >= n && wave_id * (uint32_t)cap >= n) {
+    if (handed_out >= n && wave_id * (uint32_t)cap >= n) {
         // nothing by position and nothing to refill from: this wave has no part in the pass
         if (blockIdx.x == 0 && tid == 0) {
             if (a.count_paths)
@@ -101,14 +94,14 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             // The first `cap` paths of a wave are the wave's by position: no counter, so a pass that fits the grid (every late one)
             // runs without a single atomic.
             uint32_t base = wave_id * (uint32_t)cap;
-            if (IG_TAIL_STATIC_FIRST && first) {
+            if (first) {
                 first = false;
                 if (handed_out >= n)
                     exhausted = true;
             } else {
                 if (lane == 0)
                     base = atomicAdd(a.work_counter, (uint32_t)want);
-                base = __shfl(base, 0) + (IG_TAIL_STATIC_FIRST ? handed_out : 0u);
+                base = __shfl(base, 0) + handed_out;
                 if (base + (uint32_t)want >= n)
                     exhausted = true;
             }
@@ -322,248 +315,6 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             a.qs->tail_rays += n;
         a.qs->tail_pass_in[a.pass] = n;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_tail_wave: a wavefront of its own per wave. The per-lane kernel above keeps a path in one lane from start to
-// end, so within a wave every traversal loop waits for its longest ray twice per bounce (17 % VALU lane utilisation
-// in rocprofv3). Here a wave owns a slice of `slice` paths whose state lives in HBM, like the big wavefront kernels,
-// and runs bounce rounds over the slice: closest-hit traversal with lanes re-filled from the slice as they finish,
-// shading in windows of 64 with wave-aggregated appends into the wave's private region, any-hit traversal of the
-// shadow rays. No barriers, no atomics inside a round, no launches between rounds. After `max_bounces` rounds the
-// survivors are appended to `out` for the next, compacted pass (as in k_tail).
-IG_DEV void wave_phase_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <int AH, bool STATS, typename Load, typename Done>
-IG_DEV void traverse_slice(const DevScene& sc, StackOf<kTailThreads>& stack, int tid, uint2* deep_col, uint32_t count, uint32_t* c_work,
-                           bool& overflow, Load load_ray, Done done)
-{
-    Traverser<AH, STATS, kTailThreads, true> tr;
-    tr.init_counters();
-    tr.attach_deep(deep_col, sc.deep_stride);
-    mask_t has    = 0;
-    uint32_t idx  = 0;
-    uint32_t next = 0; // wave-uniform: first ray of the slice that no lane has taken yet
-    for (;;) {
-        const mask_t idle     = ~has;
-        const uint32_t n_idle = (uint32_t)lanes_in(idle);
-        const uint32_t left   = count - next;
-        if (left != 0 && n_idle >= (left >= 16u ? 16u : 1u)) {
-            const uint32_t take = left < n_idle ? left : n_idle;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const mask_t fill   = lanes_where(rank < take) & idle;
-            f3 org = f3{ 0, 0, 0 }, dir = org;
-            float tmin = 0, tmax = 0;
-            uint32_t flags = 0;
-            if (in(fill)) {
-                idx = next + rank;
-                load_ray(idx, org, dir, tmin, tmax, flags);
-            }
-            region_end();
-            tr.begin(fill, sc, stack, tid, org, dir, tmin, tmax, flags);
-            has |= fill;
-            next += take;
-        }
-        if (!has) {
-            if (next >= count)
-                break;
-            continue;
-        }
-        tr.step(sc, stack, tid);
-        const mask_t ended = has & ~tr.active();
-        has &= ~ended;
-        if (in(ended)) {
-            overflow |= tr.overflowed();
-            done(tr, idx);
-        }
-        region_end();
-    }
-    if (STATS)
-        c_work[0] += tr.st_nodes, c_work[1] += tr.st_tris, c_work[2] += tr.st_leaves;
-}
-
-template <bool STATS>
-__global__ void __launch_bounds__(kTailThreads, IG_TAIL_OCC) k_tail_wave(const TailArgs a)
-{
-    __shared__ StackOf<kTailThreads> s_stack;
-
-    const int tid      = threadIdx.x;
-    const int lane     = tid & 63;
-    const DevScene& sc = a.scene;
-    const uint32_t n   = *a.in_count;
-    uint2* deep_col    = sc.deep_stack + (a.deep_lane_base + blockIdx.x * kTailThreads + tid);
-
-    const uint32_t first = blockIdx.x * a.slice; // this wave's region in `in`, work[] and sec
-    uint32_t count       = first < n ? (n - first < a.slice ? n - first : a.slice) : 0u;
-
-    uint32_t c_bounce = 0, c_shadow = 0, c_unoccluded = 0;
-    uint32_t c_work[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
-    bool overflow = false;
-
-    // column views of the current input / output region
-    auto region = [&](const PrimaryCols& c) {
-        PrimaryCols r = c;
-        r.rayA += first, r.rayB += first, r.meta += first, r.pay += first, r.hit += first, r.eta += first, r.hit_v += first;
-        return r;
-    };
-    PrimaryCols src = region(a.in);
-    SecondaryCols sec = a.sec;
-    sec.rayA += first, sec.rayB += first, sec.col += first;
-
-    int round = 0;
-    while (count != 0) {
-        const PrimaryCols dst = region(a.work[round & 1]);
-
-        // ---- closest-hit traversal of the slice
-        traverse_slice<0, STATS>(
-            sc, s_stack, tid, deep_col, count, c_work[0], overflow,
-            [&](uint32_t i, f3& org, f3& dir, float& tmin, float& tmax, uint32_t& flags) {
-                const float4 ra = src.rayA[i], rb = src.rayB[i];
-                org = f3{ ra.x, ra.y, ra.z }, dir = f3{ rb.x, rb.y, rb.z }, tmin = ra.w, tmax = rb.w, flags = (uint32_t)src.meta[i].y;
-            },
-            [&](auto& tr, uint32_t i) {
-                src.hit[i]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
-                src.hit_v[i] = tr.hit_v;
-            });
-
-        // Lanes of this wave exchange data through HBM between the phases (hit records, accumulator slots, rays):
-        // a workgroup-scope release / acquire pair orders them and refreshes this CU's L1 view of its own stores.
-        wave_phase_fence();
-
-        // ---- shading in windows of 64, wave-aggregated appends into the wave's own regions
-        uint32_t n_out = 0, n_sec = 0; // wave-uniform
-        for (uint32_t w = 0; w < count; w += 64u) {
-            const uint32_t i = w + (uint32_t)lane;
-            PathVertexOut out;
-            out.bounce = out.shadow = out.has_radiance = false;
-            int ray_id = 0;
-            if (i < count) {
-                PathVertexIn in;
-                const float4 ra = src.rayA[i], rb = src.rayB[i], pay = src.pay[i], hit = src.hit[i];
-                const int4 meta = src.meta[i];
-                in.ray_id  = ray_id = meta.x;
-                in.org     = f3{ ra.x, ra.y, ra.z };
-                in.dir     = f3{ rb.x, rb.y, rb.z };
-                in.rnd     = (uint32_t)meta.z;
-                in.inv_pdf = pay.x;
-                in.contrib = Col{ pay.y, pay.z, pay.w };
-                in.depth   = meta.w;
-                in.eta     = src.eta[i];
-                in.ent     = (int)igm_bits(hit.x);
-                in.prim    = (int)igm_bits(hit.y);
-                in.t = hit.z, in.u = hit.w, in.v = src.hit_v[i];
-                shade_vertex<false>(sc, a.frame, in, out);
-                if (out.has_radiance) {
-                    float4* acc = a.accum + ((int64_t)ray_id - a.id_base);
-                    float4 v    = *acc;
-                    v.x += out.radiance.r * a.inv_spi;
-                    v.y += out.radiance.g * a.inv_spi;
-                    v.z += out.radiance.b * a.inv_spi;
-                    *acc = v;
-                }
-            }
-            const unsigned long long mb = __ballot(out.bounce), ms = __ballot(out.shadow);
-            if (out.bounce) {
-                const uint32_t o = n_out + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                dst.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, kRayOffset); // (lean variant: no medium bounces)
-                dst.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
-                dst.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
-                dst.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
-                dst.eta[o]  = out.b_eta;
-            }
-            if (out.shadow) {
-                const uint32_t o = n_sec + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-                sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
-                sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
-                sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)ray_id));
-            }
-            n_out += (uint32_t)__popcll(mb);
-            n_sec += (uint32_t)__popcll(ms);
-        }
-        c_bounce += lane == 0 ? n_out : 0u;
-        c_shadow += lane == 0 ? n_sec : 0u;
-        wave_phase_fence();
-
-        // ---- any-hit traversal of the shadow rays, splat on a miss (the slot is owned by the ray's sample, and all
-        // of this wave's earlier writes to it are complete: a wave's memory operations are ordered)
-        traverse_slice<1, STATS>(
-            sc, s_stack, tid, deep_col, n_sec, c_work[1], overflow,
-            [&](uint32_t i, f3& org, f3& dir, float& tmin, float& tmax, uint32_t& flags) {
-                const float4 ra = sec.rayA[i], rb = sec.rayB[i];
-                org = f3{ ra.x, ra.y, ra.z }, dir = f3{ rb.x, rb.y, rb.z }, tmin = ra.w, tmax = rb.w, flags = IG_RAY_FLAG_SHADOW;
-            },
-            [&](auto& tr, uint32_t i) {
-                if (tr.hit_prim < 0) {
-                    ++c_unoccluded;
-                    const float4 c = sec.col[i];
-                    float4* acc    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                    float4 v       = *acc;
-                    v.x += c.x * a.inv_spi;
-                    v.y += c.y * a.inv_spi;
-                    v.z += c.z * a.inv_spi;
-                    *acc = v;
-                }
-            });
-
-        wave_phase_fence();
-        src   = dst;
-        count = n_out;
-        ++round;
-        if (a.max_bounces > 0 && round >= a.max_bounces)
-            break;
-    }
-
-    // ---- survivors go to the next pass, compacted across waves
-    if (count != 0) {
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(a.out_count, count);
-        base = __shfl(base, 0);
-        for (uint32_t i = (uint32_t)lane; i < count; i += 64u) {
-            a.out.rayA[base + i] = src.rayA[i];
-            a.out.rayB[base + i] = src.rayB[i];
-            a.out.meta[base + i] = src.meta[i];
-            a.out.pay[base + i]  = src.pay[i];
-            a.out.eta[base + i]  = src.eta[i];
-        }
-    }
-
-    if (overflow)
-        atomicOr(&a.qs->error_flags, 1u);
-    const uint32_t u = wave_sum_u32(c_unoccluded);
-    if (lane == 0) {
-        if (c_bounce) atomicAdd(&a.qs->bounce_rays, (unsigned long long)c_bounce);
-        if (c_shadow) atomicAdd(&a.qs->shadow_rays, (unsigned long long)c_shadow);
-        if (u) atomicAdd(&a.qs->unoccluded, (unsigned long long)u);
-    }
-    if (STATS) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const uint32_t nn = wave_sum_u32(c_work[k][0]), tt = wave_sum_u32(c_work[k][1]), ll = wave_sum_u32(c_work[k][2]);
-            if (lane == 0) {
-                atomicAdd(&a.qs->nodes[k], (unsigned long long)nn);
-                atomicAdd(&a.qs->tris[k], (unsigned long long)tt);
-                atomicAdd(&a.qs->leaves[k], (unsigned long long)ll);
-            }
-        }
-    }
-    if (a.count_paths && blockIdx.x == 0 && tid == 0)
-        a.qs->tail_rays += n;
-}
-
-template __global__ void k_tail_wave<false>(const TailArgs);
-template __global__ void k_tail_wave<true>(const TailArgs);
-
-void launch_tail_wave(const TailArgs& args, bool stats, int grid_blocks, hipStream_t stream)
-{
-    if (stats)
-        hipLaunchKernelGGL((k_tail_wave<true>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
-    else
-        hipLaunchKernelGGL((k_tail_wave<false>), dim3((unsigned)grid_blocks), dim3(kTailThreads), 0, stream, args);
 }
 
 template __global__ void k_tail<false, false>(const TailArgs);

@@ -50,14 +50,6 @@ constexpr int kLdsStack     = IG_LDS_STACK;
 constexpr int kTraverseOcc  = IG_TRAV_OCC;   // workgroups of 256 per CU = waves per SIMD the kernel is built for
 constexpr int kBlockThreads = 256;
 constexpr int kScanLeaves   = 2; // entity-leaf section: leaves of a run fetched per round trip (the host builder keeps runs <= 2)
-#ifndef IG_TRI_FULL
-#define IG_TRI_FULL 0
-#endif
-constexpr bool kTriFull = IG_TRI_FULL != 0; // triangle section: both halves of a packet fetched with its ids (one round trip, 24 more registers)
-#ifndef IG_LEAF_EARLY
-#define IG_LEAF_EARLY 1
-#endif
-constexpr bool kLeafEarly = IG_LEAF_EARLY != 0; // entity-leaf section: rows 2 - 7 of the first scanned leaf fetched with the scan rows
 
 // Per-lane LDS of one workgroup of BLOCK lanes: the traversal stacks, entry-major so that a wave's accesses are conflict free.
 template <int BLOCK>
@@ -405,13 +397,13 @@ struct Traverser {
             mask_t enter  = 0;
             int enter_at  = 0;
             int entity_id = 0;
-            float4 early[6]; // kLeafEarly: rows 2 - 7 of the leaf the scan looked at first
+            // rows 2 - 7 of the leaf the scan looks at first come with its scan rows: the common case (that leaf is entered) then costs one
+            // round trip instead of three (+1 %, any hit -3 %; profiles/r04_experiment_ab.txt)
+            float4 early[6];
             int early_at = -1;
-            if (kLeafEarly) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    early[k] = make_float4(0, 0, 0, 0);
-            }
+            for (int k = 0; k < 6; ++k)
+                early[k] = make_float4(0, 0, 0, 0);
             do {
                 prof(4);
                 bool inside = false, last = false;
@@ -426,7 +418,7 @@ struct Traverser {
 #pragma unroll
                     for (int k = 0; k < kScanLeaves; ++k)
                         lr[k][0] = ld16(ls, lsat, 2 * k), lr[k][1] = ld16(ls, lsat, 2 * k + 1);
-                    if (kLeafEarly && !SPHERES) {
+                    if (!SPHERES) {
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
                             early[k] = ld16(sc.leaves, (uint32_t)at * (uint32_t)(kDevLeafRows * 16), 2 + k);
@@ -467,7 +459,7 @@ struct Traverser {
                     const void* lf      = SPHERES ? sc.sphere_leaves : sc.leaves;
                     const uint32_t lfat = (uint32_t)enter_at * (uint32_t)(kDevLeafRows * 16);
                     float4 l2, l3, l4, l5, l6 = make_float4(0, 0, 0, 0), l7 = l6;
-                    const bool have_early = kLeafEarly && !SPHERES && enter_at == early_at;
+                    const bool have_early = !SPHERES && enter_at == early_at;
                     if (have_early) {
                         l2 = early[0], l3 = early[1], l4 = early[2], l5 = early[3], l6 = early[4], l7 = early[5];
                     } else {
@@ -698,12 +690,6 @@ struct Traverser {
                 // of 48, and the second half is not even fetched when the packet holds no more than two triangles
                 const int4 pid4  = ld16i(sc.geom, tri_at, 12);
                 const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
-                float4 call[2][6];
-                if (kTriFull) {
-#pragma unroll
-                    for (int m = 0; m < 12; ++m)
-                        call[m / 6][m % 6] = ld16(sc.geom, tri_at, m);
-                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     // (valid triangles are packed from slot 0: the first -1 ends the packet, mapping_cpu.art:386; the first half comes
@@ -719,7 +705,7 @@ struct Traverser {
                     float4 c[6];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
-                        c[m] = kTriFull ? call[h][m] : ld16(sc.geom, tri_at, 6 * h + m);
+                        c[m] = ld16(sc.geom, tri_at, 6 * h + m);
                     float q[12][2];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
