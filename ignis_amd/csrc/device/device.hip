@@ -211,6 +211,7 @@ struct igd_device {
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     int tail_split = 6;
+    int tail_wide  = 4; // IGD_TAIL_WIDE: TailArgs::wide_lanes
     // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
     // with 256 / 1 024 / 3 072 waves, workgroups of one or four waves alike; a bare launch of that shape costs 1 ns per wave,
     // tools/launch_cost.hip, so the kernel spends it -- where is open). Pass j of a chunk gets as many waves as twice the
@@ -909,9 +910,17 @@ void collect(igd_device* d, igd_device::Flight& f)
     d->stats.shadow_rays += q.shadow_rays;
     d->stats.unoccluded += q.unoccluded;
     d->stats.tail_rays += q.tail_rays;
-    if (q.tail_pass_in[0]) // (a chunk without a tail leaves the table as it is)
+    if (q.tail_pass_in[0]) { // (a chunk without a tail leaves the table as it is)
         for (int j = 0; j < 24; ++j)
             d->tail_share[j] = (double)q.tail_pass_in[j] / (double)q.tail_pass_in[0];
+        static const bool tail_debug = std::getenv("IGD_TAIL_DEBUG") != nullptr;
+        if (tail_debug) {
+            std::fprintf(stderr, "[tail] paths at the start of the passes:");
+            for (int j = 0; j < 24 && q.tail_pass_in[j]; ++j)
+                std::fprintf(stderr, " %u", q.tail_pass_in[j]);
+            std::fprintf(stderr, "\n");
+        }
+    }
     d->noteDeep(q.deep_total, q.camera_rays + q.bounce_rays + q.shadow_rays);
     d->stats.nodes_primary += q.nodes[0], d->stats.nodes_secondary += q.nodes[1];
     d->stats.tris_primary += q.tris[0], d->stats.tris_secondary += q.tris[1];
@@ -1527,6 +1536,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.frame        = frame;
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
+            tl.wide_lanes   = (uint32_t)d->tail_wide;
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
             HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
@@ -1904,6 +1914,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_TAIL_WIDE"))
+            d->tail_wide = std::min(64, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("IGD_TAIL_ADAPT"))
             d->tail_adapt = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_DENSITY"))

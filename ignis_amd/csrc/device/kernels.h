@@ -243,6 +243,9 @@ struct TailArgs {
     int32_t count_paths; // add the input size to qs->tail_rays
     int32_t pass;        // index of this pass (qs->tail_pass_in)
     uint32_t deep_lane_base; // first deep-stack column of this launch's lanes
+    // a wave that follows no more than this many paths traverses their closest-hit rays one at a time with all its lanes
+    // (wide_core.h); 0: never
+    uint32_t wide_lanes;
 };
 
 struct ResolveArgs {

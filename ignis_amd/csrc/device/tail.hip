@@ -15,6 +15,7 @@
 // full waves instead of pinning every wave of the grid behind its longest lane.
 #include "shade_core.h"
 #include "traverse_core.h"
+#include "wide_core.h"
 
 namespace igdev {
 
@@ -132,29 +133,56 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         TAIL_MARK(0); // refill
         const mask_t have_m = lanes_where(have);
         {
-            Traverser<false, STATS, kTailBlock, true> tr;
-            tr.init_counters();
-            tr.attach_deep(deep_col, sc.deep_stride);
-            tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
-            while (tr.active()) {
-                tr.step(sc, s_stack, tid);
+            if (lanes_in(have_m) <= (int)a.wide_lanes) {
+                // a handful of paths: their rays one after the other, each traversed by the whole wave
+                mask_t todo = have_m;
+                while (todo) {
+                    const int l = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    WideTraverser<STATS> w;
+                    w.run(sc, s_stack, wide_bcast(in.org, l), wide_bcast(in.dir, l), wide_bcast(tmin, l), wide_bcast(tmax, l), (uint32_t)wide_bcast((int)flags, l));
+                    if (lane == l) {
+                        in.ent  = w.hit_ent;
+                        in.prim = w.hit_prim;
+                        in.t = w.tmax, in.u = w.hit_u, in.v = w.hit_v;
+                        overflow |= w.overflow;
+                        if (STATS) {
+                            c_nodes[0] += w.st_nodes;
+                            c_tris[0] += w.st_tris;
+                            c_leaves[0] += w.st_leaves;
+                        }
+                    }
+                    region_end();
 #ifdef IG_TAIL_CLOCKS
-                tclk[5] += 1; // passes of the closest-hit traversal
+                    tclk[5] += 1;
 #endif
-            }
-            TAIL_MARK(1); // closest-hit traversal
-            if (have) {
-                in.ent  = tr.hit_ent;
-                in.prim = tr.hit_prim;
-                in.t = tr.tmax, in.u = tr.hit_u, in.v = tr.hit_v;
-                overflow |= tr.overflowed();
-                if (STATS) {
-                    c_nodes[0] += tr.st_nodes;
-                    c_tris[0] += tr.st_tris;
-                    c_leaves[0] += tr.st_leaves;
                 }
+                TAIL_MARK(1);
+            } else {
+                Traverser<false, STATS, kTailBlock, true> tr;
+                tr.init_counters();
+                tr.attach_deep(deep_col, sc.deep_stride);
+                tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
+                while (tr.active()) {
+                    tr.step(sc, s_stack, tid);
+#ifdef IG_TAIL_CLOCKS
+                    tclk[5] += 1; // passes of the closest-hit traversal
+#endif
+                }
+                TAIL_MARK(1); // closest-hit traversal
+                if (have) {
+                    in.ent  = tr.hit_ent;
+                    in.prim = tr.hit_prim;
+                    in.t = tr.tmax, in.u = tr.hit_u, in.v = tr.hit_v;
+                    overflow |= tr.overflowed();
+                    if (STATS) {
+                        c_nodes[0] += tr.st_nodes;
+                        c_tris[0] += tr.st_tris;
+                        c_leaves[0] += tr.st_leaves;
+                    }
+                }
+                region_end();
             }
-            region_end();
             if (sc.sphere_node_count) {
                 // the sphere geometry, from the hit so far (traverse.hip launches it as a second pass)
                 Traverser<false, STATS, kTailBlock, false, true> tp;

@@ -32,24 +32,25 @@ def diamond_scene():
     return LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 128, 128)
 
 
-@pytest.fixture(scope="session", params=["tail", "rounds"])
+@pytest.fixture(scope="session", params=["tail", "rounds", "tail-wide"])
 def gpu_device(request):
-    """The device every feature-parity test renders on, in two schedules. "tail": the product's default — a
+    """The device every feature-parity test renders on, in three schedules. "tail": the product's default — a
     stream of <= 1 Mi paths is handed to k_tail before round 0, which is where every small-film test ends up. "rounds":
     IGD_TAIL_THRESHOLD=0, the same test through the wavefront kernels the benchmark runs (k_shade + k_traverse rounds to the
-    last path). The schedule is read when the device is created."""
+    last path). "tail-wide": IGD_TAIL_WIDE=64, k_tail with every closest-hit ray traversed by a whole wave (wide_core.h, what
+    the product does for waves that follow <= 4 paths). The schedule is read when the device is created."""
     from ignis_amd import Device
-    old = os.environ.get("IGD_TAIL_THRESHOLD")
-    if request.param == "rounds":
-        os.environ["IGD_TAIL_THRESHOLD"] = "0"
+    env = {"rounds": {"IGD_TAIL_THRESHOLD": "0"}, "tail-wide": {"IGD_TAIL_WIDE": "64"}}.get(request.param, {})
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         dev = Device(0, acquire_stats=True)
     finally:
-        if request.param == "rounds":
-            if old is None:
-                del os.environ["IGD_TAIL_THRESHOLD"]
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
             else:
-                os.environ["IGD_TAIL_THRESHOLD"] = old
+                os.environ[k] = v
     yield dev
     dev.close()
 

@@ -157,6 +157,8 @@ def test_small_stream_capacity_chunks_match(diamond_scene):
     {"IGD_TAIL_THRESHOLD": "100000000", "IGD_TAIL_SPLIT": "5"},                     # everything after round 0
     {"IGD_TAIL_THRESHOLD": "20000", "IGD_TAIL_SPLIT": "3", "IGD_FLIGHTS": "2"},      # two chunks in flight
     {"IGD_TAIL_THRESHOLD": "20000", "IGD_TAIL_SPLIT": "3", "IGD_FLIGHTS": "8"},
+    {"IGD_TAIL_THRESHOLD": "100000000", "IGD_TAIL_SPLIT": "5", "IGD_TAIL_WIDE": "64"},  # every closest-hit ray of the tail by a whole wave
+    {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_TAIL_WIDE": "0"},       # none
 ])
 def test_overlapped_tail_schedules_match_blocking(diamond_scene, monkeypatch, env):
     """The long-path tail of iteration i runs on a second stream while iteration i + 1 starts, in one or many
