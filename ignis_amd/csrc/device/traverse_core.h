@@ -74,6 +74,15 @@ IG_DEV int lanes_in(mask_t m) { return __builtin_popcountll(m); }
 // volatile asm that keeps the region's join a block of its own, and (ii) masks are never assigned under any `if`: their updates
 // are unconditional scalar code (an empty region costs its two scalar instructions either way).
 IG_DEV void region_end() { asm volatile(""); }
+// a register with no particular value, at no instruction: for state that is written before it is read by the lanes that count
+// (a v_mov of 0 per register otherwise: the one-time prologue, the early rows of the leaf scan)
+IG_DEV float any_f32()
+{
+    float x;
+    asm volatile("" : "=v"(x));
+    return x;
+}
+IG_DEV f3 any_f3() { return f3{ any_f32(), any_f32(), any_f32() }; }
 // -DIG_ISA_MARKS: comment lines in the assembly at the borders of the kernel's parts, for tools/isa_regions.py (static
 // instructions per part; with the event counts of tools/trav_events.py: the dynamic mix). Analysis builds only.
 #ifdef IG_ISA_MARKS
@@ -193,11 +202,12 @@ struct Traverser {
         st_nodes = st_tris = st_leaves = 0;
         for (int k = 0; k < 3; ++k)
             sec_pass[k] = sec_lane[k] = 0;
-        scene_ray = RayT{ f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 }, f3{ 0, 0, 0 } };
-        lorg = ldir = inv = io = f3{ 0, 0, 0 };
-        tmin = tmax = scene_tmax = 0;
+        // (ray and hit: begin() writes them for every lane that gets a ray, and no other lane's are looked at)
+        scene_ray = RayT{ any_f3(), any_f3(), any_f3(), any_f3() };
+        lorg = any_f3(), ldir = any_f3(), inv = any_f3(), io = any_f3();
+        tmin = any_f32(), tmax = any_f32(), scene_tmax = any_f32();
         rflags = 0;
-        hit_u = hit_v = l_u = l_v = 0;
+        hit_u = any_f32(), hit_v = any_f32(), l_u = any_f32(), l_v = any_f32();
         hit_prim = hit_ent = l_prim = -1;
         lbase = sp = 0;
         top = make_uint2(0u, 0u);
@@ -345,22 +355,27 @@ struct Traverser {
             IG_MARK("settle.ret");
             // shape BVH done: back to the scene leaf run (mapping_cpu.art:489-508). The local hit is
             // accepted only if its (rounded) distance does not exceed the current one.
-            bool accept = false;
+            // (the verdict as a mask, and the two outcomes as regions of their own: the hit registers are written in place, not selected)
+            const mask_t accept = lanes_where(l_prim != -1) & lanes_where(tmax <= scene_tmax) & ret;
             if (in(ret)) {
                 pop_top(st);
-                accept   = (l_prim != -1) & (tmax <= scene_tmax);
-                hit_u    = accept ? l_u : hit_u;
-                hit_v    = accept ? l_v : hit_v;
-                hit_prim = accept ? l_prim : hit_prim;
-                hit_ent  = accept ? cur_ent : hit_ent;
-                tmax     = accept ? tmax : scene_tmax;
                 inv       = scene_ray.inv_dir;
                 io        = scene_ray.inv_org;
                 nodes_off = sc.scene_nodes_off;
             }
             region_end();
+            if (in(accept)) {
+                hit_u    = l_u;
+                hit_v    = l_v;
+                hit_prim = l_prim;
+                hit_ent  = cur_ent;
+            }
+            region_end();
+            if (in(ret & ~accept))
+                tmax = scene_tmax;
+            region_end();
             // (an any-hit ray that just accepted its hit is done: it must not be taken for a lane waiting at its next leaf)
-            const mask_t on = ANY_HIT ? ret & ~lanes_where(accept) : ret;
+            const mask_t on = ANY_HIT ? ret & ~accept : ret;
             m_node |= work & ~sentinel & ~leaf;
             m_tri |= tris;
             m_leaf |= ents | (on & ~ent_last); // a leaf to enter; on with the leaf run after a shape
@@ -403,7 +418,7 @@ struct Traverser {
             int early_at = -1;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-                early[k] = make_float4(0, 0, 0, 0);
+                early[k] = make_float4(any_f32(), any_f32(), any_f32(), any_f32()); // (read only where early_at says they were loaded)
             do {
                 prof(4);
                 bool inside = false, last = false;
@@ -458,13 +473,11 @@ struct Traverser {
                 if (in(enter)) {
                     const void* lf      = SPHERES ? sc.sphere_leaves : sc.leaves;
                     const uint32_t lfat = (uint32_t)enter_at * (uint32_t)(kDevLeafRows * 16);
-                    float4 l2, l3, l4, l5, l6 = make_float4(0, 0, 0, 0), l7 = l6;
+                    // (the early rows where they are the entered leaf's, loaded over otherwise: no copies either way)
+                    float4 l2 = early[0], l3 = early[1], l4 = early[2], l5 = early[3], l6 = early[4], l7 = early[5];
                     const bool have_early = !SPHERES && enter_at == early_at;
-                    if (have_early) {
-                        l2 = early[0], l3 = early[1], l4 = early[2], l5 = early[3], l6 = early[4], l7 = early[5];
-                    } else {
+                    if (!have_early)
                         l2 = ld16(lf, lfat, 2), l3 = ld16(lf, lfat, 3), l4 = ld16(lf, lfat, 4), l5 = ld16(lf, lfat, 5);
-                    }
                     const uint2 ext = make_uint2(igm_bits(l5.x), igm_bits(l5.y));
                     m34 m;
                     m.c0 = f3{ l2.x, l2.y, l2.z };
