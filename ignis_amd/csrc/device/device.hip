@@ -31,7 +31,7 @@ void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int gri
 int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
-void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream);
+void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream, uint32_t classes);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
@@ -210,6 +210,8 @@ struct igd_device {
     // the survivors, compacted, to the next one. Path lengths are geometric (a path inside a dielectric survives
     // a bounce with p ~ 0.85), so without this every wave idles behind its longest lane and pins registers and
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
+    uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
+    bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
     int tail_split = 6;
     int tail_wide  = 4; // IGD_TAIL_WIDE: TailArgs::wide_lanes
     // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
@@ -794,6 +796,11 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT | IG_MAT_EXPR_NUMBERS)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
+    d->shade_classes = 1u;
+    for (uint32_t i = 0; i < s->material_count; ++i) {
+        const int t = s->materials[i].bsdf_type;
+        d->shade_classes |= t == IG_BSDF_PRINCIPLED ? 2u : (t == IG_BSDF_PLASTIC || t == IG_BSDF_ROUGH_DIELECTRIC) ? 4u : t == IG_BSDF_BLEND ? 8u : 0u;
+    }
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
     d->full_bsdfs |= simple_selector;
@@ -1452,7 +1459,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 if (ppm)
                     launch_shade_ppm(sa, shade_grid, on);
                 else
-                    launch_shade(sa, shade_grid, d->full_bsdfs, on);
+                    launch_shade(sa, shade_grid, d->full_bsdfs, on, d->shade_by_class ? d->shade_classes : 0u);
                 launch_round_end(qs, in_slot, on);
             });
 
@@ -1914,6 +1921,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_SHADE_CLASSES"))
+            d->shade_by_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_WIDE"))
             d->tail_wide = std::min(64, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("IGD_TAIL_ADAPT"))

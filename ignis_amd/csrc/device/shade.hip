@@ -437,6 +437,10 @@ template __global__ void k_shade<true>(const ShadeArgs);
 template __global__ void k_shade<true, true, true>(const ShadeArgs);
 template __global__ void k_shade<true, false, true>(const ShadeArgs);
 template __global__ void k_shade<true, false, true, true>(const ShadeArgs);
+template __global__ void k_shade<true, false, false, false, 0, kClassBasic>(const ShadeArgs);
+template __global__ void k_shade<true, false, false, false, 0, kClassPrincipled>(const ShadeArgs);
+template __global__ void k_shade<true, false, false, false, 0, kClassCoated>(const ShadeArgs);
+template __global__ void k_shade<true, false, false, false, 0, kClassBlend>(const ShadeArgs);
 
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream)
 {
@@ -444,7 +448,9 @@ void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream)
     hipLaunchKernelGGL(k_generate_light, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, args);
 }
 
-void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream)
+// classes: which material classes the scene has (bit 0 basic — always launched: the misses are its —, 1 principled, 2 coated,
+// 3 blend); 0: the one instantiation with every model
+void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream, uint32_t classes)
 {
     if (args.scene.tech.type == IG_TECHNIQUE_LIGHTTRACER)
         hipLaunchKernelGGL((k_shade<true, false, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
@@ -452,7 +458,15 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipSt
         hipLaunchKernelGGL((k_shade<true, true, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else if (args.scene.expr_code) // materials with shading expressions: the instantiation with the interpreter (no tail kernels either)
         hipLaunchKernelGGL((k_shade<true, false, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
-    else if (full_bsdfs)
+    else if (full_bsdfs && classes != 0) {
+        hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBasic>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+        if (classes & 2u)
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassPrincipled>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+        if (classes & 4u)
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassCoated>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+        if (classes & 8u)
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBlend>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+    } else if (full_bsdfs)
         hipLaunchKernelGGL((k_shade<true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else
         hipLaunchKernelGGL((k_shade<false>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);

@@ -1365,8 +1365,12 @@ IG_DEV Col material_color(const DevScene& sc, const ig_material& m, const Surf& 
 
 // RARE: the BSDFs only the instantiation for scenes with expressions / Radiance materials carries (k_shade<true, *, true>): in the
 // ordinary full kernel the BRTDfunc / Roos code cost diamond_scene_principled 3 % of its shading time
-template <bool FULL, bool TOP = true, bool RARE = false>
+// TYPES: the BSDF models this instantiation carries (bit IG_BSDF_*; the kernels split by material class, shade_kernel.h): a model
+// outside it is not compiled in, the caller guarantees no such material arrives. The BSDFs inside a blend are built with all of them.
+template <bool FULL, bool TOP = true, bool RARE = false, uint32_t TYPES = ~0u>
 struct BsdfCtx {
+    template <int T>
+    IG_DEV bool is() const { return ((TYPES >> T) & 1u) != 0u && mat->bsdf_type == T; }
     const ig_material* mat;
     Surf surf; // the surface the BSDF is built on (bump-mapped materials: re-oriented local frame)
     Col kd;    // diffuse reflectance (constant or checkerboard)
@@ -1389,7 +1393,7 @@ struct BsdfCtx {
                 kd.r = eval_expr(sc, m.tex_id, surf, -ray_dir).x;
         }
         if constexpr (FULL && RARE) {
-            if (m.bsdf_type == IG_BSDF_RAD_ROOS) { // cosN = -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28); kd carries (rf, tau)
+            if (is<IG_BSDF_RAD_ROOS>()) { // cosN = -dot(ctx.ray.dir, ctx.surf.local.col(2)) (RadRoosBSDF.cpp:28); kd carries (rf, tau)
                 const f2 ft = rad_roos_factors(m, -dot3(ray_dir, surf.local.c2));
                 kd          = Col{ ft.x, ft.y, 0 };
             }
@@ -1417,21 +1421,21 @@ struct BsdfCtx {
     IG_DEV bool all_delta() const
     {
         if constexpr (FULL && TOP) {
-            if (mat->bsdf_type == IG_BSDF_BLEND) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
+            if (is<IG_BSDF_BLEND>()) // mat1.is_all_delta & mat2.is_all_delta (mix.art:63)
                 return inner(0).all_delta() && inner(1).all_delta();
         }
-        return mat->bsdf_type == IG_BSDF_DIELECTRIC || (FULL && mat->bsdf_type == IG_BSDF_TRANSPARENT) || (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH));
+        return is<IG_BSDF_DIELECTRIC>() || (FULL && is<IG_BSDF_TRANSPARENT>()) || (is<IG_BSDF_CONDUCTOR>() && (mat->flags & IG_MAT_SMOOTH));
     }
     IG_DEV Ggx ggx() const { return Ggx{ surf.local, mat->p[9], mat->p[10] }; }
     // the weight of a blend: p[0], or (instantiation with expressions only) the value the constructor left in kd.r
     IG_DEV float blend_weight() const { return RARE ? kd.r : mat->p[0]; }
-    IG_DEV bool is_rad() const { return FULL && RARE && (mat->bsdf_type == IG_BSDF_RAD_BRTD || mat->bsdf_type == IG_BSDF_RAD_ROOS); }
+    IG_DEV bool is_rad() const { return FULL && RARE && (is<IG_BSDF_RAD_BRTD>() || is<IG_BSDF_RAD_ROOS>()); }
     // make_rad_brtdfunc_bsdf / make_rad_roos_bsdf (bsdf/rad.art) from the material record
     IG_DEV RadBrtd rad() const
     {
         const Col td{ mat->q[0], mat->q[1], mat->q[2] };
         const Col rf{ mat->p[6], mat->p[7], mat->p[8] }, rb{ mat->p[9], mat->p[10], mat->p[11] };
-        if (mat->bsdf_type == IG_BSDF_RAD_ROOS) {
+        if (is<IG_BSDF_RAD_ROOS>()) {
             const Col black{ 0, 0, 0 };
             return make_rad_brtd(surf.entering, Col{ kd.r, kd.r, kd.r }, Col{ kd.g, kd.g, kd.g }, rf + black, rb + black, td);
         }
@@ -1516,7 +1520,7 @@ struct BsdfCtx {
             return Col{ mat->p[0], mat->p[1], mat->p[2] };
         case IG_BSDF_ROUGH_DIELECTRIC:
         case IG_BSDF_DIELECTRIC: // make_pure_dielectric_bsdf / make_rough_dielectric_bsdf (bsdf/dielectric.art:35,190); thin: ks (:60)
-            if (mat->bsdf_type == IG_BSDF_DIELECTRIC && (mat->flags & IG_MAT_THIN))
+            if (is<IG_BSDF_DIELECTRIC>() && (mat->flags & IG_MAT_THIN))
                 return Col{ mat->p[2], mat->p[3], mat->p[4] };
             return lerp_col(Col{ mat->p[2], mat->p[3], mat->p[4] }, Col{ mat->p[5], mat->p[6], mat->p[7] }, 0.5f);
         case IG_BSDF_CONDUCTOR: { // compute_albedo (bsdf/conductor.art:50-56), kd = black
@@ -1550,27 +1554,27 @@ struct BsdfCtx {
         if constexpr (FULL && TOP) {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
-            if (mat->bsdf_type == IG_BSDF_BLEND) // eval_f = color_lerp (mix.art:5-8,68)
+            if (is<IG_BSDF_BLEND>()) // eval_f = color_lerp (mix.art:5-8,68)
                 return lerp_col(inner(0).eval(in_dir, out_dir), inner(1).eval(in_dir, out_dir), blend_weight());
         }
         if constexpr (FULL) {
             if (is_rad())
                 return rad().eval(surf.local, in_dir);
-            if (mat->bsdf_type == IG_BSDF_PHONG)
+            if (is<IG_BSDF_PHONG>())
                 return phong_eval(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+            if (is<IG_BSDF_PRINCIPLED>())
                 return principled().eval(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_PLASTIC)
+            if (is<IG_BSDF_PLASTIC>())
                 return Plastic(*mat, surf.local, kd).eval(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+            if (is<IG_BSDF_ROUGH_DIELECTRIC>())
                 return RoughDielectric(*mat, surf.local, surf.entering).eval(in_dir, out_dir);
         }
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+        if (is<IG_BSDF_DIFFUSE>()) {
             if (FULL && mat->p[3] > kFltEps) // make_diffuse_bsdf (bsdf/diffuse.art:52-58): a roughness selects Oren-Nayar
                 return orennayar_eval(in_dir, out_dir);
             return kd * (pos_cos(in_dir, N) * kInvPi);
         }
-        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+        if (is<IG_BSDF_CONDUCTOR>()) {
             const float cos_o = abs_cos(out_dir, N);
             const float cos_i = abs_cos(in_dir, N);
             if (cos_o <= kFltEps || cos_i <= kFltEps)
@@ -1592,7 +1596,7 @@ struct BsdfCtx {
         if constexpr (FULL && TOP) {
             in_dir  = ds_flip ? -in_dir : in_dir;
             out_dir = ds_flip ? -out_dir : out_dir;
-            if (mat->bsdf_type == IG_BSDF_BLEND) { // mix.art:10-22 with a constant weight
+            if (is<IG_BSDF_BLEND>()) { // mix.art:10-22 with a constant weight
                 const float k = blend_weight();
                 if (k <= 0)
                     return inner(0).pdf(in_dir, out_dir);
@@ -1604,18 +1608,18 @@ struct BsdfCtx {
         if constexpr (FULL) {
             if (is_rad())
                 return rad().pdf(surf.local, in_dir);
-            if (mat->bsdf_type == IG_BSDF_PHONG)
+            if (is<IG_BSDF_PHONG>())
                 return phong_pdf(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_PRINCIPLED)
+            if (is<IG_BSDF_PRINCIPLED>())
                 return principled().pdf(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_PLASTIC)
+            if (is<IG_BSDF_PLASTIC>())
                 return Plastic(*mat, surf.local, kd).pdf(in_dir, out_dir);
-            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC)
+            if (is<IG_BSDF_ROUGH_DIELECTRIC>())
                 return RoughDielectric(*mat, surf.local, surf.entering).pdf(in_dir, out_dir);
         }
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE)
+        if (is<IG_BSDF_DIFFUSE>())
             return pos_cos(in_dir, surf.local.c2) / kPi;
-        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+        if (is<IG_BSDF_CONDUCTOR>()) {
             const f3 H      = normalize3(in_dir + out_dir);
             const float cho = abs_cos(out_dir, H);
             return ggx().pdf(out_dir, H) * safe_div(1, 4 * cho);
@@ -1638,7 +1642,7 @@ struct BsdfCtx {
     {
         const f3 N = surf.local.c2;
         if constexpr (FULL && TOP) {
-            if (mat->bsdf_type == IG_BSDF_BLEND) {
+            if (is<IG_BSDF_BLEND>()) {
                 // make_join_bsdf.sample (mix.art:27-55); sample_mat(first, second, t)
                 const float k    = blend_weight();
                 const bool pick1 = rnd.f32() < 1 - k;
@@ -1663,13 +1667,13 @@ struct BsdfCtx {
                 s_eta = 1;
                 return true;
             }
-            if (mat->bsdf_type == IG_BSDF_PHONG) {
+            if (is<IG_BSDF_PHONG>()) {
                 phong_sample(rnd, out_dir, in_dir, pdf_out, color);
                 s_eta  = 1;
                 sdelta = false;
                 return true;
             }
-            if (mat->bsdf_type == IG_BSDF_TRANSPARENT) { // make_perfect_refraction_bsdf.sample (bsdf/dielectric.art:6-8)
+            if (is<IG_BSDF_TRANSPARENT>()) { // make_perfect_refraction_bsdf.sample (bsdf/dielectric.art:6-8)
                 in_dir  = -out_dir;
                 pdf_out = 1;
                 color   = Col{ mat->p[0], mat->p[1], mat->p[2] };
@@ -1677,20 +1681,20 @@ struct BsdfCtx {
                 sdelta  = true;
                 return true;
             }
-            if (mat->bsdf_type == IG_BSDF_PRINCIPLED) {
+            if (is<IG_BSDF_PRINCIPLED>()) {
                 sdelta = false;
                 return principled().sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, adjoint);
             }
-            if (mat->bsdf_type == IG_BSDF_ROUGH_DIELECTRIC) {
+            if (is<IG_BSDF_ROUGH_DIELECTRIC>()) {
                 sdelta = false;
                 return RoughDielectric(*mat, surf.local, surf.entering).sample(rnd, out_dir, in_dir, pdf_out, color, s_eta, adjoint);
             }
-            if (mat->bsdf_type == IG_BSDF_PLASTIC) {
+            if (is<IG_BSDF_PLASTIC>()) {
                 s_eta = 1;
                 return Plastic(*mat, surf.local, kd).sample(rnd, out_dir, in_dir, pdf_out, color, sdelta);
             }
         }
-        if (mat->bsdf_type == IG_BSDF_DIFFUSE) {
+        if (is<IG_BSDF_DIFFUSE>()) {
             // make_lambertian_bsdf.sample (bsdf/diffuse.art:5-9), sample_cosine_hemisphere (core/sampling.art:62-70)
             const float u   = rnd.f32();
             const float v   = rnd.f32();
@@ -1706,7 +1710,7 @@ struct BsdfCtx {
             sdelta          = false;
             return true;
         }
-        if (mat->bsdf_type == IG_BSDF_CONDUCTOR && (mat->flags & IG_MAT_SMOOTH)) {
+        if (is<IG_BSDF_CONDUCTOR>() && (mat->flags & IG_MAT_SMOOTH)) {
             // delta branch of make_rough_base_conductor_bsdf (bsdf/conductor.art:56-68): compute_albedo(out_dir), kd = black
             const float cos_o = abs_cos(out_dir, N);
             const Col F  = Col{ conductor_factor(mat->p[0], mat->p[3], cos_o), conductor_factor(mat->p[1], mat->p[4], cos_o), conductor_factor(mat->p[2], mat->p[5], cos_o) };
@@ -1718,7 +1722,7 @@ struct BsdfCtx {
             sdelta  = true;
             return true;
         }
-        if (mat->bsdf_type == IG_BSDF_CONDUCTOR) {
+        if (is<IG_BSDF_CONDUCTOR>()) {
             // make_rough_base_conductor_bsdf.sample (bsdf/conductor.art:93-114)
             const float cos_o = abs_cos(out_dir, N);
             if (cos_o <= kFltEps)
@@ -2546,7 +2550,7 @@ IG_DEV Col clamp_color(const ig_technique& tech, Col c) // handle_color, techniq
 // DEBUG_VIEWS: the instantiation for the debug technique (its 28 views, with a second copy of the BSDF code for the BSDF check,
 // cost the ordinary full kernel ten times its spills when they were a run-time branch of it)
 // EXPR: the instantiation for scenes whose materials carry shading expressions (include/ig_expr.h)
-template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, class CLK = NoClock>
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, uint32_t TYPES = ~0u, class CLK = NoClock>
 IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVertexIn& in, PathVertexOut& out, CLK&& clk = CLK{})
 {
     out.has_radiance = false;
@@ -2617,7 +2621,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     clk.mark(2);
     ig_material mat_local;
     const ig_material& mat = resolve_material<EXPR>(sc, sc.materials[sc.entity_material[in.ent]], surf, -in.dir, mat_local);
-    const BsdfCtx<FULL, true, EXPR> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
+    const BsdfCtx<FULL, true, EXPR, TYPES> bsdf(sc, mat, surf, in.dir, std::bool_constant<EXPR>{});
     clk.mark(3);
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;

@@ -26,10 +26,23 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #define IG_SHADE_OCC_LEAN 4
 #endif
 constexpr int kBounceBins = 16; // the bounce rays of a window leave grouped by (specular bounce, octant of the direction)
+
+// The full path-tracer variant by material class: one instantiation per group of BSDF models, each
+// launched over the same hits and shading only the rays whose material is of its group (the others are some other launch's). What a
+// kernel's register file has to hold is then the largest model of its group, not of the whole library: the one-for-all instantiation
+// needs 252 VGPRs (168 + 292 B of scratch at three waves per SIMD). Misses go with the basic group. A blend carries every model.
+constexpr uint32_t kClassMiss       = 1u << 31;
+constexpr uint32_t kClassBasic      = (1u << IG_BSDF_DIFFUSE) | (1u << IG_BSDF_DIELECTRIC) | (1u << IG_BSDF_CONDUCTOR) | (1u << IG_BSDF_TRANSPARENT) | (1u << IG_BSDF_PHONG) | kClassMiss;
+constexpr uint32_t kClassPrincipled = 1u << IG_BSDF_PRINCIPLED;
+constexpr uint32_t kClassCoated     = (1u << IG_BSDF_PLASTIC) | (1u << IG_BSDF_ROUGH_DIELECTRIC);
+constexpr uint32_t kClassBlend      = 1u << IG_BSDF_BLEND;
+constexpr uint32_t kClassAll        = ~0u;
+
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
-template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false, int PPM = 0>
+template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false, int PPM = 0, uint32_t TYPES = kClassAll>
 __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
+    constexpr bool BY_CLASS = TYPES != kClassAll;
     __shared__ uint32_t s_hist[kShadeThreads];
     __shared__ uint32_t s_scan[kShadeThreads];
     __shared__ uint16_t s_perm[kShadeThreads];
@@ -73,6 +86,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             if (i < n) {
                 const int ent = (int)igm_bits(a.in.hit[i].x);
                 key           = ent < 0 ? M : sc.entity_material[ent];
+                if (BY_CLASS) { // a ray of another class goes to the bin behind the last one this launch shades
+                    const uint32_t bit = key == M ? kClassMiss : 1u << (sc.materials[key].bsdf_type & 31);
+                    key                = (TYPES & bit) ? key : M + 1;
+                }
             }
             s_hist[tid] = 0;
             __syncthreads();
@@ -100,7 +117,15 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             s_perm[start + r]    = (uint16_t)tid;
             __syncthreads();
             j = base + s_perm[tid];
+            if (BY_CLASS && (uint32_t)tid >= s_scan[M]) // (bins 0 .. M hold this launch's rays)
+                j = n;
             __syncthreads();
+        } else if (BY_CLASS) {
+            if (j < n) {
+                const int ent      = (int)igm_bits(a.in.hit[j].x);
+                const uint32_t bit = ent < 0 ? kClassMiss : 1u << (sc.materials[sc.entity_material[ent]].bsdf_type & 31);
+                j                  = (TYPES & bit) ? j : n;
+            }
         }
 
         clk.mark(0); // the sort
@@ -130,7 +155,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             else if constexpr (LT)
                 shade_vertex_lt(sc, fr, LtCamera(a.lt_cam), in, out, s_slot);
             else
-                shade_vertex<FULL, DEBUG_VIEWS, EXPR>(sc, fr, in, out, clk);
+                shade_vertex<FULL, DEBUG_VIEWS, EXPR, TYPES>(sc, fr, in, out, clk);
             clk.mark(6); // on_bounce (a miss: everything)
             if (out.has_radiance) {
                 // per-sample accumulator; the slot is owned by this ray: a plain read-modify-write (no-return float atomics give the same
