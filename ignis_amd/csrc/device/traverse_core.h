@@ -96,6 +96,24 @@ IG_DEV f3 any_f3() { return f3{ any_f32(), any_f32(), any_f32() }; }
 IG_DEV float4 ld16(const void* base, uint32_t off, int row = 0) { return reinterpret_cast<const float4*>(static_cast<const uint8_t*>(base) + off)[row]; }
 IG_DEV int4 ld16i(const void* base, uint32_t off, int row = 0) { return reinterpret_cast<const int4*>(static_cast<const uint8_t*>(base) + off)[row]; }
 
+// 16 bytes at a wave-uniform address through the scalar cache (s_load_dwordx4: the constant address space tells the compiler so): the
+// vector L1 path, which the traversal keeps ~97 % busy (TCP / TD counters, tools/tcp_pmc.sh), does not see the request
+typedef float scalar_f4 __attribute__((ext_vector_type(4)));
+typedef int scalar_i4 __attribute__((ext_vector_type(4)));
+IG_DEV float4 ld16s(const void* base, uint32_t off)
+{
+    const scalar_f4 v = *(const __attribute__((address_space(4))) scalar_f4*)(uintptr_t)(static_cast<const uint8_t*>(base) + off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+IG_DEV int4 ld16si(const void* base, uint32_t off)
+{
+    const scalar_i4 v = *(const __attribute__((address_space(4))) scalar_i4*)(uintptr_t)(static_cast<const uint8_t*>(base) + off);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+#ifndef IG_ROOT_SCALAR
+#define IG_ROOT_SCALAR 1 // the visit of the scene root inside begin(), from scalar loads, when the new rays agree on their direction's octant
+#endif
+
 template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false, bool SPHERES = false>
 struct Traverser {
     using Stack = StackOf<BLOCK>;
@@ -290,9 +308,19 @@ struct Traverser {
         ent_last |= lanes;
         // the cull at level entry (mapping_cpu.art:326-347): a root that starts behind tmax is popped, which leaves the sentinel: done
         const mask_t start = (SPHERES ? sc.sphere_node_count : sc.scene_node_count) != 0 ? (lanes_where(tmin_ <= tmax_) & lanes) : 0ull;
-        m_node             = (m_node & ~lanes) | start;
         m_tri &= ~lanes;
         m_leaf &= ~lanes;
+        if (IG_ROOT_SCALAR && !SPHERES) {
+            const mask_t nx = lanes_where(inv.x < 0) & start, ny = lanes_where(inv.y < 0) & start, nz = lanes_where(inv.z < 0) & start;
+            // (one visit per octant among the new rays, for up to two or for any number of octants, loses: 9 030 / 8 180 against 9 370 Mrays/s —
+            // the arithmetic of a visit is paid per execution, profiles/r04_experiment_ab.txt section 19)
+            if (start != 0ull && (nx == 0ull || nx == start) && (ny == 0ull || ny == start) && (nz == 0ull || nz == start)) {
+                m_node &= ~lanes;
+                root_visit(sc, st, tid, start, nx != 0ull, ny != 0ull, nz != 0ull);
+                return;
+            }
+        }
+        m_node = (m_node & ~lanes) | start;
     }
     // init_hit of a later geometry pass: the hit found so far (tmax passed to begin() is its distance)
     IG_DEV void set_initial_hit(mask_t lanes, int ent, int prim, float u, float v)
@@ -598,6 +626,89 @@ struct Traverser {
         IG_MARK("leaf.end");
     }
 
+    // (per lane, inside a region) the children of one inner node: slab tests and nearest-first insertion against the cached top
+    // (mapping_cpu.art:350-377). rows(h, ...) fetches the near / far plane rows of half h (children 4 h .. 4 h + 3).
+    template <class Rows>
+    IG_DEV void test_children(Stack& st, const int4 c4lo, const int4 c4hi, bool& out, Rows&& rows)
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int4 c4 = h ? c4hi : c4lo;
+            // two halves of four children keep the live register set small; children are packed from slot 0 (the first zero ends the
+            // list, mapping_cpu.art:357)
+            if (h == 1 && c4.x == 0)
+                break;
+            if (h == 1) {
+                prof(7);
+                IG_MARK("node.half1");
+            }
+            float4 nx, fx, ny, fy, nz, fz;
+            rows(h, nx, fx, ny, fy, nz, fz);
+            const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
+            const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
+            const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // (v_pk_fma_f32 for two children at once measured no faster: it issues like two fmas, and half of the scalar
+                // operands end up in register pairs built with v_mov; profiles/r04_experiment_ab.txt)
+                const float entry = igm_max(igm_max(igm_fma(inv.x, nb[0][i], io.x), igm_fma(inv.y, nb[1][i], io.y)), igm_max(igm_fma(inv.z, nb[2][i], io.z), tmin));
+                const float exit  = igm_min(igm_min(igm_fma(inv.x, fb[0][i], io.x), igm_fma(inv.y, fb[1][i], io.y)), igm_min(igm_fma(inv.z, fb[2][i], io.z), tmax));
+                const bool hit    = (ch[i] != 0) & !(exit < entry);
+                if (hit) {
+                    // push (becomes the top) if nearer than the current top, else push_after
+                    const bool front = ANY_HIT || (igm_float(top.y) > entry);
+                    const int pn     = front ? (int)top.x : ch[i];
+                    const float pt   = front ? igm_float(top.y) : entry;
+                    if (DEEP) {
+                        out |= push_entry(st, pn, pt);
+                    } else {
+                        // (how far the node got, and whether that was too far, is read off the address once after the eight children)
+                        sp += kRow;
+                        if (sp < kLdsEnd)
+                            slot(st, sp) = make_uint2((uint32_t)pn, igm_bits(pt));
+                    }
+                    if (front)
+                        top = make_uint2((uint32_t)ch[i], igm_bits(entry));
+                }
+            }
+        }
+    }
+
+    // The visit of the scene root for the rays begin() just started, all of one direction octant: the node is the same for every
+    // lane and so are the rows the sign of the direction picks, hence scalar loads (the root is a seventh to two fifths of the node
+    // visits of a ray, and every one of them is 14 requests of the lane to the vector L1). Same operations in the same order as the
+    // inner-node section's, then settle(): the lanes leave begin() where their first section execution would have left them.
+    IG_DEV void root_visit(const DevScene& sc, Stack& st, int tid, mask_t lanes, bool neg_x, bool neg_y, bool neg_z)
+    {
+        const uint32_t node_at = sc.scene_nodes_off;
+        const uint32_t sx = neg_x ? 32u : 0u, sy = neg_y ? 32u : 0u, sz = neg_z ? 32u : 0u;
+        const int4 c4lo = ld16si(sc.geom, node_at + 192u), c4hi = ld16si(sc.geom, node_at + 208u);
+        bool pushed = false, out = false;
+        if (in(lanes)) {
+            // (the root popped: the sentinel is the cached top, the lane's stack is empty)
+            top = make_uint2(0u, igm_bits(kFltMax));
+            sp  = tid * (int)sizeof(uint2) - kRow;
+            if (STATS)
+                st_nodes += 1u;
+            count_section(1);
+            const int sp_before = sp;
+            test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+                const uint32_t hb = node_at + 16u * (uint32_t)h;
+                nx = ld16s(sc.geom, hb + sx), fx = ld16s(sc.geom, hb + 32u - sx);
+                ny = ld16s(sc.geom, hb + 64u + sy), fy = ld16s(sc.geom, hb + 96u - sy);
+                nz = ld16s(sc.geom, hb + 128u + sz), fz = ld16s(sc.geom, hb + 160u - sz);
+            });
+            if (!DEEP)
+                out = sp >= kLdsEnd;
+            pushed = sp != sp_before;
+        }
+        region_end();
+        const mask_t o = lanes_where(out) & lanes, live = lanes & ~o;
+        overflow |= o;
+        need_cull |= live & ~lanes_where(pushed);
+        settle(sc, st, live);
+    }
+
     // ---- one inner node: fetch 256 B, test 8 children (mapping_cpu.art:350-377); the lanes of m_node
     IG_DEV void node_section(const DevScene& sc, Stack& st)
     {
@@ -624,51 +735,14 @@ struct Traverser {
             const uint32_t near_z = node_at + 128u + sz, far_z = node_at + 160u - sz;
             // both halves' child ids with the first batch of loads: the test for the second half does not cost a round trip of its own
             const int4 c4lo = ld16i(sc.geom, node_at, 12), c4hi = ld16i(sc.geom, node_at, 13);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int4 c4 = h ? c4hi : c4lo;
-                // two halves of four children keep the live register set small; children are packed from slot 0 (the first zero ends the
-                // list, mapping_cpu.art:357)
-                if (h == 1 && c4.x == 0)
-                    break;
-                if (h == 1) {
-                    prof(7);
-                    IG_MARK("node.half1");
-                }
-                // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
-                // between is materialised as a 64-bit pointer per lane)
+            // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
+            // between is materialised as a 64-bit pointer per lane)
+            test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
                 const uint32_t hb = 16u * (uint32_t)h;
-                const float4 nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
-                const float4 ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
-                const float4 nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
-                const float nb[3][4] = { { nx.x, nx.y, nx.z, nx.w }, { ny.x, ny.y, ny.z, ny.w }, { nz.x, nz.y, nz.z, nz.w } };
-                const float fb[3][4] = { { fx.x, fx.y, fx.z, fx.w }, { fy.x, fy.y, fy.z, fy.w }, { fz.x, fz.y, fz.z, fz.w } };
-                const int ch[4] = { c4.x, c4.y, c4.z, c4.w };
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // (v_pk_fma_f32 for two children at once measured no faster: it issues like two fmas, and half of the scalar
-                    // operands end up in register pairs built with v_mov; profiles/r04_experiment_ab.txt)
-                    const float entry = igm_max(igm_max(igm_fma(inv.x, nb[0][i], io.x), igm_fma(inv.y, nb[1][i], io.y)), igm_max(igm_fma(inv.z, nb[2][i], io.z), tmin));
-                    const float exit  = igm_min(igm_min(igm_fma(inv.x, fb[0][i], io.x), igm_fma(inv.y, fb[1][i], io.y)), igm_min(igm_fma(inv.z, fb[2][i], io.z), tmax));
-                    const bool hit    = (ch[i] != 0) & !(exit < entry);
-                    if (hit) {
-                        // push (becomes the top) if nearer than the current top, else push_after
-                        const bool front = ANY_HIT || (igm_float(top.y) > entry);
-                        const int pn     = front ? (int)top.x : ch[i];
-                        const float pt   = front ? igm_float(top.y) : entry;
-                        if (DEEP) {
-                            out |= push_entry(st, pn, pt);
-                        } else {
-                            // (how far the node got, and whether that was too far, is read off the address once after the eight children)
-                            sp += kRow;
-                            if (sp < kLdsEnd)
-                                slot(st, sp) = make_uint2((uint32_t)pn, igm_bits(pt));
-                        }
-                        if (front)
-                            top = make_uint2((uint32_t)ch[i], igm_bits(entry));
-                    }
-                }
-            }
+                nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
+                ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
+                nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
+            });
             if (!DEEP)
                 out = sp >= kLdsEnd; // out of stack: the ray ends here (see push_entry)
             pushed = sp != sp_before;
