@@ -97,7 +97,8 @@ IG_DEV float4 ld16(const void* base, uint32_t off, int row = 0) { return reinter
 IG_DEV int4 ld16i(const void* base, uint32_t off, int row = 0) { return reinterpret_cast<const int4*>(static_cast<const uint8_t*>(base) + off)[row]; }
 
 // 16 bytes at a wave-uniform address through the scalar cache (s_load_dwordx4: the constant address space tells the compiler so): the
-// vector L1 path, which the traversal keeps ~97 % busy (TCP / TD counters, tools/tcp_pmc.sh), does not see the request
+// vector L1 path, which the traversal loads to a third to a half of its 64 B / clk (and keeps pending 97 % of the time; TCP / TD
+// counters, tools/tcp_pmc.sh), does not see the request
 typedef float scalar_f4 __attribute__((ext_vector_type(4)));
 typedef int scalar_i4 __attribute__((ext_vector_type(4)));
 IG_DEV float4 ld16s(const void* base, uint32_t off)
