@@ -629,7 +629,7 @@ struct Traverser {
 
     // (per lane, inside a region) the children of one inner node: slab tests and nearest-first insertion against the cached top
     // (mapping_cpu.art:350-377). rows(h, ...) fetches the near / far plane rows of half h (children 4 h .. 4 h + 3).
-    template <class Rows>
+    template <bool SECTION = true, class Rows>
     IG_DEV void test_children(Stack& st, const int4 c4lo, const int4 c4hi, bool& out, Rows&& rows)
     {
 #pragma unroll
@@ -639,7 +639,7 @@ struct Traverser {
             // list, mapping_cpu.art:357)
             if (h == 1 && c4.x == 0)
                 break;
-            if (h == 1) {
+            if (h == 1 && SECTION) { // (the profile builds' event and the mark of the inner-node section's second half)
                 prof(7);
                 IG_MARK("node.half1");
             }
@@ -693,7 +693,7 @@ struct Traverser {
                 st_nodes += 1u;
             count_section(1);
             const int sp_before = sp;
-            test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+            test_children<false>(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
                 const uint32_t hb = node_at + 16u * (uint32_t)h;
                 nx = ld16s(sc.geom, hb + sx), fx = ld16s(sc.geom, hb + 32u - sx);
                 ny = ld16s(sc.geom, hb + 64u + sy), fy = ld16s(sc.geom, hb + 96u - sy);
