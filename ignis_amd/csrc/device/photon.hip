@@ -24,7 +24,7 @@ void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream
 }
 
 // keys of the stored photons: (cell << 32) | index; a light path that left no photon (light == -1) gets the all-ones key and sorts last
-__global__ void __launch_bounds__(256) k_photon_keys(const igp_photon* photons, uint32_t n, PpmArgs grid, unsigned long long* keys, uint32_t* cell_count, uint32_t* valid)
+__global__ void __launch_bounds__(256) k_photon_keys(const igp_photon* photons, uint32_t n, PpmArgs grid, unsigned long long* keys, uint32_t* cell_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -37,13 +37,13 @@ __global__ void __launch_bounds__(256) k_photon_keys(const igp_photon* photons, 
     const uint32_t cell = (uint32_t)igp_grid_cell(p.pos, grid.bbox_min, grid.bbox_max);
     keys[i]             = ((unsigned long long)cell << 32) | i;
     atomicAdd(&cell_count[cell], 1u);
-    atomicAdd(valid, 1u);
 }
 
-__global__ void __launch_bounds__(256) k_photon_gather(const igp_photon* photons, const unsigned long long* sorted_keys, const uint32_t* valid, igp_photon* sorted)
+// (the light paths without a photon carry the all-ones key and sort behind every stored one: their slots are not gathered)
+__global__ void __launch_bounds__(256) k_photon_gather(const igp_photon* photons, const unsigned long long* sorted_keys, uint32_t n, igp_photon* sorted)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *valid)
+    if (i >= n || sorted_keys[i] == ~0ull)
         return;
     const uint32_t src = (uint32_t)(sorted_keys[i] & 0xFFFFFFFFull);
     const int4* s      = reinterpret_cast<const int4*>(photons) + 2 * (size_t)src;
@@ -66,19 +66,23 @@ hipError_t build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArg
                        uint32_t* cell_offset /* IGP_GRID_CELLS + 1 */, unsigned long long* keys /* 2 n */, uint32_t* valid, void* temp, size_t temp_bytes, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(cell_count, 0, (size_t)(IGP_GRID_CELLS + 1) * sizeof(uint32_t), stream);
-    if (e == hipSuccess)
-        e = hipMemsetAsync(valid, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess)
         return e;
     const unsigned blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(k_photon_keys, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, n, grid, keys, cell_count, valid);
+    hipLaunchKernelGGL(k_photon_keys, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, n, grid, keys, cell_count);
     size_t bytes = temp_bytes;
-    e = hipcub::DeviceRadixSort::SortKeys(temp, bytes, keys, keys + n, (int)n, 0, 64, stream);
+    // (21 bits of cell over 32 bits of index: the all-ones key of an empty slot still sorts behind every photon of the last cell)
+    static_assert(IGP_GRID_CELLS == (1 << 21), "key layout");
+    e = hipcub::DeviceRadixSort::SortKeys(temp, bytes, keys, keys + n, (int)n, 0, 53, stream);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k_photon_gather, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, keys + n, valid, sorted);
+    hipLaunchKernelGGL(k_photon_gather, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, photons, keys + n, n, sorted);
     bytes = temp_bytes;
-    return hipcub::DeviceScan::ExclusiveSum(temp, bytes, cell_count, cell_offset, IGP_GRID_CELLS + 1, stream);
+    e     = hipcub::DeviceScan::ExclusiveSum(temp, bytes, cell_count, cell_offset, IGP_GRID_CELLS + 1, stream);
+    if (e != hipSuccess)
+        return e;
+    // the number of stored photons is the scan's total (no counter of its own: it was one same-address atomic per photon)
+    return hipMemcpyAsync(valid, cell_offset + IGP_GRID_CELLS, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
 }
 
 } // namespace igdev
