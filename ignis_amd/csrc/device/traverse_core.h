@@ -121,6 +121,9 @@ struct Traverser {
     static constexpr int kRow    = BLOCK * (int)sizeof(uint2);  // bytes between two entries of a lane's stack
     // an entry's byte offset is entry * kRow + tid * 8 with tid * 8 < kRow, so `offset < kLdsEnd` says `entry < kLdsStack` for every lane
     static constexpr int kLdsEnd = kLdsStack * kRow;
+    // a node's twelve rows / a packet's twelve rows in one round trip (k_traverse), or the second half after a look at its ids (k_tail, whose
+    // register file is the shading code's: the 24 more live registers are 60 B more scratch there and cost the late passes 5 %)
+    static constexpr bool kOneTrip = BLOCK == kBlockThreads;
 
     // ---- what the lanes wait for (a lane with a ray is in exactly one of the three between two sections; in none: no ray, or done)
     mask_t m_node; // an inner node is on top of the stack
@@ -738,12 +741,28 @@ struct Traverser {
             const int4 c4lo = ld16i(sc.geom, node_at, 12), c4hi = ld16i(sc.geom, node_at, 13);
             // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
             // between is materialised as a 64-bit pointer per lane)
-            test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+            // all twelve rows with the child ids: one round trip per visit. (Nearly every node has more than four children — 2.09 of 2.10 visits
+            // per 64 rays on the headline, 29.8 of 29.9 on the stand-in — so fetching the second half after the look at its ids bought nothing
+            // and cost a second round trip: stand-in +3.8 %, headline +0.5 %, profiles/r04_experiment_ab.txt section 21.)
+            const auto load_half = [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+                // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across a branch in
+                // between is materialised as a 64-bit pointer per lane)
                 const uint32_t hb = 16u * (uint32_t)h;
                 nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
                 ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
                 nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
-            });
+            };
+            if constexpr (kOneTrip) {
+                float4 rw[2][6];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    load_half(h, rw[h][0], rw[h][1], rw[h][2], rw[h][3], rw[h][4], rw[h][5]);
+                test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+                    nx = rw[h][0], fx = rw[h][1], ny = rw[h][2], fy = rw[h][3], nz = rw[h][4], fz = rw[h][5];
+                });
+            } else {
+                test_children(st, c4lo, c4hi, out, load_half);
+            }
             if (!DEEP)
                 out = sp >= kLdsEnd; // out of stack: the ray ends here (see push_entry)
             pushed = sp != sp_before;
@@ -774,10 +793,18 @@ struct Traverser {
                 count_section(2);
                 const uint32_t tri_at = tri_off + (uint32_t)tri_cursor * 208u; // byte offset of the packet inside geom
                 tri_cursor += 1;
-                // two triangles of the packet at a time (a 96-byte half of the re-ordered packet): 24 live registers instead
-                // of 48, and the second half is not even fetched when the packet holds no more than two triangles
+                // two triangles of the packet at a time (a 96-byte half of the re-ordered packet) are tested, the second half only when the
+                // packet holds more than two triangles
                 const int4 pid4  = ld16i(sc.geom, tri_at, 12);
                 const int pid[4] = { pid4.x, pid4.y, pid4.z, pid4.w };
+                // the whole packet with its ids: one round trip (85 % of the packets visited on the headline and 99 % on the stand-in hold more
+                // than two triangles; +0.8 % / +0.9 %, profiles/r04_experiment_ab.txt section 21)
+                float4 call[kOneTrip ? 12 : 1];
+                if constexpr (kOneTrip) {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m)
+                        call[m] = ld16(sc.geom, tri_at, m);
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     // (valid triangles are packed from slot 0: the first -1 ends the packet, mapping_cpu.art:386; the first half comes
@@ -793,7 +820,7 @@ struct Traverser {
                     float4 c[6];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
-                        c[m] = ld16(sc.geom, tri_at, 6 * h + m);
+                        c[m] = kOneTrip ? call[kOneTrip ? 6 * h + m : 0] : ld16(sc.geom, tri_at, 6 * h + m);
                     float q[12][2];
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
