@@ -212,6 +212,7 @@ struct igd_device {
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
     bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
+    int node_repeat = -1; // IGD_NODE_REPEAT: DevScene::node_repeat (-1: by the size of the BVH)
     int tail_split = 6;
     int tail_wide  = 4; // IGD_TAIL_WIDE: TailArgs::wide_lanes
     // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
@@ -772,6 +773,8 @@ void assignScene(igd_device* d, const igd_scene* s)
                         || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS; // the Radiance BSDFs live in that instantiation too
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
+    // (the 8 L2s hold 32 MB together: a BVH beyond that is fetched from the Infinity Cache / HBM on most visits)
+    ds.node_repeat          = d->node_repeat >= 0 ? (uint32_t)d->node_repeat : (blob.size() > ((size_t)64 << 20) ? 3u : 0u);
     ds.scene_radius         = s->scene_radius;
     for (int k = 0; k < 3; ++k) {
         ds.scene_center[k] = s->bbox_min[k] + (s->bbox_max[k] - s->bbox_min[k]) * 0.5f; // bbox_center (core/bbox.art:22)
@@ -1921,6 +1924,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_NODE_REPEAT"))
+            d->node_repeat = std::min(16, std::atoi(e));
         if (const char* e = std::getenv("IGD_SHADE_CLASSES"))
             d->shade_by_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_WIDE"))

@@ -69,6 +69,7 @@ struct DevScene {
     uint2* deep_stack;
     uint32_t deep_stride;
     uint32_t deep_tail_base; // bbox_radius(scene) * 1.01 for the environment light (light/env.art:88)
+    uint32_t node_repeat;    // traverse_core.h step(): extra executions of the inner-node section per pass (0 unless the BVH outgrows the L2s)
 };
 
 // Ray queues in HBM. The reference's streams are one float per column (src/artic/driver/streams.art:
