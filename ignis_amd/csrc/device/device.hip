@@ -32,6 +32,7 @@ int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream, uint32_t classes);
+void launch_bin_sort(const BinSortArgs& args, int num_cus, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
@@ -161,6 +162,11 @@ struct igd_device {
     DevBuf<float> primary[2], secondary;
     DevBuf<uint32_t> deep_rays; // indices of the rays a traversal launch hands to its DEEP launch
     DevBuf<float> list_rays;
+    // the by-class shading kernels' global sort of a round's hits by material (BinSortArgs, kernels.h): the sorted ray indices and the
+    // key column (allocated with the first render that needs them), the sort's state words, the bins' order and classes (per scene)
+    DevBuf<uint32_t> sort_idx, sort_state;
+    DevBuf<uint8_t> sort_keys, sort_tables;
+    size_t sort_capacity = 0;
 
     // Several chunks can be in flight: while side streams finish chunks k - 3 .. k (tail passes, resolve, counter
     // read-back: a latency chain of ~max_depth dependent bounces, little work) the main stream already runs the
@@ -304,6 +310,9 @@ struct igd_device {
             primary[s].release();
         secondary.release();
         deep_rays.release();
+        sort_idx.release();
+        sort_keys.release();
+        sort_capacity = 0;
         for (auto& f : flight) {
             f.accum.release();
             f.accum_mis[0].release();
@@ -323,7 +332,7 @@ struct igd_device {
             return;
         releaseStreams();
         bool capped = false;
-        const size_t bytes_per_ray = (size_t)(2 * kPrimaryCols + kSecondaryCols + 1 + 4 * n_flights) * sizeof(float);
+        const size_t bytes_per_ray = (size_t)(2 * kPrimaryCols + kSecondaryCols + 1 + 4 * n_flights) * sizeof(float) + 5; // (+ sort_idx, sort_keys)
         {
             // (an explicit igd_setup.stream_capacity is an upper bound too: what does not fit is processed in chunks, render())
             size_t free_b = 0, total_b = 0;
@@ -800,9 +809,31 @@ void assignScene(igd_device* d, const igd_scene* s)
         d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT | IG_MAT_EXPR_NUMBERS)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
     d->shade_classes = 1u;
-    for (uint32_t i = 0; i < s->material_count; ++i) {
-        const int t = s->materials[i].bsdf_type;
-        d->shade_classes |= t == IG_BSDF_PRINCIPLED ? 2u : (t == IG_BSDF_PLASTIC || t == IG_BSDF_ROUGH_DIELECTRIC) ? 4u : t == IG_BSDF_BLEND ? 8u : 0u;
+    {
+        // the bins of the by-class kernels' sort (one per material + the misses') in class-major order, models of a class together
+        auto cls = [&](uint32_t bin) {
+            if (bin >= s->material_count)
+                return 0; // misses: the basic class
+            const int t = s->materials[bin].bsdf_type;
+            return t == IG_BSDF_PRINCIPLED ? 1 : (t == IG_BSDF_PLASTIC || t == IG_BSDF_ROUGH_DIELECTRIC) ? 2 : t == IG_BSDF_BLEND ? 3 : 0;
+        };
+        for (uint32_t i = 0; i < s->material_count; ++i)
+            d->shade_classes |= 1u << cls(i);
+        std::vector<uint8_t> tables(2 * kSortBins, 0);
+        if (s->material_count + 1 <= (uint32_t)kSortBins) {
+            std::vector<uint32_t> order(s->material_count + 1);
+            for (uint32_t i = 0; i <= s->material_count; ++i)
+                order[i] = i;
+            auto model = [&](uint32_t bin) { return bin >= s->material_count ? -1 : (int)s->materials[bin].bsdf_type; };
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cls(a) != cls(b) ? cls(a) < cls(b) : model(a) < model(b); });
+            for (uint32_t i = 0; i <= s->material_count; ++i) {
+                tables[i]             = (uint8_t)order[i];
+                tables[kSortBins + i] = (uint8_t)cls(i);
+            }
+        }
+        d->sort_tables.upload(tables.data(), tables.size());
+        d->sort_state.alloc(kSortStateWords);
+        HIP_CHECK(hipMemset(d->sort_state.ptr, 0, kSortStateWords * sizeof(uint32_t)));
     }
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
@@ -1068,6 +1099,18 @@ void render(igd_device* d, const igd_render_settings* rs)
     }
     if (list_mode)
         d->list_rays.upload(rs->rays, (size_t)rs->width * 8);
+    // the by-class shading kernels (shade_kernel.h) and the global sort that feeds them: the path tracer's full variant, when the
+    // bins fit the sort's key byte (launch_shade takes the other instantiations first: light tracer, debug views, expressions)
+    const bool by_class = d->shade_by_class && d->full_bsdfs && d->dscene.material_count + 1 <= (uint32_t)kSortBins && !d->dscene.expr_code
+                          && (d->dscene.tech.type == IG_TECHNIQUE_PATH || d->dscene.tech.type == IG_TECHNIQUE_AO || d->dscene.tech.type == IG_TECHNIQUE_VOLPATH);
+    if (by_class && d->sort_capacity < d->capacity) {
+        finish(d);
+        d->sort_idx.release();
+        d->sort_keys.release();
+        d->sort_idx.alloc(d->capacity);
+        d->sort_keys.alloc(d->capacity);
+        d->sort_capacity = d->capacity;
+    }
 
     // the per-film constants of the camera, evaluated on the host
     float sx, sy;
@@ -1461,8 +1504,25 @@ void render(igd_device* d, const igd_render_settings* rs)
             timed(2, on, [&] {
                 if (ppm)
                     launch_shade_ppm(sa, shade_grid, on);
-                else
-                    launch_shade(sa, shade_grid, d->full_bsdfs, on, d->shade_by_class ? d->shade_classes : 0u);
+                else {
+                    if (by_class) {
+                        // K3: the round's hits sorted by material, so that each class kernel shades its own dense run
+                        BinSortArgs ba{};
+                        ba.hit             = in.hit;
+                        ba.count           = &qs->q[in_slot].primary;
+                        ba.entity_material = d->dscene.entity_material;
+                        ba.material_count  = d->dscene.material_count;
+                        ba.keys            = d->sort_keys.ptr;
+                        ba.sort_idx        = d->sort_idx.ptr;
+                        ba.state           = d->sort_state.ptr;
+                        ba.bin_order       = d->sort_tables.ptr;
+                        ba.bin_class       = d->sort_tables.ptr + kSortBins;
+                        launch_bin_sort(ba, d->num_cus, on);
+                        sa.sort_idx  = d->sort_idx.ptr;
+                        sa.cls_range = d->sort_state.ptr;
+                    }
+                    launch_shade(sa, shade_grid, d->full_bsdfs, on, by_class ? d->shade_classes : 0u);
+                }
                 launch_round_end(qs, in_slot, on);
             });
 

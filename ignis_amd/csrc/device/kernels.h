@@ -224,6 +224,28 @@ struct ShadeArgs {
     float inv_spi;
     LtCameraArgs lt_cam; // IG_TECHNIQUE_LIGHTTRACER
     PpmArgs ppm;         // IG_TECHNIQUE_PPM
+    // the by-class launches (shade_kernel.h): the round's hits sorted by material and this launch's run of them {first, count}
+    const uint32_t* sort_idx;
+    const uint32_t* cls_range;
+};
+
+// Global counting sort of a round's hits by material (K3a-e, gpu_sort_primary, mapping_gpu.art:409-502), keys in class-major order
+// so that each material class of the shading kernels is one run of the sorted index list. `state` (uint32 words):
+//   [0, 256) histogram by bin (bin = material id, material_count = miss)   [256, 512) first slot of a bin   [512, 768) scatter cursors
+//   [768, 776) per class {first, count}
+constexpr int kSortBins       = 256;
+constexpr int kSortStateWords = 3 * kSortBins + 8;
+constexpr int kSortClasses    = 4;
+struct BinSortArgs {
+    const float4* hit;
+    const uint32_t* count;
+    const int32_t* entity_material;
+    uint32_t material_count;
+    uint8_t* keys;           // one per ray
+    uint32_t* sort_idx;      // out: ray indices, sorted
+    uint32_t* state;
+    const uint8_t* bin_order; // [material_count + 1]: the bins in class-major order
+    const uint8_t* bin_class; // [material_count + 1]: class of a bin (0 basic + misses, 1 principled, 2 coated, 3 blend)
 };
 
 struct TailArgs {

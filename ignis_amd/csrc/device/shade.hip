@@ -442,6 +442,101 @@ template __global__ void k_shade<true, false, false, false, 0, kClassPrincipled>
 template __global__ void k_shade<true, false, false, false, 0, kClassCoated>(const ShadeArgs);
 template __global__ void k_shade<true, false, false, false, 0, kClassBlend>(const ShadeArgs);
 
+// ---------------------------------------------------------------- k_bin_*: the round's hits sorted by material
+
+// Pass 1: a ray's bin (its hit's material; material_count for a miss) into the key column, the bins' sizes into the global histogram
+// (an LDS histogram per workgroup, flushed once: 256 global atomics per workgroup).
+__global__ void __launch_bounds__(256) k_bin_count(const BinSortArgs a)
+{
+    __shared__ uint32_t s_hist[kSortBins];
+    const uint32_t tid = threadIdx.x;
+    s_hist[tid]        = 0;
+    __syncthreads();
+    const uint32_t n = *a.count;
+    const uint32_t M = a.material_count;
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+        const int ent      = (int)igm_bits(a.hit[i].x);
+        const uint32_t key = ent < 0 ? M : (uint32_t)a.entity_material[ent];
+        a.keys[i]          = (uint8_t)key;
+        atomicAdd(&s_hist[key], 1u);
+    }
+    __syncthreads();
+    if (s_hist[tid])
+        atomicAdd(&a.state[tid], s_hist[tid]);
+}
+
+// Pass 2, one workgroup: the bins' first slots in class-major order (bin_order) and each class's {first, count}; clears the histogram
+// and the cursors for the next use.
+__global__ void __launch_bounds__(256) k_bin_scan(const BinSortArgs a)
+{
+    __shared__ uint32_t s_cnt[kSortBins], s_first[kSortBins];
+    const uint32_t tid  = threadIdx.x;
+    const uint32_t bins = a.material_count + 1;
+    const uint32_t bin  = tid < bins ? a.bin_order[tid] : 0u;
+    s_cnt[tid]          = tid < bins ? a.state[bin] : 0u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, cls_first[kSortClasses] = {}, cls_count[kSortClasses] = {};
+        int last = -1;
+        for (uint32_t k = 0; k < bins; ++k) {
+            const int c = a.bin_class[a.bin_order[k]];
+            if (c != last)
+                cls_first[c] = run, last = c;
+            cls_count[c] += s_cnt[k];
+            s_first[k] = run;
+            run += s_cnt[k];
+        }
+        for (int c = 0; c < kSortClasses; ++c) {
+            a.state[3 * kSortBins + 2 * c]     = cls_first[c];
+            a.state[3 * kSortBins + 2 * c + 1] = cls_count[c];
+        }
+    }
+    __syncthreads();
+    if (tid < bins)
+        a.state[kSortBins + bin] = s_first[tid];
+    a.state[tid]                 = 0;
+    a.state[2 * kSortBins + tid] = 0;
+}
+
+// Pass 3: windows of kBinWindow rays; a window reserves its share of every bin it has rays for with one atomic per bin and
+// writes the ray indices there (inside a bin, rays of a window stay together: the shading kernel's gathers touch few lines).
+constexpr uint32_t kBinItems  = 8;
+constexpr uint32_t kBinWindow = 256 * kBinItems;
+__global__ void __launch_bounds__(256) k_bin_scatter(const BinSortArgs a)
+{
+    __shared__ uint32_t s_hist[kSortBins], s_base[kSortBins];
+    const uint32_t tid     = threadIdx.x;
+    const uint32_t n       = *a.count;
+    const uint32_t windows = (n + kBinWindow - 1) / kBinWindow;
+    for (uint32_t w = blockIdx.x; w < windows; w += gridDim.x) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        uint32_t key[kBinItems], rank[kBinItems];
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems; ++k) {
+            const uint32_t i = w * kBinWindow + k * 256u + tid;
+            key[k]           = i < n ? a.keys[i] : 0xFFFFFFFFu;
+            rank[k]          = i < n ? atomicAdd(&s_hist[key[k]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (s_hist[tid])
+            s_base[tid] = a.state[kSortBins + tid] + atomicAdd(&a.state[2 * kSortBins + tid], s_hist[tid]);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems; ++k)
+            if (key[k] != 0xFFFFFFFFu)
+                a.sort_idx[s_base[key[k]] + rank[k]] = w * kBinWindow + k * 256u + tid;
+        __syncthreads();
+    }
+}
+
+void launch_bin_sort(const BinSortArgs& args, int num_cus, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)num_cus * 8u), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)num_cus * 8u), dim3(256), 0, stream, args);
+}
+
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream)
 {
     const unsigned blocks = (args.n + 255u) / 256u;
@@ -459,13 +554,20 @@ void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipSt
     else if (args.scene.expr_code) // materials with shading expressions: the instantiation with the interpreter (no tail kernels either)
         hipLaunchKernelGGL((k_shade<true, false, true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else if (full_bsdfs && classes != 0) {
-        hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBasic>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+        // (the caller has run launch_bin_sort on this round's hits: args.sort_idx, args.cls_range = the sort's state words)
+        ShadeArgs ca       = args;
+        const uint32_t* cr = args.cls_range + 3 * kSortBins;
+        ca.cls_range       = cr;
+        hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBasic>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, ca);
+        ca.cls_range = cr + 2;
         if (classes & 2u)
-            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassPrincipled>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassPrincipled>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, ca);
+        ca.cls_range = cr + 4;
         if (classes & 4u)
-            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassCoated>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassCoated>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, ca);
+        ca.cls_range = cr + 6;
         if (classes & 8u)
-            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBlend>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
+            hipLaunchKernelGGL((k_shade<true, false, false, false, 0, kClassBlend>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, ca);
     } else if (full_bsdfs)
         hipLaunchKernelGGL((k_shade<true>), dim3((unsigned)grid_blocks), dim3(kShadeThreads), 0, stream, args);
     else

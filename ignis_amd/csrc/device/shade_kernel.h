@@ -28,9 +28,12 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 constexpr int kBounceBins = 16; // the bounce rays of a window leave grouped by (specular bounce, octant of the direction)
 
 // The full path-tracer variant by material class: one instantiation per group of BSDF models, each
-// launched over the same hits and shading only the rays whose material is of its group (the others are some other launch's). What a
-// kernel's register file has to hold is then the largest model of its group, not of the whole library: the one-for-all instantiation
-// needs 252 VGPRs (168 + 292 B of scratch at three waves per SIMD). Misses go with the basic group. A blend carries every model.
+// launched over its own run of the round's hits, which k_bin_count / k_bin_scan / k_bin_scatter (shade.hip) sort by material globally —
+// class-major, so a class is one contiguous run of the index list — as the reference's gpu_sort_primary does (mapping_gpu.art:409-502).
+// What a kernel's register file has to hold is then the largest model of its group, not of the whole library: the one-for-all
+// instantiation needs 252 VGPRs (168 + 292 B of scratch at three waves per SIMD). Misses go with the basic group. A blend carries
+// every model. (Round 4 launched every class over every hit and let a window-local sort park the other classes' rays: each window
+// re-sorted four times and most of its lanes idled)
 constexpr uint32_t kClassMiss       = 1u << 31;
 constexpr uint32_t kClassBasic      = (1u << IG_BSDF_DIFFUSE) | (1u << IG_BSDF_DIELECTRIC) | (1u << IG_BSDF_CONDUCTOR) | (1u << IG_BSDF_TRANSPARENT) | (1u << IG_BSDF_PHONG) | kClassMiss;
 constexpr uint32_t kClassPrincipled = 1u << IG_BSDF_PRINCIPLED;
@@ -54,12 +57,16 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
     const int lane = tid & 63;
 
     const DevScene& sc = a.scene;
-    const uint32_t n   = *a.in_count;
-    const int M        = (int)sc.material_count;
+    // BY_CLASS: this launch's rays are a run of the round's hits sorted by material (k_bin_*, shade.hip): entries
+    // [cls_range[0], cls_range[0] + cls_range[1]) of sort_idx name them
+    const uint32_t n         = BY_CLASS ? a.cls_range[1] : *a.in_count;
+    const uint32_t cls_first = BY_CLASS ? a.cls_range[0] : 0u;
+    const int M              = (int)sc.material_count;
     // The lean variant has three BSDF models and waits for memory, not for issue slots (a TEA with one round instead of four changes its
     // time by 1 %, profiles/r03_experiment_shade.txt): the sort's two dependent loads and five barriers in front of every window cost it
     // more (4 %) than the divergence they remove. The full variants sort.
-    const bool do_sort = FULL && (M + 2) <= kMaxSortBins;
+    // The by-class variants get their rays sorted already: dense waves of one material, no window sort.
+    const bool do_sort = FULL && !BY_CLASS && (M + 2) <= kMaxSortBins;
 
     const ShadeFrame fr = a.frame;
 
@@ -86,10 +93,6 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             if (i < n) {
                 const int ent = (int)igm_bits(a.in.hit[i].x);
                 key           = ent < 0 ? M : sc.entity_material[ent];
-                if (BY_CLASS) { // a ray of another class goes to the bin behind the last one this launch shades
-                    const uint32_t bit = key == M ? kClassMiss : 1u << (sc.materials[key].bsdf_type & 31);
-                    key                = (TYPES & bit) ? key : M + 1;
-                }
             }
             s_hist[tid] = 0;
             __syncthreads();
@@ -117,16 +120,11 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
             s_perm[start + r]    = (uint16_t)tid;
             __syncthreads();
             j = base + s_perm[tid];
-            if (BY_CLASS && (uint32_t)tid >= s_scan[M]) // (bins 0 .. M hold this launch's rays)
-                j = n;
             __syncthreads();
-        } else if (BY_CLASS) {
-            if (j < n) {
-                const int ent      = (int)igm_bits(a.in.hit[j].x);
-                const uint32_t bit = ent < 0 ? kClassMiss : 1u << (sc.materials[sc.entity_material[ent]].bsdf_type & 31);
-                j                  = (TYPES & bit) ? j : n;
-            }
         }
+        bool valid = j < n;
+        if (BY_CLASS && valid)
+            j = a.sort_idx[cls_first + j];
 
         clk.mark(0); // the sort
         PathVertexOut out;
@@ -134,7 +132,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         int ray_id = 0;
         int in_ent_for_bin = 0;
         int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
-        if (j < n) {
+        if (valid) {
             PathVertexIn in;
             const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], pay = a.in.pay[j], hit = a.in.hit[j];
             const int4 meta = a.in.meta[j];

@@ -390,25 +390,65 @@ def test_deep_bvh_spills_the_stack_to_hbm(tmp_path):
         assert tot["max_stack"] > 24  # otherwise this test does not reach the global part
 
 
-@pytest.mark.parametrize("triangles,instances,width,height,spi,iters", [(60_000, 24, 192, 108, 2, 2), (1_000_000, 96, 192, 108, 2, 2),
-                                                                       (1_000_000, 96, 1920, 1080, 1, 1), (16_000_000, None, 1920, 1080, 1, 1)])
-def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances, width, height, spi, iters):
-    """SURVEY.md 8d configs 3 / 5 (assets absent): the seeded procedural stand-in — >= 1 M unique triangles, 33
-    materials (diffuse / rough conductor / dielectric / checkerboard), 4 area lights, geometry far beyond L2. The last case is the
-    film size bench.py --scene runs it at (1920x1080: 2 M camera paths through 160 MB of BVH), hits, counters and radiance
-    against the oracle like the small ones; the very last one is the HBM-regime workload of tools/run_standin.sh itself
-    (16 M unique triangles, 1.6 GB of BVH: profiles/r03_*_standin.*)."""
-    from ignis_amd import Device
+def _standin(tmp_path, triangles, instances, width, height, materials="divergent"):
     from ignis_amd.tables import LoadedScene
     import subprocess, sys
     tool = os.path.join(os.path.dirname(SCENES), "tools", "make_standin_scene.py")
-    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", str(triangles), "--seed", "7", "--width", str(width), "--height", str(height)]
+    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", str(triangles), "--seed", "7", "--width", str(width), "--height", str(height), "--materials", materials]
                    + (["--instances", str(instances)] if instances else []), check=True, capture_output=True)  # (None: the tool's default, as tools/run_standin.sh)
-    sc = LoadedScene.from_file(str(tmp_path / "standin.json"), width, height)
+    return LoadedScene.from_file(str(tmp_path / "standin.json"), width, height)
+
+
+def _device_with_env(env, **kw):
+    """A device created under the given IGD_* switches (they are read at igd_create)."""
+    from ignis_amd import Device
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return Device(0, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("triangles,instances,width,height,spi,iters,materials",
+                         [(60_000, 24, 192, 108, 2, 2, "lean"), (1_000_000, 96, 1920, 1080, 1, 1, "lean"), (16_000_000, None, 1920, 1080, 1, 1, "lean"),
+                          (60_000, 24, 192, 108, 2, 2, "divergent"), (1_000_000, 96, 192, 108, 2, 2, "divergent"),
+                          (1_000_000, 96, 1920, 1080, 1, 1, "divergent"), (16_000_000, None, 1920, 1080, 1, 1, "divergent")])
+def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances, width, height, spi, iters, materials):
+    """SURVEY.md 8d configs 3 / 5 (assets absent): the seeded procedural stand-in — >= 1 M unique triangles, 4 area lights, geometry
+    far beyond L2, 32 materials: "divergent" = what config 3 is for (principled / rough plastic / rough dielectric / blends / bump-mapped
+    bitmap diffuse / rough conductor / checkerboard / smooth dielectric: every class of the shading kernels and the global sort by material
+    that feeds them), "lean" = the round 2 - 4 mix the lean kernel covers (the HBM-regime traversal workload of tools/run_standin.sh).
+    1920x1080 is the film bench.py runs them at (2 M camera paths: wavefront rounds, then the tail); hits' counters and radiance
+    against the oracle like the small ones; 16 M unique triangles = 1.6 GB of BVH."""
+    from ignis_amd import Device
+    sc = _standin(tmp_path, triangles, instances, width, height, materials)
     dev = Device(0, acquire_stats=True)
     tot = _compare_with_oracle(dev, sc, width, height, spi, seed=7, iters=iters)
     dev.close()
     assert tot["camera_rays"] == width * height * spi * iters
+
+
+@pytest.mark.parametrize("env", [{"IGD_TAIL_THRESHOLD": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_SHADE_CLASSES": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_NODE_REPEAT": "3"},
+                                 {"IGD_NODE_REPEAT": "3"}, {"IGD_TAIL_THRESHOLD": "65536"}],
+                         ids=["rounds-by-class", "rounds-one-kernel", "rounds-node-repeat", "tail-node-repeat", "rounds-then-tail"])
+def test_divergent_standin_through_every_shading_schedule(tmp_path, env):
+    """The divergent stand-in through the switches a production run can take without the suite's default fixtures reaching them:
+    the wavefront rounds with the by-class kernels on the globally sorted hits (the default for such a scene), with the
+    one-for-all kernel (IGD_SHADE_CLASSES=0), with the inner-node section repeated within a pass (IGD_NODE_REPEAT=3, what
+    igd_assign_scene switches on for BVHs beyond 64 MB) in rounds and in the tail, and rounds handing over to the tail mid-way."""
+    sc = _standin(tmp_path, 60_000, 24, 256, 144, "divergent")
+    dev = _device_with_env(env, acquire_stats=True)
+    tot = _compare_with_oracle(dev, sc, 256, 144, 4, seed=3, iters=2)
+    st = dev.stats()
+    dev.close()
+    assert tot["camera_rays"] == 256 * 144 * 4 * 2
+    if env.get("IGD_TAIL_THRESHOLD") == "0":
+        assert st["rounds"] > 0 and st["tail_rays"] == 0
 
 
 def test_config5_film_shape_4096_rows_of_rank0_of_8(tmp_path):
@@ -416,14 +456,9 @@ def test_config5_film_shape_4096_rows_of_rank0_of_8(tmp_path):
     row_stride 8: 512 rows = 2 Mi camera paths, twice the tail threshold, so wavefront rounds and the tail both run), one
     iteration. Owned rows, counters and — rows of other ranks — untouched pixels against the oracle's rendering of the same rows."""
     from ignis_amd import Device
-    from ignis_amd.tables import LoadedScene
-    import subprocess, sys
     import oracle
     w = h = 4096
-    tool = os.path.join(os.path.dirname(SCENES), "tools", "make_standin_scene.py")
-    subprocess.run([sys.executable, tool, str(tmp_path), "--triangles", "1000000", "--instances", "96", "--seed", "7", "--width", str(w), "--height", str(h)],
-                   check=True, capture_output=True)
-    sc = LoadedScene.from_file(str(tmp_path / "standin.json"), w, h)
+    sc = _standin(tmp_path, 1_000_000, 96, w, h, "divergent")
     dev = Device(0, acquire_stats=True)
     fb, st = _render_gpu(dev, sc, 1, w, h, seed=5, row_offset=0, row_stride=8)
     dev.close()

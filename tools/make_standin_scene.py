@@ -2,23 +2,44 @@
 """Seeded procedural stand-in for the reference's Bedroom / Living-room configs (SURVEY.md 8d, configs 3 and 5;
 the assets are not in the reference tree). States what it is: a synthetic scene, NOT those assets.
 
-    python tools/make_standin_scene.py OUT_DIR [--triangles 1000000] [--seed 7] [--instances 96]
+    python tools/make_standin_scene.py OUT_DIR [--triangles 1000000] [--seed 7] [--instances 96] [--materials divergent|lean]
 
-Writes OUT_DIR/standin.json + OUT_DIR/meshes/*.ply (binary little-endian PLY, the loader's own format):
+Writes OUT_DIR/standin.json + OUT_DIR/meshes/*.ply (binary little-endian PLY, the loader's own format)
++ OUT_DIR/textures/*.png:
   * one heightfield terrain (about 60 % of the unique triangles) inside a closed room,
   * 8 unique noise-displaced icosphere "rocks" (the rest), instanced `--instances` times with random
     rotation / scale / translation,
-  * 32 materials cycling {diffuse, rough conductor alpha in U[0.05, 0.5], smooth dielectric, checkerboard diffuse}
-    (the bump-mapped diffuse of SURVEY's recipe needs bitmap textures, which the HIP backend does not lower yet;
-    the checkerboard keeps a textured, uv-dependent material in the mix),
+  * 32 materials. `--materials divergent` (the default, what BASELINE config 3 is for: "divergent BSDF/shading stress")
+    cycles {principled, rough plastic, rough dielectric, blend of two named BSDFs, bump-mapped diffuse with bitmap
+    reflectance + bitmap height map, rough conductor, diffuse (every other one a checkerboard), smooth dielectric}:
+    every material class of the shading kernels (basic / principled / coated / blend) and bitmap lookups take part.
+    `--materials lean` is the round 2 - 4 mix {diffuse, rough conductor, smooth dielectric, checkerboard diffuse}, which
+    the lean shading kernel covers: the HBM-regime traversal workload of tools/run_standin.sh. The geometry (terrain,
+    rocks, instance transforms, instance -> material slot) is the same bytes in both modes,
   * 4 rectangular area lights under the ceiling.
 Everything derives from numpy's PCG64 seeded with --seed, so the same arguments give the same bytes.
 """
 import argparse
 import json
 import os
+import struct
+import zlib
 
 import numpy as np
+
+
+def write_png(path, img):
+    """8-bit PNG (gray for HxW, RGB for HxWx3), filter type 0 rows, one IDAT."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    ctype = 0 if img.ndim == 2 else 2
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, -1)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 def write_ply(path, verts, faces):
@@ -112,6 +133,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=16)
+    ap.add_argument("--materials", choices=("divergent", "lean"), default="divergent")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     os.makedirs(os.path.join(args.out, "meshes"), exist_ok=True)
@@ -133,25 +155,81 @@ def main():
         write_ply(os.path.join(args.out, "meshes", f"rock{r}.ply"), rv, rf)
         shapes.append({"type": "external", "name": f"rock{r}", "filename": f"meshes/rock{r}.ply"})
 
+    # (both modes take the same draws from `rng`, so what follows — the instance transforms and material slots — does not depend on the mode)
+    lean_bsdfs = []
     for m in range(32):
         kind = m % 4
         col = [round(float(x), 4) for x in rng.uniform(0.2, 0.9, 3)]
         if kind == 0:
-            bsdfs.append({"type": "diffuse", "name": f"mat{m}", "reflectance": col})
+            lean_bsdfs.append({"type": "diffuse", "name": f"mat{m}", "reflectance": col})
         elif kind == 1:
-            bsdfs.append({"type": "conductor", "name": f"mat{m}", "roughness": round(float(rng.uniform(0.05, 0.5)), 4),
-                          "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": col})
+            lean_bsdfs.append({"type": "conductor", "name": f"mat{m}", "roughness": round(float(rng.uniform(0.05, 0.5)), 4),
+                               "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14], "specular_reflectance": col})
         elif kind == 2:
-            bsdfs.append({"type": "dielectric", "name": f"mat{m}", "int_ior": round(float(rng.uniform(1.3, 2.0)), 4)})
+            lean_bsdfs.append({"type": "dielectric", "name": f"mat{m}", "int_ior": round(float(rng.uniform(1.3, 2.0)), 4)})
         else:
-            bsdfs.append({"type": "diffuse", "name": f"mat{m}", "reflectance": f"check{m}"})
+            lean_bsdfs.append({"type": "diffuse", "name": f"mat{m}", "reflectance": f"check{m}"})
     textures = [{"type": "checkerboard", "name": f"check{m}", "scale_x": 8, "scale_y": 8,
                  "color0": [0.8, 0.8, 0.8], "color1": [round(float(x), 4) for x in rng.uniform(0.05, 0.4, 3)]}
                 for m in range(3, 32, 4)]
+    if args.materials == "lean":
+        bsdfs += lean_bsdfs
+    else:
+        mr = np.random.default_rng([args.seed, 0x6d617473])  # the materials' own stream
+        os.makedirs(os.path.join(args.out, "textures"), exist_ok=True)
+        for t in range(4):
+            # a colour map and a height map per bitmap material: smooth noise, 256 x 256
+            hm = value_noise(mr, 255, octaves=4 + t % 2)
+            hm = (hm - hm.min()) / max(hm.max() - hm.min(), 1e-9)
+            write_png(os.path.join(args.out, "textures", f"height{t}.png"), np.round(hm * 255))
+            base = mr.uniform(0.25, 0.95, 3)
+            alt = mr.uniform(0.05, 0.6, 3)
+            cm = hm[..., None] * base + (1 - hm[..., None]) * alt
+            write_png(os.path.join(args.out, "textures", f"color{t}.png"), np.round(cm * 255))
+            textures.append({"type": "image", "name": f"height{t}", "filename": f"textures/height{t}.png", "filter_type": "bilinear", "linear": True})
+            textures.append({"type": "image", "name": f"color{t}", "filename": f"textures/color{t}.png", "filter_type": "bilinear"})
+
+        def u(lo, hi):
+            return round(float(mr.uniform(lo, hi)), 4)
+
+        def colour(lo=0.2, hi=0.9):
+            return [round(float(x), 4) for x in mr.uniform(lo, hi, 3)]
+        for m in range(32):
+            kind, rep = m % 8, m // 8
+            name = f"mat{m}"
+            if kind == 0:
+                b = {"type": "principled", "name": name, "base_color": colour(), "metallic": u(0, 1) if rep % 2 else 0.0, "roughness": u(0.05, 0.8),
+                     "specular_tint": u(0, 1), "sheen": u(0, 1) if rep == 1 else 0.0, "sheen_tint": u(0, 1),
+                     "clearcoat": u(0.2, 1) if rep >= 2 else 0.0, "clearcoat_gloss": u(0, 1), "ior": u(1.3, 1.8),
+                     "specular_transmission": u(0.3, 0.9) if rep == 3 else 0.0}
+                bsdfs.append(b)
+            elif kind == 1:
+                bsdfs.append({"type": "roughplastic" if rep % 2 == 0 else "plastic", "name": name, "diffuse_reflectance": colour(), "int_ior": u(1.3, 1.7),
+                              **({"roughness": u(0.03, 0.4)} if rep % 2 == 0 else {})})
+            elif kind == 2:
+                bsdfs.append({"type": "roughdielectric", "name": name, "int_ior": u(1.3, 2.0), "roughness": u(0.02, 0.3)})
+            elif kind == 3:
+                # a blend needs two named inner BSDFs (BlendBSDF.cpp:14-56); neither is a blend or a bump map
+                bsdfs.append({"type": "diffuse", "name": f"{name}-a", "reflectance": colour()})
+                second = ({"type": "conductor", "name": f"{name}-b", "roughness": u(0.05, 0.4), "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]} if rep % 2 == 0 else
+                          {"type": "principled", "name": f"{name}-b", "base_color": colour(), "metallic": u(0.3, 1), "roughness": u(0.1, 0.6)})
+                bsdfs.append(second)
+                bsdfs.append({"type": "blend", "name": name, "first": f"{name}-a", "second": f"{name}-b", "weight": u(0.2, 0.8)})
+            elif kind == 4:
+                bsdfs.append({"type": "diffuse", "name": f"{name}-inner", "reflectance": f"color{rep}"})
+                bsdfs.append({"type": "bumpmap", "name": name, "bsdf": f"{name}-inner", "map": f"height{rep}", "strength": u(0.5, 2.0)})
+            elif kind == 5:
+                bsdfs.append({"type": "conductor", "name": name, "roughness": u(0.05, 0.5), "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14],
+                              "specular_reflectance": colour()})
+            elif kind == 6:
+                bsdfs.append({"type": "diffuse", "name": name, "reflectance": f"check{4 * rep + 3}" if rep % 2 else colour()})
+            else:
+                bsdfs.append({"type": "dielectric", "name": name, "int_ior": u(1.3, 2.0)})
     bsdfs.append({"type": "diffuse", "name": "mat-room", "reflectance": [0.7, 0.7, 0.7]})
     bsdfs.append({"type": "diffuse", "name": "mat-light", "reflectance": [0, 0, 0]})
 
-    entities.append({"name": "terrain", "shape": "terrain", "bsdf": "mat0"})
+    # the terrain takes half of the camera hits: the lean mix keeps it plain diffuse, the divergent one gives it the bump-mapped bitmap material
+    entities.append({"name": "terrain", "shape": "terrain", "bsdf": "mat0" if args.materials == "lean" else "mat4"})
     for i in range(args.instances):
         s = float(rng.uniform(0.25, 0.9))
         R = rot(rng) * s
@@ -190,7 +268,7 @@ def main():
     unique = len(tf) + rock_tris
     inst = len(tf) + (rock_tris // 8) * args.instances
     print(json.dumps({"scene": os.path.join(args.out, "standin.json"), "unique_triangles": int(unique),
-                      "instanced_triangles": int(inst), "entities": len(entities), "materials": len(bsdfs), "seed": args.seed}))
+                      "instanced_triangles": int(inst), "entities": len(entities), "materials": len(bsdfs), "material_mix": args.materials, "seed": args.seed}))
 
 
 if __name__ == "__main__":
