@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
 VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
 SHADER_GHZ = 2.1            # effective shader clock of the traversal launches (GRBM_GUI_ACTIVE / duration; 2.4 GHz is the boost limit)
-PROFILE_TAG = "r04"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+PROFILE_TAG = "r05"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
 
 
 def valu_cycles_per_inst():
@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--collective", choices=("gather", "reduce"), default="gather", help="rows sharding: gather of the owned rows (default) or reduce(SUM) of whole framebuffers")
     ap.add_argument("--as-rank-of", type=int, default=0, help="experiments only: one process renders what rank 0 of N row-sharding ranks would (estimate of per-GPU throughput at N GPUs)")
     ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (BASELINE configs 3 and 4 measured next to the headline)")
     return ap.parse_args()
 
 
@@ -77,6 +78,103 @@ def geometry_bytes(nodes, tris, leaves):
     """SURVEY.md 8(d) geometry term with this backend's layouts: 256 B per Node8 fetched + 52 B per triangle tested (a 208 B
     Tri4 packet holds 4) + 96 B per EntityLeaf1 tested."""
     return 256 * nodes + 52 * tris + 96 * leaves
+
+
+def shade_stream_bytes(n_in, n_bounce, n_shadow):
+    """Bytes of the ray streams one k_shade launch has to move: a hit read (rayA rayB meta pay hit + eta hit_v = 88 B),
+    a continuation ray written (rayA rayB meta pay + eta = 68 B), a shadow ray written (48 B). Accumulator updates and the scene's
+    shading tables come on top and are not priced: a lower bound."""
+    return 88 * n_in + 68 * n_bounce + 48 * n_shadow
+
+
+def shadow_stream_bytes(n_shadow, n_unoccluded):
+    """56 B per shadow ray (the 48 B the any-hit launch reads + its id) and 24 B per unoccluded splat."""
+    return 56 * n_shadow + 24 * n_unoccluded
+
+
+def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_index=0):
+    """One more workload of BASELINE.json's `configs` through the same product path as the headline (igd_render per iteration on one
+    GPU, inputs resident, HIP-event stage timers on the render stream), with the roofline of ITS dominant kernel: the stage with the
+    most GPU time among closest-hit traversal, shading and any-hit traversal, algorithmic stream bytes per launch from a counter
+    replay of the same steps / that stage's average launch time."""
+    from ignis_amd import Device, LoadedScene
+    t_load = time.perf_counter()
+    scene = LoadedScene.from_file(scene_path, W, H)
+    t_load = time.perf_counter() - t_load
+    dev = Device(device_index, acquire_stats=1, stream_capacity=capacity)
+    dev.assign_scene(scene)
+    dev.resize(W, H)
+
+    def run(on, k):
+        for it in range(k):
+            on.render(spi, W, H, iteration=it, seed=SEED)
+    run(dev, warmup)
+    dev.synchronize()
+    dev.clear_framebuffer()
+    dev.reset_stats()
+    t0 = time.perf_counter()
+    run(dev, steps)
+    dev.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = dev.stats()
+    dev.close()
+    cdev = Device(device_index, acquire_stats=2, stream_capacity=capacity)
+    cdev.assign_scene(scene)
+    cdev.resize(W, H)
+    run(cdev, steps)
+    cs = cdev.stats()
+    cdev.close()
+    rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    n_primary = cs["camera_rays"] + cs["bounce_rays"]
+    rounds = max(1, st["traverse_primary_launches"])
+    geom_resident = int(scene.scene.primbvh_size) + int(scene.scene.scene_node_count) * 256 + int(scene.scene.scene_leaf_count) * 96
+    per_launch = {
+        "k_traverse<closest>": (st["ms_traverse_primary"] / rounds,
+                                stream_bytes(n_primary) / rounds + min(geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"]) / rounds, geom_resident)),
+        "k_shade": (st["ms_shade"] / rounds, shade_stream_bytes(n_primary, cs["bounce_rays"], cs["shadow_rays"]) / rounds),
+        "k_traverse<any>": (st["ms_traverse_secondary"] / max(1, st["traverse_secondary_launches"]),
+                            shadow_stream_bytes(cs["shadow_rays"], cs["unoccluded"]) / max(1, st["traverse_secondary_launches"])
+                            + min(geometry_bytes(cs["nodes_secondary"], cs["tris_secondary"], cs["leaves_secondary"]) / max(1, st["traverse_secondary_launches"]), geom_resident)),
+    }
+    kernel = max(per_launch, key=lambda k: per_launch[k][0])
+    ms, alg = per_launch[kernel]
+    achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"name": name,
+            "workload": f"{name}: {W}x{H}, path integrator, spi {spi} x {steps} iterations, seed {SEED}",
+            "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "msamples_per_s": round(st["camera_rays"] / elapsed / 1e6, 3), "timed_seconds": round(elapsed, 3), "scene_load_seconds": round(t_load, 2),
+            "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"]},
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")},
+            "geometry_resident_bytes": geom_resident,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "avg_launch_ms": round(ms, 5), "launches": int(rounds), "algorithmic_bytes_per_launch": int(alg),
+                         "note": "dominant stage of this workload by HIP-event time; stream bytes (+ min(geometry visited, resident) for the traversals) per launch / "
+                                 "average launch time; k_shade = the sort passes + every class kernel of a round"}}
+
+
+def extra_configs(args):
+    """BASELINE.json configs 3 and 4 next to the headline: the seeded 1 M-triangle stand-in with the divergent
+    material mix (the Bedroom asset is absent; tools/make_standin_scene.py, generated here into a temporary directory) and
+    scenes/many_point_lights.json, both 1920x1080."""
+    import subprocess
+    import tempfile
+    out = []
+    steps, warmup = 16, 8
+    cap = int(os.environ.get("BENCH_CAPACITY", 1 << 28))
+    with tempfile.TemporaryDirectory(prefix="standin_") as tmp:
+        t = time.perf_counter()
+        made = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_standin_scene.py"), tmp, "--triangles", "1000000", "--instances", "96", "--seed", "7",
+                               "--materials", "divergent"], capture_output=True, text=True)
+        if made.returncode == 0:
+            c = measure_config("config 3 stand-in (seeded procedural scene, 1 M unique triangles, 32 divergent materials, 4 area lights; NOT the Bedroom asset)",
+                               os.path.join(tmp, "standin.json"), WIDTH, HEIGHT, SPI, steps, warmup, cap)
+            c["generator"] = "tools/make_standin_scene.py --triangles 1000000 --instances 96 --seed 7 --materials divergent"
+            c["generate_seconds"] = round(time.perf_counter() - t - c["scene_load_seconds"] - c["timed_seconds"], 2)
+            out.append(c)
+        else:
+            out.append({"name": "config 3 stand-in", "error": made.stderr[-400:]})
+    out.append(measure_config("config 4 scenes/many_point_lights.json", os.path.join(ROOT, "scenes", "many_point_lights.json"), WIDTH, HEIGHT, SPI, 32, 16, cap))
+    return out
 
 
 def main():
@@ -323,6 +421,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if world == 1 and shards == 1 and not args.no_extra_configs and args.scene == SCENE:
+            out["configs"] = extra_configs(args)
 
     dev.close()  # (idempotent: rank 0 closed it before the counter replay)
     # RCCL writes a version banner to the C stdout buffer of the ranks; every rank pushes its buffer out before rank 0

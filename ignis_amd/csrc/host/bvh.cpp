@@ -249,6 +249,8 @@ struct Reinserter {
         float gain = 0;
     };
 
+    mutable std::vector<std::pair<float, uint32_t>> open; // bestMove's work list (kept across calls: one allocation per pass, not per node)
+
     Move bestMove(uint32_t node) const
     {
         Move best;
@@ -260,7 +262,7 @@ struct Reinserter {
         uint32_t side          = siblingOf(node);
         BBox shrunk            = getBounds(nodes[side]); // box of the ancestor reached so far, without `node`
         uint32_t pivot         = up;
-        std::vector<std::pair<float, uint32_t>> open;
+        open.clear();
         do {
             // positions inside the subtree that hangs beside the path at this height
             open.emplace_back(saved, side);
@@ -339,6 +341,7 @@ struct Reinserter {
         std::vector<float> area(count);
         std::vector<Move> moves;
         std::vector<char> touched(count);
+        const bool debug = std::getenv("IGH_BVH_DEBUG") != nullptr;
         for (int it = 0; it < iterations; ++it) {
             // the `batch` nodes of largest area (never the root)
             for (uint32_t i = 0; i < (uint32_t)count; ++i)
@@ -370,7 +373,7 @@ struct Reinserter {
                 ++applied;
                 promised += m.gain;
             }
-            if (std::getenv("IGH_BVH_DEBUG")) {
+            if (debug) {
                 double inner = 0;
                 for (const Bvh2Node& n : nodes)
                     if (!n.isLeaf())
@@ -395,7 +398,8 @@ float bvh2_sah_cost(const Bvh2& bvh)
 void optimize_bvh2(Bvh2& bvh)
 {
     // defaults of bvh::v2::ReinsertionOptimizer::Config (batch_size_ratio 0.05, max_iter_count 3); IGH_BVH_REINSERT=0 switches the pass off,
-    // IGH_BVH_REINSERT_ITERS / IGH_BVH_REINSERT_RATIO override (experiments, tools/bvh_stats.py)
+    // IGH_BVH_REINSERT_ITERS / IGH_BVH_REINSERT_RATIO override (experiments, tools/bvh_visits.py). Load-time cost: per iteration a
+    // partial sort of the nodes by area and a branch-and-bound search for 5 % of them (16 M triangles: a few seconds on top of the sweep).
     int iterations = 3;
     float ratio    = 0.05f;
     if (const char* e = std::getenv("IGH_BVH_REINSERT"))
@@ -536,8 +540,22 @@ struct CollapsePlan {
     explicit CollapsePlan(const Bvh2& bvh)
         : e(bvh.nodes.size())
     {
-        // children have larger indices than their parent (build_bvh2 appends them): backwards = bottom-up
-        for (size_t n = bvh.nodes.size(); n-- > 0;) {
+        // Bottom-up = a pre-order walk from the root, backwards. (build_bvh2 appends children behind their parent, but the reinsertion
+        // pass re-links nodes — a moved pair can sit below its new parent in the array — so index order is not a topological order.)
+        std::vector<uint32_t> order;
+        order.reserve(bvh.nodes.size());
+        {
+            std::vector<uint32_t> open{ 0u };
+            while (!open.empty()) {
+                const uint32_t n = open.back();
+                open.pop_back();
+                order.push_back(n);
+                if (!bvh.nodes[n].isLeaf())
+                    open.push_back(bvh.nodes[n].first), open.push_back(bvh.nodes[n].first + 1);
+            }
+        }
+        for (size_t at = order.size(); at-- > 0;) {
+            const uint32_t n     = order[at];
             const Bvh2Node& node = bvh.nodes[n];
             Entry& en            = e[n];
             if (node.isLeaf()) {
@@ -605,6 +623,31 @@ void convertNodeOptimal(const Bvh2& original, const CollapsePlan& plan, uint32_t
     const uint32_t first = bvh.nodes[cur_id].first_child_or_primitive;
     for (size_t i = 0; i < children.size(); ++i)
         convertNodeOptimal(original, plan, children[i], bvh, first + (uint32_t)i);
+}
+
+// T(n, 1) by plain recursion over the tree as it is linked (no assumption about the order of the array): what CollapsePlan's table must hold
+void recursiveCollapseCost(const Bvh2& bvh, uint32_t n, float t[N + 1])
+{
+    const Bvh2Node& node = bvh.nodes[n];
+    if (node.isLeaf()) {
+        for (size_t i = 0; i <= N; ++i)
+            t[i] = 0;
+        return;
+    }
+    float l[N + 1], r[N + 1], d[N + 1];
+    recursiveCollapseCost(bvh, node.first, l);
+    recursiveCollapseCost(bvh, node.first + 1, r);
+    for (size_t j = 2; j <= N; ++j) {
+        d[j] = std::numeric_limits<float>::infinity();
+        for (size_t k = 1; k < j; ++k)
+            d[j] = std::min(d[j], l[std::min(k, N - 1)] + r[std::min(j - k, N - 1)]);
+    }
+    const float* b = node.bounds;
+    const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+    t[1] = (dx * dy + dy * dz + dz * dx) + d[N];
+    for (size_t i = 2; i < N; ++i)
+        t[i] = std::min(d[i], t[i - 1]);
+    t[N] = t[N - 1];
 }
 
 bool greedyCollapse()
@@ -824,6 +867,46 @@ void build_scene_bvh8(const std::vector<EntityObject>& objs, std::vector<ig_node
         }
         leaves.back().entity_id |= (int32_t)0x80000000;
     });
+}
+
+// Diagnostics (tests/test_bvh_builder.py through igh_test_collapse_plan): sweep build over the boxes, the reinsertion pass with the given
+// parameters, then out[0] = the collapse plan's cost of the root as a wide node, out[1] = the same by plain recursion, out[2] = inner
+// nodes with a child below them in the array (what the reinsertion pass leaves behind), out[3] = inner nodes whose box does not
+// contain a child's, out[4] = summed area of the wide nodes convertToNArity really emits.
+void collapse_plan_check(const std::vector<BBox>& boxes, float ratio, int iterations, double out[5])
+{
+    std::vector<V3> centers(boxes.size());
+    for (size_t i = 0; i < boxes.size(); ++i)
+        centers[i] = (boxes[i].min + boxes[i].max) * 0.5f;
+    Bvh2 bvh = build_bvh2(boxes, centers, 8, 1);
+    Reinserter(bvh).run(ratio, iterations);
+    for (Bvh2Node& n : bvh.nodes)
+        if (!n.isLeaf() && getBounds(bvh.nodes[n.first]).halfArea() < getBounds(bvh.nodes[n.first + 1]).halfArea())
+            std::swap(bvh.nodes[n.first], bvh.nodes[n.first + 1]);
+    const CollapsePlan plan(bvh);
+    float t[N + 1];
+    recursiveCollapseCost(bvh, 0, t);
+    out[0] = bvh.nodes[0].isLeaf() ? 0.0 : (double)plan.e[0].t[1];
+    out[1] = bvh.nodes[0].isLeaf() ? 0.0 : (double)t[1];
+    out[2] = out[3] = out[4] = 0;
+    for (uint32_t i = 0; i < (uint32_t)bvh.nodes.size(); ++i) {
+        const Bvh2Node& n = bvh.nodes[i];
+        if (n.isLeaf())
+            continue;
+        out[2] += n.first < i ? 1 : 0;
+        const BBox b = getBounds(n);
+        for (uint32_t c = n.first; c < n.first + 2; ++c) {
+            const BBox cb = getBounds(bvh.nodes[c]);
+            const bool inside = b.min.x <= cb.min.x && b.min.y <= cb.min.y && b.min.z <= cb.min.z && b.max.x >= cb.max.x && b.max.y >= cb.max.y && b.max.z >= cb.max.z;
+            out[3] += inside ? 0 : 1;
+        }
+    }
+    const NBvh wide = convertToNArity(bvh);
+    for (const NNode& n : wide.nodes)
+        if (!n.isLeaf()) {
+            const float dx = n.bounds[1] - n.bounds[0], dy = n.bounds[3] - n.bounds[2], dz = n.bounds[5] - n.bounds[4];
+            out[4] += (double)(dx * dy + dy * dz + dz * dx);
+        }
 }
 
 } // namespace igh

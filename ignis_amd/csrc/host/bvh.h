@@ -8,7 +8,8 @@
 // sweep-SAH, min_leaf_size 1, max_leaf_size 8, cost_ratio 1). The library is
 // not available here, so its published algorithms are restated: the top-down
 // sweep-SAH build and the reinsertion optimiser DefaultBuilder runs behind it
-// at its default quality (Meister & Bittner 2018). Tree topology is "parity
+// at its default quality (Meister & Bittner 2018; here the moves of a batch are
+// applied one after the other in gain order with a conflict set, as there). Tree topology is "parity
 // unpinned" all the same (the reference has no test that inspects it, and the
 // dependency is pinned to a moving branch).
 //
@@ -50,6 +51,9 @@ Bvh2 build_bvh2(const std::vector<BBox>& bboxes, const std::vector<V3>& centers,
 void optimize_bvh2(Bvh2& bvh);
 // Sum over the nodes of area x (1 | primitives), relative to the root's area
 float bvh2_sah_cost(const Bvh2& bvh);
+
+// Diagnostics of the collapse plan on a tree the reinsertion pass has re-linked (bvh.cpp; tests/test_bvh_builder.py)
+void collapse_plan_check(const std::vector<BBox>& boxes, float ratio, int iterations, double out[5]);
 
 // Triangle BVH of a mesh in the reference's <8,4> layout.
 void build_tri_bvh8(const TriMesh& mesh, std::vector<ig_node8>& nodes, std::vector<ig_tri4>& tris);

@@ -2964,6 +2964,19 @@ double igh_eval_sky(int32_t channel, double turbidity, double albedo, double ele
     return igh::hosek::radiance(igh::hosek::init(channel, turbidity, albedo, elevation), theta, gamma);
 }
 
+int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinsert_ratio, int32_t reinsert_iterations, double out[5])
+{
+    if (!boxes || !out || count == 0)
+        return -1;
+    std::vector<igh::BBox> bb(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        bb[i].min = igh::V3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]);
+        bb[i].max = igh::V3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]);
+    }
+    igh::collapse_plan_check(bb, reinsert_ratio, reinsert_iterations, out);
+    return 0;
+}
+
 const char* igh_last_error(void) { return g_last_error.c_str(); }
 
 } // extern "C"

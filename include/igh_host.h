@@ -75,6 +75,13 @@ int32_t igh_eval_expression(const char* source, const float* vars, float result[
  * sample implementation the reference ships (tests/golden/hosek_golden.npz). */
 double igh_eval_sky(int32_t channel, double turbidity, double albedo, double elevation, double theta, double gamma);
 
+/* Builder diagnostics (tests/test_bvh_builder.py): the binary sweep tree over `count` boxes (min xyz, max xyz each), the reinsertion
+ * pass (ReinsertionOptimizer of the reference's madmann91/bvh dependency, src/runtime/bvh/TriBVHAdapter.h:216-220) with the given batch
+ * ratio and iteration count, then the BVH8 collapse plan. out[0] the plan's cost of the root, out[1] the same by plain recursion,
+ * out[2] inner nodes with a child below them in the array, out[3] inner nodes whose box does not contain a child's, out[4] summed
+ * area of the wide inner nodes the collapse emits. Returns 0. */
+int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinsert_ratio, int32_t reinsert_iterations, double out[5]);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

@@ -35,7 +35,17 @@ for off in offsets:  # where each shape's {header, Node8[], Tri4[]} starts: the 
     tr = np.frombuffer(blob[off + 16 + nodes * 256:off + 16 + nodes * 256 + packets * 208].tobytes(), np.int32).reshape(packets, 52)
     pid = tr[:, 48:52]
     ids = (pid[pid != -1] & 0x7FFFFFFF)
-    out.append({"nodes": nodes, "children_min": int((child != 0).sum(1).min()), "children_max": int((child != 0).sum(1).max()),
+    # containment: the box slot c of node n holds for an inner child = the union of that child's own slots
+    viol = 0
+    for nidx in range(nodes):
+        for c in range(8):
+            k = int(child[nidx, c])
+            if k > 0:
+                cb = b[k - 1]
+                used = child[k - 1] != 0
+                lo = cb[0::2][:, used].min(1); hi = cb[1::2][:, used].max(1)
+                viol += int((b[nidx, 0::2, c] > lo).any() or (b[nidx, 1::2, c] < hi).any())
+    out.append({"box_violations": viol, "nodes": nodes, "children_min": int((child != 0).sum(1).min()), "children_max": int((child != 0).sum(1).max()),
                 "inner_area": float(area[inner].sum()), "leaves": int((child < 0).sum()), "triangles": int(len(ids)),
                 "unique": int(len(np.unique(ids))), "max_id": int(ids.max())})
 runs, n = [], 0
@@ -65,12 +75,13 @@ def terrain(tmp_path_factory):
 @pytest.mark.parametrize("which", ["diamond", "terrain"])
 def test_tables_are_complete_whatever_the_tuning(which, terrain):
     scene = terrain if which == "terrain" else os.path.join(SCENES, "diamond_scene.json")
-    for env in ({}, {"IGH_COLLAPSE": "greedy"}, {"IGH_BVH_REFERENCE": "1"}, {"IGH_SCENE_MAX_LEAF": "8", "IGH_MIN_LEAF": "2"}):
+    for env in ({}, {"IGH_COLLAPSE": "greedy"}, {"IGH_BVH_REFERENCE": "1"}, {"IGH_SCENE_MAX_LEAF": "8", "IGH_MIN_LEAF": "2"}, {"IGH_BVH_REINSERT_RATIO": "0.5"}):
         st = _stats(scene, **env)
         assert sum(st["runs"]) == st["entities"]
         for sh in st["shapes"]:
             assert 1 <= sh["children_min"] and sh["children_max"] <= 8, env
             assert sh["triangles"] == sh["unique"] == sh["max_id"] + 1, env  # every triangle once
+            assert sh["box_violations"] == 0, env  # a Node8's child box contains the boxes of that child's own children
 
 
 def test_scene_leaves_hold_at_most_two_entities(terrain):
@@ -85,3 +96,29 @@ def test_the_collapse_minimises_the_area_of_the_wide_nodes(terrain):
     na, nb = sum(s["nodes"] for s in best["shapes"]), sum(s["nodes"] for s in greedy["shapes"])
     assert [s["leaves"] for s in best["shapes"]] == [s["leaves"] for s in greedy["shapes"]]  # the binary tree's leaves either way
     assert a <= b * (1 + 1e-5) and na < nb
+
+
+def test_collapse_plan_on_a_tree_the_reinsertion_pass_has_relinked():
+    """ADVICE r04: Reinserter::apply() re-links nodes, so a child can sit below its parent in the array; the collapse plan's bottom-up
+    pass must follow the links, not the indices. 60 k mixed-size boxes at the default ratio / iteration count (and a heavier setting):
+    the plan's cost of the root equals a plain recursive evaluation, and every box still contains its children."""
+    from ignis_amd import tables
+    lib = tables.host_lib()
+    lib.igh_test_collapse_plan.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_float, C.c_int32, C.POINTER(C.c_double)]
+    lib.igh_test_collapse_plan.restype = C.c_int32
+    rng = np.random.default_rng(11)
+    n = 60_000
+    c = rng.uniform(-10, 10, (n, 3))
+    r = rng.lognormal(-2.5, 1.2, (n, 3))  # a few large boxes among many small ones: what makes reinsertion find moves
+    boxes = np.ascontiguousarray(np.concatenate([c - r, c + r], axis=1), dtype=np.float32)
+    relinked = 0
+    for ratio, iters in ((0.05, 3), (0.5, 4)):
+        out = (C.c_double * 5)()
+        assert lib.igh_test_collapse_plan(boxes.ctypes.data_as(C.POINTER(C.c_float)), n, ratio, iters, out) == 0
+        plan, rec, below, broken, emitted = list(out)
+        assert below > 0  # otherwise this test does not reach the case
+        relinked += below
+        assert broken == 0
+        assert plan == rec
+        assert abs(emitted - plan) <= 1e-4 * plan  # what convertToNArity emits is the plan (float sums in another order)
+    assert relinked > 100

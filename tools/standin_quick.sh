@@ -3,10 +3,11 @@
 # usage: tools/standin_quick.sh <tag> <triangles> <steps> "ENV1=a ENV2=b" "ENV1=c" ...      ("-" = no extra environment)
 TAG=$1; TRIS=$2; STEPS=$3; shift; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-DIR=/tmp/standin_$TRIS
+MATS=${STANDIN_MATERIALS:-lean}
+DIR=/tmp/standin_${TRIS}_$MATS
 mkdir -p "$ROOT/gpurun_out/$TAG"
 cd "$ROOT"
-[ -f "$DIR/standin.json" ] || python tools/make_standin_scene.py "$DIR" --triangles "$TRIS" > "$ROOT/gpurun_out/$TAG/standin_make.log" 2>&1
+[ -f "$DIR/standin.json" ] || python tools/make_standin_scene.py "$DIR" --triangles "$TRIS" --materials "$MATS" > "$ROOT/gpurun_out/$TAG/standin_make.log" 2>&1
 for E in "$@"; do
   [ "$E" = "-" ] && E=""
   env $E timeout 900 python bench.py --scene "$DIR/standin.json" --steps "$STEPS" --warmup "$STEPS" --no-cpu-baseline --no-literal-config 2> "$ROOT/gpurun_out/$TAG/standin_quick.err" | tail -1 | python -c "
