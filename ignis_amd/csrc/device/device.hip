@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -28,6 +29,8 @@
 
 namespace igdev {
 void launch_traverse(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20, bool deep_primary = false);
+void launch_traverse_q8(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks = 1 << 20, bool deep_primary = false);
+void launch_tail_q8(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
 int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
@@ -219,6 +222,11 @@ struct igd_device {
     uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
     bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
     int node_repeat = -1; // IGD_NODE_REPEAT: DevScene::node_repeat (-1: by the size of the BVH)
+    // IGD_NODE_FORMAT: -1 auto (the 128-byte quantised node records when the builder left every node on its 8-bit grid — it does from
+    // 64 MB of nodes on — and the scene has no analytic spheres), 0 always Node8, 1 quantised whenever the tables allow it
+    int node_format_mode = -1;
+    uint32_t scene_node8_off = 0; // the scene BVH's Node8 records inside geom (the "scene_bvh" named buffer; the kernels may read the quantised copy)
+    bool q8_nodes        = false; // this scene's kernels are the _q8 instantiations (traverse.hip, tail.hip with -DIG_QNODE=1)
     int tail_split = 6;
     int tail_wide  = 4; // IGD_TAIL_WIDE: TailArgs::wide_lanes
     // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
@@ -419,6 +427,67 @@ namespace {
 
 int guarded(const char* what, const std::function<void()>& fn);
 
+// the traversal kernels of the scene's node format (traverse.hip is compiled once per format)
+void launchTraverse(const igd_device* d, const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks, bool deep_primary)
+{
+    (d->q8_nodes ? launch_traverse_q8 : launch_traverse)(args, any_hit, stats, grid_blocks, deep_work_counter, stream, deep_grid_blocks, deep_primary);
+}
+
+// Node8 records whose builder left them on a per-node 8-bit grid (ig_node8::pad, csrc/host/bvh.cpp quantise_node8) as 128-byte records:
+//   row 0 (origin.xyz, the three biased scale exponents)   rows 1 - 3, one per axis: lo[0..7], hi[0..7], a byte per plane
+//   rows 4 - 5 child ids   rows 6 - 7 unused (a record is one cache line)
+// Lossless or not at all: false as soon as one plane of a used slot is not fmaf(q, 2^e, origin) for a byte q.
+bool packQuantisedNodes(const ig_node8* nodes, size_t count, uint8_t* out)
+{
+    for (size_t n = 0; n < count; ++n) {
+        const ig_node8& nd = nodes[n];
+        const uint32_t hd  = (uint32_t)nd.pad[3];
+        if ((hd & 0xFF000000u) != IG_NODE8_QUANT_MARK)
+            return false;
+        uint32_t rec[32] = {};
+        uint8_t* q       = reinterpret_cast<uint8_t*>(rec + 4);
+        for (int a = 0; a < 3; ++a) {
+            float origin;
+            std::memcpy(&origin, &nd.pad[a], 4);
+            const uint32_t eb = (hd >> (8 * a)) & 0xFFu;
+            if (eb == 0 || eb == 255 || !std::isfinite(origin))
+                return false;
+            const float sc = std::ldexp(1.0f, (int)eb - 127);
+            rec[a]         = (uint32_t)nd.pad[a];
+            for (int i = 0; i < 8; ++i) {
+                if (nd.child[i] == 0)
+                    continue;
+                for (int k = 0; k < 2; ++k) {
+                    const float plane = nd.bounds[2 * a + k][i];
+                    const double qd   = std::nearbyint(((double)plane - (double)origin) / (double)sc);
+                    if (!(qd >= 0 && qd <= 255))
+                        return false;
+                    // (several q can decode to the same float when the grid is finer than the floats around the origin: any of them will do)
+                    bool found = false;
+                    for (int dq = 0; dq <= 2 && !found; ++dq)
+                        for (int sg = -1; sg <= 1 && !found; sg += 2) {
+                            const double c = qd + sg * dq;
+                            if (c < 0 || c > 255)
+                                continue;
+                            const float dec = std::fmaf((float)c, sc, origin);
+                            if (std::memcmp(&dec, &plane, 4) == 0) {
+                                q[16 * a + 8 * k + i] = (uint8_t)c;
+                                found                 = true;
+                            }
+                        }
+                    if (!found)
+                        return false;
+                }
+            }
+        }
+        rec[3] = hd & 0x00FFFFFFu;
+        for (int i = 0; i < 8; ++i)
+            rec[16 + i] = (uint32_t)nd.child[i];
+        std::memcpy(out + n * 128, rec, 128);
+    }
+    return true;
+}
+
 void assignScene(igd_device* d, const igd_scene* s)
 {
     if (s->entity_count > 0 && (!s->entities || !s->shape_data || (s->scene_node_count > 0 && (!s->scene_nodes || !s->scene_leaves || !s->primbvh))
@@ -529,6 +598,45 @@ void assignScene(igd_device* d, const igd_scene* s)
         const uint8_t* pn = reinterpret_cast<const uint8_t*>(s->sphere_nodes);
         blob.insert(blob.end(), pn, pn + (size_t)s->sphere_node_count * sizeof(ig_node8));
     }
+    // The inner nodes once more as 128-byte quantised records, behind everything else, when every Node8 of the scene allows it
+    // (packQuantisedNodes): the traversal kernels of that format (launch_traverse_q8) read nodes there and nowhere else. The Node8
+    // records stay in the blob for the named buffers.
+    std::unordered_map<uint64_t, uint32_t> q8_at; // prim-BVH offset of a shape -> byte offset of its quantised nodes inside geom
+    uint32_t q8_scene_off = 0;
+    bool q8 = d->node_format_mode != 0 && s->sphere_node_count == 0 && s->scene_node_count > 0;
+    if (q8) {
+        std::vector<std::pair<uint64_t, uint32_t>> shapes;
+        size_t total = s->scene_node_count;
+        for (uint32_t i = 0; i < s->scene_leaf_count && q8; ++i) {
+            const ig_entity_leaf1& l = s->scene_leaves[i];
+            const uint64_t off       = (((uint64_t)(uint32_t)l.user[1] << 32) | (uint64_t)(uint32_t)l.user[0]) * 4;
+            if (off + 16 > s->primbvh_size || q8_at.count(off))
+                continue; // (out of range: reported by the loop over the leaves below)
+            uint32_t nc;
+            std::memcpy(&nc, s->primbvh + off, 4);
+            if (off + 16 + (uint64_t)nc * sizeof(ig_node8) > s->primbvh_size)
+                continue;
+            q8_at[off] = 0;
+            shapes.emplace_back(off, nc);
+            total += nc;
+        }
+        std::vector<uint8_t> qn(total * 128);
+        q8 = packQuantisedNodes(s->scene_nodes, s->scene_node_count, qn.data());
+        size_t at = (size_t)s->scene_node_count * 128;
+        const size_t base = blob.size(); // (a multiple of 256)
+        for (size_t k = 0; k < shapes.size() && q8; ++k) {
+            q8 = packQuantisedNodes(reinterpret_cast<const ig_node8*>(s->primbvh + shapes[k].first + 16), shapes[k].second, qn.data() + at);
+            q8_at[shapes[k].first] = (uint32_t)(base + at);
+            at += (size_t)shapes[k].second * 128;
+        }
+        if (q8 && base + qn.size() + 256 < ((size_t)1 << 32)) {
+            q8_scene_off = (uint32_t)base;
+            blob.insert(blob.end(), qn.begin(), qn.end());
+        } else {
+            q8 = false;
+        }
+    }
+    d->q8_nodes = q8;
     if (blob.size() >= ((size_t)1 << 32))
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_assign_scene: BVH blob exceeds 4 GiB (32-bit node offsets)" };
     blob.resize(blob.size() + 256); // tail padding: vector loads never run past the allocation
@@ -576,7 +684,7 @@ void assignScene(igd_device* d, const igd_scene* s)
             r[6]   = make_float4(root.bounds[0][0], root.bounds[2][0], root.bounds[4][0], 0);
             r[7]   = make_float4(root.bounds[1][0], root.bounds[3][0], root.bounds[5][0], 0);
         }
-        r[5] = make_float4(igm_float((uint32_t)(off + 16) | one_leaf), igm_float((uint32_t)tris_at), igm_float((uint32_t)child0), 0);
+        r[5] = make_float4(igm_float((q8 ? q8_at[off] : (uint32_t)(off + 16)) | one_leaf), igm_float((uint32_t)tris_at), igm_float((uint32_t)child0), 0);
     }
     d->geom.upload(blob.data(), blob.size());
     d->dev_leaves.upload(dl.data(), dl.size());
@@ -746,7 +854,8 @@ void assignScene(igd_device* d, const igd_scene* s)
 
     DevScene& ds            = d->dscene;
     ds.geom                 = d->geom.ptr;
-    ds.scene_nodes_off      = scene_nodes_off;
+    ds.scene_nodes_off      = q8 ? q8_scene_off : scene_nodes_off;
+    d->scene_node8_off      = scene_nodes_off;
     ds.scene_node_count     = s->scene_node_count;
     ds.leaves               = d->dev_leaves.ptr;
     ds.leaf_scan            = d->dev_leaf_scan.ptr;
@@ -1229,7 +1338,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 ta.qs           = lq;
                 ta.hit = in.hit, ta.hit_v = in.hit_v;
                 ta.sphere_work_counter = &lq->work_counter[4];
-                launch_traverse(ta, false, counters, d->traverseGrid(), &lq->work_counter[1], st, d->deep_grid, d->deep_primary);
+                launchTraverse(d, ta, false, counters, d->traverseGrid(), &lq->work_counter[1], st, d->deep_grid, d->deep_primary);
                 ShadeArgs sa{};
                 sa.scene     = d->dscene;
                 sa.in        = in;
@@ -1311,7 +1420,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.qs           = iq;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.sphere_work_counter = &iq->work_counter[4];
-            launch_traverse(ta, false, false, d->traverseGrid(), &iq->work_counter[1], st, d->deep_grid, d->deep_primary);
+            launchTraverse(d, ta, false, false, d->traverseGrid(), &iq->work_counter[1], st, d->deep_grid, d->deep_primary);
             InfoArgs ia{};
             ia.scene   = d->dscene;
             ia.in      = in;
@@ -1471,7 +1580,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.sphere_work_counter = &qs->work_counter[4];
-            timed(1, on, [&] { launch_traverse(ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid, d->deep_primary); });
+            timed(1, on, [&] { launchTraverse(d, ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid, d->deep_primary); });
 
             ShadeArgs sa{};
             sa.scene     = d->dscene;
@@ -1544,7 +1653,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.inv_spi = inv;
             tb.atomic_splat = light_tracer ? 1 : 0;
             timed(3, on, [&] {
-                launch_traverse(tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid, d->deep_primary);
+                launchTraverse(d, tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid, d->deep_primary);
                 launch_secondary_end(qs, in_slot ^ 1, mirror, on);
             });
             d->stats.rounds++;
@@ -1638,7 +1747,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     static const bool tail_debug = std::getenv("IGD_TAIL_DEBUG") != nullptr;
                     if (tail_debug)
                         std::fprintf(stderr, "[tail] pass %d: share %.6f live %llu grid %d of %d\n", j, d->tail_share[j], (unsigned long long)live, pass_grid, tail_grid);
-                    launch_tail(p, counters, d->full_bsdfs, pass_grid, side);
+                    (d->q8_nodes ? launch_tail_q8 : launch_tail)(p, counters, d->full_bsdfs, pass_grid, side);
                 }
             });
 
@@ -1736,7 +1845,7 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     for (int r = 0; r < repeat; ++r) {
         HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, sizeof(qs->work_counter) + sizeof(qs->deep_count), st));
         HIP_CHECK(hipEventRecord(d->event(0), st));
-        launch_traverse(ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st, d->deep_grid, d->deep_primary);
+        launchTraverse(d, ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st, d->deep_grid, d->deep_primary);
         HIP_CHECK(hipEventRecord(d->event(1), st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms = 0;
@@ -1874,7 +1983,7 @@ NamedBuffer namedBuffer(igd_device* d, const char* name)
         return NamedBuffer{ d->geom_ref.ptr, d->geom_ref.ptr ? (uint64_t)d->primbvh_bytes : 0 };
     }
     if (n == "scene_bvh_nodes")
-        return NamedBuffer{ d->geom.ptr ? d->geom.ptr + d->dscene.scene_nodes_off : nullptr, (uint64_t)d->dscene.scene_node_count * sizeof(ig_node8) };
+        return NamedBuffer{ d->geom.ptr ? d->geom.ptr + d->scene_node8_off : nullptr, (uint64_t)d->dscene.scene_node_count * sizeof(ig_node8) };
     if (n == "scene_bvh_leaves")
         return of(d->leaves);
     if (n == "materials")
@@ -1984,6 +2093,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->tail_waves_per_cu = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("IGD_TAIL_SPLIT"))
             d->tail_split = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_NODE_FORMAT")) // "full": always Node8 records; anything else: auto
+            d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
         if (const char* e = std::getenv("IGD_SHADE_CLASSES"))
@@ -2336,6 +2447,8 @@ int32_t igd_synchronize(igd_device* dev)
         finish(dev);
     });
 }
+
+int32_t igd_node_bytes(const igd_device* dev) { return dev && dev->has_scene ? (dev->q8_nodes ? 128 : 256) : 0; }
 
 const char* igd_last_error(void) { return g_error.c_str(); }
 

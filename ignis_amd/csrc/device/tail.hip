@@ -13,11 +13,19 @@
 // passes: a pass follows each path for at most `max_bounces` bounces and appends the survivors, compacted,
 // to the input of the next pass, so that the long paths (geometric length distribution) end up in a few
 // full waves instead of pinning every wave of the grid behind its longest lane.
+// Compiled twice, like traverse.hip: as is (launch_tail) and with -DIG_QNODE=1 for scenes whose inner nodes are the quantised
+// records (launch_tail_q8; no wide single-ray traversal there, wide_core.h reads Node8 rows).
 #include "shade_core.h"
 #include "traverse_core.h"
 #include "wide_core.h"
 
+#ifndef IG_QNODE
+#define IG_QNODE 0
+#endif
+
 namespace igdev {
+
+constexpr bool kQNode = IG_QNODE != 0;
 
 // One wave per workgroup: a straggling path then pins 12 KiB of LDS and one wave slot, not a 256-lane
 // workgroup's 48 KiB, which matters because the tail overlaps the next chunk's traversal launches.
@@ -29,7 +37,7 @@ namespace igdev {
 #endif
 constexpr int kTailBlock = IG_TAIL_BLOCK;
 
-template <bool STATS, bool FULL>
+template <bool STATS, bool FULL, bool QNODE = false>
 __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs a)
 {
     __shared__ StackOf<kTailBlock> s_stack;
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         TAIL_MARK(0); // refill
         const mask_t have_m = lanes_where(have);
         {
-            if (lanes_in(have_m) <= (int)a.wide_lanes) {
+            if (!QNODE && lanes_in(have_m) <= (int)a.wide_lanes) {
                 // a handful of paths: their rays one after the other, each traversed by the whole wave
                 mask_t todo = have_m;
                 while (todo) {
@@ -159,7 +167,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 }
                 TAIL_MARK(1);
             } else {
-                Traverser<false, STATS, kTailBlock, true> tr;
+                Traverser<false, STATS, kTailBlock, true, false, QNODE> tr;
                 tr.init_counters();
                 tr.attach_deep(deep_col, sc.deep_stride);
                 tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
@@ -222,7 +230,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         const mask_t shadow_m = lanes_where(shadow);
         if (shadow_m) {
             const uint32_t sflags = sc.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW;
-            Traverser<true, STATS, kTailBlock, true> ts;
+            Traverser<true, STATS, kTailBlock, true, false, QNODE> ts;
             ts.init_counters();
             ts.attach_deep(deep_col, sc.deep_stride);
             ts.begin(shadow_m, sc, s_stack, tid, out.s_org, out.s_dir, kRayOffset, out.s_tmax, sflags);
@@ -345,24 +353,27 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
     }
 }
 
-template __global__ void k_tail<false, false>(const TailArgs);
-template __global__ void k_tail<true, false>(const TailArgs);
-template __global__ void k_tail<false, true>(const TailArgs);
-template __global__ void k_tail<true, true>(const TailArgs);
+template __global__ void k_tail<false, false, kQNode>(const TailArgs);
+template __global__ void k_tail<true, false, kQNode>(const TailArgs);
+template __global__ void k_tail<false, true, kQNode>(const TailArgs);
+template __global__ void k_tail<true, true, kQNode>(const TailArgs);
 
+#if IG_QNODE
+#define launch_tail launch_tail_q8
+#endif
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream)
 {
     const dim3 grid((unsigned)((grid_blocks + kTailBlock / 64 - 1) / (kTailBlock / 64))), block(kTailBlock); // grid_blocks counts waves
     if (full_bsdfs) {
         if (stats)
-            hipLaunchKernelGGL((k_tail<true, true>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_tail<true, true, kQNode>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_tail<false, true>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_tail<false, true, kQNode>), grid, block, 0, stream, args);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_tail<true, false>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_tail<true, false, kQNode>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_tail<false, false>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_tail<false, false, kQNode>), grid, block, 0, stream, args);
     }
 }
 

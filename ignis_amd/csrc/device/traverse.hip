@@ -5,9 +5,17 @@
 // one ray per lane (traverse_core.h); each wave reserves batches of ray indices from a
 // device-resident counter (one atomic per 256 rays) and re-fills idle lanes from its batch
 // (__ballot + lane rank) instead of one thread per ray and one launch per 1 M-ray batch.
+// Compiled twice: as is (Node8 records, launch_traverse) and with -DIG_QNODE=1 (the 128-byte quantised node records of
+// DevScene::node_format, launch_traverse_q8); device.hip picks by the scene.
 #include "traverse_core.h"
 
+#ifndef IG_QNODE
+#define IG_QNODE 0
+#endif
+
 namespace igdev {
+
+constexpr bool kQNode = IG_QNODE != 0;
 
 #ifndef IG_REFILL_IDLE
 #define IG_REFILL_IDLE 24
@@ -19,7 +27,7 @@ constexpr int kRefillIdleClosest = IG_REFILL_IDLE;     // refill when at least t
 constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit launches (shorter rays)
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
-template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false>
+template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false, bool QNODE = false>
 __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
@@ -37,7 +45,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
     uint32_t last_base         = 0; // where the previous reservation of this wave started
 
-    Traverser<ANY_HIT, STATS, kBlockThreads, DEEP, SPHERES> tr;
+    Traverser<ANY_HIT, STATS, kBlockThreads, DEEP, SPHERES, QNODE> tr;
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
     tr.clk_start();
@@ -222,7 +230,9 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     }
 }
 
+#if !IG_QNODE
 int traverse_workgroups_per_cu() { return kTraverseOcc; }
+#endif
 
 template <bool DEEP, bool SPHERES = false>
 static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)
@@ -230,14 +240,14 @@ static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int g
     const dim3 grid((unsigned)grid_blocks), block(kBlockThreads);
     if (any_hit) {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<true, true, DEEP, SPHERES>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, true, DEEP, SPHERES, kQNode>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<true, false, DEEP, SPHERES>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<true, false, DEEP, SPHERES, kQNode>), grid, block, 0, stream, args);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_traverse<false, true, DEEP, SPHERES>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, true, DEEP, SPHERES, kQNode>), grid, block, 0, stream, args);
         else
-            hipLaunchKernelGGL((k_traverse<false, false, DEEP, SPHERES>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((k_traverse<false, false, DEEP, SPHERES, kQNode>), grid, block, 0, stream, args);
     }
 }
 
@@ -246,6 +256,9 @@ static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int g
 // `deep_primary`: the scene's rays are known to outgrow the LDS stack (device.hip watches the overflow counts): ONE launch of the
 // DEEP instantiation over the whole stream, whose lanes spill into their HBM columns as they go, instead of finishing most rays,
 // listing the rest and re-traversing those from the root.
+#if IG_QNODE
+#define launch_traverse launch_traverse_q8
+#endif
 void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks, bool deep_primary)
 {
     TraverseArgs args = args_in;

@@ -115,8 +115,13 @@ IG_DEV int4 ld16si(const void* base, uint32_t off)
 #define IG_ROOT_SCALAR 1 // the visit of the scene root inside begin(), from scalar loads, when the new rays agree on their direction's octant
 #endif
 
-template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false, bool SPHERES = false>
+// QNODE: the inner nodes are the 128-byte quantised records igd_assign_scene packs when every Node8 of the scene is losslessly
+// representable that way (kernels.h, DevScene::node_format): one cache line and six 16-byte requests per visit instead of two lines and
+// fourteen. The planes are decoded to the very floats the Node8 holds (fma(q, 2^e, origin): the host's builder wrote those), then tested
+// as usual: hits and counters stay those of the reference order on the same tables.
+template <bool ANY_HIT, bool STATS, int BLOCK = kBlockThreads, bool DEEP = false, bool SPHERES = false, bool QNODE = false>
 struct Traverser {
+    static constexpr uint32_t kNodeBytes = QNODE ? 128u : 256u;
     using Stack = StackOf<BLOCK>;
     static constexpr int kRow    = BLOCK * (int)sizeof(uint2);  // bytes between two entries of a lane's stack
     // an entry's byte offset is entry * kRow + tid * 8 with tid * 8 < kRow, so `offset < kLdsEnd` says `entry < kLdsStack` for every lane
@@ -314,7 +319,7 @@ struct Traverser {
         const mask_t start = (SPHERES ? sc.sphere_node_count : sc.scene_node_count) != 0 ? (lanes_where(tmin_ <= tmax_) & lanes) : 0ull;
         m_tri &= ~lanes;
         m_leaf &= ~lanes;
-        if (IG_ROOT_SCALAR && !SPHERES) {
+        if (IG_ROOT_SCALAR && !SPHERES && !QNODE) {
             const mask_t nx = lanes_where(inv.x < 0) & start, ny = lanes_where(inv.y < 0) & start, nz = lanes_where(inv.z < 0) & start;
             // (one visit per octant among the new rays, for up to two or for any number of octants, loses: 9 030 / 8 180 against 9 370 Mrays/s —
             // the arithmetic of a visit is paid per execution, profiles/r04_experiment_ab.txt section 19)
@@ -721,47 +726,71 @@ struct Traverser {
         IG_MARK("node.half0");
         bool pushed = false, out = false;
         if (in(here)) {
-            const uint32_t node_at = nodes_off + (top.x - 1u) * 256u; // byte offset of the Node8 inside geom
+            const uint32_t node_at = nodes_off + (top.x - 1u) * kNodeBytes; // byte offset of the node inside geom
             pop_top(st);
             if (STATS)
                 st_nodes += 1u;
             count_section(1);
             const int sp_before = sp;
-            // The slab test of the reference takes min / max of the two plane distances per axis
-            // (intersection.art:38-58); which plane is the near one is decided by the sign of inv_dir alone
-            // (fma is monotonic and lo <= hi), so the near / far rows are picked by address instead and six
-            // of the eighteen min / max per child disappear. Results are bit-identical for real children
-            // (empty slots are masked by child == 0).
-            // (rows of a Node8, 16 bytes each: x lo [0, 1], x hi [2, 3], y lo [4, 5], y hi [6, 7], z lo [8, 9], z hi [10, 11], child ids [12, 13])
-            const uint32_t sx = inv.x < 0 ? 32u : 0u, sy = inv.y < 0 ? 32u : 0u, sz = inv.z < 0 ? 32u : 0u;
-            const uint32_t near_x = node_at + sx, far_x = node_at + 32u - sx;
-            const uint32_t near_y = node_at + 64u + sy, far_y = node_at + 96u - sy;
-            const uint32_t near_z = node_at + 128u + sz, far_z = node_at + 160u - sz;
-            // both halves' child ids with the first batch of loads: the test for the second half does not cost a round trip of its own
-            const int4 c4lo = ld16i(sc.geom, node_at, 12), c4hi = ld16i(sc.geom, node_at, 13);
-            // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
-            // between is materialised as a 64-bit pointer per lane)
-            // all twelve rows with the child ids: one round trip per visit. (Nearly every node has more than four children — 2.09 of 2.10 visits
-            // per 64 rays on the headline, 29.8 of 29.9 on the stand-in — so fetching the second half after the look at its ids bought nothing
-            // and cost a second round trip: stand-in +3.8 %, headline +0.5 %, profiles/r04_experiment_ab.txt section 21.)
-            const auto load_half = [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
-                // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across a branch in
-                // between is materialised as a 64-bit pointer per lane)
-                const uint32_t hb = 16u * (uint32_t)h;
-                nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
-                ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
-                nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
-            };
-            if constexpr (kOneTrip) {
-                float4 rw[2][6];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    load_half(h, rw[h][0], rw[h][1], rw[h][2], rw[h][3], rw[h][4], rw[h][5]);
+            if constexpr (QNODE) {
+                // rows of a quantised node: 0 (origin.xyz, the three scale exponents), 1 - 3 x / y / z: (lo[0..3], lo[4..7], hi[0..3], hi[4..7])
+                // one byte per plane, 4 - 5 child ids; plane = fma(q, 2^e, origin), bit for bit the float of the Node8 it was packed from
+                const float4 hd = ld16(sc.geom, node_at, 0);
+                const int4 qx = ld16i(sc.geom, node_at, 1), qy = ld16i(sc.geom, node_at, 2), qz = ld16i(sc.geom, node_at, 3);
+                const int4 c4lo = ld16i(sc.geom, node_at, 4), c4hi = ld16i(sc.geom, node_at, 5);
+                const uint32_t ex = igm_bits(hd.w);
+                const float sx = igm_float((ex & 0xFFu) << 23), sy = igm_float(((ex >> 8) & 0xFFu) << 23), sz = igm_float(((ex >> 16) & 0xFFu) << 23);
+                const bool ox = inv.x < 0, oy = inv.y < 0, oz = inv.z < 0;
                 test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
-                    nx = rw[h][0], fx = rw[h][1], ny = rw[h][2], fy = rw[h][3], nz = rw[h][4], fz = rw[h][5];
+                    const auto dec = [](uint32_t w, float s, float o) {
+                        // (byte k of w as a float: v_cvt_f32_ubyte<k>)
+                        return make_float4(igm_fma((float)(w & 0xFFu), s, o), igm_fma((float)((w >> 8) & 0xFFu), s, o),
+                                           igm_fma((float)((w >> 16) & 0xFFu), s, o), igm_fma((float)(w >> 24), s, o));
+                    };
+                    const uint32_t lx = (uint32_t)(h ? qx.y : qx.x), hx = (uint32_t)(h ? qx.w : qx.z);
+                    const uint32_t ly = (uint32_t)(h ? qy.y : qy.x), hy = (uint32_t)(h ? qy.w : qy.z);
+                    const uint32_t lz = (uint32_t)(h ? qz.y : qz.x), hz = (uint32_t)(h ? qz.w : qz.z);
+                    nx = dec(ox ? hx : lx, sx, hd.x), fx = dec(ox ? lx : hx, sx, hd.x);
+                    ny = dec(oy ? hy : ly, sy, hd.y), fy = dec(oy ? ly : hy, sy, hd.y);
+                    nz = dec(oz ? hz : lz, sz, hd.z), fz = dec(oz ? lz : hz, sz, hd.z);
                 });
             } else {
-                test_children(st, c4lo, c4hi, out, load_half);
+                // The slab test of the reference takes min / max of the two plane distances per axis
+                // (intersection.art:38-58); which plane is the near one is decided by the sign of inv_dir alone
+                // (fma is monotonic and lo <= hi), so the near / far rows are picked by address instead and six
+                // of the eighteen min / max per child disappear. Results are bit-identical for real children
+                // (empty slots are masked by child == 0).
+                // (rows of a Node8, 16 bytes each: x lo [0, 1], x hi [2, 3], y lo [4, 5], y hi [6, 7], z lo [8, 9], z hi [10, 11], child ids [12, 13])
+                const uint32_t sx = inv.x < 0 ? 32u : 0u, sy = inv.y < 0 ? 32u : 0u, sz = inv.z < 0 ? 32u : 0u;
+                const uint32_t near_x = node_at + sx, far_x = node_at + 32u - sx;
+                const uint32_t near_y = node_at + 64u + sy, far_y = node_at + 96u - sy;
+                const uint32_t near_z = node_at + 128u + sz, far_z = node_at + 160u - sz;
+                // both halves' child ids with the first batch of loads: the test for the second half does not cost a round trip of its own
+                const int4 c4lo = ld16i(sc.geom, node_at, 12), c4hi = ld16i(sc.geom, node_at, 13);
+                // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across the branch in
+                // between is materialised as a 64-bit pointer per lane)
+                // all twelve rows with the child ids: one round trip per visit. (Nearly every node has more than four children — 2.09 of 2.10 visits
+                // per 64 rays on the headline, 29.8 of 29.9 on the stand-in — so fetching the second half after the look at its ids bought nothing
+                // and cost a second round trip: stand-in +3.8 %, headline +0.5 %, profiles/r04_experiment_ab.txt section 21.)
+                const auto load_half = [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+                    // (the second half's rows by 32-bit offsets of their own: an address shared with the first half's loads across a branch in
+                    // between is materialised as a 64-bit pointer per lane)
+                    const uint32_t hb = 16u * (uint32_t)h;
+                    nx = ld16(sc.geom, near_x + hb), fx = ld16(sc.geom, far_x + hb);
+                    ny = ld16(sc.geom, near_y + hb), fy = ld16(sc.geom, far_y + hb);
+                    nz = ld16(sc.geom, near_z + hb), fz = ld16(sc.geom, far_z + hb);
+                };
+                if constexpr (kOneTrip) {
+                    float4 rw[2][6];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        load_half(h, rw[h][0], rw[h][1], rw[h][2], rw[h][3], rw[h][4], rw[h][5]);
+                    test_children(st, c4lo, c4hi, out, [&](int h, float4& nx, float4& fx, float4& ny, float4& fy, float4& nz, float4& fz) {
+                        nx = rw[h][0], fx = rw[h][1], ny = rw[h][2], fy = rw[h][3], nz = rw[h][4], fz = rw[h][5];
+                    });
+                } else {
+                    test_children(st, c4lo, c4hi, out, load_half);
+                }
             }
             if (!DEEP)
                 out = sp >= kLdsEnd; // out of stack: the ray ends here (see push_entry)

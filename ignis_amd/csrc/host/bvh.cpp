@@ -869,6 +869,60 @@ void build_scene_bvh8(const std::vector<EntityObject>& objs, std::vector<ig_node
     });
 }
 
+// Child boxes on a per-node 8-bit grid (Ylitie, Karras, Laine 2017, section 3.2: origin = the node's lower corner, one power-of-two
+// scale per axis, lower planes rounded down and upper planes up), written back as the floats they decode to: plane =
+// fmaf(q, 2^e, origin). The tables stay ordinary Node8 records — any traversal (the oracle's included) reads slightly larger child
+// boxes — and the HIP device can hold such a node in 128 bytes without loss (igd_assign_scene, DevScene::node_format). The grid is
+// left in the record's padding words: pad[0..2] = origin, pad[3] = the three biased exponents | IG_NODE8_QUANT_MARK.
+void quantise_node8(ig_node8* nodes, size_t count)
+{
+    for (size_t n = 0; n < count; ++n) {
+        ig_node8& nd = nodes[n];
+        uint32_t exps = 0;
+        for (int a = 0; a < 3; ++a) {
+            float origin = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
+            for (int i = 0; i < 8; ++i)
+                if (nd.child[i] != 0)
+                    origin = std::min(origin, nd.bounds[2 * a][i]), top = std::max(top, nd.bounds[2 * a + 1][i]);
+            if (!(origin <= top)) // (no children: never written by the builder)
+                origin = top = 0;
+            const double extent = (double)top - (double)origin;
+            int e               = extent > 0 ? (int)std::ceil(std::log2(extent / 255.0)) : -126;
+            e                   = std::max(-126, std::min(127, e));
+            uint8_t qlo[8], qhi[8];
+            for (;; ++e) {
+                const float s = std::ldexp(1.0f, e);
+                bool fits     = true;
+                for (int i = 0; i < 8 && fits; ++i) {
+                    qlo[i] = qhi[i] = 0;
+                    if (nd.child[i] == 0)
+                        continue;
+                    const float lo = nd.bounds[2 * a][i], hi = nd.bounds[2 * a + 1][i];
+                    double ql = std::floor(((double)lo - (double)origin) / (double)s), qh = std::ceil(((double)hi - (double)origin) / (double)s);
+                    ql = std::min(255.0, std::max(0.0, ql)), qh = std::max(0.0, qh);
+                    while (ql > 0 && std::fmaf((float)ql, s, origin) > lo)
+                        ql -= 1;
+                    while (qh <= 255 && std::fmaf((float)qh, s, origin) < hi)
+                        qh += 1;
+                    fits   = qh <= 255;
+                    qlo[i] = (uint8_t)ql, qhi[i] = (uint8_t)std::min(255.0, qh);
+                }
+                if (fits || e >= 127)
+                    break;
+            }
+            const float s = std::ldexp(1.0f, e);
+            for (int i = 0; i < 8; ++i)
+                if (nd.child[i] != 0) {
+                    nd.bounds[2 * a][i]     = std::fmaf((float)qlo[i], s, origin);
+                    nd.bounds[2 * a + 1][i] = std::fmaf((float)qhi[i], s, origin);
+                }
+            std::memcpy(&nd.pad[a], &origin, 4);
+            exps |= (uint32_t)(e + 127) << (8 * a);
+        }
+        nd.pad[3] = (int32_t)(exps | IG_NODE8_QUANT_MARK);
+    }
+}
+
 // Diagnostics (tests/test_bvh_builder.py through igh_test_collapse_plan): sweep build over the boxes, the reinsertion pass with the given
 // parameters, then out[0] = the collapse plan's cost of the root as a wide node, out[1] = the same by plain recursion, out[2] = inner
 // nodes with a child below them in the array (what the reinsertion pass leaves behind), out[3] = inner nodes whose box does not

@@ -52,6 +52,9 @@ void optimize_bvh2(Bvh2& bvh);
 // Sum over the nodes of area x (1 | primitives), relative to the root's area
 float bvh2_sah_cost(const Bvh2& bvh);
 
+// Snaps every child box of the nodes outward to the node's own 8-bit grid, in place (bvh.cpp).
+void quantise_node8(ig_node8* nodes, size_t count);
+
 // Diagnostics of the collapse plan on a tree the reinsertion pass has re-linked (bvh.cpp; tests/test_bvh_builder.py)
 void collapse_plan_check(const std::vector<BBox>& boxes, float ratio, int iterations, double out[5]);
 

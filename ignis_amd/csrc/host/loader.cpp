@@ -452,6 +452,7 @@ struct Scene {
     std::vector<ig_lookup_entry> shape_lookups;
     std::vector<uint8_t> shape_data;
     std::vector<uint8_t> primbvh;
+    std::vector<std::pair<size_t, uint32_t>> primbvh_nodes; // where each shape's Node8[] sits inside primbvh (byte offset, count)
     std::vector<ig_node8> scene_nodes;
     std::vector<ig_entity_leaf1> scene_leaves;
     std::vector<ig_node8> sphere_nodes;
@@ -676,6 +677,7 @@ static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::str
     const uint64_t bvh_offset = sc.primbvh.size() / sizeof(float);
     const uint32_t header[4]  = { (uint32_t)nodes.size(), (uint32_t)tris.size(), 0, 0 };
     appendBytes(sc.primbvh, header, 4);
+    sc.primbvh_nodes.emplace_back(sc.primbvh.size(), (uint32_t)nodes.size());
     appendBytes(sc.primbvh, nodes.data(), nodes.size());
     appendBytes(sc.primbvh, tris.data(), tris.size());
 
@@ -2615,6 +2617,22 @@ static std::unique_ptr<Scene> buildScene(const JsonValue& doc, const std::string
         else if (!finite.empty()) {
             tech.light_selector = IG_SELECTOR_HIERARCHY;
             buildLightHierarchy(hier_entries, sc->light_hierarchy, sc->light_codes);
+        }
+    }
+
+    // ---- large BVHs: child boxes on per-node 8-bit grids, so that the HIP device can keep a node in one 128-byte line
+    // (bvh.cpp quantise_node8; IGH_NODE_QUANT=0 never, 1 always, default: from 64 MB of Node8 records on — what the GPU's L2s no longer hold)
+    {
+        size_t node_bytes = (sc->scene_nodes.size() + sc->sphere_nodes.size()) * sizeof(ig_node8);
+        for (const auto& r : sc->primbvh_nodes)
+            node_bytes += (size_t)r.second * sizeof(ig_node8);
+        const char* e    = std::getenv("IGH_NODE_QUANT");
+        const bool quant = e && *e ? std::atoi(e) != 0 : node_bytes > ((size_t)64 << 20);
+        if (quant) {
+            for (const auto& r : sc->primbvh_nodes)
+                quantise_node8(reinterpret_cast<ig_node8*>(sc->primbvh.data() + r.first), r.second);
+            quantise_node8(sc->scene_nodes.data(), sc->scene_nodes.size());
+            quantise_node8(sc->sphere_nodes.data(), sc->sphere_nodes.size());
         }
     }
 

@@ -49,6 +49,7 @@ EXPORTS = [
     "igd_framebuffer_device", "igd_clear_framebuffer", "igd_sync_framebuffer_to_device", "igd_get_stats",
     "igd_reset_stats", "igd_traverse", "igd_set_parameter_i32", "igd_set_parameter_f32", "igd_set_parameter_vec3",
     "igd_synchronize", "igd_last_error", "igd_buffer_size", "igd_buffer_copy", "igd_buffer_ptr",
+    "igd_node_bytes",
 ]
 
 _lib = None
@@ -106,6 +107,8 @@ def lib():
         l.igd_set_parameter_vec3.argtypes = [C.c_void_p, C.c_char_p, fp]
         l.igd_synchronize.restype = C.c_int32
         l.igd_synchronize.argtypes = [C.c_void_p]
+        l.igd_node_bytes.restype = C.c_int32
+        l.igd_node_bytes.argtypes = [C.c_void_p]
         l.igd_last_error.restype = C.c_char_p
         l.igd_buffer_size.restype = C.c_uint64
         l.igd_buffer_size.argtypes = [C.c_void_p, C.c_char_p]
@@ -199,6 +202,10 @@ class Device:
         size = C.c_uint64(0)
         p = lib().igd_buffer_ptr(self._h, name.encode(), C.byref(size))
         return (int(p) if p else None), int(size.value)
+
+    def node_bytes(self):
+        """Bytes per inner BVH node the traversal kernels fetch for the assigned scene (256: Node8, 128: quantised)."""
+        return int(lib().igd_node_bytes(self._h))
 
     def synchronize(self):
         """Waits for the part of the last render that overlaps the next one (tail paths + resolve) and reports

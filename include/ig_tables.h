@@ -35,8 +35,12 @@ extern "C" {
 typedef struct ig_node8 {
     float bounds[6][8]; /* min_x, max_x, min_y, max_y, min_z, max_z  x 8 children */
     int32_t child[8];
+    /* Unused by the reference. This backend's host builder may leave the node's quantisation grid here (csrc/host/bvh.cpp,
+     * quantise_node8): pad[0..2] = origin.xyz (float bits), pad[3] = IG_NODE8_QUANT_MARK | biased exponents of the three scales
+     * (x in bits 0-7, y 8-15, z 16-23); every plane of a used slot is then fmaf(q, 2^(e - 127), origin) for an integer q in 0..255. */
     int32_t pad[8];
 } ig_node8;
+#define IG_NODE8_QUANT_MARK 0x51000000u
 
 /* Four triangles in Moeller-Trumbore form: v0, e1 = v2 - v0, e2 = v0 - v1,
  * n = stable(e1 x e2); prim_id == -1 marks an unused slot, bit 31 of

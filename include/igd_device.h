@@ -193,6 +193,11 @@ int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float va
  * IGD_ASYNC_TAIL=0 keeps the tail on the critical path. */
 int32_t igd_synchronize(igd_device* dev);
 
+/* Bytes of one inner BVH node as the traversal kernels of the assigned scene fetch it: 256 (the reference's Node8,
+ * src/artic/traversal/bvh.art:85-89) or 128 (the same node on its 8-bit grid, when the scene's builder quantised the boxes and
+ * the device packed them without loss; IGD_NODE_FORMAT=full keeps Node8). What a roofline prices a node visit at. 0: no scene. */
+int32_t igd_node_bytes(const igd_device* dev);
+
 /* Thread-local message of the last failed igd_* call ("" if none). */
 const char* igd_last_error(void);
 

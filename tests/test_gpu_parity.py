@@ -451,6 +451,52 @@ def test_divergent_standin_through_every_shading_schedule(tmp_path, env):
         assert st["rounds"] > 0 and st["tail_rays"] == 0
 
 
+@pytest.mark.parametrize("env", [{}, {"IGD_TAIL_THRESHOLD": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_NODE_REPEAT": "3"}, {"IGD_NODE_FORMAT": "full"}],
+                         ids=["tail", "rounds", "rounds-node-repeat", "node8-records"])
+@pytest.mark.parametrize("which", ["diamond", "standin"])
+def test_quantised_node_records_vs_oracle(tmp_path, monkeypatch, env, which):
+    """The 128-byte node records: the builder snaps the child boxes to per-node 8-bit grids (IGH_NODE_QUANT=1; by
+    default from 64 MB of nodes on), igd_assign_scene packs such tables without loss and the _q8 traversal / tail kernels decode the
+    very floats the Node8 records hold — so hits, radiance AND the node / triangle / leaf counters equal the oracle's on the same tables,
+    in the tail, in the wavefront rounds and with the inner-node section repeated. IGD_NODE_FORMAT=full: the same tables as Node8."""
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    monkeypatch.setenv("IGH_NODE_QUANT", "1")
+    if which == "diamond":
+        w, h = 160, 120
+        sc = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), w, h)
+    else:
+        w, h = 192, 108
+        sc = _standin(tmp_path, 60_000, 24, w, h, "divergent")
+    dev = _device_with_env(env, acquire_stats=True)
+    dev.assign_scene(sc)
+    assert dev.node_bytes() == (256 if env.get("IGD_NODE_FORMAT") == "full" else 128)
+    rays, _ = oracle.generate_rays(sc, 2, w, h, 0, w * h * 2, seed=21)
+    dev.reset_stats()
+    got = dev.traverse(rays, flags=1)
+    st = dev.stats()
+    ref = oracle.trace(sc, rays, flags=1)
+    _assert_hits_equal(ref, got)
+    for k in ("nodes", "tris", "leaves"):
+        assert st[k] == ref["stats"][k], k
+    tot = _compare_with_oracle(dev, sc, w, h, 2, seed=9, iters=2)
+    dev.close()
+    assert tot["camera_rays"] == w * h * 2 * 2
+
+
+def test_quantised_node_records_hbm_regime_vs_oracle(tmp_path):
+    """The workload the format is for: the 16 M-triangle stand-in at 1920x1080 (1.6 GB of Node8 records, which the builder
+    quantises by default and the device holds as 0.8 GB of 128-byte records), hits' counters and radiance against the oracle."""
+    from ignis_amd import Device
+    sc = _standin(tmp_path, 16_000_000, None, 1920, 1080, "lean")
+    dev = Device(0, acquire_stats=True)
+    dev.assign_scene(sc)
+    assert dev.node_bytes() == 128
+    tot = _compare_with_oracle(dev, sc, 1920, 1080, 1, seed=7, iters=1)
+    dev.close()
+    assert tot["camera_rays"] == 1920 * 1080
+
+
 def test_config5_film_shape_4096_rows_of_rank0_of_8(tmp_path):
     """configs[4]'s shape (asset absent: the seeded stand-in): a 4096 x 4096 film, the rows rank 0 of 8 owns (row_offset 0,
     row_stride 8: 512 rows = 2 Mi camera paths, twice the tail threshold, so wavefront rounds and the tail both run), one

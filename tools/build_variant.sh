@@ -12,6 +12,10 @@ for f in traverse shade photon tail device; do
   S=$(sched $f); [ -n "${NO_SCHED:-}" ] && S=""
   /opt/rocm/bin/hipcc $FLAGS $S "$@" -c "$ROOT/ignis_amd/csrc/device/$f.hip" -o "$OUT/$f.o" &
 done
+for f in traverse tail; do
+  S=$(sched $f); [ -n "${NO_SCHED:-}" ] && S=""
+  /opt/rocm/bin/hipcc $FLAGS $S "$@" -DIG_QNODE=1 -c "$ROOT/ignis_amd/csrc/device/$f.hip" -o "$OUT/${f}_q8.o" &
+done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OUT"/*.o -o "$ROOT/ignis_amd/lib/var/libig_device_hip_$NAME.so"
 rm -rf "$OUT"
