@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--collective", choices=("gather", "reduce"), default="gather", help="rows sharding: gather of the owned rows (default) or reduce(SUM) of whole framebuffers")
     ap.add_argument("--as-rank-of", type=int, default=0, help="experiments only: one process renders what rank 0 of N row-sharding ranks would (estimate of per-GPU throughput at N GPUs)")
     ap.add_argument("--scene", default=SCENE, help="other scene file (not the headline workload), e.g. tools/make_standin_scene.py output")
+    ap.add_argument("--dist", choices=("rccl", "torch"), default="rccl",
+                    help="N > 1: rccl = the device library's own RCCL communicator (igd_comm_*, ignis_amd/comm.py; no torch in the process), "
+                         "torch = torch.distributed with the nccl backend (the path of rounds 1 - 4)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (BASELINE configs 3 and 4 measured next to the headline)")
     return ap.parse_args()
 
@@ -188,7 +191,9 @@ def main():
 
     dist = None
     torch = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank
+    distributed = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))  # BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank
+    native = distributed and args.dist == "rccl"
+    if distributed and not native:
         # torch first: its bundled HIP runtime and RCCL are the ones every library in this process binds to
         import torch
         import torch.distributed as dist
@@ -197,6 +202,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if native:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
 
     import numpy as np
     from ignis_amd import Device, LoadedScene, sharding
@@ -210,7 +219,15 @@ def main():
     dev.assign_scene(scene)
     dev.resize(W, H)
 
+    comm = None
+    if native:
+        # the device library's own communicator: ncclCommInitRank inside libig_device_hip.so, the id handed round by ignis_amd.comm
+        from ignis_amd.comm import Comm
+        comm = Comm(dev, rank, world)
+
     def barrier():
+        if comm is not None:
+            comm.barrier()  # (an all-reduce on the render stream, waited for)
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
@@ -242,6 +259,15 @@ def main():
 
     fb_tensor = None
     collective = None
+    if comm is not None:
+        if not by_rows:
+            raise SystemExit("--sharding iterations needs --dist torch (the native communicator implements the gather of owned rows)")
+        # RCCL sets up its channels / kernels for a message size on first use: do that outside the timed region (the film is cleared below)
+        comm.gather_rows(dst=0)
+        dev.clear_framebuffer()
+        collective = {"op": "gather of owned rows to rank 0 (grouped ncclSend / ncclRecv by libig_device_hip.so, igd_comm_gather_rows)",
+                      "bytes_per_rank": sharding.gather_bytes(H, W, world), "backend": "rccl (dlopen by the device library, no torch)",
+                      "world_size_from_backend": comm.world_size_from_backend()}
     if dist is not None:
         class _Wrap:  # zero-copy view of the device framebuffer for RCCL
             def __init__(self, ptr, shape):
@@ -269,6 +295,8 @@ def main():
     dev.synchronize()  # everything submitted above is finished before the clock stops (and before the collective)
     if os.environ.get("BENCH_TRACE"):
         print(f"[trace] loop {(t_sync - t0) * 1e3:.1f} ms, final synchronize {(time.perf_counter() - t_sync) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+    if comm is not None:
+        comm.gather_rows(dst=0)  # the ONLY collective: final accumulation of the tile-sharded framebuffer on rank 0 (returns when it is complete)
     if dist is not None:
         # the ONLY collective: final accumulation of the tile-sharded framebuffer on rank 0
         collective_op(fb_tensor)
@@ -279,7 +307,10 @@ def main():
     st = dev.stats()
     rays_local = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
     samples_local = st["camera_rays"]
-    if dist is not None:
+    if comm is not None:
+        elapsed = comm.allreduce([elapsed], "max")[0]
+        rays_total, samples_total = comm.allreduce([rays_local, samples_local], "sum")
+    elif dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -424,6 +455,8 @@ def main():
         if world == 1 and shards == 1 and not args.no_extra_configs and args.scene == SCENE:
             out["configs"] = extra_configs(args)
 
+    if comm is not None:
+        pass  # (the communicator went with its device: rank 0 closed that before the counter replay)
     dev.close()  # (idempotent: rank 0 closed it before the counter replay)
     # RCCL writes a version banner to the C stdout buffer of the ranks; every rank pushes its buffer out before rank 0
     # prints, so that the JSON line is the LAST line of the job's stdout

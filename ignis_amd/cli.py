@@ -72,7 +72,8 @@ def main(argv=None, load=loadFromFile):
     ap.add_argument("--stats", action="store_true", help="acquire ray statistics and stage timers")
     ap.add_argument("--full-stats", action="store_true", help="also count traversal work (slower kernels)")
     ap.add_argument("--gpus", type=int, default=1, help="tile-shard the film over this many GPUs of the node (one process each, one RCCL gather at the end)")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend of --gpus N (nccl = RCCL over xGMI)")
+    ap.add_argument("--backend", default="rccl", choices=("rccl", "nccl", "gloo"),
+                    help="--gpus N: rccl = the device library's own RCCL communicator (igd_comm_*, no torch); nccl / gloo = torch.distributed with that backend (gloo: CPU tests)")
     args = ap.parse_args(argv)
     if args.spp is None and args.time is None:
         args.spp = 64
@@ -84,19 +85,21 @@ def main(argv=None, load=loadFromFile):
         return 2
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
+    native = args.backend == "rccl"
     sharded = world > 1 or bool(os.environ.get("IGNIS_CLI_FORCE_DIST"))  # (the variable: a single rank through the whole RCCL path, for tests)
     if sharded:
         if args.time is not None:
             print("--time is not available with --gpus N (ranks must render the same iterations)", file=sys.stderr)
             return 2
-        import torch  # first: its HIP runtime and RCCL are the ones the device library binds to in this process
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        if not native:
+            import torch  # first: its HIP runtime and RCCL are the ones the device library binds to in this process
+            import torch.distributed as dist
+            if args.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         args.gpu = local_rank
     chatty = rank == 0
 
@@ -138,8 +141,20 @@ def main(argv=None, load=loadFromFile):
 
     gathered = None
     st = rt.getStatistics() if (args.stats or args.full_stats) else None
-    if sharded:
-        # the ONLY collective: the rows each rank owns, to rank 0 (W x H x 12 / world bytes per rank)
+    comm = None
+    if sharded and native:
+        # the ONLY collective: the rows each rank owns, to rank 0 (W x H x 12 / world bytes per rank), by the device library itself
+        from .comm import Comm
+        comm = Comm(rt.device, rank, world)
+        t0 = time.perf_counter()
+        comm.gather_rows(dst=0)
+        t_render += time.perf_counter() - t0
+        if rank == 0:
+            gathered = rt.getFramebufferForHost().copy()
+        if st is not None:
+            keys = [k for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes", "tris", "leaves") if k in st]
+            st = dict(st, **{k: int(v) for k, v in zip(keys, comm.allreduce([float(st[k]) for k in keys], "sum"))})
+    elif sharded:
         from . import sharding
         t0 = time.perf_counter()
         fb = rt.framebufferTensor(torch, on_device=args.backend == "nccl")
@@ -162,6 +177,9 @@ def main(argv=None, load=loadFromFile):
         t_saving = time.perf_counter() - t0
         print(f"Result saved to {args.output}" if ok else f"Failed to save EXR file {args.output}", file=sys.stderr)
     ms_all = (time.perf_counter() - t_all) * 1e3
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "igd_device.h"
+#include "comm.h"
 #include "kernels.h"
 #include "ig_expr.h"
 #include "ig_photon.h"
@@ -240,6 +241,8 @@ struct igd_device {
     double tail_density       = 0.5; // expected paths per launched wave of a pass after the first (IGD_TAIL_DENSITY)
     double tail_share[24]     = {}; // paths at the start of pass j / paths at the start of pass 0, last collected chunk; [0] == 0: unknown
 
+    igdev::Comm* comm = nullptr; // igd_comm_init: the RCCL communicator of a tile-sharded render (comm.hip)
+
     // statistics
     igd_stats stats{};
     std::vector<hipEvent_t> events; // pool for the stage timers
@@ -252,6 +255,7 @@ struct igd_device {
         for (auto sd : side)
             if (sd)
                 (void)hipStreamSynchronize(sd);
+        igdev::comm_destroy(comm);
         for (auto e : events)
             (void)hipEventDestroy(e);
         for (auto e : poll_event)
@@ -2446,6 +2450,75 @@ int32_t igd_synchronize(igd_device* dev)
         HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
         finish(dev);
     });
+}
+
+int32_t igd_comm_unique_id(uint8_t id[IGD_COMM_ID_BYTES])
+{
+    if (!id) {
+        g_error = "igd_comm_unique_id: null id";
+        return IGD_ERR_INVALID_ARG;
+    }
+    return guarded("igd_comm_unique_id", [&] { comm_unique_id(id); });
+}
+
+int32_t igd_comm_init(igd_device* dev, const uint8_t id[IGD_COMM_ID_BYTES], int32_t rank, int32_t world_size)
+{
+    if (!dev || !id) {
+        g_error = "igd_comm_init: null device or id";
+        return IGD_ERR_INVALID_ARG;
+    }
+    return guarded("igd_comm_init", [&] {
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        comm_destroy(dev->comm);
+        dev->comm = nullptr;
+        dev->comm = comm_create(id, rank, world_size);
+    });
+}
+
+int32_t igd_comm_world_size(igd_device* dev)
+{
+    if (!dev || !dev->comm)
+        return 0;
+    int n = 0;
+    return guarded("igd_comm_world_size", [&] { n = comm_world_size(dev->comm); }) == IGD_OK ? n : 0;
+}
+
+int32_t igd_comm_gather_rows(igd_device* dev, int32_t dst_rank)
+{
+    if (!dev || !dev->comm) {
+        g_error = "igd_comm_gather_rows: no communicator (igd_comm_init)";
+        return IGD_ERR_INVALID_ARG;
+    }
+    return guarded("igd_comm_gather_rows", [&] {
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        finish(dev); // everything rendered so far is in the framebuffer
+        if (!dev->fb.ptr)
+            throw HipError{ IGD_ERR_INVALID_ARG, "no framebuffer yet" };
+        static const bool loopback = std::getenv("IGD_COMM_LOOPBACK") != nullptr; // tests on one GPU: rank dst's own rows travel too
+        comm_gather_rows(dev->comm, dev->fb.ptr, dev->fb_w, dev->fb_h, dst_rank, dev->stream, loopback);
+        dev->fb_host_dirty = true;
+    });
+}
+
+int32_t igd_comm_allreduce_f64(igd_device* dev, double* values, int32_t count, int32_t op)
+{
+    if (!dev || !dev->comm || (!values && count > 0)) {
+        g_error = "igd_comm_allreduce_f64: no communicator (igd_comm_init) or null values";
+        return IGD_ERR_INVALID_ARG;
+    }
+    return guarded("igd_comm_allreduce_f64", [&] {
+        HIP_CHECK(hipSetDevice(dev->setup.gpu_index));
+        comm_allreduce_f64(dev->comm, values, count, op, dev->stream);
+    });
+}
+
+int32_t igd_comm_destroy(igd_device* dev)
+{
+    if (!dev)
+        return IGD_ERR_INVALID_ARG;
+    comm_destroy(dev->comm);
+    dev->comm = nullptr;
+    return IGD_OK;
 }
 
 int32_t igd_node_bytes(const igd_device* dev) { return dev && dev->has_scene ? (dev->q8_nodes ? 128 : 256) : 0; }

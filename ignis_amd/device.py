@@ -50,6 +50,7 @@ EXPORTS = [
     "igd_reset_stats", "igd_traverse", "igd_set_parameter_i32", "igd_set_parameter_f32", "igd_set_parameter_vec3",
     "igd_synchronize", "igd_last_error", "igd_buffer_size", "igd_buffer_copy", "igd_buffer_ptr",
     "igd_node_bytes",
+    "igd_comm_unique_id", "igd_comm_init", "igd_comm_world_size", "igd_comm_gather_rows", "igd_comm_allreduce_f64", "igd_comm_destroy",
 ]
 
 _lib = None
@@ -109,6 +110,18 @@ def lib():
         l.igd_synchronize.argtypes = [C.c_void_p]
         l.igd_node_bytes.restype = C.c_int32
         l.igd_node_bytes.argtypes = [C.c_void_p]
+        l.igd_comm_unique_id.restype = C.c_int32
+        l.igd_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+        l.igd_comm_init.restype = C.c_int32
+        l.igd_comm_init.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+        l.igd_comm_world_size.restype = C.c_int32
+        l.igd_comm_world_size.argtypes = [C.c_void_p]
+        l.igd_comm_gather_rows.restype = C.c_int32
+        l.igd_comm_gather_rows.argtypes = [C.c_void_p, C.c_int32]
+        l.igd_comm_allreduce_f64.restype = C.c_int32
+        l.igd_comm_allreduce_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32]
+        l.igd_comm_destroy.restype = C.c_int32
+        l.igd_comm_destroy.argtypes = [C.c_void_p]
         l.igd_last_error.restype = C.c_char_p
         l.igd_buffer_size.restype = C.c_uint64
         l.igd_buffer_size.argtypes = [C.c_void_p, C.c_char_p]

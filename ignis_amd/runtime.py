@@ -121,6 +121,11 @@ class Runtime:
         if not opts.IsTracer:
             self._device.resize(self._width, self._height)
 
+    @property
+    def device(self):
+        """The render device (ignis_amd.Device) behind this runtime: what ignis_amd.comm.Comm attaches its communicator to."""
+        return self._device
+
     # -- context manager like RuntimeWrap (runtime.cpp:313-320)
     def __enter__(self):
         return self

@@ -193,6 +193,22 @@ int32_t igd_set_parameter_vec3(igd_device* dev, const char* name, const float va
  * IGD_ASYNC_TAIL=0 keeps the tail on the critical path. */
 int32_t igd_synchronize(igd_device* dev);
 
+/* ---- the one exchange step of a tile-sharded render (BASELINE.json north_star: "tile-sharded across GPUs with an RCCL gather over
+ * xGMI only for final accumulation"). One process per GPU; rank r renders film rows r, r + N, ... (igd_render_settings.row_offset /
+ * row_stride) and igd_comm_gather_rows moves each rank's rows into rank dst's framebuffer: ceil(H / N) x W x 12 bytes per rank,
+ * grouped ncclSend / ncclRecv on the device's render stream, no arithmetic on the way. The reference has no counterpart (its
+ * devices render whole films, src/runtime/device/IRenderDevice.h:44; Runtime::getFramebufferForHost, Runtime.cpp:438-455, is where
+ * the gathered film is read). librccl.so is opened at run time by the device library itself (no torch, no MPI); the launcher hands
+ * every rank the id rank 0 obtained (ignis_amd/comm.py). */
+#define IGD_COMM_ID_BYTES 128
+int32_t igd_comm_unique_id(uint8_t id[IGD_COMM_ID_BYTES]);                                                    /* ncclGetUniqueId */
+int32_t igd_comm_init(igd_device* dev, const uint8_t id[IGD_COMM_ID_BYTES], int32_t rank, int32_t world_size); /* ncclCommInitRank on the device's GPU */
+int32_t igd_comm_world_size(igd_device* dev);                                                                 /* ncclCommCount; 0: no communicator */
+int32_t igd_comm_gather_rows(igd_device* dev, int32_t dst_rank);
+/* values[i] <- sum (op 0) or max (op 2) over the ranks: ray statistics, the slowest rank's clock; a barrier as well */
+int32_t igd_comm_allreduce_f64(igd_device* dev, double* values, int32_t count, int32_t op);
+int32_t igd_comm_destroy(igd_device* dev);
+
 /* Bytes of one inner BVH node as the traversal kernels of the assigned scene fetch it: 256 (the reference's Node8,
  * src/artic/traversal/bvh.art:85-89) or 128 (the same node on its 8-bit grid, when the scene's builder quantised the boxes and
  * the device packed them without loss; IGD_NODE_FORMAT=full keeps Node8). What a roofline prices a node visit at. 0: no scene. */

@@ -497,6 +497,31 @@ def test_quantised_node_records_hbm_regime_vs_oracle(tmp_path):
     assert tot["camera_rays"] == 1920 * 1080
 
 
+def test_native_rccl_communicator_single_rank_loopback(monkeypatch):
+    """igd_comm_* (csrc/device/comm.hip): librccl opened by the device library, ncclGetUniqueId / ncclCommInitRank / ncclCommCount,
+    and the gather's data path on one GPU — IGD_COMM_LOOPBACK makes rank 0 pack its own rows (all of them at world 1), send them to
+    itself with ncclSend / ncclRecv in one group, clear them in the film and put back what arrived: the image must come back bit for
+    bit. The all-reduce returns its input at world 1. (More than one rank needs more than one GPU: the driver's scaling run.)"""
+    from ignis_amd import Device
+    from ignis_amd.comm import Comm
+    from ignis_amd.tables import LoadedScene
+    monkeypatch.setenv("IGD_COMM_LOOPBACK", "1")
+    w, h = 96, 50
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), w, h)
+    dev = Device(0, acquire_stats=True)
+    fb, _ = _render_gpu(dev, scene, 2, w, h, iters=2, seed=5)
+    before = fb.copy()
+    comm = Comm(dev, 0, 1)
+    assert comm.world_size_from_backend() == 1
+    comm.gather_rows(dst=0)
+    np.testing.assert_array_equal(_bits(dev.framebuffer()), _bits(before))
+    assert before.any()
+    assert comm.allreduce([1.5, -2.0, 3e9], "sum") == [1.5, -2.0, 3e9] and comm.allreduce([7.25], "max") == [7.25]
+    comm.barrier()
+    comm.close()
+    dev.close()
+
+
 def test_config5_film_shape_4096_rows_of_rank0_of_8(tmp_path):
     """configs[4]'s shape (asset absent: the seeded stand-in): a 4096 x 4096 film, the rows rank 0 of 8 owns (row_offset 0,
     row_stride 8: 512 rows = 2 Mi camera paths, twice the tail threshold, so wavefront rounds and the tail both run), one
@@ -1317,19 +1342,22 @@ def test_resending_unchanged_parameters_keeps_the_batch(diamond_scene, monkeypat
     assert sc["traverse_primary_launches"] > sa["traverse_primary_launches"]
 
 
-def test_bench_single_rank_through_rccl():
-    """bench.py's N > 1 code path with one rank (BENCH_FORCE_DIST=1): process group on the nccl (= RCCL) backend, zero-copy
-    torch view of the device framebuffer, the gather collective, the max-over-ranks timing — and the same JSON contract."""
+@pytest.mark.parametrize("how", ["rccl", "torch"])
+def test_bench_single_rank_through_rccl(how):
+    """bench.py's N > 1 code path with one rank (BENCH_FORCE_DIST=1). rccl (the default): the device library's own communicator
+    (igd_comm_*: ncclCommInitRank inside libig_device_hip.so, the gather of owned rows, the max / sum all-reduces for the clock and
+    the ray counts; no torch in the process). torch: a process group on the nccl (= RCCL) backend with a zero-copy torch view of the
+    device framebuffer. The same JSON contract either way."""
     import subprocess
     import sys
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(os.path.dirname(SCENES), "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320", "--height", "180",
-           "--no-cpu-baseline", "--no-literal-config"]
+           "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--dist", how]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["collective"]["world_size_from_backend"] == 1 and line["collective"]["backend"] == "nccl"
+    assert line["collective"]["world_size_from_backend"] == 1 and line["collective"]["backend"].startswith("nccl" if how == "torch" else "rccl")
     assert line["collective"]["bytes_per_rank"] == 320 * 180 * 12
     assert line["rays"]["camera"] == 320 * 180 * 8 * 4
     assert 0 < line["roofline"]["frac"] <= 1

@@ -203,3 +203,27 @@ def test_cli_gpus_n_entry_point_over_gloo(tmp_path, world):
         oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=ref)
     np.testing.assert_allclose(got, ref / np.float32(3), rtol=2e-5, atol=1e-6)
     assert attrs["igSPP"][1] == str(3 * SPI).encode()
+
+
+def _id_rank(rank, world, port, out_dir):
+    from ignis_amd.comm import exchange_id, ID_BYTES
+    blob = exchange_id(rank, world, lambda: bytes(range(ID_BYTES)), addr="127.0.0.1", port=port, timeout=60)
+    with open(os.path.join(out_dir, f"id{rank}.bin"), "wb") as f:
+        f.write(blob)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_rccl_id_rendezvous_without_torch(tmp_path, world):
+    """The launcher's half of the native RCCL path (ignis_amd/comm.py): rank 0's 128-byte id reaches every rank over one TCP
+    exchange, whatever order the ranks come up in (no torch.distributed, no store)."""
+    import multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_id_rank, args=(r, world, port, str(tmp_path))) for r in reversed(range(world))]  # (rank 0 last)
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert (tmp_path / f"id{r}.bin").read_bytes() == bytes(range(128))

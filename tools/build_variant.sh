@@ -8,7 +8,7 @@ OUT=$ROOT/ignis_amd/lib/var/$NAME
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-parameter -I$ROOT/include"
 sched() { case $1 in traverse) echo "-mllvm -amdgpu-sched-strategy=max-memory-clause";; shade|photon|tail) echo "-mllvm -amdgpu-sched-strategy=max-ilp";; esac; }
-for f in traverse shade photon tail device; do
+for f in traverse shade photon tail comm device; do
   S=$(sched $f); [ -n "${NO_SCHED:-}" ] && S=""
   /opt/rocm/bin/hipcc $FLAGS $S "$@" -c "$ROOT/ignis_amd/csrc/device/$f.hip" -o "$OUT/$f.o" &
 done
