@@ -46,6 +46,9 @@ void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uin
 // photon.hip (IG_TECHNIQUE_PPM)
 void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 size_t photon_grid_temp_bytes(uint32_t n);
+size_t lt_splat_temp_bytes(uint32_t bound);
+hipError_t launch_lt_splat(const float4* col, const float4* verdict, const uint32_t* path_id, const uint32_t* count, uint32_t bound, unsigned long long* keys, uint32_t* vals,
+                           void* temp, size_t temp_bytes, float4* accum, int64_t id_base, float inv_spi, hipStream_t stream);
 hipError_t build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArgs& grid, igp_photon* sorted, uint32_t* cell_count, uint32_t* cell_offset, unsigned long long* keys, uint32_t* valid,
                        void* temp, size_t temp_bytes, hipStream_t stream);
 } // namespace igdev
@@ -166,6 +169,12 @@ struct igd_device {
     DevBuf<float> primary[2], secondary;
     DevBuf<uint32_t> deep_rays; // indices of the rays a traversal launch hands to its DEEP launch
     DevBuf<float> list_rays;
+    // light tracer: per shadow ray the id of its light path, and the sort of a round's unoccluded connections by (slot, path)
+    // (launch_lt_splat, photon.hip); allocated by the first light-tracer render
+    DevBuf<uint32_t> lt_path_id, lt_vals;
+    DevBuf<unsigned long long> lt_keys;
+    DevBuf<uint8_t> lt_temp;
+    size_t lt_capacity = 0;
     // the by-class shading kernels' global sort of a round's hits by material (BinSortArgs, kernels.h): the sorted ray indices and the
     // key column (allocated with the first render that needs them), the sort's state words, the bins' order and classes (per scene)
     DevBuf<uint32_t> sort_idx, sort_state;
@@ -302,6 +311,7 @@ struct igd_device {
         q.rayA = reinterpret_cast<float4*>(b + 0 * c);
         q.rayB = reinterpret_cast<float4*>(b + 4 * c);
         q.col  = reinterpret_cast<float4*>(b + 8 * c);
+        q.path_id = lt_path_id.ptr;
         return q;
     }
 
@@ -325,6 +335,11 @@ struct igd_device {
         sort_idx.release();
         sort_keys.release();
         sort_capacity = 0;
+        lt_path_id.release();
+        lt_vals.release();
+        lt_keys.release();
+        lt_temp.release();
+        lt_capacity = 0;
         for (auto& f : flight) {
             f.accum.release();
             f.accum_mis[0].release();
@@ -377,6 +392,7 @@ struct igd_device {
         q.rayA = reinterpret_cast<float4*>(b + 0 * c);
         q.rayB = reinterpret_cast<float4*>(b + 4 * c);
         q.col  = reinterpret_cast<float4*>(b + 8 * c);
+        q.path_id = nullptr;
         return q;
     }
 
@@ -1387,6 +1403,23 @@ void render(igd_device* d, const igd_render_settings* rs)
         // a connection lands in any pixel of the film: its accumulator slot has to exist in the chunk that traces the path
         throw HipError{ IGD_ERR_UNSUPPORTED, "igd_render: the light tracer needs the whole film in one wavefront (no row sharding, no ray lists, stream capacity >= width * height * spi)" };
 
+    if (light_tracer && d->lt_capacity < d->capacity) {
+        // the connections' deterministic splat (launch_lt_splat): path ids, verdicts, sort buffers for one round's shadow rays
+        finish(d);
+        d->lt_path_id.release(), d->lt_vals.release(), d->lt_keys.release(), d->lt_temp.release();
+        d->lt_path_id.alloc(d->capacity);
+        d->lt_vals.alloc(2 * d->capacity);
+        d->lt_keys.alloc(2 * d->capacity);
+        const size_t tb = lt_splat_temp_bytes((uint32_t)std::min<size_t>(d->capacity, 0x7FFFFFFFu));
+        if (tb == 0)
+            throw HipError{ IGD_ERR_DEVICE, "igd_render: the light tracer's connection sort could not be sized" };
+        d->lt_temp.alloc(tb);
+        d->lt_capacity = d->capacity;
+        if (d->secondary_hit.count < d->capacity * 4) {
+            d->secondary_hit.release();
+            d->secondary_hit.alloc(d->capacity * 4);
+        }
+    }
     // (the light tracer has no camera-flagged rays, so the wrapper below never splats for it: "Normals" / "Albedo" stay zero)
     if (d->setup.info_aovs && !list_mode && rs->iteration == 0 && !light_tracer) {
         // wrap_infobuffer_renderer (technique/internal/infobuffer.art:4-30): normals and albedo of the camera rays' first hits of
@@ -1566,6 +1599,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             uint32_t* deep_rays;
             float4* sec_hit;
         };
+        uint32_t round_bound = n; // upper bound of the round's primary stream, hence of its shadow rays (light tracer: what its connection sort covers)
         auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror, bool bounce_rays_only) {
             const PrimaryCols in = b.prim[in_slot];
             TraverseArgs ta{};
@@ -1655,9 +1689,16 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.accum_nee = accum_mis[1];
             tb.id_base = first;
             tb.inv_spi = inv;
-            tb.atomic_splat = light_tracer ? 1 : 0;
+            if (light_tracer) {
+                // K6 records verdicts only; K7 / K8 below add the unoccluded connections into their pixels' slots in a fixed order
+                tb.accum = nullptr;
+                tb.hit   = reinterpret_cast<float4*>(d->secondary_hit.ptr);
+            }
             timed(3, on, [&] {
                 launchTraverse(d, tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid, d->deep_primary);
+                if (light_tracer)
+                    HIP_CHECK(launch_lt_splat(b.sec.col, reinterpret_cast<const float4*>(d->secondary_hit.ptr), b.sec.path_id, &qs->q[in_slot ^ 1].secondary, round_bound,
+                                              d->lt_keys.ptr, d->lt_vals.ptr, d->lt_temp.ptr, d->lt_temp.count, accum, first, inv, on));
                 launch_secondary_end(qs, in_slot ^ 1, mirror, on);
             });
             d->stats.rounds++;
@@ -1683,6 +1724,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 break;
             }
             // size after this round -> pinned slot (round & 1), written by the round's last kernel itself
+            round_bound = known_live;
             launchRound(st, main_bufs, in_slot, d->traverseGrid(), d->shadeGrid(), d->host_store_dev + igd_device::kMaxFlights + (round & 1), round > 0);
             in_slot ^= 1;
             HIP_CHECK(hipEventRecord(d->poll_event[round & 1], st));

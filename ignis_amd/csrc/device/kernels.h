@@ -93,6 +93,7 @@ struct SecondaryCols {
     float4* rayA;
     float4* rayB;
     float4* col;
+    uint32_t* path_id; // light tracer only (null otherwise): the id of the light path a connection comes from (launch_lt_splat's sort key)
 };
 
 // Device-resident queue state: no host round trip per bounce (the reference reads counters back
@@ -141,7 +142,6 @@ struct TraverseArgs {
     float4* accum_nee; // "NEE Weights" (ig_technique.aov_mis): the same splat once more, or null
     int64_t id_base;
     float inv_spi;
-    int32_t atomic_splat; // light tracer: the slot col.w names belongs to another path's pixel, so the splat is atomic
     // scenes with analytic spheres: the launch over the triangle BVH is followed by one over the sphere BVH that starts from its
     // hits. 0: single pass; 1: first of two (any-hit: the hit must be stored and the splat is left to the second); 2: the sphere pass
     int32_t sphere_pass;

@@ -85,4 +85,73 @@ hipError_t build_photon_grid(const igp_photon* photons, uint32_t n, const PpmArg
     return hipMemcpyAsync(valid, cell_offset + IGP_GRID_CELLS, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
 }
 
+// ---------------------------------------------------------------- the light tracer's connections
+
+// K7 + K8 of the reference for the light tracer (gpu_sort_secondary: the shadow rays partitioned by verdict, and gpu_advanced_shadow:
+// on_shadow_miss per unoccluded ray, mapping_gpu.art:293-333,504-614; technique/lighttracer.art:116-120 splats the connection into the
+// film). A connection lands in the accumulator slot of ANOTHER path's pixel, so many rays of a round add into one slot; the reference
+// (and rounds 1 - 4 here) do that with float atomics, in whatever order the hardware serves them. Here: the any-hit launch only
+// records its verdicts, the unoccluded rays get the key (slot, light path id) — unique within a round: a path makes one connection
+// per bounce — one radix sort puts them in that order (the occluded ones behind), and one thread per slot adds its run in order:
+// the film of a given seed is the same bits run after run.
+__global__ void __launch_bounds__(256) k_lt_keys(const float4* __restrict__ col, const float4* __restrict__ verdict, const uint32_t* __restrict__ path_id, const uint32_t* count,
+                                                  uint32_t bound, unsigned long long* keys, uint32_t* vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bound)
+        return;
+    unsigned long long key = ~0ull;
+    if (i < *count && (int)igm_bits(verdict[i].y) < 0) // (prim id of the any-hit launch: negative = nothing in the way)
+        key = ((unsigned long long)igm_bits(col[i].w) << 32) | path_id[i];
+    keys[i] = key;
+    vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_lt_splat(const float4* __restrict__ col, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t bound,
+                                                   float4* accum, int64_t id_base, float inv_spi)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= bound)
+        return;
+    const unsigned long long key = keys[j];
+    if (key == ~0ull)
+        return;
+    const uint32_t slot = (uint32_t)(key >> 32);
+    if (j > 0 && (uint32_t)(keys[j - 1] >> 32) == slot)
+        return; // not the first of its slot's run
+    float4* dst = accum + ((int64_t)(int32_t)slot - id_base);
+    float4 v    = *dst;
+    for (uint32_t k = j; k < bound && (uint32_t)(keys[k] >> 32) == slot && keys[k] != ~0ull; ++k) {
+        const float4 c = col[vals[k]];
+        v.x += c.x * inv_spi;
+        v.y += c.y * inv_spi;
+        v.z += c.z * inv_spi;
+    }
+    *dst = v;
+}
+
+size_t lt_splat_temp_bytes(uint32_t bound)
+{
+    size_t bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)bound) != hipSuccess)
+        return 0;
+    return bytes;
+}
+
+// col / verdict / path_id: the round's shadow rays (count on the device, at most `bound`); keys, vals: 2 x bound entries each
+hipError_t launch_lt_splat(const float4* col, const float4* verdict, const uint32_t* path_id, const uint32_t* count, uint32_t bound, unsigned long long* keys, uint32_t* vals,
+                           void* temp, size_t temp_bytes, float4* accum, int64_t id_base, float inv_spi, hipStream_t stream)
+{
+    if (bound == 0)
+        return hipSuccess;
+    const unsigned blocks = (bound + 255u) / 256u;
+    hipLaunchKernelGGL(k_lt_keys, dim3(blocks), dim3(256), 0, stream, col, verdict, path_id, count, bound, keys, vals);
+    size_t bytes       = temp_bytes;
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys, keys + bound, vals, vals + bound, (int)bound, 0, 64, stream);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k_lt_splat, dim3(blocks), dim3(256), 0, stream, col, keys + bound, vals + bound, bound, accum, id_base, inv_spi);
+    return hipGetLastError();
+}
+
 } // namespace igdev

@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
                 a.sec.rayA[o] = make_float4(out.s_org.x, out.s_org.y, out.s_org.z, kRayOffset);
                 a.sec.rayB[o] = make_float4(out.s_dir.x, out.s_dir.y, out.s_dir.z, out.s_tmax);
                 a.sec.col[o]  = make_float4(out.s_col.r, out.s_col.g, out.s_col.b, igm_float((uint32_t)(LT ? s_slot : ray_id)));
+                if constexpr (LT)
+                    a.sec.path_id[o] = (uint32_t)ray_id;
             }
             __syncthreads(); // s_wave_cnt / s_base are reused by the next chunk
             clk.mark(9); // the stores (drained), the last barrier

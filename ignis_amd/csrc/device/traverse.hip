@@ -161,19 +161,13 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             // profiles/r03_experiment_shade.txt.)
                             const float4 c = splat;
                             float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                            // (the light tracer's connections, on_advanced_shadow_miss, technique/lighttracer.art:116-120, add into the
-                            // slots of one pixel from many paths: atomics for correctness there)
-                            if (a.atomic_splat) {
-                                unsafeAtomicAdd(&dst->x, c.x * a.inv_spi);
-                                unsafeAtomicAdd(&dst->y, c.y * a.inv_spi);
-                                unsafeAtomicAdd(&dst->z, c.z * a.inv_spi);
-                            } else {
-                                float4 v = *dst;
-                                v.x += c.x * a.inv_spi;
-                                v.y += c.y * a.inv_spi;
-                                v.z += c.z * a.inv_spi;
-                                *dst = v;
-                            }
+                            // (the light tracer's connections add into the slots of OTHER paths' pixels: its launches pass no accumulator and
+                            // record verdicts only, launch_lt_splat adds them in a fixed order afterwards, photon.hip)
+                            float4 v = *dst;
+                            v.x += c.x * a.inv_spi;
+                            v.y += c.y * a.inv_spi;
+                            v.z += c.z * a.inv_spi;
+                            *dst = v;
                             if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
                                 float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
                                 float4 w   = *nd;
