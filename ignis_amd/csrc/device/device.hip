@@ -231,6 +231,7 @@ struct igd_device {
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
     bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
+    bool skip_misses       = true; // IGD_SKIP_MISSES=0: k_shade reads a miss's columns although the scene has no environment light (ShadeArgs::skip_misses)
     int node_repeat = -1; // IGD_NODE_REPEAT: DevScene::node_repeat (-1: by the size of the BVH)
     // IGD_NODE_FORMAT: -1 auto (the 128-byte quantised node records when the builder left every node on its 8-bit grid — it does from
     // 64 MB of nodes on — and the scene has no analytic spheres), 0 always Node8, 1 quantised whenever the tables allow it
@@ -911,7 +912,8 @@ void assignScene(igd_device* d, const igd_scene* s)
                         || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS; // the Radiance BSDFs live in that instantiation too
         ds.expr_code = any_expr ? d->expr_code.ptr : nullptr;
     }
-    // (the 8 L2s hold 32 MB together: a BVH beyond that is fetched from the Infinity Cache / HBM on most visits)
+    // (the 8 L2s hold 32 MB together; the switch sits at twice that, 64 MB, where the stand-in sweep put the break-even: below it most visits
+    // still hit an L2 and the repeats run for too few lanes)
     ds.node_repeat          = d->node_repeat >= 0 ? (uint32_t)d->node_repeat : (blob.size() > ((size_t)64 << 20) ? 3u : 0u);
     ds.scene_radius         = s->scene_radius;
     for (int k = 0; k < 3; ++k) {
@@ -959,6 +961,10 @@ void assignScene(igd_device* d, const igd_scene* s)
                 tables[i]             = (uint8_t)order[i];
                 tables[kSortBins + i] = (uint8_t)cls(i);
             }
+            // on_miss (technique/pathtracer.art:141-168) sums over the infinite lights: without one a miss adds nothing and ends the
+            // path — the sort leaves such rays out of every run (the path tracer and its volumetric variant; the AO renderer has no on_miss)
+            if (s->infinite_light_count == 0)
+                tables[kSortBins + s->material_count] = (uint8_t)kSortDeadBin;
         }
         d->sort_tables.upload(tables.data(), tables.size());
         d->sort_state.alloc(kSortStateWords);
@@ -1648,6 +1654,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 sa.lt_cam.width = rs->width, sa.lt_cam.height = rs->height;
             }
             sa.ppm = ppm_args;
+            sa.skip_misses = d->skip_misses && d->dscene.infinite_light_count == 0 && (d->dscene.tech.type == IG_TECHNIQUE_PATH || d->dscene.tech.type == IG_TECHNIQUE_VOLPATH) ? 1 : 0;
             timed(2, on, [&] {
                 if (ppm)
                     launch_shade_ppm(sa, shade_grid, on);
@@ -2143,6 +2150,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
+        if (const char* e = std::getenv("IGD_SKIP_MISSES"))
+            d->skip_misses = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SHADE_CLASSES"))
             d->shade_by_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_WIDE"))

@@ -227,6 +227,7 @@ struct ShadeArgs {
     // the by-class launches (shade_kernel.h): the round's hits sorted by material and this launch's run of them {first, count}
     const uint32_t* sort_idx;
     const uint32_t* cls_range;
+    int32_t skip_misses; // the scene has no infinite light: a miss needs no shading (the kernels without the sort look at the hit first)
 };
 
 // Global counting sort of a round's hits by material (K3a-e, gpu_sort_primary, mapping_gpu.art:409-502), keys in class-major order
@@ -236,6 +237,7 @@ struct ShadeArgs {
 constexpr int kSortBins       = 256;
 constexpr int kSortStateWords = 3 * kSortBins + 8;
 constexpr int kSortClasses    = 4;
+constexpr int kSortDeadBin    = 255; // bin_class of a bin whose rays need no shading at all
 struct BinSortArgs {
     const float4* hit;
     const uint32_t* count;
@@ -245,7 +247,7 @@ struct BinSortArgs {
     uint32_t* sort_idx;      // out: ray indices, sorted
     uint32_t* state;
     const uint8_t* bin_order; // [material_count + 1]: the bins in class-major order
-    const uint8_t* bin_class; // [material_count + 1]: class of a bin (0 basic + misses, 1 principled, 2 coated, 3 blend)
+    const uint8_t* bin_class; // [material_count + 1]: class of a bin (0 basic + misses, 1 principled, 2 coated, 3 blend, kSortDeadBin)
 };
 
 struct TailArgs {

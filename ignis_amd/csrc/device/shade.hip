@@ -458,7 +458,14 @@ __global__ void __launch_bounds__(256) k_bin_count(const BinSortArgs a)
         const int ent      = (int)igm_bits(a.hit[i].x);
         const uint32_t key = ent < 0 ? M : (uint32_t)a.entity_material[ent];
         a.keys[i]          = (uint8_t)key;
-        atomicAdd(&s_hist[key], 1u);
+        // (as in k_bin_scatter: one LDS atomic for the lanes that share the first lane's key)
+        const unsigned long long lm   = __ballot(true);
+        const uint32_t lead_key       = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(lm));
+        const unsigned long long same = __ballot(key == lead_key);
+        if (key != lead_key)
+            atomicAdd(&s_hist[key], 1u);
+        else if ((tid & 63u) == (uint32_t)__builtin_ctzll(same))
+            atomicAdd(&s_hist[lead_key], (uint32_t)__popcll(same));
     }
     __syncthreads();
     if (s_hist[tid])
@@ -480,10 +487,12 @@ __global__ void __launch_bounds__(256) k_bin_scan(const BinSortArgs a)
         int last = -1;
         for (uint32_t k = 0; k < bins; ++k) {
             const int c = a.bin_class[a.bin_order[k]];
+            s_first[k]  = run;
+            if (c >= kSortClasses)
+                continue; // a bin no kernel shades (kSortDeadBin: the misses of a scene without environment lights): no slots
             if (c != last)
                 cls_first[c] = run, last = c;
             cls_count[c] += s_cnt[k];
-            s_first[k] = run;
             run += s_cnt[k];
         }
         for (int c = 0; c < kSortClasses; ++c) {
@@ -516,7 +525,28 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const BinSortArgs a)
         for (uint32_t k = 0; k < kBinItems; ++k) {
             const uint32_t i = w * kBinWindow + k * 256u + tid;
             key[k]           = i < n ? a.keys[i] : 0xFFFFFFFFu;
-            rank[k]          = i < n ? atomicAdd(&s_hist[key[k]], 1u) : 0u;
+            if (key[k] != 0xFFFFFFFFu && a.bin_class[key[k]] >= kSortClasses)
+                key[k] = 0xFFFFFFFFu; // nobody shades this ray
+            // rank inside the window's bin: the lanes that share the first lane's key (neighbouring rays hit the same material more often
+            // than not) take consecutive ranks from ONE LDS atomic, the others one each (64 same-address LDS atomics serialise)
+            {
+                const bool live           = key[k] != 0xFFFFFFFFu;
+                const unsigned long long lm = __ballot(live);
+                rank[k]                   = 0u;
+                if (lm) {
+                    const uint32_t lead_key = (uint32_t)__builtin_amdgcn_readlane((int)key[k], __builtin_ctzll(lm));
+                    const unsigned long long same = __ballot(live && key[k] == lead_key);
+                    const uint32_t lane_id  = tid & 63u;
+                    uint32_t base_rank      = 0;
+                    if (lane_id == (uint32_t)__builtin_ctzll(same))
+                        base_rank = atomicAdd(&s_hist[lead_key], (uint32_t)__popcll(same));
+                    base_rank = (uint32_t)__builtin_amdgcn_readlane((int)base_rank, __builtin_ctzll(same));
+                    if (live && key[k] == lead_key)
+                        rank[k] = base_rank + (uint32_t)__popcll(same & ((1ull << lane_id) - 1ull));
+                    else if (live)
+                        rank[k] = atomicAdd(&s_hist[key[k]], 1u);
+                }
+            }
         }
         __syncthreads();
         if (s_hist[tid])

@@ -25,6 +25,9 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #ifndef IG_SHADE_OCC_LEAN
 #define IG_SHADE_OCC_LEAN 4
 #endif
+#ifndef IG_SHADE_OCC_BASIC
+#define IG_SHADE_OCC_BASIC IG_SHADE_OCC_FULL // the by-class kernel of the basic models + misses (memory-bound: see profiles/r05_traffic_principled.json)
+#endif
 constexpr int kBounceBins = 16; // the bounce rays of a window leave grouped by (specular bounce, octant of the direction)
 
 // The full path-tracer variant by material class: one instantiation per group of BSDF models, each
@@ -43,7 +46,7 @@ constexpr uint32_t kClassAll        = ~0u;
 
 // LT: the light tracer's callbacks (lt_core.h) instead of the path tracer's; PPM: the photon mapper's light (1) or camera (2) pass (ppm_core.h)
 template <bool FULL, bool DEBUG_VIEWS = false, bool EXPR = false, bool LT = false, int PPM = 0, uint32_t TYPES = kClassAll>
-__global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC_FULL) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
+__global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kClassBasic ? IG_SHADE_OCC_BASIC : IG_SHADE_OCC_FULL)) : IG_SHADE_OCC_LEAN) k_shade(const ShadeArgs a)
 {
     constexpr bool BY_CLASS = TYPES != kClassAll;
     __shared__ uint32_t s_hist[kShadeThreads];
@@ -125,6 +128,12 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : IG_SHADE_OCC
         bool valid = j < n;
         if (BY_CLASS && valid)
             j = a.sort_idx[cls_first + j];
+        if (!BY_CLASS && !LT && PPM == 0 && !DEBUG_VIEWS && a.skip_misses) {
+            // a scene without environment lights: a miss adds nothing and ends its path (shade_vertex's on_miss sums over no light), so
+            // its columns are not even read — a look at the hit first, a wave whose rays all missed (camera rays past the geometry) goes on
+            if (valid)
+                valid = (int)igm_bits(a.in.hit[j].x) >= 0;
+        }
 
         clk.mark(0); // the sort
         PathVertexOut out;

@@ -141,19 +141,22 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
         TAIL_MARK(0); // refill
         const mask_t have_m = lanes_where(have);
         {
+            // the lanes whose ray the per-lane machine traverses: all of them, or — a handful of paths — those whose whole-wave traversal
+            // ran out of its stack (practically never: it holds kLdsStack * 64 - 64 entries; the per-lane machine then spills to HBM)
+            mask_t per_lane = have_m;
             if (!QNODE && lanes_in(have_m) <= (int)a.wide_lanes) {
                 // a handful of paths: their rays one after the other, each traversed by the whole wave
                 mask_t todo = have_m;
+                per_lane    = 0;
                 while (todo) {
                     const int l = __builtin_ctzll(todo);
                     todo &= todo - 1ull;
                     WideTraverser<STATS> w;
                     w.run(sc, s_stack, wide_bcast(in.org, l), wide_bcast(in.dir, l), wide_bcast(tmin, l), wide_bcast(tmax, l), (uint32_t)wide_bcast((int)flags, l));
-                    if (lane == l) {
+                    if (lane == l && !w.overflow) {
                         in.ent  = w.hit_ent;
                         in.prim = w.hit_prim;
                         in.t = w.tmax, in.u = w.hit_u, in.v = w.hit_v;
-                        overflow |= w.overflow;
                         if (STATS) {
                             c_nodes[0] += w.st_nodes;
                             c_tris[0] += w.st_tris;
@@ -161,16 +164,19 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                         }
                     }
                     region_end();
+                    if (wide_any(w.overflow)) // (the traversal's state is wave-uniform) what it counted does not count: the ray starts again below
+                        per_lane |= 1ull << l;
 #ifdef IG_TAIL_CLOCKS
                     tclk[5] += 1;
 #endif
                 }
                 TAIL_MARK(1);
-            } else {
+            }
+            if (per_lane) {
                 Traverser<false, STATS, kTailBlock, true, false, QNODE> tr;
                 tr.init_counters();
                 tr.attach_deep(deep_col, sc.deep_stride);
-                tr.begin(have_m, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
+                tr.begin(per_lane, sc, s_stack, tid, in.org, in.dir, tmin, tmax, flags);
                 while (tr.active()) {
                     tr.step(sc, s_stack, tid);
 #ifdef IG_TAIL_CLOCKS
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
 #endif
                 }
                 TAIL_MARK(1); // closest-hit traversal
-                if (have) {
+                if (igdev::in(per_lane)) {
                     in.ent  = tr.hit_ent;
                     in.prim = tr.hit_prim;
                     in.t = tr.tmax, in.u = tr.hit_u, in.v = tr.hit_v;

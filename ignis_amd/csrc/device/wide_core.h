@@ -7,7 +7,7 @@
 //                other in slot order on wave-uniform state — the reference's order (mapping_cpu.art:350-377)
 //   Tri4 packet: lane t runs the test of triangle t up to its verdict; the candidates are accepted in slot order against
 //                the distance the earlier ones left (mapping_cpu.art:379-410)
-//   entity run : lane k looks at leaf k of the run (runs are <= 2 leaves), the first one the ray enters is entered
+//   entity run : lane k looks at leaf k of the run (the builder keeps runs at <= 2 leaves by default, IGH_SCENE_MAX_LEAF / IGH_BVH_REFERENCE allow 8: the loop takes any length), the first one the ray enters is entered
 // Everything else — the stack (a linear array in the wave's LDS), the cull points, the level switch — is the per-lane
 // machine's logic (traverse_core.h settle()) on wave-uniform values, i.e. scalar branches. Same visit order, same
 // arithmetic per test, hence the same hit and the same node / triangle / leaf counts as Traverser<false, ...> (the GPU
