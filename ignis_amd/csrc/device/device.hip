@@ -36,7 +36,7 @@ int traverse_workgroups_per_cu();
 void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream, uint32_t classes);
-void launch_bin_sort(const BinSortArgs& args, int num_cus, hipStream_t stream);
+void launch_bin_sort(const BinSortArgs& args, int grid, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
@@ -431,6 +431,7 @@ struct igd_device {
             deep_primary = true;
     }
     int shadeGrid() const { return num_cus * shade_mult; }
+    int sortGrid() const { return num_cus * 8; } // workgroups (= chunks of the stream) of the sort by material (shade.hip k_bin_*)
 
     hipEvent_t event(size_t i)
     {
@@ -967,8 +968,9 @@ void assignScene(igd_device* d, const igd_scene* s)
                 tables[kSortBins + s->material_count] = (uint8_t)kSortDeadBin;
         }
         d->sort_tables.upload(tables.data(), tables.size());
-        d->sort_state.alloc(kSortStateWords);
-        HIP_CHECK(hipMemset(d->sort_state.ptr, 0, kSortStateWords * sizeof(uint32_t)));
+        const size_t sort_words = (size_t)kSortStateWords + (size_t)kSortBins * (size_t)d->sortGrid();
+        d->sort_state.alloc(sort_words);
+        HIP_CHECK(hipMemset(d->sort_state.ptr, 0, sort_words * sizeof(uint32_t)));
     }
     d->full_bsdfs |= s->sphere_node_count != 0; // surface elements of analytic spheres
     d->full_bsdfs |= s->technique.type == IG_TECHNIQUE_AO || s->technique.type == IG_TECHNIQUE_VOLPATH || s->technique.type == IG_TECHNIQUE_DEBUG;
@@ -1669,9 +1671,10 @@ void render(igd_device* d, const igd_render_settings* rs)
                         ba.keys            = d->sort_keys.ptr;
                         ba.sort_idx        = d->sort_idx.ptr;
                         ba.state           = d->sort_state.ptr;
+                        ba.wg_hist         = d->sort_state.ptr + kSortStateWords;
                         ba.bin_order       = d->sort_tables.ptr;
                         ba.bin_class       = d->sort_tables.ptr + kSortBins;
-                        launch_bin_sort(ba, d->num_cus, on);
+                        launch_bin_sort(ba, d->sortGrid(), on);
                         sa.sort_idx  = d->sort_idx.ptr;
                         sa.cls_range = d->sort_state.ptr;
                     }

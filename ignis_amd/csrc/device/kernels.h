@@ -232,8 +232,9 @@ struct ShadeArgs {
 
 // Global counting sort of a round's hits by material (K3a-e, gpu_sort_primary, mapping_gpu.art:409-502), keys in class-major order
 // so that each material class of the shading kernels is one run of the sorted index list. `state` (uint32 words):
-//   [0, 256) histogram by bin (bin = material id, material_count = miss)   [256, 512) first slot of a bin   [512, 768) scatter cursors
+//   [0, 256) size of a bin (bin = material id, material_count = miss)   [256, 512) first slot of a bin   [512, 768) unused
 //   [768, 776) per class {first, count}
+// `wg_hist`: [bin][workgroup] the bin's rays inside each workgroup's chunk of the stream, then their exclusive prefix over the workgroups
 constexpr int kSortBins       = 256;
 constexpr int kSortStateWords = 3 * kSortBins + 8;
 constexpr int kSortClasses    = 4;
@@ -246,6 +247,7 @@ struct BinSortArgs {
     uint8_t* keys;           // one per ray
     uint32_t* sort_idx;      // out: ray indices, sorted
     uint32_t* state;
+    uint32_t* wg_hist;       // kSortBins x grid words
     const uint8_t* bin_order; // [material_count + 1]: the bins in class-major order
     const uint8_t* bin_class; // [material_count + 1]: class of a bin (0 basic + misses, 1 principled, 2 coated, 3 blend, kSortDeadBin)
 };

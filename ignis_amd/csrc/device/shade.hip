@@ -443,22 +443,32 @@ template __global__ void k_shade<true, false, false, false, 0, kClassCoated>(con
 template __global__ void k_shade<true, false, false, false, 0, kClassBlend>(const ShadeArgs);
 
 // ---------------------------------------------------------------- k_bin_*: the round's hits sorted by material
+//
+// A counting sort in the shape of one radix-sort digit pass, without a single global atomic (round 5's first version reserved
+// a window's share of a bin with one atomic per window and bin: 160 K same-address atomics per 66 M hits bounded it at 0.38 ms):
+// workgroup c of G owns the contiguous chunk c of the hits. k_bin_count: the chunk's histogram -> wg_hist[bin][c] (and the key byte
+// of every ray); k_bin_prefix: per bin, the exclusive prefix over the G chunks and the bin's total; k_bin_scan: the bins' first
+// slots in class-major order and the classes' runs; k_bin_scatter: the chunk's rays into their slots from LDS cursors that start at
+// first[bin] + prefix[bin][c]. Inside a bin the rays of a chunk stay together and chunks follow each other in stream order: the
+// shading kernel's gathers walk the stream forwards.
+IG_DEV uint32_t bin_chunk_len(uint32_t n, uint32_t grid) { return (((n + grid - 1u) / grid) + 255u) & ~255u; }
 
-// Pass 1: a ray's bin (its hit's material; material_count for a miss) into the key column, the bins' sizes into the global histogram
-// (an LDS histogram per workgroup, flushed once: 256 global atomics per workgroup).
 __global__ void __launch_bounds__(256) k_bin_count(const BinSortArgs a)
 {
     __shared__ uint32_t s_hist[kSortBins];
     const uint32_t tid = threadIdx.x;
     s_hist[tid]        = 0;
     __syncthreads();
-    const uint32_t n = *a.count;
-    const uint32_t M = a.material_count;
-    for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+    const uint32_t n   = *a.count;
+    const uint32_t M   = a.material_count;
+    const uint32_t len = bin_chunk_len(n, gridDim.x);
+    const uint32_t lo = blockIdx.x * len, hi = lo + len < n ? lo + len : n;
+    for (uint32_t i = lo + tid; i < hi; i += 256u) {
         const int ent      = (int)igm_bits(a.hit[i].x);
         const uint32_t key = ent < 0 ? M : (uint32_t)a.entity_material[ent];
         a.keys[i]          = (uint8_t)key;
-        // (as in k_bin_scatter: one LDS atomic for the lanes that share the first lane's key)
+        // one LDS atomic for the lanes that share the first lane's key (neighbouring rays hit the same material more often than not;
+        // 64 same-address LDS atomics serialise), one each for the others
         const unsigned long long lm   = __ballot(true);
         const uint32_t lead_key       = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(lm));
         const unsigned long long same = __ballot(key == lead_key);
@@ -468,12 +478,45 @@ __global__ void __launch_bounds__(256) k_bin_count(const BinSortArgs a)
             atomicAdd(&s_hist[lead_key], (uint32_t)__popcll(same));
     }
     __syncthreads();
-    if (s_hist[tid])
-        atomicAdd(&a.state[tid], s_hist[tid]);
+    if (tid <= M)
+        a.wg_hist[(size_t)tid * gridDim.x + blockIdx.x] = s_hist[tid];
 }
 
-// Pass 2, one workgroup: the bins' first slots in class-major order (bin_order) and each class's {first, count}; clears the histogram
-// and the cursors for the next use.
+// one workgroup per bin: wg_hist[bin][0 .. G) -> its exclusive prefix, the total -> state[bin]
+__global__ void __launch_bounds__(256) k_bin_prefix(const BinSortArgs a, uint32_t grid)
+{
+    __shared__ uint32_t s_part[256];
+    const uint32_t tid = threadIdx.x, bin = blockIdx.x;
+    uint32_t* row      = a.wg_hist + (size_t)bin * grid;
+    const uint32_t per = (grid + 255u) / 256u; // entries per thread, consecutive
+    uint32_t sum       = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t c = tid * per + k;
+        sum += c < grid ? row[c] : 0u;
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele over the 256 partial sums
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum; // exclusive
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t c = tid * per + k;
+        if (c < grid) {
+            const uint32_t v = row[c];
+            row[c]           = run;
+            run += v;
+        }
+    }
+    if (tid == 255u)
+        a.state[bin] = s_part[255];
+}
+
+// one workgroup: the bins' first slots in class-major order (bin_order) and each class's {first, count}
 __global__ void __launch_bounds__(256) k_bin_scan(const BinSortArgs a)
 {
     __shared__ uint32_t s_cnt[kSortBins], s_first[kSortBins];
@@ -503,68 +546,48 @@ __global__ void __launch_bounds__(256) k_bin_scan(const BinSortArgs a)
     __syncthreads();
     if (tid < bins)
         a.state[kSortBins + bin] = s_first[tid];
-    a.state[tid]                 = 0;
-    a.state[2 * kSortBins + tid] = 0;
 }
 
-// Pass 3: windows of kBinWindow rays; a window reserves its share of every bin it has rays for with one atomic per bin and
-// writes the ray indices there (inside a bin, rays of a window stay together: the shading kernel's gathers touch few lines).
-constexpr uint32_t kBinItems  = 8;
-constexpr uint32_t kBinWindow = 256 * kBinItems;
 __global__ void __launch_bounds__(256) k_bin_scatter(const BinSortArgs a)
 {
-    __shared__ uint32_t s_hist[kSortBins], s_base[kSortBins];
-    const uint32_t tid     = threadIdx.x;
-    const uint32_t n       = *a.count;
-    const uint32_t windows = (n + kBinWindow - 1) / kBinWindow;
-    for (uint32_t w = blockIdx.x; w < windows; w += gridDim.x) {
-        s_hist[tid] = 0;
-        __syncthreads();
-        uint32_t key[kBinItems], rank[kBinItems];
-#pragma unroll
-        for (uint32_t k = 0; k < kBinItems; ++k) {
-            const uint32_t i = w * kBinWindow + k * 256u + tid;
-            key[k]           = i < n ? a.keys[i] : 0xFFFFFFFFu;
-            if (key[k] != 0xFFFFFFFFu && a.bin_class[key[k]] >= kSortClasses)
-                key[k] = 0xFFFFFFFFu; // nobody shades this ray
-            // rank inside the window's bin: the lanes that share the first lane's key (neighbouring rays hit the same material more often
-            // than not) take consecutive ranks from ONE LDS atomic, the others one each (64 same-address LDS atomics serialise)
-            {
-                const bool live           = key[k] != 0xFFFFFFFFu;
-                const unsigned long long lm = __ballot(live);
-                rank[k]                   = 0u;
-                if (lm) {
-                    const uint32_t lead_key = (uint32_t)__builtin_amdgcn_readlane((int)key[k], __builtin_ctzll(lm));
-                    const unsigned long long same = __ballot(live && key[k] == lead_key);
-                    const uint32_t lane_id  = tid & 63u;
-                    uint32_t base_rank      = 0;
-                    if (lane_id == (uint32_t)__builtin_ctzll(same))
-                        base_rank = atomicAdd(&s_hist[lead_key], (uint32_t)__popcll(same));
-                    base_rank = (uint32_t)__builtin_amdgcn_readlane((int)base_rank, __builtin_ctzll(same));
-                    if (live && key[k] == lead_key)
-                        rank[k] = base_rank + (uint32_t)__popcll(same & ((1ull << lane_id) - 1ull));
-                    else if (live)
-                        rank[k] = atomicAdd(&s_hist[key[k]], 1u);
-                }
-            }
+    __shared__ uint32_t s_cursor[kSortBins];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n   = *a.count;
+    const uint32_t M   = a.material_count;
+    s_cursor[tid]      = tid <= M ? a.state[kSortBins + tid] + a.wg_hist[(size_t)tid * gridDim.x + blockIdx.x] : 0u;
+    const bool dead    = tid <= M && a.bin_class[tid] >= kSortClasses;
+    __shared__ uint8_t s_dead[kSortBins];
+    s_dead[tid] = dead ? 1 : 0;
+    __syncthreads();
+    const uint32_t len = bin_chunk_len(n, gridDim.x);
+    const uint32_t lo = blockIdx.x * len, hi = lo + len < n ? lo + len : n;
+    const uint32_t lane_id = tid & 63u;
+    for (uint32_t i = lo + tid; i < hi; i += 256u) {
+        const uint32_t key = a.keys[i];
+        const bool live    = !s_dead[key]; // (a dead bin's rays are nobody's: no slot)
+        const unsigned long long lm = __ballot(live);
+        if (lm) {
+            // the lanes that share the first live lane's key take consecutive slots from ONE LDS atomic, the others one each
+            const uint32_t lead_key       = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(lm));
+            const unsigned long long same = __ballot(live && key == lead_key);
+            uint32_t base                 = 0;
+            if (lane_id == (uint32_t)__builtin_ctzll(same))
+                base = atomicAdd(&s_cursor[lead_key], (uint32_t)__popcll(same));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(same));
+            if (live && key == lead_key)
+                a.sort_idx[base + (uint32_t)__popcll(same & ((1ull << lane_id) - 1ull))] = i;
+            else if (live)
+                a.sort_idx[atomicAdd(&s_cursor[key], 1u)] = i;
         }
-        __syncthreads();
-        if (s_hist[tid])
-            s_base[tid] = a.state[kSortBins + tid] + atomicAdd(&a.state[2 * kSortBins + tid], s_hist[tid]);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < kBinItems; ++k)
-            if (key[k] != 0xFFFFFFFFu)
-                a.sort_idx[s_base[key[k]] + rank[k]] = w * kBinWindow + k * 256u + tid;
-        __syncthreads();
     }
 }
 
-void launch_bin_sort(const BinSortArgs& args, int num_cus, hipStream_t stream)
+void launch_bin_sort(const BinSortArgs& args, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)num_cus * 8u), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)grid), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_bin_prefix, dim3(args.material_count + 1u), dim3(256), 0, stream, args, (uint32_t)grid);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, stream, args);
-    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)num_cus * 8u), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)grid), dim3(256), 0, stream, args);
 }
 
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream)
