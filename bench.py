@@ -77,10 +77,24 @@ def stream_bytes(n_rays):
     return 60 * n_rays
 
 
-def geometry_bytes(nodes, tris, leaves):
-    """SURVEY.md 8(d) geometry term with this backend's layouts: 256 B per Node8 fetched + 52 B per triangle tested (a 208 B
-    Tri4 packet holds 4) + 96 B per EntityLeaf1 tested."""
-    return 256 * nodes + 52 * tris + 96 * leaves
+def geometry_bytes(nodes, tris, leaves, node_bytes=256):
+    """SURVEY.md 8(d) geometry term with this backend's layouts: 256 B per Node8 fetched (128 B when the scene runs on the quantised
+    node records, igd_node_bytes) + 52 B per triangle tested (a 208 B Tri4 packet holds 4) + 96 B per EntityLeaf1 tested."""
+    return node_bytes * nodes + 52 * tris + 96 * leaves
+
+
+def _primbvh_nodes(scene):
+    """Node8 records of all shape BVHs: the "trimesh_primbvh" fix table is {u32 nodes, u32 packets, pad, pad} Node8[] Tri4[] per shape."""
+    import ctypes as C
+    s = scene.scene
+    seen, total = set(), 0
+    for i in range(s.scene_leaf_count):
+        off = (((int(s.scene_leaves[i].user[1]) & 0xFFFFFFFF) << 32) | (int(s.scene_leaves[i].user[0]) & 0xFFFFFFFF)) * 4
+        if off in seen or off + 16 > s.primbvh_size:
+            continue
+        seen.add(off)
+        total += int(C.cast(C.c_void_p(C.addressof(s.primbvh.contents) + off), C.POINTER(C.c_uint32))[0])
+    return total
 
 
 def shade_stream_bytes(n_in, n_bounce, n_shadow):
@@ -126,6 +140,7 @@ def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_
     cdev.resize(W, H)
     run(cdev, steps)
     cs = cdev.stats()
+    node_bytes = cdev.node_bytes()
     cdev.close()
     rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
     n_primary = cs["camera_rays"] + cs["bounce_rays"]
@@ -133,11 +148,11 @@ def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_
     geom_resident = int(scene.scene.primbvh_size) + int(scene.scene.scene_node_count) * 256 + int(scene.scene.scene_leaf_count) * 96
     per_launch = {
         "k_traverse<closest>": (st["ms_traverse_primary"] / rounds,
-                                stream_bytes(n_primary) / rounds + min(geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"]) / rounds, geom_resident)),
+                                stream_bytes(n_primary) / rounds + min(geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"], node_bytes) / rounds, geom_resident)),
         "k_shade": (st["ms_shade"] / rounds, shade_stream_bytes(n_primary, cs["bounce_rays"], cs["shadow_rays"]) / rounds),
         "k_traverse<any>": (st["ms_traverse_secondary"] / max(1, st["traverse_secondary_launches"]),
                             shadow_stream_bytes(cs["shadow_rays"], cs["unoccluded"]) / max(1, st["traverse_secondary_launches"])
-                            + min(geometry_bytes(cs["nodes_secondary"], cs["tris_secondary"], cs["leaves_secondary"]) / max(1, st["traverse_secondary_launches"]), geom_resident)),
+                            + min(geometry_bytes(cs["nodes_secondary"], cs["tris_secondary"], cs["leaves_secondary"], node_bytes) / max(1, st["traverse_secondary_launches"]), geom_resident)),
     }
     kernel = max(per_launch, key=lambda k: per_launch[k][0])
     ms, alg = per_launch[kernel]
@@ -350,15 +365,18 @@ def main():
         cdev.resize(W, H)
         run(cdev, replay)
         cs = cdev.stats()
+        node_bytes = cdev.node_bytes()
         cdev.close()
         n_primary = cs["camera_rays"] + cs["bounce_rays"]
         c_launches = max(1, cs["traverse_primary_launches"])
         s_per_launch = stream_bytes(n_primary) / c_launches
-        g_per_launch = geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"]) / c_launches
+        g_per_launch = geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"], node_bytes) / c_launches
         # Each byte of the geometry has to come from HBM at least once per launch; what the rays re-visit beyond that is
         # served by L1 / L2 / Infinity Cache whenever the BVH fits them. The HBM-side algorithmic bytes are therefore
         # the streams + min(geometry visited, geometry resident); the 8(d) figure incl. every re-visit is kept separately.
         geom_resident = int(scene.scene.primbvh_size) + int(scene.scene.scene_node_count) * 256 + int(scene.scene.scene_leaf_count) * 96
+        if node_bytes == 128:  # the kernels read the 128-byte records, not the Node8 tables: half of the node bytes are resident for them
+            geom_resident -= (_primbvh_nodes(scene) + int(scene.scene.scene_node_count)) * 128
         hbm_alg = s_per_launch + min(g_per_launch, geom_resident)
         achieved = hbm_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         incl_cache = (s_per_launch + g_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -403,6 +421,7 @@ def main():
                             "(SURVEY 8d's A), most of which L1 / L2 serve when the BVH is small; `traffic` = measured HBM-side bytes per launch",
                     "incl_cache_hits": {"achieved": round(incl_cache, 2), "unit": "GB/s", "bytes_per_launch": int(s_per_launch + g_per_launch)},
                     "stream_bytes_per_launch": int(s_per_launch), "geometry_resident_bytes": geom_resident,
+                    "node_bytes": node_bytes,
                     "valu": valu, "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(hbm_alg)}
 

@@ -18,17 +18,32 @@ from . import device as _device
 ID_BYTES = 128
 
 
+_MAGIC = b"IGD-RCCL-ID\x01"
+_PORT_SPAN = 8  # rank 0 listens on the first free port of MASTER_PORT + 1 .. + 8; the others try them in turn
+
+
 def exchange_id(rank, world, make_id, addr=None, port=None, timeout=600.0):
-    """Rank 0 calls make_id() -> bytes and serves them to the world - 1 others; returns the id on every rank."""
+    """Rank 0 calls make_id() -> bytes and serves them to the world - 1 others; returns the id on every rank. `port` is the first
+    candidate (default MASTER_PORT + 1: MASTER_PORT itself belongs to the launcher's store); a peer is recognised by a magic word,
+    so a port that something else listens on is skipped."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29511")) + 1)
     if world == 1:
         return make_id()
     if rank == 0:
         blob = make_id()
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("", port))
+        srv = None
+        for p in range(port, port + _PORT_SPAN):
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind(("", p))
+                break
+            except OSError:
+                srv.close()
+                srv = None
+        if srv is None:
+            raise OSError(f"rank 0: no free port in {port} .. {port + _PORT_SPAN - 1} for the RCCL id exchange")
         srv.listen(world)
         srv.settimeout(timeout)
         served = set()
@@ -36,30 +51,33 @@ def exchange_id(rank, world, make_id, addr=None, port=None, timeout=600.0):
             while len(served) < world - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    conn.settimeout(timeout)
-                    hello = _recv_exact(conn, 8)
-                    peer, peer_world = struct.unpack("<ii", hello)
-                    if peer_world != world or not (0 < peer < world):
-                        conn.sendall(b"\x00" * ID_BYTES)  # (a stray connection: it gets no id)
+                    try:
+                        conn.settimeout(10.0)
+                        hello = _recv_exact(conn, len(_MAGIC) + 8)
+                        peer, peer_world = struct.unpack("<ii", hello[len(_MAGIC):])
+                        if hello[:len(_MAGIC)] != _MAGIC or peer_world != world or not (0 < peer < world):
+                            continue  # (a stray connection: it gets nothing)
+                        conn.sendall(_MAGIC + blob)
+                        served.add(peer)
+                    except (OSError, ConnectionError, struct.error):
                         continue
-                    conn.sendall(blob)
-                    served.add(peer)
         finally:
             srv.close()
         return blob
     deadline = time.monotonic() + timeout
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as conn:
-                conn.settimeout(timeout)
-                conn.sendall(struct.pack("<ii", rank, world))
-                blob = _recv_exact(conn, ID_BYTES)
-            if blob != b"\x00" * ID_BYTES:
-                return blob
-        except OSError:
-            pass
+        for p in range(port, port + _PORT_SPAN):
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(_MAGIC + struct.pack("<ii", rank, world))
+                    reply = _recv_exact(conn, len(_MAGIC) + ID_BYTES)
+                if reply[:len(_MAGIC)] == _MAGIC:
+                    return reply[len(_MAGIC):]
+            except (OSError, ConnectionError):
+                pass
         if time.monotonic() > deadline:
-            raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 at {addr}:{port}")
+            raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 at {addr}:{port}..{port + _PORT_SPAN - 1}")
         time.sleep(0.05)
 
 

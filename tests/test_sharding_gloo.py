@@ -212,12 +212,20 @@ def _id_rank(rank, world, port, out_dir):
         f.write(blob)
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_rccl_id_rendezvous_without_torch(tmp_path, world):
+@pytest.mark.parametrize("world,first_port_taken", [(1, False), (3, False), (3, True)])
+def test_rccl_id_rendezvous_without_torch(tmp_path, world, first_port_taken):
     """The launcher's half of the native RCCL path (ignis_amd/comm.py): rank 0's 128-byte id reaches every rank over one TCP
-    exchange, whatever order the ranks come up in (no torch.distributed, no store)."""
+    exchange, whatever order the ranks come up in (no torch.distributed, no store) — also when something else already listens on the
+    first candidate port (rank 0 moves to the next, the others recognise it by the magic word)."""
     import multiprocessing as mp
+    import socket
     port = _free_port()
+    squatter = None
+    if first_port_taken:
+        squatter = socket.socket()
+        squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        squatter.bind(("127.0.0.1", port))
+        squatter.listen(8)
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_id_rank, args=(r, world, port, str(tmp_path))) for r in reversed(range(world))]  # (rank 0 last)
     for p in procs:
@@ -225,5 +233,7 @@ def test_rccl_id_rendezvous_without_torch(tmp_path, world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    if squatter is not None:
+        squatter.close()
     for r in range(world):
         assert (tmp_path / f"id{r}.bin").read_bytes() == bytes(range(128))
