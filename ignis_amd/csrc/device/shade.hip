@@ -2,13 +2,15 @@
 //
 // Replaces the reference stages K1 (gpu_generate_rays, src/artic/driver/mapping_gpu.art:616-669),
 // K3a-e (gpu_sort_primary, :409-502), K4 (gpu_hit_shade, :123-214), K5 (gpu_miss_shade, :237-274)
-// and K9 (gpu_compact_primary, :686-711) with three kernels:
+// and K9 (gpu_compact_primary, :686-711) with:
 //   k_generate : one thread per camera sample, writes the SoA primary stream;
-//   k_shade    : workgroup-local counting sort of 256 consecutive hits by material (LDS histogram +
-//                scan) so each wave shades one BSDF type, then surface reconstruction, emission/MIS,
-//                NEE shadow-ray emission, BSDF sampling + Russian roulette; survivors are appended
-//                to the OTHER primary stream with one wave-aggregated atomic (sort, M per-material
-//                launches, host scan and compaction of the reference collapse into this kernel);
+//   k_bin_*    : (scenes with the full BSDF library) the round's hits sorted by material, class-major, as one counting-sort pass
+//                without global atomics; each material class of the shading kernels is then one run of the sorted index list;
+//   k_shade    : surface reconstruction, emission/MIS, NEE shadow-ray emission, BSDF sampling + Russian roulette; survivors are
+//                appended to the OTHER primary stream with one atomic per 256-ray window for both queues (M per-material
+//                launches, host scan and compaction of the reference collapse into this kernel). The lean variant takes the hits
+//                in stream order, the by-class variants their sorted runs, the one-for-all variant (IGD_SHADE_CLASSES=0, light
+//                tracer, debug views, expressions) sorts 256 consecutive hits by material inside the workgroup;
 //   k_resolve  : fixed-order sum of the per-sample accumulators into the framebuffer, so a given
 //                seed reproduces the image bit for bit (the reference GPU path uses float atomics).
 // Shading arithmetic follows src/artic/{core,bsdf,light,technique,camera} expression by expression
