@@ -231,6 +231,10 @@ struct igd_device {
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
     bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
+    // > 0: the closest-hit launches of a render round write their hits as one packed 16-byte row with that many prim bits (kernels.h
+    // pack_hit; igd_assign_scene: the entity count and the largest mesh fit 32 bits together, no analytic spheres). IGD_HIT_PACK=0: never
+    uint32_t hit_pack_bits = 0;
+    bool hit_pack_allowed  = true;
     bool skip_misses       = true; // IGD_SKIP_MISSES=0: k_shade reads a miss's columns although the scene has no environment light (ShadeArgs::skip_misses)
     int node_repeat = -1; // IGD_NODE_REPEAT: DevScene::node_repeat (-1: by the size of the BVH)
     // IGD_NODE_FORMAT: -1 auto (the 128-byte quantised node records when the builder left every node on its 8-bit grid — it does from
@@ -940,6 +944,21 @@ void assignScene(igd_device* d, const igd_scene* s)
     for (uint32_t i = 0; i < s->material_count; ++i)
         d->full_bsdfs |= (s->materials[i].flags & (IG_MAT_DOUBLESIDED | IG_MAT_EXPR_COLOR | IG_MAT_EXPR_NORMAL | IG_MAT_EXPR_WEIGHT | IG_MAT_EXPR_NUMBERS)) != 0 || (s->materials[i].bsdf_type == IG_BSDF_DIFFUSE && s->materials[i].p[3] > 1.1920928955e-07f) || s->materials[i].bsdf_type == IG_BSDF_TRANSPARENT || s->materials[i].bsdf_type == IG_BSDF_PHONG || s->materials[i].bsdf_type == IG_BSDF_RAD_BRTD || s->materials[i].bsdf_type == IG_BSDF_RAD_ROOS || s->materials[i].bsdf_type == IG_BSDF_PRINCIPLED || s->materials[i].bsdf_type == IG_BSDF_PLASTIC || s->materials[i].bsdf_type == IG_BSDF_ROUGH_DIELECTRIC || s->materials[i].bsdf_type == IG_BSDF_BLEND
                          || (s->materials[i].bsdf_type == IG_BSDF_DIELECTRIC && (s->materials[i].flags & IG_MAT_THIN));
+    {
+        // one-row hits (pack_hit): entity ids in the upper bits (the all-ones word is the miss), prim ids below
+        uint32_t eb = 1;
+        while (eb < 32 && ((uint64_t)1 << eb) - 1 < (uint64_t)s->entity_count)
+            ++eb;
+        uint64_t max_faces = 0;
+        for (uint32_t i = 0; i < s->shape_count; ++i)
+            if (s->shape_lookups[i].type_id == IG_SHAPE_TRIMESH && s->shape_lookups[i].offset + 4 <= s->shape_data_size) {
+                uint32_t faces;
+                std::memcpy(&faces, s->shape_data + s->shape_lookups[i].offset, 4);
+                max_faces = std::max<uint64_t>(max_faces, faces);
+            }
+        const uint32_t pb = 32 - eb;
+        d->hit_pack_bits  = (d->hit_pack_allowed && eb < 31 && s->sphere_node_count == 0 && max_faces <= ((uint64_t)1 << pb)) ? pb : 0u;
+    }
     d->shade_classes = 1u;
     {
         // the bins of the by-class kernels' sort (one per material + the misses') in class-major order, models of a class together
@@ -1625,6 +1644,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.index_count  = &qs->deep_count;
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
+            ta.hit_pack = d->hit_pack_bits;
             ta.sphere_work_counter = &qs->work_counter[4];
             timed(1, on, [&] { launchTraverse(d, ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid, d->deep_primary); });
 
@@ -1656,6 +1676,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 sa.lt_cam.width = rs->width, sa.lt_cam.height = rs->height;
             }
             sa.ppm = ppm_args;
+            sa.hit_pack = d->hit_pack_bits;
             sa.skip_misses = d->skip_misses && d->dscene.infinite_light_count == 0 && (d->dscene.tech.type == IG_TECHNIQUE_PATH || d->dscene.tech.type == IG_TECHNIQUE_VOLPATH) ? 1 : 0;
             timed(2, on, [&] {
                 if (ppm)
@@ -1665,6 +1686,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                         // K3: the round's hits sorted by material, so that each class kernel shades its own dense run
                         BinSortArgs ba{};
                         ba.hit             = in.hit;
+                        ba.hit_pack        = d->hit_pack_bits;
                         ba.count           = &qs->q[in_slot].primary;
                         ba.entity_material = d->dscene.entity_material;
                         ba.material_count  = d->dscene.material_count;
@@ -2153,6 +2175,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
+        if (const char* e = std::getenv("IGD_HIT_PACK"))
+            d->hit_pack_allowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SKIP_MISSES"))
             d->skip_misses = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SHADE_CLASSES"))

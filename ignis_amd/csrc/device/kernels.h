@@ -119,6 +119,22 @@ struct QueueState {
     uint32_t tail_pass_in[24]; // paths each pass of the chunk's tail started with (tail.hip): the host sizes the next chunk's passes by them
 };
 
+// The hit of a closest-hit launch in ONE 16-byte row (round 5): x = (entity << bits) | prim (all ones: a miss), y = t, z = u, w = v —
+// when the scene's entity count and largest mesh fit 32 bits together (igd_assign_scene decides; `bits` = 0: the two-column form
+// hit = (entity, prim, t, u), hit_v = v). The 4-byte hit_v store of every finished ray costs the traversal kernel 3 - 4 % (a lane's
+// store is a cache line of its own), the load a little of the shading kernel's.
+__device__ __forceinline__ float4 pack_hit(uint32_t bits, int ent, int prim, float t, float u, float v)
+{
+    const uint32_t w = prim < 0 ? 0xFFFFFFFFu : (((uint32_t)ent << bits) | (uint32_t)prim);
+    return make_float4(__uint_as_float(w), t, u, v);
+}
+__device__ __forceinline__ void unpack_hit_ids(uint32_t bits, uint32_t w, int& ent, int& prim)
+{
+    const bool miss = w == 0xFFFFFFFFu;
+    ent  = miss ? -1 : (int)(w >> bits);
+    prim = miss ? -1 : (int)(w & ((1u << bits) - 1u));
+}
+
 struct TraverseArgs {
     DevScene scene;
     // input rays: rayA = (org, tmin), rayB = (dir, tmax); meta == nullptr -> uniform_flags
@@ -136,6 +152,7 @@ struct TraverseArgs {
     // outputs: hit = (ent_id, prim_id, t, u), hit_v = v. Any-hit launches may leave them null.
     float4* hit;
     float* hit_v;
+    uint32_t hit_pack; // closest hit: > 0: the packed one-row form with that many prim bits (pack_hit), hit_v is not written
     // any-hit epilogue (shadow rays): unoccluded rays add col.rgb into accum[id - id_base], id = bits(col.w)
     const float4* col;
     float4* accum;
@@ -227,6 +244,7 @@ struct ShadeArgs {
     // the by-class launches (shade_kernel.h): the round's hits sorted by material and this launch's run of them {first, count}
     const uint32_t* sort_idx;
     const uint32_t* cls_range;
+    uint32_t hit_pack; // the `in` stream's hits are packed rows (pack_hit) with that many prim bits; 0: hit + hit_v
     int32_t skip_misses; // the scene has no infinite light: a miss needs no shading (the kernels without the sort look at the hit first)
 };
 
@@ -241,6 +259,7 @@ constexpr int kSortClasses    = 4;
 constexpr int kSortDeadBin    = 255; // bin_class of a bin whose rays need no shading at all
 struct BinSortArgs {
     const float4* hit;
+    uint32_t hit_pack;
     const uint32_t* count;
     const int32_t* entity_material;
     uint32_t material_count;

@@ -466,7 +466,9 @@ __global__ void __launch_bounds__(256) k_bin_count(const BinSortArgs a)
     const uint32_t len = bin_chunk_len(n, gridDim.x);
     const uint32_t lo = blockIdx.x * len, hi = lo + len < n ? lo + len : n;
     for (uint32_t i = lo + tid; i < hi; i += 256u) {
-        const int ent      = (int)igm_bits(a.hit[i].x);
+        int ent = (int)igm_bits(a.hit[i].x), prim_;
+        if (a.hit_pack)
+            unpack_hit_ids(a.hit_pack, igm_bits(a.hit[i].x), ent, prim_);
         const uint32_t key = ent < 0 ? M : (uint32_t)a.entity_material[ent];
         a.keys[i]          = (uint8_t)key;
         // one LDS atomic for the lanes that share the first lane's key (neighbouring rays hit the same material more often than not;

@@ -94,8 +94,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             const uint32_t i = base + tid;
             int key          = M + 1;
             if (i < n) {
-                const int ent = (int)igm_bits(a.in.hit[i].x);
-                key           = ent < 0 ? M : sc.entity_material[ent];
+                int ent = (int)igm_bits(a.in.hit[i].x), prim_;
+                if (a.hit_pack)
+                    unpack_hit_ids(a.hit_pack, igm_bits(a.in.hit[i].x), ent, prim_);
+                key = ent < 0 ? M : sc.entity_material[ent];
             }
             s_hist[tid] = 0;
             __syncthreads();
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             // a scene without environment lights: a miss adds nothing and ends its path (shade_vertex's on_miss sums over no light), so
             // its columns are not even read — a look at the hit first, a wave whose rays all missed (camera rays past the geometry) goes on
             if (valid)
-                valid = (int)igm_bits(a.in.hit[j].x) >= 0;
+                valid = a.hit_pack ? igm_bits(a.in.hit[j].x) != 0xFFFFFFFFu : (int)igm_bits(a.in.hit[j].x) >= 0;
         }
 
         clk.mark(0); // the sort
@@ -155,7 +157,14 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             in.eta     = a.in.eta[j];
             in.ent     = in_ent_for_bin = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
-            in.t = hit.z, in.u = hit.w, in.v = a.in.hit_v[j];
+            in.t = hit.z, in.u = hit.w;
+            if (a.hit_pack) {
+                unpack_hit_ids(a.hit_pack, igm_bits(hit.x), in.ent, in.prim);
+                in_ent_for_bin = in.ent;
+                in.t = hit.y, in.u = hit.z, in.v = hit.w;
+            } else {
+                in.v = a.in.hit_v[j];
+            }
             clk.mark(1); // the ray's columns
             if constexpr (PPM != 0)
                 shade_vertex_ppm<PPM == 1>(sc, fr, a.ppm, in, out);

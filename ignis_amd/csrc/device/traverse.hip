@@ -179,8 +179,12 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                         }
                     }
                 } else {
-                    a.hit[ray_idx]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
-                    a.hit_v[ray_idx] = tr.hit_v;
+                    if (a.hit_pack) {
+                        a.hit[ray_idx] = pack_hit(a.hit_pack, tr.hit_ent, tr.hit_prim, tr.tmax, tr.hit_u, tr.hit_v);
+                    } else {
+                        a.hit[ray_idx]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
+                        a.hit_v[ray_idx] = tr.hit_v;
+                    }
                 }
             }
             region_end();
