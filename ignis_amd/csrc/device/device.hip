@@ -1378,6 +1378,10 @@ void render(igd_device* d, const igd_render_settings* rs)
                 TraverseArgs ta{};
                 ta.scene = d->dscene;
                 ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
+                if (round > 0) { // a stream k_shade wrote: bounce rays all (its meta.y carries eta, kernels.h kStream*)
+                    ta.meta          = nullptr;
+                    ta.uniform_flags = IG_RAY_FLAG_BOUNCE;
+                }
                 ta.count        = &lq->q[lslot].primary;
                 ta.work_counter = &lq->work_counter[0];
                 ta.index_list   = d->deep_rays.ptr;
@@ -1399,6 +1403,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 sa.frame     = lframe;
                 sa.inv_spi   = 1;
                 sa.ppm       = ppm_args;
+                sa.in_kind   = round > 0 ? kStreamShaded : kStreamLight;
                 launch_shade_ppm(sa, d->shadeGrid(), st);
                 launch_round_end(lq, lslot, st);
                 lslot ^= 1;
@@ -1618,6 +1623,7 @@ void render(igd_device* d, const igd_render_settings* rs)
         const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1), wire_footprint };
         uint32_t live          = n;
         bool run_tail          = false;
+        int tail_from_round    = 0; // rounds submitted before the hand-over to the tail: 0 = its input is what k_generate wrote
         // One bounce round on stream `on` over the given stream buffers: closest-hit traversal (K2) -> sort +
         // shade + compact (K3, K4, K5, K9) -> any-hit traversal of the shadow rays + splat (K6).
         struct RoundBufs {
@@ -1677,6 +1683,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             }
             sa.ppm = ppm_args;
             sa.hit_pack = d->hit_pack_bits;
+            sa.in_kind  = bounce_rays_only ? kStreamShaded : (light_tracer ? kStreamLight : kStreamCamera);
             sa.skip_misses = d->skip_misses && d->dscene.infinite_light_count == 0 && (d->dscene.tech.type == IG_TECHNIQUE_PATH || d->dscene.tech.type == IG_TECHNIQUE_VOLPATH) ? 1 : 0;
             timed(2, on, [&] {
                 if (ppm)
@@ -1751,8 +1758,9 @@ void render(igd_device* d, const igd_render_settings* rs)
                 break;
             // (the tail kernels keep one accumulator per path and have no debug views: such scenes run their rounds to the end instead)
             if (known_live <= d->tail_threshold && !mis_aovs && d->dscene.tech.type != IG_TECHNIQUE_DEBUG && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && d->dscene.tech.type != IG_TECHNIQUE_WIREFRAME && !ppm && !d->dscene.expr_code) {
-                live     = known_live;
-                run_tail = true;
+                live            = known_live;
+                run_tail        = true;
+                tail_from_round = round;
                 break;
             }
             // size after this round -> pinned slot (round & 1), written by the round's last kernel itself
@@ -1794,6 +1802,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
             tl.wide_lanes   = (uint32_t)d->tail_wide;
+            tl.in_kind      = tail_from_round > 0 ? kStreamShaded : kStreamCamera; // (the light tracer never runs the tail)
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
             HIP_CHECK(hipMemsetAsync(fl.tail_ctr.ptr, 0, 2 * kMaxTailPasses * sizeof(uint32_t), st));
@@ -1819,6 +1828,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     p.max_bounces  = j + 1 < passes ? d->tail_split : 0;
                     p.count_paths  = j == 0;
                     p.pass         = j;
+                    p.in_kind      = j == 0 ? tl.in_kind : kStreamShaded;
                     int pass_grid  = tail_grid;
                     if (d->tail_adapt && j > 0 && d->tail_share[0] > 0)
                         pass_grid = std::max(64, std::min(tail_grid, (int)std::ceil(d->tail_share[j] * (double)live / d->tail_density)));

@@ -88,6 +88,14 @@ struct PrimaryCols {
     float* hit_v;
 };
 
+// Which columns of a primary stream carry data depends on its writer (round 5: what is constant is not moved):
+//   kStreamShaded (k_shade, k_tail's spill): meta.y = the bits of eta (every such ray is a bounce ray: its flags are IG_RAY_FLAG_BOUNCE,
+//                  which the traversal takes as uniform_flags), no eta column traffic
+//   kStreamCamera (k_generate): meta.y = the ray's flags; the payload is init_pt_raypayload's constant (inv_pdf 0, contrib white, eta 1,
+//                  technique/pathtracer.art:33-38): neither pay nor eta is written or read
+//   kStreamLight  (k_generate_light): meta.y = flags, pay = the light path's payload, eta = 1 (not written)
+constexpr int kStreamShaded = 0, kStreamCamera = 1, kStreamLight = 2;
+
 // Shadow-ray queue: rayA = (org.xyz, tmin), rayB = (dir.xyz, tmax), col = (rgb, ray id bits)
 struct SecondaryCols {
     float4* rayA;
@@ -245,6 +253,7 @@ struct ShadeArgs {
     const uint32_t* sort_idx;
     const uint32_t* cls_range;
     uint32_t hit_pack; // the `in` stream's hits are packed rows (pack_hit) with that many prim bits; 0: hit + hit_v
+    int32_t in_kind;   // who wrote the `in` stream (kStreamShaded / kStreamCamera / kStreamLight below)
     int32_t skip_misses; // the scene has no infinite light: a miss needs no shading (the kernels without the sort look at the hit first)
 };
 
@@ -292,6 +301,7 @@ struct TailArgs {
     // a wave that follows no more than this many paths traverses their closest-hit rays one at a time with all its lanes
     // (wide_core.h); 0: never
     uint32_t wide_lanes;
+    int32_t in_kind; // who wrote `in` (kStreamShaded / kStreamCamera / kStreamLight); `out` is always kStreamShaded
 };
 
 struct ResolveArgs {

@@ -213,9 +213,9 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
     a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
     a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
     // init_pt_raypayload (technique/pathtracer.art:33-38): inv_pdf 0, contrib white, depth 1, eta 1
+    // (kStreamCamera: the payload of init_pt_raypayload — inv_pdf 0, contrib white, depth 1, eta 1, technique/pathtracer.art:33-38 — is
+    // the same for every camera ray: the readers supply it, the pay / eta columns are not written)
     a.out.meta[i] = make_int4((int32_t)lid, (int32_t)flags, (int32_t)rnd.counter, 1);
-    a.out.pay[i]  = make_float4(0, 1, 1, 1);
-    a.out.eta[i]  = 1;
 }
 
 // make_lt_emitter (technique/lighttracer.art:35-62): the light selector at position 0, Light::sample_emission, payload
@@ -261,8 +261,7 @@ __global__ void __launch_bounds__(256) k_generate_light(const GenerateLightArgs 
     a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
     a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
     a.out.meta[i] = make_int4((int32_t)lid, (int32_t)flags, (int32_t)rnd.counter, 1);
-    a.out.pay[i]  = make_float4(a.ppm ? (float)li_used : 0.0f, contrib.r, contrib.g, contrib.b);
-    a.out.eta[i]  = 1;
+    a.out.pay[i]  = make_float4(a.ppm ? (float)li_used : 0.0f, contrib.r, contrib.g, contrib.b); // (kStreamLight: eta 1 is the readers')
 }
 
 // Bookkeeping between bounce rounds, one thread: statistics (Statistics.h:57-64; BounceRayCount
@@ -645,8 +644,7 @@ __global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols
         dst.rayA[i] = src.rayA[i];
         dst.rayB[i] = src.rayB[i];
         dst.meta[i] = src.meta[i];
-        dst.pay[i]  = src.pay[i];
-        dst.eta[i]  = src.eta[i];
+        dst.pay[i]  = src.pay[i]; // (eta travels in meta.y or is the constant 1: kernels.h kStream*)
     }
 }
 

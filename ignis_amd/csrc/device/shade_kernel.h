@@ -145,8 +145,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
         int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
         if (valid) {
             PathVertexIn in;
-            const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], pay = a.in.pay[j], hit = a.in.hit[j];
+            const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], hit = a.in.hit[j];
             const int4 meta = a.in.meta[j];
+            // (what the stream's writer left constant is not read: kernels.h kStream*)
+            const float4 pay = a.in_kind == kStreamCamera ? make_float4(0, 1, 1, 1) : a.in.pay[j];
             in.ray_id  = ray_id = meta.x;
             in.org     = f3{ ra.x, ra.y, ra.z };
             in.dir     = f3{ rb.x, rb.y, rb.z };
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             in.inv_pdf = pay.x;
             in.contrib = Col{ pay.y, pay.z, pay.w };
             in.depth   = meta.w;
-            in.eta     = a.in.eta[j];
+            in.eta     = a.in_kind == kStreamShaded ? igm_float((uint32_t)meta.y) : 1.0f;
             in.ent     = in_ent_for_bin = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w;
@@ -245,9 +247,8 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
                 const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
                 a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, FULL ? out.b_tmin : kRayOffset);
                 a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
-                a.out.meta[o] = make_int4(ray_id, (int32_t)IG_RAY_FLAG_BOUNCE, (int32_t)out.b_rnd, out.b_depth);
+                a.out.meta[o] = make_int4(ray_id, (int32_t)igm_bits(out.b_eta), (int32_t)out.b_rnd, out.b_depth); // (kStreamShaded: eta where the flags were)
                 a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
-                a.out.eta[o]  = out.b_eta;
             }
             if (out.shadow) {
                 const uint32_t o = os + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));

@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             const uint32_t i    = base + rank;
             if (!have && rank < (uint32_t)want && i < n) {
                 have            = true;
-                const float4 ra = a.in.rayA[i], rb = a.in.rayB[i], pay = a.in.pay[i];
+                const float4 ra = a.in.rayA[i], rb = a.in.rayB[i];
                 const int4 meta = a.in.meta[i];
+                const float4 pay = a.in_kind == kStreamCamera ? make_float4(0, 1, 1, 1) : a.in.pay[i]; // (kernels.h kStream*)
                 in.ray_id  = meta.x;
                 in.org     = f3{ ra.x, ra.y, ra.z };
                 in.dir     = f3{ rb.x, rb.y, rb.z };
@@ -127,9 +128,9 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 in.inv_pdf = pay.x;
                 in.contrib = Col{ pay.y, pay.z, pay.w };
                 in.depth   = meta.w;
-                in.eta     = a.in.eta[i];
+                in.eta     = a.in_kind == kStreamShaded ? igm_float((uint32_t)meta.y) : 1.0f;
                 tmin = ra.w, tmax = rb.w;
-                flags = (uint32_t)meta.y;
+                flags = a.in_kind == kStreamShaded ? (uint32_t)IG_RAY_FLAG_BOUNCE : (uint32_t)meta.y;
                 acc   = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
                 hops  = 0;
             }
@@ -313,9 +314,8 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 const uint32_t o = base + (uint32_t)__popcll(mspill & ((1ull << lane) - 1ull));
                 a.out.rayA[o] = make_float4(in.org.x, in.org.y, in.org.z, tmin);
                 a.out.rayB[o] = make_float4(in.dir.x, in.dir.y, in.dir.z, tmax);
-                a.out.meta[o] = make_int4(in.ray_id, (int32_t)flags, (int32_t)in.rnd, in.depth);
+                a.out.meta[o] = make_int4(in.ray_id, (int32_t)igm_bits(in.eta), (int32_t)in.rnd, in.depth); // (kStreamShaded; a spilled path has bounced: its flags are IG_RAY_FLAG_BOUNCE)
                 a.out.pay[o]  = make_float4(in.inv_pdf, in.contrib.r, in.contrib.g, in.contrib.b);
-                a.out.eta[o]  = in.eta;
                 a.accum[(int64_t)in.ray_id - a.id_base] = acc;
                 have                                    = false;
             }
