@@ -12,6 +12,9 @@
 #ifndef IG_QNODE
 #define IG_QNODE 0
 #endif
+#ifndef IG_SPLAT_PREFETCH
+#define IG_SPLAT_PREFETCH 1 // the shadow ray's accumulator fetched with the ray (0: read in the epilogue); profiles/r05_experiment_ab.txt section 16
+#endif
 
 namespace igdev {
 
@@ -53,6 +56,9 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     mask_t has_ray         = 0; // lanes with a ray in flight (a lane mask in scalar registers, like the traverser's)
     uint32_t ray_idx       = 0;
     uint32_t st_unoccluded = 0;
+#if IG_SPLAT_PREFETCH
+    float4 acc_pre = make_float4(0, 0, 0, 0);
+#endif
     float4 splat           = make_float4(0, 0, 0, 0); // any hit: the shadow ray's colour and slot, fetched with the ray (one round trip per refill instead of one per finished lane)
     uint32_t snap_nodes = 0, snap_tris = 0, snap_leaves = 0; // work counters at the start of the current ray
     bool fatal = false;
@@ -104,8 +110,14 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                     h  = a.hit[idx];
                     hv = ANY_HIT ? 0.0f : a.hit_v[idx];
                 }
-                if (ANY_HIT && a.accum)
+                if (ANY_HIT && a.accum) {
                     splat = a.col[idx];
+#if IG_SPLAT_PREFETCH
+                    // the accumulator the ray would add into, fetched with the ray: the epilogue's add-and-store then waits for nothing (the
+                    // slot is this ray's sample's for the length of the launch: one shadow ray per path and round)
+                    acc_pre = a.accum[(int64_t)(int32_t)igm_bits(splat.w) - a.id_base];
+#endif
+                }
                 if (STATS && !DEEP)
                     snap_nodes = tr.st_nodes, snap_tris = tr.st_tris, snap_leaves = tr.st_leaves;
             }
@@ -163,7 +175,11 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                             float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
                             // (the light tracer's connections add into the slots of OTHER paths' pixels: its launches pass no accumulator and
                             // record verdicts only, launch_lt_splat adds them in a fixed order afterwards, photon.hip)
+#if IG_SPLAT_PREFETCH
+                            float4 v = acc_pre;
+#else
                             float4 v = *dst;
+#endif
                             v.x += c.x * a.inv_spi;
                             v.y += c.y * a.inv_spi;
                             v.z += c.z * a.inv_spi;
