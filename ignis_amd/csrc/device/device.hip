@@ -42,7 +42,7 @@ void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStrea
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
 void launch_info(const InfoArgs& args, int grid_blocks, hipStream_t stream);
 void launch_tail(const TailArgs& args, bool stats, bool full_bsdfs, int grid_blocks, hipStream_t stream);
-void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream);
+void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, const CameraStream& cam, hipStream_t stream);
 // photon.hip (IG_TECHNIQUE_PPM)
 void launch_shade_ppm(const ShadeArgs& args, int grid_blocks, hipStream_t stream);
 size_t photon_grid_temp_bytes(uint32_t n);
@@ -235,6 +235,7 @@ struct igd_device {
     // pack_hit; igd_assign_scene: the entity count and the largest mesh fit 32 bits together, no analytic spheres). IGD_HIT_PACK=0: never
     uint32_t hit_pack_bits = 0;
     bool hit_pack_allowed  = true;
+    bool camera_compact    = true; // IGD_CAMERA_COMPACT=0: camera streams with every column although the rays all leave one point (kernels.h CameraStream)
     bool skip_misses       = true; // IGD_SKIP_MISSES=0: k_shade reads a miss's columns although the scene has no environment light (ShadeArgs::skip_misses)
     int node_repeat = -1; // IGD_NODE_REPEAT: DevScene::node_repeat (-1: by the size of the BVH)
     // IGD_NODE_FORMAT: -1 auto (the 128-byte quantised node records when the builder left every node on its 8-bit grid — it does from
@@ -1589,6 +1590,17 @@ void render(igd_device* d, const igd_render_settings* rs)
         ga.rays_per_iteration = (int32_t)std::max<int64_t>(per_it, 1);
         ga.n              = n;
         ga.list_rays      = list_mode ? d->list_rays.ptr : nullptr;
+        // a camera whose rays all leave one point writes only the directions (kernels.h CameraStream)
+        CameraStream cam_stream{};
+        {
+            const ig_camera& c = d->camera;
+            const bool one_point = (c.type == IG_CAMERA_PERSPECTIVE && !(c.aperture_radius > 1.1920928955e-07f)) || (c.type == IG_CAMERA_FISHLENS && !c.fisheye_mask);
+            cam_stream.compact     = d->camera_compact && one_point && !list_mode && !light_tracer ? 1 : 0;
+            cam_stream.rnd_counter = c.pixel_sampler == IG_PIXEL_SAMPLER_HALTON ? 1u : 3u; // Tea{seed, 1} after the sampler's two draws (none for Halton)
+            cam_stream.first_id    = first;
+            cam_stream.rayA        = make_float4(c.eye[0], c.eye[1], c.eye[2], c.near_clip);
+        }
+        ga.compact = cam_stream.compact;
         if (light_tracer) {
             GenerateLightArgs gl{};
             gl.scene     = d->dscene;
@@ -1643,6 +1655,12 @@ void render(igd_device* d, const igd_render_settings* rs)
                 // meta column for the visibility flags (16 of the 48 bytes it reads per ray)
                 ta.meta          = nullptr;
                 ta.uniform_flags = IG_RAY_FLAG_BOUNCE;
+            } else if (cam_stream.compact) {
+                // round 0 of a compact camera stream: rayB is all there is
+                ta.rayA          = nullptr;
+                ta.uniform_rayA  = cam_stream.rayA;
+                ta.meta          = nullptr;
+                ta.uniform_flags = IG_RAY_FLAG_CAMERA;
             }
             ta.count        = &qs->q[in_slot].primary;
             ta.work_counter = &qs->work_counter[0];
@@ -1684,6 +1702,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             sa.ppm = ppm_args;
             sa.hit_pack = d->hit_pack_bits;
             sa.in_kind  = bounce_rays_only ? kStreamShaded : (light_tracer ? kStreamLight : kStreamCamera);
+            sa.cam_stream = cam_stream;
             sa.skip_misses = d->skip_misses && d->dscene.infinite_light_count == 0 && (d->dscene.tech.type == IG_TECHNIQUE_PATH || d->dscene.tech.type == IG_TECHNIQUE_VOLPATH) ? 1 : 0;
             timed(2, on, [&] {
                 if (ppm)
@@ -1790,7 +1809,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             // moved out of the primary stream, which the next chunk overwrites.
             d->ensureTailInput(fl, live);
             const PrimaryCols keep = igd_device::colsAt(fl.tail_in.ptr, fl.tail_capacity);
-            launch_copy_paths(d->primaryCols(in_slot), keep, &qs->q[in_slot].primary, live, st);
+            launch_copy_paths(d->primaryCols(in_slot), keep, &qs->q[in_slot].primary, live, tail_from_round == 0 ? cam_stream : CameraStream{}, st);
             tl.scene        = d->dscene;
             tl.in           = keep;
             tl.in_count     = &qs->q[in_slot].primary;
@@ -2185,6 +2204,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
+        if (const char* e = std::getenv("IGD_CAMERA_COMPACT"))
+            d->camera_compact = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_HIT_PACK"))
             d->hit_pack_allowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SKIP_MISSES"))

@@ -92,9 +92,17 @@ struct PrimaryCols {
 //   kStreamShaded (k_shade, k_tail's spill): meta.y = the bits of eta (every such ray is a bounce ray: its flags are IG_RAY_FLAG_BOUNCE,
 //                  which the traversal takes as uniform_flags), no eta column traffic
 //   kStreamCamera (k_generate): meta.y = the ray's flags; the payload is init_pt_raypayload's constant (inv_pdf 0, contrib white, eta 1,
-//                  technique/pathtracer.art:33-38): neither pay nor eta is written or read
+//                  technique/pathtracer.art:33-38): neither pay nor eta is written or read. With CameraStream::compact (a camera whose
+//                  rays all leave one point: perspective without a lens, unmasked fishlens) ONLY rayB is stored: rayA = (eye, near clip),
+//                  the flags, depth 1 and the generator's counter are the same for every ray and the id is first_id + the stream index
 //   kStreamLight  (k_generate_light): meta.y = flags, pay = the light path's payload, eta = 1 (not written)
 constexpr int kStreamShaded = 0, kStreamCamera = 1, kStreamLight = 2;
+struct CameraStream {
+    int32_t compact;      // != 0: the stream holds rayB only
+    uint32_t rnd_counter; // Tea::counter after the pixel sampler's draws
+    int64_t first_id;     // ray id of stream index 0
+    float4 rayA;          // (eye, near clip)
+};
 
 // Shadow-ray queue: rayA = (org.xyz, tmin), rayB = (dir.xyz, tmax), col = (rgb, ray id bits)
 struct SecondaryCols {
@@ -160,6 +168,7 @@ struct TraverseArgs {
     // outputs: hit = (ent_id, prim_id, t, u), hit_v = v. Any-hit launches may leave them null.
     float4* hit;
     float* hit_v;
+    float4 uniform_rayA; // rayA == nullptr: every ray's (org, tmin) (CameraStream::compact)
     uint32_t hit_pack; // closest hit: > 0: the packed one-row form with that many prim bits (pack_hit), hit_v is not written
     // any-hit epilogue (shadow rays): unoccluded rays add col.rgb into accum[id - id_base], id = bits(col.w)
     const float4* col;
@@ -200,6 +209,7 @@ struct GenerateArgs {
     int32_t rays_per_iteration;     // local pixels * spi (multi-iteration calls: iteration += id / rays_per_iteration)
     uint32_t n;                     // rays to generate
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
+    int32_t compact;                // CameraStream::compact: only rayB is written
     // Halton pixel sampler (sampler/pixel_sampler.art:101-150): what setup_halton_pixel_sampler derives from the film
     // size, filled by launch_generate; the per-pixel offset it keeps in "__halton_offset" is recomputed per sample
     uint32_t halton_scale_x, halton_scale_y, halton_exp_x, halton_exp_y;
@@ -254,6 +264,7 @@ struct ShadeArgs {
     const uint32_t* cls_range;
     uint32_t hit_pack; // the `in` stream's hits are packed rows (pack_hit) with that many prim bits; 0: hit + hit_v
     int32_t in_kind;   // who wrote the `in` stream (kStreamShaded / kStreamCamera / kStreamLight below)
+    CameraStream cam_stream; // in_kind == kStreamCamera
     int32_t skip_misses; // the scene has no infinite light: a miss needs no shading (the kernels without the sort look at the hit first)
 };
 

@@ -210,8 +210,10 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         }
     }
 
-    a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
     a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
+    if (a.compact)
+        return; // (CameraStream::compact: origin, near clip, flags, depth and the generator's counter are the same for every ray)
+    a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
     // init_pt_raypayload (technique/pathtracer.art:33-38): inv_pdf 0, contrib white, depth 1, eta 1
     // (kStreamCamera: the payload of init_pt_raypayload — inv_pdf 0, contrib white, depth 1, eta 1, technique/pathtracer.art:33-38 — is
     // the same for every camera ray: the readers supply it, the pay / eta columns are not written)
@@ -636,22 +638,23 @@ void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStrea
     hipLaunchKernelGGL(k_secondary_end, dim3(1), dim3(64), 0, stream, qs, slot, mirror);
 }
 
-// Moves the surviving paths (the columns the tail kernel reads) out of a primary stream.
-__global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols dst, const uint32_t* __restrict__ count)
+// Moves the surviving paths (the columns the tail kernel reads) out of a primary stream. A compact camera stream (kernels.h CameraStream)
+// is written out in full: the tail kernel reads rayA and meta like any other stream's.
+__global__ void __launch_bounds__(256) k_copy_paths(PrimaryCols src, PrimaryCols dst, const uint32_t* __restrict__ count, CameraStream cam)
 {
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        dst.rayA[i] = src.rayA[i];
+        dst.rayA[i] = cam.compact ? cam.rayA : src.rayA[i];
         dst.rayB[i] = src.rayB[i];
-        dst.meta[i] = src.meta[i];
+        dst.meta[i] = cam.compact ? make_int4((int32_t)(cam.first_id + i), (int32_t)IG_RAY_FLAG_CAMERA, (int32_t)cam.rnd_counter, 1) : src.meta[i];
         dst.pay[i]  = src.pay[i]; // (eta travels in meta.y or is the constant 1: kernels.h kStream*)
     }
 }
 
-void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, hipStream_t stream)
+void launch_copy_paths(const PrimaryCols& src, const PrimaryCols& dst, const uint32_t* count, uint32_t max_count, const CameraStream& cam, hipStream_t stream)
 {
     const unsigned blocks = std::min(4096u, (max_count + 255u) / 256u);
-    hipLaunchKernelGGL(k_copy_paths, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, src, dst, count);
+    hipLaunchKernelGGL(k_copy_paths, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, src, dst, count, cam);
 }
 
 void launch_resolve(const ResolveArgs& args, hipStream_t stream)

@@ -145,8 +145,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
         int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
         if (valid) {
             PathVertexIn in;
-            const float4 ra = a.in.rayA[j], rb = a.in.rayB[j], hit = a.in.hit[j];
-            const int4 meta = a.in.meta[j];
+            const bool compact = a.in_kind == kStreamCamera && a.cam_stream.compact; // (kernels.h CameraStream: only rayB is stored)
+            const float4 ra = compact ? a.cam_stream.rayA : a.in.rayA[j];
+            const float4 rb = a.in.rayB[j], hit = a.in.hit[j];
+            const int4 meta = compact ? make_int4((int32_t)(a.cam_stream.first_id + j), (int32_t)IG_RAY_FLAG_CAMERA, (int32_t)a.cam_stream.rnd_counter, 1) : a.in.meta[j];
             // (what the stream's writer left constant is not read: kernels.h kStream*)
             const float4 pay = a.in_kind == kStreamCamera ? make_float4(0, 1, 1, 1) : a.in.pay[j];
             in.ray_id  = ray_id = meta.x;

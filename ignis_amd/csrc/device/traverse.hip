@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 const uint32_t idx = (DEEP && a.index_list) ? a.index_list[batch_next + rank] : batch_next + rank; // (DEEP as the primary kernel: no list)
                 ray_idx = idx;
                 tr.prof(2, true);
-                ra = a.rayA[idx], rb = a.rayB[idx];
+                ra = a.rayA ? a.rayA[idx] : a.uniform_rayA, rb = a.rayB[idx]; // (no rayA column: a compact camera stream, kernels.h CameraStream)
                 if (a.meta)
                     flags = (uint32_t)a.meta[idx].y;
                 if (SPHERES) {
