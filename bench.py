@@ -17,6 +17,10 @@ over RCCL (W x H x 12 / N bytes per rank; ignis_amd.sharding.gather_rows). K ite
 "scaling": "strong". N = 1 runs the same code path without a process group. `--sharding iterations` keeps the other
 partition (rank r renders K whole-film iterations r*K .. r*K+K-1, reduce(SUM); "weak").
 
+`roofline.traffic` is measured in the run itself at N = 1 (two more passes of the same command under `rocprofv3 --pmc FETCH_SIZE` /
+`WRITE_SIZE --kernel-trace` as child processes, ~10 s each; `--no-live-traffic` or a failing profiler fall back to the figure
+profiles/<tag>_traffic.json holds, which `traffic_from_profiles` always shows next to it).
+
 Prints ONE JSON line (rank 0): Mrays/s = (camera + bounce + shadow rays) / s as the reference counts them
 (src/runtime/Statistics.cpp:286-290), plus Msamples/s (src/frontend/cli/main.cpp:134), the roofline block of the
 dominant kernel (closest-hit traversal) and the CPU baseline (oracle) on rank 0.
@@ -67,6 +71,9 @@ def parse():
     ap.add_argument("--dist", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: rccl = the device library's own RCCL communicator (igd_comm_*, ignis_amd/comm.py; no torch in the process), "
                          "torch = torch.distributed with the nccl backend (the path of rounds 1 - 4)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of the same command as child processes); "
+                         "the figure then comes from profiles/<tag>_traffic.json")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (BASELINE configs 3 and 4 measured next to the headline)")
     return ap.parse_args()
 
@@ -95,6 +102,57 @@ def _primbvh_nodes(scene):
         seen.add(off)
         total += int(C.cast(C.c_void_p(C.addressof(s.primbvh.contents) + off), C.POINTER(C.c_uint32))[0])
     return total
+
+
+def live_traffic(args, rays_per_launch):
+    """roofline.traffic measured in THIS run: the same command twice more as a child process under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, counters alone with the kernel
+    trace, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), the closest-hit traversal kernel's per-launch means from the rocpd
+    databases: HBM bytes = 2 x FETCH_SIZE (the guide's gfx950 correction, which profiles/r05_fetch_calibration.txt confirms for this
+    kernel's 16-byte gathers) + WRITE_SIZE, in KiB. Per ray x this run's rays per launch (the workload is deterministic: the child runs
+    traverse the same rays). None (and the reason) when rocprofv3 is not there or a pass fails: the caller falls back to profiles/."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    means = {}
+    # (the per-ray figures of a deterministic workload do not depend on the wavefront size: a long run is profiled on a shorter one; the
+    # child's warm-up is the same batch of iterations as its timed steps, so the mean over ALL its launches is the timed launches' mean)
+    pmc_steps = min(args.steps, 32)
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(pmc_steps), "--warmup", str(pmc_steps), "--width", str(args.width), "--height", str(args.height), "--spi", str(args.spi),
+                   "--scene", args.scene, "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name"
+            hit = [(n, c, v) for n, c, v in cur.execute(q, (counter,)) if "k_traverse<false, false, false" in n]  # <closest, no stats, not DEEP, ...>
+            if not hit:
+                return None, f"no closest-hit traversal launches in the {counter} pass"
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            n_rays = line["rays"]["camera"] + line["rays"]["bounce"]
+            means[counter] = (hit[0][2] * 1024.0, n_rays / max(1, line["roofline"]["launches"]))
+    except Exception as e:  # (a profiler hiccup must not cost the bench line)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, rays_f = means["FETCH_SIZE"]
+    write, rays_w = means["WRITE_SIZE"]
+    per_ray = 2.0 * fetch / rays_f + write / rays_w
+    return int(per_ray * rays_per_launch), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, own passes of this command as child "
+                                            f"processes at {pmc_steps} steps; k_traverse<closest> means per launch, reads x 2 (gfx950 correction, "
+                                            "profiles/r05_fetch_calibration.txt), per-ray figure x this run's rays per launch")
 
 
 def shade_stream_bytes(n_in, n_bounce, n_shadow):
@@ -413,6 +471,15 @@ def main():
                             "issue_frac": round(insts * cpi / (1024 * SHADER_GHZ * 1e9 * avg_ms * 1e-3), 4) if cpi else None,
                             "issue_frac_note": f"{cpi} cycles per wave64 instruction (profiles/{PROFILE_TAG}_issue_accounting.json: dynamic opcode histogram x calibrated prices), {SHADER_GHZ} GHz under load",
                             "source": f"profiles/{tname}"}
+        traffic_file, traffic_file_src = traffic, traffic_src
+        if world == 1 and shards == 1 and not distributed and not args.no_live_traffic and not args.no_stage_timers:
+            live, why = live_traffic(args, n_primary / c_launches)
+            if live:
+                traffic, traffic_src = live, why
+            elif traffic_src:
+                traffic_src += f" [live measurement skipped: {why}]"
+            else:
+                traffic_src = f"none: {why}; no profiles/{tname} for this workload"
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,
@@ -421,7 +488,7 @@ def main():
                             "(SURVEY 8d's A), most of which L1 / L2 serve when the BVH is small; `traffic` = measured HBM-side bytes per launch",
                     "incl_cache_hits": {"achieved": round(incl_cache, 2), "unit": "GB/s", "bytes_per_launch": int(s_per_launch + g_per_launch)},
                     "stream_bytes_per_launch": int(s_per_launch), "geometry_resident_bytes": geom_resident,
-                    "node_bytes": node_bytes,
+                    "node_bytes": node_bytes, "traffic_from_profiles": traffic_file,
                     "valu": valu, "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(hbm_alg)}
 

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 for rep in 1 2; do
 for n in "$@"; do
   if [ "$n" = base ]; then unset IGD_LIBRARY; else export IGD_LIBRARY=$ROOT/ignis_amd/lib/var/libig_device_hip_$n.so; fi
-  timeout 300 python $ROOT/bench.py --steps $STEPS --warmup 16 --no-cpu-baseline --no-literal-config --no-extra-configs 2>/dev/null | tail -1 | python -c "
+  timeout 300 python $ROOT/bench.py --steps $STEPS --warmup 16 --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 s = d['stage_ms_rank0']

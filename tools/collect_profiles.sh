@@ -23,13 +23,13 @@ EOF
 # 1. the bench line on its own (no profiler attached)
 timeout 900 python bench.py $ARGS > "$OUT/${TAG}_bench$SUF.json" 2> "$OUT/bench$SUF.err"
 # 2. same command under --kernel-trace --stats
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats$SUF" -o stats -- python bench.py $ARGS --no-cpu-baseline --no-extra-configs > "$OUT/bench_under_rocprof$SUF.json" 2> "$OUT/stats$SUF.err"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats$SUF" -o stats -- python bench.py $ARGS --no-cpu-baseline --no-live-traffic --no-extra-configs > "$OUT/bench_under_rocprof$SUF.json" 2> "$OUT/stats$SUF.err"
 # 3. PMC passes of the same command (same step count: the per-launch averages then refer to the same launches)
 for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs > "$OUT/pmc_$C$SUF.json" 2> "$OUT/pmc_$C$SUF.err"
+    timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$C$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic > "$OUT/pmc_$C$SUF.json" 2> "$OUT/pmc_$C$SUF.err"
 done
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$OUT/pmc_SQ$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs > "$OUT/pmc_SQ$SUF.json" 2> "$OUT/pmc_SQ$SUF.err"
-timeout 900 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE_CYCLES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --kernel-trace -d "$OUT/pmc_MEM$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs > "$OUT/pmc_MEM$SUF.json" 2> "$OUT/pmc_MEM$SUF.err"
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$OUT/pmc_SQ$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic > "$OUT/pmc_SQ$SUF.json" 2> "$OUT/pmc_SQ$SUF.err"
+timeout 900 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE_CYCLES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --kernel-trace -d "$OUT/pmc_MEM$SUF" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic > "$OUT/pmc_MEM$SUF.json" 2> "$OUT/pmc_MEM$SUF.err"
 db() { find "$OUT/$1" -name "*.db" | head -1; }
 python tools/prof_summary.py stats "$(db stats$SUF)" > "$OUT/${TAG}_rocprofv3_stats$SUF.txt" 2>> "$OUT/summary.err"
 python tools/prof_summary.py pmc "$(db pmc_FETCH_SIZE$SUF)" "$(db pmc_WRITE_SIZE$SUF)" "$(db pmc_SQ$SUF)" "$(db pmc_MEM$SUF)" > "$OUT/${TAG}_rocprofv3_pmc$SUF.txt" 2>> "$OUT/summary.err"

@@ -25,7 +25,7 @@ i=0
 for G in "${PMCG[@]}"; do
   if [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then i=$((i+1)); continue; fi
   D=$OUT/pmcg_${LABEL}_$i
-  timeout 600 rocprofv3 --pmc $G --kernel-trace -d "$D" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs > "$D.json" 2> "$D.err"
+  timeout 600 rocprofv3 --pmc $G --kernel-trace -d "$D" -o pmc -- python bench.py $ARGS --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic > "$D.json" 2> "$D.err"
   DB=$(find "$D" -name "*.db" | head -1)
   if [ -n "$DB" ]; then python tools/prof_summary.py pmc "$DB" | grep -v "rocclr\|k_round_end\|k_secondary_end\|k_copy" >> "$F"; else echo "## group $i failed: $G" >> "$F"; tail -3 "$D.err" >> "$F"; fi
   rm -rf "$D"

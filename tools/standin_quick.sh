@@ -10,7 +10,7 @@ cd "$ROOT"
 [ -f "$DIR/standin.json" ] || python tools/make_standin_scene.py "$DIR" --triangles "$TRIS" --materials "$MATS" > "$ROOT/gpurun_out/$TAG/standin_make.log" 2>&1
 for E in "$@"; do
   [ "$E" = "-" ] && E=""
-  env $E timeout 900 python bench.py --scene "$DIR/standin.json" --steps "$STEPS" --warmup "$STEPS" --no-cpu-baseline --no-literal-config 2> "$ROOT/gpurun_out/$TAG/standin_quick.err" | tail -1 | python -c "
+  env $E timeout 900 python bench.py --scene "$DIR/standin.json" --steps "$STEPS" --warmup "$STEPS" --no-cpu-baseline --no-live-traffic --no-literal-config 2> "$ROOT/gpurun_out/$TAG/standin_quick.err" | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 s = d['stage_ms_rank0']

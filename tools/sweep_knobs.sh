@@ -4,7 +4,7 @@
 run() {
   local label="$1"; shift
   local v
-  v=$(env "$@" timeout 120 python bench.py --no-cpu-baseline --no-literal-config --no-extra-configs --steps ${SWEEP_STEPS:-32} --warmup ${SWEEP_WARMUP:-2} 2>/dev/null | tail -1 | python -c 'import sys,json; print(json.loads(sys.stdin.read())["value"])' 2>/dev/null)
+  v=$(env "$@" timeout 120 python bench.py --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic --steps ${SWEEP_STEPS:-32} --warmup ${SWEEP_WARMUP:-2} 2>/dev/null | tail -1 | python -c 'import sys,json; print(json.loads(sys.stdin.read())["value"])' 2>/dev/null)
   echo "$label $v"
 }
 run default X=1

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/tailpmc; mkdir -p $OUT
 for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"; do
   rm -rf $OUT/t
-  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/t -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-literal-config --no-extra-configs "$@" > /dev/null 2> $OUT/err.txt
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/t -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic "$@" > /dev/null 2> $OUT/err.txt
   f=$(find $OUT/t -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/tailtrace
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tailtrace/t -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-literal-config --no-extra-configs $BENCH_ARGS > /dev/null 2> gpurun_out/tailtrace/err.txt
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tailtrace/t -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic $BENCH_ARGS > /dev/null 2> gpurun_out/tailtrace/err.txt
 f=$(find gpurun_out/tailtrace/t -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
