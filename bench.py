@@ -131,7 +131,7 @@ def live_traffic(args, rays_per_launch):
                    "--steps", str(pmc_steps), "--warmup", str(pmc_steps), "--width", str(args.width), "--height", str(args.height), "--spi", str(args.spi),
                    "--scene", args.scene, "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
