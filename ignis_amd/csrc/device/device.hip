@@ -1353,7 +1353,8 @@ void render(igd_device* d, const igd_render_settings* rs)
         ppm_args.radius       = igp_compute_radius(tech.merge_radius, iteration);
         for (int k = 0; k < 3; ++k)
             ppm_args.bbox_min[k] = d->scene_bbox[k], ppm_args.bbox_max[k] = d->scene_bbox[3 + k];
-        const ShadeFrame lframe{ (int32_t)P, 1, iteration, rs->frame, rs->user_seed, 0, 1, (int32_t)P, 0.0f };
+        ShadeFrame lframe{ (int32_t)P, 1, iteration, rs->frame, rs->user_seed, 0, 1, (int32_t)P, 0.0f };
+        lframe.finish();
         const uint32_t lchunk = (uint32_t)std::min<size_t>(d->capacity, P);
         for (uint32_t lfirst = 0; lfirst < P; lfirst += lchunk) {
             const uint32_t ln = std::min(lchunk, P - lfirst);
@@ -1632,7 +1633,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             const float cr[3] = { dx[1] * dy[2] - dx[2] * dy[1], dx[2] * dy[0] - dx[0] * dy[2], dx[0] * dy[1] - dx[1] * dy[0] };
             wire_footprint    = std::sqrt(std::fma(cr[0], cr[0], std::fma(cr[1], cr[1], cr[2] * cr[2])));
         }
-        const ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1), wire_footprint };
+        ShadeFrame frame{ rs->width, rs->spi, rs->iteration, rs->frame, rs->user_seed, row_offset, row_stride, (int32_t)std::max<int64_t>(per_it, 1), wire_footprint };
+        frame.finish();
         uint32_t live          = n;
         bool run_tail          = false;
         int tail_from_round    = 0; // rounds submitted before the hand-over to the tail: 0 = its input is what k_generate wrote

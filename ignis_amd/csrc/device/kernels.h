@@ -8,6 +8,27 @@
 
 namespace igdev {
 
+// x / d for 0 <= x < 2^31 and a divisor known on the host: one 64-bit multiply and a shift instead of the ~35 instructions of an
+// integer division (Granlund & Montgomery: m = ceil(2^(31 + s) / d), s = ceil(log2 d); the error m d - 2^(31 + s) < 2^s, so the floor is
+// exact for every x below 2^31). Ray ids are decomposed into (iteration, pixel, sample) with three of them per shaded vertex.
+struct FastDiv {
+    uint32_t m, shift, d;
+#ifdef __HIPCC__
+    __device__ __forceinline__ uint32_t div(uint32_t x) const { return (uint32_t)(((unsigned long long)x * m) >> shift); }
+#endif
+    static FastDiv make(uint32_t d)
+    {
+        FastDiv f{};
+        f.d        = d ? d : 1u;
+        uint32_t s = 0;
+        while (((unsigned long long)1 << s) < f.d)
+            ++s;
+        f.shift = 31 + s;
+        f.m     = (uint32_t)((((unsigned long long)1 << f.shift) + f.d - 1) / f.d);
+        return f;
+    }
+};
+
 // Geometry resident in HBM. `geom` = ["trimesh_primbvh" fix table | scene Node8 array], so every
 // BVH node / Tri4 packet is addressed as geom + 32-bit byte offset (SGPR base + VGPR offset).
 constexpr int kDeepStack = 104; // traversal stack entries per lane beyond the LDS part, in DevScene::deep_stack
@@ -208,6 +229,7 @@ struct GenerateArgs {
     int64_t first_local_id;         // first local ray id of this chunk
     int32_t rays_per_iteration;     // local pixels * spi (multi-iteration calls: iteration += id / rays_per_iteration)
     uint32_t n;                     // rays to generate
+    FastDiv by_rays_per_iteration, by_spi, by_width; // (launch_generate fills them)
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
     int32_t compact;                // CameraStream::compact: only rayB is written
     // Halton pixel sampler (sampler/pixel_sampler.art:101-150): what setup_halton_pixel_sampler derives from the film
@@ -222,6 +244,23 @@ struct ShadeFrame { // per-iteration constants (src/artic/driver/settings.art:2-
     int32_t row_offset, row_stride;
     int32_t rays_per_iteration; // local pixels * spi: ray ids of a multi-iteration call continue across iterations
     float wire_footprint;       // IG_TECHNIQUE_WIREFRAME: |dx x dy| of camera.differential (technique/wireframe.art:25-26)
+    FastDiv by_rays_per_iteration, by_spi, by_width; // (set by ShadeFrame::finish)
+    void finish()
+    {
+        by_rays_per_iteration = FastDiv::make((uint32_t)rays_per_iteration);
+        by_spi                = FastDiv::make((uint32_t)spi);
+        by_width              = FastDiv::make((uint32_t)width);
+    }
+    // a ray id -> (iteration of the call, sample of the pixel, local pixel x, local row)
+    __device__ __forceinline__ void decompose(int ray_id, int& it_local, int& sample, int& px, int& row) const
+    {
+        const uint32_t id     = (uint32_t)ray_id;
+        const uint32_t it     = by_rays_per_iteration.div(id);
+        const uint32_t within = id - it * (uint32_t)rays_per_iteration;
+        const uint32_t lpix   = by_spi.div(within);
+        const uint32_t r      = by_width.div(lpix);
+        it_local = (int)it, sample = (int)(within - lpix * (uint32_t)spi), px = (int)(lpix - r * (uint32_t)width), row = (int)r;
+    }
 };
 
 // the pinhole camera of the light tracer's connections (Camera::sample_pixel, camera/perspective.art:16-57)

@@ -267,12 +267,8 @@ IG_DEV void shade_vertex_lt(const DevScene& sc, const ShadeFrame& fr, const LtCa
     const f3 N       = surf.local.c2;
     const f3 out_dir = -in.dir;
 
-    const int it_l   = in.ray_id / fr.rays_per_iteration;
-    const int within = in.ray_id % fr.rays_per_iteration;
-    const int sample = within % fr.spi;
-    const int lpix   = within / fr.spi;
-    const int px     = lpix % fr.width;
-    const int py     = lpix / fr.width;
+    int it_l, sample, px, py;
+    fr.decompose(in.ray_id, it_l, sample, px, py);
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
     // ---- on_shadow (lighttracer.art:75-113): camera.sample_pixel of make_perspective_camera (camera/perspective.art:16-26,43-57)

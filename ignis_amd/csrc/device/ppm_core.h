@@ -129,12 +129,10 @@ IG_DEV void shade_vertex_ppm(const DevScene& sc, const ShadeFrame& fr, const Ppm
     const bool emissive  = mat.light_id >= 0;
     const bool all_delta = bsdf.all_delta();
 
-    const int it_l   = in.ray_id / fr.rays_per_iteration;
-    const int within = in.ray_id % fr.rays_per_iteration;
-    const int sample = within % fr.spi;
-    const int lpix   = within / fr.spi;
-    const int px     = lpix % fr.width;
-    const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
+    int it_l, sample, px, row;
+    fr.decompose(in.ray_id, it_l, sample, px, row);
+    const int py     = fr.row_offset + row * fr.row_stride;
+    const int within = in.ray_id - it_l * fr.rays_per_iteration; // the light path's index inside its iteration: its photon slot
     Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
 
     if constexpr (LIGHT_PASS) {

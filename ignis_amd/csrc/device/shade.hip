@@ -91,13 +91,17 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
         return;
 
     // gpu_generate_rays id convention: ray id = pixel * spi + sample, linear over the film
+    // (ids stay below 2^31, igd_render checks: 32-bit arithmetic with the host's multipliers instead of 64-bit divisions)
     const int64_t lid     = a.first_local_id + i;
-    const int it_local    = (int)(lid / a.rays_per_iteration); // multi-iteration call: which of its iterations
-    const int64_t within  = lid % a.rays_per_iteration;
-    const int sample      = (int)(within % a.spi);
-    const int64_t lpixel  = within / a.spi;
-    const int x           = (int)(lpixel % a.width);
-    const int y           = a.row_offset + (int)(lpixel / a.width) * a.row_stride;
+    const uint32_t uid    = (uint32_t)lid;
+    const uint32_t it_u   = a.by_rays_per_iteration.div(uid);
+    const int it_local    = (int)it_u; // multi-iteration call: which of its iterations
+    const uint32_t within = uid - it_u * (uint32_t)a.rays_per_iteration;
+    const uint32_t lpixel = a.by_spi.div(within);
+    const int sample      = (int)(within - lpixel * (uint32_t)a.spi);
+    const uint32_t lrow   = a.by_width.div(lpixel);
+    const int x           = (int)(lpixel - lrow * (uint32_t)a.width);
+    const int y           = a.row_offset + (int)lrow * a.row_stride;
 
     Tea rnd{ make_seed(sample, a.iteration + it_local, a.frame, x, y, a.seed), 1 };
     f3 org, dir;
@@ -417,6 +421,9 @@ static void extended_gcd(uint32_t a, uint32_t b, int32_t& x, int32_t& y)
 void launch_generate(const GenerateArgs& in, hipStream_t stream)
 {
     GenerateArgs args = in;
+    args.by_rays_per_iteration = FastDiv::make((uint32_t)args.rays_per_iteration);
+    args.by_spi                = FastDiv::make((uint32_t)args.spi);
+    args.by_width              = FastDiv::make((uint32_t)args.width);
     if (args.cam.pixel_sampler == IG_PIXEL_SAMPLER_HALTON) {
         // compute_halton_base_info + multiplicative_inverse of setup_halton_pixel_sampler (:66-75,87-90,107-111)
         args.halton_scale_x = 1, args.halton_exp_x = 0;

@@ -2627,12 +2627,9 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const f3 out_dir = -in.dir;
 
     // RNG resumes where the path left off (mapping_gpu.art:171)
-    const int it_l   = in.ray_id / fr.rays_per_iteration; // multi-iteration call: which of its iterations
-    const int within = in.ray_id % fr.rays_per_iteration;
-    const int sample = within % fr.spi;
-    const int lpix   = within / fr.spi;
-    const int px     = lpix % fr.width;
-    const int py     = fr.row_offset + (lpix / fr.width) * fr.row_stride;
+    int it_l, sample, px, row; // multi-iteration call: which of its iterations; the pixel's sample; local pixel
+    fr.decompose(in.ray_id, it_l, sample, px, row);
+    const int py = fr.row_offset + row * fr.row_stride;
 #ifdef IG_EXP_CHEAP_SEED // experiment: what do the seed hash and the three integer divisions in front of it cost? (wrong images)
     Tea rnd{ (uint32_t)in.ray_id * 747796405u + 12345u, in.rnd };
 #else
