@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <cmath>
 #include <cstdio>
@@ -1380,9 +1381,11 @@ void render(igd_device* d, const igd_render_settings* rs)
                 TraverseArgs ta{};
                 ta.scene = d->dscene;
                 ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
-                if (round > 0) { // a stream k_shade wrote: bounce rays all (its meta.y carries eta, kernels.h kStream*)
-                    ta.meta          = nullptr;
-                    ta.uniform_flags = IG_RAY_FLAG_BOUNCE;
+                if (round > 0) { // a stream k_shade wrote: bounce rays all (its meta.y carries eta, its rayB.w the seed: kernels.h kStream*)
+                    ta.meta             = nullptr;
+                    ta.uniform_flags    = IG_RAY_FLAG_BOUNCE;
+                    ta.uniform_tmax     = std::numeric_limits<float>::max();
+                    ta.use_uniform_tmax = 1;
                 }
                 ta.count        = &lq->q[lslot].primary;
                 ta.work_counter = &lq->work_counter[0];
@@ -1655,8 +1658,10 @@ void render(igd_device* d, const igd_render_settings* rs)
             if (bounce_rays_only) {
                 // every ray k_shade appends carries IG_RAY_FLAG_BOUNCE (shade_kernel.h): from round 1 on the traversal need not read the
                 // meta column for the visibility flags (16 of the 48 bytes it reads per ray)
-                ta.meta          = nullptr;
-                ta.uniform_flags = IG_RAY_FLAG_BOUNCE;
+                ta.meta             = nullptr;
+                ta.uniform_flags    = IG_RAY_FLAG_BOUNCE;
+                ta.uniform_tmax     = std::numeric_limits<float>::max(); // (FLT_MAX, what k_shade used to write into rayB.w; the path's seed travels there now)
+                ta.use_uniform_tmax = 1;
             } else if (cam_stream.compact) {
                 // round 0 of a compact camera stream: rayB is all there is
                 ta.rayA          = nullptr;

@@ -111,7 +111,9 @@ struct PrimaryCols {
 
 // Which columns of a primary stream carry data depends on its writer (round 5: what is constant is not moved):
 //   kStreamShaded (k_shade, k_tail's spill): meta.y = the bits of eta (every such ray is a bounce ray: its flags are IG_RAY_FLAG_BOUNCE,
-//                  which the traversal takes as uniform_flags), no eta column traffic
+//                  which the traversal takes as uniform_flags), no eta column traffic; rayB.w = the path's generator seed (a bounce ray's
+//                  tmax is FLT_MAX, which the traversal takes as uniform_tmax): the six FNV steps and three divisions of make_seed run
+//                  once per path, not once per vertex
 //   kStreamCamera (k_generate): meta.y = the ray's flags; the payload is init_pt_raypayload's constant (inv_pdf 0, contrib white, eta 1,
 //                  technique/pathtracer.art:33-38): neither pay nor eta is written or read. With CameraStream::compact (a camera whose
 //                  rays all leave one point: perspective without a lens, unmasked fishlens) ONLY rayB is stored: rayA = (eye, near clip),
@@ -190,6 +192,8 @@ struct TraverseArgs {
     float4* hit;
     float* hit_v;
     float4 uniform_rayA; // rayA == nullptr: every ray's (org, tmin) (CameraStream::compact)
+    float uniform_tmax;  // use_uniform_tmax != 0: every ray's tmax (a kStreamShaded stream keeps the path's seed in rayB.w)
+    int32_t use_uniform_tmax;
     uint32_t hit_pack; // closest hit: > 0: the packed one-row form with that many prim bits (pack_hit), hit_v is not written
     // any-hit epilogue (shadow rays): unoccluded rays add col.rgb into accum[id - id_base], id = bits(col.w)
     const float4* col;

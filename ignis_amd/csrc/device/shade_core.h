@@ -2390,6 +2390,9 @@ struct PathVertexIn {
     // hit (ent < 0: miss)
     int ent, prim;
     float t, u, v;
+    // the path's generator seed, when the stream carries it (kStreamShaded: a bounce ray's rayB.w; the tail keeps it in a register);
+    // 0 = not known: make_seed from the ray id (what a camera ray's first vertex does). A seed that IS 0 is recomputed, to the same value.
+    uint32_t seed;
 };
 
 struct PathVertexOut {
@@ -2402,7 +2405,7 @@ struct PathVertexOut {
     bool bounce;       // continued path
     f3 b_org, b_dir;
     float b_tmin;
-    uint32_t b_rnd;
+    uint32_t b_rnd, b_seed; // b_seed: the path's generator seed (the path tracer's callbacks; 0 from the others)
     float b_inv_pdf, b_eta;
     Col b_contrib;
     int b_depth;
@@ -2627,13 +2630,19 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
     const f3 out_dir = -in.dir;
 
     // RNG resumes where the path left off (mapping_gpu.art:171)
-    int it_l, sample, px, row; // multi-iteration call: which of its iterations; the pixel's sample; local pixel
-    fr.decompose(in.ray_id, it_l, sample, px, row);
-    const int py = fr.row_offset + row * fr.row_stride;
+    // (the seed is a hash of the sample's coordinates: six FNV steps behind three divisions; a path computes it once and carries it)
+    uint32_t seed = in.seed;
+    if (seed == 0u) {
+        int it_l, sample, px, row; // multi-iteration call: which of its iterations; the pixel's sample; local pixel
+        fr.decompose(in.ray_id, it_l, sample, px, row);
+        const int py = fr.row_offset + row * fr.row_stride;
+        seed         = make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed);
+    }
+    out.b_seed = seed;
 #ifdef IG_EXP_CHEAP_SEED // experiment: what do the seed hash and the three integer divisions in front of it cost? (wrong images)
     Tea rnd{ (uint32_t)in.ray_id * 747796405u + 12345u, in.rnd };
 #else
-    Tea rnd{ make_seed(sample, fr.iteration + it_l, fr.frame, px, py, fr.seed), in.rnd };
+    Tea rnd{ seed, in.rnd };
 #endif
 
     if constexpr (FULL && DEBUG_VIEWS) {

@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
         clk.mark(0); // the sort
         PathVertexOut out;
         out.bounce = out.shadow = out.has_radiance = false;
+        out.b_seed = 0u;
         int ray_id = 0;
         int in_ent_for_bin = 0;
         int s_slot = 0; // light tracer: the accumulator slot of the pixel a connection lands in
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             in.contrib = Col{ pay.y, pay.z, pay.w };
             in.depth   = meta.w;
             in.eta     = a.in_kind == kStreamShaded ? igm_float((uint32_t)meta.y) : 1.0f;
+            in.seed    = a.in_kind == kStreamShaded ? igm_bits(rb.w) : 0u;
             in.ent     = in_ent_for_bin = (int)igm_bits(hit.x);
             in.prim    = (int)igm_bits(hit.y);
             in.t = hit.z, in.u = hit.w;
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             if (out.bounce) {
                 const uint32_t o = s_base[0] + s_binoff[bkey] + brank;
                 a.out.rayA[o] = make_float4(out.b_org.x, out.b_org.y, out.b_org.z, FULL ? out.b_tmin : kRayOffset);
-                a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, kFltMax);
+                a.out.rayB[o] = make_float4(out.b_dir.x, out.b_dir.y, out.b_dir.z, igm_float(out.b_seed)); // (kStreamShaded: tmax is FLT_MAX for every bounce ray)
                 a.out.meta[o] = make_int4(ray_id, (int32_t)igm_bits(out.b_eta), (int32_t)out.b_rnd, out.b_depth); // (kStreamShaded: eta where the flags were)
                 a.out.pay[o]  = make_float4(out.b_inv_pdf, out.b_contrib.r, out.b_contrib.g, out.b_contrib.b);
             }

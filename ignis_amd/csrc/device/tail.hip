@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
     bool have = false;
     PathVertexIn in{};
     float tmin = 0, tmax = 0;
-    uint32_t flags = 0;
+    uint32_t flags = 0, seed = 0;
     float4 acc     = make_float4(0, 0, 0, 0);
     bool exhausted = false;
     int hops       = 0; // bounces this lane has followed its current path for
@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 in.contrib = Col{ pay.y, pay.z, pay.w };
                 in.depth   = meta.w;
                 in.eta     = a.in_kind == kStreamShaded ? igm_float((uint32_t)meta.y) : 1.0f;
-                tmin = ra.w, tmax = rb.w;
+                tmin = ra.w, tmax = a.in_kind == kStreamShaded ? kFltMax : rb.w;
+                seed = a.in_kind == kStreamShaded ? igm_bits(rb.w) : 0u; // (kernels.h kStream*: a shaded stream keeps the path's seed there)
                 flags = a.in_kind == kStreamShaded ? (uint32_t)IG_RAY_FLAG_BOUNCE : (uint32_t)meta.y;
                 acc   = a.accum[(int64_t)in.ray_id - a.id_base]; // owned by this path until it ends
                 hops  = 0;
@@ -222,7 +223,9 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
 
         PathVertexOut out;
         out.shadow = out.bounce = out.has_radiance = false;
+        out.b_seed = 0u;
         if (have) {
+            in.seed = seed;
             shade_vertex<FULL>(sc, a.frame, in, out);
             if (out.has_radiance) {
                 acc.x += out.radiance.r * a.inv_spi;
@@ -290,6 +293,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                 in.org     = out.b_org;
                 in.dir     = out.b_dir;
                 in.rnd     = out.b_rnd;
+                seed       = out.b_seed;
                 in.inv_pdf = out.b_inv_pdf;
                 in.contrib = out.b_contrib;
                 in.depth   = out.b_depth;
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
             if (spill) {
                 const uint32_t o = base + (uint32_t)__popcll(mspill & ((1ull << lane) - 1ull));
                 a.out.rayA[o] = make_float4(in.org.x, in.org.y, in.org.z, tmin);
-                a.out.rayB[o] = make_float4(in.dir.x, in.dir.y, in.dir.z, tmax);
+                a.out.rayB[o] = make_float4(in.dir.x, in.dir.y, in.dir.z, igm_float(seed)); // (kStreamShaded: a bounce ray's tmax is FLT_MAX)
                 a.out.meta[o] = make_int4(in.ray_id, (int32_t)igm_bits(in.eta), (int32_t)in.rnd, in.depth); // (kStreamShaded; a spilled path has bounced: its flags are IG_RAY_FLAG_BOUNCE)
                 a.out.pay[o]  = make_float4(in.inv_pdf, in.contrib.r, in.contrib.g, in.contrib.b);
                 a.accum[(int64_t)in.ray_id - a.id_base] = acc;

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 tr.begin(fill, a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, h.z, flags);
                 tr.set_initial_hit(fill, (int)igm_bits(h.x), (int)igm_bits(h.y), h.w, hv);
             } else {
-                tr.begin(fill, a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, rb.w, flags);
+                tr.begin(fill, a.scene, s_stack, tid, f3{ ra.x, ra.y, ra.z }, f3{ rb.x, rb.y, rb.z }, ra.w, a.use_uniform_tmax ? a.uniform_tmax : rb.w, flags);
             }
             has_ray |= fill;
             batch_next += take;
