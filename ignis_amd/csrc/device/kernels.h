@@ -236,6 +236,7 @@ struct GenerateArgs {
     FastDiv by_rays_per_iteration, by_spi, by_width; // (launch_generate fills them)
     const float* list_rays;         // list emitter (emitter.art:18-30): 8 floats per ray, or nullptr
     int32_t compact;                // CameraStream::compact: only rayB is written
+    float4* accum_clear;            // the chunk's per-sample accumulators, cleared here (sample i <-> slot i) instead of by a memset of their own; or null
     // Halton pixel sampler (sampler/pixel_sampler.art:101-150): what setup_halton_pixel_sampler derives from the film
     // size, filled by launch_generate; the per-pixel offset it keeps in "__halton_offset" is recomputed per sample
     uint32_t halton_scale_x, halton_scale_y, halton_exp_x, halton_exp_y;

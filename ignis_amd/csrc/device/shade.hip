@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(256) k_generate(const GenerateArgs a)
     }
 
     a.out.rayB[i] = make_float4(dir.x, dir.y, dir.z, tmax);
+    if (a.accum_clear)
+        a.accum_clear[i] = make_float4(0, 0, 0, 0);
     if (a.compact)
         return; // (CameraStream::compact: origin, near clip, flags, depth and the generator's counter are the same for every ray)
     a.out.rayA[i] = make_float4(org.x, org.y, org.z, tmin);
