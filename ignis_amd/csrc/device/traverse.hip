@@ -12,6 +12,9 @@
 #ifndef IG_QNODE
 #define IG_QNODE 0
 #endif
+#ifndef IG_DEFER_HIT_STORE
+#define IG_DEFER_HIT_STORE 1 // the results of finished rays go out at the wave's next refill (one store instruction for all of them) instead of in the pass they end in (0); profiles/r05_experiment_ab.txt section 23
+#endif
 #ifndef IG_SPLAT_PREFETCH
 #define IG_SPLAT_PREFETCH 1 // the shadow ray's accumulator fetched with the ray (0: read in the epilogue); profiles/r05_experiment_ab.txt section 16
 #endif
@@ -66,6 +69,54 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     // wave-local batch of reserved ray indices (uniform across the wave)
     uint32_t batch_next = 0, batch_end = 0;
     bool exhausted = false;
+    mask_t unsent = 0; // IG_DEFER_HIT_STORE: lanes whose ray has ended and whose hit is still in the traverser's registers
+    // what a finished ray leaves behind (called for the lanes concerned, inside a region): the closest hit's row; the shadow ray's verdict
+    // and, unoccluded, its colour into the sample's accumulator. With IG_DEFER_HIT_STORE the lanes wait in `unsent` until the wave's next
+    // refill (their results are in registers the refill overwrites, not before) and go out in one instruction each instead of one per pass.
+    // (closest hit only: deferring the shadow rays' read-modify-write costs their launch 10 %, section 23)
+    constexpr bool kDefer = IG_DEFER_HIT_STORE && !ANY_HIT;
+    const auto commit = [&]() {
+        if (ANY_HIT) {
+            if (a.hit)
+                a.hit[ray_idx] = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
+            if (tr.hit_prim < 0 && a.sphere_pass != 1) { // (with a sphere pass to come, the verdict is its)
+                if (STATS)
+                    ++st_unoccluded;
+                if (a.accum) {
+                    // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample accumulator: a plain
+                    // read-modify-write, the slot is owned by this ray's sample for the length of the launch. The colour came
+                    // with the ray. (No-return float atomics instead are bit-identical but slower: the epilogue +25 %,
+                    // profiles/r03_experiment_shade.txt.)
+                    const float4 c = splat;
+                    float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
+                    // (the light tracer's connections add into the slots of OTHER paths' pixels: its launches pass no accumulator and
+                    // record verdicts only, launch_lt_splat adds them in a fixed order afterwards, photon.hip)
+#if IG_SPLAT_PREFETCH
+                    float4 v = acc_pre;
+#else
+                    float4 v = *dst;
+#endif
+                    v.x += c.x * a.inv_spi;
+                    v.y += c.y * a.inv_spi;
+                    v.z += c.z * a.inv_spi;
+                    *dst = v;
+                    if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
+                        float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
+                        float4 w   = *nd;
+                        w.x += c.x * a.inv_spi;
+                        w.y += c.y * a.inv_spi;
+                        w.z += c.z * a.inv_spi;
+                        *nd = w;
+                    }
+                }
+            }
+        } else if (a.hit_pack) {
+            a.hit[ray_idx] = pack_hit(a.hit_pack, tr.hit_ent, tr.hit_prim, tr.tmax, tr.hit_u, tr.hit_v);
+        } else {
+            a.hit[ray_idx]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
+            a.hit_v[ray_idx] = tr.hit_v;
+        }
+    };
 
     for (;;) {
         tr.mark(0); // epilogue of the previous pass (hit stores / splat), loop bookkeeping
@@ -99,6 +150,12 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             float4 ra = make_float4(0, 0, 0, 0), rb = ra, h = ra;
             uint32_t flags = a.uniform_flags;
             float hv       = 0;
+            if (kDefer) {
+                if (in(unsent))
+                    commit();
+                region_end();
+                unsent = 0;
+            }
             if (in(fill)) {
                 const uint32_t idx = (DEEP && a.index_list) ? a.index_list[batch_next + rank] : batch_next + rank; // (DEEP as the primary kernel: no list)
                 ray_idx = idx;
@@ -159,52 +216,19 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 }
                 region_end();
             }
-            if (in(ended & ~lost)) {
-                if (ANY_HIT) {
-                    if (a.hit)
-                        a.hit[ray_idx] = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
-                    if (tr.hit_prim < 0 && a.sphere_pass != 1) { // (with a sphere pass to come, the verdict is its)
-                        if (STATS)
-                            ++st_unoccluded;
-                        if (a.accum) {
-                            // gpu_traverse_secondary splat (mapping_gpu.art:96-117) into the per-sample accumulator: a plain
-                            // read-modify-write, the slot is owned by this ray's sample for the length of the launch. The colour came
-                            // with the ray. (No-return float atomics instead are bit-identical but slower: the epilogue +25 %,
-                            // profiles/r03_experiment_shade.txt.)
-                            const float4 c = splat;
-                            float4* dst    = a.accum + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                            // (the light tracer's connections add into the slots of OTHER paths' pixels: its launches pass no accumulator and
-                            // record verdicts only, launch_lt_splat adds them in a fixed order afterwards, photon.hip)
-#if IG_SPLAT_PREFETCH
-                            float4 v = acc_pre;
-#else
-                            float4 v = *dst;
-#endif
-                            v.x += c.x * a.inv_spi;
-                            v.y += c.y * a.inv_spi;
-                            v.z += c.z * a.inv_spi;
-                            *dst = v;
-                            if (a.accum_nee) { // aov_nee.splat in on_shadow_miss (technique/pathtracer.art:212-218)
-                                float4* nd = a.accum_nee + ((int64_t)(int32_t)igm_bits(c.w) - a.id_base);
-                                float4 w   = *nd;
-                                w.x += c.x * a.inv_spi;
-                                w.y += c.y * a.inv_spi;
-                                w.z += c.z * a.inv_spi;
-                                *nd = w;
-                            }
-                        }
-                    }
-                } else {
-                    if (a.hit_pack) {
-                        a.hit[ray_idx] = pack_hit(a.hit_pack, tr.hit_ent, tr.hit_prim, tr.tmax, tr.hit_u, tr.hit_v);
-                    } else {
-                        a.hit[ray_idx]   = make_float4(igm_float((uint32_t)tr.hit_ent), igm_float((uint32_t)tr.hit_prim), tr.tmax, tr.hit_u);
-                        a.hit_v[ray_idx] = tr.hit_v;
-                    }
-                }
+            if (kDefer) {
+                unsent |= ended & ~lost;
+            } else {
+                if (in(ended & ~lost))
+                    commit();
+                region_end();
             }
-            region_end();
         }
+    }
+    if (kDefer) {
+        if (in(unsent))
+            commit();
+        region_end();
     }
 
     if (fatal)
