@@ -236,6 +236,8 @@ struct igd_device {
     // pack_hit; igd_assign_scene: the entity count and the largest mesh fit 32 bits together, no analytic spheres). IGD_HIT_PACK=0: never
     uint32_t hit_pack_bits = 0;
     bool hit_pack_allowed  = true;
+    int work_shards_env = -1;      // IGD_WORK_SHARDS: 1 = the rays of a traversal launch handed out by one counter, 8 = in shares (kernels.h WorkCounters); default by the size of the BVH
+    int work_shards = kWorkShards;
     bool clear_in_generate = true; // IGD_CLEAR_IN_GENERATE=0: a memset of the chunk's accumulators in front of k_generate instead of inside it
     bool camera_compact    = true; // IGD_CAMERA_COMPACT=0: camera streams with every column although the rays all leave one point (kernels.h CameraStream)
     bool skip_misses       = true; // IGD_SKIP_MISSES=0: k_shade reads a miss's columns although the scene has no environment light (ShadeArgs::skip_misses)
@@ -457,8 +459,10 @@ namespace {
 int guarded(const char* what, const std::function<void()>& fn);
 
 // the traversal kernels of the scene's node format (traverse.hip is compiled once per format)
-void launchTraverse(const igd_device* d, const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks, bool deep_primary)
+void launchTraverse(const igd_device* d, const TraverseArgs& args_in, bool any_hit, bool stats, int grid_blocks, uint32_t* deep_work_counter, hipStream_t stream, int deep_grid_blocks, bool deep_primary)
 {
+    TraverseArgs args = args_in;
+    args.work_shards  = (uint32_t)d->work_shards;
     (d->q8_nodes ? launch_traverse_q8 : launch_traverse)(args, any_hit, stats, grid_blocks, deep_work_counter, stream, deep_grid_blocks, deep_primary);
 }
 
@@ -922,6 +926,9 @@ void assignScene(igd_device* d, const igd_scene* s)
     }
     // (the 8 L2s hold 32 MB together; the switch sits at twice that, 64 MB, where the stand-in sweep put the break-even: below it most visits
     // still hit an L2 and the repeats run for too few lanes)
+    // a BVH beyond the caches is better walked by ONE front of rays (what the XCDs' L2s and the Infinity Cache hold is then the same part of it);
+    // such rays are slow enough for one counter (profiles/r05_experiment_ab.txt section 26)
+    d->work_shards          = d->work_shards_env > 0 ? d->work_shards_env : (blob.size() > ((size_t)64 << 20) ? 1 : kWorkShards);
     ds.node_repeat          = d->node_repeat >= 0 ? (uint32_t)d->node_repeat : (blob.size() > ((size_t)64 << 20) ? 3u : 0u);
     ds.scene_radius         = s->scene_radius;
     for (int k = 0; k < 3; ++k) {
@@ -1078,7 +1085,7 @@ void resizeFb(igd_device* d, int w, int h)
 void readQueueState(igd_device* d, const QueueState* dev_qs, QueueState& out)
 {
     QueueState* slot = d->host_store + igd_device::kMaxFlights + 2;
-    HIP_CHECK(hipMemcpyAsync(slot, dev_qs, sizeof(QueueState), hipMemcpyDeviceToHost, d->stream));
+    HIP_CHECK(hipMemcpyAsync(slot, dev_qs, kQueueStateHead, hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
     out = *slot;
 }
@@ -1389,13 +1396,13 @@ void render(igd_device* d, const igd_render_settings* rs)
                     ta.use_uniform_tmax = 1;
                 }
                 ta.count        = &lq->q[lslot].primary;
-                ta.work_counter = &lq->work_counter[0];
+                ta.work_counter = &lq->work[0].w[0][0];
                 ta.index_list   = d->deep_rays.ptr;
                 ta.index_count  = &lq->deep_count;
                 ta.qs           = lq;
                 ta.hit = in.hit, ta.hit_v = in.hit_v;
-                ta.sphere_work_counter = &lq->work_counter[4];
-                launchTraverse(d, ta, false, counters, d->traverseGrid(), &lq->work_counter[1], st, d->deep_grid, d->deep_primary);
+                ta.sphere_work_counter = &lq->work[4].w[0][0];
+                launchTraverse(d, ta, false, counters, d->traverseGrid(), &lq->work[1].w[0][0], st, d->deep_grid, d->deep_primary);
                 ShadeArgs sa{};
                 sa.scene     = d->dscene;
                 sa.in        = in;
@@ -1420,7 +1427,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                     break;
             }
             QueueState host{};
-            HIP_CHECK(hipMemcpyAsync(&host, lq, sizeof(QueueState), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(&host, lq, kQueueStateHead, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             if (host.error_flags & 1u)
                 throw HipError{ IGD_ERR_DEVICE, "traversal stack overflow (BVH deeper than the LDS stack)" };
@@ -1489,13 +1496,13 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.scene = d->dscene;
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
             ta.count        = &iq->q[0].primary;
-            ta.work_counter = &iq->work_counter[0];
+            ta.work_counter = &iq->work[0].w[0][0];
             ta.index_list   = d->deep_rays.ptr;
             ta.index_count  = &iq->deep_count;
             ta.qs           = iq;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
-            ta.sphere_work_counter = &iq->work_counter[4];
-            launchTraverse(d, ta, false, false, d->traverseGrid(), &iq->work_counter[1], st, d->deep_grid, d->deep_primary);
+            ta.sphere_work_counter = &iq->work[4].w[0][0];
+            launchTraverse(d, ta, false, false, d->traverseGrid(), &iq->work[1].w[0][0], st, d->deep_grid, d->deep_primary);
             InfoArgs ia{};
             ia.scene   = d->dscene;
             ia.in      = in;
@@ -1675,14 +1682,14 @@ void render(igd_device* d, const igd_render_settings* rs)
                 ta.uniform_flags = IG_RAY_FLAG_CAMERA;
             }
             ta.count        = &qs->q[in_slot].primary;
-            ta.work_counter = &qs->work_counter[0];
+            ta.work_counter = &qs->work[0].w[0][0];
             ta.index_list   = b.deep_rays;
             ta.index_count  = &qs->deep_count;
             ta.qs           = qs;
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.hit_pack = d->hit_pack_bits;
-            ta.sphere_work_counter = &qs->work_counter[4];
-            timed(1, on, [&] { launchTraverse(d, ta, false, counters, trav_grid, &qs->work_counter[1], on, d->deep_grid, d->deep_primary); });
+            ta.sphere_work_counter = &qs->work[4].w[0][0];
+            timed(1, on, [&] { launchTraverse(d, ta, false, counters, trav_grid, &qs->work[1].w[0][0], on, d->deep_grid, d->deep_primary); });
 
             ShadeArgs sa{};
             sa.scene     = d->dscene;
@@ -1748,13 +1755,13 @@ void render(igd_device* d, const igd_render_settings* rs)
             tb.rayA = b.sec.rayA, tb.rayB = b.sec.rayB, tb.meta = nullptr;
             tb.uniform_flags = d->dscene.tech.type == IG_TECHNIQUE_AO ? IG_RAY_FLAG_BOUNCE : IG_RAY_FLAG_SHADOW; // aotracer.art:13
             tb.count         = &qs->q[in_slot ^ 1].secondary; // generated by this round's k_shade
-            tb.work_counter  = &qs->work_counter[2];
+            tb.work_counter  = &qs->work[2].w[0][0];
             tb.index_list    = b.deep_rays;
             tb.index_count   = &qs->deep_count;
             tb.qs            = qs;
             tb.col     = b.sec.col;
             tb.hit     = b.sec_hit; // only with a sphere pass (null otherwise)
-            tb.sphere_work_counter = &qs->work_counter[5];
+            tb.sphere_work_counter = &qs->work[5].w[0][0];
             tb.accum   = accum;
             tb.accum_nee = accum_mis[1];
             tb.id_base = first;
@@ -1765,7 +1772,7 @@ void render(igd_device* d, const igd_render_settings* rs)
                 tb.hit   = reinterpret_cast<float4*>(d->secondary_hit.ptr);
             }
             timed(3, on, [&] {
-                launchTraverse(d, tb, true, counters, trav_grid, &qs->work_counter[3], on, d->deep_grid, d->deep_primary);
+                launchTraverse(d, tb, true, counters, trav_grid, &qs->work[3].w[0][0], on, d->deep_grid, d->deep_primary);
                 if (light_tracer)
                     HIP_CHECK(launch_lt_splat(b.sec.col, reinterpret_cast<const float4*>(d->secondary_hit.ptr), b.sec.path_id, &qs->q[in_slot ^ 1].secondary, round_bound,
                                               d->lt_keys.ptr, d->lt_vals.ptr, d->lt_temp.ptr, d->lt_temp.count, accum, first, inv, on));
@@ -1896,7 +1903,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             }
         HIP_CHECK(hipEventRecord(fl.resolved, side));
         fl.used = true;
-        HIP_CHECK(hipMemcpyAsync(fl.host, qs, sizeof(QueueState), hipMemcpyDeviceToHost, side));
+        HIP_CHECK(hipMemcpyAsync(fl.host, qs, kQueueStateHead, hipMemcpyDeviceToHost, side));
         HIP_CHECK(hipEventRecord(fl.done, side));
     }
     HIP_CHECK(hipGetLastError());
@@ -1949,22 +1956,23 @@ void traverseList(igd_device* d, int64_t count, const float* rays, uint32_t ray_
     ta.meta          = nullptr;
     ta.uniform_flags = ray_flags;
     ta.count         = &qs->q[0].primary;
-    ta.work_counter  = &qs->work_counter[0];
+    ta.work_counter  = &qs->work[0].w[0][0];
     ta.index_list    = deep_rays.ptr;
     ta.index_count   = &qs->deep_count;
     ta.qs            = qs;
     ta.hit           = reinterpret_cast<float4*>(out.ptr);
     ta.hit_v         = out.ptr + n * 4;
-    ta.sphere_work_counter = &qs->work_counter[any_hit ? 5 : 4];
+    ta.sphere_work_counter = &qs->work[any_hit ? 5 : 4].w[0][0];
 
     const bool stats = d->setup.acquire_stats >= 2;
     if (repeat < 1)
         repeat = 1;
     float total_ms = 0;
     for (int r = 0; r < repeat; ++r) {
-        HIP_CHECK(hipMemsetAsync(&qs->work_counter[0], 0, sizeof(qs->work_counter) + sizeof(qs->deep_count), st));
+        HIP_CHECK(hipMemsetAsync(&qs->work[0], 0, sizeof(qs->work), st));
+        HIP_CHECK(hipMemsetAsync(&qs->deep_count, 0, sizeof(qs->deep_count), st));
         HIP_CHECK(hipEventRecord(d->event(0), st));
-        launchTraverse(d, ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work_counter[1], st, d->deep_grid, d->deep_primary);
+        launchTraverse(d, ta, any_hit != 0, stats && r == 0, d->traverseGrid(), &qs->work[1].w[0][0], st, d->deep_grid, d->deep_primary);
         HIP_CHECK(hipEventRecord(d->event(1), st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms = 0;
@@ -2216,6 +2224,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
+        if (const char* e = std::getenv("IGD_WORK_SHARDS"))
+            d->work_shards_env = std::atoi(e) > 1 ? kWorkShards : 1;
         if (const char* e = std::getenv("IGD_CLEAR_IN_GENERATE"))
             d->clear_in_generate = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_CAMERA_COMPACT"))

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "ig_tables.h"
@@ -137,6 +138,20 @@ struct SecondaryCols {
 
 // Device-resident queue state: no host round trip per bounce (the reference reads counters back
 // 3x per bounce, mapping_gpu.art:457-465,686-711).
+// The ray indices of a traversal launch are handed out by kWorkShards counters, each on a cache line of its own and each over its own
+// contiguous share of the stream: one counter word sustains ~88 atomics / us, which at 64 rays per reservation is the very rate the
+// headline scene's closest-hit launches run at (5.5 G rays / s) — a launch of a few million rays spent most of its time in that queue
+// (profiles/r05_experiment_ab.txt section 26). The workgroups of one XCD (blockIdx mod 8) start on the same share(s), so that an XCD's L2 sees one
+// front of the stream, not all of them; a wave moves on to the next share when its own is used up.
+#ifndef IG_WORK_SHARDS
+#define IG_WORK_SHARDS 8
+#endif
+constexpr int kWorkShards     = IG_WORK_SHARDS; // a multiple of the 8 XCDs
+constexpr int kWorkShardWords = 32; // 128 bytes between two counters
+struct WorkCounters {
+    uint32_t w[kWorkShards][kWorkShardWords];
+};
+
 struct QueueState {
     // q[s].primary: size of primary stream s; q[s].secondary: shadow rays generated together with it. The pair is one
     // aligned 64-bit word so that k_shade reserves space in both queues with ONE atomic (a counter word sustains only
@@ -145,7 +160,6 @@ struct QueueState {
         uint32_t primary, secondary;
     };
     alignas(8) Counts q[2];
-    uint32_t work_counter[6];  // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch, [4] / [5] the sphere passes
     uint32_t deep_count;       // rays of the traversal launch in flight whose stack outgrew LDS (re-traversed by the DEEP launch)
     // ---- from here on: cleared once per igd_render, not per chunk
     uint32_t error_flags;      // bit 0: traversal stack overflow
@@ -156,7 +170,11 @@ struct QueueState {
     unsigned long long nodes[2], tris[2], leaves[2]; // [0] closest-hit launches, [1] any-hit launches
     unsigned long long section_passes[6], section_lanes[6]; // igd_stats: wave-level section executions and the lanes with work in them
     uint32_t tail_pass_in[24]; // paths each pass of the chunk's tail started with (tail.hip): the host sizes the next chunk's passes by them
+    // ---- not part of what the host mirrors (kQueueStateHead bytes)
+    // dynamic ray fetch: [0] traverse primary, [1] its DEEP launch, [2] traverse secondary, [3] its DEEP launch, [4] / [5] the sphere passes
+    alignas(128) WorkCounters work[6];
 };
+constexpr size_t kQueueStateHead = offsetof(QueueState, work);
 
 // The hit of a closest-hit launch in ONE 16-byte row (round 5): x = (entity << bits) | prim (all ones: a miss), y = t, z = u, w = v —
 // when the scene's entity count and largest mesh fit 32 bits together (igd_assign_scene decides; `bits` = 0: the two-column form
@@ -186,7 +204,7 @@ struct TraverseArgs {
     // DEEP launch: the rays to traverse are index_list[0 .. *count)
     uint32_t* index_list;
     uint32_t* index_count;
-    uint32_t* work_counter; // zero before launch
+    uint32_t* work_counter; // a WorkCounters (kWorkShards counters, kWorkShardWords apart), zero before launch
     QueueState* qs;
     // outputs: hit = (ent_id, prim_id, t, u), hit_v = v. Any-hit launches may leave them null.
     float4* hit;
@@ -204,7 +222,8 @@ struct TraverseArgs {
     // scenes with analytic spheres: the launch over the triangle BVH is followed by one over the sphere BVH that starts from its
     // hits. 0: single pass; 1: first of two (any-hit: the hit must be stored and the splat is left to the second); 2: the sphere pass
     int32_t sphere_pass;
-    uint32_t* sphere_work_counter; // zero before launch
+    uint32_t* sphere_work_counter; // (a WorkCounters too) zero before launch
+    uint32_t work_shards;          // > 1: the stream is handed out in kWorkShards shares (1: by the first counter alone)
 };
 
 // k_generate_light: make_lt_emitter (technique/lighttracer.art:35-62), one light path per ray id

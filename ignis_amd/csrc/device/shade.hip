@@ -276,17 +276,14 @@ __global__ void __launch_bounds__(256) k_generate_light(const GenerateLightArgs 
 // mapping_gpu.art:864, ShadowRayCount :857 -- real shadow rays here) and counter resets.
 __global__ void k_round_end(QueueState* qs, int in_slot)
 {
+    if (threadIdx.x < kWorkShards && blockIdx.x == 0)
+        for (int k = 0; k < 6; ++k)
+            qs->work[k].w[threadIdx.x][0] = 0;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const int out_slot = in_slot ^ 1;
         qs->bounce_rays += qs->q[out_slot].primary;
         qs->shadow_rays += qs->q[out_slot].secondary;
         qs->q[in_slot].primary = 0; // becomes the append target of the next round (its .secondary is already 0)
-        qs->work_counter[0]        = 0;
-        qs->work_counter[1]        = 0;
-        qs->work_counter[2]        = 0;
-        qs->work_counter[3]        = 0;
-        qs->work_counter[4]        = 0;
-        qs->work_counter[5]        = 0;
         qs->deep_total += qs->deep_count;
         qs->deep_count             = 0;
     }
@@ -298,17 +295,21 @@ __global__ void k_round_end(QueueState* qs, int in_slot)
 // hipMemcpyAsync D2H put ~155 us of engine hand-over between the shadow traversal and the next round).
 __global__ void k_secondary_end(QueueState* qs, int slot, QueueState* mirror)
 {
+    if (threadIdx.x < kWorkShards && blockIdx.x == 0)
+        qs->work[2].w[threadIdx.x][0] = 0, qs->work[3].w[threadIdx.x][0] = 0, qs->work[5].w[threadIdx.x][0] = 0;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         qs->q[slot].secondary = 0;
-        qs->work_counter[2] = 0;
-        qs->work_counter[3] = 0;
-        qs->work_counter[5] = 0;
         qs->deep_total += qs->deep_count;
         qs->deep_count      = 0;
-        if (mirror) {
-            *mirror = *qs;
-            __threadfence_system();
-        }
+    }
+    if (mirror && blockIdx.x == 0) {
+        // (everything but the work counters, a word per thread and trip)
+        __syncthreads();
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(qs);
+        uint32_t* dst       = reinterpret_cast<uint32_t*>(mirror);
+        for (uint32_t i = threadIdx.x; i < kQueueStateHead / 4; i += blockDim.x)
+            dst[i] = src[i];
+        __threadfence_system();
     }
 }
 

@@ -8,6 +8,12 @@
 // Compiled twice: as is (Node8 records, launch_traverse) and with -DIG_QNODE=1 (the 128-byte quantised node records of
 // DevScene::node_format, launch_traverse_q8); device.hip picks by the scene.
 #include "traverse_core.h"
+#ifdef IG_TRAV_TIMELINE
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 #ifndef IG_QNODE
 #define IG_QNODE 0
@@ -23,6 +29,9 @@ namespace igdev {
 
 constexpr bool kQNode = IG_QNODE != 0;
 
+#ifndef IG_MIN_RAY_BATCH
+#define IG_MIN_RAY_BATCH 64 // smallest reservation of ray indices (the end of a stream)
+#endif
 #ifndef IG_REFILL_IDLE
 #define IG_REFILL_IDLE 24
 #endif
@@ -32,6 +41,13 @@ constexpr bool kQNode = IG_QNODE != 0;
 constexpr int kRefillIdleClosest = IG_REFILL_IDLE;     // refill when at least this many lanes of a wave are idle
 constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit launches (shorter rays)
 constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
+
+#ifdef IG_TRAV_TIMELINE
+// variant build (tools/trav_timeline.sh): when each wave of a launch started, ran out of rays to fetch, ended, and how many rays it took
+// (100 MHz wall clock); launch_traverse prints the summary of every non-DEEP launch to the file IGD_TRAV_TIMELINE names
+constexpr int kTimelineWaves = 1 << 14;
+__device__ unsigned long long g_timeline[kTimelineWaves * 4];
+#endif
 
 template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false, bool QNODE = false>
 __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const TraverseArgs a)
@@ -47,15 +63,26 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
     // Guided self-scheduling: a wave asks for (what it believes is left) / (4 x waves) rays, between 64 and
     // kMaxRayBatch. Large batches keep the shared counter cold while the stream is long; towards its end the
     // batches shrink to one wave's worth, so the launch does not end with a few waves chewing on 1024 rays
-    // each while the rest of the chip idles.
+    // each while the rest of the chip idles. The stream is cut into kWorkShards contiguous shares with a counter each (kernels.h
+    // WorkCounters): a wave draws from the share it starts on until that is used up, then from the next one, one probe per pass.
     const uint32_t total_waves = gridDim.x * (kBlockThreads / 64);
-    uint32_t last_base         = 0; // where the previous reservation of this wave started
+    const uint32_t n_shards    = a.work_shards > 1u ? (uint32_t)kWorkShards : 1u; // (1: one front over the whole stream, what a BVH beyond the caches wants)
+    const uint32_t shard_waves = total_waves >= n_shards ? total_waves / n_shards : 1u;
+    const uint32_t shard_rays  = ((count + n_shards - 1u) / n_shards + 63u) & ~63u; // rays per share (the last ones may be short or empty)
+    // (workgroups go to the XCDs round-robin: blockIdx mod 8 is the XCD, whose workgroups share kWorkShards / 8 shares)
+    uint32_t shard = n_shards == 1u ? 0u : ((blockIdx.x % 8u) * (uint32_t)(kWorkShards / 8) + (blockIdx.x / 8u) % (uint32_t)(kWorkShards / 8));
+    uint32_t shards_left = n_shards; // shares this wave has not seen the end of
+    uint32_t last_off          = 0; // where, in its share, the previous reservation of this wave started
 
     Traverser<ANY_HIT, STATS, kBlockThreads, DEEP, SPHERES, QNODE> tr;
     tr.attach_deep(a.scene.deep_stack + (blockIdx.x * kBlockThreads + tid), a.scene.deep_stride);
     tr.init_counters();
     tr.clk_start();
     tr.prof_start();
+#ifdef IG_TRAV_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_dry = 0, tl_rays = 0;
+#endif
     mask_t has_ray         = 0; // lanes with a ray in flight (a lane mask in scalar registers, like the traverser's)
     uint32_t ray_idx       = 0;
     uint32_t st_unoccluded = 0;
@@ -127,19 +154,30 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         const int n_idle  = lanes_in(idle);
         if (n_idle >= (ANY_HIT ? kRefillIdleAny : kRefillIdleClosest) && !(exhausted && batch_next >= batch_end)) {
             if (batch_next >= batch_end) {
-                const uint32_t left = count > last_base ? count - last_base : 0u;
-                uint32_t kRayBatch  = left / (total_waves * 4u);
-                kRayBatch           = kRayBatch < 64u ? 64u : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
-                kRayBatch &= ~63u;
-                uint32_t base = 0;
-                if (lane == 0)
-                    base = atomicAdd(a.work_counter, (uint32_t)kRayBatch);
-                base       = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); // wave-uniform by construction: keeps the batch bookkeeping (and the loop) scalar
-                last_base  = base;
-                batch_next = base < count ? base : count;
-                batch_end  = base + kRayBatch < count ? base + kRayBatch : count;
-                if (base + kRayBatch >= count)
-                    exhausted = true;
+                const uint32_t lo  = shard * shard_rays;
+                const uint32_t len = lo < count ? (count - lo < shard_rays ? count - lo : shard_rays) : 0u; // rays of this share
+                bool share_done    = true;
+                if (len) {
+                    const uint32_t left = len > last_off ? len - last_off : 0u;
+                    uint32_t kRayBatch  = left / (shard_waves * 4u);
+                    kRayBatch           = kRayBatch < (uint32_t)IG_MIN_RAY_BATCH ? (uint32_t)IG_MIN_RAY_BATCH : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
+                    kRayBatch &= ~63u;
+                    uint32_t off = 0;
+                    if (lane == 0)
+                        off = atomicAdd(a.work_counter + shard * (uint32_t)kWorkShardWords, (uint32_t)kRayBatch);
+                    off        = (uint32_t)__builtin_amdgcn_readfirstlane((int)off); // wave-uniform by construction: keeps the batch bookkeeping (and the loop) scalar
+                    last_off   = off;
+                    batch_next = lo + (off < len ? off : len);
+                    batch_end  = lo + (off + kRayBatch < len ? off + kRayBatch : len);
+                    share_done = off + kRayBatch >= len;
+                }
+                if (share_done) {
+                    // (this reservation was the share's last, or came too late: the next one goes to the next share)
+                    shard    = shard + 1u == n_shards ? 0u : shard + 1u;
+                    last_off = 0xFFFFFFFFu; // (how far the others have come there is not known: the smallest reservation first)
+                    if (--shards_left == 0)
+                        exhausted = true;
+                }
             }
             tr.prof(1);
             IG_MARK("refill");
@@ -188,12 +226,19 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
             }
             has_ray |= fill;
             batch_next += take;
+#ifdef IG_TRAV_TIMELINE
+            tl_rays += take;
+#endif
             IG_MARK("refill.end");
         }
         // (no `continue` for the wave that got no ray out of a refill: a second back edge makes the compiler rotate the loop-carried
         // state registers through copies at the end of every pass; an empty step() is a few scalar instructions, once per launch)
         if (!has_ray && exhausted && batch_next >= batch_end)
             break;
+#ifdef IG_TRAV_TIMELINE
+        if (!tl_dry && exhausted && batch_next >= batch_end)
+            tl_dry = wall_clock64();
+#endif
 
         tr.mark(5); // refill: batch reservation, ray loads, begin()
         tr.step(a.scene, s_stack, tid);
@@ -231,6 +276,15 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
         region_end();
     }
 
+#ifdef IG_TRAV_TIMELINE
+    if (!DEEP && !SPHERES && lane == 0) {
+        const unsigned w = blockIdx.x * (kBlockThreads / 64) + tid / 64;
+        if (w < (unsigned)kTimelineWaves) {
+            const unsigned long long tl_end = wall_clock64();
+            g_timeline[w * 4 + 0] = tl_start, g_timeline[w * 4 + 1] = tl_dry ? tl_dry : tl_end, g_timeline[w * 4 + 2] = tl_end, g_timeline[w * 4 + 3] = tl_rays;
+        }
+    }
+#endif
     if (fatal)
         atomicOr(&a.qs->error_flags, 1u);
 #ifdef IG_TRAV_PROFILE
@@ -308,6 +362,37 @@ void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int 
         launch_one<true>(all, any_hit, stats, grid_blocks, stream);
     } else {
         launch_one<false>(args, any_hit, stats, grid_blocks, stream);
+#ifdef IG_TRAV_TIMELINE
+        if (const char* path = std::getenv("IGD_TRAV_TIMELINE")) {
+            (void)hipStreamSynchronize(stream);
+            const int waves = std::min(kTimelineWaves, grid_blocks * (kBlockThreads / 64));
+            std::vector<unsigned long long> h((size_t)waves * 4);
+            (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_timeline), h.size() * 8);
+            unsigned long long t0 = ~0ull, t1 = 0, rays = 0;
+            for (int w = 0; w < waves; ++w)
+                t0 = std::min(t0, h[w * 4]), t1 = std::max(t1, h[w * 4 + 2]), rays += h[w * 4 + 3];
+            std::vector<double> start, dry, end, dry_to_end;
+            for (int w = 0; w < waves; ++w) {
+                start.push_back((h[w * 4] - t0) * 0.01), dry.push_back((h[w * 4 + 1] - t0) * 0.01), end.push_back((h[w * 4 + 2] - t0) * 0.01);
+                dry_to_end.push_back((h[w * 4 + 2] - h[w * 4 + 1]) * 0.01);
+            }
+            auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            if (FILE* f = std::fopen(path, "a")) {
+                std::fprintf(f, "%s rays %llu span %.1f us | wave start p50 %.1f max %.1f | out of rays p1 %.1f p50 %.1f p99 %.1f | end p1 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | dry->end p50 %.1f p90 %.1f p99 %.1f max %.1f | alive at 10%% steps of the span:",
+                             any_hit ? "any-hit" : "closest", rays, (t1 - t0) * 0.01, pct(start, 0.5), pct(start, 1.0), pct(dry, 0.01), pct(dry, 0.5), pct(dry, 0.99), pct(end, 0.01), pct(end, 0.5), pct(end, 0.9),
+                             pct(end, 0.99), pct(end, 1.0), pct(dry_to_end, 0.5), pct(dry_to_end, 0.9), pct(dry_to_end, 0.99), pct(dry_to_end, 1.0));
+                for (int k = 1; k <= 10; ++k) {
+                    const double t = (t1 - t0) * 0.01 * k / 10.0 - 1e-9;
+                    int alive = 0;
+                    for (int w = 0; w < waves; ++w)
+                        alive += start[w] <= t && end[w] > t;
+                    std::fprintf(f, " %d", alive);
+                }
+                std::fprintf(f, "\n");
+                std::fclose(f);
+            }
+        }
+#endif
         TraverseArgs deep = args;
         deep.count        = args.index_count;
         deep.work_counter = deep_work_counter;

@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05ag; mkdir -p $O
+bash tools/ab.sh 20 ws1 base ws16 > $O/ab_shards2_headline.log 2>&1; cat $O/ab_shards2_headline.log
+for v in ws1 base ws16; do
+  if [ $v = base ]; then unset IGD_LIBRARY; else export IGD_LIBRARY=$GRAFT_REPO_ROOT/ignis_amd/lib/var/libig_device_hip_$v.so; fi
+  for rep in 1 2; do echo -n "[as-rank-of 8] $v "; python bench.py --steps 20 --warmup 5 --as-rank-of 8 --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); s = d['stage_ms_rank0']
+print('%8.1f Mrays/s  %.3f ms/step trav1 %.1f shade %.1f trav2 %.1f tail %.1f' % (d['value'], d['ms_per_step'], s['ms_traverse_primary'], s['ms_shade'], s['ms_traverse_secondary'], s['ms_tail']))"
+done; done 2>&1 | tee $O/ab_shards2_rankof8.log
+unset IGD_LIBRARY
+python tools/make_standin_scene.py /tmp/standin_1m_div --triangles 1000000 --instances 96 --materials divergent > /dev/null 2>&1
+bash tools/ab_scene.sh /tmp/standin_1m_div/standin.json 16 ws1 base ws16 > $O/ab_shards2_standin.log 2>&1; cat $O/ab_shards2_standin.log
