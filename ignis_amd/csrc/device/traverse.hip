@@ -29,6 +29,9 @@ namespace igdev {
 
 constexpr bool kQNode = IG_QNODE != 0;
 
+#ifndef IG_GUIDED_DIV
+#define IG_GUIDED_DIV 4
+#endif
 #ifndef IG_MIN_RAY_BATCH
 #define IG_MIN_RAY_BATCH 64 // smallest reservation of ray indices (the end of a stream)
 #endif
@@ -40,7 +43,10 @@ constexpr bool kQNode = IG_QNODE != 0;
 #endif
 constexpr int kRefillIdleClosest = IG_REFILL_IDLE;     // refill when at least this many lanes of a wave are idle
 constexpr int kRefillIdleAny     = IG_REFILL_IDLE_ANY; // ... in the any-hit launches (shorter rays)
-constexpr int kMaxRayBatch = 1024; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
+#ifndef IG_MAX_RAY_BATCH
+#define IG_MAX_RAY_BATCH 1024
+#endif
+constexpr int kMaxRayBatch = IG_MAX_RAY_BATCH; // ray indices reserved per atomic (one word sustains ~88 atomics/us)
 
 #ifdef IG_TRAV_TIMELINE
 // variant build (tools/trav_timeline.sh): when each wave of a launch started, ran out of rays to fetch, ended, and how many rays it took
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 bool share_done    = true;
                 if (len) {
                     const uint32_t left = len > last_off ? len - last_off : 0u;
-                    uint32_t kRayBatch  = left / (shard_waves * 4u);
+                    uint32_t kRayBatch  = left / (shard_waves * (uint32_t)IG_GUIDED_DIV);
                     kRayBatch           = kRayBatch < (uint32_t)IG_MIN_RAY_BATCH ? (uint32_t)IG_MIN_RAY_BATCH : (kRayBatch > (uint32_t)kMaxRayBatch ? (uint32_t)kMaxRayBatch : kRayBatch);
                     kRayBatch &= ~63u;
                     uint32_t off = 0;

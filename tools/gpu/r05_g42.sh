@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05aj; mkdir -p $O
+bash tools/ab.sh 20 base ri8 ri16 ri32 ws16 mx256 gd8 > $O/ab_sched_headline.log 2>&1; cat $O/ab_sched_headline.log
+for v in base ri16 ws16 mx256 gd8; do
+  if [ $v = base ]; then unset IGD_LIBRARY; else export IGD_LIBRARY=$GRAFT_REPO_ROOT/ignis_amd/lib/var/libig_device_hip_$v.so; fi
+  for rep in 1 2; do echo -n "[as-rank-of 8] $v "; python bench.py --steps 20 --warmup 5 --as-rank-of 8 --no-cpu-baseline --no-literal-config --no-extra-configs --no-live-traffic 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); s = d['stage_ms_rank0']
+print('%8.1f Mrays/s  %.3f ms/step trav1 %.1f shade %.1f trav2 %.1f tail %.1f' % (d['value'], d['ms_per_step'], s['ms_traverse_primary'], s['ms_shade'], s['ms_traverse_secondary'], s['ms_tail']))"
+done; done 2>&1 | tee $O/ab_sched_rankof8.log
+unset IGD_LIBRARY
+TRACE_NAME=rankof8_shards BENCH_ARGS="--as-rank-of 8" bash tools/round_trace.sh
