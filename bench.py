@@ -297,7 +297,22 @@ def main():
     if native:
         # the device library's own communicator: ncclCommInitRank inside libig_device_hip.so, the id handed round by ignis_amd.comm
         from ignis_amd.comm import Comm
-        comm = Comm(dev, rank, world)
+        try:
+            if os.environ.get("BENCH_NATIVE_COMM_FAIL"):  # tests: the fallback below
+                raise RuntimeError("BENCH_NATIVE_COMM_FAIL is set")
+            comm = Comm(dev, rank, world)
+            comm.barrier()  # (the first collective: a communicator that cannot talk fails here, not inside the timed region)
+        except Exception as e:  # noqa: BLE001 - whatever the library, the loader or the rendezvous raised
+            # The library's own communicator has run on one GPU only so far. If it cannot come up here, every rank starts over on the
+            # torch.distributed process group (a fresh process: torch has to be the first to load its HIP runtime and RCCL).
+            print(f"[bench] rank {rank}: native RCCL communicator failed ({type(e).__name__}: {e}); re-executing with --dist torch", file=sys.stderr, flush=True)
+            argv = [a for i, a in enumerate(sys.argv) if not (a == "--dist" or (i > 0 and sys.argv[i - 1] == "--dist") or a.startswith("--dist="))]
+            os.environ.pop("BENCH_NATIVE_COMM_FAIL", None)
+            try:
+                dev.close()
+            except Exception:  # noqa: BLE001
+                pass
+            os.execv(sys.executable, [sys.executable] + argv + ["--dist", "torch"])
 
     def barrier():
         if comm is not None:

@@ -1345,19 +1345,25 @@ def test_resending_unchanged_parameters_keeps_the_batch(diamond_scene, monkeypat
     assert sc["traverse_primary_launches"] > sa["traverse_primary_launches"]
 
 
-@pytest.mark.parametrize("how", ["rccl", "torch"])
+@pytest.mark.parametrize("how", ["rccl", "torch", "fallback"])
 def test_bench_single_rank_through_rccl(how):
     """bench.py's N > 1 code path with one rank (BENCH_FORCE_DIST=1). rccl (the default): the device library's own communicator
     (igd_comm_*: ncclCommInitRank inside libig_device_hip.so, the gather of owned rows, the max / sum all-reduces for the clock and
     the ray counts; no torch in the process). torch: a process group on the nccl (= RCCL) backend with a zero-copy torch view of the
-    device framebuffer. The same JSON contract either way."""
+    device framebuffer. fallback: the native communicator fails to come up (BENCH_NATIVE_COMM_FAIL) and the rank re-executes itself on the
+    torch process group. The same JSON contract either way."""
     import subprocess
     import sys
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(os.path.dirname(SCENES), "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320", "--height", "180",
-           "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--dist", how]
+           "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--dist", "rccl" if how == "fallback" else how]
+    if how == "fallback":
+        env["BENCH_NATIVE_COMM_FAIL"] = "1"
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
+    if how == "fallback":
+        assert "re-executing with --dist torch" in res.stderr
+        how = "torch"
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 0
     assert line["collective"]["world_size_from_backend"] == 1 and line["collective"]["backend"].startswith("nccl" if how == "torch" else "rccl")

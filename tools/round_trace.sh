@@ -1,4 +1,5 @@
-# tools/round_trace.sh: the kernel timeline of the LAST render of `bench.py --steps 20 --warmup 5 $BENCH_ARGS` (rocprofv3 kernel trace):
+# tools/round_trace.sh: the kernel timeline of the TIMED render of `bench.py --steps 20 --warmup 5 $BENCH_ARGS` (rocprofv3 kernel trace; the render
+# after it is bench.py's replay with the work counters on):
 # every launch with its start, duration and the gap to the previous launch's end, to see what a small wavefront's rounds are made of.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/roundtrace; mkdir -p $OUT
@@ -10,7 +11,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 gens = [i for i, r in enumerate(rows) if "k_generate" in r["Kernel_Name"]]
-rows = rows[gens[-1]:]
+rows = rows[gens[-2]:gens[-1]]
 t0 = int(rows[0]["Start_Timestamp"])
 def short(n):
     m = re.match(r"(?:void )?(?:igdev::)?(k_\w+)(<[^>]*>)?", n)
