@@ -10,6 +10,9 @@ namespace igdev {
 
 // ---------------------------------------------------------------- k_shade
 
+#ifndef IG_SHADE_PREFETCH
+#define IG_SHADE_PREFETCH 1
+#endif
 #ifndef IG_SHADE_THREADS
 #define IG_SHADE_THREADS 256 // (experiments: the expression kernels' LDS register file is sized for 256)
 #endif
@@ -80,9 +83,25 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
     NoClock clk;
 #endif
     const uint32_t chunks = (n + kShadeThreads - 1) / kShadeThreads;
+    // The lean variant waits for memory: its window starts with two dependent round trips (the hit, whose entity decides whether the ray's
+    // other columns are read at all, then those columns). The hit row of the NEXT window is fetched while this one is shaded.
+    constexpr bool kPrefetchHit = IG_SHADE_PREFETCH && !FULL && !LT && PPM == 0 && !DEBUG_VIEWS;
+    // (The ray's other columns the same way — 16 more registers — lose more to the spills at 4 waves per SIMD, or to 3 waves per SIMD, than the
+    // round trip is worth: A/B section 27.)
+    // (The by-class variants, which start with three — the sorted index, the hit, the columns —, gain nothing from index and hit fetched ahead:
+    // they wait for issue slots. A/B section 27.)
+    float4 hit_pre = make_float4(0, 0, 0, 0);
+    if (kPrefetchHit && blockIdx.x < chunks && blockIdx.x * kShadeThreads + tid < n)
+        hit_pre = a.in.hit[blockIdx.x * kShadeThreads + tid];
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         const uint32_t base = chunk * kShadeThreads;
         clk.mark(10); // loop overhead (and, for the first window, the kernel's prologue)
+        const float4 hit_now = hit_pre;
+        if (kPrefetchHit) {
+            const uint32_t nj = (chunk + gridDim.x) * kShadeThreads + tid;
+            if (chunk + gridDim.x < chunks && nj < n)
+                hit_pre = a.in.hit[nj];
+        }
 
         // ---- workgroup-local counting sort by material (miss = bin M, out of range = bin M + 1)
         uint32_t j = base + tid;
@@ -133,8 +152,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
         if (!BY_CLASS && !LT && PPM == 0 && !DEBUG_VIEWS && a.skip_misses) {
             // a scene without environment lights: a miss adds nothing and ends its path (shade_vertex's on_miss sums over no light), so
             // its columns are not even read — a look at the hit first, a wave whose rays all missed (camera rays past the geometry) goes on
-            if (valid)
-                valid = a.hit_pack ? igm_bits(a.in.hit[j].x) != 0xFFFFFFFFu : (int)igm_bits(a.in.hit[j].x) >= 0;
+            if (valid) {
+                const uint32_t hx = igm_bits(kPrefetchHit ? hit_now.x : a.in.hit[j].x);
+                valid             = a.hit_pack ? hx != 0xFFFFFFFFu : (int)hx >= 0;
+            }
         }
 
         clk.mark(0); // the sort
@@ -148,7 +169,7 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             PathVertexIn in;
             const bool compact = a.in_kind == kStreamCamera && a.cam_stream.compact; // (kernels.h CameraStream: only rayB is stored)
             const float4 ra = compact ? a.cam_stream.rayA : a.in.rayA[j];
-            const float4 rb = a.in.rayB[j], hit = a.in.hit[j];
+            const float4 rb = a.in.rayB[j], hit = kPrefetchHit ? hit_now : a.in.hit[j];
             const int4 meta = compact ? make_int4((int32_t)(a.cam_stream.first_id + j), (int32_t)IG_RAY_FLAG_CAMERA, (int32_t)a.cam_stream.rnd_counter, 1) : a.in.meta[j];
             // (what the stream's writer left constant is not read: kernels.h kStream*)
             const float4 pay = a.in_kind == kStreamCamera ? make_float4(0, 1, 1, 1) : a.in.pay[j];

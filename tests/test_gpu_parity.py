@@ -1354,7 +1354,8 @@ def test_bench_single_rank_through_rccl(how):
     torch process group. The same JSON contract either way."""
     import subprocess
     import sys
-    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BENCH_CAPACITY=str(1 << 22))  # (streams for this small film, not the 157 GB of a full batch: the cases may run side by side under xdist)
     cmd = [sys.executable, os.path.join(os.path.dirname(SCENES), "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320", "--height", "180",
            "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--dist", "rccl" if how == "fallback" else how]
     if how == "fallback":
