@@ -1228,7 +1228,39 @@ static uint32_t appendEnvironmentCdf(std::vector<float>& out, const std::vector<
     return (uint32_t)offset;
 }
 
-// A colour property of a BSDF (ShadingTree::addColor, src/runtime/loader/ShadingTree.cpp): a constant, a bitmap or checkerboard
+// A colour property that names a brick texture (src/runtime/pattern/BrickPattern.cpp:13-38: color0 / color1 / scale_x,y / gap_x,y with
+// the defaults below) as the shading expression make_brick_texture is (src/artic/texture/brick.art:1-19, identity transform):
+//   suv = uv * scale;  x = fract(select(fract(suv.y * 0.5) > 0.5, suv.x + 0.5, suv.x));  y = fract(suv.y)
+//   step(edge, v) = select(v < edge, 0, 1);  color_lerp(color0, color1, step(x, 1 - gap.x) * step(y, 1 - gap.y))
+// The interpreter shared by the kernels and the oracle (include/ig_expr.h) evaluates it; the factor is 0 or 1, so the lerp returns one of
+// the two colours exactly.
+static bool brickExpression(const JsonValue& prop, const JsonValue& textures, std::string& expr, const std::string& owner)
+{
+    if (!prop.isString())
+        return false;
+    for (const auto& t : textures.arr) {
+        if (t.getString("name") != prop.str || t.getString("type") != "brick")
+            continue;
+        if (t.has("transform"))
+            fail("'" + owner + "': brick transforms are not supported by this loader");
+        const V3 c0 = getColor(t, "color0", V3(0, 0, 0), prop.str), c1 = getColor(t, "color1", V3(1, 1, 1), prop.str);
+        const float sx = getConstNumber(t, "scale_x", 3.0f, prop.str), sy = getConstNumber(t, "scale_y", 6.0f, prop.str);
+        const float gx = getConstNumber(t, "gap_x", 0.05f, prop.str), gy = getConstNumber(t, "gap_y", 0.1f, prop.str);
+        const auto num = [](float v) { // (nine significant digits name a float exactly)
+            char buf[48];
+            std::snprintf(buf, sizeof buf, "(%.9g)", (double)v);
+            return std::string(buf);
+        };
+        const auto col = [&](const V3& c) { return "color(" + num(c.x) + ", " + num(c.y) + ", " + num(c.z) + ")"; };
+        const std::string su = "uv.x * " + num(sx), sv = "uv.y * " + num(sy);
+        expr = "mix(" + col(c0) + ", " + col(c1) + ", select((1 - " + num(gx) + ") < fract(select(fract(" + sv + " * 0.5) > 0.5, " + su + " + 0.5, " + su + ")), 0.0, 1.0)"
+               + " * select((1 - " + num(gy) + ") < fract(" + sv + "), 0.0, 1.0))";
+        return true;
+    }
+    return false;
+}
+
+// A colour property of a BSDF (ShadingTree::addColor, src/runtime/loader/ShadingTree.cpp): a constant, a bitmap, checkerboard or brick
 // texture by name, or a PExpr string, which becomes a program of the expression table unless it folds to a constant.
 static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const JsonValue& textures, TextureBank& bank, ig_material& m, const std::string& name)
 {
@@ -1240,13 +1272,15 @@ static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const Jso
                 m.tex_refl = bank.get(col->str, name);
                 return;
             }
-    if (col && lowerCheckerboard(*col, textures, m, name))
+    std::string brick;
+    const bool is_brick = col && brickExpression(*col, textures, brick, name);
+    if (col && !is_brick && lowerCheckerboard(*col, textures, m, name))
         return;
     V3 c = def;
-    if (col && !parseConstColor(*col, c)) {
+    if (col && (is_brick || !parseConstColor(*col, c))) {
         if (!col->isString())
             fail("'" + name + "': property '" + key + "' is neither a colour nor an expression");
-        const igh::pexpr::Program prog = bank.compileExpr(col->str, name);
+        const igh::pexpr::Program prog = bank.compileExpr(is_brick ? brick : col->str, name);
         using igh::pexpr::Type;
         if (prog.type == Type::Bool || prog.type == Type::Vec2) // "Expression does not return a number or color" (Transpiler.cpp:1303-1306)
             fail("'" + name + "': expression of property '" + key + "' is a " + igh::pexpr::typeName(prog.type) + ", not a number or colour");

@@ -1732,6 +1732,25 @@ def test_radiance_brtdfunc_and_roos_bsdfs_vs_oracle(gpu_device, stem):
     _compare_with_oracle(gpu_device, sc, 96, 96, 4, seed=47, iters=2)
 
 
+def test_brick_textures_vs_oracle(gpu_device):
+    """"brick" textures (BrickPattern.cpp, texture/brick.art) as the reflectance of the diamond box's walls and the base colour of a plastic:
+    the loader lowers them to shading expressions (tests/test_pexpr.py pins those against the reference's node), the expression kernels run them."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["textures"] = [{"type": "brick", "name": "wall", "color0": [0.15, 0.12, 0.1], "color1": [0.8, 0.35, 0.25], "scale_x": 4, "scale_y": 8},
+                     {"type": "brick", "name": "tiles", "color0": [0.05, 0.05, 0.05], "color1": [0.9, 0.9, 0.85], "scale_x": 2, "scale_y": 2, "gap_x": 0.2, "gap_y": 0.02}]
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-GrayWall":
+            b["reflectance"] = "wall"
+    s["bsdfs"].append({"type": "plastic", "name": "tiled", "diffuse_reflectance": "tiles", "roughness": 0.1})
+    for e in s["entities"]:
+        if e["bsdf"] == "mat-Diamond" and e["name"].endswith("1"):
+            e["bsdf"] = "tiled"
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 8)) >= 1
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=59, iters=2)
+
+
 def test_expression_weights_of_blend_and_cutoff_vs_oracle(gpu_device):
     """Blend and mask weights as number expressions (IG_MAT_EXPR_WEIGHT): a procedural blend on the walls, a texture-driven cutoff on the diamonds."""
     from ignis_amd.tables import LoadedScene

@@ -169,6 +169,51 @@ def test_oracle_expression_checkerboard_equals_the_lowered_checkerboard():
     assert np.array_equal(fa, fb) and fa.max() > 0.5
 
 
+def _node_brick(u, v, sx, sy, gx, gy):
+    """src/artic/texture/brick.art:1-12 in float32 (math::fract = x - floor(x); step(edge, x) = select(x < edge, 0, 1))."""
+    su, sv = F(u) * F(sx), F(v) * F(sy)
+    fr = lambda a: F(a) - F(np.floor(F(a)))
+    x = fr(su + F(0.5) if fr(sv * F(0.5)) > F(0.5) else su)
+    y = fr(sv)
+    step = lambda edge, a: F(0) if a < edge else F(1)
+    return step(x, F(1) - F(gx)) * step(y, F(1) - F(gy))
+
+
+def _brick_expression(c0, c1, sx, sy, gx, gy):
+    col = lambda c: "color(%r, %r, %r)" % tuple(float(F(x)) for x in c)
+    su, sv = f"uv.x * {float(F(sx))!r}", f"uv.y * {float(F(sy))!r}"
+    return (f"mix({col(c0)}, {col(c1)}, select((1 - {float(F(gx))!r}) < fract(select(fract({sv} * 0.5) > 0.5, {su} + 0.5, {su})), 0.0, 1.0)"
+            f" * select((1 - {float(F(gy))!r}) < fract({sv}), 0.0, 1.0))")
+
+
+def test_brick_texture_is_the_reference_node_and_the_loader_lowers_it_to_that_expression():
+    """A "brick" texture (src/runtime/pattern/BrickPattern.cpp:13-38; make_brick_texture, src/artic/texture/brick.art) named by a colour
+    property: the expression the loader writes for it equals a float32 restatement of node_brick over a grid of coordinates (negative and
+    beyond 1 included), and the scene with the texture renders the very pixels of the scene with that expression written out."""
+    import oracle
+    c0, c1, sx, sy, gx, gy = (0.1, 0.2, 0.3), (0.9, 0.8, 0.7), 3.0, 6.0, 0.05, 0.1
+    src = _brick_expression(c0, c1, sx, sy, gx, gy)
+    seen = set()
+    for u in np.linspace(-1.3, 2.1, 41):
+        for v in np.linspace(-0.7, 1.9, 37):
+            t = _node_brick(u, v, sx, sy, gx, gy)
+            seen.add(float(t))
+            want = tuple(float(F(a) * (F(1) - t) + F(b) * t) for a, b in zip(c0, c1)) + (1.0,)
+            ty, got = ev(src, uvw=(float(F(u)), float(F(v)), 0))
+            assert ty == "vec4" and near(got, want, 1e-7), (u, v, got, want)
+    assert seen == {0.0, 1.0}
+    tex = {"textures": [{"type": "brick", "name": "wall", "color0": list(c0), "color1": list(c1)}]}  # the pattern's defaults: scale (3, 6), gap (0.05, 0.1)
+    a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "wall"}, tex)), SCENES, 64, 64)
+    b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": src})), SCENES, 64, 64)
+    assert a.scene.materials[0].flags & (1 << 8) and b.scene.materials[0].flags & (1 << 8)
+    fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+    fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+    assert np.array_equal(fa, fb) and 0.05 < fa.min() and fa.max() > 0.5 and len(np.unique(fa.round(3))) > 2
+    with pytest.raises(RuntimeError, match="brick transforms"):
+        tex["textures"][0]["transform"] = [{"scale": 2}]
+        LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "wall"}, tex)), SCENES, 64, 64)
+
+
 def test_oracle_transform_bsdf_with_the_plain_normal_changes_nothing_and_a_tilted_one_does():
     """make_normal_set (bsdf/map.art:36-42) with normal = N aligns the frame with itself; tilting the normal re-weights the cosine."""
     import oracle
