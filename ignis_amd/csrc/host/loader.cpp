@@ -714,6 +714,8 @@ static void handleShape(Scene& sc, std::vector<ShapeRec>& shapes, const std::str
     shapes.push_back(rec);
 }
 
+static void textureCoordinates(const JsonValue& tex, std::string& u, std::string& v);
+
 // A colour property that names a checkerboard texture (src/runtime/pattern/CheckerBoardPattern.cpp:13-33,
 // src/artic/texture/checkerboard.art) is lowered into the material record; other textures are refused.
 static bool lowerCheckerboard(const JsonValue& prop, const JsonValue& textures, ig_material& m, const std::string& owner)
@@ -761,8 +763,12 @@ static bool lowerCheckerboard(const JsonValue& prop, const JsonValue& textures, 
             continue;
         if (t.getString("type") != "checkerboard")
             fail("'" + owner + "': texture '" + prop.str + "' of type '" + t.getString("type") + "' is not supported by the HIP backend here");
-        if (t.has("transform"))
-            fail("'" + owner + "': checkerboard transforms are not supported by this loader");
+        if (t.has("transform")) {
+            std::string tu, tv;
+            textureCoordinates(t, tu, tv);
+            if (tu != "uv.x" || tv != "uv.y") // (colour properties take the expression route, lowerColor)
+                fail("'" + owner + "': a checkerboard under a transform is not supported by this loader here");
+        }
         const V3 c0 = getColor(t, "color0", V3(0, 0, 0), prop.str);
         const V3 c1 = getColor(t, "color1", V3(1, 1, 1), prop.str);
         m.flags |= IG_MAT_CHECKER;
@@ -1228,6 +1234,36 @@ static uint32_t appendEnvironmentCdf(std::vector<float>& out, const std::vector<
     return (uint32_t)offset;
 }
 
+// The "transform" of a procedural texture as the reference applies it to the surface coordinates: LoaderUtils::inlineTransformAs2d
+// (src/runtime/loader/LoaderUtils.cpp:40-64) keeps the upper-left 2 x 2 block and the x / y translation of the 3D transform, WRITES the nine
+// numbers into the generated shader with a stream's default precision (six significant digits: restated by printing and re-reading), and
+// mat3x3_transform_point_affine (src/artic/core/matrix.art:237-240) is vec3_dot(row, (u, v, 1)) per coordinate — `dot` of the expression
+// language is that fma chain (include/ig_expr.h IGE_DOT). An identity matrix (Eigen's isIdentity, precision 1e-5) is left out.
+static void textureCoordinates(const JsonValue& tex, std::string& u, std::string& v)
+{
+    u = "uv.x", v = "uv.y";
+    if (!tex.has("transform"))
+        return;
+    const Affine t = getTransform(tex);
+    float m[2][3]  = { { t.L.m[0][0], t.L.m[0][1], t.t[0] }, { t.L.m[1][0], t.L.m[1][1], t.t[1] } };
+    bool identity  = true;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+            char buf[48];
+            std::snprintf(buf, sizeof buf, "%g", (double)m[i][j]);
+            m[i][j] = std::strtof(buf, nullptr);
+            identity = identity && std::fabs(m[i][j] - (i == j ? 1.0f : 0.0f)) <= 1e-5f;
+        }
+    if (identity)
+        return;
+    const auto row = [&](int i) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "dot(vec3((%.9g), (%.9g), (%.9g)), vec3(uv.x, uv.y, 1.0))", (double)m[i][0], (double)m[i][1], (double)m[i][2]);
+        return std::string(buf);
+    };
+    u = row(0), v = row(1);
+}
+
 // A colour property that names a brick texture (src/runtime/pattern/BrickPattern.cpp:13-38: color0 / color1 / scale_x,y / gap_x,y with
 // the defaults below) as the shading expression make_brick_texture is (src/artic/texture/brick.art:1-19, identity transform):
 //   suv = uv * scale;  x = fract(select(fract(suv.y * 0.5) > 0.5, suv.x + 0.5, suv.x));  y = fract(suv.y)
@@ -1241,8 +1277,6 @@ static bool brickExpression(const JsonValue& prop, const JsonValue& textures, st
     for (const auto& t : textures.arr) {
         if (t.getString("name") != prop.str || t.getString("type") != "brick")
             continue;
-        if (t.has("transform"))
-            fail("'" + owner + "': brick transforms are not supported by this loader");
         const V3 c0 = getColor(t, "color0", V3(0, 0, 0), prop.str), c1 = getColor(t, "color1", V3(1, 1, 1), prop.str);
         const float sx = getConstNumber(t, "scale_x", 3.0f, prop.str), sy = getConstNumber(t, "scale_y", 6.0f, prop.str);
         const float gx = getConstNumber(t, "gap_x", 0.05f, prop.str), gy = getConstNumber(t, "gap_y", 0.1f, prop.str);
@@ -1252,7 +1286,9 @@ static bool brickExpression(const JsonValue& prop, const JsonValue& textures, st
             return std::string(buf);
         };
         const auto col = [&](const V3& c) { return "color(" + num(c.x) + ", " + num(c.y) + ", " + num(c.z) + ")"; };
-        const std::string su = "uv.x * " + num(sx), sv = "uv.y * " + num(sy);
+        std::string tu, tv;
+        textureCoordinates(t, tu, tv);
+        const std::string su = tu + " * " + num(sx), sv = tv + " * " + num(sy);
         expr = "mix(" + col(c0) + ", " + col(c1) + ", select((1 - " + num(gx) + ") < fract(select(fract(" + sv + " * 0.5) > 0.5, " + su + " + 0.5, " + su + ")), 0.0, 1.0)"
                + " * select((1 - " + num(gy) + ") < fract(" + sv + "), 0.0, 1.0))";
         return true;
@@ -1273,7 +1309,25 @@ static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const Jso
                 return;
             }
     std::string brick;
-    const bool is_brick = col && brickExpression(*col, textures, brick, name);
+    bool is_brick = col && brickExpression(*col, textures, brick, name);
+    if (col && !is_brick && col->isString())
+        for (const auto& t : textures.arr)
+            if (t.getString("name") == col->str && t.getString("type") == "checkerboard" && t.has("transform")) {
+                // a checkerboard under a transform: make_checkerboard_texture (texture/checkerboard.art:4-13) written out — color0 where the
+                // parities of the two scaled coordinates differ, i.e. where node_checkerboard2 (the expression language's checkerboard(vec2)) is 0
+                std::string tu, tv;
+                textureCoordinates(t, tu, tv);
+                if (tu == "uv.x" && tv == "uv.y")
+                    break; // (an identity: the record form below)
+                const V3 c0 = getColor(t, "color0", V3(0, 0, 0), col->str), c1 = getColor(t, "color1", V3(1, 1, 1), col->str);
+                char buf[512];
+                std::snprintf(buf, sizeof buf, "select(checkerboard(vec2(%s * (%.9g), %s * (%.9g))) == 1, color((%.9g), (%.9g), (%.9g)), color((%.9g), (%.9g), (%.9g)))", tu.c_str(),
+                              (double)getConstNumber(t, "scale_x", 2.0f, col->str), tv.c_str(), (double)getConstNumber(t, "scale_y", 2.0f, col->str), (double)c1.x, (double)c1.y,
+                              (double)c1.z, (double)c0.x, (double)c0.y, (double)c0.z);
+                brick    = buf;
+                is_brick = true;
+                break;
+            }
     if (col && !is_brick && lowerCheckerboard(*col, textures, m, name))
         return;
     V3 c = def;

@@ -209,9 +209,56 @@ def test_brick_texture_is_the_reference_node_and_the_loader_lowers_it_to_that_ex
     fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
     fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
     assert np.array_equal(fa, fb) and 0.05 < fa.min() and fa.max() > 0.5 and len(np.unique(fa.round(3))) > 2
-    with pytest.raises(RuntimeError, match="brick transforms"):
-        tex["textures"][0]["transform"] = [{"scale": 2}]
-        LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "wall"}, tex)), SCENES, 64, 64)
+
+
+_M2D = ((1.5, 0.25, 0.125), (-0.5, 2.0, 0.75))  # upper-left 2 x 2 block and x / y translation of the 4 x 4 below
+_T16 = [1.5, 0.25, 0, 0.125, -0.5, 2.0, 0, 0.75, 0, 0, 1, 0, 0, 0, 0, 1]
+
+
+def _affine(u, v):
+    """mat3x3_transform_point_affine (core/matrix.art:237-240): vec3_dot(row, (u, v, 1)) = fmaf(x, u, fmaf(y, v, z * 1)) per coordinate."""
+    fma = lambda a, b, c: F(np.float64(F(a)) * np.float64(F(b)) + np.float64(F(c)))
+    return tuple(fma(r[0], u, fma(r[1], v, F(r[2]) * F(1))) for r in _M2D)
+
+
+def _uv_rows():
+    return tuple("dot(vec3(%r, %r, %r), vec3(uv.x, uv.y, 1.0))" % r for r in _M2D)
+
+
+def test_procedural_textures_under_a_transform():
+    """The "transform" of a brick / checkerboard texture (LoaderUtils::inlineTransformAs2d: the 2 x 2 block and x / y translation of the 3D
+    transform; mat3x3_transform_point_affine in front of the scale): the loader writes the affine map into the expression. Hand-written
+    expressions with the same map against float32 restatements over a grid, and the scenes with the textures against the scenes with those
+    expressions, pixel for pixel."""
+    import oracle
+    c0, c1 = (0.1, 0.2, 0.3), (0.9, 0.8, 0.7)
+    tu, tv = _uv_rows()
+    col = lambda c: "color(%r, %r, %r)" % tuple(float(F(x)) for x in c)
+    brick = (f"mix({col(c0)}, {col(c1)}, select((1 - {float(F(0.05))!r}) < fract(select(fract({tv} * 6.0 * 0.5) > 0.5, {tu} * 3.0 + 0.5, {tu} * 3.0)), 0.0, 1.0)"
+             f" * select((1 - {float(F(0.1))!r}) < fract({tv} * 6.0), 0.0, 1.0))")
+    check = f"select(checkerboard(vec2({tu} * 4.0, {tv} * 2.0)) == 1, {col(c1)}, {col(c0)})"
+    wrap2 = lambda x: F(x) - F(2) * F(np.floor(F(x) / F(2)))  # math::wrap(x, 0, 2) (core/math.art:88-91) for these magnitudes
+    for u in np.linspace(-0.9, 1.7, 23):
+        for v in np.linspace(-0.4, 1.3, 19):
+            U, V = _affine(u, v)
+            t = _node_brick(U, V, 3.0, 6.0, 0.05, 0.1)
+            want = tuple(float(F(a) * (F(1) - t) + F(b) * t) for a, b in zip(c0, c1)) + (1.0,)
+            assert near(ev(brick, uvw=(float(F(u)), float(F(v)), 0))[1], want, 1e-7), (u, v)
+            px, py = int(wrap2(U * F(4))) % 2 == 0, int(wrap2(V * F(2))) % 2 == 0  # make_checkerboard_texture (texture/checkerboard.art:4-13)
+            want = tuple(float(F(x)) for x in (c0 if px != py else c1)) + (1.0,)
+            assert near(ev(check, uvw=(float(F(u)), float(F(v)), 0))[1], want, 1e-7), (u, v)
+    for tex, src in (({"type": "brick", "name": "t", "color0": list(c0), "color1": list(c1), "transform": _T16}, brick),
+                     ({"type": "checkerboard", "name": "t", "color0": list(c0), "color1": list(c1), "scale_x": 4, "scale_y": 2, "transform": _T16}, check)):
+        a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [tex]})), SCENES, 64, 64)
+        b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": src})), SCENES, 64, 64)
+        assert a.scene.materials[0].flags & (1 << 8) and b.scene.materials[0].flags & (1 << 8)
+        fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+        fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+        assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 2
+    # an identity transform leaves the checkerboard in its record form
+    ident = {"type": "checkerboard", "name": "t", "color0": list(c0), "color1": list(c1), "transform": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]}
+    sc = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [ident]})), SCENES, 64, 64)
+    assert sc.scene.materials[0].flags & (1 << 2) and not sc.scene.materials[0].flags & (1 << 8)
 
 
 def test_oracle_transform_bsdf_with_the_plain_normal_changes_nothing_and_a_tilted_one_does():
