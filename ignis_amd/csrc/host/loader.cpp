@@ -1275,7 +1275,25 @@ static bool brickExpression(const JsonValue& prop, const JsonValue& textures, st
     if (!prop.isString())
         return false;
     for (const auto& t : textures.arr) {
-        if (t.getString("name") != prop.str || t.getString("type") != "brick")
+        if (t.getString("name") != prop.str)
+            continue;
+        const std::string type = t.getString("type");
+        if (type == "noise" || type == "cellnoise" || type == "pnoise") {
+            // NoisePattern.cpp:33-57 -> make_[c]<type>_texture (src/artic/texture/noise.art:250-275): color * func(transform(uv) * scale, seed),
+            // "colored": the three-channel form of the function
+            const V3 c     = getColor(t, "color", V3(1, 1, 1), prop.str);
+            const float sd = getConstNumber(t, "seed", 36326639.0f, prop.str);
+            const float sx = getConstNumber(t, "scale_x", 10.0f, prop.str), sy = getConstNumber(t, "scale_y", 10.0f, prop.str);
+            const JsonValue* colored = t.find("colored");
+            std::string tu, tv;
+            textureCoordinates(t, tu, tv);
+            char buf[768];
+            std::snprintf(buf, sizeof buf, "color((%.9g), (%.9g), (%.9g)) * %s%s(vec2(%s * (%.9g), %s * (%.9g)), (%.9g))", (double)c.x, (double)c.y, (double)c.z,
+                          colored && colored->isBool() && colored->b ? "c" : "", type.c_str(), tu.c_str(), (double)sx, tv.c_str(), (double)sy, (double)sd);
+            expr = buf;
+            return true;
+        }
+        if (type != "brick")
             continue;
         const V3 c0 = getColor(t, "color0", V3(0, 0, 0), prop.str), c1 = getColor(t, "color1", V3(1, 1, 1), prop.str);
         const float sx = getConstNumber(t, "scale_x", 3.0f, prop.str), sy = getConstNumber(t, "scale_y", 6.0f, prop.str);

@@ -600,6 +600,18 @@ private:
         }
         if (name == "luminance" && n == 1 && a[0]->type == Type::Vec4)
             return make(IGE_LUMINANCE, Type::Num, 0, std::move(a));
+        {
+            // the hash noises over a vec2, with the seed or the default one (Transpiler.cpp:734-775 -> noise2_v / cellnoise2 / pnoise2 and
+            // cnoise2 / ccellnoise2 / cpnoise2, *_def = DEFAULT_NOISE_SEED, src/artic/texture/noise.art:218-244)
+            static const struct { const char* name; uint32_t imm; } noises[] = { { "noise", IGE_NOISE_WHITE }, { "cellnoise", IGE_NOISE_CELL }, { "pnoise", IGE_NOISE_VALUE },
+                                                                                   { "cnoise", IGE_NOISE_WHITE | 4u }, { "ccellnoise", IGE_NOISE_CELL | 4u }, { "cpnoise", IGE_NOISE_VALUE | 4u } };
+            for (const auto& f : noises)
+                if (name == f.name && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
+                    if (n == 1)
+                        a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
+                    return make(IGE_NOISE, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm, std::move(a));
+                }
+        }
         if (name == "checkerboard" && n == 1 && (a[0]->type == Type::Vec2 || a[0]->type == Type::Vec3)) {
             const uint32_t d = (uint32_t)lanes(a[0]->type);
             return make(IGE_CHECKER, Type::Int, d, std::move(a));

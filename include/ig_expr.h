@@ -67,6 +67,7 @@ enum ige_op {
     IGE_WRAP,     /* math::wrap(v, min, max) (core/math.art:88-91) */
     IGE_DIST,
     IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
+    IGE_NOISE,    /* the hash noises over a vec2 (texture/noise.art:35-75): f(r[a].xy, seed r[b].x), imm = enum ige_noise | 4 for the colour form */
     IGE_OP_COUNT
 };
 
@@ -80,6 +81,12 @@ enum ige_var {
     IGE_VAR_NY,      /* ctx.surf.local.col(1) */
     IGE_VAR_FRONT,   /* ctx.surf.is_entering */
     IGE_VAR_COUNT
+};
+
+enum ige_noise {
+    IGE_NOISE_WHITE = 0, /* noise2_v / cnoise2: one value per distinct coordinate */
+    IGE_NOISE_CELL  = 1, /* cellnoise2 / ccellnoise2: per integer cell */
+    IGE_NOISE_VALUE = 2, /* pnoise2 / cpnoise2: smoothstep-interpolated values of the cell corners */
 };
 
 enum ige_f1 {
@@ -106,6 +113,48 @@ IGM_FN int ige_ftoi(float x)
     if (x <= -2147483648.0f)
         return -2147483647 - 1;
     return (int)x;
+}
+
+/* hash_combine (FNV over the four bytes, core/random.art:7-13), sample_tea_u32 (:15-24) and the first next_f32 of
+ * create_random_generator(seed) (:65-70,82-87: counter starts at 1; a float in [1, 2) minus 1) */
+IGM_FN uint32_t ige_hash_combine(uint32_t h, uint32_t d)
+{
+    h = (h * 16777619u) ^ (d & 0xFFu);
+    h = (h * 16777619u) ^ ((d >> 8) & 0xFFu);
+    h = (h * 16777619u) ^ ((d >> 16) & 0xFFu);
+    h = (h * 16777619u) ^ ((d >> 24) & 0xFFu);
+    return h;
+}
+IGM_FN uint32_t ige_tea(uint32_t v0, uint32_t v1)
+{
+    uint32_t sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v1;
+}
+/* noise2[T](u, v, seed) (texture/noise.art:35-37) on the BITS of its coordinates: float bits for noise2_v / pnoise2, integer bits for cellnoise2 */
+IGM_FN float ige_noise2_bits(uint32_t ub, uint32_t vb, float seed)
+{
+    const uint32_t h = ige_hash_combine(ige_hash_combine(ige_hash_combine(0x811C9DC5u, igm_bits(seed)), ub), vb);
+    return igm_float((ige_tea(h, 1u) & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
+}
+IGM_FN float ige_noise2(int kind, float u, float v, float seed)
+{
+    if (kind == IGE_NOISE_CELL) /* cellnoise2: noise2(uv.x as i32, uv.y as i32, seed) (:44) */
+        return ige_noise2_bits((uint32_t)ige_ftoi(u), (uint32_t)ige_ftoi(v), seed);
+    if (kind == IGE_NOISE_VALUE) { /* pnoise2 (:47-59): math::trunc, |smoothstep| of the fractions, lerp(a, b, k) = (1 - k) a + k b */
+        const float ix = (float)ige_ftoi(u), iy = (float)ige_ftoi(v);
+        const float fx = u - ix, fy = v - iy;
+        const float kx = igm_abs(fx * fx * (3 - 2 * fx)), ky = igm_abs(fy * fy * (3 - 2 * fy));
+        const float p00 = ige_noise2_bits(igm_bits(ix), igm_bits(iy), seed), p10 = ige_noise2_bits(igm_bits(ix + 1), igm_bits(iy), seed);
+        const float p01 = ige_noise2_bits(igm_bits(ix), igm_bits(iy + 1), seed), p11 = ige_noise2_bits(igm_bits(ix + 1), igm_bits(iy + 1), seed);
+        const float a = (1 - kx) * p00 + kx * p10, b = (1 - kx) * p01 + kx * p11;
+        return (1 - ky) * a + ky * b;
+    }
+    return ige_noise2_bits(igm_bits(u), igm_bits(v), seed); /* noise2_v (:39) */
 }
 
 IGM_FN float ige_f1_apply(int f, float x)
@@ -404,6 +453,28 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
         case IGE_PACK:
             o.v[0] = a.v[0], o.v[1] = b.v[0], o.v[2] = c.v[0], o.v[3] = r[imm & 0xFu].v[0];
             break;
+        case IGE_NOISE: {
+            const int kind = (int)(imm & 3u);
+            float u = a.v[0], v = a.v[1];
+            if (!(imm & 4u)) {
+                const float n = ige_noise2(kind, u, v, b.v[0]);
+                for (int i = 0; i < 4; ++i)
+                    o.v[i] = n;
+                break;
+            }
+            /* cnoise2 = (noise(seed), noise(seed + 1234), noise(seed + 5678), 1) (:42); ccellnoise2 hashes the FLOATS of the truncated
+             * coordinates (:45); cpnoise2 interpolates the corners' colours, alpha 1 throughout (:61-75: the same lerps per channel) */
+            int k = kind;
+            if (kind == IGE_NOISE_CELL) {
+                u = (float)ige_ftoi(u), v = (float)ige_ftoi(v);
+                k = IGE_NOISE_WHITE;
+            }
+            o.v[0] = ige_noise2(k, u, v, b.v[0]);
+            o.v[1] = ige_noise2(k, u, v, b.v[0] + 1234.0f);
+            o.v[2] = ige_noise2(k, u, v, b.v[0] + 5678.0f);
+            o.v[3] = 1.0f;
+            break;
+        }
         default:
             break;
         }

@@ -1751,6 +1751,29 @@ def test_brick_textures_vs_oracle(gpu_device):
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=59, iters=2)
 
 
+def test_noise_textures_vs_oracle(gpu_device):
+    """"noise" / "cellnoise" / "pnoise" textures (NoisePattern.cpp, texture/noise.art: FNV hash + one TEA draw per lookup, smoothstep-
+    interpolated for pnoise, "colored" = three draws), one of them under a transform, and a roughness driven by pnoise(uv)."""
+    from ignis_amd.tables import LoadedScene
+    s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
+    s["textures"] = [{"type": "pnoise", "name": "clouds", "color": [0.9, 0.8, 0.7], "scale_x": 5, "scale_y": 5, "transform": [{"translate": [0.3, 0.1, 0]}, {"scale": [2, 1, 1]}]},
+                     {"type": "cellnoise", "name": "cells", "colored": True, "scale_x": 6, "scale_y": 6, "seed": 17},
+                     {"type": "noise", "name": "grain", "color": [0.6, 0.6, 0.6], "scale_x": 100, "scale_y": 100}]
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-GrayWall":
+            b["reflectance"] = "clouds"
+        if b["name"] == "mat-ColoredWall":
+            b["reflectance"] = "cells"
+    s["bsdfs"] += [{"type": "plastic", "name": "grainy", "diffuse_reflectance": "grain", "roughness": 0.2},
+                   {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(uv * 8, 3)"}]
+    for e in s["entities"]:
+        if e["bsdf"] == "mat-Diamond":
+            e["bsdf"] = "grainy" if e["name"].endswith("1") else ("brushed" if e["name"].endswith("2") else e["bsdf"])
+    sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 8)) >= 3
+    _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=61, iters=2)
+
+
 def test_expression_weights_of_blend_and_cutoff_vs_oracle(gpu_device):
     """Blend and mask weights as number expressions (IG_MAT_EXPR_WEIGHT): a procedural blend on the walls, a texture-driven cutoff on the diamonds."""
     from ignis_amd.tables import LoadedScene

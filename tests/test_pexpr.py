@@ -261,6 +261,87 @@ def test_procedural_textures_under_a_transform():
     assert sc.scene.materials[0].flags & (1 << 2) and not sc.scene.materials[0].flags & (1 << 8)
 
 
+def _u32(x):
+    return int(x) & 0xFFFFFFFF
+
+
+def _hash_combine(h, d):
+    """core/random.art:7-13 (FNV over the four bytes)"""
+    for k in range(4):
+        h = _u32(h * 16777619) ^ ((d >> (8 * k)) & 0xFF)
+    return h
+
+
+def _tea(v0, v1):
+    """sample_tea_u32, core/random.art:15-24"""
+    s = 0
+    for _ in range(4):
+        s = _u32(s + 0x9e3779b9)
+        v0 = _u32(v0 + ((_u32(v1 << 4) + 0xa341316c) ^ _u32(v1 + s) ^ ((v1 >> 5) + 0xc8013ea4)))
+        v1 = _u32(v1 + ((_u32(v0 << 4) + 0xad90777d) ^ _u32(v0 + s) ^ ((v0 >> 5) + 0x7e95761e)))
+    return v1
+
+
+def _bits(f):
+    return int(np.array(f, F).view(np.uint32))
+
+
+def _noise2_bits(ub, vb, seed):
+    """noise2[T] (texture/noise.art:35-37): the first next_f32 of create_random_generator(hash of seed, u, v) (core/random.art:65-70,82-87)"""
+    x = _tea(_hash_combine(_hash_combine(_hash_combine(0x811C9DC5, _bits(seed)), ub), vb), 1)
+    return F(np.array((x & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
+
+
+def _noise2(kind, u, v, seed):
+    u, v, seed = F(u), F(v), F(seed)
+    if kind == "cellnoise":  # (:44) integer bits of the truncated coordinates
+        return _noise2_bits(_u32(int(u)), _u32(int(v)), seed)
+    if kind == "pnoise":  # (:47-59)
+        ix, iy = F(int(u)), F(int(v))  # math::trunc = (x as i32) as f32 (core/math.art:73): +0 for -0.18
+        sm = lambda x: F(abs(F(F(x * x) * F(F(3) - F(F(2) * x)))))
+        kx, ky = sm(F(u - ix)), sm(F(v - iy))
+        p = lambda a, b: _noise2_bits(_bits(a), _bits(b), seed)
+        lerp = lambda a, b, k: F(F(F(F(1) - k) * a) + F(k * b))
+        return lerp(lerp(p(ix, iy), p(F(ix + 1), iy), kx), lerp(p(ix, F(iy + 1)), p(F(ix + 1), F(iy + 1)), kx), ky)
+    return _noise2_bits(_bits(u), _bits(v), seed)
+
+
+def _cnoise2(kind, u, v, seed):
+    """cnoise2 / ccellnoise2 / cpnoise2 (:42,45,61-75); the interpolation of cpnoise2 is per channel the one of pnoise2"""
+    if kind == "cellnoise":
+        u, v, kind = F(int(F(u))), F(int(F(v))), "noise"
+    return tuple(float(_noise2(kind, u, v, F(F(seed) + F(o)))) for o in (0, 1234, 5678)) + (1.0,)
+
+
+def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_to_them():
+    """noise / cellnoise / pnoise and their colour forms over a vec2 (Transpiler.cpp:734-775 -> src/artic/texture/noise.art:35-75,218-244)
+    against a Python restatement of hash_combine, sample_tea_u32 and the generator's first float, on a grid with negative coordinates, with
+    and without a seed; then "noise" / "cellnoise" / "pnoise" textures (NoisePattern.cpp:33-57: color * func(uv * scale, seed), "colored")
+    against the scenes with those expressions written out."""
+    import oracle
+    default = 36326639.0
+    for u in np.linspace(-3.7, 9.3, 14):
+        for v in np.linspace(-2.2, 7.9, 11):
+            uvw = (float(F(u)), float(F(v)), 0)
+            for kind in ("noise", "cellnoise", "pnoise"):
+                assert near(ev(f"{kind}(uv)", uvw=uvw)[1], float(_noise2(kind, u, v, default)), 1e-7), (kind, u, v)
+                assert near(ev(f"{kind}(uv, 7.5)", uvw=uvw)[1], float(_noise2(kind, u, v, 7.5)), 1e-7), (kind, u, v)
+                assert near(ev(f"c{kind}(uv, 3)", uvw=uvw)[1], _cnoise2(kind, u, v, 3.0), 1e-7), (kind, u, v)
+    vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
+    assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
+    with pytest.raises(RuntimeError, match="not supported"):
+        ev("noise(P)", P=(1, 2, 3))  # (the 1D / 3D forms, perlin, fbm, voronoi, gabor stay refused)
+    for tex, src in (({"type": "noise", "name": "t", "color": [0.9, 0.5, 0.3], "scale_x": 40, "scale_y": 30}, "color(0.9, 0.5, 0.3) * noise(vec2(uv.x * 40.0, uv.y * 30.0), 36326639.0)"),
+                     ({"type": "cellnoise", "name": "t", "seed": 11, "colored": True}, "color(1, 1, 1) * ccellnoise(vec2(uv.x * 10.0, uv.y * 10.0), 11.0)"),
+                     ({"type": "pnoise", "name": "t", "scale_x": 6, "scale_y": 6, "transform": _T16}, "color(1, 1, 1) * pnoise(vec2(%s * 6.0, %s * 6.0), 36326639.0)" % _uv_rows())):
+        a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [tex]})), SCENES, 64, 64)
+        b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": src})), SCENES, 64, 64)
+        assert a.scene.materials[0].flags & (1 << 8) and b.scene.materials[0].flags & (1 << 8)
+        fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+        fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+        assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8, tex["type"]
+
+
 def test_oracle_transform_bsdf_with_the_plain_normal_changes_nothing_and_a_tilted_one_does():
     """make_normal_set (bsdf/map.art:36-42) with normal = N aligns the frame with itself; tilting the normal re-weights the cosine."""
     import oracle
