@@ -612,6 +612,13 @@ private:
                     return make(IGE_NOISE, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm, std::move(a));
                 }
         }
+        if (name == "snoise" && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
+            // snoise2(uv, seed) = noise2_v(uv, seed) * 2 - 1 (src/artic/texture/noise.art:40)
+            if (n == 1)
+                a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
+            NodeP twice = make(IGE_MUL, Type::Num, 0, list(make(IGE_NOISE, Type::Num, IGE_NOISE_WHITE, std::move(a)), constant(Type::Num, 2, 2, 2, 2)));
+            return make(IGE_SUB, Type::Num, 0, list(std::move(twice), constant(Type::Num, 1, 1, 1, 1)));
+        }
         if (name == "checkerboard" && n == 1 && (a[0]->type == Type::Vec2 || a[0]->type == Type::Vec3)) {
             const uint32_t d = (uint32_t)lanes(a[0]->type);
             return make(IGE_CHECKER, Type::Int, d, std::move(a));

@@ -327,6 +327,7 @@ def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_
                 assert near(ev(f"{kind}(uv)", uvw=uvw)[1], float(_noise2(kind, u, v, default)), 1e-7), (kind, u, v)
                 assert near(ev(f"{kind}(uv, 7.5)", uvw=uvw)[1], float(_noise2(kind, u, v, 7.5)), 1e-7), (kind, u, v)
                 assert near(ev(f"c{kind}(uv, 3)", uvw=uvw)[1], _cnoise2(kind, u, v, 3.0), 1e-7), (kind, u, v)
+    assert near(ev("snoise(uv, 2)", uvw=(0.3, 0.7, 0))[1], float(_noise2("noise", 0.3, 0.7, 2.0) * F(2) - F(1)), 1e-7)  # snoise2 (:40)
     vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
     assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
     with pytest.raises(RuntimeError, match="not supported"):
