@@ -604,7 +604,8 @@ private:
             // the hash noises over a vec2, with the seed or the default one (Transpiler.cpp:734-775 -> noise2_v / cellnoise2 / pnoise2 and
             // cnoise2 / ccellnoise2 / cpnoise2, *_def = DEFAULT_NOISE_SEED, src/artic/texture/noise.art:218-244)
             static const struct { const char* name; uint32_t imm; } noises[] = { { "noise", IGE_NOISE_WHITE }, { "cellnoise", IGE_NOISE_CELL }, { "pnoise", IGE_NOISE_VALUE },
-                                                                                   { "cnoise", IGE_NOISE_WHITE | 4u }, { "ccellnoise", IGE_NOISE_CELL | 4u }, { "cpnoise", IGE_NOISE_VALUE | 4u } };
+                                                                                   { "cnoise", IGE_NOISE_WHITE | 4u }, { "ccellnoise", IGE_NOISE_CELL | 4u }, { "cpnoise", IGE_NOISE_VALUE | 4u },
+                                                                                   { "perlin", IGE_NOISE_PERLIN }, { "sperlin", IGE_NOISE_PERLIN | 8u }, { "cperlin", IGE_NOISE_PERLIN | 4u } };
             for (const auto& f : noises)
                 if (name == f.name && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
                     if (n == 1)

@@ -67,7 +67,7 @@ enum ige_op {
     IGE_WRAP,     /* math::wrap(v, min, max) (core/math.art:88-91) */
     IGE_DIST,
     IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
-    IGE_NOISE,    /* the hash noises over a vec2 (texture/noise.art:35-75): f(r[a].xy, seed r[b].x), imm = enum ige_noise | 4 for the colour form */
+    IGE_NOISE,    /* the noises over a vec2 (texture/noise.art:35-128): f(r[a].xy, seed r[b].x), imm = enum ige_noise | 4 for the colour form */
     IGE_OP_COUNT
 };
 
@@ -87,6 +87,7 @@ enum ige_noise {
     IGE_NOISE_WHITE = 0, /* noise2_v / cnoise2: one value per distinct coordinate */
     IGE_NOISE_CELL  = 1, /* cellnoise2 / ccellnoise2: per integer cell */
     IGE_NOISE_VALUE = 2, /* pnoise2 / cpnoise2: smoothstep-interpolated values of the cell corners */
+    IGE_NOISE_PERLIN = 3, /* perlin2 / cperlin2 (gradient noise); imm bit 3: sperlin2, the signed form */
 };
 
 enum ige_f1 {
@@ -141,8 +142,46 @@ IGM_FN float ige_noise2_bits(uint32_t ub, uint32_t vb, float seed)
     const uint32_t h = ige_hash_combine(ige_hash_combine(ige_hash_combine(0x811C9DC5u, igm_bits(seed)), ub), vb);
     return igm_float((ige_tea(h, 1u) & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
 }
+/* sperlin2 (texture/noise.art:79-127, "classic Perlin noise" after the cited gist), every operation as written there: vec4_divf is a
+ * product with 1 / t, vec2_dot / vec2_len2 an fma, norm.y belongs to g01 and norm.z to g10 although n10 takes norm.y and n01 norm.z */
+IGM_FN float ige_mod289(float x) { return x - igm_floor(x / 289.0f) * 289.0f; }
+IGM_FN float ige_permute289(float v) { return ige_mod289((v * 34.0f) * v + v); }
+IGM_FN float ige_sperlin2(float u, float v, float seed)
+{
+    /* noise1(1234, seed) (:2-4, the coordinate an integer): the offset of the lattice */
+    const uint32_t h  = ige_hash_combine(ige_hash_combine(0x811C9DC5u, igm_bits(seed)), 1234u);
+    const float shift = igm_float((ige_tea(h, 1u) & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
+    const float px = u + shift, py = v + shift;
+    const float pix_ = igm_floor(px), piy_ = igm_floor(py), piz_ = pix_ + 1, piw_ = piy_ + 1;
+    const float pfx = px - pix_, pfy = py - piy_, pfz = pfx - 1, pfw = pfy - 1;
+    const float pix = ige_mod289(pix_), piy = ige_mod289(piy_), piz = ige_mod289(piz_), piw = ige_mod289(piw_);
+    const float vix[4] = { pix, piz, pix, piz }, viy[4] = { piy, piy, piw, piw }, vfx[4] = { pfx, pfz, pfx, pfz }, vfy[4] = { pfy, pfy, pfw, pfw };
+    float gx2[4], gy[4];
+    const float inv41 = 1 / 41.0f;
+    for (int i = 0; i < 4; ++i) {
+        const float vi = ige_permute289(ige_permute289(vix[i]) + viy[i]);
+        const float q  = vi * inv41;
+        const float gx = (q - igm_floor(q)) * 2.0f - 1.0f;
+        gy[i]          = igm_abs(gx) - 0.5f;
+        gx2[i]         = gx - igm_floor(gx + 0.5f);
+    }
+    /* g00 = lane 0, g10 = lane 1, g01 = lane 2, g11 = lane 3; norm = (len2 g00, len2 g01, len2 g10, len2 g11) */
+    const float len2[4] = { igm_fma(gx2[0], gx2[0], gy[0] * gy[0]), igm_fma(gx2[1], gx2[1], gy[1] * gy[1]), igm_fma(gx2[2], gx2[2], gy[2] * gy[2]), igm_fma(gx2[3], gx2[3], gy[3] * gy[3]) };
+    const float norm[4] = { 1.79284291400159f - len2[0] * 0.85373472095314f, 1.79284291400159f - len2[2] * 0.85373472095314f, 1.79284291400159f - len2[1] * 0.85373472095314f,
+                            1.79284291400159f - len2[3] * 0.85373472095314f };
+    const float n00 = igm_fma(gx2[0], vfx[0], gy[0] * vfy[0]) * norm[0];
+    const float n10 = igm_fma(gx2[1], vfx[1], gy[1] * vfy[1]) * norm[1];
+    const float n01 = igm_fma(gx2[2], vfx[2], gy[2] * vfy[2]) * norm[2];
+    const float n11 = igm_fma(gx2[3], vfx[3], gy[3] * vfy[3]) * norm[3];
+    const float fx = pfx * pfx * pfx * (pfx * (pfx * 6 - 15) + 10), fy = pfy * pfy * pfy * (pfy * (pfy * 6 - 15) + 10); /* smootherstep (core/common.art:242) */
+    const float nx0 = (1 - fx) * n00 + fx * n10, nx1 = (1 - fx) * n01 + fx * n11; /* vec2_lerp((n00, n01), (n10, n11), fade_x) */
+    return 2.3f * ((1 - fy) * nx0 + fy * nx1);
+}
+
 IGM_FN float ige_noise2(int kind, float u, float v, float seed)
 {
+    if (kind == IGE_NOISE_PERLIN) /* perlin2 = (sperlin2 + 1) / 2 (:128) */
+        return (ige_sperlin2(u, v, seed) + 1) / 2;
     if (kind == IGE_NOISE_CELL) /* cellnoise2: noise2(uv.x as i32, uv.y as i32, seed) (:44) */
         return ige_noise2_bits((uint32_t)ige_ftoi(u), (uint32_t)ige_ftoi(v), seed);
     if (kind == IGE_NOISE_VALUE) { /* pnoise2 (:47-59): math::trunc, |smoothstep| of the fractions, lerp(a, b, k) = (1 - k) a + k b */
@@ -457,7 +496,7 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
             const int kind = (int)(imm & 3u);
             float u = a.v[0], v = a.v[1];
             if (!(imm & 4u)) {
-                const float n = ige_noise2(kind, u, v, b.v[0]);
+                const float n = (imm & 8u) ? ige_sperlin2(u, v, b.v[0]) : ige_noise2(kind, u, v, b.v[0]);
                 for (int i = 0; i < 4; ++i)
                     o.v[i] = n;
                 break;
@@ -469,10 +508,17 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
                 u = (float)ige_ftoi(u), v = (float)ige_ftoi(v);
                 k = IGE_NOISE_WHITE;
             }
+            if (kind == IGE_NOISE_PERLIN)
+                k = IGE_NOISE_VALUE; /* cperlin2 = cpnoise2 * perlin2, alpha too (color_mulf, :211-214) */
             o.v[0] = ige_noise2(k, u, v, b.v[0]);
             o.v[1] = ige_noise2(k, u, v, b.v[0] + 1234.0f);
             o.v[2] = ige_noise2(k, u, v, b.v[0] + 5678.0f);
             o.v[3] = 1.0f;
+            if (kind == IGE_NOISE_PERLIN) {
+                const float f = ige_noise2(IGE_NOISE_PERLIN, u, v, b.v[0]);
+                for (int i = 0; i < 4; ++i)
+                    o.v[i] *= f;
+            }
             break;
         }
         default:

@@ -1753,7 +1753,8 @@ def test_brick_textures_vs_oracle(gpu_device):
 
 def test_noise_textures_vs_oracle(gpu_device):
     """"noise" / "cellnoise" / "pnoise" textures (NoisePattern.cpp, texture/noise.art: FNV hash + one TEA draw per lookup, smoothstep-
-    interpolated for pnoise, "colored" = three draws), one of them under a transform, and a roughness driven by pnoise(uv)."""
+    interpolated for pnoise, "colored" = three draws; "perlin": the gradient noise, coloured = cpnoise * perlin), one of them under a transform, and a
+    roughness driven by pnoise(uv)."""
     from ignis_amd.tables import LoadedScene
     s = json.load(open(os.path.join(SCENES, "diamond_scene.json")))
     s["textures"] = [{"type": "pnoise", "name": "clouds", "color": [0.9, 0.8, 0.7], "scale_x": 5, "scale_y": 5, "transform": [{"translate": [0.3, 0.1, 0]}, {"scale": [2, 1, 1]}]},
@@ -1764,11 +1765,13 @@ def test_noise_textures_vs_oracle(gpu_device):
             b["reflectance"] = "clouds"
         if b["name"] == "mat-ColoredWall":
             b["reflectance"] = "cells"
+    s["textures"].append({"type": "perlin", "name": "marble", "color": [0.8, 0.85, 0.9], "scale_x": 9, "scale_y": 4, "colored": True})
     s["bsdfs"] += [{"type": "plastic", "name": "grainy", "diffuse_reflectance": "grain", "roughness": 0.2},
-                   {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(uv * 8, 3)"}]
+                   {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(uv * 8, 3)"},
+                   {"type": "diffuse", "name": "veined", "reflectance": "marble"}]
     for e in s["entities"]:
         if e["bsdf"] == "mat-Diamond":
-            e["bsdf"] = "grainy" if e["name"].endswith("1") else ("brushed" if e["name"].endswith("2") else e["bsdf"])
+            e["bsdf"] = "grainy" if e["name"].endswith("1") else ("brushed" if e["name"].endswith("2") else "veined")
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
     assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 8)) >= 3
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=61, iters=2)

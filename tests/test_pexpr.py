@@ -118,7 +118,7 @@ def test_bump_node():
 
 
 @pytest.mark.parametrize("src,what", [
-    ("foo", "unknown variable 'foo'"), ("perlin(uv)", "'perlin' is not supported"), ("entity_id", "'entity_id' is not supported"),
+    ("foo", "unknown variable 'foo'"), ("voronoi(uv)", "'voronoi' is not supported"), ("entity_id", "'entity_id' is not supported"),
     ("uv.z", "outside of vec2"), ("1 +", "end of expression"), ("vec3(1,2) ", "no function vec3(int, int)"), ("1 && 2", "expects bool"),
     ("vec3(1) < vec3(2)", "expects int or num"), ("vec2(1) + vec3(1)", "cannot add vec2 and vec3"), ("3 % 2.0", "'%' expects int"),
     ("2 / vec3(1)", "cannot divide int and vec3"), ("'text'", "string"), ("(1", "expected ')'"), ("1 $ 2", "unexpected character"),
@@ -148,7 +148,7 @@ def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
     m = sc.scene.materials[0]
     assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
     assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
-    for bad, what in (("perlin(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+    for bad, what in (("fbm(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
     with pytest.raises(RuntimeError, match="inside a blend"):
@@ -311,6 +311,64 @@ def _cnoise2(kind, u, v, seed):
     if kind == "cellnoise":
         u, v, kind = F(int(F(u))), F(int(F(v))), "noise"
     return tuple(float(_noise2(kind, u, v, F(F(seed) + F(o)))) for o in (0, 1234, 5678)) + (1.0,)
+
+
+def _sperlin2(u, v, seed):
+    """sperlin2 (src/artic/texture/noise.art:79-127) in float32, operation by operation; fmaf as one rounding of the exact value."""
+    fma = lambda a, b, c: F(np.float64(a) * np.float64(b) + np.float64(c))
+    fl = lambda x: F(np.floor(x))
+    mod289 = lambda x: F(x - F(fl(F(x / F(289))) * F(289)))
+    permute = lambda x: mod289(F(F(F(x * F(34)) * x) + x))
+    x = _tea(_hash_combine(_hash_combine(0x811C9DC5, _bits(seed)), 1234), 1)  # noise1(1234, seed): an integer coordinate
+    shift = F(np.array((x & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
+    px, py = F(F(u) + shift), F(F(v) + shift)
+    pix_, piy_ = fl(px), fl(py)
+    piz_, piw_ = F(pix_ + 1), F(piy_ + 1)
+    pfx, pfy = F(px - pix_), F(py - piy_)
+    pfz, pfw = F(pfx - 1), F(pfy - 1)
+    pix, piy, piz, piw = mod289(pix_), mod289(piy_), mod289(piz_), mod289(piw_)
+    vix, viy, vfx, vfy = (pix, piz, pix, piz), (piy, piy, piw, piw), (pfx, pfz, pfx, pfz), (pfy, pfy, pfw, pfw)
+    inv41 = F(F(1) / F(41))
+    gx2, gy = [], []
+    for i in range(4):
+        vi = permute(F(permute(vix[i]) + viy[i]))
+        q = F(vi * inv41)
+        gx = F(F(F(q - fl(q)) * F(2)) - F(1))
+        gy.append(F(F(abs(gx)) - F(0.5)))
+        gx2.append(F(gx - fl(F(gx + F(0.5)))))
+    len2 = [fma(gx2[i], gx2[i], F(gy[i] * gy[i])) for i in range(4)]  # lanes: g00, g10, g01, g11
+    c0, c1 = F(1.79284291400159), F(0.85373472095314)
+    norm = [F(c0 - F(len2[0] * c1)), F(c0 - F(len2[2] * c1)), F(c0 - F(len2[1] * c1)), F(c0 - F(len2[3] * c1))]  # (g00, g01, g10, g11)
+    n = [F(fma(gx2[i], vfx[i], F(gy[i] * vfy[i])) * norm[i]) for i in range(4)]  # n00 * norm.x, n10 * norm.y, n01 * norm.z, n11 * norm.w
+    sm = lambda t: F(F(F(t * t) * t) * F(F(t * F(F(t * F(6)) - F(15))) + F(10)))
+    lerp = lambda a, b, k: F(F(F(F(1) - k) * a) + F(k * b))
+    fx, fy = sm(pfx), sm(pfy)
+    return F(F(2.3) * lerp(lerp(n[0], n[1], fx), lerp(n[2], n[3], fx), fy))
+
+
+def test_perlin_noise_equals_the_reference_function():
+    """perlin / sperlin / cperlin over a vec2 (Transpiler.cpp:758-761 -> sperlin2, perlin2 = (s + 1) / 2, cperlin2 = cpnoise2 * perlin2,
+    src/artic/texture/noise.art:79-128,211-214) against a float32 restatement, and the "perlin" texture against its expression."""
+    import oracle
+    lo, hi = 1.0, -1.0
+    for u in np.linspace(-2.3, 6.1, 15):
+        for v in np.linspace(-1.1, 4.7, 13):
+            uvw = (float(F(u)), float(F(v)), 0)
+            s7 = _sperlin2(u, v, 7.0)
+            lo, hi = min(lo, float(s7)), max(hi, float(s7))
+            assert near(ev("sperlin(uv, 7)", uvw=uvw)[1], float(s7), 2e-6), (u, v)
+            assert near(ev("perlin(uv, 7)", uvw=uvw)[1], float(F(F(s7 + F(1)) / F(2))), 2e-6), (u, v)
+            pd = F(F(_sperlin2(u, v, 36326639.0) + F(1)) / F(2))
+            assert near(ev("perlin(uv)", uvw=uvw)[1], float(pd), 2e-6), (u, v)
+            want = tuple(float(F(F(c) * pd)) for c in _cnoise2("pnoise", u, v, 36326639.0))
+            assert near(ev("cperlin(uv)", uvw=uvw)[1], want, 2e-6), (u, v)
+    assert lo < -0.3 and hi > 0.3
+    tex = {"type": "perlin", "name": "t", "color": [0.9, 0.7, 0.5], "scale_x": 7, "scale_y": 5}
+    a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [tex]})), SCENES, 64, 64)
+    b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "color(0.9, 0.7, 0.5) * perlin(vec2(uv.x * 7.0, uv.y * 5.0), 36326639.0)"})), SCENES, 64, 64)
+    fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+    fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+    assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8 and np.isfinite(fa).all()
 
 
 def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_to_them():
