@@ -606,19 +606,28 @@ private:
             static const struct { const char* name; uint32_t imm; } noises[] = { { "noise", IGE_NOISE_WHITE }, { "cellnoise", IGE_NOISE_CELL }, { "pnoise", IGE_NOISE_VALUE },
                                                                                    { "cnoise", IGE_NOISE_WHITE | 4u }, { "ccellnoise", IGE_NOISE_CELL | 4u }, { "cpnoise", IGE_NOISE_VALUE | 4u },
                                                                                    { "perlin", IGE_NOISE_PERLIN }, { "sperlin", IGE_NOISE_PERLIN | 8u }, { "cperlin", IGE_NOISE_PERLIN | 4u } };
-            for (const auto& f : noises)
-                if (name == f.name && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
-                    if (n == 1)
-                        a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
-                    return make(IGE_NOISE, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm, std::move(a));
-                }
+            for (const auto& f : noises) {
+                if (name != f.name || (n != 1 && n != 2) || (n == 2 && a[1]->type != Type::Num && a[1]->type != Type::Int))
+                    continue;
+                const Type ct = a[0]->type; // a number, vec2 or vec3 of coordinates (perlin: vec2 only, there is no other form in the reference)
+                const uint32_t dims = (ct == Type::Num || ct == Type::Int) ? 1u : (ct == Type::Vec2 ? 2u : (ct == Type::Vec3 ? 3u : 0u));
+                if (dims == 0 || ((f.imm & 3u) == IGE_NOISE_PERLIN && dims != 2))
+                    continue;
+                if (n == 1)
+                    a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
+                return make(IGE_NOISE, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm | dims << 4, std::move(a));
+            }
         }
-        if (name == "snoise" && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
-            // snoise2(uv, seed) = noise2_v(uv, seed) * 2 - 1 (src/artic/texture/noise.art:40)
-            if (n == 1)
-                a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
-            NodeP twice = make(IGE_MUL, Type::Num, 0, list(make(IGE_NOISE, Type::Num, IGE_NOISE_WHITE, std::move(a)), constant(Type::Num, 2, 2, 2, 2)));
-            return make(IGE_SUB, Type::Num, 0, list(std::move(twice), constant(Type::Num, 1, 1, 1, 1)));
+        if (name == "snoise" && (n == 1 || n == 2) && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
+            // snoiseN(x, seed) = noiseN_v(x, seed) * 2 - 1 (src/artic/texture/noise.art:6,40,157)
+            const Type ct = a[0]->type;
+            const uint32_t dims = (ct == Type::Num || ct == Type::Int) ? 1u : (ct == Type::Vec2 ? 2u : (ct == Type::Vec3 ? 3u : 0u));
+            if (dims) {
+                if (n == 1)
+                    a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
+                NodeP twice = make(IGE_MUL, Type::Num, 0, list(make(IGE_NOISE, Type::Num, IGE_NOISE_WHITE | dims << 4, std::move(a)), constant(Type::Num, 2, 2, 2, 2)));
+                return make(IGE_SUB, Type::Num, 0, list(std::move(twice), constant(Type::Num, 1, 1, 1, 1)));
+            }
         }
         if (name == "checkerboard" && n == 1 && (a[0]->type == Type::Vec2 || a[0]->type == Type::Vec3)) {
             const uint32_t d = (uint32_t)lanes(a[0]->type);

@@ -67,7 +67,7 @@ enum ige_op {
     IGE_WRAP,     /* math::wrap(v, min, max) (core/math.art:88-91) */
     IGE_DIST,
     IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
-    IGE_NOISE,    /* the noises over a vec2 (texture/noise.art:35-128): f(r[a].xy, seed r[b].x), imm = enum ige_noise | 4 for the colour form */
+    IGE_NOISE,    /* the noises of texture/noise.art: f(r[a] leading lanes, seed r[b].x), imm = enum ige_noise | 4 colour form | 8 signed | dims << 4 */
     IGE_OP_COUNT
 };
 
@@ -136,10 +136,13 @@ IGM_FN uint32_t ige_tea(uint32_t v0, uint32_t v1)
     }
     return v1;
 }
-/* noise2[T](u, v, seed) (texture/noise.art:35-37) on the BITS of its coordinates: float bits for noise2_v / pnoise2, integer bits for cellnoise2 */
-IGM_FN float ige_noise2_bits(uint32_t ub, uint32_t vb, float seed)
+/* noiseN[T](coordinates, seed) (texture/noise.art:2-4,35-37,152-154) on the BITS of its coordinates: float bits for noiseN_v / pnoiseN, integer
+ * bits for cellnoiseN */
+IGM_FN float ige_noise_bits(int dims, const uint32_t* cb, float seed)
 {
-    const uint32_t h = ige_hash_combine(ige_hash_combine(ige_hash_combine(0x811C9DC5u, igm_bits(seed)), ub), vb);
+    uint32_t h = ige_hash_combine(0x811C9DC5u, igm_bits(seed));
+    for (int i = 0; i < dims; ++i)
+        h = ige_hash_combine(h, cb[i]);
     return igm_float((ige_tea(h, 1u) & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
 }
 /* sperlin2 (texture/noise.art:79-127, "classic Perlin noise" after the cited gist), every operation as written there: vec4_divf is a
@@ -178,22 +181,38 @@ IGM_FN float ige_sperlin2(float u, float v, float seed)
     return 2.3f * ((1 - fy) * nx0 + fy * nx1);
 }
 
-IGM_FN float ige_noise2(int kind, float u, float v, float seed)
+IGM_FN float ige_noise(int kind, int dims, const float* x, float seed)
 {
-    if (kind == IGE_NOISE_PERLIN) /* perlin2 = (sperlin2 + 1) / 2 (:128) */
-        return (ige_sperlin2(u, v, seed) + 1) / 2;
-    if (kind == IGE_NOISE_CELL) /* cellnoise2: noise2(uv.x as i32, uv.y as i32, seed) (:44) */
-        return ige_noise2_bits((uint32_t)ige_ftoi(u), (uint32_t)ige_ftoi(v), seed);
-    if (kind == IGE_NOISE_VALUE) { /* pnoise2 (:47-59): math::trunc, |smoothstep| of the fractions, lerp(a, b, k) = (1 - k) a + k b */
-        const float ix = (float)ige_ftoi(u), iy = (float)ige_ftoi(v);
-        const float fx = u - ix, fy = v - iy;
-        const float kx = igm_abs(fx * fx * (3 - 2 * fx)), ky = igm_abs(fy * fy * (3 - 2 * fy));
-        const float p00 = ige_noise2_bits(igm_bits(ix), igm_bits(iy), seed), p10 = ige_noise2_bits(igm_bits(ix + 1), igm_bits(iy), seed);
-        const float p01 = ige_noise2_bits(igm_bits(ix), igm_bits(iy + 1), seed), p11 = ige_noise2_bits(igm_bits(ix + 1), igm_bits(iy + 1), seed);
-        const float a = (1 - kx) * p00 + kx * p10, b = (1 - kx) * p01 + kx * p11;
-        return (1 - ky) * a + ky * b;
+    uint32_t cb[3] = { 0, 0, 0 };
+    if (kind == IGE_NOISE_PERLIN) /* perlin2 = (sperlin2 + 1) / 2 (:128); two coordinates only */
+        return (ige_sperlin2(x[0], x[1], seed) + 1) / 2;
+    if (kind == IGE_NOISE_CELL) { /* cellnoiseN: noiseN(x as i32, ..., seed) (:10,44,161) */
+        for (int i = 0; i < dims; ++i)
+            cb[i] = (uint32_t)ige_ftoi(x[i]);
+        return ige_noise_bits(dims, cb, seed);
     }
-    return ige_noise2_bits(igm_bits(u), igm_bits(v), seed); /* noise2_v (:39) */
+    if (kind == IGE_NOISE_VALUE) {
+        /* pnoiseN (:14-22,47-59,164-184): math::trunc, |smoothstep| of the fractions, the corners' values interpolated along x, then y, then z with
+         * lerp(a, b, k) = (1 - k) a + k b */
+        float ip[3], k[3], p[8];
+        for (int i = 0; i < dims; ++i) {
+            ip[i]         = (float)ige_ftoi(x[i]);
+            const float f = x[i] - ip[i];
+            k[i]          = igm_abs(f * f * (3 - 2 * f));
+        }
+        for (int c = 0; c < (1 << dims); ++c) {
+            for (int i = 0; i < dims; ++i)
+                cb[i] = igm_bits((c >> i) & 1 ? ip[i] + 1 : ip[i]);
+            p[c] = ige_noise_bits(dims, cb, seed);
+        }
+        for (int i = 0; i < dims; ++i)
+            for (int c = 0; c < (1 << (dims - 1 - i)); ++c)
+                p[c] = (1 - k[i]) * p[2 * c] + k[i] * p[2 * c + 1];
+        return p[0];
+    }
+    for (int i = 0; i < dims; ++i) /* noiseN_v (:2-4,39,156) */
+        cb[i] = igm_bits(x[i]);
+    return ige_noise_bits(dims, cb, seed);
 }
 
 IGM_FN float ige_f1_apply(int f, float x)
@@ -493,29 +512,31 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
             o.v[0] = a.v[0], o.v[1] = b.v[0], o.v[2] = c.v[0], o.v[3] = r[imm & 0xFu].v[0];
             break;
         case IGE_NOISE: {
-            const int kind = (int)(imm & 3u);
-            float u = a.v[0], v = a.v[1];
+            const int kind = (int)(imm & 3u), dims = (int)((imm >> 4) & 3u);
+            float x[3] = { a.v[0], a.v[1], a.v[2] };
             if (!(imm & 4u)) {
-                const float n = (imm & 8u) ? ige_sperlin2(u, v, b.v[0]) : ige_noise2(kind, u, v, b.v[0]);
+                const float n = (imm & 8u) ? ige_sperlin2(x[0], x[1], b.v[0]) : ige_noise(kind, dims, x, b.v[0]);
                 for (int i = 0; i < 4; ++i)
                     o.v[i] = n;
                 break;
             }
-            /* cnoise2 = (noise(seed), noise(seed + 1234), noise(seed + 5678), 1) (:42); ccellnoise2 hashes the FLOATS of the truncated
-             * coordinates (:45); cpnoise2 interpolates the corners' colours, alpha 1 throughout (:61-75: the same lerps per channel) */
+            /* cnoiseN = (noise(seed), noise(seed + 1234), noise(seed + 5678), 1) (:8,42,159); ccellnoiseN hashes the FLOATS of the truncated
+             * coordinates (:11,45,162); cpnoiseN interpolates the corners' colours, alpha 1 throughout (:24-33,61-75,186-206: the same lerps per
+             * channel); cperlin2 = cpnoise2 * perlin2, alpha too (color_mulf, :211-214) */
             int k = kind;
             if (kind == IGE_NOISE_CELL) {
-                u = (float)ige_ftoi(u), v = (float)ige_ftoi(v);
+                for (int i = 0; i < dims; ++i)
+                    x[i] = (float)ige_ftoi(x[i]);
                 k = IGE_NOISE_WHITE;
             }
             if (kind == IGE_NOISE_PERLIN)
-                k = IGE_NOISE_VALUE; /* cperlin2 = cpnoise2 * perlin2, alpha too (color_mulf, :211-214) */
-            o.v[0] = ige_noise2(k, u, v, b.v[0]);
-            o.v[1] = ige_noise2(k, u, v, b.v[0] + 1234.0f);
-            o.v[2] = ige_noise2(k, u, v, b.v[0] + 5678.0f);
+                k = IGE_NOISE_VALUE;
+            o.v[0] = ige_noise(k, dims, x, b.v[0]);
+            o.v[1] = ige_noise(k, dims, x, b.v[0] + 1234.0f);
+            o.v[2] = ige_noise(k, dims, x, b.v[0] + 5678.0f);
             o.v[3] = 1.0f;
             if (kind == IGE_NOISE_PERLIN) {
-                const float f = ige_noise2(IGE_NOISE_PERLIN, u, v, b.v[0]);
+                const float f = ige_noise(IGE_NOISE_PERLIN, dims, x, b.v[0]);
                 for (int i = 0; i < 4; ++i)
                     o.v[i] *= f;
             }

@@ -1767,7 +1767,7 @@ def test_noise_textures_vs_oracle(gpu_device):
             b["reflectance"] = "cells"
     s["textures"].append({"type": "perlin", "name": "marble", "color": [0.8, 0.85, 0.9], "scale_x": 9, "scale_y": 4, "colored": True})
     s["bsdfs"] += [{"type": "plastic", "name": "grainy", "diffuse_reflectance": "grain", "roughness": 0.2},
-                   {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(uv * 8, 3)"},
+                   {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(P * 6, 3) * cellnoise(P.x * 4)"},  # (the 3D and 1D forms)
                    {"type": "diffuse", "name": "veined", "reflectance": "marble"}]
     for e in s["entities"]:
         if e["bsdf"] == "mat-Diamond":

@@ -372,7 +372,7 @@ def test_perlin_noise_equals_the_reference_function():
 
 
 def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_to_them():
-    """noise / cellnoise / pnoise and their colour forms over a vec2 (Transpiler.cpp:734-775 -> src/artic/texture/noise.art:35-75,218-244)
+    """noise / cellnoise / pnoise and their colour forms over a number, vec2 or vec3 (Transpiler.cpp:734-789 -> src/artic/texture/noise.art:2-75,152-244)
     against a Python restatement of hash_combine, sample_tea_u32 and the generator's first float, on a grid with negative coordinates, with
     and without a seed; then "noise" / "cellnoise" / "pnoise" textures (NoisePattern.cpp:33-57: color * func(uv * scale, seed), "colored")
     against the scenes with those expressions written out."""
@@ -389,7 +389,36 @@ def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_
     vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
     assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
     with pytest.raises(RuntimeError, match="not supported"):
-        ev("noise(P)", P=(1, 2, 3))  # (the 1D / 3D forms, perlin, fbm, voronoi, gabor stay refused)
+        ev("voronoi(P)", P=(1, 2, 3))  # (fbm, voronoi, gabor stay refused)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ev("perlin(P)", P=(1, 2, 3))  # (the reference has the gradient noise over a vec2 only)
+    # the forms over one and three coordinates (noise1 / noise3, cellnoise, pnoise: src/artic/texture/noise.art:2-33,152-206)
+    def noise_n(kind, xs, seed):
+        xs, seed = [F(x) for x in xs], F(seed)
+        hashed = lambda cbs: F(np.array((_tea(__import__("functools").reduce(_hash_combine, cbs, _hash_combine(0x811C9DC5, _bits(seed))), 1) & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
+        if kind == "cellnoise":
+            return hashed([_u32(int(x)) for x in xs])
+        if kind == "pnoise":
+            ip = [F(int(x)) for x in xs]
+            sm = lambda x: F(abs(F(F(x * x) * F(F(3) - F(F(2) * x)))))
+            k = [sm(F(x - i)) for x, i in zip(xs, ip)]
+            lerp = lambda a, b, t: F(F(F(F(1) - t) * a) + F(t * b))
+            p = [hashed([_bits(F(ip[i] + 1) if (c >> i) & 1 else ip[i]) for i in range(len(xs))]) for c in range(1 << len(xs))]
+            for i in range(len(xs)):
+                p = [lerp(p[2 * c], p[2 * c + 1], k[i]) for c in range(len(p) // 2)]
+            return p[0]
+        return hashed([_bits(x) for x in xs])
+    for x in np.linspace(-2.6, 5.3, 9):
+        for y in np.linspace(-1.4, 3.9, 5):
+            z = 0.37 * x - 1.1 * y
+            P = (float(F(x)), float(F(y)), float(F(z)))
+            for kind in ("noise", "cellnoise", "pnoise"):
+                assert near(ev(f"{kind}(P, 4)", P=P)[1], float(noise_n(kind, P, 4.0)), 1e-7), (kind, P)
+                assert near(ev(f"{kind}(P.x)", P=P)[1], float(noise_n(kind, P[:1], default)), 1e-7), (kind, P)
+                assert near(ev(f"{kind}(uv)", uvw=P)[1], float(_noise2(kind, P[0], P[1], default)), 1e-7), (kind, P)  # (and the two-coordinate form again)
+            want = tuple(float(noise_n("pnoise", P, F(F(2.0) + F(o)))) for o in (0, 1234, 5678)) + (1.0,)
+            assert near(ev("cpnoise(P, 2)", P=P)[1], want, 1e-7), P
+            assert near(ev("snoise(P)", P=P)[1], float(noise_n("noise", P, default) * F(2) - F(1)), 1e-7), P
     for tex, src in (({"type": "noise", "name": "t", "color": [0.9, 0.5, 0.3], "scale_x": 40, "scale_y": 30}, "color(0.9, 0.5, 0.3) * noise(vec2(uv.x * 40.0, uv.y * 30.0), 36326639.0)"),
                      ({"type": "cellnoise", "name": "t", "seed": 11, "colored": True}, "color(1, 1, 1) * ccellnoise(vec2(uv.x * 10.0, uv.y * 10.0), 11.0)"),
                      ({"type": "pnoise", "name": "t", "scale_x": 6, "scale_y": 6, "transform": _T16}, "color(1, 1, 1) * pnoise(vec2(%s * 6.0, %s * 6.0), 36326639.0)" % _uv_rows())):
