@@ -1278,7 +1278,7 @@ static bool brickExpression(const JsonValue& prop, const JsonValue& textures, st
         if (t.getString("name") != prop.str)
             continue;
         const std::string type = t.getString("type");
-        if (type == "noise" || type == "cellnoise" || type == "pnoise" || type == "perlin") {
+        if (type == "noise" || type == "cellnoise" || type == "pnoise" || type == "perlin" || type == "voronoi" || type == "fbm") {
             // NoisePattern.cpp:33-57 -> make_[c]<type>_texture (src/artic/texture/noise.art:250-275): color * func(transform(uv) * scale, seed),
             // "colored": the three-channel form of the function
             const V3 c     = getColor(t, "color", V3(1, 1, 1), prop.str);

@@ -1766,14 +1766,25 @@ def test_noise_textures_vs_oracle(gpu_device):
         if b["name"] == "mat-ColoredWall":
             b["reflectance"] = "cells"
     s["textures"].append({"type": "perlin", "name": "marble", "color": [0.8, 0.85, 0.9], "scale_x": 9, "scale_y": 4, "colored": True})
+    # (voronoi: distance to the nearest feature point of the 3 x 3 cells; fbm: six octaves of it; cells' colours in the "colored" forms)
+    s["textures"] += [{"type": "voronoi", "name": "cracks", "color": [0.9, 0.9, 0.8], "scale_x": 7, "scale_y": 7},
+                      {"type": "fbm", "name": "rust", "colored": True, "scale_x": 3, "scale_y": 3, "seed": 5}]
+    for b in s["bsdfs"]:
+        if b["name"] == "mat-Light":
+            continue
+        if b["name"] == "mat-ColoredWall":
+            b["reflectance"] = "rust"
     s["bsdfs"] += [{"type": "plastic", "name": "grainy", "diffuse_reflectance": "grain", "roughness": 0.2},
                    {"type": "conductor", "name": "brushed", "roughness": "0.05 + 0.4 * pnoise(P * 6, 3) * cellnoise(P.x * 4)"},  # (the 3D and 1D forms)
-                   {"type": "diffuse", "name": "veined", "reflectance": "marble"}]
+                   {"type": "diffuse", "name": "veined", "reflectance": "marble"},
+                   {"type": "plastic", "name": "cracked", "diffuse_reflectance": "cracks", "roughness": "0.1 + 0.3 * voronoi(uv * 4)"}]
     for e in s["entities"]:
         if e["bsdf"] == "mat-Diamond":
             e["bsdf"] = "grainy" if e["name"].endswith("1") else ("brushed" if e["name"].endswith("2") else "veined")
+        elif e["name"] == "Back":
+            e["bsdf"] = "cracked"
     sc = LoadedScene.from_string(json.dumps(s), SCENES, 96, 72)
-    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 8)) >= 3
+    assert sum(1 for i in range(sc.scene.material_count) if sc.scene.materials[i].flags & (1 << 8)) >= 5
     _compare_with_oracle(gpu_device, sc, 96, 72, 4, seed=61, iters=2)
 
 

@@ -118,7 +118,7 @@ def test_bump_node():
 
 
 @pytest.mark.parametrize("src,what", [
-    ("foo", "unknown variable 'foo'"), ("voronoi(uv)", "'voronoi' is not supported"), ("entity_id", "'entity_id' is not supported"),
+    ("foo", "unknown variable 'foo'"), ("gabor(uv)", "'gabor' is not supported"), ("entity_id", "'entity_id' is not supported"),
     ("uv.z", "outside of vec2"), ("1 +", "end of expression"), ("vec3(1,2) ", "no function vec3(int, int)"), ("1 && 2", "expects bool"),
     ("vec3(1) < vec3(2)", "expects int or num"), ("vec2(1) + vec3(1)", "cannot add vec2 and vec3"), ("3 % 2.0", "'%' expects int"),
     ("2 / vec3(1)", "cannot divide int and vec3"), ("'text'", "string"), ("(1", "expected ')'"), ("1 $ 2", "unexpected character"),
@@ -148,7 +148,7 @@ def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
     m = sc.scene.materials[0]
     assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
     assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
-    for bad, what in (("fbm(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+    for bad, what in (("gabor(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
     with pytest.raises(RuntimeError, match="inside a blend"):
@@ -371,6 +371,57 @@ def test_perlin_noise_equals_the_reference_function():
     assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8 and np.isfinite(fa).all()
 
 
+def _voronoi2(u, v, seed):
+    """voronoi2_f1_gen, Euclidean, randomness 1 (src/artic/texture/voronoi.art:100-119): (distance, cnoise2(nearest cell, seed))"""
+    u, v, seed = F(u), F(v), F(seed)
+    ip = (F(np.floor(u)), F(np.floor(v)))
+    fp = (F(u - ip[0]), F(v - ip[1]))
+    fma = lambda a, b, c: F(np.float64(a) * np.float64(b) + np.float64(c))
+    dist, target = F(8), None
+    for j in (-1, 0, 1):
+        for i in (-1, 0, 1):
+            k = (F(ip[0] + F(i)), F(ip[1] + F(j)))
+            r = (F(_noise2("noise", k[0], k[1], seed) * F(1)), F(_noise2("noise", k[0], k[1], F(seed + F(175391))) * F(1)))
+            dx, dy = F(F(F(i) + r[0]) - fp[0]), F(F(F(j) + r[1]) - fp[1])
+            d = F(np.sqrt(fma(dx, dx, F(dy * dy))))
+            if d < dist:
+                dist, target = d, k
+    return dist, tuple(_noise2("noise", target[0], target[1], F(seed + F(o))) for o in (0, 1234, 5678)) + (F(1),)
+
+
+def _fbm2(u, v, seed):
+    """fbm2_gen(uv, seed, 6, 2, 0.5, F1, Euclidean) (:221-238): the colour is weighted with the amplitude after its update"""
+    s, m, a, p, b = F(0), F(0), F(0.5), (F(u), F(v)), [F(0), F(0), F(0), F(1)]
+    for _ in range(6):
+        f, c = _voronoi2(p[0], p[1], seed)
+        s, m = F(s + F(a * f)), F(m + a)
+        a = F(a * F(0.5))
+        p = (F(p[0] * F(2)), F(p[1] * F(2)))
+        b = [F(b[i] + F(c[i] * a)) for i in range(3)] + [min(F(1), F(b[3] + F(c[3] * a)))]
+    return F(s / m), tuple(F(x / m) for x in b)
+
+
+def test_voronoi_and_fbm_equal_the_reference_functions():
+    """voronoi / cvoronoi / fbm / cfbm over a vec2 (Transpiler.cpp:769-792 -> voronoi2 / cvoronoi2 / fbm2 / cfbm2, src/artic/texture/voronoi.art)
+    against a float32 restatement, and the "voronoi" / "fbm" textures (NoisePattern.cpp, make_[c]voronoi_texture / make_[c]fbm_texture) against
+    their expressions."""
+    import oracle
+    for u in np.linspace(-2.7, 4.9, 9):
+        for v in np.linspace(-1.6, 3.3, 7):
+            uvw = (float(F(u)), float(F(v)), 0)
+            d, c = _voronoi2(u, v, 5.0)
+            assert near(ev("voronoi(uv, 5)", uvw=uvw)[1], float(d), 1e-6) and near(ev("cvoronoi(uv, 5)", uvw=uvw)[1], tuple(float(x) for x in c), 1e-7), (u, v)
+            f, fc = _fbm2(u, v, 36326639.0)
+            assert near(ev("fbm(uv)", uvw=uvw)[1], float(f), 2e-6) and near(ev("cfbm(uv)", uvw=uvw)[1], tuple(float(x) for x in fc), 2e-6), (u, v)
+    for tex, src in (({"type": "voronoi", "name": "t", "color": [0.9, 0.8, 0.6], "scale_x": 6, "scale_y": 4}, "color(0.9, 0.8, 0.6) * voronoi(vec2(uv.x * 6.0, uv.y * 4.0), 36326639.0)"),
+                     ({"type": "fbm", "name": "t", "colored": True, "scale_x": 3, "scale_y": 3, "seed": 9}, "color(1, 1, 1) * cfbm(vec2(uv.x * 3.0, uv.y * 3.0), 9.0)")):
+        a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [tex]})), SCENES, 64, 64)
+        b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": src})), SCENES, 64, 64)
+        fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+        fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+        assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8 and np.isfinite(fa).all(), tex["type"]
+
+
 def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_to_them():
     """noise / cellnoise / pnoise and their colour forms over a number, vec2 or vec3 (Transpiler.cpp:734-789 -> src/artic/texture/noise.art:2-75,152-244)
     against a Python restatement of hash_combine, sample_tea_u32 and the generator's first float, on a grid with negative coordinates, with
@@ -389,7 +440,7 @@ def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_
     vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
     assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
     with pytest.raises(RuntimeError, match="not supported"):
-        ev("voronoi(P)", P=(1, 2, 3))  # (fbm, voronoi, gabor stay refused)
+        ev("voronoi(P)", P=(1, 2, 3))  # (voronoi / fbm over one or three coordinates and gabor stay refused)
     with pytest.raises(RuntimeError, match="not supported"):
         ev("perlin(P)", P=(1, 2, 3))  # (the reference has the gradient noise over a vec2 only)
     # the forms over one and three coordinates (noise1 / noise3, cellnoise, pnoise: src/artic/texture/noise.art:2-33,152-206)
