@@ -800,10 +800,13 @@ struct TextureBank {
                 return true;
         return false;
     }
+    std::map<std::string, igh::pexpr::Param> local_params; // the custom variables of the "expr" texture being lowered (lowerColor)
     igh::pexpr::Program compileExpr(const std::string& src, const std::string& owner)
     {
         igh::pexpr::Env env;
         env.params  = params;
+        for (const auto& lp : local_params)
+            env.params[lp.first] = lp.second;
         env.texture = [&](const std::string& n) { return has(n) ? get(n, owner) : -1; };
         try {
             return igh::pexpr::compile(src, env);
@@ -1328,6 +1331,38 @@ static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const Jso
             }
     std::string brick;
     bool is_brick = col && brickExpression(*col, textures, brick, name);
+    bank.local_params.clear();
+    if (col && !is_brick && col->isString())
+        for (const auto& t : textures.arr)
+            if (t.getString("name") == col->str && t.getString("type") == "expr") {
+                // ExprPattern.cpp:14-75: the texture IS its "expr" string; properties num_<x> / color_<x> / vec_<x> / bool_<x> are variables <x> of
+                // it (constants here; the reference allows textures and expressions there too)
+                brick    = t.getString("expr");
+                is_brick = true;
+                if (brick.empty())
+                    fail("Texture '" + col->str + "' requires an expression");
+                for (const auto& kv : t.obj) {
+                    const std::string& k = kv.first;
+                    igh::pexpr::Param p{};
+                    V3 c;
+                    if (k.rfind("num_", 0) == 0 && k.size() > 4) {
+                        const float v = getConstNumber(t, k, 0.0f, col->str);
+                        p.type = igh::pexpr::Type::Num, p.value = { v, v, v, v };
+                        bank.local_params[k.substr(4)] = p;
+                    } else if ((k.rfind("color_", 0) == 0 && k.size() > 6) || (k.rfind("vec_", 0) == 0 && k.size() > 4)) {
+                        const bool is_col = k[0] == 'c';
+                        if (!parseConstColor(kv.second, c))
+                            fail("Texture '" + col->str + "': property '" + k + "' is not a constant; textures and expressions there are not supported by the HIP backend");
+                        p.type = is_col ? igh::pexpr::Type::Vec4 : igh::pexpr::Type::Vec3, p.value = { c.x, c.y, c.z, is_col ? 1.0f : 0.0f };
+                        bank.local_params[k.substr(is_col ? 6 : 4)] = p;
+                    } else if (k.rfind("bool_", 0) == 0 && k.size() > 5 && kv.second.isBool()) {
+                        const float v = kv.second.b ? 1.0f : 0.0f;
+                        p.type = igh::pexpr::Type::Bool, p.value = { v, v, v, v };
+                        bank.local_params[k.substr(5)] = p;
+                    }
+                }
+                break;
+            }
     if (col && !is_brick && col->isString())
         for (const auto& t : textures.arr)
             if (t.getString("name") == col->str && t.getString("type") == "checkerboard" && t.has("transform")) {
@@ -1356,6 +1391,7 @@ static void lowerColor(const JsonValue& bsdf, const char* key, V3 def, const Jso
         using igh::pexpr::Type;
         if (prog.type == Type::Bool || prog.type == Type::Vec2) // "Expression does not return a number or color" (Transpiler.cpp:1303-1306)
             fail("'" + name + "': expression of property '" + key + "' is a " + igh::pexpr::typeName(prog.type) + ", not a number or colour");
+        bank.local_params.clear();
         if (!prog.is_const) {
             m.flags |= IG_MAT_EXPR_COLOR;
             m.tex_refl = bank.addProgram(prog);

@@ -422,6 +422,25 @@ def test_voronoi_and_fbm_equal_the_reference_functions():
         assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8 and np.isfinite(fa).all(), tex["type"]
 
 
+def test_expr_texture_with_custom_variables():
+    """An "expr" texture (ExprPattern.cpp:14-75): its expression with the num_ / color_ / vec_ / bool_ properties as variables, named by a colour
+    property — the same pixels as the expression written out with the values in place."""
+    import oracle
+    tex = {"type": "expr", "name": "t", "expr": "mix(base, color(shift.x, shift.y, shift.z) * pnoise(uv * freq), select(flip, 0.25, 0.75))",
+           "num_freq": 6, "color_base": [0.9, 0.2, 0.1], "vec_shift": [0.1, 0.5, 0.9], "bool_flip": True}
+    src = "mix(color(0.9, 0.2, 0.1), color(0.1, 0.5, 0.9) * pnoise(uv * 6.0), select(true, 0.25, 0.75))"
+    a = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [tex]})), SCENES, 64, 64)
+    b = LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": src})), SCENES, 64, 64)
+    assert a.scene.materials[0].flags & (1 << 8) and b.scene.materials[0].flags & (1 << 8)
+    fa, _ = oracle.render(a, 4, 64, 64, iteration=0, seed=3)
+    fb, _ = oracle.render(b, 4, 64, 64, iteration=0, seed=3)
+    assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8
+    with pytest.raises(RuntimeError, match="requires an expression"):
+        LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "t"}, {"textures": [{"type": "expr", "name": "t"}]})), SCENES, 64, 64)
+    with pytest.raises(RuntimeError, match="unknown variable 'freq'"):  # (the variables are the texture's own)
+        LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": "pnoise(uv * freq)"}, {"textures": [tex]})), SCENES, 64, 64)
+
+
 def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_to_them():
     """noise / cellnoise / pnoise and their colour forms over a number, vec2 or vec3 (Transpiler.cpp:734-789 -> src/artic/texture/noise.art:2-75,152-244)
     against a Python restatement of hash_combine, sample_tea_u32 and the generator's first float, on a grid with negative coordinates, with
