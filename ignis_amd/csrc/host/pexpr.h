@@ -621,7 +621,7 @@ private:
         {
             // voronoi / cvoronoi / fbm / cfbm over a vec2 (Transpiler.cpp:769-792 -> voronoi2 / cvoronoi2 / fbm2 / cfbm2, src/artic/texture/voronoi.art:259-287:
             // F1, Euclidean distance; fbm: 6 octaves, lacunarity 2, gain 0.5)
-            static const struct { const char* name; uint32_t imm; } cells[] = { { "voronoi", 0u }, { "cvoronoi", 4u }, { "fbm", 1u }, { "cfbm", 5u } };
+            static const struct { const char* name; uint32_t imm; } cells[] = { { "voronoi", 0u }, { "cvoronoi", 4u }, { "fbm", 1u }, { "cfbm", 5u }, { "gabor", 2u } };
             for (const auto& f : cells)
                 if (name == f.name && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
                     if (n == 1)

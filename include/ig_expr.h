@@ -68,7 +68,8 @@ enum ige_op {
     IGE_DIST,
     IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
     IGE_NOISE,    /* the noises of texture/noise.art: f(r[a] leading lanes, seed r[b].x), imm = enum ige_noise | 4 colour form | 8 signed | dims << 4 */
-    IGE_VORONOI,  /* voronoi2 / cvoronoi2 / fbm2 / cfbm2 (texture/voronoi.art:100-119,221-238,259-274): f(r[a].xy, seed r[b].x), imm bit 0: fbm, bit 2: colour */
+    IGE_VORONOI,  /* voronoi2 / cvoronoi2 / fbm2 / cfbm2 (texture/voronoi.art:100-119,221-238,259-274) and gabor2 (texture/noise.art:131-150):
+                   * f(r[a].xy, seed r[b].x), imm bit 0: fbm, bit 1: gabor, bit 2: colour */
     IGE_OP_COUNT
 };
 
@@ -255,6 +256,29 @@ IGM_FN float ige_fbm2(float u, float v, float seed, float* col)
     for (int i = 0; i < 4; ++i)
         col[i] = b[i] / m;
     return s / m;
+}
+
+/* gabor2 = gabor2_gen(uv, seed, 100, 20, 5, 0.01) (texture/noise.art:131-150): a hundred Gabor kernels whose positions and orientations are
+ * noise2 of INTEGER coordinates (i, 0 .. 3); exp / cos / sin / atan2 are this backend's deterministic ones (ig_detmath.h) */
+IGM_FN float ige_gabor2(float u, float v, float seed)
+{
+    const float pi = 3.14159265359f, phase = 20.0f, frequency = 5.0f, bandwidth = 0.01f;
+    float acc = 0.0f;
+    for (int i = 0; i < 100; ++i) {
+        uint32_t cb[2] = { (uint32_t)i, 0u };
+        float n[4];
+        for (uint32_t k = 0; k < 4; ++k) {
+            cb[1] = k;
+            n[k]  = ige_noise_bits(2, cb, seed);
+        }
+        const float omega_d = igm_atan2(n[2], n[3]) * phase;
+        const float ox = igm_cos(omega_d), oy = igm_sin(omega_d);
+        const float len = igm_sqrt(igm_fma(n[0], n[0], n[1] * n[1]));
+        const float kk  = igm_exp(-len * bandwidth * pi);
+        const float dx = u - n[0], dy = v - n[1];
+        acc += kk * igm_cos(2 * pi * frequency * igm_fma(dx, ox, dy * oy));
+    }
+    return acc / igm_sqrt(100.0f);
 }
 
 IGM_FN float ige_f1_apply(int f, float x)
@@ -586,7 +610,7 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
         }
         case IGE_VORONOI: {
             float col[4];
-            const float f = (imm & 1u) ? ige_fbm2(a.v[0], a.v[1], b.v[0], col) : ige_voronoi2(a.v[0], a.v[1], b.v[0], col);
+            const float f = (imm & 2u) ? ige_gabor2(a.v[0], a.v[1], b.v[0]) : ((imm & 1u) ? ige_fbm2(a.v[0], a.v[1], b.v[0], col) : ige_voronoi2(a.v[0], a.v[1], b.v[0], col));
             for (int i = 0; i < 4; ++i)
                 o.v[i] = (imm & 4u) ? col[i] : f;
             break;

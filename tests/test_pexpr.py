@@ -118,7 +118,7 @@ def test_bump_node():
 
 
 @pytest.mark.parametrize("src,what", [
-    ("foo", "unknown variable 'foo'"), ("gabor(uv)", "'gabor' is not supported"), ("entity_id", "'entity_id' is not supported"),
+    ("foo", "unknown variable 'foo'"), ("hash(uv)", "'hash' is not supported"), ("entity_id", "'entity_id' is not supported"),
     ("uv.z", "outside of vec2"), ("1 +", "end of expression"), ("vec3(1,2) ", "no function vec3(int, int)"), ("1 && 2", "expects bool"),
     ("vec3(1) < vec3(2)", "expects int or num"), ("vec2(1) + vec3(1)", "cannot add vec2 and vec3"), ("3 % 2.0", "'%' expects int"),
     ("2 / vec3(1)", "cannot divide int and vec3"), ("'text'", "string"), ("(1", "expected ')'"), ("1 $ 2", "unexpected character"),
@@ -148,7 +148,7 @@ def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
     m = sc.scene.materials[0]
     assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
     assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
-    for bad, what in (("gabor(uv) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+    for bad, what in (("voronoi(P) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
     with pytest.raises(RuntimeError, match="inside a blend"):
@@ -422,6 +422,26 @@ def test_voronoi_and_fbm_equal_the_reference_functions():
         assert np.array_equal(fa, fb) and len(np.unique(fa.round(3))) > 8 and np.isfinite(fa).all(), tex["type"]
 
 
+def test_gabor_noise_equals_the_reference_function():
+    """gabor(vec2[, seed]) = gabor2_gen(uv, seed, 100, 20, 5, 0.01) (Transpiler.cpp:796-797, src/artic/texture/noise.art:131-150) against a
+    restatement with numpy's exp / cos / sin / arctan2 (the backend's deterministic ones differ from libm in the last places: 100 terms)."""
+    pi = F(3.14159265359)
+    for seed, src in ((36326639.0, "gabor(uv)"), (4.0, "gabor(uv, 4)")):
+        for u, v in ((0.3, 0.4), (1.7, -0.6), (-2.2, 3.1), (5.5, 0.25)):
+            acc = F(0)
+            for i in range(100):
+                n = [_noise2_bits(i, k, F(seed)) for k in range(4)]  # noise2(i, k, seed): integer coordinates
+                od = F(F(np.arctan2(n[2], n[3])) * F(20))
+                ox, oy = F(np.cos(od)), F(np.sin(od))
+                ln = F(np.sqrt(F(F(n[0] * n[0]) + F(n[1] * n[1]))))
+                kk = F(np.exp(F(F(F(-ln) * F(0.01)) * pi)))
+                dot = F(F(F(F(u) - n[0]) * ox) + F(F(F(v) - n[1]) * oy))
+                acc = F(acc + F(kk * F(np.cos(F(F(F(F(2) * pi) * F(5)) * dot)))))
+            want = float(F(acc / F(np.sqrt(F(100)))))
+            got = ev(src, uvw=(float(F(u)), float(F(v)), 0))[1]
+            assert abs(got - want) < 2e-4, (src, u, v, got, want)
+
+
 def test_expr_texture_with_custom_variables():
     """An "expr" texture (ExprPattern.cpp:14-75): its expression with the num_ / color_ / vec_ / bool_ properties as variables, named by a colour
     property — the same pixels as the expression written out with the values in place."""
@@ -459,7 +479,7 @@ def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_
     vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
     assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
     with pytest.raises(RuntimeError, match="not supported"):
-        ev("voronoi(P)", P=(1, 2, 3))  # (voronoi / fbm over one or three coordinates and gabor stay refused)
+        ev("voronoi(P)", P=(1, 2, 3))  # (voronoi / fbm over one or three coordinates stay refused)
     with pytest.raises(RuntimeError, match="not supported"):
         ev("perlin(P)", P=(1, 2, 3))  # (the reference has the gradient noise over a vec2 only)
     # the forms over one and three coordinates (noise1 / noise3, cellnoise, pnoise: src/artic/texture/noise.art:2-33,152-206)
