@@ -622,12 +622,17 @@ private:
             // voronoi / cvoronoi / fbm / cfbm over a vec2 (Transpiler.cpp:769-792 -> voronoi2 / cvoronoi2 / fbm2 / cfbm2, src/artic/texture/voronoi.art:259-287:
             // F1, Euclidean distance; fbm: 6 octaves, lacunarity 2, gain 0.5)
             static const struct { const char* name; uint32_t imm; } cells[] = { { "voronoi", 0u }, { "cvoronoi", 4u }, { "fbm", 1u }, { "cfbm", 5u }, { "gabor", 2u } };
-            for (const auto& f : cells)
-                if (name == f.name && (n == 1 || n == 2) && a[0]->type == Type::Vec2 && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
-                    if (n == 1)
-                        a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
-                    return make(IGE_VORONOI, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm, std::move(a));
-                }
+            for (const auto& f : cells) {
+                if (name != f.name || (n != 1 && n != 2) || (n == 2 && a[1]->type != Type::Num && a[1]->type != Type::Int))
+                    continue;
+                const Type ct = a[0]->type;
+                const uint32_t dims = (ct == Type::Num || ct == Type::Int) ? 1u : (ct == Type::Vec2 ? 2u : (ct == Type::Vec3 ? 3u : 0u));
+                if (dims == 0 || ((f.imm & 2u) && dims != 2)) // (gabor: a vec2 only)
+                    continue;
+                if (n == 1)
+                    a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));
+                return make(IGE_VORONOI, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm | dims << 4, std::move(a));
+            }
         }
         if (name == "snoise" && (n == 1 || n == 2) && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
             // snoiseN(x, seed) = noiseN_v(x, seed) * 2 - 1 (src/artic/texture/noise.art:6,40,157)

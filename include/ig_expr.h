@@ -68,8 +68,8 @@ enum ige_op {
     IGE_DIST,
     IGE_PACK,     /* make_vecN: (r[a].x, r[b].x, r[c].x, r[imm].x) */
     IGE_NOISE,    /* the noises of texture/noise.art: f(r[a] leading lanes, seed r[b].x), imm = enum ige_noise | 4 colour form | 8 signed | dims << 4 */
-    IGE_VORONOI,  /* voronoi2 / cvoronoi2 / fbm2 / cfbm2 (texture/voronoi.art:100-119,221-238,259-274) and gabor2 (texture/noise.art:131-150):
-                   * f(r[a].xy, seed r[b].x), imm bit 0: fbm, bit 1: gabor, bit 2: colour */
+    IGE_VORONOI,  /* voronoiN / cvoronoiN / fbmN / cfbmN (texture/voronoi.art:46-63,100-119,158-181,221-274) and gabor2 (texture/noise.art:131-150):
+                   * f(r[a] leading lanes, seed r[b].x), imm bit 0: fbm, bit 1: gabor, bit 2: colour, dims << 4 */
     IGE_OP_COUNT
 };
 
@@ -217,38 +217,49 @@ IGM_FN float ige_noise(int kind, int dims, const float* x, float seed)
     return ige_noise_bits(dims, cb, seed);
 }
 
-/* voronoi2_f1_gen with the Euclidean distance and randomness 1 (texture/voronoi.art:100-119: what voronoi2 / cvoronoi2 and the octaves of fbm2
- * use): the nearest feature point of the 3 x 3 cells around uv, rows j = -1 .. 1, columns i = -1 .. 1 inside; the point of cell k sits at
- * (noise2_v(k, seed), noise2_v(k, seed + DEFAULT_CNOISE_SEED_SHIFT0 = 175391)); returns the distance, `col` = cnoise2(nearest cell, seed) */
-IGM_FN float ige_voronoi2(float u, float v, float seed, float* col)
+/* voronoiN_f1_gen with the Euclidean distance and randomness 1 (texture/voronoi.art:46-63,100-119,158-181: what voronoiN / cvoronoiN and the octaves of
+ * fbmN use): the nearest feature point of the 3^N cells around x, the first coordinate in the innermost loop; the point of cell k sits at
+ * noiseN_v(k, seed [+ DEFAULT_CNOISE_SEED_SHIFT0 = 175391, + SHIFT1 = 822167 for the second / third coordinate]); distances |d|, vec2_len, vec3_len;
+ * returns the distance, `col` = cnoiseN(nearest cell, seed) */
+IGM_FN float ige_voronoi(int dims, const float* x, float seed, float* col)
 {
-    const float ipx = igm_floor(u), ipy = igm_floor(v), fpx = u - ipx, fpy = v - ipy;
-    float dist = 8.0f, tx = 0.0f, ty = 0.0f;
-    for (int j = -1; j < 2; ++j)
-        for (int i = -1; i < 2; ++i) {
-            const float gx = (float)i, gy = (float)j, k[2] = { ipx + gx, ipy + gy };
-            const float rx = ige_noise(IGE_NOISE_WHITE, 2, k, seed) * 1.0f, ry = ige_noise(IGE_NOISE_WHITE, 2, k, seed + 175391.0f) * 1.0f;
-            const float dx = (gx + rx) - fpx, dy = (gy + ry) - fpy;
-            const float d  = igm_sqrt(igm_fma(dx, dx, dy * dy)); /* vec2_len = sqrt(vec2_dot(v, v)) */
-            if (d < dist)
-                tx = k[0], ty = k[1], dist = d;
+    float ip[3] = { 0, 0, 0 }, fp[3] = { 0, 0, 0 }, t[3] = { 0, 0, 0 };
+    for (int i = 0; i < dims; ++i)
+        ip[i] = igm_floor(x[i]), fp[i] = x[i] - ip[i];
+    const float shifts[3] = { 0.0f, 175391.0f, 822167.0f };
+    float dist = 8.0f;
+    const int cells = dims == 1 ? 3 : (dims == 2 ? 9 : 27);
+    for (int c = 0; c < cells; ++c) {
+        const float g[3] = { (float)(c % 3 - 1), (float)((c / 3) % 3 - 1), (float)(c / 9 - 1) };
+        float k[3], dd[3] = { 0, 0, 0 };
+        for (int i = 0; i < dims; ++i)
+            k[i] = ip[i] + g[i];
+        for (int i = 0; i < dims; ++i)
+            dd[i] = (g[i] + ige_noise(IGE_NOISE_WHITE, dims, k, i == 0 ? seed : seed + shifts[i]) * 1.0f) - fp[i];
+        const float d = dims == 1 ? igm_abs(dd[0]) : igm_sqrt(dims == 2 ? igm_fma(dd[0], dd[0], dd[1] * dd[1]) : igm_fma(dd[0], dd[0], igm_fma(dd[1], dd[1], dd[2] * dd[2])));
+        if (d < dist) {
+            for (int i = 0; i < dims; ++i)
+                t[i] = k[i];
+            dist = d;
         }
-    const float t[2] = { tx, ty };
-    col[0] = ige_noise(IGE_NOISE_WHITE, 2, t, seed), col[1] = ige_noise(IGE_NOISE_WHITE, 2, t, seed + 1234.0f), col[2] = ige_noise(IGE_NOISE_WHITE, 2, t, seed + 5678.0f);
+    }
+    col[0] = ige_noise(IGE_NOISE_WHITE, dims, t, seed), col[1] = ige_noise(IGE_NOISE_WHITE, dims, t, seed + 1234.0f), col[2] = ige_noise(IGE_NOISE_WHITE, dims, t, seed + 5678.0f);
     col[3] = 1.0f;
     return dist;
 }
-/* fbm2 / cfbm2 = fbm2_gen(uv, seed, 6, 2, 0.5, F1, Euclidean) (:221-238,267-274): the colour sum takes the amplitude AFTER its update */
-IGM_FN float ige_fbm2(float u, float v, float seed, float* col)
+/* fbmN / cfbmN = fbmN_gen(x, seed, 6, 2, 0.5, F1, Euclidean) (:221-257,267-274): the colour sum takes the amplitude AFTER its update */
+IGM_FN float ige_fbm(int dims, const float* x0, float seed, float* col)
 {
     float s = 0.0f, m = 0.0f, a = 0.5f, b[4] = { 0.0f, 0.0f, 0.0f, 1.0f }; /* color_builtins::black = (0, 0, 0, 1) */
+    float x[3] = { x0[0], x0[1], x0[2] };
     for (int o = 0; o < 6; ++o) {
         float c[4];
-        const float f = ige_voronoi2(u, v, seed, c);
+        const float f = ige_voronoi(dims, x, seed, c);
         s += a * f;
         m += a;
         a *= 0.5f;
-        u = u * 2.0f, v = v * 2.0f;
+        for (int i = 0; i < dims; ++i)
+            x[i] = x[i] * 2.0f;
         for (int i = 0; i < 3; ++i)
             b[i] = b[i] + c[i] * a;
         b[3] = igm_min(1.0f, b[3] + c[3] * a); /* color_add clamps the alpha (core/color.art:11) */
@@ -610,7 +621,8 @@ IGM_FN ige_v4 ige_run(const uint32_t* code, const Ctx& ctx, Regs&& r)
         }
         case IGE_VORONOI: {
             float col[4];
-            const float f = (imm & 2u) ? ige_gabor2(a.v[0], a.v[1], b.v[0]) : ((imm & 1u) ? ige_fbm2(a.v[0], a.v[1], b.v[0], col) : ige_voronoi2(a.v[0], a.v[1], b.v[0], col));
+            const int dims = (int)((imm >> 4) & 3u);
+            const float f  = (imm & 2u) ? ige_gabor2(a.v[0], a.v[1], b.v[0]) : ((imm & 1u) ? ige_fbm(dims, a.v, b.v[0], col) : ige_voronoi(dims, a.v, b.v[0], col));
             for (int i = 0; i < 4; ++i)
                 o.v[i] = (imm & 4u) ? col[i] : f;
             break;

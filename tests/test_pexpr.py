@@ -148,7 +148,7 @@ def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
     m = sc.scene.materials[0]
     assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
     assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
-    for bad, what in (("voronoi(P) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+    for bad, what in (("hash(P) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
     with pytest.raises(RuntimeError, match="inside a blend"):
@@ -401,6 +401,53 @@ def _fbm2(u, v, seed):
     return F(s / m), tuple(F(x / m) for x in b)
 
 
+def test_voronoi_and_fbm_over_one_and_three_coordinates():
+    """voronoi1_f1_gen / voronoi3_f1_gen and fbm over them (src/artic/texture/voronoi.art:46-63,158-181,240-257): three / twenty-seven cells, the
+    feature point's coordinates drawn with the seed shifted by 0 / 175391 / 822167, |d| / vec3_len as the distance."""
+    import functools
+    hashed = lambda cbs, seed: F(np.array((_tea(functools.reduce(_hash_combine, cbs, _hash_combine(0x811C9DC5, _bits(seed))), 1) & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
+    white = lambda xs, seed: hashed([_bits(x) for x in xs], F(seed))
+    fma = lambda a, b, c: F(np.float64(a) * np.float64(b) + np.float64(c))
+
+    def voronoi(xs, seed):
+        xs, seed = [F(x) for x in xs], F(seed)
+        n = len(xs)
+        ip = [F(np.floor(x)) for x in xs]
+        fp = [F(x - i) for x, i in zip(xs, ip)]
+        dist, target = F(8), [F(0)] * n
+        for c in range(3 ** n):
+            g = [F((c // 3 ** i) % 3 - 1) for i in range(n)]
+            k = [F(ip[i] + g[i]) for i in range(n)]
+            dd = [F(F(g[i] + F(white(k, F(seed + F((0, 175391, 822167)[i]))) * F(1))) - fp[i]) for i in range(n)]
+            d = F(abs(dd[0])) if n == 1 else F(np.sqrt(fma(dd[0], dd[0], fma(dd[1], dd[1], F(dd[2] * dd[2])))))
+            if d < dist:
+                dist, target = d, k
+        return dist, tuple(white(target, F(seed + F(o))) for o in (0, 1234, 5678)) + (F(1),)
+
+    def fbm(xs, seed):
+        s, m, a, p, b = F(0), F(0), F(0.5), [F(x) for x in xs], [F(0), F(0), F(0), F(1)]
+        for _ in range(6):
+            f, c = voronoi(p, seed)
+            s, m = F(s + F(a * f)), F(m + a)
+            a = F(a * F(0.5))
+            p = [F(x * F(2)) for x in p]
+            b = [F(b[i] + F(c[i] * a)) for i in range(3)] + [min(F(1), F(b[3] + F(c[3] * a)))]
+        return F(s / m), tuple(F(x / m) for x in b)
+    for x in np.linspace(-2.4, 3.8, 7):
+        for y in (-1.3, 0.45, 2.6):
+            P = (float(F(x)), float(F(y)), float(F(0.7 * x + 0.2 * y)))
+            d, c = voronoi(P, 3.0)
+            assert near(ev("voronoi(P, 3)", P=P)[1], float(d), 1e-6) and near(ev("cvoronoi(P, 3)", P=P)[1], tuple(float(v) for v in c), 1e-7), P
+            d1, c1 = voronoi(P[:1], 36326639.0)
+            assert near(ev("voronoi(P.x)", P=P)[1], float(d1), 1e-6) and near(ev("cvoronoi(P.x)", P=P)[1], tuple(float(v) for v in c1), 1e-7), P
+            f, fc = fbm(P, 2.0)
+            assert near(ev("fbm(P, 2)", P=P)[1], float(f), 2e-6) and near(ev("cfbm(P, 2)", P=P)[1], tuple(float(v) for v in fc), 2e-6), P
+            f1, _ = fbm(P[:1], 36326639.0)
+            assert near(ev("fbm(P.x)", P=P)[1], float(f1), 2e-6), P
+    with pytest.raises(RuntimeError, match="not supported"):
+        ev("gabor(P)", P=(1, 2, 3))  # (the reference has it over a vec2 only)
+
+
 def test_voronoi_and_fbm_equal_the_reference_functions():
     """voronoi / cvoronoi / fbm / cfbm over a vec2 (Transpiler.cpp:769-792 -> voronoi2 / cvoronoi2 / fbm2 / cfbm2, src/artic/texture/voronoi.art)
     against a float32 restatement, and the "voronoi" / "fbm" textures (NoisePattern.cpp, make_[c]voronoi_texture / make_[c]fbm_texture) against
@@ -478,8 +525,6 @@ def test_hash_noises_equal_the_reference_functions_and_the_textures_are_lowered_
     assert near(ev("snoise(uv, 2)", uvw=(0.3, 0.7, 0))[1], float(_noise2("noise", 0.3, 0.7, 2.0) * F(2) - F(1)), 1e-7)  # snoise2 (:40)
     vals = [ev("noise(uv)", uvw=(float(x), 0.5, 0))[1] for x in np.linspace(0, 1, 200)]
     assert 0 <= min(vals) < 0.05 and 0.95 < max(vals) < 1 and 0.4 < np.mean(vals) < 0.6
-    with pytest.raises(RuntimeError, match="not supported"):
-        ev("voronoi(P)", P=(1, 2, 3))  # (voronoi / fbm over one or three coordinates stay refused)
     with pytest.raises(RuntimeError, match="not supported"):
         ev("perlin(P)", P=(1, 2, 3))  # (the reference has the gradient noise over a vec2 only)
     # the forms over one and three coordinates (noise1 / noise3, cellnoise, pnoise: src/artic/texture/noise.art:2-33,152-206)
