@@ -634,6 +634,14 @@ private:
                 return make(IGE_VORONOI, (f.imm & 4u) ? Type::Vec4 : Type::Num, f.imm | dims << 4, std::move(a));
             }
         }
+        if (name == "hash" && n == 1 && (a[0]->type == Type::Num || a[0]->type == Type::Int)) {
+            // hash_rndf(seed) (Transpiler.cpp:678, src/artic/core/random.art:91-93): the first float of the generator seeded with hash_combine(init, bits(seed)) —
+            // the white noise over NO coordinate with the argument as its seed
+            std::vector<NodeP> args;
+            args.push_back(constant(Type::Num, 0, 0, 0, 0));
+            args.push_back(std::move(a[0]));
+            return make(IGE_NOISE, Type::Num, IGE_NOISE_WHITE, std::move(args));
+        }
         if (name == "snoise" && (n == 1 || n == 2) && (n == 1 || a[1]->type == Type::Num || a[1]->type == Type::Int)) {
             // snoiseN(x, seed) = noiseN_v(x, seed) * 2 - 1 (src/artic/texture/noise.art:6,40,157)
             const Type ct = a[0]->type;
@@ -712,7 +720,7 @@ private:
             return variable(name);
 
         static const char* known[] = {
-            "cbrt", "signbit", "hash", "rgbtoxyz", "xyztorgb", "rgbtohsv", "hsvtorgb", "rgbtohsl", "hsltorgb", "blackbody", "snap", "pingpong", "angle",
+            "cbrt", "signbit", "rgbtoxyz", "xyztorgb", "rgbtohsv", "hsvtorgb", "rgbtohsl", "hsltorgb", "blackbody", "snap", "pingpong", "angle",
             "rotate_euler", "rotate_euler_inverse", "rotate_axis", "fresnel_dielectric", "fresnel_conductor", "noise", "snoise", "pnoise", "cellnoise",
             "perlin", "sperlin", "fbm", "voronoi", "cvoronoi", "gabor", "cnoise", "cpnoise", "ccellnoise", "cperlin", "cfbm", "smin", "smax",
             "transform_point", "transform_direction", "transform_normal", "mix_screen", "mix_overlay", "mix_dodge", "mix_burn", "mix_soft", "mix_linear",

@@ -118,7 +118,7 @@ def test_bump_node():
 
 
 @pytest.mark.parametrize("src,what", [
-    ("foo", "unknown variable 'foo'"), ("hash(uv)", "'hash' is not supported"), ("entity_id", "'entity_id' is not supported"),
+    ("foo", "unknown variable 'foo'"), ("cbrt(P.x)", "'cbrt' is not supported"), ("entity_id", "'entity_id' is not supported"),
     ("uv.z", "outside of vec2"), ("1 +", "end of expression"), ("vec3(1,2) ", "no function vec3(int, int)"), ("1 && 2", "expects bool"),
     ("vec3(1) < vec3(2)", "expects int or num"), ("vec2(1) + vec3(1)", "cannot add vec2 and vec3"), ("3 % 2.0", "'%' expects int"),
     ("2 / vec3(1)", "cannot divide int and vec3"), ("'text'", "string"), ("(1", "expected ')'"), ("1 $ 2", "unexpected character"),
@@ -148,7 +148,7 @@ def test_loader_folds_constant_expressions_and_keeps_the_rest_as_programs():
     m = sc.scene.materials[0]
     assert m.flags & (1 << 8) and m.tex_refl == 0 and sc.scene.expr_code_count > 4
     assert sc.scene.expr_code[sc.scene.expr_code_count - 1] & 0xFF == 0  # IGE_END closes the program
-    for bad, what in (("hash(P) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
+    for bad, what in (("cbrt(P.x) * color(1)", "not supported"), ("uv", "vec2, not a number or colour"), ("nosuchtex", "unknown variable")):
         with pytest.raises(RuntimeError, match=what):
             LoadedScene.from_string(json.dumps(_scene({"type": "diffuse", "name": "m", "reflectance": bad})), SCENES, 64, 64)
     with pytest.raises(RuntimeError, match="inside a blend"):
@@ -446,6 +446,9 @@ def test_voronoi_and_fbm_over_one_and_three_coordinates():
             assert near(ev("fbm(P.x)", P=P)[1], float(f1), 2e-6), P
     with pytest.raises(RuntimeError, match="not supported"):
         ev("gabor(P)", P=(1, 2, 3))  # (the reference has it over a vec2 only)
+    for x in (0.0, 1.0, -3.25, 36326639.0, 0.1):  # hash(x) = hash_rndf (core/random.art:91-93): the generator's first float for the seed hash(bits(x))
+        want = F(np.array((_tea(_hash_combine(0x811C9DC5, _bits(F(x))), 1) & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
+        assert near(ev("hash(P.x)", P=(x, 0, 0))[1], float(want), 1e-7), x
 
 
 def test_voronoi_and_fbm_equal_the_reference_functions():
