@@ -220,7 +220,7 @@ def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "msamples_per_s": round(st["camera_rays"] / elapsed / 1e6, 3), "timed_seconds": round(elapsed, 3), "scene_load_seconds": round(t_load, 2),
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"]},
-            "stage_ms": {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")},
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve", "ms_ray_sort")},
             "geometry_resident_bytes": geom_resident,
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None, "avg_launch_ms": round(ms, 5), "launches": int(rounds), "algorithmic_bytes_per_launch": int(alg),
@@ -507,7 +507,7 @@ def main():
                     "valu": valu, "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(hbm_alg)}
 
-        stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve")}
+        stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve", "ms_ray_sort")}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

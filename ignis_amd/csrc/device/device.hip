@@ -38,6 +38,7 @@ void launch_generate(const GenerateArgs& args, hipStream_t stream);
 void launch_generate_light(const GenerateLightArgs& args, hipStream_t stream);
 void launch_shade(const ShadeArgs& args, int grid_blocks, bool full_bsdfs, hipStream_t stream, uint32_t classes);
 void launch_bin_sort(const BinSortArgs& args, int grid, hipStream_t stream);
+const uint32_t* launch_ray_sort(const RaySortArgs& args, int grid, hipStream_t stream);
 void launch_round_end(QueueState* qs, int in_slot, hipStream_t stream);
 void launch_secondary_end(QueueState* qs, int slot, QueueState* mirror, hipStream_t stream);
 void launch_resolve(const ResolveArgs& args, hipStream_t stream);
@@ -181,6 +182,16 @@ struct igd_device {
     DevBuf<uint32_t> sort_idx, sort_state;
     DevBuf<uint8_t> sort_keys, sort_tables;
     size_t sort_capacity = 0;
+    // raysort.hip: bounce and shadow rays traversed in (direction octant, origin cell) order when the BVH outgrows the L2s
+    DevBuf<uint32_t> rs_keys[2], rs_idx[2], rs_state;
+    size_t rs_capacity = 0;
+    int ray_sort_env   = -1; // IGD_RAY_SORT=1: on (default off: it does not pay, see assignScene)
+    bool ray_sort      = false;
+    int ray_sort_bits  = 7;  // IGD_RAY_SORT_BITS: bits per axis of the origin's cell
+    int ray_sort_octant_low = 0; // IGD_RAY_SORT_ORDER=cell: cell-major keys
+    int ray_sort_dir_bits   = 0; // IGD_RAY_SORT_DIR_BITS: > 0: the direction's cell on the octahedral map instead of its octant
+    uint32_t ray_sort_min = 1u << 18; // IGD_RAY_SORT_MIN: streams known to be shorter are traversed as they are
+    int ray_sort_which = 3; // IGD_RAY_SORT_STREAMS: bit 0 bounce rays, bit 1 shadow rays
 
     // Several chunks can be in flight: while side streams finish chunks k - 3 .. k (tail passes, resolve, counter
     // read-back: a latency chain of ~max_depth dependent bounces, little work) the main stream already runs the
@@ -345,6 +356,9 @@ struct igd_device {
         sort_idx.release();
         sort_keys.release();
         sort_capacity = 0;
+        for (int k = 0; k < 2; ++k)
+            rs_keys[k].release(), rs_idx[k].release();
+        rs_capacity = 0;
         lt_path_id.release();
         lt_vals.release();
         lt_keys.release();
@@ -929,6 +943,10 @@ void assignScene(igd_device* d, const igd_scene* s)
     // a BVH beyond the caches is better walked by ONE front of rays (what the XCDs' L2s and the Infinity Cache hold is then the same part of it);
     // such rays are slow enough for one counter (profiles/r05_experiment_ab.txt section 26)
     d->work_shards          = d->work_shards_env > 0 ? d->work_shards_env : (blob.size() > ((size_t)64 << 20) ? 1 : kWorkShards);
+    // (off unless asked for: on the stand-ins the whole span between a random permutation of a bounce stream and camera-ray coherence is
+    // 1.9 -> 2.6 G rays / s, the stream order k_shade leaves already sits at 2.26, the best key reaches 2.35 and the sort costs more than
+    // that: profiles/r06_ray_order.txt, profiles/r06_experiment_ab.txt section 1)
+    d->ray_sort             = d->ray_sort_env > 0;
     ds.node_repeat          = d->node_repeat >= 0 ? (uint32_t)d->node_repeat : (blob.size() > ((size_t)64 << 20) ? 3u : 0u);
     ds.scene_radius         = s->scene_radius;
     for (int k = 0; k < 3; ++k) {
@@ -1098,6 +1116,7 @@ void addSpan(igd_device* d, int kind, float ms)
     case 2: d->stats.ms_shade += ms; break;
     case 3: d->stats.ms_traverse_secondary += ms; break;
     case 4: d->stats.ms_resolve += ms; break;
+    case 6: d->stats.ms_ray_sort += ms; break;
     default: d->stats.ms_tail += ms; break;
     }
 }
@@ -1276,6 +1295,17 @@ void render(igd_device* d, const igd_render_settings* rs)
         d->sort_idx.alloc(d->capacity);
         d->sort_keys.alloc(d->capacity);
         d->sort_capacity = d->capacity;
+    }
+
+    const bool ray_sort = d->ray_sort && !list_mode && d->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER && d->dscene.tech.type != IG_TECHNIQUE_PPM;
+    if (ray_sort && d->rs_capacity < d->capacity) {
+        finish(d);
+        for (int k = 0; k < 2; ++k) {
+            d->rs_keys[k].release(), d->rs_idx[k].release();
+            d->rs_keys[k].alloc(d->capacity), d->rs_idx[k].alloc(d->capacity);
+        }
+        d->rs_state.alloc(256 + (size_t)256 * (size_t)d->sortGrid());
+        d->rs_capacity = d->capacity;
     }
 
     // the per-film constants of the camera, evaluated on the host
@@ -1662,8 +1692,30 @@ void render(igd_device* d, const igd_render_settings* rs)
             float4* sec_hit;
         };
         uint32_t round_bound = n; // upper bound of the round's primary stream, hence of its shadow rays (light tracer: what its connection sort covers)
+        // raysort.hip: the order a traversal launch takes the stream in
+        auto sortedOrder = [&](hipStream_t on, const float4* rayA, const float4* rayB, const uint32_t* count) -> const uint32_t* {
+            RaySortArgs ra{};
+            ra.rayA = rayA, ra.rayB = rayB, ra.count = count;
+            const float cells = (float)(1u << d->ray_sort_bits);
+            for (int k = 0; k < 3; ++k) {
+                const float ext = d->scene_bbox[3 + k] - d->scene_bbox[k];
+                ra.box_min[k]   = d->scene_bbox[k];
+                ra.box_scale[k] = ext > 0 ? cells / ext : 0.0f;
+            }
+            ra.cell_bits  = (uint32_t)d->ray_sort_bits;
+            ra.octant_low = (uint32_t)d->ray_sort_octant_low;
+            ra.dir_bits   = (uint32_t)std::min(d->ray_sort_dir_bits, (32 - 3 * d->ray_sort_bits) / 2);
+            for (int k = 0; k < 2; ++k)
+                ra.keys[k] = d->rs_keys[k].ptr, ra.idx[k] = d->rs_idx[k].ptr;
+            ra.state   = d->rs_state.ptr;
+            ra.wg_hist = d->rs_state.ptr + 256;
+            const uint32_t* order = nullptr;
+            timed(6, on, [&] { order = launch_ray_sort(ra, d->sortGrid(), on); });
+            return order;
+        };
         auto launchRound = [&](hipStream_t on, const RoundBufs& b, int in_slot, int trav_grid, int shade_grid, QueueState* mirror, bool bounce_rays_only) {
             const PrimaryCols in = b.prim[in_slot];
+            const bool sort_round = ray_sort && bounce_rays_only && round_bound >= d->ray_sort_min;
             TraverseArgs ta{};
             ta.scene = d->dscene;
             ta.rayA = in.rayA, ta.rayB = in.rayB, ta.meta = in.meta;
@@ -1689,6 +1741,8 @@ void render(igd_device* d, const igd_render_settings* rs)
             ta.hit = in.hit, ta.hit_v = in.hit_v;
             ta.hit_pack = d->hit_pack_bits;
             ta.sphere_work_counter = &qs->work[4].w[0][0];
+            if (sort_round && (d->ray_sort_which & 1))
+                ta.sort_idx = sortedOrder(on, in.rayA, in.rayB, &qs->q[in_slot].primary);
             timed(1, on, [&] { launchTraverse(d, ta, false, counters, trav_grid, &qs->work[1].w[0][0], on, d->deep_grid, d->deep_primary); });
 
             ShadeArgs sa{};
@@ -1771,6 +1825,8 @@ void render(igd_device* d, const igd_render_settings* rs)
                 tb.accum = nullptr;
                 tb.hit   = reinterpret_cast<float4*>(d->secondary_hit.ptr);
             }
+            if (ray_sort && round_bound >= d->ray_sort_min && (d->ray_sort_which & 2))
+                tb.sort_idx = sortedOrder(on, b.sec.rayA, b.sec.rayB, &qs->q[in_slot ^ 1].secondary);
             timed(3, on, [&] {
                 launchTraverse(d, tb, true, counters, trav_grid, &qs->work[3].w[0][0], on, d->deep_grid, d->deep_primary);
                 if (light_tracer)
@@ -2226,6 +2282,18 @@ igd_device* igd_create(const igd_setup* setup)
             d->node_format_mode = std::strcmp(e, "full") == 0 || std::strcmp(e, "0") == 0 ? 0 : -1;
         if (const char* e = std::getenv("IGD_NODE_REPEAT"))
             d->node_repeat = std::min(16, std::atoi(e));
+        if (const char* e = std::getenv("IGD_RAY_SORT"))
+            d->ray_sort_env = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("IGD_RAY_SORT_BITS"))
+            d->ray_sort_bits = std::max(1, std::min(9, std::atoi(e)));
+        if (const char* e = std::getenv("IGD_RAY_SORT_ORDER"))
+            d->ray_sort_octant_low = std::strcmp(e, "cell") == 0 ? 1 : 0;
+        if (const char* e = std::getenv("IGD_RAY_SORT_DIR_BITS"))
+            d->ray_sort_dir_bits = std::max(0, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("IGD_RAY_SORT_MIN"))
+            d->ray_sort_min = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("IGD_RAY_SORT_STREAMS"))
+            d->ray_sort_which = std::atoi(e) & 3;
         if (const char* e = std::getenv("IGD_WORK_SHARDS"))
             d->work_shards_env = std::atoi(e) > 1 ? kWorkShards : 1;
         if (const char* e = std::getenv("IGD_CLEAR_IN_GENERATE"))

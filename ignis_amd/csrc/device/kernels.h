@@ -224,6 +224,25 @@ struct TraverseArgs {
     int32_t sphere_pass;
     uint32_t* sphere_work_counter; // (a WorkCounters too) zero before launch
     uint32_t work_shards;          // > 1: the stream is handed out in kWorkShards shares (1: by the first counter alone)
+    // the launch takes its rays in this order (raysort.hip: stream position -> ray index), or null: in stream order. Everything a ray
+    // reads and leaves behind stays at its own index
+    const uint32_t* sort_idx;
+};
+
+// raysort.hip: the rays of a stream ordered by (octant of the direction, Morton code of the origin in the scene's box)
+struct RaySortArgs {
+    const float4* rayA;
+    const float4* rayB;
+    const uint32_t* count;
+    float box_min[3];
+    float box_scale[3];  // 2^cell_bits / extent of the box
+    uint32_t cell_bits;  // bits per axis of the origin's cell (<= 9: the key is 3 + 3 * cell_bits bits)
+    uint32_t octant_low; // != 0: the octant in the key's low bits (cell-major order) instead of its high ones
+    uint32_t dir_bits;   // > 0: instead of the octant, the direction's cell on the octahedral map, dir_bits bits per axis (2 * dir_bits + 3 * cell_bits <= 32)
+    uint32_t* keys[2];   // ping-pong, one word per ray
+    uint32_t* idx[2];
+    uint32_t* wg_hist;   // 256 x grid words
+    uint32_t* state;     // 256 words
 };
 
 // k_generate_light: make_lt_emitter (technique/lighttracer.art:35-62), one light path per ray id

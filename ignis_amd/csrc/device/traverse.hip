@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 unsent = 0;
             }
             if (in(fill)) {
-                const uint32_t idx = (DEEP && a.index_list) ? a.index_list[batch_next + rank] : batch_next + rank; // (DEEP as the primary kernel: no list)
+                uint32_t idx = batch_next + rank;
+                if (DEEP && a.index_list) // (DEEP as the primary kernel: no list)
+                    idx = a.index_list[idx];
+                else if (a.sort_idx) // the stream in key order (raysort.hip)
+                    idx = a.sort_idx[idx];
                 ray_idx = idx;
                 tr.prof(2, true);
                 ra = a.rayA ? a.rayA[idx] : a.uniform_rayA, rb = a.rayB[idx]; // (no rayA column: a compact camera stream, kernels.h CameraStream)

@@ -90,6 +90,7 @@ typedef struct igd_stats {
      * section_passes counts wave-level executions, section_lanes the lanes that had work in them, [0..2] closest-hit launches,
      * [3..5] any-hit launches; lanes / (64 * passes) is the useful share of the issued section instructions (acquire_stats >= 2) */
     uint64_t section_passes[6], section_lanes[6];
+    double ms_ray_sort; /* ordering bounce / shadow rays in space in front of their traversal launches (scenes whose BVH outgrows the L2s) */
 } igd_stats;
 
 /* IDeviceInterface::getVersion (IDeviceInterface.h:11) */

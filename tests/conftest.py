@@ -32,15 +32,18 @@ def diamond_scene():
     return LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 128, 128)
 
 
-@pytest.fixture(scope="session", params=["tail", "rounds", "tail-wide"])
+@pytest.fixture(scope="session", params=["tail", "rounds", "tail-wide", "rounds-sorted"])
 def gpu_device(request):
     """The device every feature-parity test renders on, in three schedules. "tail": the product's default — a
     stream of <= 1 Mi paths is handed to k_tail before round 0, which is where every small-film test ends up. "rounds":
     IGD_TAIL_THRESHOLD=0, the same test through the wavefront kernels the benchmark runs (k_shade + k_traverse rounds to the
     last path). "tail-wide": IGD_TAIL_WIDE=64, k_tail with every closest-hit ray traversed by a whole wave (wide_core.h, what
-    the product does for waves that follow <= 4 paths). The schedule is read when the device is created."""
+    the product does for waves that follow <= 4 paths). "rounds-sorted": the rounds with every bounce and shadow stream traversed in
+    (direction octant, origin cell) order (raysort.hip; IGD_RAY_SORT=1, what igd_assign_scene switches on for BVHs beyond 64 MB).
+    The schedule is read when the device is created."""
     from ignis_amd import Device
-    env = {"rounds": {"IGD_TAIL_THRESHOLD": "0"}, "tail-wide": {"IGD_TAIL_WIDE": "64"}}.get(request.param, {})
+    env = {"rounds": {"IGD_TAIL_THRESHOLD": "0"}, "tail-wide": {"IGD_TAIL_WIDE": "64"},
+           "rounds-sorted": {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"}}.get(request.param, {})
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

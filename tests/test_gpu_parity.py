@@ -161,6 +161,9 @@ def test_small_stream_capacity_chunks_match(diamond_scene):
     {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_TAIL_WIDE": "0"},       # none
     {"IGD_TAIL_THRESHOLD": "0", "IGD_WORK_SHARDS": "1"},                             # a traversal launch's rays from one counter instead of 8 shares
     {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_WORK_SHARDS": "1"},
+    {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"},        # bounce and shadow rays traversed in key order (raysort.hip)
+    {"IGD_TAIL_THRESHOLD": "3000", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0", "IGD_RAY_SORT_ORDER": "cell", "IGD_RAY_SORT_BITS": "9"},
+    {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0", "IGD_RAY_SORT_BITS": "2", "IGD_WORK_SHARDS": "1"},  # a one-pass sort
 ])
 def test_overlapped_tail_schedules_match_blocking(diamond_scene, monkeypatch, env):
     """The long-path tail of iteration i runs on a second stream while iteration i + 1 starts, in one or many
@@ -436,14 +439,19 @@ def test_procedural_standin_scene_vs_oracle(tmp_path, triangles, instances, widt
 
 
 @pytest.mark.parametrize("env", [{"IGD_TAIL_THRESHOLD": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_SHADE_CLASSES": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_NODE_REPEAT": "3"},
-                                 {"IGD_NODE_REPEAT": "3"}, {"IGD_TAIL_THRESHOLD": "65536"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_WORK_SHARDS": "1"}],
-                         ids=["rounds-by-class", "rounds-one-kernel", "rounds-node-repeat", "tail-node-repeat", "rounds-then-tail", "rounds-one-work-counter"])
+                                 {"IGD_NODE_REPEAT": "3"}, {"IGD_TAIL_THRESHOLD": "65536"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_WORK_SHARDS": "1"},
+                                 {"IGD_TAIL_THRESHOLD": "0", "IGD_WORK_SHARDS": "1", "IGD_NODE_REPEAT": "3", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"},
+                                 {"IGD_TAIL_THRESHOLD": "65536", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0", "IGD_RAY_SORT_ORDER": "cell"}],
+                         ids=["rounds-by-class", "rounds-one-kernel", "rounds-node-repeat", "tail-node-repeat", "rounds-then-tail", "rounds-one-work-counter",
+                              "rounds-ray-sort", "rounds-ray-sort-cell-major-then-tail"])
 def test_divergent_standin_through_every_shading_schedule(tmp_path, env):
     """The divergent stand-in through the switches a production run can take without the suite's default fixtures reaching them:
     the wavefront rounds with the by-class kernels on the globally sorted hits (the default for such a scene), with the
     one-for-all kernel (IGD_SHADE_CLASSES=0), with the inner-node section repeated within a pass (IGD_NODE_REPEAT=3, what
     igd_assign_scene switches on for BVHs beyond 64 MB) in rounds and in the tail, rounds handing over to the tail mid-way, and the
-    traversal launches' rays handed out by one counter (IGD_WORK_SHARDS=1, likewise the default beyond 64 MB) instead of in 8 shares."""
+    traversal launches' rays handed out by one counter (IGD_WORK_SHARDS=1, likewise the default beyond 64 MB) instead of in 8 shares,
+    and the bounce / shadow streams traversed in (direction octant, origin cell) order (IGD_RAY_SORT=1, raysort.hip: the three
+    switches a BVH beyond 64 MB turns on together)."""
     sc = _standin(tmp_path, 60_000, 24, 256, 144, "divergent")
     dev = _device_with_env(env, acquire_stats=True)
     tot = _compare_with_oracle(dev, sc, 256, 144, 4, seed=3, iters=2)

@@ -14,5 +14,5 @@ for E in "$@"; do
 import sys, json
 d = json.loads(sys.stdin.read())
 s = d['stage_ms_rank0']
-print('%-40s %8.1f Mrays/s   trav1 %7.1f  shade %7.1f  trav2 %7.1f  tail %6.1f  launch %.3f ms  frac %s' % ('$E', d['value'], s['ms_traverse_primary'], s['ms_shade'], s['ms_traverse_secondary'], s['ms_tail'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))"
+print('%-40s %8.1f Mrays/s   trav1 %7.1f  shade %7.1f  trav2 %7.1f  tail %6.1f  sort %6.1f  launch %.3f ms  frac %s' % ('$E', d['value'], s['ms_traverse_primary'], s['ms_shade'], s['ms_traverse_secondary'], s['ms_tail'], s.get('ms_ray_sort', 0.0), d['roofline']['avg_launch_ms'], d['roofline']['frac']))"
 done
