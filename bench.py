@@ -524,7 +524,15 @@ def main():
                 threads = int(os_["threads_used"])
                 n_it += 1
             dt = time.perf_counter() - t1
+            # the same restatement on ONE thread over a quarter-size film (the all-thread figure divided by it = how the port scales
+            # on this host; before round 6 its per-thread counters shared cache lines and 8 threads ran 1.9 x one)
+            t2 = time.perf_counter()
+            _, o1 = oracle.render(scene, spi, max(16, cw // 4), max(16, ch // 4), iteration=0, seed=SEED, threads=1)
+            dt1 = time.perf_counter() - t2
+            one = (o1["camera_rays"] + o1["bounce_rays"] + o1["shadow_rays"]) / dt1 / 1e6
             cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "single_thread": {"value": round(one, 3), "unit": "Mrays/s", "sample": f"1 iteration at {max(16, cw // 4)}x{max(16, ch // 4)} spi {spi}", "seconds": round(dt1, 2)},
+                   "speedup_over_single_thread": round(cpu_rays / dt / 1e6 / one, 2) if one > 0 else None,
                    "sample": f"{n_it} iteration(s) of {os.path.basename(args.scene)} {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",
                    "msamples_per_s": round(cpu_samples / dt / 1e6, 3), "seconds": round(dt, 2)}
 

@@ -274,6 +274,23 @@ def cdf2d(table, size_x, size_y, mode, u):
     return pos, pdf.value
 
 
+def warp(which, a, b):
+    """core/warp.art forward maps as the oracle's shading code calls them: "disk" square_to_concentric_disk -> (x, y);
+    "sphere" equal_area_square_to_sphere -> (x, y, z); "dir" dir_from_spherical(theta, phi) -> (x, y, z);
+    "spherical" spherical_from_dir(dir_from_spherical(theta, phi)) -> (theta, phi)."""
+    out = np.zeros(3, np.float32)
+    k = {"disk": 0, "sphere": 1, "dir": 2, "spherical": 3}[which]
+    lib().oracle_warp(C.c_int32(k), C.c_float(a), C.c_float(b), _fp(out))
+    return out[:2] if k in (0, 3) else out
+
+
+def interval_search(arr, value, strict=False):
+    """interval::binary_search (core/interval.art:7-23) with the predicate arr[i] <= value (or < value)."""
+    arr = np.ascontiguousarray(arr, dtype=np.int32)
+    lib().oracle_interval_search.restype = C.c_int32
+    return int(lib().oracle_interval_search(_ip(arr), C.c_int32(arr.size), C.c_int32(value), C.c_int32(1 if strict else 0)))
+
+
 def hardware_threads():
     return int(lib().oracle_hardware_threads())
 

@@ -242,7 +242,9 @@ int compact_secondary(SecondaryStream& s, int size)
     return k;
 }
 
-struct Counters {
+// (a cache line of its own, and each worker counts into a copy on its stack: the per-thread blocks used to be packed 64-byte neighbours
+// that every node visit incremented — false sharing held 8 threads to 1.9 x one)
+struct alignas(64) Counters {
     uint64_t camera = 0, bounce = 0, shadow = 0, unoccluded = 0;
     TraversalStats trav;
 };
@@ -861,14 +863,17 @@ int oracle_render_aovs(const igd_scene* sc, const oracle_settings* cfg, float* f
         primary.resize(capacity);
         secondary.resize(capacity);
         std::vector<int> ray_begins(sc->entity_count + 2), ray_ends(sc->entity_count + 2);
+        Counters local;
         for (;;) {
             const int tile = next_tile.fetch_add(1);
-            if (tile >= num_tiles)
+            if (tile >= num_tiles) {
+                counters[(size_t)tid] = local;
                 break;
+            }
             const int tx = tile % tiles_x, ty = tile / tiles_x;
             const int xmin = x0 + tx * tile_size, ymin = sharded ? rows[(size_t)ty] : y0 + ty * tile_size;
             const int xmax = std::min(xmin + tile_size, x1), ymax = sharded ? ymin + 1 : std::min(ymin + tile_size, y1);
-            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, aov_normals, aov_albedo, aov_direct, aov_nee, primary, secondary, ray_begins, ray_ends, counters[(size_t)tid]);
+            trace_tile(*sc, *cfg, cam, pt, xmin, ymin, xmax, ymax, fb, aov_normals, aov_albedo, aov_direct, aov_nee, primary, secondary, ray_begins, ray_ends, local);
         }
     };
 
@@ -1139,6 +1144,38 @@ int oracle_bsdf_probe(const igd_scene* sc, int32_t mat_id, int32_t entering, int
         }
     }
     return 0;
+}
+
+// The warps the reference's test_warp.art checks for bijectivity (core/warp.art), forward direction, as the shading code calls them.
+// which 0: square_to_concentric_disk(a, b) -> out[0..1]; 1: equal_area_square_to_sphere(a, b) -> out[0..2];
+// 2: dir_from_spherical(theta = a, phi = b) as sphere_unmap_uv evaluates it -> out[0..2]; 3: spherical_from_dir of the direction
+// (a = theta, b = phi) names, through sphere_map_uv -> out[0] = theta, out[1] = phi
+void oracle_warp(int32_t which, float a, float b, float out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    if (which == 0) {
+        square_to_concentric_disk(a, b, out[0], out[1]);
+    } else if (which == 1) {
+        const Vec3 d = equal_area_square_to_sphere(a, b);
+        out[0] = d.x, out[1] = d.y, out[2] = d.z;
+    } else if (which == 2) {
+        // sphere_unmap_uv returns (dir.y, -dir.x, dir.z) of dir_from_spherical(v pi, u 2 pi): undo the swizzle
+        const Vec3 s = sphere_unmap_uv(Vec2{ b / (2 * flt_pi), a / flt_pi });
+        out[0] = -s.y, out[1] = s.x, out[2] = s.z;
+    } else {
+        const float st = igm_sin(a);
+        const Vec3 dir = make_vec3(st * igm_cos(b), st * igm_sin(b), igm_cos(a));
+        // sphere_map_uv applies spherical_from_dir to (dir.y, -dir.x, dir.z): hand it the direction whose swizzle is `dir`
+        float u, v;
+        sphere_map_uv(make_vec3(-dir.y, dir.x, dir.z), u, v);
+        out[0] = v * flt_pi, out[1] = u * (2 * flt_pi);
+    }
+}
+
+// interval::binary_search (core/interval.art:7-23) over an integer array: mode 0: pred(i) = arr[i] <= value, 1: arr[i] < value
+int32_t oracle_interval_search(const int32_t* arr, int32_t size, int32_t value, int32_t mode)
+{
+    return interval_binary_search(size, [&](int32_t i) { return mode == 0 ? arr[i] <= value : arr[i] < value; });
 }
 
 // CDF probes for the tests (core/cdf.art). `data` omits the leading zero, as the device buffers do.

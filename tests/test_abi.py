@@ -544,8 +544,8 @@ def test_constant_expressions_and_the_inline_checkerboard_idiom():
 
 def test_sun_position_from_time_and_place():
     """LoaderUtils::getEA without a direction: the PSA algorithm on the light's date, time and place (defaults: 6 May 2020 12:00,
-    49.24 N, 7.00 E, UTC+2). Checked against textbook solar geometry (Cooper's declination, hour angle from UTC and longitude;
-    good to about a degree) and for the obvious symmetries."""
+    49.24 N, 7.00 E, UTC+2). Pinned by the reference unit test's known answer (units/sun.cpp), then checked against textbook solar
+    geometry (Cooper's declination, hour angle from UTC and longitude; good to about a degree) on other dates and for the obvious symmetries."""
     import numpy as np
     from ignis_amd.tables import LoadedScene
 
@@ -563,6 +563,10 @@ def test_sun_position_from_time_and_place():
         la = np.radians(lat)
         return np.degrees(np.arcsin(np.sin(la) * np.sin(decl) + np.cos(la) * np.cos(decl) * np.cos(h)))
 
+    # the reference's own known answer first (src/tests/units/sun.cpp:8-37; also tests/test_sky.py): 20.86 deg above the horizon, 10.81 deg west of south
+    ka = sun(year=2022, month=11, day=18, hour=13, minute=0, seconds=0, latitude=49.235422, longitude=-6.9965744, timezone=-1)
+    np.testing.assert_allclose([ka[0], ka[2], ka[1]], [-0.175382, -0.918072, 0.355506], rtol=1e-3)
+    assert np.degrees(np.arcsin(ka[1])) == pytest.approx(20.86, rel=1e-2) and np.degrees(np.arctan2(-ka[0], -ka[2])) == pytest.approx(10.81, rel=1e-2)
     d = sun()
     assert np.linalg.norm(d) == pytest.approx(1, abs=1e-6)
     assert np.degrees(np.arcsin(d[1])) == pytest.approx(textbook(127, 10.0, 49.235422, 6.9965744), abs=1.0)
@@ -837,3 +841,31 @@ def test_constant_expressions_in_number_and_colour_properties():
     assert p[0:3] == pytest.approx([-1.0, 1.0, 2.0], abs=1e-6)
     with pytest.raises(RuntimeError, match="not a constant number"):
         material({"type": "conductor", "roughness": 0.2, "anisotropic": "uv.x * 0.5"})  # (roughness itself may vary: tests/test_number_expressions.py)
+
+
+def test_meshes_recognised_as_spheres_like_the_reference_unit_test():
+    """src/tests/units/trimesh_sphere.cpp: TriMesh::getAsSphere recognises MakeIcoSphere(0, 4, 4) — origin 0, radius 4, area 4 pi r^2 —
+    and refuses the ico sphere with 0 subdivisions, MakeUVSphere(0, 4, 4, 2), a triangle and the capped / uncapped cylinder
+    MakeCylinder(0, 4, +z, 4, 32, *). Observable through the loader: an area light on a recognised mesh becomes the sphere emitter
+    (IG_LIGHT_SPHERE: centre, radius, area), on any other mesh the triangle-mesh emitter (AreaLight.cpp:50-62)."""
+    import numpy as np
+    from ignis_amd.tables import LoadedScene
+
+    def light_of(shape):
+        s = flat_scene([{"type": "area", "name": "l", "entity": "E", "radiance": [1, 1, 1]}])
+        s["shapes"].append(dict(shape, name="S"))
+        s["entities"].append({"name": "E", "shape": "S", "bsdf": "ground"})
+        sc = LoadedScene.from_string(json.dumps(s))
+        assert sc.scene.light_count == 1
+        return sc.scene.lights[0].type, np.float64(list(sc.scene.lights[0].d))
+
+    IG_LIGHT_PLANE, IG_LIGHT_MESH_AREA, IG_LIGHT_SPHERE = 0, 8, 9
+    t, d = light_of({"type": "icosphere", "radius": 4, "subdivisions": 4})
+    assert t == IG_LIGHT_SPHERE
+    np.testing.assert_allclose(d[0:3], 0, atol=1e-6)
+    assert d[3] == pytest.approx(4, rel=1e-6) and d[7] == pytest.approx(4 * np.pi * 16, rel=1e-5)
+    for shape in ({"type": "icosphere", "radius": 4, "subdivisions": 0}, {"type": "uvsphere", "radius": 4, "stacks": 4, "slices": 2},
+                  {"type": "cylinder", "radius": 4, "p0": [0, 0, 0], "p1": [0, 0, 4], "sections": 32, "filled": True},
+                  {"type": "cylinder", "radius": 4, "p0": [0, 0, 0], "p1": [0, 0, 4], "sections": 32, "filled": False}):
+        assert light_of(shape)[0] == IG_LIGHT_MESH_AREA, shape
+    assert light_of({"type": "triangle", "p0": [0, 0, 0], "p1": [1, 0, 0], "p2": [0, 1, 0]})[0] in (IG_LIGHT_PLANE, IG_LIGHT_MESH_AREA)  # (a plane shape at most: never a sphere)

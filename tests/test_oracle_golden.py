@@ -1392,3 +1392,81 @@ def test_radiance_brtdfunc_bsdf_lobes():
         up = d[:, 2] > 0
         assert np.allclose(ev[up].sum(axis=0) * 4 * np.pi / len(d), refl, rtol=0.02)  # eval carries the cosine
         assert np.allclose(ev[~up].sum(axis=0) * 4 * np.pi / len(d), [0.1, 0.15, 0.2], rtol=0.02)
+
+
+# ---- src/tests/artic/test_warp.art and test_interval.art (the reference's own cases; its eq_f32 passes anything within 1.5, interface.cpp:22-32 —
+# here the inverses are float32 restatements of core/warp.art:24-41,96-128 written for this test and the bound is 2e-6)
+
+def _concentric_disk_to_square(p):
+    """concentric_disk_to_square (core/warp.art:24-41)"""
+    f = np.float32
+    x, y = f(p[0]), f(p[1])
+    quadrant = abs(x) > abs(y)
+    r_sign = x if quadrant else y
+    r = f(np.copysign(np.sqrt(f(x * x + y * y)), r_sign))
+    prodsign = lambda a, b: f(-a) if np.signbit(b) else f(a)  # flips a's sign when b is negative (core/common.art prodsign)
+    phi = f(np.arctan2(prodsign(y, r_sign), prodsign(x, r_sign)))
+    c = f(f(4) * phi / f(np.pi))
+    t = f((c if quadrant else f(2) - c) * r)
+    a, b = (r, t) if quadrant else (t, r)
+    return np.array([(a + f(1)) * f(0.5), (b + f(1)) * f(0.5)], np.float32)
+
+
+def _equal_area_sphere_to_square(d):
+    """equal_area_sphere_to_square (core/warp.art:96-128)"""
+    f = np.float32
+    ad = np.abs(np.float32(d))
+    r = f(np.sqrt(max(f(1) - ad[2], f(0))))
+    a, b_ = max(ad[0], ad[1]), min(ad[0], ad[1])
+    b = f(0) if abs(a) <= np.finfo(np.float32).eps else f(b_ / a)
+    phi_ = f(np.arctan(b) * f(2) / f(np.pi))
+    phi = f(1) - phi_ if ad[0] < ad[1] else phi_
+    v_ = f(phi * r)
+    u_ = f(r - v_)
+    u, v = (f(1) - v_, f(1) - u_) if d[2] < 0 else (u_, v_)
+    return np.array([f(0.5) * (f(np.copysign(u, d[0])) + f(1)), f(0.5) * (f(np.copysign(v, d[1])) + f(1))], np.float32)
+
+
+WARP_SQUARE_POINTS = [(0.2, 0.8), (0, 0.2), (0.9, 0.4), (1, 0), (0.2, 1)]  # test_warp.art:44-54
+
+
+@pytest.mark.parametrize("a,b", WARP_SQUARE_POINTS)
+def test_warp_equal_area_sphere_is_bijective_on_the_reference_points(a, b):
+    d = oracle.warp("sphere", a, b)
+    assert np.linalg.norm(np.float64(d)) == pytest.approx(1, abs=2e-6)
+    np.testing.assert_allclose(_equal_area_sphere_to_square(d), [a, b], atol=2e-6)
+    # (0.5, 0.5) is +z, the square's corners are -z (warp.art:60-62)
+    np.testing.assert_allclose(oracle.warp("sphere", 0.5, 0.5), [0, 0, 1], atol=1e-7)
+    np.testing.assert_allclose(oracle.warp("sphere", 1, 0), [0, 0, -1], atol=1e-6)
+
+
+@pytest.mark.parametrize("a,b", WARP_SQUARE_POINTS)
+def test_warp_concentric_disk_is_bijective_on_the_reference_points(a, b):
+    p = oracle.warp("disk", a, b)
+    assert np.hypot(*np.float64(p)) <= 1 + 2e-6
+    np.testing.assert_allclose(_concentric_disk_to_square(p), [a, b], atol=2e-6)
+
+
+@pytest.mark.parametrize("theta,phi", [(0, np.pi), (np.pi / 2, np.pi), (np.pi / 2, 0), (0, 0), (0, np.pi / 4)])  # test_warp.art:56-60
+def test_warp_spherical_direction_round_trip_on_the_reference_points(theta, phi):
+    d = np.float64(oracle.warp("dir", theta, phi))
+    np.testing.assert_allclose(d, [np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], atol=2e-6)
+    t2, p2 = oracle.warp("spherical", theta, phi)
+    assert t2 == pytest.approx(theta, abs=2e-6)
+    # (at the pole phi is free: atan2 of two zeros keeps only the sign of x — pi for phi = pi, 0 for phi = pi / 4, which the reference's
+    # eq_f32 accepts because its tolerance is 1.5, interface.cpp:24)
+    assert p2 == pytest.approx(phi, abs=2e-6 if theta != 0 else 1.5)
+    if theta == 0 and phi == np.pi:
+        assert p2 == pytest.approx(np.pi, abs=2e-6)  # atan2(+-0, -0) = +-pi, wrapped into [0, 2 pi)
+
+
+def test_interval_binary_search_known_answers():
+    """test_interval.art: interval::binary_search (core/interval.art:7-23), the six cases with their expected indices."""
+    a = [0, 1, 2, 4, 5, 8]
+    assert oracle.interval_search(a, 4) == 3     # simple
+    assert oracle.interval_search(a, -1) == 0    # lower
+    assert oracle.interval_search(a, 16) == 5    # upper
+    m = [0, 1, 2, 4, 4, 4, 5, 8]
+    assert oracle.interval_search(m, 4) == 5     # multiple: the last of the equal ones
+    assert oracle.interval_search(m, 4, strict=True) == 2  # multiple2
+    assert oracle.interval_search([0, 1, 2, 2, 2, 4, 5, 8], 3) == 4  # multiple3

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, SCENES
 from ignis_amd import LoadedScene, tables
@@ -69,3 +70,69 @@ def test_sky_light_image_and_cdf_follow_skymodel_cpp():
     np.testing.assert_allclose(marginal, np.cumsum(rows) / rows.sum(), rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(cond[37], np.cumsum(resp[37].astype(np.float64)) / resp[37].sum(), rtol=2e-3, atol=1e-5)
     assert marginal[-1] == 1 and (cond[:, -1] == 1).all()
+
+
+# ---- reference-held known answers of the sky / sun helpers (src/tests/units/{sun,perez,elevation_azimuth}.cpp), at the reference's own tolerances
+
+def _sky_light(**kw):
+    """The loader's record of a function sky whose sun comes from LoaderUtils::getEA: d[9:12] = ElevationAzimuth::toDirectionYUp."""
+    import json
+    s = {"technique": {"type": "path", "max_depth": 2},
+         "camera": {"type": "perspective", "fov": 90, "transform": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1]}, "film": {"size": [16, 16]},
+         "bsdfs": [{"type": "diffuse", "name": "g"}], "shapes": [{"type": "rectangle", "name": "r"}],
+         "entities": [{"name": "r", "shape": "r", "bsdf": "g"}], "lights": [dict({"type": "cie_clear", "name": "sky"}, **kw)]}
+    sc = LoadedScene.from_string(json.dumps(s))
+    return sc, np.float64(list(sc.scene.lights[0].d))
+
+
+def _ea_of_yup(d):
+    """ElevationAzimuth::fromDirectionYUp (skysun/ElevationAzimuth.h:16-21)"""
+    phi = np.arctan2(-d[0], -d[2])
+    return np.pi / 2 - np.arccos(d[1]), phi + 2 * np.pi if phi < 0 else phi
+
+
+def test_sun_position_known_answer_of_the_reference_unit_test():
+    """src/tests/units/sun.cpp:8-37: computeSunEA(2022-11-18 13:00:00, 49.235422 N, -6.9965744 (degrees west), timezone -1) = elevation
+    20.86 deg, azimuth 10.81 deg west of south (relative 1e-2), (20.8, 10.8) within 1e-3 rad, and the Z-up direction
+    (-0.175382, -0.918072, 0.355506) of the Radiance cross-check (relative 1e-3). The loader stores the Y-up direction (x, z, y swapped)."""
+    _, d = _sky_light(year=2022, month=11, day=18, hour=13, minute=0, seconds=0, latitude=49.235422, longitude=-6.9965744, timezone=-1)
+    yup = d[9:12]
+    el, az = _ea_of_yup(yup)
+    assert el == pytest.approx(np.radians(20.86), rel=1e-2) and az == pytest.approx(np.radians(10.81), rel=1e-2)
+    assert el == pytest.approx(np.radians(20.8), abs=1e-3) and az == pytest.approx(np.radians(10.8), abs=1e-3)
+    zup = np.array([yup[0], yup[2], yup[1]])  # toDirectionZUp = (-cosE sinA, -cosE cosA, sinE), toDirectionYUp = (-cosE sinA, sinE, -cosE cosA)
+    np.testing.assert_allclose(zup, [-0.175382, -0.918072, 0.355506], rtol=1e-3)
+
+
+def test_elevation_azimuth_mappings_of_the_reference_unit_test():
+    """src/tests/units/elevation_azimuth.cpp: the nominal directions ([90 deg, 0] -> +up, [0, 0] -> south, [0, 90 deg] -> west,
+    [0, 180 deg] -> north, [0, 270 deg] -> east; absolute 1e-4), the Radiance cross-check (12.5 deg, 39.1 deg) ->
+    (-0.615494, -0.757725, 0.216842) Z-up (relative 1e-2), and direction -> (elevation, azimuth) -> direction round trips through the
+    `direction` property (fromDirectionYUp then toDirectionYUp), (0, -pi) coming back as azimuth +pi."""
+    def zup(**kw):
+        y = _sky_light(**kw)[1][9:12]
+        return np.array([y[0], y[2], y[1]])
+    for (el, az), exp in (((90, 0), (0, 0, 1)), ((0, 0), (0, -1, 0)), ((0, 90), (-1, 0, 0)), ((0, 180), (0, 1, 0)), ((0, 270), (1, 0, 0))):
+        np.testing.assert_allclose(zup(elevation=float(np.radians(el)), azimuth=float(np.radians(az))), exp, atol=1e-4)
+    np.testing.assert_allclose(zup(elevation=float(np.radians(12.5)), azimuth=float(np.radians(39.1))), [-0.615494, -0.757725, 0.216842], rtol=1e-2)
+    for el, az in ((0.0, 0.0), (1.0, 1.0), (0.0, -np.pi)):
+        want = np.array([-np.cos(el) * np.sin(az), np.sin(el), -np.cos(el) * np.cos(az)])
+        got = _sky_light(direction=[float(v) for v in want])[1][9:12]  # fromDirectionYUp, then toDirectionYUp
+        np.testing.assert_allclose(got, want, atol=2e-6)
+        e2, a2 = _ea_of_yup(got)
+        assert e2 == pytest.approx(el, abs=2e-6) and a2 == pytest.approx(az + 2 * np.pi if az < 0 else az, abs=2e-6)
+
+
+def test_perez_model_known_answer_of_the_reference_unit_test():
+    """src/tests/units/perez.cpp:9-40, the cross-check with Radiance's gendaylit (11 18 13 -y 2022 ... -W 0.39 57.03 -O 1): from diffuse
+    irradiance 57.03, direct irradiance 0.39, the sun at (-0.615494, -0.757725, 0.216842) Z-up (zenith angle 77.5 deg) on day 322
+    the model's coefficients are a..e = 0.597123, -0.562370, 0.828195, -0.625727, 0.009207 (relative 1e-4) and the diffuse
+    normalisation diffirrad / integrate = 10.64 (relative 1e-2). (The sky clearness 1.0019 and brightness 0.1841 the test also names
+    select and weight those coefficients: Perez' table is binned by the first and linear in the second.) `output: solarradiance`
+    makes the light's sky colour that normalisation (PerezLight.cpp:10-136)."""
+    _, d = _sky_light(type="perez", direction=[-0.615494, 0.216842, -0.757725], year=2022, month=11, day=18, diffuse_irradiance=57.029998779296875,
+                      direct_irradiance=0.38999998569488525, output="solarradiance", has_sun=False, color=[1, 1, 1])
+    zenith = np.arccos(d[10])
+    assert zenith == pytest.approx(np.radians(77.5), rel=1e-3)
+    np.testing.assert_allclose([d[6], d[7], d[8], d[12], d[13]], [0.597123, -0.562370, 0.828195, -0.625727, 0.009207], rtol=1e-4)
+    assert d[0] == pytest.approx(10.64, rel=1e-2) and d[0] == d[1] == d[2]
