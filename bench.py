@@ -295,23 +295,24 @@ def main():
 
     comm = None
     if native:
-        # the device library's own communicator: ncclCommInitRank inside libig_device_hip.so, the id handed round by ignis_amd.comm
+        # The device library's own communicator: ncclCommInitRank inside libig_device_hip.so, the id handed round by ignis_amd.comm.
+        # Brought up by a vote (ignis_amd/comm.py agree): every rank says whether it can take part before anyone enters
+        # ncclCommInitRank, every rank reports whether its communicator came up and talks, rank 0 broadcasts the verdict — so the ranks
+        # either ALL go on natively or ALL start over on the torch.distributed process group, and no rank is left inside a collective
+        # the others abandoned (a fresh process each: torch has to be the first to load its HIP runtime and RCCL).
         from ignis_amd.comm import Comm
-        try:
-            if os.environ.get("BENCH_NATIVE_COMM_FAIL"):  # tests: the fallback below
-                raise RuntimeError("BENCH_NATIVE_COMM_FAIL is set")
-            comm = Comm(dev, rank, world)
-            comm.barrier()  # (the first collective: a communicator that cannot talk fails here, not inside the timed region)
-        except Exception as e:  # noqa: BLE001 - whatever the library, the loader or the rendezvous raised
-            # The library's own communicator has run on one GPU only so far. If it cannot come up here, every rank starts over on the
-            # torch.distributed process group (a fresh process: torch has to be the first to load its HIP runtime and RCCL).
-            print(f"[bench] rank {rank}: native RCCL communicator failed ({type(e).__name__}: {e}); re-executing with --dist torch", file=sys.stderr, flush=True)
+        fail = os.environ.get("BENCH_NATIVE_COMM_FAIL")  # tests: "raise" / "hang" / "probe" (or any other value = "raise"), on the rank BENCH_NATIVE_COMM_FAIL_RANK names (default: every rank)
+        if fail and int(os.environ.get("BENCH_NATIVE_COMM_FAIL_RANK", rank)) != rank:
+            fail = None
+        if fail and fail not in ("raise", "hang", "probe"):
+            fail = "raise"
+        comm = Comm.agreed(dev, rank, world, deadline=float(os.environ.get("BENCH_COMM_DEADLINE", "60")), fail=fail)
+        if comm is None:
+            print(f"[bench] rank {rank}: the ranks agreed not to use the native RCCL communicator ({Comm.last_fallback_reason}); re-executing with --dist torch", file=sys.stderr, flush=True)
             argv = [a for i, a in enumerate(sys.argv) if not (a == "--dist" or (i > 0 and sys.argv[i - 1] == "--dist") or a.startswith("--dist="))]
             os.environ.pop("BENCH_NATIVE_COMM_FAIL", None)
-            try:
-                dev.close()
-            except Exception:  # noqa: BLE001
-                pass
+            sys.stderr.flush()
+            # (no dev.close(): a helper thread may still sit inside ncclCommInitRank on this device; the new process image disposes of both)
             os.execv(sys.executable, [sys.executable] + argv + ["--dist", "torch"])
 
     def barrier():

@@ -31,9 +31,10 @@ def _spawn_ranks(argv, gpus):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    nonce = os.urandom(8).hex()  # (ignis_amd/comm.py job_token: the ranks of this launch recognise each other by it)
     procs = []
     for r in range(gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IGNIS_JOB_TOKEN=nonce)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-m", "ignis_amd.cli"] + list(argv), env=env))
     # all ranks are watched together: the first one that fails (a negative code = killed by a signal counts) takes the others down, which
@@ -56,7 +57,15 @@ def _spawn_ranks(argv, gpus):
     return failed
 
 
-def main(argv=None, load=loadFromFile):
+def _reexec(argv):
+    """Replaces this process by a fresh `python -m ignis_amd.cli` (a rank that falls back to torch.distributed must import torch before
+    any HIP library is loaded, and may have a helper thread inside ncclCommInitRank to get rid of)."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, [sys.executable, "-m", "ignis_amd.cli"] + list(argv))
+
+
+def main(argv=None, load=loadFromFile, reexec=_reexec):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser(prog="ignis_amd.cli", description=__doc__.splitlines()[0])
     ap.add_argument("scene")
@@ -117,6 +126,27 @@ def main(argv=None, load=loadFromFile):
     rt = load(args.scene, opts)
     t_loading = time.perf_counter() - t0
 
+    comm = None
+    if sharded and native:
+        # The communicator FIRST: brought up by a vote among the ranks before anything is rendered (ignis_amd/comm.py agree), so
+        # that a communicator that cannot come up costs nothing — the ranks then all start over on the torch.distributed route, none is
+        # left waiting in a collective — and so that its set-up is not hidden behind the render.
+        from .comm import Comm
+        fail = os.environ.get("IGNIS_COMM_FAIL")  # tests: "raise" / "hang" / "probe" on rank IGNIS_COMM_FAIL_RANK (default: every rank)
+        if fail and int(os.environ.get("IGNIS_COMM_FAIL_RANK", rank)) != rank:
+            fail = None
+        t0 = time.perf_counter()
+        comm = Comm.agreed(rt.device, rank, world, deadline=float(os.environ.get("IGNIS_COMM_DEADLINE", "60")), fail=fail)
+        t_comm = time.perf_counter() - t0
+        if comm is None:
+            fallback = os.environ.get("IGNIS_CLI_FALLBACK_BACKEND", "nccl")
+            print(f"rank {rank}: the ranks agreed not to use the native RCCL communicator ({Comm.last_fallback_reason}); starting over with --backend {fallback}", file=sys.stderr, flush=True)
+            rest = [a for i, a in enumerate(argv) if not (a == "--backend" or (i > 0 and argv[i - 1] == "--backend") or a.startswith("--backend="))]
+            os.environ.pop("IGNIS_COMM_FAIL", None)
+            return reexec(rest + ["--backend", fallback])
+        if chatty:
+            print(f"RCCL communicator of {comm.world_size_from_backend()} ranks up in {beautiful_time(t_comm * 1e3)}", file=sys.stderr)
+
     spi = rt.SPI
     desired_iter = int(math.ceil((args.spp or 0) / spi))
     if args.spp and args.spp % spi:
@@ -141,11 +171,8 @@ def main(argv=None, load=loadFromFile):
 
     gathered = None
     st = rt.getStatistics() if (args.stats or args.full_stats) else None
-    comm = None
     if sharded and native:
         # the ONLY collective: the rows each rank owns, to rank 0 (W x H x 12 / world bytes per rank), by the device library itself
-        from .comm import Comm
-        comm = Comm(rt.device, rank, world)
         t0 = time.perf_counter()
         comm.gather_rows(dst=0)
         t_render += time.perf_counter() - t0

@@ -19,6 +19,7 @@ struct CommError : std::runtime_error {
 };
 
 struct Comm;
+bool comm_available(std::string& why);                    // librccl.so loaded with every symbol comm.hip calls
 void comm_unique_id(uint8_t* id);                         // ncclGetUniqueId
 Comm* comm_create(const uint8_t* id, int rank, int world); // ncclCommInitRank on the current device
 void comm_destroy(Comm* c);

@@ -93,6 +93,13 @@ Rccl& loaded()
 
 static_assert(sizeof(ncclUniqueId) == kCommIdBytes, "igd_comm_unique_id's id is an ncclUniqueId");
 
+bool comm_available(std::string& why)
+{
+    const Rccl& r = rccl();
+    why           = r.error;
+    return r.error.empty();
+}
+
 void comm_unique_id(uint8_t* id)
 {
     ncclUniqueId u;

@@ -2655,6 +2655,17 @@ int32_t igd_synchronize(igd_device* dev)
     });
 }
 
+int32_t igd_comm_available(void)
+{
+    std::string why;
+    if (igdev::comm_available(why)) {
+        g_error.clear();
+        return 1;
+    }
+    g_error = why;
+    return 0;
+}
+
 int32_t igd_comm_unique_id(uint8_t id[IGD_COMM_ID_BYTES])
 {
     if (!id) {

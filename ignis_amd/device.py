@@ -50,7 +50,7 @@ EXPORTS = [
     "igd_reset_stats", "igd_traverse", "igd_set_parameter_i32", "igd_set_parameter_f32", "igd_set_parameter_vec3",
     "igd_synchronize", "igd_last_error", "igd_buffer_size", "igd_buffer_copy", "igd_buffer_ptr",
     "igd_node_bytes",
-    "igd_comm_unique_id", "igd_comm_init", "igd_comm_world_size", "igd_comm_gather_rows", "igd_comm_allreduce_f64", "igd_comm_destroy",
+    "igd_comm_available", "igd_comm_unique_id", "igd_comm_init", "igd_comm_world_size", "igd_comm_gather_rows", "igd_comm_allreduce_f64", "igd_comm_destroy",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def lib():
         l.igd_synchronize.argtypes = [C.c_void_p]
         l.igd_node_bytes.restype = C.c_int32
         l.igd_node_bytes.argtypes = [C.c_void_p]
+        l.igd_comm_available.restype = C.c_int32
+        l.igd_comm_available.argtypes = []
         l.igd_comm_unique_id.restype = C.c_int32
         l.igd_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
         l.igd_comm_init.restype = C.c_int32

@@ -202,6 +202,9 @@ int32_t igd_synchronize(igd_device* dev);
  * the gathered film is read). librccl.so is opened at run time by the device library itself (no torch, no MPI); the launcher hands
  * every rank the id rank 0 obtained (ignis_amd/comm.py). */
 #define IGD_COMM_ID_BYTES 128
+/* 1: librccl.so is loaded with every entry point this library calls; 0: not (igd_last_error says why). What a rank reports in the
+ * launcher's bring-up vote before any rank enters ncclCommInitRank (ignis_amd/comm.py agree): a collective a peer cannot join never starts. */
+int32_t igd_comm_available(void);
 int32_t igd_comm_unique_id(uint8_t id[IGD_COMM_ID_BYTES]);                                                    /* ncclGetUniqueId */
 int32_t igd_comm_init(igd_device* dev, const uint8_t id[IGD_COMM_ID_BYTES], int32_t rank, int32_t world_size); /* ncclCommInitRank on the device's GPU */
 int32_t igd_comm_world_size(igd_device* dev);                                                                 /* ncclCommCount; 0: no communicator */

@@ -141,6 +141,7 @@ class _OracleRuntime:
         self.IterationCount = self.SampleCount = 0
         self._fb = np.zeros((h, w, 3), np.float32)
         self._stats = {"camera_rays": 0, "bounce_rays": 0, "shadow_rays": 0}
+        self.device = None  # (no igd_device behind it: a native communicator cannot come up on this "runtime")
 
     def recommendedBatch(self):
         return 2
@@ -237,3 +238,141 @@ def test_rccl_id_rendezvous_without_torch(tmp_path, world, first_port_taken):
         squatter.close()
     for r in range(world):
         assert (tmp_path / f"id{r}.bin").read_bytes() == bytes(range(128))
+
+
+# ---- the bring-up vote of the native RCCL path (ignis_amd/comm.py agree): all ranks native or all ranks on the
+# fallback, within the deadline, whatever one of them does. The communicator itself is faked (no GPU here): the protocol is the subject.
+
+def _vote_rank(rank, world, port, out_dir, mode, bad_rank, deadline, token):
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["IGNIS_JOB_TOKEN"] = token
+    from ignis_amd.comm import ID_BYTES, agree
+    if mode == "absent" and rank == bad_rank:
+        return  # this rank dies before it says hello
+    marker = os.path.join(out_dir, f"entered{rank}")
+
+    def bring_up(blob):
+        open(marker, "w").close()
+        assert blob == bytes(range(ID_BYTES))
+        if rank == bad_rank and mode == "raise":
+            raise RuntimeError("ncclCommInitRank failed (injected)")
+        if rank == bad_rank and mode == "hang":
+            time.sleep(3600)
+        if mode in ("raise", "hang"):
+            time.sleep(3600 if rank != bad_rank else 0)  # the healthy ranks sit in a collective the failed one never joins
+        return True
+
+    def probe():
+        if rank == bad_rank and mode == "probe":
+            raise RuntimeError("librccl.so could not be loaded (injected)")
+    t0 = time.monotonic()
+    ok, why = agree(rank, world, lambda: bytes(range(ID_BYTES)), bring_up, probe if rank else None, addr="127.0.0.1", port=port, deadline=deadline)
+    with open(os.path.join(out_dir, f"verdict{rank}"), "w") as f:
+        f.write(f"{int(ok)} {time.monotonic() - t0:.2f} {why}")
+    os._exit(0)  # (like the callers' re-exec: a helper thread may still be asleep inside the fake collective)
+
+
+def _run_vote(tmp_path, world, mode, bad_rank, deadline, port=None, token="t"):
+    import multiprocessing as mp
+    port = port or _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_vote_rank, args=(r, world, port, str(tmp_path), mode, bad_rank, deadline, token)) for r in reversed(range(world))]
+    for p in procs:
+        p.start()
+    return procs
+
+
+def _verdicts(tmp_path, procs, world, absent=()):
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    out = {}
+    for r in range(world):
+        if r in absent:
+            continue
+        ok, secs, *why = (tmp_path / f"verdict{r}").read_text().split(" ", 2)
+        out[r] = (bool(int(ok)), float(secs), why[0] if why else "")
+    return out
+
+
+def test_bring_up_vote_all_ranks_native(tmp_path):
+    v = _verdicts(tmp_path, _run_vote(tmp_path, 3, "fine", -1, 30.0), 3)
+    assert all(ok for ok, _, _ in v.values()) and all(secs < 20 for _, secs, _ in v.values())
+    assert all((tmp_path / f"entered{r}").exists() for r in range(3))
+
+
+@pytest.mark.parametrize("mode,bad_rank", [("raise", 1), ("raise", 0), ("hang", 2), ("hang", 0)])
+def test_bring_up_vote_one_failing_rank_sends_every_rank_to_the_fallback(tmp_path, mode, bad_rank):
+    """One of three ranks fails inside its bring-up — raises, or never returns — while the other two wait in a collective it never joins:
+    all three end up on the fallback, the waiting ones released by the deadline (4 s here) instead of hanging."""
+    v = _verdicts(tmp_path, _run_vote(tmp_path, 3, mode, bad_rank, 4.0), 3)
+    assert not any(ok for ok, _, _ in v.values()), v
+    assert all(secs < 4.0 * 2 + 25 for _, secs, _ in v.values()), v
+    assert any("rank" in why for _, _, why in v.values())
+
+
+def test_bring_up_vote_a_rank_without_rccl_keeps_everyone_out_of_the_collective(tmp_path):
+    """Phase 1: a rank whose librccl does not load says so BEFORE anyone enters ncclCommInitRank — nobody's bring-up runs."""
+    v = _verdicts(tmp_path, _run_vote(tmp_path, 3, "probe", 2, 20.0), 3)
+    assert not any(ok for ok, _, _ in v.values())
+    assert all(secs < 15 for _, secs, _ in v.values())
+    assert not any((tmp_path / f"entered{r}").exists() for r in range(3))
+    assert "cannot take part" in v[0][2]
+
+
+def test_bring_up_vote_a_rank_that_never_arrives(tmp_path):
+    v = _verdicts(tmp_path, _run_vote(tmp_path, 3, "absent", 1, 3.0), 3, absent=(1,))
+    assert not any(ok for ok, _, _ in v.values())
+    assert all(secs < 3.0 * 2 + 25 for _, secs, _ in v.values())
+    assert "2 of 3 ranks arrived" in v[0][2]
+    assert not any((tmp_path / f"entered{r}").exists() for r in (0, 2))
+
+
+def test_two_jobs_on_adjacent_ports_do_not_cross_connect(tmp_path):
+    """two jobs of the same world size whose MASTER_PORTs are neighbours share seven of their eight candidate ports. The
+    hello's job token keeps a rank of one from being served by the other's rank 0: both jobs come up, each with its own ranks."""
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    port = _free_port()
+    pa = _run_vote(a, 3, "fine", -1, 30.0, port=port, token="job-a")
+    pb = _run_vote(b, 3, "fine", -1, 30.0, port=port + 1, token="job-b")
+    va, vb = _verdicts(a, pa, 3), _verdicts(b, pb, 3)
+    assert all(ok for ok, _, _ in va.values()) and all(ok for ok, _, _ in vb.values())
+
+
+def _cli_rank_native_then_fallback(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      IGNIS_CLI_FALLBACK_BACKEND="gloo", IGNIS_COMM_DEADLINE="20")
+    from ignis_amd import cli
+    seen = []
+
+    def reexec(argv):  # (the product replaces the process image; here the same interpreter runs the new command line)
+        seen.append(list(argv))
+        return cli.main(argv, load=_OracleRuntime, reexec=reexec)
+    rc = cli.main([os.path.join(SCENES, "diamond_scene.json"), "--spp", str(2 * SPI), "--spi", str(SPI), "--width", str(W), "--height", str(H),
+                   "--seed", str(SEED), "-o", out_path, "--gpus", str(world), "--backend", "rccl"], load=_OracleRuntime, reexec=reexec)
+    assert rc == 0
+    assert len(seen) == 1 and seen[0][-2:] == ["--backend", "gloo"] and seen[0].count("--backend") == 1
+
+
+def test_cli_native_backend_falls_back_on_every_rank_when_rccl_cannot_come_up(tmp_path):
+    """`python -m ignis_amd.cli --gpus 3` with its default backend on a box without GPUs: rank 0 cannot make an RCCL id, says so in the
+    bring-up vote (ignis_amd/comm.py), and ALL three ranks start over with the fallback backend before anything was rendered — nobody
+    waits in a collective, the finished image is the single-process one."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from ignis_amd.tables import LoadedScene
+    from test_abi import _read_exr
+
+    out = str(tmp_path / "fallback.exr")
+    mp.spawn(_cli_rank_native_then_fallback, args=(3, _free_port(), out), nprocs=3, join=True)
+    planes, _ = _read_exr(out)
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    scene = LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), W, H)
+    ref = np.zeros((H, W, 3), np.float32)
+    for it in range(2):
+        oracle.render(scene, SPI, W, H, iteration=it, seed=SEED, threads=2, fb=ref)
+    np.testing.assert_allclose(got, ref / np.float32(2), rtol=2e-5, atol=1e-6)
