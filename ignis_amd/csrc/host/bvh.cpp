@@ -878,21 +878,36 @@ void quantise_node8(ig_node8* nodes, size_t count)
 {
     for (size_t n = 0; n < count; ++n) {
         ig_node8& nd = nodes[n];
+        // Everything into temporaries first: a node is rewritten on all three axes or not at all. A node whose planes do not fit a grid —
+        // only one with a non-finite plane can fail to: the extent of finite floats is below 255 x 2^122 — keeps its floats and gets no
+        // mark (clamping the byte of an upper plane would write a box that no longer contains the child's); the device then
+        // keeps such a scene on Node8 records (packQuantisedNodes: lossless or not at all).
+        float planes[6][8];
+        float origins[3];
         uint32_t exps = 0;
-        for (int a = 0; a < 3; ++a) {
+        bool node_fits = true;
+        for (int a = 0; a < 3 && node_fits; ++a) {
             float origin = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
+            bool finite  = true;
             for (int i = 0; i < 8; ++i)
-                if (nd.child[i] != 0)
+                if (nd.child[i] != 0) {
+                    finite = finite && std::isfinite(nd.bounds[2 * a][i]) && std::isfinite(nd.bounds[2 * a + 1][i]);
                     origin = std::min(origin, nd.bounds[2 * a][i]), top = std::max(top, nd.bounds[2 * a + 1][i]);
+                }
+            if (!finite) {
+                node_fits = false;
+                break;
+            }
             if (!(origin <= top)) // (no children: never written by the builder)
                 origin = top = 0;
             const double extent = (double)top - (double)origin;
             int e               = extent > 0 ? (int)std::ceil(std::log2(extent / 255.0)) : -126;
             e                   = std::max(-126, std::min(127, e));
             uint8_t qlo[8], qhi[8];
-            for (;; ++e) {
+            bool fits = false;
+            for (; e <= 127; ++e) {
                 const float s = std::ldexp(1.0f, e);
-                bool fits     = true;
+                fits          = true;
                 for (int i = 0; i < 8 && fits; ++i) {
                     qlo[i] = qhi[i] = 0;
                     if (nd.child[i] == 0)
@@ -904,21 +919,31 @@ void quantise_node8(ig_node8* nodes, size_t count)
                         ql -= 1;
                     while (qh <= 255 && std::fmaf((float)qh, s, origin) < hi)
                         qh += 1;
-                    fits   = qh <= 255;
+                    // (the decoded planes must be finite and on the right side: fmaf can overflow at the top of the float range)
+                    fits   = qh <= 255 && std::fmaf((float)ql, s, origin) <= lo && std::isfinite(std::fmaf((float)std::min(255.0, qh), s, origin));
                     qlo[i] = (uint8_t)ql, qhi[i] = (uint8_t)std::min(255.0, qh);
                 }
-                if (fits || e >= 127)
+                if (fits)
                     break;
             }
+            if (!fits) {
+                node_fits = false;
+                break;
+            }
             const float s = std::ldexp(1.0f, e);
-            for (int i = 0; i < 8; ++i)
-                if (nd.child[i] != 0) {
-                    nd.bounds[2 * a][i]     = std::fmaf((float)qlo[i], s, origin);
-                    nd.bounds[2 * a + 1][i] = std::fmaf((float)qhi[i], s, origin);
-                }
-            std::memcpy(&nd.pad[a], &origin, 4);
+            for (int i = 0; i < 8; ++i) {
+                planes[2 * a][i]     = nd.child[i] != 0 ? std::fmaf((float)qlo[i], s, origin) : nd.bounds[2 * a][i];
+                planes[2 * a + 1][i] = nd.child[i] != 0 ? std::fmaf((float)qhi[i], s, origin) : nd.bounds[2 * a + 1][i];
+            }
+            origins[a] = origin;
             exps |= (uint32_t)(e + 127) << (8 * a);
         }
+        if (!node_fits) {
+            nd.pad[0] = nd.pad[1] = nd.pad[2] = nd.pad[3] = 0;
+            continue;
+        }
+        std::memcpy(nd.bounds, planes, sizeof(planes));
+        std::memcpy(&nd.pad[0], origins, sizeof(origins));
         nd.pad[3] = (int32_t)(exps | IG_NODE8_QUANT_MARK);
     }
 }

@@ -3137,6 +3137,24 @@ int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinser
     return 0;
 }
 
+int32_t igh_test_quantise_nodes(float* bounds, const int32_t* child, uint32_t count, int32_t* pad)
+{
+    if (!bounds || !child || !pad)
+        return -1;
+    std::vector<ig_node8> nodes(count);
+    for (uint32_t n = 0; n < count; ++n) {
+        std::memset(&nodes[n], 0, sizeof(ig_node8));
+        std::memcpy(nodes[n].bounds, bounds + (size_t)n * 48, sizeof(nodes[n].bounds));
+        std::memcpy(nodes[n].child, child + (size_t)n * 8, sizeof(nodes[n].child));
+    }
+    igh::quantise_node8(nodes.data(), nodes.size());
+    for (uint32_t n = 0; n < count; ++n) {
+        std::memcpy(bounds + (size_t)n * 48, nodes[n].bounds, sizeof(nodes[n].bounds));
+        std::memcpy(pad + (size_t)n * 4, nodes[n].pad, 4 * sizeof(int32_t));
+    }
+    return 0;
+}
+
 const char* igh_last_error(void) { return g_last_error.c_str(); }
 
 } // extern "C"

@@ -623,11 +623,19 @@ private:
             // F1, Euclidean distance; fbm: 6 octaves, lacunarity 2, gain 0.5)
             static const struct { const char* name; uint32_t imm; } cells[] = { { "voronoi", 0u }, { "cvoronoi", 4u }, { "fbm", 1u }, { "cfbm", 5u }, { "gabor", 2u } };
             for (const auto& f : cells) {
-                if (name != f.name || (n != 1 && n != 2) || (n == 2 && a[1]->type != Type::Num && a[1]->type != Type::Int))
+                if (name != f.name)
+                    continue;
+                // the reference also has forms with their parameters as arguments — voronoi(x, seed, scale, "distance", "feature"[, p]),
+                // fbm(x, seed, octaves, lacunarity, gain), gabor(x, seed, impulses, ...) (Transpiler.cpp:765-795: handleVoronoiGen, fbm2_arg /
+                // fbm3_arg, gabor2_gen): known, not lowered — said so instead of "no function" 
+                if (n > 2)
+                    error(std::string(f.name) + " with its parameters as arguments (" + std::to_string(n) + " given) is not supported by the HIP backend: only " + f.name + "(x) and " + f.name + "(x, seed) are");
+                if ((n != 1 && n != 2) || (n == 2 && a[1]->type != Type::Num && a[1]->type != Type::Int))
                     continue;
                 const Type ct = a[0]->type;
                 const uint32_t dims = (ct == Type::Num || ct == Type::Int) ? 1u : (ct == Type::Vec2 ? 2u : (ct == Type::Vec3 ? 3u : 0u));
-                if (dims == 0 || ((f.imm & 2u) && dims != 2)) // (gabor: a vec2 only)
+                // gabor: a vec2 only; fbm / cfbm: vec2 and vec3 (the reference has no fbm1: Transpiler.cpp:790-795)
+                if (dims == 0 || ((f.imm & 2u) && dims != 2) || ((f.imm & 3u) == 1u && dims == 1))
                     continue;
                 if (n == 1)
                     a.push_back(constant(Type::Num, 36326639.0f, 36326639.0f, 36326639.0f, 36326639.0f));

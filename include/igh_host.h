@@ -82,6 +82,11 @@ double igh_eval_sky(int32_t channel, double turbidity, double albedo, double ele
  * area of the wide inner nodes the collapse emits. Returns 0. */
 int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinsert_ratio, int32_t reinsert_iterations, double out[5]);
 
+/* Builder diagnostics: quantise_node8 (csrc/host/bvh.cpp) on `count` Node8 records given as bounds [count][6][8] (min_x, max_x, min_y, ...
+ * per child slot, rewritten in place) and child [count][8] (0 = unused slot); pad [count][4] receives the grid each node got (origin
+ * bits, exponents | IG_NODE8_QUANT_MARK) or zeros for a node that was left as it is. Returns 0. */
+int32_t igh_test_quantise_nodes(float* bounds, const int32_t* child, uint32_t count, int32_t* pad);
+
 const char* igh_last_error(void);
 
 #ifdef __cplusplus

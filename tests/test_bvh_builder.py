@@ -185,3 +185,63 @@ def test_quantised_node_boxes_decode_exactly_and_contain_the_exact_ones(terrain,
         assert np.array_equal(out["0"][k], out["1"][k]), k
     we, wq = out["0"]["work"], out["1"]["work"]
     assert wq[0] >= we[0] and wq[0] <= 1.2 * we[0]  # node visits: a few more, not many
+
+
+def test_quantise_node8_is_conservative_or_leaves_the_node_alone():
+    """quantise_node8 on hand-made nodes — ordinary boxes, boxes of one point, denormal extents, extents at the top of the float
+    range, and nodes with an infinite or NaN plane. Every used slot of a marked node contains the box it replaces (new_lo <= old_lo,
+    new_hi >= old_hi) and decodes from its grid; a node that cannot be put on a grid keeps its floats bit for bit and gets NO mark
+    (igd_assign_scene then holds the scene as Node8 records: lossless or not at all)."""
+    import ctypes as C
+    from ignis_amd.tables import host_lib
+    rng = np.random.default_rng(11)
+    n = 4096
+    lo = rng.uniform(-1, 1, (n, 3, 8)).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, (n, 1, 1)).astype(np.float32)
+    ext = np.abs(rng.normal(size=(n, 3, 8))).astype(np.float32) * np.float32(10.0) ** rng.integers(-40, 20, (n, 1, 1)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        hi = (lo + ext * np.abs(lo) + ext).astype(np.float32)
+    hi = np.where(np.isfinite(hi), hi, np.float32(3.0e38))
+    lo[1], hi[1] = 0.5, 0.5                                    # a point
+    lo[2], hi[2] = -3.0e38, 3.0e38                            # the whole float range on every axis
+    lo[3], hi[3] = np.float32(1e-45), np.float32(3e-45)       # denormals
+    lo[4, 0, :4], hi[4, 0, :4] = -3.4e38, 3.4e38
+    bad = [5, 6, 7]
+    hi[5, 1, 2] = np.inf
+    lo[6, 2, 0] = -np.inf
+    lo[7, 0, 7] = np.nan
+    child = rng.integers(0, 2, (n, 8)).astype(np.int32) * rng.integers(1, 1000, (n, 8)).astype(np.int32)
+    child[:8] = 1  # (the special nodes use every slot)
+    bounds = np.empty((n, 6, 8), np.float32)
+    bounds[:, 0::2] = lo
+    bounds[:, 1::2] = hi
+    before = bounds.copy()
+    pad = np.zeros((n, 4), np.int32)
+    l = host_lib()
+    l.igh_test_quantise_nodes.restype = C.c_int32
+    assert l.igh_test_quantise_nodes(bounds.ctypes.data_as(C.POINTER(C.c_float)), child.ctypes.data_as(C.POINTER(C.c_int32)), n, pad.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    marked = (pad[:, 3].view(np.uint32) & 0xFF000000) == 0x51000000
+    # (node 4: planes at +-3.4e38 — the next grid step above the upper plane is beyond FLT_MAX, so it has no finite conservative grid either)
+    assert not marked[bad + [4]].any() and marked[[0, 1, 2, 3]].all() and marked.sum() >= n - len(bad) - 1
+    for b in np.flatnonzero(~marked):  # untouched, bit for bit
+        assert np.array_equal(bounds[b].view(np.uint32), before[b].view(np.uint32)) and not pad[b].any()
+    used = (child != 0)[:, None, :] & marked[:, None, None]
+    assert np.isfinite(bounds[np.broadcast_to(used, (n, 3, 8)).repeat(2, axis=1)]).all()
+    new_lo, new_hi = bounds[:, 0::2], bounds[:, 1::2]
+    old_lo, old_hi = before[:, 0::2], before[:, 1::2]
+    u3 = np.broadcast_to(used, (n, 3, 8))
+    assert (new_lo <= old_lo)[u3].all() and (new_hi >= old_hi)[u3].all()
+    # unused slots keep what they held
+    un = np.broadcast_to((child == 0)[:, None, :], (n, 3, 8))
+    assert np.array_equal(new_lo.view(np.uint32)[un], old_lo.view(np.uint32)[un]) and np.array_equal(new_hi.view(np.uint32)[un], old_hi.view(np.uint32)[un])
+    # every plane of a marked node decodes from its grid: fmaf(q, 2^e, origin) for a byte q (float64 holds origin + q * 2^e exactly or rounds it once)
+    for a in range(3):
+        origin = pad[:, a].copy().view(np.float32).astype(np.float64)[:, None]
+        e = ((pad[:, 3].view(np.uint32) >> (8 * a)) & 0xFF).astype(np.int64) - 127
+        scale = np.ldexp(1.0, e)[:, None]
+        for planes in (new_lo[:, a], new_hi[:, a]):
+            with np.errstate(invalid="ignore", over="ignore"):
+                q = np.rint((planes.astype(np.float64) - origin) / scale)
+                hit = np.zeros(planes.shape, bool)
+                for d in (-1, 0, 1):
+                    hit |= ((origin + (q + d) * scale).astype(np.float32) == planes) & (q + d >= 0) & (q + d <= 255)
+            assert hit[used[:, 0, :]].all()

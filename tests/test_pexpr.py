@@ -442,10 +442,16 @@ def test_voronoi_and_fbm_over_one_and_three_coordinates():
             assert near(ev("voronoi(P.x)", P=P)[1], float(d1), 1e-6) and near(ev("cvoronoi(P.x)", P=P)[1], tuple(float(v) for v in c1), 1e-7), P
             f, fc = fbm(P, 2.0)
             assert near(ev("fbm(P, 2)", P=P)[1], float(f), 2e-6) and near(ev("cfbm(P, 2)", P=P)[1], tuple(float(v) for v in fc), 2e-6), P
-            f1, _ = fbm(P[:1], 36326639.0)
-            assert near(ev("fbm(P.x)", P=P)[1], float(f1), 2e-6), P
     with pytest.raises(RuntimeError, match="not supported"):
         ev("gabor(P)", P=(1, 2, 3))  # (the reference has it over a vec2 only)
+    # the reference has no fbm over one coordinate (Transpiler.cpp:790-795: fbm2 / fbm3 only), and its argument-list forms are refused by name
+    for bad in ("fbm(P.x)", "cfbm(P.x, 3)"):
+        with pytest.raises(RuntimeError, match="not supported|no function"):
+            ev(bad, P=(1, 2, 3))
+    for bad, what in (("fbm(uv, 1, 4, 2.0, 0.5)", "fbm with its parameters as arguments"), ("gabor(uv, 1, 32, 0.05, 0.5, 0.0)", "gabor with its parameters as arguments"),
+                      ("voronoi(P, 1, 1.0, 'euclidean', 'f1')", "voronoi with its parameters as arguments")):
+        with pytest.raises(RuntimeError, match=what):
+            ev(bad, P=(1, 2, 3))
     for x in (0.0, 1.0, -3.25, 36326639.0, 0.1):  # hash(x) = hash_rndf (core/random.art:91-93): the generator's first float for the seed hash(bits(x))
         want = F(np.array((_tea(_hash_combine(0x811C9DC5, _bits(F(x))), 1) & 0x7FFFFF) | 0x3F800000, np.uint32).view(F)) - F(1)
         assert near(ev("hash(P.x)", P=(x, 0, 0))[1], float(want), 1e-7), x
