@@ -40,7 +40,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU peak for the "valu" line: 256 CUs x 4 SIMDs x 32 lanes/cycle (a wave64 v_fma_f32 takes 2 cycles, MI355X_MICROARCH.md) x 2.4 GHz
 VALU_PEAK_GLANE_OPS = 256 * 4 * 32 * 2.4
 SHADER_GHZ = 2.1            # effective shader clock of the traversal launches (GRBM_GUI_ACTIVE / duration; 2.4 GHz is the boost limit)
-PROFILE_TAG = "r05"  # profiles/<tag>_traffic[_<scene stem>].json: PMC summary of this command, tools/collect_profiles.sh
+PROFILE_TAG = "r06"  # profiles/<tag>_traffic[_<profile key>].json: PMC summary of this command, tools/collect_profiles.sh
+# cycles a wave64 VALU instruction of the shading kernels occupies on average (the lean kernel's mix, 3.03; the traversal kernels'
+# price comes from profiles/<tag>_issue_accounting.json)
+SHADE_CYCLES_PER_INST = 3.0
+SQ_GROUP = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]
+# which kernels make up a stage of a bounce round (short names as rocprofv3 reports them, `void igdev::` stripped)
+# (the traversal kernels of the timed steps: <ANY_HIT, STATS = false, DEEP = false, ...>; the counter replay's STATS instantiations and the — empty — DEEP launches are not them)
+STAGE_KERNELS = {"k_traverse<closest>": ("k_traverse<false, false, false",), "k_traverse<any>": ("k_traverse<true, false, false",), "k_shade": ("k_shade<", "k_bin_", "k_round_end")}
 
 
 def valu_cycles_per_inst():
@@ -48,8 +55,11 @@ def valu_cycles_per_inst():
     counts of its parts x how often each runs, scaled to the measured SQ_INSTS_VALU) x the calibrated price of each opcode class —
     profiles/<tag>_issue_accounting.json, written by tools/issue_accounting.py from profiles/<tag>_valu_calibration.txt,
     _trav_events_closest.json and _traffic.json. None when that file is missing (the `valu.issue_frac` field is then left out)."""
-    p = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_issue_accounting.json")
-    return json.load(open(p))["valu_cycles_per_inst"] if os.path.exists(p) else None
+    for tag in (PROFILE_TAG, "r05"):
+        p = os.path.join(ROOT, "profiles", f"{tag}_issue_accounting.json")
+        if os.path.exists(p):
+            return json.load(open(p))["valu_cycles_per_inst"]
+    return None
 DEFAULT_STEPS = 256
 
 
@@ -75,7 +85,30 @@ def parse():
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of the same command as child processes); "
                          "the figure then comes from profiles/<tag>_traffic.json")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (BASELINE configs 3 and 4 measured next to the headline)")
+    ap.add_argument("--profile-key", default=None,
+                    help="names this workload's committed counter summary, profiles/<tag>_traffic_<key>.json (the fallback of the live measurement); "
+                         "the headline scene needs none, another scene without a key has no fallback (two scene files may share a basename)")
     return ap.parse_args()
+
+
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) — the GPU
+    boxes show 256 hardware threads under a quota of 16 CPUs, where 256 worker threads only add switching."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return (max(1, min(n, int(quota + 0.5))) if quota else max(1, n)), n, quota
 
 
 def stream_bytes(n_rays):
@@ -104,13 +137,15 @@ def _primbvh_nodes(scene):
     return total
 
 
-def live_traffic(args, rays_per_launch):
-    """roofline.traffic measured in THIS run: the same command twice more as a child process under
-    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, counters alone with the kernel
-    trace, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), the closest-hit traversal kernel's per-launch means from the rocpd
-    databases: HBM bytes = 2 x FETCH_SIZE (the guide's gfx950 correction, which profiles/r05_fetch_calibration.txt confirms for this
-    kernel's 16-byte gathers) + WRITE_SIZE, in KiB. Per ray x this run's rays per launch (the workload is deterministic: the child runs
-    traverse the same rays). None (and the reason) when rocprofv3 is not there or a pass fails: the caller falls back to profiles/."""
+def _short(name):
+    return name.replace("void ", "").replace("igdev::", "").split("(")[0]
+
+
+def pmc_passes(scene, W, H, spi, steps, groups):
+    """This workload under the counters, in THIS run: the same command once per counter group as a child
+    process under `rocprofv3 --pmc <group> --kernel-trace` (separate passes, counters alone with the kernel trace, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes). Returns ({kernel: {counter: {"sum", "launches", "ns"}}}, the child's bench line)
+    or (None, the reason) when rocprofv3 is not there or a pass fails."""
     import glob
     import shutil
     import sqlite3
@@ -119,46 +154,92 @@ def live_traffic(args, rays_per_launch):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None, "rocprofv3 not found"
-    means = {}
-    # (the per-ray figures of a deterministic workload do not depend on the wavefront size: a long run is profiled on a shorter one; the
-    # child's warm-up is the same batch of iterations as its timed steps, so the mean over ALL its launches is the timed launches' mean)
-    pmc_steps = min(args.steps, 32)
+    ctr, line = {}, None
     tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", str(pmc_steps), "--warmup", str(pmc_steps), "--width", str(args.width), "--height", str(args.height), "--spi", str(args.spi),
-                   "--scene", args.scene, "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
+        for gi, group in enumerate(groups):
+            out = os.path.join(tmp, f"g{gi}")
+            cmd = [exe, "--pmc"] + list(group) + ["--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(steps), "--warmup", str(steps), "--width", str(W), "--height", str(H), "--spi", str(spi),
+                   "--scene", scene, "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+                return None, f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
             cur = sqlite3.connect(dbs[0]).cursor()
-            q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name"
-            hit = [(n, c, v) for n, c, v in cur.execute(q, (counter,)) if "k_traverse<false, false, false" in n]  # <closest, no stats, not DEEP, ...>
-            if not hit:
-                return None, f"no closest-hit traversal launches in the {counter} pass"
+            q = "select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection group by kernel_name, counter_name"
+            for k, c, n, v, d in cur.execute(q):
+                ctr.setdefault(_short(k), {})[c] = {"sum": float(v), "launches": int(n), "ns": float(d or 0)}
             line = json.loads(r.stdout.strip().splitlines()[-1])
-            n_rays = line["rays"]["camera"] + line["rays"]["bounce"]
-            means[counter] = (hit[0][2] * 1024.0, n_rays / max(1, line["roofline"]["launches"]))
     except Exception as e:  # (a profiler hiccup must not cost the bench line)
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    fetch, rays_f = means["FETCH_SIZE"]
-    write, rays_w = means["WRITE_SIZE"]
-    per_ray = 2.0 * fetch / rays_f + write / rays_w
-    return int(per_ray * rays_per_launch), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, own passes of this command as child "
-                                            f"processes at {pmc_steps} steps; k_traverse<closest> means per launch, reads x 2 (gfx950 correction, "
-                                            "profiles/r05_fetch_calibration.txt), per-ray figure x this run's rays per launch")
+    return ctr, line
+
+
+def stage_evidence(ctr, child_line, stage, ms_launch, rays_scale=1.0):
+    """What the counters say about one stage of a bounce round (STAGE_KERNELS): HBM-side bytes per launch (2 x FETCH_SIZE — the guide's
+    gfx950 correction, which profiles/r05_fetch_calibration.txt confirms for 16-byte gathers — + WRITE_SIZE, KiB), the VALU line and what
+    the waves spend their cycles on, all per round of the child run and scaled by `rays_scale` (this run's rays per launch / the child's:
+    the per-ray work of a deterministic workload does not depend on the wavefront size). `ms_launch` is THIS run's HIP-event launch time.
+    The class the data put the stage in — `limiter_class`: "hbm" when the measured traffic is at least half of the 8 TB/s peak in the
+    launch's time, else "valu" when the VALU instructions fill at least 0.6 of the issue cycles, else "latency" (neither the memory
+    system nor the issue slots are at their limit: the waves wait)."""
+    # per round: every kernel of the stage runs once per round, so a round's figure is the sum of the kernels' per-launch means (the child's
+    # warm-up, timed steps and counter replay are the same iterations: the mean over all of a kernel's launches is the timed launches' mean);
+    # `tot` (sums) serves the ratios
+    tot, per_round = {}, {}
+    for k, cs in ctr.items():
+        if any(k.startswith(p) for p in STAGE_KERNELS[stage]):
+            for c, v in cs.items():
+                tot[c] = tot.get(c, 0.0) + v["sum"]
+                per_round[c] = per_round.get(c, 0.0) + v["sum"] / max(1, v["launches"])
+    if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
+        return None
+    traffic = (2.0 * per_round["FETCH_SIZE"] + per_round["WRITE_SIZE"]) * 1024.0 * rays_scale
+    secs = ms_launch * 1e-3
+    ev = {"traffic": int(traffic), "measured_frac": round(traffic / secs / 1e9 / HBM_PEAK_GBS, 5) if secs > 0 else None}
+    if all(tot.get(c, 0) > 0 for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")):
+        cpi = (valu_cycles_per_inst() or 3.0) if stage.startswith("k_traverse") else SHADE_CYCLES_PER_INST
+        insts = per_round["SQ_INSTS_VALU"] * rays_scale
+        util = tot["SQ_THREAD_CYCLES_VALU"] / (64.0 * tot["SQ_ACTIVE_INST_VALU"])
+        g = insts * 64.0 * util / secs / 1e9 if secs > 0 else 0.0
+        ev["valu"] = {"achieved": round(g, 1), "peak": round(VALU_PEAK_GLANE_OPS, 1), "unit": "G lane-ops/s", "frac": round(g / VALU_PEAK_GLANE_OPS, 4),
+                      "insts_per_launch": int(insts),
+                      "issue_frac": round(insts * cpi / (1024 * SHADER_GHZ * 1e9 * secs), 4) if secs > 0 else None,
+                      "issue_frac_note": f"{cpi} cycles per wave64 instruction ("
+                                         + ("the closest-hit traversal's dynamic opcode histogram x calibrated prices, profiles/*_issue_accounting.json" if stage.startswith("k_traverse")
+                                            else "the lean shading kernel's mix, DESIGN.md 4.3") + f"), 1024 SIMDs at {SHADER_GHZ} GHz under load"}
+        ev["limiter"] = {"valu_lane_utilisation": round(util, 4), "wave_wait_share": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4),
+                         "wave_issue_share": round(tot["SQ_ACTIVE_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 4) if tot.get("SQ_ACTIVE_INST_ANY") else None,
+                         "source": "SQ counters of this run's rocprofv3 --pmc pass"}
+    mf, isf = ev["measured_frac"] or 0.0, (ev.get("valu") or {}).get("issue_frac") or 0.0
+    ev["limiter_class"] = "hbm" if mf >= 0.5 else ("valu" if isf >= 0.6 else "latency")
+    return ev
+
+
+def live_traffic(args, rays_per_launch):
+    """roofline.traffic and the VALU / limiter blocks of the headline kernel measured in THIS run: three passes of the same command under the
+    counters (pmc_passes: FETCH_SIZE, WRITE_SIZE, the SQ group), priced per ray x this run's rays per launch."""
+    # (the per-ray figures of a deterministic workload do not depend on the wavefront size: a long run is profiled on a shorter one; the
+    # child's warm-up is the same batch of iterations as its timed steps, so the mean over ALL its launches is the timed launches' mean)
+    pmc_steps = min(args.steps, 32)
+    ctr, line = pmc_passes(args.scene, args.width, args.height, args.spi, pmc_steps, [["FETCH_SIZE"], ["WRITE_SIZE"], SQ_GROUP])
+    if ctr is None:
+        return None, line
+    n_rays = line["rays"]["camera"] + line["rays"]["bounce"]
+    child_rpl = n_rays / max(1, line["roofline"]["launches"])
+    return (ctr, line, rays_per_launch / child_rpl), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* --kernel-trace, own passes of this command as child "
+                                                      f"processes at {pmc_steps} steps; k_traverse<closest> sums per round, reads x 2 (gfx950 correction, "
+                                                      "profiles/r05_fetch_calibration.txt), per-ray figure x this run's rays per launch")
 
 
 def shade_stream_bytes(n_in, n_bounce, n_shadow):
-    """Bytes of the ray streams one k_shade launch has to move: a hit read (rayA rayB meta pay hit + eta hit_v = 88 B),
-    a continuation ray written (rayA rayB meta pay + eta = 68 B), a shadow ray written (48 B). Accumulator updates and the scene's
-    shading tables come on top and are not priced: a lower bound."""
+    """SURVEY.md 8(d) / DESIGN.md 3, the reference's columns: a hit read (rayA rayB meta pay hit + eta hit_v = 88 B), a continuation ray
+    written (rayA rayB meta pay + eta = 68 B), a shadow ray written (48 B). Accumulator updates and the scene's shading tables come on top
+    and are not priced: a lower bound of the SURVEY model. What the kernels move since round 5 is less: moved_bytes()."""
     return 88 * n_in + 68 * n_bounce + 48 * n_shadow
 
 
@@ -167,11 +248,23 @@ def shadow_stream_bytes(n_shadow, n_unoccluded):
     return 56 * n_shadow + 24 * n_unoccluded
 
 
-def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_index=0):
+def moved_bytes(stats, sb):
+    """Stream bytes the three stages move BY CONSTRUCTION since round 5 (the SURVEY model above prices columns the kernels no
+    longer carry): the columns each stream kind holds (`sb` = igd_stats.stream_bytes, include/igd_device.h) x the ray counts. k_shade:
+    every hit's columns (a miss that needs no shading reads its hit only: an upper bound there), bounce and shadow rays written;
+    accumulator updates of k_shade are not priced."""
+    cam, bounce, shadow, unocc = stats["camera_rays"], stats["bounce_rays"], stats["shadow_rays"], stats["unoccluded"]
+    return {"k_traverse<closest>": cam * (sb[0] + sb[2]) + bounce * (sb[1] + sb[2]),
+            "k_shade": cam * sb[3] + bounce * sb[4] + bounce * sb[5] + shadow * sb[6],
+            "k_traverse<any>": shadow * sb[6] + unocc * sb[7]}
+
+
+def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_index=0, live=True):
     """One more workload of BASELINE.json's `configs` through the same product path as the headline (igd_render per iteration on one
     GPU, inputs resident, HIP-event stage timers on the render stream), with the roofline of ITS dominant kernel: the stage with the
     most GPU time among closest-hit traversal, shading and any-hit traversal, algorithmic stream bytes per launch from a counter
-    replay of the same steps / that stage's average launch time."""
+    replay of the same steps / that stage's average launch time — and, measured in the run (pmc_passes: three child passes of this
+    workload under rocprofv3 --pmc), that stage's HBM traffic, VALU line and wave states, from which `bound` is decided."""
     from ignis_amd import Device, LoadedScene
     t_load = time.perf_counter()
     scene = LoadedScene.from_file(scene_path, W, H)
@@ -203,18 +296,44 @@ def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_
     rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
     n_primary = cs["camera_rays"] + cs["bounce_rays"]
     rounds = max(1, st["traverse_primary_launches"])
+    rounds2 = max(1, st["traverse_secondary_launches"])
     geom_resident = int(scene.scene.primbvh_size) + int(scene.scene.scene_node_count) * 256 + int(scene.scene.scene_leaf_count) * 96
     per_launch = {
         "k_traverse<closest>": (st["ms_traverse_primary"] / rounds,
                                 stream_bytes(n_primary) / rounds + min(geometry_bytes(cs["nodes_primary"], cs["tris_primary"], cs["leaves_primary"], node_bytes) / rounds, geom_resident)),
         "k_shade": (st["ms_shade"] / rounds, shade_stream_bytes(n_primary, cs["bounce_rays"], cs["shadow_rays"]) / rounds),
-        "k_traverse<any>": (st["ms_traverse_secondary"] / max(1, st["traverse_secondary_launches"]),
-                            shadow_stream_bytes(cs["shadow_rays"], cs["unoccluded"]) / max(1, st["traverse_secondary_launches"])
-                            + min(geometry_bytes(cs["nodes_secondary"], cs["tris_secondary"], cs["leaves_secondary"], node_bytes) / max(1, st["traverse_secondary_launches"]), geom_resident)),
+        "k_traverse<any>": (st["ms_traverse_secondary"] / rounds2,
+                            shadow_stream_bytes(cs["shadow_rays"], cs["unoccluded"]) / rounds2
+                            + min(geometry_bytes(cs["nodes_secondary"], cs["tris_secondary"], cs["leaves_secondary"], node_bytes) / rounds2, geom_resident)),
     }
     kernel = max(per_launch, key=lambda k: per_launch[k][0])
     ms, alg = per_launch[kernel]
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    moved = moved_bytes(cs, cs["stream_bytes"])[kernel] / (rounds2 if kernel == "k_traverse<any>" else rounds)
+    roof = {"bound": None, "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "measured_frac": None, "avg_launch_ms": round(ms, 5), "launches": int(rounds), "algorithmic_bytes_per_launch": int(alg),
+            "moved_stream_bytes_per_launch": int(moved),
+            "note": "dominant stage of this workload by HIP-event time; `achieved` = the SURVEY 8(d) byte model (the reference's columns: 60 B per traversed ray, 88 / 68 / 48 B "
+                    "per shaded hit / bounce ray / shadow ray, + min(geometry visited, resident) for the traversals) per launch / average launch time; "
+                    "`moved_stream_bytes_per_launch` = the columns the kernels carry since round 5 x the ray counts (igd_stats.stream_bytes); `traffic` = HBM-side bytes "
+                    "per launch measured in this run (2 x FETCH_SIZE + WRITE_SIZE of the stage's kernels); `bound` = the class the counters put the stage in "
+                    "(stage_evidence: hbm / valu / latency); k_shade = the sort passes + every class kernel of a round"}
+    why = None
+    if live:
+        ctr, line = pmc_passes(scene_path, W, H, spi, steps, [["FETCH_SIZE"], ["WRITE_SIZE"], SQ_GROUP])
+        if ctr is None:
+            why = line
+        else:
+            ev = stage_evidence(ctr, line, kernel, ms)
+            if ev is None:
+                why = f"no {kernel} launches under the counters"
+            else:
+                roof.update({"traffic": ev["traffic"], "measured_frac": ev["measured_frac"], "valu": ev.get("valu"), "limiter": ev.get("limiter"),
+                             "bound": ev["limiter_class"], "limiter_class": ev["limiter_class"],
+                             "traffic_source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* --kernel-trace, own passes of this workload at {steps} steps"})
+    if roof["bound"] is None:
+        roof["bound"] = "unknown"
+        roof["traffic_source"] = f"none: {why or 'live measurement switched off'}"
     return {"name": name,
             "workload": f"{name}: {W}x{H}, path integrator, spi {spi} x {steps} iterations, seed {SEED}",
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -222,10 +341,7 @@ def measure_config(name, scene_path, W, H, spi, steps, warmup, capacity, device_
             "rays": {"camera": st["camera_rays"], "bounce": st["bounce_rays"], "shadow": st["shadow_rays"]},
             "stage_ms": {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve", "ms_ray_sort")},
             "geometry_resident_bytes": geom_resident,
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "avg_launch_ms": round(ms, 5), "launches": int(rounds), "algorithmic_bytes_per_launch": int(alg),
-                         "note": "dominant stage of this workload by HIP-event time; stream bytes (+ min(geometry visited, resident) for the traversals) per launch / "
-                                 "average launch time; k_shade = the sort passes + every class kernel of a round"}}
+            "roofline": roof}
 
 
 def extra_configs(args):
@@ -244,13 +360,13 @@ def extra_configs(args):
                                "--materials", "divergent"], capture_output=True, text=True)
         if made.returncode == 0:
             c = measure_config("config 3 stand-in (seeded procedural scene, 1 M unique triangles, 32 divergent materials, 4 area lights; NOT the Bedroom asset)",
-                               os.path.join(tmp, "standin.json"), WIDTH, HEIGHT, SPI, steps, warmup, cap)
+                               os.path.join(tmp, "standin.json"), WIDTH, HEIGHT, SPI, steps, warmup, cap, live=not args.no_live_traffic)
             c["generator"] = "tools/make_standin_scene.py --triangles 1000000 --instances 96 --seed 7 --materials divergent"
             c["generate_seconds"] = round(time.perf_counter() - t - c["scene_load_seconds"] - c["timed_seconds"], 2)
             out.append(c)
         else:
             out.append({"name": "config 3 stand-in", "error": made.stderr[-400:]})
-    out.append(measure_config("config 4 scenes/many_point_lights.json", os.path.join(ROOT, "scenes", "many_point_lights.json"), WIDTH, HEIGHT, SPI, 32, 32, cap))
+    out.append(measure_config("config 4 scenes/many_point_lights.json", os.path.join(ROOT, "scenes", "many_point_lights.json"), WIDTH, HEIGHT, SPI, 32, 32, cap, live=not args.no_live_traffic))
     return out
 
 
@@ -457,14 +573,19 @@ def main():
         # measured HBM-side bytes per launch of the same kernel: PMC passes of this command, summarised into
         # profiles/ by tools/prof_summary.py (counters cannot be read from inside the process)
         traffic, traffic_src, limiter, valu = None, None, None, None
-        stem = os.path.splitext(os.path.basename(args.scene))[0]
-        tname = f"{PROFILE_TAG}_traffic.json" if args.scene == SCENE else f"{PROFILE_TAG}_traffic_{stem}.json"
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath) and (W, H, spi) == (WIDTH, HEIGHT, SPI) and world == 1:
+        # the committed counter summary of this workload (the fallback of the live measurement): the headline's own file, or the one
+        # --profile-key names (keyed by the caller, not by the scene's basename: two stand-ins are both called standin.json)
+        key = args.profile_key if args.profile_key else (None if args.scene != SCENE else "")
+        tname = None if key is None else (f"{PROFILE_TAG}_traffic.json" if key == "" else f"{PROFILE_TAG}_traffic_{key}.json")
+        if tname and not os.path.exists(os.path.join(ROOT, "profiles", tname)):
+            prev = tname.replace(PROFILE_TAG + "_", "r05_", 1)
+            tname = prev if os.path.exists(os.path.join(ROOT, "profiles", prev)) else tname
+        tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+        rays_per_launch = n_primary / c_launches
+        if tpath and os.path.exists(tpath) and (W, H, spi) == (WIDTH, HEIGHT, SPI) and world == 1:
             tj = json.load(open(tpath))
             tk = next((v for k, v in tj["kernels"].items() if k.startswith("k_traverse<false, false, false")), None)  # <closest, no stats, not DEEP[, no spheres]>
             pr = tj.get("closest_hit_per_ray")
-            rays_per_launch = n_primary / c_launches
             if tk and (pr or tj.get("steps") == args.steps):
                 # The counters were collected on this command at tj["steps"] steps. Per launch they scale with the rays a launch
                 # traverses (the per-ray work of a deterministic workload does not depend on the wavefront size), so a run at another
@@ -485,27 +606,40 @@ def main():
                     valu = {"achieved": round(g, 1), "peak": round(VALU_PEAK_GLANE_OPS, 1), "unit": "G lane-ops/s", "frac": round(g / VALU_PEAK_GLANE_OPS, 4),
                             "insts_per_ray": round(insts * 64.0 / rays_per_launch, 1),
                             "issue_frac": round(insts * cpi / (1024 * SHADER_GHZ * 1e9 * avg_ms * 1e-3), 4) if cpi else None,
-                            "issue_frac_note": f"{cpi} cycles per wave64 instruction (profiles/{PROFILE_TAG}_issue_accounting.json: dynamic opcode histogram x calibrated prices), {SHADER_GHZ} GHz under load",
+                            "issue_frac_note": f"{cpi} cycles per wave64 instruction (profiles/*_issue_accounting.json: dynamic opcode histogram x calibrated prices), {SHADER_GHZ} GHz under load",
                             "source": f"profiles/{tname}"}
         traffic_file, traffic_file_src = traffic, traffic_src
+        limiter_class = None
         if world == 1 and shards == 1 and not distributed and not args.no_live_traffic and not args.no_stage_timers:
-            live, why = live_traffic(args, n_primary / c_launches)
-            if live:
-                traffic, traffic_src = live, why
+            live, why = live_traffic(args, rays_per_launch)
+            ev = stage_evidence(live[0], live[1], "k_traverse<closest>", avg_ms, live[2]) if live else None
+            if ev:
+                traffic, traffic_src = ev["traffic"], why
+                if ev.get("valu"):
+                    valu = dict(ev["valu"], insts_per_ray=round(ev["valu"]["insts_per_launch"] * 64.0 / rays_per_launch, 1), source="this run's SQ pass")
+                    limiter = ev["limiter"]
+                limiter_class = ev["limiter_class"]
             elif traffic_src:
-                traffic_src += f" [live measurement skipped: {why}]"
+                traffic_src += f" [live measurement skipped: {why if not live else 'no closest-hit launches under the counters'}]"
             else:
-                traffic_src = f"none: {why}; no profiles/{tname} for this workload"
+                traffic_src = f"none: {why}; no committed counter summary for this workload" + ("" if tname else " (--profile-key names one)")
+        if limiter_class is None and traffic is not None and avg_ms > 0:
+            mf, isf = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, (valu or {}).get("issue_frac") or 0.0
+            limiter_class = "hbm" if mf >= 0.5 else ("valu" if isf >= 0.6 else "latency")
+        moved = moved_bytes(cs, cs["stream_bytes"])["k_traverse<closest>"] / c_launches
         roofline = {"bound": "hbm", "kernel": "k_traverse<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_ms > 0 else None,
-                    "note": "achieved = HBM-side algorithmic bytes per launch (60 B per ray of the streams + the geometry bytes that have to be fetched at "
-                            "least once: min(visited, resident)) / launch time; `incl_cache_hits` prices every Node8 / triangle / leaf visit at its size "
-                            "(SURVEY 8d's A), most of which L1 / L2 serve when the BVH is small; `traffic` = measured HBM-side bytes per launch",
+                    "note": "achieved = HBM-side algorithmic bytes per launch by SURVEY 8(d)'s model (60 B per ray of the reference's stream columns + the geometry bytes that "
+                            "have to be fetched at least once: min(visited, resident)) / launch time — the MODEL, not the bytes moved: `moved_stream_bytes_per_launch` prices the "
+                            "columns the kernels carry since round 5 (igd_stats.stream_bytes x ray counts); `incl_cache_hits` prices every Node8 / triangle / leaf visit at its size "
+                            "(SURVEY 8d's A), most of which L1 / L2 serve when the BVH is small; `traffic` = measured HBM-side bytes per launch; `bound` names the axis of "
+                            "achieved / peak, `limiter_class` what the counters say the kernel waits for (stage_evidence)",
                     "incl_cache_hits": {"achieved": round(incl_cache, 2), "unit": "GB/s", "bytes_per_launch": int(s_per_launch + g_per_launch)},
-                    "stream_bytes_per_launch": int(s_per_launch), "geometry_resident_bytes": geom_resident,
+                    "stream_bytes_per_launch": int(s_per_launch), "moved_stream_bytes_per_launch": int(moved), "stream_bytes_per_ray": cs["stream_bytes"],
+                    "geometry_resident_bytes": geom_resident,
                     "node_bytes": node_bytes, "traffic_from_profiles": traffic_file,
-                    "valu": valu, "limiter": limiter, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                    "valu": valu, "limiter": limiter, "limiter_class": limiter_class, "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(hbm_alg)}
 
         stage_ms = {k: round(st[k], 3) for k in ("ms_generate", "ms_traverse_primary", "ms_shade", "ms_traverse_secondary", "ms_tail", "ms_resolve", "ms_ray_sort")}
@@ -517,9 +651,10 @@ def main():
             cw, ch = W, H
             cpu_rays = cpu_samples = 0
             n_it, threads = 0, 1
+            use, hw, quota = effective_cpus()
             t1 = time.perf_counter()
             while n_it < 8 and (n_it == 0 or time.perf_counter() - t1 < 12.0):
-                _, os_ = oracle.render(scene, spi, cw, ch, iteration=n_it, seed=SEED)
+                _, os_ = oracle.render(scene, spi, cw, ch, iteration=n_it, seed=SEED, threads=use)
                 cpu_rays += os_["camera_rays"] + os_["bounce_rays"] + os_["shadow_rays"]
                 cpu_samples += os_["camera_rays"]
                 threads = int(os_["threads_used"])
@@ -532,6 +667,7 @@ def main():
             dt1 = time.perf_counter() - t2
             one = (o1["camera_rays"] + o1["bounce_rays"] + o1["shadow_rays"]) / dt1 / 1e6
             cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "host": f"{hw} hardware threads visible" + (f", container CPU quota {quota:g}" if quota else ", no CPU quota") + f": {use} worker threads",
                    "single_thread": {"value": round(one, 3), "unit": "Mrays/s", "sample": f"1 iteration at {max(16, cw // 4)}x{max(16, ch // 4)} spi {spi}", "seconds": round(dt1, 2)},
                    "speedup_over_single_thread": round(cpu_rays / dt / 1e6 / one, 2) if one > 0 else None,
                    "sample": f"{n_it} iteration(s) of {os.path.basename(args.scene)} {cw}x{ch} spi {spi} (oracle/, CPU restatement of cpu_trace, not the AnyDSL binary)",

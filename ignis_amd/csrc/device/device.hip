@@ -2552,6 +2552,21 @@ int32_t igd_get_stats(igd_device* dev, igd_stats* out)
         finish(dev);
     });
     *out = dev->stats;
+    {
+        // the byte model of the streams (igd_stats::stream_bytes): which columns exist follows from the scene and the camera alone
+        const ig_camera& c   = dev->camera;
+        const bool one_point = (c.type == IG_CAMERA_PERSPECTIVE && !(c.aperture_radius > 1.1920928955e-07f)) || (c.type == IG_CAMERA_FISHLENS && !c.fisheye_mask);
+        const bool compact   = dev->camera_compact && one_point && dev->dscene.tech.type != IG_TECHNIQUE_LIGHTTRACER;
+        const uint32_t hit   = dev->hit_pack_bits ? 16u : 20u;
+        out->stream_bytes[0] = compact ? 16u : 48u;
+        out->stream_bytes[1] = 32u;
+        out->stream_bytes[2] = hit;
+        out->stream_bytes[3] = (compact ? 16u : 48u) + hit;
+        out->stream_bytes[4] = 64u + hit;
+        out->stream_bytes[5] = 64u;
+        out->stream_bytes[6] = 48u;
+        out->stream_bytes[7] = 32u;
+    }
     return rc;
 }
 

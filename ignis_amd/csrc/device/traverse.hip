@@ -55,7 +55,10 @@ constexpr int kTimelineWaves = 1 << 14;
 __device__ unsigned long long g_timeline[kTimelineWaves * 4];
 #endif
 
-template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false, bool QNODE = false>
+// SORTED: the launch takes its rays through TraverseArgs::sort_idx (raysort.hip). An instantiation of its own: as a run-time test of the
+// pointer in the refill it cost the headline's closest-hit launches 6 % (profiles/r06_experiment_ab.txt section 2) — the kernel's scalar
+// registers are that tight.
+template <bool ANY_HIT, bool STATS, bool DEEP, bool SPHERES = false, bool QNODE = false, bool SORTED = false>
 __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const TraverseArgs a)
 {
     __shared__ StackLds s_stack;
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(kBlockThreads, kTraverseOcc) k_traverse(const 
                 uint32_t idx = batch_next + rank;
                 if (DEEP && a.index_list) // (DEEP as the primary kernel: no list)
                     idx = a.index_list[idx];
-                else if (a.sort_idx) // the stream in key order (raysort.hip)
+                else if (SORTED) // the stream in key order (raysort.hip)
                     idx = a.sort_idx[idx];
                 ray_idx = idx;
                 tr.prof(2, true);
@@ -340,6 +343,22 @@ template <bool DEEP, bool SPHERES = false>
 static void launch_one(const TraverseArgs& args, bool any_hit, bool stats, int grid_blocks, hipStream_t stream)
 {
     const dim3 grid((unsigned)grid_blocks), block(kBlockThreads);
+    if constexpr (!DEEP && !SPHERES) {
+        if (args.sort_idx) {
+            if (any_hit) {
+                if (stats)
+                    hipLaunchKernelGGL((k_traverse<true, true, false, false, kQNode, true>), grid, block, 0, stream, args);
+                else
+                    hipLaunchKernelGGL((k_traverse<true, false, false, false, kQNode, true>), grid, block, 0, stream, args);
+            } else {
+                if (stats)
+                    hipLaunchKernelGGL((k_traverse<false, true, false, false, kQNode, true>), grid, block, 0, stream, args);
+                else
+                    hipLaunchKernelGGL((k_traverse<false, false, false, false, kQNode, true>), grid, block, 0, stream, args);
+            }
+            return;
+        }
+    }
     if (any_hit) {
         if (stats)
             hipLaunchKernelGGL((k_traverse<true, true, DEEP, SPHERES, kQNode>), grid, block, 0, stream, args);
@@ -366,6 +385,8 @@ void launch_traverse(const TraverseArgs& args_in, bool any_hit, bool stats, int 
     TraverseArgs args = args_in;
     const bool spheres = args.scene.sphere_node_count != 0;
     args.sphere_pass   = spheres ? 1 : 0;
+    if (deep_primary || spheres)
+        args.sort_idx = nullptr; // (the DEEP-as-primary launch and the sphere pass take the stream as it lies)
     if (deep_primary) {
         TraverseArgs all = args;
         all.index_list   = nullptr;

@@ -32,11 +32,12 @@ class Stats(C.Structure):
                 ("ms_generate", C.c_double), ("ms_traverse_primary", C.c_double), ("ms_shade", C.c_double),
                 ("ms_traverse_secondary", C.c_double), ("ms_resolve", C.c_double), ("ms_total", C.c_double),
                 ("rounds", C.c_uint32), ("pad", C.c_uint32), ("tail_rays", C.c_uint64), ("ms_tail", C.c_double),
-                ("section_passes", C.c_uint64 * 6), ("section_lanes", C.c_uint64 * 6), ("ms_ray_sort", C.c_double)]
+                ("section_passes", C.c_uint64 * 6), ("section_lanes", C.c_uint64 * 6), ("ms_ray_sort", C.c_double), ("stream_bytes", C.c_uint32 * 8)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("pad", "section_passes", "section_lanes")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("pad", "section_passes", "section_lanes", "stream_bytes")}
         d["section_passes"], d["section_lanes"] = list(self.section_passes), list(self.section_lanes)
+        d["stream_bytes"] = list(self.stream_bytes)
         for k in ("nodes", "tris", "leaves"):
             d[k] = d[k + "_primary"] + d[k + "_secondary"]
         return d

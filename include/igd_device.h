@@ -90,7 +90,16 @@ typedef struct igd_stats {
      * section_passes counts wave-level executions, section_lanes the lanes that had work in them, [0..2] closest-hit launches,
      * [3..5] any-hit launches; lanes / (64 * passes) is the useful share of the issued section instructions (acquire_stats >= 2) */
     uint64_t section_passes[6], section_lanes[6];
-    double ms_ray_sort; /* ordering bounce / shadow rays in space in front of their traversal launches (scenes whose BVH outgrows the L2s) */
+    double ms_ray_sort; /* ordering bounce / shadow rays in space in front of their traversal launches (IGD_RAY_SORT=1) */
+    /* Bytes per ray the wavefront kernels of the assigned scene and camera move BY CONSTRUCTION (the columns each stream kind carries,
+     * csrc/device/kernels.h kStream*; what a roofline's byte model multiplies with the ray counts above):
+     * [0] a camera ray read by the closest-hit launch (16: a one-point camera stores directions only; 48 otherwise)
+     * [1] a bounce ray read by the closest-hit launch (32: origin and direction; its flags and tmax are uniform)
+     * [2] the hit written per ray (16 packed, else 20)
+     * [3] what k_shade reads per camera hit, [4] per bounce hit (the ray's columns + the hit; a skipped miss reads the hit only)
+     * [5] a bounce ray written by k_shade (64), [6] a shadow ray written by k_shade and read by the any-hit launch (48)
+     * [7] the accumulator traffic of an unoccluded shadow ray (16 read with the ray + 16 written) */
+    uint32_t stream_bytes[8];
 } igd_stats;
 
 /* IDeviceInterface::getVersion (IDeviceInterface.h:11) */

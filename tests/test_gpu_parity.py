@@ -1785,7 +1785,7 @@ def test_noise_textures_vs_oracle(gpu_device):
     s["bsdfs"] += [{"type": "plastic", "name": "grainy", "diffuse_reflectance": "grain", "roughness": 0.2},
                    {"type": "conductor", "name": "brushed", "roughness": "clamp(0.05 + 0.4 * pnoise(P * 6, 3) * cellnoise(P.x * 4) + 0.02 * gabor(uv * 2), 0.02, 0.6)"},  # (the 3D and 1D forms; gabor)
                    {"type": "diffuse", "name": "veined", "reflectance": "marble"},
-                   {"type": "plastic", "name": "cracked", "diffuse_reflectance": "cracks", "roughness": "0.1 + 0.3 * voronoi(P * 3) * fbm(P.y * 2)"}]  # (over three coordinates and one)
+                   {"type": "plastic", "name": "cracked", "diffuse_reflectance": "cracks", "roughness": "0.1 + 0.3 * voronoi(P * 3) * fbm(P.xz * 2) * (0.5 + voronoi(P.y * 2))"}]  # (voronoi over three coordinates and one; fbm over two: the reference has no fbm over one)
     for e in s["entities"]:
         if e["bsdf"] == "mat-Diamond":
             e["bsdf"] = "grainy" if e["name"].endswith("1") else ("brushed" if e["name"].endswith("2") else "veined")

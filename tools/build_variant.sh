@@ -11,7 +11,7 @@ OUT=$LIB/var/$NAME
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-parameter -I$ROOT/include"
 sched() { case $1 in traverse) echo "-mllvm -amdgpu-sched-strategy=max-memory-clause";; shade|photon|tail) echo "-mllvm -amdgpu-sched-strategy=max-ilp";; esac; }
-ALL="traverse shade photon tail comm device"
+ALL="traverse raysort shade photon tail comm device"
 for f in $ALL; do
   S=$(sched $f); [ -n "${NO_SCHED:-}" ] && S=""
   if [ -z "${ONLY:-}" ] || [[ " $ONLY " == *" $f "* ]]; then

@@ -9,6 +9,8 @@ TAG=${1:-r03}
 SUF=${2:-}
 shift; shift
 ARGS="$*"
+# the committed counter summary bench.py falls back to is named by the caller (two stand-ins are both standin.json)
+[ -n "$SUF" ] && ARGS="$ARGS --profile-key ${SUF#_}"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

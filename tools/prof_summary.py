@@ -79,9 +79,11 @@ def traffic(fetch_db, write_db, sq_db=None, steps=None, bench_json=None):
                 lanes = q["SQ_INSTS_VALU"]["mean"] * 64.0
                 cycles_per_inst = 2.0
                 if bench_json:
-                    acc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.path.basename(bench_json).split("_")[0] + "_issue_accounting.json")
-                    if os.path.exists(acc):
-                        cycles_per_inst = json.load(open(acc))["valu_cycles_per_inst"]
+                    for tag in (os.path.basename(bench_json).split("_")[0], "r05"):  # (this round's accounting, else the last one collected)
+                        acc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", tag + "_issue_accounting.json")
+                        if os.path.exists(acc):
+                            cycles_per_inst = json.load(open(acc))["valu_cycles_per_inst"]
+                            break
                 util = res["kernels"][short(k)]["valu_lane_utilisation"]
                 secs = q["SQ_INSTS_VALU"]["avg_ns"] * 1e-9
                 peak = 256 * 4 * 32 * 2.4e9
