@@ -260,6 +260,7 @@ struct igd_device {
     bool q8_nodes        = false; // this scene's kernels are the _q8 instantiations (traverse.hip, tail.hip with -DIG_QNODE=1)
     int tail_split = 6;
     int tail_wide  = 4; // IGD_TAIL_WIDE: TailArgs::wide_lanes
+    int tail_wide8 = 8; // IGD_TAIL_WIDE8: TailArgs::wide8_lanes (one batch of eight rays: + 0.3 - 1 %; two batches and more lose, profiles/r06_experiment_ab.txt section 4)
     // A wave of the tail kernel costs 62 ns whatever it finds to do (3 072 of them: 0.19 ms per pass, measured on empty passes
     // with 256 / 1 024 / 3 072 waves, workgroups of one or four waves alike; a bare launch of that shape costs 1 ns per wave,
     // tools/launch_cost.hip, so the kernel spends it -- where is open). Pass j of a chunk gets as many waves as twice the
@@ -1896,6 +1897,7 @@ void render(igd_device* d, const igd_render_settings* rs)
             tl.inv_spi      = inv;
             tl.count_paths  = 1;
             tl.wide_lanes   = (uint32_t)d->tail_wide;
+            tl.wide8_lanes  = (uint32_t)d->tail_wide8;
             tl.in_kind      = tail_from_round > 0 ? kStreamShaded : kStreamCamera; // (the light tracer never runs the tail)
             tl.deep_lane_base = d->dscene.deep_tail_base + (uint32_t)slot * d->tail_lanes; // concurrent tails: own columns
             fl.tail_ctr.alloc(2 * kMaxTailPasses);
@@ -2308,6 +2310,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->shade_by_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_WIDE"))
             d->tail_wide = std::min(64, std::max(0, std::atoi(e)));
+        if (const char* e = std::getenv("IGD_TAIL_WIDE8"))
+            d->tail_wide8 = std::max(0, std::min(64, std::atoi(e)));
         if (const char* e = std::getenv("IGD_TAIL_ADAPT"))
             d->tail_adapt = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_DENSITY"))

@@ -394,6 +394,9 @@ struct TailArgs {
     // a wave that follows no more than this many paths traverses their closest-hit rays one at a time with all its lanes
     // (wide_core.h); 0: never
     uint32_t wide_lanes;
+    // a wave that follows more than wide_lanes and no more than this many paths traverses their closest-hit rays eight at a time, eight lanes
+    // per ray (group_core.h); 0: never
+    uint32_t wide8_lanes;
     int32_t in_kind; // who wrote `in` (kStreamShaded / kStreamCamera / kStreamLight); `out` is always kStreamShaded
 };
 

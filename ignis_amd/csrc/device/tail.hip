@@ -18,6 +18,7 @@
 #include "shade_core.h"
 #include "traverse_core.h"
 #include "wide_core.h"
+#include "group_core.h"
 
 #ifndef IG_QNODE
 #define IG_QNODE 0
@@ -168,6 +169,48 @@ __global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs
                     region_end();
                     if (wide_any(w.overflow)) // (the traversal's state is wave-uniform) what it counted does not count: the ray starts again below
                         per_lane |= 1ull << l;
+#ifdef IG_TAIL_CLOCKS
+                    tclk[5] += 1;
+#endif
+                }
+                TAIL_MARK(1);
+            } else if (!QNODE && lanes_in(have_m) <= (int)a.wide8_lanes) {
+                // some more paths (group_core.h): eight rays at a time, eight lanes each. Group g of a batch takes the ray of the g-th lane
+                // that still has one; the lanes of the batch read their results back from their groups
+                mask_t todo = have_m;
+                per_lane    = 0;
+                while (todo) {
+                    int src      = -1;
+                    mask_t batch = 0;
+                    for (int k = 0; k < 8 && todo; ++k) {
+                        const int l = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        batch |= 1ull << l;
+                        src = (lane >> 3) == k ? l : src;
+                    }
+                    const int from = src < 0 ? 0 : src;
+                    GroupTraverser<STATS> w;
+                    w.run(sc, s_stack, src >= 0, f3{ __shfl(in.org.x, from), __shfl(in.org.y, from), __shfl(in.org.z, from) },
+                          f3{ __shfl(in.dir.x, from), __shfl(in.dir.y, from), __shfl(in.dir.z, from) }, __shfl(tmin, from), __shfl(tmax, from), (uint32_t)__shfl((int)flags, from));
+                    // the lane of the batch's r-th ray takes what group r found
+                    const int mine   = 8 * __popcll(batch & ((1ull << lane) - 1ull));
+                    const int g_ent  = __shfl(w.hit_ent, mine), g_prim = __shfl(w.hit_prim, mine);
+                    const float g_t = __shfl(w.tmax, mine), g_u = __shfl(w.hit_u, mine), g_v = __shfl(w.hit_v, mine);
+                    const bool g_ovf = __shfl((int)w.overflow, mine) != 0;
+                    const uint32_t g_n = (uint32_t)__shfl((int)w.st_nodes, mine), g_tr = (uint32_t)__shfl((int)w.st_tris, mine), g_l = (uint32_t)__shfl((int)w.st_leaves, mine);
+                    const bool took = igdev::in(batch);
+                    if (took && !g_ovf) {
+                        in.ent  = g_ent;
+                        in.prim = g_prim;
+                        in.t = g_t, in.u = g_u, in.v = g_v;
+                        if (STATS) {
+                            c_nodes[0] += g_n;
+                            c_tris[0] += g_tr;
+                            c_leaves[0] += g_l;
+                        }
+                    }
+                    region_end();
+                    per_lane |= lanes_where(took && g_ovf); // (what such a traversal counted does not count: the ray starts again below)
 #ifdef IG_TAIL_CLOCKS
                     tclk[5] += 1;
 #endif

@@ -32,7 +32,7 @@ def diamond_scene():
     return LoadedScene.from_file(os.path.join(SCENES, "diamond_scene.json"), 128, 128)
 
 
-@pytest.fixture(scope="session", params=["tail", "rounds", "tail-wide", "rounds-sorted"])
+@pytest.fixture(scope="session", params=["tail", "rounds", "tail-wide", "rounds-sorted", "tail-wide8"])
 def gpu_device(request):
     """The device every feature-parity test renders on, in three schedules. "tail": the product's default — a
     stream of <= 1 Mi paths is handed to k_tail before round 0, which is where every small-film test ends up. "rounds":
@@ -40,10 +40,12 @@ def gpu_device(request):
     last path). "tail-wide": IGD_TAIL_WIDE=64, k_tail with every closest-hit ray traversed by a whole wave (wide_core.h, what
     the product does for waves that follow <= 4 paths). "rounds-sorted": the rounds with every bounce and shadow stream traversed in
     (direction octant, origin cell) order (raysort.hip; IGD_RAY_SORT=1, what igd_assign_scene switches on for BVHs beyond 64 MB).
-    The schedule is read when the device is created."""
+    "tail-wide8": IGD_TAIL_WIDE=0 IGD_TAIL_WIDE8=64, k_tail with every closest-hit ray traversed by a group of eight lanes, eight rays of a
+    wave at a time (group_core.h, what waves that follow 5 - IGD_TAIL_WIDE8 paths do). The schedule is read when the device is created."""
     from ignis_amd import Device
     env = {"rounds": {"IGD_TAIL_THRESHOLD": "0"}, "tail-wide": {"IGD_TAIL_WIDE": "64"},
-           "rounds-sorted": {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"}}.get(request.param, {})
+           "rounds-sorted": {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"},
+           "tail-wide8": {"IGD_TAIL_WIDE": "0", "IGD_TAIL_WIDE8": "64"}}.get(request.param, {})
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

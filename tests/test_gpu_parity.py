@@ -161,6 +161,8 @@ def test_small_stream_capacity_chunks_match(diamond_scene):
     {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_TAIL_WIDE": "0"},       # none
     {"IGD_TAIL_THRESHOLD": "0", "IGD_WORK_SHARDS": "1"},                             # a traversal launch's rays from one counter instead of 8 shares
     {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_WORK_SHARDS": "1"},
+    {"IGD_TAIL_THRESHOLD": "100000000", "IGD_TAIL_SPLIT": "5", "IGD_TAIL_WIDE": "0", "IGD_TAIL_WIDE8": "64"},  # every closest-hit ray of the tail by a group of eight lanes (group_core.h)
+    {"IGD_TAIL_THRESHOLD": "3000", "IGD_TAIL_SPLIT": "2", "IGD_TAIL_WIDE": "4", "IGD_TAIL_WIDE8": "16"},       # the three machines by the number of paths a wave follows
     {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0"},        # bounce and shadow rays traversed in key order (raysort.hip)
     {"IGD_TAIL_THRESHOLD": "3000", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0", "IGD_RAY_SORT_ORDER": "cell", "IGD_RAY_SORT_BITS": "9"},
     {"IGD_TAIL_THRESHOLD": "0", "IGD_RAY_SORT": "1", "IGD_RAY_SORT_MIN": "0", "IGD_RAY_SORT_BITS": "2", "IGD_WORK_SHARDS": "1"},  # a one-pass sort
