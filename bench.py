@@ -161,7 +161,7 @@ def pmc_passes(scene, W, H, spi, steps, groups):
             out = os.path.join(tmp, f"g{gi}")
             cmd = [exe, "--pmc"] + list(group) + ["--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(steps), "--warmup", str(steps), "--width", str(W), "--height", str(H), "--spi", str(spi),
-                   "--scene", scene, "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
+                   "--scene", os.path.abspath(scene), "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
@@ -187,17 +187,19 @@ def stage_evidence(ctr, child_line, stage, ms_launch, rays_scale=1.0):
     The class the data put the stage in — `limiter_class`: "hbm" when the measured traffic is at least half of the 8 TB/s peak in the
     launch's time, else "valu" when the VALU instructions fill at least 0.6 of the issue cycles, else "latency" (neither the memory
     system nor the issue slots are at their limit: the waves wait)."""
-    # per round: every kernel of the stage runs once per round, so a round's figure is the sum of the kernels' per-launch means (the child's
-    # warm-up, timed steps and counter replay are the same iterations: the mean over all of a kernel's launches is the timed launches' mean);
-    # `tot` (sums) serves the ratios
-    tot, per_round = {}, {}
+    # per round = the stage's sums / the rounds the child ran (its warm-up, timed steps and counter replay are the same iterations, so the
+    # mean over all rounds is the timed rounds' mean). A traversal stage launches ONE of its kernels per round (the plain instantiation, or
+    # the SORTED one from round 1 on under IGD_RAY_SORT): rounds = the launches of all of them; the shading stage launches each of its
+    # kernels once per round: rounds = the launches of the most launched one. `tot` (sums) serves the ratios.
+    tot, launches = {}, {}
     for k, cs in ctr.items():
         if any(k.startswith(p) for p in STAGE_KERNELS[stage]):
             for c, v in cs.items():
                 tot[c] = tot.get(c, 0.0) + v["sum"]
-                per_round[c] = per_round.get(c, 0.0) + v["sum"] / max(1, v["launches"])
+                launches.setdefault(c, []).append(v["launches"])
     if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
         return None
+    per_round = {c: tot[c] / max(1, sum(n) if stage.startswith("k_traverse") else max(n)) for c, n in launches.items()}
     traffic = (2.0 * per_round["FETCH_SIZE"] + per_round["WRITE_SIZE"]) * 1024.0 * rays_scale
     secs = ms_launch * 1e-3
     ev = {"traffic": int(traffic), "measured_frac": round(traffic / secs / 1e9 / HBM_PEAK_GBS, 5) if secs > 0 else None}

@@ -80,6 +80,27 @@ IG_DEV m33 orthonormal_basis(f3 n)
     return m;
 }
 
+// 1 / x where the sources write a reciprocal (shade_core.h). IG_FAST_RCP: v_rcp_f32 + one Newton step, which IS the correctly rounded
+// quotient for 2^-100 <= |x| <= 2^100 (every bit pattern compared, tools/rcp_exhaustive.hip, profiles/r03_rcp_exhaustive.txt), with the
+// compiler's division behind a branch for the rest: 3 + 4 instructions instead of 11. Measured in round 6 (profiles/r06_experiment_ab.txt
+// section 6); the default build divides.
+#ifndef IG_FAST_RCP
+#define IG_FAST_RCP 0
+#endif
+IG_DEV float igm_rcp(float x)
+{
+#if IG_FAST_RCP
+    const float r  = __builtin_amdgcn_rcpf(x);
+    float q        = igm_fma(r, igm_fma(-x, r, 1.0f), r);
+    const float ax = igm_abs(x);
+    if (__builtin_expect(!(ax >= 0x1p-100f && ax <= 0x1p100f), 0))
+        q = 1 / x;
+    return q;
+#else
+    return 1 / x;
+#endif
+}
+
 // core/common.art:210-215
 IG_DEV float safe_rcp(float x)
 {

@@ -120,7 +120,7 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
             s.point         = org + dir * t;
             const f3 d      = s.point - xform_point(global, f3{ sp.x, sp.y, sp.z });
             const float len = len3(d);
-            const f3 n      = d * (1 / len);
+            const f3 n      = d * (igm_rcp(len));
             s.tex           = f2{ u, v };
             s.entering      = true;
             s.face_normal   = n;
@@ -139,7 +139,7 @@ IG_DEV Surf surface_element(const DevScene& sc, int ent_id, int prim_id, f3 org,
     const f3 e1 = v2 - v0, e2 = v0 - v1, e3 = v1 - v2;
     const f3 n  = stable_normal(e1, e2, e3); // make_triangle, core/triangle.art:12-29
     const float nn = len3(n);
-    const f3 fn    = n * (1 / nn);
+    const f3 fn    = n * (igm_rcp(nn));
 
     const f3 n0 = f3{ a3.x, a3.y, a3.z }, n1 = f3{ a4.x, a4.y, a4.z }, n2 = f3{ a5.x, a5.y, a5.z };
     const f3 ln = f3{ lerp2(n0.x, n1.x, n2.x, u, v), lerp2(n0.y, n1.y, n2.y, u, v), lerp2(n0.z, n1.z, n2.z, u, v) };
@@ -204,8 +204,8 @@ struct PlaneLight {
         radiance       = Col{ d[20], d[21], d[22] };
         width          = len3(xa);
         height         = len3(ya);
-        ex             = xa * (1 / width);
-        ey             = ya * (1 / height);
+        ex             = xa * (igm_rcp(width));
+        ey             = ya * (igm_rcp(height));
     }
 
     struct SQ {
@@ -280,7 +280,7 @@ IG_DEV float fresnel_factor(float eta, float cos_i, float cos_t)
 
 IG_DEV bool fresnel(float eta, float cos_i, float& cos_t, float& factor)
 {
-    const float eta2   = cos_i < 0 ? 1 / eta : eta;
+    const float eta2   = cos_i < 0 ? igm_rcp(eta) : eta;
     const float cos2_t = 1 - (1 - cos_i * cos_i) * eta2 * eta2; // snell
     if (cos2_t <= 0.0f)
         return false;
@@ -474,7 +474,7 @@ IG_DEV m33 align_vectors(f3 a, f3 b) // core/matrix.art:261-284
         m.c0 = f3{ -1, 0, 0 }, m.c1 = f3{ 0, -1, 0 }, m.c2 = f3{ 0, 0, -1 };
         return m;
     }
-    const float k = 1 / (1 + cosA);
+    const float k = igm_rcp(1 + cosA);
     m.c0 = f3{ (axis.x * axis.x * k) + cosA, (axis.y * axis.x * k) - axis.z, (axis.z * axis.x * k) + axis.y };
     m.c1 = f3{ (axis.x * axis.y * k) + axis.z, (axis.y * axis.y * k) + cosA, (axis.z * axis.y * k) - axis.x };
     m.c2 = f3{ (axis.x * axis.z * k) - axis.y, (axis.y * axis.z * k) + axis.x, (axis.z * axis.z * k) + cosA };
@@ -592,8 +592,8 @@ IG_DEV m33 bumped_frame(const DevScene& sc, const ig_material& mat, const Surf& 
         const Col c0      = image_lookup(sc, t, s.tex);
         const Col cx      = image_lookup(sc, t, f2{ s.tex.x + delta, s.tex.y });
         const Col cy      = image_lookup(sc, t, f2{ s.tex.x, s.tex.y + delta });
-        const float dx    = (cx.r - c0.r) * (1 / delta);
-        const float dy    = (cy.r - c0.r) * (1 / delta);
+        const float dx    = (cx.r - c0.r) * (igm_rcp(delta));
+        const float dy    = (cy.r - c0.r) * (igm_rcp(delta));
         N = normalize3(s.local.c2 - (s.local.c0 * dx + s.local.c1 * dy) * mat.p[11]);
     }
     const f3 n          = ensure_valid_reflection(s.face_normal, -ray_dir, normalize3(N));
@@ -670,8 +670,8 @@ struct Principled {
         cc_rough    = m.r[5];
         thin        = (m.flags & IG_MAT_THIN) != 0;
         cc_top_only = (m.flags & IG_MAT_CLEARCOAT_ALL) == 0;
-        refl_eta    = (entering || thin) ? 1 / refl_ior : refl_ior;
-        refr_eta    = (entering || thin) ? 1 / refr_ior : refr_ior;
+        refl_eta    = (entering || thin) ? igm_rcp(refl_ior) : refl_ior;
+        refr_eta    = (entering || thin) ? igm_rcp(refr_ior) : refr_ior;
     }
 
     IG_DEV static m33 identity()
@@ -726,7 +726,7 @@ struct Principled {
         const float lk    = schlick_approx(aNdL);
         const float vk    = schlick_approx(aNdV);
         const float fss   = (1 - lk + fss90 * lk) * (1 - vk + fss90 * vk);
-        return 1.25f * (fss * (1 / (aNdL + aNdV + 1e-5f) - 0.5f) + 0.5f);
+        return 1.25f * (fss * (igm_rcp(aNdL + aNdV + 1e-5f) - 0.5f) + 0.5f);
     }
     // evalSheenTerm (principled.art:110-113)
     IG_DEV Col sheen_term(f3 wi) const
@@ -987,7 +987,7 @@ struct Principled {
         in_dir  = to_world(dir);
         pdf_out = spdf;
         // light paths carry 1 / eta^2 across a refraction (principled.art:471)
-        const float spread = (adjoint && !thin && !same_hemi(wo, dir)) ? 1 / (refr_eta * refr_eta) : 1.0f;
+        const float spread = (adjoint && !thin && !same_hemi(wo, dir)) ? igm_rcp(refr_eta * refr_eta) : 1.0f;
         color   = eval(in_dir, out_dir) * (spread / spdf);
         return true;
     }
@@ -1080,7 +1080,7 @@ struct RoughDielectric {
         }
         const float cos_i = dot3(N, in_dir);
         pdf_out           = mpdf * sel_pdf;
-        color             = eval(in_dir, out_dir) * safe_div((igm_signbit(cos_i * cos_o) && adjoint) ? 1 / (eta * eta) : 1.0f, pdf_out); // dielectric.art:181-185
+        color             = eval(in_dir, out_dir) * safe_div((igm_signbit(cos_i * cos_o) && adjoint) ? igm_rcp(eta * eta) : 1.0f, pdf_out); // dielectric.art:181-185
         s_eta             = !igm_signbit(cos_i * cos_o) ? 1.0f : eta;
         return true;
     }
@@ -1091,7 +1091,7 @@ IG_DEV float fresnel_diffuse_factor(float eta)
 {
     if (eta < 1)
         return -1.4399f * (eta * eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
-    const float ieta1 = 1 / eta;
+    const float ieta1 = igm_rcp(eta);
     const float ieta2 = ieta1 * ieta1;
     const float ieta3 = ieta2 * ieta1;
     const float ieta4 = ieta3 * ieta1;
@@ -1188,7 +1188,7 @@ struct Plastic {
         in_dir      = H * (2 * dot3(H, out_dir)) - out_dir;
         if (abs_cos(in_dir, N) <= kFltEps)
             return false;
-        const float jacob = 1 / (4 * abs_cos(out_dir, H));
+        const float jacob = igm_rcp(4 * abs_cos(out_dir, H));
         pdf               = mpdf * jacob;
         color             = lobe_eval(1, in_dir, out_dir) * safe_div(1, pdf);
         return true;
@@ -1493,7 +1493,7 @@ struct BsdfCtx {
         const f3 refl   = N * (2 * dot3(N, out_dir)) - out_dir;
         const float u   = rnd.f32();
         const float v   = rnd.f32();
-        const float c   = igm_min(fastpow(v, 1 / (ns + 1)), 1.0f); // sample_cosine_power_hemisphere (core/sampling.art:84-96)
+        const float c   = igm_min(fastpow(v, igm_rcp(ns + 1)), 1.0f); // sample_cosine_power_hemisphere (core/sampling.art:84-96)
         const float sn  = igm_sqrt(1 - c * c);
         const float phi = 2 * kPi * u;
         pdf_out         = (c != 0 ? v / c : 0.0f) * (ns + 1) * (1 / (2 * kPi));
@@ -1705,7 +1705,7 @@ struct BsdfCtx {
             pdf_out         = c / kPi;
             color           = kd;
             if (FULL && mat->p[3] > kFltEps)
-                color = orennayar_eval(in_dir, out_dir) * (1 / pdf_out); // bsdf/diffuse.art:46
+                color = orennayar_eval(in_dir, out_dir) * (igm_rcp(pdf_out)); // bsdf/diffuse.art:46
             s_eta           = 1;
             sdelta          = false;
             return true;
@@ -1738,7 +1738,7 @@ struct BsdfCtx {
             if (abs_cos(in_dir, N) <= kFltEps)
                 return false;
             const float cho = abs_cos(out_dir, H);
-            pdf_out         = mpdf * (1 / (4 * cho));
+            pdf_out         = mpdf * (igm_rcp(4 * cho));
             color           = eval(in_dir, out_dir) * safe_div(1, pdf_out);
             s_eta           = 1;
             sdelta          = false;
@@ -1955,7 +1955,7 @@ struct MeshEmitter {
         const f3 v2    = xform_point(global, ld3v(verts + tri.z * 4));
         const f3 n     = stable_normal(v2 - v0, v0 - v1, v1 - v2);
         const float nn = len3(n);
-        face_normal    = n * (1 / nn);
+        face_normal    = n * (igm_rcp(nn));
         area           = nn / 2;
         point          = f3{ lerp2(v0.x, v1.x, v2.x, u, v), lerp2(v0.y, v1.y, v2.y, u, v), lerp2(v0.z, v1.z, v2.z, u, v) };
     }
@@ -2019,7 +2019,7 @@ struct SphereEmitter {
             const f3 np   = point + (glb_org - point) * 2;
             const f3 norm = normalize3(np - glb_org);
             const f3 diag = f3{ nmat.c0.x, nmat.c1.y, nmat.c2.z };
-            const f3 ln   = f3{ dot3(nmat.c0, norm), dot3(nmat.c1, norm), dot3(nmat.c2, norm) } * (1 / dot3(diag, diag));
+            const f3 ln   = f3{ dot3(nmat.c0, norm), dot3(nmat.c1, norm), dot3(nmat.c2, norm) } * (igm_rcp(dot3(diag, diag)));
             surface(ln, point, face_normal);
         }
     }
@@ -2057,7 +2057,7 @@ struct CieSky {
         const float x4 = x2 * x2;
         const float a  = (x4 * x4) * x2;
         const float f1 = a * a / (a * a + 1);
-        const float f2 = 1 / (a * a + 1);
+        const float f2 = igm_rcp(a * a + 1);
         return c1 * f1 + c2 * f2;
     }
     IG_DEV Col radiance(f3 dir) const
@@ -2171,7 +2171,7 @@ IG_DEV float hier_cost(const HierEntry& e, f3 pos)
     const float cos_d = e.has_dir ? igm_abs(dot3(e.dir, normalize3(cdir))) : 1.0f;
     return safe_div(e.flux * cos_d, dist2);
 }
-IG_DEV float hier_left_prop(const HierEntry& l, const HierEntry& r, f3 pos) { return 1 / (1 + hier_cost(r, pos) / hier_cost(l, pos)); }
+IG_DEV float hier_left_prop(const HierEntry& l, const HierEntry& r, f3 pos) { return igm_rcp(1 + hier_cost(r, pos) / hier_cost(l, pos)); }
 IG_DEV int hier_sample(const DevScene& sc, Tea& rnd, f3 pos, float& pdf)
 {
     pdf           = 1;
@@ -2215,7 +2215,7 @@ IG_DEV int select_light_cdf(const DevScene& sc, Tea& rnd, float& pdf)
     const float q = rnd.f32();
     if (q < 0.5f) {
         const int id = pick_light_id(rnd, n_inf);
-        pdf          = (1 / (float)n_inf) * 0.5f;
+        pdf          = (igm_rcp((float)n_inf)) * 0.5f;
         return id;
     }
     float p;
@@ -2230,7 +2230,7 @@ IG_DEV float select_pdf_cdf(const DevScene& sc, int li)
     const Cdf1D cdf{ sc.light_cdf, n_fin };
     if (n_inf == 0)
         return cdf.pdf_discrete(li);
-    return li < n_inf ? (1 / (float)n_inf) * 0.5f : cdf.pdf_discrete(li - n_inf) * (1 - 0.5f);
+    return li < n_inf ? (igm_rcp((float)n_inf)) * 0.5f : cdf.pdf_discrete(li - n_inf) * (1 - 0.5f);
 }
 
 template <bool FULL>
@@ -2241,7 +2241,7 @@ IG_DEV int select_light(const DevScene& sc, Tea& rnd, f3 from_pos, float& pdf)
         return select_light_cdf<FULL>(sc, rnd, pdf);
     if (!sc.use_hierarchy) {
         const int num = (int)sc.light_count;
-        pdf           = num == 0 ? 1.0f : 1 / (float)num;
+        pdf           = num == 0 ? 1.0f : igm_rcp((float)num);
         return pick_light_id(rnd, num);
     }
     if (n_inf == 0) {
@@ -2251,7 +2251,7 @@ IG_DEV int select_light(const DevScene& sc, Tea& rnd, f3 from_pos, float& pdf)
         }
         return hier_sample(sc, rnd, from_pos, pdf);
     }
-    const float pdf_inf = 1 / (float)n_inf;
+    const float pdf_inf = igm_rcp((float)n_inf);
     const float q       = rnd.f32();
     if (q < 0.5f) {
         const int id = pick_light_id(rnd, n_inf);
@@ -2273,11 +2273,11 @@ IG_DEV float select_pdf(const DevScene& sc, int li, f3 from_pos)
     if (FULL && sc.light_cdf)
         return select_pdf_cdf<FULL>(sc, li);
     if (!sc.use_hierarchy)
-        return sc.light_count == 0 ? 1.0f : 1 / (float)sc.light_count;
+        return sc.light_count == 0 ? 1.0f : igm_rcp((float)sc.light_count);
     if (n_inf == 0)
         return n_fin == 1 ? 1.0f : hier_pdf(sc, li, from_pos);
     if (li < n_inf)
-        return (1 / (float)n_inf) * 0.5f;
+        return (igm_rcp((float)n_inf)) * 0.5f;
     return (n_fin == 1 ? 1.0f : hier_pdf(sc, li - n_inf, from_pos)) * (1 - 0.5f);
 }
 
@@ -2436,7 +2436,7 @@ IG_DEV Col debug_color(const DevScene& sc, int mode, const PathVertexIn& in, con
         const float4 r6 = e[6], r7 = e[7], r8 = e[8];
         const f3 c0{ r6.x, r6.y, r6.z }, c1{ r6.w, r7.x, r7.y }, c2{ r7.z, r7.w, r8.x };
         const f3 d{ c0.x, c1.y, c2.z };
-        return normalize3(f3{ dot3(c0, n), dot3(c1, n), dot3(c2, n) } * (1 / dot3(d, d)));
+        return normalize3(f3{ dot3(c0, n), dot3(c1, n), dot3(c2, n) } * (igm_rcp(dot3(d, d))));
     };
     auto local_p = [&](f3 p) { // to_local_point: entity.local_mat
         const float4 r0 = e[0], r1 = e[1], r2 = e[2];
@@ -2608,7 +2608,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             } else {
                 continue; // delta lights
             }
-            const float mis   = nee ? 1 / (1 + mis_inv_pdf * select_pdf<FULL>(sc, (int)li, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? igm_rcp(1 + mis_inv_pdf * select_pdf<FULL>(sc, (int)li, in.org) * pdf_s) : 1.0f;
             if (volumetric)
                 emit = emit * Medium(sc, medium_id).eval_inf(); // volpathtracer.art:135
             const Col c       = clamp_color(tech, (in.contrib * emit) * mis);
@@ -2707,7 +2707,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 emit  = pl.radiance;
                 pdf_s = pl.pdf(in.org);
             }
-            const float mis   = nee ? 1 / (1 + mis_inv_pdf * select_pdf<FULL>(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
+            const float mis   = nee ? igm_rcp(1 + mis_inv_pdf * select_pdf<FULL>(sc, mat.light_id, in.org) * pdf_s) : 1.0f;
             if (volumetric)
                 emit = emit * Medium(sc, medium_id).eval(in.org, surf.point); // volpathtracer.art:104-105
             out.has_radiance  = true;
@@ -2785,7 +2785,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             const TexturedEnv env(sc, L);
             Col intensity;
             env.sample_dir(rnd, ldir, intensity, pdf_value);
-            lint     = intensity * (1 / pdf_value);
+            lint     = intensity * (igm_rcp(pdf_value));
             lpos     = surf.point + ldir * sc.scene_radius;
             lcos     = 1.0f;
             ldist    = sc.scene_radius;
@@ -2832,12 +2832,12 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 const float phi = 2 * kPi * ux;
                 const f3 dir    = switch_env_up(f3{ sn * igm_cos(phi), sn * igm_sin(phi), c });
                 pdf_value       = c / kPi;
-                lint            = sky.radiance(dir) * (1 / pdf_value);
+                lint            = sky.radiance(dir) * (igm_rcp(pdf_value));
                 ldir            = f3{ dot3(sky.transform.c0, dir), dot3(sky.transform.c1, dir), dot3(sky.transform.c2, dir) };
             } else {
                 ldir      = square_to_sphere(ux, uy);
                 pdf_value = 1 / (4 * kPi);
-                lint      = sky.radiance(mul33(sky.transform, ldir)) * (1 / pdf_value);
+                lint      = sky.radiance(mul33(sky.transform, ldir)) * (igm_rcp(pdf_value));
             }
             lpos     = surf.point + ldir * sc.scene_radius;
             lcos     = 1.0f;
@@ -2865,7 +2865,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 // make_perez_light_raw.sample_direct (light/perez.art:304-308): plus the sky seen in the sampled direction
                 const CieSky sky(L);
                 const f3 d = f3{ dot3(sky.transform.c0, ldir), dot3(sky.transform.c1, ldir), dot3(sky.transform.c2, ldir) };
-                lint       = lint + sky.radiance(d) * (1 / pdf_value);
+                lint       = lint + sky.radiance(d) * (igm_rcp(pdf_value));
             }
             lcos                = z;
             ldist               = __builtin_inff();
@@ -2876,7 +2876,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
             const float uy = rnd.f32();
             ldir           = square_to_sphere(ux, uy);
             pdf_value      = 1 / (4 * kPi);
-            lint           = Col{ L.d[0], L.d[1], L.d[2] } * (1 / pdf_value);
+            lint           = Col{ L.d[0], L.d[1], L.d[2] } * (igm_rcp(pdf_value));
             lpos           = surf.point + ldir * sc.scene_radius;
             lcos           = 1.0f;
             ldist          = sc.scene_radius;
@@ -2887,7 +2887,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
         if (pdf_l_s > kFltEps && lcos > kFltEps) {
             float mis = 1;
             if (!delta && !(volumetric && igm_signbit(in.inv_pdf))) // was_medium_interaction (volpathtracer.art:39,53)
-                mis = 1 / (1 + bsdf.pdf(ldir, out_dir) / pdf_l_s);
+                mis = igm_rcp(1 + bsdf.pdf(ldir, out_dir) / pdf_l_s);
             const float factor = pdf_value / pdf_l_s;
             const Col c        = clamp_color(tech, (lint * (in.contrib * bsdf.eval(ldir, out_dir))) * (mis * factor));
             if ((c.r + c.g + c.b) / 3 > kFltEps) {
@@ -2927,7 +2927,7 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                     out.b_tmin    = 0;
                     out.b_rnd     = rnd.counter;
                     out.b_inv_pdf = -1; // "the last interaction was a medium"
-                    out.b_contrib = nc * (1 / rr_prob);
+                    out.b_contrib = nc * (igm_rcp(rr_prob));
                     out.b_depth   = (depth + 1) | ((medium_id + 1) << 16);
                     out.b_eta     = in.eta;
                 }
@@ -2948,8 +2948,8 @@ IG_DEV void shade_vertex(const DevScene& sc, const ShadeFrame& fr, const PathVer
                 out.b_org     = surf.point;
                 out.b_dir     = in_dir;
                 out.b_rnd     = rnd.counter;
-                out.b_inv_pdf = sdelta ? 0 : 1 / pdf;
-                out.b_contrib = nc * (1 / rr_prob);
+                out.b_inv_pdf = sdelta ? 0 : igm_rcp(pdf);
+                out.b_contrib = nc * (igm_rcp(rr_prob));
                 out.b_depth   = depth + 1;
                 out.b_eta     = in.eta * s_eta;
                 if (volumetric) {

@@ -29,7 +29,10 @@ constexpr int kMaxSortBins  = 254; // material_count + 2 bins must fit one entry
 #define IG_SHADE_OCC_LEAN 4
 #endif
 #ifndef IG_SHADE_OCC_BASIC
-#define IG_SHADE_OCC_BASIC IG_SHADE_OCC_FULL // the by-class kernel of the basic models + misses (memory-bound: see profiles/r05_traffic_principled.json)
+// the by-class kernel of the basic models + misses waits for memory (light-hierarchy descents, environment lookups: waves waiting 64 % of their
+// cycles on many_point_lights, profiles/r06_traffic_many_point_lights.json): four waves per SIMD at 128 VGPRs. many_point_lights + 2.5 %, the
+// principled scene + 1.1 %, the divergent stand-in + 0 (profiles/r06_experiment_ab.txt section 7; round 5 had measured + 1 % / - 0.5 % and kept 3)
+#define IG_SHADE_OCC_BASIC 4
 #endif
 constexpr int kBounceBins = 16; // the bounce rays of a window leave grouped by (specular bounce, octant of the direction)
 

@@ -26,7 +26,7 @@ with tempfile.TemporaryDirectory() as tmp:
     subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-DIG_ISA_MARKS", *extra, "-mllvm",
                     "-amdgpu-sched-strategy=max-memory-clause", os.path.join(ROOT, "ignis_amd", "csrc", "device", "traverse.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
     text = open(out).read()
-sym = "_ZN5igdev10k_traverseILb%dELb0ELb0ELb0ELb0EEEvNS_12TraverseArgsE" % (1 if which == "any" else 0)  # <ANY_HIT, no stats, not DEEP, no spheres, Node8 records>
+sym = "_ZN5igdev10k_traverseILb%dELb0ELb0ELb0ELb0ELb0EEEvNS_12TraverseArgsE" % (1 if which == "any" else 0)  # <ANY_HIT, no stats, not DEEP, no spheres, Node8 records, stream order>
 m = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(sym), text, re.S | re.M)
 body = m.group(0)
 cur = "prologue"
