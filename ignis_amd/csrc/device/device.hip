@@ -243,6 +243,7 @@ struct igd_device {
     // LDS that the overlapping traversal launches of the next chunk need. IGD_TAIL_SPLIT overrides (0: one launch).
     uint32_t shade_classes = 1; // material classes of the scene (launch_shade)
     bool shade_by_class    = true; // IGD_SHADE_CLASSES=0: the one full instantiation for every material
+    bool sort_single_class = true; // IGD_SORT_SINGLE_CLASS=0: a scene whose materials are all of the basic class skips the sort by material
     // > 0: the closest-hit launches of a render round write their hits as one packed 16-byte row with that many prim bits (kernels.h
     // pack_hit; igd_assign_scene: the entity count and the largest mesh fit 32 bits together, no analytic spheres). IGD_HIT_PACK=0: never
     uint32_t hit_pack_bits = 0;
@@ -1782,7 +1783,10 @@ void render(igd_device* d, const igd_render_settings* rs)
                 if (ppm)
                     launch_shade_ppm(sa, shade_grid, on);
                 else {
-                    if (by_class) {
+                    if (by_class && d->shade_classes == 1u && !d->sort_single_class) {
+                        // every material of the scene is of the basic class: its kernel takes the stream as it lies (sa.sort_idx stays null) —
+                        // no sort, no index indirection
+                    } else if (by_class) {
                         // K3: the round's hits sorted by material, so that each class kernel shades its own dense run
                         BinSortArgs ba{};
                         ba.hit             = in.hit;
@@ -2306,6 +2310,8 @@ igd_device* igd_create(const igd_setup* setup)
             d->hit_pack_allowed = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SKIP_MISSES"))
             d->skip_misses = std::atoi(e) != 0;
+        if (const char* e = std::getenv("IGD_SORT_SINGLE_CLASS"))
+            d->sort_single_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_SHADE_CLASSES"))
             d->shade_by_class = std::atoi(e) != 0;
         if (const char* e = std::getenv("IGD_TAIL_WIDE"))

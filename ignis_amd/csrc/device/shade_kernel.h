@@ -68,8 +68,10 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
     const DevScene& sc = a.scene;
     // BY_CLASS: this launch's rays are a run of the round's hits sorted by material (k_bin_*, shade.hip): entries
     // [cls_range[0], cls_range[0] + cls_range[1]) of sort_idx name them
-    const uint32_t n         = BY_CLASS ? a.cls_range[1] : *a.in_count;
-    const uint32_t cls_first = BY_CLASS ? a.cls_range[0] : 0u;
+    // (BY_CLASS without an index list: a scene whose materials all belong to this class — the launch takes the stream as it lies, no sort)
+    const bool by_index      = BY_CLASS && a.sort_idx != nullptr;
+    const uint32_t n         = by_index ? a.cls_range[1] : *a.in_count;
+    const uint32_t cls_first = by_index ? a.cls_range[0] : 0u;
     const int M              = (int)sc.material_count;
     // The lean variant has three BSDF models and waits for memory, not for issue slots (a TEA with one round instead of four changes its
     // time by 1 %, profiles/r03_experiment_shade.txt): the sort's two dependent loads and five barriers in front of every window cost it
@@ -150,9 +152,9 @@ __global__ void __launch_bounds__(kShadeThreads, FULL ? (EXPR ? 2 : (TYPES == kC
             __syncthreads();
         }
         bool valid = j < n;
-        if (BY_CLASS && valid)
+        if (by_index && valid)
             j = a.sort_idx[cls_first + j];
-        if (!BY_CLASS && !LT && PPM == 0 && !DEBUG_VIEWS && a.skip_misses) {
+        if (!by_index && !LT && PPM == 0 && !DEBUG_VIEWS && a.skip_misses) {
             // a scene without environment lights: a miss adds nothing and ends its path (shade_vertex's on_miss sums over no light), so
             // its columns are not even read — a look at the hit first, a wave whose rays all missed (camera rays past the geometry) goes on
             if (valid) {
