@@ -295,6 +295,23 @@ def test_many_point_lights_radiance_vs_oracle(gpu_device):
         assert st[k] == tot[k], k
 
 
+def test_single_class_scene_without_the_sort_by_material():
+    """IGD_SORT_SINGLE_CLASS=0: a scene whose materials all fall into the basic class (many_point_lights) shaded by the class kernel over the
+    stream as it lies — no k_bin_* sort, no index — must give what the sorted default gives, which the test above holds against the oracle:
+    same image bits, same counters (it is slower: profiles/r06_experiment_ab.txt section 8; the switch stays a switch)."""
+    w, h, spi = 160, 120, 4
+    scene = _many_lights_scene(w, h)
+    out = []
+    for env in ({"IGD_TAIL_THRESHOLD": "0"}, {"IGD_TAIL_THRESHOLD": "0", "IGD_SORT_SINGLE_CLASS": "0"}):
+        dev = _device_with_env(env, acquire_stats=True)
+        out.append(_render_gpu(dev, scene, spi, w, h, iters=2, seed=4))
+        dev.close()
+    np.testing.assert_array_equal(_bits(out[0][0]), _bits(out[1][0]))
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "unoccluded", "nodes", "tris", "leaves"):
+        assert out[0][1][k] == out[1][1][k], k
+    assert out[0][1]["rounds"] > 0 and out[0][1]["tail_rays"] == 0
+
+
 @pytest.mark.parametrize("selector", ["uniform", "hierarchy", "simple"])
 def test_selectors_and_env_vs_oracle(gpu_device, selector):
     import oracle
