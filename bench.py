@@ -425,6 +425,8 @@ def main():
         if fail and fail not in ("raise", "hang", "probe"):
             fail = "raise"
         comm = Comm.agreed(dev, rank, world, deadline=float(os.environ.get("BENCH_COMM_DEADLINE", "60")), fail=fail)
+        if comm is None and Comm.last_fallback_reason.startswith("abort: "):
+            raise SystemExit(f"[bench] rank {rank}: {Comm.last_fallback_reason} — the job is incomplete, no collective can run")
         if comm is None:
             print(f"[bench] rank {rank}: the ranks agreed not to use the native RCCL communicator ({Comm.last_fallback_reason}); re-executing with --dist torch", file=sys.stderr, flush=True)
             argv = [a for i, a in enumerate(sys.argv) if not (a == "--dist" or (i > 0 and sys.argv[i - 1] == "--dist") or a.startswith("--dist="))]

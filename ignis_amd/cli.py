@@ -138,6 +138,9 @@ def main(argv=None, load=loadFromFile, reexec=_reexec):
         t0 = time.perf_counter()
         comm = Comm.agreed(rt.device, rank, world, deadline=float(os.environ.get("IGNIS_COMM_DEADLINE", "60")), fail=fail)
         t_comm = time.perf_counter() - t0
+        if comm is None and Comm.last_fallback_reason.startswith("abort: "):
+            print(f"rank {rank}: {Comm.last_fallback_reason} — the job is incomplete, giving up", file=sys.stderr, flush=True)
+            return 3
         if comm is None:
             fallback = os.environ.get("IGNIS_CLI_FALLBACK_BACKEND", "nccl")
             print(f"rank {rank}: the ranks agreed not to use the native RCCL communicator ({Comm.last_fallback_reason}); starting over with --backend {fallback}", file=sys.stderr, flush=True)

@@ -38,7 +38,8 @@ _MAGIC = b"IGD-RCCL-ID\x02"
 _PORT_SPAN = 8  # rank 0 listens on the first free port of MASTER_PORT + 1 .. + 8; the others try them in turn
 _TOKEN_BYTES = 16
 _HELLO = struct.Struct("<ii16sB")  # rank, world, job token, "I can take part"
-_ACK, _GO, _FALLBACK, _NATIVE = b"A", b"G", b"F", b"N"
+_ACK, _GO, _FALLBACK, _NATIVE, _ABORT = b"A", b"G", b"F", b"N", b"X"
+ABORT = "abort: "  # prefix of a reason that no fallback can cure (ranks of the job are missing): callers give up instead of starting over
 
 
 def job_token(world, addr=None, port=None):
@@ -146,10 +147,14 @@ def _within(fn, t_end):
     return True, box.get("value")
 
 
-def agree(rank, world, make_id, bring_up, probe=None, addr=None, port=None, deadline=60.0):
+def agree(rank, world, make_id, bring_up, probe=None, addr=None, port=None, deadline=60.0, arrive=None):
     """The two-phase bring-up vote (module docstring). make_id() -> the id bytes (rank 0 only); probe() raises if this rank cannot
     take part (ranks > 0); bring_up(id) creates the communicator and proves that it talks (may block: run under the deadline).
-    Returns (True, "") on every rank or (False, reason) on every rank — never a mixture — within about two deadlines."""
+    Returns (True, "") on every rank or (False, reason) on every rank — never a mixture — within about two deadlines. A reason that starts
+    with ABORT means that ranks of the job never showed up: no fallback collective can work either, callers exit instead of starting over."""
+    # `deadline` bounds the bring-up (phase 2); the ranks get `arrive` seconds (default five deadlines) to show up at all: they reach this point
+    # after loading a scene and allocating their streams, which on a fresh box differs by more than a collective may wait
+    arrive = 5.0 * deadline if arrive is None else float(arrive)
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29511")) + 1)
     token = job_token(world, addr, base - 1)
@@ -165,15 +170,16 @@ def agree(rank, world, make_id, bring_up, probe=None, addr=None, port=None, dead
         srv = _listen(addr, base, world)
         peers = {}
         try:
-            peers = _serve(srv, world, token, time.monotonic() + deadline)
-            if len(peers) < world - 1:
-                vote, why = False, why or f"only {len(peers) + 1} of {world} ranks arrived within {deadline:.0f} s"
+            peers = _serve(srv, world, token, time.monotonic() + arrive)
+            missing = len(peers) < world - 1
+            if missing:
+                vote, why = False, f"{ABORT}only {len(peers) + 1} of {world} ranks arrived within {arrive:.0f} s"
             no = sorted(r for r, (_, v) in peers.items() if not v)
             if no:
                 vote, why = False, why or f"rank(s) {no} cannot take part"
             for conn, _ in peers.values():
                 try:
-                    conn.sendall((_GO if vote else _FALLBACK) + blob)
+                    conn.sendall((_GO if vote else (_ABORT if missing else _FALLBACK)) + blob)
                 except (OSError, ConnectionError):
                     pass  # (that peer reports nothing in phase 2: the verdict below becomes "fall back")
             if not vote:
@@ -205,17 +211,19 @@ def agree(rank, world, make_id, bring_up, probe=None, addr=None, port=None, dead
         except Exception as e:  # noqa: BLE001
             vote, why = False, f"rank {rank} cannot take part ({type(e).__name__}: {e})"
     try:
-        conn = _join(rank, world, token, vote, addr, base, time.monotonic() + deadline)
+        conn = _join(rank, world, token, vote, addr, base, time.monotonic() + arrive)
     except TimeoutError as e:
-        return False, str(e)
+        return False, ABORT + str(e)
     with conn:
         try:
-            conn.settimeout(deadline + 10.0)  # rank 0 answers when everybody has arrived, or at its deadline
+            conn.settimeout(arrive + 10.0)  # rank 0 answers when everybody has arrived, or at its deadline
             reply = _recv_exact(conn, 1 + ID_BYTES)
         except (OSError, ConnectionError) as e:
             return False, f"rank {rank}: no decision from rank 0 ({type(e).__name__})"
+        if reply[:1] == _ABORT:
+            return False, f"{ABORT}rank 0 said: ranks of this job are missing"
         if reply[:1] != _GO or not vote:
-            return False, why or "rank 0 said: fall back (a rank is missing or cannot take part)"
+            return False, why or "rank 0 said: fall back (a rank cannot take part)"
         t_end = time.monotonic() + deadline
         ok, res = _within(lambda: bring_up(reply[1:]), t_end)
         try:
