@@ -36,10 +36,13 @@ constexpr bool kQNode = IG_QNODE != 0;
 #ifndef IG_TAIL_BLOCK
 #define IG_TAIL_BLOCK 64 // threads per workgroup of k_tail (its waves never meet: no barrier, LDS rows by thread)
 #endif
+#ifndef IG_TAIL_OCC_FULL
+#define IG_TAIL_OCC_FULL IG_TAIL_OCC // ... of the full-BSDF instantiations (they spill ~ 370 VGPRs at 168: A/B r06 section 10)
+#endif
 constexpr int kTailBlock = IG_TAIL_BLOCK;
 
 template <bool STATS, bool FULL, bool QNODE = false>
-__global__ void __launch_bounds__(kTailBlock, IG_TAIL_OCC) k_tail(const TailArgs a)
+__global__ void __launch_bounds__(kTailBlock, FULL ? IG_TAIL_OCC_FULL : IG_TAIL_OCC) k_tail(const TailArgs a)
 {
     __shared__ StackOf<kTailBlock> s_stack;
 
