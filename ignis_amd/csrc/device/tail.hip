@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kTailBlock, FULL ? IG_TAIL_OCC_FULL : IG_TAIL_
                     w.run(sc, s_stack, src >= 0, f3{ __shfl(in.org.x, from), __shfl(in.org.y, from), __shfl(in.org.z, from) },
                           f3{ __shfl(in.dir.x, from), __shfl(in.dir.y, from), __shfl(in.dir.z, from) }, __shfl(tmin, from), __shfl(tmax, from), (uint32_t)__shfl((int)flags, from));
                     // the lane of the batch's r-th ray takes what group r found
-                    const int mine   = 8 * __popcll(batch & ((1ull << lane) - 1ull));
+                    const int mine   = 8 * (__popcll(batch & ((1ull << lane) - 1ull)) & 7); // (a lane above the whole batch counts 8 of them: it takes nothing, any group will do)
                     const int g_ent  = __shfl(w.hit_ent, mine), g_prim = __shfl(w.hit_prim, mine);
                     const float g_t = __shfl(w.tmax, mine), g_u = __shfl(w.hit_u, mine), g_v = __shfl(w.hit_v, mine);
                     const bool g_ovf = __shfl((int)w.overflow, mine) != 0;
