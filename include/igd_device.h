@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define IGD_ABI_VERSION 1u
+/* 2 (round 6): igd_stats grew at its end (ms_ray_sort, stream_bytes) and igd_comm_available was added; a caller built against version 1
+ * would hand igd_get_stats a smaller struct — what the reference's DeviceManager compares before it uses a device (DeviceManager.cpp:180-194). */
+#define IGD_ABI_VERSION 2u
 
 enum igd_status {
     IGD_OK                = 0,
