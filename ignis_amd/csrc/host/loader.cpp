@@ -3137,6 +3137,41 @@ int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinser
     return 0;
 }
 
+int32_t igh_test_mesh_edges(int32_t which, float radius, uint32_t subdivisions, uint64_t out[6])
+{
+    if (!out)
+        return -1;
+    const igh::TriMesh mesh = which == 0 ? igh::TriMesh::MakeIcoSphere(igh::V3(0, 0, 0), radius, subdivisions)
+                                         : igh::TriMesh::MakeTriangle(igh::V3(0, 0, 0), igh::V3(1, 0, 0), igh::V3(0, 1, 0));
+    // the directed edges of the faces in face order: edge 3 f + k runs from corner k to corner k + 1 of face f — the half edges of
+    // TriMesh::computeHalfEdges (TriMesh.cpp:733-768), whose twin is the edge that runs the other way in another face
+    const size_t faces = mesh.faceCount();
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_id;
+    for (size_t f = 0; f < faces; ++f)
+        for (uint32_t k = 0; k < 3; ++k)
+            edge_id[{ mesh.indices[4 * f + k], mesh.indices[4 * f + (k + 1) % 3] }] = (uint32_t)(3 * f + k);
+    auto twin_of = [&](uint32_t id) -> int64_t {
+        const size_t f = id / 3, k = id % 3;
+        const auto it  = edge_id.find({ mesh.indices[4 * f + (k + 1) % 3], mesh.indices[4 * f + k] });
+        return it == edge_id.end() ? -1 : (int64_t)it->second;
+    };
+    uint64_t with_twin = 0, mutual = 0, around_vertex = 0;
+    for (uint32_t id = 0; id < 3 * faces; ++id) {
+        const int64_t t = twin_of(id);
+        if (t < 0)
+            continue;
+        ++with_twin;
+        mutual += twin_of((uint32_t)t) == (int64_t)id ? 1 : 0;
+        // "the twin of the previous half edge has the same vertex": previous = the edge into this edge's start corner
+        const uint32_t prev = (uint32_t)(3 * (id / 3) + (id % 3 + 2) % 3);
+        const int64_t pt    = twin_of(prev);
+        if (pt >= 0)
+            around_vertex += mesh.indices[4 * ((size_t)pt / 3) + (size_t)pt % 3] == mesh.indices[4 * (id / 3) + id % 3] ? 1 : 0;
+    }
+    out[0] = faces, out[1] = 3 * faces, out[2] = edge_id.size(), out[3] = with_twin, out[4] = mutual, out[5] = around_vertex;
+    return 0;
+}
+
 int32_t igh_test_quantise_nodes(float* bounds, const int32_t* child, uint32_t count, int32_t* pad)
 {
     if (!bounds || !child || !pad)

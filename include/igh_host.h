@@ -82,6 +82,12 @@ double igh_eval_sky(int32_t channel, double turbidity, double albedo, double ele
  * area of the wide inner nodes the collapse emits. Returns 0. */
 int32_t igh_test_collapse_plan(const float* boxes, uint32_t count, float reinsert_ratio, int32_t reinsert_iterations, double out[5]);
 
+/* Mesh diagnostics (src/tests/units/trimesh_he.cpp): the directed edges of MakeIcoSphere(0, radius, subdivisions) (which = 0) or of
+ * MakeTriangle(0, X, Y) (which = 1) as the sphere recognition pairs them (csrc/host/mesh.cpp getAsSphere; TriMesh::computeHalfEdges in the
+ * reference). out = {faces, directed edges, distinct directed edges, edges with a twin, twins whose twin is the edge itself, edges whose
+ * previous edge's twin starts at the edge's own start vertex}. Returns 0. */
+int32_t igh_test_mesh_edges(int32_t which, float radius, uint32_t subdivisions, uint64_t out[6]);
+
 /* Builder diagnostics: quantise_node8 (csrc/host/bvh.cpp) on `count` Node8 records given as bounds [count][6][8] (min_x, max_x, min_y, ...
  * per child slot, rewritten in place) and child [count][8] (0 = unused slot); pad [count][4] receives the grid each node got (origin
  * bits, exponents | IG_NODE8_QUANT_MARK) or zeros for a node that was left as it is. Returns 0. */

@@ -869,3 +869,22 @@ def test_meshes_recognised_as_spheres_like_the_reference_unit_test():
                   {"type": "cylinder", "radius": 4, "p0": [0, 0, 0], "p1": [0, 0, 4], "sections": 32, "filled": False}):
         assert light_of(shape)[0] == IG_LIGHT_MESH_AREA, shape
     assert light_of({"type": "triangle", "p0": [0, 0, 0], "p1": [1, 0, 0], "p2": [0, 1, 0]})[0] in (IG_LIGHT_PLANE, IG_LIGHT_MESH_AREA)  # (a plane shape at most: never a sphere)
+
+
+def test_half_edge_structure_like_the_reference_unit_test():
+    """src/tests/units/trimesh_he.cpp: on MakeIcoSphere(0, 4, 4) every half edge has a twin, the twin of the twin is the edge itself, next
+    and previous stay in the face (by construction here: edge 3 f + k), and the twin of the previous half edge starts at the edge's own vertex;
+    a lone triangle has no twins at all. The pairing is what TriMesh::getAsSphere walks (csrc/host/mesh.cpp)."""
+    import ctypes as C
+    from ignis_amd.tables import host_lib
+    l = host_lib()
+    l.igh_test_mesh_edges.restype = C.c_int32
+    l.igh_test_mesh_edges.argtypes = [C.c_int32, C.c_float, C.c_uint32, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 6)()
+    assert l.igh_test_mesh_edges(0, 4.0, 4, out) == 0
+    faces, edges, distinct, with_twin, mutual, around = (int(v) for v in out)
+    assert faces == 20 * 4 ** 4 and edges == 3 * faces and distinct == edges  # a closed, consistently oriented surface: no directed edge twice
+    assert edges < faces * 3 * 2                                              # (the reference's first REQUIRE)
+    assert with_twin == edges and mutual == edges and around == edges
+    assert l.igh_test_mesh_edges(1, 0.0, 0, out) == 0
+    assert [int(v) for v in out] == [1, 3, 3, 0, 0, 0]
