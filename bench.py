@@ -154,6 +154,8 @@ def pmc_passes(scene, W, H, spi, steps, groups):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None, "rocprofv3 not found"
+    if pmc_passes.broken:  # (a profiler that failed or timed out once is not asked again for the next workload: the line must come out in minutes)
+        return None, pmc_passes.broken
     ctr, line = {}, None
     tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     try:
@@ -163,20 +165,25 @@ def pmc_passes(scene, W, H, spi, steps, groups):
                    "--steps", str(steps), "--warmup", str(steps), "--width", str(W), "--height", str(H), "--spi", str(spi),
                    "--scene", os.path.abspath(scene), "--no-cpu-baseline", "--no-literal-config", "--no-extra-configs", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
+                pmc_passes.broken = f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
+                return None, pmc_passes.broken
             cur = sqlite3.connect(dbs[0]).cursor()
             q = "select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection group by kernel_name, counter_name"
             for k, c, n, v, d in cur.execute(q):
                 ctr.setdefault(_short(k), {})[c] = {"sum": float(v), "launches": int(n), "ns": float(d or 0)}
             line = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # (a profiler hiccup must not cost the bench line)
-        return None, f"{type(e).__name__}: {e}"
+        pmc_passes.broken = f"{type(e).__name__}: {e}"
+        return None, pmc_passes.broken
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return ctr, line
+
+
+pmc_passes.broken = None
 
 
 def stage_evidence(ctr, child_line, stage, ms_launch, rays_scale=1.0):
